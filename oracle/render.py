@@ -35,17 +35,21 @@ def rays_from_xy(xy, R, T, focal, principal):
     return p1 - d, d
 
 
-def obj_local(rays_o, rays_d, Ro, To):
-    """convert_obj_to_local, utils/renderer.py:180-188 / 424-432 /
-    utils/renderer_batch.py:176-182: o' = Ro (o - To), d' = Ro d.
-    Works for [B,3] with Ro [3,3] and for [F,P,3] with Ro [F,3,3], To [F,3]."""
+def obj_local(rays_o, rays_d, Ro, To, repeat=False):
+    """convert_obj_to_local: o' = Ro (o - To), d' = Ro d.
+    utils/renderer.py:180-188 (single field: Ro broadcast as [1,3,3]),
+    :424-432 (fitting: Ro repeated to [B,3,3] -> `repeat=True`; torch.matmul
+    picks different kernels for the two forms once Ro requires grad, so the
+    distinction is kept), utils/renderer_batch.py:176-182 ([F,P,3] rays with
+    Ro [F,3,3], To [F,3])."""
     if rays_o.dim() == 3:
         o = rays_o - To[:, None, :]
-        return (torch.matmul(Ro[:, None], o[..., None])[..., 0],
-                torch.matmul(Ro[:, None], rays_d[..., None])[..., 0])
+        return (torch.matmul(Ro[:, None], o[..., None])[..., -1],
+                torch.matmul(Ro[:, None], rays_d[..., None])[..., -1])
+    R = Ro[None].repeat(rays_o.shape[0], 1, 1) if repeat else Ro[None]
     o = rays_o - To[None, :]
-    return (torch.matmul(Ro[None], o[..., None])[..., 0],
-            torch.matmul(Ro[None], rays_d[..., None])[..., 0])
+    return (torch.matmul(R, o[..., None])[..., -1],
+            torch.matmul(R, rays_d[..., None])[..., -1])
 
 
 def coarse_z(near, far, n_samples, t_rand):
@@ -248,7 +252,7 @@ def render_dual(hand, obj, rays_o, rays_d, near, far, t_rand, n_samples, n_impor
     SURVEY B-1 in the batched up-sampling."""
     batched = rays_o.dim() == 3
     o_h, d_h = rays_o, rays_d
-    o_o, d_o = obj_local(rays_o, rays_d, Ro, To)
+    o_o, d_o = obj_local(rays_o, rays_d, Ro, To, repeat=True)
     lead = rays_o.shape[:-1]
     sample_dist = (far - near) / n_samples
     z = coarse_z(near, far, n_samples, as_t(t_rand).reshape(*lead, 1))

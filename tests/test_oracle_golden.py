@@ -110,8 +110,13 @@ def test_render_dual_forward_backward(golden):
         # with every input requiring grad torch takes other matmul-backward paths than with
         # plain tensors (bitwise equal without requires_grad): allow the north-star 1e-4
         assert_close(res[k], g[k], 1e-4, k)
-    inds = torch.stack([x for pair in zip(res['inds_hand'], res['inds_obj']) for x in pair])
+    # sample indices: bit-exact on plain tensors (same torch kernels as the reference run)
+    plain = orr.render_dual(hand, obj, t(g['rays_o']), t(g['rays_d']), float(g['near']), float(g['far']),
+                            t(g['t_rand']), 64, 64, 4, t(g['bt_inv']), t(g['T_pose']), t(g['Ro']), t(g['To']))
+    inds = torch.stack([x for pair in zip(plain['inds_hand'], plain['inds_obj']) for x in pair])
     assert np.array_equal(inds.numpy(), g['inds'])
+    for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj', 'gradient_hand', 'gradient_obj'):
+        assert_close(plain[k], g[k], RT, k + ' (plain)')
     loss = ((res['color_fine'] * t(g['w_color'])).sum() + (res['weight_sum'] * t(g['w_wsum'])).sum()
             + (res['sdf_hand'] * t(g['w_sdf_hand'])).sum() + (res['sdf_obj'] * t(g['w_sdf_obj'])).sum())
     assert_close(loss, g['loss'], RT, 'loss')
