@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- ray-samples/sec of the HO-NeRF rendering hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY 8d "C2"): single-GPU offline render with the
+hand nets at conf size, 512 x 512 rays x 64 samples per ray (n_samples=64,
+n_importance=0), synthetic pose / camera / random-init weights, fp32 (exact MFMA f32,
+parity mode).  One step = ray generation + NeuSRenderer.render of one full frame with
+everything already resident in HBM.  With --gpus N (launched by torch.distributed.run,
+one rank per GPU) every rank renders its own frame (frame-sharded, no data-path
+collective): weak scaling, value = all ranks' ray-samples / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel: the fused
+hand field kernel, MFMA-bound) and `cpu_baseline` (the CPU oracle -- a port of the
+reference's PyTorch path -- timed on this box's host cores on a bounded crop).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+H_IMG = W_IMG = 512
+N_SAMPLES = 64
+NEAR, FAR = 0.4, 1.5
+# algorithmic work per ray-sample of the hand field: 1 sdf forward + 1 input-gradient
+# sweep + 1 colour forward = 2 * 1,234,176 + 624,640 MAC = 6.186 MFLOP
+HAND_FLOP_PER_SAMPLE = 2.0 * (2 * 1234176 + 624640)
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def build_scene(dev, seed):
+    from honerf_amd import synth
+    from honerf_amd.nets import SDFNetwork, RenderingNetwork, SingleVarianceNetwork
+    from honerf_amd.renderer import NeuSRenderer
+    sdf, col, var = SDFNetwork().to(dev), RenderingNetwork(use_gradients=True).to(dev), SingleVarianceNetwork(0.3).to(dev)
+    sdf.reset_parameters(21)
+    col.reset_parameters(22)
+    ren = NeuSRenderer(sdf, var, col, 'hand', N_SAMPLES, 0, 0, 4, 1.0)
+    bt_inv, T_pose, joints = synth.synth_hand_pose(seed)
+    cam = synth.front_camera(dist=0.0, focal=2.0)
+    # the hand (~0.2 m across at z ~ 0.95) fills about half of the image width
+    xy = synth.ndc_grid(H_IMG, W_IMG) * 0.45
+    xy[:, 1] += 0.12
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    scene = dict(xy=t(xy), R=t(cam['R']), T=t(cam['T']), focal=t(cam['focal']), principal=t(cam['principal']),
+                 bt_inv=t(bt_inv), T_pose=t(T_pose), t_rand=torch.rand(H_IMG * W_IMG, 1, device=dev,
+                                                                         generator=torch.Generator(dev).manual_seed(1)))
+    return ren, sdf, col, scene
+
+
+def cpu_baseline(sdf, col, scene, crop=40):
+    """The CPU oracle (port of the reference's PyTorch path) on a crop x crop centre block of
+    the same frame, all host cores."""
+    from oracle.nets import Field
+    from oracle import render as orr
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cpu = lambda v: v.detach().cpu()
+    field = Field('hand', {k: cpu(v) for k, v in sdf.state_dict().items()},
+                  {k: cpu(v) for k, v in col.state_dict().items()}, 0.3)
+    idx = torch.arange(H_IMG * W_IMG).reshape(H_IMG, W_IMG)
+    a = (H_IMG - crop) // 2
+    sel = idx[a:a + crop, a:a + crop].reshape(-1)
+    xy = cpu(scene['xy'])[sel]
+    o, d = orr.rays_from_xy(xy, cpu(scene['R'])[0], cpu(scene['T'])[0], cpu(scene['focal'])[0], cpu(scene['principal'])[0])
+    tr = cpu(scene['t_rand'])[sel]
+    t0 = time.perf_counter()
+    n_done = 0
+    chunk = 400
+    for s in range(0, o.shape[0], chunk):
+        orr.render_single(field, o[s:s + chunk], d[s:s + chunk], NEAR, FAR, tr[s:s + chunk], N_SAMPLES, 0, 4,
+                          bt_inv=cpu(scene['bt_inv']), T_pose=cpu(scene['T_pose']))
+        n_done += o[s:s + chunk].shape[0]
+    dt = time.perf_counter() - t0
+    return {'value': n_done * N_SAMPLES / dt, 'unit': 'ray-samples/s', 'cores': cores, 'kind': 'port',
+            'sample': '%dx%d centre crop of the same 512x512x64 frame (%d ray-samples, %.1f s)'
+                      % (crop, crop, n_done * N_SAMPLES, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-crop', type=int, default=40)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from honerf_amd import lib as L
+    lib = L.load()
+    ren, sdf, col, sc = build_scene(dev, seed=9 + rank)      # every rank renders its own frame
+    B = H_IMG * W_IMG
+    rays_o = torch.empty(B, 3, device=dev)
+    rays_d = torch.empty(B, 3, device=dev)
+
+    def step():
+        L.check(lib.hn_ray_gen(L.ptr(sc['xy']), L.ptr(sc['R']), L.ptr(sc['T']), L.ptr(sc['focal']),
+                               L.ptr(sc['principal']), 1, B, L.ptr(rays_o), L.ptr(rays_d), L.stream_ptr()), 'hn_ray_gen')
+        return ren.render(rays_o, rays_d, NEAR, FAR, sc['bt_inv'], sc['T_pose'], None, None, None, 0,
+                          t_rand=sc['t_rand'])
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    samples_per_step = B * N_SAMPLES
+    value = world * samples_per_step * args.steps / dt
+
+    # ---- dominant kernel alone (k_field_hand<true>), HIP events on the launch stream ----------
+    field = ren.field()
+    z = ren.last_z_vals
+    pts = torch.empty(B * N_SAMPLES, 3, device=dev)
+    dists = torch.empty(B * N_SAMPLES, device=dev)
+    L.check(lib.hn_sample_points(L.ptr(rays_o), L.ptr(rays_d), L.ptr(z), B, N_SAMPLES, 1, (FAR - NEAR) / N_SAMPLES,
+                                 L.ptr(pts), L.ptr(dists), L.stream_ptr()), 'hn_sample_points')
+    n = B * N_SAMPLES
+    o_sdf, o_grad, o_rgb = torch.empty(n, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+    ws_bytes = lib.hn_field_workspace_bytes(field.handle, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    bt, tp = sc['bt_inv'].reshape(1, 21, 4, 4).contiguous(), sc['T_pose'].reshape(1, 21, 3).contiguous()
+
+    def field_launch():
+        L.check(lib.hn_field_eval(field.handle, L.ptr(pts), L.ptr(rays_d), n, N_SAMPLES, L.ptr(bt), L.ptr(tp), 1, n,
+                                  L.ptr(o_sdf), L.ptr(o_grad), L.ptr(o_rgb), None, L.ptr(ws), ws_bytes, L.stream_ptr()),
+                'hn_field_eval')
+
+    field_launch()
+    torch.cuda.synchronize()
+    k_launches = max(1, min(args.steps, 3))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(k_launches):
+        field_launch()
+    e1.record()
+    torch.cuda.synchronize()
+    kernel_ms = e0.elapsed_time(e1) / k_launches
+    achieved = n * HAND_FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        res = {
+            'metric': 'ray-samples/sec/GPU (512x512x64)', 'value': value, 'unit': 'ray-samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C2: hand nets (conf size, random init), 512x512 rays x 64 samples, '
+                                   'n_importance=0, dense (no far-field culling), one frame per GPU',
+                       'rays': B, 'samples_per_ray': N_SAMPLES, 'frames_per_step': world},
+            'roofline': {'bound': 'mfma', 'kernel': 'k_field_hand<true>', 'achieved': achieved,
+                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                         'traffic': None, 'kernel_ms': kernel_ms,
+                         'flop_per_launch': n * HAND_FLOP_PER_SAMPLE},
+            'weight_sum_mean': float(out['weight_sum'].mean()),
+        }
+        if not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(sdf, col, sc, args.cpu_crop)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,426 @@
+// extern "C" surface of libhonerf (include/honerf.h) and the launch sequences of the two
+// whole renders.  Nothing here allocates or synchronises (except field create/destroy).
+#include <stdarg.h>
+#include <string.h>
+
+#include "hn_common.h"
+
+namespace hn {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// implemented in the other translation units
+int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float variance, float scale, int precision,
+                 hn_field** out, hipStream_t stream);
+int ray_gen(const float*, const float*, const float*, const float*, const float*, int, int, float*, float*, hipStream_t);
+int obj_local_fwd(const float*, const float*, const float*, const float*, int, int, float*, float*, hipStream_t);
+int obj_local_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
+                  float*, float*, float*, hipStream_t);
+int coarse_z(const float*, int, int, float, float, float, float*, hipStream_t);
+int sample_points(const float*, const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
+int upsample(const float*, const float*, int, int, int, float, float*, int64_t*, hipStream_t);
+int merge(const float*, const float*, const float*, const float*, int, int, int, int, float*, float*, int64_t*,
+          hipStream_t);
+int sort_rows(const float*, int, int, float*, hipStream_t);
+int alpha(const float*, const float*, const float*, const float*, int, int, float, float*, float*, hipStream_t);
+int composite1(const float*, const float*, const float*, const float*, int, int, float*, float*, float*, float*, float*,
+               hipStream_t);
+int composite2(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
+               float*, float*, float*, float*, hipStream_t);
+size_t field_obj_workspace_bytes(int n_pts, int n_cus);
+size_t field_hand_workspace_bytes(int n_pts, int n_cus);
+int launch_field_obj(const hn_field*, const float*, const float*, int, int, float*, float*, float*, float*, void*, size_t,
+                     bool, hipStream_t);
+int launch_field_hand(const hn_field*, const float*, int, const float*, const float*, int, int, float*, float*, float*,
+                      float*, void*, size_t, bool, hipStream_t);
+
+__global__ void k_scale(float* v, int n, float s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] *= s;
+}
+__global__ void k_copy_cols(const float* __restrict__ src, int n_rows, int n_src, float* __restrict__ dst, int n_dst,
+                            int dst_off) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * n_src) return;
+    const int r = i / n_src, c = i % n_src;
+    dst[(size_t)r * n_dst + dst_off + c] = src[i];
+}
+
+// bump allocator over the caller's workspace
+struct Arena {
+    char* base;
+    size_t cap;
+    size_t used = 0;
+    bool ok = true;
+    Arena(void* p, size_t n) : base(reinterpret_cast<char*>(p)), cap(n) {}
+    void* take(size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        if (base == nullptr) {   // sizing pass
+            used += bytes;
+            return nullptr;
+        }
+        if (used + bytes > cap) {
+            ok = false;
+            return nullptr;
+        }
+        void* p = base + used;
+        used += bytes;
+        return p;
+    }
+    float* f(size_t n) { return reinterpret_cast<float*>(take(n * sizeof(float))); }
+};
+
+static int g_cus = -1;
+static int device_cus() {
+    if (g_cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            g_cus = 0;
+        else
+            g_cus = prop.multiProcessorCount;
+    }
+    return g_cus;
+}
+
+static size_t field_ws(const hn_field* f, int n_pts) {
+    int cus = device_cus();
+    if (cus <= 0) cus = 256;
+    return f->kind == HN_FIELD_OBJ ? field_obj_workspace_bytes(n_pts, cus) : field_hand_workspace_bytes(n_pts, cus);
+}
+
+static int field_sdf(const hn_field* f, const float* pts, int n, const float* bt, const float* Tp, int n_frames, int ppf,
+                     float* sdf, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (f->kind == HN_FIELD_OBJ) return launch_field_obj(f, pts, nullptr, n, 1, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
+    return launch_field_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
+}
+static int field_eval(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt,
+                      const float* Tp, int n_frames, int ppf, float* sdf, float* grad, float* rgb, float* feat, void* ws,
+                      size_t ws_bytes, hipStream_t s) {
+    if (f->kind == HN_FIELD_OBJ) return launch_field_obj(f, pts, rays_d, n, spr, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
+    return launch_field_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
+}
+
+#define HN_TRY(expr)             \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != HN_OK) return _rc; \
+    } while (0)
+
+// One importance-sampling track (utils/renderer.py:214-234): coarse sdf, then up_sample_steps x
+// {up_sample, cat_z_vals}.  On return z_cur [n_rays, n_samples + n_importance] is sorted.
+// new_z_all (optional) collects every step's new depths, [n_rays, cat_stride] at column cat_off + 2*i*n_new
+struct Track {
+    float *z_a, *z_b, *sdf_a, *sdf_b, *z_new, *sdf_new, *pts;
+};
+static void track_alloc(Arena& ar, Track& t, size_t n_rays, int S, int n_new) {
+    t.z_a = ar.f(n_rays * S);
+    t.z_b = ar.f(n_rays * S);
+    t.sdf_a = ar.f(n_rays * S);
+    t.sdf_b = ar.f(n_rays * S);
+    t.z_new = ar.f(n_rays * n_new);
+    t.sdf_new = ar.f(n_rays * n_new);
+    t.pts = ar.f(n_rays * S * 3);
+}
+
+static int render_single_impl(const hn_field* f, const float* rays_o, const float* rays_d, const float* t_rand,
+                              int n_rays, double near, double far, int n_samples, int n_importance, int steps,
+                              const float* bt_inv, const float* T_pose, float* color, float* cdf, float* weight_sum,
+                              float* weight_max, float* gradient_error, float* z_vals, void* workspace,
+                              size_t workspace_bytes, hipStream_t s, size_t* need) {
+    HN_REQUIRE(n_samples >= 2 && n_importance >= 0 && n_rays >= 0, "bad sample counts");
+    HN_REQUIRE(n_importance == 0 || (steps >= 1 && n_importance % steps == 0), "n_importance must divide into steps");
+    const int S = n_samples + n_importance;
+    HN_REQUIRE(S <= 256, "at most 256 samples per ray");
+    const int n_new = n_importance > 0 ? n_importance / steps : 0;
+    const size_t N = (size_t)n_rays * S;
+    Arena ar(workspace, workspace_bytes);
+    Track t;
+    track_alloc(ar, t, n_rays, S, n_new > 0 ? n_new : 1);
+    float* dists = ar.f(N);
+    float* sdf = ar.f(N);
+    float* grad = ar.f(N * 3);
+    float* rgb = ar.f(N * 3);
+    float* al = ar.f(N);
+    const size_t fws_bytes = field_ws(f, (int)N);
+    void* fws = ar.take(fws_bytes);
+    if (need != nullptr) {
+        *need = ar.used;
+        return HN_OK;
+    }
+    if (!ar.ok) {
+        set_error("render_single workspace too small: %zu bytes given", workspace_bytes);
+        return HN_ENOMEM;
+    }
+    if (n_rays == 0) return HN_OK;
+    const float sample_dist = (float)((far - near) / (double)n_samples);
+    const int hand_ppf = n_rays * S;   // single field: one frame
+    HN_TRY(coarse_z(t_rand, n_rays, n_samples, (float)near, (float)(far - near), sample_dist, t.z_a, s));
+    float* z_cur = t.z_a;
+    if (n_importance > 0) {
+        int k = n_samples;
+        HN_TRY(sample_points(rays_o, rays_d, t.z_a, n_rays, k, 0, 0.f, t.pts, nullptr, s));
+        HN_TRY(field_sdf(f, t.pts, n_rays * k, bt_inv, T_pose, 1, n_rays * k, t.sdf_a, fws, fws_bytes, s));
+        float *za = t.z_a, *zb = t.z_b, *sa = t.sdf_a, *sb = t.sdf_b;
+        for (int i = 0; i < steps; ++i) {
+            HN_TRY(upsample(za, sa, n_rays, k, n_new, (float)(64 << i), t.z_new, nullptr, s));
+            if (i + 1 < steps) {
+                HN_TRY(sample_points(rays_o, rays_d, t.z_new, n_rays, n_new, 0, 0.f, t.pts, nullptr, s));
+                HN_TRY(field_sdf(f, t.pts, n_rays * n_new, bt_inv, T_pose, 1, n_rays * n_new, t.sdf_new, fws, fws_bytes, s));
+                HN_TRY(merge(za, t.z_new, sa, t.sdf_new, n_rays, k, n_new, 0, zb, sb, nullptr, s));
+            } else {
+                HN_TRY(merge(za, t.z_new, nullptr, nullptr, n_rays, k, n_new, 0, zb, nullptr, nullptr, s));
+            }
+            float* tmp = za; za = zb; zb = tmp;
+            tmp = sa; sa = sb; sb = tmp;
+            k += n_new;
+        }
+        z_cur = za;
+    }
+    HN_TRY(sample_points(rays_o, rays_d, z_cur, n_rays, S, 1, sample_dist, t.pts, dists, s));
+    HN_TRY(field_eval(f, t.pts, rays_d, (int)N, S, bt_inv, T_pose, 1, hand_ppf, sdf, grad, rgb, nullptr, fws, fws_bytes, s));
+    HN_TRY(alpha(sdf, grad, rays_d, dists, (int)N, S, f->inv_s, al, cdf, s));
+    HN_CHECK_HIP(hipMemsetAsync(gradient_error, 0, sizeof(float), s));
+    HN_TRY(composite1(al, cdf, rgb, grad, n_rays, S, color, nullptr, weight_sum, weight_max, gradient_error, s));
+    hipLaunchKernelGGL(k_scale, dim3(1), dim3(64), 0, s, gradient_error, 1, 1.f / (float)N);
+    HN_LAUNCH_CHECK();
+    if (z_vals != nullptr) HN_CHECK_HIP(hipMemcpyAsync(z_vals, z_cur, N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return HN_OK;
+}
+
+static int render_dual_impl(const hn_field* hand, const hn_field* obj, const float* rays_o, const float* rays_d,
+                            const float* t_rand, int n_frames, int rpf, double near, double far, int n_samples,
+                            int n_importance, int steps, const float* bt_inv, const float* T_pose, const float* Ro,
+                            const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand,
+                            float* sdf_obj, float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals,
+                            void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need) {
+    HN_REQUIRE(n_samples >= 2 && n_importance >= 0 && n_frames >= 1 && rpf >= 0, "bad sizes");
+    HN_REQUIRE(n_importance == 0 || (steps >= 1 && n_importance % steps == 0), "n_importance must divide into steps");
+    HN_REQUIRE(hand->kind == HN_FIELD_HAND && obj->kind == HN_FIELD_OBJ, "field kinds (hand, obj) expected");
+    const int n_rays = n_frames * rpf;
+    const int S = n_samples + 2 * n_importance;
+    const int St = n_samples + n_importance;   // per-track length
+    HN_REQUIRE(S <= 256, "at most 256 samples per ray");
+    const int n_new = n_importance > 0 ? n_importance / steps : 0;
+    const size_t N = (size_t)n_rays * S;
+    Arena ar(workspace, workspace_bytes);
+    float* o_obj = ar.f((size_t)n_rays * 3);
+    float* d_obj = ar.f((size_t)n_rays * 3);
+    Track th, to;
+    track_alloc(ar, th, n_rays, St, n_new > 0 ? n_new : 1);
+    track_alloc(ar, to, n_rays, St, n_new > 0 ? n_new : 1);
+    float* zcat = ar.f(N);
+    float* z = ar.f(N);
+    float* pts = ar.f(N * 3);
+    float* dists = ar.f(N);
+    float* rgb_h = ar.f(N * 3);
+    float* rgb_o = ar.f(N * 3);
+    float* al_h = ar.f(N);
+    float* al_o = ar.f(N);
+    const size_t fws_h = field_ws(hand, (int)N), fws_o = field_ws(obj, (int)N);
+    const size_t fws_bytes = fws_h > fws_o ? fws_h : fws_o;
+    void* fws = ar.take(fws_bytes);
+    if (need != nullptr) {
+        *need = ar.used;
+        return HN_OK;
+    }
+    if (!ar.ok) {
+        set_error("render_dual workspace too small: %zu bytes given", workspace_bytes);
+        return HN_ENOMEM;
+    }
+    if (n_rays == 0) return HN_OK;
+    const float sample_dist = (float)((far - near) / (double)n_samples);
+    const int quirk = (batch_quirk && n_frames > 1) ? rpf : 0;
+    HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_obj, d_obj, s));
+    HN_TRY(coarse_z(t_rand, n_rays, n_samples, (float)near, (float)(far - near), sample_dist, th.z_a, s));
+    // shared coarse depths: start the concatenated list with them
+    hipLaunchKernelGGL(k_copy_cols, dim3((n_rays * n_samples + 255) / 256), dim3(256), 0, s, th.z_a, n_rays, n_samples,
+                       zcat, S, 0);
+    HN_LAUNCH_CHECK();
+    const float* z_final = zcat;
+    if (n_importance > 0) {
+        HN_CHECK_HIP(hipMemcpyAsync(to.z_a, th.z_a, (size_t)n_rays * n_samples * sizeof(float), hipMemcpyDeviceToDevice, s));
+        int k = n_samples;
+        HN_TRY(sample_points(rays_o, rays_d, th.z_a, n_rays, k, 0, 0.f, th.pts, nullptr, s));
+        HN_TRY(field_sdf(hand, th.pts, n_rays * k, bt_inv, T_pose, n_frames, rpf * k, th.sdf_a, fws, fws_bytes, s));
+        HN_TRY(sample_points(o_obj, d_obj, to.z_a, n_rays, k, 0, 0.f, to.pts, nullptr, s));
+        HN_TRY(field_sdf(obj, to.pts, n_rays * k, nullptr, nullptr, 1, n_rays * k, to.sdf_a, fws, fws_bytes, s));
+        for (int i = 0; i < steps; ++i) {
+            for (int which = 0; which < 2; ++which) {
+                Track& t = which == 0 ? th : to;
+                const hn_field* f = which == 0 ? hand : obj;
+                const float* ro = which == 0 ? rays_o : o_obj;
+                const float* rd = which == 0 ? rays_d : d_obj;
+                HN_TRY(upsample(t.z_a, t.sdf_a, n_rays, k, n_new, (float)(64 << i), t.z_new, nullptr, s));
+                hipLaunchKernelGGL(k_copy_cols, dim3((n_rays * n_new + 255) / 256), dim3(256), 0, s, t.z_new, n_rays,
+                                   n_new, zcat, S, n_samples + (2 * i + which) * n_new);
+                HN_LAUNCH_CHECK();
+                if (i + 1 < steps) {
+                    HN_TRY(sample_points(ro, rd, t.z_new, n_rays, n_new, 0, 0.f, t.pts, nullptr, s));
+                    HN_TRY(field_sdf(f, t.pts, n_rays * n_new, bt_inv, T_pose, n_frames, rpf * n_new, t.sdf_new, fws, fws_bytes, s));
+                    HN_TRY(merge(t.z_a, t.z_new, t.sdf_a, t.sdf_new, n_rays, k, n_new, quirk, t.z_b, t.sdf_b, nullptr, s));
+                    float* tmp = t.z_a; t.z_a = t.z_b; t.z_b = tmp;
+                    tmp = t.sdf_a; t.sdf_a = t.sdf_b; t.sdf_b = tmp;
+                }
+            }
+            k += n_new;
+        }
+        HN_TRY(sort_rows(zcat, n_rays, S, z, s));
+        z_final = z;
+    }
+    // both fields at the shared sorted depths (utils/renderer.py:500-510)
+    HN_TRY(sample_points(rays_o, rays_d, z_final, n_rays, S, 1, sample_dist, pts, dists, s));
+    HN_TRY(field_eval(hand, pts, rays_d, (int)N, S, bt_inv, T_pose, n_frames, rpf * S, sdf_hand, grad_hand, rgb_h, nullptr,
+                      fws, fws_bytes, s));
+    HN_TRY(alpha(sdf_hand, grad_hand, rays_d, dists, (int)N, S, hand->inv_s, al_h, nullptr, s));
+    HN_TRY(sample_points(o_obj, d_obj, z_final, n_rays, S, 1, sample_dist, pts, dists, s));
+    HN_TRY(field_eval(obj, pts, d_obj, (int)N, S, nullptr, nullptr, 1, (int)N, sdf_obj, grad_obj, rgb_o, nullptr, fws,
+                      fws_bytes, s));
+    HN_TRY(alpha(sdf_obj, grad_obj, d_obj, dists, (int)N, S, obj->inv_s, al_o, nullptr, s));
+    HN_CHECK_HIP(hipMemsetAsync(gradient_error, 0, 2 * sizeof(float), s));
+    HN_TRY(composite2(al_h, rgb_h, grad_hand, al_o, rgb_o, grad_obj, n_rays, S, color, weight_sum, nullptr, nullptr,
+                      gradient_error, s));
+    hipLaunchKernelGGL(k_scale, dim3(1), dim3(64), 0, s, gradient_error, 2, 1.f / (float)N);
+    HN_LAUNCH_CHECK();
+    if (z_vals != nullptr) HN_CHECK_HIP(hipMemcpyAsync(z_vals, z_final, N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return HN_OK;
+}
+
+}  // namespace hn
+
+using namespace hn;
+
+extern "C" {
+
+int hn_version(void) { return HN_VERSION; }
+const char* hn_last_error(void) { return g_err; }
+int hn_device_cus(void) { return device_cus(); }
+
+int hn_field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* color, float variance, float scale,
+                    int precision, hn_field** out, hn_stream_t stream) {
+    return field_create(kind, sdf, color, variance, scale, precision, out, (hipStream_t)stream);
+}
+int hn_field_destroy(hn_field* f) {
+    if (f == nullptr) return HN_OK;
+    if (f->blob != nullptr) (void)hipFree(f->blob);
+    delete f;
+    return HN_OK;
+}
+float hn_field_inv_s(const hn_field* f) { return f ? f->inv_s : 0.f; }
+
+int hn_ray_gen(const float* xy, const float* R, const float* T, const float* focal, const float* principal, int n_cams,
+               int rays_per_cam, float* rays_o, float* rays_d, hn_stream_t stream) {
+    return ray_gen(xy, R, T, focal, principal, n_cams, rays_per_cam, rays_o, rays_d, (hipStream_t)stream);
+}
+int hn_obj_local_fwd(const float* rays_o, const float* rays_d, const float* Ro, const float* To, int n_frames,
+                     int rays_per_frame, float* o_out, float* d_out, hn_stream_t stream) {
+    return obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rays_per_frame, o_out, d_out, (hipStream_t)stream);
+}
+int hn_obj_local_bwd(const float* rays_o, const float* rays_d, const float* Ro, const float* To, const float* g_o_out,
+                     const float* g_d_out, int n_frames, int rays_per_frame, float* g_rays_o, float* g_rays_d,
+                     float* g_Ro, float* g_To, hn_stream_t stream) {
+    return obj_local_bwd(rays_o, rays_d, Ro, To, g_o_out, g_d_out, n_frames, rays_per_frame, g_rays_o, g_rays_d, g_Ro,
+                         g_To, (hipStream_t)stream);
+}
+int hn_coarse_z(const float* t_rand, int n_rays, int n_samples, double near, double far, float* z, hn_stream_t stream) {
+    return coarse_z(t_rand, n_rays, n_samples, (float)near, (float)(far - near),
+                    (float)((far - near) / (double)n_samples), z, (hipStream_t)stream);
+}
+int hn_sample_points(const float* rays_o, const float* rays_d, const float* z, int n_rays, int n, int mid,
+                     float sample_dist, float* pts, float* dists, hn_stream_t stream) {
+    return sample_points(rays_o, rays_d, z, n_rays, n, mid, sample_dist, pts, dists, (hipStream_t)stream);
+}
+int hn_upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, float inv_s, float* z_new,
+                int64_t* inds, hn_stream_t stream) {
+    return upsample(z, sdf, n_rays, k, n_new, inv_s, z_new, inds, (hipStream_t)stream);
+}
+int hn_merge(const float* z, const float* z_new, const float* sdf, const float* sdf_new, int n_rays, int k, int m,
+             int quirk_rays_per_frame, float* z_out, float* sdf_out, int64_t* index, hn_stream_t stream) {
+    return merge(z, z_new, sdf, sdf_new, n_rays, k, m, quirk_rays_per_frame, z_out, sdf_out, index, (hipStream_t)stream);
+}
+int hn_sort_rows(const float* v, int n_rays, int n, float* out, hn_stream_t stream) {
+    return sort_rows(v, n_rays, n, out, (hipStream_t)stream);
+}
+
+size_t hn_field_workspace_bytes(const hn_field* f, int n_pts) { return f ? field_ws(f, n_pts) : 0; }
+
+int hn_field_sdf(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
+                 int pts_per_frame, float* sdf, void* workspace, size_t workspace_bytes, hn_stream_t stream) {
+    HN_REQUIRE(f != nullptr, "null field");
+    return field_sdf(f, pts, n_pts, bt_inv, T_pose, n_frames, pts_per_frame, sdf, workspace, workspace_bytes,
+                     (hipStream_t)stream);
+}
+int hn_field_eval(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray,
+                  const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame, float* sdf, float* grad,
+                  float* rgb, float* feat, void* workspace, size_t workspace_bytes, hn_stream_t stream) {
+    HN_REQUIRE(f != nullptr, "null field");
+    return field_eval(f, pts, rays_d, n_pts, samples_per_ray, bt_inv, T_pose, n_frames, pts_per_frame, sdf, grad, rgb,
+                      feat, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int hn_alpha(const float* sdf, const float* grad, const float* rays_d, const float* dists, int n_pts,
+             int samples_per_ray, float inv_s, float* alpha_out, float* c, hn_stream_t stream) {
+    return alpha(sdf, grad, rays_d, dists, n_pts, samples_per_ray, inv_s, alpha_out, c, (hipStream_t)stream);
+}
+int hn_composite1(const float* alpha_in, const float* c, const float* rgb, const float* grad, int n_rays, int S,
+                  float* color, float* weights, float* weight_sum, float* weight_max, float* eik_sum,
+                  hn_stream_t stream) {
+    return composite1(alpha_in, c, rgb, grad, n_rays, S, color, weights, weight_sum, weight_max, eik_sum,
+                      (hipStream_t)stream);
+}
+int hn_composite2(const float* alpha_h, const float* rgb_h, const float* grad_h, const float* alpha_o,
+                  const float* rgb_o, const float* grad_o, int n_rays, int S, float* color, float* weight_sum,
+                  float* w_hand, float* w_obj, float* eik_sum, hn_stream_t stream) {
+    return composite2(alpha_h, rgb_h, grad_h, alpha_o, rgb_o, grad_o, n_rays, S, color, weight_sum, w_hand, w_obj,
+                      eik_sum, (hipStream_t)stream);
+}
+
+size_t hn_render_single_workspace_bytes(const hn_field* f, int n_rays, int n_samples, int n_importance) {
+    size_t need = 0;
+    if (f == nullptr) return 0;
+    if (render_single_impl(f, nullptr, nullptr, nullptr, n_rays, 0.0, 1.0, n_samples, n_importance,
+                           n_importance > 0 ? 1 : 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, 0, nullptr, &need) != HN_OK)
+        return 0;
+    return need;
+}
+int hn_render_single(const hn_field* f, const float* rays_o, const float* rays_d, const float* t_rand, int n_rays,
+                     double near, double far, int n_samples, int n_importance, int up_sample_steps, const float* bt_inv,
+                     const float* T_pose, float* color, float* cdf, float* weight_sum, float* weight_max,
+                     float* gradient_error, float* z_vals, void* workspace, size_t workspace_bytes, hn_stream_t stream) {
+    HN_REQUIRE(f != nullptr, "null field");
+    return render_single_impl(f, rays_o, rays_d, t_rand, n_rays, near, far, n_samples, n_importance, up_sample_steps,
+                              bt_inv, T_pose, color, cdf, weight_sum, weight_max, gradient_error, z_vals, workspace,
+                              workspace_bytes, (hipStream_t)stream, nullptr);
+}
+
+size_t hn_render_dual_workspace_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples,
+                                      int n_importance) {
+    size_t need = 0;
+    if (hand == nullptr || obj == nullptr) return 0;
+    if (render_dual_impl(hand, obj, nullptr, nullptr, nullptr, 1, n_rays, 0.0, 1.0, n_samples, n_importance,
+                         n_importance > 0 ? 1 : 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &need) != HN_OK)
+        return 0;
+    return need;
+}
+int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_o, const float* rays_d,
+                   const float* t_rand, int n_frames, int rays_per_frame, double near, double far, int n_samples,
+                   int n_importance, int up_sample_steps, const float* bt_inv, const float* T_pose, const float* Ro,
+                   const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand, float* sdf_obj,
+                   float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals, void* workspace,
+                   size_t workspace_bytes, hn_stream_t stream) {
+    HN_REQUIRE(hand != nullptr && obj != nullptr, "null field");
+    return render_dual_impl(hand, obj, rays_o, rays_d, t_rand, n_frames, rays_per_frame, near, far, n_samples,
+                            n_importance, up_sample_steps, bt_inv, T_pose, Ro, To, batch_quirk, color, weight_sum,
+                            sdf_hand, sdf_obj, grad_hand, grad_obj, gradient_error, z_vals, workspace, workspace_bytes,
+                            (hipStream_t)stream, nullptr);
+}
+
+}  // extern "C"

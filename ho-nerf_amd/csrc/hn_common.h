@@ -1,0 +1,96 @@
+// Shared host/device definitions of the honerf library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/honerf.h"
+
+namespace hn {
+
+// ---- error plumbing ----------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define HN_CHECK_HIP(expr)                                                                    \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            hn::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return HN_EHIP;                                                                   \
+        }                                                                                     \
+    } while (0)
+#define HN_REQUIRE(cond, ...)                  \
+    do {                                       \
+        if (!(cond)) {                         \
+            hn::set_error(__VA_ARGS__);        \
+            return HN_EINVAL;                  \
+        }                                      \
+    } while (0)
+#define HN_LAUNCH_CHECK() HN_CHECK_HIP(hipGetLastError())
+
+// ---- network geometry (fixed by the reference confs; checked in hn_field_create) ---------
+constexpr int H = 256;           // d_hidden == d_feature
+constexpr int NT = H / 32;       // 8 row tiles of 32 neurons
+constexpr int N_BONES = 21;
+constexpr int PTS_FREQS = 10;    // v_multires
+constexpr int OBJ_DIR_FREQS = 4; // r_multires, obj conf
+constexpr int HAND_DIR_FREQS = 7;// r_multires, hand conf
+constexpr int GRAD_FREQS = 4;    // grad_multires
+constexpr int OBJ_IN = 63;
+constexpr int BONE_FEAT = 66;
+constexpr int HAND_IN = N_BONES * BONE_FEAT;  // 1386
+constexpr int L3_OUT_OBJ = H - OBJ_IN;        // 193 -> 7 tiles
+
+// K-step ("pair") spaces: one MFMA k-step consumes two input columns, one per
+// lane half.  The order of the pairs is ours (baked into the packed weights).
+constexpr int OBJ_X_STEPS = 32;   // 30 sin/cos pairs + (px,py) + (pz,0)
+constexpr int VEC_STEPS = 16;     // enc4 of a 3-vector: 12 sin/cos pairs + (x,y) + (z,0) + 2 pad
+constexpr int BONE_STEPS = 36;    // 33 pairs per bone + 3 pad
+constexpr int HAND_X_STEPS = N_BONES * BONE_STEPS;   // 756
+// reverse sweep over the hand features: groups of 4 bones = 144 pairs = 9 tiles
+constexpr int BONE_GROUP = 4;
+constexpr int GROUP_TILES = 9;
+constexpr int N_GROUPS = 6;       // 5 full groups + 1 bone in the last
+
+// accumulator-tile geometry of v_mfma_f32_32x32x2_f32: lane l holds column l&31;
+// register r of lane half h = l>>5 holds row (r&3) + 8*(r>>2) + 4*h.
+__host__ __device__ inline int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// One packed matrix: float4 fragments [out_tiles][steps/4][64 lanes].
+struct PackedMat {
+    const float4* w = nullptr;
+    int out_tiles = 0;
+    int steps = 0;   // k-steps (multiple of 4)
+};
+
+}  // namespace hn
+
+// The opaque handle of the C ABI.
+struct hn_field {
+    int kind = 0;
+    int precision = 0;
+    float variance = 0.f;
+    float inv_s = 0.f;
+    float scale = 1.f;
+    void* blob = nullptr;       // one device allocation holding every packed array
+    size_t blob_bytes = 0;
+    // --- SDF network -------------------------------------------------------------------
+    hn::PackedMat sdf_fwd[9];    // l = 0..7: W_l; [8]: rows 1..256 of W_8 (feature rows)
+    hn::PackedMat sdf_skip;      // W_4[:, skip columns] over the input space (scaled 1/sqrt2)
+    hn::PackedMat sdf_bwd[8];    // l = 1..7: W_l^T over hidden space ([0] unused)
+    hn::PackedMat sdf_bwd_in0;   // W_0^T : rows = input space
+    hn::PackedMat sdf_bwd_in4;   // W_4[:, skip]^T : rows = input space
+    const float* sdf_bias[9] = {};   // tile-row order (padded to 32*tiles); [8] = feature rows
+    const float* sdf_w8row = nullptr;// W_8[0, :] (256)
+    float sdf_b8 = 0.f;              // b_8[0]
+    // --- colour network ----------------------------------------------------------------
+    hn::PackedMat col_in_x;      // lin0 columns over the point/feature input space
+    hn::PackedMat col_in_d;      // lin0 columns over enc(view dir) (obj only)
+    hn::PackedMat col_in_f;      // lin0 columns over the 256 feature vector
+    hn::PackedMat col_in_g;      // lin0 columns over enc(gradient)
+    hn::PackedMat col_fwd[4];    // l = 1..3 ([0] unused)
+    const float* col_bias[4] = {};
+    const float* col_wlast = nullptr;   // lin4: [3][256]
+    float col_blast[3] = {0.f, 0.f, 0.f};
+};

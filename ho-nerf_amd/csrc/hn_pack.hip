@@ -1,0 +1,379 @@
+// Weight packer: reads the reference's state-dict layout (lin{l}.weight_g / weight_v / bias,
+// old-style weight-norm, utils/fields.py:120-121, 216-217, 307-308, 382-383), folds
+// W = g * v / ||v||_row once and re-lays every matrix the kernels multiply by into MFMA
+// A-fragment order (hn_mlp.h): float4 [out_tile][step/4][lane], where the fragment of
+// lane l for k-step s is  scale * W[rowmap[32 t + (l&31)]][colmap[2 s + (l>>5)]].
+// Row maps and column maps describe our own orderings of neurons / input columns; -1 = pad.
+#include <math.h>
+
+#include "hn_common.h"
+
+namespace hn {
+
+// effective weight of one layer, row-major [out][in]
+__global__ void k_fold_weight_norm(const float* __restrict__ g, const float* __restrict__ v, int out, int in,
+                                   float* __restrict__ w) {
+    const int row = blockIdx.x;
+    if (row >= out) return;
+    const float* vr = v + (size_t)row * in;
+    float scale = 1.f;
+    if (g != nullptr) {
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < in; i += blockDim.x) ss = fmaf(vr[i], vr[i], ss);
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        __shared__ float part[4];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        ss = part[0] + part[1] + part[2] + part[3];
+        // torch._weight_norm: v * (g / ||v||)
+        scale = g[row] / sqrtf(ss);
+    }
+    for (int i = threadIdx.x; i < in; i += blockDim.x) w[(size_t)row * in + i] = vr[i] * scale;
+}
+
+// dst fragment order; src row-major [src_rows][src_cols]; transposed: element (row, col) = src[col][row]
+__global__ void k_pack(const float* __restrict__ src, int src_cols, int transposed, const int* __restrict__ rowmap,
+                       const int* __restrict__ colmap, int out_tiles, int steps, float scale,
+                       float4* __restrict__ dst) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over [tile][q][lane]
+    const size_t total = (size_t)out_tiles * (steps / 4) * 64;
+    if (idx >= total) return;
+    const int lane = idx & 63;
+    const int q = (idx >> 6) % (steps / 4);
+    const int t = (idx >> 6) / (steps / 4);
+    const int row = rowmap[32 * t + (lane & 31)];
+    float v[4];
+    for (int jj = 0; jj < 4; ++jj) {
+        const int col = colmap[2 * (4 * q + jj) + (lane >> 5)];
+        float x = 0.f;
+        if (row >= 0 && col >= 0) x = transposed ? src[(size_t)col * src_cols + row] : src[(size_t)row * src_cols + col];
+        v[jj] = x * scale;
+    }
+    dst[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ void k_gather_vec(const float* __restrict__ src, const int* __restrict__ map, int n, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = map[i] >= 0 ? src[map[i]] : 0.f;
+}
+
+// ---- index-space descriptions ----------------------------------------------------------------
+// "tile-row space": position 32 t + i  -> neuron (or -1).
+static std::vector<int> identity_rows(int n, int tiles, int offset = 0) {
+    std::vector<int> m(32 * tiles, -1);
+    for (int i = 0; i < n; ++i) m[i] = offset + i;
+    return m;
+}
+// B-operand columns when the input is an accumulator tile array with the given tile-row map:
+// k-step s = 16 u + r contracts tile rows tile_row(r, 0) and tile_row(r, 1) of tile u.
+static std::vector<int> cols_from_tiles(const std::vector<int>& tile_rows) {
+    const int tiles = (int)tile_rows.size() / 32;
+    std::vector<int> c(2 * 16 * tiles);
+    for (int u = 0; u < tiles; ++u)
+        for (int r = 0; r < 16; ++r)
+            for (int h = 0; h < 2; ++h) c[2 * (16 * u + r) + h] = tile_rows[32 * u + tile_row(r, h)];
+    return c;
+}
+// Tile-row map of an accumulator whose rows are the members of k-step pairs:
+// tile u, row i  <->  pair 16 u + r, member h  with i = tile_row(r, h).
+static std::vector<int> rows_from_pairs(const std::vector<int>& pair_cols) {
+    const int pairs = (int)pair_cols.size() / 2;
+    const int tiles = (pairs + 15) / 16;
+    std::vector<int> m(32 * tiles, -1);
+    for (int p = 0; p < pairs; ++p)
+        for (int h = 0; h < 2; ++h) m[32 * (p / 16) + tile_row(p % 16, h)] = pair_cols[2 * p + h];
+    return m;
+}
+
+// pair list (2 columns per k-step) of [x, enc_L(x)] for a 3-vector, reference column order
+// [x(3), per channel c: sin 2^0..2^(L-1), cos 2^0..2^(L-1)] (utils/fields.py:13-20), padded to `steps`.
+static std::vector<int> vec_pairs(int L, int base, int steps) {
+    std::vector<int> c(2 * steps, -1);
+    int s = 0;
+    for (int ch = 0; ch < 3; ++ch)
+        for (int k = 0; k < L; ++k, ++s) {
+            c[2 * s] = base + 3 + 2 * L * ch + k;
+            c[2 * s + 1] = base + 3 + 2 * L * ch + L + k;
+        }
+    c[2 * s] = base + 0;
+    c[2 * s + 1] = base + 1;
+    ++s;
+    c[2 * s] = base + 2;
+    return c;
+}
+
+// pair list of one hand bone's 66 features (utils/fields.py:142-147): [v, sin(2^k v) k<10,
+// cos(2^k v) k<10, r(3), per channel c: sin(2^k r_c) k<7, cos(2^k r_c) k<7], 36 steps.
+static void bone_pairs(int bone, int base, std::vector<int>& c) {
+    const int b0 = base + BONE_FEAT * bone;
+    std::vector<int> p(2 * BONE_STEPS, -1);
+    p[0] = b0 + 0;
+    p[1] = b0 + 21;
+    p[2] = b0 + 22;
+    p[3] = b0 + 23;
+    for (int k = 0; k < PTS_FREQS; ++k) {
+        p[2 * (2 + k)] = b0 + 1 + k;
+        p[2 * (2 + k) + 1] = b0 + 11 + k;
+    }
+    for (int ch = 0; ch < 3; ++ch)
+        for (int k = 0; k < HAND_DIR_FREQS; ++k) {
+            const int s = 12 + HAND_DIR_FREQS * ch + k;
+            p[2 * s] = b0 + 24 + 2 * HAND_DIR_FREQS * ch + k;
+            p[2 * s + 1] = b0 + 24 + 2 * HAND_DIR_FREQS * ch + HAND_DIR_FREQS + k;
+        }
+    c.insert(c.end(), p.begin(), p.end());
+}
+static std::vector<int> hand_pairs(int base, int n_bones_padded) {
+    std::vector<int> c;
+    for (int b = 0; b < n_bones_padded; ++b) {
+        if (b < N_BONES)
+            bone_pairs(b, base, c);
+        else
+            c.insert(c.end(), 2 * BONE_STEPS, -1);
+    }
+    return c;
+}
+
+// ---- the packer -----------------------------------------------------------------------------
+struct Packer {
+    hipStream_t stream;
+    bool dry = true;          // first pass: only count bytes
+    char* base = nullptr;
+    size_t used = 0;
+    std::vector<void*> temps; // device temporaries to free at the end
+    int status = HN_OK;
+
+    void* take(size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        void* p = dry ? nullptr : base + used;
+        used += bytes;
+        return p;
+    }
+    int* upload(const std::vector<int>& v) {
+        int* d = nullptr;
+        if (hipMalloc(&d, v.size() * sizeof(int)) != hipSuccess) {
+            status = HN_ENOMEM;
+            return nullptr;
+        }
+        temps.push_back(d);
+        if (hipMemcpyAsync(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess)
+            status = HN_EHIP;
+        return d;
+    }
+    PackedMat mat(const float* w_eff, int src_cols, bool transposed, const std::vector<int>& rowmap,
+                  const std::vector<int>& colmap, float scale) {
+        PackedMat m;
+        m.out_tiles = (int)rowmap.size() / 32;
+        m.steps = (int)colmap.size() / 2;
+        const size_t n4 = (size_t)m.out_tiles * (m.steps / 4) * 64;
+        float4* dst = reinterpret_cast<float4*>(take(n4 * sizeof(float4)));
+        m.w = dst;
+        if (dry || status != HN_OK) return m;
+        int* dr = upload(rowmap);
+        int* dc = upload(colmap);
+        if (status != HN_OK) return m;
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, w_eff, src_cols,
+                           transposed ? 1 : 0, dr, dc, m.out_tiles, m.steps, scale, dst);
+        return m;
+    }
+    const float* vec(const float* src, const std::vector<int>& map) {
+        float* dst = reinterpret_cast<float*>(take(map.size() * sizeof(float)));
+        if (dry || status != HN_OK) return dst;
+        int* dm = upload(map);
+        if (status != HN_OK) return dst;
+        hipLaunchKernelGGL(k_gather_vec, dim3((unsigned)((map.size() + 255) / 256)), dim3(256), 0, stream, src, dm,
+                           (int)map.size(), dst);
+        return dst;
+    }
+    void free_temps() {
+        for (void* p : temps) (void)hipFree(p);
+        temps.clear();
+    }
+};
+
+static int check_shapes(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col) {
+    const int in0 = kind == HN_FIELD_OBJ ? OBJ_IN : HAND_IN;
+    HN_REQUIRE(sdf->n_layers == 9 && col->n_layers == 5, "expected 9 sdf and 5 colour layers, got %d / %d",
+               sdf->n_layers, col->n_layers);
+    for (int l = 0; l < 9; ++l) {
+        int out = H, in = H;
+        if (l == 0) in = in0;
+        if (l == 8) out = H + 1;
+        if (kind == HN_FIELD_OBJ && l == 3) out = L3_OUT_OBJ;
+        if (kind == HN_FIELD_HAND && l == 4) in = H + HAND_IN;
+        HN_REQUIRE(sdf->out_dim[l] == out && sdf->in_dim[l] == in, "sdf lin%d: expected [%d,%d], got [%d,%d]", l, out,
+                   in, sdf->out_dim[l], sdf->in_dim[l]);
+    }
+    const int cin = kind == HN_FIELD_OBJ ? OBJ_IN + 27 + H + 27 : HAND_IN + H + 27;
+    for (int l = 0; l < 5; ++l) {
+        const int out = l == 4 ? 3 : H, in = l == 0 ? cin : H;
+        HN_REQUIRE(col->out_dim[l] == out && col->in_dim[l] == in, "colour lin%d: expected [%d,%d], got [%d,%d]", l,
+                   out, in, col->out_dim[l], col->in_dim[l]);
+    }
+    return HN_OK;
+}
+
+static int build(hn_field* f, Packer& pk, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float* const* w_sdf,
+                 float* const* w_col, const float* w8_host_row_bias /* [b8, cb0, cb1, cb2] */) {
+    const bool obj = f->kind == HN_FIELD_OBJ;
+    const float rs2 = (float)(1.0 / sqrt(2.0));
+    const std::vector<int> hid = identity_rows(H, NT);
+    const std::vector<int> hid_cols = cols_from_tiles(hid);
+    // input ("X") space of the sdf net
+    const std::vector<int> x_pairs = obj ? vec_pairs(PTS_FREQS, 0, OBJ_X_STEPS) : hand_pairs(0, N_BONES);
+    // rows of d sdf / d X: obj 2 tiles; hand 6 groups x 9 tiles over 24 (padded) bones
+    const std::vector<int> x_rows = rows_from_pairs(obj ? x_pairs : hand_pairs(0, BONE_GROUP * N_GROUPS));
+
+    // ---- sdf forward -------------------------------------------------------------------
+    f->sdf_fwd[0] = pk.mat(w_sdf[0], sdf->in_dim[0], false, hid, x_pairs, 1.f);
+    f->sdf_bias[0] = pk.vec(sdf->bias[0], hid);
+    for (int l = 1; l <= 7; ++l) {
+        std::vector<int> rows = hid, cols = hid_cols;
+        float scale = 1.f;
+        if (obj && l == 3) rows = identity_rows(L3_OUT_OBJ, 7);
+        if (l == 4) {
+            scale = rs2;
+            if (obj) cols = cols_from_tiles(identity_rows(L3_OUT_OBJ, 7));
+        }
+        f->sdf_fwd[l] = pk.mat(w_sdf[l], sdf->in_dim[l], false, rows, cols, scale);
+        f->sdf_bias[l] = pk.vec(sdf->bias[l], rows);
+    }
+    {   // skip columns of lin4 over the X space
+        std::vector<int> cols = x_pairs;
+        const int off = obj ? L3_OUT_OBJ : H;
+        for (int& c : cols)
+            if (c >= 0) c += off;
+        f->sdf_skip = pk.mat(w_sdf[4], sdf->in_dim[4], false, hid, cols, rs2);
+        // and its transpose: rows = X space
+        std::vector<int> xr = x_rows;
+        for (int& c : xr)
+            if (c >= 0) c += off;
+        f->sdf_bwd_in4 = pk.mat(w_sdf[4], sdf->in_dim[4], true, xr, hid_cols, rs2);
+    }
+    f->sdf_bwd_in0 = pk.mat(w_sdf[0], sdf->in_dim[0], true, x_rows, hid_cols, 1.f);
+    {   // lin8: row 0 = sdf (plain vector), rows 1..256 = feature vector
+        f->sdf_fwd[8] = pk.mat(w_sdf[8], sdf->in_dim[8], false, identity_rows(H, NT, 1), hid_cols, 1.f);
+        f->sdf_bias[8] = pk.vec(sdf->bias[8], identity_rows(H, NT, 1));
+        f->sdf_w8row = pk.vec(w_sdf[8], identity_rows(H, NT));
+        f->sdf_b8 = w8_host_row_bias[0];
+    }
+    // ---- sdf reverse sweep: W_l^T, rows = layer input space, contraction over layer outputs
+    for (int l = 1; l <= 7; ++l) {
+        std::vector<int> rows = hid, cols = hid_cols;
+        float scale = 1.f;
+        if (l == 4) {
+            scale = rs2;
+            if (obj) rows = identity_rows(L3_OUT_OBJ, 7);
+        }
+        if (obj && l == 3) cols = cols_from_tiles(identity_rows(L3_OUT_OBJ, 7));
+        f->sdf_bwd[l] = pk.mat(w_sdf[l], sdf->in_dim[l], true, rows, cols, scale);
+    }
+    // ---- colour net ----------------------------------------------------------------------
+    const int cin = col->in_dim[0];
+    if (obj) {
+        // [enc10(p) 63 | enc4(d) 27 | feature 256 | enc4(g) 27]  (utils/fields.py:389-396)
+        f->col_in_x = pk.mat(w_col[0], cin, false, hid, x_pairs, 1.f);
+        f->col_in_d = pk.mat(w_col[0], cin, false, hid, vec_pairs(OBJ_DIR_FREQS, OBJ_IN, VEC_STEPS), 1.f);
+        std::vector<int> fc = hid_cols;
+        for (int& c : fc) c += OBJ_IN + 27;
+        f->col_in_f = pk.mat(w_col[0], cin, false, hid, fc, 1.f);
+        f->col_in_g = pk.mat(w_col[0], cin, false, hid, vec_pairs(GRAD_FREQS, OBJ_IN + 27 + H, VEC_STEPS), 1.f);
+    } else {
+        // [xyz_feature 1386 | feature 256 | enc4(g) 27]  (utils/fields.py:224-229)
+        f->col_in_x = pk.mat(w_col[0], cin, false, hid, x_pairs, 1.f);
+        std::vector<int> fc = hid_cols;
+        for (int& c : fc) c += HAND_IN;
+        f->col_in_f = pk.mat(w_col[0], cin, false, hid, fc, 1.f);
+        f->col_in_g = pk.mat(w_col[0], cin, false, hid, vec_pairs(GRAD_FREQS, HAND_IN + H, VEC_STEPS), 1.f);
+    }
+    f->col_bias[0] = pk.vec(col->bias[0], hid);
+    for (int l = 1; l <= 3; ++l) {
+        f->col_fwd[l] = pk.mat(w_col[l], H, false, hid, hid_cols, 1.f);
+        f->col_bias[l] = pk.vec(col->bias[l], hid);
+    }
+    {
+        std::vector<int> m(3 * H);
+        for (int i = 0; i < 3 * H; ++i) m[i] = i;
+        f->col_wlast = pk.vec(w_col[4], m);
+        for (int c = 0; c < 3; ++c) f->col_blast[c] = w8_host_row_bias[1 + c];
+    }
+    return pk.status;
+}
+
+int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float variance, float scale, int precision,
+                 hn_field** out, hipStream_t stream) {
+    HN_REQUIRE(out != nullptr && sdf != nullptr && col != nullptr, "null argument");
+    HN_REQUIRE(kind == HN_FIELD_OBJ || kind == HN_FIELD_HAND, "unknown field kind %d", kind);
+    HN_REQUIRE(precision == HN_PREC_FP32, "unsupported precision %d", precision);
+    int rc = check_shapes(kind, sdf, col);
+    if (rc != HN_OK) return rc;
+
+    hn_field* f = new hn_field();
+    f->kind = kind;
+    f->precision = precision;
+    f->variance = variance;
+    f->scale = scale;
+    {
+        float s = expf(variance * 10.f);
+        f->inv_s = fminf(fmaxf(s, 1e-6f), 1e6f);
+    }
+    // fold weight norm into temporaries
+    Packer pk;
+    pk.stream = stream;
+    float* w_sdf[9] = {};
+    float* w_col[5] = {};
+    auto fold = [&](const hn_mlp_desc* d, int l, float** dst) -> int {
+        const size_t n = (size_t)d->out_dim[l] * d->in_dim[l];
+        HN_CHECK_HIP(hipMalloc(dst, n * sizeof(float)));
+        pk.temps.push_back(*dst);
+        hipLaunchKernelGGL(k_fold_weight_norm, dim3(d->out_dim[l]), dim3(256), 0, stream, d->weight_g[l], d->weight_v[l],
+                           d->out_dim[l], d->in_dim[l], *dst);
+        HN_LAUNCH_CHECK();
+        return HN_OK;
+    };
+    for (int l = 0; l < 9 && rc == HN_OK; ++l) rc = fold(sdf, l, &w_sdf[l]);
+    for (int l = 0; l < 5 && rc == HN_OK; ++l) rc = fold(col, l, &w_col[l]);
+    float hostb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rc == HN_OK) {
+        if (hipMemcpyAsync(&hostb[0], sdf->bias[8], sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipMemcpyAsync(&hostb[1], col->bias[4], 3 * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) {
+            set_error("reading last-layer biases failed");
+            rc = HN_EHIP;
+        }
+    }
+    if (rc == HN_OK) {
+        pk.dry = true;
+        pk.used = 0;
+        build(f, pk, sdf, col, w_sdf, w_col, hostb);
+        f->blob_bytes = pk.used;
+        if (hipMalloc(&f->blob, f->blob_bytes) != hipSuccess) {
+            set_error("hipMalloc of %zu bytes for packed weights failed", f->blob_bytes);
+            rc = HN_ENOMEM;
+        }
+    }
+    if (rc == HN_OK) {
+        pk.dry = false;
+        pk.base = reinterpret_cast<char*>(f->blob);
+        pk.used = 0;
+        rc = build(f, pk, sdf, col, w_sdf, w_col, hostb);
+        if (rc == HN_OK && hipGetLastError() != hipSuccess) {
+            set_error("a pack kernel failed to launch");
+            rc = HN_EHIP;
+        }
+        if (hipStreamSynchronize(stream) != hipSuccess && rc == HN_OK) {
+            set_error("pack kernels failed");
+            rc = HN_EHIP;
+        }
+    }
+    pk.free_temps();
+    if (rc != HN_OK) {
+        if (f->blob) (void)hipFree(f->blob);
+        delete f;
+        return rc;
+    }
+    *out = f;
+    return HN_OK;
+}
+
+}  // namespace hn

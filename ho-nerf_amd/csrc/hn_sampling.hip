@@ -1,0 +1,341 @@
+// Rays, depth sampling, hierarchical (importance) sampling.
+//
+// The sampling kernels are deliberately ONE THREAD PER RAY with strictly sequential
+// prefix products / prefix sums: the reference builds its cdf with torch.cumprod and
+// torch.cumsum (sequential on its CPU path) and inverts it with searchsorted; sample
+// indices have to agree bit-for-bit, so the association order is kept (hard
+// part 3).  The work is O(k) per ray on a few hundred bytes: launch-latency bound, never
+// a bandwidth problem (rows are read once, L1-resident per lane).
+#include "hn_common.h"
+
+namespace hn {
+
+// ---- _xy_to_ray_bundle (utils/utils.py:31-115) ------------------------------------------------
+// PyTorch3D convention (third-party, restated: X_view = ((x-px) z/fx, (y-py) z/fy, z),
+// X_world = (X_view - T) R^T).
+__global__ void k_ray_gen(const float* __restrict__ xy, const float* __restrict__ R, const float* __restrict__ T,
+                          const float* __restrict__ focal, const float* __restrict__ principal, int n_cams,
+                          int rays_per_cam, float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cams * rays_per_cam) return;
+    const int cam = i / rays_per_cam;
+    const float* Rc = R + 9 * cam;
+    const float* Tc = T + 3 * cam;
+    const float fx = focal[2 * cam], fy = focal[2 * cam + 1];
+    const float px = principal[2 * cam], py = principal[2 * cam + 1];
+    const float x = xy[2 * i], y = xy[2 * i + 1];
+    float pw[2][3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float z = (float)(k + 1);
+        const float v[3] = {(x - px) * z / fx - Tc[0], (y - py) * z / fy - Tc[1], z - Tc[2]};
+        // (X_view - T) @ R^T : out_j = sum_i v_i R[j][i]
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) pw[k][jj] = v[0] * Rc[3 * jj] + v[1] * Rc[3 * jj + 1] + v[2] * Rc[3 * jj + 2];
+    }
+    float d[3] = {pw[1][0] - pw[0][0], pw[1][1] - pw[0][1], pw[1][2] - pw[0][2]};
+    const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);   // F.normalize eps
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        d[jj] /= nrm;
+        rays_d[3 * i + jj] = d[jj];
+        rays_o[3 * i + jj] = pw[0][jj] - d[jj];
+    }
+}
+
+// ---- convert_obj_to_local (utils/renderer.py:180-188) -----------------------------------------
+__global__ void k_obj_local_fwd(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ Ro,
+                                const float* __restrict__ To, int n, int rays_per_frame, float* __restrict__ o_out,
+                                float* __restrict__ d_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int f = i / rays_per_frame;
+    const float* R = Ro + 9 * f;
+    const float* T = To + 3 * f;
+    const float a[3] = {o[3 * i] - T[0], o[3 * i + 1] - T[1], o[3 * i + 2] - T[2]};
+    const float b[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        o_out[3 * i + r] = R[3 * r] * a[0] + R[3 * r + 1] * a[1] + R[3 * r + 2] * a[2];
+        d_out[3 * i + r] = R[3 * r] * b[0] + R[3 * r + 1] * b[1] + R[3 * r + 2] * b[2];
+    }
+}
+
+// one block per frame: dRo = sum go' (o-To)^T + gd' d^T ; dTo = -Ro^T sum go' ; do = Ro^T go' ; dd = Ro^T gd'
+__global__ __launch_bounds__(256) void k_obj_local_bwd(const float* __restrict__ o, const float* __restrict__ d,
+                                                       const float* __restrict__ Ro, const float* __restrict__ To,
+                                                       const float* __restrict__ go_out,
+                                                       const float* __restrict__ gd_out, int rays_per_frame,
+                                                       float* __restrict__ g_o, float* __restrict__ g_d,
+                                                       float* __restrict__ g_Ro, float* __restrict__ g_To) {
+    const int f = blockIdx.x;
+    const float* R = Ro + 9 * f;
+    const float* T = To + 3 * f;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int p = threadIdx.x; p < rays_per_frame; p += blockDim.x) {
+        const int i = f * rays_per_frame + p;
+        const float a[3] = {o[3 * i] - T[0], o[3 * i + 1] - T[1], o[3 * i + 2] - T[2]};
+        const float b[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+        const float go[3] = {go_out[3 * i], go_out[3 * i + 1], go_out[3 * i + 2]};
+        const float gd[3] = {gd_out[3 * i], gd_out[3 * i + 1], gd_out[3 * i + 2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[3 * r + c] += go[r] * a[c] + gd[r] * b[c];
+            acc[9 + r] += go[r];
+        }
+        if (g_o != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g_o[3 * i + c] = R[c] * go[0] + R[3 + c] * go[1] + R[6 + c] * go[2];
+        }
+        if (g_d != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g_d[3 * i + c] = R[c] * gd[0] + R[3 + c] * gd[1] + R[6 + c] * gd[2];
+        }
+    }
+    __shared__ float red[4][12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        float v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const int k = threadIdx.x;
+        red[0][k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) g_Ro[9 * f + threadIdx.x] = red[0][threadIdx.x];
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        g_To[3 * f + c] = -(R[c] * red[0][9] + R[3 + c] * red[0][10] + R[6 + c] * red[0][11]);
+    }
+}
+
+// ---- coarse depths (utils/renderer.py:204-212) ------------------------------------------------
+// near, span = far - near and sample_dist = (far - near)/n are rounded from double on the host,
+// the way Python floats meet float32 tensors in the reference.
+__global__ void k_coarse_z(const float* __restrict__ t_rand, int n_rays, int n, float near, float span,
+                           float sample_dist, float* __restrict__ z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays * n) return;
+    const int b = i / n, k = i % n;
+    // torch.linspace(0, 1, n): step = 1/(n-1); first half start + k*step, second half end - (n-1-k)*step
+    const float step = 1.f / (float)(n - 1);
+    const float lin = (k < n / 2) ? (float)k * step : 1.f - (float)(n - 1 - k) * step;
+    z[i] = (near + span * lin) + (t_rand[b] - 0.5f) * sample_dist;
+}
+
+// ---- sample positions (utils/renderer.py:216 / 119-123) -----------------------------------------
+__global__ void k_sample_points(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z,
+                                int n_rays, int n, int mid, float sample_dist, float* __restrict__ pts,
+                                float* __restrict__ dists) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays * n) return;
+    const int b = i / n, k = i % n;
+    float t = z[i];
+    if (mid) {
+        const float dist = (k + 1 < n) ? z[i + 1] - t : sample_dist;
+        dists[i] = dist;
+        t = t + dist * 0.5f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pts[3 * (size_t)i + c] = o[3 * b + c] + d[3 * b + c] * t;
+}
+
+// ---- up_sample + sample_pdf(det=True) (utils/renderer.py:60-86, 10-37) -------------------------
+constexpr int UPS_MAX_K = 256;
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(64) void k_upsample(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays,
+                                                 int k, int n_new, float inv_s, float* __restrict__ z_new,
+                                                 int64_t* __restrict__ inds_out) {
+    extern __shared__ float lds[];   // cdf[k][64]
+    const int lane = threadIdx.x;
+    const int ray = blockIdx.x * 64 + lane;
+    if (ray >= n_rays) return;
+    const float* zr = z + (size_t)ray * k;
+    const float* sr = sdf + (size_t)ray * k;
+    // pass 1: section weights, sequential transmittance (torch.cumprod order)
+    float prev_cos = 0.f, T = 1.f, sum = 0.f;
+    float z0 = zr[0], s0 = sr[0];
+    for (int i = 0; i + 1 < k; ++i) {
+        const float z1 = zr[i + 1], s1 = sr[i + 1];
+        const float mid_sdf = (s0 + s1) * 0.5f;
+        const float cosv = (s1 - s0) / (z1 - z0 + 1e-5f);
+        float c = fminf(prev_cos, cosv);
+        c = fminf(fmaxf(c, -1e3f), 0.f);
+        prev_cos = cosv;
+        const float dist = z1 - z0;
+        const float prev_cdf = sigmoid_acc((mid_sdf - c * dist * 0.5f) * inv_s);
+        const float next_cdf = sigmoid_acc((mid_sdf + c * dist * 0.5f) * inv_s);
+        const float alpha = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
+        const float w = alpha * T + 1e-5f;           // weights + 1e-5 (sample_pdf)
+        T = T * (1.f - alpha + 1e-7f);
+        lds[(i + 1) * 64 + lane] = w;
+        sum += w;
+        z0 = z1;
+        s0 = s1;
+    }
+    // pass 2: cdf = [0, cumsum(w / sum)]
+    lds[lane] = 0.f;
+    float run = 0.f;
+    for (int i = 1; i < k; ++i) {
+        run += lds[i * 64 + lane] / sum;
+        lds[i * 64 + lane] = run;
+    }
+    // pass 3: invert at u = linspace(0.5/n, 1-0.5/n, n)
+    const float u_start = 0.f + 0.5f / (float)n_new, u_end = 1.f - 0.5f / (float)n_new;
+    const float u_step = (u_end - u_start) / (float)(n_new - 1);
+    int ptr = 0;   // number of cdf entries <= u (searchsorted right=True); cdf and u are both non-decreasing
+    for (int jj = 0; jj < n_new; ++jj) {
+        const float u = (jj < n_new / 2) ? u_start + (float)jj * u_step : u_end - (float)(n_new - 1 - jj) * u_step;
+        while (ptr < k && lds[ptr * 64 + lane] <= u) ++ptr;
+        const int below = ptr - 1 > 0 ? ptr - 1 : 0;
+        const int above = ptr < k - 1 ? ptr : k - 1;
+        const float c_lo = lds[below * 64 + lane], c_hi = lds[above * 64 + lane];
+        const float b_lo = zr[below], b_hi = zr[above];
+        float denom = c_hi - c_lo;
+        denom = denom < 1e-5f ? 1.f : denom;
+        const float t = (u - c_lo) / denom;
+        z_new[(size_t)ray * n_new + jj] = b_lo + t * (b_hi - b_lo);
+        if (inds_out != nullptr) inds_out[(size_t)ray * n_new + jj] = ptr;
+    }
+}
+
+// ---- cat_z_vals (utils/renderer.py:88-105): stable merge of two sorted rows ----------------------
+__global__ void k_merge(const float* __restrict__ z, const float* __restrict__ z_new, const float* __restrict__ sdf,
+                        const float* __restrict__ sdf_new, int n_rays, int k, int m, int quirk_p,
+                        float* __restrict__ z_out, float* __restrict__ sdf_out, int64_t* __restrict__ index) {
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= n_rays) return;
+    const float* a = z + (size_t)ray * k;
+    const float* b = z_new + (size_t)ray * m;
+    // SURVEY B-1: the batched renderer gathers SDF values from frame 0's row of the same pixel
+    const int srow = quirk_p > 0 ? ray % quirk_p : ray;
+    const float* sa = sdf ? sdf + (size_t)srow * k : nullptr;
+    const float* sb = sdf_new ? sdf_new + (size_t)srow * m : nullptr;
+    float* zo = z_out + (size_t)ray * (k + m);
+    int i = 0, jj = 0;
+    for (int o = 0; o < k + m; ++o) {
+        bool take_a;
+        if (i >= k) take_a = false;
+        else if (jj >= m) take_a = true;
+        else take_a = a[i] <= b[jj];          // ties: the old sample first (stable sort of cat([z, z_new]))
+        if (take_a) {
+            zo[o] = a[i];
+            if (sdf_out) sdf_out[(size_t)ray * (k + m) + o] = sa[i];
+            if (index) index[(size_t)ray * (k + m) + o] = i;
+            ++i;
+        } else {
+            zo[o] = b[jj];
+            if (sdf_out) sdf_out[(size_t)ray * (k + m) + o] = sb[jj];
+            if (index) index[(size_t)ray * (k + m) + o] = k + jj;
+            ++jj;
+        }
+    }
+}
+
+// ---- row sort (utils/renderer.py:498): rank sort, one wave per row -------------------------------
+__global__ __launch_bounds__(64) void k_sort_rows(const float* __restrict__ v, int n_rows, int n, float* __restrict__ out) {
+    __shared__ float row[256];
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n; i += 64) row[i] = v[(size_t)r * n + i];
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+        const float x = row[i];
+        int rank = 0;
+        for (int jj = 0; jj < n; ++jj) {
+            const float y = row[jj];
+            rank += (y < x || (y == x && jj < i)) ? 1 : 0;
+        }
+        out[(size_t)r * n + rank] = x;
+    }
+}
+
+// ---- host launchers ----------------------------------------------------------------------------
+static inline dim3 grid1d(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+int ray_gen(const float* xy, const float* R, const float* T, const float* focal, const float* principal, int n_cams,
+            int rays_per_cam, float* rays_o, float* rays_d, hipStream_t s) {
+    HN_REQUIRE(n_cams > 0 && rays_per_cam >= 0, "bad ray_gen sizes");
+    const size_t n = (size_t)n_cams * rays_per_cam;
+    if (n == 0) return HN_OK;
+    hipLaunchKernelGGL(k_ray_gen, grid1d(n, 256), dim3(256), 0, s, xy, R, T, focal, principal, n_cams, rays_per_cam,
+                       rays_o, rays_d);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int obj_local_fwd(const float* o, const float* d, const float* Ro, const float* To, int n_frames, int rpf, float* oo,
+                  float* dd, hipStream_t s) {
+    HN_REQUIRE(n_frames > 0 && rpf >= 0, "bad obj_local sizes");
+    const size_t n = (size_t)n_frames * rpf;
+    if (n == 0) return HN_OK;
+    hipLaunchKernelGGL(k_obj_local_fwd, grid1d(n, 256), dim3(256), 0, s, o, d, Ro, To, (int)n, rpf, oo, dd);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int obj_local_bwd(const float* o, const float* d, const float* Ro, const float* To, const float* go, const float* gd,
+                  int n_frames, int rpf, float* g_o, float* g_d, float* g_Ro, float* g_To, hipStream_t s) {
+    HN_REQUIRE(n_frames > 0 && rpf >= 0, "bad obj_local sizes");
+    hipLaunchKernelGGL(k_obj_local_bwd, dim3(n_frames), dim3(256), 0, s, o, d, Ro, To, go, gd, rpf, g_o, g_d, g_Ro,
+                       g_To);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int coarse_z(const float* t_rand, int n_rays, int n, float near, float span, float sample_dist, float* z,
+             hipStream_t s) {
+    HN_REQUIRE(n >= 2, "n_samples must be >= 2");
+    if (n_rays == 0) return HN_OK;
+    hipLaunchKernelGGL(k_coarse_z, grid1d((size_t)n_rays * n, 256), dim3(256), 0, s, t_rand, n_rays, n, near, span,
+                       sample_dist, z);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int sample_points(const float* o, const float* d, const float* z, int n_rays, int n, int mid, float sample_dist,
+                  float* pts, float* dists, hipStream_t s) {
+    HN_REQUIRE(!mid || dists != nullptr, "dists required for mid-point sampling");
+    if (n_rays == 0 || n == 0) return HN_OK;
+    hipLaunchKernelGGL(k_sample_points, grid1d((size_t)n_rays * n, 256), dim3(256), 0, s, o, d, z, n_rays, n, mid,
+                       sample_dist, pts, dists);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, float inv_s, float* z_new, int64_t* inds,
+             hipStream_t s) {
+    HN_REQUIRE(k >= 2 && k <= UPS_MAX_K && n_new >= 2 && n_new <= 64, "upsample: k=%d n_new=%d out of range", k, n_new);
+    if (n_rays == 0) return HN_OK;
+    hipLaunchKernelGGL(k_upsample, grid1d(n_rays, 64), dim3(64), (size_t)k * 64 * sizeof(float), s, z, sdf, n_rays, k,
+                       n_new, inv_s, z_new, inds);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int merge(const float* z, const float* z_new, const float* sdf, const float* sdf_new, int n_rays, int k, int m,
+          int quirk_p, float* z_out, float* sdf_out, int64_t* index, hipStream_t s) {
+    HN_REQUIRE((sdf_out == nullptr) || (sdf != nullptr && sdf_new != nullptr), "merge: sdf inputs missing");
+    if (n_rays == 0) return HN_OK;
+    hipLaunchKernelGGL(k_merge, grid1d(n_rays, 64), dim3(64), 0, s, z, z_new, sdf, sdf_new, n_rays, k, m, quirk_p, z_out,
+                       sdf_out, index);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int sort_rows(const float* v, int n_rows, int n, float* out, hipStream_t s) {
+    HN_REQUIRE(n >= 1 && n <= 256, "sort_rows: n=%d out of range", n);
+    if (n_rows == 0) return HN_OK;
+    hipLaunchKernelGGL(k_sort_rows, dim3(n_rows), dim3(64), 0, s, v, n_rows, n, out);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+}  // namespace hn

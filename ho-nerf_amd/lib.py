@@ -1,0 +1,114 @@
+"""ctypes binding of libhonerf.so (include/honerf.h).
+
+The library is built in-tree by ``make -C ho-nerf_amd/csrc`` (or
+``__graft_entry__.build()``).  There is NO fallback: if the shared object is
+missing or a call fails, a RuntimeError is raised -- the product path never
+routes through a CPU or eager-PyTorch substitute.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhonerf.so')
+
+HN_FIELD_OBJ = 0
+HN_FIELD_HAND = 1
+HN_PREC_FP32 = 0
+HN_MAX_LAYERS = 9
+
+c_f = ctypes.c_void_p     # device float*
+c_i = ctypes.c_int
+c_sz = ctypes.c_size_t
+c_fl = ctypes.c_float
+c_db = ctypes.c_double
+c_vp = ctypes.c_void_p
+
+
+class MlpDesc(ctypes.Structure):
+    _fields_ = [
+        ('n_layers', c_i),
+        ('out_dim', c_i * HN_MAX_LAYERS),
+        ('in_dim', c_i * HN_MAX_LAYERS),
+        ('weight_g', c_vp * HN_MAX_LAYERS),
+        ('weight_v', c_vp * HN_MAX_LAYERS),
+        ('bias', c_vp * HN_MAX_LAYERS),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/honerf.h one to one
+SIGNATURES = {
+    'hn_version': (c_i, []),
+    'hn_last_error': (ctypes.c_char_p, []),
+    'hn_device_cus': (c_i, []),
+    'hn_field_create': (c_i, [c_i, ctypes.POINTER(MlpDesc), ctypes.POINTER(MlpDesc), c_fl, c_fl, c_i,
+                              ctypes.POINTER(c_vp), c_vp]),
+    'hn_field_destroy': (c_i, [c_vp]),
+    'hn_field_inv_s': (c_fl, [c_vp]),
+    'hn_ray_gen': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
+    'hn_obj_local_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
+    'hn_obj_local_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_vp]),
+    'hn_coarse_z': (c_i, [c_f, c_i, c_i, c_db, c_db, c_f, c_vp]),
+    'hn_sample_points': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_f, c_f, c_vp]),
+    'hn_upsample': (c_i, [c_f, c_f, c_i, c_i, c_i, c_fl, c_f, c_vp, c_vp]),
+    'hn_merge': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_vp, c_vp]),
+    'hn_sort_rows': (c_i, [c_f, c_i, c_i, c_f, c_vp]),
+    'hn_field_workspace_bytes': (c_sz, [c_vp, c_i]),
+    'hn_field_sdf': (c_i, [c_vp, c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_vp, c_sz, c_vp]),
+    'hn_field_eval': (c_i, [c_vp, c_f, c_f, c_i, c_i, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
+    'hn_alpha': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_vp]),
+    'hn_composite1': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp]),
+    'hn_composite2': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp]),
+    'hn_render_single_workspace_bytes': (c_sz, [c_vp, c_i, c_i, c_i]),
+    'hn_render_single': (c_i, [c_vp, c_f, c_f, c_f, c_i, c_db, c_db, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f,
+                               c_f, c_f, c_vp, c_sz, c_vp]),
+    'hn_render_dual_workspace_bytes': (c_sz, [c_vp, c_vp, c_i, c_i, c_i]),
+    'hn_render_dual': (c_i, [c_vp, c_vp, c_f, c_f, c_f, c_i, c_i, c_db, c_db, c_i, c_i, c_i, c_f, c_f, c_f, c_f,
+                             c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libhonerf.so (once) and set every prototype.  Raises RuntimeError if
+    the library has not been built -- there is no substitute path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libhonerf.so not found at %s: build it with `make -C %s` '
+                           '(hipcc --offload-arch=gfx950); there is no CPU fallback'
+                           % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().hn_last_error()
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), 'honerf expects contiguous device tensors'
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32(t, device=None):
+    """Contiguous fp32 device tensor view/copy of t."""
+    t = t if isinstance(t, torch.Tensor) else torch.as_tensor(t)
+    return t.detach().to(device=device or 'cuda', dtype=torch.float32).contiguous()

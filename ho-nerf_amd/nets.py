@@ -1,0 +1,270 @@
+"""Parameter containers with the reference's constructor signatures and
+state-dict layout, and the packed device-side field they feed.
+
+The classes mirror utils/fields.py (Embedding :8-20, SDFNetwork :56-177,
+RenderingNetwork :179-240, SingleVarianceNetwork :243-249, SDFNetwork_OBJ
+:251-347, RenderingNetwork_OBJ :349-405): same constructor arguments, same
+parameter names (``lin{l}.weight_g``, ``lin{l}.weight_v``, ``lin{l}.bias``,
+``se3_refine``, ``variance``), so a reference checkpoint loads with
+``load_state_dict`` unchanged.  They hold parameters only: every evaluation
+goes through the HIP library (PackedField); there is no PyTorch forward.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import lib as _lib
+from . import synth
+
+
+class Embedding(nn.Module):
+    """Placeholder for the reference's `barf_encoding` argument (utils/fields.py:8-20).
+    The encoding itself is evaluated inside the field kernels."""
+
+    def __init__(self):
+        super().__init__()
+
+
+class _WNLinear(nn.Module):
+    """Parameters of one weight-normalised nn.Linear (old-style nn.utils.weight_norm)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight_g = nn.Parameter(torch.ones(cout, 1))
+        self.weight_v = nn.Parameter(torch.zeros(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class _MLPParams(nn.Module):
+    kind = None
+
+    def _build(self, d_hidden, seed_kind):
+        shapes = synth.layer_shapes(self.kind, d_hidden)
+        self.num_layers = len(shapes) + 1
+        for l, (out, cin) in enumerate(shapes):
+            setattr(self, 'lin%d' % l, _WNLinear(cin, out))
+        self.reset_parameters(0)
+
+    def reset_parameters(self, seed=0):
+        """Random init with the statistics of the reference constructors (geometric
+        init for the SDF nets), drawn from honerf_amd.synth so that it is reproducible."""
+        sd = synth.synth_state_dict(self.kind, seed)
+        with torch.no_grad():
+            for k, v in sd.items():
+                mod, name = k.split('.')
+                getattr(getattr(self, mod), name).copy_(torch.from_numpy(v))
+
+    def layers(self):
+        return [getattr(self, 'lin%d' % l) for l in range(self.num_layers - 1)]
+
+
+class SDFNetwork_OBJ(_MLPParams):
+    """utils/fields.py:251-347."""
+    kind = 'sdf_obj'
+
+    def __init__(self, barf_encoding=None, traindata_num=1, data_type='real', d_in=3, d_out=257, d_hidden=256,
+                 n_layers=8, skip_in=(4,), v_multires=10, r_multires=4, bias=0.5, scale=1, geometric_init=True,
+                 weight_norm=True, inside_outside=False):
+        super().__init__()
+        _require(d_in == 3 and d_out == 257 and d_hidden == 256 and n_layers == 8 and tuple(skip_in) == (4,)
+                 and v_multires == 10 and weight_norm, 'SDFNetwork_OBJ: only the published conf shape is supported')
+        self.scale = scale
+        self._build(d_hidden, 'sdf_obj')
+        se3 = torch.zeros((traindata_num, 6 + 3))
+        se3[:, 0] = 1
+        se3[:, 3] = 1
+        self.se3_refine = nn.Parameter(se3)
+
+
+class SDFNetwork(_MLPParams):
+    """utils/fields.py:56-177 (hand)."""
+    kind = 'sdf_hand'
+
+    def __init__(self, barf_encoding=None, traindata_num=1, data_type='real', d_in=3, d_out=257, d_hidden=256,
+                 n_layers=8, skip_in=(4,), v_multires=10, r_multires=7, bias=0.5, scale=1, geometric_init=True,
+                 weight_norm=True, inside_outside=False, use_batch=False):
+        super().__init__()
+        _require(d_in == 3 and d_out == 257 and d_hidden == 256 and n_layers == 8 and tuple(skip_in) == (4,)
+                 and v_multires == 10 and r_multires == 7 and weight_norm,
+                 'SDFNetwork: only the published conf shape is supported')
+        self.scale = scale
+        self.use_batch = use_batch
+        self._build(d_hidden, 'sdf_hand')
+        se3 = torch.zeros((traindata_num, 6 + 3 + 20 + 7))
+        se3[:, 0] = 1
+        se3[:, 3] = 1
+        self.se3_refine = nn.Parameter(se3)
+
+
+class RenderingNetwork_OBJ(_MLPParams):
+    """utils/fields.py:349-405."""
+    kind = 'color_obj'
+
+    def __init__(self, barf_encoding=None, data_type='real', d_feature=256, d_in=3, d_out=3, d_hidden=256, n_layers=4,
+                 weight_norm=True, v_multires=10, r_multires=4, grad_multires=4, squeeze_out=True,
+                 use_gradients=False):
+        super().__init__()
+        _require(d_feature == 256 and d_in == 3 and d_out == 3 and d_hidden == 256 and n_layers == 4 and weight_norm
+                 and v_multires == 10 and r_multires == 4 and grad_multires == 4 and squeeze_out,
+                 'RenderingNetwork_OBJ: only the published conf shape is supported')
+        self._build(d_hidden, 'color_obj')
+
+
+class RenderingNetwork(_MLPParams):
+    """utils/fields.py:179-240 (hand)."""
+    kind = 'color_hand'
+
+    def __init__(self, barf_encoding=None, data_type='real', d_feature=256, d_in=3, d_out=3, d_hidden=256, n_layers=4,
+                 weight_norm=True, v_multires=10, r_multires=7, grad_multires=4, squeeze_out=True,
+                 use_gradients=False):
+        super().__init__()
+        _require(d_feature == 256 and d_in == 3 and d_out == 3 and d_hidden == 256 and n_layers == 4 and weight_norm
+                 and v_multires == 10 and r_multires == 7 and grad_multires == 4 and squeeze_out and use_gradients,
+                 'RenderingNetwork: only the published conf shape (use_gradients=True) is supported')
+        self._build(d_hidden, 'color_hand')
+
+
+class SingleVarianceNetwork(nn.Module):
+    """utils/fields.py:243-249."""
+
+    def __init__(self, init_val):
+        super().__init__()
+        self.register_parameter('variance', nn.Parameter(torch.tensor(float(init_val))))
+
+
+def _require(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+def _state_of(module_or_sd):
+    if isinstance(module_or_sd, dict):
+        return module_or_sd
+    return module_or_sd.state_dict()
+
+
+def _mlp_desc(sd, keep):
+    """hn_mlp_desc from a state dict (tensors or numpy); `keep` collects the device
+    tensors so they outlive the call."""
+    d = _lib.MlpDesc()
+    l = 0
+    while ('lin%d.bias' % l) in sd:
+        b = _lib.f32(sd['lin%d.bias' % l])
+        if ('lin%d.weight_v' % l) in sd:
+            v = _lib.f32(sd['lin%d.weight_v' % l])
+            g = _lib.f32(sd['lin%d.weight_g' % l])
+            d.weight_g[l] = g.data_ptr()
+            keep.append(g)
+        else:                                   # a plain nn.Linear checkpoint
+            v = _lib.f32(sd['lin%d.weight' % l])
+            d.weight_g[l] = None
+        keep += [v, b]
+        d.weight_v[l] = v.data_ptr()
+        d.bias[l] = b.data_ptr()
+        d.out_dim[l], d.in_dim[l] = v.shape
+        l += 1
+    d.n_layers = l
+    return d
+
+
+class PackedField:
+    """Device-resident, immutable packed weights of one field (hn_field).
+
+    kind 'obj' | 'hand'; `sdf`, `color` are modules (ours or the reference's) or
+    state dicts in the reference layout; `variance` a SingleVarianceNetwork, a
+    tensor or a float."""
+
+    def __init__(self, kind, sdf, color, variance, scale=None):
+        self.lib = _lib.load()
+        self.kind = kind
+        sdf_sd, col_sd = _state_of(sdf), _state_of(color)
+        if isinstance(variance, nn.Module):
+            variance = variance.variance
+        var = float(variance.detach().cpu()) if isinstance(variance, torch.Tensor) else float(variance)
+        if scale is None:
+            scale = float(getattr(sdf, 'scale', 1.0)) if not isinstance(sdf, dict) else 1.0
+        keep = []
+        d_sdf, d_col = _mlp_desc(sdf_sd, keep), _mlp_desc(col_sd, keep)
+        handle = ctypes.c_void_p()
+        torch.cuda.synchronize()
+        rc = self.lib.hn_field_create(_lib.HN_FIELD_OBJ if kind == 'obj' else _lib.HN_FIELD_HAND,
+                                      ctypes.byref(d_sdf), ctypes.byref(d_col), var, float(scale), _lib.HN_PREC_FP32,
+                                      ctypes.byref(handle), _lib.stream_ptr())
+        _lib.check(rc, 'hn_field_create')
+        del keep
+        self.handle = handle
+        self.variance = var
+        self.inv_s = float(self.lib.hn_field_inv_s(handle))
+
+    def __del__(self):
+        h = getattr(self, 'handle', None)
+        if h is not None and h.value:
+            try:
+                torch.cuda.synchronize()
+                self.lib.hn_field_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+    # ---- direct field queries (utils/fields.py .sdf / forward+gradient+colour) ----------
+    def _frames(self, pts, bt_inv, T_pose):
+        n = pts.shape[0]
+        if self.kind == 'obj':
+            return None, None, 1, max(n, 1)
+        bt = _lib.f32(bt_inv).reshape(-1, 21, 4, 4)
+        tp = _lib.f32(T_pose).reshape(-1, 21, 3)
+        nf = bt.shape[0]
+        if tp.shape[0] != nf:
+            tp = tp.expand(nf, 21, 3).contiguous()
+        assert n % nf == 0, 'points must split evenly over frames'
+        return bt, tp, nf, max(n // nf, 1)
+
+    def sdf(self, pts, bt_inv=None, T_pose=None):
+        """[..,3] -> [M,1] (utils/fields.py:158-160, 330-331)."""
+        pts = _lib.f32(pts).reshape(-1, 3)
+        n = pts.shape[0]
+        bt, tp, nf, ppf = self._frames(pts, bt_inv, T_pose)
+        out = torch.empty(n, device=pts.device, dtype=torch.float32)
+        ws_bytes = self.lib.hn_field_workspace_bytes(self.handle, n)
+        ws = torch.empty(max(ws_bytes, 16), device=pts.device, dtype=torch.uint8)
+        rc = self.lib.hn_field_sdf(self.handle, _lib.ptr(pts), n, _lib.ptr(bt), _lib.ptr(tp), nf, ppf, _lib.ptr(out),
+                                   _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+        _lib.check(rc, 'hn_field_sdf')
+        return out.reshape(n, 1)
+
+    def evaluate(self, pts, rays_d, samples_per_ray, bt_inv=None, T_pose=None, want_feat=False):
+        """pts [n,3], rays_d [n/samples_per_ray,3] -> sdf [n,1], grad [n,3], rgb [n,3] (, feat [n,256])."""
+        pts = _lib.f32(pts).reshape(-1, 3)
+        rays_d = _lib.f32(rays_d).reshape(-1, 3)
+        n = pts.shape[0]
+        bt, tp, nf, ppf = self._frames(pts, bt_inv, T_pose)
+        dev = pts.device
+        sdf = torch.empty(n, device=dev)
+        grad = torch.empty(n, 3, device=dev)
+        rgb = torch.empty(n, 3, device=dev)
+        feat = torch.empty(n, 256, device=dev) if want_feat else None
+        ws_bytes = self.lib.hn_field_workspace_bytes(self.handle, n)
+        ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
+        rc = self.lib.hn_field_eval(self.handle, _lib.ptr(pts), _lib.ptr(rays_d), n, int(samples_per_ray),
+                                    _lib.ptr(bt), _lib.ptr(tp), nf, ppf, _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb),
+                                    _lib.ptr(feat), _lib.ptr(ws), ws_bytes, _lib.stream_ptr())
+        _lib.check(rc, 'hn_field_eval')
+        out = (sdf.reshape(n, 1), grad, rgb)
+        return out + (feat,) if want_feat else out
+
+
+def params_version(*modules):
+    """A cheap fingerprint of the parameters' in-place versions: the adapters
+    re-pack when a checkpoint is loaded after construction."""
+    v = []
+    for m in modules:
+        if isinstance(m, nn.Module):
+            v += [(id(p), p._version) for p in m.parameters()]
+        elif isinstance(m, dict):
+            v.append(id(m))
+        else:
+            v.append(repr(m))
+    return tuple(v)

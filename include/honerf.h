@@ -1,0 +1,203 @@
+/* honerf.h -- C ABI of the MI355X-native HO-NeRF volume-rendering core.
+ *
+ * The reference (iscas3dv/HO-NeRF) is pure Python and has no FFI layer; its
+ * boundary for this path is the Python object surface of utils/renderer.py,
+ * utils/renderer_batch.py and utils/fields.py.  Every entry point below names
+ * the reference function it replaces (paths relative to the reference
+ * checkout); ho-nerf_amd/lib.py binds them with ctypes and
+ * ho-nerf_amd/renderer*.py re-exposes the reference's classes on top.
+ *
+ * Conventions
+ *   - every function returns HN_OK (0) or a negative HN_E* code; the message
+ *     is available from hn_last_error() (thread-local);
+ *   - all tensor arguments are DEVICE pointers to contiguous fp32 (indices:
+ *     int64, to match torch) unless a parameter is documented as host;
+ *   - the last argument is the hipStream_t to launch on (as void*); no entry
+ *     point synchronises, allocates or frees device memory except
+ *     hn_field_create / hn_field_destroy / hn_workspace_*;
+ *   - outputs and workspaces are caller-owned; sizes come from the
+ *     *_workspace_bytes queries.
+ */
+#ifndef HONERF_H
+#define HONERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HN_VERSION 100 /* 0.1.0 */
+
+#define HN_OK 0
+#define HN_EINVAL (-1)   /* bad argument / unsupported shape */
+#define HN_EHIP (-2)     /* a HIP runtime call failed */
+#define HN_ENOMEM (-3)   /* workspace too small / allocation failed */
+
+#define HN_FIELD_OBJ 0  /* SDFNetwork_OBJ + RenderingNetwork_OBJ (utils/fields.py:251-405) */
+#define HN_FIELD_HAND 1 /* SDFNetwork + RenderingNetwork (utils/fields.py:56-240) */
+
+#define HN_PREC_FP32 0   /* exact fp32: v_mfma_f32_32x32x2_f32 == fmaf chains */
+
+#define HN_MAX_LAYERS 9
+#define HN_N_BONES 21
+
+typedef void* hn_stream_t;         /* hipStream_t */
+typedef struct hn_field hn_field;  /* opaque: packed, immutable weights of one field */
+
+/* One MLP in the reference's state-dict layout (old-style weight-norm,
+ * utils/fields.py:120-121): W[i,:] = weight_g[i] * weight_v[i,:] / ||weight_v[i,:]||.
+ * weight_g[l] may be NULL: then weight_v[l] is the effective weight.
+ * Pointers are DEVICE pointers. */
+typedef struct {
+    int n_layers;
+    int out_dim[HN_MAX_LAYERS];
+    int in_dim[HN_MAX_LAYERS];
+    const float* weight_g[HN_MAX_LAYERS];
+    const float* weight_v[HN_MAX_LAYERS];
+    const float* bias[HN_MAX_LAYERS];
+} hn_mlp_desc;
+
+int hn_version(void);
+const char* hn_last_error(void);
+
+/* Number of compute units of the current device (0 if no device). */
+int hn_device_cus(void);
+
+/* ---- weights --------------------------------------------------------------------------
+ * Folds weight-norm and re-lays every matrix in MFMA fragment order (once; the
+ * networks are frozen on every path this library serves).  `variance` is
+ * SingleVarianceNetwork.variance (utils/fields.py:243-249); `scale` is
+ * SDFNetwork_OBJ.scale (:328).  Synchronises the stream before returning. */
+int hn_field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* color, float variance, float scale,
+                    int precision, hn_field** out, hn_stream_t stream);
+int hn_field_destroy(hn_field* f);
+/* clip(exp(10 * variance), 1e-6, 1e6): utils/renderer.py:144. */
+float hn_field_inv_s(const hn_field* f);
+
+/* ---- rays -----------------------------------------------------------------------------
+ * _xy_to_ray_bundle (utils/utils.py:31-115): NDC xy -> unproject at depth 1 and
+ * 2 -> d = normalize(p2-p1), o = p1 - d.  n_cams cameras, rays_per_cam rays each:
+ * xy [n_cams*rays_per_cam, 2]; R [n_cams,3,3]; T [n_cams,3]; focal, principal
+ * [n_cams,2] (PyTorch3D row-vector convention X_view = X_world R + T). */
+int hn_ray_gen(const float* xy, const float* R, const float* T, const float* focal, const float* principal,
+               int n_cams, int rays_per_cam, float* rays_o, float* rays_d, hn_stream_t stream);
+
+/* convert_obj_to_local (utils/renderer.py:180-188, 424-432; renderer_batch.py:176-182):
+ * o' = Ro (o - To), d' = Ro d.  n_frames poses, rays_per_frame rays each. */
+int hn_obj_local_fwd(const float* rays_o, const float* rays_d, const float* Ro, const float* To, int n_frames,
+                     int rays_per_frame, float* o_out, float* d_out, hn_stream_t stream);
+/* Adjoint: given dL/do', dL/dd' -> dL/do, dL/dd [n,3] (may be NULL), dL/dRo [n_frames,3,3],
+ * dL/dTo [n_frames,3] (both overwritten). */
+int hn_obj_local_bwd(const float* rays_o, const float* rays_d, const float* Ro, const float* To, const float* g_o_out,
+                     const float* g_d_out, int n_frames, int rays_per_frame, float* g_rays_o, float* g_rays_d,
+                     float* g_Ro, float* g_To, hn_stream_t stream);
+
+/* Coarse depths (utils/renderer.py:204-212): z[b,k] = near + (far-near) k/(n-1) +
+ * (t_rand[b] - 0.5) (far-near)/n.  t_rand [B] in [0,1) comes from the caller's RNG.  near / far
+ * are doubles (Python floats in the reference) and are rounded to fp32 where torch would. */
+int hn_coarse_z(const float* t_rand, int n_rays, int n_samples, double near, double far, float* z,
+                hn_stream_t stream);
+
+/* Sample positions.  mid == 0: p = o + d z (utils/renderer.py:216).  mid == 1:
+ * section mid-points p = o + d (z + dist/2), dist[k] = z[k+1]-z[k], last = sample_dist
+ * (utils/renderer.py:119-123); `dists` [n_rays*n] is then written too (else may be NULL). */
+int hn_sample_points(const float* rays_o, const float* rays_d, const float* z, int n_rays, int n, int mid,
+                     float sample_dist, float* pts, float* dists, hn_stream_t stream);
+
+/* ---- hierarchical sampling ------------------------------------------------------------
+ * NeuSRenderer.up_sample + sample_pdf(det=True) (utils/renderer.py:60-86, 10-37).
+ * z, sdf [n_rays,k] -> z_new [n_rays,n_new]; inds (int64 [n_rays,n_new], may be
+ * NULL) is the searchsorted(right=True) result. k <= 256, n_new <= 64. */
+int hn_upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, float inv_s, float* z_new,
+                int64_t* inds, hn_stream_t stream);
+
+/* cat_z_vals (utils/renderer.py:88-105): stable merge of sorted z [n_rays,k] with
+ * sorted z_new [n_rays,m]; carries sdf / sdf_new when non-NULL; `index` (int64
+ * [n_rays,k+m], may be NULL) is torch.sort's index into cat([z, z_new]).
+ * sdf_row_stride_frames > 0 reproduces the batched renderer's quirk
+ * (utils/renderer_batch.py:108-111, SURVEY B-1): with rays laid out
+ * [frames, P], ray (f,p) gathers its SDF values from ray (0,p); pass P, or 0 for
+ * the regular behaviour. */
+int hn_merge(const float* z, const float* z_new, const float* sdf, const float* sdf_new, int n_rays, int k, int m,
+             int quirk_rays_per_frame, float* z_out, float* sdf_out, int64_t* index, hn_stream_t stream);
+
+/* Row-wise ascending sort of v [n_rays,n] (n <= 256) -- the final torch.sort over
+ * the concatenated depths of the two-field renderer (utils/renderer.py:498). */
+int hn_sort_rows(const float* v, int n_rays, int n, float* out, hn_stream_t stream);
+
+/* ---- fields ---------------------------------------------------------------------------
+ * Hand fields take per-frame bone transforms: bt_inv [n_frames,21,4,4], T_pose
+ * [n_frames,21,3]; point i belongs to frame i / pts_per_frame (one frame: pass
+ * n_frames = 1, pts_per_frame = n_pts).  Obj fields ignore them (pass NULL). */
+size_t hn_field_workspace_bytes(const hn_field* f, int n_pts);
+
+/* .sdf() (utils/fields.py:158-160, 330-331): pts [n,3] -> sdf [n]. */
+int hn_field_sdf(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose,
+                 int n_frames, int pts_per_frame, float* sdf, void* workspace, size_t workspace_bytes,
+                 hn_stream_t stream);
+
+/* The three module calls of render_core / get_alpha_sample_color
+ * (utils/renderer.py:130-142, 380-396): sdf network forward, its input
+ * gradient (analytic, replaces autograd.grad of utils/fields.py:165-177, 336-347)
+ * and the colour network.  pts [n,3]; dirs are per ray: rays_d [n/samples_per_ray,3].
+ * -> sdf [n], grad [n,3], rgb [n,3]; feat (may be NULL) receives the 256-d
+ * feature vector [n,256]. */
+int hn_field_eval(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray,
+                  const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame, float* sdf,
+                  float* grad, float* rgb, float* feat, void* workspace, size_t workspace_bytes,
+                  hn_stream_t stream);
+
+/* ---- SDF -> alpha, compositing --------------------------------------------------------
+ * utils/renderer.py:147-161 (cos_anneal_ratio = 1): alpha [n] (clipped to [0,1]) and
+ * c = sigmoid(prev_sdf * inv_s) [n] from sdf, grad, per-ray dirs and dists. */
+int hn_alpha(const float* sdf, const float* grad, const float* rays_d, const float* dists, int n_pts,
+             int samples_per_ray, float inv_s, float* alpha, float* c, hn_stream_t stream);
+
+/* Single-field compositing (utils/renderer.py:163-169, 246-258): transmittance is
+ * seeded with c[.,0] (not 1).  alpha, c [B,S]; rgb, grad [B,S,3] ->
+ * color [B,3], weights [B,S] (may be NULL), weight_sum [B], weight_max [B],
+ * eik_sum [1] += sum over samples of (||grad||-1)^2 (caller zeroes it, divides by B*S). */
+int hn_composite1(const float* alpha, const float* c, const float* rgb, const float* grad, int n_rays, int S,
+                  float* color, float* weights, float* weight_sum, float* weight_max, float* eik_sum,
+                  hn_stream_t stream);
+
+/* Two-field compositing (utils/renderer.py:512-524): T_k = prod_{j<k} (1-a_h+1e-7)(1-a_o+1e-7).
+ * -> color [B,3], weight_sum [B], w_hand / w_obj [B,S] (may be NULL), eik_sum [2]
+ * (hand, obj; accumulated, caller zeroes). */
+int hn_composite2(const float* alpha_h, const float* rgb_h, const float* grad_h, const float* alpha_o,
+                  const float* rgb_o, const float* grad_o, int n_rays, int S, float* color, float* weight_sum,
+                  float* w_hand, float* w_obj, float* eik_sum, hn_stream_t stream);
+
+/* ---- whole renders ----------------------------------------------------------------------
+ * NeuSRenderer.render (utils/renderer.py:190-258).  rays already in the field's frame
+ * (obj: after hn_obj_local_fwd).  t_rand [B].  Outputs: color [B,3], cdf [B,S],
+ * weight_sum [B], weight_max [B], gradient_error [1], z_vals [B,S] (may be NULL);
+ * S = n_samples + n_importance.  s_val is 1/inv_s (host side). */
+size_t hn_render_single_workspace_bytes(const hn_field* f, int n_rays, int n_samples, int n_importance);
+int hn_render_single(const hn_field* f, const float* rays_o, const float* rays_d, const float* t_rand, int n_rays,
+                     double near, double far, int n_samples, int n_importance, int up_sample_steps,
+                     const float* bt_inv, const float* T_pose, float* color, float* cdf, float* weight_sum,
+                     float* weight_max, float* gradient_error, float* z_vals, void* workspace,
+                     size_t workspace_bytes, hn_stream_t stream);
+
+/* NeuSRenderer_fitting.render (utils/renderer.py:434-535; frame-batched:
+ * utils/renderer_batch.py:184-281).  World rays [n_frames*P,3]; Ro, To [n_frames,..];
+ * bt_inv [n_frames,21,4,4]; T_pose [n_frames,21,3].  S = n_samples + 2 n_importance.
+ * Outputs: color [N,3], weight_sum [N], sdf_hand, sdf_obj [N*S], grad_hand,
+ * grad_obj [N*S,3], gradient_error [2] (hand, obj), z_vals [N,S] (may be NULL).
+ * batch_quirk != 0 reproduces SURVEY B-1 (only meaningful for n_frames > 1). */
+size_t hn_render_dual_workspace_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples,
+                                      int n_importance);
+int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_o, const float* rays_d,
+                   const float* t_rand, int n_frames, int rays_per_frame, double near, double far, int n_samples,
+                   int n_importance, int up_sample_steps, const float* bt_inv, const float* T_pose, const float* Ro,
+                   const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand,
+                   float* sdf_obj, float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals,
+                   void* workspace, size_t workspace_bytes, hn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HONERF_H */
