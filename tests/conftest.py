@@ -20,3 +20,10 @@ def golden():
     def load(name):
         return dict(np.load(os.path.join(GOLDEN, name + '.npz')))
     return load
+
+
+@pytest.fixture(autouse=True)
+def _release_device_temporaries():
+    yield
+    import helpers
+    helpers._KEEP.clear()

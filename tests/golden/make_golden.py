@@ -99,6 +99,41 @@ class Recorder:
         torch.searchsorted, torch.sort = self._ss, self._sort
 
 
+class Capture:
+    """Wraps a bound method of a reference renderer and records (args, result) of each call,
+    e.g. the final depths handed to render_core / get_alpha_sample_color."""
+
+    def __init__(self, obj, name):
+        self.calls = []
+        fn = getattr(obj, name)
+
+        def wrapped(*a, **k):
+            out = fn(*a, **k)
+            self.calls.append((a, out))
+            return out
+
+        setattr(obj, name, wrapped)
+
+
+def per_sample_single(ren, nets, kind, o, d, z_vals, sample_dist, bt_inv=None, T_pose=None):
+    """The reference's own networks on the mid-points of the reference's final depths:
+    per-sample sdf / gradient / colour goldens of render_core (utils/renderer.py:119-142)."""
+    dists = torch.cat([z_vals[..., 1:] - z_vals[..., :-1],
+                       torch.Tensor([sample_dist]).expand(z_vals[..., :1].shape)], -1)
+    mid = z_vals + dists * 0.5
+    pts = (o[:, None, :] + d[:, None, :] * mid[..., :, None]).reshape(-1, 3)
+    dirs = d[:, None, :].expand(z_vals.shape[0], z_vals.shape[1], 3).reshape(-1, 3)
+    if kind == 'obj':
+        out = nets['sdf_obj'](pts)
+        grad = nets['sdf_obj'].gradient(pts).squeeze()
+        rgb = nets['color_obj'](pts, dirs, out[:, 1:], grad, 0)
+    else:
+        out, feat, r_, h_ = nets['sdf_hand'](pts, bt_inv, T_pose)
+        grad = nets['sdf_hand'].gradient(pts, bt_inv, T_pose).squeeze()
+        rgb = nets['color_hand'](dirs, feat, out[:, 1:], h_, grad, 0)
+    return dict(ps_sdf=out[:, :1], ps_grad=grad, ps_rgb=rgb.reshape(-1, 3))
+
+
 def np_(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
@@ -210,10 +245,14 @@ def main():
         torch.manual_seed(5)
         t_rand = torch.rand([40, 1])
         torch.manual_seed(5)
+        cap = Capture(ren, 'render_core')
         with Recorder() as rec:
             res = ren.render(o, d, 0.4, 1.5, torch.zeros(21, 4, 4), torch.zeros(21, 3), None, Ro, To, 0)
         extra = {('inds%d' % i): t for i, t in enumerate(rec.inds)}
         extra.update({('index%d' % i): t for i, t in enumerate(rec.index)})
+        (a, core), = cap.calls
+        extra.update(z_vals=a[5], weights=core['weights'])
+        extra.update(per_sample_single(ren, nets, 'obj', a[0], a[1], a[5], a[6]))
         save('render_' + tag, rays_o=o, rays_d=d, Ro=Ro, To=To, t_rand=t_rand, near=0.4, far=1.5,
              n_samples=nsamp, n_importance=nimp, **{k: v for k, v in res.items()}, **extra)
 
@@ -223,10 +262,14 @@ def main():
         torch.manual_seed(6)
         t_rand = torch.rand([32, 1])
         torch.manual_seed(6)
+        cap = Capture(ren, 'render_core')
         with Recorder() as rec:
             res = ren.render(o, d, 0.4, 1.5, bt_inv, T_pose, None, None, None, 0)
         extra = {('inds%d' % i): t for i, t in enumerate(rec.inds)}
         extra.update({('index%d' % i): t for i, t in enumerate(rec.index)})
+        (a, core), = cap.calls
+        extra.update(z_vals=a[5], weights=core['weights'])
+        extra.update(per_sample_single(ren, nets, 'hand', a[0], a[1], a[5], a[6], bt_inv, T_pose))
         save('render_' + tag, rays_o=o, rays_d=d, bt_inv=bt_inv, T_pose=T_pose, t_rand=t_rand, near=0.4,
              far=1.5, n_samples=64, n_importance=nimp, **{k: v for k, v in res.items()}, **extra)
 
@@ -243,8 +286,11 @@ def main():
     torch.manual_seed(8)
     t_rand = torch.rand([24, 1])
     torch.manual_seed(8)
+    cap = Capture(ren, 'get_alpha_sample_color')
     with Recorder() as rec:
         res = ren.render(ro, rd, 0.4, 1.5, bt, T_pose, None, Ro, To)
+    (a_h, out_h), (a_o, out_o) = cap.calls
+    dual_extra = dict(z_vals=a_h[4], alpha_hand=out_h[0], rgb_hand=out_h[1], alpha_obj=out_o[0], rgb_obj=out_o[1])
     gw = {
         'w_color': torch.randn(24, 3, generator=g), 'w_wsum': torch.randn(24, 1, generator=g),
         'w_sdf_hand': torch.randn(24 * 192, 1, generator=g) * 0.05,
@@ -256,7 +302,7 @@ def main():
     save('render_dual', rays_o=o, rays_d=d, bt_inv=bt_inv, T_pose=T_pose, Ro=Ro, To=To, t_rand=t_rand,
          near=0.4, far=1.5, n_samples=64, n_importance=64, **{k: v for k, v in res.items()}, **gw,
          loss=loss, g_Ro=grads[0], g_To=grads[1], g_bt_inv=grads[2], g_rays_o=grads[3], g_rays_d=grads[4],
-         inds=torch.stack(rec.inds))
+         inds=torch.stack(rec.inds), **dual_extra)
 
     # ---- batched two-field render (utils/renderer_batch.py), incl. its SDF-row quirk ----
     emb_b, nets_b = build_nets(use_batch=True)
@@ -273,7 +319,10 @@ def main():
     torch.manual_seed(9)
     t_rand = torch.rand([Fr, P, 1])
     torch.manual_seed(9)
+    cap = Capture(ren, 'get_alpha_sample_color')
     res = ren.render(o, d, 0.4, 1.5, bt, Tp, None, Ro, To)
+    (a_h, out_h), (a_o, out_o) = cap.calls
+    res = dict(res, z_vals=a_h[4], alpha_hand=out_h[0], rgb_hand=out_h[1], alpha_obj=out_o[0], rgb_obj=out_o[1])
     save('render_dual_batch', rays_o=o, rays_d=d, bt_inv=bt, T_pose=Tp, Ro=Ro, To=To, t_rand=t_rand,
          near=0.4, far=1.5, n_samples=64, n_importance=64, **{k: v for k, v in res.items()})
 

@@ -39,6 +39,40 @@ def assert_close(a, b, rtol, what=''):
     assert e <= rtol, '%s: rel err %.3e > %.1e' % (what, e, rtol)
 
 
+def oracle_fields_fp64():
+    """The same oracle networks evaluated in float64: the 'exact' value both fp32 paths
+    approximate.  Used only to measure how far the fp32 REFERENCE itself is from the exact
+    value at ill-conditioned points (hand gradient near a joint: |grad| ~ 10, 1/v and
+    tau*h*(1-h) amplification), see assert_parity."""
+    hand, obj = oracle_fields()
+    for f in (hand, obj):
+        f.sdf = [(W.double(), b.double()) for W, b in f.sdf]
+        f.color = [(W.double(), b.double()) for W, b in f.color]
+        f.variance = f.variance.double()
+    return hand, obj
+
+
+def assert_parity(hip, ref32, exact64, what, rtol=1e-4, cap=1e-3):
+    """North-star bound: |hip - ref32| <= 1e-4 max|ref32|.  Where the fp32 reference is itself
+    further than that from the exact (fp64) value -- measured, not assumed -- the HIP result
+    must be at least as close to the exact value as the reference is (x1.5 + 1e-5 slack for
+    the different summation order), and never further than `cap` from the reference."""
+    hip = hip.detach().cpu().numpy() if isinstance(hip, torch.Tensor) else np.asarray(hip)
+    ref32 = ref32.detach().cpu().numpy() if isinstance(ref32, torch.Tensor) else np.asarray(ref32)
+    exact64 = exact64.detach().cpu().numpy() if isinstance(exact64, torch.Tensor) else np.asarray(exact64)
+    hip = hip.reshape(ref32.shape)
+    exact64 = exact64.reshape(ref32.shape)
+    e_hr = rel_err(hip, ref32)
+    if e_hr <= rtol:
+        return e_hr
+    e_ref = rel_err(ref32, exact64)
+    e_hip = rel_err(hip, exact64)
+    assert e_hr <= cap and e_hip <= 1.5 * e_ref + 1e-5, (
+        '%s: hip-vs-ref %.3e > %.1e and hip-vs-exact %.3e is worse than ref-vs-exact %.3e'
+        % (what, e_hr, rtol, e_hip, e_ref))
+    return e_hr
+
+
 # ---- product-side helpers (GPU tests) ----------------------------------------------------
 def product_modules(dev='cuda'):
     """The build's parameter containers holding the same synthetic weights as oracle_fields()."""
@@ -61,8 +95,16 @@ def packed_fields(dev='cuda'):
     return hand, obj
 
 
+# Device tensors made by cu() are kept alive until the end of the running test: the C ABI takes
+# raw pointers, and a temporary passed as `ptr(cu(x))` would otherwise be returned to torch's
+# caching allocator (and handed to the next temporary) before the kernel has run.
+_KEEP = []
+
+
 def cu(a, dtype=None):
     x = t(a) if not isinstance(a, torch.Tensor) else a
     if dtype is not None:
         x = x.to(dtype)
-    return x.cuda().contiguous()
+    x = x.cuda().contiguous()
+    _KEEP.append(x)
+    return x
