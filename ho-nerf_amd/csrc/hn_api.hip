@@ -40,6 +40,12 @@ int launch_field_obj(const hn_field*, const float*, const float*, int, int, floa
 int launch_field_hand(const hn_field*, const float*, int, const float*, const float*, int, int, float*, float*, float*,
                       float*, void*, size_t, bool, hipStream_t);
 
+namespace v2 {
+size_t field2_obj_workspace_bytes(int n_pts, int n_cus);
+int launch_field2_obj(const hn_field*, const float*, const float*, int, int, float*, float*, float*, float*, void*, size_t,
+                      bool, hipStream_t);
+}
+
 __global__ void k_scale(float* v, int n, float s) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] *= s;
@@ -92,17 +98,22 @@ static int device_cus() {
 static size_t field_ws(const hn_field* f, int n_pts) {
     int cus = device_cus();
     if (cus <= 0) cus = 256;
+    if (f->precision == HN_PREC_F16X3 && f->kind == HN_FIELD_OBJ) return v2::field2_obj_workspace_bytes(n_pts, cus);
     return f->kind == HN_FIELD_OBJ ? field_obj_workspace_bytes(n_pts, cus) : field_hand_workspace_bytes(n_pts, cus);
 }
 
 static int field_sdf(const hn_field* f, const float* pts, int n, const float* bt, const float* Tp, int n_frames, int ppf,
                      float* sdf, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (f->precision == HN_PREC_F16X3 && f->kind == HN_FIELD_OBJ)
+        return v2::launch_field2_obj(f, pts, nullptr, n, 1, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
     if (f->kind == HN_FIELD_OBJ) return launch_field_obj(f, pts, nullptr, n, 1, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
     return launch_field_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
 }
 static int field_eval(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt,
                       const float* Tp, int n_frames, int ppf, float* sdf, float* grad, float* rgb, float* feat, void* ws,
                       size_t ws_bytes, hipStream_t s) {
+    if (f->precision == HN_PREC_F16X3 && f->kind == HN_FIELD_OBJ)
+        return v2::launch_field2_obj(f, pts, rays_d, n, spr, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
     if (f->kind == HN_FIELD_OBJ) return launch_field_obj(f, pts, rays_d, n, spr, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
     return launch_field_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
 }
@@ -309,6 +320,8 @@ int hn_field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* color, 
 int hn_field_destroy(hn_field* f) {
     if (f == nullptr) return HN_OK;
     if (f->blob != nullptr) (void)hipFree(f->blob);
+    if (f->v2_full != nullptr) (void)hipFree(f->v2_full);
+    if (f->v2_sdf != nullptr) (void)hipFree(f->v2_sdf);
     delete f;
     return HN_OK;
 }

@@ -93,4 +93,9 @@ struct hn_field {
     const float* col_bias[4] = {};
     const float* col_wlast = nullptr;   // lin4: [3][256]
     float col_blast[3] = {0.f, 0.f, 0.f};
+    // --- v2 (HN_PREC_F16X3): weight streams in consumption order (hn_pack2.hip) ---------
+    void* v2_full = nullptr;     // sdf forward + reverse sweep + colour
+    size_t v2_full_bytes = 0;
+    void* v2_sdf = nullptr;      // sdf forward only (sampling passes)
+    size_t v2_sdf_bytes = 0;
 };

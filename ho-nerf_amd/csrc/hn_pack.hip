@@ -300,11 +300,16 @@ static int build(hn_field* f, Packer& pk, const hn_mlp_desc* sdf, const hn_mlp_d
     return pk.status;
 }
 
+namespace v2 {
+int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float* const* w_sdf,
+                     float* const* w_col, hipStream_t stream);
+}
+
 int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float variance, float scale, int precision,
                  hn_field** out, hipStream_t stream) {
     HN_REQUIRE(out != nullptr && sdf != nullptr && col != nullptr, "null argument");
     HN_REQUIRE(kind == HN_FIELD_OBJ || kind == HN_FIELD_HAND, "unknown field kind %d", kind);
-    HN_REQUIRE(precision == HN_PREC_FP32, "unsupported precision %d", precision);
+    HN_REQUIRE(precision == HN_PREC_FP32 || precision == HN_PREC_F16X3, "unsupported precision %d", precision);
     int rc = check_shapes(kind, sdf, col);
     if (rc != HN_OK) return rc;
 
@@ -366,8 +371,11 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
             rc = HN_EHIP;
         }
     }
+    if (rc == HN_OK && precision == HN_PREC_F16X3) rc = v2::build_v2_streams(f, sdf, col, w_sdf, w_col, stream);
     pk.free_temps();
     if (rc != HN_OK) {
+        if (f->v2_full) (void)hipFree(f->v2_full);
+        if (f->v2_sdf) (void)hipFree(f->v2_sdf);
         if (f->blob) (void)hipFree(f->blob);
         delete f;
         return rc;

@@ -1,0 +1,298 @@
+// v2 weight streams (HN_PREC_F16X3): every matrix of a field re-laid as the sequence of LDS
+// chunks the v2 kernels consume, fp16 hi / scaled-lo MFMA A fragments (hn_mlp2.h).  Packing
+// runs once per field on the host (a few MB; the networks are frozen on every path this
+// library serves): the weight-norm-folded matrices are copied back from the device, laid out
+// here and uploaded as one blob per program.
+//
+// Reads the reference's state-dict layout through hn_mlp_desc (utils/fields.py:120-121,
+// 216-217, 307-308, 382-383).
+#include <math.h>
+#include <string.h>
+
+#include "hn_mlp2.h"
+
+namespace hn {
+namespace v2 {
+
+struct HostMat {
+    std::vector<float> w;   // row-major [rows][cols], weight-norm folded
+    std::vector<float> b;   // [rows]
+    int rows = 0, cols = 0;
+    float at(int r, int c) const { return w[(size_t)r * cols + c]; }
+};
+
+// neuron (row of a [256 x samples] activation) held in k-step s, lane half h, fragment element j
+static inline int hid_k(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+// inverse for rows of an accumulator whose rows ARE k-slots: natural row n -> (s, h, j)
+static inline void k_of_row(int n, int& s, int& h, int& j) {
+    s = n >> 4;
+    const int rem = n & 15;
+    h = (rem >> 2) & 1;
+    j = 4 * (rem >> 3) + (rem & 3);
+}
+
+struct Builder {
+    std::vector<char> blob;
+
+    // One chunk: tiles x ks k-step blocks (+ tail).  rowmap[ti*32 + r] = matrix row of tile ti's row r
+    // (-1 pad); colslot[s*16 + 8h + j] = matrix column of k-slot (s,h,j) (-1 pad).  transposed:
+    // element (row, col) = M[col][row].
+    void chunk(const HostMat& M, bool transposed, float scale, int tiles, int ks, const int* rowmap, const int* colslot,
+               const float* tail /* 256 floats or nullptr */) {
+        const size_t base = blob.size();
+        blob.resize(base + (size_t)tiles * ks * KS_BYTES + (tail ? TAIL_BYTES : 0));
+        _Float16* dst = reinterpret_cast<_Float16*>(blob.data() + base);
+        for (int ti = 0; ti < tiles; ++ti)
+            for (int s = 0; s < ks; ++s) {
+                _Float16* hi = dst + ((size_t)(ti * ks + s) * KS_BYTES) / 2;
+                _Float16* lo = hi + 512;
+                for (int l = 0; l < 64; ++l) {
+                    const int r = l & 31, h = l >> 5;
+                    const int row = rowmap[ti * 32 + r];
+                    for (int j = 0; j < 8; ++j) {
+                        const int col = colslot[s * 16 + 8 * h + j];
+                        float x = 0.f;
+                        if (row >= 0 && col >= 0) x = (transposed ? M.at(col, row) : M.at(row, col)) * scale;
+                        const _Float16 xh = (_Float16)x;
+                        hi[l * 8 + j] = xh;
+                        lo[l * 8 + j] = (_Float16)((x - (float)xh) * LO_SCALE);
+                    }
+                }
+            }
+        if (tail) memcpy(blob.data() + base + (size_t)tiles * ks * KS_BYTES, tail, TAIL_BYTES);
+    }
+};
+
+// tail slot k <- 32 values given in natural tile-row order, stored [half][16]
+static void tail_put(float* tail, int k, const float* v32) {
+    for (int h = 0; h < 2; ++h)
+        for (int i = 0; i < 16; ++i) tail[k * 32 + h * 16 + i] = v32[tile_row(i, h)];
+}
+
+// ---- k-slot descriptions of the encoded inputs -----------------------------------------------------
+// [x(3), enc_L(x)] column of (channel c, frequency k, sin|cos) in the reference's layout
+// (utils/fields.py:13-20): 3 + 2 L c + k (+ L for cos)
+static inline int enc_col(int L, int c, int k, int is_cos) { return 3 + 2 * L * c + k + (is_cos ? L : 0); }
+
+// obj sdf input (63 columns) over 4 k-steps: s = channel for frequencies 0..7; s = 3: frequencies 8, 9 of
+// the three channels, then (p0 | p2), (p1 | pad).  Half 0 holds sines / first members, half 1 cosines.
+static std::vector<int> obj_x_slots() {
+    std::vector<int> c(64, -1);
+    for (int s = 0; s < 3; ++s)
+        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 8; ++j) c[s * 16 + 8 * h + j] = enc_col(10, s, j, h);
+    for (int h = 0; h < 2; ++h) {
+        for (int j = 0; j < 6; ++j) c[48 + 8 * h + j] = enc_col(10, j >> 1, 8 + (j & 1), h);
+        c[48 + 8 * h + 6] = h ? 2 : 0;
+        c[48 + 8 * h + 7] = h ? -1 : 1;
+    }
+    return c;
+}
+// [v(3), enc_4(v)] (27 columns) over 2 k-steps
+static std::vector<int> vec4_slots() {
+    std::vector<int> c(32, -1);
+    for (int h = 0; h < 2; ++h) {
+        for (int j = 0; j < 8; ++j) c[8 * h + j] = enc_col(4, j >> 2, j & 3, h);
+        for (int j = 0; j < 4; ++j) c[16 + 8 * h + j] = enc_col(4, 2, j, h);
+        c[16 + 8 * h + 4] = h ? 2 : 0;
+        c[16 + 8 * h + 5] = h ? -1 : 1;
+    }
+    return c;
+}
+static std::vector<int> hid_slots(int n_real = 256, int ks = 16) {
+    std::vector<int> c(ks * 16, -1);
+    for (int s = 0; s < ks; ++s)
+        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 8; ++j) {
+                const int n = hid_k(s, h, j);
+                c[s * 16 + 8 * h + j] = n < n_real ? n : -1;
+            }
+    return c;
+}
+static std::vector<int> offset(std::vector<int> v, int off) {
+    for (int& x : v)
+        if (x >= 0) x += off;
+    return v;
+}
+static std::vector<int> rows_of_tile(int t, int n_real, int off = 0) {
+    std::vector<int> r(32, -1);
+    for (int i = 0; i < 32; ++i)
+        if (32 * t + i < n_real) r[i] = off + 32 * t + i;
+    return r;
+}
+static std::vector<int> cat(std::vector<int> a, const std::vector<int>& b) {
+    a.insert(a.end(), b.begin(), b.end());
+    return a;
+}
+
+// hidden layer, forward: out tile t, 16 k-steps, tail = bias (+ extra tail slots)
+static void fwd_tiles(Builder& B, const HostMat& M, float scale, int out_tiles, int n_out, int row_off,
+                      const std::vector<int>& slots, int ks, const float* const* extra_rows /* up to 3 */, int n_extra) {
+    for (int t = 0; t < out_tiles; ++t) {
+        const std::vector<int> rows = rows_of_tile(t, n_out, row_off);
+        float tail[256] = {0.f};
+        float v[32];
+        for (int i = 0; i < 32; ++i) v[i] = rows[i] >= 0 ? M.b[rows[i]] : 0.f;
+        tail_put(tail, 0, v);
+        for (int e = 0; e < n_extra; ++e) {
+            for (int i = 0; i < 32; ++i) v[i] = 32 * t + i < n_out ? extra_rows[e][32 * t + i] : 0.f;
+            tail_put(tail, 1 + e, v);
+        }
+        B.chunk(M, false, scale, 1, ks, rows.data(), slots.data(), tail);
+    }
+}
+// transposed hidden layer (reverse sweep): rows = the layer's inputs, K = its outputs
+static void bwd_tiles(Builder& B, const HostMat& M, float scale, int in_tiles, int n_in, int col_off, int n_out, int ks) {
+    const std::vector<int> slots = hid_slots(n_out, ks);
+    for (int t = 0; t < in_tiles; ++t) {
+        const std::vector<int> rows = rows_of_tile(t, n_in, col_off);
+        B.chunk(M, true, scale, 1, ks, rows.data(), slots.data(), nullptr);
+    }
+}
+// rows = k-slots of an encoded input (d sdf / d encoded input): tile u row r <-> slot of natural row 32u + r
+static void slot_rows_T(Builder& B, const HostMat& M, float scale, const std::vector<int>& in_slots, int col_off) {
+    const int tiles = (int)in_slots.size() / 32;
+    const std::vector<int> slots = hid_slots();
+    for (int u = 0; u < tiles; ++u) {
+        std::vector<int> rows(32, -1);
+        for (int r = 0; r < 32; ++r) {
+            int s, h, j;
+            k_of_row(32 * u + r, s, h, j);
+            const int c = in_slots[s * 16 + 8 * h + j];
+            rows[r] = c >= 0 ? col_off + c : -1;
+        }
+        B.chunk(M, true, scale, 1, 16, rows.data(), slots.data(), nullptr);
+    }
+}
+
+// The obj program (contract with k_field2_obj): sdf forward [+ feature rows + reverse sweep + colour]
+static void build_obj_stream(Builder& B, const HostMat* S, const HostMat* C, bool full) {
+    const float rs2 = (float)(1.0 / sqrt(2.0));
+    const std::vector<int> xs = obj_x_slots();
+    const std::vector<int> hs = hid_slots();
+    // lin0: 2 chunks of 4 tiles x 4 k-steps, tail = the 4 biases
+    for (int c = 0; c < 2; ++c) {
+        std::vector<int> rows;
+        float tail[256] = {0.f};
+        for (int ti = 0; ti < 4; ++ti) {
+            const std::vector<int> r = rows_of_tile(4 * c + ti, 256);
+            rows = cat(rows, r);
+            float v[32];
+            for (int i = 0; i < 32; ++i) v[i] = S[0].b[r[i]];
+            tail_put(tail, ti, v);
+        }
+        B.chunk(S[0], false, 1.f, 4, 4, rows.data(), xs.data(), tail);
+    }
+    fwd_tiles(B, S[1], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    fwd_tiles(B, S[2], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    fwd_tiles(B, S[3], 1.f, 7, L3_OUT_OBJ, 0, hs, 16, nullptr, 0);
+    {   // lin4: k-steps 0..11 = a4[0..191]; 12..15 = X slots (columns 193 + x) with a4[192] in the pad slot
+        std::vector<int> slots = hid_slots(192, 12);
+        std::vector<int> x = offset(xs, L3_OUT_OBJ);
+        x[48 + 8 + 7] = 192;
+        slots = cat(slots, x);
+        fwd_tiles(B, S[4], rs2, 8, 256, 0, slots, 16, nullptr, 0);
+    }
+    fwd_tiles(B, S[5], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    fwd_tiles(B, S[6], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    {   // lin7, tail slot 1 = W8[0, :]
+        std::vector<float> w8(256);
+        for (int i = 0; i < 256; ++i) w8[i] = S[8].at(0, i);
+        const float* extra[1] = {w8.data()};
+        fwd_tiles(B, S[7], 1.f, 8, 256, 0, hs, 16, extra, 1);
+    }
+    if (!full) return;
+    fwd_tiles(B, S[8], 1.f, 8, 256, 1, hs, 16, nullptr, 0);   // feature rows 1..256
+    // reverse sweep
+    bwd_tiles(B, S[7], 1.f, 8, 256, 0, 256, 16);
+    bwd_tiles(B, S[6], 1.f, 8, 256, 0, 256, 16);
+    bwd_tiles(B, S[5], 1.f, 8, 256, 0, 256, 16);
+    bwd_tiles(B, S[4], rs2, 7, L3_OUT_OBJ, 0, 256, 16);      // columns 0..192 of W4
+    bwd_tiles(B, S[3], 1.f, 8, 256, 0, L3_OUT_OBJ, 13);
+    bwd_tiles(B, S[2], 1.f, 8, 256, 0, 256, 16);
+    bwd_tiles(B, S[1], 1.f, 8, 256, 0, 256, 16);
+    slot_rows_T(B, S[0], 1.f, xs, 0);                 // W0^T over the X slots (2 tiles)
+    slot_rows_T(B, S[4], rs2, xs, L3_OUT_OBJ);       // W4[:, 193:]^T over the X slots
+    // colour lin0: [enc(p) 63 | enc(d) 27 | feature 256 | enc(g) 27] (utils/fields.py:389-396)
+    {
+        const std::vector<int> v4 = vec4_slots();
+        const std::vector<int> fv = offset(hs, OBJ_IN + 27);
+        const std::vector<int> misc = cat(cat(xs, offset(v4, OBJ_IN)), offset(v4, OBJ_IN + 27 + H));
+        for (int t = 0; t < 8; ++t) {
+            const std::vector<int> rows = rows_of_tile(t, 256);
+            B.chunk(C[0], false, 1.f, 1, 16, rows.data(), fv.data(), nullptr);
+            float tail[256] = {0.f};
+            float v[32];
+            for (int i = 0; i < 32; ++i) v[i] = C[0].b[rows[i]];
+            tail_put(tail, 0, v);
+            B.chunk(C[0], false, 1.f, 1, 8, rows.data(), misc.data(), tail);
+        }
+    }
+    fwd_tiles(B, C[1], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    fwd_tiles(B, C[2], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    {   // lin3, tail slots 1..3 = the three rows of lin4
+        std::vector<float> w0(256), w1(256), w2(256);
+        for (int i = 0; i < 256; ++i) {
+            w0[i] = C[4].at(0, i);
+            w1[i] = C[4].at(1, i);
+            w2[i] = C[4].at(2, i);
+        }
+        const float* extra[3] = {w0.data(), w1.data(), w2.data()};
+        fwd_tiles(B, C[3], 1.f, 8, 256, 0, hs, 16, extra, 3);
+    }
+}
+
+static int upload(const std::vector<char>& blob, void** dev, size_t* bytes, hipStream_t stream) {
+    HN_CHECK_HIP(hipMalloc(dev, blob.size()));
+    HN_CHECK_HIP(hipMemcpyAsync(*dev, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
+    HN_CHECK_HIP(hipStreamSynchronize(stream));
+    *bytes = blob.size();
+    return HN_OK;
+}
+
+void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, bool full);
+
+// w_sdf / w_col: device pointers to the folded matrices (row-major [out][in])
+int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float* const* w_sdf,
+                     float* const* w_col, hipStream_t stream) {
+    HostMat S[9], C[5];
+    auto fetch = [&](const hn_mlp_desc* d, int l, float* dev_w, HostMat& M) -> int {
+        M.rows = d->out_dim[l];
+        M.cols = d->in_dim[l];
+        M.w.resize((size_t)M.rows * M.cols);
+        M.b.resize(M.rows);
+        HN_CHECK_HIP(hipMemcpyAsync(M.w.data(), dev_w, M.w.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HN_CHECK_HIP(hipMemcpyAsync(M.b.data(), d->bias[l], M.b.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        return HN_OK;
+    };
+    for (int l = 0; l < 9; ++l) {
+        const int rc = fetch(sdf, l, w_sdf[l], S[l]);
+        if (rc != HN_OK) return rc;
+    }
+    for (int l = 0; l < 5; ++l) {
+        const int rc = fetch(col, l, w_col[l], C[l]);
+        if (rc != HN_OK) return rc;
+    }
+    HN_CHECK_HIP(hipStreamSynchronize(stream));
+    for (int pass = 0; pass < 2; ++pass) {
+        Builder B;
+        const bool full = pass == 0;
+        if (f->kind == HN_FIELD_OBJ)
+            build_obj_stream(B, S, C, full);
+        else
+            build_hand_stream(B, S, C, full);
+        const int rc = upload(B.blob, full ? &f->v2_full : &f->v2_sdf, full ? &f->v2_full_bytes : &f->v2_sdf_bytes, stream);
+        if (rc != HN_OK) return rc;
+    }
+    return HN_OK;
+}
+
+void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, bool full) {
+    (void)B;
+    (void)S;
+    (void)C;
+    (void)full;   // filled in by hn_field2_hand
+}
+
+}  // namespace v2
+}  // namespace hn

@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, 'libhonerf.so')
 HN_FIELD_OBJ = 0
 HN_FIELD_HAND = 1
 HN_PREC_FP32 = 0
+HN_PREC_F16X3 = 1
+PRECISIONS = {'fp32': HN_PREC_FP32, 'f16x3': HN_PREC_F16X3}
 HN_MAX_LAYERS = 9
 
 c_f = ctypes.c_void_p     # device float*

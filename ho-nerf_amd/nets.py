@@ -177,9 +177,10 @@ class PackedField:
     state dicts in the reference layout; `variance` a SingleVarianceNetwork, a
     tensor or a float."""
 
-    def __init__(self, kind, sdf, color, variance, scale=None):
+    def __init__(self, kind, sdf, color, variance, scale=None, precision='fp32'):
         self.lib = _lib.load()
         self.kind = kind
+        self.precision = precision
         sdf_sd, col_sd = _state_of(sdf), _state_of(color)
         if isinstance(variance, nn.Module):
             variance = variance.variance
@@ -191,7 +192,7 @@ class PackedField:
         handle = ctypes.c_void_p()
         torch.cuda.synchronize()
         rc = self.lib.hn_field_create(_lib.HN_FIELD_OBJ if kind == 'obj' else _lib.HN_FIELD_HAND,
-                                      ctypes.byref(d_sdf), ctypes.byref(d_col), var, float(scale), _lib.HN_PREC_FP32,
+                                      ctypes.byref(d_sdf), ctypes.byref(d_col), var, float(scale), _lib.PRECISIONS[precision],
                                       ctypes.byref(handle), _lib.stream_ptr())
         _lib.check(rc, 'hn_field_create')
         del keep

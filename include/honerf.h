@@ -39,6 +39,8 @@ extern "C" {
 #define HN_FIELD_HAND 1 /* SDFNetwork + RenderingNetwork (utils/fields.py:56-240) */
 
 #define HN_PREC_FP32 0   /* exact fp32: v_mfma_f32_32x32x2_f32 == fmaf chains */
+#define HN_PREC_F16X3 1  /* fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16 per product, fp32
+                          * accumulate: fp32-equivalent results (22-bit operands) at 16/3 x the rate */
 
 #define HN_MAX_LAYERS 9
 #define HN_N_BONES 21

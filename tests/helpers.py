@@ -87,11 +87,11 @@ def product_modules(dev='cuda'):
     return {k: v.to(dev) for k, v in m.items()}
 
 
-def packed_fields(dev='cuda'):
+def packed_fields(dev='cuda', precision='fp32'):
     from honerf_amd.nets import PackedField
     m = product_modules(dev)
-    hand = PackedField('hand', m['sdf_hand'], m['color_hand'], m['var_hand'])
-    obj = PackedField('obj', m['sdf_obj'], m['color_obj'], m['var_obj'])
+    hand = PackedField('hand', m['sdf_hand'], m['color_hand'], m['var_hand'], precision=precision)
+    obj = PackedField('obj', m['sdf_obj'], m['color_obj'], m['var_obj'], precision=precision)
     return hand, obj
 
 
