@@ -5,6 +5,8 @@
 // Reference: utils/fields.py:316-347 (sdf net, .gradient), :387-405 (colour net), called from
 // utils/renderer.py:130-135 / 380-385.  The chunk order below is the contract with
 // hn_pack2.hip (build_obj_stream).
+#include <stdlib.h>
+
 #include "hn_mlp2.h"
 
 namespace hn {
@@ -25,15 +27,8 @@ struct Obj2Args {
     float* rgb;
     float* feat;           // optional [n,256]
     float4* scratch;       // per-wave stash slots (FULL only)
+    int dbg;               // timing experiments only (HN_DBG): 1 = no stash stores, 2 = no stash loads
 };
-
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
 
 // stash slots of one wave (32 KiB each)
 enum { OS_A1 = 0 /* a1..a7 -> 0..6 */, OS_DZ7 = 7, OS_FVEC = 8, OS_DZ4 = 9, OBJ2_SLOTS = 10 };
@@ -83,10 +78,10 @@ template <bool FULL>
 __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar addressing
     const int j = lane & 31;
     const int h = lane >> 5;
-    float4* const wslot = a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * OBJ2_SLOTS * SLOT_F4;
+    float4* wslot = a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * OBJ2_SLOTS * SLOT_F4;
     auto slot = [&](int i) { return wslot + (size_t)i * SLOT_F4; };
     const int n_tiles = (a.n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
 
@@ -102,6 +97,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const bool more = tile + (int)gridDim.x < n_tiles;
+        wslot = launder_uniform(wslot);
         const int n = tile * WG_SAMPLES + wave * 32 + j;
         const bool valid = n < a.n_pts;
         const int nn = valid ? n : a.n_pts - 1;
@@ -131,53 +127,42 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 f32x16 z = combine(c1, c2);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = softplus100(z[i]);
-                if (FULL) stash_tile(slot(OS_A1 + 0), t, z, lane);
+                if (FULL && !(a.dbg & 1)) stash_tile(slot(OS_A1 + 0), t, z, lane);
                 split_tile(z, ah[2 * t], al[2 * t], ah[2 * t + 1], al[2 * t + 1]);
             });
         });
 
-        // generic forward hidden layer: out tile t = act(bias + W x); next_after = bytes of the chunk after this layer
-        auto fwd_layer = [&](auto OT_, auto KS_, const h8(&inh)[16], const h8(&inl)[16], int next_after, auto&& epi) {
-            constexpr int OT = decltype(OT_)::value;
-            constexpr int KS = decltype(KS_)::value;
-            static_for<OT>([&](auto T) {
-                constexpr int t = decltype(T)::value;
-                const char* buf = ws.acquire(t + 1 < OT ? CB_HID : next_after);
-                f32x16 c1 = tail_tile(buf + 16 * KS_BYTES, 0, h), c2 = zero16();
-                mma_tile<KS, 0>(buf, inh, inl, c1, c2, lane);
-                epi(T, combine(c1, c2), buf + 16 * KS_BYTES);
-            });
+        struct Act {
+            f32x16 v;
         };
+        auto no_pre = [](auto, const char*) { return NoData{}; };
+        // softplus layer: a_{l+1} = softplus(z) -> stash (reverse sweep) + next layer's fragments
         auto softplus_to = [&](h8(&oh)[16], h8(&ol)[16], int stash_slot) {
-            return [&oh, &ol, stash_slot, &slot, lane](auto T, f32x16 z, const char*) {
+            return [&oh, &ol, stash_slot, &slot, lane, &a](auto T, f32x16 z, NoData) {
                 constexpr int t = decltype(T)::value;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = softplus100(z[i]);
-                if (FULL) stash_tile(slot(stash_slot), t, z, lane);
+                if (FULL && !(a.dbg & 1)) stash_tile(slot(stash_slot), t, z, lane);
                 split_tile(z, oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
             };
         };
-        using I7 = std::integral_constant<int, 7>;
-        using I8 = std::integral_constant<int, 8>;
-        using I13 = std::integral_constant<int, 13>;
-        using I16 = std::integral_constant<int, 16>;
 
-        fwd_layer(I8{}, I16{}, ah, al, CB_HID, softplus_to(bh, bl, OS_A1 + 1));   // lin1: a1 -> a2
-        fwd_layer(I8{}, I16{}, bh, bl, CB_HID, softplus_to(ah, al, OS_A1 + 2));   // lin2: a2 -> a3
+        run_layer<8, 16, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, softplus_to(bh, bl, OS_A1 + 1));   // lin1
+        run_layer<8, 16, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, softplus_to(ah, al, OS_A1 + 2));   // lin2
         // ---- lin3: 193 outputs = 7 tiles (tile 6 holds neuron 192 in row 0)
         float a4_192 = 0.f;
-        fwd_layer(I7{}, I16{}, ah, al, CB_HID, [&](auto T, f32x16 z, const char*) {
+        run_layer<7, 16, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, [&](auto T, f32x16 z, NoData) {
             constexpr int t = decltype(T)::value;
 #pragma unroll
             for (int i = 0; i < 16; ++i) z[i] = softplus100(z[i]);
-            if (t == 6) {
-                // rows 193..223 are padding: zero weights and zero bias give softplus(0); drop them
+            if constexpr (t == 6) {
+                // rows 193..223 are padding (zero weights, zero bias give softplus(0)): drop them
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = (i == 0 && h == 0) ? z[i] : 0.f;
                 a4_192 = z[0];
             }
-            if (FULL) stash_tile(slot(OS_A1 + 3), t, z, lane);
-            if (t < 6) split_tile(z, bh[2 * t], bl[2 * t], bh[2 * t + 1], bl[2 * t + 1]);
+            if (FULL && !(a.dbg & 1)) stash_tile(slot(OS_A1 + 3), t, z, lane);
+            if constexpr (t < 6) split_tile(z, bh[2 * t], bl[2 * t], bh[2 * t + 1], bl[2 * t + 1]);
         });
         // ---- lin4: [a4 (192 via k-steps 0..11) | X with a4[192] in its pad slot] / sqrt2
         {
@@ -193,29 +178,31 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             }
             split8(f3, bh[15], bl[15]);
         }
-        fwd_layer(I8{}, I16{}, bh, bl, CB_HID, softplus_to(ah, al, OS_A1 + 4));   // lin4 -> a5
-        fwd_layer(I8{}, I16{}, ah, al, CB_HID, softplus_to(bh, bl, OS_A1 + 5));   // lin5 -> a6
-        fwd_layer(I8{}, I16{}, bh, bl, CB_HID, softplus_to(ah, al, OS_A1 + 6));   // lin6 -> a7
+        run_layer<8, 16, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, softplus_to(ah, al, OS_A1 + 4));   // lin4
+        run_layer<8, 16, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, softplus_to(bh, bl, OS_A1 + 5));   // lin5
+        run_layer<8, 16, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, softplus_to(ah, al, OS_A1 + 6));   // lin6
         // ---- lin7 -> a8; sdf = W8[0,:] a8 + b8; seed of the reverse sweep dz7 = sigma'(z7) W8[0,:] / scale
         float sdf_acc = 0.f;
-        fwd_layer(I8{}, I16{}, ah, al, FULL ? CB_HID : (more ? CB_L0 : 0), [&](auto T, f32x16 z, const char* tail) {
-            constexpr int t = decltype(T)::value;
-            const f32x16 w8 = tail_tile(tail, 1, h);
-            f32x16 dz;
+        run_layer<8, 16, true>(
+            ws, CB_HID, FULL ? CB_HID : (more ? CB_L0 : 0), ah, al, lane, h,
+            [&](auto, const char* tail) { return Act{tail_tile(tail, 1, h)}; },
+            [&](auto T, f32x16 z, const Act& w8) {
+                constexpr int t = decltype(T)::value;
+                f32x16 dz;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                z[i] = softplus100(z[i]);
-                sdf_acc = fmaf(w8[i], z[i], sdf_acc);
-                dz[i] = dsoftplus_from_act(z[i]) * w8[i] * a.inv_scale;
-            }
-            if (FULL) {
-                split_tile(z, bh[2 * t], bl[2 * t], bh[2 * t + 1], bl[2 * t + 1]);   // a8 feeds lin8
-                h8 dh0, dl0, dh1, dl1;
-                split_tile(dz, dh0, dl0, dh1, dl1);
-                stash_frag(slot(OS_DZ7), 2 * t, dh0, dl0, lane);
-                stash_frag(slot(OS_DZ7), 2 * t + 1, dh1, dl1, lane);
-            }
-        });
+                for (int i = 0; i < 16; ++i) {
+                    z[i] = softplus100(z[i]);
+                    sdf_acc = fmaf(w8.v[i], z[i], sdf_acc);
+                    dz[i] = dsoftplus_from_act(z[i]) * w8.v[i] * a.inv_scale;
+                }
+                if (FULL) {
+                    split_tile(z, bh[2 * t], bl[2 * t], bh[2 * t + 1], bl[2 * t + 1]);   // a8 feeds lin8
+                    h8 dh0, dl0, dh1, dl1;
+                    split_tile(dz, dh0, dl0, dh1, dl1);
+                    stash_frag(slot(OS_DZ7), 2 * t, dh0, dl0, lane);
+                    stash_frag(slot(OS_DZ7), 2 * t + 1, dh1, dl1, lane);
+                }
+            });
         const float sdf = (half_sum(sdf_acc) + a.b8) * a.inv_scale;
         if (!FULL) {
             if (valid && h == 0) a.sdf[n] = sdf;
@@ -223,7 +210,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         }
 
         // ---- lin8 rows 1..256: the feature vector (no activation) -> stash as fragments for colour lin0
-        fwd_layer(I8{}, I16{}, bh, bl, CB_BWD, [&](auto T, f32x16 z, const char*) {
+        run_layer<8, 16, true>(ws, CB_HID, CB_BWD, bh, bl, lane, h, no_pre, [&](auto T, f32x16 z, NoData) {
             constexpr int t = decltype(T)::value;
             if (a.feat != nullptr && valid) {
 #pragma unroll
@@ -235,58 +222,49 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             stash_frag(slot(OS_FVEC), 2 * t + 1, fh1, fl1, lane);
         });
 
-        // ---- reverse sweep ------------------------------------------------------------------------
-        // dz_{l-1} = sigma'(z_{l-1}) * (W_l^T dz_l); sigma' recovered from the stashed activation a_l
-        auto bwd_layer = [&](auto OT_, auto KS_, int cb, const h8(&inh)[16], const h8(&inl)[16], int next_after,
-                             auto&& epi) {
-            constexpr int OT = decltype(OT_)::value;
-            constexpr int KS = decltype(KS_)::value;
-            static_for<OT>([&](auto T) {
-                constexpr int t = decltype(T)::value;
-                const char* buf = ws.acquire(t + 1 < OT ? cb : next_after);
-                f32x16 c1 = zero16(), c2 = zero16();
-                mma_tile<KS, 0>(buf, inh, inl, c1, c2, lane);
-                epi(T, combine(c1, c2));
-            });
+        // ---- reverse sweep: dz_{l-1} = sigma'(z_{l-1}) * (W_l^T dz_l); sigma' from the stashed activation a_l
+        auto act_of = [&](int act_slot) {
+            return [&slot, act_slot, lane, &a](auto T, const char*) {
+                if (a.dbg & 2) return Act{zero16()};
+                return Act{unstash_tile(slot(act_slot), decltype(T)::value, lane)};
+            };
         };
-        auto dsig_to = [&](h8(&oh)[16], h8(&ol)[16], int act_slot) {
-            return [&oh, &ol, act_slot, &slot, lane](auto T, f32x16 g) {
+        auto dsig_to = [&](h8(&oh)[16], h8(&ol)[16]) {
+            return [&oh, &ol](auto T, f32x16 g, const Act& act) {
                 constexpr int t = decltype(T)::value;
-                const f32x16 act = unstash_tile(slot(act_slot), t, lane);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) g[i] *= dsoftplus_from_act(act[i]);
+                for (int i = 0; i < 16; ++i) g[i] *= dsoftplus_from_act(act.v[i]);
                 split_tile(g, oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
             };
         };
 #pragma unroll
         for (int s = 0; s < 16; ++s) unstash_frag(slot(OS_DZ7), s, ah[s], al[s], lane);
-        bwd_layer(I8{}, I16{}, CB_BWD, ah, al, CB_BWD, dsig_to(bh, bl, OS_A1 + 6));   // W7^T: dz7 -> dz6 (a7)
-        bwd_layer(I8{}, I16{}, CB_BWD, bh, bl, CB_BWD, dsig_to(ah, al, OS_A1 + 5));   // W6^T: dz6 -> dz5 (a6)
-        bwd_layer(I8{}, I16{}, CB_BWD, ah, al, CB_BWD, [&](auto T, f32x16 g) {      // W5^T: dz5 -> dz4 (a5), kept
-            constexpr int t = decltype(T)::value;
-            const f32x16 act = unstash_tile(slot(OS_A1 + 4), t, lane);
+        run_layer<8, 16, false>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 6), dsig_to(bh, bl));   // W7^T -> dz6
+        run_layer<8, 16, false>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 5), dsig_to(ah, al));   // W6^T -> dz5
+        run_layer<8, 16, false>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 4),                     // W5^T -> dz4 (kept)
+                                [&](auto T, f32x16 g, const Act& act) {
+                                    constexpr int t = decltype(T)::value;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) g[i] *= dsoftplus_from_act(act[i]);
-            split_tile(g, bh[2 * t], bl[2 * t], bh[2 * t + 1], bl[2 * t + 1]);
-            stash_frag(slot(OS_DZ4), 2 * t, bh[2 * t], bl[2 * t], lane);
-            stash_frag(slot(OS_DZ4), 2 * t + 1, bh[2 * t + 1], bl[2 * t + 1], lane);
-        });
+                                    for (int i = 0; i < 16; ++i) g[i] *= dsoftplus_from_act(act.v[i]);
+                                    split_tile(g, bh[2 * t], bl[2 * t], bh[2 * t + 1], bl[2 * t + 1]);
+                                    stash_frag(slot(OS_DZ4), 2 * t, bh[2 * t], bl[2 * t], lane);
+                                    stash_frag(slot(OS_DZ4), 2 * t + 1, bh[2 * t + 1], bl[2 * t + 1], lane);
+                                });
         // W4[:, :193]^T: dz4 -> dz3 (193 rows = 7 tiles; a4's padding rows were stashed as 0 => sigma' = 0)
-        bwd_layer(I7{}, I16{}, CB_BWD, bh, bl, CB_BWD3, [&](auto T, f32x16 g) {
+        run_layer<7, 16, false>(ws, CB_BWD, CB_BWD3, bh, bl, lane, h, act_of(OS_A1 + 3), [&](auto T, f32x16 g, const Act& act) {
             constexpr int t = decltype(T)::value;
-            const f32x16 act = unstash_tile(slot(OS_A1 + 3), t, lane);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) g[i] *= dsoftplus_from_act(act[i]);
-            if (t < 6) {
+            for (int i = 0; i < 16; ++i) g[i] *= dsoftplus_from_act(act.v[i]);
+            if constexpr (t < 6) {
                 split_tile(g, ah[2 * t], al[2 * t], ah[2 * t + 1], al[2 * t + 1]);
             } else {
                 h8 d0, d1;   // only k-step 12 exists (neuron 192); 13 is padding
                 split_tile(g, ah[12], al[12], d0, d1);
             }
         });
-        bwd_layer(I8{}, I13{}, CB_BWD3, ah, al, CB_BWD, dsig_to(bh, bl, OS_A1 + 2));   // W3^T: dz3 -> dz2 (a3)
-        bwd_layer(I8{}, I16{}, CB_BWD, bh, bl, CB_BWD, dsig_to(ah, al, OS_A1 + 1));    // W2^T: dz2 -> dz1 (a2)
-        bwd_layer(I8{}, I16{}, CB_BWD, ah, al, CB_BWD, dsig_to(bh, bl, OS_A1 + 0));    // W1^T: dz1 -> dz0 (a1)
+        run_layer<8, 13, false>(ws, CB_BWD3, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 2), dsig_to(bh, bl));   // W3^T -> dz2
+        run_layer<8, 16, false>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 1), dsig_to(ah, al));    // W2^T -> dz1
+        run_layer<8, 16, false>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 0), dsig_to(bh, bl));    // W1^T -> dz0
         // d sdf / d X-space = W0^T dz0 + W4[:, 193:]^T dz4   (64 rows = 2 tiles; row <-> k-slot of the same lane)
         f32x16 G1[2] = {zero16(), zero16()}, G2[2] = {zero16(), zero16()};
         static_for<2>([&](auto U) {
@@ -365,24 +343,28 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             split_tile(z, bh[2 * t], bl[2 * t], bh[2 * t + 1], bl[2 * t + 1]);
         });
         auto relu_to = [&](h8(&oh)[16], h8(&ol)[16]) {
-            return [&oh, &ol](auto T, f32x16 z, const char*) {
+            return [&oh, &ol](auto T, f32x16 z, NoData) {
                 constexpr int t = decltype(T)::value;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = fmaxf(z[i], 0.f);
                 split_tile(z, oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
             };
         };
-        fwd_layer(I8{}, I16{}, bh, bl, CB_HID, relu_to(ah, al));   // colour lin1
-        fwd_layer(I8{}, I16{}, ah, al, CB_HID, relu_to(bh, bl));   // colour lin2
+        run_layer<8, 16, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, relu_to(ah, al));   // colour lin1
+        run_layer<8, 16, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, relu_to(bh, bl));   // colour lin2
         float rgb[3] = {0.f, 0.f, 0.f};
-        fwd_layer(I8{}, I16{}, bh, bl, more ? CB_L0 : 0, [&](auto T, f32x16 z, const char* tail) {   // colour lin3 + lin4
+        struct W3 {
+            f32x16 w[3];
+        };
+        run_layer<8, 16, true>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
+            ws, CB_HID, more ? CB_L0 : 0, bh, bl, lane, h,
+            [&](auto, const char* tail) { return W3{{tail_tile(tail, 1, h), tail_tile(tail, 2, h), tail_tile(tail, 3, h)}}; },
+            [&](auto, f32x16 z, const W3& w) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const f32x16 w = tail_tile(tail, 1 + c, h);
+                for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) rgb[c] = fmaf(w[i], fmaxf(z[i], 0.f), rgb[c]);
-            }
-        });
+                    for (int i = 0; i < 16; ++i) rgb[c] = fmaf(w.w[c][i], fmaxf(z[i], 0.f), rgb[c]);
+            });
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_fast(half_sum(rgb[c]) + a.c_blast[c]);
         if (valid && h == 0) {
@@ -431,6 +413,10 @@ int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, 
     a.rgb = rgb;
     a.feat = feat;
     a.scratch = reinterpret_cast<float4*>(workspace);
+    {
+        const char* e = getenv("HN_DBG");
+        a.dbg = e ? atoi(e) : 0;
+    }
     int n_cus = hn_device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = obj2_grid(n_pts, n_cus);

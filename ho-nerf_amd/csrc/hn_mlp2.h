@@ -147,17 +147,52 @@ __device__ __forceinline__ f32x16 combine(const f32x16& c1, const f32x16& c2) {
 // nn.Softplus(beta=100, threshold=20) (utils/fields.py:125, 310): max(z,0) + log1p(exp(-100|z|))/100.
 // Beyond the threshold the log term is below half an ulp of z, i.e. the result IS z, as in torch.
 __device__ __forceinline__ float softplus100(float z) {
-    const float e = __builtin_amdgcn_exp2f(-fabsf(z) * 144.26950408889634f);    // exp(-100 |z|)
-    // log1p(e)/100 = log2(1+e) * ln2/100; for tiny e the rounding of 1+e costs < 6e-10 absolute
-    const float small = e * (1.f - 0.5f * e);
-    const float l = e < 1e-4f ? small * 0.01f : __builtin_amdgcn_logf(1.f + e) * 0.0069314718055994531f;
-    return fmaxf(z, 0.f) + l;
+    // branch-free, 6 VALU ops: exp(-100|z|) -> log2(1 + e) * ln2/100 + max(z, 0).  The rounding of
+    // 1 + e costs at most 6e-8 * ln2/100 = 4e-10 absolute, far below the fp32 resolution of the sums
+    // this value enters (and 4e-8 on the derivative recovered from it).
+    const float e = __builtin_amdgcn_exp2f(-fabsf(z * 144.26950408889634f));
+    return fmaf(__builtin_amdgcn_logf(1.f + e), 0.0069314718055994531f, fmaxf(z, 0.f));
 }
 // sigmoid(100 z) recovered from a = softplus(z): exp(100 a) = 1 + exp(100 z) => s = 1 - exp(-100 a)
 __device__ __forceinline__ float dsoftplus_from_act(float a) {
     return 1.f - __builtin_amdgcn_exp2f(a * -144.26950408889634f);
 }
 __device__ __forceinline__ float sigmoid_fast(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ---- a layer as a software pipeline over its output tiles ----------------------------------------
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+struct NoData {};
+
+// OT output tiles, one chunk of KS k-steps (+ 1 KiB tail if TAIL, whose slot 0 is the tile's bias) each.
+// Step t: publish chunk t (barrier), start the DMA of the next one, fetch what tile t's epilogue will
+// need (`pre`, e.g. side data from the tail, stashed activations), issue the 3 KS MFMAs of tile t, and --
+// in the same scheduling region, so that VALU and MFMA overlap -- run the epilogue `post` of tile t-1.
+template <int OT, int KS, bool TAIL, typename Pre, typename Post>
+__device__ __forceinline__ void run_layer(WStream& ws, int cb_same, int next_after, const h8 (&xh)[16], const h8 (&xl)[16],
+                                          int lane, int h, Pre&& pre, Post&& post) {
+    using I0 = std::integral_constant<int, 0>;
+    using PD = decltype(pre(I0{}, (const char*)nullptr));
+    f32x16 c1[2], c2[2];
+    PD pd[2];
+    static_for<OT>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        const char* buf = ws.acquire(t + 1 < OT ? cb_same : next_after);
+        const char* tail = buf + KS * KS_BYTES;
+        c1[t & 1] = TAIL ? tail_tile(tail, 0, h) : zero16();
+        c2[t & 1] = zero16();
+        pd[t & 1] = pre(T, tail);
+        mma_tile<KS, 0>(buf, xh, xl, c1[t & 1], c2[t & 1], lane);
+        if constexpr (t > 0)
+            post(std::integral_constant<int, t - 1>{}, combine(c1[(t - 1) & 1], c2[(t - 1) & 1]), pd[(t - 1) & 1]);
+    });
+    post(std::integral_constant<int, OT - 1>{}, combine(c1[(OT - 1) & 1], c2[(OT - 1) & 1]), pd[(OT - 1) & 1]);
+}
 
 // ---- per-wave stash in global memory (slots of 32 KiB, every instruction moves 1 KiB) -----------
 constexpr size_t SLOT_F4 = 8 * 4 * 64;   // float4 per slot
@@ -188,6 +223,19 @@ __device__ __forceinline__ void unstash_frag(const float4* slot, int s, h8& hi, 
     const float4 b = slot[(s * 2 + 1) * 64 + lane];
     hi = *reinterpret_cast<const h8*>(&a);
     lo = *reinterpret_cast<const h8*>(&b);
+}
+
+// Re-materialises a wave-uniform pointer in SGPRs behind an opaque asm so that the compiler cannot
+// hoist the (hundreds of) addresses derived from it out of the persistent tile loop -- hoisted, they
+// are all live across the whole loop and spill.
+template <typename T>
+__device__ __forceinline__ T* launder_uniform(T* p) {
+    unsigned lo = (unsigned)(reinterpret_cast<uintptr_t>(p) & 0xffffffffu);
+    unsigned hi = (unsigned)(reinterpret_cast<uintptr_t>(p) >> 32);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return reinterpret_cast<T*>((static_cast<uintptr_t>(hi) << 32) | lo);
 }
 
 __device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
