@@ -31,7 +31,7 @@ struct Obj2Args {
 };
 
 // stash slots of one wave (32 KiB each)
-enum { OS_A1 = 0 /* a1..a7 -> 0..6 */, OS_DZ7 = 7, OS_FVEC = 8, OS_DZ4 = 9, OBJ2_SLOTS = 10 };
+enum { OS_A1 = 0 /* a1..a7 -> 0..6 */, OS_DZ7 = 7, OS_FVEC = 8, OS_DZ4 = 9, OS_X = 10, OBJ2_SLOTS = 11 };
 
 constexpr int CB_HID = chunk_bytes(1, 16, true);     // hidden layer tile: 16 k-steps + tail
 constexpr int CB_L0 = chunk_bytes(4, 4, true);       // lin0: 4 tiles x 4 k-steps + tail
@@ -43,7 +43,7 @@ constexpr int CB_C0B = chunk_bytes(1, 8, true);      // colour lin0, enc(p) | en
 // sin/cos(2^k x) of one lane half: half 0 keeps the sines, half 1 the cosines
 __device__ __forceinline__ float sc_half(float ang, int h) {
     float s, c;
-    sincosf(ang, &s, &c);
+    sincos_cw(ang, s, c);
     return h ? c : s;
 }
 // X space of the sdf net, 4 k-steps x 8 values per lane (see build_obj_stream: x_slots)
@@ -86,14 +86,9 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     const int n_tiles = (a.n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
 
     WStream ws;
-    ws.g = a.blob;
-    ws.begin = a.blob;
-    ws.end = a.blob + a.blob_bytes;
-    ws.lds = lds;
-    ws.phase = 0;
-    ws.wave = wave;
-    ws.lane = lane;
-    if ((int)blockIdx.x < n_tiles) ws.fetch(CB_L0);
+    ws.init(a.blob, a.blob_bytes, lds, wave, lane);
+    ws.dbg_nofetch = (a.dbg & 4) ? 1 : 0;
+    if ((int)blockIdx.x < n_tiles) ws.fetch_all(CB_L0);
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const bool more = tile + (int)gridDim.x < n_tiles;
@@ -103,124 +98,164 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         const int nn = valid ? n : a.n_pts - 1;
         const float p[3] = {a.pts[3 * nn], a.pts[3 * nn + 1], a.pts[3 * nn + 2]};
 
-        h8 xh[4], xl[4];      // X space fragments (lin0, colour lin0)
-        float x3f[8];         // fp32 values of X k-step 3 (its pad slot carries a4[192] into lin4)
+        // X space fragments (lin0, lin4 skip, colour lin0).  The full kernel parks them in the stash
+        // between uses (40 registers over ~150 chunks); the sdf-only kernel has room to keep them.
+        h8 xh[4], xl[4];
         {
             float f[4][8];
             encode_x(p, h, f);
 #pragma unroll
             for (int s = 0; s < 4; ++s) split8(f[s], xh[s], xl[s]);
+            if constexpr (FULL) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x3f[k] = f[3][k];
+                for (int s = 0; s < 4; ++s) stash_frag(slot(OS_X), s, xh[s], xl[s], lane);
+            }
         }
         h8 ah[16], al[16], bh[16], bl[16];   // ping-pong activation fragments
-
-        // ---- lin0: X -> a1 (2 chunks of 4 tiles) ------------------------------------------------
-        static_for<2>([&](auto C) {
-            constexpr int c = decltype(C)::value;
-            const char* buf = ws.acquire(c == 0 ? CB_L0 : CB_HID);
-            static_for<4>([&](auto TI) {
-                constexpr int ti = decltype(TI)::value;
-                constexpr int t = 4 * c + ti;
-                f32x16 c1 = tail_tile(buf + 16 * KS_BYTES, ti, h), c2 = zero16();
-                mma_tile<4, 0>(buf + ti * 4 * KS_BYTES, xh, xl, c1, c2, lane);
-                f32x16 z = combine(c1, c2);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) z[i] = softplus100(z[i]);
-                if (FULL && !(a.dbg & 1)) stash_tile(slot(OS_A1 + 0), t, z, lane);
-                split_tile(z, ah[2 * t], al[2 * t], ah[2 * t + 1], al[2 * t + 1]);
-            });
-        });
-
         struct Act {
             f32x16 v;
         };
         auto no_pre = [](auto, const char*) { return NoData{}; };
-        // softplus layer: a_{l+1} = softplus(z) -> stash (reverse sweep) + next layer's fragments
-        auto softplus_to = [&](h8(&oh)[16], h8(&ol)[16], int stash_slot) {
-            return [&oh, &ol, stash_slot, &slot, lane, &a](auto T, f32x16 z, NoData) {
+        auto no_store = [](auto, const auto&) {};
+        struct Frags {
+            h8 hi[2], lo[2];
+        };
+        // fragments of the finished tile -> the next layer's input registers
+        auto to_regs = [&](h8(&oh)[16], h8(&ol)[16]) {
+            return [&oh, &ol](auto T, EpiState& st, const auto&) {
                 constexpr int t = decltype(T)::value;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) z[i] = softplus100(z[i]);
-                if (FULL && !(a.dbg & 1)) stash_tile(slot(stash_slot), t, z, lane);
-                split_tile(z, oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
+                asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                oh[2 * t] = st.hi[0];
+                ol[2 * t] = st.lo[0];
+                oh[2 * t + 1] = st.hi[1];
+                ol[2 * t + 1] = st.lo[1];
+                return NoData{};
+            };
+        };
+        // ... and, in the full kernel, the fp32 activation to the stash for the reverse sweep
+        auto to_regs_keep = [&](h8(&oh)[16], h8(&ol)[16], int stash_slot) {
+            return [&oh, &ol, stash_slot, &slot, lane, &a](auto T, EpiState& st, const auto&) {
+                constexpr int t = decltype(T)::value;
+                asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                oh[2 * t] = st.hi[0];
+                ol[2 * t] = st.lo[0];
+                oh[2 * t + 1] = st.hi[1];
+                ol[2 * t + 1] = st.lo[1];
+                if (FULL && !(a.dbg & 1)) stash_tile(slot(stash_slot), t, st.v, lane);
+                return NoData{};
+            };
+        };
+        auto stash_frags = [&](int stash_slot) {
+            return [stash_slot, &slot, lane](auto T, const Frags& f) {
+                constexpr int t = decltype(T)::value;
+                stash_frag(slot(stash_slot), 2 * t, f.hi[0], f.lo[0], lane);
+                stash_frag(slot(stash_slot), 2 * t + 1, f.hi[1], f.lo[1], lane);
             };
         };
 
-        run_layer<8, 16, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, softplus_to(bh, bl, OS_A1 + 1));   // lin1
-        run_layer<8, 16, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, softplus_to(ah, al, OS_A1 + 2));   // lin2
+        // ---- lin0: X -> a1 (2 chunks of 4 tiles x 4 k-steps)
+        {
+            h8 x16h[16], x16l[16];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                x16h[s] = xh[s];
+                x16l[s] = xl[s];
+            }
+            run_layer<8, 4, 4, true, true>(ws, CB_L0, CB_HID, x16h, x16l, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 0), no_store);
+        }
+        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, OS_A1 + 1), no_store);   // lin1
+        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 2), no_store);   // lin2
         // ---- lin3: 193 outputs = 7 tiles (tile 6 holds neuron 192 in row 0)
         float a4_192 = 0.f;
-        run_layer<7, 16, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, [&](auto T, f32x16 z, NoData) {
-            constexpr int t = decltype(T)::value;
+        run_layer<7, 16, 1, true, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, PhSoftplus{},
+                                        [&](auto T, EpiState& st, const auto&) {
+                                            constexpr int t = decltype(T)::value;
+                                            asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                                            if constexpr (t == 6) {
+                                                // rows 193..223 are padding (zero weights and bias give softplus(0)): drop them
 #pragma unroll
-            for (int i = 0; i < 16; ++i) z[i] = softplus100(z[i]);
-            if constexpr (t == 6) {
-                // rows 193..223 are padding (zero weights, zero bias give softplus(0)): drop them
-#pragma unroll
-                for (int i = 0; i < 16; ++i) z[i] = (i == 0 && h == 0) ? z[i] : 0.f;
-                a4_192 = z[0];
-            }
-            if (FULL && !(a.dbg & 1)) stash_tile(slot(OS_A1 + 3), t, z, lane);
-            if constexpr (t < 6) split_tile(z, bh[2 * t], bl[2 * t], bh[2 * t + 1], bl[2 * t + 1]);
-        });
+                                                for (int i = 0; i < 16; ++i) st.v[i] = (i == 0 && h == 0) ? st.v[i] : 0.f;
+                                                a4_192 = st.v[0];
+                                            } else {
+                                                bh[2 * t] = st.hi[0];
+                                                bl[2 * t] = st.lo[0];
+                                                bh[2 * t + 1] = st.hi[1];
+                                                bl[2 * t + 1] = st.lo[1];
+                                            }
+                                            if (FULL && !(a.dbg & 1)) stash_tile(slot(OS_A1 + 3), t, st.v, lane);
+                                            return NoData{};
+                                        },
+                                        no_store);
         // ---- lin4: [a4 (192 via k-steps 0..11) | X with a4[192] in its pad slot] / sqrt2
         {
             const float v192 = __shfl_xor(a4_192, 32, 64);   // half 1 receives half 0's value
-            float f3[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) f3[k] = x3f[k];
-            f3[7] = h ? v192 : x3f[7];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                bh[12 + s] = xh[s];
-                bl[12 + s] = xl[s];
+            for (int s = 0; s < 4; ++s) {
+                if constexpr (FULL) {
+                    unstash_frag(slot(OS_X), s, bh[12 + s], bl[12 + s], lane);
+                } else {
+                    bh[12 + s] = xh[s];
+                    bl[12 + s] = xl[s];
+                }
             }
-            split8(f3, bh[15], bl[15]);
+            // the pad slot (k-step 3, half 1, element 7) carries a4[192]
+            const _Float16 vh = hi_part(v192);
+            const _Float16 vl = (_Float16)((v192 - (float)vh) * LO_SCALE);
+            bh[15][7] = h ? vh : bh[15][7];
+            bl[15][7] = h ? vl : bl[15][7];
         }
-        run_layer<8, 16, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, softplus_to(ah, al, OS_A1 + 4));   // lin4
-        run_layer<8, 16, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, softplus_to(bh, bl, OS_A1 + 5));   // lin5
-        run_layer<8, 16, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, softplus_to(ah, al, OS_A1 + 6));   // lin6
+        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 4), no_store);   // lin4
+        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, OS_A1 + 5), no_store);   // lin5
+        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 6), no_store);   // lin6
         // ---- lin7 -> a8; sdf = W8[0,:] a8 + b8; seed of the reverse sweep dz7 = sigma'(z7) W8[0,:] / scale
         float sdf_acc = 0.f;
-        run_layer<8, 16, true>(
+        run_layer<8, 16, 1, true, true>(
             ws, CB_HID, FULL ? CB_HID : (more ? CB_L0 : 0), ah, al, lane, h,
-            [&](auto, const char* tail) { return Act{tail_tile(tail, 1, h)}; },
-            [&](auto T, f32x16 z, const Act& w8) {
+            [&](auto, const char* tail) { return Act{tail_tile(tail, 1, h)}; }, PhSoftplus{},
+            [&](auto T, EpiState& st, const Act& w8) {
                 constexpr int t = decltype(T)::value;
+                asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
                 f32x16 dz;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    z[i] = softplus100(z[i]);
-                    sdf_acc = fmaf(w8.v[i], z[i], sdf_acc);
-                    dz[i] = dsoftplus_from_act(z[i]) * w8.v[i] * a.inv_scale;
+                    sdf_acc = fmaf(w8.v[i], st.v[i], sdf_acc);
+                    dz[i] = dsoftplus_from_act(st.v[i]) * w8.v[i] * (a.inv_scale * BWD_SCALE);
                 }
                 if (FULL) {
-                    split_tile(z, bh[2 * t], bl[2 * t], bh[2 * t + 1], bl[2 * t + 1]);   // a8 feeds lin8
-                    h8 dh0, dl0, dh1, dl1;
-                    split_tile(dz, dh0, dl0, dh1, dl1);
-                    stash_frag(slot(OS_DZ7), 2 * t, dh0, dl0, lane);
-                    stash_frag(slot(OS_DZ7), 2 * t + 1, dh1, dl1, lane);
+                    bh[2 * t] = st.hi[0];   // a8 feeds lin8
+                    bl[2 * t] = st.lo[0];
+                    bh[2 * t + 1] = st.hi[1];
+                    bl[2 * t + 1] = st.lo[1];
+                    Frags f;
+                    split_tile(dz, f.hi[0], f.lo[0], f.hi[1], f.lo[1]);
+                    stash_frags(OS_DZ7)(T, f);
                 }
-            });
+                return NoData{};
+            },
+            no_store);
         const float sdf = (half_sum(sdf_acc) + a.b8) * a.inv_scale;
         if (!FULL) {
             if (valid && h == 0) a.sdf[n] = sdf;
             continue;
         }
+        if (a.dbg & 8) {   // bisecting aid: stop after the forward pass (single tile per workgroup only)
+            if (valid && h == 0) a.sdf[n] = sdf;
+            return;
+        }
 
         // ---- lin8 rows 1..256: the feature vector (no activation) -> stash as fragments for colour lin0
-        run_layer<8, 16, true>(ws, CB_HID, CB_BWD, bh, bl, lane, h, no_pre, [&](auto T, f32x16 z, NoData) {
-            constexpr int t = decltype(T)::value;
-            if (a.feat != nullptr && valid) {
+        run_layer<8, 16, 1, true, true>(
+            ws, CB_HID, CB_BWD, bh, bl, lane, h, no_pre, PhIdentity{},
+            [&](auto T, EpiState& st, const auto&) {
+                constexpr int t = decltype(T)::value;
+                if (a.feat != nullptr && valid) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) a.feat[(size_t)n * H + 32 * t + tile_row(i, h)] = z[i];
-            }
-            h8 fh0, fl0, fh1, fl1;
-            split_tile(z, fh0, fl0, fh1, fl1);
-            stash_frag(slot(OS_FVEC), 2 * t, fh0, fl0, lane);
-            stash_frag(slot(OS_FVEC), 2 * t + 1, fh1, fl1, lane);
-        });
+                    for (int i = 0; i < 16; ++i) a.feat[(size_t)n * H + 32 * t + tile_row(i, h)] = st.v[i];
+                }
+                stash_frags(OS_FVEC)(T, Frags{{st.hi[0], st.hi[1]}, {st.lo[0], st.lo[1]}});
+                return NoData{};
+            },
+            no_store);
 
         // ---- reverse sweep: dz_{l-1} = sigma'(z_{l-1}) * (W_l^T dz_l); sigma' from the stashed activation a_l
         auto act_of = [&](int act_slot) {
@@ -229,62 +264,69 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 return Act{unstash_tile(slot(act_slot), decltype(T)::value, lane)};
             };
         };
-        auto dsig_to = [&](h8(&oh)[16], h8(&ol)[16]) {
-            return [&oh, &ol](auto T, f32x16 g, const Act& act) {
-                constexpr int t = decltype(T)::value;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) g[i] *= dsoftplus_from_act(act.v[i]);
-                split_tile(g, oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
-            };
-        };
 #pragma unroll
         for (int s = 0; s < 16; ++s) unstash_frag(slot(OS_DZ7), s, ah[s], al[s], lane);
-        run_layer<8, 16, false>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 6), dsig_to(bh, bl));   // W7^T -> dz6
-        run_layer<8, 16, false>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 5), dsig_to(ah, al));   // W6^T -> dz5
-        run_layer<8, 16, false>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 4),                     // W5^T -> dz4 (kept)
-                                [&](auto T, f32x16 g, const Act& act) {
-                                    constexpr int t = decltype(T)::value;
-#pragma unroll
-                                    for (int i = 0; i < 16; ++i) g[i] *= dsoftplus_from_act(act.v[i]);
-                                    split_tile(g, bh[2 * t], bl[2 * t], bh[2 * t + 1], bl[2 * t + 1]);
-                                    stash_frag(slot(OS_DZ4), 2 * t, bh[2 * t], bl[2 * t], lane);
-                                    stash_frag(slot(OS_DZ4), 2 * t + 1, bh[2 * t + 1], bl[2 * t + 1], lane);
-                                });
+        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 6), PhDsig{}, to_regs(bh, bl), no_store);   // W7^T -> dz6
+        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 5), PhDsig{}, to_regs(ah, al), no_store);   // W6^T -> dz5
+        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 4), PhDsig{},                          // W5^T -> dz4 (kept)
+                                         [&](auto T, EpiState& st, const auto&) {
+                                             constexpr int t = decltype(T)::value;
+                                             asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                                             bh[2 * t] = st.hi[0];
+                                             bl[2 * t] = st.lo[0];
+                                             bh[2 * t + 1] = st.hi[1];
+                                             bl[2 * t + 1] = st.lo[1];
+                                             stash_frags(OS_DZ4)(T, Frags{{st.hi[0], st.hi[1]}, {st.lo[0], st.lo[1]}});
+                                             return NoData{};
+                                         },
+                                         no_store);
         // W4[:, :193]^T: dz4 -> dz3 (193 rows = 7 tiles; a4's padding rows were stashed as 0 => sigma' = 0)
-        run_layer<7, 16, false>(ws, CB_BWD, CB_BWD3, bh, bl, lane, h, act_of(OS_A1 + 3), [&](auto T, f32x16 g, const Act& act) {
-            constexpr int t = decltype(T)::value;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) g[i] *= dsoftplus_from_act(act.v[i]);
-            if constexpr (t < 6) {
-                split_tile(g, ah[2 * t], al[2 * t], ah[2 * t + 1], al[2 * t + 1]);
-            } else {
-                h8 d0, d1;   // only k-step 12 exists (neuron 192); 13 is padding
-                split_tile(g, ah[12], al[12], d0, d1);
-            }
-        });
-        run_layer<8, 13, false>(ws, CB_BWD3, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 2), dsig_to(bh, bl));   // W3^T -> dz2
-        run_layer<8, 16, false>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 1), dsig_to(ah, al));    // W2^T -> dz1
-        run_layer<8, 16, false>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 0), dsig_to(bh, bl));    // W1^T -> dz0
+        run_layer<7, 16, 1, false, true>(ws, CB_BWD, CB_BWD3, bh, bl, lane, h, act_of(OS_A1 + 3), PhDsig{},
+                                         [&](auto T, EpiState& st, const auto&) {
+                                             constexpr int t = decltype(T)::value;
+                                             asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                                             if constexpr (t < 6) {
+                                                 ah[2 * t] = st.hi[0];
+                                                 al[2 * t] = st.lo[0];
+                                                 ah[2 * t + 1] = st.hi[1];
+                                                 al[2 * t + 1] = st.lo[1];
+                                             } else {
+                                                 ah[12] = st.hi[0];   // only k-step 12 exists (neuron 192); 13 is padding
+                                                 al[12] = st.lo[0];
+                                             }
+                                             return NoData{};
+                                         },
+                                         no_store);
+        run_layer<8, 13, 1, false, true>(ws, CB_BWD3, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 2), PhDsig{}, to_regs(bh, bl), no_store);   // W3^T -> dz2
+        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 1), PhDsig{}, to_regs(ah, al), no_store);    // W2^T -> dz1
+        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 0), PhDsig{}, to_regs(bh, bl), no_store);    // W1^T -> dz0
         // d sdf / d X-space = W0^T dz0 + W4[:, 193:]^T dz4   (64 rows = 2 tiles; row <-> k-slot of the same lane)
         f32x16 G1[2] = {zero16(), zero16()}, G2[2] = {zero16(), zero16()};
         static_for<2>([&](auto U) {
             constexpr int u = decltype(U)::value;
-            const char* buf = ws.acquire(CB_BWD);
-            mma_tile<16, 0>(buf, bh, bl, G1[u], G2[u], lane);
+            const char* buf = ws.template acquire<0>();
+            ws.begin(CB_BWD);
+            mma_tile<16, 0, true>(ws, buf, bh, bl, G1[u], G2[u], lane);
         });
 #pragma unroll
         for (int s = 0; s < 16; ++s) unstash_frag(slot(OS_DZ4), s, ah[s], al[s], lane);
         static_for<2>([&](auto U) {
             constexpr int u = decltype(U)::value;
-            const char* buf = ws.acquire(u == 0 ? CB_BWD : CB_C0A);
-            mma_tile<16, 0>(buf, ah, al, G1[u], G2[u], lane);
+            const char* buf = ws.template acquire<0>();
+            ws.begin(u == 0 ? CB_BWD : CB_C0A);
+            mma_tile<16, 0, true>(ws, buf, ah, al, G1[u], G2[u], lane);
         });
         // ---- Jacobian of the encoding (in-lane: G row of tile u, register 8(s&1)+j <-> k-slot (s = 2u + .., h, j))
         float g[3] = {0.f, 0.f, 0.f};
         {
             float f[4][8];
             encode_x(p, h, f);
-            const f32x16 G0 = combine(G1[0], G2[0]), Gb = combine(G1[1], G2[1]);
+            f32x16 G0 = combine(G1[0], G2[0]), Gb = combine(G1[1], G2[1]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                G0[i] *= BWD_INV;
+                Gb[i] *= BWD_INV;
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float fr = 1.f;
@@ -315,10 +357,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         h8 mh[8], ml[8];   // the 8 k-steps of chunk B: X (4), enc(d) (2), enc(g) (2)
         {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                mh[s] = xh[s];
-                ml[s] = xl[s];
-            }
+            for (int s = 0; s < 4; ++s) unstash_frag(slot(OS_X), s, mh[s], ml[s], lane);
             float fd[2][8], fg[2][8];
             encode_v4(d, h, fd);
             encode_v4(g, h, fg);
@@ -329,42 +368,74 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) unstash_frag(slot(OS_FVEC), s, ah[s], al[s], lane);
-        static_for<8>([&](auto T) {
-            constexpr int t = decltype(T)::value;
-            const char* bufa = ws.acquire(CB_C0B);
-            f32x16 c1 = zero16(), c2 = zero16();
-            mma_tile<16, 0>(bufa, ah, al, c1, c2, lane);
-            const char* bufb = ws.acquire(t + 1 < 8 ? CB_C0A : CB_HID);
-            const f32x16 bias = tail_tile(bufb + 8 * KS_BYTES, 0, h);
-            mma_tile<8, 0>(bufb, mh, ml, c1, c2, lane);
-            f32x16 z = combine(c1, c2);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) z[i] = fmaxf(z[i] + bias[i], 0.f);
-            split_tile(z, bh[2 * t], bl[2 * t], bh[2 * t + 1], bl[2 * t + 1]);
-        });
-        auto relu_to = [&](h8(&oh)[16], h8(&ol)[16]) {
-            return [&oh, &ol](auto T, f32x16 z, NoData) {
+        {
+            // two chunks per tile (16 feature-vector k-steps, then 8 encoding k-steps + bias); the epilogue of
+            // tile t-1 rides on chunk A's MFMAs of tile t
+            f32x16 c1[2], c2[2];
+            EpiState st;
+            NoData nd;
+            PhRelu relu;
+            auto put = [&](auto T) {
                 constexpr int t = decltype(T)::value;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) z[i] = fmaxf(z[i], 0.f);
-                split_tile(z, oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
+                asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                bh[2 * t] = st.hi[0];
+                bl[2 * t] = st.lo[0];
+                bh[2 * t + 1] = st.hi[1];
+                bl[2 * t + 1] = st.lo[1];
             };
-        };
-        run_layer<8, 16, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, relu_to(ah, al));   // colour lin1
-        run_layer<8, 16, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, relu_to(bh, bl));   // colour lin2
+            static_for<8>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                const char* bufa = ws.template acquire<0>();
+                ws.begin(CB_C0B);
+                arm(st);
+                if constexpr (t > 0) {
+                    st.c1 = c1[(t - 1) & 1];
+                    st.c2 = c2[(t - 1) & 1];
+                }
+                c1[t & 1] = zero16();
+                c2[t & 1] = zero16();
+                if constexpr (t > 0) {
+                    Epi<true, PhRelu, NoData> epi{st, relu, nd};
+                    mma_tile<16, 0, true>(ws, bufa, ah, al, c1[t & 1], c2[t & 1], lane, epi);
+                    split_finish<true>(st);
+                    put(std::integral_constant<int, t - 1>{});
+                } else {
+                    mma_tile<16, 0, true>(ws, bufa, ah, al, c1[t & 1], c2[t & 1], lane);
+                }
+                const char* bufb = ws.template acquire<0>();
+                ws.begin(t + 1 < 8 ? CB_C0A : CB_HID);
+                const f32x16 bias = tail_tile(bufb + 8 * KS_BYTES, 0, h);
+                mma_tile<8, 0, true>(ws, bufb, mh, ml, c1[t & 1], c2[t & 1], lane);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) c1[t & 1][i] += bias[i];
+            });
+            arm(st);
+            st.c1 = c1[1];
+            st.c2 = c2[1];
+            Epi<true, PhRelu, NoData> epi{st, relu, nd};
+            epi.run_all();
+            split_finish<true>(st);
+            put(std::integral_constant<int, 7>{});
+        }
+        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, PhRelu{}, to_regs(ah, al), no_store);   // colour lin1
+        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, PhRelu{}, to_regs(bh, bl), no_store);   // colour lin2
         float rgb[3] = {0.f, 0.f, 0.f};
         struct W3 {
             f32x16 w[3];
         };
-        run_layer<8, 16, true>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
+        run_layer<8, 16, 1, true, false>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
             ws, CB_HID, more ? CB_L0 : 0, bh, bl, lane, h,
             [&](auto, const char* tail) { return W3{{tail_tile(tail, 1, h), tail_tile(tail, 2, h), tail_tile(tail, 3, h)}}; },
-            [&](auto, f32x16 z, const W3& w) {
+            PhRelu{},
+            [&](auto, EpiState& st, const W3& w) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) rgb[c] = fmaf(w.w[c][i], fmaxf(z[i], 0.f), rgb[c]);
-            });
+                    for (int i = 0; i < 16; ++i) rgb[c] = fmaf(w.w[c][i], st.v[i], rgb[c]);
+                asm volatile("" : "+v"(rgb[0]), "+v"(rgb[1]), "+v"(rgb[2]));
+                return NoData{};
+            },
+            no_store);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_fast(half_sum(rgb[c]) + a.c_blast[c]);
         if (valid && h == 0) {

@@ -40,6 +40,11 @@ constexpr int TAIL_BYTES = 1024;          // 256 floats of side data
 constexpr int CHUNK_MAX = 16 * KS_BYTES + TAIL_BYTES;   // 33 KiB
 constexpr float LO_SCALE = 2048.f;
 constexpr float LO_INV = 1.f / 2048.f;
+// The reverse sweep carries d sdf / d z scaled by 2^8 (exact): its entries are small in ABSOLUTE terms
+// (1e-5 .. 1e-2), and whatever falls below the fp16 normal range keeps only the 11 bits of the lo part
+// (see hi_part); scaled, that floor drops to 2.4e-7 while |dz| < 255 stays clear of fp16 overflow.
+constexpr float BWD_SCALE = 256.f;
+constexpr float BWD_INV = 1.f / 256.f;
 constexpr int WG_WAVES = 4;
 constexpr int WG_SAMPLES = 32 * WG_WAVES;
 
@@ -47,41 +52,93 @@ __host__ __device__ constexpr int chunk_bytes(int tiles, int ks, bool tail) {
     return tiles * ks * KS_BYTES + (tail ? TAIL_BYTES : 0);
 }
 
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
 // ---- weight stream ---------------------------------------------------------------------------
+// The stream is cyclic (after the last chunk of a sample tile comes the first again) and is read
+// through a buffer descriptor: buffer_load_dwordx4 ... offen lds with a scalar byte offset per 1 KiB
+// piece and M0 as the LDS destination -- two SALU instructions and one VMEM instruction per piece, no
+// 64-bit vector address arithmetic.  Piece p of a chunk is fetched by wave p % 4.
+//
+// Protocol per chunk i (all waves run the same sequence):
+//   acquire()       s_waitcnt vmcnt(0): this wave's pieces of chunk i have landed; s_barrier: everybody's
+//                   pieces landed, everybody finished reading chunk i-1
+//   begin(bytes)    chunk i+1 goes to the other buffer ...
+//   piece(k)        ... one 1 KiB piece at a time, spread over the MFMA slots of chunk i by mma_tile
 struct WStream {
-    const char* g;      // global address of the next chunk to fetch
-    const char* begin;  // the stream is cyclic: after the last chunk of a sample tile comes the first again
-    const char* end;
+    __amdgpu_buffer_rsrc_t rsrc;
+    int total;          // stream bytes
+    int goff;           // byte offset of the next chunk to fetch
     char* lds;          // two buffers of CHUNK_MAX bytes
     int phase;          // buffer that receives the next fetch
-    int wave, lane;
+    int wave, voff;     // wave id (uniform), lane * 16
+    // the fetch in progress
+    int f_goff, f_pieces;
+    char* f_dst;
+    int dbg_nofetch;    // timing experiments only
 
-    __device__ __forceinline__ void fetch(int bytes) {
-        if (g == end) g = begin;
-        char* dst = lds + phase * CHUNK_MAX;
-        const int pieces = bytes >> 10;
-        for (int p = wave; p < pieces; p += WG_WAVES)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (size_t)p * 1024 + lane * 16), (lds_void_t*)(dst + p * 1024),
-                                             16, 0, 0);
-        g += bytes;
+    __device__ __forceinline__ void init(const char* blob, size_t bytes, char* lds_base, int wave_, int lane) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(blob), 0, (int)bytes, 0x00020000);
+        total = (int)bytes;
+        goff = 0;
+        lds = lds_base;
+        phase = 0;
+        wave = wave_;
+        voff = lane * 16;
+        f_pieces = 0;
+        f_goff = 0;
+        f_dst = lds_base;
+        dbg_nofetch = 0;
+    }
+    __device__ __forceinline__ void begin(int bytes) {
+        if (goff == total) goff = 0;
+        f_goff = goff + wave * 1024;
+        f_dst = lds + phase * CHUNK_MAX + wave * 1024;
+        f_pieces = dbg_nofetch ? 0 : ((bytes >> 10) + WG_WAVES - 1 - wave) / WG_WAVES;   // pieces of this wave
+        goff += bytes;
         phase ^= 1;
     }
-    // Publishes the chunk fetched last (all waves' pieces) and starts the fetch of the following
-    // one (next_bytes == 0: nothing to fetch).  Returns the LDS address of the published chunk.
-    __device__ __forceinline__ const char* acquire(int next_bytes) {
-        __syncthreads();   // s_waitcnt vmcnt(0) + s_barrier: my pieces landed, everybody is done with the other buffer
-        const char* cur = lds + (phase ^ 1) * CHUNK_MAX;
-        if (next_bytes > 0) fetch(next_bytes);
-        return cur;
+    // k-th piece of this wave (k < 9: a chunk has at most 33 pieces)
+    __device__ __forceinline__ void piece(int k) {
+        if (k < f_pieces)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(f_dst + k * 4096), 16, voff, f_goff + k * 4096, 0, 0);
+    }
+    __device__ __forceinline__ void fetch_all(int bytes) {
+        begin(bytes);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) piece(k);
+    }
+    template <int ALLOW>
+    __device__ __forceinline__ const char* acquire() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        return lds + (phase ^ 1) * CHUNK_MAX;
     }
 };
+constexpr int MAX_PIECES_PER_WAVE = 9;
 
 // ---- fragments -------------------------------------------------------------------------------
+// hi part of the split on the DEVICE.  Values below the fp16 normal range (2^-14) get hi = 0 and go
+// entirely into the scaled lo part (11 significant bits, absolute error < 1.5e-8): the MFMA reads an fp16
+// subnormal as its IEEE value, but the conversions back to fp32 that form the residual (plain, SDWA or
+// mix forms, the compiler's choice) do not all agree on subnormals -- measured: a hi part read as x by
+// the matrix pipe and as 0 by the residual is an error of up to 6e-5 per element.  (The host-side weight
+// packer converts with IEEE semantics and needs no such rule.)
+__host__ __device__ __forceinline__ _Float16 hi_part(float x) {
+    return (x < 6.103515625e-5f && x > -6.103515625e-5f) ? (_Float16)0.f : (_Float16)x;
+}
 // fp16 hi / scaled-lo split of 8 fp32 values (one B fragment)
 __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const _Float16 hj = (_Float16)x[j];
+        const _Float16 hj = hi_part(x[j]);
         hi[j] = hj;
         lo[j] = (_Float16)((x[j] - (float)hj) * LO_SCALE);
     }
@@ -92,6 +149,9 @@ __device__ __forceinline__ void split_tile(const f32x16& a, h8& hi0, h8& lo0, h8
     const float x1[8] = {a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]};
     split8(x0, hi0, lo0);
     split8(x1, hi1, lo1);
+    // keep the conversion where it is written (beside the next tile's MFMAs) instead of letting the
+    // compiler sink it to the fragments' first use one layer later
+    asm volatile("" : "+v"(hi0), "+v"(lo0), "+v"(hi1), "+v"(lo1));
 }
 // fp32 value back from a stored fragment element
 __device__ __forceinline__ float unsplit(_Float16 hi, _Float16 lo) { return fmaf((float)lo, LO_INV, (float)hi); }
@@ -100,19 +160,54 @@ __device__ __forceinline__ f32x16 mfma16(const h8& a, const h8& b, const f32x16&
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// c1/c2 += W[tile rows, KS k-steps] * x[S0 .. S0+KS)  -- `blk` points at the tile's first k-step block in LDS
-template <int KS, int S0, int NX>
-__device__ __forceinline__ void mma_tile(const char* blk, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16& c1, f32x16& c2,
-                                         int lane) {
+// c1/c2 += W[tile rows, KS k-steps] * x[S0 .. S0+KS)  -- `blk` points at the tile's first k-step block in LDS.
+// Hand-scheduled: the two A fragments of k-step s+2 are read from LDS before the MFMAs of k-step s (LDS
+// latency ~100+ cycles against 96 MFMA cycles per k-step), and after each MFMA one slice of `epi` -- the
+// element-wise epilogue of the PREVIOUS tile -- is issued, so that the VALU work runs in the shadow of the
+// matrix pipe.  sched_barrier(0) pins this order (the compiler's own placement serialises the two).
+struct NoEpi {
+    template <int Q, int NQ>
+    __device__ __forceinline__ void run() {}
+};
+// FETCH: the DMA pieces of the next chunk are issued from this tile's MFMA slots (one piece per
+// stride of slots, all within the first ~half of the tile so that they land before the next barrier)
+template <int KS, int S0, bool FETCH, int NX, typename Epi>
+__device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16& c1,
+                                         f32x16& c2, int lane, Epi& epi) {
     static_assert(S0 + KS <= NX, "k-step range");
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const h8 ah = *reinterpret_cast<const h8*>(blk + s * KS_BYTES + lane * 16);
-        const h8 al = *reinterpret_cast<const h8*>(blk + s * KS_BYTES + 1024 + lane * 16);
-        c1 = mfma16(ah, xh[S0 + s], c1);
-        c2 = mfma16(ah, xl[S0 + s], c2);
-        c2 = mfma16(al, xh[S0 + s], c2);
-    }
+    constexpr int NQ = 3 * KS;
+    constexpr int STRIDE = NQ >= 27 ? 3 : (NQ >= 18 ? 2 : 1);
+    static_assert(!FETCH || NQ >= MAX_PIECES_PER_WAVE, "not enough slots for the DMA pieces");
+    h8 ah[3], al[3];
+    auto load = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        ah[s % 3] = *reinterpret_cast<const h8*>(blk + s * KS_BYTES + lane * 16);
+        al[s % 3] = *reinterpret_cast<const h8*>(blk + s * KS_BYTES + 1024 + lane * 16);
+    };
+    auto slot = [&](auto Q_) {
+        constexpr int Q = decltype(Q_)::value;
+        if constexpr (FETCH && Q % STRIDE == STRIDE - 1 && Q / STRIDE < MAX_PIECES_PER_WAVE) ws.piece(Q / STRIDE);
+        epi.template run<Q, NQ>();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    load(std::integral_constant<int, 0>{});
+    if constexpr (KS > 1) load(std::integral_constant<int, 1>{});
+    static_for<KS>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        if constexpr (s + 2 < KS) load(std::integral_constant<int, s + 2>{});
+        c1 = mfma16(ah[s % 3], xh[S0 + s], c1);
+        slot(std::integral_constant<int, 3 * s>{});
+        c2 = mfma16(ah[s % 3], xl[S0 + s], c2);
+        slot(std::integral_constant<int, 3 * s + 1>{});
+        c2 = mfma16(al[s % 3], xh[S0 + s], c2);
+        slot(std::integral_constant<int, 3 * s + 2>{});
+    });
+}
+template <int KS, int S0, bool FETCH, int NX>
+__device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16& c1,
+                                         f32x16& c2, int lane) {
+    NoEpi e;
+    mma_tile<KS, S0, FETCH>(ws, blk, xh, xl, c1, c2, lane, e);
 }
 
 // tail helpers: 32 floats stored [half][16] so that lane half h reads its 16 rows as 4 float4
@@ -160,39 +255,184 @@ __device__ __forceinline__ float dsoftplus_from_act(float a) {
 __device__ __forceinline__ float sigmoid_fast(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // ---- a layer as a software pipeline over its output tiles ----------------------------------------
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
 struct NoData {};
 
-// OT output tiles, one chunk of KS k-steps (+ 1 KiB tail if TAIL, whose slot 0 is the tile's bias) each.
-// Step t: publish chunk t (barrier), start the DMA of the next one, fetch what tile t's epilogue will
-// need (`pre`, e.g. side data from the tail, stashed activations), issue the 3 KS MFMAs of tile t, and --
-// in the same scheduling region, so that VALU and MFMA overlap -- run the epilogue `post` of tile t-1.
-template <int OT, int KS, bool TAIL, typename Pre, typename Post>
-__device__ __forceinline__ void run_layer(WStream& ws, int cb_same, int next_after, const h8 (&xh)[16], const h8 (&xl)[16],
-                                          int lane, int h, Pre&& pre, Post&& post) {
+// Element-wise epilogue of one tile, cut into 48 phase calls (16 elements x 3 phases) that mma_tile
+// spreads over the next tile's MFMA slots.  Phases 0 and 1 are the layer's own (`ph(I, P, st, pd)` turns
+// the accumulator pair st.c1/st.c2 into st.v[I]); phase 2 is the fp16 hi/lo split of st.v into the two
+// B fragments st.hi/st.lo of the next layer (skipped when FRAGS is false).
+struct EpiState {
+    f32x16 c1, c2;   // the finished accumulators of the tile
+    f32x16 z, e;     // per-element temporaries carried from phase 0 to phase 1
+    f32x16 v;        // results
+    h8 hi[2], lo[2]; // fragments of k-steps 2t, 2t+1
+    float r0, r1;    // residuals of the pair being converted
+    float inv;       // 1/2048, laundered behind the tile's barrier: ties every phase-0 to this side of it
+};
+template <int I, bool FRAGS>
+__device__ __forceinline__ void split_phase(EpiState& st) {
+    if constexpr (FRAGS) {
+        constexpr int u = I >> 3, j = I & 7;
+        if constexpr ((I & 1) == 1) {
+            // hi halves of the pair (I-1, I) and their residuals
+            const _Float16 h0 = hi_part(st.v[I - 1]), h1 = hi_part(st.v[I]);
+            st.hi[u][j - 1] = h0;
+            st.hi[u][j] = h1;
+            st.r0 = st.v[I - 1] - (float)h0;
+            st.r1 = st.v[I] - (float)h1;
+        } else if constexpr (I >= 2) {
+            // scaled lo halves of the previous pair (I-2, I-1)
+            constexpr int up = (I - 2) >> 3, jp = (I - 2) & 7;
+            st.lo[up][jp] = (_Float16)(st.r0 * LO_SCALE);
+            st.lo[up][jp + 1] = (_Float16)(st.r1 * LO_SCALE);
+        }
+    }
+}
+template <bool FRAGS>
+__device__ __forceinline__ void split_finish(EpiState& st) {
+    if constexpr (FRAGS) {
+        st.lo[1][6] = (_Float16)(st.r0 * LO_SCALE);
+        st.lo[1][7] = (_Float16)(st.r1 * LO_SCALE);
+    }
+}
+template <bool FRAGS, typename Ph, typename PD>
+struct Epi {
+    EpiState& st;
+    Ph& ph;
+    const PD& pd;
+    // slots Q of NQ: phase calls [Q*48/NQ, (Q+1)*48/NQ)
+    template <int Q, int NQ>
+    __device__ __forceinline__ void run() {
+        constexpr int lo = Q * 48 / NQ, hi = (Q + 1) * 48 / NQ;
+        static_for<hi - lo>([&](auto K) {
+            constexpr int c = lo + decltype(K)::value;
+            constexpr int I = c / 3, P = c % 3;
+            if constexpr (P < 2)
+                ph(std::integral_constant<int, I>{}, std::integral_constant<int, P>{}, st, pd);
+            else
+                split_phase<I, FRAGS>(st);
+        });
+    }
+    __device__ __forceinline__ void run_all() {
+        static_for<48>([&](auto K) {
+            constexpr int c = decltype(K)::value;
+            constexpr int I = c / 3, P = c % 3;
+            if constexpr (P < 2)
+                ph(std::integral_constant<int, I>{}, std::integral_constant<int, P>{}, st, pd);
+            else
+                split_phase<I, FRAGS>(st);
+        });
+    }
+};
+
+// Ties the epilogue of the previous tile to this side of the barrier just passed: every phase 0 multiplies
+// by st.inv, which comes out of an opaque asm placed after the barrier.
+__device__ __forceinline__ void arm(EpiState& st) {
+    float inv = LO_INV;
+    asm volatile("" : "+v"(inv));
+    st.inv = inv;
+}
+
+// OT output tiles of KS k-steps; TPC tiles share one chunk (+ 1 KiB tail if TAIL, whose slot (t % TPC) is
+// the tile's bias).  Step t:
+//   - publish the chunk when t opens one (s_waitcnt vmcnt(0) + s_barrier);
+//   - `store(T-2, held)`: the global stores (stash) of tile t-2, deliberately one step late and in FRONT of
+//     this step's DMA pieces, so that the vmcnt(0) of the next barrier finds them long complete (VMEM
+//     completion is not ordered between stores and loads, a counted wait cannot skip them);
+//   - `pre(T, tail)`: what tile t's epilogue will need (side data from the tail, stashed activations);
+//   - the MFMAs of tile t with the DMA of the next chunk and the epilogue of tile t-1 in their shadow;
+//   - `held = fin(T-1, st, pd)`: the finished tile's fragments -> registers; returns what `store` needs.
+// next_same / next_after: bytes of the chunk that follows a chunk of this layer (another of the same
+// layer / the first of the next layer; 0 = none).
+template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, typename Pre, typename Ph, typename Fin, typename Store>
+__device__ __forceinline__ void run_layer(WStream& ws, int next_same, int next_after, const h8 (&xh)[16], const h8 (&xl)[16],
+                                          int lane, int h, Pre&& pre, Ph&& ph, Fin&& fin, Store&& store) {
     using I0 = std::integral_constant<int, 0>;
     using PD = decltype(pre(I0{}, (const char*)nullptr));
     f32x16 c1[2], c2[2];
     PD pd[2];
+    EpiState st;
+    using Held = decltype(fin(I0{}, st, pd[0]));
+    Held held;
+    const char* buf = nullptr;
     static_for<OT>([&](auto T) {
         constexpr int t = decltype(T)::value;
-        const char* buf = ws.acquire(t + 1 < OT ? cb_same : next_after);
-        const char* tail = buf + KS * KS_BYTES;
-        c1[t & 1] = TAIL ? tail_tile(tail, 0, h) : zero16();
+        constexpr bool opens = t % TPC == 0;
+        if constexpr (opens) buf = ws.template acquire<0>();
+        if constexpr (t >= 2) store(std::integral_constant<int, t - 2>{}, held);
+        if constexpr (opens) ws.begin(t + TPC < OT ? next_same : next_after);
+        const char* tail = buf + TPC * KS * KS_BYTES;
+        arm(st);
+        if constexpr (t > 0) {
+            st.c1 = c1[(t - 1) & 1];
+            st.c2 = c2[(t - 1) & 1];
+        }
+        c1[t & 1] = TAIL ? tail_tile(tail, t % TPC, h) : zero16();
         c2[t & 1] = zero16();
         pd[t & 1] = pre(T, tail);
-        mma_tile<KS, 0>(buf, xh, xl, c1[t & 1], c2[t & 1], lane);
-        if constexpr (t > 0)
-            post(std::integral_constant<int, t - 1>{}, combine(c1[(t - 1) & 1], c2[(t - 1) & 1]), pd[(t - 1) & 1]);
+        if constexpr (t > 0) {
+            Epi<FRAGS, std::remove_reference_t<Ph>, PD> epi{st, ph, pd[(t - 1) & 1]};
+            mma_tile<KS, 0, opens>(ws, buf + (t % TPC) * KS * KS_BYTES, xh, xl, c1[t & 1], c2[t & 1], lane, epi);
+            split_finish<FRAGS>(st);
+            held = fin(std::integral_constant<int, t - 1>{}, st, pd[(t - 1) & 1]);
+        } else {
+            mma_tile<KS, 0, opens>(ws, buf + (t % TPC) * KS * KS_BYTES, xh, xl, c1[t & 1], c2[t & 1], lane);
+        }
     });
-    post(std::integral_constant<int, OT - 1>{}, combine(c1[(OT - 1) & 1], c2[(OT - 1) & 1]), pd[(OT - 1) & 1]);
+    if constexpr (OT >= 2) store(std::integral_constant<int, OT - 2>{}, held);
+    arm(st);
+    st.c1 = c1[(OT - 1) & 1];
+    st.c2 = c2[(OT - 1) & 1];
+    Epi<FRAGS, std::remove_reference_t<Ph>, PD> epi{st, ph, pd[(OT - 1) & 1]};
+    epi.run_all();
+    split_finish<FRAGS>(st);
+    held = fin(std::integral_constant<int, OT - 1>{}, st, pd[(OT - 1) & 1]);
+    store(std::integral_constant<int, OT - 1>{}, held);
 }
+
+// standard phases ---------------------------------------------------------------------------------
+constexpr float K100 = 144.26950408889634f;      // 100 * log2(e)
+constexpr float C100 = 0.0069314718055994531f;   // ln(2) / 100
+// softplus(beta=100): v = max(z,0) + log2(1 + exp2(-|z| K100)) * C100
+struct PhSoftplus {
+    template <typename I_, typename P_, typename PD>
+    __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD&) const {
+        constexpr int I = I_::value, P = P_::value;
+        if constexpr (P == 0) {
+            st.z[I] = fmaf(st.c2[I], st.inv, st.c1[I]);
+            st.e[I] = __builtin_amdgcn_exp2f(-fabsf(st.z[I] * K100));
+        } else {
+            st.v[I] = fmaf(__builtin_amdgcn_logf(1.f + st.e[I]), C100, fmaxf(st.z[I], 0.f));
+        }
+    }
+};
+// reverse sweep: v = g * sigma'(z) with sigma' = 1 - exp(-100 a) from the stashed activation pd.v
+struct PhDsig {
+    template <typename I_, typename P_, typename PD>
+    __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD& pd) const {
+        constexpr int I = I_::value, P = P_::value;
+        if constexpr (P == 0) {
+            st.z[I] = fmaf(st.c2[I], st.inv, st.c1[I]);
+            st.e[I] = __builtin_amdgcn_exp2f(pd.v[I] * -K100);
+        } else {
+            st.v[I] = fmaf(st.z[I], -st.e[I], st.z[I]);
+        }
+    }
+};
+struct PhRelu {
+    template <typename I_, typename P_, typename PD>
+    __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD&) const {
+        constexpr int I = I_::value, P = P_::value;
+        if constexpr (P == 0) st.v[I] = fmaxf(fmaf(st.c2[I], st.inv, st.c1[I]), 0.f);
+    }
+};
+struct PhIdentity {
+    template <typename I_, typename P_, typename PD>
+    __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD&) const {
+        constexpr int I = I_::value, P = P_::value;
+        if constexpr (P == 0) st.v[I] = fmaf(st.c2[I], st.inv, st.c1[I]);
+    }
+};
 
 // ---- per-wave stash in global memory (slots of 32 KiB, every instruction moves 1 KiB) -----------
 constexpr size_t SLOT_F4 = 8 * 4 * 64;   // float4 per slot
@@ -235,7 +475,28 @@ __device__ __forceinline__ T* launder_uniform(T* p) {
     lo = __builtin_amdgcn_readfirstlane(lo);
     hi = __builtin_amdgcn_readfirstlane(hi);
     asm volatile("" : "+s"(lo), "+s"(hi));
-    return reinterpret_cast<T*>((static_cast<uintptr_t>(hi) << 32) | lo);
+    // rebuilt as a GLOBAL pointer: from a bare integer the compiler would fall back to flat_* accesses
+    typedef __attribute__((address_space(1))) T* gptr_t;
+    return (T*)(gptr_t)((static_cast<uintptr_t>(hi) << 32) | lo);
+}
+
+// sin and cos of arguments up to ~1e4 rad (the encodings reach 2^9 |x|): 3-term Cody-Waite reduction by
+// pi/2 with FMAs (exact product k * pi/2 to ~2^-70), then the cephes minimax polynomials on [-pi/4, pi/4].
+// ~1 ulp, branch-free, no scratch (ocml's sincosf carries a Payne-Hanek path with a private table).
+__device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
+    const float kf = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(kf, -1.57079637050628662109375f, x);
+    r = fmaf(kf, 4.37113900018624283e-8f, r);
+    r = fmaf(kf, 1.71512449965966931e-15f, r);
+    const float r2 = r * r;
+    const float sp = fmaf(r * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                          fmaf(r2, -0.5f, 1.f));
+    const int k = (int)kf;
+    const float ss = (k & 1) ? cp : sp;
+    const float cc = (k & 1) ? sp : cp;
+    s = (k & 2) ? -ss : ss;
+    c = ((k + 1) & 2) ? -cc : cc;
 }
 
 __device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }

@@ -53,7 +53,7 @@ struct Builder {
                         const int col = colslot[s * 16 + 8 * h + j];
                         float x = 0.f;
                         if (row >= 0 && col >= 0) x = (transposed ? M.at(col, row) : M.at(row, col)) * scale;
-                        const _Float16 xh = (_Float16)x;
+                        const _Float16 xh = (_Float16)x;   // IEEE, subnormals kept: the MFMA reads them as such
                         hi[l * 8 + j] = xh;
                         lo[l * 8 + j] = (_Float16)((x - (float)xh) * LO_SCALE);
                     }
