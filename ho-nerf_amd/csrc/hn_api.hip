@@ -44,6 +44,9 @@ namespace v2 {
 size_t field2_obj_workspace_bytes(int n_pts, int n_cus);
 int launch_field2_obj(const hn_field*, const float*, const float*, int, int, float*, float*, float*, float*, void*, size_t,
                       bool, hipStream_t);
+size_t field2_hand_workspace_bytes(int n_pts, int n_cus);
+int launch_field2_hand(const hn_field*, const float*, int, const float*, const float*, int, int, float*, float*, float*,
+                       float*, void*, size_t, bool, hipStream_t);
 }
 
 __global__ void k_scale(float* v, int n, float s) {
@@ -98,7 +101,8 @@ static int device_cus() {
 static size_t field_ws(const hn_field* f, int n_pts) {
     int cus = device_cus();
     if (cus <= 0) cus = 256;
-    if (f->precision == HN_PREC_F16X3 && f->kind == HN_FIELD_OBJ) return v2::field2_obj_workspace_bytes(n_pts, cus);
+    if (f->precision == HN_PREC_F16X3)
+        return f->kind == HN_FIELD_OBJ ? v2::field2_obj_workspace_bytes(n_pts, cus) : v2::field2_hand_workspace_bytes(n_pts, cus);
     return f->kind == HN_FIELD_OBJ ? field_obj_workspace_bytes(n_pts, cus) : field_hand_workspace_bytes(n_pts, cus);
 }
 
@@ -106,6 +110,8 @@ static int field_sdf(const hn_field* f, const float* pts, int n, const float* bt
                      float* sdf, void* ws, size_t ws_bytes, hipStream_t s) {
     if (f->precision == HN_PREC_F16X3 && f->kind == HN_FIELD_OBJ)
         return v2::launch_field2_obj(f, pts, nullptr, n, 1, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
+    if (f->precision == HN_PREC_F16X3)
+        return v2::launch_field2_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
     if (f->kind == HN_FIELD_OBJ) return launch_field_obj(f, pts, nullptr, n, 1, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
     return launch_field_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
 }
@@ -114,6 +120,8 @@ static int field_eval(const hn_field* f, const float* pts, const float* rays_d, 
                       size_t ws_bytes, hipStream_t s) {
     if (f->precision == HN_PREC_F16X3 && f->kind == HN_FIELD_OBJ)
         return v2::launch_field2_obj(f, pts, rays_d, n, spr, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
+    if (f->precision == HN_PREC_F16X3)
+        return v2::launch_field2_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
     if (f->kind == HN_FIELD_OBJ) return launch_field_obj(f, pts, rays_d, n, spr, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
     return launch_field_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
 }

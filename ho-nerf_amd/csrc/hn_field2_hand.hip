@@ -1,0 +1,644 @@
+// v2 hand field (f16x3 MFMA, LDS-streamed weights): per-bone local coordinates (anerf_emb_point) ->
+// 1386-wide masked encoding -> SDFNetwork forward, analytic d sdf / d p (reverse sweep + encoding
+// Jacobian) and RenderingNetwork, fused; 4 waves x 32 samples per workgroup, one workgroup per CU
+// (hn_mlp2.h).  The 1386 features are generated once per sample tile as MFMA B fragments (fp16 hi/lo),
+// parked in the wave's stash and streamed back for the three layers that consume them (lin0, the lin4
+// skip columns, colour lin0) and for the Jacobian.
+//
+// Reference: utils/fields.py:22-52 (bone coordinates), :132-177 (sdf net, .gradient), :222-240 (colour
+// net), called from utils/renderer.py:137-142 / 390-396.  The chunk order below is the contract with
+// hn_pack2.hip (build_hand_stream); the feature k-slot layout is bone_slots / left_slots there.
+#include <stdlib.h>
+
+#include "hn_mlp2.h"
+
+namespace hn {
+namespace v2 {
+
+__constant__ float c_cutoff2[N_BONES] = {0.08f, 0.03f, 0.03f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f,
+                                         0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f};
+constexpr float TAU2 = 200.f;
+
+struct Hand2Args {
+    const float* pts;      // [n,3]
+    const float* bt_inv;   // [n_frames,21,4,4]
+    const float* T_pose;   // [n_frames,21,3]
+    int n_pts;
+    int pts_per_frame;
+    int n_frames;
+    const char* blob;
+    size_t blob_bytes;
+    float b8;
+    float c_blast[3];
+    float* sdf;
+    float* grad;
+    float* rgb;
+    float* feat;
+    float4* scratch;
+    int dbg;
+};
+
+// stash slots of one wave (32 KiB each)
+enum {
+    HS_A1 = 0,      // a1..a7 -> 0..6 (fp32 activations for the reverse sweep)
+    HS_DZ7 = 7,     // fragments
+    HS_FVEC = 8,    // fragments
+    HS_DZ4 = 9,     // fragments
+    HS_A4F = 10,    // a4 as fragments (input of lin4's hidden part, needed in both passes)
+    HS_FEAT = 11,   // 87 k-step blocks of feature fragments (84 bone + 3 leftover) = 174 KiB -> 6 slots
+    HS_LEFT = 17,   // 21 x 64 floats: the leftover (r_1 | r_2) h values while the bones are generated
+    HAND2_SLOTS = 18,
+    HAND2_SLOTS_SDF = 18,
+};
+constexpr int FEAT_BLOCKS = 4 * N_BONES;     // first leftover block index
+
+constexpr int HB_HID = chunk_bytes(1, 16, true);
+constexpr int HB_BWD = chunk_bytes(1, 16, false);
+constexpr int HB_BONE = chunk_bytes(4, 4, false);
+constexpr int HB_LEFT_T = chunk_bytes(4, 3, true);    // leftover chunk with the 4 biases (lin0)
+constexpr int HB_LEFT = chunk_bytes(4, 3, false);
+constexpr int HB_G = chunk_bytes(4, 2, true);         // colour lin0: enc(g) columns + the 4 biases
+
+struct Bone2 {
+    float v, r[3], hh;
+};
+// utils/fields.py:26-35: q = R_b p + t_b - T_b; v = |q|; r = q / v; h = 1 - sigmoid(200 (v - cutoff_b))
+__device__ __forceinline__ Bone2 bone_coords2(const float p[3], const float* __restrict__ M, const float* __restrict__ Tp,
+                                              int b) {
+    Bone2 o;
+    const float* m = M + 16 * b;
+    const float q0 = m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3] - Tp[3 * b];
+    const float q1 = m[4] * p[0] + m[5] * p[1] + m[6] * p[2] + m[7] - Tp[3 * b + 1];
+    const float q2 = m[8] * p[0] + m[9] * p[1] + m[10] * p[2] + m[11] - Tp[3 * b + 2];
+    o.v = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+    o.r[0] = q0 / o.v;   // no epsilon: a sample on a joint is NaN, as in the reference (SURVEY B-10)
+    o.r[1] = q1 / o.v;
+    o.r[2] = q2 / o.v;
+    const float sg = 1.f / (1.f + expf(-TAU2 * (o.v - c_cutoff2[b])));
+    o.hh = 1.f - sg;
+    return o;
+}
+__device__ __forceinline__ float sc_half2(float ang, int h) {
+    float s, c;
+    sincos_cw(ang, s, c);
+    return h ? c : s;
+}
+// the 4 k-steps x 8 values of one bone for this lane (bone_slots in hn_pack2.hip), already times h
+__device__ __forceinline__ void bone_features2(const Bone2& bn, int h, float (&f)[4][8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[0][j] = sc_half2(bn.v * (float)(1 << j), h) * bn.hh;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) f[1][j] = sc_half2(bn.v * (float)(256 << j), h) * bn.hh;
+#pragma unroll
+    for (int j = 2; j < 8; ++j) f[1][j] = sc_half2(bn.r[0] * (float)(1 << (j - 2)), h) * bn.hh;
+    f[2][0] = sc_half2(bn.r[0] * 64.f, h) * bn.hh;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) f[2][j] = sc_half2(bn.r[1] * (float)(1 << (j - 1)), h) * bn.hh;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) f[3][j] = sc_half2(bn.r[2] * (float)(1 << j), h) * bn.hh;
+    f[3][7] = (h ? bn.r[0] : bn.v) * bn.hh;
+}
+__device__ __forceinline__ void encode_v4h(const float v[3], int h, float (&f)[2][8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[0][j] = sc_half2(v[j >> 2] * (float)(1 << (j & 3)), h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[1][j] = sc_half2(v[2] * (float)(1 << j), h);
+    f[1][4] = h ? v[2] : v[0];
+    f[1][5] = h ? 0.f : v[1];
+    f[1][6] = 0.f;
+    f[1][7] = 0.f;
+}
+
+// Encoding Jacobian of one bone's 64 main slots.  own[s][j] = this lane's stored feature (phi * h); its
+// partner lane (other half, same sample) stores the conjugate function (cos for sin) * h, so
+//   d(sin(f x) h)/dx = +f partner,  d(cos(f x) h)/dx = -f partner,  and every slot adds own * h'/h to d/dv
+// with h'/h = -tau sigmoid(tau (v - cutoff)) =: kk.  G0 covers k-steps 0,1 (register 8 s + j), G1 k-steps 2,3.
+__device__ __forceinline__ void bone_jacobian(const f32x16& G0, const f32x16& G1, const float (&own)[4][8], const Bone2& bn,
+                                              float kk, int h, float& Sv, float (&Sr)[3]) {
+    float sum_own = 0.f;   // sum G * own  (the h'/h term)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float Gv = (s < 2) ? G0[8 * s + j] : G1[8 * (s - 2) + j];
+            sum_own = fmaf(Gv, own[s][j], sum_own);
+            if (s == 3 && j == 7) {
+                // raw pair (v | r_0) h
+                Sv += h ? 0.f : Gv * bn.hh;
+                Sr[0] += h ? Gv * bn.hh : 0.f;
+                continue;
+            }
+            const float other = __shfl_xor(own[s][j], 32, 64);
+            // which variable / frequency this slot encodes
+            int var, k;   // var 0 = v, 1..3 = r_0..r_2
+            if (s == 0) {
+                var = 0;
+                k = j;
+            } else if (s == 1) {
+                var = j < 2 ? 0 : 1;
+                k = j < 2 ? 8 + j : j - 2;
+            } else if (s == 2) {
+                var = j < 1 ? 1 : 2;
+                k = j < 1 ? 6 : j - 1;
+            } else {
+                var = 3;
+                k = j;
+            }
+            const float fr = (float)(1 << k);
+            const float t = Gv * (h ? -fr : fr) * other;
+            if (var == 0)
+                Sv += t;
+            else
+                Sr[var - 1] += t;
+        }
+    Sv = fmaf(sum_own, kk, Sv);
+}
+// (Sv, Sr) of one bone -> d sdf / d p contribution: d/dq = Sv r + (Sr - (Sr.r) r) / v ; d/dp = R_b^T d/dq
+__device__ __forceinline__ void bone_to_p(float Sv, const float (&Sr)[3], const Bone2& q, const float* __restrict__ m,
+                                          float (&g)[3]) {
+    const float sv = half_sum(Sv);
+    const float sr0 = half_sum(Sr[0]), sr1 = half_sum(Sr[1]), sr2 = half_sum(Sr[2]);
+    const float dot = sr0 * q.r[0] + sr1 * q.r[1] + sr2 * q.r[2];
+    const float dq0 = sv * q.r[0] + (sr0 - dot * q.r[0]) / q.v;
+    const float dq1 = sv * q.r[1] + (sr1 - dot * q.r[1]) / q.v;
+    const float dq2 = sv * q.r[2] + (sr2 - dot * q.r[2]) / q.v;
+    g[0] += m[0] * dq0 + m[4] * dq1 + m[8] * dq2;
+    g[1] += m[1] * dq0 + m[5] * dq1 + m[9] * dq2;
+    g[2] += m[2] * dq0 + m[6] * dq1 + m[10] * dq2;
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    float4* wslot = a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * HAND2_SLOTS * SLOT_F4;
+    auto slot = [&](int i) { return wslot + (size_t)i * SLOT_F4; };
+    const int n_tiles = (a.n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
+
+    WStream ws;
+    ws.init(a.blob, a.blob_bytes, lds, wave, lane);
+    ws.dbg_nofetch = (a.dbg & 4) ? 1 : 0;
+    if ((int)blockIdx.x < n_tiles) ws.fetch_all(HB_BONE);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const bool more = tile + (int)gridDim.x < n_tiles;
+        wslot = launder_uniform(wslot);
+        const int n = tile * WG_SAMPLES + wave * 32 + j;
+        const bool valid = n < a.n_pts;
+        const int nn = valid ? n : a.n_pts - 1;
+        const float p[3] = {a.pts[3 * nn], a.pts[3 * nn + 1], a.pts[3 * nn + 2]};
+        int frame = nn / a.pts_per_frame;
+        frame = frame < a.n_frames ? frame : a.n_frames - 1;
+        const float* M = a.bt_inv + (size_t)frame * N_BONES * 16;
+        const float* Tp = a.T_pose + (size_t)frame * N_BONES * 3;
+        float4* const feat = slot(HS_FEAT);
+        float* const left = reinterpret_cast<float*>(slot(HS_LEFT));
+
+        // ---- F0: features of the 21 bones -> fragments in the stash -------------------------------------
+#pragma unroll 1
+        for (int b = 0; b < N_BONES; ++b) {
+            const Bone2 bn = bone_coords2(p, M, Tp, b);
+            float f[4][8];
+            bone_features2(bn, h, f);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                h8 fh, fl;
+                split8(f[s], fh, fl);
+                stash_frag(feat, 4 * b + s, fh, fl, lane);
+            }
+            left[b * 64 + lane] = (h ? bn.r[2] : bn.r[1]) * bn.hh;
+        }
+        {   // leftover block: element j of k-step u belongs to bone 8u + j
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                float f[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) f[jj] = (8 * u + jj < N_BONES) ? left[(8 * u + jj) * 64 + lane] : 0.f;
+                h8 fh, fl;
+                split8(f, fh, fl);
+                stash_frag(feat, FEAT_BLOCKS + u, fh, fl, lane);
+            }
+        }
+
+        h8 ah[16], al[16], bh[16], bl[16];   // ping-pong activation fragments
+        struct Act {
+            f32x16 v;
+        };
+        struct Frags {
+            h8 hi[2], lo[2];
+        };
+        auto no_pre = [](auto, const char*) { return NoData{}; };
+        auto no_store = [](auto, const auto&) {};
+        auto stash_frags = [&](int stash_slot) {
+            return [stash_slot, &slot, lane](auto T, const Frags& f) {
+                constexpr int t = decltype(T)::value;
+                stash_frag(slot(stash_slot), 2 * t, f.hi[0], f.lo[0], lane);
+                stash_frag(slot(stash_slot), 2 * t + 1, f.hi[1], f.lo[1], lane);
+            };
+        };
+        auto to_regs = [&](h8(&oh)[16], h8(&ol)[16]) {
+            return [&oh, &ol](auto T, EpiState& st, const auto&) {
+                constexpr int t = decltype(T)::value;
+                asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                oh[2 * t] = st.hi[0];
+                ol[2 * t] = st.lo[0];
+                oh[2 * t + 1] = st.hi[1];
+                ol[2 * t + 1] = st.lo[1];
+                return NoData{};
+            };
+        };
+        auto to_regs_keep = [&](h8(&oh)[16], h8(&ol)[16], int stash_slot) {
+            return [&oh, &ol, stash_slot, &slot, lane](auto T, EpiState& st, const auto&) {
+                constexpr int t = decltype(T)::value;
+                asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                oh[2 * t] = st.hi[0];
+                ol[2 * t] = st.lo[0];
+                oh[2 * t + 1] = st.hi[1];
+                ol[2 * t + 1] = st.lo[1];
+                if (FULL) stash_tile(slot(stash_slot), t, st.v, lane);
+                return NoData{};
+            };
+        };
+
+        // ---- a block of 4 output tiles over the feature space: 21 bone chunks + the leftover chunk ------
+        // c1/c2[ti] += W[tile 4p+ti, features] * feat.  Bone b+1's fragments are loaded while bone b's
+        // MFMAs run.  Returns the leftover chunk's LDS address (its tail holds side data for some layers).
+        auto feature_pass = [&](f32x16(&c1)[4], f32x16(&c2)[4], int left_bytes, int next_after) -> const char* {
+            h8 fh[2][4], fl[2][4];
+            auto load_bone = [&](int b, h8(&oh)[4], h8(&ol)[4]) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) unstash_frag(feat, 4 * b + s, oh[s], ol[s], lane);
+            };
+            auto step = [&](int b, const h8(&uh)[4], const h8(&ul)[4], h8(&nh)[4], h8(&nl)[4]) {
+                const char* buf = ws.template acquire<0>();
+                ws.begin(b + 1 < N_BONES ? HB_BONE : left_bytes);
+                load_bone(b + 1, nh, nl);   // b + 1 == 21: the leftover blocks 84..86 (+ one unused)
+                static_for<4>([&](auto TI) {
+                    constexpr int ti = decltype(TI)::value;
+                    if constexpr (ti == 0)
+                        mma_tile<4, 0, true>(ws, buf + ti * 4 * KS_BYTES, uh, ul, c1[ti], c2[ti], lane);
+                    else
+                        mma_tile<4, 0, false>(ws, buf + ti * 4 * KS_BYTES, uh, ul, c1[ti], c2[ti], lane);
+                });
+            };
+            load_bone(0, fh[0], fl[0]);
+#pragma unroll 1
+            for (int b2 = 0; b2 < N_BONES / 2; ++b2) {
+                step(2 * b2, fh[0], fl[0], fh[1], fl[1]);
+                step(2 * b2 + 1, fh[1], fl[1], fh[0], fl[0]);
+            }
+            step(N_BONES - 1, fh[0], fl[0], fh[1], fl[1]);
+            const char* buf = ws.template acquire<0>();
+            ws.begin(next_after);
+            static_for<4>([&](auto TI) {
+                constexpr int ti = decltype(TI)::value;
+                if constexpr (ti == 0)
+                    mma_tile<3, 0, true>(ws, buf + ti * 3 * KS_BYTES, fh[1], fl[1], c1[ti], c2[ti], lane);
+                else
+                    mma_tile<3, 0, false>(ws, buf + ti * 3 * KS_BYTES, fh[1], fl[1], c1[ti], c2[ti], lane);
+            });
+            return buf;
+        };
+        // epilogue of a finished block (not overlapped with MFMAs): ph / fin as in run_layer
+        auto block_epilogue = [&](auto P_, f32x16(&c1)[4], f32x16(&c2)[4], auto&& ph, auto&& fin) {
+            constexpr int pass = decltype(P_)::value;
+            static_for<4>([&](auto TI) {
+                constexpr int ti = decltype(TI)::value;
+                EpiState st;
+                arm(st);
+                st.c1 = c1[ti];
+                st.c2 = c2[ti];
+                NoData nd;
+                Epi<true, std::remove_reference_t<decltype(ph)>, NoData> epi{st, ph, nd};
+                epi.run_all();
+                split_finish<true>(st);
+                fin(std::integral_constant<int, 4 * pass + ti>{}, st, nd);
+            });
+        };
+
+        // ---- lin0: features -> a1 -------------------------------------------------------------------------
+        static_for<2>([&](auto P_) {
+            constexpr int pass = decltype(P_)::value;
+            f32x16 c1[4], c2[4];
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+                c1[ti] = zero16();
+                c2[ti] = zero16();
+            }
+            const char* lbuf = feature_pass(c1, c2, HB_LEFT_T, pass == 0 ? HB_BONE : HB_HID);
+            const char* tail = lbuf + 4 * 3 * KS_BYTES;
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+                const f32x16 bias = tail_tile(tail, ti, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) c1[ti][i] += bias[i];
+            }
+            block_epilogue(P_, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 0));
+        });
+        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 1), no_store);   // lin1
+        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 2), no_store);   // lin2
+        // lin3 -> a4: kept as fragments in the stash too (lin4's hidden part reads them in both passes)
+        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhSoftplus{},
+                                        [&](auto T, EpiState& st, const auto&) {
+                                            constexpr int t = decltype(T)::value;
+                                            if (FULL) stash_tile(slot(HS_A1 + 3), t, st.v, lane);
+                                            stash_frags(HS_A4F)(T, Frags{{st.hi[0], st.hi[1]}, {st.lo[0], st.lo[1]}});
+                                            return NoData{};
+                                        },
+                                        no_store);
+        // ---- lin4 = [a4 | features] / sqrt2 -> a5: per pass 4 hidden tiles, then the feature block
+        static_for<2>([&](auto P_) {
+            constexpr int pass = decltype(P_)::value;
+            f32x16 c1[4], c2[4];
+            {
+                h8 xh[16], xl[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) unstash_frag(slot(HS_A4F), s, xh[s], xl[s], lane);
+                static_for<4>([&](auto TI) {
+                    constexpr int ti = decltype(TI)::value;
+                    const char* buf = ws.template acquire<0>();
+                    ws.begin(ti < 3 ? HB_HID : HB_BONE);
+                    c1[ti] = tail_tile(buf + 16 * KS_BYTES, 0, h);
+                    c2[ti] = zero16();
+                    mma_tile<16, 0, true>(ws, buf, xh, xl, c1[ti], c2[ti], lane);
+                });
+            }
+            feature_pass(c1, c2, HB_LEFT, HB_HID);
+            block_epilogue(P_, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 4));
+        });
+        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 5), no_store);   // lin5
+        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 6), no_store);   // lin6
+        // ---- lin7 -> a8; sdf = W8[0,:] a8 + b8; seed of the reverse sweep dz7 = sigma'(z7) W8[0,:] (scaled)
+        float sdf_acc = 0.f;
+        run_layer<8, 16, 1, true, true>(
+            ws, HB_HID, FULL ? HB_HID : (more ? HB_BONE : 0), ah, al, lane, h,
+            [&](auto, const char* tail) { return Act{tail_tile(tail, 1, h)}; }, PhSoftplus{},
+            [&](auto T, EpiState& st, const Act& w8) {
+                constexpr int t = decltype(T)::value;
+                asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                f32x16 dz;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    sdf_acc = fmaf(w8.v[i], st.v[i], sdf_acc);
+                    dz[i] = dsoftplus_from_act(st.v[i]) * w8.v[i] * BWD_SCALE;
+                }
+                if (FULL) {
+                    bh[2 * t] = st.hi[0];   // a8 feeds lin8
+                    bl[2 * t] = st.lo[0];
+                    bh[2 * t + 1] = st.hi[1];
+                    bl[2 * t + 1] = st.lo[1];
+                    Frags f;
+                    split_tile(dz, f.hi[0], f.lo[0], f.hi[1], f.lo[1]);
+                    stash_frags(HS_DZ7)(T, f);
+                }
+                return NoData{};
+            },
+            no_store);
+        const float sdf = half_sum(sdf_acc) + a.b8;
+        if (!FULL) {
+            if (valid && h == 0) a.sdf[n] = sdf;
+            continue;
+        }
+
+        // ---- lin8 rows 1..256: the feature vector (no activation) -> stash as fragments for colour lin0
+        run_layer<8, 16, 1, true, true>(
+            ws, HB_HID, HB_BWD, bh, bl, lane, h, no_pre, PhIdentity{},
+            [&](auto T, EpiState& st, const auto&) {
+                constexpr int t = decltype(T)::value;
+                if (a.feat != nullptr && valid) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) a.feat[(size_t)n * H + 32 * t + tile_row(i, h)] = st.v[i];
+                }
+                stash_frags(HS_FVEC)(T, Frags{{st.hi[0], st.hi[1]}, {st.lo[0], st.lo[1]}});
+                return NoData{};
+            },
+            no_store);
+
+        // ---- reverse sweep: dz_{l-1} = sigma'(z_{l-1}) * (W_l^T dz_l); sigma' from the stashed activation a_l
+        auto act_of = [&](int act_slot) {
+            return [&slot, act_slot, lane](auto T, const char*) { return Act{unstash_tile(slot(act_slot), decltype(T)::value, lane)}; };
+        };
+#pragma unroll
+        for (int s = 0; s < 16; ++s) unstash_frag(slot(HS_DZ7), s, ah[s], al[s], lane);
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 6), PhDsig{}, to_regs(bh, bl), no_store);   // W7^T -> dz6
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 5), PhDsig{}, to_regs(ah, al), no_store);   // W6^T -> dz5
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 4), PhDsig{},                               // W5^T -> dz4 (kept)
+                                         [&](auto T, EpiState& st, const auto&) {
+                                             constexpr int t = decltype(T)::value;
+                                             asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                                             bh[2 * t] = st.hi[0];
+                                             bl[2 * t] = st.lo[0];
+                                             bh[2 * t + 1] = st.hi[1];
+                                             bl[2 * t + 1] = st.lo[1];
+                                             stash_frags(HS_DZ4)(T, Frags{{st.hi[0], st.hi[1]}, {st.lo[0], st.lo[1]}});
+                                             return NoData{};
+                                         },
+                                         no_store);
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 3), PhDsig{}, to_regs(ah, al), no_store);   // W4h^T -> dz3
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 2), PhDsig{}, to_regs(bh, bl), no_store);   // W3^T -> dz2
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 1), PhDsig{}, to_regs(ah, al), no_store);   // W2^T -> dz1
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 0), PhDsig{}, to_regs(bh, bl), no_store);   // W1^T -> dz0
+
+        // ---- d sdf / d features contracted with the encoding Jacobian, bone by bone: first W0^T dz0 (dz0 is in
+        //      bh/bl), then W4[:, 256:]^T dz4 (reloaded into ah/al)
+        float g[3] = {0.f, 0.f, 0.f};
+        auto jacobian_pass = [&](const h8(&dh)[16], const h8(&dl)[16], int next_after) {
+#pragma unroll 1
+            for (int b = 0; b < N_BONES; ++b) {
+                f32x16 G1[2], G2[2];
+                h8 fh[4], fl[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) unstash_frag(feat, 4 * b + s, fh[s], fl[s], lane);
+                static_for<2>([&](auto U) {
+                    constexpr int u = decltype(U)::value;
+                    const char* buf = ws.template acquire<0>();
+                    ws.begin(HB_BWD);
+                    G1[u] = zero16();
+                    G2[u] = zero16();
+                    mma_tile<16, 0, true>(ws, buf, dh, dl, G1[u], G2[u], lane);
+                });
+                const Bone2 bn = bone_coords2(p, M, Tp, b);
+                const float kk = -TAU2 * (1.f - bn.hh);
+                float own[4][8];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) own[s][jj] = unsplit(fh[s][jj], fl[s][jj]);
+                float Sv = 0.f, Sr[3] = {0.f, 0.f, 0.f};
+                bone_jacobian(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn, kk, h, Sv, Sr);
+                bone_to_p(Sv, Sr, bn, M + 16 * b, g);
+            }
+            // leftover block: 2 tiles; register 8 (u & 1) + j of tile u >> 1 <-> bone 8 u + j : (r_1 | r_2) h
+            f32x16 L1[2], L2[2];
+            static_for<2>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                const char* buf = ws.template acquire<0>();
+                ws.begin(u == 0 ? HB_BWD : next_after);
+                L1[u] = zero16();
+                L2[u] = zero16();
+                mma_tile<16, 0, true>(ws, buf, dh, dl, L1[u], L2[u], lane);
+            });
+            const f32x16 La = combine(L1[0], L2[0]), Lb = combine(L1[1], L2[1]);
+            static_for<N_BONES>([&](auto B_) {
+                constexpr int b = decltype(B_)::value;
+                const float Gv = b < 16 ? La[b] : Lb[b - 16];
+                const Bone2 bn = bone_coords2(p, M, Tp, b);
+                const float kk = -TAU2 * (1.f - bn.hh);
+                const float own = (h ? bn.r[2] : bn.r[1]) * bn.hh;
+                float Sv = Gv * own * kk;
+                float Sr[3] = {0.f, h ? 0.f : Gv * bn.hh, h ? Gv * bn.hh : 0.f};
+                bone_to_p(Sv, Sr, bn, M + 16 * b, g);
+            });
+        };
+        jacobian_pass(bh, bl, HB_BWD);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) unstash_frag(slot(HS_DZ4), s, ah[s], al[s], lane);
+        jacobian_pass(ah, al, HB_BWD);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] *= BWD_INV;
+
+        // ---- colour lin0 = [features | feature vector | enc(g)] -> relu: per pass 4 feature-vector tiles, the
+        //      feature block, then the enc(g) chunk (whose tail holds the 4 biases)
+        h8 gh[2], gl[2];
+        {
+            float fg[2][8];
+            encode_v4h(g, h, fg);
+            split8(fg[0], gh[0], gl[0]);
+            split8(fg[1], gh[1], gl[1]);
+        }
+        static_for<2>([&](auto P_) {
+            constexpr int pass = decltype(P_)::value;
+            f32x16 c1[4], c2[4];
+            {
+                h8 xh[16], xl[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) unstash_frag(slot(HS_FVEC), s, xh[s], xl[s], lane);
+                static_for<4>([&](auto TI) {
+                    constexpr int ti = decltype(TI)::value;
+                    const char* buf = ws.template acquire<0>();
+                    ws.begin(ti < 3 ? HB_BWD : HB_BONE);
+                    c1[ti] = zero16();
+                    c2[ti] = zero16();
+                    mma_tile<16, 0, true>(ws, buf, xh, xl, c1[ti], c2[ti], lane);
+                });
+            }
+            feature_pass(c1, c2, HB_LEFT, HB_G);
+            {
+                const char* buf = ws.template acquire<0>();
+                ws.begin(pass == 0 ? HB_BWD : HB_HID);
+                ws.pieces_all();   // 6 MFMA slots per tile here: too few to spread the pieces over
+                const char* tail = buf + 4 * 2 * KS_BYTES;
+                static_for<4>([&](auto TI) {
+                    constexpr int ti = decltype(TI)::value;
+                    mma_tile<2, 0, false>(ws, buf + ti * 2 * KS_BYTES, gh, gl, c1[ti], c2[ti], lane);
+                    const f32x16 bias = tail_tile(tail, ti, h);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) c1[ti][i] += bias[i];
+                });
+            }
+            block_epilogue(P_, c1, c2, PhRelu{}, to_regs(bh, bl));
+        });
+        auto relu_to = [&](h8(&oh)[16], h8(&ol)[16]) { return to_regs(oh, ol); };
+        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhRelu{}, relu_to(ah, al), no_store);   // colour lin1
+        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhRelu{}, relu_to(bh, bl), no_store);   // colour lin2
+        float rgb[3] = {0.f, 0.f, 0.f};
+        struct W3 {
+            f32x16 w[3];
+        };
+        run_layer<8, 16, 1, true, false>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
+            ws, HB_HID, more ? HB_BONE : 0, bh, bl, lane, h,
+            [&](auto, const char* tail) { return W3{{tail_tile(tail, 1, h), tail_tile(tail, 2, h), tail_tile(tail, 3, h)}}; },
+            PhRelu{},
+            [&](auto, EpiState& st, const W3& w) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) rgb[c] = fmaf(w.w[c][i], st.v[i], rgb[c]);
+                asm volatile("" : "+v"(rgb[0]), "+v"(rgb[1]), "+v"(rgb[2]));
+                return NoData{};
+            },
+            no_store);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_fast(half_sum(rgb[c]) + a.c_blast[c]);
+        if (valid && h == 0) {
+            a.sdf[n] = sdf;
+            a.grad[3 * n] = g[0];
+            a.grad[3 * n + 1] = g[1];
+            a.grad[3 * n + 2] = g[2];
+            a.rgb[3 * n] = rgb[0];
+            a.rgb[3 * n + 1] = rgb[1];
+            a.rgb[3 * n + 2] = rgb[2];
+        }
+    }
+}
+
+constexpr size_t HAND2_LDS = 2 * CHUNK_MAX;
+
+static int hand2_grid(int n_pts, int n_cus) {
+    const int n_tiles = (n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
+    return n_tiles < n_cus ? n_tiles : n_cus;
+}
+
+size_t field2_hand_workspace_bytes(int n_pts, int n_cus) {
+    return (size_t)hand2_grid(n_pts, n_cus) * WG_WAVES * HAND2_SLOTS * SLOT_F4 * sizeof(float4);
+}
+
+int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose,
+                       int n_frames, int pts_per_frame, float* sdf, float* grad, float* rgb, float* feat, void* workspace,
+                       size_t workspace_bytes, bool full, hipStream_t stream) {
+    if (n_pts <= 0) return HN_OK;
+    HN_REQUIRE(bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1,
+               "hand field needs bt_inv / T_pose and frame sizes");
+    Hand2Args a;
+    a.pts = pts;
+    a.bt_inv = bt_inv;
+    a.T_pose = T_pose;
+    a.n_pts = n_pts;
+    a.pts_per_frame = pts_per_frame;
+    a.n_frames = n_frames;
+    a.blob = reinterpret_cast<const char*>(full ? f->v2_full : f->v2_sdf);
+    a.blob_bytes = full ? f->v2_full_bytes : f->v2_sdf_bytes;
+    if (a.blob == nullptr) {
+        set_error("field was not created with HN_PREC_F16X3");
+        return HN_EINVAL;
+    }
+    a.b8 = f->sdf_b8;
+    for (int c = 0; c < 3; ++c) a.c_blast[c] = f->col_blast[c];
+    a.sdf = sdf;
+    a.grad = grad;
+    a.rgb = rgb;
+    a.feat = feat;
+    a.scratch = reinterpret_cast<float4*>(workspace);
+    {
+        const char* e = getenv("HN_DBG");
+        a.dbg = e ? atoi(e) : 0;
+    }
+    int n_cus = hn_device_cus();
+    if (n_cus <= 0) n_cus = 256;
+    const int grid = hand2_grid(n_pts, n_cus);
+    const size_t need = (size_t)grid * WG_WAVES * HAND2_SLOTS * SLOT_F4 * sizeof(float4);
+    if (workspace == nullptr || workspace_bytes < need) {
+        set_error("field workspace too small: %zu < %zu", workspace_bytes, need);
+        return HN_ENOMEM;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        HN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_field2_hand<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)HAND2_LDS));
+        HN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_field2_hand<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)HAND2_LDS));
+        attr_set = true;
+    }
+    if (full)
+        hipLaunchKernelGGL(k_field2_hand<true>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
+    else
+        hipLaunchKernelGGL(k_field2_hand<false>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+}  // namespace v2
+}  // namespace hn

@@ -109,10 +109,13 @@ struct WStream {
         if (k < f_pieces)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(f_dst + k * 4096), 16, voff, f_goff + k * 4096, 0, 0);
     }
-    __device__ __forceinline__ void fetch_all(int bytes) {
-        begin(bytes);
+    __device__ __forceinline__ void pieces_all() {
 #pragma unroll
         for (int k = 0; k < 9; ++k) piece(k);
+    }
+    __device__ __forceinline__ void fetch_all(int bytes) {
+        begin(bytes);
+        pieces_all();
     }
     template <int ALLOW>
     __device__ __forceinline__ const char* acquire() {

@@ -287,11 +287,136 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
     return HN_OK;
 }
 
+// ---- hand field ---------------------------------------------------------------------------------------
+// One bone's 66 features (utils/fields.py:142-147): [v, sin(2^k v) k<10, cos(2^k v) k<10, r(3), per channel
+// c: sin(2^k r_c) k<7, cos(2^k r_c) k<7], all times the bone mask h.  33 (first | second) pairs; 32 of them
+// fill 4 k-steps per bone (half 0 holds sines / first members, half 1 cosines / second members), the 33rd,
+// (r_1 | r_2), goes to the LEFTOVER block: 3 k-steps whose element j of k-step u belongs to bone 8u + j.
+//   k-step 0: v, frequencies 0..7          k-step 1: v, 8..9; r_0, 0..5
+//   k-step 2: r_0, 6; r_1, 0..6            k-step 3: r_2, 0..6; (v | r_0)
+static int bone_col(int idx) { return idx; }
+static std::vector<int> bone_slots(int bone) {
+    std::vector<int> c(64, -1);
+    const int b0 = BONE_FEAT * bone;
+    auto vcol = [&](int k, int h) { return b0 + 1 + k + (h ? PTS_FREQS : 0); };
+    auto rcol = [&](int ch, int k, int h) { return b0 + 24 + 2 * HAND_DIR_FREQS * ch + k + (h ? HAND_DIR_FREQS : 0); };
+    for (int h = 0; h < 2; ++h) {
+        for (int j = 0; j < 8; ++j) c[0 * 16 + 8 * h + j] = vcol(j, h);
+        for (int j = 0; j < 2; ++j) c[1 * 16 + 8 * h + j] = vcol(8 + j, h);
+        for (int j = 2; j < 8; ++j) c[1 * 16 + 8 * h + j] = rcol(0, j - 2, h);
+        c[2 * 16 + 8 * h + 0] = rcol(0, 6, h);
+        for (int j = 1; j < 8; ++j) c[2 * 16 + 8 * h + j] = rcol(1, j - 1, h);
+        for (int j = 0; j < 7; ++j) c[3 * 16 + 8 * h + j] = rcol(2, j, h);
+        c[3 * 16 + 8 * h + 7] = h ? b0 + 21 : b0 + 0;   // (v | r_0)
+    }
+    (void)bone_col;
+    return c;
+}
+static std::vector<int> left_slots() {
+    std::vector<int> c(48, -1);
+    for (int u = 0; u < 3; ++u)
+        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 8; ++j) {
+                const int bone = 8 * u + j;
+                if (bone < N_BONES) c[u * 16 + 8 * h + j] = BONE_FEAT * bone + (h ? 23 : 22);   // (r_1 | r_2)
+            }
+    return c;
+}
+// W[rows of 4 tiles][feature space]: 21 bone chunks (4 tiles x 4 k-steps) + the leftover chunk (4 tiles x 3)
+static void feature_block(Builder& B, const HostMat& M, float scale, int pass, int col_off, const float* tail) {
+    std::vector<int> rows;
+    for (int ti = 0; ti < 4; ++ti) rows = cat(rows, rows_of_tile(4 * pass + ti, 256));
+    for (int b = 0; b < N_BONES; ++b) {
+        const std::vector<int> slots = offset(bone_slots(b), col_off);
+        B.chunk(M, false, scale, 4, 4, rows.data(), slots.data(), nullptr);
+    }
+    const std::vector<int> ls = offset(left_slots(), col_off);
+    B.chunk(M, false, scale, 4, 3, rows.data(), ls.data(), tail);
+}
+static void tail_biases4(float* tail, const HostMat& M, int pass) {
+    for (int ti = 0; ti < 4; ++ti) {
+        float v[32];
+        for (int i = 0; i < 32; ++i) v[i] = M.b[32 * (4 * pass + ti) + i];
+        tail_put(tail, ti, v);
+    }
+}
+// rows = the feature slots of every bone (2 tiles each) and of the leftover block (2 tiles), W transposed
+static void feature_rows_T(Builder& B, const HostMat& M, float scale, int col_off) {
+    for (int b = 0; b < N_BONES; ++b) slot_rows_T(B, M, scale, bone_slots(b), col_off);
+    std::vector<int> ls = left_slots();
+    ls.resize(64, -1);
+    slot_rows_T(B, M, scale, ls, col_off);
+}
+
+// The hand program (contract with k_field2_hand)
 void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, bool full) {
-    (void)B;
-    (void)S;
-    (void)C;
-    (void)full;   // filled in by hn_field2_hand
+    const float rs2 = (float)(1.0 / sqrt(2.0));
+    const std::vector<int> hs = hid_slots();
+    // lin0: two passes of 4 output tiles over the feature space; the leftover chunk's tail holds the 4 biases
+    for (int p = 0; p < 2; ++p) {
+        float tail[256] = {0.f};
+        tail_biases4(tail, S[0], p);
+        feature_block(B, S[0], 1.f, p, 0, tail);
+    }
+    fwd_tiles(B, S[1], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    fwd_tiles(B, S[2], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    fwd_tiles(B, S[3], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    // lin4 = [a4 (256) | features (1386)] / sqrt2: per pass 4 hidden tiles (+bias), then the feature block
+    for (int p = 0; p < 2; ++p) {
+        for (int ti = 0; ti < 4; ++ti) {
+            const int t = 4 * p + ti;
+            const std::vector<int> rows = rows_of_tile(t, 256);
+            float tail[256] = {0.f};
+            float v[32];
+            for (int i = 0; i < 32; ++i) v[i] = S[4].b[rows[i]];
+            tail_put(tail, 0, v);
+            B.chunk(S[4], false, rs2, 1, 16, rows.data(), hs.data(), tail);
+        }
+        feature_block(B, S[4], rs2, p, H, nullptr);
+    }
+    fwd_tiles(B, S[5], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    fwd_tiles(B, S[6], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    {
+        std::vector<float> w8(256);
+        for (int i = 0; i < 256; ++i) w8[i] = S[8].at(0, i);
+        const float* extra[1] = {w8.data()};
+        fwd_tiles(B, S[7], 1.f, 8, 256, 0, hs, 16, extra, 1);
+    }
+    if (!full) return;
+    fwd_tiles(B, S[8], 1.f, 8, 256, 1, hs, 16, nullptr, 0);
+    for (int l = 7; l >= 1; --l) bwd_tiles(B, S[l], l == 4 ? rs2 : 1.f, 8, 256, 0, 256, 16);
+    feature_rows_T(B, S[0], 1.f, 0);      // W0^T dz0
+    feature_rows_T(B, S[4], rs2, H);      // W4[:, 256:]^T dz4
+    // colour lin0 = [features 1386 | feature vector 256 | enc4(g) 27] (utils/fields.py:224-229)
+    {
+        const std::vector<int> v4 = vec4_slots();
+        const std::vector<int> fv = offset(hs, HAND_IN);
+        const std::vector<int> gs = offset(v4, HAND_IN + H);
+        for (int p = 0; p < 2; ++p) {
+            for (int ti = 0; ti < 4; ++ti) {
+                const std::vector<int> rows = rows_of_tile(4 * p + ti, 256);
+                B.chunk(C[0], false, 1.f, 1, 16, rows.data(), fv.data(), nullptr);
+            }
+            feature_block(B, C[0], 1.f, p, 0, nullptr);
+            std::vector<int> rows;
+            for (int ti = 0; ti < 4; ++ti) rows = cat(rows, rows_of_tile(4 * p + ti, 256));
+            float tail[256] = {0.f};
+            tail_biases4(tail, C[0], p);
+            B.chunk(C[0], false, 1.f, 4, 2, rows.data(), gs.data(), tail);
+        }
+    }
+    fwd_tiles(B, C[1], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    fwd_tiles(B, C[2], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
+    {
+        std::vector<float> w0(256), w1(256), w2(256);
+        for (int i = 0; i < 256; ++i) {
+            w0[i] = C[4].at(0, i);
+            w1[i] = C[4].at(1, i);
+            w2[i] = C[4].at(2, i);
+        }
+        const float* extra[3] = {w0.data(), w1.data(), w2.data()};
+        fwd_tiles(B, C[3], 1.f, 8, 256, 0, hs, 16, extra, 3);
+    }
 }
 
 }  // namespace v2
