@@ -3,8 +3,10 @@
 
 Workload (BASELINE.json configs[1], SURVEY 8d "C2"): single-GPU offline render with the
 hand nets at conf size, 512 x 512 rays x 64 samples per ray (n_samples=64,
-n_importance=0), synthetic pose / camera / random-init weights, fp32 (exact MFMA f32,
-parity mode).  One step = ray generation + NeuSRenderer.render of one full frame with
+n_importance=0), synthetic pose / camera / random-init weights, dense (no far-field
+culling).  Arithmetic: "f16x3" -- fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16 per
+product, fp32 accumulate: fp32-equivalent results (parity ~3e-6 against the reference);
+--precision fp32 selects the exact-fp32 MFMA kernels instead.  One step = ray generation + NeuSRenderer.render of one full frame with
 everything already resident in HBM.  With --gpus N (launched by torch.distributed.run,
 one rank per GPU) every rank renders its own frame (frame-sharded, no data-path
 collective): weak scaling, value = all ranks' ray-samples / max-over-ranks time.
@@ -33,9 +35,10 @@ NEAR, FAR = 0.4, 1.5
 # sweep + 1 colour forward = 2 * 1,234,176 + 624,640 MAC = 6.186 MFLOP
 HAND_FLOP_PER_SAMPLE = 2.0 * (2 * 1234176 + 624640)
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: bf16/f16 MFMA, dense
 
 
-def build_scene(dev, seed):
+def build_scene(dev, seed, precision='f16x3'):
     from honerf_amd import synth
     from honerf_amd.nets import SDFNetwork, RenderingNetwork, SingleVarianceNetwork
     from honerf_amd.renderer import NeuSRenderer
@@ -43,6 +46,7 @@ def build_scene(dev, seed):
     sdf.reset_parameters(21)
     col.reset_parameters(22)
     ren = NeuSRenderer(sdf, var, col, 'hand', N_SAMPLES, 0, 0, 4, 1.0)
+    ren.precision = precision
     bt_inv, T_pose, joints = synth.synth_hand_pose(seed)
     cam = synth.front_camera(dist=0.0, focal=2.0)
     # the hand (~0.2 m across at z ~ 0.95) fills about half of the image width
@@ -55,12 +59,12 @@ def build_scene(dev, seed):
     return ren, sdf, col, scene
 
 
-def cpu_baseline(sdf, col, scene, crop=40):
+def cpu_baseline(sdf, col, scene, crop=96, threads=32):
     """The CPU oracle (port of the reference's PyTorch path) on a crop x crop centre block of
-    the same frame, all host cores."""
+    the same frame, on `threads` host cores (more than ~32 only adds contention at these sizes)."""
     from oracle.nets import Field
     from oracle import render as orr
-    cores = os.cpu_count() or 1
+    cores = min(threads, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     cpu = lambda v: v.detach().cpu()
     field = Field('hand', {k: cpu(v) for k, v in sdf.state_dict().items()},
@@ -90,7 +94,8 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-crop', type=int, default=40)
+    ap.add_argument('--cpu-crop', type=int, default=96)
+    ap.add_argument('--precision', default='f16x3', choices=['f16x3', 'fp32'])
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -105,7 +110,7 @@ def main():
 
     from honerf_amd import lib as L
     lib = L.load()
-    ren, sdf, col, sc = build_scene(dev, seed=9 + rank)      # every rank renders its own frame
+    ren, sdf, col, sc = build_scene(dev, seed=9 + rank, precision=args.precision)      # every rank renders its own frame
     B = H_IMG * W_IMG
     rays_o = torch.empty(B, 3, device=dev)
     rays_d = torch.empty(B, 3, device=dev)
@@ -166,19 +171,27 @@ def main():
     torch.cuda.synchronize()
     kernel_ms = e0.elapsed_time(e1) / k_launches
     achieved = n * HAND_FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12
+    if args.precision == 'f16x3':
+        # three f16 MFMA products per fp32-equivalent product: the algorithmic rate is priced against a
+        # third of the dense f16 MFMA peak (equivalently: issued MFMA FLOP/s against the full peak)
+        peak, kname, dtype = PEAK_F16_MFMA_TFLOPS / 3.0, 'hn::v2::k_field2_hand<true>', 'f16x3'
+    else:
+        peak, kname, dtype = PEAK_F32_MFMA_TFLOPS, 'hn::k_field_hand<true>', 'f32'
 
     if rank == 0:
         res = {
             'metric': 'ray-samples/sec/GPU (512x512x64)', 'value': value, 'unit': 'ray-samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': 'C2: hand nets (conf size, random init), 512x512 rays x 64 samples, '
                                    'n_importance=0, dense (no far-field culling), one frame per GPU',
                        'rays': B, 'samples_per_ray': N_SAMPLES, 'frames_per_step': world},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_field_hand<true>', 'achieved': achieved,
-                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+            'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': achieved,
+                         'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': None, 'kernel_ms': kernel_ms,
-                         'flop_per_launch': n * HAND_FLOP_PER_SAMPLE},
+                         'flop_per_launch': n * HAND_FLOP_PER_SAMPLE,
+                         'mfma_issued_tflops': achieved * (3.0 if args.precision == 'f16x3' else 1.0),
+                         'mfma_peak_tflops': PEAK_F16_MFMA_TFLOPS if args.precision == 'f16x3' else PEAK_F32_MFMA_TFLOPS},
             'weight_sum_mean': float(out['weight_sum'].mean()),
         }
         if not args.no_cpu_baseline:

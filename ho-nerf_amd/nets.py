@@ -177,9 +177,10 @@ class PackedField:
     state dicts in the reference layout; `variance` a SingleVarianceNetwork, a
     tensor or a float."""
 
-    def __init__(self, kind, sdf, color, variance, scale=None, precision='fp32'):
+    def __init__(self, kind, sdf, color, variance, scale=None, precision=None):
         self.lib = _lib.load()
         self.kind = kind
+        precision = precision or _lib.DEFAULT_PRECISION
         self.precision = precision
         sdf_sd, col_sd = _state_of(sdf), _state_of(color)
         if isinstance(variance, nn.Module):

@@ -49,6 +49,7 @@ class NeuSRenderer:
         self.n_outside = n_outside
         self.up_sample_steps = up_sample_steps
         self.perturb = perturb
+        self.precision = None            # None -> lib.DEFAULT_PRECISION ('f16x3'); 'fp32' selects the exact-fp32 kernels
         self._field = None
         self._version = None
         self._ws = _Workspace()
@@ -57,9 +58,10 @@ class NeuSRenderer:
     # the renderer keeps references to the modules (utils/renderer.py:50-52); the packed copy is
     # rebuilt lazily whenever their parameters change (checkpoints are loaded after construction)
     def field(self):
-        ver = params_version(self.sdf_network, self.color_network, self.deviation_network)
+        ver = params_version(self.sdf_network, self.color_network, self.deviation_network) + (self.precision,)
         if self._field is None or ver != self._version:
-            self._field = PackedField(self.model_type, self.sdf_network, self.color_network, self.deviation_network)
+            self._field = PackedField(self.model_type, self.sdf_network, self.color_network, self.deviation_network,
+                                      precision=self.precision)
             self._version = ver
         return self._field
 
@@ -138,6 +140,7 @@ class NeuSRenderer_fitting:
         self.up_sample_steps = up_sample_steps
         self.perturb = perturb
         self.strict_reference = True     # reproduce SURVEY appendix-B quirks (batched SDF-row gather)
+        self.precision = None            # None -> lib.DEFAULT_PRECISION
         self._fields = None
         self._version = None
         self._ws = _Workspace()
@@ -146,9 +149,10 @@ class NeuSRenderer_fitting:
     def fields(self):
         mods = (self.sdf_network_hand, self.color_network_hand, self.deviation_network_hand, self.sdf_network_obj,
                 self.color_network_obj, self.deviation_network_obj)
-        ver = params_version(*mods)
+        ver = params_version(*mods) + (self.precision,)
         if self._fields is None or ver != self._version:
-            self._fields = (PackedField('hand', mods[0], mods[1], mods[2]), PackedField('obj', mods[3], mods[4], mods[5]))
+            self._fields = (PackedField('hand', mods[0], mods[1], mods[2], precision=self.precision),
+                            PackedField('obj', mods[3], mods[4], mods[5], precision=self.precision))
             self._version = ver
         return self._fields
 

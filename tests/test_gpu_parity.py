@@ -30,9 +30,16 @@ def L():
     return lib
 
 
+@pytest.fixture(scope='module', params=['f16x3', 'fp32'])
+def prec(request):
+    """Both kernel families are held to the same bounds: 'f16x3' (fp16 hi/lo split operands on the f16
+    MFMA, the default product path) and 'fp32' (exact-fp32 MFMA)."""
+    return request.param
+
+
 @pytest.fixture(scope='module')
-def fields():
-    return packed_fields()
+def fields(prec):
+    return packed_fields(precision=prec)
 
 
 def st():
@@ -270,23 +277,26 @@ def test_fields_vs_oracle_ragged(fields):
 
 
 # ---------------------------------------------------------------------------------------------
-def _single_renderer(model_type, n_samples, n_importance):
+def _single_renderer(model_type, n_samples, n_importance, prec):
     from honerf_amd.renderer import NeuSRenderer
     m = product_modules()
     if model_type == 'obj':
-        return NeuSRenderer(m['sdf_obj'], m['var_obj'], m['color_obj'], 'obj', n_samples, n_importance, 0, 4, 1.0)
-    return NeuSRenderer(m['sdf_hand'], m['var_hand'], m['color_hand'], 'hand', n_samples, n_importance, 0, 4, 1.0)
+        ren = NeuSRenderer(m['sdf_obj'], m['var_obj'], m['color_obj'], 'obj', n_samples, n_importance, 0, 4, 1.0)
+    else:
+        ren = NeuSRenderer(m['sdf_hand'], m['var_hand'], m['color_hand'], 'hand', n_samples, n_importance, 0, 4, 1.0)
+    ren.precision = prec
+    return ren
 
 
 KEYS1 = ('color_fine', 's_val', 'cdf_fine', 'weight_sum', 'weight_max', 'gradient_error')
 
 
 @pytest.mark.parametrize('tag', ['obj_32_0', 'hand_64_0'])
-def test_render_single_golden_coarse_only(golden, tag):
+def test_render_single_golden_coarse_only(golden, tag, prec):
     """a3, a14, a15, a17 without importance sampling: straight 1e-4 against the reference."""
     g = golden('render_' + tag)
     kind = tag.split('_')[0]
-    ren = _single_renderer(kind, int(g['n_samples']), 0)
+    ren = _single_renderer(kind, int(g['n_samples']), 0, prec)
     out = ren.render(cu(g['rays_o']), cu(g['rays_d']), float(g['near']), float(g['far']), g.get('bt_inv'),
                      g.get('T_pose'), None, g.get('Ro'), g.get('To'), 0, t_rand=cu(g['t_rand']))
     for k in KEYS1:
@@ -294,12 +304,12 @@ def test_render_single_golden_coarse_only(golden, tag):
 
 
 @pytest.mark.parametrize('tag', ['obj_64_64', 'hand_64_64'])
-def test_render_single_golden_importance(golden, tag):
+def test_render_single_golden_importance(golden, tag, prec):
     """The whole chain with 4 up-sampling rounds.  The chain is ill-conditioned, so the
     end-to-end bound is looser; the stage-wise test below holds the 1e-4 line."""
     g = golden('render_' + tag)
     kind = tag.split('_')[0]
-    ren = _single_renderer(kind, 64, 64)
+    ren = _single_renderer(kind, 64, 64, prec)
     out = ren.render(cu(g['rays_o']), cu(g['rays_d']), float(g['near']), float(g['far']), g.get('bt_inv'),
                      g.get('T_pose'), None, g.get('Ro'), g.get('To'), 0, t_rand=cu(g['t_rand']))
     errs = {k: rel_err(out[k].cpu().numpy().reshape(g[k].shape), g[k]) for k in KEYS1}
@@ -309,7 +319,7 @@ def test_render_single_golden_importance(golden, tag):
 
 
 @pytest.mark.parametrize('kind', ['obj', 'hand'])
-def test_render_core_on_reference_depths(golden, kind):
+def test_render_core_on_reference_depths(golden, kind, prec):
     """a14/a15/a17 at 1e-4 with importance samples: take the REFERENCE's final 128 depths
     (golden z_vals) and run the HIP mid-point sampling + field + alpha + compositing on
     exactly those; every per-sample and per-ray output against the reference's own."""
@@ -317,7 +327,7 @@ def test_render_core_on_reference_depths(golden, kind):
     from oracle import render as orr
     lib = L.load()
     g = golden('render_%s_64_64' % kind)
-    hand, obj = packed_fields()
+    hand, obj = packed_fields(precision=prec)
     f = obj if kind == 'obj' else hand
     o, d = t(g['rays_o']), t(g['rays_d'])
     if kind == 'obj':
@@ -359,14 +369,14 @@ def test_render_core_on_reference_depths(golden, kind):
 
 
 @pytest.mark.parametrize('name', ['render_dual', 'render_dual_batch'])
-def test_dual_core_on_reference_depths(golden, name):
+def test_dual_core_on_reference_depths(golden, name, prec):
     """a16/a18 stage-wise: both fields + alpha + two-field compositing on the reference's own
     192 sorted depths (single frame and the frame-batched layout)."""
     from honerf_amd import lib as L
     from oracle import render as orr
     lib = L.load()
     g = golden(name)
-    hand, obj = packed_fields()
+    hand, obj = packed_fields(precision=prec)
     S = g['z_vals'].shape[-1]
     F_ = g['rays_o'].shape[0] if g['rays_o'].ndim == 3 else 1
     o = t(g['rays_o']).reshape(F_, -1, 3)
@@ -413,13 +423,14 @@ def test_dual_core_on_reference_depths(golden, name):
     assert_close(eik[1] / (N * S), g['gradient_error_obj'], 2e-4, name + ' gradient_error_obj')
 
 
-def test_render_dual_golden(golden):
+def test_render_dual_golden(golden, prec):
     """a16/a18: two-field render against the reference (forward)."""
     from honerf_amd.renderer import NeuSRenderer_fitting
     g = golden('render_dual')
     m = product_modules()
     ren = NeuSRenderer_fitting(m['sdf_hand'], m['var_hand'], m['color_hand'], m['sdf_obj'], m['var_obj'],
                                m['color_obj'], 64, 64, 0, 4, 1.0)
+    ren.precision = prec
     out = ren.render(cu(g['rays_o']), cu(g['rays_d']), 0.4, 1.5, g['bt_inv'], g['T_pose'], None, g['Ro'], g['To'],
                      t_rand=cu(g['t_rand']))
     errs = {k: rel_err(out[k].cpu().numpy().reshape(g[k].shape), g[k])
@@ -432,13 +443,14 @@ def test_render_dual_golden(golden):
     assert out['sdf_hand'].shape == (24 * 192, 1) and out['gradient_obj'].shape == (24 * 192, 3)
 
 
-def test_render_dual_batch_golden(golden):
+def test_render_dual_batch_golden(golden, prec):
     """utils/renderer_batch.py surface, including the SDF-row quirk (SURVEY B-1)."""
     from honerf_amd.renderer_batch import NeuSRenderer_fitting
     g = golden('render_dual_batch')
     m = product_modules()
     ren = NeuSRenderer_fitting(m['sdf_hand'], m['var_hand'], m['color_hand'], m['sdf_obj'], m['var_obj'],
                                m['color_obj'], 64, 64, 0, 4, 1.0)
+    ren.precision = prec
     out = ren.render(cu(g['rays_o']), cu(g['rays_d']), 0.4, 1.5, g['bt_inv'], g['T_pose'], None, g['Ro'], g['To'],
                      t_rand=cu(g['t_rand']))
     assert out['color_fine'].shape == (3, 10, 3) and out['weight_sum'].shape == (3, 10, 1)
@@ -448,7 +460,7 @@ def test_render_dual_batch_golden(golden):
     assert errs['color_fine'] < 2e-3 and errs['weight_sum'] < 2e-3 and errs['sdf_obj'] < 2e-3, errs
 
 
-def test_dual_depths_match_oracle(golden):
+def test_dual_depths_match_oracle(golden, prec):
     """Sample placement of the two-field render: the 192 sorted depths against the oracle's."""
     from honerf_amd.renderer import NeuSRenderer_fitting
     from oracle import render as orr
@@ -459,6 +471,7 @@ def test_dual_depths_match_oracle(golden):
     m = product_modules()
     ren = NeuSRenderer_fitting(m['sdf_hand'], m['var_hand'], m['color_hand'], m['sdf_obj'], m['var_obj'],
                                m['color_obj'], 64, 64, 0, 4, 1.0)
+    ren.precision = prec
     ren.render(cu(g['rays_o']), cu(g['rays_d']), 0.4, 1.5, g['bt_inv'], g['T_pose'], None, g['Ro'], g['To'],
                t_rand=cu(g['t_rand']))
     z = ren.last_z_vals.cpu()
