@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void k_composite1(const float* __restrict__ al
                                                     float* __restrict__ weights, float* __restrict__ weight_sum,
                                                     float* __restrict__ weight_max, float* __restrict__ eik_sum) {
     const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= n_rays) return;
+    float eik_total = 0.f;   // one atomic per wave at the end (a single address takes ~12 ns per atomic)
+    for (int ray = blockIdx.x * 4 + (threadIdx.x >> 6); ray < n_rays; ray += gridDim.x * 4) {
     const size_t base = (size_t)ray * S;
     float carry = c[base];      // SURVEY B-3: the first factor is c_0, not 1
     float col[3] = {0.f, 0.f, 0.f}, wsum = 0.f, wmax = -1.f, eik = 0.f;
@@ -95,8 +95,10 @@ __global__ __launch_bounds__(256) void k_composite1(const float* __restrict__ al
         color[3 * ray + 2] = col[2];
         weight_sum[ray] = wsum;
         if (weight_max != nullptr) weight_max[ray] = wmax;
-        if (eik_sum != nullptr && grad != nullptr) atomicAdd(eik_sum, eik);
     }
+    eik_total += eik;
+    }
+    if (lane == 0 && eik_sum != nullptr && grad != nullptr) atomicAdd(eik_sum, eik_total);
 }
 
 // two fields: T_k = prod_{j<k} (1 - a_h + 1e-7)(1 - a_o + 1e-7); w_h = a_h T, w_o = a_o T
@@ -107,8 +109,8 @@ __global__ __launch_bounds__(256) void k_composite2(const float* __restrict__ ah
                                                     float* __restrict__ weight_sum, float* __restrict__ w_hand,
                                                     float* __restrict__ w_obj, float* __restrict__ eik_sum) {
     const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= n_rays) return;
+    float eh_total = 0.f, eo_total = 0.f;
+    for (int ray = blockIdx.x * 4 + (threadIdx.x >> 6); ray < n_rays; ray += gridDim.x * 4) {
     const size_t base = (size_t)ray * S;
     float carry = 1.f;
     float colh[3] = {0.f, 0.f, 0.f}, colo[3] = {0.f, 0.f, 0.f}, wsh = 0.f, wso = 0.f, eh = 0.f, eo = 0.f;
@@ -161,11 +163,20 @@ __global__ __launch_bounds__(256) void k_composite2(const float* __restrict__ ah
 #pragma unroll
         for (int k = 0; k < 3; ++k) color[3 * ray + k] = colh[k] + colo[k];
         weight_sum[ray] = wsh + wso;
-        if (eik_sum != nullptr) {
-            if (gh != nullptr) atomicAdd(eik_sum, eh);
-            if (go != nullptr) atomicAdd(eik_sum + 1, eo);
-        }
     }
+    eh_total += eh;
+    eo_total += eo;
+    }
+    if (lane == 0 && eik_sum != nullptr) {
+        if (gh != nullptr) atomicAdd(eik_sum, eh_total);
+        if (go != nullptr) atomicAdd(eik_sum + 1, eo_total);
+    }
+}
+
+// 4 rays per block; at most 8 blocks per CU, grid-stride beyond that
+static int composite_grid(int n_rays) {
+    const int blocks = (n_rays + 3) / 4;
+    return blocks < 2048 ? blocks : 2048;
 }
 
 int alpha(const float* sdf, const float* grad, const float* rays_d, const float* dists, int n, int spr, float inv_s,
@@ -182,7 +193,7 @@ int composite1(const float* alpha_in, const float* c, const float* rgb, const fl
                float* color, float* weights, float* weight_sum, float* weight_max, float* eik_sum, hipStream_t s) {
     HN_REQUIRE(S >= 1, "S must be positive");
     if (n_rays == 0) return HN_OK;
-    hipLaunchKernelGGL(k_composite1, dim3((n_rays + 3) / 4), dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, S, color,
+    hipLaunchKernelGGL(k_composite1, dim3(composite_grid(n_rays)), dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, S, color,
                        weights, weight_sum, weight_max, eik_sum);
     HN_LAUNCH_CHECK();
     return HN_OK;
@@ -193,7 +204,7 @@ int composite2(const float* ah, const float* rgbh, const float* gh, const float*
                hipStream_t s) {
     HN_REQUIRE(S >= 1, "S must be positive");
     if (n_rays == 0) return HN_OK;
-    hipLaunchKernelGGL(k_composite2, dim3((n_rays + 3) / 4), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, S,
+    hipLaunchKernelGGL(k_composite2, dim3(composite_grid(n_rays)), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, S,
                        color, weight_sum, w_hand, w_obj, eik_sum);
     HN_LAUNCH_CHECK();
     return HN_OK;

@@ -174,8 +174,10 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31;
     const int h = lane >> 5;
-    float4* wslot = a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * HAND2_SLOTS * SLOT_F4;
-    auto slot = [&](int i) { return wslot + (size_t)i * SLOT_F4; };
+    Stash sh;
+    sh.init(a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * HAND2_SLOTS * SLOT_F4, HAND2_SLOTS, lane);
+    constexpr int FEAT = HS_FEAT * SLOT_BYTES;   // byte offset of the feature fragment blocks
+    constexpr int LEFT = HS_LEFT * SLOT_BYTES;   // ... of the leftover values
     const int n_tiles = (a.n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
 
     WStream ws;
@@ -185,7 +187,6 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const bool more = tile + (int)gridDim.x < n_tiles;
-        wslot = launder_uniform(wslot);
         const int n = tile * WG_SAMPLES + wave * 32 + j;
         const bool valid = n < a.n_pts;
         const int nn = valid ? n : a.n_pts - 1;
@@ -194,8 +195,6 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         frame = frame < a.n_frames ? frame : a.n_frames - 1;
         const float* M = a.bt_inv + (size_t)frame * N_BONES * 16;
         const float* Tp = a.T_pose + (size_t)frame * N_BONES * 3;
-        float4* const feat = slot(HS_FEAT);
-        float* const left = reinterpret_cast<float*>(slot(HS_LEFT));
 
         // ---- F0: features of the 21 bones -> fragments in the stash -------------------------------------
 #pragma unroll 1
@@ -207,22 +206,23 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             for (int s = 0; s < 4; ++s) {
                 h8 fh, fl;
                 split8(f[s], fh, fl);
-                stash_frag(feat, 4 * b + s, fh, fl, lane);
+                sh.frag_store(FEAT, 4 * b + s, fh, fl);
             }
-            left[b * 64 + lane] = (h ? bn.r[2] : bn.r[1]) * bn.hh;
+            sh.f32_store(LEFT + b * 256, (h ? bn.r[2] : bn.r[1]) * bn.hh);
         }
         {   // leftover block: element j of k-step u belongs to bone 8u + j
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 float f[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) f[jj] = (8 * u + jj < N_BONES) ? left[(8 * u + jj) * 64 + lane] : 0.f;
+                for (int jj = 0; jj < 8; ++jj) f[jj] = (8 * u + jj < N_BONES) ? sh.f32_load(LEFT + (8 * u + jj) * 256) : 0.f;
                 h8 fh, fl;
                 split8(f, fh, fl);
-                stash_frag(feat, FEAT_BLOCKS + u, fh, fl, lane);
+                sh.frag_store(FEAT, FEAT_BLOCKS + u, fh, fl);
             }
         }
 
+        if ((a.dbg >> 8) == 1) return;   // phase timing aid
         h8 ah[16], al[16], bh[16], bl[16];   // ping-pong activation fragments
         struct Act {
             f32x16 v;
@@ -233,10 +233,10 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         auto no_pre = [](auto, const char*) { return NoData{}; };
         auto no_store = [](auto, const auto&) {};
         auto stash_frags = [&](int stash_slot) {
-            return [stash_slot, &slot, lane](auto T, const Frags& f) {
+            return [stash_slot, &sh](auto T, const Frags& f) {
                 constexpr int t = decltype(T)::value;
-                stash_frag(slot(stash_slot), 2 * t, f.hi[0], f.lo[0], lane);
-                stash_frag(slot(stash_slot), 2 * t + 1, f.hi[1], f.lo[1], lane);
+                sh.frag_store(stash_slot * SLOT_BYTES, 2 * t, f.hi[0], f.lo[0]);
+                sh.frag_store(stash_slot * SLOT_BYTES, 2 * t + 1, f.hi[1], f.lo[1]);
             };
         };
         auto to_regs = [&](h8(&oh)[16], h8(&ol)[16]) {
@@ -251,14 +251,14 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             };
         };
         auto to_regs_keep = [&](h8(&oh)[16], h8(&ol)[16], int stash_slot) {
-            return [&oh, &ol, stash_slot, &slot, lane](auto T, EpiState& st, const auto&) {
+            return [&oh, &ol, stash_slot, &sh](auto T, EpiState& st, const auto&) {
                 constexpr int t = decltype(T)::value;
                 asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
                 oh[2 * t] = st.hi[0];
                 ol[2 * t] = st.lo[0];
                 oh[2 * t + 1] = st.hi[1];
                 ol[2 * t + 1] = st.lo[1];
-                if (FULL) stash_tile(slot(stash_slot), t, st.v, lane);
+                if (FULL) sh.tile_store(stash_slot, t, st.vec());
                 return NoData{};
             };
         };
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             h8 fh[2][4], fl[2][4];
             auto load_bone = [&](int b, h8(&oh)[4], h8(&ol)[4]) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) unstash_frag(feat, 4 * b + s, oh[s], ol[s], lane);
+                for (int s = 0; s < 4; ++s) sh.frag_load(FEAT, 4 * b + s, oh[s], ol[s]);
             };
             auto step = [&](int b, const h8(&uh)[4], const h8(&ul)[4], h8(&nh)[4], h8(&nl)[4]) {
                 const char* buf = ws.template acquire<0>();
@@ -338,17 +338,19 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             }
             block_epilogue(P_, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 0));
         });
+        if ((a.dbg >> 8) == 2) return;   // phase timing aid
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 1), no_store);   // lin1
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 2), no_store);   // lin2
         // lin3 -> a4: kept as fragments in the stash too (lin4's hidden part reads them in both passes)
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhSoftplus{},
                                         [&](auto T, EpiState& st, const auto&) {
                                             constexpr int t = decltype(T)::value;
-                                            if (FULL) stash_tile(slot(HS_A1 + 3), t, st.v, lane);
+                                            if (FULL) sh.tile_store(HS_A1 + 3, t, st.vec());
                                             stash_frags(HS_A4F)(T, Frags{{st.hi[0], st.hi[1]}, {st.lo[0], st.lo[1]}});
                                             return NoData{};
                                         },
                                         no_store);
+        if ((a.dbg >> 8) == 3) return;   // phase timing aid
         // ---- lin4 = [a4 | features] / sqrt2 -> a5: per pass 4 hidden tiles, then the feature block
         static_for<2>([&](auto P_) {
             constexpr int pass = decltype(P_)::value;
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             {
                 h8 xh[16], xl[16];
 #pragma unroll
-                for (int s = 0; s < 16; ++s) unstash_frag(slot(HS_A4F), s, xh[s], xl[s], lane);
+                for (int s = 0; s < 16; ++s) sh.frag_load(HS_A4F * SLOT_BYTES, s, xh[s], xl[s]);
                 static_for<4>([&](auto TI) {
                     constexpr int ti = decltype(TI)::value;
                     const char* buf = ws.template acquire<0>();
@@ -369,6 +371,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             feature_pass(c1, c2, HB_LEFT, HB_HID);
             block_epilogue(P_, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 4));
         });
+        if ((a.dbg >> 8) == 4) return;   // phase timing aid
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 5), no_store);   // lin5
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 6), no_store);   // lin6
         // ---- lin7 -> a8; sdf = W8[0,:] a8 + b8; seed of the reverse sweep dz7 = sigma'(z7) W8[0,:] (scaled)
@@ -403,6 +406,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             continue;
         }
 
+        if ((a.dbg >> 8) == 5) return;   // phase timing aid
         // ---- lin8 rows 1..256: the feature vector (no activation) -> stash as fragments for colour lin0
         run_layer<8, 16, 1, true, true>(
             ws, HB_HID, HB_BWD, bh, bl, lane, h, no_pre, PhIdentity{},
@@ -417,12 +421,13 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             },
             no_store);
 
+        if ((a.dbg >> 8) == 6) return;   // phase timing aid
         // ---- reverse sweep: dz_{l-1} = sigma'(z_{l-1}) * (W_l^T dz_l); sigma' from the stashed activation a_l
         auto act_of = [&](int act_slot) {
-            return [&slot, act_slot, lane](auto T, const char*) { return Act{unstash_tile(slot(act_slot), decltype(T)::value, lane)}; };
+            return [&sh, act_slot](auto T, const char*) { return Act{sh.tile_load(act_slot, decltype(T)::value)}; };
         };
 #pragma unroll
-        for (int s = 0; s < 16; ++s) unstash_frag(slot(HS_DZ7), s, ah[s], al[s], lane);
+        for (int s = 0; s < 16; ++s) sh.frag_load(HS_DZ7 * SLOT_BYTES, s, ah[s], al[s]);
         run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 6), PhDsig{}, to_regs(bh, bl), no_store);   // W7^T -> dz6
         run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 5), PhDsig{}, to_regs(ah, al), no_store);   // W6^T -> dz5
         run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 4), PhDsig{},                               // W5^T -> dz4 (kept)
@@ -442,6 +447,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 1), PhDsig{}, to_regs(ah, al), no_store);   // W2^T -> dz1
         run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 0), PhDsig{}, to_regs(bh, bl), no_store);   // W1^T -> dz0
 
+        if ((a.dbg >> 8) == 7) return;   // phase timing aid
         // ---- d sdf / d features contracted with the encoding Jacobian, bone by bone: first W0^T dz0 (dz0 is in
         //      bh/bl), then W4[:, 256:]^T dz4 (reloaded into ah/al)
         float g[3] = {0.f, 0.f, 0.f};
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 f32x16 G1[2], G2[2];
                 h8 fh[4], fl[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) unstash_frag(feat, 4 * b + s, fh[s], fl[s], lane);
+                for (int s = 0; s < 4; ++s) sh.frag_load(FEAT, 4 * b + s, fh[s], fl[s]);
                 static_for<2>([&](auto U) {
                     constexpr int u = decltype(U)::value;
                     const char* buf = ws.template acquire<0>();
@@ -495,11 +501,12 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         };
         jacobian_pass(bh, bl, HB_BWD);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) unstash_frag(slot(HS_DZ4), s, ah[s], al[s], lane);
+        for (int s = 0; s < 16; ++s) sh.frag_load(HS_DZ4 * SLOT_BYTES, s, ah[s], al[s]);
         jacobian_pass(ah, al, HB_BWD);
 #pragma unroll
         for (int c = 0; c < 3; ++c) g[c] *= BWD_INV;
 
+        if ((a.dbg >> 8) == 8) return;   // phase timing aid
         // ---- colour lin0 = [features | feature vector | enc(g)] -> relu: per pass 4 feature-vector tiles, the
         //      feature block, then the enc(g) chunk (whose tail holds the 4 biases)
         h8 gh[2], gl[2];
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             {
                 h8 xh[16], xl[16];
 #pragma unroll
-                for (int s = 0; s < 16; ++s) unstash_frag(slot(HS_FVEC), s, xh[s], xl[s], lane);
+                for (int s = 0; s < 16; ++s) sh.frag_load(HS_FVEC * SLOT_BYTES, s, xh[s], xl[s]);
                 static_for<4>([&](auto TI) {
                     constexpr int ti = decltype(TI)::value;
                     const char* buf = ws.template acquire<0>();
@@ -541,6 +548,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             }
             block_epilogue(P_, c1, c2, PhRelu{}, to_regs(bh, bl));
         });
+        if ((a.dbg >> 8) == 9) return;   // phase timing aid
         auto relu_to = [&](h8(&oh)[16], h8(&ol)[16]) { return to_regs(oh, ol); };
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhRelu{}, relu_to(ah, al), no_store);   // colour lin1
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhRelu{}, relu_to(bh, bl), no_store);   // colour lin2

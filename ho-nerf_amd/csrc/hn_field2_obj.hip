@@ -81,8 +81,9 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar addressing
     const int j = lane & 31;
     const int h = lane >> 5;
-    float4* wslot = a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * OBJ2_SLOTS * SLOT_F4;
-    auto slot = [&](int i) { return wslot + (size_t)i * SLOT_F4; };
+    Stash sh;
+    sh.init(FULL ? a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * OBJ2_SLOTS * SLOT_F4 : nullptr,
+            FULL ? OBJ2_SLOTS : 0, lane);
     const int n_tiles = (a.n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
 
     WStream ws;
@@ -92,7 +93,6 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const bool more = tile + (int)gridDim.x < n_tiles;
-        wslot = launder_uniform(wslot);
         const int n = tile * WG_SAMPLES + wave * 32 + j;
         const bool valid = n < a.n_pts;
         const int nn = valid ? n : a.n_pts - 1;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             for (int s = 0; s < 4; ++s) split8(f[s], xh[s], xl[s]);
             if constexpr (FULL) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) stash_frag(slot(OS_X), s, xh[s], xl[s], lane);
+                for (int s = 0; s < 4; ++s) sh.frag_store(OS_X * SLOT_BYTES, s, xh[s], xl[s]);
             }
         }
         h8 ah[16], al[16], bh[16], bl[16];   // ping-pong activation fragments
@@ -134,22 +134,22 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         };
         // ... and, in the full kernel, the fp32 activation to the stash for the reverse sweep
         auto to_regs_keep = [&](h8(&oh)[16], h8(&ol)[16], int stash_slot) {
-            return [&oh, &ol, stash_slot, &slot, lane, &a](auto T, EpiState& st, const auto&) {
+            return [&oh, &ol, stash_slot, &sh, &a](auto T, EpiState& st, const auto&) {
                 constexpr int t = decltype(T)::value;
                 asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
                 oh[2 * t] = st.hi[0];
                 ol[2 * t] = st.lo[0];
                 oh[2 * t + 1] = st.hi[1];
                 ol[2 * t + 1] = st.lo[1];
-                if (FULL && !(a.dbg & 1)) stash_tile(slot(stash_slot), t, st.v, lane);
+                if (FULL && !(a.dbg & 1)) sh.tile_store(stash_slot, t, st.vec());
                 return NoData{};
             };
         };
         auto stash_frags = [&](int stash_slot) {
-            return [stash_slot, &slot, lane](auto T, const Frags& f) {
+            return [stash_slot, &sh](auto T, const Frags& f) {
                 constexpr int t = decltype(T)::value;
-                stash_frag(slot(stash_slot), 2 * t, f.hi[0], f.lo[0], lane);
-                stash_frag(slot(stash_slot), 2 * t + 1, f.hi[1], f.lo[1], lane);
+                sh.frag_store(stash_slot * SLOT_BYTES, 2 * t, f.hi[0], f.lo[0]);
+                sh.frag_store(stash_slot * SLOT_BYTES, 2 * t + 1, f.hi[1], f.lo[1]);
             };
         };
 
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                                                 bh[2 * t + 1] = st.hi[1];
                                                 bl[2 * t + 1] = st.lo[1];
                                             }
-                                            if (FULL && !(a.dbg & 1)) stash_tile(slot(OS_A1 + 3), t, st.v, lane);
+                                            if (FULL && !(a.dbg & 1)) sh.tile_store(OS_A1 + 3, t, st.vec());
                                             return NoData{};
                                         },
                                         no_store);
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if constexpr (FULL) {
-                    unstash_frag(slot(OS_X), s, bh[12 + s], bl[12 + s], lane);
+                    sh.frag_load(OS_X * SLOT_BYTES, s, bh[12 + s], bl[12 + s]);
                 } else {
                     bh[12 + s] = xh[s];
                     bl[12 + s] = xl[s];
@@ -259,13 +259,13 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
 
         // ---- reverse sweep: dz_{l-1} = sigma'(z_{l-1}) * (W_l^T dz_l); sigma' from the stashed activation a_l
         auto act_of = [&](int act_slot) {
-            return [&slot, act_slot, lane, &a](auto T, const char*) {
+            return [&sh, act_slot, &a](auto T, const char*) {
                 if (a.dbg & 2) return Act{zero16()};
-                return Act{unstash_tile(slot(act_slot), decltype(T)::value, lane)};
+                return Act{sh.tile_load(act_slot, decltype(T)::value)};
             };
         };
 #pragma unroll
-        for (int s = 0; s < 16; ++s) unstash_frag(slot(OS_DZ7), s, ah[s], al[s], lane);
+        for (int s = 0; s < 16; ++s) sh.frag_load(OS_DZ7 * SLOT_BYTES, s, ah[s], al[s]);
         run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 6), PhDsig{}, to_regs(bh, bl), no_store);   // W7^T -> dz6
         run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 5), PhDsig{}, to_regs(ah, al), no_store);   // W6^T -> dz5
         run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 4), PhDsig{},                          // W5^T -> dz4 (kept)
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             mma_tile<16, 0, true>(ws, buf, bh, bl, G1[u], G2[u], lane);
         });
 #pragma unroll
-        for (int s = 0; s < 16; ++s) unstash_frag(slot(OS_DZ4), s, ah[s], al[s], lane);
+        for (int s = 0; s < 16; ++s) sh.frag_load(OS_DZ4 * SLOT_BYTES, s, ah[s], al[s]);
         static_for<2>([&](auto U) {
             constexpr int u = decltype(U)::value;
             const char* buf = ws.template acquire<0>();
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         h8 mh[8], ml[8];   // the 8 k-steps of chunk B: X (4), enc(d) (2), enc(g) (2)
         {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) unstash_frag(slot(OS_X), s, mh[s], ml[s], lane);
+            for (int s = 0; s < 4; ++s) sh.frag_load(OS_X * SLOT_BYTES, s, mh[s], ml[s]);
             float fd[2][8], fg[2][8];
             encode_v4(d, h, fd);
             encode_v4(g, h, fg);
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             split8(fg[1], mh[7], ml[7]);
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) unstash_frag(slot(OS_FVEC), s, ah[s], al[s], lane);
+        for (int s = 0; s < 16; ++s) sh.frag_load(OS_FVEC * SLOT_BYTES, s, ah[s], al[s]);
         {
             // two chunks per tile (16 feature-vector k-steps, then 8 encoding k-steps + bias); the epilogue of
             // tile t-1 rides on chunk A's MFMAs of tile t

@@ -135,7 +135,8 @@ constexpr int MAX_PIECES_PER_WAVE = 9;
 // the matrix pipe and as 0 by the residual is an error of up to 6e-5 per element.  (The host-side weight
 // packer converts with IEEE semantics and needs no such rule.)
 __host__ __device__ __forceinline__ _Float16 hi_part(float x) {
-    return (x < 6.103515625e-5f && x > -6.103515625e-5f) ? (_Float16)0.f : (_Float16)x;
+    const float xs = (x < 6.103515625e-5f && x > -6.103515625e-5f) ? 0.f : x;   // select in fp32, then convert
+    return (_Float16)xs;
 }
 // fp16 hi / scaled-lo split of 8 fp32 values (one B fragment)
 __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
@@ -266,8 +267,15 @@ struct NoData {};
 // B fragments st.hi/st.lo of the next layer (skipped when FRAGS is false).
 struct EpiState {
     f32x16 c1, c2;   // the finished accumulators of the tile
-    f32x16 z, e;     // per-element temporaries carried from phase 0 to phase 1
-    f32x16 v;        // results
+    float z[2], e[2];   // per-element temporaries carried from phase 0 to phase 1 (index I & 1): plain scalars,
+                        // a 16-wide vector would pin 16 consecutive registers for two live values
+    float v[16];        // results (scalars for the same reason; vec() assembles a tile where one is needed)
+    __device__ __forceinline__ f32x16 vec() const {
+        f32x16 y;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y[i] = v[i];
+        return y;
+    }
     h8 hi[2], lo[2]; // fragments of k-steps 2t, 2t+1
     float r0, r1;    // residuals of the pair being converted
     float inv;       // 1/2048, laundered behind the tile's barrier: ties every phase-0 to this side of it
@@ -402,10 +410,10 @@ struct PhSoftplus {
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD&) const {
         constexpr int I = I_::value, P = P_::value;
         if constexpr (P == 0) {
-            st.z[I] = fmaf(st.c2[I], st.inv, st.c1[I]);
-            st.e[I] = __builtin_amdgcn_exp2f(-fabsf(st.z[I] * K100));
+            st.z[I & 1] = fmaf(st.c2[I], st.inv, st.c1[I]);
+            st.e[I & 1] = __builtin_amdgcn_exp2f(-fabsf(st.z[I & 1] * K100));
         } else {
-            st.v[I] = fmaf(__builtin_amdgcn_logf(1.f + st.e[I]), C100, fmaxf(st.z[I], 0.f));
+            st.v[I] = fmaf(__builtin_amdgcn_logf(1.f + st.e[I & 1]), C100, fmaxf(st.z[I & 1], 0.f));
         }
     }
 };
@@ -415,10 +423,10 @@ struct PhDsig {
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD& pd) const {
         constexpr int I = I_::value, P = P_::value;
         if constexpr (P == 0) {
-            st.z[I] = fmaf(st.c2[I], st.inv, st.c1[I]);
-            st.e[I] = __builtin_amdgcn_exp2f(pd.v[I] * -K100);
+            st.z[I & 1] = fmaf(st.c2[I], st.inv, st.c1[I]);
+            st.e[I & 1] = __builtin_amdgcn_exp2f(pd.v[I] * -K100);
         } else {
-            st.v[I] = fmaf(st.z[I], -st.e[I], st.z[I]);
+            st.v[I] = fmaf(st.z[I & 1], -st.e[I & 1], st.z[I & 1]);
         }
     }
 };
@@ -438,35 +446,72 @@ struct PhIdentity {
 };
 
 // ---- per-wave stash in global memory (slots of 32 KiB, every instruction moves 1 KiB) -----------
+// Addressed through a buffer descriptor: SGPR base + scalar byte offset + one shared VGPR (lane * 16), so
+// the hundreds of distinct stash addresses cost no vector registers (64-bit per-lane addresses were the
+// kernel's main source of spills).
+using u32x4 = unsigned __attribute__((ext_vector_type(4)));
 constexpr size_t SLOT_F4 = 8 * 4 * 64;   // float4 per slot
-__device__ __forceinline__ void stash_tile(float4* slot, int t, const f32x16& y, int lane) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        slot[(t * 4 + q) * 64 + lane] = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
-}
-__device__ __forceinline__ f32x16 unstash_tile(const float4* slot, int t, int lane) {
-    f32x16 y;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = slot[(t * 4 + q) * 64 + lane];
-        y[4 * q] = v.x;
-        y[4 * q + 1] = v.y;
-        y[4 * q + 2] = v.z;
-        y[4 * q + 3] = v.w;
+constexpr int SLOT_BYTES = 32768;
+struct Stash {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;   // lane * 16
+
+    __device__ __forceinline__ void init(float4* wave_base, int n_slots, int lane) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(wave_base, 0, n_slots * SLOT_BYTES, 0x00020000);
+        voff = lane * 16;
     }
-    return y;
-}
-// fragment stash: [k-step][hi|lo][lane] 16 B
-__device__ __forceinline__ void stash_frag(float4* slot, int s, const h8& hi, const h8& lo, int lane) {
-    slot[(s * 2) * 64 + lane] = *reinterpret_cast<const float4*>(&hi);
-    slot[(s * 2 + 1) * 64 + lane] = *reinterpret_cast<const float4*>(&lo);
-}
-__device__ __forceinline__ void unstash_frag(const float4* slot, int s, h8& hi, h8& lo, int lane) {
-    const float4 a = slot[(s * 2) * 64 + lane];
-    const float4 b = slot[(s * 2 + 1) * 64 + lane];
-    hi = *reinterpret_cast<const h8*>(&a);
-    lo = *reinterpret_cast<const h8*>(&b);
-}
+    // 16-byte store.  The byte offset goes into the VGPR operand and soffset stays 0 on purpose: with an
+    // SGPR soffset hipcc (ROCm 7.2) places no wait state between a buffer_store_dwordx4 and a following
+    // VALU write of its data registers (it assumes the hardware interlocks), and on gfx950 the store then
+    // picks up the NEW register contents for its later dwords (observed: dword 1 of a fragment replaced
+    // by the residual computed two instructions later).  In this form the compiler's store-data hazard
+    // rule applies and the required wait state is inserted.
+    template <typename T16>
+    __device__ __forceinline__ void st16(const T16& v, int off) const {
+        static_assert(sizeof(T16) == 16, "16-byte values only");
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff + off, 0, 0);
+    }
+    __device__ __forceinline__ u32x4 ld16(int off) const { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, off, 0); }
+    // fp32 tile t of slot `slot`: [t][q][lane] float4
+    __device__ __forceinline__ void tile_store(int slot, int t, const f32x16& y) const {
+        using f32x4 = float __attribute__((ext_vector_type(4)));
+        const int off = slot * SLOT_BYTES + t * 4096;
+        st16((f32x4)__builtin_shufflevector(y, y, 0, 1, 2, 3), off);
+        st16((f32x4)__builtin_shufflevector(y, y, 4, 5, 6, 7), off + 1024);
+        st16((f32x4)__builtin_shufflevector(y, y, 8, 9, 10, 11), off + 2048);
+        st16((f32x4)__builtin_shufflevector(y, y, 12, 13, 14, 15), off + 3072);
+    }
+    __device__ __forceinline__ f32x16 tile_load(int slot, int t) const {
+        using f32x4 = float __attribute__((ext_vector_type(4)));
+        using f32x8 = float __attribute__((ext_vector_type(8)));
+        const int off = slot * SLOT_BYTES + t * 4096;
+        const f32x4 a = __builtin_bit_cast(f32x4, ld16(off));
+        const f32x4 b = __builtin_bit_cast(f32x4, ld16(off + 1024));
+        const f32x4 c = __builtin_bit_cast(f32x4, ld16(off + 2048));
+        const f32x4 d = __builtin_bit_cast(f32x4, ld16(off + 3072));
+        const f32x8 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+        const f32x8 cd = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    }
+    // fragment block s (byte offset `base` + s * 2 KiB): [hi | lo][lane] 16 B
+    __device__ __forceinline__ void frag_store(int base, int s, const h8& hi, const h8& lo) const {
+        st16(hi, base + s * KS_BYTES);
+        st16(lo, base + s * KS_BYTES + 1024);
+    }
+    __device__ __forceinline__ void frag_load(int base, int s, h8& hi, h8& lo) const {
+        const u32x4 a = ld16(base + s * KS_BYTES);
+        const u32x4 b = ld16(base + s * KS_BYTES + 1024);
+        hi = __builtin_bit_cast(h8, a);
+        lo = __builtin_bit_cast(h8, b);
+    }
+    // one float per lane at byte offset off + lane * 4
+    __device__ __forceinline__ void f32_store(int off, float v) const {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff >> 2, off, 0);
+    }
+    __device__ __forceinline__ float f32_load(int off) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff >> 2, off, 0));
+    }
+};
 
 // Re-materialises a wave-uniform pointer in SGPRs behind an opaque asm so that the compiler cannot
 // hoist the (hundreds of) addresses derived from it out of the persistent tile loop -- hoisted, they
