@@ -1,0 +1,107 @@
+"""Host logic of the frame-sharded fitting drivers (ho-nerf_amd/fitting.py) incl. the N > 1 path on
+CPU: two processes, `gloo` backend, rendezvous on 127.0.0.1."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from honerf_amd import fitting
+
+
+def test_shards_partition_frames():
+    for n in (0, 1, 7, 8, 33):
+        for world in (1, 2, 4, 8):
+            got = sorted(f for r in range(world) for f in fitting.shard_frames(n, r, world))
+            assert got == list(range(n))
+    with pytest.raises(ValueError):
+        fitting.shard_frames(4, 2, 2)
+
+
+def test_windows_match_reference_sampler():
+    """RayImageSampler(N_images=4, N_iter=len-3) (utils/dataset.py:396-404, fitting_video.py:146-149)."""
+    assert fitting.sliding_windows(6) == [[0, 1, 2, 3], [1, 2, 3, 4], [2, 3, 4, 5]]
+    assert fitting.sliding_windows(3) == []
+    for world in (1, 2, 3):
+        sched = [fitting.window_schedule(9, r, world) for r in range(world)]
+        flat = [w for s in range(len(sched[0])) for r in range(world) for w in [sched[r][s]] if w is not None]
+        assert flat == fitting.sliding_windows(9)     # step-major, rank-minor == the sequential order
+
+
+def _fake_render(frame, rays=24, S=8):
+    g = torch.Generator().manual_seed(100 + frame)
+    return {
+        'color_fine': torch.rand(rays, 3, generator=g), 'weight_sum': torch.rand(rays, 1, generator=g),
+        'sdf_hand': (torch.rand(rays * S, 1, generator=g) - 0.5) * 0.05,
+        'sdf_obj': (torch.rand(rays * S, 1, generator=g) - 0.5) * 0.05,
+    }, torch.rand(rays, 3, generator=g), (torch.rand(rays, 1, generator=g) > 0.3).float()
+
+
+def _frame_terms(frame):
+    out, rgb, mask = _fake_render(frame)
+    return fitting.render_loss_terms(out, rgb, mask, fit_type='12')
+
+
+def test_loss_terms_formulas():
+    """fitting_single.py:251-283 restated independently."""
+    out, rgb, mask = _fake_render(3)
+    t = fitting.render_loss_terms(out, rgb, mask, fit_type='12')
+    color = ((out['color_fine'] - rgb) * mask).abs().sum() / mask.shape[0]
+    w = out['weight_sum'].clip(1e-3, 1 - 1e-3)
+    bce = -(mask * w.log() + (1 - mask) * (1 - w).log()).mean()
+    sh, so = out['sdf_hand'][:, 0], out['sdf_obj'][:, 0]
+    s = sh.abs() + so.abs()
+    contact = s[s < 1e-2].sum() / ((s < 1e-2).float().sum() + 1e-9)
+    pen = (sh < 0) & (so < 0)
+    penet = s[pen].sum() / (pen.float().sum() + 1e-9)
+    assert torch.allclose(t['color'], color) and torch.allclose(t['mask'], bce, atol=1e-6)
+    assert torch.allclose(t['contact'], contact) and torch.allclose(t['penetration'], penet)
+    assert torch.allclose(t['loss'], color + 0.5 * bce + 30 * contact + 20 * penet, atol=1e-6)
+    t1 = fitting.render_loss_terms(out, rgb, mask, fit_type='1')
+    assert float(t1['contact']) == 0.0 and torch.allclose(t1['loss'], color + 0.5 * bce, atol=1e-6)
+
+
+def test_mask_pixels_convention():
+    mask = np.zeros((8, 12), np.float32)
+    mask[2:5, 3:9] = 1
+    xy, idx = fitting.mask_pixels(mask, 50, np.random.default_rng(0))
+    py, px = idx // 12, idx % 12
+    assert mask[py, px].all()
+    assert np.allclose(xy[:, 0], -(px - 6.0) / 4.0) and np.allclose(xy[:, 1], -(py - 4.0) / 4.0)
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        done = (lambda f: f == 5)            # a frame whose result already exists is skipped on restart
+        runner = fitting.FrameShardedRunner(n_frames, done=done)
+        q.put((rank, runner.frames, runner.run(_frame_terms)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_reduction_equals_single_process():
+    n_frames = 11
+    single = fitting.FrameShardedRunner(n_frames, rank=0, world=1, done=lambda f: f == 5).run(_frame_terms)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    frames = sorted(f for _, fr, _ in res for f in fr)
+    assert frames == [f for f in range(n_frames) if f != 5]
+    for _, _, red in res:                      # both ranks hold the same reduced means
+        assert red['frames'] == single['frames'] == n_frames - 1
+        for k in fitting.LOSS_KEYS[:-1]:
+            assert abs(red[k] - single[k]) < 1e-9, (k, red[k], single[k])
