@@ -197,19 +197,28 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         const float* Tp = a.T_pose + (size_t)frame * N_BONES * 3;
 
         // ---- F0: features of the 21 bones -> fragments in the stash -------------------------------------
+        // nz bit b: some sample of this wave has a non-zero mask h for bone b.  Where none has, all 64
+        // features of the bone are exactly 0 for the whole wave: nothing is generated or stored, and the
+        // consumers substitute zero fragments instead of loading (the MFMAs still run: dense compute).
+        unsigned nz = 0;
 #pragma unroll 1
         for (int b = 0; b < N_BONES; ++b) {
             const Bone2 bn = bone_coords2(p, M, Tp, b);
-            float f[4][8];
-            bone_features2(bn, h, f);
+            const bool any = (a.dbg & 16) ? true : (__ballot(bn.hh != 0.f) != 0ull);
+            if (any) {
+                nz |= 1u << b;
+                float f[4][8];
+                bone_features2(bn, h, f);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                h8 fh, fl;
-                split8(f[s], fh, fl);
-                sh.frag_store(FEAT, 4 * b + s, fh, fl);
+                for (int s = 0; s < 4; ++s) {
+                    h8 fh, fl;
+                    split8(f[s], fh, fl);
+                    sh.frag_store(FEAT, 4 * b + s, fh, fl);
+                }
             }
-            sh.f32_store(LEFT + b * 256, (h ? bn.r[2] : bn.r[1]) * bn.hh);
+            sh.f32_store(LEFT + b * 256, any ? (h ? bn.r[2] : bn.r[1]) * bn.hh : 0.f);
         }
+        nz = __builtin_amdgcn_readfirstlane(nz);
         {   // leftover block: element j of k-step u belongs to bone 8u + j
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -263,25 +272,42 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             };
         };
 
-        // ---- a block of 4 output tiles over the feature space: 21 bone chunks + the leftover chunk ------
-        // c1/c2[ti] += W[tile 4p+ti, features] * feat.  Bone b+1's fragments are loaded while bone b's
-        // MFMAs run.  Returns the leftover chunk's LDS address (its tail holds side data for some layers).
-        auto feature_pass = [&](f32x16(&c1)[4], f32x16(&c2)[4], int left_bytes, int next_after) -> const char* {
-            h8 fh[2][4], fl[2][4];
-            auto load_bone = [&](int b, h8(&oh)[4], h8(&ol)[4]) {
+        // ---- NB blocks of 4 output tiles over the feature space: per bone NB chunks (4 tiles x 4 k-steps each)
+        //      sharing the bone's fragments, then NB leftover chunks (4 tiles x 3 k-steps [+ tail: the 4 biases,
+        //      added here when BIAS]).  c1/c2[4 blk + ti] += W[tile, features] * feat.  Bone b+1's fragments are
+        //      loaded while bone b's MFMAs run.
+        auto load_bone = [&](int b, h8(&oh)[4], h8(&ol)[4]) {
+            if (b >= N_BONES || ((nz >> b) & 1u)) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) sh.frag_load(FEAT, 4 * b + s, oh[s], ol[s]);
-            };
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        oh[s][jj] = (_Float16)0.f;
+                        ol[s][jj] = (_Float16)0.f;
+                    }
+                }
+            }
+        };
+        auto feature_pass = [&](auto NB_, auto BIAS_, auto& c1, auto& c2, int left_bytes, int next_after) {
+            constexpr int NB = decltype(NB_)::value;
+            constexpr bool BIAS = decltype(BIAS_)::value;
+            h8 fh[2][4], fl[2][4];
             auto step = [&](int b, const h8(&uh)[4], const h8(&ul)[4], h8(&nh)[4], h8(&nl)[4]) {
-                const char* buf = ws.template acquire<0>();
-                ws.begin(b + 1 < N_BONES ? HB_BONE : left_bytes);
-                load_bone(b + 1, nh, nl);   // b + 1 == 21: the leftover blocks 84..86 (+ one unused)
-                static_for<4>([&](auto TI) {
-                    constexpr int ti = decltype(TI)::value;
-                    if constexpr (ti == 0)
-                        mma_tile<4, 0, true>(ws, buf + ti * 4 * KS_BYTES, uh, ul, c1[ti], c2[ti], lane);
-                    else
-                        mma_tile<4, 0, false>(ws, buf + ti * 4 * KS_BYTES, uh, ul, c1[ti], c2[ti], lane);
+                static_for<NB>([&](auto BLK) {
+                    constexpr int blk = decltype(BLK)::value;
+                    const char* buf = ws.template acquire<0>();
+                    ws.begin((blk + 1 < NB || b + 1 < N_BONES) ? HB_BONE : left_bytes);
+                    if constexpr (blk == 0) load_bone(b + 1, nh, nl);   // b + 1 == 21: the leftover blocks 84..86
+                    static_for<4>([&](auto TI) {
+                        constexpr int ti = decltype(TI)::value;
+                        if constexpr (ti == 0)
+                            mma_tile<4, 0, true>(ws, buf + ti * 4 * KS_BYTES, uh, ul, c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                        else
+                            mma_tile<4, 0, false>(ws, buf + ti * 4 * KS_BYTES, uh, ul, c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                    });
                 });
             };
             load_bone(0, fh[0], fl[0]);
@@ -291,21 +317,28 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 step(2 * b2 + 1, fh[1], fl[1], fh[0], fl[0]);
             }
             step(N_BONES - 1, fh[0], fl[0], fh[1], fl[1]);
-            const char* buf = ws.template acquire<0>();
-            ws.begin(next_after);
-            static_for<4>([&](auto TI) {
-                constexpr int ti = decltype(TI)::value;
-                if constexpr (ti == 0)
-                    mma_tile<3, 0, true>(ws, buf + ti * 3 * KS_BYTES, fh[1], fl[1], c1[ti], c2[ti], lane);
-                else
-                    mma_tile<3, 0, false>(ws, buf + ti * 3 * KS_BYTES, fh[1], fl[1], c1[ti], c2[ti], lane);
+            static_for<NB>([&](auto BLK) {
+                constexpr int blk = decltype(BLK)::value;
+                const char* buf = ws.template acquire<0>();
+                ws.begin(blk + 1 < NB ? left_bytes : next_after);
+                static_for<4>([&](auto TI) {
+                    constexpr int ti = decltype(TI)::value;
+                    if constexpr (ti == 0)
+                        mma_tile<3, 0, true>(ws, buf + ti * 3 * KS_BYTES, fh[1], fl[1], c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                    else
+                        mma_tile<3, 0, false>(ws, buf + ti * 3 * KS_BYTES, fh[1], fl[1], c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                    if constexpr (BIAS) {
+                        const f32x16 bias = tail_tile(buf + 4 * 3 * KS_BYTES, ti, h);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) c1[4 * blk + ti][i] += bias[i];
+                    }
+                });
             });
-            return buf;
         };
         // epilogue of a finished block (not overlapped with MFMAs): ph / fin as in run_layer
-        auto block_epilogue = [&](auto P_, f32x16(&c1)[4], f32x16(&c2)[4], auto&& ph, auto&& fin) {
-            constexpr int pass = decltype(P_)::value;
-            static_for<4>([&](auto TI) {
+        auto block_epilogue = [&](auto NT_, auto& c1, auto& c2, auto&& ph, auto&& fin) {
+            constexpr int NTT = decltype(NT_)::value;
+            static_for<NTT>([&](auto TI) {
                 constexpr int ti = decltype(TI)::value;
                 EpiState st;
                 arm(st);
@@ -315,30 +348,25 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 Epi<true, std::remove_reference_t<decltype(ph)>, NoData> epi{st, ph, nd};
                 epi.run_all();
                 split_finish<true>(st);
-                fin(std::integral_constant<int, 4 * pass + ti>{}, st, nd);
+                fin(std::integral_constant<int, ti>{}, st, nd);
             });
         };
+        using I2 = std::integral_constant<int, 2>;
+        using I8t = std::integral_constant<int, 8>;
+        using BTrue = std::integral_constant<bool, true>;
+        using BFalse = std::integral_constant<bool, false>;
 
-        // ---- lin0: features -> a1 -------------------------------------------------------------------------
-        static_for<2>([&](auto P_) {
-            constexpr int pass = decltype(P_)::value;
-            f32x16 c1[4], c2[4];
+        // ---- lin0: features -> a1 (one pass, 8 tile accumulators) ---------------------------------------------
+        {
+            f32x16 c1[8], c2[8];
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
+            for (int ti = 0; ti < 8; ++ti) {
                 c1[ti] = zero16();
                 c2[ti] = zero16();
             }
-            const char* lbuf = feature_pass(c1, c2, HB_LEFT_T, pass == 0 ? HB_BONE : HB_HID);
-            const char* tail = lbuf + 4 * 3 * KS_BYTES;
-#pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                const f32x16 bias = tail_tile(tail, ti, h);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) c1[ti][i] += bias[i];
-            }
-            block_epilogue(P_, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 0));
-        });
-        if ((a.dbg >> 8) == 2) return;   // phase timing aid
+            feature_pass(I2{}, BTrue{}, c1, c2, HB_LEFT_T, HB_HID);
+            block_epilogue(I8t{}, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 0));
+        }
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 1), no_store);   // lin1
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 2), no_store);   // lin2
         // lin3 -> a4: kept as fragments in the stash too (lin4's hidden part reads them in both passes)
@@ -351,27 +379,25 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                                         },
                                         no_store);
         if ((a.dbg >> 8) == 3) return;   // phase timing aid
-        // ---- lin4 = [a4 | features] / sqrt2 -> a5: per pass 4 hidden tiles, then the feature block
-        static_for<2>([&](auto P_) {
-            constexpr int pass = decltype(P_)::value;
-            f32x16 c1[4], c2[4];
+        // ---- lin4 = [a4 | features] / sqrt2 -> a5: 8 hidden tiles (bias from the tail), then the feature pass
+        {
+            f32x16 c1[8], c2[8];
             {
                 h8 xh[16], xl[16];
 #pragma unroll
                 for (int s = 0; s < 16; ++s) sh.frag_load(HS_A4F * SLOT_BYTES, s, xh[s], xl[s]);
-                static_for<4>([&](auto TI) {
+                static_for<8>([&](auto TI) {
                     constexpr int ti = decltype(TI)::value;
                     const char* buf = ws.template acquire<0>();
-                    ws.begin(ti < 3 ? HB_HID : HB_BONE);
+                    ws.begin(ti < 7 ? HB_HID : HB_BONE);
                     c1[ti] = tail_tile(buf + 16 * KS_BYTES, 0, h);
                     c2[ti] = zero16();
                     mma_tile<16, 0, true>(ws, buf, xh, xl, c1[ti], c2[ti], lane);
                 });
             }
-            feature_pass(c1, c2, HB_LEFT, HB_HID);
-            block_epilogue(P_, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 4));
-        });
-        if ((a.dbg >> 8) == 4) return;   // phase timing aid
+            feature_pass(I2{}, BFalse{}, c1, c2, HB_LEFT, HB_HID);
+            block_epilogue(I8t{}, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 4));
+        }
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 5), no_store);   // lin5
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 6), no_store);   // lin6
         // ---- lin7 -> a8; sdf = W8[0,:] a8 + b8; seed of the reverse sweep dz7 = sigma'(z7) W8[0,:] (scaled)
@@ -451,58 +477,71 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         // ---- d sdf / d features contracted with the encoding Jacobian, bone by bone: first W0^T dz0 (dz0 is in
         //      bh/bl), then W4[:, 256:]^T dz4 (reloaded into ah/al)
         float g[3] = {0.f, 0.f, 0.f};
-        auto jacobian_pass = [&](const h8(&dh)[16], const h8(&dl)[16], int next_after) {
+        // G = W0^T dz0 + W4[:, 256:]^T dz4 accumulated per tile (chunks alternate between the two matrices),
+        // so that the features and the Jacobian are visited once
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sh.frag_load(HS_DZ4 * SLOT_BYTES, s, ah[s], al[s]);
+        {
 #pragma unroll 1
             for (int b = 0; b < N_BONES; ++b) {
                 f32x16 G1[2], G2[2];
                 h8 fh[4], fl[4];
+                const bool live = (nz >> b) & 1u;
+                if (live) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) sh.frag_load(FEAT, 4 * b + s, fh[s], fl[s]);
+                    for (int s = 0; s < 4; ++s) sh.frag_load(FEAT, 4 * b + s, fh[s], fl[s]);
+                }
                 static_for<2>([&](auto U) {
                     constexpr int u = decltype(U)::value;
-                    const char* buf = ws.template acquire<0>();
+                    const char* buf0 = ws.template acquire<0>();
                     ws.begin(HB_BWD);
                     G1[u] = zero16();
                     G2[u] = zero16();
-                    mma_tile<16, 0, true>(ws, buf, dh, dl, G1[u], G2[u], lane);
+                    mma_tile<16, 0, true>(ws, buf0, bh, bl, G1[u], G2[u], lane);
+                    const char* buf4 = ws.template acquire<0>();
+                    ws.begin(HB_BWD);
+                    mma_tile<16, 0, true>(ws, buf4, ah, al, G1[u], G2[u], lane);
                 });
-                const Bone2 bn = bone_coords2(p, M, Tp, b);
-                const float kk = -TAU2 * (1.f - bn.hh);
-                float own[4][8];
+                if (live) {   // a bone whose mask is 0 for the whole wave contributes exactly 0
+                    const Bone2 bn = bone_coords2(p, M, Tp, b);
+                    const float kk = -TAU2 * (1.f - bn.hh);
+                    float own[4][8];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                    for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) own[s][jj] = unsplit(fh[s][jj], fl[s][jj]);
-                float Sv = 0.f, Sr[3] = {0.f, 0.f, 0.f};
-                bone_jacobian(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn, kk, h, Sv, Sr);
-                bone_to_p(Sv, Sr, bn, M + 16 * b, g);
+                        for (int jj = 0; jj < 8; ++jj) own[s][jj] = unsplit(fh[s][jj], fl[s][jj]);
+                    float Sv = 0.f, Sr[3] = {0.f, 0.f, 0.f};
+                    bone_jacobian(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn, kk, h, Sv, Sr);
+                    bone_to_p(Sv, Sr, bn, M + 16 * b, g);
+                }
             }
             // leftover block: 2 tiles; register 8 (u & 1) + j of tile u >> 1 <-> bone 8 u + j : (r_1 | r_2) h
             f32x16 L1[2], L2[2];
             static_for<2>([&](auto U) {
                 constexpr int u = decltype(U)::value;
-                const char* buf = ws.template acquire<0>();
-                ws.begin(u == 0 ? HB_BWD : next_after);
+                const char* buf0 = ws.template acquire<0>();
+                ws.begin(HB_BWD);
                 L1[u] = zero16();
                 L2[u] = zero16();
-                mma_tile<16, 0, true>(ws, buf, dh, dl, L1[u], L2[u], lane);
+                mma_tile<16, 0, true>(ws, buf0, bh, bl, L1[u], L2[u], lane);
+                const char* buf4 = ws.template acquire<0>();
+                ws.begin(HB_BWD);   // after the last one: colour lin0's first feature-vector chunk, same size
+                mma_tile<16, 0, true>(ws, buf4, ah, al, L1[u], L2[u], lane);
             });
             const f32x16 La = combine(L1[0], L2[0]), Lb = combine(L1[1], L2[1]);
             static_for<N_BONES>([&](auto B_) {
                 constexpr int b = decltype(B_)::value;
-                const float Gv = b < 16 ? La[b] : Lb[b - 16];
-                const Bone2 bn = bone_coords2(p, M, Tp, b);
-                const float kk = -TAU2 * (1.f - bn.hh);
-                const float own = (h ? bn.r[2] : bn.r[1]) * bn.hh;
-                float Sv = Gv * own * kk;
-                float Sr[3] = {0.f, h ? 0.f : Gv * bn.hh, h ? Gv * bn.hh : 0.f};
-                bone_to_p(Sv, Sr, bn, M + 16 * b, g);
+                if ((nz >> b) & 1u) {
+                    const float Gv = b < 16 ? La[b] : Lb[b - 16];
+                    const Bone2 bn = bone_coords2(p, M, Tp, b);
+                    const float kk = -TAU2 * (1.f - bn.hh);
+                    const float own = (h ? bn.r[2] : bn.r[1]) * bn.hh;
+                    float Sv = Gv * own * kk;
+                    float Sr[3] = {0.f, h ? 0.f : Gv * bn.hh, h ? Gv * bn.hh : 0.f};
+                    bone_to_p(Sv, Sr, bn, M + 16 * b, g);
+                }
             });
-        };
-        jacobian_pass(bh, bl, HB_BWD);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) sh.frag_load(HS_DZ4 * SLOT_BYTES, s, ah[s], al[s]);
-        jacobian_pass(ah, al, HB_BWD);
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) g[c] *= BWD_INV;
 
@@ -516,39 +555,38 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             split8(fg[0], gh[0], gl[0]);
             split8(fg[1], gh[1], gl[1]);
         }
-        static_for<2>([&](auto P_) {
-            constexpr int pass = decltype(P_)::value;
-            f32x16 c1[4], c2[4];
+        {
+            f32x16 c1[8], c2[8];
             {
                 h8 xh[16], xl[16];
 #pragma unroll
                 for (int s = 0; s < 16; ++s) sh.frag_load(HS_FVEC * SLOT_BYTES, s, xh[s], xl[s]);
-                static_for<4>([&](auto TI) {
+                static_for<8>([&](auto TI) {
                     constexpr int ti = decltype(TI)::value;
                     const char* buf = ws.template acquire<0>();
-                    ws.begin(ti < 3 ? HB_BWD : HB_BONE);
+                    ws.begin(ti < 7 ? HB_BWD : HB_BONE);
                     c1[ti] = zero16();
                     c2[ti] = zero16();
                     mma_tile<16, 0, true>(ws, buf, xh, xl, c1[ti], c2[ti], lane);
                 });
             }
-            feature_pass(c1, c2, HB_LEFT, HB_G);
-            {
+            feature_pass(I2{}, BFalse{}, c1, c2, HB_LEFT, HB_G);
+            static_for<2>([&](auto BLK) {
+                constexpr int blk = decltype(BLK)::value;
                 const char* buf = ws.template acquire<0>();
-                ws.begin(pass == 0 ? HB_BWD : HB_HID);
+                ws.begin(blk == 0 ? HB_G : HB_HID);
                 ws.pieces_all();   // 6 MFMA slots per tile here: too few to spread the pieces over
                 const char* tail = buf + 4 * 2 * KS_BYTES;
                 static_for<4>([&](auto TI) {
                     constexpr int ti = decltype(TI)::value;
-                    mma_tile<2, 0, false>(ws, buf + ti * 2 * KS_BYTES, gh, gl, c1[ti], c2[ti], lane);
+                    mma_tile<2, 0, false>(ws, buf + ti * 2 * KS_BYTES, gh, gl, c1[4 * blk + ti], c2[4 * blk + ti], lane);
                     const f32x16 bias = tail_tile(tail, ti, h);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) c1[ti][i] += bias[i];
+                    for (int i = 0; i < 16; ++i) c1[4 * blk + ti][i] += bias[i];
                 });
-            }
-            block_epilogue(P_, c1, c2, PhRelu{}, to_regs(bh, bl));
-        });
-        if ((a.dbg >> 8) == 9) return;   // phase timing aid
+            });
+            block_epilogue(I8t{}, c1, c2, PhRelu{}, to_regs(bh, bl));
+        }
         auto relu_to = [&](h8(&oh)[16], h8(&ol)[16]) { return to_regs(oh, ol); };
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhRelu{}, relu_to(ah, al), no_store);   // colour lin1
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhRelu{}, relu_to(bh, bl), no_store);   // colour lin2

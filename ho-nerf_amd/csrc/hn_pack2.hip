@@ -322,16 +322,19 @@ static std::vector<int> left_slots() {
             }
     return c;
 }
-// W[rows of 4 tiles][feature space]: 21 bone chunks (4 tiles x 4 k-steps) + the leftover chunk (4 tiles x 3)
-static void feature_block(Builder& B, const HostMat& M, float scale, int pass, int col_off, const float* tail) {
-    std::vector<int> rows;
-    for (int ti = 0; ti < 4; ++ti) rows = cat(rows, rows_of_tile(4 * pass + ti, 256));
+// W[all 8 output tiles][feature space] in the order feature_pass consumes it: per bone two chunks (tiles 0..3,
+// tiles 4..7; 4 k-steps), then the two leftover chunks (3 k-steps, + tail when given)
+static void feature_block(Builder& B, const HostMat& M, float scale, int col_off, const float* tail0, const float* tail1) {
+    std::vector<int> rows[2];
+    for (int blk = 0; blk < 2; ++blk)
+        for (int ti = 0; ti < 4; ++ti) rows[blk] = cat(rows[blk], rows_of_tile(4 * blk + ti, 256));
     for (int b = 0; b < N_BONES; ++b) {
         const std::vector<int> slots = offset(bone_slots(b), col_off);
-        B.chunk(M, false, scale, 4, 4, rows.data(), slots.data(), nullptr);
+        for (int blk = 0; blk < 2; ++blk) B.chunk(M, false, scale, 4, 4, rows[blk].data(), slots.data(), nullptr);
     }
     const std::vector<int> ls = offset(left_slots(), col_off);
-    B.chunk(M, false, scale, 4, 3, rows.data(), ls.data(), tail);
+    B.chunk(M, false, scale, 4, 3, rows[0].data(), ls.data(), tail0);
+    B.chunk(M, false, scale, 4, 3, rows[1].data(), ls.data(), tail1);
 }
 static void tail_biases4(float* tail, const HostMat& M, int pass) {
     for (int ti = 0; ti < 4; ++ti) {
@@ -340,12 +343,28 @@ static void tail_biases4(float* tail, const HostMat& M, int pass) {
         tail_put(tail, ti, v);
     }
 }
-// rows = the feature slots of every bone (2 tiles each) and of the leftover block (2 tiles), W transposed
-static void feature_rows_T(Builder& B, const HostMat& M, float scale, int col_off) {
-    for (int b = 0; b < N_BONES; ++b) slot_rows_T(B, M, scale, bone_slots(b), col_off);
-    std::vector<int> ls = left_slots();
-    ls.resize(64, -1);
-    slot_rows_T(B, M, scale, ls, col_off);
+// d sdf / d features = W0^T dz0 + W4[:, 256:]^T dz4: rows = the feature slots of every bone (2 tiles) and of
+// the leftover block (2 tiles); per tile first the W0 chunk, then the W4 chunk (same accumulator)
+static void one_slot_tile_T(Builder& B, const HostMat& M, float scale, const std::vector<int>& in_slots, int col_off, int u) {
+    const std::vector<int> slots = hid_slots();
+    std::vector<int> rows(32, -1);
+    for (int r = 0; r < 32; ++r) {
+        int s, h, j;
+        k_of_row(32 * u + r, s, h, j);
+        const int c = in_slots[s * 16 + 8 * h + j];
+        rows[r] = c >= 0 ? col_off + c : -1;
+    }
+    B.chunk(M, true, scale, 1, 16, rows.data(), slots.data(), nullptr);
+}
+static void feature_rows_T(Builder& B, const HostMat& M0, const HostMat& M4, float scale4, int col_off4) {
+    for (int b = 0; b <= N_BONES; ++b) {
+        std::vector<int> sl = b < N_BONES ? bone_slots(b) : left_slots();
+        sl.resize(64, -1);
+        for (int u = 0; u < 2; ++u) {
+            one_slot_tile_T(B, M0, 1.f, sl, 0, u);
+            one_slot_tile_T(B, M4, scale4, sl, col_off4, u);
+        }
+    }
 }
 
 // The hand program (contract with k_field2_hand)
@@ -353,27 +372,18 @@ void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, bool full
     const float rs2 = (float)(1.0 / sqrt(2.0));
     const std::vector<int> hs = hid_slots();
     // lin0: two passes of 4 output tiles over the feature space; the leftover chunk's tail holds the 4 biases
-    for (int p = 0; p < 2; ++p) {
-        float tail[256] = {0.f};
-        tail_biases4(tail, S[0], p);
-        feature_block(B, S[0], 1.f, p, 0, tail);
+    {
+        float tail0[256] = {0.f}, tail1[256] = {0.f};
+        tail_biases4(tail0, S[0], 0);
+        tail_biases4(tail1, S[0], 1);
+        feature_block(B, S[0], 1.f, 0, tail0, tail1);
     }
     fwd_tiles(B, S[1], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
     fwd_tiles(B, S[2], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
     fwd_tiles(B, S[3], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
-    // lin4 = [a4 (256) | features (1386)] / sqrt2: per pass 4 hidden tiles (+bias), then the feature block
-    for (int p = 0; p < 2; ++p) {
-        for (int ti = 0; ti < 4; ++ti) {
-            const int t = 4 * p + ti;
-            const std::vector<int> rows = rows_of_tile(t, 256);
-            float tail[256] = {0.f};
-            float v[32];
-            for (int i = 0; i < 32; ++i) v[i] = S[4].b[rows[i]];
-            tail_put(tail, 0, v);
-            B.chunk(S[4], false, rs2, 1, 16, rows.data(), hs.data(), tail);
-        }
-        feature_block(B, S[4], rs2, p, H, nullptr);
-    }
+    // lin4 = [a4 (256) | features (1386)] / sqrt2: 8 hidden tiles (+bias), then the feature block
+    fwd_tiles(B, S[4], rs2, 8, 256, 0, hs, 16, nullptr, 0);
+    feature_block(B, S[4], rs2, H, nullptr, nullptr);
     fwd_tiles(B, S[5], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
     fwd_tiles(B, S[6], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
     {
@@ -385,19 +395,18 @@ void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, bool full
     if (!full) return;
     fwd_tiles(B, S[8], 1.f, 8, 256, 1, hs, 16, nullptr, 0);
     for (int l = 7; l >= 1; --l) bwd_tiles(B, S[l], l == 4 ? rs2 : 1.f, 8, 256, 0, 256, 16);
-    feature_rows_T(B, S[0], 1.f, 0);      // W0^T dz0
-    feature_rows_T(B, S[4], rs2, H);      // W4[:, 256:]^T dz4
+    feature_rows_T(B, S[0], S[4], rs2, H);
     // colour lin0 = [features 1386 | feature vector 256 | enc4(g) 27] (utils/fields.py:224-229)
     {
         const std::vector<int> v4 = vec4_slots();
         const std::vector<int> fv = offset(hs, HAND_IN);
         const std::vector<int> gs = offset(v4, HAND_IN + H);
+        for (int t = 0; t < 8; ++t) {
+            const std::vector<int> rows = rows_of_tile(t, 256);
+            B.chunk(C[0], false, 1.f, 1, 16, rows.data(), fv.data(), nullptr);
+        }
+        feature_block(B, C[0], 1.f, 0, nullptr, nullptr);
         for (int p = 0; p < 2; ++p) {
-            for (int ti = 0; ti < 4; ++ti) {
-                const std::vector<int> rows = rows_of_tile(4 * p + ti, 256);
-                B.chunk(C[0], false, 1.f, 1, 16, rows.data(), fv.data(), nullptr);
-            }
-            feature_block(B, C[0], 1.f, p, 0, nullptr);
             std::vector<int> rows;
             for (int ti = 0; ti < 4; ++ti) rows = cat(rows, rows_of_tile(4 * p + ti, 256));
             float tail[256] = {0.f};

@@ -405,12 +405,17 @@ def test_dual_core_on_reference_depths(golden, name, prec):
         out[kind] = (sdf, grad, rgb, al)
         assert_close(sdf, g['sdf_' + kind], RT, name + ' sdf_' + kind)
         assert_close(al.reshape(g['alpha_' + kind].shape), g['alpha_' + kind], 2e-4, name + ' alpha_' + kind)
-        e_g = rel_err(grad.cpu().numpy(), g['gradient_' + kind])
-        e_c = rel_err(rgb.cpu().numpy().reshape(g['rgb_' + kind].shape), g['rgb_' + kind])
-        print(name, kind, 'grad', e_g, 'rgb', e_c)
-        # hand gradient / colour: the fp32 reference is itself ~1.3e-4 / 2.5e-4 from exact near the
-        # joints (test_render_core_on_reference_depths measures it); 5e-4 bounds both here
-        assert e_g < (1e-4 if kind == 'obj' else 5e-4) and e_c < (1e-4 if kind == 'obj' else 5e-4)
+        if kind == 'obj':
+            assert_close(grad, g['gradient_' + kind], RT, name + ' gradient_obj')
+            assert_close(rgb.reshape(g['rgb_' + kind].shape), g['rgb_' + kind], RT, name + ' rgb_obj')
+        else:
+            # hand gradient / colour near the joints: the fp32 reference is itself 1.3e-4 / 2.5e-4 from the exact
+            # value there, so the bound is the conditioning-aware one (no further from fp64 than the reference is)
+            h64, _ = oracle_fields_fp64()
+            dirs = rd.reshape(N, 1, 3).expand(N, S, 3).reshape(-1, 3)
+            _, g64, c64 = h64.evaluate(pts.cpu().double().reshape(F_, P * S, 3), dirs.double(), bt.double(), tp.double())
+            print(name, 'hand grad', assert_parity(grad, g['gradient_' + kind], g64, name + ' gradient_hand', cap=2e-3),
+                  'rgb', assert_parity(rgb.reshape(g['rgb_' + kind].shape), g['rgb_' + kind], c64, name + ' rgb_hand', cap=2e-3))
     color = torch.empty(N, 3, device='cuda')
     ws = torch.empty(N, device='cuda')
     eik = torch.zeros(2, device='cuda')
