@@ -452,6 +452,12 @@ struct PhIdentity {
 using u32x4 = unsigned __attribute__((ext_vector_type(4)));
 constexpr size_t SLOT_F4 = 8 * 4 * 64;   // float4 per slot
 constexpr int SLOT_BYTES = 32768;
+// cache policy of the stash traffic: nt (aux = 2) -- written once, read once or a few times much later, it must
+// not evict the weight stream, which every workgroup of the XCD re-reads from L2
+#ifndef HN_STASH_AUX
+#define HN_STASH_AUX 2
+#endif
+constexpr int STASH_AUX = HN_STASH_AUX;
 struct Stash {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff;   // lane * 16
@@ -469,9 +475,9 @@ struct Stash {
     template <typename T16>
     __device__ __forceinline__ void st16(const T16& v, int off) const {
         static_assert(sizeof(T16) == 16, "16-byte values only");
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff + off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff + off, 0, STASH_AUX);
     }
-    __device__ __forceinline__ u32x4 ld16(int off) const { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, off, 0); }
+    __device__ __forceinline__ u32x4 ld16(int off) const { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, off, STASH_AUX); }
     // fp32 tile t of slot `slot`: [t][q][lane] float4
     __device__ __forceinline__ void tile_store(int slot, int t, const f32x16& y) const {
         using f32x4 = float __attribute__((ext_vector_type(4)));
