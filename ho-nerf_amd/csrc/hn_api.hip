@@ -24,6 +24,7 @@ int obj_local_bwd(const float*, const float*, const float*, const float*, const 
                   float*, float*, float*, hipStream_t);
 int coarse_z(const float*, int, int, float, float, float, float*, hipStream_t);
 int sample_points(const float*, const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
+int sample_points_bwd(const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
 int upsample(const float*, const float*, int, int, int, float, float*, int64_t*, hipStream_t);
 int merge(const float*, const float*, const float*, const float*, int, int, int, int, float*, float*, int64_t*,
           hipStream_t);
@@ -33,6 +34,12 @@ int composite1(const float*, const float*, const float*, const float*, int, int,
                hipStream_t);
 int composite2(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
                float*, float*, float*, float*, hipStream_t);
+int alpha_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float, float*,
+              float*, float*, hipStream_t);
+int composite1_bwd(const float*, const float*, const float*, const float*, const float*, int, int, float*, float*, float*,
+                   hipStream_t);
+int composite2_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
+                   float*, float*, float*, hipStream_t);
 size_t field_obj_workspace_bytes(int n_pts, int n_cus);
 size_t field_hand_workspace_bytes(int n_pts, int n_cus);
 int launch_field_obj(const hn_field*, const float*, const float*, int, int, float*, float*, float*, float*, void*, size_t,
@@ -357,6 +364,10 @@ int hn_sample_points(const float* rays_o, const float* rays_d, const float* z, i
                      float sample_dist, float* pts, float* dists, hn_stream_t stream) {
     return sample_points(rays_o, rays_d, z, n_rays, n, mid, sample_dist, pts, dists, (hipStream_t)stream);
 }
+int hn_sample_points_bwd(const float* z, const float* g_pts, int n_rays, int n, int mid, float sample_dist, float* g_rays_o,
+                         float* g_rays_d, hn_stream_t stream) {
+    return sample_points_bwd(z, g_pts, n_rays, n, mid, sample_dist, g_rays_o, g_rays_d, (hipStream_t)stream);
+}
 int hn_upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, float inv_s, float* z_new,
                 int64_t* inds, hn_stream_t stream) {
     return upsample(z, sdf, n_rays, k, n_new, inv_s, z_new, inds, (hipStream_t)stream);
@@ -400,6 +411,23 @@ int hn_composite2(const float* alpha_h, const float* rgb_h, const float* grad_h,
                   float* w_hand, float* w_obj, float* eik_sum, hn_stream_t stream) {
     return composite2(alpha_h, rgb_h, grad_h, alpha_o, rgb_o, grad_o, n_rays, S, color, weight_sum, w_hand, w_obj,
                       eik_sum, (hipStream_t)stream);
+}
+
+int hn_alpha_bwd(const float* sdf, const float* grad, const float* rays_d, const float* dists, const float* g_alpha,
+                 const float* g_c, int n_pts, int samples_per_ray, float inv_s, float* g_sdf, float* g_grad,
+                 float* g_rays_d, hn_stream_t stream) {
+    return alpha_bwd(sdf, grad, rays_d, dists, g_alpha, g_c, n_pts, samples_per_ray, inv_s, g_sdf, g_grad, g_rays_d,
+                     (hipStream_t)stream);
+}
+int hn_composite1_bwd(const float* alpha_in, const float* c, const float* rgb, const float* g_color, const float* g_weight_sum,
+                      int n_rays, int S, float* g_alpha, float* g_c, float* g_rgb, hn_stream_t stream) {
+    return composite1_bwd(alpha_in, c, rgb, g_color, g_weight_sum, n_rays, S, g_alpha, g_c, g_rgb, (hipStream_t)stream);
+}
+int hn_composite2_bwd(const float* alpha_h, const float* rgb_h, const float* alpha_o, const float* rgb_o,
+                      const float* g_color, const float* g_weight_sum, int n_rays, int S, float* g_alpha_h, float* g_rgb_h,
+                      float* g_alpha_o, float* g_rgb_o, hn_stream_t stream) {
+    return composite2_bwd(alpha_h, rgb_h, alpha_o, rgb_o, g_color, g_weight_sum, n_rays, S, g_alpha_h, g_rgb_h, g_alpha_o,
+                          g_rgb_o, (hipStream_t)stream);
 }
 
 size_t hn_render_single_workspace_bytes(const hn_field* f, int n_rays, int n_samples, int n_importance) {

@@ -173,6 +173,119 @@ __global__ __launch_bounds__(256) void k_composite2(const float* __restrict__ ah
     }
 }
 
+// ---- adjoints (pose fitting back-propagates through these stages: fitting_single.py:289-291) ---------
+// d/d(sdf, grad, rays_d) of k_alpha.  One thread per sample; the per-ray direction gradient is accumulated
+// with atomics (S adders per ray; the fitting configs have ~200 rays).  dists carry no gradient: they come
+// from depths the reference samples under no_grad (utils/renderer.py:215, 461).
+__global__ void k_alpha_bwd(const float* __restrict__ sdf, const float* __restrict__ grad, const float* __restrict__ rays_d,
+                            const float* __restrict__ dists, const float* __restrict__ g_alpha,
+                            const float* __restrict__ g_c, int n, int spr, float inv_s, float* __restrict__ g_sdf,
+                            float* __restrict__ g_grad, float* __restrict__ g_rays_d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ray = i / spr;
+    const float d0 = rays_d[3 * ray], d1 = rays_d[3 * ray + 1], d2 = rays_d[3 * ray + 2];
+    const float q0 = grad[3 * (size_t)i], q1 = grad[3 * (size_t)i + 1], q2 = grad[3 * (size_t)i + 2];
+    const float tc = d0 * q0 + d1 * q1 + d2 * q2;
+    const float ic = -fmaxf(-tc, 0.f);
+    const float s = sdf[i], dist = dists[i];
+    const float half = ic * dist * 0.5f;
+    const float c = sigmoid_e((s - half) * inv_s);
+    const float nx = sigmoid_e((s + half) * inv_s);
+    const float A = (c - nx) + 1e-5f, B = c + 1e-5f;
+    const float a_raw = A / B;
+    const float ga = (a_raw > 0.f && a_raw < 1.f) ? g_alpha[i] : 0.f;   // clip(0, 1)
+    // a = A / B: da/dc = (B - A) / B^2, da/dnx = -1 / B
+    float gc = ga * (B - A) / (B * B) + (g_c != nullptr ? g_c[i] : 0.f);
+    float gnx = -ga / B;
+    const float gx1 = gc * inv_s * c * (1.f - c);      // x1 = s - half
+    const float gx2 = gnx * inv_s * nx * (1.f - nx);   // x2 = s + half
+    g_sdf[i] = gx1 + gx2;
+    const float ghalf = gx2 - gx1;
+    const float gtc = (tc < 0.f) ? ghalf * dist * 0.5f : 0.f;   // ic = min(tc, 0)
+    g_grad[3 * (size_t)i] = gtc * d0;
+    g_grad[3 * (size_t)i + 1] = gtc * d1;
+    g_grad[3 * (size_t)i + 2] = gtc * d2;
+    if (g_rays_d != nullptr) {
+        atomicAdd(g_rays_d + 3 * ray, gtc * q0);
+        atomicAdd(g_rays_d + 3 * ray + 1, gtc * q1);
+        atomicAdd(g_rays_d + 3 * ray + 2, gtc * q2);
+    }
+}
+
+// Adjoint of the transmittance products without dividing by a factor that may be ~1e-7: with
+// L = sum_k T_k s_k (s_k = what multiplies T_k) and T_k = seed * prod_{j<k} f_j,
+//   dL/df_k = T_k P_k,   P_k = s_{k+1} + f_{k+1} P_{k+1}  (P_{S-1} = 0),   dL/dseed = (s_0 + f_0 P_0) = P_{-1}.
+// One thread per ray, sequential over its S samples (latency-bound at the sizes back-propagation runs at).
+__global__ void k_composite1_bwd(const float* __restrict__ alpha, const float* __restrict__ c, const float* __restrict__ rgb,
+                                 const float* __restrict__ g_color, const float* __restrict__ g_wsum, int n_rays, int S,
+                                 float* __restrict__ g_alpha, float* __restrict__ g_c, float* __restrict__ g_rgb) {
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= n_rays) return;
+    const size_t base = (size_t)ray * S;
+    const float gC0 = g_color[3 * ray], gC1 = g_color[3 * ray + 1], gC2 = g_color[3 * ray + 2];
+    const float gW = g_wsum != nullptr ? g_wsum[ray] : 0.f;
+    // forward transmittances into g_alpha (scratch), seeded with c_0 (SURVEY B-3)
+    float T = c[base];
+    for (int k = 0; k < S; ++k) {
+        const float a = alpha[base + k];
+        g_alpha[base + k] = T;
+        const float w = a * T;
+        g_rgb[3 * (base + k)] = w * gC0;
+        g_rgb[3 * (base + k) + 1] = w * gC1;
+        g_rgb[3 * (base + k) + 2] = w * gC2;
+        T *= (1.f - a + 1e-7f);
+    }
+    float P = 0.f;
+    for (int k = S - 1; k >= 0; --k) {
+        const float a = alpha[base + k];
+        const float* r = rgb + 3 * (base + k);
+        const float u = gC0 * r[0] + gC1 * r[1] + gC2 * r[2] + gW;   // dL/dw_k
+        const float Tk = g_alpha[base + k];
+        g_alpha[base + k] = Tk * u - Tk * P;        // w = a T ; f = 1 - a + 1e-7
+        g_c[base + k] = 0.f;
+        P = a * u + (1.f - a + 1e-7f) * P;
+    }
+    g_c[base] = P;   // dL/dseed: T_k is linear in the seed c_0
+}
+
+__global__ void k_composite2_bwd(const float* __restrict__ ah, const float* __restrict__ rgbh, const float* __restrict__ ao,
+                                 const float* __restrict__ rgbo, const float* __restrict__ g_color,
+                                 const float* __restrict__ g_wsum, int n_rays, int S, float* __restrict__ g_ah,
+                                 float* __restrict__ g_rgbh, float* __restrict__ g_ao, float* __restrict__ g_rgbo) {
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= n_rays) return;
+    const size_t base = (size_t)ray * S;
+    const float gC0 = g_color[3 * ray], gC1 = g_color[3 * ray + 1], gC2 = g_color[3 * ray + 2];
+    const float gW = g_wsum != nullptr ? g_wsum[ray] : 0.f;
+    float T = 1.f;
+    for (int k = 0; k < S; ++k) {
+        const float a1 = ah[base + k], a2 = ao[base + k];
+        g_ah[base + k] = T;
+        const float w1 = a1 * T, w2 = a2 * T;
+        g_rgbh[3 * (base + k)] = w1 * gC0;
+        g_rgbh[3 * (base + k) + 1] = w1 * gC1;
+        g_rgbh[3 * (base + k) + 2] = w1 * gC2;
+        g_rgbo[3 * (base + k)] = w2 * gC0;
+        g_rgbo[3 * (base + k) + 1] = w2 * gC1;
+        g_rgbo[3 * (base + k) + 2] = w2 * gC2;
+        T *= (1.f - a1 + 1e-7f) * (1.f - a2 + 1e-7f);
+    }
+    float P = 0.f;
+    for (int k = S - 1; k >= 0; --k) {
+        const float a1 = ah[base + k], a2 = ao[base + k];
+        const float* r1 = rgbh + 3 * (base + k);
+        const float* r2 = rgbo + 3 * (base + k);
+        const float u1 = gC0 * r1[0] + gC1 * r1[1] + gC2 * r1[2] + gW;
+        const float u2 = gC0 * r2[0] + gC1 * r2[1] + gC2 * r2[2] + gW;
+        const float Tk = g_ah[base + k];
+        const float f1 = 1.f - a1 + 1e-7f, f2 = 1.f - a2 + 1e-7f;
+        g_ah[base + k] = Tk * u1 - Tk * P * f2;     // df/da1 = -f2
+        g_ao[base + k] = Tk * u2 - Tk * P * f1;     // df/da2 = -f1
+        P = (a1 * u1 + a2 * u2) + f1 * f2 * P;
+    }
+}
+
 // 4 rays per block; at most 8 blocks per CU, grid-stride beyond that
 static int composite_grid(int n_rays) {
     const int blocks = (n_rays + 3) / 4;
@@ -206,6 +319,38 @@ int composite2(const float* ah, const float* rgbh, const float* gh, const float*
     if (n_rays == 0) return HN_OK;
     hipLaunchKernelGGL(k_composite2, dim3(composite_grid(n_rays)), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, S,
                        color, weight_sum, w_hand, w_obj, eik_sum);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int alpha_bwd(const float* sdf, const float* grad, const float* rays_d, const float* dists, const float* g_alpha,
+              const float* g_c, int n, int spr, float inv_s, float* g_sdf, float* g_grad, float* g_rays_d, hipStream_t s) {
+    HN_REQUIRE(spr > 0, "samples_per_ray must be positive");
+    if (n == 0) return HN_OK;
+    if (g_rays_d != nullptr) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n / spr) * 3 * sizeof(float), s));
+    hipLaunchKernelGGL(k_alpha_bwd, dim3((n + 255) / 256), dim3(256), 0, s, sdf, grad, rays_d, dists, g_alpha, g_c, n, spr,
+                       inv_s, g_sdf, g_grad, g_rays_d);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int composite1_bwd(const float* alpha_in, const float* c, const float* rgb, const float* g_color, const float* g_wsum,
+                   int n_rays, int S, float* g_alpha, float* g_c, float* g_rgb, hipStream_t s) {
+    HN_REQUIRE(S >= 1, "S must be positive");
+    if (n_rays == 0) return HN_OK;
+    hipLaunchKernelGGL(k_composite1_bwd, dim3((n_rays + 63) / 64), dim3(64), 0, s, alpha_in, c, rgb, g_color, g_wsum, n_rays,
+                       S, g_alpha, g_c, g_rgb);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int composite2_bwd(const float* ah, const float* rgbh, const float* ao, const float* rgbo, const float* g_color,
+                   const float* g_wsum, int n_rays, int S, float* g_ah, float* g_rgbh, float* g_ao, float* g_rgbo,
+                   hipStream_t s) {
+    HN_REQUIRE(S >= 1, "S must be positive");
+    if (n_rays == 0) return HN_OK;
+    hipLaunchKernelGGL(k_composite2_bwd, dim3((n_rays + 63) / 64), dim3(64), 0, s, ah, rgbh, ao, rgbo, g_color, g_wsum,
+                       n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

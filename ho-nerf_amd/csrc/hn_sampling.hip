@@ -146,6 +146,38 @@ __global__ void k_sample_points(const float* __restrict__ o, const float* __rest
     for (int c = 0; c < 3; ++c) pts[3 * (size_t)i + c] = o[3 * b + c] + d[3 * b + c] * t;
 }
 
+// adjoint of k_sample_points w.r.t. the rays (the depths are sampled under no_grad): one wave per ray
+//   g_o = sum_k g_pts[k],  g_d = sum_k t_k g_pts[k]   (t_k = z_k, or the section mid-point)
+__global__ __launch_bounds__(256) void k_sample_points_bwd(const float* __restrict__ z, const float* __restrict__ g_pts,
+                                                           int n_rays, int n, int mid, float sample_dist,
+                                                           float* __restrict__ g_o, float* __restrict__ g_d) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < n; k += 64) {
+        const size_t i = (size_t)ray * n + k;
+        float t = z[i];
+        if (mid) t = t + ((k + 1 < n) ? z[i + 1] - t : sample_dist) * 0.5f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = g_pts[3 * i + c];
+            acc[c] += g;
+            acc[3 + c] += t * g;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+        for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g_o[3 * ray + c] = acc[c];
+            g_d[3 * ray + c] = acc[3 + c];
+        }
+    }
+}
+
 // ---- up_sample + sample_pdf(det=True) (utils/renderer.py:60-86, 10-37) -------------------------
 constexpr int UPS_MAX_K = 256;
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
@@ -306,6 +338,16 @@ int sample_points(const float* o, const float* d, const float* z, int n_rays, in
     if (n_rays == 0 || n == 0) return HN_OK;
     hipLaunchKernelGGL(k_sample_points, grid1d((size_t)n_rays * n, 256), dim3(256), 0, s, o, d, z, n_rays, n, mid,
                        sample_dist, pts, dists);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int sample_points_bwd(const float* z, const float* g_pts, int n_rays, int n, int mid, float sample_dist, float* g_o,
+                      float* g_d, hipStream_t s) {
+    if (n_rays == 0) return HN_OK;
+    HN_REQUIRE(n >= 1, "n must be positive");
+    hipLaunchKernelGGL(k_sample_points_bwd, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, g_pts, n_rays, n, mid, sample_dist,
+                       g_o, g_d);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

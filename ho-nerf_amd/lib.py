@@ -56,6 +56,7 @@ SIGNATURES = {
     'hn_obj_local_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_vp]),
     'hn_coarse_z': (c_i, [c_f, c_i, c_i, c_db, c_db, c_f, c_vp]),
     'hn_sample_points': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_f, c_f, c_vp]),
+    'hn_sample_points_bwd': (c_i, [c_f, c_f, c_i, c_i, c_i, c_fl, c_f, c_f, c_vp]),
     'hn_upsample': (c_i, [c_f, c_f, c_i, c_i, c_i, c_fl, c_f, c_vp, c_vp]),
     'hn_merge': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f, c_f, c_vp, c_vp]),
     'hn_sort_rows': (c_i, [c_f, c_i, c_i, c_f, c_vp]),
@@ -65,6 +66,9 @@ SIGNATURES = {
     'hn_alpha': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_vp]),
     'hn_composite1': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp]),
     'hn_composite2': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp]),
+    'hn_alpha_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_f, c_vp]),
+    'hn_composite1_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_vp]),
+    'hn_composite2_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_vp]),
     'hn_render_single_workspace_bytes': (c_sz, [c_vp, c_i, c_i, c_i]),
     'hn_render_single': (c_i, [c_vp, c_f, c_f, c_f, c_i, c_db, c_db, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f,
                                c_f, c_f, c_vp, c_sz, c_vp]),

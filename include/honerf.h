@@ -108,6 +108,11 @@ int hn_coarse_z(const float* t_rand, int n_rays, int n_samples, double near, dou
 int hn_sample_points(const float* rays_o, const float* rays_d, const float* z, int n_rays, int n, int mid,
                      float sample_dist, float* pts, float* dists, hn_stream_t stream);
 
+/* Adjoint of hn_sample_points w.r.t. the rays (depths are sampled under no_grad): g_pts [n_rays*n,3] ->
+ * g_rays_o, g_rays_d [n_rays,3] (overwritten). */
+int hn_sample_points_bwd(const float* z, const float* g_pts, int n_rays, int n, int mid, float sample_dist,
+                         float* g_rays_o, float* g_rays_d, hn_stream_t stream);
+
 /* ---- hierarchical sampling ------------------------------------------------------------
  * NeuSRenderer.up_sample + sample_pdf(det=True) (utils/renderer.py:60-86, 10-37).
  * z, sdf [n_rays,k] -> z_new [n_rays,n_new]; inds (int64 [n_rays,n_new], may be
@@ -171,6 +176,23 @@ int hn_composite1(const float* alpha, const float* c, const float* rgb, const fl
 int hn_composite2(const float* alpha_h, const float* rgb_h, const float* grad_h, const float* alpha_o,
                   const float* rgb_o, const float* grad_o, int n_rays, int S, float* color, float* weight_sum,
                   float* w_hand, float* w_obj, float* eik_sum, hn_stream_t stream);
+
+/* ---- adjoints of the two stages above (pose fitting back-propagates through them:
+ * fitting_single.py:289-291, fitting_video.py:340-342).  Depths / dists carry no gradient (sampled under
+ * no_grad, utils/renderer.py:215, 461).
+ * hn_alpha_bwd: g_alpha, g_c [n] (g_c may be NULL) -> g_sdf [n], g_grad [n,3], g_rays_d [n/spr,3]
+ * (zeroed here, then accumulated; may be NULL). */
+int hn_alpha_bwd(const float* sdf, const float* grad, const float* rays_d, const float* dists, const float* g_alpha,
+                 const float* g_c, int n_pts, int samples_per_ray, float inv_s, float* g_sdf, float* g_grad,
+                 float* g_rays_d, hn_stream_t stream);
+/* g_color [B,3], g_weight_sum [B] (may be NULL) -> g_alpha [B,S], g_c [B,S] (only column 0 is non-zero: the
+ * seed), g_rgb [B,S,3]. */
+int hn_composite1_bwd(const float* alpha, const float* c, const float* rgb, const float* g_color,
+                      const float* g_weight_sum, int n_rays, int S, float* g_alpha, float* g_c, float* g_rgb,
+                      hn_stream_t stream);
+int hn_composite2_bwd(const float* alpha_h, const float* rgb_h, const float* alpha_o, const float* rgb_o,
+                      const float* g_color, const float* g_weight_sum, int n_rays, int S, float* g_alpha_h,
+                      float* g_rgb_h, float* g_alpha_o, float* g_rgb_o, hn_stream_t stream);
 
 /* ---- whole renders ----------------------------------------------------------------------
  * NeuSRenderer.render (utils/renderer.py:190-258).  rays already in the field's frame

@@ -483,3 +483,74 @@ def test_dual_depths_match_oracle(golden, prec):
     frac_close = float(((z - ref['z_vals']).abs() < 1e-4).float().mean())
     print('dual depths within 1e-4:', frac_close)
     assert frac_close > 0.98
+
+
+def test_alpha_and_composite_adjoints(L):
+    """hn_alpha_bwd / hn_composite1_bwd / hn_composite2_bwd against autograd of the oracle
+    (utils/renderer.py:147-169, 512-524 differentiated by torch)."""
+    from oracle import render as orr
+    lib = L.load()
+    gen = torch.Generator().manual_seed(7)
+    B, S = 29, 192
+    inv_s = 14.9
+    sdf = (torch.randn(B * S, 1, generator=gen) * 0.05).requires_grad_(True)
+    grad = torch.randn(B * S, 3, generator=gen).requires_grad_(True)
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=gen), dim=-1).requires_grad_(True)
+    dists = torch.rand(B * S, 1, generator=gen) * 0.02
+    dirs = d[:, None, :].expand(B, S, 3).reshape(-1, 3)
+    a_ref, c_ref = orr.sdf_to_alpha(sdf, grad, dirs, dists, torch.tensor(inv_s))
+    ga, gc = torch.randn(B * S, 1, generator=gen), torch.randn(B * S, 1, generator=gen)
+    ref = torch.autograd.grad((a_ref * ga).sum() + (c_ref * gc).sum(), [sdf, grad, d])
+    g_sdf, g_grad, g_d = torch.empty(B * S, device='cuda'), torch.empty(B * S, 3, device='cuda'), torch.empty(B, 3, device='cuda')
+    L.check(lib.hn_alpha_bwd(L.ptr(cu(sdf)), L.ptr(cu(grad)), L.ptr(cu(d)), L.ptr(cu(dists)), L.ptr(cu(ga)), L.ptr(cu(gc)),
+                             B * S, S, inv_s, L.ptr(g_sdf), L.ptr(g_grad), L.ptr(g_d), st()), 'alpha_bwd')
+    assert_close(g_sdf.reshape(-1, 1), ref[0], 2e-5, 'g_sdf')
+    assert_close(g_grad, ref[1], 2e-5, 'g_grad')
+    assert_close(g_d, ref[2], 2e-5, 'g_rays_d')
+    # single field
+    al = (torch.rand(B, S, generator=gen) * 0.3).requires_grad_(True)
+    al.data[:, 5] = 1.0                      # a saturated sample: the transmittance factor is 1e-7
+    cc = torch.rand(B, S, generator=gen).requires_grad_(True)
+    rgb = torch.rand(B, S, 3, generator=gen).requires_grad_(True)
+    w, col = orr.composite_single(al, cc, rgb)
+    gC, gW = torch.randn(B, 3, generator=gen), torch.randn(B, generator=gen)
+    ref = torch.autograd.grad((col * gC).sum() + (w.sum(-1) * gW).sum(), [al, cc, rgb])
+    g_al, g_cc, g_rgb = torch.empty(B, S, device='cuda'), torch.empty(B, S, device='cuda'), torch.empty(B, S, 3, device='cuda')
+    L.check(lib.hn_composite1_bwd(L.ptr(cu(al)), L.ptr(cu(cc)), L.ptr(cu(rgb)), L.ptr(cu(gC)), L.ptr(cu(gW)), B, S,
+                                  L.ptr(g_al), L.ptr(g_cc), L.ptr(g_rgb), st()), 'composite1_bwd')
+    assert_close(g_al, ref[0], 2e-5, 'g_alpha')
+    assert_close(g_cc, ref[1], 2e-5, 'g_c')
+    assert_close(g_rgb, ref[2], 2e-5, 'g_rgb')
+    # two fields
+    ah = (torch.rand(B, S, generator=gen) * 0.3).requires_grad_(True)
+    ao = (torch.rand(B, S, generator=gen) * 0.3).requires_grad_(True)
+    ah.data[:, 9] = 1.0
+    rh = torch.rand(B, S, 3, generator=gen).requires_grad_(True)
+    ro = torch.rand(B, S, 3, generator=gen).requires_grad_(True)
+    col, ws, _, _ = orr.composite_dual(ah, rh, ao, ro)
+    ref = torch.autograd.grad((col * gC).sum() + (ws[:, 0] * gW).sum(), [ah, rh, ao, ro])
+    outs = [torch.empty(B, S, device='cuda'), torch.empty(B, S, 3, device='cuda'), torch.empty(B, S, device='cuda'),
+            torch.empty(B, S, 3, device='cuda')]
+    L.check(lib.hn_composite2_bwd(L.ptr(cu(ah)), L.ptr(cu(rh)), L.ptr(cu(ao)), L.ptr(cu(ro)), L.ptr(cu(gC)), L.ptr(cu(gW)),
+                                  B, S, L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]), L.ptr(outs[3]), st()), 'composite2_bwd')
+    for nm, x, y in zip(('g_alpha_h', 'g_rgb_h', 'g_alpha_o', 'g_rgb_o'), outs, ref):
+        assert_close(x, y, 2e-5, nm)
+
+
+def test_sample_points_adjoint(L):
+    from oracle import render as orr
+    lib = L.load()
+    gen = torch.Generator().manual_seed(8)
+    B, n, sd = 23, 192, (1.5 - 0.4) / 64
+    z = torch.sort(0.4 + 1.1 * torch.rand(B, n, generator=gen), -1)[0]
+    o = torch.randn(B, 3, generator=gen).requires_grad_(True)
+    d = torch.randn(B, 3, generator=gen).requires_grad_(True)
+    gp = torch.randn(B * n, 3, generator=gen)
+    for mid in (1, 0):
+        t_ = orr.mid_points(z, sd)[0] if mid else z
+        pts = orr._pts(o, d, t_).reshape(-1, 3)
+        ref = torch.autograd.grad((pts * gp).sum(), [o, d])
+        g_o, g_d = torch.empty(B, 3, device='cuda'), torch.empty(B, 3, device='cuda')
+        L.check(lib.hn_sample_points_bwd(L.ptr(cu(z)), L.ptr(cu(gp)), B, n, mid, sd, L.ptr(g_o), L.ptr(g_d), st()), 'pts_bwd')
+        assert_close(g_o, ref[0], 1e-5, 'g_rays_o')
+        assert_close(g_d, ref[1], 1e-5, 'g_rays_d')
