@@ -51,6 +51,7 @@ enum {
     HAND2_SLOTS_SDF = 18,
 };
 constexpr int FEAT_BLOCKS = 4 * N_BONES;     // first leftover block index
+constexpr int STAGE_BYTES = 8 * 1024;        // LDS staging of one bone's 4 fragment pairs (Jacobian pass)
 
 constexpr int HB_HID = chunk_bytes(1, 16, true);
 constexpr int HB_BWD = chunk_bytes(1, 16, false);
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 
     WStream ws;
     ws.init(a.blob, a.blob_bytes, lds, wave, lane);
+    char* const stage = lds + 2 * CHUNK_MAX + wave * STAGE_BYTES;   // per-wave staging of one bone's fragments
     ws.dbg_nofetch = (a.dbg & 4) ? 1 : 0;
     if ((int)blockIdx.x < n_tiles) ws.fetch_all(HB_BONE);
 
@@ -485,16 +487,20 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 #pragma unroll 1
             for (int b = 0; b < N_BONES; ++b) {
                 f32x16 G1[2], G2[2];
-                h8 fh[4], fl[4];
                 const bool live = (nz >> b) & 1u;
-                if (live) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) sh.frag_load(FEAT, 4 * b + s, fh[s], fl[s]);
-                }
                 static_for<2>([&](auto U) {
                     constexpr int u = decltype(U)::value;
                     const char* buf0 = ws.template acquire<0>();
                     ws.begin(HB_BWD);
+                    // the bone's own features go stash -> LDS by DMA (no registers: loaded into VGPRs here they
+                    // are spilled one load at a time, 8 serialised round trips per bone); they land under the
+                    // bone's MFMAs, the next acquire's vmcnt(0) covers them
+                    if (u == 0 && live) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(sh.rsrc, (lds_void_t*)(stage + i * 1024), 16, sh.voff,
+                                                                     FEAT + (4 * b + (i >> 1)) * KS_BYTES + (i & 1) * 1024, 0, STASH_AUX);
+                    }
                     G1[u] = zero16();
                     G2[u] = zero16();
                     mma_tile<16, 0, true>(ws, buf0, bh, bl, G1[u], G2[u], lane);
@@ -507,9 +513,12 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     const float kk = -TAU2 * (1.f - bn.hh);
                     float own[4][8];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                    for (int s = 0; s < 4; ++s) {
+                        const h8 fh = *reinterpret_cast<const h8*>(stage + (2 * s) * 1024 + lane * 16);
+                        const h8 fl = *reinterpret_cast<const h8*>(stage + (2 * s + 1) * 1024 + lane * 16);
 #pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) own[s][jj] = unsplit(fh[s][jj], fl[s][jj]);
+                        for (int jj = 0; jj < 8; ++jj) own[s][jj] = unsplit(fh[jj], fl[jj]);
+                    }
                     float Sv = 0.f, Sr[3] = {0.f, 0.f, 0.f};
                     bone_jacobian(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn, kk, h, Sv, Sr);
                     bone_to_p(Sv, Sr, bn, M + 16 * b, g);
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     }
 }
 
-constexpr size_t HAND2_LDS = 2 * CHUNK_MAX;
+constexpr size_t HAND2_LDS = 2 * CHUNK_MAX + WG_WAVES * STAGE_BYTES;
 
 static int hand2_grid(int n_pts, int n_cus) {
     const int n_tiles = (n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
@@ -688,3 +697,9 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
 
 }  // namespace v2
 }  // namespace hn
+
+#ifdef HN_TS
+extern "C" int hn_debug_ts(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hn::v2::g_hn_ts), sizeof(unsigned long long) * n);
+}
+#endif

@@ -37,7 +37,7 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 
 constexpr int KS_BYTES = 2048;            // one k-step block: hi fragment + lo fragment
 constexpr int TAIL_BYTES = 1024;          // 256 floats of side data
-constexpr int CHUNK_MAX = 16 * KS_BYTES + TAIL_BYTES;   // 33 KiB
+constexpr int CHUNK_MAX = 9 * 4096;   // 36 KiB: a chunk is at most 33 KiB; every wave always issues 9 pieces (WStream::piece)
 constexpr float LO_SCALE = 2048.f;
 constexpr float LO_INV = 1.f / 2048.f;
 // The reverse sweep carries d sdf / d z scaled by 2^8 (exact): its entries are small in ABSOLUTE terms
@@ -71,13 +71,30 @@ __device__ __forceinline__ void static_for(F&& f) {
 //                   pieces landed, everybody finished reading chunk i-1
 //   begin(bytes)    chunk i+1 goes to the other buffer ...
 //   piece(k)        ... one 1 KiB piece at a time, spread over the MFMA slots of chunk i by mma_tile
+#ifdef HN_TS
+// timing aid (tools/ts_report.py): workgroup 0 records s_memtime stamps at the chunk barrier and tile ends
+static __device__ unsigned long long g_hn_ts[4 * 8192];
+#endif
 struct WStream {
+#ifdef HN_TS
+    int ts_n, ts_on;
+    __device__ __forceinline__ void stamp(int id) {
+        if (ts_on) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            if (voff == 0 && ts_n < 8192) g_hn_ts[wave * 8192 + ts_n] = (t & 0x0fffffffffffffffull) | ((unsigned long long)id << 60);
+            ts_n++;
+        }
+    }
+#else
+    __device__ __forceinline__ void stamp(int) {}
+#endif
     __amdgpu_buffer_rsrc_t rsrc;
     int total;          // stream bytes
     int goff;           // byte offset of the next chunk to fetch
     char* lds;          // two buffers of CHUNK_MAX bytes
     int phase;          // buffer that receives the next fetch
     int wave, voff;     // wave id (uniform), lane * 16
+    int voff_oob;       // lane * 16 + 0x7f000000: beyond num_records for every stream
     // the fetch in progress
     int f_goff, f_pieces;
     char* f_dst;
@@ -91,10 +108,15 @@ struct WStream {
         phase = 0;
         wave = wave_;
         voff = lane * 16;
+        voff_oob = lane * 16 + 0x7f000000;
         f_pieces = 0;
         f_goff = 0;
         f_dst = lds_base;
         dbg_nofetch = 0;
+#ifdef HN_TS
+        ts_n = 0;
+        ts_on = blockIdx.x == 0;
+#endif
     }
     __device__ __forceinline__ void begin(int bytes) {
         if (goff == total) goff = 0;
@@ -104,10 +126,21 @@ struct WStream {
         goff += bytes;
         phase ^= 1;
     }
-    // k-th piece of this wave (k < 9: a chunk has at most 33 pieces)
+    // k-th piece of this wave (k < 9: a chunk has at most 33 pieces).  Branch-free on purpose: a piece the
+    // chunk does not have is issued with an out-of-range VGPR offset (the buffer range check drops it: no
+    // memory traffic; its LDS destination lies in the unused tail of the 36 KiB buffer).  A uniform branch
+    // here would end the basic block inside the MFMA stream, and the compiler then sinks the epilogue slices
+    // of all earlier slots below the last branch (measured: ~100 VALU instructions in one lump per chunk).
+    // BRANCHY: the plain conditional form.  Kept for the layers where the lump it causes happens to give the
+    // register allocator a shorter live range than the interleaved order (hn_field2_hand.hip, reverse sweep).
+    template <bool BRANCHY = false>
     __device__ __forceinline__ void piece(int k) {
-        if (k < f_pieces)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(f_dst + k * 4096), 16, voff, f_goff + k * 4096, 0, 0);
+        if constexpr (BRANCHY) {
+            if (k < f_pieces) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(f_dst + k * 4096), 16, voff, f_goff + k * 4096, 0, 0);
+            return;
+        }
+        const int vo = (k < f_pieces) ? voff : voff_oob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(f_dst + k * 4096), 16, vo, f_goff + k * 4096, 0, 0);
     }
     __device__ __forceinline__ void pieces_all() {
 #pragma unroll
@@ -119,9 +152,12 @@ struct WStream {
     }
     template <int ALLOW>
     __device__ __forceinline__ const char* acquire() {
+        stamp(1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW) : "memory");
+        stamp(2);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        stamp(3);
         return lds + (phase ^ 1) * CHUNK_MAX;
     }
 };
@@ -169,7 +205,21 @@ __device__ __forceinline__ f32x16 mfma16(const h8& a, const h8& b, const f32x16&
 // latency ~100+ cycles against 96 MFMA cycles per k-step), and after each MFMA one slice of `epi` -- the
 // element-wise epilogue of the PREVIOUS tile -- is issued, so that the VALU work runs in the shadow of the
 // matrix pipe.  sched_barrier(0) pins this order (the compiler's own placement serialises the two).
+// per-translation-unit choice of the DMA piece form by layer kind (see WStream::piece)
+#ifndef HN_BRANCHY_FWD
+#define HN_BRANCHY_FWD false
+#endif
+#ifndef HN_BRANCHY_REV
+#define HN_BRANCHY_REV false
+#endif
+#ifndef HN_BRANCHY_RELU
+#define HN_BRANCHY_RELU false
+#endif
+#ifndef HN_BRANCHY_NOEPI
+#define HN_BRANCHY_NOEPI false
+#endif
 struct NoEpi {
+    static constexpr bool branchy = HN_BRANCHY_NOEPI;
     template <int Q, int NQ>
     __device__ __forceinline__ void run() {}
 };
@@ -190,7 +240,7 @@ __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 
     };
     auto slot = [&](auto Q_) {
         constexpr int Q = decltype(Q_)::value;
-        if constexpr (FETCH && Q % STRIDE == STRIDE - 1 && Q / STRIDE < MAX_PIECES_PER_WAVE) ws.piece(Q / STRIDE);
+        if constexpr (FETCH && Q % STRIDE == STRIDE - 1 && Q / STRIDE < MAX_PIECES_PER_WAVE) ws.template piece<Epi::branchy>(Q / STRIDE);
         epi.template run<Q, NQ>();
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -206,6 +256,7 @@ __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 
         c2 = mfma16(al[s % 3], xh[S0 + s], c2);
         slot(std::integral_constant<int, 3 * s + 2>{});
     });
+    ws.stamp(4);
 }
 template <int KS, int S0, bool FETCH, int NX>
 __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16& c1,
@@ -308,6 +359,7 @@ __device__ __forceinline__ void split_finish(EpiState& st) {
 }
 template <bool FRAGS, typename Ph, typename PD>
 struct Epi {
+    static constexpr bool branchy = Ph::branchy;
     EpiState& st;
     Ph& ph;
     const PD& pd;
@@ -406,6 +458,7 @@ constexpr float K100 = 144.26950408889634f;      // 100 * log2(e)
 constexpr float C100 = 0.0069314718055994531f;   // ln(2) / 100
 // softplus(beta=100): v = max(z,0) + log2(1 + exp2(-|z| K100)) * C100
 struct PhSoftplus {
+    static constexpr bool branchy = HN_BRANCHY_FWD;
     template <typename I_, typename P_, typename PD>
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD&) const {
         constexpr int I = I_::value, P = P_::value;
@@ -419,6 +472,7 @@ struct PhSoftplus {
 };
 // reverse sweep: v = g * sigma'(z) with sigma' = 1 - exp(-100 a) from the stashed activation pd.v
 struct PhDsig {
+    static constexpr bool branchy = HN_BRANCHY_REV;
     template <typename I_, typename P_, typename PD>
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD& pd) const {
         constexpr int I = I_::value, P = P_::value;
@@ -431,6 +485,7 @@ struct PhDsig {
     }
 };
 struct PhRelu {
+    static constexpr bool branchy = HN_BRANCHY_RELU;
     template <typename I_, typename P_, typename PD>
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD&) const {
         constexpr int I = I_::value, P = P_::value;
@@ -438,6 +493,7 @@ struct PhRelu {
     }
 };
 struct PhIdentity {
+    static constexpr bool branchy = HN_BRANCHY_FWD;
     template <typename I_, typename P_, typename PD>
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD&) const {
         constexpr int I = I_::value, P = P_::value;

@@ -1,0 +1,110 @@
+// Microbenchmark of run_layer (hn_mlp2.h): cycles per 16-k-step chunk of one wave, by variant.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DVARIANT=n [-DHN_PIECE_BRANCH] -I ../../ho-nerf_amd/csrc layer_bench.hip -o layer_bench_n
+// VARIANT 0: softplus epilogue in the MFMA slots; 1: relu; 2: no epilogue work (identity, no fragments);
+//         3: softplus + fp32 tile stash store; 4: dsig with stash pre-load (reverse sweep)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "hn_common.h"
+#include "hn_mlp2.h"
+using namespace hn::v2;
+#ifndef VARIANT
+#define VARIANT 0
+#endif
+constexpr int HB = chunk_bytes(1, 16, true);
+struct Act { f32x16 v; };
+__global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, int layers, float4* scratch, long long* cyc, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5;
+    WStream ws;
+    ws.init(blob, bytes, lds, wave, lane);
+    ws.fetch_all(HB);
+    Stash sh;
+    sh.init(scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * 2 * SLOT_F4, 2, lane);
+    h8 ah[16], al[16], bh[16], bl[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ah[s][j] = (_Float16)(0.01f * ((lane + s + j) % 7));
+            al[s][j] = (_Float16)(0.5f * ((lane + 3 * s + j) % 5));
+        }
+    auto no_pre = [](auto, const char*) { return NoData{}; };
+    auto no_store = [](auto, const auto&) {};
+    auto to_regs = [&](h8(&oh)[16], h8(&ol)[16]) {
+        return [&oh, &ol, &sh](auto T, EpiState& st, const auto&) {
+            constexpr int t = decltype(T)::value;
+            asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+            oh[2 * t] = st.hi[0]; ol[2 * t] = st.lo[0]; oh[2 * t + 1] = st.hi[1]; ol[2 * t + 1] = st.lo[1];
+            if (VARIANT == 3) sh.tile_store(0, t, st.vec());
+            return NoData{};
+        };
+    };
+    float acc = 0.f;
+    auto sink_fin = [&](auto T, EpiState& st, const auto&) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += st.v[i];
+        return NoData{};
+    };
+    auto act_of = [&](auto T, const char*) { return Act{sh.tile_load(0, decltype(T)::value)}; };
+    const long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+    for (int l = 0; l < layers; l += 2) {
+        if (VARIANT == 0 || VARIANT == 3) {
+            run_layer<8, 16, 1, true, true>(ws, HB, HB, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs(bh, bl), no_store);
+            run_layer<8, 16, 1, true, true>(ws, HB, HB, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs(ah, al), no_store);
+        } else if (VARIANT == 1) {
+            run_layer<8, 16, 1, true, true>(ws, HB, HB, ah, al, lane, h, no_pre, PhRelu{}, to_regs(bh, bl), no_store);
+            run_layer<8, 16, 1, true, true>(ws, HB, HB, bh, bl, lane, h, no_pre, PhRelu{}, to_regs(ah, al), no_store);
+        } else if (VARIANT == 2) {
+            run_layer<8, 16, 1, true, false>(ws, HB, HB, ah, al, lane, h, no_pre, PhIdentity{}, sink_fin, no_store);
+            run_layer<8, 16, 1, true, false>(ws, HB, HB, ah, al, lane, h, no_pre, PhIdentity{}, sink_fin, no_store);
+        } else {
+            run_layer<8, 16, 1, true, true>(ws, HB, HB, ah, al, lane, h, act_of, PhDsig{}, to_regs(bh, bl), no_store);
+            run_layer<8, 16, 1, true, true>(ws, HB, HB, bh, bl, lane, h, act_of, PhDsig{}, to_regs(ah, al), no_store);
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the last prefetch before the LDS goes away
+    __syncthreads();
+    float s = acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)ah[k][j] + (float)al[k][j];
+    sink[blockIdx.x * 256 + threadIdx.x] = s;
+    if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+}
+int main(int argc, char** argv) {
+    const int layers = argc > 1 ? atoi(argv[1]) : 32;
+    const int wgs = argc > 2 ? atoi(argv[2]) : 256;
+    const size_t bytes = (size_t)HB * 8 * 8;   // 8 layers of 8 chunks, cycled
+    std::vector<_Float16> hostw(bytes / 2);
+    for (size_t i = 0; i < hostw.size(); ++i) hostw[i] = (_Float16)(0.02f * (float)((int)(i * 2654435761u >> 24) % 13 - 6));
+    char* blob; float4* scratch; long long* cyc; float* sink;
+    hipMalloc(&blob, bytes); hipMemcpy(blob, hostw.data(), bytes, hipMemcpyHostToDevice);
+    hipMalloc(&scratch, (size_t)wgs * 4 * 2 * SLOT_BYTES); hipMemset(scratch, 0, (size_t)wgs * 4 * 2 * SLOT_BYTES);
+    hipMalloc(&cyc, wgs * 4 * 8); hipMalloc(&sink, wgs * 256 * 4);
+    hipFuncSetAttribute((const void*)k_bench, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CHUNK_MAX);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_bench, dim3(wgs), dim3(256), 2 * CHUNK_MAX, 0, blob, bytes, layers, scratch, cyc, sink);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    }
+    std::vector<long long> c(wgs * 4);
+    hipMemcpy(c.data(), cyc, wgs * 4 * 8, hipMemcpyDeviceToHost);
+    double mean = 0; for (auto v : c) mean += v; mean /= c.size();
+    const int chunks = layers * 8;
+    printf("variant %d%s: %d wgs, %d chunks: %.3f ms -> %.3f us/chunk, %.0f ticks/chunk (%.0f ticks/us); MFMA floor 1536 cycles\n", VARIANT,
+#ifdef HN_PIECE_BRANCH
+           " [branchy pieces]",
+#else
+           "",
+#endif
+           wgs, chunks, ms, ms * 1e3 / chunks, mean / chunks, mean / (ms * 1e3));
+    return hipGetLastError() != hipSuccess;
+}
