@@ -171,6 +171,7 @@ __device__ __forceinline__ void bone_to_p(float Sv, const float (&Sr)[3], const 
 template <bool FULL>
 __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    f16_flush_mode();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 #pragma unroll 1
         for (int b = 0; b < N_BONES; ++b) {
             const Bone2 bn = bone_coords2(p, M, Tp, b);
-            const bool any = (a.dbg & 16) ? true : (__ballot(bn.hh != 0.f) != 0ull);
+            const bool any = __ballot(bn.hh != 0.f) != 0ull;
             if (any) {
                 nz |= 1u << b;
                 float f[4][8];

@@ -77,6 +77,7 @@ __device__ __forceinline__ void encode_v4(const float v[3], int h, float (&f)[2]
 template <bool FULL>
 __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    f16_flush_mode();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar addressing
     const int j = lane & 31;

@@ -170,9 +170,22 @@ constexpr int MAX_PIECES_PER_WAVE = 9;
 // mix forms, the compiler's choice) do not all agree on subnormals -- measured: a hi part read as x by
 // the matrix pipe and as 0 by the residual is an error of up to 6e-5 per element.  (The host-side weight
 // packer converts with IEEE semantics and needs no such rule.)
+#ifndef HN_F16_FLUSH
+#define HN_F16_FLUSH 1
+#endif
 __host__ __device__ __forceinline__ _Float16 hi_part(float x) {
+#if HN_F16_FLUSH && defined(__HIP_DEVICE_COMPILE__)
+    return (_Float16)x;   // the kernel runs with fp16 denormals flushed (f16_flush_mode): the conversion itself gives 0
+#else
     const float xs = (x < 6.103515625e-5f && x > -6.103515625e-5f) ? 0.f : x;   // select in fp32, then convert
     return (_Float16)xs;
+#endif
+}
+// MODE.FP_DENORM[7:6] (fp16/fp64) = 0: flush input and output denormals; [5:4] (fp32) stays 3 (IEEE)
+__device__ __forceinline__ void f16_flush_mode() {
+#if HN_F16_FLUSH
+    __builtin_amdgcn_s_setreg(((4 - 1) << 11) | (4 << 6) | 1, 3);
+#endif
 }
 // fp16 hi / scaled-lo split of 8 fp32 values (one B fragment)
 __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {

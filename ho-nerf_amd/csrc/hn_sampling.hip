@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_sample_points_bwd(const float* __restri
 constexpr int UPS_MAX_K = 256;
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ __launch_bounds__(64) void k_upsample(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays,
+__global__ __launch_bounds__(64) void k_upsample_direct(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays,
                                                  int k, int n_new, float inv_s, float* __restrict__ z_new,
                                                  int64_t* __restrict__ inds_out) {
     extern __shared__ float lds[];   // cdf[k][64]
@@ -238,8 +238,87 @@ __global__ __launch_bounds__(64) void k_upsample(const float* __restrict__ z, co
     }
 }
 
+// The same arithmetic with the 64 rows of a block staged through LDS: rows are read from global memory with
+// consecutive lanes on consecutive addresses and walked from LDS (row pitch k+1 words: conflict-free), instead of
+// every lane striding through its own row in global memory.  The weights / cdf overwrite the staged sdf row.
+__global__ __launch_bounds__(64) void k_upsample(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays,
+                                                 int k, int n_new, float inv_s, float* __restrict__ z_new,
+                                                 int64_t* __restrict__ inds_out) {
+    extern __shared__ float lds[];   // zs[64][k+1], cs[64][k+1]
+    const int lane = threadIdx.x;
+    const int pitch = k + 1;
+    float* zs = lds;
+    float* cs = lds + 64 * pitch;
+    const int ray0 = blockIdx.x * 64;
+    const int nvalid = n_rays - ray0 < 64 ? n_rays - ray0 : 64;
+    {
+        const size_t base = (size_t)ray0 * k;
+        const int total = nvalid * k;
+        int r = 0, c = lane;
+        for (int idx = lane; idx < total; idx += 64) {
+            while (c >= k) {
+                c -= k;
+                ++r;
+            }
+            zs[r * pitch + c] = z[base + idx];
+            cs[r * pitch + c] = sdf[base + idx];
+            c += 64;
+        }
+    }
+    __syncthreads();
+    if (lane >= nvalid) return;
+    const int ray = ray0 + lane;
+    const float* zr = zs + lane * pitch;
+    float* cr = cs + lane * pitch;
+    // pass 1: section weights, sequential transmittance (torch.cumprod order)
+    float prev_cos = 0.f, T = 1.f, sum = 0.f;
+    float z0 = zr[0], s0 = cr[0];
+    for (int i = 0; i + 1 < k; ++i) {
+        const float z1 = zr[i + 1], s1 = cr[i + 1];
+        const float mid_sdf = (s0 + s1) * 0.5f;
+        const float cosv = (s1 - s0) / (z1 - z0 + 1e-5f);
+        float c = fminf(prev_cos, cosv);
+        c = fminf(fmaxf(c, -1e3f), 0.f);
+        prev_cos = cosv;
+        const float dist = z1 - z0;
+        const float prev_cdf = sigmoid_acc((mid_sdf - c * dist * 0.5f) * inv_s);
+        const float next_cdf = sigmoid_acc((mid_sdf + c * dist * 0.5f) * inv_s);
+        const float alpha = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
+        const float w = alpha * T + 1e-5f;           // weights + 1e-5 (sample_pdf)
+        T = T * (1.f - alpha + 1e-7f);
+        cr[i + 1] = w;                               // s1 is in a register: its slot is free
+        sum += w;
+        z0 = z1;
+        s0 = s1;
+    }
+    // pass 2: cdf = [0, cumsum(w / sum)]
+    cr[0] = 0.f;
+    float run = 0.f;
+    for (int i = 1; i < k; ++i) {
+        run += cr[i] / sum;
+        cr[i] = run;
+    }
+    // pass 3: invert at u = linspace(0.5/n, 1-0.5/n, n)
+    const float u_start = 0.f + 0.5f / (float)n_new, u_end = 1.f - 0.5f / (float)n_new;
+    const float u_step = (u_end - u_start) / (float)(n_new - 1);
+    int ptr = 0;   // number of cdf entries <= u (searchsorted right=True); cdf and u are both non-decreasing
+    for (int jj = 0; jj < n_new; ++jj) {
+        const float u = (jj < n_new / 2) ? u_start + (float)jj * u_step : u_end - (float)(n_new - 1 - jj) * u_step;
+        while (ptr < k && cr[ptr] <= u) ++ptr;
+        const int below = ptr - 1 > 0 ? ptr - 1 : 0;
+        const int above = ptr < k - 1 ? ptr : k - 1;
+        const float c_lo = cr[below], c_hi = cr[above];
+        const float b_lo = zr[below], b_hi = zr[above];
+        float denom = c_hi - c_lo;
+        denom = denom < 1e-5f ? 1.f : denom;
+        const float t = (u - c_lo) / denom;
+        z_new[(size_t)ray * n_new + jj] = b_lo + t * (b_hi - b_lo);
+        if (inds_out != nullptr) inds_out[(size_t)ray * n_new + jj] = ptr;
+    }
+}
+
 // ---- cat_z_vals (utils/renderer.py:88-105): stable merge of two sorted rows ----------------------
-__global__ void k_merge(const float* __restrict__ z, const float* __restrict__ z_new, const float* __restrict__ sdf,
+__global__ void k_merge_serial(const float* __restrict__ z, const float* __restrict__ z_new, const float* __restrict__ sdf,
                         const float* __restrict__ sdf_new, int n_rays, int k, int m, int quirk_p,
                         float* __restrict__ z_out, float* __restrict__ sdf_out, int64_t* __restrict__ index) {
     const int ray = blockIdx.x * blockDim.x + threadIdx.x;
@@ -267,6 +346,64 @@ __global__ void k_merge(const float* __restrict__ z, const float* __restrict__ z
             if (sdf_out) sdf_out[(size_t)ray * (k + m) + o] = sb[jj];
             if (index) index[(size_t)ray * (k + m) + o] = k + jj;
             ++jj;
+        }
+    }
+}
+
+// The same merge by ranks, one wave per ray (k <= 256, m <= 64): element a_i lands at i + #{j: b_j < a_i}, element
+// b_j at j + #{i: a_i <= b_j} (ties: the old sample first, as the stable sort of cat([z, z_new]) places them).
+// Rows are read and written with consecutive lanes on consecutive addresses; the serial kernel above walks one
+// row per lane (row stride k floats: every access its own cache line) and runs at 4 % of the HBM rate.
+__global__ __launch_bounds__(256) void k_merge(const float* __restrict__ z, const float* __restrict__ z_new,
+                                               const float* __restrict__ sdf, const float* __restrict__ sdf_new, int n_rays,
+                                               int k, int m, int quirk_p, float* __restrict__ z_out,
+                                               float* __restrict__ sdf_out, int64_t* __restrict__ index) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int ray = blockIdx.x * 4 + wave; ray < n_rays; ray += gridDim.x * 4) {
+        const int srow = quirk_p > 0 ? ray % quirk_p : ray;   // SURVEY B-1
+        const float* a = z + (size_t)ray * k;
+        const float* b = z_new + (size_t)ray * m;
+        const size_t ob = (size_t)ray * (k + m);
+        float av[4], as[4];
+        int cnt[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = r * 64 + lane;
+            const bool ok = e < k;
+            av[r] = ok ? a[e] : 0.f;
+            as[r] = (ok && sdf_out) ? sdf[(size_t)srow * k + e] : 0.f;
+            cnt[r] = 0;
+        }
+        const float bv = lane < m ? b[lane] : 0.f;
+        const float bs = (lane < m && sdf_out) ? sdf_new[(size_t)srow * m + lane] : 0.f;
+        int bcnt = 0;
+        for (int j = 0; j < m; ++j) {
+            const float bj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), j));
+            int le = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = r * 64 + lane < k;
+                cnt[r] += (ok && bj < av[r]) ? 1 : 0;
+                le += __popcll(__ballot(ok && av[r] <= bj));
+            }
+            if (lane == j) bcnt = le;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = r * 64 + lane;
+            if (e < k) {
+                const int o = e + cnt[r];
+                z_out[ob + o] = av[r];
+                if (sdf_out) sdf_out[ob + o] = as[r];
+                if (index) index[ob + o] = e;
+            }
+        }
+        if (lane < m) {
+            const int o = lane + bcnt;
+            z_out[ob + o] = bv;
+            if (sdf_out) sdf_out[ob + o] = bs;
+            if (index) index[ob + o] = k + lane;
         }
     }
 }
@@ -356,8 +493,13 @@ int upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, flo
              hipStream_t s) {
     HN_REQUIRE(k >= 2 && k <= UPS_MAX_K && n_new >= 2 && n_new <= 64, "upsample: k=%d n_new=%d out of range", k, n_new);
     if (n_rays == 0) return HN_OK;
-    hipLaunchKernelGGL(k_upsample, grid1d(n_rays, 64), dim3(64), (size_t)k * 64 * sizeof(float), s, z, sdf, n_rays, k,
-                       n_new, inv_s, z_new, inds);
+    if (k <= 64) {   // staged: 2 x 64 x (k+1) floats of LDS per wave; beyond 64 columns the occupancy loss outweighs it (measured)
+        hipLaunchKernelGGL(k_upsample, grid1d(n_rays, 64), dim3(64), (size_t)2 * 64 * (k + 1) * sizeof(float), s, z, sdf,
+                           n_rays, k, n_new, inv_s, z_new, inds);
+    } else {
+        hipLaunchKernelGGL(k_upsample_direct, grid1d(n_rays, 64), dim3(64), (size_t)k * 64 * sizeof(float), s, z, sdf, n_rays,
+                           k, n_new, inv_s, z_new, inds);
+    }
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -366,8 +508,14 @@ int merge(const float* z, const float* z_new, const float* sdf, const float* sdf
           int quirk_p, float* z_out, float* sdf_out, int64_t* index, hipStream_t s) {
     HN_REQUIRE((sdf_out == nullptr) || (sdf != nullptr && sdf_new != nullptr), "merge: sdf inputs missing");
     if (n_rays == 0) return HN_OK;
-    hipLaunchKernelGGL(k_merge, grid1d(n_rays, 64), dim3(64), 0, s, z, z_new, sdf, sdf_new, n_rays, k, m, quirk_p, z_out,
-                       sdf_out, index);
+    if (k <= 256 && m <= 64) {
+        const int blocks = (n_rays + 3) / 4 < 8192 ? (n_rays + 3) / 4 : 8192;
+        hipLaunchKernelGGL(k_merge, dim3(blocks), dim3(256), 0, s, z, z_new, sdf, sdf_new, n_rays, k, m, quirk_p, z_out,
+                           sdf_out, index);
+    } else {
+        hipLaunchKernelGGL(k_merge_serial, grid1d(n_rays, 64), dim3(64), 0, s, z, z_new, sdf, sdf_new, n_rays, k, m, quirk_p,
+                           z_out, sdf_out, index);
+    }
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

@@ -105,3 +105,12 @@ def test_two_rank_reduction_equals_single_process():
         assert red['frames'] == single['frames'] == n_frames - 1
         for k in fitting.LOSS_KEYS[:-1]:
             assert abs(red[k] - single[k]) < 1e-9, (k, red[k], single[k])
+
+
+def test_to_image_matches_reference_formula():
+    """exp_runner.py:370: (rgb * 255).clip(0, 255) on the [H, W, 3] reshape; uint8 as written by cv2.imwrite."""
+    from honerf_amd.harness import to_image
+    rgb = torch.tensor([[0.0, 0.5, 1.0], [1.2, -0.1, 0.999], [0.25, 0.75, 0.1], [0.0, 0.0, 0.0]])
+    img = to_image(rgb, 2, 2)
+    assert img.shape == (2, 2, 3) and img.dtype == np.uint8
+    assert img[0, 0].tolist() == [0, 127, 255] and img[0, 1].tolist() == [255, 0, 254]

@@ -554,3 +554,30 @@ def test_sample_points_adjoint(L):
         L.check(lib.hn_sample_points_bwd(L.ptr(cu(z)), L.ptr(cu(gp)), B, n, mid, sd, L.ptr(g_o), L.ptr(g_d), st()), 'pts_bwd')
         assert_close(g_o, ref[0], 1e-5, 'g_rays_o')
         assert_close(g_d, ref[1], 1e-5, 'g_rays_d')
+
+
+# ---------------------------------------------------------------------------------------------
+def test_image_harness_obj_16x16(prec):
+    """Runner.test's counterpart (exp_runner.py:338-372): full NDC grid -> rays -> one render call -> uint8 image,
+    against the oracle driven with the same grid; also chunked rendering must give the same image."""
+    from honerf_amd import harness, synth
+    from oracle import render as R
+    H = W = 16
+    cam = synth.front_camera()
+    ren = _single_renderer('obj', 32, 0, prec)
+    Ro, _ = synth.synth_obj_pose(3)
+    To = np.array([0.02, -0.01, 0.05], dtype=np.float32)   # in front of the camera at distance ~1
+    gen = torch.Generator().manual_seed(11)
+    t_rand = torch.rand(H * W, 1, generator=gen)
+    img, out = harness.render_image(ren, cam, H, W, 0.4, 1.5, None, None, Ro=Ro, To=To, t_rand=cu(t_rand))
+    assert img.shape == (H, W, 3) and img.dtype == np.uint8
+    img2, _ = harness.render_image(ren, cam, H, W, 0.4, 1.5, None, None, Ro=Ro, To=To, t_rand=cu(t_rand), batch_size=100)
+    assert np.array_equal(img, img2), 'chunked rendering must not change the image'
+    _, obj_o = oracle_fields()
+    xy = t(synth.ndc_grid(H, W))
+    ro, rd = R.rays_from_xy(xy, t(cam['R'])[0], t(cam['T'])[0], t(cam['focal'])[0], t(cam['principal'])[0])
+    ref = R.render_single(obj_o, ro, rd, 0.4, 1.5, t_rand, 32, 0, Ro=t(Ro).T.contiguous(), To=t(To))
+    assert_close(out['color_fine'], ref['color_fine'], RT, 'image colour')
+    ref_img = (ref['color_fine'].detach().numpy().reshape(H, W, 3) * 255.0).clip(0, 255).astype(np.uint8)
+    assert ref_img.max() > 32, 'the synthetic view must show the object'
+    assert np.abs(img.astype(int) - ref_img.astype(int)).max() <= 1, 'uint8 image may differ by one count at most'

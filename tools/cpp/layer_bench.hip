@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, i
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
+    f16_flush_mode();
     WStream ws;
     ws.init(blob, bytes, lds, wave, lane);
     ws.fetch_all(HB);
@@ -77,7 +78,28 @@ __global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, i
     sink[blockIdx.x * 256 + threadIdx.x] = s;
     if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
 }
+__global__ void k_flush_check(const float* in, float* out, const unsigned short* hbits) {
+    f16_flush_mode();
+    const int i = threadIdx.x;
+    h8 a, b;
+    float x[8];
+    for (int j = 0; j < 8; ++j) x[j] = in[(i + j) % 8];
+    split8(x, a, b);
+    out[i] = (float)a[0];                                  // hi of in[i]
+    out[8 + i] = (float)b[0];                              // scaled lo of in[i]
+    out[16 + i] = (float)__builtin_bit_cast(_Float16, hbits[i]);   // a stored fp16 bit pattern read back
+}
 int main(int argc, char** argv) {
+    {
+        const float hin[8] = {1.0f, 6.2e-5f, 6.0e-5f, 3.0e-6f, -3.0e-6f, 1.0e-7f, 2.9e-8f, 0.3337f};
+        const unsigned short hb[8] = {0x3c00, 0x0400, 0x03ff, 0x0001, 0x8001, 0x0200, 0x7bff, 0x0000};
+        float *din, *dout; unsigned short* dh; float hout[24];
+        (void)hipMalloc(&din, 32); (void)hipMalloc(&dout, 96); (void)hipMalloc(&dh, 16);
+        (void)hipMemcpy(din, hin, 32, hipMemcpyHostToDevice); (void)hipMemcpy(dh, hb, 16, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_flush_check, dim3(1), dim3(8), 0, 0, din, dout, dh);
+        (void)hipMemcpy(hout, dout, 96, hipMemcpyDeviceToHost);
+        for (int i = 0; i < 8; ++i) printf("  x=%.4e hi=%.6e lo/2048=%.6e sum-x=%.2e | half 0x%04x -> %.6e\n", hin[i], hout[i], hout[8 + i] / 2048.f, (hout[i] + hout[8 + i] / 2048.f) - hin[i], hb[i], hout[16 + i]);
+    }
     const int layers = argc > 1 ? atoi(argv[1]) : 32;
     const int wgs = argc > 2 ? atoi(argv[2]) : 256;
     const size_t bytes = (size_t)HB * 8 * 8;   // 8 layers of 8 chunks, cycled
