@@ -88,6 +88,23 @@ def cpu_baseline(sdf, col, scene, crop=96, threads=32):
                       % (crop, crop, n_done * N_SAMPLES, dt)}
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of the dominant kernel, from the committed PMC summary of this same workload
+    (profiles/r*/pmc_bench_*.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot collect counters itself;
+    the newest summary for this kernel is quoted, or None."""
+    import glob
+    best = (None, None)
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'pmc_bench_*.json'))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if kernel in str(d.get('kernel')) and 'derived' in d and 'hbm_bytes_per_launch' in d['derived']:
+            best = (d['derived']['hbm_bytes_per_launch'], os.path.relpath(path, ROOT))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -95,6 +112,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-crop', type=int, default=96)
+    ap.add_argument('--no-culled', action='store_true', help='skip the secondary culled measurement')
     ap.add_argument('--precision', default='f16x3', choices=['f16x3', 'fp32'])
     args = ap.parse_args()
 
@@ -171,6 +189,19 @@ def main():
     torch.cuda.synchronize()
     kernel_ms = e0.elapsed_time(e1) / k_launches
     achieved = n * HAND_FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12
+    # ---- secondary figure: the same step with the exact far-field early-out enabled ("may additionally
+    #      be reported culled"); `value` above stays the dense number
+    culled = None
+    if args.precision == 'f16x3' and not args.no_culled:
+        field.set_culling(True)
+        step()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        culled = samples_per_step * args.steps / (time.perf_counter() - tc)
+        field.set_culling(False)
     if args.precision == 'f16x3':
         # three f16 MFMA products per fp32-equivalent product: the algorithmic rate is priced against a
         # third of the dense f16 MFMA peak (equivalently: issued MFMA FLOP/s against the full peak)
@@ -178,6 +209,7 @@ def main():
     else:
         peak, kname, dtype = PEAK_F32_MFMA_TFLOPS, 'hn::k_field_hand<true>', 'f32'
 
+    traffic, traffic_src = pmc_traffic(kname)
     if rank == 0:
         res = {
             'metric': 'ray-samples/sec/GPU (512x512x64)', 'value': value, 'unit': 'ray-samples/s',
@@ -188,12 +220,14 @@ def main():
                        'rays': B, 'samples_per_ray': N_SAMPLES, 'frames_per_step': world},
             'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': achieved,
                          'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': None, 'kernel_ms': kernel_ms,
+                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': kernel_ms,
                          'flop_per_launch': n * HAND_FLOP_PER_SAMPLE,
                          'mfma_issued_tflops': achieved * (3.0 if args.precision == 'f16x3' else 1.0),
                          'mfma_peak_tflops': PEAK_F16_MFMA_TFLOPS if args.precision == 'f16x3' else PEAK_F32_MFMA_TFLOPS},
             'weight_sum_mean': float(out['weight_sum'].mean()),
         }
+        if culled is not None:
+            res['value_culled'] = culled   # rank 0's frame, far-field early-out on (bit-identical output)
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(sdf, col, sc, args.cpu_crop)
         print(json.dumps(res))

@@ -341,6 +341,14 @@ int hn_field_destroy(hn_field* f) {
     return HN_OK;
 }
 float hn_field_inv_s(const hn_field* f) { return f ? f->inv_s : 0.f; }
+int hn_field_set_culling(hn_field* f, int enabled) {
+    if (f == nullptr) {
+        hn::set_error("hn_field_set_culling: null field");
+        return HN_EINVAL;
+    }
+    f->cull_far_field = enabled ? 1 : 0;
+    return HN_OK;
+}
 
 int hn_ray_gen(const float* xy, const float* R, const float* T, const float* focal, const float* principal, int n_cams,
                int rays_per_cam, float* rays_o, float* rays_d, hn_stream_t stream) {

@@ -98,4 +98,5 @@ struct hn_field {
     size_t v2_full_bytes = 0;
     void* v2_sdf = nullptr;      // sdf forward only (sampling passes)
     size_t v2_sdf_bytes = 0;
+    int cull_far_field = 0;      // hn_field_set_culling: skip the chunks of bones whose mask is 0 for a whole workgroup
 };

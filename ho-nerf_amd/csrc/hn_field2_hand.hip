@@ -36,6 +36,7 @@ struct Hand2Args {
     float* feat;
     float4* scratch;
     int dbg;
+    int cull;   // hn_field_set_culling
 };
 
 // stash slots of one wave (32 KiB each)
@@ -234,6 +235,16 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             }
         }
 
+        // nzw: the bones whose weight chunks this workgroup runs.  Dense: all of them.  Culled: those that are live
+        // in at least one of the 4 waves (the chunks are shared through LDS, so the skip has to be workgroup-wide),
+        // plus bone 0, whose first chunk is always in flight when a pass starts.
+        unsigned nzw = (1u << N_BONES) - 1u;
+        if (a.cull) {
+            unsigned* ex = reinterpret_cast<unsigned*>(lds + 2 * CHUNK_MAX + WG_WAVES * STAGE_BYTES);
+            if (lane == 0) ex[wave] = nz;
+            __syncthreads();
+            nzw = __builtin_amdgcn_readfirstlane(ex[0] | ex[1] | ex[2] | ex[3] | 1u);
+        }
         if ((a.dbg >> 8) == 1) return;   // phase timing aid
         h8 ah[16], al[16], bh[16], bl[16];   // ping-pong activation fragments
         struct Act {
@@ -298,12 +309,20 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             constexpr int NB = decltype(NB_)::value;
             constexpr bool BIAS = decltype(BIAS_)::value;
             h8 fh[2][4], fl[2][4];
-            auto step = [&](int b, const h8(&uh)[4], const h8(&ul)[4], h8(&nh)[4], h8(&nl)[4]) {
+            // bone b's NB chunks (fragments in uh/ul); the last one prefetches the first chunk of bone nb (the next
+            // bone that is run; nb == N_BONES: the leftover chunks, which follow the 21 bones in the stream)
+            const int base = ws.goff - HB_BONE;   // stream offset of bone 0's first chunk (the chunk in flight)
+            auto step = [&](int nb, const h8(&uh)[4], const h8(&ul)[4], h8(&nh)[4], h8(&nl)[4]) {
                 static_for<NB>([&](auto BLK) {
                     constexpr int blk = decltype(BLK)::value;
                     const char* buf = ws.template acquire<0>();
-                    ws.begin((blk + 1 < NB || b + 1 < N_BONES) ? HB_BONE : left_bytes);
-                    if constexpr (blk == 0) load_bone(b + 1, nh, nl);   // b + 1 == 21: the leftover blocks 84..86
+                    if constexpr (blk + 1 < NB) {
+                        ws.begin(HB_BONE);
+                    } else {
+                        ws.goff = base + nb * (NB * HB_BONE);
+                        ws.begin(nb < N_BONES ? HB_BONE : left_bytes);
+                    }
+                    if constexpr (blk == 0) load_bone(nb, nh, nl);   // nb == 21: the leftover blocks 84..86
                     static_for<4>([&](auto TI) {
                         constexpr int ti = decltype(TI)::value;
                         if constexpr (ti == 0)
@@ -314,12 +333,19 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 });
             };
             load_bone(0, fh[0], fl[0]);
+            unsigned rem = nzw & ~1u;
 #pragma unroll 1
-            for (int b2 = 0; b2 < N_BONES / 2; ++b2) {
-                step(2 * b2, fh[0], fl[0], fh[1], fl[1]);
-                step(2 * b2 + 1, fh[1], fl[1], fh[0], fl[0]);
+            while (true) {
+                const int nb = rem ? __builtin_ctz(rem) : N_BONES;
+                rem &= rem - 1u;
+                step(nb, fh[0], fl[0], fh[1], fl[1]);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    fh[0][s4] = fh[1][s4];
+                    fl[0][s4] = fl[1][s4];
+                }
+                if (nb == N_BONES) break;
             }
-            step(N_BONES - 1, fh[0], fl[0], fh[1], fl[1]);
             static_for<NB>([&](auto BLK) {
                 constexpr int blk = decltype(BLK)::value;
                 const char* buf = ws.template acquire<0>();
@@ -327,9 +353,9 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 static_for<4>([&](auto TI) {
                     constexpr int ti = decltype(TI)::value;
                     if constexpr (ti == 0)
-                        mma_tile<3, 0, true>(ws, buf + ti * 3 * KS_BYTES, fh[1], fl[1], c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                        mma_tile<3, 0, true>(ws, buf + ti * 3 * KS_BYTES, fh[0], fl[0], c1[4 * blk + ti], c2[4 * blk + ti], lane);
                     else
-                        mma_tile<3, 0, false>(ws, buf + ti * 3 * KS_BYTES, fh[1], fl[1], c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                        mma_tile<3, 0, false>(ws, buf + ti * 3 * KS_BYTES, fh[0], fl[0], c1[4 * blk + ti], c2[4 * blk + ti], lane);
                     if constexpr (BIAS) {
                         const f32x16 bias = tail_tile(buf + 4 * 3 * KS_BYTES, ti, h);
 #pragma unroll
@@ -485,8 +511,13 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) sh.frag_load(HS_DZ4 * SLOT_BYTES, s, ah[s], al[s]);
         {
+            const int jbase = ws.goff - HB_BWD;   // stream offset of bone 0's first chunk (in flight)
+            unsigned rem = nzw & ~1u;
+            int b = 0;
 #pragma unroll 1
-            for (int b = 0; b < N_BONES; ++b) {
+            while (b < N_BONES) {
+                const int nb = rem ? __builtin_ctz(rem) : N_BONES;   // the next bone that is run (21: leftover chunks)
+                rem &= rem - 1u;
                 f32x16 G1[2], G2[2];
                 const bool live = (nz >> b) & 1u;
                 static_for<2>([&](auto U) {
@@ -506,6 +537,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     G2[u] = zero16();
                     mma_tile<16, 0, true>(ws, buf0, bh, bl, G1[u], G2[u], lane);
                     const char* buf4 = ws.template acquire<0>();
+                    if constexpr (u == 1) ws.goff = jbase + nb * (4 * HB_BWD);
                     ws.begin(HB_BWD);
                     mma_tile<16, 0, true>(ws, buf4, ah, al, G1[u], G2[u], lane);
                 });
@@ -524,6 +556,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     bone_jacobian(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn, kk, h, Sv, Sr);
                     bone_to_p(Sv, Sr, bn, M + 16 * b, g);
                 }
+                b = nb;
             }
             // leftover block: 2 tiles; register 8 (u & 1) + j of tile u >> 1 <-> bone 8 u + j : (r_1 | r_2) h
             f32x16 L1[2], L2[2];
@@ -631,7 +664,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     }
 }
 
-constexpr size_t HAND2_LDS = 2 * CHUNK_MAX + WG_WAVES * STAGE_BYTES;
+constexpr size_t HAND2_LDS = 2 * CHUNK_MAX + WG_WAVES * STAGE_BYTES + 16;   // + the 4 per-wave bone masks (culling)
 
 static int hand2_grid(int n_pts, int n_cus) {
     const int n_tiles = (n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
@@ -672,6 +705,7 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
         const char* e = getenv("HN_DBG");
         a.dbg = e ? atoi(e) : 0;
     }
+    a.cull = f->cull_far_field;
     int n_cus = hn_device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = hand2_grid(n_pts, n_cus);

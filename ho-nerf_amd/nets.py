@@ -211,6 +211,11 @@ class PackedField:
                 pass
             self.handle = None
 
+    def set_culling(self, enabled):
+        """Exact far-field early-out of the hand field (hn_field_set_culling); results stay bit-identical."""
+        torch.cuda.synchronize()
+        _lib.check(self.lib.hn_field_set_culling(self.handle, 1 if enabled else 0), 'hn_field_set_culling')
+
     # ---- direct field queries (utils/fields.py .sdf / forward+gradient+colour) ----------
     def _frames(self, pts, bt_inv, T_pose):
         n = pts.shape[0]

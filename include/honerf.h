@@ -78,6 +78,13 @@ int hn_field_destroy(hn_field* f);
 /* clip(exp(10 * variance), 1e-6, 1e6): utils/renderer.py:144. */
 float hn_field_inv_s(const hn_field* f);
 
+/* Exact far-field early-out of the hand field (SURVEY B-11): a bone whose mask h = 1 - sigmoid(200 (v - cutoff))
+ * (utils/fields.py:33-35) is exactly 0 in fp32 for every sample of a 128-sample workgroup contributes exactly 0
+ * to lin0, the lin4 skip, colour lin0 and the gradient; with culling enabled the f16x3 kernels skip that bone's
+ * weight chunks (results are bit-identical to the dense evaluation).  Off by default: throughput figures are
+ * quoted dense.  Set it before launching work on the field; no effect on obj fields and on HN_PREC_FP32. */
+int hn_field_set_culling(hn_field* f, int enabled);
+
 /* ---- rays -----------------------------------------------------------------------------
  * _xy_to_ray_bundle (utils/utils.py:31-115): NDC xy -> unproject at depth 1 and
  * 2 -> d = normalize(p2-p1), o = p1 - d.  n_cams cameras, rays_per_cam rays each:

@@ -581,3 +581,35 @@ def test_image_harness_obj_16x16(prec):
     ref_img = (ref['color_fine'].detach().numpy().reshape(H, W, 3) * 255.0).clip(0, 255).astype(np.uint8)
     assert ref_img.max() > 32, 'the synthetic view must show the object'
     assert np.abs(img.astype(int) - ref_img.astype(int)).max() <= 1, 'uint8 image may differ by one count at most'
+
+
+def test_hand_far_field_culling_is_exact(prec):
+    """hn_field_set_culling (SURVEY B-11): skipping the weight chunks of bones whose mask is 0 for a whole
+    workgroup must not change a single bit of sdf / gradient / colour (full and sdf-only kernels)."""
+    if prec != 'f16x3':
+        pytest.skip('culling exists in the f16x3 kernels only')
+    from honerf_amd import synth
+    hand, _ = packed_fields('cuda', prec)
+    bt_inv, T_pose, joints = synth.synth_hand_pose(7)
+    gen = torch.Generator().manual_seed(5)
+    j = t(joints)
+    n = 128 * 37 + 19
+    near = j[torch.randint(0, 21, (n,), generator=gen)] + 0.02 * torch.randn(n, 3, generator=gen)
+    far = j.mean(0) + 0.6 * torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    tip = j[20] + 0.01 * torch.randn(n, 3, generator=gen)           # one bone only: most chunks are skipped
+    sel = torch.arange(n) // 128 % 3                               # whole 128-sample tiles of each kind, plus mixing
+    pts = torch.where((sel == 0)[:, None], near, torch.where((sel == 1)[:, None], far, tip))
+    pts[-19:] = near[-19:]
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    bt, tp = t(bt_inv)[None], t(T_pose)[None]
+    dense = [x.clone() for x in hand.evaluate(cu(pts), cu(d), 1, bt, tp)]
+    dense_sdf = hand.sdf(cu(pts), bt, tp).clone()
+    hand.set_culling(True)
+    try:
+        culled = hand.evaluate(cu(pts), cu(d), 1, bt, tp)
+        culled_sdf = hand.sdf(cu(pts), bt, tp)
+        for a, b, what in zip(dense, culled, ('sdf', 'grad', 'rgb')):
+            assert torch.equal(a, b), 'culled %s differs from dense' % what
+        assert torch.equal(dense_sdf, culled_sdf)
+    finally:
+        hand.set_culling(False)
