@@ -323,13 +323,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                         ws.begin(nb < N_BONES ? HB_BONE : left_bytes);
                     }
                     if constexpr (blk == 0) load_bone(nb, nh, nl);   // nb == 21: the leftover blocks 84..86
-                    static_for<4>([&](auto TI) {
-                        constexpr int ti = decltype(TI)::value;
-                        if constexpr (ti == 0)
-                            mma_tile<4, 0, true>(ws, buf + ti * 4 * KS_BYTES, uh, ul, c1[4 * blk + ti], c2[4 * blk + ti], lane);
-                        else
-                            mma_tile<4, 0, false>(ws, buf + ti * 4 * KS_BYTES, uh, ul, c1[4 * blk + ti], c2[4 * blk + ti], lane);
-                    });
+                    mma_chunk<4, 4>(ws, buf, uh, ul, &c1[4 * blk], &c2[4 * blk], lane);   // one pipeline over the 16 blocks
                 });
             };
             load_bone(0, fh[0], fl[0]);

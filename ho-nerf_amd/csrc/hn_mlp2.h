@@ -126,6 +126,11 @@ struct WStream {
         goff += bytes;
         phase ^= 1;
     }
+    // the next chunk is not the sequentially next one (half-layer passes, skipped bones)
+    __device__ __forceinline__ void begin_at(int off, int bytes) {
+        goff = off;
+        begin(bytes);
+    }
     // k-th piece of this wave (k < 9: a chunk has at most 33 pieces).  Branch-free on purpose: a piece the
     // chunk does not have is issued with an out-of-range VGPR offset (the buffer range check drops it: no
     // memory traffic; its LDS destination lies in the unused tail of the 36 KiB buffer).  A uniform branch
@@ -278,6 +283,45 @@ __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 
     mma_tile<KS, S0, FETCH>(ws, blk, xh, xl, c1, c2, lane, e);
 }
 
+// A whole chunk of NT tiles x KS k-steps that share the KS fragments xh/xl (the hand field's feature passes):
+// c1/c2[t] += W[tile t, KS k-steps] * x.  One continuous software pipeline over the NT*KS blocks of the chunk (they
+// are contiguous in LDS): the A-fragment ring keeps running across the tile boundaries, where NT separate mma_tile
+// calls would each start with an empty ring and expose the LDS latency again.  The DMA pieces of the next chunk go
+// into the first slots.
+template <int NT, int KS, int NX>
+__device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16* c1,
+                                          f32x16* c2, int lane) {
+    static_assert(KS <= NX, "k-step range");
+    constexpr int N = NT * KS;           // blocks in the chunk
+    constexpr int NQ = 3 * N;
+    constexpr int STRIDE = NQ >= 27 ? 3 : (NQ >= 18 ? 2 : 1);
+    static_assert(NQ >= MAX_PIECES_PER_WAVE, "not enough slots for the DMA pieces");
+    h8 ah[3], al[3];
+    auto load = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        ah[s % 3] = *reinterpret_cast<const h8*>(buf + s * KS_BYTES + lane * 16);
+        al[s % 3] = *reinterpret_cast<const h8*>(buf + s * KS_BYTES + 1024 + lane * 16);
+    };
+    auto slot = [&](auto Q_) {
+        constexpr int Q = decltype(Q_)::value;
+        if constexpr (Q % STRIDE == STRIDE - 1 && Q / STRIDE < MAX_PIECES_PER_WAVE) ws.template piece<NoEpi::branchy>(Q / STRIDE);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    load(std::integral_constant<int, 0>{});
+    load(std::integral_constant<int, 1>{});
+    static_for<N>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        constexpr int t = s / KS, k = s % KS;
+        if constexpr (s + 2 < N) load(std::integral_constant<int, s + 2>{});
+        c1[t] = mfma16(ah[s % 3], xh[k], c1[t]);
+        slot(std::integral_constant<int, 3 * s>{});
+        c2[t] = mfma16(ah[s % 3], xl[k], c2[t]);
+        slot(std::integral_constant<int, 3 * s + 1>{});
+        c2[t] = mfma16(al[s % 3], xh[k], c2[t]);
+        slot(std::integral_constant<int, 3 * s + 2>{});
+    });
+}
+
 // tail helpers: 32 floats stored [half][16] so that lane half h reads its 16 rows as 4 float4
 // (row of register i, half h: (i&3) + 8 (i>>2) + 4 h)
 __device__ __forceinline__ f32x16 tail_tile(const char* tail, int slot, int h) {
@@ -323,7 +367,13 @@ __device__ __forceinline__ float dsoftplus_from_act(float a) {
 __device__ __forceinline__ float sigmoid_fast(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // ---- a layer as a software pipeline over its output tiles ----------------------------------------
+constexpr float K100_ = 144.26950408889634f;      // 100 * log2(e)
+constexpr float C100_ = 0.0069314718055994531f;   // ln(2) / 100
 struct NoData {};
+using f32x2 = float __attribute__((ext_vector_type(2)));
+#ifndef HN_EPI_PAIRS
+#define HN_EPI_PAIRS 1
+#endif
 
 // Element-wise epilogue of one tile, cut into 48 phase calls (16 elements x 3 phases) that mma_tile
 // spreads over the next tile's MFMA slots.  Phases 0 and 1 are the layer's own (`ph(I, P, st, pd)` turns
@@ -342,6 +392,7 @@ struct EpiState {
     }
     h8 hi[2], lo[2]; // fragments of k-steps 2t, 2t+1
     float r0, r1;    // residuals of the pair being converted
+    f32x2 z2, t2, e2;   // pair pipeline (HN_EPI_PAIRS): pre-activation, scaled argument, exponential
     float inv;       // 1/2048, laundered behind the tile's barrier: ties every phase-0 to this side of it
 };
 template <int I, bool FRAGS>
@@ -365,9 +416,58 @@ __device__ __forceinline__ void split_phase(EpiState& st) {
 }
 template <bool FRAGS>
 __device__ __forceinline__ void split_finish(EpiState& st) {
-    if constexpr (FRAGS) {
+    if constexpr (FRAGS && !HN_EPI_PAIRS) {
         st.lo[1][6] = (_Float16)(st.r0 * LO_SCALE);
         st.lo[1][7] = (_Float16)(st.r1 * LO_SCALE);
+    }
+}
+// Pair form of the same epilogue (HN_EPI_PAIRS): the 16 elements are processed as 8 pairs x 6 phases (48 calls, one
+// per MFMA slot of a 16-k-step tile) so that the multiply-adds become packed fp32 instructions (v_pk_fma/mul/add_f32:
+// two elements per issue slot).  The wave is issue-bound -- every VALU instruction of the epilogue costs ~4 cycles
+// of the same in-order stream that has to issue the MFMAs -- so the instruction count, not the ALU rate, is what
+// matters.  kind: 0 softplus(beta=100), 1 g * sigma'(z) from the stashed activation, 2 relu, 3 identity.
+template <int J, int P, int KIND, bool FRAGS, typename PD>
+__device__ __forceinline__ void pair_phase(EpiState& st, const PD& pd) {
+    constexpr int i0 = 2 * J, i1 = 2 * J + 1;
+    if constexpr (P == 0) {
+        const f32x2 c1 = {st.c1[i0], st.c1[i1]}, c2 = {st.c2[i0], st.c2[i1]};
+        const f32x2 inv = {st.inv, st.inv};
+        st.z2 = c2 * inv + c1;
+        if constexpr (KIND == 0) st.t2 = st.z2 * f32x2{K100_, K100_};
+        if constexpr (KIND == 1) st.t2 = f32x2{pd.v[i0], pd.v[i1]} * f32x2{-K100_, -K100_};
+    } else if constexpr (P == 1) {
+        if constexpr (KIND == 0) st.e2 = f32x2{__builtin_amdgcn_exp2f(-fabsf(st.t2[0])), __builtin_amdgcn_exp2f(-fabsf(st.t2[1]))};
+        if constexpr (KIND == 1) st.e2 = f32x2{__builtin_amdgcn_exp2f(st.t2[0]), __builtin_amdgcn_exp2f(st.t2[1])};
+    } else if constexpr (P == 2) {
+        if constexpr (KIND == 0) {
+            const f32x2 u = st.e2 + f32x2{1.f, 1.f};
+            st.e2 = f32x2{__builtin_amdgcn_logf(u[0]), __builtin_amdgcn_logf(u[1])};
+        }
+    } else if constexpr (P == 3) {
+        f32x2 v;
+        if constexpr (KIND == 0) v = st.e2 * f32x2{C100_, C100_} + f32x2{fmaxf(st.z2[0], 0.f), fmaxf(st.z2[1], 0.f)};
+        if constexpr (KIND == 1) v = st.z2 - st.z2 * st.e2;
+        if constexpr (KIND == 2) v = f32x2{fmaxf(st.z2[0], 0.f), fmaxf(st.z2[1], 0.f)};
+        if constexpr (KIND == 3) v = st.z2;
+        st.v[i0] = v[0];
+        st.v[i1] = v[1];
+    } else if constexpr (P == 4) {
+        if constexpr (FRAGS) {
+            constexpr int u = i0 >> 3, j = i0 & 7;
+            const _Float16 h0 = hi_part(st.v[i0]), h1 = hi_part(st.v[i1]);
+            st.hi[u][j] = h0;
+            st.hi[u][j + 1] = h1;
+            const f32x2 r = f32x2{st.v[i0], st.v[i1]} - f32x2{(float)h0, (float)h1};
+            st.r0 = r[0];
+            st.r1 = r[1];
+        }
+    } else {
+        if constexpr (FRAGS) {
+            constexpr int u = i0 >> 3, j = i0 & 7;
+            const f32x2 l = f32x2{st.r0, st.r1} * f32x2{LO_SCALE, LO_SCALE};
+            st.lo[u][j] = (_Float16)l[0];
+            st.lo[u][j + 1] = (_Float16)l[1];
+        }
     }
 }
 template <bool FRAGS, typename Ph, typename PD>
@@ -376,28 +476,26 @@ struct Epi {
     EpiState& st;
     Ph& ph;
     const PD& pd;
+    template <int C>
+    __device__ __forceinline__ void call() {
+#if HN_EPI_PAIRS
+        pair_phase<C / 6, C % 6, Ph::kind, FRAGS>(st, pd);
+#else
+        constexpr int I = C / 3, P = C % 3;
+        if constexpr (P < 2)
+            ph(std::integral_constant<int, I>{}, std::integral_constant<int, P>{}, st, pd);
+        else
+            split_phase<I, FRAGS>(st);
+#endif
+    }
     // slots Q of NQ: phase calls [Q*48/NQ, (Q+1)*48/NQ)
     template <int Q, int NQ>
     __device__ __forceinline__ void run() {
         constexpr int lo = Q * 48 / NQ, hi = (Q + 1) * 48 / NQ;
-        static_for<hi - lo>([&](auto K) {
-            constexpr int c = lo + decltype(K)::value;
-            constexpr int I = c / 3, P = c % 3;
-            if constexpr (P < 2)
-                ph(std::integral_constant<int, I>{}, std::integral_constant<int, P>{}, st, pd);
-            else
-                split_phase<I, FRAGS>(st);
-        });
+        static_for<hi - lo>([&](auto K) { call<lo + decltype(K)::value>(); });
     }
     __device__ __forceinline__ void run_all() {
-        static_for<48>([&](auto K) {
-            constexpr int c = decltype(K)::value;
-            constexpr int I = c / 3, P = c % 3;
-            if constexpr (P < 2)
-                ph(std::integral_constant<int, I>{}, std::integral_constant<int, P>{}, st, pd);
-            else
-                split_phase<I, FRAGS>(st);
-        });
+        static_for<48>([&](auto K) { call<decltype(K)::value>(); });
     }
 };
 
@@ -471,6 +569,7 @@ constexpr float K100 = 144.26950408889634f;      // 100 * log2(e)
 constexpr float C100 = 0.0069314718055994531f;   // ln(2) / 100
 // softplus(beta=100): v = max(z,0) + log2(1 + exp2(-|z| K100)) * C100
 struct PhSoftplus {
+    static constexpr int kind = 0;
     static constexpr bool branchy = HN_BRANCHY_FWD;
     template <typename I_, typename P_, typename PD>
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD&) const {
@@ -485,6 +584,7 @@ struct PhSoftplus {
 };
 // reverse sweep: v = g * sigma'(z) with sigma' = 1 - exp(-100 a) from the stashed activation pd.v
 struct PhDsig {
+    static constexpr int kind = 1;
     static constexpr bool branchy = HN_BRANCHY_REV;
     template <typename I_, typename P_, typename PD>
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD& pd) const {
@@ -498,6 +598,7 @@ struct PhDsig {
     }
 };
 struct PhRelu {
+    static constexpr int kind = 2;
     static constexpr bool branchy = HN_BRANCHY_RELU;
     template <typename I_, typename P_, typename PD>
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD&) const {
@@ -506,6 +607,7 @@ struct PhRelu {
     }
 };
 struct PhIdentity {
+    static constexpr int kind = 3;
     static constexpr bool branchy = HN_BRANCHY_FWD;
     template <typename I_, typename P_, typename PD>
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD&) const {

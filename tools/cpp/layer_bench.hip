@@ -12,6 +12,7 @@ using namespace hn::v2;
 #define VARIANT 0
 #endif
 constexpr int HB = chunk_bytes(1, 16, true);
+constexpr int HBB = chunk_bytes(4, 4, false);
 struct Act { f32x16 v; };
 __global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, int layers, float4* scratch, long long* cyc, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, i
     f16_flush_mode();
     WStream ws;
     ws.init(blob, bytes, lds, wave, lane);
-    ws.fetch_all(HB);
+    ws.fetch_all((VARIANT == 5 || VARIANT == 6) ? HBB : HB);
     Stash sh;
     sh.init(scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * 2 * SLOT_F4, 2, lane);
     h8 ah[16], al[16], bh[16], bl[16];
@@ -62,6 +63,39 @@ __global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, i
         } else if (VARIANT == 2) {
             run_layer<8, 16, 1, true, false>(ws, HB, HB, ah, al, lane, h, no_pre, PhIdentity{}, sink_fin, no_store);
             run_layer<8, 16, 1, true, false>(ws, HB, HB, ah, al, lane, h, no_pre, PhIdentity{}, sink_fin, no_store);
+        } else if (VARIANT == 5 || VARIANT == 6) {
+            // feature-pass shape: chunks of 4 tiles x 4 k-steps sharing 4 fragments, 8 live accumulator pairs
+            f32x16 c1[8], c2[8];
+            h8 fh[4], fl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fh[i] = ah[i]; fl[i] = al[i]; }
+#pragma unroll
+            for (int i = 4; i < 16; ++i) asm volatile("" :: "v"(ah[i]), "v"(al[i]));   // the rest is dead from here
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { c1[i] = zero16(); c2[i] = zero16(); }
+#pragma unroll 1
+            for (int cch = 0; cch < 8; ++cch) {
+                static_for<2>([&](auto BLK) {
+                    constexpr int blk = decltype(BLK)::value;
+                    const char* buf = ws.template acquire<0>();
+                    ws.begin(HBB);
+                    if constexpr (VARIANT == 5) {
+                        static_for<4>([&](auto TI) {
+                            constexpr int ti = decltype(TI)::value;
+                            if constexpr (ti == 0)
+                                mma_tile<4, 0, true>(ws, buf + ti * 4 * KS_BYTES, fh, fl, c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                            else
+                                mma_tile<4, 0, false>(ws, buf + ti * 4 * KS_BYTES, fh, fl, c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                        });
+                    } else {
+                        mma_chunk<4, 4>(ws, buf, fh, fl, &c1[4 * blk], &c2[4 * blk], lane);
+                    }
+                });
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc += c1[i][r] + c2[i][r];
         } else {
             run_layer<8, 16, 1, true, true>(ws, HB, HB, ah, al, lane, h, act_of, PhDsig{}, to_regs(bh, bl), no_store);
             run_layer<8, 16, 1, true, true>(ws, HB, HB, bh, bl, lane, h, act_of, PhDsig{}, to_regs(ah, al), no_store);
@@ -72,7 +106,7 @@ __global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, i
     __syncthreads();
     float s = acc;
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
+    for (int k = 0; k < ((VARIANT == 5 || VARIANT == 6) ? 4 : 16); ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += (float)ah[k][j] + (float)al[k][j];
     sink[blockIdx.x * 256 + threadIdx.x] = s;
@@ -102,7 +136,7 @@ int main(int argc, char** argv) {
     }
     const int layers = argc > 1 ? atoi(argv[1]) : 32;
     const int wgs = argc > 2 ? atoi(argv[2]) : 256;
-    const size_t bytes = (size_t)HB * 8 * 8;   // 8 layers of 8 chunks, cycled
+    const size_t bytes = (VARIANT == 5 || VARIANT == 6) ? (size_t)HBB * 64 : (size_t)HB * 8 * 8;   // 8 layers of 8 chunks, cycled
     std::vector<_Float16> hostw(bytes / 2);
     for (size_t i = 0; i < hostw.size(); ++i) hostw[i] = (_Float16)(0.02f * (float)((int)(i * 2654435761u >> 24) % 13 - 6));
     char* blob; float4* scratch; long long* cyc; float* sink;
@@ -120,7 +154,7 @@ int main(int argc, char** argv) {
     std::vector<long long> c(wgs * 4);
     hipMemcpy(c.data(), cyc, wgs * 4 * 8, hipMemcpyDeviceToHost);
     double mean = 0; for (auto v : c) mean += v; mean /= c.size();
-    const int chunks = layers * 8;
+    const int chunks = layers * 8;   // variants 5/6: 16 chunks per 2 'layers' as well
     printf("variant %d%s: %d wgs, %d chunks: %.3f ms -> %.3f us/chunk, %.0f ticks/chunk (%.0f ticks/us); MFMA floor 1536 cycles\n", VARIANT,
 #ifdef HN_PIECE_BRANCH
            " [branchy pieces]",
