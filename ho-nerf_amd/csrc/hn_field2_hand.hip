@@ -11,6 +11,12 @@
 #include <stdlib.h>
 
 #include "hn_mlp2.h"
+#ifndef HN_PARK_AGPR
+#define HN_PARK_AGPR 1
+#endif
+#ifndef HN_EXP_ACC
+#define HN_EXP_ACC 4
+#endif
 
 namespace hn {
 namespace v2 {
@@ -130,7 +136,7 @@ __device__ __forceinline__ void bone_jacobian(const f32x16& G0, const f32x16& G1
                 Sr[0] += h ? Gv * bn.hh : 0.f;
                 continue;
             }
-            const float other = __shfl_xor(own[s][j], 32, 64);
+            const float other = other_half(own[s][j], h);
             // which variable / frequency this slot encodes
             int var, k;   // var 0 = v, 1..3 = r_0..r_2
             if (s == 0) {
@@ -253,6 +259,14 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         struct Frags {
             h8 hi[2], lo[2];
         };
+        // Finished output fragments are parked in AGPRs until the next layer reads them: the layer that produces them
+        // already holds its 128 input-fragment registers, the epilogue state and the pre-loaded side data in VGPRs, and
+        // with the outputs there too the allocator goes to scratch memory inside the MFMA loops.
+        auto park = [](h8& a0, h8& a1, h8& a2, h8& a3) {
+#if HN_PARK_AGPR
+            asm volatile("" : "+a"(a0), "+a"(a1), "+a"(a2), "+a"(a3));
+#endif
+        };
         auto no_pre = [](auto, const char*) { return NoData{}; };
         auto no_store = [](auto, const auto&) {};
         auto stash_frags = [&](int stash_slot) {
@@ -263,24 +277,26 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             };
         };
         auto to_regs = [&](h8(&oh)[16], h8(&ol)[16]) {
-            return [&oh, &ol](auto T, EpiState& st, const auto&) {
+            return [&oh, &ol, &park](auto T, EpiState& st, const auto&) {
                 constexpr int t = decltype(T)::value;
                 asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
                 oh[2 * t] = st.hi[0];
                 ol[2 * t] = st.lo[0];
                 oh[2 * t + 1] = st.hi[1];
                 ol[2 * t + 1] = st.lo[1];
+                park(oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
                 return NoData{};
             };
         };
         auto to_regs_keep = [&](h8(&oh)[16], h8(&ol)[16], int stash_slot) {
-            return [&oh, &ol, stash_slot, &sh](auto T, EpiState& st, const auto&) {
+            return [&oh, &ol, stash_slot, &sh, &park](auto T, EpiState& st, const auto&) {
                 constexpr int t = decltype(T)::value;
                 asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
                 oh[2 * t] = st.hi[0];
                 ol[2 * t] = st.lo[0];
                 oh[2 * t + 1] = st.hi[1];
                 ol[2 * t + 1] = st.lo[1];
+                park(oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
                 if (FULL) sh.tile_store(stash_slot, t, st.vec());
                 return NoData{};
             };
@@ -323,22 +339,35 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                         ws.begin(nb < N_BONES ? HB_BONE : left_bytes);
                     }
                     if constexpr (blk == 0) load_bone(nb, nh, nl);   // nb == 21: the leftover blocks 84..86
-                    mma_chunk<4, 4>(ws, buf, uh, ul, &c1[4 * blk], &c2[4 * blk], lane);   // one pipeline over the 16 blocks
+                    mma_chunk<4, 4>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);   // one pipeline over the 16 blocks
                 });
             };
             load_bone(0, fh[0], fl[0]);
             unsigned rem = nzw & ~1u;
+            // two steps per trip with the fragment buffers swapped, NOT one step plus a copy: with a copy at the end
+            // of the trip the compiler coalesces the two buffers and sinks the next bone's loads to the point of the
+            // copy, i.e. the prefetch becomes a load that the very next MFMAs wait for (measured: ~2000 cycles per bone)
+            bool in_first = false;   // the leftover fragments ended up in fh[0] (else fh[1])
 #pragma unroll 1
             while (true) {
                 const int nb = rem ? __builtin_ctz(rem) : N_BONES;
                 rem &= rem - 1u;
                 step(nb, fh[0], fl[0], fh[1], fl[1]);
+                if (nb == N_BONES) break;
+                const int nb2 = rem ? __builtin_ctz(rem) : N_BONES;
+                rem &= rem - 1u;
+                step(nb2, fh[1], fl[1], fh[0], fl[0]);
+                if (nb2 == N_BONES) {
+                    in_first = true;
+                    break;
+                }
+            }
+            if (!in_first) {
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
                     fh[0][s4] = fh[1][s4];
                     fl[0][s4] = fl[1][s4];
                 }
-                if (nb == N_BONES) break;
             }
             static_for<NB>([&](auto BLK) {
                 constexpr int blk = decltype(BLK)::value;
@@ -504,6 +533,9 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         // so that the features and the Jacobian are visited once
 #pragma unroll
         for (int s = 0; s < 16; ++s) sh.frag_load(HS_DZ4 * SLOT_BYTES, s, ah[s], al[s]);
+        // dz0 (parked in AGPRs by the last reverse layer) is the B operand of 44 chunks: back into VGPRs once, here
+#pragma unroll
+        for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(bh[s]), "+v"(bl[s]));
         {
             const int jbase = ws.goff - HB_BWD;   // stream offset of bone 0's first chunk (in flight)
             unsigned rem = nzw & ~1u;

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                                         no_store);
         // ---- lin4: [a4 (192 via k-steps 0..11) | X with a4[192] in its pad slot] / sqrt2
         {
-            const float v192 = __shfl_xor(a4_192, 32, 64);   // half 1 receives half 0's value
+            const float v192 = other_half(a4_192, h);   // half 1 receives half 0's value
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if constexpr (FULL) {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 float fr = 1.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float other = __shfl_xor(f[c][k], 32, 64);   // the conjugate function of the same angle
+                    const float other = other_half(f[c][k], h);   // the conjugate function of the same angle
                     const float Gv = (c < 2) ? G0[8 * c + k] : Gb[k];
                     g[c] = fmaf(Gv, (h ? -fr : fr) * other, g[c]);
                     fr *= 2.f;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
 #pragma unroll
             for (int jj = 0; jj < 6; ++jj) {
                 const float fr = (jj & 1) ? 512.f : 256.f;
-                const float other = __shfl_xor(f[3][jj], 32, 64);
+                const float other = other_half(f[3][jj], h);
                 g[jj >> 1] = fmaf(Gb[8 + jj], (h ? -fr : fr) * other, g[jj >> 1]);
             }
             g[0] += h ? 0.f : Gb[14];

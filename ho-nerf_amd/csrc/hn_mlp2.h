@@ -155,10 +155,22 @@ struct WStream {
         begin(bytes);
         pieces_all();
     }
-    template <int ALLOW>
+    // VISIBLE: issue the drain as the s_waitcnt builtin instead of inline asm, so that the compiler's own wait-count
+    // bookkeeping sees it.  With the opaque asm it still believes every earlier register load may be pending and
+    // (the DMA pieces being conditional) guards the first use with a counted vmcnt that can only be met by draining
+    // the loads issued AFTER them.  That matters where register loads are issued one step ahead (the hand field's
+    // feature passes: ~2000 cycles per bone); elsewhere the visible form changes the register allocation for the
+    // worse (reverse sweep 123 -> 202 us per tile), so it is opt-in.
+    // gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14.
+    template <int ALLOW, bool VISIBLE = false>
     __device__ __forceinline__ const char* acquire() {
         stamp(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW) : "memory");
+        if constexpr (VISIBLE) {
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt((ALLOW & 15) | (7 << 4) | (15 << 8) | ((ALLOW >> 4) << 14));
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW) : "memory");
+        }
         stamp(2);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -313,6 +325,7 @@ __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8
         constexpr int s = decltype(S)::value;
         constexpr int t = s / KS, k = s % KS;
         if constexpr (s + 2 < N) load(std::integral_constant<int, s + 2>{});
+        if constexpr (k == 0) ws.stamp(5);
         c1[t] = mfma16(ah[s % 3], xh[k], c1[t]);
         slot(std::integral_constant<int, 3 * s>{});
         c2[t] = mfma16(ah[s % 3], xl[k], c2[t]);
@@ -320,6 +333,7 @@ __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8
         c2[t] = mfma16(al[s % 3], xh[k], c2[t]);
         slot(std::integral_constant<int, 3 * s + 2>{});
     });
+    ws.stamp(4);
 }
 
 // tail helpers: 32 floats stored [half][16] so that lane half h reads its 16 rows as 4 float4
@@ -724,7 +738,20 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
     c = ((k + 1) & 2) ? -cc : cc;
 }
 
-__device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+// Exchange between the two 32-lane halves with v_permlane32_swap_b32 (gfx950): a VALU instruction, where
+// __shfl_xor(v, 32) becomes a ds_bpermute through the LDS crossbar.  The swap of (x, x) leaves {x.lo, x.lo} in
+// the first and {x.hi, x.hi} in the second result.
+__device__ __forceinline__ float half_sum(float v) {
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// the other half's value of the same column: lane l <- lane l ^ 32  (h = l >> 5)
+__device__ __forceinline__ float other_half(float v, int h) {
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return __builtin_bit_cast(float, (unsigned)(h ? r[0] : r[1]));
+}
 
 }  // namespace v2
 }  // namespace hn

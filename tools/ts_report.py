@@ -58,3 +58,12 @@ print('chunks:', len(r))
 print('wave0 per chunk [dma-wait, barrier, mma, tail, tiles]:')
 for ci in range(len(r)):
     print(ci, ' '.join('%5d' % x for x in r[ci]), '|', ' '.join('%5d' % sum(out[w][ci][:4]) for w in range(4) if ci < len(out[w])))
+
+if os.environ.get('RAW'):
+    w = 0
+    ids = (a[w] >> np.uint64(60)).astype(int); t = (a[w] & np.uint64((1 << 60) - 1)).astype(np.int64)
+    lo, hi = [int(x) for x in os.environ['RAW'].split(':')]
+    starts = np.nonzero(ids == 1)[0]
+    for ci in range(lo, hi):
+        s0, e0 = starts[ci], starts[ci + 1]
+        print('chunk', ci, ' '.join('%d:%d' % (ids[k], t[k] - t[s0]) for k in range(s0, e0)))
