@@ -173,6 +173,218 @@ __global__ __launch_bounds__(256) void k_composite2(const float* __restrict__ ah
     }
 }
 
+// ---- S a multiple of 64: 16 lanes per ray, every lane owns S/16 consecutive samples -----------------------------
+// A wave takes 4 consecutive rays; lane (row r = lane >> 4, l = lane & 15) owns samples l*CPS .. l*CPS + CPS-1 of ray
+// 4 g + r, so a wave reads 4*S consecutive floats of every per-sample array with 16-byte loads.  The transmittance is a
+// sequential product inside the lane, an exclusive product scan over the 16 lanes of the row (DPP row_shr: VALU only,
+// where __shfl_up goes through the LDS crossbar) and the per-ray sums are row_ror butterflies.
+template <int CTRL>
+__device__ __forceinline__ float dpp(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                  0xf, 0xf, false));
+}
+// inclusive product over the 16 lanes of a row (row_shr:n = 0x110 + n; lanes without a source keep `old` = 1)
+__device__ __forceinline__ float row_incl_prod(float v) {
+    v *= dpp<0x111>(1.f, v);
+    v *= dpp<0x112>(1.f, v);
+    v *= dpp<0x114>(1.f, v);
+    v *= dpp<0x118>(1.f, v);
+    return v;
+}
+// sum / max over the row, result in every lane (row_ror:n = 0x120 + n)
+__device__ __forceinline__ float row_sum(float v) {
+    v += dpp<0x128>(0.f, v);
+    v += dpp<0x124>(0.f, v);
+    v += dpp<0x122>(0.f, v);
+    v += dpp<0x121>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, dpp<0x128>(0.f, v));
+    v = fmaxf(v, dpp<0x124>(0.f, v));
+    v = fmaxf(v, dpp<0x122>(0.f, v));
+    v = fmaxf(v, dpp<0x121>(0.f, v));
+    return v;
+}
+// loads CPS consecutive floats / CPS consecutive float3 of this lane (16-byte accesses)
+template <int CPS>
+__device__ __forceinline__ void load_run(const float* __restrict__ p, float (&v)[CPS]) {
+#pragma unroll
+    for (int q = 0; q < CPS / 4; ++q) {
+        const float4 t = reinterpret_cast<const float4*>(p)[q];
+        v[4 * q] = t.x;
+        v[4 * q + 1] = t.y;
+        v[4 * q + 2] = t.z;
+        v[4 * q + 3] = t.w;
+    }
+}
+template <int CPS>
+__device__ __forceinline__ void store_run(float* __restrict__ p, const float (&v)[CPS]) {
+#pragma unroll
+    for (int q = 0; q < CPS / 4; ++q) reinterpret_cast<float4*>(p)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+__device__ __forceinline__ float wave_sum_rows(float v) {   // v is already a row sum (equal within a row)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int CPS>
+__global__ __launch_bounds__(256) void k_composite1_rows(const float* __restrict__ alpha, const float* __restrict__ c,
+                                                         const float* __restrict__ rgb, const float* __restrict__ grad,
+                                                         int n_rays, float* __restrict__ color, float* __restrict__ weights,
+                                                         float* __restrict__ weight_sum, float* __restrict__ weight_max,
+                                                         float* __restrict__ eik_sum) {
+    constexpr int S = 16 * CPS;
+    const int lane = threadIdx.x & 63, l = lane & 15, row = lane >> 4;
+    float eik_total = 0.f;
+    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g * 4 < n_rays; g += gridDim.x * 4) {
+        const int ray = g * 4 + row;
+        const bool ok = ray < n_rays;
+        const size_t base = (size_t)(ok ? ray : n_rays - 1) * S + l * CPS;
+        float a[CPS], w[CPS], x[3 * CPS];
+        load_run<CPS>(alpha + base, a);
+        float P = 1.f;
+#pragma unroll
+        for (int i = 0; i < CPS; ++i) P *= 1.f - a[i] + 1e-7f;
+        const float incl = row_incl_prod(P);
+        float excl = dpp<0x111>(1.f, incl);                       // row_shr:1, lane 0 of the row keeps 1
+        float T = c[(size_t)(ok ? ray : n_rays - 1) * S] * excl;   // SURVEY B-3: the first factor is c_0, not 1
+        float wsum = 0.f, wmax = -1.f;
+#pragma unroll
+        for (int i = 0; i < CPS; ++i) {
+            w[i] = a[i] * T;
+            T *= 1.f - a[i] + 1e-7f;
+            wsum += w[i];
+            wmax = fmaxf(wmax, w[i]);
+        }
+        if (ok && weights != nullptr) store_run<CPS>(weights + base, w);
+        load_run<3 * CPS>(rgb + 3 * base, x);
+        float col[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < CPS; ++i) {
+            col[0] += w[i] * x[3 * i];
+            col[1] += w[i] * x[3 * i + 1];
+            col[2] += w[i] * x[3 * i + 2];
+        }
+        float eik = 0.f;
+        if (grad != nullptr) {
+            load_run<3 * CPS>(grad + 3 * base, x);
+#pragma unroll
+            for (int i = 0; i < CPS; ++i) {
+                const float nrm = sqrtf(x[3 * i] * x[3 * i] + x[3 * i + 1] * x[3 * i + 1] + x[3 * i + 2] * x[3 * i + 2]) - 1.f;
+                eik += nrm * nrm;
+            }
+        }
+        col[0] = row_sum(col[0]);
+        col[1] = row_sum(col[1]);
+        col[2] = row_sum(col[2]);
+        wsum = row_sum(wsum);
+        wmax = row_max(wmax);
+        if (ok && l == 0) {
+            color[3 * ray] = col[0];
+            color[3 * ray + 1] = col[1];
+            color[3 * ray + 2] = col[2];
+            weight_sum[ray] = wsum;
+            if (weight_max != nullptr) weight_max[ray] = wmax;
+        }
+        eik_total += ok ? eik : 0.f;
+    }
+    if (eik_sum != nullptr && grad != nullptr) {
+        const float t = wave_sum_rows(row_sum(eik_total));
+        if (lane == 0) atomicAdd(eik_sum, t);
+    }
+}
+
+template <int CPS>
+__global__ __launch_bounds__(256) void k_composite2_rows(const float* __restrict__ ah, const float* __restrict__ rgbh,
+                                                         const float* __restrict__ gh, const float* __restrict__ ao,
+                                                         const float* __restrict__ rgbo, const float* __restrict__ go,
+                                                         int n_rays, float* __restrict__ color, float* __restrict__ weight_sum,
+                                                         float* __restrict__ w_hand, float* __restrict__ w_obj,
+                                                         float* __restrict__ eik_sum) {
+    constexpr int S = 16 * CPS;
+    const int lane = threadIdx.x & 63, l = lane & 15, row = lane >> 4;
+    float eh_total = 0.f, eo_total = 0.f;
+    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g * 4 < n_rays; g += gridDim.x * 4) {
+        const int ray = g * 4 + row;
+        const bool ok = ray < n_rays;
+        const size_t base = (size_t)(ok ? ray : n_rays - 1) * S + l * CPS;
+        float a1[CPS], a2[CPS], w1[CPS], w2[CPS], x[3 * CPS];
+        load_run<CPS>(ah + base, a1);
+        load_run<CPS>(ao + base, a2);
+        float P = 1.f;
+#pragma unroll
+        for (int i = 0; i < CPS; ++i) P *= (1.f - a1[i] + 1e-7f) * (1.f - a2[i] + 1e-7f);
+        const float incl = row_incl_prod(P);
+        float T = dpp<0x111>(1.f, incl);
+        float ws = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPS; ++i) {
+            w1[i] = a1[i] * T;
+            w2[i] = a2[i] * T;
+            T *= (1.f - a1[i] + 1e-7f) * (1.f - a2[i] + 1e-7f);
+            ws += w1[i] + w2[i];
+        }
+        if (ok && w_hand != nullptr) store_run<CPS>(w_hand + base, w1);
+        if (ok && w_obj != nullptr) store_run<CPS>(w_obj + base, w2);
+        float col[3] = {0.f, 0.f, 0.f};
+        load_run<3 * CPS>(rgbh + 3 * base, x);
+#pragma unroll
+        for (int i = 0; i < CPS; ++i) {
+            col[0] += w1[i] * x[3 * i];
+            col[1] += w1[i] * x[3 * i + 1];
+            col[2] += w1[i] * x[3 * i + 2];
+        }
+        load_run<3 * CPS>(rgbo + 3 * base, x);
+#pragma unroll
+        for (int i = 0; i < CPS; ++i) {
+            col[0] += w2[i] * x[3 * i];
+            col[1] += w2[i] * x[3 * i + 1];
+            col[2] += w2[i] * x[3 * i + 2];
+        }
+        float eh = 0.f, eo = 0.f;
+        if (gh != nullptr) {
+            load_run<3 * CPS>(gh + 3 * base, x);
+#pragma unroll
+            for (int i = 0; i < CPS; ++i) {
+                const float nrm = sqrtf(x[3 * i] * x[3 * i] + x[3 * i + 1] * x[3 * i + 1] + x[3 * i + 2] * x[3 * i + 2]) - 1.f;
+                eh += nrm * nrm;
+            }
+        }
+        if (go != nullptr) {
+            load_run<3 * CPS>(go + 3 * base, x);
+#pragma unroll
+            for (int i = 0; i < CPS; ++i) {
+                const float nrm = sqrtf(x[3 * i] * x[3 * i] + x[3 * i + 1] * x[3 * i + 1] + x[3 * i + 2] * x[3 * i + 2]) - 1.f;
+                eo += nrm * nrm;
+            }
+        }
+        col[0] = row_sum(col[0]);
+        col[1] = row_sum(col[1]);
+        col[2] = row_sum(col[2]);
+        ws = row_sum(ws);
+        if (ok && l == 0) {
+            color[3 * ray] = col[0];
+            color[3 * ray + 1] = col[1];
+            color[3 * ray + 2] = col[2];
+            weight_sum[ray] = ws;
+        }
+        eh_total += ok ? eh : 0.f;
+        eo_total += ok ? eo : 0.f;
+    }
+    if (eik_sum != nullptr) {
+        if (gh != nullptr) {
+            const float t = wave_sum_rows(row_sum(eh_total));
+            if (lane == 0) atomicAdd(eik_sum, t);
+        }
+        if (go != nullptr) {
+            const float t = wave_sum_rows(row_sum(eo_total));
+            if (lane == 0) atomicAdd(eik_sum + 1, t);
+        }
+    }
+}
+
 // ---- adjoints (pose fitting back-propagates through these stages: fitting_single.py:289-291) ---------
 // d/d(sdf, grad, rays_d) of k_alpha.  One thread per sample; the per-ray direction gradient is accumulated
 // with atomics (S adders per ray; the fitting configs have ~200 rays).  dists carry no gradient: they come
@@ -306,8 +518,18 @@ int composite1(const float* alpha_in, const float* c, const float* rgb, const fl
                float* color, float* weights, float* weight_sum, float* weight_max, float* eik_sum, hipStream_t s) {
     HN_REQUIRE(S >= 1, "S must be positive");
     if (n_rays == 0) return HN_OK;
-    hipLaunchKernelGGL(k_composite1, dim3(composite_grid(n_rays)), dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, S, color,
-                       weights, weight_sum, weight_max, eik_sum);
+    const int groups = (n_rays + 3) / 4;   // the row kernels take 4 rays per wave
+    const dim3 rgrid((groups + 3) / 4 < 4096 ? (groups + 3) / 4 : 4096);
+    // measured at 262144 rays: the row form wins at S = 128 (267 vs 294 us) and loses at S = 64 (242 vs 197 us)
+    if (S == 128)
+        hipLaunchKernelGGL(k_composite1_rows<8>, rgrid, dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, color, weights, weight_sum,
+                           weight_max, eik_sum);
+    else if (S == 192)
+        hipLaunchKernelGGL(k_composite1_rows<12>, rgrid, dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, color, weights, weight_sum,
+                           weight_max, eik_sum);
+    else
+        hipLaunchKernelGGL(k_composite1, dim3(composite_grid(n_rays)), dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, S, color,
+                           weights, weight_sum, weight_max, eik_sum);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -317,8 +539,17 @@ int composite2(const float* ah, const float* rgbh, const float* gh, const float*
                hipStream_t s) {
     HN_REQUIRE(S >= 1, "S must be positive");
     if (n_rays == 0) return HN_OK;
-    hipLaunchKernelGGL(k_composite2, dim3(composite_grid(n_rays)), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, S,
-                       color, weight_sum, w_hand, w_obj, eik_sum);
+    const int groups = (n_rays + 3) / 4;
+    const dim3 rgrid((groups + 3) / 4 < 4096 ? (groups + 3) / 4 : 4096);
+    if (S == 128)
+        hipLaunchKernelGGL(k_composite2_rows<8>, rgrid, dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, color, weight_sum,
+                           w_hand, w_obj, eik_sum);
+    else if (S == 192)
+        hipLaunchKernelGGL(k_composite2_rows<12>, rgrid, dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, color, weight_sum,
+                           w_hand, w_obj, eik_sum);
+    else
+        hipLaunchKernelGGL(k_composite2, dim3(composite_grid(n_rays)), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, S,
+                           color, weight_sum, w_hand, w_obj, eik_sum);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
