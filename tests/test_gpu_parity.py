@@ -613,3 +613,66 @@ def test_hand_far_field_culling_is_exact(prec):
         assert torch.equal(dense_sdf, culled_sdf)
     finally:
         hand.set_culling(False)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_error_paths_return_status_and_message(L):
+    """C ABI error behaviour: int status < 0 + hn_last_error(), nothing launched."""
+    lib = L.load()
+    hand, obj = packed_fields('cuda', 'f16x3')
+    n = 300
+    pts, sdf = torch.zeros(n, 3, device='cuda'), torch.empty(n, device='cuda')
+    need = lib.hn_field_workspace_bytes(obj.handle, n)
+    small = torch.empty(64, dtype=torch.uint8, device="cuda")   # far below `need`
+    grad, rgb = torch.empty(n, 3, device='cuda'), torch.empty(n, 3, device='cuda')
+    rc = lib.hn_field_eval(obj.handle, L.ptr(pts), L.ptr(pts), n, 1, None, None, 1, n, L.ptr(sdf), L.ptr(grad), L.ptr(rgb), None,
+                           L.ptr(small), small.numel(), st())
+    assert rc < 0 and b'workspace' in lib.hn_last_error()
+    ws = torch.empty(lib.hn_field_workspace_bytes(hand.handle, n), dtype=torch.uint8, device='cuda')
+    rc = lib.hn_field_sdf(hand.handle, L.ptr(pts), n, None, None, 1, n, L.ptr(sdf), L.ptr(ws), ws.numel(), st())
+    assert rc < 0 and b'bt_inv' in lib.hn_last_error()          # a hand field needs its bone transforms
+    z = torch.zeros(4, 300, device='cuda')
+    out, inds = torch.empty(4, 16, device='cuda'), torch.empty(4, 16, dtype=torch.int64, device='cuda')
+    rc = lib.hn_upsample(L.ptr(z), L.ptr(z), 4, 300, 16, 64.0, L.ptr(out), L.ptr(inds), st())
+    assert rc < 0 and b'upsample' in lib.hn_last_error()        # k beyond the supported row length
+    with pytest.raises(RuntimeError, match='hn_upsample'):
+        L.check(rc, 'hn_upsample')
+    # empty inputs are a no-op, not an error
+    assert lib.hn_field_sdf(obj.handle, L.ptr(pts), 0, None, None, 1, 1, L.ptr(sdf), L.ptr(ws), ws.numel(), st()) == 0
+    assert lib.hn_merge(L.ptr(z), L.ptr(z), None, None, 0, 64, 16, 0, L.ptr(z), None, None, st()) == 0
+
+
+def test_full_size_frame_properties():
+    """BASELINE configs[1] at full size (512 x 512 rays x 64 samples, hand nets): size-independent properties.
+    One call over all rays == the same frame rendered in 8 chunks (bit for bit: no result may depend on how
+    samples are grouped into tiles or workgroups); culling on == off; outputs finite and in range."""
+    import bench
+    dev = torch.device('cuda')
+    ren, sdf, col, sc = bench.build_scene(dev, seed=9)
+    from honerf_amd import lib as Lm
+    lib = Lm.load()
+    B = bench.H_IMG * bench.W_IMG
+    rays_o, rays_d = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
+    Lm.check(lib.hn_ray_gen(Lm.ptr(sc['xy']), Lm.ptr(sc['R']), Lm.ptr(sc['T']), Lm.ptr(sc['focal']), Lm.ptr(sc['principal']),
+                            1, B, Lm.ptr(rays_o), Lm.ptr(rays_d), Lm.stream_ptr()), 'hn_ray_gen')
+
+    def render(lo, hi):
+        o = ren.render(rays_o[lo:hi], rays_d[lo:hi], bench.NEAR, bench.FAR, sc['bt_inv'], sc['T_pose'], None, None, None, 0,
+                       t_rand=sc['t_rand'][lo:hi])
+        return {k: o[k].clone() for k in ('color_fine', 'weight_sum', 'weight_max', 'cdf_fine')}
+
+    whole = render(0, B)
+    assert all(torch.isfinite(v).all() for v in whole.values())
+    assert float(whole['weight_sum'].min()) >= 0.0 and float(whole['weight_sum'].max()) <= 1.0 + 1e-4
+    assert float(whole['color_fine'].min()) >= 0.0 and float(whole['color_fine'].max()) <= 1.0 + 1e-4
+    step = B // 8 + 77                                             # ragged chunks, not multiples of the 128-sample tile
+    parts = [render(lo, min(lo + step, B)) for lo in range(0, B, step)]
+    for k in whole:
+        assert torch.equal(whole[k], torch.cat([p[k] for p in parts], 0)), 'chunked frame differs in %s' % k
+    ren.field().set_culling(True)
+    try:
+        culled = render(0, B)
+    finally:
+        ren.field().set_culling(False)
+    for k in whole:
+        assert torch.equal(whole[k], culled[k]), 'culled frame differs in %s' % k
