@@ -71,13 +71,24 @@ struct Bone2 {
     float v, r[3], hh;
 };
 // utils/fields.py:26-35: q = R_b p + t_b - T_b; v = |q|; r = q / v; h = 1 - sigmoid(200 (v - cutoff_b))
-__device__ __forceinline__ Bone2 bone_coords2(const float p[3], const float* __restrict__ M, const float* __restrict__ Tp,
-                                              int b) {
+// Element i of a read-only array.  UNI: the pointer is wave-uniform (all 64 samples belong to one frame, the usual
+// case) and the load goes through the constant address space, i.e. the scalar data cache: no vector-memory round trip
+// and no VGPRs for the 15 pose values a bone needs.
+typedef const float __attribute__((address_space(4))) cfloat_t;
+template <bool UNI>
+__device__ __forceinline__ float rd(const float* p, int i) {
+    if constexpr (UNI)
+        return ((cfloat_t*)p)[i];
+    else
+        return p[i];
+}
+template <bool UNI>
+__device__ __forceinline__ Bone2 bone_coords2(const float p[3], const float* M, const float* Tp, int b) {
     Bone2 o;
     const float* m = M + 16 * b;
-    const float q0 = m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3] - Tp[3 * b];
-    const float q1 = m[4] * p[0] + m[5] * p[1] + m[6] * p[2] + m[7] - Tp[3 * b + 1];
-    const float q2 = m[8] * p[0] + m[9] * p[1] + m[10] * p[2] + m[11] - Tp[3 * b + 2];
+    const float q0 = rd<UNI>(m, 0) * p[0] + rd<UNI>(m, 1) * p[1] + rd<UNI>(m, 2) * p[2] + rd<UNI>(m, 3) - rd<UNI>(Tp, 3 * b);
+    const float q1 = rd<UNI>(m, 4) * p[0] + rd<UNI>(m, 5) * p[1] + rd<UNI>(m, 6) * p[2] + rd<UNI>(m, 7) - rd<UNI>(Tp, 3 * b + 1);
+    const float q2 = rd<UNI>(m, 8) * p[0] + rd<UNI>(m, 9) * p[1] + rd<UNI>(m, 10) * p[2] + rd<UNI>(m, 11) - rd<UNI>(Tp, 3 * b + 2);
     o.v = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
     o.r[0] = q0 / o.v;   // no epsilon: a sample on a joint is NaN, as in the reference (SURVEY B-10)
     o.r[1] = q1 / o.v;
@@ -162,17 +173,17 @@ __device__ __forceinline__ void bone_jacobian(const f32x16& G0, const f32x16& G1
     Sv = fmaf(sum_own, kk, Sv);
 }
 // (Sv, Sr) of one bone -> d sdf / d p contribution: d/dq = Sv r + (Sr - (Sr.r) r) / v ; d/dp = R_b^T d/dq
-__device__ __forceinline__ void bone_to_p(float Sv, const float (&Sr)[3], const Bone2& q, const float* __restrict__ m,
-                                          float (&g)[3]) {
+template <bool UNI>
+__device__ __forceinline__ void bone_to_p(float Sv, const float (&Sr)[3], const Bone2& q, const float* m, float (&g)[3]) {
     const float sv = half_sum(Sv);
     const float sr0 = half_sum(Sr[0]), sr1 = half_sum(Sr[1]), sr2 = half_sum(Sr[2]);
     const float dot = sr0 * q.r[0] + sr1 * q.r[1] + sr2 * q.r[2];
     const float dq0 = sv * q.r[0] + (sr0 - dot * q.r[0]) / q.v;
     const float dq1 = sv * q.r[1] + (sr1 - dot * q.r[1]) / q.v;
     const float dq2 = sv * q.r[2] + (sr2 - dot * q.r[2]) / q.v;
-    g[0] += m[0] * dq0 + m[4] * dq1 + m[8] * dq2;
-    g[1] += m[1] * dq0 + m[5] * dq1 + m[9] * dq2;
-    g[2] += m[2] * dq0 + m[6] * dq1 + m[10] * dq2;
+    g[0] += rd<UNI>(m, 0) * dq0 + rd<UNI>(m, 4) * dq1 + rd<UNI>(m, 8) * dq2;
+    g[1] += rd<UNI>(m, 1) * dq0 + rd<UNI>(m, 5) * dq1 + rd<UNI>(m, 9) * dq2;
+    g[2] += rd<UNI>(m, 2) * dq0 + rd<UNI>(m, 6) * dq1 + rd<UNI>(m, 10) * dq2;
 }
 
 template <bool FULL>
@@ -205,6 +216,18 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         frame = frame < a.n_frames ? frame : a.n_frames - 1;
         const float* M = a.bt_inv + (size_t)frame * N_BONES * 16;
         const float* Tp = a.T_pose + (size_t)frame * N_BONES * 3;
+        // the usual case: the wave's 32 samples belong to one frame -> pose values through the scalar cache
+        const int frame0 = __builtin_amdgcn_readfirstlane(frame);
+        const bool uni = __ballot(frame != frame0) == 0ull;
+        const float* Mu = a.bt_inv + (size_t)frame0 * N_BONES * 16;
+        const float* Tu = a.T_pose + (size_t)frame0 * N_BONES * 3;
+        auto coords = [&](int b) { return uni ? bone_coords2<true>(p, Mu, Tu, b) : bone_coords2<false>(p, M, Tp, b); };
+        auto to_p = [&](float Sv, const float(&Sr)[3], const Bone2& bn, int b, float(&g)[3]) {
+            if (uni)
+                bone_to_p<true>(Sv, Sr, bn, Mu + 16 * b, g);
+            else
+                bone_to_p<false>(Sv, Sr, bn, M + 16 * b, g);
+        };
 
         // ---- F0: features of the 21 bones -> fragments in the stash -------------------------------------
         // nz bit b: some sample of this wave has a non-zero mask h for bone b.  Where none has, all 64
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         unsigned nz = 0;
 #pragma unroll 1
         for (int b = 0; b < N_BONES; ++b) {
-            const Bone2 bn = bone_coords2(p, M, Tp, b);
+            const Bone2 bn = coords(b);
             const bool any = __ballot(bn.hh != 0.f) != 0ull;
             if (any) {
                 nz |= 1u << b;
@@ -568,7 +591,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     mma_tile<16, 0, true>(ws, buf4, ah, al, G1[u], G2[u], lane);
                 });
                 if (live) {   // a bone whose mask is 0 for the whole wave contributes exactly 0
-                    const Bone2 bn = bone_coords2(p, M, Tp, b);
+                    const Bone2 bn = coords(b);
                     const float kk = -TAU2 * (1.f - bn.hh);
                     float own[4][8];
 #pragma unroll
@@ -580,7 +603,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     }
                     float Sv = 0.f, Sr[3] = {0.f, 0.f, 0.f};
                     bone_jacobian(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn, kk, h, Sv, Sr);
-                    bone_to_p(Sv, Sr, bn, M + 16 * b, g);
+                    to_p(Sv, Sr, bn, b, g);
                 }
                 b = nb;
             }
@@ -602,12 +625,12 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 constexpr int b = decltype(B_)::value;
                 if ((nz >> b) & 1u) {
                     const float Gv = b < 16 ? La[b] : Lb[b - 16];
-                    const Bone2 bn = bone_coords2(p, M, Tp, b);
+                    const Bone2 bn = coords(b);
                     const float kk = -TAU2 * (1.f - bn.hh);
                     const float own = (h ? bn.r[2] : bn.r[1]) * bn.hh;
                     float Sv = Gv * own * kk;
                     float Sr[3] = {0.f, h ? 0.f : Gv * bn.hh, h ? Gv * bn.hh : 0.f};
-                    bone_to_p(Sv, Sr, bn, M + 16 * b, g);
+                    to_p(Sv, Sr, bn, b, g);
                 }
             });
         }
