@@ -322,6 +322,15 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
 
 using namespace hn;
 
+namespace hn {
+namespace bwd {
+size_t field_bwd_workspace_bytes(const hn_field* f, int n);
+int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
+                   const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
+                   const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
+                   size_t workspace_bytes, hipStream_t s);
+}
+}
 extern "C" {
 
 int hn_version(void) { return HN_VERSION; }
@@ -337,8 +346,21 @@ int hn_field_destroy(hn_field* f) {
     if (f->blob != nullptr) (void)hipFree(f->blob);
     if (f->v2_full != nullptr) (void)hipFree(f->v2_full);
     if (f->v2_sdf != nullptr) (void)hipFree(f->v2_sdf);
+    if (f->raw != nullptr) (void)hipFree(f->raw);
     delete f;
     return HN_OK;
+}
+size_t hn_field_bwd_workspace_bytes(const hn_field* f, int n_pts) {
+    if (f == nullptr || n_pts <= 0) return 0;
+    return hn::bwd::field_bwd_workspace_bytes(f, n_pts);
+}
+int hn_field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray,
+                      const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf,
+                      const float* g_grad, const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv,
+                      float* g_T_pose, void* workspace, size_t workspace_bytes, hn_stream_t stream) {
+    return hn::bwd::field_eval_bwd(f, pts, rays_d, n_pts, samples_per_ray, bt_inv, T_pose, n_frames, pts_per_frame, g_sdf, g_grad,
+                                   g_rgb, g_pts, g_rays_d, g_bt_inv, g_T_pose, workspace, workspace_bytes,
+                                   reinterpret_cast<hipStream_t>(stream));
 }
 float hn_field_inv_s(const hn_field* f) { return f ? f->inv_s : 0.f; }
 int hn_field_set_culling(hn_field* f, int enabled) {

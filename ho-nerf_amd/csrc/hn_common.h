@@ -98,5 +98,12 @@ struct hn_field {
     size_t v2_full_bytes = 0;
     void* v2_sdf = nullptr;      // sdf forward only (sampling passes)
     size_t v2_sdf_bytes = 0;
+    // --- folded (weight-norm applied) weights and biases, row-major [out, in], for the adjoint (hn_field_bwd.hip)
+    void* raw = nullptr;
+    const float* raw_sdf_w[9] = {};
+    const float* raw_sdf_b[9] = {};
+    const float* raw_col_w[5] = {};
+    const float* raw_col_b[5] = {};
+    int sdf_out[9] = {}, sdf_in[9] = {}, col_out[5] = {}, col_in[5] = {};
     int cull_far_field = 0;      // hn_field_set_culling: skip the chunks of bones whose mask is 0 for a whole workgroup
 };

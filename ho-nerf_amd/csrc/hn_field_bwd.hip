@@ -1,0 +1,433 @@
+// Adjoint of hn_field_eval: d loss / d (pts, rays_d, bt_inv, T_pose) from d loss / d (sdf, grad, rgb).
+//
+// The reference gets this from autograd through the two networks including the second-order path through
+// `.gradient()` (utils/fields.py:165-177, 336-347 with create_graph=True; consumed by fitting_single.py:289-291,
+// fitting_video.py:340-342).  Here the backward pass is the explicit sequence of sweeps specified and checked against
+// autograd in oracle/field_bwd.py (steps 1-6 there), run as a sequence of launches over row-major [n, width] fp32
+// arrays in the caller's workspace:
+//   * k_dense: C (+)= alpha * A[n,K] * op(W) (+ bias) on v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulate),
+//     64 x 64 output tile per workgroup, operands staged through LDS; W is addressed with two strides so that W, W^T
+//     and column blocks of W (the skip / colour-input blocks) need no copies;
+//   * element-wise kernels for the softplus tape and the products between the sweeps;
+//   * the input maps (object: [p, enc10(p)]; hand: the 21-bone encoding) with their Jacobian, transposed Jacobian and
+//     second-order terms.
+// This first version favours being checkable step by step over speed: the fitting configurations evaluate ~4e4 samples
+// per step, where the whole adjoint is a few milliseconds.
+#include "hn_common.h"
+
+namespace hn {
+namespace bwd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr float BETA = 100.f;
+
+// ---- C[n,M] (+)= alpha * A[n,K] * B (+ bias),  B(k, col) = W[k * wsk + col * wsc] --------------------------------
+struct DenseArgs {
+    const float* A;
+    int lda;
+    const float* W;
+    int wsk, wsc;
+    const float* bias;
+    float* C;
+    int ldc;
+    int n, K, M;
+    float alpha;
+    int accumulate;
+};
+__global__ __launch_bounds__(256) void k_dense(const DenseArgs a) {
+    __shared__ float As[64][33];
+    __shared__ float Bs[32][65];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, j = lane & 31;
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k0 = 0; k0 < a.K; k0 += 32) {
+        {
+            const int r = t >> 2, c8 = (t & 3) * 8;
+            const int row = row0 + r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + c8 + e;
+                As[r][c8 + e] = (row < a.n && k < a.K) ? a.A[(size_t)row * a.lda + k] : 0.f;
+            }
+        }
+        {
+            const int kk = t >> 3, c8 = (t & 7) * 8;
+            const int k = k0 + kk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int col = col0 + c8 + e;
+                Bs[kk][c8 + e] = (k < a.K && col < a.M) ? a.W[(size_t)k * a.wsk + (size_t)col * a.wsc] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[wr * 32 + j][2 * ks + h], Bs[2 * ks + h][wc * 32 + j], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int col = col0 + wc * 32 + j;
+    if (col < a.M) {
+        const float b = a.bias != nullptr ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < a.n) {
+                float v = a.alpha * acc[r] + b;
+                float* c = a.C + (size_t)row * a.ldc + col;
+                if (a.accumulate) v += *c;
+                *c = v;
+            }
+        }
+    }
+}
+
+// ---- element-wise --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus(float z) {   // nn.Softplus(beta=100, threshold=20)
+    return BETA * z > 20.f ? z : log1pf(expf(BETA * z)) / BETA;
+}
+__device__ __forceinline__ float sig_from_act(float a) { return 1.f - expf(-BETA * a); }   // sigma'(z) from a = softplus(z)
+
+__global__ void k_softplus(float* __restrict__ z, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) z[i] = softplus(z[i]);
+}
+__global__ void k_bcast_row(const float* __restrict__ w, int width, float scale, float* __restrict__ out, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = w[i % width] * scale;
+}
+// dz = sigma'(z) * u
+__global__ void k_dz(const float* __restrict__ act, const float* __restrict__ u, float* __restrict__ dz, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) dz[i] = sig_from_act(act[i]) * u[i];
+}
+// forward-direction sweep: sb = u * dzb (kept), v = sigma' * dzb (input of the next product; may alias dzb)
+__global__ void k_fwd_dir(const float* __restrict__ act, const float* __restrict__ u, const float* __restrict__ dzb,
+                          float* __restrict__ sb, float* __restrict__ v, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float d = dzb[i];
+        sb[i] = u[i] * d;
+        if (v != nullptr) v[i] = sig_from_act(act[i]) * d;
+    }
+}
+// zb = sigma' * ab + sigma'' * sb
+__global__ void k_zb(const float* __restrict__ act, const float* __restrict__ ab, const float* __restrict__ sb,
+                     float* __restrict__ zb, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float s = sig_from_act(act[i]);
+        zb[i] = s * ab[i] + BETA * s * (1.f - s) * sb[i];
+    }
+}
+__global__ void k_relu(float* __restrict__ x, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) x[i] = fmaxf(x[i], 0.f);
+}
+__global__ void k_relu_mask(const float* __restrict__ act, float* __restrict__ xb, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) xb[i] = act[i] > 0.f ? xb[i] : 0.f;
+}
+// rgb = sigmoid(zc); xb = g_rgb * rgb (1 - rgb)
+__global__ void k_rgb_seed(const float* __restrict__ zc, const float* __restrict__ g_rgb, float* __restrict__ xb, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float r = 1.f / (1.f + expf(-zc[i]));
+        xb[i] = g_rgb[i] * r * (1.f - r);
+    }
+}
+// z8 adjoint: [g_sdf / scale, fb]  (row width 257)
+__global__ void k_z8_bar(const float* __restrict__ g_sdf, float inv_scale, float* __restrict__ z8b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z8b[(size_t)i * 257] = g_sdf[i] * inv_scale;
+}
+
+// ---- [x, enc_L(x)] of a 3-vector: features, J^T, J, second derivative ------------------------------------------
+// layout: x (3), then per channel c: sin(2^k x_c) k<L, cos(2^k x_c) k<L
+template <int L>
+__global__ void k_enc3(const float* __restrict__ x, int n, int rep, float* __restrict__ out, int ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* xi = x + 3 * (size_t)(i / rep);
+    float* o = out + (size_t)i * ld;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = xi[c];
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            float s, co;
+            sincosf(xi[c] * (float)(1 << k), &s, &co);
+            o[3 + c * 2 * L + k] = s;
+            o[3 + c * 2 * L + L + k] = co;
+        }
+    }
+}
+// out[i] (+)= J^T fbar [+ second-order term sum_f GX_f d2X_f gbar_c];  fbar row width ld
+template <int L>
+__global__ void k_enc3_pull(const float* __restrict__ x, int n, int rep, const float* __restrict__ fbar, int ld,
+                            const float* __restrict__ GX, int ldg, const float* __restrict__ gbar, float* __restrict__ out,
+                            int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* xi = x + 3 * (size_t)(i / rep);
+    const float* fb = fbar + (size_t)i * ld;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float acc = fb[c];
+        float sec = 0.f;
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            const float f = (float)(1 << k);
+            float s, co;
+            sincosf(xi[c] * f, &s, &co);
+            acc += f * co * fb[3 + c * 2 * L + k] - f * s * fb[3 + c * 2 * L + L + k];
+            if (GX != nullptr) {
+                const float* gx = GX + (size_t)i * ldg;
+                sec += -f * f * (s * gx[3 + c * 2 * L + k] + co * gx[3 + c * 2 * L + L + k]);
+            }
+        }
+        if (GX != nullptr) acc += sec * gbar[3 * (size_t)i + c];
+        float* o = out + 3 * (size_t)i + c;
+        *o = accumulate ? *o + acc : acc;
+    }
+}
+// J gbar -> [n, 3 + 6L]
+template <int L>
+__global__ void k_enc3_push(const float* __restrict__ x, int n, const float* __restrict__ gbar, float* __restrict__ out, int ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* xi = x + 3 * (size_t)i;
+    float* o = out + (size_t)i * ld;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float gb = gbar[3 * (size_t)i + c];
+        o[c] = gb;
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            const float f = (float)(1 << k);
+            float s, co;
+            sincosf(xi[c] * f, &s, &co);
+            o[3 + c * 2 * L + k] = f * co * gb;
+            o[3 + c * 2 * L + L + k] = -f * s * gb;
+        }
+    }
+}
+__global__ void k_add3(const float* __restrict__ a, float* __restrict__ b, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) b[i] += a[i];
+}
+// per-ray sum of per-sample direction gradients
+__global__ void k_sum_rays(const float* __restrict__ per_sample, int n_rays, int spr, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays * 3) return;
+    const int ray = i / 3, c = i % 3;
+    float s = 0.f;
+    for (int k = 0; k < spr; ++k) s += per_sample[3 * ((size_t)ray * spr + k) + c];
+    out[i] = s;
+}
+
+// ---- orchestration ---------------------------------------------------------------------------------------------
+struct Arena {
+    char* base;
+    size_t used, cap;
+    float* take(size_t floats) {
+        const size_t bytes = (floats * sizeof(float) + 255) & ~size_t(255);
+        float* p = base ? reinterpret_cast<float*>(base + used) : nullptr;
+        used += bytes;
+        return p;
+    }
+};
+static inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+struct Ctx {
+    hipStream_t s;
+    int n;
+    void dense(const float* A, int lda, int K, const float* W, int wsk, int wsc, int M, const float* bias, float alpha,
+               float* C, int ldc, bool accumulate) const {
+        DenseArgs a{A, lda, W, wsk, wsc, bias, C, ldc, n, K, M, alpha, accumulate ? 1 : 0};
+        hipLaunchKernelGGL(k_dense, dim3((M + 63) / 64, (n + 63) / 64), dim3(256), 0, s, a);
+    }
+    // C = A * W[:, c0:c0+K]^T  (W row-major [M, ldw])          "forward" use of a weight block
+    void nt(const float* A, int lda, int K, const float* W, int ldw, int c0, int M, const float* bias, float alpha, float* C,
+            int ldc, bool acc) const {
+        dense(A, lda, K, W + c0, 1, ldw, M, bias, alpha, C, ldc, acc);
+    }
+    // C = A * W[:, c0:c0+M]      (A [n, rows of W])            "transposed" use of the same block
+    void nn(const float* A, int lda, int K, const float* W, int ldw, int c0, int M, float alpha, float* C, int ldc, bool acc) const {
+        dense(A, lda, K, W + c0, ldw, 1, M, nullptr, alpha, C, ldc, acc);
+    }
+};
+
+size_t field_bwd_workspace(const hn_field* f, int n, Arena* out_layout);
+
+// Buffers of one adjoint evaluation (all [n, width] row-major)
+struct Bufs {
+    float *X, *a[9], *u[8], *dz[8], *z8, *GX, *g, *din, *gin, *c[5], *xb, *cb[2], *Xb, *db, *gbin, *gb, *GXb, *dzb, *v, *sb[8], *ab,
+        *zb, *gdir, *z8b;
+};
+static void layout(const hn_field* f, int n, Arena& ar, Bufs& b) {
+    const bool obj = f->kind == HN_FIELD_OBJ;
+    const size_t N = (size_t)n;
+    const int Din = obj ? OBJ_IN : HAND_IN;
+    b.X = ar.take(N * Din);
+    for (int l = 1; l <= 8; ++l) b.a[l] = ar.take(N * f->sdf_out[l - 1]);
+    for (int l = 0; l < 8; ++l) {
+        b.u[l] = ar.take(N * f->sdf_out[l]);
+        b.dz[l] = ar.take(N * f->sdf_out[l]);
+        b.sb[l] = ar.take(N * f->sdf_out[l]);
+    }
+    b.z8 = ar.take(N * 257);
+    b.z8b = ar.take(N * 257);
+    b.GX = ar.take(N * Din);
+    b.GXb = ar.take(N * Din);
+    b.Xb = ar.take(N * Din);
+    b.g = ar.take(N * 3);
+    b.gb = ar.take(N * 3);
+    b.gdir = ar.take(N * 3);
+    b.din = ar.take(N * 27);
+    b.gin = ar.take(N * 27);
+    b.db = ar.take(N * 27);
+    b.gbin = ar.take(N * 27);
+    for (int l = 1; l <= 4; ++l) b.c[l] = ar.take(N * H);
+    b.xb = ar.take(N * 3);
+    b.cb[0] = ar.take(N * H);
+    b.cb[1] = ar.take(N * H);
+    b.dzb = ar.take(N * H);
+    b.v = ar.take(N * H);
+    b.ab = ar.take(N * H);
+    b.zb = ar.take(N * H);
+}
+
+size_t field_bwd_workspace_bytes(const hn_field* f, int n) {
+    Arena ar{nullptr, 0, 0};
+    Bufs b;
+    layout(f, n, ar, b);
+    return ar.used;
+}
+
+int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
+                   const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
+                   const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
+                   size_t workspace_bytes, hipStream_t s) {
+    HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");
+    HN_REQUIRE(f->kind == HN_FIELD_OBJ, "hn_field_eval_bwd: the hand field's adjoint is not built yet");
+    HN_REQUIRE(pts && g_sdf && g_grad && g_rgb && g_pts && spr >= 1 && n % spr == 0, "bad arguments");
+    if (n == 0) return HN_OK;
+    Arena ar{reinterpret_cast<char*>(workspace), 0, workspace_bytes};
+    Bufs b;
+    layout(f, n, ar, b);
+    if (workspace == nullptr || ar.used > workspace_bytes) {
+        set_error("adjoint workspace too small: %zu < %zu", workspace_bytes, ar.used);
+        return HN_ENOMEM;
+    }
+    const Ctx cx{s, n};
+    const size_t N = (size_t)n;
+    const int Din = OBJ_IN;
+    const float rs2 = 0.70710678118654752f;
+    const float inv_scale = 1.f / f->scale;
+    const float* const* W = f->raw_sdf_w;
+    const float* const* Bv = f->raw_sdf_b;
+    const int H4 = f->sdf_in[4] - Din;   // hidden columns of lin4's input (193)
+    auto width = [&](int l) { return f->sdf_out[l]; };
+
+    // 1. forward tape -------------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(k_enc3<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.X, Din);
+    b.a[0] = b.X;
+    for (int l = 0; l < 8; ++l) {
+        if (l == 4) {
+            cx.nt(b.a[4], H4, H4, W[4], f->sdf_in[4], 0, width(4), Bv[4], rs2, b.a[5], width(4), false);
+            cx.nt(b.X, Din, Din, W[4], f->sdf_in[4], H4, width(4), nullptr, rs2, b.a[5], width(4), true);
+        } else {
+            const int K = l == 0 ? Din : f->sdf_in[l];
+            cx.nt(b.a[l], K, K, W[l], f->sdf_in[l], 0, width(l), Bv[l], 1.f, b.a[l + 1], width(l), false);
+        }
+        hipLaunchKernelGGL(k_softplus, g1(N * width(l)), dim3(256), 0, s, b.a[l + 1], N * width(l));
+    }
+    cx.nt(b.a[8], H, H, W[8], H, 0, 257, Bv[8], 1.f, b.z8, 257, false);
+    // 2. reverse sweep ------------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(k_bcast_row, g1(N * H), dim3(256), 0, s, W[8], H, inv_scale, b.u[7], N * H);
+    for (int l = 7; l >= 0; --l) {
+        hipLaunchKernelGGL(k_dz, g1(N * width(l)), dim3(256), 0, s, b.a[l + 1], b.u[l], b.dz[l], N * width(l));
+        if (l > 0) {   // u_{l-1} = dz_l * Wh_l
+            if (l == 4)
+                cx.nn(b.dz[4], width(4), width(4), W[4], f->sdf_in[4], 0, H4, rs2, b.u[3], H4, false);
+            else
+                cx.nn(b.dz[l], width(l), width(l), W[l], f->sdf_in[l], 0, f->sdf_in[l], 1.f, b.u[l - 1], f->sdf_in[l], false);
+        }
+    }
+    cx.nn(b.dz[0], H, H, W[0], Din, 0, Din, 1.f, b.GX, Din, false);
+    cx.nn(b.dz[4], H, H, W[4], f->sdf_in[4], H4, Din, rs2, b.GX, Din, true);
+    hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.GX, Din, nullptr, 0, nullptr, b.g, 0);
+    // 3. colour network forward + backward ------------------------------------------------------------------------
+    const float* const* C = f->raw_col_w;
+    const float* const* Cb = f->raw_col_b;
+    const int cin = f->col_in[0];                                  // 373 = 63 | 27 | 256 | 27
+    hipLaunchKernelGGL(k_enc3<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, rays_d, n, spr, b.din, 27);
+    hipLaunchKernelGGL(k_enc3<4>, g1(n), dim3(256), 0, s, b.g, n, 1, b.gin, 27);
+    cx.nt(b.X, Din, Din, C[0], cin, 0, H, Cb[0], 1.f, b.c[1], H, false);
+    cx.nt(b.din, 27, 27, C[0], cin, Din, H, nullptr, 1.f, b.c[1], H, true);
+    cx.nt(b.z8 + 1, 257, H, C[0], cin, Din + 27, H, nullptr, 1.f, b.c[1], H, true);
+    cx.nt(b.gin, 27, 27, C[0], cin, Din + 27 + H, H, nullptr, 1.f, b.c[1], H, true);
+    hipLaunchKernelGGL(k_relu, g1(N * H), dim3(256), 0, s, b.c[1], N * H);
+    for (int l = 1; l <= 3; ++l) {
+        cx.nt(b.c[l], H, H, C[l], H, 0, H, Cb[l], 1.f, b.c[l + 1], H, false);
+        hipLaunchKernelGGL(k_relu, g1(N * H), dim3(256), 0, s, b.c[l + 1], N * H);
+    }
+    cx.nt(b.c[4], H, H, C[4], H, 0, 3, Cb[4], 1.f, b.xb, 3, false);
+    hipLaunchKernelGGL(k_rgb_seed, g1(N * 3), dim3(256), 0, s, b.xb, g_rgb, b.xb, N * 3);
+    cx.nn(b.xb, 3, 3, C[4], H, 0, H, 1.f, b.cb[0], H, false);
+    hipLaunchKernelGGL(k_relu_mask, g1(N * H), dim3(256), 0, s, b.c[4], b.cb[0], N * H);
+    int cur = 0;
+    for (int l = 3; l >= 1; --l) {
+        cx.nn(b.cb[cur], H, H, C[l], H, 0, H, 1.f, b.cb[cur ^ 1], H, false);
+        cur ^= 1;
+        hipLaunchKernelGGL(k_relu_mask, g1(N * H), dim3(256), 0, s, b.c[l], b.cb[cur], N * H);
+    }
+    const float* cb1 = b.cb[cur];
+    cx.nn(cb1, H, H, C[0], cin, 0, Din, 1.f, b.Xb, Din, false);                    // Xb starts as the colour net's share
+    cx.nn(cb1, H, H, C[0], cin, Din, 27, 1.f, b.db, 27, false);
+    hipLaunchKernelGGL(k_z8_bar, g1(n), dim3(256), 0, s, g_sdf, inv_scale, b.z8b, n);
+    cx.nn(cb1, H, H, C[0], cin, Din + 27, H, 1.f, b.z8b + 1, 257, false);         // fb
+    cx.nn(cb1, H, H, C[0], cin, Din + 27 + H, 27, 1.f, b.gbin, 27, false);
+    hipLaunchKernelGGL(k_enc3_pull<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, rays_d, n, spr, b.db, 27, nullptr, 0, nullptr, b.gdir, 0);
+    if (g_rays_d != nullptr) hipLaunchKernelGGL(k_sum_rays, g1((size_t)(n / spr) * 3), dim3(256), 0, s, b.gdir, n / spr, spr, g_rays_d);
+    hipLaunchKernelGGL(k_enc3_pull<4>, g1(n), dim3(256), 0, s, b.g, n, 1, b.gbin, 27, nullptr, 0, nullptr, b.gb, 0);
+    hipLaunchKernelGGL(k_add3, g1(N * 3), dim3(256), 0, s, g_grad, b.gb, N * 3);
+    // 4. adjoint of the reverse sweep ---------------------------------------------------------------------------
+    hipLaunchKernelGGL(k_enc3_push<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, b.gb, b.GXb, Din);
+    cx.nt(b.GXb, Din, Din, W[0], Din, 0, H, nullptr, 1.f, b.dzb, H, false);
+    for (int l = 1; l <= 7; ++l) {
+        const int wprev = width(l - 1);
+        hipLaunchKernelGGL(k_fwd_dir, g1(N * wprev), dim3(256), 0, s, b.a[l], b.u[l - 1], b.dzb, b.sb[l - 1], b.v, N * wprev);
+        if (l == 4) {
+            cx.nt(b.v, H4, H4, W[4], f->sdf_in[4], 0, H, nullptr, rs2, b.dzb, H, false);
+            cx.nt(b.GXb, Din, Din, W[4], f->sdf_in[4], H4, H, nullptr, rs2, b.dzb, H, true);
+        } else {
+            cx.nt(b.v, wprev, wprev, W[l], f->sdf_in[l], 0, width(l), nullptr, 1.f, b.dzb, width(l), false);
+        }
+    }
+    hipLaunchKernelGGL(k_fwd_dir, g1(N * H), dim3(256), 0, s, b.a[8], b.u[7], b.dzb, b.sb[7], (float*)nullptr, N * H);
+    // 5. first-order reverse sweep with the second-order sources ---------------------------------------------------
+    cx.nn(b.z8b, 257, 257, W[8], H, 0, H, 1.f, b.ab, H, false);
+    for (int l = 7; l >= 0; --l) {
+        hipLaunchKernelGGL(k_zb, g1(N * width(l)), dim3(256), 0, s, b.a[l + 1], b.ab, b.sb[l], b.zb, N * width(l));
+        if (l == 4) {
+            cx.nn(b.zb, H, H, W[4], f->sdf_in[4], H4, Din, rs2, b.Xb, Din, true);
+            cx.nn(b.zb, H, H, W[4], f->sdf_in[4], 0, H4, rs2, b.ab, H4, false);
+        } else if (l == 0) {
+            cx.nn(b.zb, H, H, W[0], Din, 0, Din, 1.f, b.Xb, Din, true);
+        } else {
+            cx.nn(b.zb, width(l), width(l), W[l], f->sdf_in[l], 0, f->sdf_in[l], 1.f, b.ab, f->sdf_in[l], false);
+        }
+    }
+    // 6. input map: g_pts = J^T Xb + second-order term ------------------------------------------------------------
+    hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.Xb, Din, b.GX, Din, b.gb, g_pts, 0);
+    HN_LAUNCH_CHECK();
+    (void)bt_inv; (void)T_pose; (void)n_frames; (void)pts_per_frame; (void)g_bt_inv; (void)g_T_pose;
+    return HN_OK;
+}
+
+}  // namespace bwd
+}  // namespace hn

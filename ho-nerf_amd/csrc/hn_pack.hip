@@ -371,12 +371,47 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
             rc = HN_EHIP;
         }
     }
+    if (rc == HN_OK) {   // keep the folded matrices and biases (row-major) for the adjoint path
+        size_t total = 0;
+        auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
+        for (int l = 0; l < 9; ++l) total += pad((size_t)sdf->out_dim[l] * sdf->in_dim[l]) + pad(sdf->out_dim[l]);
+        for (int l = 0; l < 5; ++l) total += pad((size_t)col->out_dim[l] * col->in_dim[l]) + pad(col->out_dim[l]);
+        if (hipMalloc(&f->raw, total * sizeof(float)) != hipSuccess) {
+            set_error("hipMalloc of %zu bytes for the folded weights failed", total * sizeof(float));
+            rc = HN_ENOMEM;
+        } else {
+            float* q = reinterpret_cast<float*>(f->raw);
+            auto keep = [&](const float* src, size_t n) {
+                const float* dst = q;
+                (void)hipMemcpyAsync(q, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream);
+                q += pad(n);
+                return dst;
+            };
+            for (int l = 0; l < 9; ++l) {
+                f->sdf_out[l] = sdf->out_dim[l];
+                f->sdf_in[l] = sdf->in_dim[l];
+                f->raw_sdf_w[l] = keep(w_sdf[l], (size_t)sdf->out_dim[l] * sdf->in_dim[l]);
+                f->raw_sdf_b[l] = keep(reinterpret_cast<const float*>(sdf->bias[l]), sdf->out_dim[l]);
+            }
+            for (int l = 0; l < 5; ++l) {
+                f->col_out[l] = col->out_dim[l];
+                f->col_in[l] = col->in_dim[l];
+                f->raw_col_w[l] = keep(w_col[l], (size_t)col->out_dim[l] * col->in_dim[l]);
+                f->raw_col_b[l] = keep(reinterpret_cast<const float*>(col->bias[l]), col->out_dim[l]);
+            }
+            if (hipStreamSynchronize(stream) != hipSuccess) {
+                set_error("copying the folded weights failed");
+                rc = HN_EHIP;
+            }
+        }
+    }
     if (rc == HN_OK && precision == HN_PREC_F16X3) rc = v2::build_v2_streams(f, sdf, col, w_sdf, w_col, stream);
     pk.free_temps();
     if (rc != HN_OK) {
         if (f->v2_full) (void)hipFree(f->v2_full);
         if (f->v2_sdf) (void)hipFree(f->v2_sdf);
         if (f->blob) (void)hipFree(f->blob);
+        if (f->raw) (void)hipFree(f->raw);
         delete f;
         return rc;
     }

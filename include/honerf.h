@@ -184,6 +184,17 @@ int hn_composite2(const float* alpha_h, const float* rgb_h, const float* grad_h,
                   const float* rgb_o, const float* grad_o, int n_rays, int S, float* color, float* weight_sum,
                   float* w_hand, float* w_obj, float* eik_sum, hn_stream_t stream);
 
+/* Adjoint of hn_field_eval (what autograd runs through the two networks in the reference, including the second-order
+ * path through `.gradient()`: utils/fields.py:165-177, 336-347 with create_graph=True; fitting_single.py:289-291).
+ * g_sdf [n], g_grad [n,3], g_rgb [n,3] -> g_pts [n,3], g_rays_d [n/samples_per_ray,3] (may be NULL), and for hand
+ * fields g_bt_inv [n_frames,21,4,4], g_T_pose [n_frames,21,3] (may be NULL).  The sweeps are specified in
+ * oracle/field_bwd.py.  Round 1: object fields (HN_EINVAL for a hand field).  Workspace: hn_field_bwd_workspace_bytes. */
+size_t hn_field_bwd_workspace_bytes(const hn_field* f, int n_pts);
+int hn_field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray,
+                      const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf,
+                      const float* g_grad, const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv,
+                      float* g_T_pose, void* workspace, size_t workspace_bytes, hn_stream_t stream);
+
 /* ---- adjoints of the two stages above (pose fitting back-propagates through them:
  * fitting_single.py:289-291, fitting_video.py:340-342).  Depths / dists carry no gradient (sampled under
  * no_grad, utils/renderer.py:215, 461).

@@ -676,3 +676,40 @@ def test_full_size_frame_properties():
         ren.field().set_culling(False)
     for k in whole:
         assert torch.equal(whole[k], culled[k]), 'culled frame differs in %s' % k
+
+
+# ---------------------------------------------------------------------------------------------
+def _field_adjoint_gpu(L, field, pts, dirs, spr, gs, gg, gr, bt=None, tp=None):
+    lib = L.load()
+    n = pts.shape[0]
+    g_pts = torch.empty(n, 3, device='cuda')
+    g_dirs = torch.empty(n // spr, 3, device='cuda')
+    nf = 1 if bt is None else bt.shape[0]
+    g_bt = torch.zeros(nf, 21, 4, 4, device='cuda') if bt is not None else None
+    g_tp = torch.zeros(nf, 21, 3, device='cuda') if bt is not None else None
+    need = lib.hn_field_bwd_workspace_bytes(field.handle, n)
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    L.check(lib.hn_field_eval_bwd(field.handle, L.ptr(cu(pts)), L.ptr(cu(dirs)), n, spr, L.ptr(cu(bt)) if bt is not None else None,
+                                  L.ptr(cu(tp)) if tp is not None else None, nf, n // nf, L.ptr(cu(gs)), L.ptr(cu(gg)), L.ptr(cu(gr)),
+                                  L.ptr(g_pts), L.ptr(g_dirs), L.ptr(g_bt) if g_bt is not None else None,
+                                  L.ptr(g_tp) if g_tp is not None else None, L.ptr(ws), need, st()), 'hn_field_eval_bwd')
+    return g_pts, g_dirs, g_bt, g_tp
+
+
+def test_obj_field_adjoint(L):
+    """hn_field_eval_bwd (object field) against the hand-written adjoint of the oracle (oracle/field_bwd.py, itself
+    checked against autograd in tests/test_field_adjoint_spec.py): d/d pts incl. the second-order path, d/d rays_d."""
+    from oracle.field_bwd import field_adjoint
+    _, obj = packed_fields('cuda', 'f16x3')
+    _, obj64 = oracle_fields_fp64()
+    gen = torch.Generator().manual_seed(2)
+    spr, rays = 8, 37
+    n = spr * rays
+    pts = (torch.rand(n, 3, generator=gen) - 0.5) * 0.9
+    d = torch.nn.functional.normalize(torch.randn(rays, 3, generator=gen), dim=-1)
+    gs, gg, gr = torch.randn(n, 1, generator=gen), torch.randn(n, 3, generator=gen), torch.randn(n, 3, generator=gen)
+    dirs = d[:, None, :].expand(rays, spr, 3).reshape(n, 3)
+    ref = field_adjoint(obj64, pts.double(), dirs.double(), gs.double(), gg.double(), gr.double())
+    g_pts, g_dirs, _, _ = _field_adjoint_gpu(L, obj, pts, d, spr, gs, gg, gr)
+    assert_close(g_pts, ref['g_pts'].float(), 2e-4, 'd/d pts')
+    assert_close(g_dirs, ref['g_dirs'].reshape(rays, spr, 3).sum(1).float(), 2e-4, 'd/d rays_d')
