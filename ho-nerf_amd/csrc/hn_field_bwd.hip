@@ -228,6 +228,197 @@ __global__ void k_sum_rays(const float* __restrict__ per_sample, int n_rays, int
     out[i] = s;
 }
 
+
+// ---- hand input map (utils/fields.py:22-36, 134-147) ---------------------------------------------------------------
+// Per bone b: q = R_b p + t_b - T_b, v = |q|, r = q / v, h = 1 - sigmoid(200 (v - cutoff_b)); 66 features
+// [v, sin(2^k v) k<10, cos(2^k v) k<10, r (3), per c: sin(2^k r_c) k<7, cos(2^k r_c) k<7] * h.
+// A feature is phi(y) h(v) with y one of (v, r_0, r_1, r_2); for a weight row G the bone's scalar function
+// F(q) = sum_f G_f F_f(q) has  grad F = Sv r + sum_i Sr_i (e_i - r_i r) / v  with
+//   S0_a = sum_{f on argument a} G phi,  S1_a = sum G phi',  S2_a = sum G phi'',  tot = sum_a S0_a,
+//   Sv = h S1_v + h' tot,  Sr_i = h S1_{r_i}            (oracle/field_bwd.py, _HandInput)
+__constant__ float c_cut[N_BONES] = {0.08f, 0.03f, 0.03f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f,
+                                     0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f};
+constexpr float TAU = 200.f;
+struct BoneQ {
+    float v, r[3], h, h1, h2;
+};
+__device__ __forceinline__ BoneQ bone_q(const float p[3], const float* __restrict__ m, const float* __restrict__ T, int b) {
+    BoneQ o;
+    const float q0 = m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3] - T[0];
+    const float q1 = m[4] * p[0] + m[5] * p[1] + m[6] * p[2] + m[7] - T[1];
+    const float q2 = m[8] * p[0] + m[9] * p[1] + m[10] * p[2] + m[11] - T[2];
+    o.v = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+    o.r[0] = q0 / o.v;
+    o.r[1] = q1 / o.v;
+    o.r[2] = q2 / o.v;
+    const float sg = 1.f / (1.f + expf(-TAU * (o.v - c_cut[b])));
+    o.h = 1.f - sg;
+    o.h1 = -TAU * sg * (1.f - sg);
+    o.h2 = -TAU * TAU * sg * (1.f - sg) * (1.f - 2.f * sg);
+    return o;
+}
+// visits the 66 features of a bone in the reference's order: fn(f, argument a in 0..3, phi, phi', phi'')
+template <typename Fn>
+__device__ __forceinline__ void bone_features(const BoneQ& q, Fn&& fn) {
+    fn(0, 0, q.v, 1.f, 0.f);
+    for (int k = 0; k < 10; ++k) {
+        const float f = (float)(1 << k);
+        float s, c;
+        sincosf(q.v * f, &s, &c);
+        fn(1 + k, 0, s, f * c, -f * f * s);
+        fn(11 + k, 0, c, -f * s, -f * f * c);
+    }
+    for (int i = 0; i < 3; ++i) fn(21 + i, 1 + i, q.r[i], 1.f, 0.f);
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 7; ++k) {
+            const float f = (float)(1 << k);
+            float s, c;
+            sincosf(q.r[i] * f, &s, &c);
+            fn(24 + i * 14 + k, 1 + i, s, f * c, -f * f * s);
+            fn(24 + i * 14 + 7 + k, 1 + i, c, -f * s, -f * f * c);
+        }
+}
+struct FrameRef {
+    const float* M;   // [21,4,4]
+    const float* T;   // [21,3]
+    int frame;
+};
+__device__ __forceinline__ FrameRef frame_of(int i, int ppf, int nf, const float* bt_inv, const float* T_pose) {
+    int fr = i / ppf;
+    fr = fr < nf ? fr : nf - 1;
+    return {bt_inv + (size_t)fr * N_BONES * 16, T_pose + (size_t)fr * N_BONES * 3, fr};
+}
+
+__global__ void k_hand_feat(const float* __restrict__ pts, int n, int ppf, int nf, const float* __restrict__ bt_inv,
+                            const float* __restrict__ T_pose, float* __restrict__ X) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+    const FrameRef fr = frame_of(i, ppf, nf, bt_inv, T_pose);
+    for (int b = 0; b < N_BONES; ++b) {
+        const BoneQ q = bone_q(p, fr.M + 16 * b, fr.T + 3 * b, b);
+        float* o = X + (size_t)i * HAND_IN + b * 66;
+        bone_features(q, [&](int f, int, float phi, float, float) { o[f] = phi * q.h; });
+    }
+}
+// J gbar: directional derivative of every feature along dq = R_b gbar
+__global__ void k_hand_push(const float* __restrict__ pts, int n, int ppf, int nf, const float* __restrict__ bt_inv,
+                            const float* __restrict__ T_pose, const float* __restrict__ gbar, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+    const float gb[3] = {gbar[3 * (size_t)i], gbar[3 * (size_t)i + 1], gbar[3 * (size_t)i + 2]};
+    const FrameRef fr = frame_of(i, ppf, nf, bt_inv, T_pose);
+    for (int b = 0; b < N_BONES; ++b) {
+        const float* m = fr.M + 16 * b;
+        const BoneQ q = bone_q(p, m, fr.T + 3 * b, b);
+        const float w[3] = {m[0] * gb[0] + m[1] * gb[1] + m[2] * gb[2], m[4] * gb[0] + m[5] * gb[1] + m[6] * gb[2],
+                            m[8] * gb[0] + m[9] * gb[1] + m[10] * gb[2]};
+        const float rw = q.r[0] * w[0] + q.r[1] * w[1] + q.r[2] * w[2];
+        const float dy[4] = {rw, (w[0] - q.r[0] * rw) / q.v, (w[1] - q.r[1] * rw) / q.v, (w[2] - q.r[2] * rw) / q.v};
+        float* o = out + (size_t)i * HAND_IN + b * 66;
+        bone_features(q, [&](int f, int a, float phi, float phi1, float) { o[f] = phi1 * q.h * dy[a] + phi * q.h1 * rw; });
+    }
+}
+// adjoint of q = R p + t - T for one (sample, bone): g_pts, and the pose gradients by atomics
+__device__ __forceinline__ void spread(const float qb[3], const float p[3], const float* __restrict__ m, int frame, int b,
+                                       float (&gp)[3], float* __restrict__ g_bt, float* __restrict__ g_T) {
+    gp[0] += m[0] * qb[0] + m[4] * qb[1] + m[8] * qb[2];
+    gp[1] += m[1] * qb[0] + m[5] * qb[1] + m[9] * qb[2];
+    gp[2] += m[2] * qb[0] + m[6] * qb[1] + m[10] * qb[2];
+    if (g_bt != nullptr) {
+        float* gm = g_bt + ((size_t)frame * N_BONES + b) * 16;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(gm + 4 * r + c, qb[r] * p[c]);
+            atomicAdd(gm + 4 * r + 3, qb[r]);
+        }
+    }
+    if (g_T != nullptr) {
+        float* gt = g_T + ((size_t)frame * N_BONES + b) * 3;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) atomicAdd(gt + r, -qb[r]);
+    }
+}
+// MODE 0: out[n,3] = g = sum_b R_b^T grad_q F_b(G)                       (`.gradient()`)
+// MODE 1: J^T G: out (+)= sum_b R_b^T grad_q F_b(G); pose gradients += spread
+// MODE 2: second-order term of g . gbar with G fixed: explicit R_b^T (pose) and the Hessian-vector product along R_b gbar
+template <int MODE>
+__global__ void k_hand_pull(const float* __restrict__ pts, int n, int ppf, int nf, const float* __restrict__ bt_inv,
+                            const float* __restrict__ T_pose, const float* __restrict__ G, const float* __restrict__ gbar,
+                            float* __restrict__ out, int accumulate, float* __restrict__ g_bt, float* __restrict__ g_T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+    const FrameRef fr = frame_of(i, ppf, nf, bt_inv, T_pose);
+    float gp[3] = {0.f, 0.f, 0.f};
+    float gb[3] = {0.f, 0.f, 0.f};
+    if (MODE == 2) {
+        gb[0] = gbar[3 * (size_t)i];
+        gb[1] = gbar[3 * (size_t)i + 1];
+        gb[2] = gbar[3 * (size_t)i + 2];
+    }
+    for (int b = 0; b < N_BONES; ++b) {
+        const float* m = fr.M + 16 * b;
+        const BoneQ q = bone_q(p, m, fr.T + 3 * b, b);
+        const float* g = G + (size_t)i * HAND_IN + b * 66;
+        float S0[4] = {0.f, 0.f, 0.f, 0.f}, S1[4] = {0.f, 0.f, 0.f, 0.f}, S2[4] = {0.f, 0.f, 0.f, 0.f};
+        bone_features(q, [&](int f, int a, float phi, float phi1, float phi2) {
+            const float gv = g[f];
+            S0[a] += gv * phi;
+            S1[a] += gv * phi1;
+            S2[a] += gv * phi2;
+        });
+        const float tot = S0[0] + S0[1] + S0[2] + S0[3];
+        const float Sv = q.h * S1[0] + q.h1 * tot;
+        const float Sr[3] = {q.h * S1[1], q.h * S1[2], q.h * S1[3]};
+        const float dot = Sr[0] * q.r[0] + Sr[1] * q.r[1] + Sr[2] * q.r[2];
+        float dq[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dq[c] = Sv * q.r[c] + (Sr[c] - dot * q.r[c]) / q.v;
+        if (MODE == 0) {
+            gp[0] += m[0] * dq[0] + m[4] * dq[1] + m[8] * dq[2];
+            gp[1] += m[1] * dq[0] + m[5] * dq[1] + m[9] * dq[2];
+            gp[2] += m[2] * dq[0] + m[6] * dq[1] + m[10] * dq[2];
+        } else if (MODE == 1) {
+            spread(dq, p, m, fr.frame, b, gp, g_bt, g_T);
+        } else {
+            if (g_bt != nullptr) {   // g = sum_b R_b^T dq_b depends on R_b explicitly
+                float* gm = g_bt + ((size_t)fr.frame * N_BONES + b) * 16;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) atomicAdd(gm + 4 * r + c, dq[r] * gb[c]);
+            }
+            const float w[3] = {m[0] * gb[0] + m[1] * gb[1] + m[2] * gb[2], m[4] * gb[0] + m[5] * gb[1] + m[6] * gb[2],
+                                m[8] * gb[0] + m[9] * gb[1] + m[10] * gb[2]};
+            const float rw = q.r[0] * w[0] + q.r[1] * w[1] + q.r[2] * w[2];
+            float wt[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wt[c] = (w[c] - q.r[c] * rw) / q.v;
+            const float B1[3] = {S1[1], S1[2], S1[3]}, B2[3] = {S2[1], S2[2], S2[3]};
+            const float dSv_dv = 2.f * q.h1 * S1[0] + q.h * S2[0] + q.h2 * tot;
+            const float hb_r = q.h1 * (B1[0] * q.r[0] + B1[1] * q.r[1] + B1[2] * q.r[2]);
+            const float cc = q.h1 * (B1[0] * wt[0] + B1[1] * wt[1] + B1[2] * wt[2]);
+            const float e[3] = {q.h * B2[0] * wt[0], q.h * B2[1] * wt[1], q.h * B2[2] * wt[2]};
+            const float e_r = e[0] * q.r[0] + e[1] * q.r[1] + e[2] * q.r[2];
+            const float sr_wt = Sr[0] * wt[0] + Sr[1] * wt[1] + Sr[2] * wt[2];
+            float hv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float gSv = dSv_dv * q.r[c] + (q.h1 * B1[c] - hb_r * q.r[c]) / q.v;
+                hv[c] = gSv * rw + Sv * wt[c] + cc * q.r[c] + (e[c] - e_r * q.r[c]) / q.v -
+                        ((Sr[c] - dot * q.r[c]) / q.v * rw + dot * wt[c]) / q.v - sr_wt * q.r[c] / q.v;
+            }
+            spread(hv, p, m, fr.frame, b, gp, g_bt, g_T);
+        }
+    }
+    float* o = out + 3 * (size_t)i;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = accumulate ? o[c] + gp[c] : gp[c];
+}
+
 // ---- orchestration ---------------------------------------------------------------------------------------------
 struct Arena {
     char* base;
@@ -312,7 +503,9 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
                    size_t workspace_bytes, hipStream_t s) {
     HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");
-    HN_REQUIRE(f->kind == HN_FIELD_OBJ, "hn_field_eval_bwd: the hand field's adjoint is not built yet");
+    const bool obj = f->kind == HN_FIELD_OBJ;
+    HN_REQUIRE(obj || (bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1),
+               "hand field needs bt_inv / T_pose and frame sizes");
     HN_REQUIRE(pts && g_sdf && g_grad && g_rgb && g_pts && spr >= 1 && n % spr == 0, "bad arguments");
     if (n == 0) return HN_OK;
     Arena ar{reinterpret_cast<char*>(workspace), 0, workspace_bytes};
@@ -324,7 +517,7 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     }
     const Ctx cx{s, n};
     const size_t N = (size_t)n;
-    const int Din = OBJ_IN;
+    const int Din = obj ? OBJ_IN : HAND_IN;
     const float rs2 = 0.70710678118654752f;
     const float inv_scale = 1.f / f->scale;
     const float* const* W = f->raw_sdf_w;
@@ -333,7 +526,10 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     auto width = [&](int l) { return f->sdf_out[l]; };
 
     // 1. forward tape -------------------------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_enc3<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.X, Din);
+    if (obj)
+        hipLaunchKernelGGL(k_enc3<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.X, Din);
+    else
+        hipLaunchKernelGGL(k_hand_feat, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.X);
     b.a[0] = b.X;
     for (int l = 0; l < 8; ++l) {
         if (l == 4) {
@@ -359,17 +555,24 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     }
     cx.nn(b.dz[0], H, H, W[0], Din, 0, Din, 1.f, b.GX, Din, false);
     cx.nn(b.dz[4], H, H, W[4], f->sdf_in[4], H4, Din, rs2, b.GX, Din, true);
-    hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.GX, Din, nullptr, 0, nullptr, b.g, 0);
+    if (obj)
+        hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.GX, Din, nullptr, 0, nullptr, b.g, 0);
+    else
+        hipLaunchKernelGGL(k_hand_pull<0>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX,
+                           (const float*)nullptr, b.g, 0, (float*)nullptr, (float*)nullptr);
     // 3. colour network forward + backward ------------------------------------------------------------------------
     const float* const* C = f->raw_col_w;
     const float* const* Cb = f->raw_col_b;
-    const int cin = f->col_in[0];                                  // 373 = 63 | 27 | 256 | 27
-    hipLaunchKernelGGL(k_enc3<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, rays_d, n, spr, b.din, 27);
+    const int cin = f->col_in[0];                                  // obj 373 = 63 | 27 | 256 | 27; hand 1669 = 1386 | 256 | 27
+    const int o_d = Din, o_f = obj ? Din + 27 : Din, o_g = o_f + H;
     hipLaunchKernelGGL(k_enc3<4>, g1(n), dim3(256), 0, s, b.g, n, 1, b.gin, 27);
     cx.nt(b.X, Din, Din, C[0], cin, 0, H, Cb[0], 1.f, b.c[1], H, false);
-    cx.nt(b.din, 27, 27, C[0], cin, Din, H, nullptr, 1.f, b.c[1], H, true);
-    cx.nt(b.z8 + 1, 257, H, C[0], cin, Din + 27, H, nullptr, 1.f, b.c[1], H, true);
-    cx.nt(b.gin, 27, 27, C[0], cin, Din + 27 + H, H, nullptr, 1.f, b.c[1], H, true);
+    if (obj) {   // the hand's colour net ignores the view direction (utils/fields.py:222-240)
+        hipLaunchKernelGGL(k_enc3<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, rays_d, n, spr, b.din, 27);
+        cx.nt(b.din, 27, 27, C[0], cin, o_d, H, nullptr, 1.f, b.c[1], H, true);
+    }
+    cx.nt(b.z8 + 1, 257, H, C[0], cin, o_f, H, nullptr, 1.f, b.c[1], H, true);
+    cx.nt(b.gin, 27, 27, C[0], cin, o_g, H, nullptr, 1.f, b.c[1], H, true);
     hipLaunchKernelGGL(k_relu, g1(N * H), dim3(256), 0, s, b.c[1], N * H);
     for (int l = 1; l <= 3; ++l) {
         cx.nt(b.c[l], H, H, C[l], H, 0, H, Cb[l], 1.f, b.c[l + 1], H, false);
@@ -387,16 +590,24 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     }
     const float* cb1 = b.cb[cur];
     cx.nn(cb1, H, H, C[0], cin, 0, Din, 1.f, b.Xb, Din, false);                    // Xb starts as the colour net's share
-    cx.nn(cb1, H, H, C[0], cin, Din, 27, 1.f, b.db, 27, false);
     hipLaunchKernelGGL(k_z8_bar, g1(n), dim3(256), 0, s, g_sdf, inv_scale, b.z8b, n);
-    cx.nn(cb1, H, H, C[0], cin, Din + 27, H, 1.f, b.z8b + 1, 257, false);         // fb
-    cx.nn(cb1, H, H, C[0], cin, Din + 27 + H, 27, 1.f, b.gbin, 27, false);
-    hipLaunchKernelGGL(k_enc3_pull<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, rays_d, n, spr, b.db, 27, nullptr, 0, nullptr, b.gdir, 0);
-    if (g_rays_d != nullptr) hipLaunchKernelGGL(k_sum_rays, g1((size_t)(n / spr) * 3), dim3(256), 0, s, b.gdir, n / spr, spr, g_rays_d);
+    cx.nn(cb1, H, H, C[0], cin, o_f, H, 1.f, b.z8b + 1, 257, false);               // fb
+    cx.nn(cb1, H, H, C[0], cin, o_g, 27, 1.f, b.gbin, 27, false);
+    if (obj) {
+        cx.nn(cb1, H, H, C[0], cin, o_d, 27, 1.f, b.db, 27, false);
+        hipLaunchKernelGGL(k_enc3_pull<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, rays_d, n, spr, b.db, 27, nullptr, 0, nullptr, b.gdir, 0);
+        if (g_rays_d != nullptr)
+            hipLaunchKernelGGL(k_sum_rays, g1((size_t)(n / spr) * 3), dim3(256), 0, s, b.gdir, n / spr, spr, g_rays_d);
+    } else if (g_rays_d != nullptr) {
+        HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n / spr) * 3 * sizeof(float), s));
+    }
     hipLaunchKernelGGL(k_enc3_pull<4>, g1(n), dim3(256), 0, s, b.g, n, 1, b.gbin, 27, nullptr, 0, nullptr, b.gb, 0);
     hipLaunchKernelGGL(k_add3, g1(N * 3), dim3(256), 0, s, g_grad, b.gb, N * 3);
     // 4. adjoint of the reverse sweep ---------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_enc3_push<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, b.gb, b.GXb, Din);
+    if (obj)
+        hipLaunchKernelGGL(k_enc3_push<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, b.gb, b.GXb, Din);
+    else
+        hipLaunchKernelGGL(k_hand_push, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.gb, b.GXb);
     cx.nt(b.GXb, Din, Din, W[0], Din, 0, H, nullptr, 1.f, b.dzb, H, false);
     for (int l = 1; l <= 7; ++l) {
         const int wprev = width(l - 1);
@@ -423,9 +634,15 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
         }
     }
     // 6. input map: g_pts = J^T Xb + second-order term ------------------------------------------------------------
-    hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.Xb, Din, b.GX, Din, b.gb, g_pts, 0);
+    if (obj) {
+        hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.Xb, Din, b.GX, Din, b.gb, g_pts, 0);
+    } else {   // the pose gradients accumulate into the caller's (zeroed) g_bt_inv / g_T_pose
+        hipLaunchKernelGGL(k_hand_pull<1>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.Xb,
+                           (const float*)nullptr, g_pts, 0, g_bt_inv, g_T_pose);
+        hipLaunchKernelGGL(k_hand_pull<2>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX,
+                           b.gb, g_pts, 1, g_bt_inv, g_T_pose);
+    }
     HN_LAUNCH_CHECK();
-    (void)bt_inv; (void)T_pose; (void)n_frames; (void)pts_per_frame; (void)g_bt_inv; (void)g_T_pose;
     return HN_OK;
 }
 

@@ -713,3 +713,31 @@ def test_obj_field_adjoint(L):
     g_pts, g_dirs, _, _ = _field_adjoint_gpu(L, obj, pts, d, spr, gs, gg, gr)
     assert_close(g_pts, ref['g_pts'].float(), 2e-4, 'd/d pts')
     assert_close(g_dirs, ref['g_dirs'].reshape(rays, spr, 3).sum(1).float(), 2e-4, 'd/d rays_d')
+
+
+def test_hand_field_adjoint(L):
+    """hn_field_eval_bwd (hand field): d/d pts, d/d bt_inv, d/d T_pose including the second-order path through the
+    bone encoding, against the oracle's hand-written adjoint evaluated in float64.  Near joints the problem is
+    ill-conditioned (see assert_parity): the bar is the fp32 evaluation of the same formulas."""
+    from oracle.field_bwd import field_adjoint
+    from honerf_amd import synth
+    hand, _ = packed_fields('cuda', 'f16x3')
+    hand32, _ = oracle_fields()
+    hand64, _ = oracle_fields_fp64()
+    gen = torch.Generator().manual_seed(6)
+    bt_inv, T_pose, joints = synth.synth_hand_pose(8)
+    bt, tp, j = t(bt_inv), t(T_pose), t(joints)
+    spr, rays = 4, 45
+    n = spr * rays
+    pts = j[torch.randint(0, 21, (n,), generator=gen)] + 0.03 * torch.randn(n, 3, generator=gen)
+    pts[:6] += 0.5
+    d = torch.nn.functional.normalize(torch.randn(rays, 3, generator=gen), dim=-1)
+    dirs = d[:, None, :].expand(rays, spr, 3).reshape(n, 3)
+    gs, gg, gr = torch.randn(n, 1, generator=gen), torch.randn(n, 3, generator=gen), torch.randn(n, 3, generator=gen)
+    ref64 = field_adjoint(hand64, pts.double(), dirs.double(), gs.double(), gg.double(), gr.double(), bt.double(), tp.double())
+    ref32 = field_adjoint(hand32, pts, dirs, gs, gg, gr, bt, tp)
+    g_pts, g_dirs, g_bt, g_tp = _field_adjoint_gpu(L, hand, pts, d, spr, gs, gg, gr, bt[None], tp[None])
+    assert_parity(g_pts, ref32['g_pts'], ref64['g_pts'], 'd/d pts', rtol=2e-4, cap=5e-3)
+    assert_parity(g_bt[0, :, :3, :], ref32['g_bt_inv'][:, :3, :], ref64['g_bt_inv'][:, :3, :], 'd/d bt_inv', rtol=2e-4, cap=5e-3)
+    assert_parity(g_tp[0], ref32['g_T_pose'], ref64['g_T_pose'], 'd/d T_pose', rtol=2e-4, cap=5e-3)
+    assert float(g_dirs.abs().max()) == 0.0
