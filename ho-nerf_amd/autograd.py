@@ -1,0 +1,122 @@
+"""Differentiable two-field render: `torch.autograd.Function` over the C ABI.
+
+The reference lets autograd differentiate `NeuSRenderer_fitting.render` w.r.t. the pose-dependent inputs
+(`rays_o, rays_d, Ro, To, bt_inv`, formally `T_pose_21`): fitting_single.py:289-291, fitting_video.py:340-342.  The
+sampling positions carry no gradient (utils/renderer.py:461 `no_grad`), so the backward pass only runs through the
+final `get_alpha_sample_color` of both fields and the compositing (utils/renderer.py:360-422, 512-524).  Here that
+backward is the launch sequence
+
+    composite2_bwd -> alpha_bwd (x2) -> field_eval_bwd (x2) -> sample_points_bwd (x2) -> obj_local_bwd
+
+on the depths the forward produced; the per-field forward values it needs (rgb, alpha) are recomputed with the same
+kernels the forward used.  Nothing here computes on the host; torch only owns the buffers.
+"""
+import torch
+
+from . import lib as _lib
+
+
+def _empty(*shape, dev):
+    return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+
+class DualRenderFn(torch.autograd.Function):
+    """(rays_o [F,P,3], rays_d [F,P,3], bt_inv [F,21,4,4], T_pose [F,21,3], Ro [F,3,3], To [F,3]) ->
+    (color [N,3], weight_sum [N,1], sdf_hand [N*S,1], sdf_obj [N*S,1], grad_hand [N*S,3], grad_obj [N*S,3], gerr [2])."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, bt_inv, T_pose, Ro, To, renderer, near, far, t_rand):
+        o = renderer._render_raw(rays_o.detach(), rays_d.detach(), near, far, bt_inv.detach(), T_pose.detach(), Ro.detach(),
+                                 To.detach(), t_rand)
+        ctx.renderer, ctx.near, ctx.far = renderer, float(near), float(far)
+        ctx.save_for_backward(rays_o.detach(), rays_d.detach(), bt_inv.detach(), T_pose.detach(), Ro.detach(), To.detach(),
+                              o['z_vals'])
+        return o['color'], o['weight_sum'], o['sdf_hand'], o['sdf_obj'], o['grad_hand'], o['grad_obj'], o['gerr']
+
+    @staticmethod
+    def backward(ctx, g_color, g_wsum, g_sdf_h, g_sdf_o, g_grad_h, g_grad_o, g_gerr):
+        L = _lib
+        lib = L.load()
+        ren = ctx.renderer
+        rays_o, rays_d, bt, tp, Ro, To, z = ctx.saved_tensors
+        hand, obj = ren.fields()
+        F, P = rays_o.shape[0], rays_o.shape[1]
+        N, S = F * P, z.shape[-1]
+        n = N * S
+        dev = rays_o.device
+        st = L.stream_ptr()
+        ro, rd = L.f32(rays_o).reshape(N, 3), L.f32(rays_d).reshape(N, 3)
+        bt, tp = L.f32(bt).reshape(F, 21, 4, 4), L.f32(tp).reshape(-1, 21, 3)
+        if tp.shape[0] != F:
+            tp = tp.expand(F, 21, 3).contiguous()
+        Ro, To = L.f32(Ro).reshape(F, 3, 3), L.f32(To).reshape(F, 3)
+        z = L.f32(z).reshape(N, S)
+        if getattr(ren, '_backward_depths', None) is not None:   # test hook: differentiate on given depths
+            z = L.f32(ren._backward_depths).reshape(N, S)
+        sample_dist = float(torch.tensor((ctx.far - ctx.near) / ren.n_samples, dtype=torch.float32))
+
+        def field_forward(field, o, d, frames):
+            pts, dists = _empty(n, 3, dev=dev), _empty(n, dev=dev)
+            L.check(lib.hn_sample_points(L.ptr(o), L.ptr(d), L.ptr(z), N, S, 1, sample_dist, L.ptr(pts), L.ptr(dists), st), 'hn_sample_points')
+            sdf, grad, rgb = _empty(n, dev=dev), _empty(n, 3, dev=dev), _empty(n, 3, dev=dev)
+            wsb = lib.hn_field_workspace_bytes(field.handle, n)
+            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+            L.check(lib.hn_field_eval(field.handle, L.ptr(pts), L.ptr(d), n, S, L.ptr(bt) if frames else None,
+                                      L.ptr(tp) if frames else None, F if frames else 1, P * S if frames else n, L.ptr(sdf),
+                                      L.ptr(grad), L.ptr(rgb), None, L.ptr(ws), wsb, st), 'hn_field_eval')
+            alpha = _empty(n, dev=dev)
+            L.check(lib.hn_alpha(L.ptr(sdf), L.ptr(grad), L.ptr(d), L.ptr(dists), n, S, float(field.inv_s), L.ptr(alpha), None, st), 'hn_alpha')
+            return pts, dists, sdf, grad, rgb, alpha
+
+        # forward values of the two branches on the forward's depths
+        o_l, d_l = _empty(N, 3, dev=dev), _empty(N, 3, dev=dev)
+        L.check(lib.hn_obj_local_fwd(L.ptr(ro), L.ptr(rd), L.ptr(Ro), L.ptr(To), F, P, L.ptr(o_l), L.ptr(d_l), st), 'hn_obj_local_fwd')
+        pts_h, dists, sdf_h, grad_h, rgb_h, alpha_h = field_forward(hand, ro, rd, True)
+        pts_o, _, sdf_o, grad_o, rgb_o, alpha_o = field_forward(obj, o_l, d_l, False)
+
+        # compositing
+        g_color = L.f32(g_color).reshape(N, 3) if g_color is not None else torch.zeros(N, 3, device=dev)
+        g_wsum = L.f32(g_wsum).reshape(N) if g_wsum is not None else None
+        g_ah, g_ao = _empty(n, dev=dev), _empty(n, dev=dev)
+        g_rgbh, g_rgbo = _empty(n, 3, dev=dev), _empty(n, 3, dev=dev)
+        L.check(lib.hn_composite2_bwd(L.ptr(alpha_h), L.ptr(rgb_h), L.ptr(alpha_o), L.ptr(rgb_o), L.ptr(g_color), L.ptr(g_wsum), N, S,
+                                      L.ptr(g_ah), L.ptr(g_rgbh), L.ptr(g_ao), L.ptr(g_rgbo), st), 'hn_composite2_bwd')
+
+        def branch(field, pts, d, sdf, grad, g_alpha, g_rgb, g_sdf_out, g_grad_out, g_eik, frames):
+            gs, gg, gd = _empty(n, dev=dev), _empty(n, 3, dev=dev), _empty(N, 3, dev=dev)
+            L.check(lib.hn_alpha_bwd(L.ptr(sdf), L.ptr(grad), L.ptr(d), L.ptr(dists), L.ptr(g_alpha), None, n, S, float(field.inv_s),
+                                     L.ptr(gs), L.ptr(gg), L.ptr(gd), st), 'hn_alpha_bwd')
+            if g_sdf_out is not None:                       # the per-sample sdf feeds the contact / penetration losses
+                gs += L.f32(g_sdf_out).reshape(n)
+            if g_grad_out is not None:
+                gg += L.f32(g_grad_out).reshape(n, 3)
+            if g_eik is not None and float(g_eik) != 0.0:   # gradient_error = mean((|g| - 1)^2)
+                nrm = grad.norm(dim=-1, keepdim=True)
+                gg += (2.0 * float(g_eik) / n) * (nrm - 1.0) * grad / nrm
+            g_pts, g_dir = _empty(n, 3, dev=dev), _empty(N, 3, dev=dev)
+            g_bt = torch.zeros(F, 21, 4, 4, device=dev) if frames else None
+            g_tp = torch.zeros(F, 21, 3, device=dev) if frames else None
+            need = lib.hn_field_bwd_workspace_bytes(field.handle, n)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            L.check(lib.hn_field_eval_bwd(field.handle, L.ptr(pts), L.ptr(d), n, S, L.ptr(bt) if frames else None,
+                                          L.ptr(tp) if frames else None, F if frames else 1, P * S if frames else n, L.ptr(gs),
+                                          L.ptr(gg), L.ptr(g_rgb), L.ptr(g_pts), L.ptr(g_dir), L.ptr(g_bt), L.ptr(g_tp), L.ptr(ws),
+                                          need, st), 'hn_field_eval_bwd')
+            g_o, g_d = _empty(N, 3, dev=dev), _empty(N, 3, dev=dev)
+            L.check(lib.hn_sample_points_bwd(L.ptr(z), L.ptr(g_pts), N, S, 1, sample_dist, L.ptr(g_o), L.ptr(g_d), st), 'hn_sample_points_bwd')
+            return g_o, g_d + gd + g_dir, g_bt, g_tp
+
+        ge = g_gerr if g_gerr is not None else (None, None)
+        go_h, gd_h, g_bt, g_tp = branch(hand, pts_h, rd, sdf_h, grad_h, g_ah, g_rgbh, g_sdf_h, g_grad_h, ge[0], True)
+        go_l, gd_l, _, _ = branch(obj, pts_o, d_l, sdf_o, grad_o, g_ao, g_rgbo, g_sdf_o, g_grad_o, ge[1], False)
+        g_ro, g_rd = _empty(N, 3, dev=dev), _empty(N, 3, dev=dev)
+        g_Ro, g_To = _empty(F, 3, 3, dev=dev), _empty(F, 3, dev=dev)
+        L.check(lib.hn_obj_local_bwd(L.ptr(ro), L.ptr(rd), L.ptr(Ro), L.ptr(To), L.ptr(go_l.contiguous()), L.ptr(gd_l.contiguous()), F, P,
+                                     L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_Ro), L.ptr(g_To), st), 'hn_obj_local_bwd')
+        g_rays_o = (go_h + g_ro).reshape(rays_o.shape)
+        g_rays_d = (gd_h + g_rd).reshape(rays_d.shape)
+        def like(g, ref):          # an input shared by all frames (e.g. T_pose [21,3]) receives the sum over frames
+            return g.reshape(ref.shape) if g.numel() == ref.numel() else g.reshape(F, *ref.shape[-(ref.dim()):]).sum(0).reshape(ref.shape)
+
+        sv = ctx.saved_tensors
+        return (g_rays_o, g_rays_d, like(g_bt, sv[2]), like(g_tp, sv[3]), like(g_Ro, sv[4]), like(g_To, sv[5]), None, None, None, None)

@@ -119,6 +119,10 @@ class NeuSRenderer:
         return self.field().sdf(pts, bt_inv, T_pose_21)
 
 
+def _wants_grad(*xs):
+    return torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs)
+
+
 class NeuSRenderer_fitting:
     """Two-field (hand + object) renderer of the fitting stage (utils/renderer.py:286-572)."""
 
@@ -193,6 +197,8 @@ class NeuSRenderer_fitting:
         """utils/renderer.py:434-535.  rays [B,3]."""
         if self.perturb <= 0:
             raise ValueError('render requires perturb > 0, as the reference does')
+        if _wants_grad(rays_o, rays_d, bt_inv, T_pose_21, Ro, To):
+            return self._render_autograd(rays_o, rays_d, near, far, bt_inv, T_pose_21, Ro, To, t_rand, (1, -1))
         ro = _lib.f32(rays_o).reshape(1, -1, 3)
         rd = _lib.f32(rays_d).reshape(1, -1, 3)
         o = self._render_raw(ro, rd, near, far, bt_inv, T_pose_21, Ro, To, t_rand)
@@ -206,6 +212,25 @@ class NeuSRenderer_fitting:
             'gradient_error_obj': o['gerr'][1],
             'gradient_hand': o['grad_hand'],
             'gradient_obj': o['grad_obj'],
+        }
+
+    def _render_autograd(self, rays_o, rays_d, near, far, bt_inv, T_pose_21, Ro, To, t_rand, lead):
+        """The same render with the outputs attached to the autograd graph of the pose-dependent inputs
+        (what fitting_single.py:289-291 / fitting_video.py:340-342 back-propagate through)."""
+        from .autograd import DualRenderFn
+        dev = torch.device('cuda')
+        g = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(x)).to(device=dev, dtype=torch.float32)
+        ro, rd = g(rays_o), g(rays_d)
+        if lead == (1, -1):
+            ro, rd = ro.reshape(1, -1, 3), rd.reshape(1, -1, 3)
+        F, P = ro.shape[0], ro.shape[1]
+        outs = DualRenderFn.apply(ro, rd, g(bt_inv), g(T_pose_21), g(Ro), g(To), self, near, far, t_rand)
+        color, wsum, sdf_h, sdf_o, grad_h, grad_o, gerr = outs
+        if self.batched:
+            color, wsum = color.reshape(F, P, 3), wsum.reshape(F, P, 1)
+        return {
+            'color_fine': color, 'weight_sum': wsum, 'sdf_hand': sdf_h, 'sdf_obj': sdf_o,
+            'gradient_error_hand': gerr[0], 'gradient_error_obj': gerr[1], 'gradient_hand': grad_h, 'gradient_obj': grad_o,
         }
 
     def get_inner_point_id(self, pts, bt_inv, T_pose_21):

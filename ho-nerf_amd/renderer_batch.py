@@ -13,6 +13,10 @@ class NeuSRenderer_fitting(_Unbatched):
         """utils/renderer_batch.py:184-281."""
         if self.perturb <= 0:
             raise ValueError('render requires perturb > 0, as the reference does')
+        from .renderer import _wants_grad
+        if _wants_grad(rays_o, rays_d, bt_inv, T_pose_21, Ro, To):
+            self.batch_size, self.pixel_sample = rays_o.shape[0], rays_o.shape[1]
+            return self._render_autograd(rays_o, rays_d, near, far, bt_inv, T_pose_21, Ro, To, t_rand, None)
         ro = _lib.f32(rays_o)
         rd = _lib.f32(rays_d)
         F, P = ro.shape[0], ro.shape[1]

@@ -188,7 +188,7 @@ int hn_composite2(const float* alpha_h, const float* rgb_h, const float* grad_h,
  * path through `.gradient()`: utils/fields.py:165-177, 336-347 with create_graph=True; fitting_single.py:289-291).
  * g_sdf [n], g_grad [n,3], g_rgb [n,3] -> g_pts [n,3], g_rays_d [n/samples_per_ray,3] (may be NULL), and for hand
  * fields g_bt_inv [n_frames,21,4,4], g_T_pose [n_frames,21,3] (may be NULL).  The sweeps are specified in
- * oracle/field_bwd.py.  Round 1: object fields (HN_EINVAL for a hand field).  Workspace: hn_field_bwd_workspace_bytes. */
+ * oracle/field_bwd.py.  g_bt_inv / g_T_pose are ACCUMULATED into (zero them first).  Workspace: hn_field_bwd_workspace_bytes. */
 size_t hn_field_bwd_workspace_bytes(const hn_field* f, int n_pts);
 int hn_field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray,
                       const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf,
