@@ -43,23 +43,47 @@ __global__ __launch_bounds__(256) void k_dense(const DenseArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // A rows and the fast-varying index of B are read as 8 consecutive floats per thread (two 16-byte loads where the
+    // row pitch and offset allow it)
+    const bool a_vec = (a.lda & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
+    const bool w_vec = ((a.wsk == 1 ? a.wsc : a.wsk) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
     for (int k0 = 0; k0 < a.K; k0 += 32) {
         {
             const int r = t >> 2, c8 = (t & 3) * 8;
             const int row = row0 + r;
+            const float* src = a.A + (size_t)row * a.lda + k0 + c8;
+            if (a_vec && row < a.n && k0 + c8 + 8 <= a.K) {
+                const float4 v0 = reinterpret_cast<const float4*>(src)[0], v1 = reinterpret_cast<const float4*>(src)[1];
+                As[r][c8 + 0] = v0.x; As[r][c8 + 1] = v0.y; As[r][c8 + 2] = v0.z; As[r][c8 + 3] = v0.w;
+                As[r][c8 + 4] = v1.x; As[r][c8 + 5] = v1.y; As[r][c8 + 6] = v1.z; As[r][c8 + 7] = v1.w;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = k0 + c8 + e;
-                As[r][c8 + e] = (row < a.n && k < a.K) ? a.A[(size_t)row * a.lda + k] : 0.f;
+                for (int e = 0; e < 8; ++e) As[r][c8 + e] = (row < a.n && k0 + c8 + e < a.K) ? src[e] : 0.f;
             }
         }
-        {
+        if (a.wsk == 1) {   // B(k, col) = W[col * wsc + k]: k is the contiguous index -> thread = (col, 8 k's)
+            const int c = t >> 2, k8 = (t & 3) * 8;
+            const int col = col0 + c;
+            const float* src = a.W + (size_t)col * a.wsc + k0 + k8;
+            if (w_vec && col < a.M && k0 + k8 + 8 <= a.K) {
+                const float4 v0 = reinterpret_cast<const float4*>(src)[0], v1 = reinterpret_cast<const float4*>(src)[1];
+                Bs[k8 + 0][c] = v0.x; Bs[k8 + 1][c] = v0.y; Bs[k8 + 2][c] = v0.z; Bs[k8 + 3][c] = v0.w;
+                Bs[k8 + 4][c] = v1.x; Bs[k8 + 5][c] = v1.y; Bs[k8 + 6][c] = v1.z; Bs[k8 + 7][c] = v1.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Bs[k8 + e][c] = (col < a.M && k0 + k8 + e < a.K) ? src[e] : 0.f;
+            }
+        } else {            // B(k, col) = W[k * wsk + col]: col is contiguous -> thread = (k, 8 cols)
             const int kk = t >> 3, c8 = (t & 7) * 8;
             const int k = k0 + kk;
+            const float* src = a.W + (size_t)k * a.wsk + col0 + c8;
+            if (w_vec && k < a.K && col0 + c8 + 8 <= a.M) {
+                const float4 v0 = reinterpret_cast<const float4*>(src)[0], v1 = reinterpret_cast<const float4*>(src)[1];
+                Bs[kk][c8 + 0] = v0.x; Bs[kk][c8 + 1] = v0.y; Bs[kk][c8 + 2] = v0.z; Bs[kk][c8 + 3] = v0.w;
+                Bs[kk][c8 + 4] = v1.x; Bs[kk][c8 + 5] = v1.y; Bs[kk][c8 + 6] = v1.z; Bs[kk][c8 + 7] = v1.w;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int col = col0 + c8 + e;
-                Bs[kk][c8 + e] = (k < a.K && col < a.M) ? a.W[(size_t)k * a.wsk + (size_t)col * a.wsc] : 0.f;
+                for (int e = 0; e < 8; ++e) Bs[kk][c8 + e] = (k < a.K && col0 + c8 + e < a.M) ? src[e] : 0.f;
             }
         }
         __syncthreads();
@@ -320,9 +344,23 @@ __global__ void k_hand_push(const float* __restrict__ pts, int n, int ppf, int n
         bone_features(q, [&](int f, int a, float phi, float phi1, float) { o[f] = phi1 * q.h * dy[a] + phi * q.h1 * rw; });
     }
 }
-// adjoint of q = R p + t - T for one (sample, bone): g_pts, and the pose gradients by atomics
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// one atomic per wave when all its samples belong to one frame (the usual case), else one per lane
+__device__ __forceinline__ void pose_add(float* addr, float v, bool uniform, int lane) {
+    if (uniform) {
+        const float s = wave_sum64(v);
+        if (lane == 0) atomicAdd(addr, s);
+    } else if (v != 0.f) {
+        atomicAdd(addr, v);
+    }
+}
+// adjoint of q = R p + t - T for one (sample, bone): g_pts, and the pose gradients (qb must be 0 in inactive lanes)
 __device__ __forceinline__ void spread(const float qb[3], const float p[3], const float* __restrict__ m, int frame, int b,
-                                       float (&gp)[3], float* __restrict__ g_bt, float* __restrict__ g_T) {
+                                       float (&gp)[3], float* __restrict__ g_bt, float* __restrict__ g_T, bool uniform, int lane) {
     gp[0] += m[0] * qb[0] + m[4] * qb[1] + m[8] * qb[2];
     gp[1] += m[1] * qb[0] + m[5] * qb[1] + m[9] * qb[2];
     gp[2] += m[2] * qb[0] + m[6] * qb[1] + m[10] * qb[2];
@@ -331,14 +369,14 @@ __device__ __forceinline__ void spread(const float qb[3], const float p[3], cons
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) atomicAdd(gm + 4 * r + c, qb[r] * p[c]);
-            atomicAdd(gm + 4 * r + 3, qb[r]);
+            for (int c = 0; c < 3; ++c) pose_add(gm + 4 * r + c, qb[r] * p[c], uniform, lane);
+            pose_add(gm + 4 * r + 3, qb[r], uniform, lane);
         }
     }
     if (g_T != nullptr) {
         float* gt = g_T + ((size_t)frame * N_BONES + b) * 3;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) atomicAdd(gt + r, -qb[r]);
+        for (int r = 0; r < 3; ++r) pose_add(gt + r, -qb[r], uniform, lane);
     }
 }
 // MODE 0: out[n,3] = g = sum_b R_b^T grad_q F_b(G)                       (`.gradient()`)
@@ -348,10 +386,13 @@ template <int MODE>
 __global__ void k_hand_pull(const float* __restrict__ pts, int n, int ppf, int nf, const float* __restrict__ bt_inv,
                             const float* __restrict__ T_pose, const float* __restrict__ G, const float* __restrict__ gbar,
                             float* __restrict__ out, int accumulate, float* __restrict__ g_bt, float* __restrict__ g_T) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i0 < n;
+    const int i = valid ? i0 : n - 1;               // inactive lanes shadow the last sample and contribute zeros
+    const int lane = threadIdx.x & 63;
     const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
     const FrameRef fr = frame_of(i, ppf, nf, bt_inv, T_pose);
+    const bool uniform = __ballot(fr.frame != __shfl(fr.frame, 0, 64)) == 0ull;
     float gp[3] = {0.f, 0.f, 0.f};
     float gb[3] = {0.f, 0.f, 0.f};
     if (MODE == 2) {
@@ -376,20 +417,20 @@ __global__ void k_hand_pull(const float* __restrict__ pts, int n, int ppf, int n
         const float dot = Sr[0] * q.r[0] + Sr[1] * q.r[1] + Sr[2] * q.r[2];
         float dq[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dq[c] = Sv * q.r[c] + (Sr[c] - dot * q.r[c]) / q.v;
+        for (int c = 0; c < 3; ++c) dq[c] = valid ? Sv * q.r[c] + (Sr[c] - dot * q.r[c]) / q.v : 0.f;
         if (MODE == 0) {
             gp[0] += m[0] * dq[0] + m[4] * dq[1] + m[8] * dq[2];
             gp[1] += m[1] * dq[0] + m[5] * dq[1] + m[9] * dq[2];
             gp[2] += m[2] * dq[0] + m[6] * dq[1] + m[10] * dq[2];
         } else if (MODE == 1) {
-            spread(dq, p, m, fr.frame, b, gp, g_bt, g_T);
+            spread(dq, p, m, fr.frame, b, gp, g_bt, g_T, uniform, lane);
         } else {
             if (g_bt != nullptr) {   // g = sum_b R_b^T dq_b depends on R_b explicitly
                 float* gm = g_bt + ((size_t)fr.frame * N_BONES + b) * 16;
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) atomicAdd(gm + 4 * r + c, dq[r] * gb[c]);
+                    for (int c = 0; c < 3; ++c) pose_add(gm + 4 * r + c, dq[r] * gb[c], uniform, lane);
             }
             const float w[3] = {m[0] * gb[0] + m[1] * gb[1] + m[2] * gb[2], m[4] * gb[0] + m[5] * gb[1] + m[6] * gb[2],
                                 m[8] * gb[0] + m[9] * gb[1] + m[10] * gb[2]};
@@ -410,13 +451,16 @@ __global__ void k_hand_pull(const float* __restrict__ pts, int n, int ppf, int n
                 const float gSv = dSv_dv * q.r[c] + (q.h1 * B1[c] - hb_r * q.r[c]) / q.v;
                 hv[c] = gSv * rw + Sv * wt[c] + cc * q.r[c] + (e[c] - e_r * q.r[c]) / q.v -
                         ((Sr[c] - dot * q.r[c]) / q.v * rw + dot * wt[c]) / q.v - sr_wt * q.r[c] / q.v;
+                if (!valid) hv[c] = 0.f;
             }
-            spread(hv, p, m, fr.frame, b, gp, g_bt, g_T);
+            spread(hv, p, m, fr.frame, b, gp, g_bt, g_T, uniform, lane);
         }
     }
-    float* o = out + 3 * (size_t)i;
+    if (valid) {
+        float* o = out + 3 * (size_t)i;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] = accumulate ? o[c] + gp[c] : gp[c];
+        for (int c = 0; c < 3; ++c) o[c] = accumulate ? o[c] + gp[c] : gp[c];
+    }
 }
 
 // ---- orchestration ---------------------------------------------------------------------------------------------
