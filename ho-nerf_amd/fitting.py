@@ -120,3 +120,28 @@ def mask_pixels(mask, n_rays, rng):
     x = -(px - W / 2.0) / (H / 2.0)
     y = -(py - H / 2.0) / (H / 2.0)
     return np.stack([x, y], -1).astype(np.float32), py * W + px
+
+
+def allreduce_pose_gradients(params, dist=None):
+    """Window-parallel `fitting_video` step: every rank has back-propagated ITS window's loss into the
+    shared `[data_num, ...]` pose parameters (non-zero on the window's 4 rows); one all-reduce (SUM) of the flattened
+    gradient block -- data_num x 45 floats, ~18 KB at 100 frames: latency-bound, a single call -- makes the gradients
+    identical on all ranks, after which every rank takes the same Adam step on its replica.  A rank whose window list
+    has run out passes parameters without `.grad` (treated as zeros).  Returns the number of floats exchanged."""
+    if dist is None:
+        import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    params = list(params)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].reshape(p.shape)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n
+    return int(flat.numel())

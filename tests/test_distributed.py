@@ -114,3 +114,67 @@ def test_to_image_matches_reference_formula():
     img = to_image(rgb, 2, 2)
     assert img.shape == (2, 2, 3) and img.dtype == np.uint8
     assert img[0, 0].tolist() == [0, 127, 255] and img[0, 1].tolist() == [255, 0, 254]
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        n_frames = 9
+        torch.manual_seed(0)
+        pose = [torch.zeros(n_frames, 6, requires_grad=True), torch.zeros(n_frames, 3, requires_grad=True),
+                torch.zeros(n_frames, 20, requires_grad=True)]            # shared [data_num, .] parameters
+        sched = fitting.window_schedule(n_frames, rank, world)
+        target = torch.arange(n_frames, dtype=torch.float32)[:, None]
+        log = []
+        for win in sched:                                                 # one synchronous step per schedule entry
+            for p in pose:
+                p.grad = None
+            if win is not None:
+                loss = sum(((p[win] - target[win]) ** 2).sum() for p in pose)
+                loss.backward()
+            n = fitting.allreduce_pose_gradients(pose, dist)
+            with torch.no_grad():
+                for p in pose:
+                    p -= 0.1 * p.grad
+            log.append(n)
+        q.put((rank, [p.detach().clone() for p in pose], log))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_window_parallel_gradient_allreduce_keeps_replicas_identical():
+    """fitting_video's synchronous window-parallel step: after the all-reduce both ranks hold the same gradients, so
+    their parameter replicas stay bit-identical, and equal a single process that sums the two windows' gradients."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, pose0, log0), (_, pose1, log1) = res
+    assert log0 == log1 and all(n == 9 * 29 for n in log0)
+    for a, b in zip(pose0, pose1):
+        assert torch.equal(a, b)
+    # single-process reference of the same schedule
+    n_frames = 9
+    pose = [torch.zeros(n_frames, k) for k in (6, 3, 20)]
+    target = torch.arange(n_frames, dtype=torch.float32)[:, None]
+    s0, s1 = fitting.window_schedule(n_frames, 0, 2), fitting.window_schedule(n_frames, 1, 2)
+    for w0, w1 in zip(s0, s1):
+        grads = [torch.zeros_like(p) for p in pose]
+        for win in (w0, w1):
+            if win is not None:
+                for g, p in zip(grads, pose):
+                    g[win] += 2 * (p[win] - target[win])
+        for g, p in zip(grads, pose):
+            p -= 0.1 * g
+    for a, b in zip(pose0, pose):
+        assert torch.allclose(a, b, atol=1e-6)
