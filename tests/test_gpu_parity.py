@@ -848,3 +848,40 @@ def test_dual_render_backward_reference_golden(golden):
         e = rel_err(got, want)
         print('on the reference depths: d loss / d %-7s vs reference: %.2e' % (k, e))
         assert e < 5e-3, 'd loss / d %s on the reference depths: %.3e' % (k, e)
+
+
+def test_dual_render_batch_backward(golden):
+    """The frame-batched renderer (renderer_batch.py, fitting_video) under loss.backward(): per-frame poses
+    (bt_inv [F,21,4,4], Ro [F,3,3], To [F,3]) receive their own gradients.  Against autograd through the oracle's
+    batched render_dual on the golden's inputs, coarse depths only (identical sample placement on both sides)."""
+    from honerf_amd.renderer_batch import NeuSRenderer_fitting as Batched
+    from oracle import render as orr
+    g = golden('render_dual_batch')
+    F, P = g['rays_o'].shape[:2]
+    S = 40
+    hand_o, obj_o = oracle_fields()
+    gen = torch.Generator().manual_seed(21)
+    w = {k: torch.randn(*s, generator=gen) for k, s in (('c', (F, P, 3)), ('w', (F, P, 1)), ('sh', (F * P * S, 1)), ('so', (F * P * S, 1)))}
+    names = ('rays_o', 'rays_d', 'bt_inv', 'Ro', 'To')
+    leaves = [t(g[k]).clone().requires_grad_(True) for k in names]
+    o_ref = orr.render_dual(hand_o, obj_o, leaves[0], leaves[1], float(g['near']), float(g['far']), t(g['t_rand']), S, 0, 4,
+                            leaves[2], t(g['T_pose']), leaves[3], leaves[4])
+    loss_ref = ((o_ref['color_fine'] * w['c']).sum() + (o_ref['weight_sum'] * w['w']).sum()
+                + (o_ref['sdf_hand'] * w['sh']).sum() + (o_ref['sdf_obj'] * w['so']).sum())
+    ref = torch.autograd.grad(loss_ref, leaves)
+    m = product_modules()
+    ren = Batched(m['sdf_hand'], m['var_hand'], m['color_hand'], m['sdf_obj'], m['var_obj'], m['color_obj'], S, 0, 0, 4, 1.0)
+    dl = [cu(g[k]).clone().requires_grad_(True) for k in names]
+    out = ren.render(dl[0], dl[1], float(g['near']), float(g['far']), dl[2], cu(g['T_pose']), None, dl[3], dl[4], t_rand=cu(g['t_rand']))
+    assert out['color_fine'].shape == (F, P, 3)
+    assert_close(out['color_fine'], o_ref['color_fine'].detach(), 2e-4, 'batched colour')
+    loss = ((out['color_fine'] * cu(w['c'])).sum() + (out['weight_sum'] * cu(w['w'])).sum()
+            + (out['sdf_hand'] * cu(w['sh'])).sum() + (out['sdf_obj'] * cu(w['so'])).sum())
+    loss.backward()
+    for i, name in enumerate(names):
+        got, want = dl[i].grad.detach().cpu().numpy(), ref[i].numpy()
+        if name == 'bt_inv':
+            got, want = got[:, :, :3, :], want[:, :, :3, :]
+        e = rel_err(got, want)
+        print('batched d loss / d %-7s vs fp32 autograd: %.2e' % (name, e))
+        assert e < 3e-3, 'batched d loss / d %s: %.3e' % (name, e)
