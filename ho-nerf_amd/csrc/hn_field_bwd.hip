@@ -34,22 +34,30 @@ struct DenseArgs {
     float alpha;
     int accumulate;
 };
+// Workgroup tile 128 x BN (BN = 128, or 64 for narrow outputs), K step 32; 4 waves as 2 x 2, each 64 x BN/2 outputs
+// = 2 x (BN/64) MFMA tiles.  At 128 x 128 the operand traffic is 32 flop per byte of L2 read (the 64 x 64 tile of
+// the first version, 16 flop/B, was bound by L2 -> LDS bandwidth at ~40 TFLOP/s).
+template <int BN>
 __global__ __launch_bounds__(256) void k_dense(const DenseArgs a) {
-    __shared__ float As[64][33];
-    __shared__ float Bs[32][65];
+    constexpr int BM = 128, CT = BN / 64;       // CT column tiles per wave
+    __shared__ float As[BM][33];
+    __shared__ float Bs[32][BN + 1];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, j = lane & 31;
-    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
-    f32x16 acc;
+    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    f32x16 acc[2][CT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // A rows and the fast-varying index of B are read as 8 consecutive floats per thread (two 16-byte loads where the
-    // row pitch and offset allow it)
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < CT; ++y)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[x][y][i] = 0.f;
     const bool a_vec = (a.lda & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
     const bool w_vec = ((a.wsk == 1 ? a.wsc : a.wsk) & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
     for (int k0 = 0; k0 < a.K; k0 += 32) {
-        {
-            const int r = t >> 2, c8 = (t & 3) * 8;
+#pragma unroll
+        for (int rep = 0; rep < BM / 64; ++rep) {   // A tile: thread = (row, 8 consecutive k)
+            const int r = rep * 64 + (t >> 2), c8 = (t & 3) * 8;
             const int row = row0 + r;
             const float* src = a.A + (size_t)row * a.lda + k0 + c8;
             if (a_vec && row < a.n && k0 + c8 + 8 <= a.K) {
@@ -61,49 +69,69 @@ __global__ __launch_bounds__(256) void k_dense(const DenseArgs a) {
                 for (int e = 0; e < 8; ++e) As[r][c8 + e] = (row < a.n && k0 + c8 + e < a.K) ? src[e] : 0.f;
             }
         }
-        if (a.wsk == 1) {   // B(k, col) = W[col * wsc + k]: k is the contiguous index -> thread = (col, 8 k's)
-            const int c = t >> 2, k8 = (t & 3) * 8;
-            const int col = col0 + c;
-            const float* src = a.W + (size_t)col * a.wsc + k0 + k8;
-            if (w_vec && col < a.M && k0 + k8 + 8 <= a.K) {
-                const float4 v0 = reinterpret_cast<const float4*>(src)[0], v1 = reinterpret_cast<const float4*>(src)[1];
-                Bs[k8 + 0][c] = v0.x; Bs[k8 + 1][c] = v0.y; Bs[k8 + 2][c] = v0.z; Bs[k8 + 3][c] = v0.w;
-                Bs[k8 + 4][c] = v1.x; Bs[k8 + 5][c] = v1.y; Bs[k8 + 6][c] = v1.z; Bs[k8 + 7][c] = v1.w;
-            } else {
+        if (a.wsk == 1) {   // B(k, col) = W[col * wsc + k]: k contiguous -> thread = (col, 8 k's)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) Bs[k8 + e][c] = (col < a.M && k0 + k8 + e < a.K) ? src[e] : 0.f;
+            for (int rep = 0; rep < BN / 64; ++rep) {
+                const int c = rep * 64 + (t >> 2), k8 = (t & 3) * 8;
+                const int col = col0 + c;
+                const float* src = a.W + (size_t)col * a.wsc + k0 + k8;
+                if (w_vec && col < a.M && k0 + k8 + 8 <= a.K) {
+                    const float4 v0 = reinterpret_cast<const float4*>(src)[0], v1 = reinterpret_cast<const float4*>(src)[1];
+                    Bs[k8 + 0][c] = v0.x; Bs[k8 + 1][c] = v0.y; Bs[k8 + 2][c] = v0.z; Bs[k8 + 3][c] = v0.w;
+                    Bs[k8 + 4][c] = v1.x; Bs[k8 + 5][c] = v1.y; Bs[k8 + 6][c] = v1.z; Bs[k8 + 7][c] = v1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) Bs[k8 + e][c] = (col < a.M && k0 + k8 + e < a.K) ? src[e] : 0.f;
+                }
             }
-        } else {            // B(k, col) = W[k * wsk + col]: col is contiguous -> thread = (k, 8 cols)
-            const int kk = t >> 3, c8 = (t & 7) * 8;
-            const int k = k0 + kk;
-            const float* src = a.W + (size_t)k * a.wsk + col0 + c8;
-            if (w_vec && k < a.K && col0 + c8 + 8 <= a.M) {
-                const float4 v0 = reinterpret_cast<const float4*>(src)[0], v1 = reinterpret_cast<const float4*>(src)[1];
-                Bs[kk][c8 + 0] = v0.x; Bs[kk][c8 + 1] = v0.y; Bs[kk][c8 + 2] = v0.z; Bs[kk][c8 + 3] = v0.w;
-                Bs[kk][c8 + 4] = v1.x; Bs[kk][c8 + 5] = v1.y; Bs[kk][c8 + 6] = v1.z; Bs[kk][c8 + 7] = v1.w;
-            } else {
+        } else {            // B(k, col) = W[k * wsk + col]: col contiguous -> thread = (k, 8 cols)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) Bs[kk][c8 + e] = (k < a.K && col0 + c8 + e < a.M) ? src[e] : 0.f;
+            for (int rep = 0; rep < BN / 64; ++rep) {
+                const int kk = t >> 3, c8 = rep * 64 + (t & 7) * 8;
+                const int k = k0 + kk;
+                const float* src = a.W + (size_t)k * a.wsk + col0 + c8;
+                if (w_vec && k < a.K && col0 + c8 + 8 <= a.M) {
+                    const float4 v0 = reinterpret_cast<const float4*>(src)[0], v1 = reinterpret_cast<const float4*>(src)[1];
+                    Bs[kk][c8 + 0] = v0.x; Bs[kk][c8 + 1] = v0.y; Bs[kk][c8 + 2] = v0.z; Bs[kk][c8 + 3] = v0.w;
+                    Bs[kk][c8 + 4] = v1.x; Bs[kk][c8 + 5] = v1.y; Bs[kk][c8 + 6] = v1.z; Bs[kk][c8 + 7] = v1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) Bs[kk][c8 + e] = (k < a.K && col0 + c8 + e < a.M) ? src[e] : 0.f;
+                }
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[wr * 32 + j][2 * ks + h], Bs[2 * ks + h][wc * 32 + j], acc, 0, 0, 0);
+        for (int ks = 0; ks < 16; ++ks) {
+            float av[2], bv[CT];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) av[x] = As[wr * 64 + x * 32 + j][2 * ks + h];
+#pragma unroll
+            for (int y = 0; y < CT; ++y) bv[y] = Bs[2 * ks + h][wc * (BN / 2) + y * 32 + j];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < CT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+        }
         __syncthreads();
     }
-    const int col = col0 + wc * 32 + j;
-    if (col < a.M) {
-        const float b = a.bias != nullptr ? a.bias[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < a.n) {
-                float v = a.alpha * acc[r] + b;
-                float* c = a.C + (size_t)row * a.ldc + col;
-                if (a.accumulate) v += *c;
-                *c = v;
-            }
+    for (int y = 0; y < CT; ++y) {
+        const int col = col0 + wc * (BN / 2) + y * 32 + j;
+        if (col < a.M) {
+            const float b = a.bias != nullptr ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + wr * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < a.n) {
+                        float v = a.alpha * acc[x][y][r] + b;
+                        float* c = a.C + (size_t)row * a.ldc + col;
+                        if (a.accumulate) v += *c;
+                        *c = v;
+                    }
+                }
         }
     }
 }
@@ -482,7 +510,10 @@ struct Ctx {
     void dense(const float* A, int lda, int K, const float* W, int wsk, int wsc, int M, const float* bias, float alpha,
                float* C, int ldc, bool accumulate) const {
         DenseArgs a{A, lda, W, wsk, wsc, bias, C, ldc, n, K, M, alpha, accumulate ? 1 : 0};
-        hipLaunchKernelGGL(k_dense, dim3((M + 63) / 64, (n + 63) / 64), dim3(256), 0, s, a);
+        if (M > 64)
+            hipLaunchKernelGGL(k_dense<128>, dim3((M + 127) / 128, (n + 127) / 128), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_dense<64>, dim3(1, (n + 127) / 128), dim3(256), 0, s, a);
     }
     // C = A * W[:, c0:c0+K]^T  (W row-major [M, ldw])          "forward" use of a weight block
     void nt(const float* A, int lda, int K, const float* W, int ldw, int c0, int M, const float* bias, float alpha, float* C,
