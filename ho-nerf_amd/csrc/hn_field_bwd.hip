@@ -342,20 +342,20 @@ __device__ __forceinline__ FrameRef frame_of(int i, int ppf, int nf, const float
 }
 
 __global__ void k_hand_feat(const float* __restrict__ pts, int n, int ppf, int nf, const float* __restrict__ bt_inv,
-                            const float* __restrict__ T_pose, float* __restrict__ X) {
+                            const float* __restrict__ T_pose, float* __restrict__ X, int ld) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
     const FrameRef fr = frame_of(i, ppf, nf, bt_inv, T_pose);
     for (int b = 0; b < N_BONES; ++b) {
         const BoneQ q = bone_q(p, fr.M + 16 * b, fr.T + 3 * b, b);
-        float* o = X + (size_t)i * HAND_IN + b * 66;
+        float* o = X + (size_t)i * ld + b * 66;
         bone_features(q, [&](int f, int, float phi, float, float) { o[f] = phi * q.h; });
     }
 }
 // J gbar: directional derivative of every feature along dq = R_b gbar
 __global__ void k_hand_push(const float* __restrict__ pts, int n, int ppf, int nf, const float* __restrict__ bt_inv,
-                            const float* __restrict__ T_pose, const float* __restrict__ gbar, float* __restrict__ out) {
+                            const float* __restrict__ T_pose, const float* __restrict__ gbar, float* __restrict__ out, int ld) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
@@ -368,7 +368,7 @@ __global__ void k_hand_push(const float* __restrict__ pts, int n, int ppf, int n
                             m[8] * gb[0] + m[9] * gb[1] + m[10] * gb[2]};
         const float rw = q.r[0] * w[0] + q.r[1] * w[1] + q.r[2] * w[2];
         const float dy[4] = {rw, (w[0] - q.r[0] * rw) / q.v, (w[1] - q.r[1] * rw) / q.v, (w[2] - q.r[2] * rw) / q.v};
-        float* o = out + (size_t)i * HAND_IN + b * 66;
+        float* o = out + (size_t)i * ld + b * 66;
         bone_features(q, [&](int f, int a, float phi, float phi1, float) { o[f] = phi1 * q.h * dy[a] + phi * q.h1 * rw; });
     }
 }
@@ -412,7 +412,7 @@ __device__ __forceinline__ void spread(const float qb[3], const float p[3], cons
 // MODE 2: second-order term of g . gbar with G fixed: explicit R_b^T (pose) and the Hessian-vector product along R_b gbar
 template <int MODE>
 __global__ void k_hand_pull(const float* __restrict__ pts, int n, int ppf, int nf, const float* __restrict__ bt_inv,
-                            const float* __restrict__ T_pose, const float* __restrict__ G, const float* __restrict__ gbar,
+                            const float* __restrict__ T_pose, const float* __restrict__ G, int ld, const float* __restrict__ gbar,
                             float* __restrict__ out, int accumulate, float* __restrict__ g_bt, float* __restrict__ g_T) {
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i0 < n;
@@ -431,7 +431,7 @@ __global__ void k_hand_pull(const float* __restrict__ pts, int n, int ppf, int n
     for (int b = 0; b < N_BONES; ++b) {
         const float* m = fr.M + 16 * b;
         const BoneQ q = bone_q(p, m, fr.T + 3 * b, b);
-        const float* g = G + (size_t)i * HAND_IN + b * 66;
+        const float* g = G + (size_t)i * ld + b * 66;
         float S0[4] = {0.f, 0.f, 0.f, 0.f}, S1[4] = {0.f, 0.f, 0.f, 0.f}, S2[4] = {0.f, 0.f, 0.f, 0.f};
         bone_features(q, [&](int f, int a, float phi, float phi1, float phi2) {
             const float gv = g[f];
@@ -510,10 +510,11 @@ struct Ctx {
     void dense(const float* A, int lda, int K, const float* W, int wsk, int wsc, int M, const float* bias, float alpha,
                float* C, int ldc, bool accumulate) const {
         DenseArgs a{A, lda, W, wsk, wsc, bias, C, ldc, n, K, M, alpha, accumulate ? 1 : 0};
-        if (M > 64)
+        static const int force64 = getenv("HN_DENSE64") ? 1 : 0;   // tuning aid
+        if (M > 64 && !force64)
             hipLaunchKernelGGL(k_dense<128>, dim3((M + 127) / 128, (n + 127) / 128), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL(k_dense<64>, dim3(1, (n + 127) / 128), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_dense<64>, dim3((M + 63) / 64, (n + 127) / 128), dim3(256), 0, s, a);
     }
     // C = A * W[:, c0:c0+K]^T  (W row-major [M, ldw])          "forward" use of a weight block
     void nt(const float* A, int lda, int K, const float* W, int ldw, int c0, int M, const float* bias, float alpha, float* C,
@@ -536,7 +537,7 @@ struct Bufs {
 static void layout(const hn_field* f, int n, Arena& ar, Bufs& b) {
     const bool obj = f->kind == HN_FIELD_OBJ;
     const size_t N = (size_t)n;
-    const int Din = obj ? OBJ_IN : HAND_IN;
+    const int Din = ((obj ? OBJ_IN : HAND_IN) + 3) & ~3;   // row pitch of the input-space arrays
     b.X = ar.take(N * Din);
     for (int l = 1; l <= 8; ++l) b.a[l] = ar.take(N * f->sdf_out[l - 1]);
     for (int l = 0; l < 8; ++l) {
@@ -593,6 +594,9 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     const Ctx cx{s, n};
     const size_t N = (size_t)n;
     const int Din = obj ? OBJ_IN : HAND_IN;
+    const int DP = (Din + 3) & ~3;               // row pitch of the input-space arrays (X, GX, GXb, Xb)
+    const int* LW = f->sdf_ld;                   // row pitch of the retained matrices
+    const int LC0 = f->col_ld[0];
     const float rs2 = 0.70710678118654752f;
     const float inv_scale = 1.f / f->scale;
     const float* const* W = f->raw_sdf_w;
@@ -602,52 +606,52 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
 
     // 1. forward tape -------------------------------------------------------------------------------------------
     if (obj)
-        hipLaunchKernelGGL(k_enc3<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.X, Din);
+        hipLaunchKernelGGL(k_enc3<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.X, DP);
     else
-        hipLaunchKernelGGL(k_hand_feat, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.X);
+        hipLaunchKernelGGL(k_hand_feat, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.X, DP);
     b.a[0] = b.X;
     for (int l = 0; l < 8; ++l) {
         if (l == 4) {
-            cx.nt(b.a[4], H4, H4, W[4], f->sdf_in[4], 0, width(4), Bv[4], rs2, b.a[5], width(4), false);
-            cx.nt(b.X, Din, Din, W[4], f->sdf_in[4], H4, width(4), nullptr, rs2, b.a[5], width(4), true);
+            cx.nt(b.a[4], H4, H4, W[4], LW[4], 0, width(4), Bv[4], rs2, b.a[5], width(4), false);
+            cx.nt(b.X, DP, Din, W[4], LW[4], H4, width(4), nullptr, rs2, b.a[5], width(4), true);
         } else {
             const int K = l == 0 ? Din : f->sdf_in[l];
-            cx.nt(b.a[l], K, K, W[l], f->sdf_in[l], 0, width(l), Bv[l], 1.f, b.a[l + 1], width(l), false);
+            cx.nt(b.a[l], l == 0 ? DP : K, K, W[l], LW[l], 0, width(l), Bv[l], 1.f, b.a[l + 1], width(l), false);
         }
         hipLaunchKernelGGL(k_softplus, g1(N * width(l)), dim3(256), 0, s, b.a[l + 1], N * width(l));
     }
-    cx.nt(b.a[8], H, H, W[8], H, 0, 257, Bv[8], 1.f, b.z8, 257, false);
+    cx.nt(b.a[8], H, H, W[8], LW[8], 0, 257, Bv[8], 1.f, b.z8, 257, false);
     // 2. reverse sweep ------------------------------------------------------------------------------------------
     hipLaunchKernelGGL(k_bcast_row, g1(N * H), dim3(256), 0, s, W[8], H, inv_scale, b.u[7], N * H);
     for (int l = 7; l >= 0; --l) {
         hipLaunchKernelGGL(k_dz, g1(N * width(l)), dim3(256), 0, s, b.a[l + 1], b.u[l], b.dz[l], N * width(l));
         if (l > 0) {   // u_{l-1} = dz_l * Wh_l
             if (l == 4)
-                cx.nn(b.dz[4], width(4), width(4), W[4], f->sdf_in[4], 0, H4, rs2, b.u[3], H4, false);
+                cx.nn(b.dz[4], width(4), width(4), W[4], LW[4], 0, H4, rs2, b.u[3], H4, false);
             else
-                cx.nn(b.dz[l], width(l), width(l), W[l], f->sdf_in[l], 0, f->sdf_in[l], 1.f, b.u[l - 1], f->sdf_in[l], false);
+                cx.nn(b.dz[l], width(l), width(l), W[l], LW[l], 0, f->sdf_in[l], 1.f, b.u[l - 1], f->sdf_in[l], false);
         }
     }
-    cx.nn(b.dz[0], H, H, W[0], Din, 0, Din, 1.f, b.GX, Din, false);
-    cx.nn(b.dz[4], H, H, W[4], f->sdf_in[4], H4, Din, rs2, b.GX, Din, true);
+    cx.nn(b.dz[0], H, H, W[0], LW[0], 0, Din, 1.f, b.GX, DP, false);
+    cx.nn(b.dz[4], H, H, W[4], LW[4], H4, Din, rs2, b.GX, DP, true);
     if (obj)
-        hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.GX, Din, nullptr, 0, nullptr, b.g, 0);
+        hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.GX, DP, nullptr, 0, nullptr, b.g, 0);
     else
-        hipLaunchKernelGGL(k_hand_pull<0>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX,
+        hipLaunchKernelGGL(k_hand_pull<0>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX, DP,
                            (const float*)nullptr, b.g, 0, (float*)nullptr, (float*)nullptr);
     // 3. colour network forward + backward ------------------------------------------------------------------------
     const float* const* C = f->raw_col_w;
     const float* const* Cb = f->raw_col_b;
-    const int cin = f->col_in[0];                                  // obj 373 = 63 | 27 | 256 | 27; hand 1669 = 1386 | 256 | 27
+    [[maybe_unused]] const int cin = f->col_in[0];                                  // obj 373 = 63 | 27 | 256 | 27; hand 1669 = 1386 | 256 | 27
     const int o_d = Din, o_f = obj ? Din + 27 : Din, o_g = o_f + H;
     hipLaunchKernelGGL(k_enc3<4>, g1(n), dim3(256), 0, s, b.g, n, 1, b.gin, 27);
-    cx.nt(b.X, Din, Din, C[0], cin, 0, H, Cb[0], 1.f, b.c[1], H, false);
+    cx.nt(b.X, DP, Din, C[0], LC0, 0, H, Cb[0], 1.f, b.c[1], H, false);
     if (obj) {   // the hand's colour net ignores the view direction (utils/fields.py:222-240)
         hipLaunchKernelGGL(k_enc3<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, rays_d, n, spr, b.din, 27);
-        cx.nt(b.din, 27, 27, C[0], cin, o_d, H, nullptr, 1.f, b.c[1], H, true);
+        cx.nt(b.din, 27, 27, C[0], LC0, o_d, H, nullptr, 1.f, b.c[1], H, true);
     }
-    cx.nt(b.z8 + 1, 257, H, C[0], cin, o_f, H, nullptr, 1.f, b.c[1], H, true);
-    cx.nt(b.gin, 27, 27, C[0], cin, o_g, H, nullptr, 1.f, b.c[1], H, true);
+    cx.nt(b.z8 + 1, 257, H, C[0], LC0, o_f, H, nullptr, 1.f, b.c[1], H, true);
+    cx.nt(b.gin, 27, 27, C[0], LC0, o_g, H, nullptr, 1.f, b.c[1], H, true);
     hipLaunchKernelGGL(k_relu, g1(N * H), dim3(256), 0, s, b.c[1], N * H);
     for (int l = 1; l <= 3; ++l) {
         cx.nt(b.c[l], H, H, C[l], H, 0, H, Cb[l], 1.f, b.c[l + 1], H, false);
@@ -664,12 +668,12 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
         hipLaunchKernelGGL(k_relu_mask, g1(N * H), dim3(256), 0, s, b.c[l], b.cb[cur], N * H);
     }
     const float* cb1 = b.cb[cur];
-    cx.nn(cb1, H, H, C[0], cin, 0, Din, 1.f, b.Xb, Din, false);                    // Xb starts as the colour net's share
+    cx.nn(cb1, H, H, C[0], LC0, 0, Din, 1.f, b.Xb, DP, false);                    // Xb starts as the colour net's share
     hipLaunchKernelGGL(k_z8_bar, g1(n), dim3(256), 0, s, g_sdf, inv_scale, b.z8b, n);
-    cx.nn(cb1, H, H, C[0], cin, o_f, H, 1.f, b.z8b + 1, 257, false);               // fb
-    cx.nn(cb1, H, H, C[0], cin, o_g, 27, 1.f, b.gbin, 27, false);
+    cx.nn(cb1, H, H, C[0], LC0, o_f, H, 1.f, b.z8b + 1, 257, false);               // fb
+    cx.nn(cb1, H, H, C[0], LC0, o_g, 27, 1.f, b.gbin, 27, false);
     if (obj) {
-        cx.nn(cb1, H, H, C[0], cin, o_d, 27, 1.f, b.db, 27, false);
+        cx.nn(cb1, H, H, C[0], LC0, o_d, 27, 1.f, b.db, 27, false);
         hipLaunchKernelGGL(k_enc3_pull<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, rays_d, n, spr, b.db, 27, nullptr, 0, nullptr, b.gdir, 0);
         if (g_rays_d != nullptr)
             hipLaunchKernelGGL(k_sum_rays, g1((size_t)(n / spr) * 3), dim3(256), 0, s, b.gdir, n / spr, spr, g_rays_d);
@@ -680,41 +684,41 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     hipLaunchKernelGGL(k_add3, g1(N * 3), dim3(256), 0, s, g_grad, b.gb, N * 3);
     // 4. adjoint of the reverse sweep ---------------------------------------------------------------------------
     if (obj)
-        hipLaunchKernelGGL(k_enc3_push<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, b.gb, b.GXb, Din);
+        hipLaunchKernelGGL(k_enc3_push<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, b.gb, b.GXb, DP);
     else
-        hipLaunchKernelGGL(k_hand_push, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.gb, b.GXb);
-    cx.nt(b.GXb, Din, Din, W[0], Din, 0, H, nullptr, 1.f, b.dzb, H, false);
+        hipLaunchKernelGGL(k_hand_push, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.gb, b.GXb, DP);
+    cx.nt(b.GXb, DP, Din, W[0], LW[0], 0, H, nullptr, 1.f, b.dzb, H, false);
     for (int l = 1; l <= 7; ++l) {
         const int wprev = width(l - 1);
         hipLaunchKernelGGL(k_fwd_dir, g1(N * wprev), dim3(256), 0, s, b.a[l], b.u[l - 1], b.dzb, b.sb[l - 1], b.v, N * wprev);
         if (l == 4) {
-            cx.nt(b.v, H4, H4, W[4], f->sdf_in[4], 0, H, nullptr, rs2, b.dzb, H, false);
-            cx.nt(b.GXb, Din, Din, W[4], f->sdf_in[4], H4, H, nullptr, rs2, b.dzb, H, true);
+            cx.nt(b.v, H4, H4, W[4], LW[4], 0, H, nullptr, rs2, b.dzb, H, false);
+            cx.nt(b.GXb, DP, Din, W[4], LW[4], H4, H, nullptr, rs2, b.dzb, H, true);
         } else {
-            cx.nt(b.v, wprev, wprev, W[l], f->sdf_in[l], 0, width(l), nullptr, 1.f, b.dzb, width(l), false);
+            cx.nt(b.v, wprev, wprev, W[l], LW[l], 0, width(l), nullptr, 1.f, b.dzb, width(l), false);
         }
     }
     hipLaunchKernelGGL(k_fwd_dir, g1(N * H), dim3(256), 0, s, b.a[8], b.u[7], b.dzb, b.sb[7], (float*)nullptr, N * H);
     // 5. first-order reverse sweep with the second-order sources ---------------------------------------------------
-    cx.nn(b.z8b, 257, 257, W[8], H, 0, H, 1.f, b.ab, H, false);
+    cx.nn(b.z8b, 257, 257, W[8], LW[8], 0, H, 1.f, b.ab, H, false);
     for (int l = 7; l >= 0; --l) {
         hipLaunchKernelGGL(k_zb, g1(N * width(l)), dim3(256), 0, s, b.a[l + 1], b.ab, b.sb[l], b.zb, N * width(l));
         if (l == 4) {
-            cx.nn(b.zb, H, H, W[4], f->sdf_in[4], H4, Din, rs2, b.Xb, Din, true);
-            cx.nn(b.zb, H, H, W[4], f->sdf_in[4], 0, H4, rs2, b.ab, H4, false);
+            cx.nn(b.zb, H, H, W[4], LW[4], H4, Din, rs2, b.Xb, DP, true);
+            cx.nn(b.zb, H, H, W[4], LW[4], 0, H4, rs2, b.ab, H4, false);
         } else if (l == 0) {
-            cx.nn(b.zb, H, H, W[0], Din, 0, Din, 1.f, b.Xb, Din, true);
+            cx.nn(b.zb, H, H, W[0], LW[0], 0, Din, 1.f, b.Xb, DP, true);
         } else {
-            cx.nn(b.zb, width(l), width(l), W[l], f->sdf_in[l], 0, f->sdf_in[l], 1.f, b.ab, f->sdf_in[l], false);
+            cx.nn(b.zb, width(l), width(l), W[l], LW[l], 0, f->sdf_in[l], 1.f, b.ab, f->sdf_in[l], false);
         }
     }
     // 6. input map: g_pts = J^T Xb + second-order term ------------------------------------------------------------
     if (obj) {
-        hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.Xb, Din, b.GX, Din, b.gb, g_pts, 0);
+        hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.Xb, DP, b.GX, DP, b.gb, g_pts, 0);
     } else {   // the pose gradients accumulate into the caller's (zeroed) g_bt_inv / g_T_pose
-        hipLaunchKernelGGL(k_hand_pull<1>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.Xb,
+        hipLaunchKernelGGL(k_hand_pull<1>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.Xb, DP,
                            (const float*)nullptr, g_pts, 0, g_bt_inv, g_T_pose);
-        hipLaunchKernelGGL(k_hand_pull<2>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX,
+        hipLaunchKernelGGL(k_hand_pull<2>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX, DP,
                            b.gb, g_pts, 1, g_bt_inv, g_T_pose);
     }
     HN_LAUNCH_CHECK();

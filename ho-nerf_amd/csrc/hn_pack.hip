@@ -374,14 +374,24 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
     if (rc == HN_OK) {   // keep the folded matrices and biases (row-major) for the adjoint path
         size_t total = 0;
         auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
-        for (int l = 0; l < 9; ++l) total += pad((size_t)sdf->out_dim[l] * sdf->in_dim[l]) + pad(sdf->out_dim[l]);
-        for (int l = 0; l < 5; ++l) total += pad((size_t)col->out_dim[l] * col->in_dim[l]) + pad(col->out_dim[l]);
+        auto pitch = [](int in) { return (in + 3) & ~3; };   // rows start 16-byte aligned: vector loads in k_dense
+        for (int l = 0; l < 9; ++l) total += pad((size_t)sdf->out_dim[l] * pitch(sdf->in_dim[l])) + pad(sdf->out_dim[l]);
+        for (int l = 0; l < 5; ++l) total += pad((size_t)col->out_dim[l] * pitch(col->in_dim[l])) + pad(col->out_dim[l]);
         if (hipMalloc(&f->raw, total * sizeof(float)) != hipSuccess) {
             set_error("hipMalloc of %zu bytes for the folded weights failed", total * sizeof(float));
             rc = HN_ENOMEM;
         } else {
+            (void)hipMemsetAsync(f->raw, 0, total * sizeof(float), stream);
             float* q = reinterpret_cast<float*>(f->raw);
-            auto keep = [&](const float* src, size_t n) {
+            auto keep_mat = [&](const float* src, int out, int in) {
+                const float* dst = q;
+                const int ld = pitch(in);
+                (void)hipMemcpy2DAsync(q, (size_t)ld * sizeof(float), src, (size_t)in * sizeof(float), (size_t)in * sizeof(float), out,
+                                       hipMemcpyDeviceToDevice, stream);
+                q += pad((size_t)out * ld);
+                return dst;
+            };
+            auto keep_vec = [&](const float* src, size_t n) {
                 const float* dst = q;
                 (void)hipMemcpyAsync(q, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream);
                 q += pad(n);
@@ -390,14 +400,16 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
             for (int l = 0; l < 9; ++l) {
                 f->sdf_out[l] = sdf->out_dim[l];
                 f->sdf_in[l] = sdf->in_dim[l];
-                f->raw_sdf_w[l] = keep(w_sdf[l], (size_t)sdf->out_dim[l] * sdf->in_dim[l]);
-                f->raw_sdf_b[l] = keep(reinterpret_cast<const float*>(sdf->bias[l]), sdf->out_dim[l]);
+                f->sdf_ld[l] = pitch(sdf->in_dim[l]);
+                f->raw_sdf_w[l] = keep_mat(w_sdf[l], sdf->out_dim[l], sdf->in_dim[l]);
+                f->raw_sdf_b[l] = keep_vec(reinterpret_cast<const float*>(sdf->bias[l]), sdf->out_dim[l]);
             }
             for (int l = 0; l < 5; ++l) {
                 f->col_out[l] = col->out_dim[l];
                 f->col_in[l] = col->in_dim[l];
-                f->raw_col_w[l] = keep(w_col[l], (size_t)col->out_dim[l] * col->in_dim[l]);
-                f->raw_col_b[l] = keep(reinterpret_cast<const float*>(col->bias[l]), col->out_dim[l]);
+                f->col_ld[l] = pitch(col->in_dim[l]);
+                f->raw_col_w[l] = keep_mat(w_col[l], col->out_dim[l], col->in_dim[l]);
+                f->raw_col_b[l] = keep_vec(reinterpret_cast<const float*>(col->bias[l]), col->out_dim[l]);
             }
             if (hipStreamSynchronize(stream) != hipSuccess) {
                 set_error("copying the folded weights failed");
