@@ -11,6 +11,9 @@
 #include <stdlib.h>
 
 #include "hn_mlp2.h"
+#ifndef HN_JAC_VARIANT
+#define HN_JAC_VARIANT 2
+#endif
 #ifndef HN_PARK_AGPR
 #define HN_PARK_AGPR 1
 #endif
@@ -557,8 +560,16 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) sh.frag_load(HS_DZ4 * SLOT_BYTES, s, ah[s], al[s]);
         // dz0 (parked in AGPRs by the last reverse layer) is the B operand of 44 chunks: back into VGPRs once, here
+#if HN_JAC_VARIANT == 0
 #pragma unroll
         for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(bh[s]), "+v"(bl[s]));
+#elif HN_JAC_VARIANT == 2
+#pragma unroll
+        for (int s = 0; s < 16; ++s) asm volatile("" : "+a"(bh[s]), "+a"(bl[s]), "+a"(ah[s]), "+a"(al[s]));
+#elif HN_JAC_VARIANT == 3
+#pragma unroll
+        for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(bh[s]), "+v"(bl[s]), "+a"(ah[s]), "+a"(al[s]));
+#endif
         {
             const int jbase = ws.goff - HB_BWD;   // stream offset of bone 0's first chunk (in flight)
             unsigned rem = nzw & ~1u;
