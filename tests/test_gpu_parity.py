@@ -885,3 +885,42 @@ def test_dual_render_batch_backward(golden):
         e = rel_err(got, want)
         print('batched d loss / d %-7s vs fp32 autograd: %.2e' % (name, e))
         assert e < 3e-3, 'batched d loss / d %s: %.3e' % (name, e)
+
+
+def test_pose_optimisation_recovers_object_translation():
+    """End to end through the product path only: render a target with the true object pose, start from a perturbed
+    translation and run Adam on (To) through NeuSRenderer_fitting.render + loss.backward() (the loop of
+    fitting_single.py:246-291, colour + mask terms).  The loss must fall and the translation must move back."""
+    from honerf_amd import synth
+    from honerf_amd.fitting import render_loss_terms
+    gen = torch.Generator().manual_seed(5)
+    ren = _dual_renderer(32, 0)
+    bt_inv, T_pose, joints = synth.synth_hand_pose(3)
+    Ro_np, _ = synth.synth_obj_pose(2)
+    centre = t(joints).mean(0)
+    B = 128
+    ro = torch.zeros(B, 3)
+    target = centre + 0.12 * torch.randn(B, 3, generator=gen)
+    rd = torch.nn.functional.normalize(target - ro, dim=-1)
+    To_true = centre + torch.tensor([0.02, 0.0, 0.03])
+    t_rand = torch.rand(B, 1, generator=gen)
+    args = (cu(ro), cu(rd), 0.4, 1.5, cu(t(bt_inv)), cu(t(T_pose)), None, cu(t(Ro_np).T.contiguous()))
+    with torch.no_grad():
+        ref = ren.render(*args, cu(To_true), t_rand=cu(t_rand))
+    true_rgb = ref['color_fine'].clone()
+    true_mask = (ref['weight_sum'] > 0.5).float()
+    floor = float(render_loss_terms(ref, true_rgb, true_mask)['loss'])     # the mask term is not 0 at the true pose
+    To = (cu(To_true) + torch.tensor([0.015, -0.01, 0.012], device='cuda')).clone().requires_grad_(True)
+    opt = torch.optim.Adam([To], lr=2e-3)
+    losses, dist0 = [], float((To.detach() - cu(To_true)).norm())
+    for _ in range(60):
+        out = ren.render(*args, To, t_rand=cu(t_rand))
+        loss = render_loss_terms(out, true_rgb, true_mask)['loss']
+        opt.zero_grad()
+        loss.backward()
+        assert torch.isfinite(To.grad).all()
+        opt.step()
+        losses.append(float(loss))
+    dist1 = float((To.detach() - cu(To_true)).norm())
+    print('loss above its value at the true pose: %.4f -> %.4f, |To - To_true| %.4f -> %.4f' % (losses[0] - floor, losses[-1] - floor, dist0, dist1))
+    assert losses[-1] - floor < 0.5 * (losses[0] - floor) and dist1 < 0.7 * dist0
