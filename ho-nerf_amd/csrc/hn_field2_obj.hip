@@ -8,6 +8,9 @@
 #include <stdlib.h>
 
 #include "hn_mlp2.h"
+#ifndef HN_PARK_AGPR
+#define HN_PARK_AGPR 1
+#endif
 
 namespace hn {
 namespace v2 {
@@ -130,6 +133,9 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 ol[2 * t] = st.lo[0];
                 oh[2 * t + 1] = st.hi[1];
                 ol[2 * t + 1] = st.lo[1];
+#if HN_PARK_AGPR
+                asm volatile("" : "+a"(oh[2 * t]), "+a"(ol[2 * t]), "+a"(oh[2 * t + 1]), "+a"(ol[2 * t + 1]));   // as hn_field2_hand.hip: park
+#endif
                 return NoData{};
             };
         };
@@ -142,6 +148,9 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 ol[2 * t] = st.lo[0];
                 oh[2 * t + 1] = st.hi[1];
                 ol[2 * t + 1] = st.lo[1];
+#if HN_PARK_AGPR
+                asm volatile("" : "+a"(oh[2 * t]), "+a"(ol[2 * t]), "+a"(oh[2 * t + 1]), "+a"(ol[2 * t + 1]));   // as hn_field2_hand.hip: park
+#endif
                 if (FULL && !(a.dbg & 1)) sh.tile_store(stash_slot, t, st.vec());
                 return NoData{};
             };
