@@ -11,6 +11,8 @@ backward is the launch sequence
 on the depths the forward produced; the per-field forward values it needs (rgb, alpha) are recomputed with the same
 kernels the forward used.  Nothing here computes on the host; torch only owns the buffers.
 """
+import ctypes
+
 import torch
 
 from . import lib as _lib
@@ -29,8 +31,22 @@ class DualRenderFn(torch.autograd.Function):
         o = renderer._render_raw(rays_o.detach(), rays_d.detach(), near, far, bt_inv.detach(), T_pose.detach(), Ro.detach(),
                                  To.detach(), t_rand)
         ctx.renderer, ctx.near, ctx.far = renderer, float(near), float(far)
+        # what the final evaluation left in the render workspace (rgb / alpha of both fields): copied out now, the
+        # workspace is re-used by the next render
+        hand, obj = renderer.fields()
+        lib = _lib.load()
+        N = rays_o.shape[0] * rays_o.shape[1]
+        S = o['z_vals'].shape[-1]
+        offs = (ctypes.c_size_t * 4)()
+        _lib.check(lib.hn_render_dual_aux_offsets(hand.handle, obj.handle, N, renderer.n_samples, renderer.n_importance,
+                                                  renderer.up_sample_steps, offs),
+                   'hn_render_dual_aux_offsets')
+        ws = renderer._ws.buf
+        n = N * S
+        view = lambda off, cnt: ws[off:off + 4 * cnt].view(torch.float32).clone()
+        aux = (view(offs[0], 3 * n).reshape(n, 3), view(offs[1], 3 * n).reshape(n, 3), view(offs[2], n), view(offs[3], n))
         ctx.save_for_backward(rays_o.detach(), rays_d.detach(), bt_inv.detach(), T_pose.detach(), Ro.detach(), To.detach(),
-                              o['z_vals'])
+                              o['z_vals'], o['sdf_hand'], o['sdf_obj'], o['grad_hand'], o['grad_obj'], *aux)
         return o['color'], o['weight_sum'], o['sdf_hand'], o['sdf_obj'], o['grad_hand'], o['grad_obj'], o['gerr']
 
     @staticmethod
@@ -38,7 +54,8 @@ class DualRenderFn(torch.autograd.Function):
         L = _lib
         lib = L.load()
         ren = ctx.renderer
-        rays_o, rays_d, bt, tp, Ro, To, z = ctx.saved_tensors
+        rays_o, rays_d, bt, tp, Ro, To, z, sv_sdf_h, sv_sdf_o, sv_grad_h, sv_grad_o, sv_rgb_h, sv_rgb_o, sv_al_h, sv_al_o = ctx.saved_tensors
+        reuse = getattr(ren, '_backward_depths', None) is None     # the saved values belong to the forward's depths
         hand, obj = ren.fields()
         F, P = rays_o.shape[0], rays_o.shape[1]
         N, S = F * P, z.shape[-1]
@@ -71,8 +88,18 @@ class DualRenderFn(torch.autograd.Function):
         # forward values of the two branches on the forward's depths
         o_l, d_l = _empty(N, 3, dev=dev), _empty(N, 3, dev=dev)
         L.check(lib.hn_obj_local_fwd(L.ptr(ro), L.ptr(rd), L.ptr(Ro), L.ptr(To), F, P, L.ptr(o_l), L.ptr(d_l), st), 'hn_obj_local_fwd')
-        pts_h, dists, sdf_h, grad_h, rgb_h, alpha_h = field_forward(hand, ro, rd, True)
-        pts_o, _, sdf_o, grad_o, rgb_o, alpha_o = field_forward(obj, o_l, d_l, False)
+        if reuse:      # only the sample positions are recomputed; field values come from the forward pass
+            def positions(o, d):
+                pts, dd = _empty(n, 3, dev=dev), _empty(n, dev=dev)
+                L.check(lib.hn_sample_points(L.ptr(o), L.ptr(d), L.ptr(z), N, S, 1, sample_dist, L.ptr(pts), L.ptr(dd), st), 'hn_sample_points')
+                return pts, dd
+            pts_h, dists = positions(ro, rd)
+            pts_o, _ = positions(o_l, d_l)
+            sdf_h, grad_h, rgb_h, alpha_h = sv_sdf_h.reshape(n), sv_grad_h.reshape(n, 3), sv_rgb_h, sv_al_h
+            sdf_o, grad_o, rgb_o, alpha_o = sv_sdf_o.reshape(n), sv_grad_o.reshape(n, 3), sv_rgb_o, sv_al_o
+        else:
+            pts_h, dists, sdf_h, grad_h, rgb_h, alpha_h = field_forward(hand, ro, rd, True)
+            pts_o, _, sdf_o, grad_o, rgb_o, alpha_o = field_forward(obj, o_l, d_l, False)
 
         # compositing
         g_color = L.f32(g_color).reshape(N, 3) if g_color is not None else torch.zeros(N, 3, device=dev)

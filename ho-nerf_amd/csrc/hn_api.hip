@@ -225,7 +225,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
                             int n_importance, int steps, const float* bt_inv, const float* T_pose, const float* Ro,
                             const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand,
                             float* sdf_obj, float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals,
-                            void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need) {
+                            void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need, size_t* aux_offsets = nullptr) {
     HN_REQUIRE(n_samples >= 2 && n_importance >= 0 && n_frames >= 1 && rpf >= 0, "bad sizes");
     HN_REQUIRE(n_importance == 0 || (steps >= 1 && n_importance % steps == 0), "n_importance must divide into steps");
     HN_REQUIRE(hand->kind == HN_FIELD_HAND && obj->kind == HN_FIELD_OBJ, "field kinds (hand, obj) expected");
@@ -245,13 +245,23 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     float* z = ar.f(N);
     float* pts = ar.f(N * 3);
     float* dists = ar.f(N);
+    const size_t off_rgb_h = ar.used;
     float* rgb_h = ar.f(N * 3);
+    const size_t off_rgb_o = ar.used;
     float* rgb_o = ar.f(N * 3);
+    const size_t off_al_h = ar.used;
     float* al_h = ar.f(N);
+    const size_t off_al_o = ar.used;
     float* al_o = ar.f(N);
     const size_t fws_h = field_ws(hand, (int)N), fws_o = field_ws(obj, (int)N);
     const size_t fws_bytes = fws_h > fws_o ? fws_h : fws_o;
     void* fws = ar.take(fws_bytes);
+    if (aux_offsets != nullptr) {   // where the final evaluation leaves rgb / alpha of both fields (bytes into the workspace)
+        aux_offsets[0] = off_rgb_h;
+        aux_offsets[1] = off_rgb_o;
+        aux_offsets[2] = off_al_h;
+        aux_offsets[3] = off_al_o;
+    }
     if (need != nullptr) {
         *need = ar.used;
         return HN_OK;
@@ -488,6 +498,14 @@ size_t hn_render_dual_workspace_bytes(const hn_field* hand, const hn_field* obj,
                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &need) != HN_OK)
         return 0;
     return need;
+}
+int hn_render_dual_aux_offsets(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples, int n_importance,
+                               int up_sample_steps, size_t* offsets4) {
+    HN_REQUIRE(hand != nullptr && obj != nullptr && offsets4 != nullptr, "null argument");
+    size_t need = 0;
+    return render_dual_impl(hand, obj, nullptr, nullptr, nullptr, 1, n_rays, 0.0, 1.0, n_samples, n_importance,
+                            n_importance > 0 ? up_sample_steps : 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &need, offsets4);
 }
 int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_o, const float* rays_d,
                    const float* t_rand, int n_frames, int rays_per_frame, double near, double far, int n_samples,

@@ -238,6 +238,12 @@ int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_
                    const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand,
                    float* sdf_obj, float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals,
                    void* workspace, size_t workspace_bytes, hn_stream_t stream);
+/* After hn_render_dual the caller's workspace still holds what the final evaluation produced for compositing:
+ * rgb_hand, rgb_obj [n_rays*S,3] and alpha_hand, alpha_obj [n_rays*S] (S = n_samples + 2 n_importance).  Byte offsets
+ * of the four arrays into the workspace, in that order (same sizes and up_sample_steps as the render call) -- the backward pass of a fitting step re-uses them instead
+ * of evaluating both fields again. */
+int hn_render_dual_aux_offsets(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples, int n_importance,
+                               int up_sample_steps, size_t* offsets4);
 
 #ifdef __cplusplus
 }
