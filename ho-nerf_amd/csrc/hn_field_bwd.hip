@@ -13,6 +13,8 @@
 //     second-order terms.
 // This first version favours being checkable step by step over speed: the fitting configurations evaluate ~4e4 samples
 // per step, where the whole adjoint is a few milliseconds.
+#include <type_traits>
+
 #include "hn_common.h"
 
 namespace hn {
@@ -142,46 +144,92 @@ __device__ __forceinline__ float softplus(float z) {   // nn.Softplus(beta=100, 
 }
 __device__ __forceinline__ float sig_from_act(float a) { return 1.f - expf(-BETA * a); }   // sigma'(z) from a = softplus(z)
 
-__global__ void k_softplus(float* __restrict__ z, size_t n) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) z[i] = softplus(z[i]);
+// The tape arrays are multiples of 4 floats only by luck of the widths (193-wide rows are not), so the element-wise
+// kernels process 4 consecutive floats per thread with a scalar tail instead of assuming float4 alignment of rows; the
+// arrays themselves start 256-byte aligned (Arena).
+template <typename F>
+__device__ __forceinline__ void for4(size_t n, F&& f) {
+    const size_t i4 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4;
+    if (i4 + 4 <= n) {
+        f(i4, std::integral_constant<int, 4>{});
+    } else {
+        for (size_t i = i4; i < n; ++i) f(i, std::integral_constant<int, 1>{});
+    }
 }
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+    float v[4];
+    __device__ __forceinline__ static Vec ld(const float* p) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        return {{t.x, t.y, t.z, t.w}};
+    }
+    __device__ __forceinline__ void st(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <>
+struct Vec<1> {
+    float v[1];
+    __device__ __forceinline__ static Vec ld(const float* p) { return {{*p}}; }
+    __device__ __forceinline__ void st(float* p) const { *p = v[0]; }
+};
+#define HN_EW(NAME, ARGS, ...)                                                       \
+    __global__ void NAME ARGS {                                                      \
+        for4(n, [&](size_t i, auto V_) {                                             \
+            constexpr int V = decltype(V_)::value;                                   \
+            __VA_ARGS__                                                              \
+        });                                                                          \
+    }
+HN_EW(k_softplus, (float* __restrict__ z, size_t n), {
+    Vec<V> x = Vec<V>::ld(z + i);
+    for (int k = 0; k < V; ++k) x.v[k] = softplus(x.v[k]);
+    x.st(z + i);
+})
 __global__ void k_bcast_row(const float* __restrict__ w, int width, float scale, float* __restrict__ out, size_t n) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) out[i] = w[i % width] * scale;
 }
 // dz = sigma'(z) * u
-__global__ void k_dz(const float* __restrict__ act, const float* __restrict__ u, float* __restrict__ dz, size_t n) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) dz[i] = sig_from_act(act[i]) * u[i];
-}
-// forward-direction sweep: sb = u * dzb (kept), v = sigma' * dzb (input of the next product; may alias dzb)
-__global__ void k_fwd_dir(const float* __restrict__ act, const float* __restrict__ u, const float* __restrict__ dzb,
-                          float* __restrict__ sb, float* __restrict__ v, size_t n) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) {
-        const float d = dzb[i];
-        sb[i] = u[i] * d;
-        if (v != nullptr) v[i] = sig_from_act(act[i]) * d;
+HN_EW(k_dz, (const float* __restrict__ act, const float* __restrict__ u, float* __restrict__ dz, size_t n), {
+    const Vec<V> a = Vec<V>::ld(act + i), uu = Vec<V>::ld(u + i);
+    Vec<V> o;
+    for (int k = 0; k < V; ++k) o.v[k] = sig_from_act(a.v[k]) * uu.v[k];
+    o.st(dz + i);
+})
+// forward-direction sweep: sb = u * dzb (kept), v = sigma' * dzb (input of the next product)
+HN_EW(k_fwd_dir, (const float* __restrict__ act, const float* __restrict__ u, const float* __restrict__ dzb, float* __restrict__ sb,
+                  float* __restrict__ v, size_t n), {
+    const Vec<V> a = Vec<V>::ld(act + i), uu = Vec<V>::ld(u + i), d = Vec<V>::ld(dzb + i);
+    Vec<V> o1, o2;
+    for (int k = 0; k < V; ++k) {
+        o1.v[k] = uu.v[k] * d.v[k];
+        o2.v[k] = sig_from_act(a.v[k]) * d.v[k];
     }
-}
+    o1.st(sb + i);
+    if (v != nullptr) o2.st(v + i);
+})
 // zb = sigma' * ab + sigma'' * sb
-__global__ void k_zb(const float* __restrict__ act, const float* __restrict__ ab, const float* __restrict__ sb,
-                     float* __restrict__ zb, size_t n) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) {
-        const float s = sig_from_act(act[i]);
-        zb[i] = s * ab[i] + BETA * s * (1.f - s) * sb[i];
+HN_EW(k_zb, (const float* __restrict__ act, const float* __restrict__ ab, const float* __restrict__ sb, float* __restrict__ zb, size_t n), {
+    const Vec<V> a = Vec<V>::ld(act + i), x = Vec<V>::ld(ab + i), y = Vec<V>::ld(sb + i);
+    Vec<V> o;
+    for (int k = 0; k < V; ++k) {
+        const float s = sig_from_act(a.v[k]);
+        o.v[k] = s * x.v[k] + BETA * s * (1.f - s) * y.v[k];
     }
-}
-__global__ void k_relu(float* __restrict__ x, size_t n) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) x[i] = fmaxf(x[i], 0.f);
-}
-__global__ void k_relu_mask(const float* __restrict__ act, float* __restrict__ xb, size_t n) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i < n) xb[i] = act[i] > 0.f ? xb[i] : 0.f;
-}
+    o.st(zb + i);
+})
+HN_EW(k_relu, (float* __restrict__ x, size_t n), {
+    Vec<V> t = Vec<V>::ld(x + i);
+    for (int k = 0; k < V; ++k) t.v[k] = fmaxf(t.v[k], 0.f);
+    t.st(x + i);
+})
+HN_EW(k_relu_mask, (const float* __restrict__ act, float* __restrict__ xb, size_t n), {
+    const Vec<V> a = Vec<V>::ld(act + i);
+    Vec<V> t = Vec<V>::ld(xb + i);
+    for (int k = 0; k < V; ++k) t.v[k] = a.v[k] > 0.f ? t.v[k] : 0.f;
+    t.st(xb + i);
+})
+#undef HN_EW
 // rgb = sigmoid(zc); xb = g_rgb * rgb (1 - rgb)
 __global__ void k_rgb_seed(const float* __restrict__ zc, const float* __restrict__ g_rgb, float* __restrict__ xb, size_t n) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -618,13 +666,13 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
             const int K = l == 0 ? Din : f->sdf_in[l];
             cx.nt(b.a[l], l == 0 ? DP : K, K, W[l], LW[l], 0, width(l), Bv[l], 1.f, b.a[l + 1], width(l), false);
         }
-        hipLaunchKernelGGL(k_softplus, g1(N * width(l)), dim3(256), 0, s, b.a[l + 1], N * width(l));
+        hipLaunchKernelGGL(k_softplus, g1((N * width(l) + 3) / 4), dim3(256), 0, s, b.a[l + 1], N * width(l));
     }
     cx.nt(b.a[8], H, H, W[8], LW[8], 0, 257, Bv[8], 1.f, b.z8, 257, false);
     // 2. reverse sweep ------------------------------------------------------------------------------------------
     hipLaunchKernelGGL(k_bcast_row, g1(N * H), dim3(256), 0, s, W[8], H, inv_scale, b.u[7], N * H);
     for (int l = 7; l >= 0; --l) {
-        hipLaunchKernelGGL(k_dz, g1(N * width(l)), dim3(256), 0, s, b.a[l + 1], b.u[l], b.dz[l], N * width(l));
+        hipLaunchKernelGGL(k_dz, g1((N * width(l) + 3) / 4), dim3(256), 0, s, b.a[l + 1], b.u[l], b.dz[l], N * width(l));
         if (l > 0) {   // u_{l-1} = dz_l * Wh_l
             if (l == 4)
                 cx.nn(b.dz[4], width(4), width(4), W[4], LW[4], 0, H4, rs2, b.u[3], H4, false);
@@ -652,20 +700,20 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     }
     cx.nt(b.z8 + 1, 257, H, C[0], LC0, o_f, H, nullptr, 1.f, b.c[1], H, true);
     cx.nt(b.gin, 27, 27, C[0], LC0, o_g, H, nullptr, 1.f, b.c[1], H, true);
-    hipLaunchKernelGGL(k_relu, g1(N * H), dim3(256), 0, s, b.c[1], N * H);
+    hipLaunchKernelGGL(k_relu, g1((N * H + 3) / 4), dim3(256), 0, s, b.c[1], N * H);
     for (int l = 1; l <= 3; ++l) {
         cx.nt(b.c[l], H, H, C[l], H, 0, H, Cb[l], 1.f, b.c[l + 1], H, false);
-        hipLaunchKernelGGL(k_relu, g1(N * H), dim3(256), 0, s, b.c[l + 1], N * H);
+        hipLaunchKernelGGL(k_relu, g1((N * H + 3) / 4), dim3(256), 0, s, b.c[l + 1], N * H);
     }
     cx.nt(b.c[4], H, H, C[4], H, 0, 3, Cb[4], 1.f, b.xb, 3, false);
     hipLaunchKernelGGL(k_rgb_seed, g1(N * 3), dim3(256), 0, s, b.xb, g_rgb, b.xb, N * 3);
     cx.nn(b.xb, 3, 3, C[4], H, 0, H, 1.f, b.cb[0], H, false);
-    hipLaunchKernelGGL(k_relu_mask, g1(N * H), dim3(256), 0, s, b.c[4], b.cb[0], N * H);
+    hipLaunchKernelGGL(k_relu_mask, g1((N * H + 3) / 4), dim3(256), 0, s, b.c[4], b.cb[0], N * H);
     int cur = 0;
     for (int l = 3; l >= 1; --l) {
         cx.nn(b.cb[cur], H, H, C[l], H, 0, H, 1.f, b.cb[cur ^ 1], H, false);
         cur ^= 1;
-        hipLaunchKernelGGL(k_relu_mask, g1(N * H), dim3(256), 0, s, b.c[l], b.cb[cur], N * H);
+        hipLaunchKernelGGL(k_relu_mask, g1((N * H + 3) / 4), dim3(256), 0, s, b.c[l], b.cb[cur], N * H);
     }
     const float* cb1 = b.cb[cur];
     cx.nn(cb1, H, H, C[0], LC0, 0, Din, 1.f, b.Xb, DP, false);                    // Xb starts as the colour net's share
@@ -690,7 +738,7 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     cx.nt(b.GXb, DP, Din, W[0], LW[0], 0, H, nullptr, 1.f, b.dzb, H, false);
     for (int l = 1; l <= 7; ++l) {
         const int wprev = width(l - 1);
-        hipLaunchKernelGGL(k_fwd_dir, g1(N * wprev), dim3(256), 0, s, b.a[l], b.u[l - 1], b.dzb, b.sb[l - 1], b.v, N * wprev);
+        hipLaunchKernelGGL(k_fwd_dir, g1((N * wprev + 3) / 4), dim3(256), 0, s, b.a[l], b.u[l - 1], b.dzb, b.sb[l - 1], b.v, N * wprev);
         if (l == 4) {
             cx.nt(b.v, H4, H4, W[4], LW[4], 0, H, nullptr, rs2, b.dzb, H, false);
             cx.nt(b.GXb, DP, Din, W[4], LW[4], H4, H, nullptr, rs2, b.dzb, H, true);
@@ -698,11 +746,11 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
             cx.nt(b.v, wprev, wprev, W[l], LW[l], 0, width(l), nullptr, 1.f, b.dzb, width(l), false);
         }
     }
-    hipLaunchKernelGGL(k_fwd_dir, g1(N * H), dim3(256), 0, s, b.a[8], b.u[7], b.dzb, b.sb[7], (float*)nullptr, N * H);
+    hipLaunchKernelGGL(k_fwd_dir, g1((N * H + 3) / 4), dim3(256), 0, s, b.a[8], b.u[7], b.dzb, b.sb[7], (float*)nullptr, N * H);
     // 5. first-order reverse sweep with the second-order sources ---------------------------------------------------
     cx.nn(b.z8b, 257, 257, W[8], LW[8], 0, H, 1.f, b.ab, H, false);
     for (int l = 7; l >= 0; --l) {
-        hipLaunchKernelGGL(k_zb, g1(N * width(l)), dim3(256), 0, s, b.a[l + 1], b.ab, b.sb[l], b.zb, N * width(l));
+        hipLaunchKernelGGL(k_zb, g1((N * width(l) + 3) / 4), dim3(256), 0, s, b.a[l + 1], b.ab, b.sb[l], b.zb, N * width(l));
         if (l == 4) {
             cx.nn(b.zb, H, H, W[4], LW[4], H4, Din, rs2, b.Xb, DP, true);
             cx.nn(b.zb, H, H, W[4], LW[4], 0, H4, rs2, b.ab, H4, false);
