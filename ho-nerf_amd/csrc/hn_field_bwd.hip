@@ -395,7 +395,7 @@ __global__ void k_hand_feat(const float* __restrict__ pts, int n, int ppf, int n
     if (i >= n) return;
     const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
     const FrameRef fr = frame_of(i, ppf, nf, bt_inv, T_pose);
-    for (int b = 0; b < N_BONES; ++b) {
+    for (int b = blockIdx.y; b <= (int)blockIdx.y; ++b) {   // one bone per grid row: 21 x the parallelism of a loop
         const BoneQ q = bone_q(p, fr.M + 16 * b, fr.T + 3 * b, b);
         float* o = X + (size_t)i * ld + b * 66;
         bone_features(q, [&](int f, int, float phi, float, float) { o[f] = phi * q.h; });
@@ -409,7 +409,7 @@ __global__ void k_hand_push(const float* __restrict__ pts, int n, int ppf, int n
     const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
     const float gb[3] = {gbar[3 * (size_t)i], gbar[3 * (size_t)i + 1], gbar[3 * (size_t)i + 2]};
     const FrameRef fr = frame_of(i, ppf, nf, bt_inv, T_pose);
-    for (int b = 0; b < N_BONES; ++b) {
+    for (int b = blockIdx.y; b <= (int)blockIdx.y; ++b) {   // one bone per grid row: 21 x the parallelism of a loop
         const float* m = fr.M + 16 * b;
         const BoneQ q = bone_q(p, m, fr.T + 3 * b, b);
         const float w[3] = {m[0] * gb[0] + m[1] * gb[1] + m[2] * gb[2], m[4] * gb[0] + m[5] * gb[1] + m[6] * gb[2],
@@ -476,7 +476,7 @@ __global__ void k_hand_pull(const float* __restrict__ pts, int n, int ppf, int n
         gb[1] = gbar[3 * (size_t)i + 1];
         gb[2] = gbar[3 * (size_t)i + 2];
     }
-    for (int b = 0; b < N_BONES; ++b) {
+    for (int b = blockIdx.y; b <= (int)blockIdx.y; ++b) {   // one bone per grid row: 21 x the parallelism of a loop
         const float* m = fr.M + 16 * b;
         const BoneQ q = bone_q(p, m, fr.T + 3 * b, b);
         const float* g = G + (size_t)i * ld + b * 66;
@@ -532,11 +532,12 @@ __global__ void k_hand_pull(const float* __restrict__ pts, int n, int ppf, int n
             spread(hv, p, m, fr.frame, b, gp, g_bt, g_T, uniform, lane);
         }
     }
-    if (valid) {
+    if (valid) {   // the 21 grid rows add their bone's share (the caller zeroes `out` unless it accumulates)
         float* o = out + 3 * (size_t)i;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = accumulate ? o[c] + gp[c] : gp[c];
+        for (int c = 0; c < 3; ++c) atomicAdd(o + c, gp[c]);
     }
+    (void)accumulate;
 }
 
 // ---- orchestration ---------------------------------------------------------------------------------------------
@@ -658,7 +659,7 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     if (obj)
         hipLaunchKernelGGL(k_enc3<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.X, DP);
     else
-        hipLaunchKernelGGL(k_hand_feat, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.X, DP);
+        hipLaunchKernelGGL(k_hand_feat, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.X, DP);
     b.a[0] = b.X;
     for (int l = 0; l < 8; ++l) {
         if (l == 4) {
@@ -684,11 +685,13 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     }
     cx.nn(b.dz[0], H, H, W[0], LW[0], 0, Din, 1.f, b.GX, DP, false);
     cx.nn(b.dz[4], H, H, W[4], LW[4], H4, Din, rs2, b.GX, DP, true);
-    if (obj)
+    if (obj) {
         hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.GX, DP, nullptr, 0, nullptr, b.g, 0);
-    else
-        hipLaunchKernelGGL(k_hand_pull<0>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX, DP,
+    } else {
+        HN_CHECK_HIP(hipMemsetAsync(b.g, 0, N * 3 * sizeof(float), s));
+        hipLaunchKernelGGL(k_hand_pull<0>, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX, DP,
                            (const float*)nullptr, b.g, 0, (float*)nullptr, (float*)nullptr);
+    }
     // 3. colour network forward + backward ------------------------------------------------------------------------
     const float* const* C = f->raw_col_w;
     const float* const* Cb = f->raw_col_b;
@@ -736,7 +739,7 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     if (obj)
         hipLaunchKernelGGL(k_enc3_push<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, b.gb, b.GXb, DP);
     else
-        hipLaunchKernelGGL(k_hand_push, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.gb, b.GXb, DP);
+        hipLaunchKernelGGL(k_hand_push, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.gb, b.GXb, DP);
     cx.nt(b.GXb, DP, Din, W[0], LW[0], 0, H, nullptr, 1.f, b.dzb, H, false);
     for (int l = 1; l <= 7; ++l) {
         const int wprev = width(l - 1);
@@ -766,9 +769,10 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     if (obj) {
         hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.Xb, DP, b.GX, DP, b.gb, g_pts, 0);
     } else {   // the pose gradients accumulate into the caller's (zeroed) g_bt_inv / g_T_pose
-        hipLaunchKernelGGL(k_hand_pull<1>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.Xb, DP,
+        HN_CHECK_HIP(hipMemsetAsync(g_pts, 0, N * 3 * sizeof(float), s));
+        hipLaunchKernelGGL(k_hand_pull<1>, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.Xb, DP,
                            (const float*)nullptr, g_pts, 0, g_bt_inv, g_T_pose);
-        hipLaunchKernelGGL(k_hand_pull<2>, dim3((n + 63) / 64), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX, DP,
+        hipLaunchKernelGGL(k_hand_pull<2>, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX, DP,
                            b.gb, g_pts, 1, g_bt_inv, g_T_pose);
     }
     HN_LAUNCH_CHECK();
