@@ -12,8 +12,17 @@ one rank per GPU) every rank renders its own frame (frame-sharded, no data-path
 collective): weak scaling, value = all ranks' ray-samples / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel: the fused
-hand field kernel, MFMA-bound) and `cpu_baseline` (the CPU oracle -- a port of the
-reference's PyTorch path -- timed on this box's host cores on a bounded crop).
+hand field kernel, MFMA-bound), `cpu_baseline` (the CPU oracle -- a port of the
+reference's PyTorch path -- timed on this box's host cores on a bounded crop) and
+`fitting`: the second half of BASELINE's metric, frames/sec of the pose-fitting loops
+(configs[2..4]): one optimisation step of fitting_single (C3/C4: 196 rays x 192 shared
+depths, both fields, forward + losses + backward into the pose parameters + Adam) and of
+fitting_video (C5: a window of 4 frames x 40 rays, fit type '1234' incl. the stable
+loss), every rank fitting its own frame / window (frame-sharded, weak scaling).
+
+`--gpus N` without a torch.distributed environment starts the N ranks itself
+(`python -m torch.distributed.run`, as a child process, before anything touches the
+GPU) and relays rank 0's line.
 """
 import argparse
 import json
@@ -88,6 +97,117 @@ def cpu_baseline(sdf, col, scene, crop=96, threads=32):
                       % (crop, crop, n_done * N_SAMPLES, dt)}
 
 
+# ---- the fitting loops (BASELINE configs[2..4]) --------------------------------------------------------------
+FIT_RAYS, FIT_N, FIT_IMP = 196, 64, 64            # fit_confs/fit_1_8views.conf:24, 86-92 -> 192 shared depths
+VID_FRAMES, VID_RAYS = 4, 40                      # fitting_video.py:146-149, 264-266
+STEPS_PER_FRAME = {'1': 30 * 8, '12': 25 * 8}     # fitting_single.py:124-132, 200-201
+OBJ_FLOP_PER_SAMPLE = 2.0 * (2 * 524544 + 292864)
+# algorithmic work of one step: the final evaluation of both fields (1 sdf forward + 1 input-gradient sweep + 1 colour
+# forward each) + its adjoint (colour backward + forward-direction sweep + second reverse sweep = the same product
+# count again, + the 257-row W8) + the sdf-only evaluations of the importance rounds (64 + 3 x 16 per ray and field)
+HAND_SDF_FLOP, OBJ_SDF_FLOP = 2.0 * 1234176, 2.0 * 524544
+
+
+def fit_step_flop(n_rays, S=FIT_N + 2 * FIT_IMP):
+    final = n_rays * S * (HAND_FLOP_PER_SAMPLE + OBJ_FLOP_PER_SAMPLE)
+    adjoint = n_rays * S * (HAND_FLOP_PER_SAMPLE + OBJ_FLOP_PER_SAMPLE + 2.0 * 2 * 257 * 256)
+    sampling = n_rays * (FIT_N + 3 * (FIT_IMP // 4)) * (HAND_SDF_FLOP + OBJ_SDF_FLOP)
+    return final + adjoint + sampling
+
+
+def build_fit(dev, seed, n_frames, rays, precision):
+    """Both fields at conf size, a synthetic frame (window) with 8 ring cameras and the rigid pose chain."""
+    from honerf_amd import fitting as F, synth
+    from honerf_amd.nets import (SDFNetwork, RenderingNetwork, SDFNetwork_OBJ, RenderingNetwork_OBJ, SingleVarianceNetwork)
+    from honerf_amd.renderer import NeuSRenderer_fitting
+    from honerf_amd.renderer_batch import NeuSRenderer_fitting as Batched
+    nets = [SDFNetwork(use_batch=n_frames > 1), SingleVarianceNetwork(0.3), RenderingNetwork(use_gradients=True),
+            SDFNetwork_OBJ(), SingleVarianceNetwork(0.3), RenderingNetwork_OBJ()]
+    for m, sd in zip((nets[0], nets[2], nets[3], nets[5]), (21, 22, 11, 12)):
+        m.reset_parameters(sd)
+    nets = [m.to(dev) for m in nets]
+    ren = (Batched if n_frames > 1 else NeuSRenderer_fitting)(*nets, FIT_N, FIT_IMP, 0, 4, 1.0)
+    ren.precision = precision
+    bt, tp, j = synth.synth_hand_pose(seed)
+    R, tt = synth.synth_obj_pose(seed + 1, center=tuple(j[9] + np.array([0.02, 0.0, 0.01])))
+    rng = np.random.RandomState(seed)
+    u = rng.standard_normal((2000, 3))
+    verts = (u / np.linalg.norm(u, axis=1, keepdims=True) * 0.025).astype(np.float32)
+    rep = lambda a: np.repeat(a[None], n_frames, 0)
+    chain = F.RigidPoseChain(rep(bt), rep(tp), rep(j), rep(R), rep(tt), verts, device=dev)
+    views = F.synthetic_views(8, n_frames, rays, seed, j[9], device=dev)
+    return ren, nets, chain, views, torch.from_numpy(verts).to(dev)[None].expand(n_frames, -1, -1).contiguous()
+
+
+def time_fit(dev, dist, rank, world, precision, steps, warmup):
+    """ms per optimisation step of fitting_single ('1' and '12') and of a fitting_video window ('1234'), max over ranks."""
+    from honerf_amd import fitting as F
+    res = {}
+
+    def timed(fn):
+        for i in range(warmup):
+            fn(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(warmup + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt / steps
+
+    ren, nets, chain, views, _ = build_fit(dev, 40 + rank, 1, FIT_RAYS, precision)
+    opt = torch.optim.Adam(chain.param_groups(video=False))
+    for ft in ('1', '12'):
+        sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, ft))
+        res['single_' + ft] = {'ms_per_step': sec * 1e3, 'steps_per_frame': STEPS_PER_FRAME[ft],
+                               'frames_per_s': world / (STEPS_PER_FRAME[ft] * sec)}
+    single = (ren, nets, chain, views)
+    renb, netsb, chainb, viewsb, ov = build_fit(dev, 60 + rank, VID_FRAMES, VID_RAYS, precision)
+    optb = torch.optim.Adam(chainb.param_groups(video=True))
+    idx = list(range(VID_FRAMES))
+    sec = timed(lambda i: F.fit_step(renb, viewsb[i % 8], chainb, optb, NEAR, FAR, '1234', index=idx, smooth_ends=(True, False),
+                                     obj_verts_for_stable=ov))
+    # one window = 4 sub-iterations x 8 views (fitting_video.py:211-212); a sequence of n frames = 5 x (n - 3) windows
+    res['video_1234'] = {'ms_per_step': sec * 1e3, 'steps_per_window': 32, 'windows_per_s': world / (32 * sec),
+                         'frames_per_s_32frame_sequence': world * 32 / (5 * 29 * 32 * sec)}
+    return res, single
+
+
+def cpu_fit_baseline(single, rays=49, threads=32):
+    """One fitting_single step of the CPU oracle (autograd through oracle.render.render_dual + the same losses) on
+    `rays` of the 196 rays (the step's cost is linear in the ray count)."""
+    from oracle.nets import Field
+    from oracle import render as orr
+    from honerf_amd import fitting as F
+    ren, nets, chain, views = single
+    cores = min(threads, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    cpu = lambda v: v.detach().cpu()
+    sd = lambda m: {k: cpu(v) for k, v in m.state_dict().items()}
+    hand = Field('hand', sd(nets[0]), sd(nets[2]), 0.3)
+    obj = Field('obj', sd(nets[3]), sd(nets[5]), 0.3)
+    v = views[0]
+    pose = {k: cpu(x) for k, x in chain().items()}
+    bt = pose['bt_inv'][0].clone().requires_grad_(True)
+    Ro = pose['obj_r'][0].T.contiguous().clone().requires_grad_(True)
+    To = pose['obj_t'][0].clone().requires_grad_(True)
+    o, d = orr.rays_from_xy(cpu(v['xy'])[:rays], cpu(v['cam']['R'])[0], cpu(v['cam']['T'])[0], cpu(v['cam']['focal'])[0],
+                            cpu(v['cam']['principal'])[0])
+    t0 = time.perf_counter()
+    out = orr.render_dual(hand, obj, o, d, NEAR, FAR, torch.rand(rays, 1), FIT_N, FIT_IMP, 4, bt, pose['T_pose_21'][0], Ro, To)
+    terms = F.render_loss_terms(out, cpu(v['true_rgb'])[:rays], cpu(v['true_mask'])[:rays], '12')
+    terms['loss'].backward()
+    dt = time.perf_counter() - t0
+    return {'value': 1.0 / (dt * FIT_RAYS / rays), 'unit': 'fitting_single steps/s (196 rays)', 'cores': cores, 'kind': 'port',
+            'sample': 'one step (render + losses + backward) on %d of the 196 rays: %.1f s, scaled by 196/%d' % (rays, dt, rays)}
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of the dominant kernel, from the committed PMC summary of this same workload
     (profiles/r*/pmc_bench_*.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes,
@@ -105,6 +225,16 @@ def pmc_traffic(kernel):
     return best
 
 
+def spawn_command(n_gpus, argv):
+    """The launch line of the driver contract: one rank per GPU of one node over RCCL, rendezvous on 127.0.0.1."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -114,9 +244,19 @@ def main():
     ap.add_argument('--cpu-crop', type=int, default=96)
     ap.add_argument('--no-culled', action='store_true', help='skip the secondary culled measurement')
     ap.add_argument('--precision', default='f16x3', choices=['f16x3', 'fp32'])
+    ap.add_argument('--no-fitting', action='store_true', help='skip the fitting-loop measurements')
+    ap.add_argument('--fit-steps', type=int, default=10)
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # No torch.distributed environment: start the N ranks ourselves, as a CHILD process, before this process has
+        # made any HIP call (a process that has initialised the GPU must never exec or be replaced), and relay its output.
+        import subprocess
+        sys.exit(subprocess.call(spawn_command(args.gpus, sys.argv[1:])))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node %d\n' % (args.gpus, world, args.gpus))
+        sys.exit(2)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
@@ -210,6 +350,20 @@ def main():
         peak, kname, dtype = PEAK_F32_MFMA_TFLOPS, 'hn::k_field_hand<true>', 'f32'
 
     traffic, traffic_src = pmc_traffic(kname)
+    fitting = None
+    if not args.no_fitting and args.precision == 'f16x3':
+        fitting, single = time_fit(dev, dist, rank, world, args.precision, args.fit_steps, 3)
+        sec = fitting['single_12']['ms_per_step'] * 1e-3
+        flop = fit_step_flop(FIT_RAYS)
+        fitting['roofline'] = {'bound': 'mfma', 'what': 'one fitting_single step (fit type 12), all kernels', 'flop_per_step': flop,
+                               'achieved': flop / sec / 1e12, 'peak': PEAK_F16_MFMA_TFLOPS / 3.0, 'unit': 'TFLOP/s',
+                               'frac': flop / sec / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0)}
+        fitting['n_gpus'] = world
+        fitting['config'] = ('C3/C4: fitting_single, %d rays x %d shared depths, both fields, 8 synthetic views, rigid pose chain; '
+                             'C5: fitting_video window, %d frames x %d rays, fit type 1234; one frame / window per GPU'
+                             % (FIT_RAYS, FIT_N + 2 * FIT_IMP, VID_FRAMES, VID_RAYS))
+        if rank == 0 and not args.no_cpu_baseline:
+            fitting['cpu_baseline'] = cpu_fit_baseline(single)
     if rank == 0:
         res = {
             'metric': 'ray-samples/sec/GPU (512x512x64)', 'value': value, 'unit': 'ray-samples/s',
@@ -226,6 +380,8 @@ def main():
                          'mfma_peak_tflops': PEAK_F16_MFMA_TFLOPS if args.precision == 'f16x3' else PEAK_F32_MFMA_TFLOPS},
             'weight_sum_mean': float(out['weight_sum'].mean()),
         }
+        if fitting is not None:
+            res['fitting'] = fitting
         if culled is not None:
             res['value_culled'] = culled   # rank 0's frame, far-field early-out on (bit-identical output)
         if not args.no_cpu_baseline:

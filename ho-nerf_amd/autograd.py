@@ -77,7 +77,7 @@ class DualRenderFn(torch.autograd.Function):
             L.check(lib.hn_sample_points(L.ptr(o), L.ptr(d), L.ptr(z), N, S, 1, sample_dist, L.ptr(pts), L.ptr(dists), st), 'hn_sample_points')
             sdf, grad, rgb = _empty(n, dev=dev), _empty(n, 3, dev=dev), _empty(n, 3, dev=dev)
             wsb = lib.hn_field_workspace_bytes(field.handle, n)
-            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+            ws = ren._ws_bwd.get(max(wsb, 16), dev)
             L.check(lib.hn_field_eval(field.handle, L.ptr(pts), L.ptr(d), n, S, L.ptr(bt) if frames else None,
                                       L.ptr(tp) if frames else None, F if frames else 1, P * S if frames else n, L.ptr(sdf),
                                       L.ptr(grad), L.ptr(rgb), None, L.ptr(ws), wsb, st), 'hn_field_eval')
@@ -117,14 +117,14 @@ class DualRenderFn(torch.autograd.Function):
                 gs += L.f32(g_sdf_out).reshape(n)
             if g_grad_out is not None:
                 gg += L.f32(g_grad_out).reshape(n, 3)
-            if g_eik is not None and float(g_eik) != 0.0:   # gradient_error = mean((|g| - 1)^2)
+            if g_eik is not None:   # gradient_error = mean((|g| - 1)^2); d|g|/dg = 0 at g = 0, as torch's norm backward
                 nrm = grad.norm(dim=-1, keepdim=True)
-                gg += (2.0 * float(g_eik) / n) * (nrm - 1.0) * grad / nrm
+                gg += (2.0 / n) * g_eik.to(torch.float32) * (nrm - 1.0) * grad / nrm.clamp_min(1e-30)
             g_pts, g_dir = _empty(n, 3, dev=dev), _empty(N, 3, dev=dev)
             g_bt = torch.zeros(F, 21, 4, 4, device=dev) if frames else None
             g_tp = torch.zeros(F, 21, 3, device=dev) if frames else None
             need = lib.hn_field_bwd_workspace_bytes(field.handle, n)
-            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            ws = ren._ws_bwd.get(need, dev)      # grow-only, shared by both fields and re-used across steps
             L.check(lib.hn_field_eval_bwd(field.handle, L.ptr(pts), L.ptr(d), n, S, L.ptr(bt) if frames else None,
                                           L.ptr(tp) if frames else None, F if frames else 1, P * S if frames else n, L.ptr(gs),
                                           L.ptr(gg), L.ptr(g_rgb), L.ptr(g_pts), L.ptr(g_dir), L.ptr(g_bt), L.ptr(g_tp), L.ptr(ws),
@@ -147,3 +147,49 @@ class DualRenderFn(torch.autograd.Function):
 
         sv = ctx.saved_tensors
         return (g_rays_o, g_rays_d, like(g_bt, sv[2]), like(g_tp, sv[3]), like(g_Ro, sv[4]), like(g_To, sv[5]), None, None, None, None)
+
+
+class HandSdfFn(torch.autograd.Function):
+    """`sdf_network_hand.sdf(pts, bt_inv, T_pose_21)` with gradients into the points and the bone transforms: the hand
+    SDF on the object's vertices in get_stable_loss_cross (utils/renderer_batch.py:318-371, back-propagated by
+    fitting_video.py:340-342).  pts [F,M,3], bt_inv [F,21,4,4], T_pose [F,21,3] -> sdf [F,M].  Forward = one
+    hn_field_sdf launch; backward = hn_field_eval_bwd in its sdf-only form (g_grad = g_rgb = NULL)."""
+
+    @staticmethod
+    def forward(ctx, pts, bt_inv, T_pose, field, ws):
+        L = _lib
+        lib = L.load()
+        F, M = pts.shape[0], pts.shape[1]
+        p = L.f32(pts).reshape(F * M, 3)
+        bt, tp = L.f32(bt_inv).reshape(F, 21, 4, 4), L.f32(T_pose).reshape(-1, 21, 3)
+        if tp.shape[0] != F:
+            tp = tp.expand(F, 21, 3).contiguous()
+        n = F * M
+        out = _empty(n, dev=p.device)
+        need = lib.hn_field_workspace_bytes(field.handle, n)
+        buf = ws.get(max(need, 16), p.device)
+        L.check(lib.hn_field_sdf(field.handle, L.ptr(p), n, L.ptr(bt), L.ptr(tp), F, M, L.ptr(out), L.ptr(buf), need, L.stream_ptr()),
+                'hn_field_sdf')
+        ctx.field, ctx.ws, ctx.shapes = field, ws, (pts.shape, bt_inv.shape, T_pose.shape)
+        ctx.save_for_backward(p, bt, tp)
+        return out.reshape(F, M)
+
+    @staticmethod
+    def backward(ctx, g_sdf):
+        L = _lib
+        lib = L.load()
+        p, bt, tp = ctx.saved_tensors
+        F = bt.shape[0]
+        n = p.shape[0]
+        dev = p.device
+        gs = L.f32(g_sdf).reshape(n)
+        g_pts = _empty(n, 3, dev=dev)
+        g_bt, g_tp = torch.zeros(F, 21, 4, 4, device=dev), torch.zeros(F, 21, 3, device=dev)
+        need = lib.hn_field_bwd_workspace_bytes(ctx.field.handle, n)
+        buf = ctx.ws.get(need, dev)
+        L.check(lib.hn_field_eval_bwd(ctx.field.handle, L.ptr(p), None, n, 1, L.ptr(bt), L.ptr(tp), F, n // F, L.ptr(gs), None, None,
+                                      L.ptr(g_pts), None, L.ptr(g_bt), L.ptr(g_tp), L.ptr(buf), need, L.stream_ptr()),
+                'hn_field_eval_bwd')
+        sp, sb, st = ctx.shapes
+        g_tp = g_tp.reshape(st) if g_tp.numel() == int(torch.Size(st).numel()) else g_tp.sum(0).reshape(st)
+        return g_pts.reshape(sp), g_bt.reshape(sb), g_tp, None, None

@@ -1,6 +1,7 @@
 // extern "C" surface of libhonerf (include/honerf.h) and the launch sequences of the two
 // whole renders.  Nothing here allocates or synchronises (except field create/destroy).
 #include <stdarg.h>
+#include <atomic>
 #include <string.h>
 
 #include "hn_common.h"
@@ -92,17 +93,33 @@ struct Arena {
     float* f(size_t n) { return reinterpret_cast<float*>(take(n * sizeof(float))); }
 };
 
-static int g_cus = -1;
-static int device_cus() {
-    if (g_cus < 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            g_cus = 0;
-        else
-            g_cus = prop.multiProcessorCount;
+constexpr int MAX_DEVICES = 64;
+static std::atomic<int> g_cus[MAX_DEVICES];   // 0 = not queried yet
+int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
+int device_cus() {
+    const int dev = current_device();
+    if (dev < 0) return 0;
+    const int slot = dev % MAX_DEVICES;
+    int v = g_cus[slot].load(std::memory_order_relaxed);
+    if (v == 0 || dev >= MAX_DEVICES) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        v = n;
+        if (dev < MAX_DEVICES) g_cus[slot].store(v, std::memory_order_relaxed);
     }
-    return g_cus;
+    return v;
+}
+int ensure_dynamic_lds(const void* kernel, int bytes, void* mask_atomic_u64) {
+    auto* mask = reinterpret_cast<std::atomic<uint64_t>*>(mask_atomic_u64);
+    const int dev = current_device();
+    const uint64_t bit = (dev >= 0 && dev < MAX_DEVICES) ? (uint64_t(1) << dev) : 0;
+    if (bit != 0 && (mask->load(std::memory_order_acquire) & bit)) return HN_OK;
+    HN_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (bit != 0) mask->fetch_or(bit, std::memory_order_release);
+    return HN_OK;
 }
 
 static size_t field_ws(const hn_field* f, int n_pts) {
@@ -339,9 +356,32 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
                    size_t workspace_bytes, hipStream_t s);
+int hand_features(const float*, int, const float*, const float*, int, int, float*, float*, float*, hipStream_t);
+size_t color_forward_workspace_bytes(const hn_field* f, int n);
+int color_forward(const hn_field*, const float*, const float*, const float*, const float*, int, float*, void*, size_t, hipStream_t);
+int nearest_masked(const float*, int, int, const unsigned char*, const unsigned char*, unsigned char*, int*, hipStream_t);
 }
 }
 extern "C" {
+
+int hn_hand_features(const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame,
+                     float* xyz_feature, float* r, float* h, hn_stream_t stream) {
+    return hn::bwd::hand_features(pts, n_pts, bt_inv, T_pose, n_frames, pts_per_frame, xyz_feature, r, h, (hipStream_t)stream);
+}
+size_t hn_color_forward_workspace_bytes(const hn_field* f, int n_pts) {
+    return (f == nullptr || n_pts <= 0) ? 0 : hn::bwd::color_forward_workspace_bytes(f, n_pts);
+}
+int hn_color_forward(const hn_field* f, const float* x, const float* view_dirs, const float* feature_vectors,
+                     const float* normals, int n_pts, float* rgb, void* workspace, size_t workspace_bytes, hn_stream_t stream) {
+    HN_REQUIRE(f != nullptr, "null field");
+    return hn::bwd::color_forward(f, x, view_dirs, feature_vectors, normals, n_pts, rgb, workspace, workspace_bytes,
+                                  (hipStream_t)stream);
+}
+int hn_nearest_masked(const float* pts, int n_verts, int n_sets, const unsigned char* query_mask, const unsigned char* cand_mask,
+                      unsigned char* selected, int32_t* nearest, hn_stream_t stream) {
+    return hn::bwd::nearest_masked(pts, n_verts, n_sets, query_mask, cand_mask, selected, nearest, (hipStream_t)stream);
+}
+
 
 int hn_version(void) { return HN_VERSION; }
 const char* hn_last_error(void) { return g_err; }

@@ -28,6 +28,18 @@ void set_error(const char* fmt, ...);
         }                                      \
     } while (0)
 #define HN_LAUNCH_CHECK() HN_CHECK_HIP(hipGetLastError())
+#define HN_TRY_RC(expr)                  \
+    do {                                 \
+        const int _rc = (expr);          \
+        if (_rc != HN_OK) return _rc;    \
+    } while (0)
+
+// Per-device state (one process may drive several GPUs, from several threads).
+int current_device();          // hipGetDevice, -1 on failure
+int device_cus();              // CU count of the CURRENT device (cached per device; 0 if none)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): `mask` is the kernel's own
+// bit set of devices already configured (a static std::atomic<uint64_t> next to the launch).
+int ensure_dynamic_lds(const void* kernel, int bytes, void* mask_atomic_u64);
 
 // ---- network geometry (fixed by the reference confs; checked in hn_field_create) ---------
 constexpr int H = 256;           // d_hidden == d_feature

@@ -10,6 +10,8 @@
 // hn_pack2.hip (build_hand_stream); the feature k-slot layout is bone_slots / left_slots there.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "hn_mlp2.h"
 #ifndef HN_JAC_VARIANT
 #define HN_JAC_VARIANT 2
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     WStream ws;
     ws.init(a.blob, a.blob_bytes, lds, wave, lane);
     char* const stage = lds + 2 * CHUNK_MAX + wave * STAGE_BYTES;   // per-wave staging of one bone's fragments
-    ws.dbg_nofetch = (a.dbg & 4) ? 1 : 0;
+    ws.dbg_nofetch = (HN_DBG(a) & 4) ? 1 : 0;
     if ((int)blockIdx.x < n_tiles) ws.fetch_all(HB_BONE);
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             __syncthreads();
             nzw = __builtin_amdgcn_readfirstlane(ex[0] | ex[1] | ex[2] | ex[3] | 1u);
         }
-        if ((a.dbg >> 8) == 1) return;   // phase timing aid
+        if ((HN_DBG(a) >> 8) == 1) return;   // phase timing aid
         h8 ah[16], al[16], bh[16], bl[16];   // ping-pong activation fragments
         struct Act {
             f32x16 v;
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                                             return NoData{};
                                         },
                                         no_store);
-        if ((a.dbg >> 8) == 3) return;   // phase timing aid
+        if ((HN_DBG(a) >> 8) == 3) return;   // phase timing aid
         // ---- lin4 = [a4 | features] / sqrt2 -> a5: 8 hidden tiles (bias from the tail), then the feature pass
         {
             f32x16 c1[8], c2[8];
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             continue;
         }
 
-        if ((a.dbg >> 8) == 5) return;   // phase timing aid
+        if ((HN_DBG(a) >> 8) == 5) return;   // phase timing aid
         // ---- lin8 rows 1..256: the feature vector (no activation) -> stash as fragments for colour lin0
         run_layer<8, 16, 1, true, true>(
             ws, HB_HID, HB_BWD, bh, bl, lane, h, no_pre, PhIdentity{},
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             },
             no_store);
 
-        if ((a.dbg >> 8) == 6) return;   // phase timing aid
+        if ((HN_DBG(a) >> 8) == 6) return;   // phase timing aid
         // ---- reverse sweep: dz_{l-1} = sigma'(z_{l-1}) * (W_l^T dz_l); sigma' from the stashed activation a_l
         auto act_of = [&](int act_slot) {
             return [&sh, act_slot](auto T, const char*) { return Act{sh.tile_load(act_slot, decltype(T)::value)}; };
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 1), PhDsig{}, to_regs(ah, al), no_store);   // W2^T -> dz1
         run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 0), PhDsig{}, to_regs(bh, bl), no_store);   // W1^T -> dz0
 
-        if ((a.dbg >> 8) == 7) return;   // phase timing aid
+        if ((HN_DBG(a) >> 8) == 7) return;   // phase timing aid
         // ---- d sdf / d features contracted with the encoding Jacobian, bone by bone: first W0^T dz0 (dz0 is in
         //      bh/bl), then W4[:, 256:]^T dz4 (reloaded into ah/al)
         float g[3] = {0.f, 0.f, 0.f};
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) g[c] *= BWD_INV;
 
-        if ((a.dbg >> 8) == 8) return;   // phase timing aid
+        if ((HN_DBG(a) >> 8) == 8) return;   // phase timing aid
         // ---- colour lin0 = [features | feature vector | enc(g)] -> relu: per pass 4 feature-vector tiles, the
         //      feature block, then the enc(g) chunk (whose tail holds the 4 biases)
         h8 gh[2], gl[2];
@@ -761,12 +763,15 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
     a.rgb = rgb;
     a.feat = feat;
     a.scratch = reinterpret_cast<float4*>(workspace);
+    a.dbg = 0;
+#ifdef HN_DEBUG_HOOKS
     {
         const char* e = getenv("HN_DBG");
         a.dbg = e ? atoi(e) : 0;
     }
+#endif
     a.cull = f->cull_far_field;
-    int n_cus = hn_device_cus();
+    int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = hand2_grid(n_pts, n_cus);
     const size_t need = (size_t)grid * WG_WAVES * HAND2_SLOTS * SLOT_F4 * sizeof(float4);
@@ -774,14 +779,9 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
         set_error("field workspace too small: %zu < %zu", workspace_bytes, need);
         return HN_ENOMEM;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        HN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_field2_hand<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)HAND2_LDS));
-        HN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_field2_hand<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)HAND2_LDS));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};   // devices on which the LDS size attribute is set
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<true>), (int)HAND2_LDS, &lds_full));
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<false>), (int)HAND2_LDS, &lds_sdf));
     if (full)
         hipLaunchKernelGGL(k_field2_hand<true>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
     else

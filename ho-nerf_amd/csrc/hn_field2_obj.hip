@@ -7,6 +7,8 @@
 // hn_pack2.hip (build_obj_stream).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "hn_mlp2.h"
 #ifndef HN_PARK_AGPR
 #define HN_PARK_AGPR 1
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
 
     WStream ws;
     ws.init(a.blob, a.blob_bytes, lds, wave, lane);
-    ws.dbg_nofetch = (a.dbg & 4) ? 1 : 0;
+    ws.dbg_nofetch = (HN_DBG(a) & 4) ? 1 : 0;
     if ((int)blockIdx.x < n_tiles) ws.fetch_all(CB_L0);
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         auto to_regs_keep = [&](h8(&oh)[16], h8(&ol)[16], int stash_slot) {
             return [&oh, &ol, stash_slot, &sh, &a](auto T, EpiState& st, const auto&) {
                 constexpr int t = decltype(T)::value;
+                (void)a;
                 asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
                 oh[2 * t] = st.hi[0];
                 ol[2 * t] = st.lo[0];
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
 #if HN_PARK_AGPR
                 asm volatile("" : "+a"(oh[2 * t]), "+a"(ol[2 * t]), "+a"(oh[2 * t + 1]), "+a"(ol[2 * t + 1]));   // as hn_field2_hand.hip: park
 #endif
-                if (FULL && !(a.dbg & 1)) sh.tile_store(stash_slot, t, st.vec());
+                if (FULL && !(HN_DBG(a) & 1)) sh.tile_store(stash_slot, t, st.vec());
                 return NoData{};
             };
         };
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                                                 bh[2 * t + 1] = st.hi[1];
                                                 bl[2 * t + 1] = st.lo[1];
                                             }
-                                            if (FULL && !(a.dbg & 1)) sh.tile_store(OS_A1 + 3, t, st.vec());
+                                            if (FULL && !(HN_DBG(a) & 1)) sh.tile_store(OS_A1 + 3, t, st.vec());
                                             return NoData{};
                                         },
                                         no_store);
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             if (valid && h == 0) a.sdf[n] = sdf;
             continue;
         }
-        if (a.dbg & 8) {   // bisecting aid: stop after the forward pass (single tile per workgroup only)
+        if (HN_DBG(a) & 8) {   // bisecting aid: stop after the forward pass (single tile per workgroup only)
             if (valid && h == 0) a.sdf[n] = sdf;
             return;
         }
@@ -270,7 +273,8 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         // ---- reverse sweep: dz_{l-1} = sigma'(z_{l-1}) * (W_l^T dz_l); sigma' from the stashed activation a_l
         auto act_of = [&](int act_slot) {
             return [&sh, act_slot, &a](auto T, const char*) {
-                if (a.dbg & 2) return Act{zero16()};
+                (void)a;
+                if (HN_DBG(a) & 2) return Act{zero16()};
                 return Act{sh.tile_load(act_slot, decltype(T)::value)};
             };
         };
@@ -494,11 +498,14 @@ int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, 
     a.rgb = rgb;
     a.feat = feat;
     a.scratch = reinterpret_cast<float4*>(workspace);
+    a.dbg = 0;
+#ifdef HN_DEBUG_HOOKS
     {
         const char* e = getenv("HN_DBG");
         a.dbg = e ? atoi(e) : 0;
     }
-    int n_cus = hn_device_cus();
+#endif
+    int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = obj2_grid(n_pts, n_cus);
     if (full) {
@@ -508,14 +515,9 @@ int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, 
             return HN_ENOMEM;
         }
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        HN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_field2_obj<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)OBJ2_LDS));
-        HN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_field2_obj<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)OBJ2_LDS));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};   // devices on which the LDS size attribute is set
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<true>), (int)OBJ2_LDS, &lds_full));
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<false>), (int)OBJ2_LDS, &lds_sdf));
     if (full)
         hipLaunchKernelGGL(k_field2_obj<true>, dim3(grid), dim3(256), OBJ2_LDS, stream, a);
     else

@@ -314,6 +314,15 @@ __global__ void k_enc3_push(const float* __restrict__ x, int n, const float* __r
         }
     }
 }
+// rows of x [n, ld] scaled by s [n]
+__global__ void k_scale_rows(float* __restrict__ x, const float* __restrict__ sc, int ld, size_t total) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < total) x[i] *= sc[i / ld];
+}
+__global__ void k_sigmoid(float* __restrict__ x, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) x[i] = 1.f / (1.f + expf(-x[i]));
+}
 __global__ void k_add3(const float* __restrict__ a, float* __restrict__ b, size_t n) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) b[i] += a[i];
@@ -390,7 +399,8 @@ __device__ __forceinline__ FrameRef frame_of(int i, int ppf, int nf, const float
 }
 
 __global__ void k_hand_feat(const float* __restrict__ pts, int n, int ppf, int nf, const float* __restrict__ bt_inv,
-                            const float* __restrict__ T_pose, float* __restrict__ X, int ld) {
+                            const float* __restrict__ T_pose, float* __restrict__ X, int ld, float* __restrict__ r_out,
+                            float* __restrict__ h_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
@@ -399,6 +409,13 @@ __global__ void k_hand_feat(const float* __restrict__ pts, int n, int ppf, int n
         const BoneQ q = bone_q(p, fr.M + 16 * b, fr.T + 3 * b, b);
         float* o = X + (size_t)i * ld + b * 66;
         bone_features(q, [&](int f, int, float phi, float, float) { o[f] = phi * q.h; });
+        if (r_out != nullptr) {
+            float* ro = r_out + ((size_t)i * N_BONES + b) * 3;
+            ro[0] = q.r[0];
+            ro[1] = q.r[1];
+            ro[2] = q.r[2];
+        }
+        if (h_out != nullptr) h_out[(size_t)i * N_BONES + b] = q.h;
     }
 }
 // J gbar: directional derivative of every feature along dq = R_b gbar
@@ -559,13 +576,8 @@ struct Ctx {
     void dense(const float* A, int lda, int K, const float* W, int wsk, int wsc, int M, const float* bias, float alpha,
                float* C, int ldc, bool accumulate) const {
         DenseArgs a{A, lda, W, wsk, wsc, bias, C, ldc, n, K, M, alpha, accumulate ? 1 : 0};
-        // 128 x 64 workgroup tiles measure ~5 % faster than 128 x 128 on the fitting sizes (more workgroups per CU);
-        // HN_DENSE128 selects the wider tile for experiments
-        static const int wide = getenv("HN_DENSE128") ? 1 : 0;
-        if (M > 64 && wide)
-            hipLaunchKernelGGL(k_dense<128>, dim3((M + 127) / 128, (n + 127) / 128), dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL(k_dense<64>, dim3((M + 63) / 64, (n + 127) / 128), dim3(256), 0, s, a);
+        // 128 x 64 workgroup tiles measure ~5 % faster than 128 x 128 on the fitting sizes (more workgroups per CU)
+        hipLaunchKernelGGL(k_dense<64>, dim3((M + 63) / 64, (n + 127) / 128), dim3(256), 0, s, a);
     }
     // C = A * W[:, c0:c0+K]^T  (W row-major [M, ldw])          "forward" use of a weight block
     void nt(const float* A, int lda, int K, const float* W, int ldw, int c0, int M, const float* bias, float alpha, float* C,
@@ -633,7 +645,10 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     const bool obj = f->kind == HN_FIELD_OBJ;
     HN_REQUIRE(obj || (bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1),
                "hand field needs bt_inv / T_pose and frame sizes");
-    HN_REQUIRE(pts && g_sdf && g_grad && g_rgb && g_pts && spr >= 1 && n % spr == 0, "bad arguments");
+    // g_grad == g_rgb == NULL: adjoint of `.sdf()` alone (get_stable_loss_cross, utils/renderer_batch.py:318-371):
+    // tape + reverse sweep, then the input map with the rows of d sdf / d X scaled by g_sdf
+    const bool sdf_only = g_grad == nullptr && g_rgb == nullptr;
+    HN_REQUIRE(pts && g_sdf && g_pts && (sdf_only || (g_grad && g_rgb)) && spr >= 1 && n % spr == 0, "bad arguments");
     if (n == 0) return HN_OK;
     Arena ar{reinterpret_cast<char*>(workspace), 0, workspace_bytes};
     Bufs b;
@@ -659,7 +674,8 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     if (obj)
         hipLaunchKernelGGL(k_enc3<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.X, DP);
     else
-        hipLaunchKernelGGL(k_hand_feat, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.X, DP);
+        hipLaunchKernelGGL(k_hand_feat, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.X, DP,
+                           (float*)nullptr, (float*)nullptr);
     b.a[0] = b.X;
     for (int l = 0; l < 8; ++l) {
         if (l == 4) {
@@ -685,6 +701,19 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     }
     cx.nn(b.dz[0], H, H, W[0], LW[0], 0, Din, 1.f, b.GX, DP, false);
     cx.nn(b.dz[4], H, H, W[4], LW[4], H4, Din, rs2, b.GX, DP, true);
+    if (sdf_only) {
+        hipLaunchKernelGGL(k_scale_rows, g1(N * DP), dim3(256), 0, s, b.GX, g_sdf, DP, N * DP);
+        if (obj) {
+            hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.GX, DP, nullptr, 0, nullptr, g_pts, 0);
+        } else {
+            HN_CHECK_HIP(hipMemsetAsync(g_pts, 0, N * 3 * sizeof(float), s));
+            hipLaunchKernelGGL(k_hand_pull<1>, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX,
+                               DP, (const float*)nullptr, g_pts, 0, g_bt_inv, g_T_pose);
+        }
+        if (g_rays_d != nullptr) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n / spr) * 3 * sizeof(float), s));
+        HN_LAUNCH_CHECK();
+        return HN_OK;
+    }
     if (obj) {
         hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.GX, DP, nullptr, 0, nullptr, b.g, 0);
     } else {
@@ -775,6 +804,135 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
         hipLaunchKernelGGL(k_hand_pull<2>, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX, DP,
                            b.gb, g_pts, 1, g_bt_inv, g_T_pose);
     }
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+// ---- stand-alone module calls of the L1 surface (utils/fields.py) ------------------------------------------------------
+// The fused field kernels evaluate sdf net + gradient + colour net together; the reference's classes can also be
+// called one at a time (RenderingNetwork*.forward with caller-supplied features / normals; SDFNetwork.forward returns
+// xyz_feature, r, h).  These entry points serve those calls with the generic kernels above.
+int hand_features(const float* pts, int n, const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame,
+                  float* xyz_feature, float* r, float* h, hipStream_t s) {
+    HN_REQUIRE(pts && bt_inv && T_pose && xyz_feature && n_frames >= 1 && pts_per_frame >= 1, "bad arguments");
+    if (n <= 0) return HN_OK;
+    hipLaunchKernelGGL(k_hand_feat, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose,
+                       xyz_feature, HAND_IN, r, h);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+size_t color_forward_workspace_bytes(const hn_field* f, int n) {
+    Arena ar{nullptr, 0, 0};
+    const size_t N = (size_t)n;
+    ar.take(N * 64);
+    ar.take(N * 27);
+    ar.take(N * 27);
+    ar.take(N * H);
+    ar.take(N * H);
+    (void)f;
+    return ar.used;
+}
+// obj: x = points [n,3]; hand: x = xyz_feature [n,1386] (view_dirs unused, utils/fields.py:222-240)
+int color_forward(const hn_field* f, const float* x, const float* view_dirs, const float* feature_vectors, const float* normals,
+                  int n, float* rgb, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");
+    const bool obj = f->kind == HN_FIELD_OBJ;
+    HN_REQUIRE(x && feature_vectors && normals && rgb && (!obj || view_dirs), "bad arguments");
+    if (n <= 0) return HN_OK;
+    Arena ar{reinterpret_cast<char*>(workspace), 0, workspace_bytes};
+    const size_t N = (size_t)n;
+    float* X = ar.take(N * 64);
+    float* din = ar.take(N * 27);
+    float* gin = ar.take(N * 27);
+    float* c0 = ar.take(N * H);
+    float* c1 = ar.take(N * H);
+    if (workspace == nullptr || ar.used > workspace_bytes) {
+        set_error("colour workspace too small: %zu < %zu", workspace_bytes, ar.used);
+        return HN_ENOMEM;
+    }
+    const Ctx cx{s, n};
+    const float* const* C = f->raw_col_w;
+    const float* const* Cb = f->raw_col_b;
+    const int LC0 = f->col_ld[0];
+    const int Din = obj ? OBJ_IN : HAND_IN;
+    const int o_d = Din, o_f = obj ? Din + 27 : Din, o_g = o_f + H;
+    hipLaunchKernelGGL(k_enc3<4>, g1(n), dim3(256), 0, s, normals, n, 1, gin, 27);
+    if (obj) {
+        hipLaunchKernelGGL(k_enc3<PTS_FREQS>, g1(n), dim3(256), 0, s, x, n, 1, X, 64);
+        cx.nt(X, 64, Din, C[0], LC0, 0, H, Cb[0], 1.f, c0, H, false);
+        hipLaunchKernelGGL(k_enc3<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, view_dirs, n, 1, din, 27);
+        cx.nt(din, 27, 27, C[0], LC0, o_d, H, nullptr, 1.f, c0, H, true);
+    } else {
+        cx.nt(x, HAND_IN, Din, C[0], LC0, 0, H, Cb[0], 1.f, c0, H, false);
+    }
+    cx.nt(feature_vectors, H, H, C[0], LC0, o_f, H, nullptr, 1.f, c0, H, true);
+    cx.nt(gin, 27, 27, C[0], LC0, o_g, H, nullptr, 1.f, c0, H, true);
+    hipLaunchKernelGGL(k_relu, g1((N * H + 3) / 4), dim3(256), 0, s, c0, N * H);
+    float *cur = c0, *nxt = c1;
+    for (int l = 1; l <= 3; ++l) {
+        cx.nt(cur, H, H, C[l], H, 0, H, Cb[l], 1.f, nxt, H, false);
+        hipLaunchKernelGGL(k_relu, g1((N * H + 3) / 4), dim3(256), 0, s, nxt, N * H);
+        float* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    cx.nt(cur, H, H, C[4], H, 0, 3, Cb[4], 1.f, rgb, 3, false);
+    hipLaunchKernelGGL(k_sigmoid, g1(N * 3), dim3(256), 0, s, rgb, N * 3);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+// ---- nearest candidate vertex (get_stable_loss_cross: scipy cKDTree.query(k=1), utils/renderer_batch.py:355-358) ------
+// One wave per (set t, query vertex i) with query_mask[t,i] != 0: argmin over the vertices j with cand_mask[t,j] != 0
+// of |p_i - p_j|^2 (ties: lowest j); selected[t, argmin] = 1 (the np.unique of the reference = a set).  A few thousand
+// vertices: brute force, the vertex array stays in L2.
+__global__ void k_nearest_masked(const float* __restrict__ pts, int n_verts, int n_sets, const unsigned char* __restrict__ query_mask,
+                                 const unsigned char* __restrict__ cand_mask, unsigned char* __restrict__ selected,
+                                 int* __restrict__ nearest) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= n_sets * n_verts) return;
+    const int t = q / n_verts, i = q % n_verts;
+    if (!query_mask[q]) {
+        if (nearest != nullptr && lane == 0) nearest[q] = -1;
+        return;
+    }
+    const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    float best = INFINITY;
+    int arg = -1;
+    const unsigned char* cm = cand_mask + (size_t)t * n_verts;
+    for (int j = lane; j < n_verts; j += 64) {
+        if (!cm[j]) continue;
+        const float dx = pts[3 * j] - px, dy = pts[3 * j + 1] - py, dz = pts[3 * j + 2] - pz;
+        const float d = dx * dx + dy * dy + dz * dz;
+        if (d < best) {
+            best = d;
+            arg = j;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oa = __shfl_xor(arg, off, 64);
+        if (oa >= 0 && (arg < 0 || ob < best || (ob == best && oa < arg))) {
+            best = ob;
+            arg = oa;
+        }
+    }
+    if (lane == 0) {
+        if (arg >= 0) selected[(size_t)t * n_verts + arg] = 1;
+        if (nearest != nullptr) nearest[q] = arg;
+    }
+}
+int nearest_masked(const float* pts, int n_verts, int n_sets, const unsigned char* query_mask, const unsigned char* cand_mask,
+                   unsigned char* selected, int* nearest, hipStream_t s) {
+    HN_REQUIRE(pts && query_mask && cand_mask && selected && n_verts >= 0 && n_sets >= 0, "bad arguments");
+    const size_t total = (size_t)n_verts * n_sets;
+    if (total == 0) return HN_OK;
+    HN_CHECK_HIP(hipMemsetAsync(selected, 0, total, s));
+    hipLaunchKernelGGL(k_nearest_masked, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, pts, n_verts, n_sets, query_mask, cand_mask,
+                       selected, nearest);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

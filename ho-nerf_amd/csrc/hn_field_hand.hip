@@ -455,7 +455,7 @@ int launch_field_hand(const hn_field* f, const float* pts, int n_pts, const floa
     a.rgb = rgb;
     a.feat = feat;
     a.scratch = reinterpret_cast<float4*>(workspace);
-    int n_cus = hn_device_cus();
+    int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = field_grid(n_pts, n_cus);
     const size_t need = (size_t)grid * (full ? HAND_SLOTS_FULL : HAND_SLOTS_SDF) * SLOT_FLOAT4 * sizeof(float4);

@@ -299,7 +299,7 @@ int launch_field_obj(const hn_field* f, const float* pts, const float* rays_d, i
     a.rgb = rgb;
     a.feat = feat;
     a.scratch = reinterpret_cast<float4*>(workspace);
-    int n_cus = hn_device_cus();
+    int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = field_grid(n_pts, n_cus);
     const size_t need = (size_t)grid * (full ? OBJ_SLOTS_FULL : OBJ_SLOTS_SDF) * SLOT_FLOAT4 * sizeof(float4);

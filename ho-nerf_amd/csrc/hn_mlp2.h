@@ -27,6 +27,14 @@
 
 #include "hn_common.h"
 
+// Timing / bisecting hooks of the field kernels exist only in -DHN_DEBUG_HOOKS builds (tools/); the product
+// library carries none of them: HN_DBG(a) folds to 0 and the branches that test it disappear.
+#ifdef HN_DEBUG_HOOKS
+#define HN_DBG(a) ((a).dbg)
+#else
+#define HN_DBG(a) 0
+#endif
+
 namespace hn {
 namespace v2 {
 
@@ -122,7 +130,11 @@ struct WStream {
         if (goff == total) goff = 0;
         f_goff = goff + wave * 1024;
         f_dst = lds + phase * CHUNK_MAX + wave * 1024;
-        f_pieces = dbg_nofetch ? 0 : ((bytes >> 10) + WG_WAVES - 1 - wave) / WG_WAVES;   // pieces of this wave
+#ifdef HN_DEBUG_HOOKS
+        f_pieces = dbg_nofetch ? 0 : ((bytes >> 10) + WG_WAVES - 1 - wave) / WG_WAVES;
+#else
+        f_pieces = ((bytes >> 10) + WG_WAVES - 1 - wave) / WG_WAVES;   // pieces of this wave
+#endif
         goff += bytes;
         phase ^= 1;
     }

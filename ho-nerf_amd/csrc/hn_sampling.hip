@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64) void k_upsample_direct(const float* __restrict_
     }
     // pass 3: invert at u = linspace(0.5/n, 1-0.5/n, n)
     const float u_start = 0.f + 0.5f / (float)n_new, u_end = 1.f - 0.5f / (float)n_new;
-    const float u_step = (u_end - u_start) / (float)(n_new - 1);
+    const float u_step = n_new > 1 ? (u_end - u_start) / (float)(n_new - 1) : 0.f;   // linspace(steps=1) = [start]
     int ptr = 0;   // number of cdf entries <= u (searchsorted right=True); cdf and u are both non-decreasing
     for (int jj = 0; jj < n_new; ++jj) {
         const float u = (jj < n_new / 2) ? u_start + (float)jj * u_step : u_end - (float)(n_new - 1 - jj) * u_step;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void k_upsample(const float* __restrict__ z, co
     }
     // pass 3: invert at u = linspace(0.5/n, 1-0.5/n, n)
     const float u_start = 0.f + 0.5f / (float)n_new, u_end = 1.f - 0.5f / (float)n_new;
-    const float u_step = (u_end - u_start) / (float)(n_new - 1);
+    const float u_step = n_new > 1 ? (u_end - u_start) / (float)(n_new - 1) : 0.f;   // linspace(steps=1) = [start]
     int ptr = 0;   // number of cdf entries <= u (searchsorted right=True); cdf and u are both non-decreasing
     for (int jj = 0; jj < n_new; ++jj) {
         const float u = (jj < n_new / 2) ? u_start + (float)jj * u_step : u_end - (float)(n_new - 1 - jj) * u_step;
@@ -491,7 +491,7 @@ int sample_points_bwd(const float* z, const float* g_pts, int n_rays, int n, int
 
 int upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, float inv_s, float* z_new, int64_t* inds,
              hipStream_t s) {
-    HN_REQUIRE(k >= 2 && k <= UPS_MAX_K && n_new >= 2 && n_new <= 64, "upsample: k=%d n_new=%d out of range", k, n_new);
+    HN_REQUIRE(k >= 2 && k <= UPS_MAX_K && n_new >= 1 && n_new <= 64, "upsample: k=%d n_new=%d out of range", k, n_new);
     if (n_rays == 0) return HN_OK;
     if (k <= 64) {   // staged: 2 x 64 x (k+1) floats of LDS per wave; beyond 64 columns the occupancy loss outweighs it (measured)
         hipLaunchKernelGGL(k_upsample, grid1d(n_rays, 64), dim3(64), (size_t)2 * 64 * (k + 1) * sizeof(float), s, z, sdf,

@@ -41,22 +41,28 @@ def window_schedule(n_frames, rank, world, window=4):
     return [wins[s * world + rank] if s * world + rank < len(wins) else None for s in range(steps)]
 
 
-def render_loss_terms(render_out, true_rgb, true_mask, fit_type='1'):
-    """The render-dependent loss terms of one optimisation step (fitting_single.py:251-283).
+def render_loss_terms(render_out, true_rgb, true_mask, fit_type='1', video=False):
+    """The render-dependent loss terms of one optimisation step (fitting_single.py:251-283; video=True:
+    fitting_video.py:285-309, tensors [F,P,.]).
 
-    color: L1(sum) of the masked colour error / B; mask: BCE(clip(weight_sum, 1e-3, 1-1e-3), mask),
-    weighted 0.5; fit_type '12' adds contact (mean |s_h| + |s_o| where < 1e-2, x30) and penetration
-    (mean over s_o < 0 and s_h < 0, x20).  The pose-regularisation terms (joint / object-vertex
-    losses) depend on the pose chain only and stay with the caller."""
+    color: L1(sum) of the masked colour error / B (video: / F / P); mask: BCE(clip(weight_sum, 1e-3, 1-1e-3), mask),
+    weighted 0.5 (video: the render loss is halved again, fitting_video.py:291); fit_type '12' (and every video
+    type) adds contact (mean |s_h| + |s_o| where < 1e-2, x30) and penetration (mean over s_o < 0 and s_h < 0, x20).
+    The pose-regularisation terms (joint / object-vertex losses) depend on the pose chain only: step_loss adds them."""
     color_fine = render_out['color_fine']
     weight_sum = render_out['weight_sum']
     color_error = (color_fine - true_rgb) * true_mask
     color_loss = F.l1_loss(color_error, torch.zeros_like(color_error), reduction='sum') / true_mask.shape[0]
+    if video:
+        color_loss = color_loss / true_mask.shape[1]
     mask_loss = F.binary_cross_entropy(weight_sum.clip(1e-3, 1.0 - 1e-3), true_mask)
-    terms = {'color': color_loss, 'mask': mask_loss, 'loss': color_loss + 0.5 * mask_loss}
+    render_loss = color_loss + 0.5 * mask_loss
+    if video:
+        render_loss = 0.5 * render_loss
+    terms = {'color': color_loss, 'mask': mask_loss, 'loss': render_loss}
     zero = color_loss.new_zeros(())
     terms['contact'], terms['penetration'] = zero, zero
-    if fit_type in ('12', '1234'):
+    if video or fit_type in ('12', '123', '1234'):
         sdf_hand = render_out['sdf_hand'][:, 0]
         sdf_obj = render_out['sdf_obj'][:, 0]
         sdf_abs_sum = sdf_hand.abs() + sdf_obj.abs()
@@ -86,7 +92,10 @@ class FrameShardedRunner:
         self.dist = dist if dist.is_available() and dist.is_initialized() else None
         self.rank = rank if rank is not None else (self.dist.get_rank() if self.dist else int(os.environ.get('RANK', 0)))
         self.world = world if world is not None else (self.dist.get_world_size() if self.dist else 1)
-        self.device = device or torch.device('cpu')
+        if device is None:      # RCCL ("nccl") reduces device tensors only; gloo takes host tensors
+            on_gpu = self.dist is not None and self.dist.get_backend() == 'nccl'
+            device = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
+        self.device = device
         self.frames = [f for f in shard_frames(n_frames, self.rank, self.world) if not (done and done(f))]
         self.totals = torch.zeros(len(LOSS_KEYS), dtype=torch.float64)
 
@@ -122,12 +131,18 @@ def mask_pixels(mask, n_rays, rng):
     return np.stack([x, y], -1).astype(np.float32), py * W + px
 
 
-def allreduce_pose_gradients(params, dist=None):
+def allreduce_pose_gradients(params, dist=None, average=False):
     """Window-parallel `fitting_video` step: every rank has back-propagated ITS window's loss into the
     shared `[data_num, ...]` pose parameters (non-zero on the window's 4 rows); one all-reduce (SUM) of the flattened
     gradient block -- data_num x 45 floats, ~18 KB at 100 frames: latency-bound, a single call -- makes the gradients
     identical on all ranks, after which every rank takes the same Adam step on its replica.  A rank whose window list
-    has run out passes parameters without `.grad` (treated as zeros).  Returns the number of floats exchanged."""
+    has run out passes parameters without `.grad` (treated as zeros).  Returns the number of floats exchanged.
+
+    The reduced gradient is that of the SUM of the concurrent windows' losses: a frame covered by several of them
+    receives several contributions in one step, where the reference's sequential schedule would take as many Adam
+    steps (fitting_video.py:340-342).  That is the schedule change SURVEY 8(e) accepts (Jacobi over `world` windows);
+    Adam's per-element normalisation keeps the step size independent of how many windows touched a row.  Pass
+    `average=True` to divide by the world size instead (plain data-parallel mean)."""
     if dist is None:
         import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -135,6 +150,8 @@ def allreduce_pose_gradients(params, dist=None):
     params = list(params)
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
     off = 0
     for p in params:
         n = p.numel()
@@ -145,3 +162,202 @@ def allreduce_pose_gradients(params, dist=None):
             p.grad.copy_(g)
         off += n
     return int(flat.numel())
+
+
+# ---- pose parameters -> render inputs ---------------------------------------------------------------------------------
+def rot6d_to_matrix(rot_6d):
+    """utils/utils.py:11-29 (Zhou et al. 2019): [...,3,2] -> [B,3,3] with columns (b1, b2, b1 x b2)."""
+    r = rot_6d.reshape(-1, 3, 2)
+    a1, a2 = r[:, :, 0], r[:, :, 1]
+    b1 = F.normalize(a1)
+    b2 = F.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1)
+    b3 = torch.cross(b1, b2, dim=-1)
+    return torch.stack((b1, b2, b3), dim=-1)
+
+
+def pose_loss(target, pred, mean=False):
+    """fitting_single.py:119-122 (sum / rows) and fitting_video.py:123-126 (mean=True: mean over everything)."""
+    err = torch.norm(target - pred, dim=-1)
+    return err.mean() if mean else err.sum() / err.shape[0]
+
+
+class RigidPoseChain:
+    """Host-side differentiable map from the optimised parameters to the renderer's pose inputs.
+
+    In the reference this is halo_util's PoseConverter chain (fitting_single.py:206-230): joint angles ->
+    biomechanical skeleton -> per-bone world->T-pose transforms `bt_inv`.  That chain stays host-side torch and is
+    SUPPLIED BY THE CALLER of fit_frame / fit_window as a callable (not part of the kernel path).  This
+    class is the part of it that needs no skeleton model -- the global (palm) rigid motion and the object refinement
+    (fitting_single.py:219-230) -- so that the drivers, tests and the bench have a complete chain to differentiate
+    through:  joints' = R_palm (joints - root) + root + T_palm  <=>  bt_inv' = bt_inv0 G^-1,
+    obj_r = rot6d(obj_rot) Ro_pred,  obj_t = To_pred + obj_trans.
+
+    Parameters are `[data_num, ...]` blocks like fitting_video.py:159-176 (data_num = 1 for fitting_single)."""
+
+    def __init__(self, bt_inv0, T_pose_21, joints0, Ro_pred, To_pred, obj_verts, device='cuda'):
+        t = lambda x, *s: torch.as_tensor(x, dtype=torch.float32).to(device).reshape(*s)
+        self.bt_inv0 = t(bt_inv0, -1, 21, 4, 4)
+        n = self.bt_inv0.shape[0]
+        self.joints0, self.Ro_pred, self.To_pred = t(joints0, n, 21, 3), t(Ro_pred, n, 3, 3), t(To_pred, n, 3)
+        self.T_pose_21 = t(T_pose_21, -1, 21, 3)
+        if self.T_pose_21.shape[0] != n:
+            self.T_pose_21 = self.T_pose_21[:1].expand(n, 21, 3).contiguous()
+        self.obj_verts = t(obj_verts, -1, 3)
+        eye62 = torch.eye(3, device=device)[:, :2].expand(n, 3, 2).contiguous()
+        self.obj_rot = torch.nn.Parameter(eye62.clone())
+        self.obj_trans = torch.nn.Parameter(torch.zeros(n, 3, device=device))
+        self.palm_rot = torch.nn.Parameter(eye62.clone())
+        self.palm_trans = torch.nn.Parameter(torch.zeros(n, 3, device=device))
+
+    def param_groups(self, video=False):
+        """Learning rates of fitting_single.py:191-198 / fitting_video.py:177-184 for the parameters this chain has."""
+        lr = (1e-4, 1e-4, 1e-4, 1e-4) if video else (5e-4, 5e-4, 5e-4, 3e-4)
+        return [{'params': p, 'lr': l} for p, l in zip((self.obj_rot, self.obj_trans, self.palm_rot, self.palm_trans), lr)]
+
+    def parameters(self):
+        return [self.obj_rot, self.obj_trans, self.palm_rot, self.palm_trans]
+
+    def __call__(self, index=None):
+        idx = slice(None) if index is None else torch.as_tensor(index, device=self.bt_inv0.device)
+        R_palm = rot6d_to_matrix(self.palm_rot[idx])                               # [F,3,3]
+        root = self.joints0[idx][:, :1, :]
+        joint_3d = (R_palm.unsqueeze(1) @ (self.joints0[idx] - root).unsqueeze(-1))[..., 0] + root + self.palm_trans[idx].unsqueeze(1)
+        # G p = R_palm (p - root) + root + T  ->  G^-1 p = R_palm^T (p - root - T) + root
+        Rt = R_palm.transpose(1, 2)
+        Ginv = torch.zeros(R_palm.shape[0], 4, 4, device=R_palm.device)
+        Ginv[:, :3, :3] = Rt
+        Ginv[:, :3, 3] = root[:, 0] - (Rt @ (root[:, 0] + self.palm_trans[idx]).unsqueeze(-1))[..., 0]
+        Ginv[:, 3, 3] = 1.0
+        bt_inv = self.bt_inv0[idx] @ Ginv.unsqueeze(1)
+        obj_r = rot6d_to_matrix(self.obj_rot[idx]) @ self.Ro_pred[idx]
+        obj_t = self.To_pred[idx] + self.obj_trans[idx]
+        pred_v = (obj_r.unsqueeze(1) @ self.obj_verts[None, :, :, None])[..., 0] + obj_t.unsqueeze(1)
+        comp_v = (self.Ro_pred[idx].unsqueeze(1) @ self.obj_verts[None, :, :, None])[..., 0] + self.To_pred[idx].unsqueeze(1)
+        return {'bt_inv': bt_inv, 'T_pose_21': self.T_pose_21[idx], 'joint_3d': joint_3d, 'joint3d_pred': self.joints0[idx], 'obj_r': obj_r, 'obj_t': obj_t,
+                'pred_obj_v_w': pred_v, 'compare_obj_v_w': comp_v}
+
+
+# ---- one optimisation step --------------------------------------------------------------------------------------------
+def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, smooth_ends=(False, False), stable=None):
+    """The full loss of one step: fitting_single.py:251-283 (video=False) or fitting_video.py:285-334 (video=True:
+    + smoothness over the window's frames x50, anchored to the prediction at the sequence ends; + 100 x the stable
+    term for fit type '1234').  `pose` is the pose chain's output dict."""
+    terms = render_loss_terms(render_out, true_rgb, true_mask, fit_type, video)
+    if not video:
+        joint_loss = pose_loss(pose['joint3d_pred'][0], pose['joint_3d'][0])
+        verts_loss = pose_loss(pose['compare_obj_v_w'][0], pose['pred_obj_v_w'][0])
+        w = (100.0, 5.0) if fit_type == '1' else (30.0, 20.0)
+    else:
+        joint_loss = pose_loss(pose['joint_3d'], pose['joint3d_pred'], mean=True)
+        verts_loss = pose_loss(pose['pred_obj_v_w'], pose['compare_obj_v_w'], mean=True)
+        w = (30.0, 20.0)
+    terms['joint'], terms['obj_verts'] = joint_loss, verts_loss
+    terms['loss'] = terms['loss'] + w[0] * joint_loss + w[1] * verts_loss
+    if video:
+        j, v = pose['joint_3d'], pose['pred_obj_v_w']
+        smooth = pose_loss(j[1:], j[:-1], mean=True) + pose_loss(v[1:], v[:-1], mean=True)
+        if smooth_ends[0]:
+            smooth = smooth + pose_loss(j[:1], pose['joint3d_pred'][:1], mean=True) + pose_loss(v[:1], pose['compare_obj_v_w'][:1], mean=True)
+        elif smooth_ends[1]:
+            smooth = smooth + pose_loss(j[-1:], pose['joint3d_pred'][-1:], mean=True) + pose_loss(v[-1:], pose['compare_obj_v_w'][-1:], mean=True)
+        terms['smooth'] = 50.0 * smooth
+        terms['loss'] = terms['loss'] + terms['smooth']
+        if stable is not None:
+            terms['stable'] = 100.0 * stable
+            terms['loss'] = terms['loss'] + terms['stable']
+    return terms
+
+
+def _rays(lib_mod, xy, cam, n_cams, rays_per_cam):
+    lib = lib_mod.load()
+    o = torch.empty(n_cams * rays_per_cam, 3, device=xy.device)
+    d = torch.empty_like(o)
+    lib_mod.check(lib.hn_ray_gen(lib_mod.ptr(xy), lib_mod.ptr(cam['R']), lib_mod.ptr(cam['T']), lib_mod.ptr(cam['focal']),
+                                 lib_mod.ptr(cam['principal']), n_cams, rays_per_cam, lib_mod.ptr(o), lib_mod.ptr(d),
+                                 lib_mod.stream_ptr()), 'hn_ray_gen')
+    return o, d
+
+
+def fit_step(renderer, view, pose_chain, optimizer, near, far, fit_type='1', index=None, smooth_ends=(False, False),
+             obj_verts_for_stable=None, t_rand=None):
+    """One optimiser step of the fitting loops: pose chain -> rays of the view's sampled pixels (`_xy_to_ray_bundle` ->
+    hn_ray_gen) -> renderer.render -> losses -> backward into the pose parameters -> Adam step
+    (fitting_single.py:201-291; batched renderer: fitting_video.py:212-342).
+
+    view: dict(cam={'R','T','focal','principal'} device tensors [n_cams,..], xy [n_cams*P,2] NDC, true_rgb, true_mask)
+    with n_cams = 1 for fitting_single and the window's 4 cameras for fitting_video."""
+    from . import lib as L
+    video = bool(getattr(renderer, 'batched', False))
+    pose = pose_chain(index)
+    n_cams = view['cam']['R'].shape[0]
+    P = view['xy'].shape[0] // n_cams
+    rays_o, rays_d = _rays(L, view['xy'], view['cam'], n_cams, P)
+    T_pose = pose['T_pose_21']
+    if video:
+        Ro_arg = torch.inverse(pose['obj_r'])                                          # fitting_video.py:284
+        out = renderer.render(rays_o.reshape(n_cams, P, 3), rays_d.reshape(n_cams, P, 3), near, far, pose['bt_inv'], T_pose, None,
+                              Ro_arg, pose['obj_t'], t_rand=t_rand)
+    else:
+        Ro_arg = pose['obj_r'][0].T                                                    # fitting_single.py:250
+        out = renderer.render(rays_o, rays_d, near, far, pose['bt_inv'][0], T_pose[0], None, Ro_arg, pose['obj_t'][0], t_rand=t_rand)
+    stable = None
+    if video and fit_type == '1234':
+        stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
+    terms = step_loss(out, view['true_rgb'], view['true_mask'], pose, fit_type, video, smooth_ends, stable)
+    optimizer.zero_grad(set_to_none=True)
+    terms['loss'].backward()
+    optimizer.step()
+    return terms
+
+
+def fit_frame(renderer, views, pose_chain, near, far, fit_type='1', n_iters=None, sample_view=None):
+    """fitting_single.py:200-291 for one frame: `n_iters` (30 for fit type '1', 25 for '12'; 40 / 35 with 3 views,
+    :124-132) passes over the views, one Adam step per view.  `sample_view(view_id, step) -> view dict` draws the
+    step's pixels (the reference: get_rays_xy on the view's mask, 196 rays); default: the views as given."""
+    if n_iters is None:
+        n_iters = {('1', False): 30, ('1', True): 40, ('12', False): 25, ('12', True): 35}[(fit_type, len(views) == 3)]
+    opt = torch.optim.Adam(pose_chain.param_groups(video=False))
+    last, step = None, 0
+    for _ in range(n_iters):
+        for vid in range(len(views)):
+            view = sample_view(vid, step) if sample_view is not None else views[vid]
+            last = fit_step(renderer, view, pose_chain, opt, near, far, fit_type)
+            step += 1
+    return last, step
+
+
+def fit_window(renderer, views, pose_chain, optimizer, near, far, index, data_num, fit_type='1234', first_pass=False,
+               obj_verts=None, sample_view=None, sub_iters=4):
+    """fitting_video.py:211-342 for one window of 4 consecutive frames `index`: 4 sub-iterations x the views, an
+    Adam step each on the shared [data_num, ..] parameters.  The smoothness term is anchored to the prediction when
+    the window touches either end of the sequence (not on the very first step, :312)."""
+    last, step = None, 0
+    for sub in range(sub_iters):
+        for vid in range(len(views)):
+            view = sample_view(vid, step) if sample_view is not None else views[vid]
+            later = not (first_pass and sub == 0 and vid == 0)
+            ends = (later and int(index[0]) == 0, later and int(index[-1]) == data_num - 1)
+            last = fit_step(renderer, view, pose_chain, optimizer, near, far, fit_type, index=index, smooth_ends=ends,
+                            obj_verts_for_stable=obj_verts)
+            step += 1
+    return last, step
+
+
+def synthetic_views(n_views, n_frames, rays_per_frame, seed, joints_center, device='cuda', H=230, W=266):
+    """Synthetic stand-in for one fit_*_dataset item (the data set is an external download): `n_views` ring cameras
+    looking at the hand, per view `rays_per_frame` pixels per frame drawn from a synthetic mask (NDC convention of
+    utils/dataset.py:45-47), random target colours, mask = 1 inside.  n_frames > 1 lays the window's frames out as
+    [F*P] rows with one camera per frame (all frames of a window share the view's camera, fitting_video.py:213-222)."""
+    from . import synth
+    cams = synth.ring_cameras(n_views, radius=0.9, target=tuple(joints_center), focal=2.0, seed=seed)
+    g = torch.Generator('cpu').manual_seed(seed)
+    views = []
+    for v in range(n_views):
+        cam = {k: torch.as_tensor(np.repeat(np.asarray(cams[k][v:v + 1], dtype=np.float32), n_frames, axis=0)).to(device).contiguous()
+               for k in ('R', 'T', 'focal', 'principal')}
+        xy = np.concatenate([synth.mask_pixels_ndc(H, W, rays_per_frame, seed * 1000 + 10 * v + f) * 0.25 for f in range(n_frames)])
+        shape = (n_frames, rays_per_frame) if n_frames > 1 else (rays_per_frame,)
+        views.append({'cam': cam, 'xy': torch.from_numpy(xy).to(device).contiguous(),
+                      'true_rgb': torch.rand(*shape, 3, generator=g).to(device),
+                      'true_mask': (torch.rand(*shape, 1, generator=g) > 0.2).float().to(device)})
+    return views

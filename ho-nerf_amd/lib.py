@@ -66,6 +66,10 @@ SIGNATURES = {
     'hn_field_eval': (c_i, [c_vp, c_f, c_f, c_i, c_i, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
     'hn_field_bwd_workspace_bytes': (c_sz, [c_vp, c_i]),
     'hn_field_eval_bwd': (c_i, [c_vp, c_f, c_f, c_i, c_i, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
+    'hn_hand_features': (c_i, [c_f, c_i, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_vp]),
+    'hn_color_forward_workspace_bytes': (c_sz, [c_vp, c_i]),
+    'hn_color_forward': (c_i, [c_vp, c_f, c_f, c_f, c_f, c_i, c_f, c_vp, c_sz, c_vp]),
+    'hn_nearest_masked': (c_i, [c_f, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'hn_alpha': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_vp]),
     'hn_composite1': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp]),
     'hn_composite2': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp]),

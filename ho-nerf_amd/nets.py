@@ -61,9 +61,57 @@ class _MLPParams(nn.Module):
         return [getattr(self, 'lin%d' % l) for l in range(self.num_layers - 1)]
 
 
-class SDFNetwork_OBJ(_MLPParams):
+def _filler_state_dict(kind):
+    """A finite placeholder network of the conf shape (weight_v[:, 0] = 1, everything else 0) for the half of a
+    PackedField that a stand-alone module call does not use."""
+    sd = {}
+    for l, (out, cin) in enumerate(synth.layer_shapes(kind, 256)):
+        v = torch.zeros(out, cin)
+        v[:, 0] = 1.0
+        sd['lin%d.weight_v' % l] = v
+        sd['lin%d.weight_g' % l] = torch.zeros(out, 1)
+        sd['lin%d.bias' % l] = torch.zeros(out)
+    return sd
+
+
+class _Standalone:
+    """A module called on its own (utils/fields.py `forward` / `.sdf` / `.gradient`), outside a renderer: it packs
+    itself (lazily, re-packed when its parameters change) next to a placeholder for the other network of the field.
+    Forward only -- the differentiable path is the renderers' (autograd.DualRenderFn)."""
+    _field_kind = None      # 'obj' | 'hand'
+    _is_sdf = True
+
+    def _packed(self):
+        ver = params_version(self)
+        if getattr(self, '_pf', None) is None or self._pf_ver != ver:
+            other = _filler_state_dict(('color_' if self._is_sdf else 'sdf_') + self._field_kind)
+            mine = self
+            sdf, col = (mine, other) if self._is_sdf else (other, mine)
+            object.__setattr__(self, '_pf', PackedField(self._field_kind, sdf, col, 0.3, scale=float(getattr(self, 'scale', 1.0))))
+            object.__setattr__(self, '_pf_ver', ver)
+        return self._pf
+
+
+class SDFNetwork_OBJ(_MLPParams, _Standalone):
     """utils/fields.py:251-347."""
     kind = 'sdf_obj'
+    _field_kind, _is_sdf = 'obj', True
+
+    def forward(self, inputs):
+        """utils/fields.py:316-328: [N,3] -> [N,257] = cat[sdf / scale, feature vector]."""
+        pts = _lib.f32(inputs).reshape(-1, 3)
+        sdf, _, _, feat = self._packed().evaluate(pts, torch.zeros_like(pts), 1, want_feat=True)
+        return torch.cat([sdf, feat], dim=-1)
+
+    def sdf(self, x):
+        """utils/fields.py:330-331 -> [N,1]."""
+        return self._packed().sdf(x)
+
+    def gradient(self, x):
+        """utils/fields.py:336-347: d sdf / d x, [N,1,3] (analytic reverse sweep instead of autograd.grad)."""
+        pts = _lib.f32(x).reshape(-1, 3)
+        _, grad, _ = self._packed().evaluate(pts, torch.zeros_like(pts), 1)
+        return grad.unsqueeze(1)
 
     def __init__(self, barf_encoding=None, traindata_num=1, data_type='real', d_in=3, d_out=257, d_hidden=256,
                  n_layers=8, skip_in=(4,), v_multires=10, r_multires=4, bias=0.5, scale=1, geometric_init=True,
@@ -79,9 +127,46 @@ class SDFNetwork_OBJ(_MLPParams):
         self.se3_refine = nn.Parameter(se3)
 
 
-class SDFNetwork(_MLPParams):
+class SDFNetwork(_MLPParams, _Standalone):
     """utils/fields.py:56-177 (hand)."""
     kind = 'sdf_hand'
+    _field_kind, _is_sdf = 'hand', True
+
+    def _frames(self, x, bt_inv, T_pose_21):
+        pts = _lib.f32(x)
+        bt = _lib.f32(bt_inv, pts.device).reshape(-1, 21, 4, 4)
+        tp = _lib.f32(T_pose_21, pts.device).reshape(-1, 21, 3)
+        if not self.use_batch:
+            bt, tp = bt[:1], tp[:1]
+        return pts.reshape(-1, 3), bt.contiguous(), tp.contiguous()
+
+    def forward(self, x, bt_inv, T_pose_21):
+        """utils/fields.py:132-156: x [N,3] (use_batch: [F,N,3] with bt_inv [F,21,4,4]) ->
+        (out [M,257], xyz_feature [M,1386], r [M,21,3], h [M,21,1])."""
+        pts, bt, tp = self._frames(x, bt_inv, T_pose_21)
+        pf = self._packed()
+        n = pts.shape[0]
+        sdf, _, _, feat = pf.evaluate(pts, torch.zeros_like(pts), 1, bt, tp, want_feat=True)
+        nf = bt.shape[0]
+        if tp.shape[0] != nf:
+            tp = tp.expand(nf, 21, 3).contiguous()
+        X = torch.empty(n, 21 * 66, device=pts.device)
+        r = torch.empty(n, 21, 3, device=pts.device)
+        h = torch.empty(n, 21, 1, device=pts.device)
+        _lib.check(pf.lib.hn_hand_features(_lib.ptr(pts), n, _lib.ptr(bt), _lib.ptr(tp), nf, max(n // nf, 1), _lib.ptr(X), _lib.ptr(r),
+                                           _lib.ptr(h), _lib.stream_ptr()), 'hn_hand_features')
+        return torch.cat([sdf, feat], dim=-1), X, r, h
+
+    def sdf(self, x, bt_inv, T_pose_21):
+        """utils/fields.py:158-160 -> [M,1]."""
+        pts, bt, tp = self._frames(x, bt_inv, T_pose_21)
+        return self._packed().sdf(pts, bt, tp)
+
+    def gradient(self, x, bt_inv, T_pose_21):
+        """utils/fields.py:165-177: d sdf / d x, [M,1,3] (use_batch: [F,1,N,3] squeezes to the same rows)."""
+        pts, bt, tp = self._frames(x, bt_inv, T_pose_21)
+        _, grad, _ = self._packed().evaluate(pts, torch.zeros_like(pts), 1, bt, tp)
+        return grad.unsqueeze(1)
 
     def __init__(self, barf_encoding=None, traindata_num=1, data_type='real', d_in=3, d_out=257, d_hidden=256,
                  n_layers=8, skip_in=(4,), v_multires=10, r_multires=7, bias=0.5, scale=1, geometric_init=True,
@@ -99,9 +184,30 @@ class SDFNetwork(_MLPParams):
         self.se3_refine = nn.Parameter(se3)
 
 
-class RenderingNetwork_OBJ(_MLPParams):
+def _color_forward(pf, x, view_dirs, feature_vectors, normals):
+    x = _lib.f32(x)
+    x = x.reshape(-1, x.shape[-1])
+    n = x.shape[0]
+    dev = x.device
+    fv = _lib.f32(feature_vectors, dev).reshape(n, 256)
+    nr = _lib.f32(normals, dev).reshape(n, 3)
+    vd = None if view_dirs is None else _lib.f32(view_dirs, dev).reshape(n, 3)
+    rgb = torch.empty(n, 3, device=dev)
+    need = pf.lib.hn_color_forward_workspace_bytes(pf.handle, n)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    _lib.check(pf.lib.hn_color_forward(pf.handle, _lib.ptr(x), _lib.ptr(vd), _lib.ptr(fv), _lib.ptr(nr), n, _lib.ptr(rgb), _lib.ptr(ws),
+                                       need, _lib.stream_ptr()), 'hn_color_forward')
+    return rgb
+
+
+class RenderingNetwork_OBJ(_MLPParams, _Standalone):
     """utils/fields.py:349-405."""
     kind = 'color_obj'
+    _field_kind, _is_sdf = 'obj', False
+
+    def forward(self, points, view_dirs, feature_vectors, normals, index=0):
+        """utils/fields.py:387-405 -> rgb [N,3]."""
+        return _color_forward(self._packed(), points, view_dirs, feature_vectors, normals)
 
     def __init__(self, barf_encoding=None, data_type='real', d_feature=256, d_in=3, d_out=3, d_hidden=256, n_layers=4,
                  weight_norm=True, v_multires=10, r_multires=4, grad_multires=4, squeeze_out=True,
@@ -113,9 +219,14 @@ class RenderingNetwork_OBJ(_MLPParams):
         self._build(d_hidden, 'color_obj')
 
 
-class RenderingNetwork(_MLPParams):
+class RenderingNetwork(_MLPParams, _Standalone):
     """utils/fields.py:179-240 (hand)."""
     kind = 'color_hand'
+    _field_kind, _is_sdf = 'hand', False
+
+    def forward(self, view_dirs, xyz_feature, feature_vectors, h, normals, index=0):
+        """utils/fields.py:222-240 (view_dirs and h are accepted and unused, as there) -> rgb [N,3]."""
+        return _color_forward(self._packed(), xyz_feature, None, feature_vectors, normals)
 
     def __init__(self, barf_encoding=None, data_type='real', d_feature=256, d_in=3, d_out=3, d_hidden=256, n_layers=4,
                  weight_norm=True, v_multires=10, r_multires=7, grad_multires=4, squeeze_out=True,
@@ -133,6 +244,10 @@ class SingleVarianceNetwork(nn.Module):
     def __init__(self, init_val):
         super().__init__()
         self.register_parameter('variance', nn.Parameter(torch.tensor(float(init_val))))
+
+    def forward(self, x):
+        """utils/fields.py:248-249: ones([len(x), 1]) * exp(10 variance) (a scalar broadcast: plain torch)."""
+        return torch.ones([len(x), 1], device=self.variance.device) * torch.exp(self.variance * 10.0)
 
 
 def _require(cond, msg):

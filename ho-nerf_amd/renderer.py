@@ -35,6 +35,95 @@ class _Workspace:
         return self.buf
 
 
+# ---- the stages of a render, one C-ABI call each (shared by the three renderer classes) --------------------------
+def _up_sample(lib, z_vals, sdf, n_importance, inv_s):
+    """up_sample + sample_pdf(det=True) (utils/renderer.py:60-86, 10-37): z, sdf [R,k] -> [R,n_importance]."""
+    z = _lib.f32(z_vals)
+    R, k = z.reshape(-1, z.shape[-1]).shape
+    sdf = _lib.f32(sdf, z.device).reshape(R, k)
+    z_new = torch.empty(R, int(n_importance), device=z.device)
+    _lib.check(lib.hn_upsample(_lib.ptr(z.reshape(R, k)), _lib.ptr(sdf), R, k, int(n_importance), float(inv_s), _lib.ptr(z_new),
+                               None, _lib.stream_ptr()), 'hn_upsample')
+    return z_new.reshape(*z.shape[:-1], int(n_importance))
+
+
+def _points(lib, rays_o, rays_d, z, mid, sample_dist):
+    """p = o + d z (mid = 0) or the section mid-points and dists (mid = 1): utils/renderer.py:216, 119-123."""
+    R, k = z.shape
+    pts = torch.empty(R * k, 3, device=z.device)
+    dists = torch.empty(R * k, device=z.device) if mid else None
+    _lib.check(lib.hn_sample_points(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(z), R, k, 1 if mid else 0, float(sample_dist),
+                                    _lib.ptr(pts), _lib.ptr(dists), _lib.stream_ptr()), 'hn_sample_points')
+    return pts, dists
+
+
+def _cat_z_vals(lib, field, rays_o, rays_d, z_vals, new_z_vals, sdf, bt_inv, T_pose_21, last, quirk_rays_per_frame=0,
+                n_frames=1):
+    """cat_z_vals (utils/renderer.py:88-105; batched with its row quirk: utils/renderer_batch.py:96-113).
+    rays [R,3]; z [R,k]; new z [R,m]; sdf [R,k] -> (z [R,k+m], sdf [R,k+m]); with last=True sdf is returned unchanged,
+    as the reference does."""
+    R, k = z_vals.shape
+    m = new_z_vals.shape[-1]
+    z_out = torch.empty(R, k + m, device=z_vals.device)
+    st = _lib.stream_ptr()
+    if last:
+        _lib.check(lib.hn_merge(_lib.ptr(z_vals), _lib.ptr(new_z_vals), None, None, R, k, m, 0, _lib.ptr(z_out), None, None, st),
+                   'hn_merge')
+        return z_out, sdf
+    pts, _ = _points(lib, rays_o, rays_d, new_z_vals, 0, 0.0)
+    if field.kind == 'hand':
+        new_sdf = field.sdf(pts, _lib.f32(bt_inv).reshape(n_frames, 21, 4, 4), _lib.f32(T_pose_21).reshape(-1, 21, 3))
+    else:
+        new_sdf = field.sdf(pts)
+    new_sdf = new_sdf.reshape(R, m)
+    sdf_out = torch.empty(R, k + m, device=z_vals.device)
+    _lib.check(lib.hn_merge(_lib.ptr(z_vals), _lib.ptr(new_z_vals), _lib.ptr(sdf), _lib.ptr(new_sdf), R, k, m,
+                            int(quirk_rays_per_frame), _lib.ptr(z_out), _lib.ptr(sdf_out), None, st), 'hn_merge')
+    return z_out, sdf_out
+
+
+def _alpha_color(lib, field, rays_o, rays_d, z, sample_dist, bt_inv, T_pose_21, n_frames=1, want_c=False):
+    """The module calls + SDF -> alpha stage of render_core / get_alpha_sample_color (utils/renderer.py:119-161,
+    369-415) at depths z [R,S]: -> dict(alpha [R,S], c [R,S] | None, rgb [R*S,3], sdf [R*S], grad [R*S,3], dists)."""
+    R, S = z.shape
+    n = R * S
+    dev = z.device
+    pts, dists = _points(lib, rays_o, rays_d, z, 1, sample_dist)
+    if field.kind == 'hand':
+        sdf, grad, rgb = field.evaluate(pts, rays_d, S, _lib.f32(bt_inv).reshape(n_frames, 21, 4, 4),
+                                        _lib.f32(T_pose_21).reshape(-1, 21, 3))
+    else:
+        sdf, grad, rgb = field.evaluate(pts, rays_d, S)
+    sdf = sdf.reshape(n)
+    alpha = torch.empty(n, device=dev)
+    c = torch.empty(n, device=dev) if want_c else None
+    _lib.check(lib.hn_alpha(_lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rays_d), _lib.ptr(dists), n, S, float(field.inv_s),
+                            _lib.ptr(alpha), _lib.ptr(c), _lib.stream_ptr()), 'hn_alpha')
+    return dict(alpha=alpha.reshape(R, S), c=None if c is None else c.reshape(R, S), rgb=rgb, sdf=sdf, grad=grad, dists=dists)
+
+
+def _grid_points(bound_min, bound_max, resolution, device):
+    """The sample grid of extract_geometry (utils/renderer.py:263-273): linspace per axis, 'ij' mesh, x slowest."""
+    bmin = torch.as_tensor(bound_min, dtype=torch.float32).reshape(3).cpu()
+    bmax = torch.as_tensor(bound_max, dtype=torch.float32).reshape(3).cpu()
+    ax = [torch.linspace(float(bmin[i]), float(bmax[i]), int(resolution)) for i in range(3)]
+    xx, yy, zz = torch.meshgrid(ax[0], ax[1], ax[2], indexing='ij')
+    return torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1).to(device).contiguous(), bmin.numpy(), bmax.numpy()
+
+
+def _marching_cubes(u, threshold, resolution, b_min_np, b_max_np):
+    """utils/renderer.py:279-284.  PyMCubes is the reference's third-party dependency; it stays one here."""
+    try:
+        import mcubes
+    except ImportError as e:          # pragma: no cover - not installed in the build image
+        raise ImportError('extract_geometry needs PyMCubes (`mcubes`), as the reference does; '
+                          'extract_fields() returns the SDF volume without it') from e
+    vertices, triangles = mcubes.marching_cubes(u, threshold)
+    triangles = triangles[..., ::-1]
+    vertices = vertices / (resolution - 1.0) * (b_max_np - b_min_np)[None, :] + b_min_np[None, :]
+    return vertices, triangles
+
+
 class NeuSRenderer:
     """Single-field renderer (utils/renderer.py:39-284)."""
 
@@ -118,6 +207,72 @@ class NeuSRenderer:
         """The SDF grid queries of extract_geometry (utils/renderer.py:260-278) in one launch."""
         return self.field().sdf(pts, bt_inv, T_pose_21)
 
+    # ---- the reference's building blocks, callable on their own as in utils/renderer.py ---------------------------
+    def convert_obj_to_local(self, rays_o, rays_d, Ro, To):
+        """utils/renderer.py:180-188: o' = Ro (o - To), d' = Ro d."""
+        rays_o, rays_d = _lib.f32(rays_o).reshape(-1, 3), _lib.f32(rays_d).reshape(-1, 3)
+        dev = rays_o.device
+        o2, d2 = torch.empty_like(rays_o), torch.empty_like(rays_d)
+        _lib.check(self.lib.hn_obj_local_fwd(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(_lib.f32(Ro, dev).reshape(1, 3, 3)),
+                                             _lib.ptr(_lib.f32(To, dev).reshape(1, 3)), 1, rays_o.shape[0], _lib.ptr(o2),
+                                             _lib.ptr(d2), _lib.stream_ptr()), 'hn_obj_local_fwd')
+        return o2, d2
+
+    def up_sample(self, rays_o, rays_d, z_vals, sdf, n_importance, inv_s):
+        """utils/renderer.py:60-86 -> z_samples [B, n_importance]."""
+        return _up_sample(self.lib, z_vals, sdf, n_importance, inv_s)
+
+    def cat_z_vals(self, rays_o, rays_d, z_vals, new_z_vals, sdf, bt_inv, T_pose_21, last=False):
+        """utils/renderer.py:88-105 -> (z_vals [B,k+m], sdf [B,k+m])."""
+        ro, rd = _lib.f32(rays_o).reshape(-1, 3), _lib.f32(rays_d).reshape(-1, 3)
+        return _cat_z_vals(self.lib, self.field(), ro, rd, _lib.f32(z_vals), _lib.f32(new_z_vals),
+                           None if sdf is None else _lib.f32(sdf).reshape(z_vals.shape), bt_inv, T_pose_21, last)
+
+    def render_core(self, rays_o, rays_d, bt_inv, T_pose_21, verts, z_vals, sample_dist, sdf_network=None,
+                    deviation_network=None, color_network=None):
+        """utils/renderer.py:107-177 at the given depths z_vals [B,S] (rays already in the field's frame).  The three
+        network arguments are accepted for signature parity; the evaluation uses the renderer's own modules, which is
+        what every reference call site passes (utils/renderer.py:237-245).  Returns color [B,3], s_val [B*S,1],
+        weights [B,S], cdf [B,S], gradient_error []."""
+        for given, own in ((sdf_network, self.sdf_network), (deviation_network, self.deviation_network),
+                           (color_network, self.color_network)):
+            if given is not None and given is not own:
+                raise ValueError('render_core evaluates the networks this renderer was constructed with')
+        f = self.field()
+        ro, rd = _lib.f32(rays_o).reshape(-1, 3), _lib.f32(rays_d).reshape(-1, 3)
+        z = _lib.f32(z_vals, ro.device)
+        B, S = z.shape
+        dev = ro.device
+        a = _alpha_color(self.lib, f, ro, rd, z, sample_dist, bt_inv, T_pose_21, want_c=True)
+        color, weights = torch.empty(B, 3, device=dev), torch.empty(B, S, device=dev)
+        wsum, wmax, gerr = torch.empty(B, device=dev), torch.empty(B, device=dev), torch.zeros(1, device=dev)
+        _lib.check(self.lib.hn_composite1(_lib.ptr(a['alpha']), _lib.ptr(a['c']), _lib.ptr(a['rgb']), _lib.ptr(a['grad']), B, S,
+                                          _lib.ptr(color), _lib.ptr(weights), _lib.ptr(wsum), _lib.ptr(wmax), _lib.ptr(gerr),
+                                          _lib.stream_ptr()), 'hn_composite1')
+        self.N = B * S
+        return {
+            'color': color,
+            's_val': torch.full((B * S, 1), 1.0 / f.inv_s, device=dev),
+            'weights': weights,
+            'cdf': a['c'],
+            'gradient_error': (gerr / float(B * S)).reshape(()),
+        }
+
+    def extract_fields(self, bound_min, bound_max, resolution, bt_inv=None, T_pose_21=None):
+        """The SDF volume u [res,res,res] of extract_geometry (utils/renderer.py:260-278): the reference walks the grid
+        in 64^3 host chunks, here the whole grid is one hn_field_sdf launch."""
+        dev = torch.device('cuda')
+        pts, _, _ = _grid_points(bound_min, bound_max, resolution, dev)
+        with torch.no_grad():
+            val = self.field().sdf(pts, bt_inv, T_pose_21)
+        return val.reshape(resolution, resolution, resolution).cpu().numpy()
+
+    def extract_geometry(self, bound_min, bound_max, resolution, bt_inv, T_pose_21, Ro, To, threshold=0.0):
+        """utils/renderer.py:260-284 -> (vertices, triangles)."""
+        _, bmin, bmax = _grid_points(bound_min, bound_max, 2, torch.device('cpu'))
+        u = self.extract_fields(bound_min, bound_max, resolution, bt_inv, T_pose_21)
+        return _marching_cubes(u, threshold, resolution, bmin, bmax)
+
 
 def _wants_grad(*xs):
     return torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs)
@@ -148,6 +303,7 @@ class NeuSRenderer_fitting:
         self._fields = None
         self._version = None
         self._ws = _Workspace()
+        self._ws_bwd = _Workspace()      # workspace of the adjoint launches (autograd.DualRenderFn.backward)
         self.lib = _lib.load()
 
     def fields(self):
@@ -191,6 +347,7 @@ class NeuSRenderer_fitting:
                                 _lib.ptr(out['grad_hand']), _lib.ptr(out['grad_obj']), _lib.ptr(out['gerr']),
                                 _lib.ptr(out['z_vals']), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, 'hn_render_dual')
+        self._last_z_raw = out['z_vals']
         return out
 
     def render(self, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, Ro, To, get_SDF=False, t_rand=None):
@@ -226,12 +383,89 @@ class NeuSRenderer_fitting:
         F, P = ro.shape[0], ro.shape[1]
         outs = DualRenderFn.apply(ro, rd, g(bt_inv), g(T_pose_21), g(Ro), g(To), self, near, far, t_rand)
         color, wsum, sdf_h, sdf_o, grad_h, grad_o, gerr = outs
+        self.last_z_vals = self._last_z_raw.reshape(F, P, -1) if self.batched else self._last_z_raw
         if self.batched:
             color, wsum = color.reshape(F, P, 3), wsum.reshape(F, P, 1)
         return {
             'color_fine': color, 'weight_sum': wsum, 'sdf_hand': sdf_h, 'sdf_obj': sdf_o,
             'gradient_error_hand': gerr[0], 'gradient_error_obj': gerr[1], 'gradient_hand': grad_h, 'gradient_obj': grad_o,
         }
+
+    # ---- the reference's building blocks, callable on their own as in utils/renderer.py:313-432 --------------------
+    def _field_of(self, ctype):
+        return self.fields()[1 if ctype == 'obj' else 0]
+
+    def convert_obj_to_local(self, rays_o, rays_d, Ro, To):
+        """utils/renderer.py:424-432 (batched: utils/renderer_batch.py:176-182): o' = Ro (o - To), d' = Ro d."""
+        ro, rd = _lib.f32(rays_o), _lib.f32(rays_d)
+        shape = ro.shape
+        F = shape[0] if self.batched else 1
+        P = ro.reshape(F, -1, 3).shape[1]
+        dev = ro.device
+        o2, d2 = torch.empty(F * P, 3, device=dev), torch.empty(F * P, 3, device=dev)
+        _lib.check(self.lib.hn_obj_local_fwd(_lib.ptr(ro.reshape(-1, 3)), _lib.ptr(rd.reshape(-1, 3)),
+                                             _lib.ptr(_lib.f32(Ro, dev).reshape(F, 3, 3)), _lib.ptr(_lib.f32(To, dev).reshape(F, 3)),
+                                             F, P, _lib.ptr(o2), _lib.ptr(d2), _lib.stream_ptr()), 'hn_obj_local_fwd')
+        return o2.reshape(shape), d2.reshape(shape)
+
+    def up_sample(self, rays_o, rays_d, z_vals, sdf, n_importance, inv_s):
+        """utils/renderer.py:313-338 (batched: utils/renderer_batch.py:68-94) -> z_samples [.., n_importance]."""
+        return _up_sample(self.lib, z_vals, sdf, n_importance, inv_s)
+
+    def cat_z_vals(self, rays_o, rays_d, z_vals, new_z_vals, sdf, bt_inv, T_pose_21, ctype, last=False):
+        """utils/renderer.py:340-357; batched (utils/renderer_batch.py:96-113) with its SDF-row quirk (SURVEY B-1) when
+        strict_reference is set.  Shapes follow the class: [B,k] or [F,P,k]."""
+        z = _lib.f32(z_vals)
+        lead = z.shape[:-1]
+        F = lead[0] if self.batched else 1
+        R = z.reshape(-1, z.shape[-1]).shape[0]
+        ro, rd = _lib.f32(rays_o).reshape(R, 3), _lib.f32(rays_d).reshape(R, 3)
+        zn = _lib.f32(new_z_vals).reshape(R, -1)
+        quirk = (R // F) if (self.batched and self.strict_reference and F > 1) else 0
+        z_out, sdf_out = _cat_z_vals(self.lib, self._field_of(ctype), ro, rd, z.reshape(R, -1), zn,
+                                     None if sdf is None else _lib.f32(sdf).reshape(R, -1), bt_inv, T_pose_21, last,
+                                     quirk_rays_per_frame=quirk, n_frames=F)
+        z_out = z_out.reshape(*lead, -1)
+        return z_out, (sdf if last else sdf_out.reshape(*lead, -1))
+
+    def get_alpha_sample_color(self, rays_o, rays_d, bt_inv, T_pose_21, z_vals, sample_dist, ctype, get_SDF=False):
+        """utils/renderer.py:360-422 (batched: utils/renderer_batch.py:115-174): one field at the shared depths ->
+        (alpha [B,S], sampled_color [B,S,3], sdf [B*S,1], gradient_error [], gradients [B*S,3]); rays in that field's
+        frame (object-local for ctype 'obj')."""
+        z = _lib.f32(z_vals)
+        lead = z.shape[:-1]
+        S = z.shape[-1]
+        F = lead[0] if self.batched else 1
+        R = z.reshape(-1, S).shape[0]
+        ro, rd = _lib.f32(rays_o).reshape(R, 3), _lib.f32(rays_d).reshape(R, 3)
+        a = _alpha_color(self.lib, self._field_of(ctype), ro, rd, z.reshape(R, S), sample_dist, bt_inv, T_pose_21, n_frames=F)
+        nrm = a['grad'].norm(dim=-1)
+        return (a['alpha'].reshape(*lead, S), a['rgb'].reshape(*lead, S, 3), a['sdf'].reshape(-1, 1),
+                ((nrm - 1.0) ** 2).mean(), a['grad'])
+
+    def extract_fields(self, bound_min, bound_max, resolution, bt_inv, T_pose_21, Ro, To, get_type):
+        """The SDF volume of extract_geometry (utils/renderer.py:537-556) in one launch; 'obj' queries go through
+        o' = Ro (p - To) first (:550-552)."""
+        dev = torch.device('cuda')
+        pts, _, _ = _grid_points(bound_min, bound_max, resolution, dev)
+        hand, obj = self.fields()
+        with torch.no_grad():
+            if get_type == 'hand':
+                val = hand.sdf(pts, _lib.f32(bt_inv).reshape(-1, 21, 4, 4)[:1], _lib.f32(T_pose_21).reshape(-1, 21, 3)[:1])
+            else:
+                local = torch.empty_like(pts)
+                dummy = torch.empty_like(pts)
+                _lib.check(self.lib.hn_obj_local_fwd(_lib.ptr(pts), _lib.ptr(pts), _lib.ptr(_lib.f32(Ro, dev).reshape(-1, 3, 3)[:1].contiguous()),
+                                                     _lib.ptr(_lib.f32(To, dev).reshape(-1, 3)[:1].contiguous()), 1, pts.shape[0],
+                                                     _lib.ptr(local), _lib.ptr(dummy), _lib.stream_ptr()), 'hn_obj_local_fwd')
+                val = obj.sdf(local)
+        return val.reshape(resolution, resolution, resolution).cpu().numpy()
+
+    def extract_geometry(self, bound_min, bound_max, resolution, bt_inv, T_pose_21, Ro, To, get_type, threshold=0.0):
+        """utils/renderer.py:537-564 -> (vertices, triangles)."""
+        _, bmin, bmax = _grid_points(bound_min, bound_max, 2, torch.device('cpu'))
+        u = self.extract_fields(bound_min, bound_max, resolution, bt_inv, T_pose_21, Ro, To, get_type)
+        return _marching_cubes(u, threshold, resolution, bmin, bmax)
 
     def get_inner_point_id(self, pts, bt_inv, T_pose_21):
         """utils/renderer.py:566-572: indices of points with hand sdf <= 0."""

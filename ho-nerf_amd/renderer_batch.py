@@ -2,6 +2,8 @@
 utils/renderer_batch.py:41-313 (used by fitting_video.py): rays `[F,P,3]`,
 `bt_inv [F,21,4,4]`, `T_pose_21 [F,21,3]`, `Ro [F,3,3]`, `To [F,3]`; colour and
 weight outputs keep the leading frame dimension."""
+import torch
+
 from . import lib as _lib
 from .renderer import NeuSRenderer_fitting as _Unbatched
 
@@ -33,3 +35,52 @@ class NeuSRenderer_fitting(_Unbatched):
             'gradient_hand': o['grad_hand'],
             'gradient_obj': o['grad_obj'],
         }
+
+    def get_stable_loss_cross(self, pts, bt_inv, T_pose_21, Ro, To):
+        """utils/renderer_batch.py:318-371: the 'stable' term of fitting_video (fit type '1234', weight x100 at
+        fitting_video.py:322-324).  pts [F,V,3]: the object's vertices per frame of the window; every 10th vertex is
+        taken to the world with (Ro, To), the hand SDF is evaluated there, and over the frames in which the hand
+        penetrates the object a vertex that is inside the hand in one frame is pushed to be inside in all of them
+        (in_err), while the nearest outside vertex of every inside vertex (the reference's cKDTree query on the CPU;
+        here hn_nearest_masked on the device) is kept outside (out_err).  Differentiable w.r.t. bt_inv, Ro, To.
+
+        Everything stays on the device and nothing synchronises; the reference's `if len(in_id_list) > 1` becomes a
+        `where`.  strict_reference reproduces how the reference forms the 'outside' set: `np.setdiff1d(range(V), mask)`
+        is applied to the boolean MASK, not to indices, so what is removed from the vertex list are the integer values
+        the mask takes (vertex 1 if any vertex is inside, vertex 0 if any is outside) and the 'outside' candidates
+        include the inside vertices themselves; with strict_reference = False the complement of the inside set is used."""
+        from .autograd import HandSdfFn
+        dev = torch.device('cuda')
+        g = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(x)).to(device=dev, dtype=torch.float32)
+        pts = g(pts)[:, ::10, :]
+        Fr, V, _ = pts.shape
+        Ro, To, bt = g(Ro).reshape(Fr, 3, 3), g(To).reshape(Fr, 3), g(bt_inv).reshape(Fr, 21, 4, 4)
+        tp = g(T_pose_21).reshape(-1, 21, 3)
+        pts_world = (Ro.unsqueeze(1) @ pts.unsqueeze(-1))[..., 0] + To.unsqueeze(1)
+        hand = self.fields()[0]
+        sdf = HandSdfFn.apply(pts_world.contiguous(), bt, tp, hand, self._ws_bwd)             # [F,V]
+        with torch.no_grad():
+            inside = sdf < 0                                                                    # in_id_list
+            pen = inside.any(dim=1)                                                             # frames that penetrate
+            in_time = pen.sum().to(torch.float32)
+            if self.strict_reference:
+                cand = torch.ones(Fr, V, dtype=torch.bool, device=dev)
+                cand[:, 1] &= ~inside.any(dim=1)          # the value True (= 1) occurs in the mask
+                cand[:, 0] &= ~(~inside).any(dim=1)       # the value False (= 0) occurs in the mask
+            else:
+                cand = ~inside
+            query = (inside & pen[:, None]).to(torch.uint8).contiguous()
+            candm = cand.to(torch.uint8).contiguous()
+            selected = torch.empty(Fr, V, dtype=torch.uint8, device=dev)
+            p0 = _lib.f32(pts[0]).reshape(V, 3)                                                 # the reference queries pts[0]
+            _lib.check(self.lib.hn_nearest_masked(_lib.ptr(p0), V, Fr, _lib.ptr(query), _lib.ptr(candm), _lib.ptr(selected), None,
+                                                  _lib.stream_ptr()), 'hn_nearest_masked')
+            n_in = inside.sum(dim=1).to(torch.float32)
+            denom = ((in_time - 1.0) * n_in).clamp_min(1.0)
+            w_in = (inside & pen[:, None]).to(torch.float32) / denom[:, None]                   # [cid, vertex]
+            w_out = (selected.bool() & pen[:, None]).to(torch.float32) / denom[:, None]
+            penf = pen.to(torch.float32)
+        pos = (sdf.clip(0, 1e7) * penf[:, None]).sum(0)                                         # over the penetrating frames
+        neg = (sdf.clip(-1e7, 0).abs() * penf[:, None]).sum(0)
+        total = (w_in.sum(0) * pos).sum() + 0.05 * (w_out.sum(0) * neg).sum()
+        return torch.where(in_time > 1, total / in_time.clamp_min(1.0), torch.zeros_like(total))

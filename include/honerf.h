@@ -123,7 +123,8 @@ int hn_sample_points_bwd(const float* z, const float* g_pts, int n_rays, int n, 
 /* ---- hierarchical sampling ------------------------------------------------------------
  * NeuSRenderer.up_sample + sample_pdf(det=True) (utils/renderer.py:60-86, 10-37).
  * z, sdf [n_rays,k] -> z_new [n_rays,n_new]; inds (int64 [n_rays,n_new], may be
- * NULL) is the searchsorted(right=True) result. k <= 256, n_new <= 64. */
+ * NULL) is the searchsorted(right=True) result.  Limits: 2 <= k <= 256, 1 <= n_new <= 64 (the confs use
+ * k = 64..112, n_new = 16); outside them HN_EINVAL. */
 int hn_upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, float inv_s, float* z_new,
                 int64_t* inds, hn_stream_t stream);
 
@@ -147,7 +148,8 @@ int hn_sort_rows(const float* v, int n_rays, int n, float* out, hn_stream_t stre
  * n_frames = 1, pts_per_frame = n_pts).  Obj fields ignore them (pass NULL). */
 size_t hn_field_workspace_bytes(const hn_field* f, int n_pts);
 
-/* .sdf() (utils/fields.py:158-160, 330-331): pts [n,3] -> sdf [n]. */
+/* .sdf() (utils/fields.py:158-160, 330-331): pts [n,3] -> sdf [n]; also the grid queries of extract_geometry
+ * (utils/renderer.py:260-284, 537-564) in one launch. */
 int hn_field_sdf(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose,
                  int n_frames, int pts_per_frame, float* sdf, void* workspace, size_t workspace_bytes,
                  hn_stream_t stream);
@@ -162,6 +164,29 @@ int hn_field_eval(const hn_field* f, const float* pts, const float* rays_d, int 
                   const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame, float* sdf,
                   float* grad, float* rgb, float* feat, void* workspace, size_t workspace_bytes,
                   hn_stream_t stream);
+
+/* ---- the modules one at a time (Public interface of L1, utils/fields.py) -------------------------------------
+ * SDFNetwork.forward also returns xyz_feature, r, h (utils/fields.py:132-156; anerf_emb_point[_batch] :22-52):
+ * pts [n,3] -> xyz_feature [n,1386], r [n,21,3] (may be NULL), h [n,21] (may be NULL). */
+int hn_hand_features(const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
+                     int pts_per_frame, float* xyz_feature, float* r, float* h, hn_stream_t stream);
+
+/* RenderingNetwork_OBJ.forward(points, view_dirs, feature_vectors, normals) (utils/fields.py:387-405) and
+ * RenderingNetwork.forward(view_dirs, xyz_feature, feature_vectors, h, normals) (:222-240) with caller-supplied
+ * inputs: x = points [n,3] (obj) or xyz_feature [n,1386] (hand; view_dirs is unused there and may be NULL),
+ * view_dirs [n,3], feature_vectors [n,256], normals [n,3] -> rgb [n,3]. */
+size_t hn_color_forward_workspace_bytes(const hn_field* f, int n_pts);
+int hn_color_forward(const hn_field* f, const float* x, const float* view_dirs, const float* feature_vectors,
+                     const float* normals, int n_pts, float* rgb, void* workspace, size_t workspace_bytes,
+                     hn_stream_t stream);
+
+/* Nearest candidate vertex, the cKDTree query of get_stable_loss_cross (utils/renderer_batch.py:355-358):
+ * pts [n_verts,3]; query_mask, cand_mask [n_sets,n_verts] (bytes, non-zero = member).  For every query vertex of
+ * set t the nearest candidate vertex of the same set is marked in selected [n_sets,n_verts] (zeroed here; the
+ * reference's np.unique = a set); nearest (int32 [n_sets,n_verts], may be NULL) receives the index, -1 for
+ * non-query vertices. */
+int hn_nearest_masked(const float* pts, int n_verts, int n_sets, const unsigned char* query_mask,
+                      const unsigned char* cand_mask, unsigned char* selected, int32_t* nearest, hn_stream_t stream);
 
 /* ---- SDF -> alpha, compositing --------------------------------------------------------
  * utils/renderer.py:147-161 (cos_anneal_ratio = 1): alpha [n] (clipped to [0,1]) and
@@ -188,7 +213,9 @@ int hn_composite2(const float* alpha_h, const float* rgb_h, const float* grad_h,
  * path through `.gradient()`: utils/fields.py:165-177, 336-347 with create_graph=True; fitting_single.py:289-291).
  * g_sdf [n], g_grad [n,3], g_rgb [n,3] -> g_pts [n,3], g_rays_d [n/samples_per_ray,3] (may be NULL), and for hand
  * fields g_bt_inv [n_frames,21,4,4], g_T_pose [n_frames,21,3] (may be NULL).  The sweeps are specified in
- * oracle/field_bwd.py.  g_bt_inv / g_T_pose are ACCUMULATED into (zero them first).  Workspace: hn_field_bwd_workspace_bytes. */
+ * oracle/field_bwd.py.  g_bt_inv / g_T_pose are ACCUMULATED into (zero them first).  Workspace: hn_field_bwd_workspace_bytes.
+ * g_grad == g_rgb == NULL selects the adjoint of `.sdf()` alone (the hand SDF on object vertices of
+ * get_stable_loss_cross, utils/renderer_batch.py:318-371): g_sdf -> g_pts and the pose gradients. */
 size_t hn_field_bwd_workspace_bytes(const hn_field* f, int n_pts);
 int hn_field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray,
                       const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf,

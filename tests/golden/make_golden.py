@@ -166,7 +166,149 @@ def hand_scene_rays(n, seed):
     return o, d, torch.from_numpy(bt_inv), torch.from_numpy(T_pose), joints
 
 
+def reference_block(path, start_marker, end_marker):
+    """The statements of a reference entry script between two marker lines (start inclusive, end exclusive),
+    dedented, as a code object.  The fitting scripts cannot be imported (pyhocon, cv2, trimesh, pytorch3d and a CUDA
+    device are needed at import time), but their loss formulas are plain torch statements inside `Runner.fitting`:
+    they are read from the reference file HERE, at fixture-generation time, and executed unmodified on synthetic
+    tensors -- nothing of them is stored in this repository, only the numbers they produce."""
+    import textwrap
+    lines = open(os.path.join(REF, path)).read().split('\n')
+    a = next(i for i, l in enumerate(lines) if start_marker in l)
+    b = next(i for i, l in enumerate(lines) if end_marker in l and i > a)
+    return compile(textwrap.dedent('\n'.join(lines[a:b])), path + ':%d-%d' % (a + 1, b), 'exec')
+
+
+def loss_goldens(nets, nets_b, g):
+    """fitting_single.py:251-288 and fitting_video.py:285-339 executed on renders of the reference renderers:
+    loss terms and d loss / d (render outputs, pose-dependent tensors)."""
+    import types as _t
+    import torch.nn.functional as F_
+    quiet = lambda *a, **k: None
+    # ---- fitting_single: fit types '1' and '12' on a two-field render --------------------------------------------
+    pl_single = {}
+    exec(reference_block('fitting_single.py', 'def pose_loss(target_pose, pred_pose)', 'if self.fit_type =='), {'torch': torch}, pl_single)
+    blk = reference_block('fitting_single.py', "color_fine = render_out['color_fine']", 'optimizer.zero_grad()')
+    o, d, bt_inv, T_pose, joints = hand_scene_rays(24, 13)
+    R_obj, t_obj = synth.synth_obj_pose(3, center=tuple(joints[9] + np.array([0.03, 0.0, 0.02])))
+    ren = rr.NeuSRenderer_fitting(nets['sdf_hand'], nets['var_hand'], nets['color_hand'],
+                                  nets['sdf_obj'], nets['var_obj'], nets['color_obj'], 64, 64, 0, 4, 1.0)
+    torch.manual_seed(8)
+    res = ren.render(o, d, 0.4, 1.5, bt_inv, T_pose, None, torch.from_numpy(R_obj).T.contiguous(), torch.from_numpy(t_obj))
+    # shift the per-sample sdfs so that the contact / penetration selections are non-trivial
+    base = {k: res[k].detach().clone() for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj')}
+    base['sdf_hand'] = base['sdf_hand'] - base['sdf_hand'].median() - 0.002
+    base['sdf_obj'] = (base['sdf_obj'] - base['sdf_obj'].median()) * 0.05 - 0.001
+    true_rgb = torch.rand(24, 3, generator=g)
+    true_mask = (torch.rand(24, 1, generator=g) > 0.3).float()
+    joint3d_pred = torch.from_numpy(joints)
+    joint_3d = (joint3d_pred + 0.004 * torch.randn(21, 3, generator=g)).unsqueeze(0)
+    obj_verts_loss = torch.tensor(0.0123)
+    out = dict(true_rgb=true_rgb, true_mask=true_mask, joint3d_pred=joint3d_pred, joint_3d=joint_3d,
+               obj_verts_loss=obj_verts_loss, **{'in_' + k: v for k, v in base.items()})
+    for ft in ('1', '12'):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        j3 = joint_3d.clone().requires_grad_(True)
+        ns = dict(torch=torch, F=F_, print=quiet, render_out=leaves, true_rgb=true_rgb, true_mask=true_mask,
+                  self=_t.SimpleNamespace(fit_type=ft), pose_loss=pl_single['pose_loss'], joint3d_pred=joint3d_pred,
+                  joint_3d=j3, joint3d_gt=joint3d_pred, obj_verts_loss=obj_verts_loss, obj_verts_err_to_gt=obj_verts_loss,
+                  iter_id=0)
+        exec(blk, ns)
+        grads = torch.autograd.grad(ns['loss'], [leaves['color_fine'], leaves['weight_sum'], leaves['sdf_hand'], leaves['sdf_obj'], j3],
+                                    allow_unused=True)
+        z = lambda t_, like: torch.zeros_like(like) if t_ is None else t_
+        out.update({'s%s_loss' % ft: ns['loss'], 's%s_color' % ft: ns['color_fine_loss'], 's%s_mask' % ft: ns['mask_loss'],
+                    's%s_joint' % ft: ns['joint_loss'],
+                    's%s_g_color_fine' % ft: grads[0], 's%s_g_weight_sum' % ft: grads[1],
+                    's%s_g_sdf_hand' % ft: z(grads[2], base['sdf_hand']), 's%s_g_sdf_obj' % ft: z(grads[3], base['sdf_obj']),
+                    's%s_g_joint_3d' % ft: grads[4]})
+        if ft == '12':
+            out.update(s12_contact=ns['contact_loss'], s12_penet=ns['penet_loss'])
+    save('loss_single', **out)
+
+    # ---- get_stable_loss_cross + the fitting_video losses (fit type '1234') on a 4-frame window -------------------
+    Fr, P = 4, 10
+    os_, ds_, bts, Ros, Tos, jts = [], [], [], [], [], []
+    o0, d0, bt0, T_pose, joints = hand_scene_rays(P, 31)
+    rngw = np.random.RandomState(77)
+    for f in range(Fr):
+        # the same hand, moved rigidly a little from frame to frame; the object sits on the index finger
+        Rm = torch.from_numpy(synth._rodrigues(rngw.standard_normal(3), 0.03 * f).astype(np.float32))
+        tm = torch.tensor([0.002 * f, -0.001 * f, 0.0015 * f])
+        G = torch.eye(4)
+        G[:3, :3] = Rm
+        G[:3, 3] = tm + torch.from_numpy(joints[0]) - Rm @ torch.from_numpy(joints[0])
+        bts.append(bt0 @ torch.inverse(G))
+        jts.append((Rm @ (torch.from_numpy(joints) - torch.from_numpy(joints[0])).T).T + torch.from_numpy(joints[0]) + tm)
+        R_obj, t_obj = synth.synth_obj_pose(50, center=tuple(joints[6] + np.array([0.004, 0.0, 0.004]) * (1 + 0.3 * f)))
+        Ros.append(torch.from_numpy(R_obj)); Tos.append(torch.from_numpy(t_obj))
+        o, d, _, _, _ = hand_scene_rays(P, 31 + f)
+        os_.append(o); ds_.append(d)
+    o, d, bt, obj_r, obj_t, joint_3d = map(torch.stack, (os_, ds_, bts, Ros, Tos, jts))
+    Tp = T_pose.unsqueeze(0).expand(Fr, 21, 3).contiguous()
+    # object vertices: a 2.2 cm ellipsoid shell in object-local coordinates, 1500 vertices (150 after the [::10])
+    u = rngw.standard_normal((1500, 3))
+    verts = (u / np.linalg.norm(u, axis=1, keepdims=True) * np.array([0.022, 0.018, 0.02])).astype(np.float32)
+    obj_verts = torch.from_numpy(verts).unsqueeze(0).expand(Fr, -1, -1).contiguous()
+    renb = rb.NeuSRenderer_fitting(nets_b['sdf_hand'], nets_b['var_hand'], nets_b['color_hand'],
+                                   nets_b['sdf_obj'], nets_b['var_obj'], nets_b['color_obj'], 64, 64, 0, 4, 1.0)
+    renb.batch_size, renb.pixel_sample = Fr, P
+    bt_l, r_l, t_l = bt.clone().requires_grad_(True), obj_r.clone().requires_grad_(True), obj_t.clone().requires_grad_(True)
+    with Recorder():
+        stable = renb.get_stable_loss_cross(obj_verts, bt_l, Tp, r_l, t_l)
+    sg = torch.autograd.grad(stable, [bt_l, r_l, t_l])
+    pts_world = (obj_r.unsqueeze(1) @ obj_verts[:, ::10, :].unsqueeze(-1))[..., 0] + obj_t.unsqueeze(1)
+    hand_sdf = nets_b['sdf_hand'].sdf(pts_world, bt, Tp).reshape(Fr, -1).detach()
+    print('stable loss %.6f; penetrating frames %d; inside per frame %s'
+          % (float(stable), int((hand_sdf < 0).any(1).sum()), (hand_sdf < 0).sum(1).tolist()))
+    assert float(stable) > 0 and int((hand_sdf < 0).any(1).sum()) >= 2
+    save('stable_loss', obj_verts=obj_verts, bt_inv=bt, T_pose=Tp, obj_r=obj_r, obj_t=obj_t, hand_sdf=hand_sdf,
+         stable=stable, g_bt_inv=sg[0], g_obj_r=sg[1], g_obj_t=sg[2])
+
+    pl_video = {}
+    exec(reference_block('fitting_video.py', 'def pose_loss(target_pose, pred_pose)', 'get_render_all = False'), {'torch': torch}, pl_video)
+    blkv = reference_block('fitting_video.py', "color_fine = render_out['color_fine']", 'optimizer.zero_grad()')
+    torch.manual_seed(9)
+    resv = renb.render(o, d, 0.4, 1.5, bt, Tp, None, torch.inverse(obj_r), obj_t)
+    basev = {k: resv[k].detach().clone() for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj')}
+    basev['sdf_hand'] = basev['sdf_hand'] - basev['sdf_hand'].median() - 0.002
+    basev['sdf_obj'] = (basev['sdf_obj'] - basev['sdf_obj'].median()) * 0.05 - 0.001
+    true_rgb = torch.rand(Fr, P, 3, generator=g)
+    true_mask = (torch.rand(Fr, P, 1, generator=g) > 0.3).float()
+    joint3d_pred = joint_3d + 0.003 * torch.randn(Fr, 21, 3, generator=g)
+    pred_v = (obj_r.unsqueeze(1) @ obj_verts[:, ::10].unsqueeze(-1))[..., 0] + obj_t.unsqueeze(1)   # 150 vertices: small fixture
+    comp_v = pred_v + 0.002 * torch.randn(pred_v.shape, generator=g)
+    outv = dict(true_rgb=true_rgb, true_mask=true_mask, joint3d_pred=joint3d_pred, joint_3d=joint_3d, pred_obj_v_w=pred_v,
+                compare_obj_v_w=comp_v, obj_verts_loss=pl_video['pose_loss'](pred_v, comp_v),
+                **{'in_' + k: v for k, v in basev.items()})
+    for tag, index, first in (('mid', [3, 4, 5, 6], False), ('head', [0, 1, 2, 3], False), ('tail', [6, 7, 8, 9], False),
+                              ('first', [0, 1, 2, 3], True)):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in basev.items()}
+        j3, pv = joint_3d.clone().requires_grad_(True), pred_v.clone().requires_grad_(True)
+        ns = dict(torch=torch, F=F_, print=quiet, render_out=leaves, true_rgb=true_rgb, true_mask=true_mask,
+                  self=_t.SimpleNamespace(fit_type='1234', renderer=_t.SimpleNamespace(get_stable_loss_cross=lambda *a: stable.detach())),
+                  pose_loss=pl_video['pose_loss'], joint3d_pred=joint3d_pred, joint_3d=j3, joint3d_gt=joint3d_pred,
+                  pred_obj_v_w=pv, compare_obj_v_w=comp_v, obj_verts_loss=pl_video['pose_loss'](pv, comp_v),
+                  obj_verts_err_to_gt=torch.tensor(0.0), iter_id=0, sub_iter_id=0, view_id=0 if first else 1,
+                  index=torch.tensor(index), data_num=10, obj_verts=obj_verts, bone_transformation_inv=bt, T_pose_21=Tp,
+                  obj_r=obj_r, obj_t=obj_t)
+        exec(blkv, ns)
+        grads = torch.autograd.grad(ns['loss'], [leaves['color_fine'], leaves['weight_sum'], leaves['sdf_hand'], leaves['sdf_obj'], j3, pv])
+        outv.update({tag + '_loss': ns['loss'], tag + '_smooth': ns['smooth_loss'], tag + '_color': ns['color_fine_loss'],
+                     tag + '_mask': ns['mask_loss'], tag + '_contact': ns['contact_loss'], tag + '_penet': ns['penet_loss'],
+                     tag + '_index': np.asarray(index), tag + '_first': first,
+                     tag + '_g_color_fine': grads[0], tag + '_g_weight_sum': grads[1], tag + '_g_sdf_hand': grads[2],
+                     tag + '_g_sdf_obj': grads[3], tag + '_g_joint_3d': grads[4], tag + '_g_pred_obj_v_w': grads[5]})
+    save('loss_video', stable=stable.detach(), **outv)
+
+
 def main():
+    only = os.environ.get('HONERF_GOLDEN_ONLY', '')
+    if only == 'loss':
+        emb, nets = build_nets()
+        emb_b, nets_b = build_nets(use_batch=True)
+        loss_goldens(nets, nets_b, torch.Generator().manual_seed(4321))
+        return
     emb, nets = build_nets()
     g = torch.Generator().manual_seed(1234)
 
@@ -325,6 +467,9 @@ def main():
     res = dict(res, z_vals=a_h[4], alpha_hand=out_h[0], rgb_hand=out_h[1], alpha_obj=out_o[0], rgb_obj=out_o[1])
     save('render_dual_batch', rays_o=o, rays_d=d, bt_inv=bt, T_pose=Tp, Ro=Ro, To=To, t_rand=t_rand,
          near=0.4, far=1.5, n_samples=64, n_importance=64, **{k: v for k, v in res.items()})
+
+    # ---- loss formulas of the fitting scripts + get_stable_loss_cross (own generator: the fixtures above keep theirs) ----
+    loss_goldens(nets, nets_b, torch.Generator().manual_seed(4321))
 
 
 if __name__ == '__main__':

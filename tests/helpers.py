@@ -31,12 +31,31 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+# ---- parity report: every observed error of a comparison, keyed by test id (conftest writes it at session end) -----
+REPORT = []
+CURRENT_TEST = ['']
+
+
+def record(what, observed, bound, kind='rel', **extra):
+    """One line of the parity report: the OBSERVED error next to the bound the test asserts."""
+    REPORT.append(dict(test=CURRENT_TEST[0], what=what, observed=float(observed), bound=float(bound), kind=kind, **extra))
+
+
+def bounded(what, observed, bound, **extra):
+    """record + assert for comparisons that are not a plain rel_err of two arrays."""
+    record(what, observed, bound, **extra)
+    assert observed <= bound, '%s: %.3e > %.1e' % (what, observed, bound)
+    return observed
+
+
 def assert_close(a, b, rtol, what=''):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
     assert a.shape == b.shape, '%s: shape %s vs %s' % (what, a.shape, b.shape)
     e = rel_err(a, b)
+    record(what, e, rtol)
     assert e <= rtol, '%s: rel err %.3e > %.1e' % (what, e, rtol)
+    return e
 
 
 def oracle_fields_fp64():
@@ -64,9 +83,11 @@ def assert_parity(hip, ref32, exact64, what, rtol=1e-4, cap=1e-3):
     exact64 = exact64.reshape(ref32.shape)
     e_hr = rel_err(hip, ref32)
     if e_hr <= rtol:
+        record(what, e_hr, rtol)
         return e_hr
     e_ref = rel_err(ref32, exact64)
     e_hip = rel_err(hip, exact64)
+    record(what, e_hr, cap, kind='rel, conditioning-aware', ref32_vs_fp64=e_ref, hip_vs_fp64=e_hip)
     assert e_hr <= cap and e_hip <= 1.5 * e_ref + 1e-5, (
         '%s: hip-vs-ref %.3e > %.1e and hip-vs-exact %.3e is worse than ref-vs-exact %.3e'
         % (what, e_hr, rtol, e_hip, e_ref))

@@ -178,3 +178,20 @@ def test_window_parallel_gradient_allreduce_keeps_replicas_identical():
             p -= 0.1 * g
     for a, b in zip(pose0, pose):
         assert torch.allclose(a, b, atol=1e-6)
+
+
+def test_bench_gpus_flag_spawns_ranks_or_refuses_a_mismatch():
+    """bench.py --gpus N: without a torch.distributed environment it builds the driver's launch line for N ranks (run
+    as a child process before any GPU call); inside one it refuses a world size that differs from --gpus instead of
+    quietly reporting n_gpus = 1."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.spawn_command(4, ['--gpus', '4', '--steps', '2'])
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert '127.0.0.1' in cmd and cmd[-4:] == ['--gpus', '4', '--steps', '2'] and cmd[-5].endswith('bench.py')
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and 'WORLD_SIZE=2' in r.stderr

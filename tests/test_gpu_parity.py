@@ -16,12 +16,25 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (assert_close, assert_parity, cu, oracle_fields, oracle_fields_fp64, packed_fields,
+from helpers import (assert_close, assert_parity, bounded, cu, oracle_fields, oracle_fields_fp64, packed_fields,
                      product_modules, rel_err, t)
 
 pytestmark = pytest.mark.gpu
 
 RT = 1e-4
+# End-to-end bounds of whole renders WITH importance sampling (every other comparison is at RT = 1e-4 or carries its
+# measured noise floor in profiles/r02/parity_report.json).  The sampler is ill-conditioned: a 1e-7 change of an SDF
+# value moves samples by 1e-5, so the end-to-end figure measures sample placement, not arithmetic; the same renders
+# are held to 1e-4 stage-wise on the reference's own depths (test_render_core_on_reference_depths,
+# test_dual_core_on_reference_depths).  Each bound is <= 4x the value observed on MI355X (parity_report.json).
+E2E = {
+    'obj_64_64': {'color_fine': 2e-3, 'weight_sum': 2e-3, 'gradient_error': 2e-3},
+    'hand_64_64': {'color_fine': 2e-3, 'weight_sum': 2e-3, 'gradient_error': 2e-3},
+    'dual': {'color_fine': 2e-3, 'weight_sum': 2e-3, 'sdf_obj': 2e-3},
+    'dual_batch': {'color_fine': 2e-3, 'weight_sum': 2e-3, 'sdf_obj': 2e-3},
+}
+E2E_GRAD = 6e-2            # gradients through our own importance-sampled depths vs the reference's gradients
+REF_DEPTH_GRAD = {'rays_o': 5e-3, 'rays_d': 5e-3, 'Ro': 5e-3, 'To': 5e-3, 'bt_inv': 5e-3}   # same, on the reference's depths
 
 
 @pytest.fixture(scope='module')
@@ -313,9 +326,11 @@ def test_render_single_golden_importance(golden, tag, prec):
     out = ren.render(cu(g['rays_o']), cu(g['rays_d']), float(g['near']), float(g['far']), g.get('bt_inv'),
                      g.get('T_pose'), None, g.get('Ro'), g.get('To'), 0, t_rand=cu(g['t_rand']))
     errs = {k: rel_err(out[k].cpu().numpy().reshape(g[k].shape), g[k]) for k in KEYS1}
-    print(tag, errs)
-    assert errs['color_fine'] < 2e-3 and errs['weight_sum'] < 2e-3, errs
-    assert errs['gradient_error'] < 2e-3, errs
+    for k in ('color_fine', 'weight_sum', 'gradient_error'):
+        bounded('%s %s (end to end, 4 importance rounds)' % (tag, k), errs[k], E2E[tag][k])
+    for k in KEYS1:
+        if k not in ('color_fine', 'weight_sum', 'gradient_error'):
+            bounded('%s %s (end to end, informational)' % (tag, k), errs[k], 1.0)
 
 
 @pytest.mark.parametrize('kind', ['obj', 'hand'])
@@ -441,8 +456,11 @@ def test_render_dual_golden(golden, prec):
     errs = {k: rel_err(out[k].cpu().numpy().reshape(g[k].shape), g[k])
             for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj', 'gradient_error_hand', 'gradient_error_obj',
                       'gradient_hand', 'gradient_obj')}
-    print('dual', errs)
-    assert errs['color_fine'] < 2e-3 and errs['weight_sum'] < 2e-3 and errs['sdf_obj'] < 2e-3, errs
+    for k in ('color_fine', 'weight_sum', 'sdf_obj'):
+        bounded('dual %s (end to end)' % k, errs[k], E2E['dual'][k])
+    for k in errs:
+        if k not in ('color_fine', 'weight_sum', 'sdf_obj'):
+            bounded('dual %s (end to end, informational)' % k, errs[k], 1.0)
     # shapes of the reference dict (utils/renderer.py:526-535)
     assert out['color_fine'].shape == (24, 3) and out['weight_sum'].shape == (24, 1)
     assert out['sdf_hand'].shape == (24 * 192, 1) and out['gradient_obj'].shape == (24 * 192, 3)
@@ -461,8 +479,11 @@ def test_render_dual_batch_golden(golden, prec):
     assert out['color_fine'].shape == (3, 10, 3) and out['weight_sum'].shape == (3, 10, 1)
     errs = {k: rel_err(out[k].cpu().numpy().reshape(g[k].shape), g[k])
             for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj', 'gradient_error_hand', 'gradient_error_obj')}
-    print('dual batch', errs)
-    assert errs['color_fine'] < 2e-3 and errs['weight_sum'] < 2e-3 and errs['sdf_obj'] < 2e-3, errs
+    for k in ('color_fine', 'weight_sum', 'sdf_obj'):
+        bounded('dual batch %s (end to end)' % k, errs[k], E2E['dual_batch'][k])
+    for k in errs:
+        if k not in ('color_fine', 'weight_sum', 'sdf_obj'):
+            bounded('dual batch %s (end to end, informational)' % k, errs[k], 1.0)
 
 
 def test_dual_depths_match_oracle(golden, prec):
@@ -481,8 +502,7 @@ def test_dual_depths_match_oracle(golden, prec):
                t_rand=cu(g['t_rand']))
     z = ren.last_z_vals.cpu()
     frac_close = float(((z - ref['z_vals']).abs() < 1e-4).float().mean())
-    print('dual depths within 1e-4:', frac_close)
-    assert frac_close > 0.98
+    bounded('fraction of the 192 dual depths further than 1e-4 from the oracle', 1.0 - frac_close, 0.02, kind='fraction')
 
 
 def test_alpha_and_composite_adjoints(L):
@@ -806,8 +826,9 @@ def test_dual_render_backward_coarse_only():
     for i, name in enumerate(('rays_o', 'rays_d', 'bt_inv', 'Ro', 'To')):
         got = sel(name, dl[i].grad).detach().cpu().numpy()
         e_ref, e_ex = rel_err(got, sel(name, ref[i]).numpy()), rel_err(got, sel(name, ex[i]).numpy())
-        print('d loss / d %-7s hip-vs-fp32-autograd %.2e  hip-vs-fp64 %.2e  (fp32-autograd vs fp64: %.2e)'
-              % (name, e_ref, e_ex, rel_err(sel(name, ref[i]).numpy(), sel(name, ex[i]).numpy())))
+        from helpers import record
+        record('coarse-only d loss / d %s: hip vs fp32 autograd of the oracle' % name, e_ref, 1e-3, kind='rel, conditioning-aware',
+               hip_vs_fp64=e_ex, ref32_vs_fp64=rel_err(sel(name, ref[i]).numpy(), sel(name, ex[i]).numpy()))
         assert e_ref < 1e-3 or e_ex < max(worst, 1e-2), 'd loss / d %s: %.3e / %.3e' % (name, e_ref, e_ex)
 
 
@@ -826,11 +847,9 @@ def test_dual_render_backward_reference_golden(golden):
     loss.backward()
     for k in ('rays_o', 'rays_d', 'Ro', 'To'):
         e = rel_err(leaves[k].grad.detach().cpu().numpy(), g['g_' + k])
-        print('d loss / d %-7s vs reference: %.2e' % (k, e))
-        assert e < 6e-2, 'd loss / d %s: %.3e' % (k, e)
+        bounded('d loss / d %s vs reference gradients (own importance depths)' % k, e, E2E_GRAD)
     e = rel_err(leaves['bt_inv'].grad.detach().cpu().numpy()[:, :3, :], g['g_bt_inv'][:, :3, :])
-    print('d loss / d bt_inv  vs reference: %.2e' % e)
-    assert e < 6e-2
+    bounded('d loss / d bt_inv vs reference gradients (own importance depths)', e, E2E_GRAD)
     # the same backward on the reference's own final depths: what remains is arithmetic, not sample placement
     for v in leaves.values():
         v.grad = None
@@ -846,8 +865,7 @@ def test_dual_render_backward_reference_golden(golden):
         if k == 'bt_inv':
             got, want = got[:, :3, :], want[:, :3, :]
         e = rel_err(got, want)
-        print('on the reference depths: d loss / d %-7s vs reference: %.2e' % (k, e))
-        assert e < 5e-3, 'd loss / d %s on the reference depths: %.3e' % (k, e)
+        bounded('d loss / d %s vs reference gradients (reference depths)' % k, e, REF_DEPTH_GRAD[k])
 
 
 def test_dual_render_batch_backward(golden):
@@ -883,8 +901,7 @@ def test_dual_render_batch_backward(golden):
         if name == 'bt_inv':
             got, want = got[:, :, :3, :], want[:, :, :3, :]
         e = rel_err(got, want)
-        print('batched d loss / d %-7s vs fp32 autograd: %.2e' % (name, e))
-        assert e < 3e-3, 'batched d loss / d %s: %.3e' % (name, e)
+        bounded('batched d loss / d %s vs fp32 autograd of the oracle' % name, e, 3e-3)
 
 
 def test_pose_optimisation_recovers_object_translation():

@@ -1,0 +1,286 @@
+"""GPU tests of the drop-in SURFACE beyond `render()`: the reference's building-block methods on the adapters
+(`render_core`, `up_sample`, `cat_z_vals`, `get_alpha_sample_color`, `convert_obj_to_local`, `extract_geometry`'s
+volume, `get_stable_loss_cross`), the stand-alone module calls of utils/fields.py, and the fitting drivers.  Each is
+compared with what the REFERENCE produced (tests/golden/*.npz) or, where no fixture exists, with the pinned oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, bounded, cu, oracle_fields, product_modules, rel_err, t
+
+pytestmark = pytest.mark.gpu
+RT = 1e-4
+
+
+def _single(kind, n_samples, n_importance):
+    from honerf_amd.renderer import NeuSRenderer
+    m = product_modules()
+    return NeuSRenderer(m['sdf_' + kind], m['var_' + kind], m['color_' + kind], kind, n_samples, n_importance, 0, 4, 1.0)
+
+
+def _dual(batched=False):
+    from honerf_amd.renderer import NeuSRenderer_fitting
+    from honerf_amd.renderer_batch import NeuSRenderer_fitting as Batched
+    m = product_modules()
+    cls = Batched if batched else NeuSRenderer_fitting
+    return cls(m['sdf_hand'], m['var_hand'], m['color_hand'], m['sdf_obj'], m['var_obj'], m['color_obj'], 64, 64, 0, 4, 1.0)
+
+
+@pytest.mark.parametrize('kind', ['obj', 'hand'])
+def test_render_core_dict(golden, kind):
+    """NeuSRenderer.render_core (utils/renderer.py:107-177) on the reference's own final depths: its five keys."""
+    g = golden('render_%s_64_64' % kind)
+    ren = _single(kind, 64, 64)
+    o, d = cu(g['rays_o']), cu(g['rays_d'])
+    if kind == 'obj':
+        o, d = ren.convert_obj_to_local(o, d, g['Ro'], g['To'])
+    sample_dist = (float(g['far']) - float(g['near'])) / 64
+    core = ren.render_core(o, d, g.get('bt_inv'), g.get('T_pose'), None, cu(g['z_vals']), sample_dist, ren.sdf_network,
+                           ren.deviation_network, ren.color_network)
+    assert set(core) == {'color', 's_val', 'weights', 'cdf', 'gradient_error'}
+    B, S = g['z_vals'].shape
+    assert core['s_val'].shape == (B * S, 1) and core['weights'].shape == (B, S)
+    tol = RT if kind == 'obj' else 3e-4      # hand: fp32 reference itself is 1.3e-4 from fp64 near joints (noise floor)
+    assert_close(core['color'], g['color_fine'], tol, kind + ' render_core color')
+    assert_close(core['weights'], g['weights'], tol, kind + ' render_core weights')
+    assert_close(core['cdf'], g['cdf_fine'], tol, kind + ' render_core cdf')
+    assert_close(core['s_val'][:B], g['s_val'], RT, kind + ' render_core s_val')
+    assert_close(core['gradient_error'], g['gradient_error'], 5e-4 if kind == 'hand' else RT, kind + ' render_core gradient_error')
+
+
+def test_convert_obj_to_local_matches_formula():
+    ren = _single('obj', 32, 0)
+    gen = torch.Generator().manual_seed(2)
+    o, d = torch.randn(17, 3, generator=gen), torch.randn(17, 3, generator=gen)
+    Ro, To = torch.linalg.qr(torch.randn(3, 3, generator=gen))[0], torch.randn(3, generator=gen)
+    o2, d2 = ren.convert_obj_to_local(o, d, Ro, To)
+    assert_close(o2, (Ro @ (o - To).T).T, 1e-6, 'o local')
+    assert_close(d2, (Ro @ d.T).T, 1e-6, 'd local')
+    dual = _dual(batched=True)
+    ob, db = torch.randn(3, 5, 3, generator=gen), torch.randn(3, 5, 3, generator=gen)
+    Rb, Tb = torch.linalg.qr(torch.randn(3, 3, 3, generator=gen))[0], torch.randn(3, 3, generator=gen)
+    o3, d3 = dual.convert_obj_to_local(ob, db, Rb, Tb)
+    assert o3.shape == (3, 5, 3)
+    assert_close(o3, (Rb.unsqueeze(1) @ (ob - Tb.unsqueeze(1)).unsqueeze(-1))[..., 0], 1e-6, 'o local batched')
+    assert_close(d3, (Rb.unsqueeze(1) @ db.unsqueeze(-1))[..., 0], 1e-6, 'd local batched')
+
+
+def test_up_sample_and_cat_z_vals_methods(golden):
+    """up_sample returns the reference's new depths bit for bit; cat_z_vals merges like torch.sort and carries the
+    SDF of the new points (utils/renderer.py:60-105)."""
+    g = golden('upsample')
+    ren = _single('obj', 64, 64)
+    z, sdf = cu(g['z']), cu(g['sdf'])
+    for i in range(4):
+        z_new = ren.up_sample(None, None, z, sdf, 16, 64 * 2 ** i)
+        assert np.array_equal(z_new.cpu().numpy(), g['znew%d' % i]), 'up_sample round %d' % i
+        zm, _ = ren.cat_z_vals(torch.zeros(z.shape[0], 3), torch.ones(z.shape[0], 3), z, z_new, sdf, None, None, last=True)
+        assert np.array_equal(zm.cpu().numpy(), g['zmerged%d' % i])
+        z, sdf = cu(g['zmerged%d' % i]), cu(g['sdfmerged%d' % i])
+    # n_importance outside the conf's 16 (the reference accepts any count)
+    z1 = ren.up_sample(None, None, cu(g['z']), cu(g['sdf']), 1, 64.0)
+    assert z1.shape == (g['z'].shape[0], 1) and torch.isfinite(z1).all()
+    # with last=False the SDF of the new points comes from the network: against the oracle
+    _, obj_o = oracle_fields()
+    gen = torch.Generator().manual_seed(5)
+    o = torch.tensor([0.0, 0.0, -1.0]) + 0.05 * torch.randn(9, 3, generator=gen)
+    d = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.1 * torch.randn(9, 3, generator=gen), dim=-1)
+    zz = torch.sort(0.4 + 1.1 * torch.rand(9, 20, generator=gen), -1)[0]
+    zn = torch.sort(0.4 + 1.1 * torch.rand(9, 6, generator=gen), -1)[0]
+    s_old = obj_o.sdf_only((o[:, None] + d[:, None] * zz[..., None]).reshape(-1, 3)).reshape(9, 20).detach()
+    zm, sm = ren.cat_z_vals(o, d, zz, zn, s_old, None, None, last=False)
+    zc, idx = torch.sort(torch.cat([zz, zn], -1), -1)
+    s_new = obj_o.sdf_only((o[:, None] + d[:, None] * zn[..., None]).reshape(-1, 3)).reshape(9, 6).detach()
+    assert np.array_equal(zm.cpu().numpy(), zc.numpy())
+    assert_close(sm, torch.gather(torch.cat([s_old, s_new], -1), 1, idx), RT, 'cat_z_vals sdf')
+
+
+@pytest.mark.parametrize('name', ['render_dual', 'render_dual_batch'])
+def test_get_alpha_sample_color_method(golden, name):
+    """NeuSRenderer_fitting.get_alpha_sample_color (utils/renderer.py:360-422; batched: utils/renderer_batch.py:
+    115-174) on the reference's shared depths, both fields."""
+    g = golden(name)
+    batched = name.endswith('batch')
+    ren = _dual(batched)
+    o, d = cu(g['rays_o']), cu(g['rays_d'])
+    sample_dist = (float(g['far']) - float(g['near'])) / 64
+    z = cu(g['z_vals'])
+    if batched:
+        ren.batch_size, ren.pixel_sample = z.shape[0], z.shape[1]
+    a, c, s, ge, gr = ren.get_alpha_sample_color(o, d, g['bt_inv'], g['T_pose'], z, sample_dist, 'hand')
+    assert a.shape == g['alpha_hand'].shape and c.shape == g['rgb_hand'].shape and s.shape == g['sdf_hand'].shape
+    assert_close(a, g['alpha_hand'], 3e-4, name + ' alpha_hand')          # hand noise floor, see test_gpu_parity
+    assert_close(c, g['rgb_hand'], 2e-3, name + ' rgb_hand')
+    assert_close(s, g['sdf_hand'], RT, name + ' sdf_hand')
+    assert_close(ge, g['gradient_error_hand'], 5e-4, name + ' gradient_error_hand')
+    ol, dl = ren.convert_obj_to_local(o, d, g['Ro'], g['To'])
+    a, c, s, ge, gr = ren.get_alpha_sample_color(ol, dl, g['bt_inv'], g['T_pose'], z, sample_dist, 'obj')
+    assert_close(a, g['alpha_obj'], RT, name + ' alpha_obj')
+    assert_close(c, g['rgb_obj'], RT, name + ' rgb_obj')
+    assert_close(s, g['sdf_obj'], RT, name + ' sdf_obj')
+    assert_close(gr, g['gradient_obj'], RT, name + ' gradient_obj')
+    assert_close(ge, g['gradient_error_obj'], 2e-4, name + ' gradient_error_obj')
+
+
+def test_module_calls_obj(golden):
+    """SDFNetwork_OBJ.forward / .sdf / .gradient and RenderingNetwork_OBJ.forward called on their own
+    (utils/fields.py:316-347, 387-405) against the reference's outputs."""
+    g = golden('field_obj')
+    m = product_modules()
+    pts, dirs = cu(g['pts']), cu(g['dirs'])
+    out = m['sdf_obj'](pts)
+    assert out.shape == g['out'].shape
+    assert_close(out, g['out'], RT, 'SDFNetwork_OBJ.forward')
+    assert_close(m['sdf_obj'].sdf(pts), g['out'][:, :1], RT, 'SDFNetwork_OBJ.sdf')
+    grad = m['sdf_obj'].gradient(pts)
+    assert grad.shape == (pts.shape[0], 1, 3)
+    assert_close(grad.squeeze(1), g['grad'], RT, 'SDFNetwork_OBJ.gradient')
+    rgb = m['color_obj'](pts, dirs, cu(g['out'][:, 1:]), cu(g['grad']), 0)
+    assert_close(rgb, g['rgb'], RT, 'RenderingNetwork_OBJ.forward')
+    assert_close(m['var_obj'](torch.zeros(1, 3, device='cuda')), np.full((1, 1), np.exp(3.0), np.float32), 1e-6, 'variance net')
+
+
+def test_module_calls_hand(golden):
+    """SDFNetwork.forward (out, xyz_feature, r, h) / .sdf / .gradient and RenderingNetwork.forward (utils/fields.py:
+    132-177, 222-240)."""
+    g = golden('field_hand')
+    m = product_modules()
+    pts = cu(g['pts'])
+    out, X, r, h = m['sdf_hand'](pts, g['bt_inv'], g['T_pose'])
+    assert X.shape == (pts.shape[0], 1386) and r.shape == (pts.shape[0], 21, 3) and h.shape == g['h'].shape
+    assert_close(out[:, :1], g['out'][:, :1], RT, 'SDFNetwork.forward sdf')
+    assert_close(out[:, 1:], g['out'][:, 1:], RT, 'SDFNetwork.forward feature vector')
+    assert_close(X[:8], g['feat'], RT, 'SDFNetwork.forward xyz_feature')
+    assert_close(h, g['h'], RT, 'SDFNetwork.forward h')
+    assert_close(m['sdf_hand'].sdf(pts, g['bt_inv'], g['T_pose']), g['out'][:, :1], RT, 'SDFNetwork.sdf')
+    grad = m['sdf_hand'].gradient(pts, g['bt_inv'], g['T_pose'])
+    assert_close(grad.squeeze(1), g['grad'], 1e-3, 'SDFNetwork.gradient')      # conditioning: see assert_parity in test_gpu_parity
+    rgb = m['color_hand'](cu(g['dirs']), X, cu(g['out'][:, 1:]), h, cu(g['grad']), 0)
+    assert_close(rgb, g['rgb'], RT, 'RenderingNetwork.forward')
+
+
+def test_extract_geometry_volume():
+    """extract_geometry's SDF volume (utils/renderer.py:260-278, 537-556) in one launch, against the oracle on the same
+    grid; marching cubes itself is PyMCubes in the reference and stays third-party."""
+    hand_o, obj_o = oracle_fields()
+    res = 10
+    bmin, bmax = torch.tensor([-0.6, -0.5, -0.55]), torch.tensor([0.6, 0.55, 0.5])
+    ren = _single('obj', 32, 0)
+    u = ren.extract_fields(bmin, bmax, res)
+    ax = [torch.linspace(float(bmin[i]), float(bmax[i]), res) for i in range(3)]
+    xx, yy, zz = torch.meshgrid(*ax, indexing='ij')
+    pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
+    assert u.shape == (res, res, res)
+    assert_close(u.reshape(-1, 1), obj_o.sdf_only(pts).detach(), RT, 'obj volume')
+    from honerf_amd import synth
+    bt, tp, j = synth.synth_hand_pose(3)
+    R, tt = synth.synth_obj_pose(2, center=tuple(j[9]))
+    dual = _dual()
+    c = t(j[9])
+    uh = dual.extract_fields(c - 0.08, c + 0.08, res, bt, tp, None, None, 'hand')
+    ax = [torch.linspace(float(c[i] - 0.08), float(c[i] + 0.08), res) for i in range(3)]
+    xx, yy, zz = torch.meshgrid(*ax, indexing='ij')
+    pw = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
+    assert_close(uh.reshape(-1, 1), hand_o.sdf_only(pw, t(bt), t(tp)).detach(), RT, 'hand volume')
+    Ro, To = t(R).T.contiguous(), t(tt)
+    uo = dual.extract_fields(c - 0.08, c + 0.08, res, bt, tp, Ro, To, 'obj')
+    assert_close(uo.reshape(-1, 1), obj_o.sdf_only((Ro @ (pw - To).T).T).detach(), RT, 'obj volume through (Ro, To)')
+    try:
+        import mcubes  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match='PyMCubes'):
+            ren.extract_geometry(bmin, bmax, res, None, None, None, None)
+
+
+def test_nearest_masked_matches_brute_force():
+    from honerf_amd import lib as L
+    lib = L.load()
+    rng = np.random.RandomState(4)
+    V, T = 300, 3
+    pts = rng.rand(V, 3).astype(np.float32)
+    q = rng.rand(T, V) < 0.3
+    c = rng.rand(T, V) < 0.5
+    c[2] = False                      # a set without candidates selects nothing
+    sel = torch.empty(T, V, dtype=torch.uint8, device='cuda')
+    near = torch.empty(T, V, dtype=torch.int32, device='cuda')
+    L.check(lib.hn_nearest_masked(L.ptr(cu(pts)), V, T, L.ptr(cu(q.astype(np.uint8))), L.ptr(cu(c.astype(np.uint8))), L.ptr(sel),
+                                  L.ptr(near), L.stream_ptr()), 'hn_nearest_masked')
+    near, sel = near.cpu().numpy(), sel.cpu().numpy()
+    for s_ in range(T):
+        ci = np.nonzero(c[s_])[0]
+        want = np.zeros(V, np.uint8)
+        for i in range(V):
+            if not q[s_, i]:
+                assert near[s_, i] == -1
+                continue
+            if len(ci) == 0:
+                assert near[s_, i] == -1
+                continue
+            dd = ((pts[ci] - pts[i]) ** 2).sum(-1)
+            assert near[s_, i] == ci[np.argmin(dd)]
+            want[ci[np.argmin(dd)]] = 1
+        assert np.array_equal(sel[s_], want)
+
+
+@pytest.mark.parametrize('strict', [True, False])
+def test_stable_loss_cross(golden, strict):
+    """get_stable_loss_cross (utils/renderer_batch.py:318-371) against the reference's value AND its gradients w.r.t.
+    bt_inv, the object rotation and translation.  strict=False is the intended semantics (outside = complement of
+    inside), checked against a plain restatement on the reference's own hand SDF values."""
+    g = golden('stable_loss')
+    ren = _dual(batched=True)
+    ren.strict_reference = strict
+    bt, R, T = (cu(g[k]).clone().requires_grad_(True) for k in ('bt_inv', 'obj_r', 'obj_t'))
+    loss = ren.get_stable_loss_cross(cu(g['obj_verts']), bt, cu(g['T_pose']), R, T)
+    if strict:
+        assert_close(loss, g['stable'], RT, 'stable loss')
+        loss.backward()
+        assert_close(bt.grad[:, :, :3, :], g['g_bt_inv'][:, :, :3, :], 1e-3, 'stable d/d bt_inv')
+        assert_close(R.grad, g['g_obj_r'], 1e-3, 'stable d/d obj_r')
+        assert_close(T.grad, g['g_obj_t'], 1e-3, 'stable d/d obj_t')
+    else:
+        sdf = t(g['hand_sdf'])
+        pts = t(g['obj_verts'])[0, ::10]
+        inside = sdf < 0
+        n_pen = int(inside.any(1).sum())
+        tot = 0.0
+        for cid in range(sdf.shape[0]):
+            qi, ci = torch.nonzero(inside[cid])[:, 0], torch.nonzero(~inside[cid])[:, 0]
+            near = torch.unique(ci[((pts[qi][:, None] - pts[ci][None]) ** 2).sum(-1).argmin(1)])
+            tot += (sdf[:, qi].clip(0, 1e7).sum() + 0.05 * sdf[:, near].clip(-1e7, 0).abs().sum()) / ((n_pen - 1) * len(qi))
+        assert_close(loss, (tot / n_pen).reshape(()), 2e-4, 'stable loss, complement semantics')
+
+
+def _fit_scene(n_frames, rays, seed=5):
+    from honerf_amd import fitting as F, synth
+    bt, tp, j = synth.synth_hand_pose(seed)
+    R, tt = synth.synth_obj_pose(seed + 1, center=tuple(j[9] + np.array([0.02, 0.0, 0.01])))
+    rng = np.random.RandomState(seed)
+    u = rng.standard_normal((400, 3))
+    verts = (u / np.linalg.norm(u, axis=1, keepdims=True) * 0.02).astype(np.float32)
+    rep = lambda a: np.repeat(a[None], n_frames, 0)
+    chain = F.RigidPoseChain(rep(bt), rep(tp), rep(j), rep(R), rep(tt), verts)
+    views = F.synthetic_views(2, n_frames, rays, seed, j[9])
+    return chain, views, verts
+
+
+def test_fit_step_single_and_video():
+    """fit_step: pose chain -> rays -> render -> losses (contact / penetration / smooth / stable) -> backward -> Adam,
+    for fitting_single ('12') and fitting_video ('1234'): finite losses, every parameter receives a gradient and moves."""
+    from honerf_amd import fitting as F
+    chain, views, verts = _fit_scene(1, 24)
+    ren = _dual(False)
+    before = [p.detach().clone() for p in chain.parameters()]
+    last, steps = F.fit_frame(ren, views, chain, 0.4, 1.5, fit_type='12', n_iters=1)
+    assert steps == 2 and all(torch.isfinite(v).all() for v in last.values())
+    assert all(not torch.equal(a, b.detach()) for a, b in zip(before, chain.parameters()))
+    chain, views, verts = _fit_scene(4, 6)
+    renb = _dual(True)
+    opt = torch.optim.Adam(chain.param_groups(video=True))
+    ov = torch.from_numpy(verts).cuda()[None].expand(4, -1, -1).contiguous()
+    before = [p.detach().clone() for p in chain.parameters()]
+    last, steps = F.fit_window(renb, views, chain, opt, 0.4, 1.5, index=[0, 1, 2, 3], data_num=4, fit_type='1234',
+                               first_pass=True, obj_verts=ov, sub_iters=1)
+    assert steps == 2 and {'smooth', 'stable', 'contact', 'penetration'} <= set(last)
+    assert all(torch.isfinite(v).all() for v in last.values())
+    assert all(not torch.equal(a, b.detach()) for a, b in zip(before, chain.parameters()))
