@@ -213,9 +213,9 @@ class NeuSRenderer:
         rays_o, rays_d = _lib.f32(rays_o).reshape(-1, 3), _lib.f32(rays_d).reshape(-1, 3)
         dev = rays_o.device
         o2, d2 = torch.empty_like(rays_o), torch.empty_like(rays_d)
-        _lib.check(self.lib.hn_obj_local_fwd(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(_lib.f32(Ro, dev).reshape(1, 3, 3)),
-                                             _lib.ptr(_lib.f32(To, dev).reshape(1, 3)), 1, rays_o.shape[0], _lib.ptr(o2),
-                                             _lib.ptr(d2), _lib.stream_ptr()), 'hn_obj_local_fwd')
+        Ro_, To_ = _lib.f32(Ro, dev).reshape(1, 3, 3), _lib.f32(To, dev).reshape(1, 3)   # named: alive until the launch is queued
+        _lib.check(self.lib.hn_obj_local_fwd(_lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(Ro_), _lib.ptr(To_), 1, rays_o.shape[0],
+                                             _lib.ptr(o2), _lib.ptr(d2), _lib.stream_ptr()), 'hn_obj_local_fwd')
         return o2, d2
 
     def up_sample(self, rays_o, rays_d, z_vals, sdf, n_importance, inv_s):
@@ -403,8 +403,8 @@ class NeuSRenderer_fitting:
         P = ro.reshape(F, -1, 3).shape[1]
         dev = ro.device
         o2, d2 = torch.empty(F * P, 3, device=dev), torch.empty(F * P, 3, device=dev)
-        _lib.check(self.lib.hn_obj_local_fwd(_lib.ptr(ro.reshape(-1, 3)), _lib.ptr(rd.reshape(-1, 3)),
-                                             _lib.ptr(_lib.f32(Ro, dev).reshape(F, 3, 3)), _lib.ptr(_lib.f32(To, dev).reshape(F, 3)),
+        Ro_, To_ = _lib.f32(Ro, dev).reshape(F, 3, 3), _lib.f32(To, dev).reshape(F, 3)   # named: alive until the launch is queued
+        _lib.check(self.lib.hn_obj_local_fwd(_lib.ptr(ro.reshape(-1, 3)), _lib.ptr(rd.reshape(-1, 3)), _lib.ptr(Ro_), _lib.ptr(To_),
                                              F, P, _lib.ptr(o2), _lib.ptr(d2), _lib.stream_ptr()), 'hn_obj_local_fwd')
         return o2.reshape(shape), d2.reshape(shape)
 
@@ -455,8 +455,8 @@ class NeuSRenderer_fitting:
             else:
                 local = torch.empty_like(pts)
                 dummy = torch.empty_like(pts)
-                _lib.check(self.lib.hn_obj_local_fwd(_lib.ptr(pts), _lib.ptr(pts), _lib.ptr(_lib.f32(Ro, dev).reshape(-1, 3, 3)[:1].contiguous()),
-                                                     _lib.ptr(_lib.f32(To, dev).reshape(-1, 3)[:1].contiguous()), 1, pts.shape[0],
+                Ro_, To_ = _lib.f32(Ro, dev).reshape(-1, 3, 3)[:1].contiguous(), _lib.f32(To, dev).reshape(-1, 3)[:1].contiguous()
+                _lib.check(self.lib.hn_obj_local_fwd(_lib.ptr(pts), _lib.ptr(pts), _lib.ptr(Ro_), _lib.ptr(To_), 1, pts.shape[0],
                                                      _lib.ptr(local), _lib.ptr(dummy), _lib.stream_ptr()), 'hn_obj_local_fwd')
                 val = obj.sdf(local)
         return val.reshape(resolution, resolution, resolution).cpu().numpy()
