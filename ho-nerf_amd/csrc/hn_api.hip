@@ -396,6 +396,7 @@ int hn_field_destroy(hn_field* f) {
     if (f->blob != nullptr) (void)hipFree(f->blob);
     if (f->v2_full != nullptr) (void)hipFree(f->v2_full);
     if (f->v2_sdf != nullptr) (void)hipFree(f->v2_sdf);
+    if (f->v2_adj != nullptr) (void)hipFree(f->v2_adj);
     if (f->raw != nullptr) (void)hipFree(f->raw);
     delete f;
     return HN_OK;

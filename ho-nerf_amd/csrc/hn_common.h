@@ -110,6 +110,8 @@ struct hn_field {
     size_t v2_full_bytes = 0;
     void* v2_sdf = nullptr;      // sdf forward only (sampling passes)
     size_t v2_sdf_bytes = 0;
+    void* v2_adj = nullptr;      // full evaluation followed by its adjoint (hn_field_eval_bwd)
+    size_t v2_adj_bytes = 0;
     // --- folded (weight-norm applied) weights and biases, row-major [out, in], for the adjoint (hn_field_bwd.hip)
     void* raw = nullptr;
     const float* raw_sdf_w[9] = {};

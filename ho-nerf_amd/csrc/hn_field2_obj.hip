@@ -33,10 +33,20 @@ struct Obj2Args {
     float* feat;           // optional [n,256]
     float4* scratch;       // per-wave stash slots (FULL only)
     int dbg;               // timing experiments only (HN_DBG): 1 = no stash stores, 2 = no stash loads
+    // adjoint (MODE 2): upstream gradients in, input gradients out
+    const float* g_sdf;    // [n]
+    const float* g_grad;   // [n,3]
+    const float* g_rgb;    // [n,3]
+    float* g_pts;          // [n,3]
+    float* g_rays_d;       // [n/spr,3] or NULL: accumulated with atomics (zeroed by the launcher)
 };
 
 // stash slots of one wave (32 KiB each)
 enum { OS_A1 = 0 /* a1..a7 -> 0..6 */, OS_DZ7 = 7, OS_FVEC = 8, OS_DZ4 = 9, OS_X = 10, OBJ2_SLOTS = 11 };
+// ... and what the adjoint adds: a8, the reverse sweep's dz_l as fp32 tiles (slot l; each is overwritten by the
+// second-order source w_l once the forward-direction sweep has passed layer l), the colour network's activations
+// (for the relu masks), d sdf / d X (tiles 0, 1) with the colour net's share of the X adjoint (tiles 2, 3), zb4
+enum { OS_A8 = 11, OS_DZ = 12 /* 12..19 */, OS_C = 20 /* c1..c4 -> 20..23 */, OS_GX = 24, OS_ZB4 = 25, OBJ2_SLOTS_ADJ = 26 };
 
 constexpr int CB_HID = chunk_bytes(1, 16, true);     // hidden layer tile: 16 k-steps + tail
 constexpr int CB_L0 = chunk_bytes(4, 4, true);       // lin0: 4 tiles x 4 k-steps + tail
@@ -44,6 +54,7 @@ constexpr int CB_BWD = chunk_bytes(1, 16, false);    // transposed hidden tile
 constexpr int CB_BWD3 = chunk_bytes(1, 13, false);   // W3^T: 193 outputs = 13 k-steps
 constexpr int CB_C0A = chunk_bytes(1, 16, false);    // colour lin0, feature-vector columns
 constexpr int CB_C0B = chunk_bytes(1, 8, true);      // colour lin0, enc(p) | enc(d) | enc(g) columns + bias
+constexpr int CB_W4ROWS = 3 * TAIL_BYTES;            // adjoint: the three rows of colour lin4, one tail-format KiB each
 
 // sin/cos(2^k x) of one lane half: half 0 keeps the sines, half 1 the cosines
 __device__ __forceinline__ float sc_half(float ang, int h) {
@@ -79,8 +90,361 @@ __device__ __forceinline__ void encode_v4(const float v[3], int h, float (&f)[2]
     f[1][7] = 0.f;
 }
 
-template <bool FULL>
+
+// ---- adjoint of the evaluation above (MODE 2) --------------------------------------------------------------------
+// oracle/field_bwd.py steps 3b-6 for the tile whose forward pass has just finished (its tape is in the wave's stash):
+//   colour network backward -> (Xb_c, d-bar, fb, gb)         [C3^T, C2^T, C1^T, C0^T chunks]
+//   forward-direction sweep  dzb_l = W_l (sigma'_{l-1} dzb_{l-1}),  w_l = sigma''(z_l) u_l dzb_l   [the forward chunks again]
+//   second reverse sweep     zb_l = sigma'(z_l) ab_l + w_l,  ab_{l-1} = W_l^T zb_l,  Xb += W0^T zb0 + W4x^T zb4
+//   input map                g_pts = J^T Xb + (d^2 X / dp^2 : GX) gb
+// Every adjoint quantity is linear in the upstream gradients (g_sdf, g_grad, g_rgb); they are scaled per sample by a
+// power of two kappa that brings the largest of them to [1, 2), so that the fp16 hi/lo fragments keep their 22 bits
+// whatever the scale of the caller's loss; the outputs are scaled back by 1 / kappa (exact).
+struct Act2 {
+    f32x16 v;   // stashed activation a_{l+1} (sigma'(z_l) = 1 - exp(-100 a))
+    f32x16 x;   // second tile: 100 dz_l (forward-direction sweep) or w_l (second reverse sweep)
+};
+struct Act1 {
+    f32x16 v;
+};
+__device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stash& sh, int lane, int h, int n, int nn, bool valid,
+                                            bool more, const float (&p)[3], const float (&d)[3], const float (&g)[3],
+                                            const float (&rgb)[3], h8 (&ah)[16], h8 (&al)[16], h8 (&bh)[16], h8 (&bl)[16]) {
+    auto no_store = [](auto, const auto&) {};
+    auto no_pre = [](auto, const char*) { return NoData{}; };
+    auto to_regs = [&](h8(&oh)[16], h8(&ol)[16]) {
+        return [&oh, &ol](auto T, EpiState& st, const auto&) {
+            constexpr int t = decltype(T)::value;
+            asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+            oh[2 * t] = st.hi[0];
+            ol[2 * t] = st.lo[0];
+            oh[2 * t + 1] = st.hi[1];
+            ol[2 * t + 1] = st.lo[1];
+#if HN_PARK_AGPR
+            asm volatile("" : "+a"(oh[2 * t]), "+a"(ol[2 * t]), "+a"(oh[2 * t + 1]), "+a"(ol[2 * t + 1]));
+#endif
+            return NoData{};
+        };
+    };
+    auto mask_of = [&](int c_slot) {
+        return [&sh, c_slot](auto T, const char*) { return Act1{sh.tile_load(c_slot, decltype(T)::value)}; };
+    };
+    // ---- seeds
+    float gs = a.g_sdf[nn], gg[3], gr[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gg[c] = a.g_grad[3 * nn + c];
+        gr[c] = a.g_rgb[3 * nn + c];
+    }
+    if (!valid) {   // lanes beyond the end shadow the last sample: they must not contribute
+        gs = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gg[c] = gr[c] = 0.f;
+    }
+    float kappa = 1.f, inv_kappa = 1.f;
+    {
+        float m = fabsf(gs);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m = fmaxf(m, fmaxf(fabsf(gg[c]), fabsf(gr[c])));
+        const unsigned e = (__builtin_bit_cast(unsigned, m) >> 23) & 0xffu;   // m in [2^(e-127), 2^(e-126))
+        if (e >= 1u && e <= 253u) {
+            kappa = __builtin_bit_cast(float, (254u - e) << 23);
+            inv_kappa = __builtin_bit_cast(float, e << 23);
+        }
+    }
+    const float gsk = gs * kappa * a.inv_scale;
+    float xb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xb[c] = kappa * gr[c] * rgb[c] * (1.f - rgb[c]);
+
+    // ---- colour lin4^T and the mask of c4:  cb4 = (c4 > 0) * (W_c4^T xb)   (the three rows arrive as one small chunk)
+    {
+        const char* buf = ws.template acquire<0>();
+        ws.begin(CB_BWD);
+        ws.pieces_all();
+        static_for<8>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            const f32x16 c4 = sh.tile_load(OS_C + 3, t);
+            const f32x16 w0 = tail_tile(buf, t, h), w1 = tail_tile(buf + TAIL_BYTES, t, h), w2 = tail_tile(buf + 2 * TAIL_BYTES, t, h);
+            f32x16 v;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = c4[i] > 0.f ? fmaf(w0[i], xb[0], fmaf(w1[i], xb[1], w2[i] * xb[2])) : 0.f;
+            split_tile(v, ah[2 * t], al[2 * t], ah[2 * t + 1], al[2 * t + 1]);
+        });
+    }
+    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, mask_of(OS_C + 2), PhMask{}, to_regs(bh, bl), no_store);   // C3^T -> cb3
+    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, mask_of(OS_C + 1), PhMask{}, to_regs(ah, al), no_store);   // C2^T -> cb2
+    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, mask_of(OS_C + 0), PhMask{}, to_regs(bh, bl), no_store);   // C1^T -> cb1
+    // ---- colour lin0^T: feature-vector rows -> fb (kept as fragments in the OS_FVEC slot for the W8 product) ...
+    run_layer<8, 16, 1, false, true>(
+        ws, CB_BWD, CB_BWD, bh, bl, lane, h, no_pre, PhIdentity{},
+        [&](auto T, EpiState& st, const auto&) {
+            constexpr int t = decltype(T)::value;
+            sh.frag_store(OS_FVEC * SLOT_BYTES, 2 * t, st.hi[0], st.lo[0]);
+            sh.frag_store(OS_FVEC * SLOT_BYTES, 2 * t + 1, st.hi[1], st.lo[1]);
+            return NoData{};
+        },
+        no_store);
+    // ... and the [X | enc(d) | enc(g)] slots: 4 tiles whose row r of tile u is k-slot (s = 2u + (reg >> 3), h, reg & 7)
+    // of the same lane.  Tiles 0, 1: the colour net's share of the X adjoint (parked); 2: enc(d); 3: enc(g).
+    float gdir[3] = {0.f, 0.f, 0.f}, gb[3] = {0.f, 0.f, 0.f};
+    static_for<4>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        const char* buf = ws.template acquire<0>();
+        ws.begin(u < 3 ? CB_BWD : CB_L0);   // after the last one: lin0 of the forward-direction sweep
+        f32x16 m1 = zero16(), m2 = zero16();
+        mma_tile<16, 0, true>(ws, buf, bh, bl, m1, m2, lane);
+        const f32x16 M = combine(m1, m2);
+        if constexpr (u < 2) {
+            sh.tile_store(OS_GX, 2 + u, M);
+        } else {
+            // J^T of [v, enc4(v)] in-lane: slot (s, j) of k-steps (0, 1) is register 8 s + j; the partner lane (other half)
+            // holds the conjugate function of the same angle
+            const float* vec = u == 2 ? d : g;
+            float* out = u == 2 ? gdir : gb;
+            float f[2][8];
+            encode_v4(vec, h, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float fr = (float)(1 << (j & 3));
+                out[j >> 2] = fmaf(M[j], (h ? -fr : fr) * other_half(f[0][j], h), out[j >> 2]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float fr = (float)(1 << j);
+                out[2] = fmaf(M[8 + j], (h ? -fr : fr) * other_half(f[1][j], h), out[2]);
+            }
+            out[0] += h ? 0.f : M[12];
+            out[2] += h ? M[12] : 0.f;
+            out[1] += h ? 0.f : M[13];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[c] = half_sum(out[c]);
+        }
+    });
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gb[c] += kappa * gg[c];   // gb = g_grad + J_enc^T (colour net's gradient w.r.t. enc(g))
+
+    // ---- forward-direction sweep: GXb = J gb -> dzb_0 = W0 GXb -> ... ; v_l = sigma'_l dzb_l feeds the next layer,
+    //      w_l = (1 - sigma'_l) dzb_l * 100 dz_l replaces dz_l in the stash
+    auto pre4 = [&](int act_slot, int dz_slot) {
+        return [&sh, act_slot, dz_slot](auto T, const char*) {
+            constexpr int t = decltype(T)::value;
+            Act2 o{sh.tile_load(act_slot, t), sh.tile_load(dz_slot, t)};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o.x[i] *= 100.f * BWD_INV;
+            return o;
+        };
+    };
+    auto fin4 = [&](h8(&oh)[16], h8(&ol)[16], int w_slot) {
+        return [&oh, &ol, w_slot, &sh](auto T, EpiState& st, const auto&) {
+            constexpr int t = decltype(T)::value;
+            asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+            oh[2 * t] = st.hi[0];
+            ol[2 * t] = st.lo[0];
+            oh[2 * t + 1] = st.hi[1];
+            ol[2 * t + 1] = st.lo[1];
+#if HN_PARK_AGPR
+            asm volatile("" : "+a"(oh[2 * t]), "+a"(ol[2 * t]), "+a"(oh[2 * t + 1]), "+a"(ol[2 * t + 1]));
+#endif
+            sh.tile_store(w_slot, t, st.wvec());
+            return NoData{};
+        };
+    };
+    {
+        // X-space fragments of J gb: slot value = d(slot function)/dp_c * gb[c]
+        float f[4][8], jg[4][8];
+        encode_x(p, h, f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float fr = 1.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                jg[c][k] = (h ? -fr : fr) * other_half(f[c][k], h) * gb[c];
+                fr *= 2.f;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+            const float fr = (jj & 1) ? 512.f : 256.f;
+            jg[3][jj] = (h ? -fr : fr) * other_half(f[3][jj], h) * gb[jj >> 1];
+        }
+        jg[3][6] = h ? gb[2] : gb[0];
+        jg[3][7] = h ? 0.f : gb[1];
+        h8 x16h[16], x16l[16];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            split8(jg[s], x16h[s], x16l[s]);
+            sh.frag_store(OS_X * SLOT_BYTES, s, x16h[s], x16l[s]);   // again for lin4's skip columns
+        }
+        run_layer<8, 4, 4, false, true>(ws, CB_L0, CB_HID, x16h, x16l, lane, h, pre4(OS_A1 + 0, OS_DZ + 0), PhFwdDir{}, fin4(ah, al, OS_DZ + 0), no_store);
+    }
+    run_layer<8, 16, 1, false, true>(ws, CB_HID, CB_HID, ah, al, lane, h, pre4(OS_A1 + 1, OS_DZ + 1), PhFwdDir{}, fin4(bh, bl, OS_DZ + 1), no_store);   // lin1
+    run_layer<8, 16, 1, false, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, pre4(OS_A1 + 2, OS_DZ + 2), PhFwdDir{}, fin4(ah, al, OS_DZ + 2), no_store);   // lin2
+    float v3_192 = 0.f;
+    run_layer<7, 16, 1, false, true>(ws, CB_HID, CB_HID, ah, al, lane, h, pre4(OS_A1 + 3, OS_DZ + 3), PhFwdDir{},                                    // lin3 (193 rows)
+                                     [&](auto T, EpiState& st, const auto&) {
+                                         constexpr int t = decltype(T)::value;
+                                         asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                                         if constexpr (t == 6) {
+                                             v3_192 = st.v[0];   // row 0 of tile 6 = neuron 192 (half 0); the padding rows are 0 (sigma' = 0)
+                                         } else {
+                                             bh[2 * t] = st.hi[0];
+                                             bl[2 * t] = st.lo[0];
+                                             bh[2 * t + 1] = st.hi[1];
+                                             bl[2 * t + 1] = st.lo[1];
+                                         }
+                                         sh.tile_store(OS_DZ + 3, t, st.wvec());
+                                         return NoData{};
+                                     },
+                                     no_store);
+    {   // lin4 = [v3 (192 via k-steps 0..11) | J gb with v3[192] in its pad slot] / sqrt2
+        const float v192 = other_half(h ? 0.f : v3_192, h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sh.frag_load(OS_X * SLOT_BYTES, s, bh[12 + s], bl[12 + s]);
+        const _Float16 vh = hi_part(v192);
+        const _Float16 vl = (_Float16)((v192 - (float)vh) * LO_SCALE);
+        bh[15][7] = h ? vh : bh[15][7];
+        bl[15][7] = h ? vl : bl[15][7];
+    }
+    run_layer<8, 16, 1, false, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, pre4(OS_A1 + 4, OS_DZ + 4), PhFwdDir{}, fin4(ah, al, OS_DZ + 4), no_store);   // lin4
+    run_layer<8, 16, 1, false, true>(ws, CB_HID, CB_HID, ah, al, lane, h, pre4(OS_A1 + 5, OS_DZ + 5), PhFwdDir{}, fin4(bh, bl, OS_DZ + 5), no_store);   // lin5
+    run_layer<8, 16, 1, false, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, pre4(OS_A1 + 6, OS_DZ + 6), PhFwdDir{}, fin4(ah, al, OS_DZ + 6), no_store);   // lin6
+    run_layer<8, 16, 1, false, false>(ws, CB_HID, CB_HID, ah, al, lane, h, pre4(OS_A8, OS_DZ + 7), PhFwdDir{},                                       // lin7: only w_7
+                                      [&](auto T, EpiState& st, const auto&) {
+                                          sh.tile_store(OS_DZ + 7, decltype(T)::value, st.wvec());
+                                          return NoData{};
+                                      },
+                                      no_store);
+
+    // ---- second reverse sweep.  ab_7 = W8[1:, :]^T fb + g_sdf / scale * W8[0, :];  zb_7 = sigma'_7 ab_7 + w_7
+    auto pre5 = [&](int act_slot, int w_slot) {
+        return [&sh, act_slot, w_slot](auto T, const char*) {
+            constexpr int t = decltype(T)::value;
+            return Act2{sh.tile_load(act_slot, t), sh.tile_load(w_slot, t)};
+        };
+    };
+#pragma unroll
+    for (int s = 0; s < 16; ++s) sh.frag_load(OS_FVEC * SLOT_BYTES, s, bh[s], bl[s]);
+    run_layer<8, 16, 1, false, true>(
+        ws, CB_HID, CB_BWD, bh, bl, lane, h,
+        [&](auto T, const char* tail) {
+            constexpr int t = decltype(T)::value;
+            Act2 o{sh.tile_load(OS_A8, t), sh.tile_load(OS_DZ + 7, t)};
+            const f32x16 w8 = tail_tile(tail, 0, h);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o.x[i] = fmaf(gsk * w8[i], dsoftplus_from_act(o.v[i]), o.x[i]);   // + sigma'_7 g_sdf W8[0, :]
+            return o;
+        },
+        PhRev2{}, to_regs(ah, al), no_store);
+    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, pre5(OS_A1 + 6, OS_DZ + 6), PhRev2{}, to_regs(bh, bl), no_store);   // W7^T -> zb6
+    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, pre5(OS_A1 + 5, OS_DZ + 5), PhRev2{}, to_regs(ah, al), no_store);   // W6^T -> zb5
+    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, pre5(OS_A1 + 4, OS_DZ + 4), PhRev2{},                               // W5^T -> zb4 (kept)
+                                     [&](auto T, EpiState& st, const auto&) {
+                                         constexpr int t = decltype(T)::value;
+                                         asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                                         bh[2 * t] = st.hi[0];
+                                         bl[2 * t] = st.lo[0];
+                                         bh[2 * t + 1] = st.hi[1];
+                                         bl[2 * t + 1] = st.lo[1];
+                                         sh.frag_store(OS_ZB4 * SLOT_BYTES, 2 * t, st.hi[0], st.lo[0]);
+                                         sh.frag_store(OS_ZB4 * SLOT_BYTES, 2 * t + 1, st.hi[1], st.lo[1]);
+                                         return NoData{};
+                                     },
+                                     no_store);
+    run_layer<7, 16, 1, false, true>(ws, CB_BWD, CB_BWD3, bh, bl, lane, h, pre5(OS_A1 + 3, OS_DZ + 3), PhRev2{},                              // W4h^T -> zb3 (193 rows)
+                                     [&](auto T, EpiState& st, const auto&) {
+                                         constexpr int t = decltype(T)::value;
+                                         asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                                         if constexpr (t < 6) {
+                                             ah[2 * t] = st.hi[0];
+                                             al[2 * t] = st.lo[0];
+                                             ah[2 * t + 1] = st.hi[1];
+                                             al[2 * t + 1] = st.lo[1];
+                                         } else {
+                                             ah[12] = st.hi[0];
+                                             al[12] = st.lo[0];
+                                         }
+                                         return NoData{};
+                                     },
+                                     no_store);
+    run_layer<8, 13, 1, false, true>(ws, CB_BWD3, CB_BWD, ah, al, lane, h, pre5(OS_A1 + 2, OS_DZ + 2), PhRev2{}, to_regs(bh, bl), no_store);   // W3^T -> zb2
+    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, pre5(OS_A1 + 1, OS_DZ + 1), PhRev2{}, to_regs(ah, al), no_store);    // W2^T -> zb1
+    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, pre5(OS_A1 + 0, OS_DZ + 0), PhRev2{}, to_regs(bh, bl), no_store);    // W1^T -> zb0
+    // X adjoint = W0^T zb0 + W4[:, 193:]^T zb4 + the colour net's share
+    f32x16 G1[2] = {zero16(), zero16()}, G2[2] = {zero16(), zero16()};
+    static_for<2>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        const char* buf = ws.template acquire<0>();
+        ws.begin(CB_BWD);
+        mma_tile<16, 0, true>(ws, buf, bh, bl, G1[u], G2[u], lane);
+    });
+#pragma unroll
+    for (int s = 0; s < 16; ++s) sh.frag_load(OS_ZB4 * SLOT_BYTES, s, ah[s], al[s]);
+    static_for<2>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        const char* buf = ws.template acquire<0>();
+        ws.begin(u == 0 ? CB_BWD : (more ? CB_L0 : 0));
+        mma_tile<16, 0, true>(ws, buf, ah, al, G1[u], G2[u], lane);
+    });
+    // ---- input map: g_pts = J^T Xb + sum_slots d2(slot) GX(slot) gb[channel of the slot]
+    float gp[3] = {0.f, 0.f, 0.f};
+    {
+        float f[4][8];
+        encode_x(p, h, f);
+        f32x16 X0 = combine(G1[0], G2[0]), X1 = combine(G1[1], G2[1]);
+        const f32x16 c0 = sh.tile_load(OS_GX, 2), c1 = sh.tile_load(OS_GX, 3);
+        const f32x16 GX0 = sh.tile_load(OS_GX, 0), GX1 = sh.tile_load(OS_GX, 1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            X0[i] += c0[i];
+            X1[i] += c1[i];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float fr = 1.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float other = other_half(f[c][k], h);
+                const float Xv = (c < 2) ? X0[8 * c + k] : X1[k];
+                const float Gv = (c < 2) ? GX0[8 * c + k] : GX1[k];
+                gp[c] = fmaf(Xv, (h ? -fr : fr) * other, gp[c]);
+                gp[c] = fmaf(Gv * gb[c], -(fr * fr) * f[c][k], gp[c]);
+                fr *= 2.f;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+            const float fr = (jj & 1) ? 512.f : 256.f;
+            const float other = other_half(f[3][jj], h);
+            gp[jj >> 1] = fmaf(X1[8 + jj], (h ? -fr : fr) * other, gp[jj >> 1]);
+            gp[jj >> 1] = fmaf(GX1[8 + jj] * gb[jj >> 1], -(fr * fr) * f[3][jj], gp[jj >> 1]);
+        }
+        gp[0] += h ? 0.f : X1[14];
+        gp[2] += h ? X1[14] : 0.f;
+        gp[1] += h ? 0.f : X1[15];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gp[c] = half_sum(gp[c]) * inv_kappa;
+    }
+    if (valid && h == 0) {
+        a.g_pts[3 * n] = gp[0];
+        a.g_pts[3 * n + 1] = gp[1];
+        a.g_pts[3 * n + 2] = gp[2];
+        if (a.g_rays_d != nullptr) {
+            const int ray = n / a.spr;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(a.g_rays_d + 3 * ray + c, gdir[c] * inv_kappa);
+        }
+    }
+}
+
+// MODE 0: sdf only (sampling passes); 1: full evaluation (sdf, d sdf / d p, colour); 2: full evaluation followed by
+// its adjoint (hn_field_eval_bwd): the sweeps of oracle/field_bwd.py in the same weight-stream / register-resident
+// form, per sample tile, with the tape in the wave's stash.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
+    constexpr bool FULL = MODE >= 1;
+    constexpr bool ADJ = MODE == 2;
+    constexpr int N_SLOTS = ADJ ? OBJ2_SLOTS_ADJ : OBJ2_SLOTS;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     f16_flush_mode();
     const int lane = threadIdx.x & 63;
@@ -88,8 +452,8 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     const int j = lane & 31;
     const int h = lane >> 5;
     Stash sh;
-    sh.init(FULL ? a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * OBJ2_SLOTS * SLOT_F4 : nullptr,
-            FULL ? OBJ2_SLOTS : 0, lane);
+    sh.init(FULL ? a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * N_SLOTS * SLOT_F4 : nullptr,
+            FULL ? N_SLOTS : 0, lane);
     const int n_tiles = (a.n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
 
     WStream ws;
@@ -242,6 +606,10 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                     Frags f;
                     split_tile(dz, f.hi[0], f.lo[0], f.hi[1], f.lo[1]);
                     stash_frags(OS_DZ7)(T, f);
+                    if constexpr (ADJ) {
+                        sh.tile_store(OS_A8, t, st.vec());
+                        sh.tile_store(OS_DZ + 7, t, dz);
+                    }
                 }
                 return NoData{};
             },
@@ -280,8 +648,24 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         };
 #pragma unroll
         for (int s = 0; s < 16; ++s) sh.frag_load(OS_DZ7 * SLOT_BYTES, s, ah[s], al[s]);
-        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 6), PhDsig{}, to_regs(bh, bl), no_store);   // W7^T -> dz6
-        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 5), PhDsig{}, to_regs(ah, al), no_store);   // W6^T -> dz5
+        // (adjoint mode: every dz_l also goes to the stash as an fp32 tile, slot OS_DZ + l)
+        auto to_regs_dz = [&](h8(&oh)[16], h8(&ol)[16], int dz_slot) {
+            return [&oh, &ol, dz_slot, &sh](auto T, EpiState& st, const auto&) {
+                constexpr int t = decltype(T)::value;
+                asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                oh[2 * t] = st.hi[0];
+                ol[2 * t] = st.lo[0];
+                oh[2 * t + 1] = st.hi[1];
+                ol[2 * t + 1] = st.lo[1];
+#if HN_PARK_AGPR
+                asm volatile("" : "+a"(oh[2 * t]), "+a"(ol[2 * t]), "+a"(oh[2 * t + 1]), "+a"(ol[2 * t + 1]));
+#endif
+                if constexpr (ADJ) sh.tile_store(dz_slot, t, st.vec());
+                return NoData{};
+            };
+        };
+        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 6), PhDsig{}, to_regs_dz(bh, bl, OS_DZ + 6), no_store);   // W7^T -> dz6
+        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 5), PhDsig{}, to_regs_dz(ah, al, OS_DZ + 5), no_store);   // W6^T -> dz5
         run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 4), PhDsig{},                          // W5^T -> dz4 (kept)
                                          [&](auto T, EpiState& st, const auto&) {
                                              constexpr int t = decltype(T)::value;
@@ -291,6 +675,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                                              bh[2 * t + 1] = st.hi[1];
                                              bl[2 * t + 1] = st.lo[1];
                                              stash_frags(OS_DZ4)(T, Frags{{st.hi[0], st.hi[1]}, {st.lo[0], st.lo[1]}});
+                                             if constexpr (ADJ) sh.tile_store(OS_DZ + 4, t, st.vec());
                                              return NoData{};
                                          },
                                          no_store);
@@ -308,12 +693,13 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                                                  ah[12] = st.hi[0];   // only k-step 12 exists (neuron 192); 13 is padding
                                                  al[12] = st.lo[0];
                                              }
+                                             if constexpr (ADJ) sh.tile_store(OS_DZ + 3, t, st.vec());
                                              return NoData{};
                                          },
                                          no_store);
-        run_layer<8, 13, 1, false, true>(ws, CB_BWD3, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 2), PhDsig{}, to_regs(bh, bl), no_store);   // W3^T -> dz2
-        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 1), PhDsig{}, to_regs(ah, al), no_store);    // W2^T -> dz1
-        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 0), PhDsig{}, to_regs(bh, bl), no_store);    // W1^T -> dz0
+        run_layer<8, 13, 1, false, true>(ws, CB_BWD3, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 2), PhDsig{}, to_regs_dz(bh, bl, OS_DZ + 2), no_store);   // W3^T -> dz2
+        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 1), PhDsig{}, to_regs_dz(ah, al, OS_DZ + 1), no_store);    // W2^T -> dz1
+        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 0), PhDsig{}, to_regs_dz(bh, bl, OS_DZ + 0), no_store);    // W1^T -> dz0
         // d sdf / d X-space = W0^T dz0 + W4[:, 193:]^T dz4   (64 rows = 2 tiles; row <-> k-slot of the same lane)
         f32x16 G1[2] = {zero16(), zero16()}, G2[2] = {zero16(), zero16()};
         static_for<2>([&](auto U) {
@@ -340,6 +726,10 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             for (int i = 0; i < 16; ++i) {
                 G0[i] *= BWD_INV;
                 Gb[i] *= BWD_INV;
+            }
+            if constexpr (ADJ) {   // d sdf / d X, for the second-order term of the input map
+                sh.tile_store(OS_GX, 0, G0);
+                sh.tile_store(OS_GX, 1, Gb);
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -396,6 +786,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 bl[2 * t] = st.lo[0];
                 bh[2 * t + 1] = st.hi[1];
                 bl[2 * t + 1] = st.lo[1];
+                if constexpr (ADJ) sh.tile_store(OS_C + 0, t, st.vec());
             };
             static_for<8>([&](auto T) {
                 constexpr int t = decltype(T)::value;
@@ -431,27 +822,48 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             split_finish<true>(st);
             put(std::integral_constant<int, 7>{});
         }
-        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, PhRelu{}, to_regs(ah, al), no_store);   // colour lin1
-        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, PhRelu{}, to_regs(bh, bl), no_store);   // colour lin2
+        // (adjoint mode: the colour activations go to the stash for the relu masks)
+        auto to_regs_c = [&](h8(&oh)[16], h8(&ol)[16], int c_slot) {
+            return [&oh, &ol, c_slot, &sh](auto T, EpiState& st, const auto&) {
+                constexpr int t = decltype(T)::value;
+                asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                oh[2 * t] = st.hi[0];
+                ol[2 * t] = st.lo[0];
+                oh[2 * t + 1] = st.hi[1];
+                ol[2 * t + 1] = st.lo[1];
+#if HN_PARK_AGPR
+                asm volatile("" : "+a"(oh[2 * t]), "+a"(ol[2 * t]), "+a"(oh[2 * t + 1]), "+a"(ol[2 * t + 1]));
+#endif
+                if constexpr (ADJ) sh.tile_store(c_slot, t, st.vec());
+                return NoData{};
+            };
+        };
+        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, PhRelu{}, to_regs_c(ah, al, OS_C + 1), no_store);   // colour lin1
+        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, PhRelu{}, to_regs_c(bh, bl, OS_C + 2), no_store);   // colour lin2
         float rgb[3] = {0.f, 0.f, 0.f};
         struct W3 {
             f32x16 w[3];
         };
         run_layer<8, 16, 1, true, false>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
-            ws, CB_HID, more ? CB_L0 : 0, bh, bl, lane, h,
+            ws, CB_HID, ADJ ? CB_W4ROWS : (more ? CB_L0 : 0), bh, bl, lane, h,
             [&](auto, const char* tail) { return W3{{tail_tile(tail, 1, h), tail_tile(tail, 2, h), tail_tile(tail, 3, h)}}; },
             PhRelu{},
-            [&](auto, EpiState& st, const W3& w) {
+            [&](auto T, EpiState& st, const W3& w) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) rgb[c] = fmaf(w.w[c][i], st.v[i], rgb[c]);
                 asm volatile("" : "+v"(rgb[0]), "+v"(rgb[1]), "+v"(rgb[2]));
+                if constexpr (ADJ) sh.tile_store(OS_C + 3, decltype(T)::value, st.vec());
                 return NoData{};
             },
             no_store);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_fast(half_sum(rgb[c]) + a.c_blast[c]);
+        if constexpr (ADJ) {
+            obj_adjoint(a, ws, sh, lane, h, n, nn, valid, more, p, d, g, rgb, ah, al, bh, bl);
+            continue;
+        }
         if (valid && h == 0) {
             a.sdf[n] = sdf;
             a.grad[3 * n] = g[0];
@@ -479,7 +891,7 @@ int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, 
                       float* grad, float* rgb, float* feat, void* workspace, size_t workspace_bytes, bool full,
                       hipStream_t stream) {
     if (n_pts <= 0) return HN_OK;
-    Obj2Args a;
+    Obj2Args a{};
     a.pts = pts;
     a.rays_d = rays_d;
     a.n_pts = n_pts;
@@ -516,12 +928,55 @@ int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, 
         }
     }
     static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};   // devices on which the LDS size attribute is set
-    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<true>), (int)OBJ2_LDS, &lds_full));
-    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<false>), (int)OBJ2_LDS, &lds_sdf));
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<1>), (int)OBJ2_LDS, &lds_full));
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<0>), (int)OBJ2_LDS, &lds_sdf));
     if (full)
-        hipLaunchKernelGGL(k_field2_obj<true>, dim3(grid), dim3(256), OBJ2_LDS, stream, a);
+        hipLaunchKernelGGL(k_field2_obj<1>, dim3(grid), dim3(256), OBJ2_LDS, stream, a);
     else
-        hipLaunchKernelGGL(k_field2_obj<false>, dim3(grid), dim3(256), OBJ2_LDS, stream, a);
+        hipLaunchKernelGGL(k_field2_obj<0>, dim3(grid), dim3(256), OBJ2_LDS, stream, a);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+size_t field2_obj_adj_workspace_bytes(int n_pts, int n_cus) {
+    return (size_t)obj2_grid(n_pts, n_cus) * WG_WAVES * OBJ2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
+}
+
+// hn_field_eval_bwd for an HN_PREC_F16X3 object field: one persistent launch (evaluation + adjoint per sample tile)
+int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int spr, const float* g_sdf,
+                          const float* g_grad, const float* g_rgb, float* g_pts, float* g_rays_d, void* workspace,
+                          size_t workspace_bytes, hipStream_t stream) {
+    if (n_pts <= 0) return HN_OK;
+    HN_REQUIRE(f->v2_adj != nullptr, "field has no adjoint program");
+    Obj2Args a{};
+    a.pts = pts;
+    a.rays_d = rays_d;
+    a.n_pts = n_pts;
+    a.spr = spr > 0 ? spr : 1;
+    a.inv_scale = 1.f / f->scale;
+    a.blob = reinterpret_cast<const char*>(f->v2_adj);
+    a.blob_bytes = f->v2_adj_bytes;
+    a.b8 = f->sdf_b8;
+    for (int c = 0; c < 3; ++c) a.c_blast[c] = f->col_blast[c];
+    a.scratch = reinterpret_cast<float4*>(workspace);
+    a.dbg = 0;
+    a.g_sdf = g_sdf;
+    a.g_grad = g_grad;
+    a.g_rgb = g_rgb;
+    a.g_pts = g_pts;
+    a.g_rays_d = g_rays_d;
+    int n_cus = device_cus();
+    if (n_cus <= 0) n_cus = 256;
+    const int grid = obj2_grid(n_pts, n_cus);
+    const size_t need = (size_t)grid * WG_WAVES * OBJ2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
+    if (workspace == nullptr || workspace_bytes < need) {
+        set_error("adjoint workspace too small: %zu < %zu", workspace_bytes, need);
+        return HN_ENOMEM;
+    }
+    if (g_rays_d != nullptr) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n_pts / a.spr) * 3 * sizeof(float), stream));
+    static std::atomic<uint64_t> lds_adj{0};
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<2>), (int)OBJ2_LDS, &lds_adj));
+    hipLaunchKernelGGL(k_field2_obj<2>, dim3(grid), dim3(256), OBJ2_LDS, stream, a);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

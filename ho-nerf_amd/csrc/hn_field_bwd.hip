@@ -18,7 +18,19 @@
 #include "hn_common.h"
 
 namespace hn {
+namespace v2 {
+size_t field2_obj_adj_workspace_bytes(int n_pts, int n_cus);
+int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int spr, const float* g_sdf,
+                          const float* g_grad, const float* g_rgb, float* g_pts, float* g_rays_d, void* workspace,
+                          size_t workspace_bytes, hipStream_t stream);
+}
 namespace bwd {
+
+// The fused adjoint kernels (hn_field2_*.hip, MODE 2) serve HN_PREC_F16X3 fields; the launch sequence below stays as
+// the HN_PREC_FP32 implementation (an independent second opinion in the tests) and for the sdf-only adjoint.
+static bool fused_adjoint(const hn_field* f, bool sdf_only) {
+    return f->precision == HN_PREC_F16X3 && f->kind == HN_FIELD_OBJ && f->v2_adj != nullptr && !sdf_only;
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float BETA = 100.f;
@@ -634,7 +646,14 @@ size_t field_bwd_workspace_bytes(const hn_field* f, int n) {
     Arena ar{nullptr, 0, 0};
     Bufs b;
     layout(f, n, ar, b);
-    return ar.used;
+    size_t need = ar.used;   // the generic sequence (also what the sdf-only adjoint uses)
+    if (fused_adjoint(f, false)) {
+        int cus = device_cus();
+        if (cus <= 0) cus = 256;
+        const size_t fused = v2::field2_obj_adj_workspace_bytes(n, cus);
+        need = fused > need ? fused : need;
+    }
+    return need;
 }
 
 int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
@@ -650,6 +669,8 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     const bool sdf_only = g_grad == nullptr && g_rgb == nullptr;
     HN_REQUIRE(pts && g_sdf && g_pts && (sdf_only || (g_grad && g_rgb)) && spr >= 1 && n % spr == 0, "bad arguments");
     if (n == 0) return HN_OK;
+    if (fused_adjoint(f, sdf_only))
+        return v2::launch_field2_obj_adj(f, pts, rays_d, n, spr, g_sdf, g_grad, g_rgb, g_pts, g_rays_d, workspace, workspace_bytes, s);
     Arena ar{reinterpret_cast<char*>(workspace), 0, workspace_bytes};
     Bufs b;
     layout(f, n, ar, b);

@@ -410,10 +410,17 @@ struct EpiState {
     float z[2], e[2];   // per-element temporaries carried from phase 0 to phase 1 (index I & 1): plain scalars,
                         // a 16-wide vector would pin 16 consecutive registers for two live values
     float v[16];        // results (scalars for the same reason; vec() assembles a tile where one is needed)
+    float w[16];        // second result of the adjoint's forward-direction layers (kind 4); unused elsewhere
     __device__ __forceinline__ f32x16 vec() const {
         f32x16 y;
 #pragma unroll
         for (int i = 0; i < 16; ++i) y[i] = v[i];
+        return y;
+    }
+    __device__ __forceinline__ f32x16 wvec() const {
+        f32x16 y;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y[i] = w[i];
         return y;
     }
     h8 hi[2], lo[2]; // fragments of k-steps 2t, 2t+1
@@ -451,7 +458,10 @@ __device__ __forceinline__ void split_finish(EpiState& st) {
 // per MFMA slot of a 16-k-step tile) so that the multiply-adds become packed fp32 instructions (v_pk_fma/mul/add_f32:
 // two elements per issue slot).  The wave is issue-bound -- every VALU instruction of the epilogue costs ~4 cycles
 // of the same in-order stream that has to issue the MFMAs -- so the instruction count, not the ALU rate, is what
-// matters.  kind: 0 softplus(beta=100), 1 g * sigma'(z) from the stashed activation, 2 relu, 3 identity.
+// matters.  kind: 0 softplus(beta=100), 1 g * sigma'(z) from the stashed activation, 2 relu, 3 identity;
+// adjoint (hn_field2_*_adj): 4 forward-direction sweep  v = z sigma',  w = z (1 - sigma') * pd.x  (pd.x = 100 dz / 256:
+// w is the second-order source sigma'' u dzb of oracle/field_bwd.py written without a division by sigma');
+// 5 second reverse sweep  v = z sigma' + pd.x;  6 relu mask  v = pd.v > 0 ? z : 0.
 template <int J, int P, int KIND, bool FRAGS, typename PD>
 __device__ __forceinline__ void pair_phase(EpiState& st, const PD& pd) {
     constexpr int i0 = 2 * J, i1 = 2 * J + 1;
@@ -460,21 +470,30 @@ __device__ __forceinline__ void pair_phase(EpiState& st, const PD& pd) {
         const f32x2 inv = {st.inv, st.inv};
         st.z2 = c2 * inv + c1;
         if constexpr (KIND == 0) st.t2 = st.z2 * f32x2{K100_, K100_};
-        if constexpr (KIND == 1) st.t2 = f32x2{pd.v[i0], pd.v[i1]} * f32x2{-K100_, -K100_};
+        if constexpr (KIND == 1 || KIND == 4 || KIND == 5) st.t2 = f32x2{pd.v[i0], pd.v[i1]} * f32x2{-K100_, -K100_};
     } else if constexpr (P == 1) {
         if constexpr (KIND == 0) st.e2 = f32x2{__builtin_amdgcn_exp2f(-fabsf(st.t2[0])), __builtin_amdgcn_exp2f(-fabsf(st.t2[1]))};
-        if constexpr (KIND == 1) st.e2 = f32x2{__builtin_amdgcn_exp2f(st.t2[0]), __builtin_amdgcn_exp2f(st.t2[1])};
+        if constexpr (KIND == 1 || KIND == 4 || KIND == 5) st.e2 = f32x2{__builtin_amdgcn_exp2f(st.t2[0]), __builtin_amdgcn_exp2f(st.t2[1])};
     } else if constexpr (P == 2) {
         if constexpr (KIND == 0) {
             const f32x2 u = st.e2 + f32x2{1.f, 1.f};
             st.e2 = f32x2{__builtin_amdgcn_logf(u[0]), __builtin_amdgcn_logf(u[1])};
         }
+        if constexpr (KIND == 4 || KIND == 5) st.e2 = st.z2 * st.e2;   // z (1 - sigma')
     } else if constexpr (P == 3) {
         f32x2 v;
         if constexpr (KIND == 0) v = st.e2 * f32x2{C100_, C100_} + f32x2{fmaxf(st.z2[0], 0.f), fmaxf(st.z2[1], 0.f)};
         if constexpr (KIND == 1) v = st.z2 - st.z2 * st.e2;
         if constexpr (KIND == 2) v = f32x2{fmaxf(st.z2[0], 0.f), fmaxf(st.z2[1], 0.f)};
         if constexpr (KIND == 3) v = st.z2;
+        if constexpr (KIND == 4) {
+            v = st.z2 - st.e2;
+            const f32x2 w = st.e2 * f32x2{pd.x[i0], pd.x[i1]};
+            st.w[i0] = w[0];
+            st.w[i1] = w[1];
+        }
+        if constexpr (KIND == 5) v = st.z2 - st.e2 + f32x2{pd.x[i0], pd.x[i1]};
+        if constexpr (KIND == 6) v = f32x2{pd.v[i0] > 0.f ? st.z2[0] : 0.f, pd.v[i1] > 0.f ? st.z2[1] : 0.f};
         st.v[i0] = v[0];
         st.v[i1] = v[1];
     } else if constexpr (P == 4) {
@@ -544,8 +563,8 @@ __device__ __forceinline__ void arm(EpiState& st) {
 //   - `held = fin(T-1, st, pd)`: the finished tile's fragments -> registers; returns what `store` needs.
 // next_same / next_after: bytes of the chunk that follows a chunk of this layer (another of the same
 // layer / the first of the next layer; 0 = none).
-template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, typename Pre, typename Ph, typename Fin, typename Store>
-__device__ __forceinline__ void run_layer(WStream& ws, int next_same, int next_after, const h8 (&xh)[16], const h8 (&xl)[16],
+template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, int NX, typename Pre, typename Ph, typename Fin, typename Store>
+__device__ __forceinline__ void run_layer(WStream& ws, int next_same, int next_after, const h8 (&xh)[NX], const h8 (&xl)[NX],
                                           int lane, int h, Pre&& pre, Ph&& ph, Fin&& fin, Store&& store) {
     using I0 = std::integral_constant<int, 0>;
     using PD = decltype(pre(I0{}, (const char*)nullptr));
@@ -621,6 +640,46 @@ struct PhDsig {
         } else {
             st.v[I] = fmaf(st.z[I & 1], -st.e[I & 1], st.z[I & 1]);
         }
+    }
+};
+// the adjoint's element-wise kinds (pair_phase kinds 4, 5, 6).  PD carries the stashed activation in .v and, for
+// 4 and 5, a second tile in .x.
+struct PhFwdDir {
+    static constexpr int kind = 4;
+    static constexpr bool branchy = HN_BRANCHY_REV;
+    template <typename I_, typename P_, typename PD>
+    __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD& pd) const {
+        constexpr int I = I_::value, P = P_::value;
+        if constexpr (P == 0) {
+            st.z[I & 1] = fmaf(st.c2[I], st.inv, st.c1[I]);
+            st.e[I & 1] = __builtin_amdgcn_exp2f(pd.v[I] * -K100) * st.z[I & 1];
+        } else {
+            st.v[I] = st.z[I & 1] - st.e[I & 1];
+            st.w[I] = st.e[I & 1] * pd.x[I];
+        }
+    }
+};
+struct PhRev2 {
+    static constexpr int kind = 5;
+    static constexpr bool branchy = HN_BRANCHY_REV;
+    template <typename I_, typename P_, typename PD>
+    __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD& pd) const {
+        constexpr int I = I_::value, P = P_::value;
+        if constexpr (P == 0) {
+            st.z[I & 1] = fmaf(st.c2[I], st.inv, st.c1[I]);
+            st.e[I & 1] = __builtin_amdgcn_exp2f(pd.v[I] * -K100) * st.z[I & 1];
+        } else {
+            st.v[I] = st.z[I & 1] - st.e[I & 1] + pd.x[I];
+        }
+    }
+};
+struct PhMask {
+    static constexpr int kind = 6;
+    static constexpr bool branchy = HN_BRANCHY_RELU;
+    template <typename I_, typename P_, typename PD>
+    __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD& pd) const {
+        constexpr int I = I_::value, P = P_::value;
+        if constexpr (P == 0) st.v[I] = pd.v[I] > 0.f ? fmaf(st.c2[I], st.inv, st.c1[I]) : 0.f;
     }
 };
 struct PhRelu {

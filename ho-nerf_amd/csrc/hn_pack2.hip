@@ -61,6 +61,12 @@ struct Builder {
             }
         if (tail) memcpy(blob.data() + base + (size_t)tiles * ks * KS_BYTES, tail, TAIL_BYTES);
     }
+    // side data only (a multiple of 1 KiB)
+    void raw(const void* data, size_t bytes) {
+        const size_t base = blob.size();
+        blob.resize(base + bytes);
+        memcpy(blob.data() + base, data, bytes);
+    }
 };
 
 // tail slot k <- 32 values given in natural tile-row order, stored [half][16]
@@ -165,8 +171,22 @@ static void slot_rows_T(Builder& B, const HostMat& M, float scale, const std::ve
     }
 }
 
-// The obj program (contract with k_field2_obj): sdf forward [+ feature rows + reverse sweep + colour]
-static void build_obj_stream(Builder& B, const HostMat* S, const HostMat* C, bool full) {
+// transposed rows of W8[1:, :] (the feature-vector rows) for the adjoint: out tile t = a8 neurons, K = feature index i
+// (matrix row 1 + i); tail slot 0 = W8[0, tile rows] (the sdf row, multiplied by g_sdf in the kernel)
+static void w8_T_tiles(Builder& B, const HostMat& M) {
+    const std::vector<int> slots = offset(hid_slots(), 1);
+    for (int t = 0; t < 8; ++t) {
+        const std::vector<int> rows = rows_of_tile(t, 256);
+        float tail[256] = {0.f};
+        float v[32];
+        for (int i = 0; i < 32; ++i) v[i] = M.at(0, rows[i]);
+        tail_put(tail, 0, v);
+        B.chunk(M, true, 1.f, 1, 16, rows.data(), slots.data(), tail);
+    }
+}
+
+// obj sdf network, forward-oriented chunks lin0..lin7 (the forward pass and the adjoint's forward-direction sweep)
+static void obj_sdf_forward_chunks(Builder& B, const HostMat* S) {
     const float rs2 = (float)(1.0 / sqrt(2.0));
     const std::vector<int> xs = obj_x_slots();
     const std::vector<int> hs = hid_slots();
@@ -201,9 +221,11 @@ static void build_obj_stream(Builder& B, const HostMat* S, const HostMat* C, boo
         const float* extra[1] = {w8.data()};
         fwd_tiles(B, S[7], 1.f, 8, 256, 0, hs, 16, extra, 1);
     }
-    if (!full) return;
-    fwd_tiles(B, S[8], 1.f, 8, 256, 1, hs, 16, nullptr, 0);   // feature rows 1..256
-    // reverse sweep
+}
+// obj sdf network, transposed chunks of the reverse sweep: W7^T .. W1^T, then W0^T and W4[:, 193:]^T over the X slots
+static void obj_sdf_reverse_chunks(Builder& B, const HostMat* S) {
+    const float rs2 = (float)(1.0 / sqrt(2.0));
+    const std::vector<int> xs = obj_x_slots();
     bwd_tiles(B, S[7], 1.f, 8, 256, 0, 256, 16);
     bwd_tiles(B, S[6], 1.f, 8, 256, 0, 256, 16);
     bwd_tiles(B, S[5], 1.f, 8, 256, 0, 256, 16);
@@ -213,11 +235,22 @@ static void build_obj_stream(Builder& B, const HostMat* S, const HostMat* C, boo
     bwd_tiles(B, S[1], 1.f, 8, 256, 0, 256, 16);
     slot_rows_T(B, S[0], 1.f, xs, 0);                 // W0^T over the X slots (2 tiles)
     slot_rows_T(B, S[4], rs2, xs, L3_OUT_OBJ);       // W4[:, 193:]^T over the X slots
+}
+
+// The obj program (contract with k_field2_obj): sdf forward [+ feature rows + reverse sweep + colour [+ adjoint]]
+// mode 0: sdf only; 1: full evaluation; 2: full evaluation followed by its adjoint (hn_field_eval_bwd)
+static void build_obj_stream(Builder& B, const HostMat* S, const HostMat* C, int mode) {
+    const std::vector<int> xs = obj_x_slots();
+    const std::vector<int> hs = hid_slots();
+    obj_sdf_forward_chunks(B, S);
+    if (mode == 0) return;
+    fwd_tiles(B, S[8], 1.f, 8, 256, 1, hs, 16, nullptr, 0);   // feature rows 1..256
+    obj_sdf_reverse_chunks(B, S);
     // colour lin0: [enc(p) 63 | enc(d) 27 | feature 256 | enc(g) 27] (utils/fields.py:389-396)
+    const std::vector<int> v4 = vec4_slots();
+    const std::vector<int> misc = cat(cat(xs, offset(v4, OBJ_IN)), offset(v4, OBJ_IN + 27 + H));
     {
-        const std::vector<int> v4 = vec4_slots();
         const std::vector<int> fv = offset(hs, OBJ_IN + 27);
-        const std::vector<int> misc = cat(cat(xs, offset(v4, OBJ_IN)), offset(v4, OBJ_IN + 27 + H));
         for (int t = 0; t < 8; ++t) {
             const std::vector<int> rows = rows_of_tile(t, 256);
             B.chunk(C[0], false, 1.f, 1, 16, rows.data(), fv.data(), nullptr);
@@ -240,6 +273,28 @@ static void build_obj_stream(Builder& B, const HostMat* S, const HostMat* C, boo
         const float* extra[3] = {w0.data(), w1.data(), w2.data()};
         fwd_tiles(B, C[3], 1.f, 8, 256, 0, hs, 16, extra, 3);
     }
+    if (mode < 2) return;
+    // ---- adjoint (oracle/field_bwd.py steps 3b-6; contract with k_field2_obj<2>) -------------------------------
+    // colour network backward: the three rows of lin4 (one tail-format KiB each: slot t = the row's 32 values of
+    // tile t), C3^T, C2^T, C1^T, then C0^T over the feature-vector rows and over the [enc(p) | enc(d) | enc(g)]
+    // slots (4 tiles: X, X, d, g)
+    for (int c = 0; c < 3; ++c) {
+        float tail[256];
+        for (int t = 0; t < 8; ++t) {
+            float v[32];
+            for (int i = 0; i < 32; ++i) v[i] = C[4].at(c, 32 * t + i);
+            tail_put(tail, t, v);
+        }
+        B.raw(tail, TAIL_BYTES);
+    }
+    bwd_tiles(B, C[3], 1.f, 8, 256, 0, 256, 16);
+    bwd_tiles(B, C[2], 1.f, 8, 256, 0, 256, 16);
+    bwd_tiles(B, C[1], 1.f, 8, 256, 0, 256, 16);
+    bwd_tiles(B, C[0], 1.f, 8, 256, OBJ_IN + 27, 256, 16);
+    slot_rows_T(B, C[0], 1.f, misc, 0);
+    obj_sdf_forward_chunks(B, S);         // forward-direction sweep dzb_l = W_l (sigma'_{l-1} dzb_{l-1}) (biases unused)
+    w8_T_tiles(B, S[8]);                  // adjoint of a8 = W8[1:, :]^T fb (+ g_sdf W8[0, :] from the tail)
+    obj_sdf_reverse_chunks(B, S);         // second reverse sweep
 }
 
 static int upload(const std::vector<char>& blob, void** dev, size_t* bytes, hipStream_t stream) {
@@ -274,14 +329,17 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
         if (rc != HN_OK) return rc;
     }
     HN_CHECK_HIP(hipStreamSynchronize(stream));
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int mode = 0; mode < 3; ++mode) {
         Builder B;
-        const bool full = pass == 0;
-        if (f->kind == HN_FIELD_OBJ)
-            build_obj_stream(B, S, C, full);
-        else
-            build_hand_stream(B, S, C, full);
-        const int rc = upload(B.blob, full ? &f->v2_full : &f->v2_sdf, full ? &f->v2_full_bytes : &f->v2_sdf_bytes, stream);
+        if (f->kind == HN_FIELD_OBJ) {
+            build_obj_stream(B, S, C, mode);
+        } else {
+            if (mode == 2) continue;   // the hand adjoint program: hn_field2_hand_adj (not built yet -> generic adjoint)
+            build_hand_stream(B, S, C, mode == 1);
+        }
+        void** dst = mode == 0 ? &f->v2_sdf : (mode == 1 ? &f->v2_full : &f->v2_adj);
+        size_t* nb = mode == 0 ? &f->v2_sdf_bytes : (mode == 1 ? &f->v2_full_bytes : &f->v2_adj_bytes);
+        const int rc = upload(B.blob, dst, nb, stream);
         if (rc != HN_OK) return rc;
     }
     return HN_OK;

@@ -716,11 +716,13 @@ def _field_adjoint_gpu(L, field, pts, dirs, spr, gs, gg, gr, bt=None, tp=None):
     return g_pts, g_dirs, g_bt, g_tp
 
 
-def test_obj_field_adjoint(L):
+@pytest.mark.parametrize('aprec', ['f16x3', 'fp32'])
+def test_obj_field_adjoint(L, aprec):
     """hn_field_eval_bwd (object field) against the hand-written adjoint of the oracle (oracle/field_bwd.py, itself
-    checked against autograd in tests/test_field_adjoint_spec.py): d/d pts incl. the second-order path, d/d rays_d."""
+    checked against autograd in tests/test_field_adjoint_spec.py): d/d pts incl. the second-order path, d/d rays_d.
+    'f16x3': the fused adjoint kernel (k_field2_obj<2>); 'fp32': the generic launch sequence (hn_field_bwd.hip)."""
     from oracle.field_bwd import field_adjoint
-    _, obj = packed_fields('cuda', 'f16x3')
+    _, obj = packed_fields('cuda', aprec)
     _, obj64 = oracle_fields_fp64()
     gen = torch.Generator().manual_seed(2)
     spr, rays = 8, 37
@@ -735,13 +737,14 @@ def test_obj_field_adjoint(L):
     assert_close(g_dirs, ref['g_dirs'].reshape(rays, spr, 3).sum(1).float(), 2e-4, 'd/d rays_d')
 
 
-def test_hand_field_adjoint(L):
+@pytest.mark.parametrize('aprec', ['f16x3', 'fp32'])
+def test_hand_field_adjoint(L, aprec):
     """hn_field_eval_bwd (hand field): d/d pts, d/d bt_inv, d/d T_pose including the second-order path through the
     bone encoding, against the oracle's hand-written adjoint evaluated in float64.  Near joints the problem is
     ill-conditioned (see assert_parity): the bar is the fp32 evaluation of the same formulas."""
     from oracle.field_bwd import field_adjoint
     from honerf_amd import synth
-    hand, _ = packed_fields('cuda', 'f16x3')
+    hand, _ = packed_fields('cuda', aprec)
     hand32, _ = oracle_fields()
     hand64, _ = oracle_fields_fp64()
     gen = torch.Generator().manual_seed(6)
