@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     if (u == 0 && live) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(sh.rsrc, (lds_void_t*)(stage + i * 1024), 16, sh.voff,
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(sh.rsrc, (lds_void_t*)(stage + i * 1024), 16, lane_x16(),
                                                                      FEAT + (4 * b + (i >> 1)) * KS_BYTES + (i & 1) * 1024, 0, STASH_AUX);
                     }
                     G1[u] = zero16();

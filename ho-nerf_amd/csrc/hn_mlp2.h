@@ -68,6 +68,17 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// lane * 16, recomputed where it is needed (3 VALU instructions) instead of being kept in a register for the whole
+// kernel: as a long-lived, rarely-read value it is the register allocator's first choice for a spill in these
+// 512-register kernels, and the reload -- a scratch_load with an s_waitcnt vmcnt(0) behind it in front of every stash
+// access -- drains the whole memory pipeline each time (measured: every stash prefetch serialised).  asm volatile:
+// the result must not be CSE'd back into one long-lived value.
+__device__ __forceinline__ int lane_x16() {
+    int v;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(v));
+    return v;
+}
+
 // ---- weight stream ---------------------------------------------------------------------------
 // The stream is cyclic (after the last chunk of a sample tile comes the first again) and is read
 // through a buffer descriptor: buffer_load_dwordx4 ... offen lds with a scalar byte offset per 1 KiB
@@ -153,10 +164,11 @@ struct WStream {
     template <bool BRANCHY = false>
     __device__ __forceinline__ void piece(int k) {
         if constexpr (BRANCHY) {
-            if (k < f_pieces) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(f_dst + k * 4096), 16, voff, f_goff + k * 4096, 0, 0);
+            if (k < f_pieces) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(f_dst + k * 4096), 16, lane_x16(), f_goff + k * 4096, 0, 0);
             return;
         }
-        const int vo = (k < f_pieces) ? voff : voff_oob;
+        const int l16 = lane_x16();
+        const int vo = (k < f_pieces) ? l16 : l16 + 0x7f000000;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(f_dst + k * 4096), 16, vo, f_goff + k * 4096, 0, 0);
     }
     __device__ __forceinline__ void pieces_all() {
@@ -728,50 +740,63 @@ struct Stash {
     // picks up the NEW register contents for its later dwords (observed: dword 1 of a fragment replaced
     // by the residual computed two instructions later).  In this form the compiler's store-data hazard
     // rule applies and the required wait state is inserted.
+    // A lane offset that the compiler has to treat as new at every use: the stash addresses are loop-invariant
+    // (lane * 16 + constant), and hoisted out of the persistent tile loop -- as LICM does with plain arithmetic --
+    // the few hundred of them are all live across the whole kernel, get spilled at its top and are re-read from
+    // scratch memory in front of every stash store (measured: 568 scratch loads in the full object kernel).
+    __device__ __forceinline__ int fresh_voff() const { return lane_x16(); }
+    template <typename T16>
+    __device__ __forceinline__ void st16_at(const T16& v, int vo) const {
+        static_assert(sizeof(T16) == 16, "16-byte values only");
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, vo, 0, STASH_AUX);
+    }
     template <typename T16>
     __device__ __forceinline__ void st16(const T16& v, int off) const {
-        static_assert(sizeof(T16) == 16, "16-byte values only");
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, voff + off, 0, STASH_AUX);
+        st16_at(v, fresh_voff() + off);
     }
-    __device__ __forceinline__ u32x4 ld16(int off) const { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, off, STASH_AUX); }
+    __device__ __forceinline__ u32x4 ld16_at(int vo, int off) const { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, off, STASH_AUX); }
+    __device__ __forceinline__ u32x4 ld16(int off) const { return ld16_at(lane_x16(), off); }
     // fp32 tile t of slot `slot`: [t][q][lane] float4
     __device__ __forceinline__ void tile_store(int slot, int t, const f32x16& y) const {
         using f32x4 = float __attribute__((ext_vector_type(4)));
-        const int off = slot * SLOT_BYTES + t * 4096;
-        st16((f32x4)__builtin_shufflevector(y, y, 0, 1, 2, 3), off);
-        st16((f32x4)__builtin_shufflevector(y, y, 4, 5, 6, 7), off + 1024);
-        st16((f32x4)__builtin_shufflevector(y, y, 8, 9, 10, 11), off + 2048);
-        st16((f32x4)__builtin_shufflevector(y, y, 12, 13, 14, 15), off + 3072);
+        const int vo = fresh_voff() + (slot * SLOT_BYTES + t * 4096);   // + 1024 q fits the instruction's offset field
+        st16_at((f32x4)__builtin_shufflevector(y, y, 0, 1, 2, 3), vo);
+        st16_at((f32x4)__builtin_shufflevector(y, y, 4, 5, 6, 7), vo + 1024);
+        st16_at((f32x4)__builtin_shufflevector(y, y, 8, 9, 10, 11), vo + 2048);
+        st16_at((f32x4)__builtin_shufflevector(y, y, 12, 13, 14, 15), vo + 3072);
     }
     __device__ __forceinline__ f32x16 tile_load(int slot, int t) const {
         using f32x4 = float __attribute__((ext_vector_type(4)));
         using f32x8 = float __attribute__((ext_vector_type(8)));
         const int off = slot * SLOT_BYTES + t * 4096;
-        const f32x4 a = __builtin_bit_cast(f32x4, ld16(off));
-        const f32x4 b = __builtin_bit_cast(f32x4, ld16(off + 1024));
-        const f32x4 c = __builtin_bit_cast(f32x4, ld16(off + 2048));
-        const f32x4 d = __builtin_bit_cast(f32x4, ld16(off + 3072));
+        const int vo = lane_x16();
+        const f32x4 a = __builtin_bit_cast(f32x4, ld16_at(vo, off));
+        const f32x4 b = __builtin_bit_cast(f32x4, ld16_at(vo, off + 1024));
+        const f32x4 c = __builtin_bit_cast(f32x4, ld16_at(vo, off + 2048));
+        const f32x4 d = __builtin_bit_cast(f32x4, ld16_at(vo, off + 3072));
         const f32x8 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
         const f32x8 cd = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     }
     // fragment block s (byte offset `base` + s * 2 KiB): [hi | lo][lane] 16 B
     __device__ __forceinline__ void frag_store(int base, int s, const h8& hi, const h8& lo) const {
-        st16(hi, base + s * KS_BYTES);
-        st16(lo, base + s * KS_BYTES + 1024);
+        const int vo = fresh_voff() + (base + s * KS_BYTES);
+        st16_at(hi, vo);
+        st16_at(lo, vo + 1024);
     }
     __device__ __forceinline__ void frag_load(int base, int s, h8& hi, h8& lo) const {
-        const u32x4 a = ld16(base + s * KS_BYTES);
-        const u32x4 b = ld16(base + s * KS_BYTES + 1024);
+        const int vo = lane_x16();
+        const u32x4 a = ld16_at(vo, base + s * KS_BYTES);
+        const u32x4 b = ld16_at(vo, base + s * KS_BYTES + 1024);
         hi = __builtin_bit_cast(h8, a);
         lo = __builtin_bit_cast(h8, b);
     }
     // one float per lane at byte offset off + lane * 4
     __device__ __forceinline__ void f32_store(int off, float v) const {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff >> 2, off, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, lane_x16() >> 2, off, 0);
     }
     __device__ __forceinline__ float f32_load(int off) const {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff >> 2, off, 0));
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_x16() >> 2, off, 0));
     }
 };
 
