@@ -48,6 +48,13 @@ struct Hand2Args {
     float4* scratch;
     int dbg;
     int cull;   // hn_field_set_culling
+    // adjoint (MODE 2): upstream gradients in, input / pose gradients out
+    const float* g_sdf;    // [n]
+    const float* g_grad;   // [n,3]
+    const float* g_rgb;    // [n,3]
+    float* g_pts;          // [n,3]
+    float* g_bt_inv;       // [n_frames,21,4,4] accumulated (atomics), or NULL
+    float* g_T_pose;       // [n_frames,21,3] accumulated (atomics), or NULL
 };
 
 // stash slots of one wave (32 KiB each)
@@ -61,6 +68,17 @@ enum {
     HS_LEFT = 17,   // 21 x 64 floats: the leftover (r_1 | r_2) h values while the bones are generated
     HAND2_SLOTS = 18,
     HAND2_SLOTS_SDF = 18,
+    // ... and what the adjoint (MODE 2) adds
+    HS_A8 = 18,     // a8 (fp32)
+    HS_DZ = 19,     // dz0..dz7 of the reverse sweep as fp32 tiles -> 19..26; slot l is overwritten by the second-order
+                    // source w_l once the forward-direction sweep has passed layer l
+    HS_C = 27,      // colour activations c1..c4 -> 27..30 (relu masks)
+    HS_GXB = 31,    // J gb as 87 k-step blocks of fragments (the layout of HS_FEAT) -> 31..36
+    HS_TS = 37,     // per bone 9 sums of d sdf / d features (T0, T1[4], T2[4]), one float per lane each -> 37, 38
+    HS_QA = 39,     // per bone the colour network's share of the bone-frame gradient qbar (3 floats per lane);
+                    // behind it (+ 16 KiB) the leftover rows of the X adjoint, one float per bone and lane
+    HS_ZB4 = 40,    // zb4 as fragments
+    HAND2_SLOTS_ADJ = 41,
 };
 constexpr int FEAT_BLOCKS = 4 * N_BONES;     // first leftover block index
 constexpr int STAGE_BYTES = 8 * 1024;        // LDS staging of one bone's 4 fragment pairs (Jacobian pass)
@@ -71,6 +89,7 @@ constexpr int HB_BONE = chunk_bytes(4, 4, false);
 constexpr int HB_LEFT_T = chunk_bytes(4, 3, true);    // leftover chunk with the 4 biases (lin0)
 constexpr int HB_LEFT = chunk_bytes(4, 3, false);
 constexpr int HB_G = chunk_bytes(4, 2, true);         // colour lin0: enc(g) columns + the 4 biases
+constexpr int HB_W4ROWS = 3 * TAIL_BYTES;             // adjoint: the three rows of colour lin4, one tail-format KiB each
 
 struct Bone2 {
     float v, r[3], hh;
@@ -191,8 +210,97 @@ __device__ __forceinline__ void bone_to_p(float Sv, const float (&Sr)[3], const 
     g[2] += rd<UNI>(m, 2) * dq0 + rd<UNI>(m, 6) * dq1 + rd<UNI>(m, 10) * dq2;
 }
 
-template <bool FULL>
+
+// ---- bone-frame calculus of the adjoint (oracle/field_bwd.py::_HandInput) -------------------------------------------
+// A bone's 66 features are phi_f(y_f) h(v) with y_f one of (v, r_0, r_1, r_2).  For a row G over the features the
+// h-weighted sums
+//   T0 = sum_f G_f phi_f h,   T1_a = sum_{f on a} G_f phi_f' h,   T2_a = sum_{f on a} G_f phi_f'' h
+// give everything the input map needs without dividing by h: with kk = h'/h = -tau (1 - h) and
+// k2 = h''/h = -tau^2 (1 - h)(2 h - 1):  Sv = T1_v + kk T0,  Sr = T1_r,  d/dq = Sv r + (Sr - (Sr.r) r) / v.
+// The stored feature of a slot is own = phi h; its partner lane (other half, same sample) stores the conjugate
+// function, so phi' h = +-f partner and phi'' h = -f^2 own.
+struct BoneSums {
+    float T0, T1[4], T2[4];
+};
+// which argument / frequency the main slot (s, j) of a bone encodes (bone_slots in hn_pack2.hip); raw: the (v | r_0) pair
+__device__ __forceinline__ constexpr int slot_var(int s, int j) { return s == 0 ? 0 : (s == 1 ? (j < 2 ? 0 : 1) : (s == 2 ? (j < 1 ? 1 : 2) : 3)); }
+__device__ __forceinline__ constexpr int slot_freq(int s, int j) { return s == 0 ? j : (s == 1 ? (j < 2 ? 8 + j : j - 2) : (s == 2 ? (j < 1 ? 6 : j - 1) : j)); }
+// per-lane partial sums over the 64 main slots (half_sum them afterwards); G0: k-steps 0, 1 (register 8 s + j), G1: 2, 3
+template <bool WITH2>
+__device__ __forceinline__ void bone_sums(const f32x16& G0, const f32x16& G1, const float (&own)[4][8], float hh, int h, BoneSums& S) {
+    S.T0 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) S.T1[a] = S.T2[a] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float Gv = (s < 2) ? G0[8 * s + j] : G1[8 * (s - 2) + j];
+            S.T0 = fmaf(Gv, own[s][j], S.T0);
+            if (s == 3 && j == 7) {   // raw pair (v | r_0) h: phi' = 1, phi'' = 0
+                S.T1[0] += h ? 0.f : Gv * hh;
+                S.T1[1] += h ? Gv * hh : 0.f;
+                continue;
+            }
+            const int var = slot_var(s, j);
+            const float fr = (float)(1 << slot_freq(s, j));
+            const float other = other_half(own[s][j], h);
+            S.T1[var] = fmaf(Gv, (h ? -fr : fr) * other, S.T1[var]);
+            if (WITH2) S.T2[var] = fmaf(Gv, -(fr * fr) * own[s][j], S.T2[var]);
+        }
+}
+__device__ __forceinline__ void sums_reduce(BoneSums& S, bool with2) {
+    S.T0 = half_sum(S.T0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        S.T1[a] = half_sum(S.T1[a]);
+        if (with2) S.T2[a] = half_sum(S.T2[a]);
+    }
+}
+// d/dq of F = sum_f G_f F_f from the (reduced) sums
+__device__ __forceinline__ void dq_from_sums(const BoneSums& S, const Bone2& q, float kk, float (&dq)[3]) {
+    const float Sv = fmaf(kk, S.T0, S.T1[0]);
+    const float dot = S.T1[1] * q.r[0] + S.T1[2] * q.r[1] + S.T1[3] * q.r[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dq[c] = Sv * q.r[c] + (S.T1[1 + c] - dot * q.r[c]) / q.v;
+}
+// Hessian-vector product of F at q along w (the second-order term of g . gbar, _HandInput.second)
+__device__ __forceinline__ void hv_from_sums(const BoneSums& S, const Bone2& q, float kk, float k2, const float (&w)[3], float (&hv)[3]) {
+    const float rw = q.r[0] * w[0] + q.r[1] * w[1] + q.r[2] * w[2];
+    float wt[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wt[c] = (w[c] - q.r[c] * rw) / q.v;
+    const float Sv = fmaf(kk, S.T0, S.T1[0]);
+    const float Sr[3] = {S.T1[1], S.T1[2], S.T1[3]};
+    const float dSv_dv = 2.f * kk * S.T1[0] + S.T2[0] + k2 * S.T0;
+    const float hb_r = kk * (Sr[0] * q.r[0] + Sr[1] * q.r[1] + Sr[2] * q.r[2]);
+    const float cc = kk * (Sr[0] * wt[0] + Sr[1] * wt[1] + Sr[2] * wt[2]);
+    const float e[3] = {S.T2[1] * wt[0], S.T2[2] * wt[1], S.T2[3] * wt[2]};
+    const float e_r = e[0] * q.r[0] + e[1] * q.r[1] + e[2] * q.r[2];
+    const float dot = Sr[0] * q.r[0] + Sr[1] * q.r[1] + Sr[2] * q.r[2];
+    const float sr_wt = Sr[0] * wt[0] + Sr[1] * wt[1] + Sr[2] * wt[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float gSv = dSv_dv * q.r[c] + (kk * Sr[c] - hb_r * q.r[c]) / q.v;
+        hv[c] = gSv * rw + Sv * wt[c] + cc * q.r[c] + (e[c] - e_r * q.r[c]) / q.v -
+                ((Sr[c] - dot * q.r[c]) / q.v * rw + dot * wt[c]) / q.v - sr_wt * q.r[c] / q.v;
+    }
+}
+// sum over the wave's lanes (64): butterfly through the LDS crossbar; cold path (12 values per live bone and tile)
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// MODE 0: sdf only (sampling passes); 1: full evaluation (sdf, d sdf / d p, colour); 2: full evaluation followed by its
+// adjoint (hn_field_eval_bwd): the sweeps of oracle/field_bwd.py in the same weight-stream / register-resident form,
+// per sample tile, with the tape in the wave's stash.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
+    constexpr bool FULL = MODE >= 1;
+    constexpr bool ADJ = MODE == 2;
+    constexpr int N_SLOTS = ADJ ? HAND2_SLOTS_ADJ : HAND2_SLOTS;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     f16_flush_mode();
     const int lane = threadIdx.x & 63;
@@ -200,9 +308,15 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     const int j = lane & 31;
     const int h = lane >> 5;
     Stash sh;
-    sh.init(a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * HAND2_SLOTS * SLOT_F4, HAND2_SLOTS, lane);
+    sh.init(a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * N_SLOTS * SLOT_F4, N_SLOTS, lane);
     constexpr int FEAT = HS_FEAT * SLOT_BYTES;   // byte offset of the feature fragment blocks
     constexpr int LEFT = HS_LEFT * SLOT_BYTES;   // ... of the leftover values
+    constexpr int GXB = HS_GXB * SLOT_BYTES;     // adjoint: J gb, same block layout as the features ...
+    constexpr int LEFT2 = LEFT + 8192;           // ... and its leftover values
+    constexpr int TS = HS_TS * SLOT_BYTES;       // per-bone sums of d sdf / d features
+    constexpr int QA = HS_QA * SLOT_BYTES;       // colour network's share of qbar per bone (3 floats per lane)
+    constexpr int LEFTX = QA + 16384;            // leftover rows of an X-space adjoint, one float per bone and lane
+    int feat_base = FEAT;                        // which block set load_bone reads (FEAT or GXB)
     const int n_tiles = (a.n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
 
     WStream ws;
@@ -337,7 +451,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         auto load_bone = [&](int b, h8(&oh)[4], h8(&ol)[4]) {
             if (b >= N_BONES || ((nz >> b) & 1u)) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) sh.frag_load(FEAT, 4 * b + s, oh[s], ol[s]);
+                for (int s = 0; s < 4; ++s) sh.frag_load(feat_base, 4 * b + s, oh[s], ol[s]);
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -502,6 +616,10 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     Frags f;
                     split_tile(dz, f.hi[0], f.lo[0], f.hi[1], f.lo[1]);
                     stash_frags(HS_DZ7)(T, f);
+                    if constexpr (ADJ) {
+                        sh.tile_store(HS_A8, t, st.vec());
+                        sh.tile_store(HS_DZ + 7, t, dz);
+                    }
                 }
                 return NoData{};
             },
@@ -534,8 +652,22 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         };
 #pragma unroll
         for (int s = 0; s < 16; ++s) sh.frag_load(HS_DZ7 * SLOT_BYTES, s, ah[s], al[s]);
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 6), PhDsig{}, to_regs(bh, bl), no_store);   // W7^T -> dz6
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 5), PhDsig{}, to_regs(ah, al), no_store);   // W6^T -> dz5
+        // (adjoint mode: every dz_l also goes to the stash as an fp32 tile, slot HS_DZ + l)
+        auto to_regs_t = [&](h8(&oh)[16], h8(&ol)[16], int tile_slot) {
+            return [&oh, &ol, tile_slot, &sh, &park](auto T, EpiState& st, const auto&) {
+                constexpr int t = decltype(T)::value;
+                asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                oh[2 * t] = st.hi[0];
+                ol[2 * t] = st.lo[0];
+                oh[2 * t + 1] = st.hi[1];
+                ol[2 * t + 1] = st.lo[1];
+                park(oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
+                if constexpr (ADJ) sh.tile_store(tile_slot, t, st.vec());
+                return NoData{};
+            };
+        };
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 6), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 6), no_store);   // W7^T -> dz6
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 5), PhDsig{}, to_regs_t(ah, al, HS_DZ + 5), no_store);   // W6^T -> dz5
         run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 4), PhDsig{},                               // W5^T -> dz4 (kept)
                                          [&](auto T, EpiState& st, const auto&) {
                                              constexpr int t = decltype(T)::value;
@@ -545,13 +677,14 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                                              bh[2 * t + 1] = st.hi[1];
                                              bl[2 * t + 1] = st.lo[1];
                                              stash_frags(HS_DZ4)(T, Frags{{st.hi[0], st.hi[1]}, {st.lo[0], st.lo[1]}});
+                                             if constexpr (ADJ) sh.tile_store(HS_DZ + 4, t, st.vec());
                                              return NoData{};
                                          },
                                          no_store);
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 3), PhDsig{}, to_regs(ah, al), no_store);   // W4h^T -> dz3
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 2), PhDsig{}, to_regs(bh, bl), no_store);   // W3^T -> dz2
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 1), PhDsig{}, to_regs(ah, al), no_store);   // W2^T -> dz1
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 0), PhDsig{}, to_regs(bh, bl), no_store);   // W1^T -> dz0
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 3), PhDsig{}, to_regs_t(ah, al, HS_DZ + 3), no_store);   // W4h^T -> dz3
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 2), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 2), no_store);   // W3^T -> dz2
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 1), PhDsig{}, to_regs_t(ah, al, HS_DZ + 1), no_store);   // W2^T -> dz1
+        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 0), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 0), no_store);   // W1^T -> dz0
 
         if ((HN_DBG(a) >> 8) == 7) return;   // phase timing aid
         // ---- d sdf / d features contracted with the encoding Jacobian, bone by bone: first W0^T dz0 (dz0 is in
@@ -614,9 +747,26 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 #pragma unroll
                         for (int jj = 0; jj < 8; ++jj) own[s][jj] = unsplit(fh[jj], fl[jj]);
                     }
-                    float Sv = 0.f, Sr[3] = {0.f, 0.f, 0.f};
-                    bone_jacobian(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn, kk, h, Sv, Sr);
-                    to_p(Sv, Sr, bn, b, g);
+                    if constexpr (ADJ) {
+                        // the same contraction through the h-weighted sums, which the adjoint's second-order term needs
+                        // again (unscaled: G carries BWD_SCALE)
+                        BoneSums S;
+                        bone_sums<true>(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn.hh, h, S);
+                        float Sv = fmaf(kk, S.T0, S.T1[0]);
+                        float Sr[3] = {S.T1[1], S.T1[2], S.T1[3]};
+                        to_p(Sv, Sr, bn, b, g);
+                        sums_reduce(S, true);
+                        sh.f32_store(TS + (9 * b) * 256, S.T0 * BWD_INV);
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            sh.f32_store(TS + (9 * b + 1 + q4) * 256, S.T1[q4] * BWD_INV);
+                            sh.f32_store(TS + (9 * b + 5 + q4) * 256, S.T2[q4] * BWD_INV);
+                        }
+                    } else {
+                        float Sv = 0.f, Sr[3] = {0.f, 0.f, 0.f};
+                        bone_jacobian(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn, kk, h, Sv, Sr);
+                        to_p(Sv, Sr, bn, b, g);
+                    }
                 }
                 b = nb;
             }
@@ -644,6 +794,11 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     float Sv = Gv * own * kk;
                     float Sr[3] = {0.f, h ? 0.f : Gv * bn.hh, h ? Gv * bn.hh : 0.f};
                     to_p(Sv, Sr, bn, b, g);
+                    if constexpr (ADJ) {   // the leftover pair's share of the bone's sums: T0, T1[r_1], T1[r_2]
+                        sh.f32_store(TS + (9 * b) * 256, sh.f32_load(TS + (9 * b) * 256) + half_sum(Gv * own) * BWD_INV);
+                        sh.f32_store(TS + (9 * b + 3) * 256, sh.f32_load(TS + (9 * b + 3) * 256) + half_sum(Sr[1]) * BWD_INV);
+                        sh.f32_store(TS + (9 * b + 4) * 256, sh.f32_load(TS + (9 * b + 4) * 256) + half_sum(Sr[2]) * BWD_INV);
+                    }
                 }
             });
         }
@@ -690,30 +845,34 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     for (int i = 0; i < 16; ++i) c1[4 * blk + ti][i] += bias[i];
                 });
             });
-            block_epilogue(I8t{}, c1, c2, PhRelu{}, to_regs(bh, bl));
+            block_epilogue(I8t{}, c1, c2, PhRelu{}, to_regs_t(bh, bl, HS_C + 0));
         }
-        auto relu_to = [&](h8(&oh)[16], h8(&ol)[16]) { return to_regs(oh, ol); };
-        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhRelu{}, relu_to(ah, al), no_store);   // colour lin1
-        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhRelu{}, relu_to(bh, bl), no_store);   // colour lin2
+        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhRelu{}, to_regs_t(ah, al, HS_C + 1), no_store);   // colour lin1
+        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhRelu{}, to_regs_t(bh, bl, HS_C + 2), no_store);   // colour lin2
         float rgb[3] = {0.f, 0.f, 0.f};
         struct W3 {
             f32x16 w[3];
         };
         run_layer<8, 16, 1, true, false>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
-            ws, HB_HID, more ? HB_BONE : 0, bh, bl, lane, h,
+            ws, HB_HID, ADJ ? HB_W4ROWS : (more ? HB_BONE : 0), bh, bl, lane, h,
             [&](auto, const char* tail) { return W3{{tail_tile(tail, 1, h), tail_tile(tail, 2, h), tail_tile(tail, 3, h)}}; },
             PhRelu{},
-            [&](auto, EpiState& st, const W3& w) {
+            [&](auto T, EpiState& st, const W3& w) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) rgb[c] = fmaf(w.w[c][i], st.v[i], rgb[c]);
                 asm volatile("" : "+v"(rgb[0]), "+v"(rgb[1]), "+v"(rgb[2]));
+                if constexpr (ADJ) sh.tile_store(HS_C + 3, decltype(T)::value, st.vec());
                 return NoData{};
             },
             no_store);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_fast(half_sum(rgb[c]) + a.c_blast[c]);
+        if constexpr (ADJ) {
+#include "hn_field2_hand_adj.inl"
+            continue;
+        }
         if (valid && h == 0) {
             a.sdf[n] = sdf;
             a.grad[3 * n] = g[0];
@@ -733,6 +892,22 @@ static int hand2_grid(int n_pts, int n_cus) {
     return n_tiles < n_cus ? n_tiles : n_cus;
 }
 
+static void hand2_common_args(Hand2Args& a, const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose,
+                              int n_frames, int pts_per_frame, void* workspace) {
+    a.pts = pts;
+    a.bt_inv = bt_inv;
+    a.T_pose = T_pose;
+    a.n_pts = n_pts;
+    a.pts_per_frame = pts_per_frame;
+    a.n_frames = n_frames;
+    a.b8 = f->sdf_b8;
+    for (int c = 0; c < 3; ++c) a.c_blast[c] = f->col_blast[c];
+    a.scratch = reinterpret_cast<float4*>(workspace);
+    a.dbg = 0;
+    a.cull = f->cull_far_field;
+}
+
+#ifndef HN_HAND_ADJ_TU   // this translation unit: the evaluation kernels (MODE 0, 1); hn_field2_hand_adj.hip: MODE 2
 size_t field2_hand_workspace_bytes(int n_pts, int n_cus) {
     return (size_t)hand2_grid(n_pts, n_cus) * WG_WAVES * HAND2_SLOTS * SLOT_F4 * sizeof(float4);
 }
@@ -743,34 +918,24 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
     if (n_pts <= 0) return HN_OK;
     HN_REQUIRE(bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1,
                "hand field needs bt_inv / T_pose and frame sizes");
-    Hand2Args a;
-    a.pts = pts;
-    a.bt_inv = bt_inv;
-    a.T_pose = T_pose;
-    a.n_pts = n_pts;
-    a.pts_per_frame = pts_per_frame;
-    a.n_frames = n_frames;
+    Hand2Args a{};
+    hand2_common_args(a, f, pts, n_pts, bt_inv, T_pose, n_frames, pts_per_frame, workspace);
     a.blob = reinterpret_cast<const char*>(full ? f->v2_full : f->v2_sdf);
     a.blob_bytes = full ? f->v2_full_bytes : f->v2_sdf_bytes;
     if (a.blob == nullptr) {
         set_error("field was not created with HN_PREC_F16X3");
         return HN_EINVAL;
     }
-    a.b8 = f->sdf_b8;
-    for (int c = 0; c < 3; ++c) a.c_blast[c] = f->col_blast[c];
     a.sdf = sdf;
     a.grad = grad;
     a.rgb = rgb;
     a.feat = feat;
-    a.scratch = reinterpret_cast<float4*>(workspace);
-    a.dbg = 0;
 #ifdef HN_DEBUG_HOOKS
     {
         const char* e = getenv("HN_DBG");
         a.dbg = e ? atoi(e) : 0;
     }
 #endif
-    a.cull = f->cull_far_field;
     int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = hand2_grid(n_pts, n_cus);
@@ -780,15 +945,52 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
         return HN_ENOMEM;
     }
     static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};   // devices on which the LDS size attribute is set
-    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<true>), (int)HAND2_LDS, &lds_full));
-    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<false>), (int)HAND2_LDS, &lds_sdf));
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<1>), (int)HAND2_LDS, &lds_full));
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<0>), (int)HAND2_LDS, &lds_sdf));
     if (full)
-        hipLaunchKernelGGL(k_field2_hand<true>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
+        hipLaunchKernelGGL(k_field2_hand<1>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
     else
-        hipLaunchKernelGGL(k_field2_hand<false>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
+        hipLaunchKernelGGL(k_field2_hand<0>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
+#else
+size_t field2_hand_adj_workspace_bytes(int n_pts, int n_cus) {
+    return (size_t)hand2_grid(n_pts, n_cus) * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
+}
+
+// hn_field_eval_bwd for an HN_PREC_F16X3 hand field: one persistent launch (evaluation + adjoint per sample tile).
+// g_bt_inv / g_T_pose are accumulated into (the caller zeroes them).
+int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
+                           int pts_per_frame, const float* g_sdf, const float* g_grad, const float* g_rgb, float* g_pts,
+                           float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (n_pts <= 0) return HN_OK;
+    HN_REQUIRE(f->v2_adj != nullptr, "field has no adjoint program");
+    Hand2Args a{};
+    hand2_common_args(a, f, pts, n_pts, bt_inv, T_pose, n_frames, pts_per_frame, workspace);
+    a.blob = reinterpret_cast<const char*>(f->v2_adj);
+    a.blob_bytes = f->v2_adj_bytes;
+    a.g_sdf = g_sdf;
+    a.g_grad = g_grad;
+    a.g_rgb = g_rgb;
+    a.g_pts = g_pts;
+    a.g_bt_inv = g_bt_inv;
+    a.g_T_pose = g_T_pose;
+    int n_cus = device_cus();
+    if (n_cus <= 0) n_cus = 256;
+    const int grid = hand2_grid(n_pts, n_cus);
+    const size_t need = (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
+    if (workspace == nullptr || workspace_bytes < need) {
+        set_error("adjoint workspace too small: %zu < %zu", workspace_bytes, need);
+        return HN_ENOMEM;
+    }
+    static std::atomic<uint64_t> lds_adj{0};
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<2>), (int)HAND2_LDS, &lds_adj));
+    hipLaunchKernelGGL(k_field2_hand<2>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+#endif
 
 }  // namespace v2
 }  // namespace hn

@@ -1,0 +1,474 @@
+// Body of k_field2_hand<2> after the forward pass of a sample tile: the adjoint of the evaluation
+// (oracle/field_bwd.py steps 3b-6), included inside the kernel's tile loop so that it shares the forward pass's
+// helpers (feature_pass, load_bone, block_epilogue, coords ...).  What it reads from the wave's stash -- the tape --
+// was written by the forward pass in this mode: a1..a8, dz0..dz7, c1..c4, the per-bone sums of d sdf / d features,
+// the feature fragments.
+//
+//   colour network backward      cb_l = relu'(c_l) * (C_{l+1}^T cb_{l+1});  C0^T cb1 -> fb | gb | X-adjoint (per bone)
+//   forward-direction sweep      GXb = J gb;  dzb_l = W_l (sigma'_{l-1} dzb_{l-1}) [+ W4x GXb];  w_l = sigma''_l u_l dzb_l
+//   second reverse sweep         zb_l = sigma'_l ab_l + w_l;  ab_{l-1} = W_l^T zb_l;  X-adjoint += W0^T zb0 + W4x^T zb4
+//   input map, bone by bone      qbar_b = d/dq (X-adjoint . features) + Hessian-vector term;  g_pts += R_b^T qbar_b;
+//                                g_bt_inv[b] += qbar_b (x) [p, 1] + d/dq(GX) (x) gb;  g_T_pose[b] -= qbar_b
+//
+// Every adjoint quantity is linear in the upstream gradients; they are scaled per sample by a power of two kappa
+// (largest seed in [1, 2)) so that the fp16 hi/lo fragments keep their 22 bits at any loss scale; 1 / kappa (exact)
+// comes back at the outputs.
+{
+    struct Act2 {
+        f32x16 v;   // stashed activation a_{l+1}: sigma'(z_l) = 1 - exp(-100 a)
+        f32x16 x;   // 100 dz_l (forward-direction sweep) or w_l (second reverse sweep)
+    };
+    // ---- seeds
+    float gs = a.g_sdf[nn], gg[3], gr[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gg[c] = a.g_grad[3 * nn + c];
+        gr[c] = a.g_rgb[3 * nn + c];
+    }
+    if (!valid) {   // lanes beyond the end shadow the last sample: they must not contribute
+        gs = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gg[c] = gr[c] = 0.f;
+    }
+    float kappa = 1.f, inv_kappa = 1.f;
+    {
+        float m = fabsf(gs);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) m = fmaxf(m, fmaxf(fabsf(gg[c]), fabsf(gr[c])));
+        const unsigned e = (__builtin_bit_cast(unsigned, m) >> 23) & 0xffu;   // m in [2^(e-127), 2^(e-126))
+        if (e >= 1u && e <= 253u) {
+            kappa = __builtin_bit_cast(float, (254u - e) << 23);
+            inv_kappa = __builtin_bit_cast(float, e << 23);
+        }
+    }
+    const float gsk = gs * kappa;
+    float xb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xb[c] = kappa * gr[c] * rgb[c] * (1.f - rgb[c]);
+
+    auto mask_of = [&](int c_slot) {
+        return [&sh, c_slot](auto T, const char*) { return Act{sh.tile_load(c_slot, decltype(T)::value)}; };
+    };
+    auto pose = [&](int b, int i) { return uni ? rd<true>(Mu + 16 * b, i) : rd<false>(M + 16 * b, i); };
+
+    // ---- colour lin4^T and the mask of c4: cb4 = (c4 > 0) * (W_c4^T xb)
+    {
+        const char* buf = ws.template acquire<0>();
+        ws.begin(HB_BWD);
+        ws.pieces_all();
+        static_for<8>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            const f32x16 c4 = sh.tile_load(HS_C + 3, t);
+            const f32x16 w0 = tail_tile(buf, t, h), w1 = tail_tile(buf + TAIL_BYTES, t, h), w2 = tail_tile(buf + 2 * TAIL_BYTES, t, h);
+            f32x16 v;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = c4[i] > 0.f ? fmaf(w0[i], xb[0], fmaf(w1[i], xb[1], w2[i] * xb[2])) : 0.f;
+            split_tile(v, ah[2 * t], al[2 * t], ah[2 * t + 1], al[2 * t + 1]);
+        });
+    }
+    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, mask_of(HS_C + 2), PhMask{}, to_regs(bh, bl), no_store);   // C3^T -> cb3
+    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, mask_of(HS_C + 1), PhMask{}, to_regs(ah, al), no_store);   // C2^T -> cb2
+    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, mask_of(HS_C + 0), PhMask{}, to_regs(bh, bl), no_store);   // C1^T -> cb1
+    // ---- colour lin0^T, feature-vector rows -> fb (fragments, kept in the HS_FVEC slot for the W8 product)
+    run_layer<8, 16, 1, false, true>(
+        ws, HB_BWD, HB_BWD, bh, bl, lane, h, no_pre, PhIdentity{},
+        [&](auto T, EpiState& st, const auto&) {
+            constexpr int t = decltype(T)::value;
+            sh.frag_store(HS_FVEC * SLOT_BYTES, 2 * t, st.hi[0], st.lo[0]);
+            sh.frag_store(HS_FVEC * SLOT_BYTES, 2 * t + 1, st.hi[1], st.lo[1]);
+            return NoData{};
+        },
+        no_store);
+    // ---- colour lin0^T, enc(g) slots (one tile) -> gb = g_grad + J_enc^T (.)
+    float gb[3] = {0.f, 0.f, 0.f};
+    {
+        const char* buf = ws.template acquire<0>();
+        ws.begin(HB_BWD);
+        f32x16 m1 = zero16(), m2 = zero16();
+        mma_tile<16, 0, true>(ws, buf, bh, bl, m1, m2, lane);
+        const f32x16 Mg = combine(m1, m2);
+        float f[2][8];
+        encode_v4h(g, h, f);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float fr = (float)(1 << (jj & 3));
+            gb[jj >> 2] = fmaf(Mg[jj], (h ? -fr : fr) * other_half(f[0][jj], h), gb[jj >> 2]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float fr = (float)(1 << jj);
+            gb[2] = fmaf(Mg[8 + jj], (h ? -fr : fr) * other_half(f[1][jj], h), gb[2]);
+        }
+        gb[0] += h ? 0.f : Mg[12];
+        gb[2] += h ? Mg[12] : 0.f;
+        gb[1] += h ? 0.f : Mg[13];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gb[c] = fmaf(kappa, gg[c], half_sum(gb[c]));
+    }
+    // the rows of an X-space adjoint that belong to the leftover block: 2 tiles; register 8 (u & 1) + jj of tile u >> 1
+    // <-> bone 8 u + jj.  Parked per bone (one float per lane) for the bone loop that follows.
+    auto park_leftover = [&](const f32x16& La, const f32x16& Lb) {
+        static_for<N_BONES>([&](auto B_) {
+            constexpr int b = decltype(B_)::value;
+            sh.f32_store(LEFTX + b * 256, b < 16 ? La[b] : Lb[b - 16]);
+        });
+    };
+    // this lane's share of the leftover pair (r_1 | r_2) h of bone b in the sums of a row G
+    auto add_leftover = [&](BoneSums& S, const Bone2& bn, int b) {
+        const float Gl = sh.f32_load(LEFTX + b * 256);
+        S.T0 = fmaf(Gl, (h ? bn.r[2] : bn.r[1]) * bn.hh, S.T0);
+        S.T1[2] += h ? 0.f : Gl * bn.hh;
+        S.T1[3] += h ? Gl * bn.hh : 0.f;
+    };
+    // own[s][jj]: this lane's stored features of the bone staged in LDS
+    auto staged_features = [&](float(&own)[4][8]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const h8 fh = *reinterpret_cast<const h8*>(stage + (2 * s) * 1024 + lane * 16);
+            const h8 fl = *reinterpret_cast<const h8*>(stage + (2 * s + 1) * 1024 + lane * 16);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) own[s][jj] = unsplit(fh[jj], fl[jj]);
+        }
+    };
+    auto stage_bone = [&](int b) {   // stash -> LDS by DMA; lands under the MFMAs that follow, the next acquire covers it
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sh.rsrc, (lds_void_t*)(stage + i * 1024), 16, lane_x16(),
+                                                     FEAT + (4 * b + (i >> 1)) * KS_BYTES + (i & 1) * 1024, 0, STASH_AUX);
+    };
+
+    // ---- colour lin0^T over the feature rows (pass A of the input map): leftover rows first, then bone by bone
+    //      (2 chunks each); per bone the colour network's share of qbar goes to the stash
+    {
+        f32x16 L1[2], L2[2];
+        static_for<2>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            const char* buf = ws.template acquire<0>();
+            ws.begin(HB_BWD);
+            L1[u] = zero16();
+            L2[u] = zero16();
+            mma_tile<16, 0, true>(ws, buf, bh, bl, L1[u], L2[u], lane);
+        });
+        park_leftover(combine(L1[0], L2[0]), combine(L1[1], L2[1]));
+        const int jbase = ws.goff - HB_BWD;   // stream offset of bone 0's first chunk (in flight)
+        unsigned rem = nzw & ~1u;
+        int b = 0;
+#pragma unroll 1
+        while (b < N_BONES) {
+            const int nb = rem ? __builtin_ctz(rem) : N_BONES;
+            rem &= rem - 1u;
+            f32x16 G1[2], G2[2];
+            const bool live = (nz >> b) & 1u;
+            static_for<2>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                const char* buf = ws.template acquire<0>();
+                if constexpr (u == 1) ws.goff = jbase + nb * (2 * HB_BWD);
+                ws.begin((u == 1 && nb == N_BONES) ? HB_BONE : HB_BWD);   // after the last bone: lin0 of the forward-direction sweep
+                if (u == 0 && live) stage_bone(b);
+                G1[u] = zero16();
+                G2[u] = zero16();
+                mma_tile<16, 0, true>(ws, buf, bh, bl, G1[u], G2[u], lane);
+            });
+            if (live) {
+                // the staged features were requested before tile 0's MFMAs; the acquire of tile 1 waited for them
+                const Bone2 bn = coords(b);
+                const float kk = -TAU2 * (1.f - bn.hh);
+                float own[4][8];
+                staged_features(own);
+                BoneSums S;
+                bone_sums<false>(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn.hh, h, S);
+                add_leftover(S, bn, b);
+                sums_reduce(S, false);
+                float dq[3];
+                dq_from_sums(S, bn, kk, dq);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sh.f32_store(QA + (3 * b + c) * 256, dq[c]);
+            }
+            b = nb;
+        }
+    }
+
+    // ---- J gb as fragments (the layout of the features): d(phi h)/dq . (R_b gb) per slot
+    {
+#pragma unroll 1
+        for (int b = 0; b < N_BONES; ++b) {
+            float left = 0.f;
+            if ((nz >> b) & 1u) {
+                const Bone2 bn = coords(b);
+                const float kk = -TAU2 * (1.f - bn.hh);
+                float w[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) w[i] = pose(b, 4 * i) * gb[0] + pose(b, 4 * i + 1) * gb[1] + pose(b, 4 * i + 2) * gb[2];
+                const float rw = bn.r[0] * w[0] + bn.r[1] * w[1] + bn.r[2] * w[2];
+                const float dy[4] = {rw, (w[0] - bn.r[0] * rw) / bn.v, (w[1] - bn.r[1] * rw) / bn.v, (w[2] - bn.r[2] * rw) / bn.v};
+                const float kr = kk * rw;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    h8 fh, fl;
+                    sh.frag_load(FEAT, 4 * b + s, fh, fl);
+                    float jg[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const float own = unsplit(fh[jj], fl[jj]);
+                        if (s == 3 && jj == 7) {
+                            jg[jj] = fmaf(bn.hh, h ? dy[1] : dy[0], own * kr);
+                        } else {
+                            const float fr = (float)(1 << slot_freq(s, jj));
+                            jg[jj] = fmaf((h ? -fr : fr) * other_half(own, h), dy[slot_var(s, jj)], own * kr);
+                        }
+                    }
+                    split8(jg, fh, fl);
+                    sh.frag_store(GXB, 4 * b + s, fh, fl);
+                }
+                left = fmaf(bn.hh, h ? dy[3] : dy[2], (h ? bn.r[2] : bn.r[1]) * bn.hh * kr);
+            }
+            sh.f32_store(LEFT2 + b * 256, left);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            float f[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) f[jj] = (8 * u + jj < N_BONES) ? sh.f32_load(LEFT2 + (8 * u + jj) * 256) : 0.f;
+            h8 fh, fl;
+            split8(f, fh, fl);
+            sh.frag_store(GXB, FEAT_BLOCKS + u, fh, fl);
+        }
+    }
+
+    // ---- forward-direction sweep
+    auto pre4 = [&](int act_slot, int dz_slot) {
+        return [&sh, act_slot, dz_slot](auto T, const char*) {
+            constexpr int t = decltype(T)::value;
+            Act2 o{sh.tile_load(act_slot, t), sh.tile_load(dz_slot, t)};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o.x[i] *= 100.f * BWD_INV;
+            return o;
+        };
+    };
+    auto fin4 = [&](h8(&oh)[16], h8(&ol)[16], int w_slot) {
+        return [&oh, &ol, w_slot, &sh, &park](auto T, EpiState& st, const auto&) {
+            constexpr int t = decltype(T)::value;
+            asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+            oh[2 * t] = st.hi[0];
+            ol[2 * t] = st.lo[0];
+            oh[2 * t + 1] = st.hi[1];
+            ol[2 * t + 1] = st.lo[1];
+            park(oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
+            sh.tile_store(w_slot, t, st.wvec());
+            return NoData{};
+        };
+    };
+    // epilogue of a finished block with per-tile side data (block_epilogue with a `pre`)
+    auto block_epilogue_pd = [&](auto& c1, auto& c2, auto&& ph, auto&& pre, auto&& fin) {
+        static_for<8>([&](auto TI) {
+            constexpr int ti = decltype(TI)::value;
+            EpiState st;
+            arm(st);
+            st.c1 = c1[ti];
+            st.c2 = c2[ti];
+            const Act2 pd = pre(TI, (const char*)nullptr);
+            Epi<true, std::remove_reference_t<decltype(ph)>, Act2> epi{st, ph, pd};
+            epi.run_all();
+            split_finish<true>(st);
+            fin(TI, st, pd);
+        });
+    };
+    feat_base = GXB;
+    {   // lin0: J gb -> dzb0
+        f32x16 c1[8], c2[8];
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) {
+            c1[ti] = zero16();
+            c2[ti] = zero16();
+        }
+        feature_pass(I2{}, BFalse{}, c1, c2, HB_LEFT, HB_HID);
+        block_epilogue_pd(c1, c2, PhFwdDir{}, pre4(HS_A1 + 0, HS_DZ + 0), fin4(ah, al, HS_DZ + 0));
+    }
+    run_layer<8, 16, 1, false, true>(ws, HB_HID, HB_HID, ah, al, lane, h, pre4(HS_A1 + 1, HS_DZ + 1), PhFwdDir{}, fin4(bh, bl, HS_DZ + 1), no_store);   // lin1
+    run_layer<8, 16, 1, false, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, pre4(HS_A1 + 2, HS_DZ + 2), PhFwdDir{}, fin4(ah, al, HS_DZ + 2), no_store);   // lin2
+    run_layer<8, 16, 1, false, true>(ws, HB_HID, HB_HID, ah, al, lane, h, pre4(HS_A1 + 3, HS_DZ + 3), PhFwdDir{}, fin4(bh, bl, HS_DZ + 3), no_store);   // lin3
+    {   // lin4 = [v3 | J gb] / sqrt2
+        f32x16 c1[8], c2[8];
+        static_for<8>([&](auto TI) {
+            constexpr int ti = decltype(TI)::value;
+            const char* buf = ws.template acquire<0>();
+            ws.begin(ti < 7 ? HB_HID : HB_BONE);
+            c1[ti] = zero16();
+            c2[ti] = zero16();
+            mma_tile<16, 0, true>(ws, buf, bh, bl, c1[ti], c2[ti], lane);
+        });
+        feature_pass(I2{}, BFalse{}, c1, c2, HB_LEFT, HB_HID);
+        block_epilogue_pd(c1, c2, PhFwdDir{}, pre4(HS_A1 + 4, HS_DZ + 4), fin4(ah, al, HS_DZ + 4));
+    }
+    feat_base = FEAT;
+    run_layer<8, 16, 1, false, true>(ws, HB_HID, HB_HID, ah, al, lane, h, pre4(HS_A1 + 5, HS_DZ + 5), PhFwdDir{}, fin4(bh, bl, HS_DZ + 5), no_store);   // lin5
+    run_layer<8, 16, 1, false, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, pre4(HS_A1 + 6, HS_DZ + 6), PhFwdDir{}, fin4(ah, al, HS_DZ + 6), no_store);   // lin6
+    run_layer<8, 16, 1, false, false>(ws, HB_HID, HB_HID, ah, al, lane, h, pre4(HS_A8, HS_DZ + 7), PhFwdDir{},                                       // lin7: only w_7
+                                      [&](auto T, EpiState& st, const auto&) {
+                                          sh.tile_store(HS_DZ + 7, decltype(T)::value, st.wvec());
+                                          return NoData{};
+                                      },
+                                      no_store);
+
+    // ---- second reverse sweep.  ab_7 = W8[1:, :]^T fb + g_sdf W8[0, :];  zb_7 = sigma'_7 ab_7 + w_7
+    auto pre5 = [&](int act_slot, int w_slot) {
+        return [&sh, act_slot, w_slot](auto T, const char*) {
+            constexpr int t = decltype(T)::value;
+            return Act2{sh.tile_load(act_slot, t), sh.tile_load(w_slot, t)};
+        };
+    };
+#pragma unroll
+    for (int s = 0; s < 16; ++s) sh.frag_load(HS_FVEC * SLOT_BYTES, s, bh[s], bl[s]);
+    run_layer<8, 16, 1, false, true>(
+        ws, HB_HID, HB_BWD, bh, bl, lane, h,
+        [&](auto T, const char* tail) {
+            constexpr int t = decltype(T)::value;
+            Act2 o{sh.tile_load(HS_A8, t), sh.tile_load(HS_DZ + 7, t)};
+            const f32x16 w8 = tail_tile(tail, 0, h);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o.x[i] = fmaf(gsk * w8[i], dsoftplus_from_act(o.v[i]), o.x[i]);   // + sigma'_7 g_sdf W8[0, :]
+            return o;
+        },
+        PhRev2{}, to_regs(ah, al), no_store);
+    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, pre5(HS_A1 + 6, HS_DZ + 6), PhRev2{}, to_regs(bh, bl), no_store);   // W7^T -> zb6
+    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, pre5(HS_A1 + 5, HS_DZ + 5), PhRev2{}, to_regs(ah, al), no_store);   // W6^T -> zb5
+    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, pre5(HS_A1 + 4, HS_DZ + 4), PhRev2{},                               // W5^T -> zb4 (kept)
+                                     [&](auto T, EpiState& st, const auto&) {
+                                         constexpr int t = decltype(T)::value;
+                                         asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                                         bh[2 * t] = st.hi[0];
+                                         bl[2 * t] = st.lo[0];
+                                         bh[2 * t + 1] = st.hi[1];
+                                         bl[2 * t + 1] = st.lo[1];
+                                         sh.frag_store(HS_ZB4 * SLOT_BYTES, 2 * t, st.hi[0], st.lo[0]);
+                                         sh.frag_store(HS_ZB4 * SLOT_BYTES, 2 * t + 1, st.hi[1], st.lo[1]);
+                                         return NoData{};
+                                     },
+                                     no_store);
+    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, pre5(HS_A1 + 3, HS_DZ + 3), PhRev2{}, to_regs(ah, al), no_store);   // W4h^T -> zb3
+    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, pre5(HS_A1 + 2, HS_DZ + 2), PhRev2{}, to_regs(bh, bl), no_store);   // W3^T -> zb2
+    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, pre5(HS_A1 + 1, HS_DZ + 1), PhRev2{}, to_regs(ah, al), no_store);   // W2^T -> zb1
+    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, pre5(HS_A1 + 0, HS_DZ + 0), PhRev2{}, to_regs(bh, bl), no_store);   // W1^T -> zb0
+
+    // ---- input map (pass B): X-adjoint rows W0^T zb0 + W4x^T zb4, leftover rows first, then bone by bone; per bone the
+    //      pull, the Hessian-vector term and the pose gradients
+    float gp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) sh.frag_load(HS_ZB4 * SLOT_BYTES, s, ah[s], al[s]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) asm volatile("" : "+a"(bh[s]), "+a"(bl[s]), "+a"(ah[s]), "+a"(al[s]));
+    {
+        f32x16 L1[2], L2[2];
+        static_for<2>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            const char* buf0 = ws.template acquire<0>();
+            ws.begin(HB_BWD);
+            L1[u] = zero16();
+            L2[u] = zero16();
+            mma_tile<16, 0, true>(ws, buf0, bh, bl, L1[u], L2[u], lane);
+            const char* buf4 = ws.template acquire<0>();
+            ws.begin(HB_BWD);
+            mma_tile<16, 0, true>(ws, buf4, ah, al, L1[u], L2[u], lane);
+        });
+        park_leftover(combine(L1[0], L2[0]), combine(L1[1], L2[1]));
+        const int jbase = ws.goff - HB_BWD;   // stream offset of bone 0's first chunk (in flight)
+        unsigned rem = nzw & ~1u;
+        int b = 0;
+#pragma unroll 1
+        while (b < N_BONES) {
+            const int nb = rem ? __builtin_ctz(rem) : N_BONES;
+            rem &= rem - 1u;
+            f32x16 G1[2], G2[2];
+            const bool live = (nz >> b) & 1u;
+            static_for<2>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                const char* buf0 = ws.template acquire<0>();
+                ws.begin(HB_BWD);
+                if (u == 0 && live) stage_bone(b);
+                G1[u] = zero16();
+                G2[u] = zero16();
+                mma_tile<16, 0, true>(ws, buf0, bh, bl, G1[u], G2[u], lane);
+                const char* buf4 = ws.template acquire<0>();
+                if constexpr (u == 1) ws.goff = jbase + nb * (4 * HB_BWD);
+                ws.begin((u == 1 && nb == N_BONES) ? (more ? HB_BONE : 0) : HB_BWD);   // after the last bone: the next tile's first chunk
+                mma_tile<16, 0, true>(ws, buf4, ah, al, G1[u], G2[u], lane);
+            });
+            if (live) {
+                const Bone2 bn = coords(b);
+                const float sg = 1.f - bn.hh;
+                const float kk = -TAU2 * sg;
+                const float k2 = -TAU2 * TAU2 * sg * (2.f * bn.hh - 1.f);
+                float own[4][8];
+                staged_features(own);
+                BoneSums S;
+                bone_sums<false>(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn.hh, h, S);
+                add_leftover(S, bn, b);
+                sums_reduce(S, false);
+                float dqB[3];
+                dq_from_sums(S, bn, kk, dqB);
+                // d sdf / d features of the forward pass (the tape): its own d/dq and its Hessian-vector product along R_b gb
+                BoneSums X;
+                X.T0 = sh.f32_load(TS + (9 * b) * 256);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    X.T1[q4] = sh.f32_load(TS + (9 * b + 1 + q4) * 256);
+                    X.T2[q4] = sh.f32_load(TS + (9 * b + 5 + q4) * 256);
+                }
+                float dqX[3], hv[3], w[3];
+                dq_from_sums(X, bn, kk, dqX);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) w[i] = pose(b, 4 * i) * gb[0] + pose(b, 4 * i + 1) * gb[1] + pose(b, 4 * i + 2) * gb[2];
+                hv_from_sums(X, bn, kk, k2, w, hv);
+                float qbar[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) qbar[c] = (dqB[c] + hv[c] + sh.f32_load(QA + (3 * b + c) * 256)) * inv_kappa;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gp[c] += pose(b, c) * qbar[0] + pose(b, 4 + c) * qbar[1] + pose(b, 8 + c) * qbar[2];
+                if (a.g_bt_inv != nullptr || a.g_T_pose != nullptr) {
+                    // g_bt_inv[b][i][:3] += qbar_i p + dqX_i gb;  [i][3] += qbar_i;  g_T_pose[b][i] -= qbar_i
+                    float vals[12];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) vals[4 * i + c] = fmaf(qbar[i], p[c], dqX[i] * gb[c] * inv_kappa);
+                        vals[4 * i + 3] = qbar[i];
+                    }
+                    const bool mine = valid && h == 0;   // both halves hold the same values: one of them contributes
+                    if (uni) {
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) vals[k] = wave_sum64(mine ? vals[k] : 0.f);
+                        if (lane == 0) {
+                            if (a.g_bt_inv != nullptr) {
+                                float* gm = a.g_bt_inv + ((size_t)frame0 * N_BONES + b) * 16;
+#pragma unroll
+                                for (int k = 0; k < 12; ++k) atomicAdd(gm + k, vals[k]);
+                            }
+                            if (a.g_T_pose != nullptr) {
+                                float* gt = a.g_T_pose + ((size_t)frame0 * N_BONES + b) * 3;
+#pragma unroll
+                                for (int i = 0; i < 3; ++i) atomicAdd(gt + i, -vals[4 * i + 3]);
+                            }
+                        }
+                    } else if (mine) {
+                        if (a.g_bt_inv != nullptr) {
+                            float* gm = a.g_bt_inv + ((size_t)frame * N_BONES + b) * 16;
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) atomicAdd(gm + k, vals[k]);
+                        }
+                        if (a.g_T_pose != nullptr) {
+                            float* gt = a.g_T_pose + ((size_t)frame * N_BONES + b) * 3;
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) atomicAdd(gt + i, -vals[4 * i + 3]);
+                        }
+                    }
+                }
+            }
+            b = nb;
+        }
+    }
+    if (valid && h == 0) {
+        a.g_pts[3 * n] = gp[0];
+        a.g_pts[3 * n + 1] = gp[1];
+        a.g_pts[3 * n + 2] = gp[2];
+    }
+}

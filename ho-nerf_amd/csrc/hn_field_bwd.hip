@@ -23,13 +23,17 @@ size_t field2_obj_adj_workspace_bytes(int n_pts, int n_cus);
 int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int spr, const float* g_sdf,
                           const float* g_grad, const float* g_rgb, float* g_pts, float* g_rays_d, void* workspace,
                           size_t workspace_bytes, hipStream_t stream);
+size_t field2_hand_adj_workspace_bytes(int n_pts, int n_cus);
+int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
+                           int pts_per_frame, const float* g_sdf, const float* g_grad, const float* g_rgb, float* g_pts,
+                           float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes, hipStream_t stream);
 }
 namespace bwd {
 
 // The fused adjoint kernels (hn_field2_*.hip, MODE 2) serve HN_PREC_F16X3 fields; the launch sequence below stays as
 // the HN_PREC_FP32 implementation (an independent second opinion in the tests) and for the sdf-only adjoint.
 static bool fused_adjoint(const hn_field* f, bool sdf_only) {
-    return f->precision == HN_PREC_F16X3 && f->kind == HN_FIELD_OBJ && f->v2_adj != nullptr && !sdf_only;
+    return f->precision == HN_PREC_F16X3 && f->v2_adj != nullptr && !sdf_only;
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -650,7 +654,7 @@ size_t field_bwd_workspace_bytes(const hn_field* f, int n) {
     if (fused_adjoint(f, false)) {
         int cus = device_cus();
         if (cus <= 0) cus = 256;
-        const size_t fused = v2::field2_obj_adj_workspace_bytes(n, cus);
+        const size_t fused = f->kind == HN_FIELD_OBJ ? v2::field2_obj_adj_workspace_bytes(n, cus) : v2::field2_hand_adj_workspace_bytes(n, cus);
         need = fused > need ? fused : need;
     }
     return need;
@@ -669,8 +673,14 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     const bool sdf_only = g_grad == nullptr && g_rgb == nullptr;
     HN_REQUIRE(pts && g_sdf && g_pts && (sdf_only || (g_grad && g_rgb)) && spr >= 1 && n % spr == 0, "bad arguments");
     if (n == 0) return HN_OK;
-    if (fused_adjoint(f, sdf_only))
-        return v2::launch_field2_obj_adj(f, pts, rays_d, n, spr, g_sdf, g_grad, g_rgb, g_pts, g_rays_d, workspace, workspace_bytes, s);
+    if (fused_adjoint(f, sdf_only)) {
+        if (obj)
+            return v2::launch_field2_obj_adj(f, pts, rays_d, n, spr, g_sdf, g_grad, g_rgb, g_pts, g_rays_d, workspace, workspace_bytes, s);
+        // the hand's colour network ignores the view direction (utils/fields.py:222-240): its gradient is exactly 0
+        if (g_rays_d != nullptr) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n / spr) * 3 * sizeof(float), s));
+        return v2::launch_field2_hand_adj(f, pts, n, bt_inv, T_pose, n_frames, pts_per_frame, g_sdf, g_grad, g_rgb, g_pts, g_bt_inv,
+                                          g_T_pose, workspace, workspace_bytes, s);
+    }
     Arena ar{reinterpret_cast<char*>(workspace), 0, workspace_bytes};
     Bufs b;
     layout(f, n, ar, b);

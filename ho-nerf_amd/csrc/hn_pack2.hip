@@ -305,7 +305,7 @@ static int upload(const std::vector<char>& blob, void** dev, size_t* bytes, hipS
     return HN_OK;
 }
 
-void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, bool full);
+void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, int mode);
 
 // w_sdf / w_col: device pointers to the folded matrices (row-major [out][in])
 int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float* const* w_sdf,
@@ -334,8 +334,7 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
         if (f->kind == HN_FIELD_OBJ) {
             build_obj_stream(B, S, C, mode);
         } else {
-            if (mode == 2) continue;   // the hand adjoint program: hn_field2_hand_adj (not built yet -> generic adjoint)
-            build_hand_stream(B, S, C, mode == 1);
+            build_hand_stream(B, S, C, mode);
         }
         void** dst = mode == 0 ? &f->v2_sdf : (mode == 1 ? &f->v2_full : &f->v2_adj);
         size_t* nb = mode == 0 ? &f->v2_sdf_bytes : (mode == 1 ? &f->v2_full_bytes : &f->v2_adj_bytes);
@@ -425,16 +424,33 @@ static void feature_rows_T(Builder& B, const HostMat& M0, const HostMat& M4, flo
     }
 }
 
-// The hand program (contract with k_field2_hand)
-void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, bool full) {
+// the adjoint's order of the same rows: the leftover block first (its per-bone values are parked while the bones are
+// visited), then the bones; one matrix (M4 == nullptr) or the two of feature_rows_T
+static void feature_rows_T_adj(Builder& B, const HostMat& M0, const HostMat* M4, float scale4, int col_off4) {
+    for (int k = 0; k <= N_BONES; ++k) {
+        const int b = k == 0 ? N_BONES : k - 1;
+        std::vector<int> sl = b < N_BONES ? bone_slots(b) : left_slots();
+        sl.resize(64, -1);
+        for (int u = 0; u < 2; ++u) {
+            one_slot_tile_T(B, M0, 1.f, sl, 0, u);
+            if (M4 != nullptr) one_slot_tile_T(B, *M4, scale4, sl, col_off4, u);
+        }
+    }
+}
+
+// hand sdf network, forward-oriented chunks lin0..lin7 (the forward pass; without the bias tails of lin0: the adjoint's
+// forward-direction sweep)
+static void hand_sdf_forward_chunks(Builder& B, const HostMat* S, bool lin0_bias_tails) {
     const float rs2 = (float)(1.0 / sqrt(2.0));
     const std::vector<int> hs = hid_slots();
     // lin0: two passes of 4 output tiles over the feature space; the leftover chunk's tail holds the 4 biases
-    {
+    if (lin0_bias_tails) {
         float tail0[256] = {0.f}, tail1[256] = {0.f};
         tail_biases4(tail0, S[0], 0);
         tail_biases4(tail1, S[0], 1);
         feature_block(B, S[0], 1.f, 0, tail0, tail1);
+    } else {
+        feature_block(B, S[0], 1.f, 0, nullptr, nullptr);
     }
     fwd_tiles(B, S[1], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
     fwd_tiles(B, S[2], 1.f, 8, 256, 0, hs, 16, nullptr, 0);
@@ -450,7 +466,15 @@ void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, bool full
         const float* extra[1] = {w8.data()};
         fwd_tiles(B, S[7], 1.f, 8, 256, 0, hs, 16, extra, 1);
     }
-    if (!full) return;
+}
+
+// The hand program (contract with k_field2_hand).  mode 0: sdf only; 1: full evaluation; 2: full evaluation followed by
+// its adjoint (hn_field2_hand_adj.inl)
+void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, int mode) {
+    const float rs2 = (float)(1.0 / sqrt(2.0));
+    const std::vector<int> hs = hid_slots();
+    hand_sdf_forward_chunks(B, S, true);
+    if (mode == 0) return;
     fwd_tiles(B, S[8], 1.f, 8, 256, 1, hs, 16, nullptr, 0);
     for (int l = 7; l >= 1; --l) bwd_tiles(B, S[l], l == 4 ? rs2 : 1.f, 8, 256, 0, 256, 16);
     feature_rows_T(B, S[0], S[4], rs2, H);
@@ -484,6 +508,27 @@ void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, bool full
         const float* extra[3] = {w0.data(), w1.data(), w2.data()};
         fwd_tiles(B, C[3], 1.f, 8, 256, 0, hs, 16, extra, 3);
     }
+    if (mode < 2) return;
+    // ---- adjoint ------------------------------------------------------------------------------------------------
+    for (int c = 0; c < 3; ++c) {   // the three rows of colour lin4, one tail-format KiB each
+        float tail[256];
+        for (int t = 0; t < 8; ++t) {
+            float v[32];
+            for (int i = 0; i < 32; ++i) v[i] = C[4].at(c, 32 * t + i);
+            tail_put(tail, t, v);
+        }
+        B.raw(tail, TAIL_BYTES);
+    }
+    bwd_tiles(B, C[3], 1.f, 8, 256, 0, 256, 16);
+    bwd_tiles(B, C[2], 1.f, 8, 256, 0, 256, 16);
+    bwd_tiles(B, C[1], 1.f, 8, 256, 0, 256, 16);
+    bwd_tiles(B, C[0], 1.f, 8, 256, HAND_IN, 256, 16);          // C0^T, feature-vector rows -> fb
+    slot_rows_T(B, C[0], 1.f, vec4_slots(), HAND_IN + H);      // C0^T, enc(g) rows (one tile) -> gb
+    feature_rows_T_adj(B, C[0], nullptr, 1.f, 0);              // C0^T, feature rows (leftover first)
+    hand_sdf_forward_chunks(B, S, false);                      // forward-direction sweep (no biases)
+    w8_T_tiles(B, S[8]);
+    for (int l = 7; l >= 1; --l) bwd_tiles(B, S[l], l == 4 ? rs2 : 1.f, 8, 256, 0, 256, 16);
+    feature_rows_T_adj(B, S[0], &S[4], rs2, H);                // W0^T zb0 + W4x^T zb4 (leftover first)
 }
 
 }  // namespace v2
