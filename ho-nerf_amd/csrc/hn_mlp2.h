@@ -287,10 +287,14 @@ __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 
     constexpr int STRIDE = NQ >= 27 ? 3 : (NQ >= 18 ? 2 : 1);
     static_assert(!FETCH || NQ >= MAX_PIECES_PER_WAVE, "not enough slots for the DMA pieces");
     h8 ah[3], al[3];
+    // this lane's LDS read address is formed per tile (see lane_x16): kept across the kernel it gets spilled, and its
+    // reload in front of every ds_read carries an s_waitcnt vmcnt(0) that also drains the weight stream's DMA
+    (void)lane;
+    const char* const lblk = blk + lane_x16();
     auto load = [&](auto S) {
         constexpr int s = decltype(S)::value;
-        ah[s % 3] = *reinterpret_cast<const h8*>(blk + s * KS_BYTES + lane * 16);
-        al[s % 3] = *reinterpret_cast<const h8*>(blk + s * KS_BYTES + 1024 + lane * 16);
+        ah[s % 3] = *reinterpret_cast<const h8*>(lblk + s * KS_BYTES);
+        al[s % 3] = *reinterpret_cast<const h8*>(lblk + s * KS_BYTES + 1024);
     };
     auto slot = [&](auto Q_) {
         constexpr int Q = decltype(Q_)::value;
@@ -333,10 +337,12 @@ __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8
     constexpr int STRIDE = NQ >= 27 ? 3 : (NQ >= 18 ? 2 : 1);
     static_assert(NQ >= MAX_PIECES_PER_WAVE, "not enough slots for the DMA pieces");
     h8 ah[3], al[3];
+    (void)lane;
+    const char* const lbuf = buf + lane_x16();   // see mma_tile
     auto load = [&](auto S) {
         constexpr int s = decltype(S)::value;
-        ah[s % 3] = *reinterpret_cast<const h8*>(buf + s * KS_BYTES + lane * 16);
-        al[s % 3] = *reinterpret_cast<const h8*>(buf + s * KS_BYTES + 1024 + lane * 16);
+        ah[s % 3] = *reinterpret_cast<const h8*>(lbuf + s * KS_BYTES);
+        al[s % 3] = *reinterpret_cast<const h8*>(lbuf + s * KS_BYTES + 1024);
     };
     auto slot = [&](auto Q_) {
         constexpr int Q = decltype(Q_)::value;

@@ -1,0 +1,24 @@
+"""K optimisation steps of fitting_single (fit type 12, 196 rays x 192 depths, both fields) for rocprofv3:
+   rocprofv3 --kernel-trace --stats -d gpurun_out/prof_fit -- python3 tools/fit_profile.py [steps]"""
+import os
+import sys
+import time
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import torch
+import bench
+from honerf_amd import fitting as F
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device('cuda')
+ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3')
+opt = torch.optim.Adam(chain.param_groups(video=False))
+for i in range(3):
+    F.fit_step(ren, views[i % 8], chain, opt, bench.NEAR, bench.FAR, '12')
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    F.fit_step(ren, views[i % 8], chain, opt, bench.NEAR, bench.FAR, '12')
+torch.cuda.synchronize()
+print('ms per step: %.3f' % ((time.perf_counter() - t0) / steps * 1e3))
