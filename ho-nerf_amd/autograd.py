@@ -8,8 +8,9 @@ backward is the launch sequence
 
     composite2_bwd -> alpha_bwd (x2) -> field_eval_bwd (x2) -> sample_points_bwd (x2) -> obj_local_bwd
 
-on the depths the forward produced; the per-field forward values it needs (rgb, alpha) are recomputed with the same
-kernels the forward used.  Nothing here computes on the host; torch only owns the buffers.
+on the depths the forward produced -- one C-ABI call, hn_render_dual_bwd, which runs the hand and the object branch
+side by side on two streams; the per-field forward values it needs (rgb, alpha) are the ones the forward pass left
+in the render workspace.  Nothing here computes on the host; torch only owns the buffers.
 """
 import ctypes
 
@@ -54,8 +55,7 @@ class DualRenderFn(torch.autograd.Function):
         L = _lib
         lib = L.load()
         ren = ctx.renderer
-        rays_o, rays_d, bt, tp, Ro, To, z, sv_sdf_h, sv_sdf_o, sv_grad_h, sv_grad_o, sv_rgb_h, sv_rgb_o, sv_al_h, sv_al_o = ctx.saved_tensors
-        reuse = getattr(ren, '_backward_depths', None) is None     # the saved values belong to the forward's depths
+        rays_o, rays_d, bt, tp, Ro, To, z, sdf_h, sdf_o, grad_h, grad_o, rgb_h, rgb_o, alpha_h, alpha_o = ctx.saved_tensors
         hand, obj = ren.fields()
         F, P = rays_o.shape[0], rays_o.shape[1]
         N, S = F * P, z.shape[-1]
@@ -68,85 +68,51 @@ class DualRenderFn(torch.autograd.Function):
             tp = tp.expand(F, 21, 3).contiguous()
         Ro, To = L.f32(Ro).reshape(F, 3, 3), L.f32(To).reshape(F, 3)
         z = L.f32(z).reshape(N, S)
-        if getattr(ren, '_backward_depths', None) is not None:   # test hook: differentiate on given depths
-            z = L.f32(ren._backward_depths).reshape(N, S)
         sample_dist = float(torch.tensor((ctx.far - ctx.near) / ren.n_samples, dtype=torch.float32))
+        sdf_h, sdf_o = L.f32(sdf_h).reshape(n), L.f32(sdf_o).reshape(n)
+        grad_h, grad_o = L.f32(grad_h).reshape(n, 3), L.f32(grad_o).reshape(n, 3)
+        if getattr(ren, '_backward_depths', None) is not None:
+            # test hook: differentiate on GIVEN depths -- the per-sample values are evaluated there first
+            z = L.f32(ren._backward_depths).reshape(N, S)
 
-        def field_forward(field, o, d, frames):
-            pts, dists = _empty(n, 3, dev=dev), _empty(n, dev=dev)
-            L.check(lib.hn_sample_points(L.ptr(o), L.ptr(d), L.ptr(z), N, S, 1, sample_dist, L.ptr(pts), L.ptr(dists), st), 'hn_sample_points')
-            sdf, grad, rgb = _empty(n, dev=dev), _empty(n, 3, dev=dev), _empty(n, 3, dev=dev)
-            wsb = lib.hn_field_workspace_bytes(field.handle, n)
-            ws = ren._ws_bwd.get(max(wsb, 16), dev)
-            L.check(lib.hn_field_eval(field.handle, L.ptr(pts), L.ptr(d), n, S, L.ptr(bt) if frames else None,
-                                      L.ptr(tp) if frames else None, F if frames else 1, P * S if frames else n, L.ptr(sdf),
-                                      L.ptr(grad), L.ptr(rgb), None, L.ptr(ws), wsb, st), 'hn_field_eval')
-            alpha = _empty(n, dev=dev)
-            L.check(lib.hn_alpha(L.ptr(sdf), L.ptr(grad), L.ptr(d), L.ptr(dists), n, S, float(field.inv_s), L.ptr(alpha), None, st), 'hn_alpha')
-            return pts, dists, sdf, grad, rgb, alpha
+            def field_forward(field, o, d, frames):
+                pts, dists = _empty(n, 3, dev=dev), _empty(n, dev=dev)
+                L.check(lib.hn_sample_points(L.ptr(o), L.ptr(d), L.ptr(z), N, S, 1, sample_dist, L.ptr(pts), L.ptr(dists), st), 'hn_sample_points')
+                sdf, grad, rgb = _empty(n, dev=dev), _empty(n, 3, dev=dev), _empty(n, 3, dev=dev)
+                wsb = lib.hn_field_workspace_bytes(field.handle, n)
+                ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+                L.check(lib.hn_field_eval(field.handle, L.ptr(pts), L.ptr(d), n, S, L.ptr(bt) if frames else None,
+                                          L.ptr(tp) if frames else None, F if frames else 1, P * S if frames else n, L.ptr(sdf),
+                                          L.ptr(grad), L.ptr(rgb), None, L.ptr(ws), wsb, st), 'hn_field_eval')
+                alpha = _empty(n, dev=dev)
+                L.check(lib.hn_alpha(L.ptr(sdf), L.ptr(grad), L.ptr(d), L.ptr(dists), n, S, float(field.inv_s), L.ptr(alpha), None, st), 'hn_alpha')
+                return sdf, grad, rgb, alpha
 
-        # forward values of the two branches on the forward's depths
-        o_l, d_l = _empty(N, 3, dev=dev), _empty(N, 3, dev=dev)
-        L.check(lib.hn_obj_local_fwd(L.ptr(ro), L.ptr(rd), L.ptr(Ro), L.ptr(To), F, P, L.ptr(o_l), L.ptr(d_l), st), 'hn_obj_local_fwd')
-        if reuse:      # only the sample positions are recomputed; field values come from the forward pass
-            def positions(o, d):
-                pts, dd = _empty(n, 3, dev=dev), _empty(n, dev=dev)
-                L.check(lib.hn_sample_points(L.ptr(o), L.ptr(d), L.ptr(z), N, S, 1, sample_dist, L.ptr(pts), L.ptr(dd), st), 'hn_sample_points')
-                return pts, dd
-            pts_h, dists = positions(ro, rd)
-            pts_o, _ = positions(o_l, d_l)
-            sdf_h, grad_h, rgb_h, alpha_h = sv_sdf_h.reshape(n), sv_grad_h.reshape(n, 3), sv_rgb_h, sv_al_h
-            sdf_o, grad_o, rgb_o, alpha_o = sv_sdf_o.reshape(n), sv_grad_o.reshape(n, 3), sv_rgb_o, sv_al_o
-        else:
-            pts_h, dists, sdf_h, grad_h, rgb_h, alpha_h = field_forward(hand, ro, rd, True)
-            pts_o, _, sdf_o, grad_o, rgb_o, alpha_o = field_forward(obj, o_l, d_l, False)
-
-        # compositing
+            o_l, d_l = _empty(N, 3, dev=dev), _empty(N, 3, dev=dev)
+            L.check(lib.hn_obj_local_fwd(L.ptr(ro), L.ptr(rd), L.ptr(Ro), L.ptr(To), F, P, L.ptr(o_l), L.ptr(d_l), st), 'hn_obj_local_fwd')
+            sdf_h, grad_h, rgb_h, alpha_h = field_forward(hand, ro, rd, True)
+            sdf_o, grad_o, rgb_o, alpha_o = field_forward(obj, o_l, d_l, False)
+        opt = lambda g, shape: None if g is None else L.f32(g).reshape(shape)
         g_color = L.f32(g_color).reshape(N, 3) if g_color is not None else torch.zeros(N, 3, device=dev)
-        g_wsum = L.f32(g_wsum).reshape(N) if g_wsum is not None else None
-        g_ah, g_ao = _empty(n, dev=dev), _empty(n, dev=dev)
-        g_rgbh, g_rgbo = _empty(n, 3, dev=dev), _empty(n, 3, dev=dev)
-        L.check(lib.hn_composite2_bwd(L.ptr(alpha_h), L.ptr(rgb_h), L.ptr(alpha_o), L.ptr(rgb_o), L.ptr(g_color), L.ptr(g_wsum), N, S,
-                                      L.ptr(g_ah), L.ptr(g_rgbh), L.ptr(g_ao), L.ptr(g_rgbo), st), 'hn_composite2_bwd')
-
-        def branch(field, pts, d, sdf, grad, g_alpha, g_rgb, g_sdf_out, g_grad_out, g_eik, frames):
-            gs, gg, gd = _empty(n, dev=dev), _empty(n, 3, dev=dev), _empty(N, 3, dev=dev)
-            L.check(lib.hn_alpha_bwd(L.ptr(sdf), L.ptr(grad), L.ptr(d), L.ptr(dists), L.ptr(g_alpha), None, n, S, float(field.inv_s),
-                                     L.ptr(gs), L.ptr(gg), L.ptr(gd), st), 'hn_alpha_bwd')
-            if g_sdf_out is not None:                       # the per-sample sdf feeds the contact / penetration losses
-                gs += L.f32(g_sdf_out).reshape(n)
-            if g_grad_out is not None:
-                gg += L.f32(g_grad_out).reshape(n, 3)
-            if g_eik is not None:   # gradient_error = mean((|g| - 1)^2); d|g|/dg = 0 at g = 0, as torch's norm backward
-                nrm = grad.norm(dim=-1, keepdim=True)
-                gg += (2.0 / n) * g_eik.to(torch.float32) * (nrm - 1.0) * grad / nrm.clamp_min(1e-30)
-            g_pts, g_dir = _empty(n, 3, dev=dev), _empty(N, 3, dev=dev)
-            g_bt = torch.zeros(F, 21, 4, 4, device=dev) if frames else None
-            g_tp = torch.zeros(F, 21, 3, device=dev) if frames else None
-            need = lib.hn_field_bwd_workspace_bytes(field.handle, n)
-            ws = ren._ws_bwd.get(need, dev)      # grow-only, shared by both fields and re-used across steps
-            L.check(lib.hn_field_eval_bwd(field.handle, L.ptr(pts), L.ptr(d), n, S, L.ptr(bt) if frames else None,
-                                          L.ptr(tp) if frames else None, F if frames else 1, P * S if frames else n, L.ptr(gs),
-                                          L.ptr(gg), L.ptr(g_rgb), L.ptr(g_pts), L.ptr(g_dir), L.ptr(g_bt), L.ptr(g_tp), L.ptr(ws),
-                                          need, st), 'hn_field_eval_bwd')
-            g_o, g_d = _empty(N, 3, dev=dev), _empty(N, 3, dev=dev)
-            L.check(lib.hn_sample_points_bwd(L.ptr(z), L.ptr(g_pts), N, S, 1, sample_dist, L.ptr(g_o), L.ptr(g_d), st), 'hn_sample_points_bwd')
-            return g_o, g_d + gd + g_dir, g_bt, g_tp
-
-        ge = g_gerr if g_gerr is not None else (None, None)
-        go_h, gd_h, g_bt, g_tp = branch(hand, pts_h, rd, sdf_h, grad_h, g_ah, g_rgbh, g_sdf_h, g_grad_h, ge[0], True)
-        go_l, gd_l, _, _ = branch(obj, pts_o, d_l, sdf_o, grad_o, g_ao, g_rgbo, g_sdf_o, g_grad_o, ge[1], False)
+        ups = (opt(g_wsum, (N,)), opt(g_sdf_h, (n,)), opt(g_sdf_o, (n,)), opt(g_grad_h, (n, 3)), opt(g_grad_o, (n, 3)), opt(g_gerr, (2,)))
         g_ro, g_rd = _empty(N, 3, dev=dev), _empty(N, 3, dev=dev)
+        g_bt, g_tp = _empty(F, 21, 4, 4, dev=dev), _empty(F, 21, 3, dev=dev)
         g_Ro, g_To = _empty(F, 3, 3, dev=dev), _empty(F, 3, dev=dev)
-        L.check(lib.hn_obj_local_bwd(L.ptr(ro), L.ptr(rd), L.ptr(Ro), L.ptr(To), L.ptr(go_l.contiguous()), L.ptr(gd_l.contiguous()), F, P,
-                                     L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_Ro), L.ptr(g_To), st), 'hn_obj_local_bwd')
-        g_rays_o = (go_h + g_ro).reshape(rays_o.shape)
-        g_rays_d = (gd_h + g_rd).reshape(rays_d.shape)
+        need = lib.hn_render_dual_bwd_workspace_bytes(hand.handle, obj.handle, N, S)
+        ws = ren._ws_bwd.get(need, dev)          # grow-only, re-used across steps
+        L.check(lib.hn_render_dual_bwd(hand.handle, obj.handle, L.ptr(ro), L.ptr(rd), F, P, S, sample_dist, L.ptr(bt), L.ptr(tp), L.ptr(Ro),
+                                       L.ptr(To), L.ptr(z), L.ptr(sdf_h), L.ptr(grad_h), L.ptr(rgb_h), L.ptr(alpha_h),
+                                       L.ptr(sdf_o), L.ptr(grad_o), L.ptr(rgb_o), L.ptr(alpha_o), L.ptr(g_color),
+                                       L.ptr(ups[0]), L.ptr(ups[1]), L.ptr(ups[2]), L.ptr(ups[3]), L.ptr(ups[4]), L.ptr(ups[5]),
+                                       L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_bt), L.ptr(g_tp), L.ptr(g_Ro), L.ptr(g_To), L.ptr(ws), need, st),
+                'hn_render_dual_bwd')
+
         def like(g, ref):          # an input shared by all frames (e.g. T_pose [21,3]) receives the sum over frames
             return g.reshape(ref.shape) if g.numel() == ref.numel() else g.reshape(F, *ref.shape[-(ref.dim()):]).sum(0).reshape(ref.shape)
 
         sv = ctx.saved_tensors
-        return (g_rays_o, g_rays_d, like(g_bt, sv[2]), like(g_tp, sv[3]), like(g_Ro, sv[4]), like(g_To, sv[5]), None, None, None, None)
+        return (g_ro.reshape(rays_o.shape), g_rd.reshape(rays_d.shape), like(g_bt, sv[2]), like(g_tp, sv[3]), like(g_Ro, sv[4]),
+                like(g_To, sv[5]), None, None, None, None)
 
 
 class HandSdfFn(torch.autograd.Function):

@@ -57,6 +57,8 @@ int launch_field2_hand(const hn_field*, const float*, int, const float*, const f
                        float*, void*, size_t, bool, hipStream_t);
 }
 
+constexpr int MAX_DEVICES = 64;
+
 __global__ void k_scale(float* v, int n, float s) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] *= s;
@@ -67,6 +69,82 @@ __global__ void k_copy_cols(const float* __restrict__ src, int n_rows, int n_src
     if (i >= n_rows * n_src) return;
     const int r = i / n_src, c = i % n_src;
     dst[(size_t)r * n_dst + dst_off + c] = src[i];
+}
+
+// g_sdf / g_grad of one field entering its adjoint: what alpha_bwd produced, plus the caller's direct gradients on the
+// per-sample sdf / gradient outputs (the contact / penetration losses read sdf_*; fitting_single.py:268-281), plus the
+// eikonal term gradient_error = mean((|g| - 1)^2) (d|g|/dg = 0 at g = 0, as torch's norm backward)
+__global__ void k_upstream(float* __restrict__ gs, float* __restrict__ gg, const float* __restrict__ g_sdf_out,
+                           const float* __restrict__ g_grad_out, const float* __restrict__ grad, const float* __restrict__ g_eik,
+                           int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (g_sdf_out != nullptr) gs[i] += g_sdf_out[i];
+    float a[3] = {0.f, 0.f, 0.f};
+    if (g_grad_out != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[c] = g_grad_out[3 * (size_t)i + c];
+    }
+    if (g_eik != nullptr) {
+        const float gx = grad[3 * (size_t)i], gy = grad[3 * (size_t)i + 1], gz = grad[3 * (size_t)i + 2];
+        const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+        const float k = (2.f / (float)n) * g_eik[0] * (nrm - 1.f) / fmaxf(nrm, 1e-30f);
+        a[0] += k * gx;
+        a[1] += k * gy;
+        a[2] += k * gz;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gg[3 * (size_t)i + c] += a[c];
+}
+// out = a + b (+ c) (+ d)
+__global__ void k_add4(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                       const float* __restrict__ d, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = a[i] + b[i];
+    if (c != nullptr) v += c[i];
+    if (d != nullptr) v += d[i];
+    out[i] = v;
+}
+
+// ---- a second stream per device: the hand and the object track of the two-field renders are independent until
+// their results meet (the sorted depths; the compositing), and each of them alone leaves most CUs idle at the fitting
+// sizes (294 sample tiles on 256 CUs = two rounds, the second 15 % full).  Fork / join are event waits on the device:
+// nothing here blocks the host.  Created once per device on first use (the only allocation outside field_create).
+struct SideStream {
+    hipStream_t s2 = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static SideStream g_side[MAX_DEVICES];
+static std::atomic<int> g_side_state[MAX_DEVICES];   // 0 unknown, 1 being created, 2 ready, 3 unavailable
+static SideStream* side_stream() {
+    const int dev = current_device();
+    if (dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    int st = g_side_state[dev].load(std::memory_order_acquire);
+    if (st == 0) {
+        int expect = 0;
+        if (g_side_state[dev].compare_exchange_strong(expect, 1)) {
+            SideStream& x = g_side[dev];
+            const bool ok = hipStreamCreateWithFlags(&x.s2, hipStreamNonBlocking) == hipSuccess &&
+                            hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+                            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+            g_side_state[dev].store(ok ? 2 : 3, std::memory_order_release);
+        }
+        while ((st = g_side_state[dev].load(std::memory_order_acquire)) == 1) {
+        }
+    }
+    return st == 2 ? &g_side[dev] : nullptr;
+}
+// s2 continues from where s is now / s continues once s2 has caught up
+static int fork_to(SideStream* x, hipStream_t s) {
+    HN_CHECK_HIP(hipEventRecord(x->fork, s));
+    HN_CHECK_HIP(hipStreamWaitEvent(x->s2, x->fork, 0));
+    return HN_OK;
+}
+static int join_from(SideStream* x, hipStream_t s) {
+    HN_CHECK_HIP(hipEventRecord(x->join, x->s2));
+    HN_CHECK_HIP(hipStreamWaitEvent(s, x->join, 0));
+    return HN_OK;
 }
 
 // bump allocator over the caller's workspace
@@ -93,7 +171,6 @@ struct Arena {
     float* f(size_t n) { return reinterpret_cast<float*>(take(n * sizeof(float))); }
 };
 
-constexpr int MAX_DEVICES = 64;
 static std::atomic<int> g_cus[MAX_DEVICES];   // 0 = not queried yet
 int current_device() {
     int dev = 0;
@@ -262,6 +339,8 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     float* z = ar.f(N);
     float* pts = ar.f(N * 3);
     float* dists = ar.f(N);
+    float* pts_o = ar.f(N * 3);      // the object track runs on its own stream: its own point / dist / field buffers
+    float* dists_o = ar.f(N);
     const size_t off_rgb_h = ar.used;
     float* rgb_h = ar.f(N * 3);
     const size_t off_rgb_o = ar.used;
@@ -271,8 +350,8 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     const size_t off_al_o = ar.used;
     float* al_o = ar.f(N);
     const size_t fws_h = field_ws(hand, (int)N), fws_o = field_ws(obj, (int)N);
-    const size_t fws_bytes = fws_h > fws_o ? fws_h : fws_o;
-    void* fws = ar.take(fws_bytes);
+    void* fwsh = ar.take(fws_h);
+    void* fwso = ar.take(fws_o);
     if (aux_offsets != nullptr) {   // where the final evaluation leaves rgb / alpha of both fields (bytes into the workspace)
         aux_offsets[0] = off_rgb_h;
         aux_offsets[1] = off_rgb_o;
@@ -290,6 +369,8 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     if (n_rays == 0) return HN_OK;
     const float sample_dist = (float)((far - near) / (double)n_samples);
     const int quirk = (batch_quirk && n_frames > 1) ? rpf : 0;
+    SideStream* side = side_stream();
+    const hipStream_t so = side != nullptr ? side->s2 : s;   // the object track's stream (s itself if no second stream)
     HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_obj, d_obj, s));
     HN_TRY(coarse_z(t_rand, n_rays, n_samples, (float)near, (float)(far - near), sample_dist, th.z_a, s));
     // shared coarse depths: start the concatenated list with them
@@ -299,43 +380,51 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     const float* z_final = zcat;
     if (n_importance > 0) {
         HN_CHECK_HIP(hipMemcpyAsync(to.z_a, th.z_a, (size_t)n_rays * n_samples * sizeof(float), hipMemcpyDeviceToDevice, s));
-        int k = n_samples;
-        HN_TRY(sample_points(rays_o, rays_d, th.z_a, n_rays, k, 0, 0.f, th.pts, nullptr, s));
-        HN_TRY(field_sdf(hand, th.pts, n_rays * k, bt_inv, T_pose, n_frames, rpf * k, th.sdf_a, fws, fws_bytes, s));
-        HN_TRY(sample_points(o_obj, d_obj, to.z_a, n_rays, k, 0, 0.f, to.pts, nullptr, s));
-        HN_TRY(field_sdf(obj, to.pts, n_rays * k, nullptr, nullptr, 1, n_rays * k, to.sdf_a, fws, fws_bytes, s));
-        for (int i = 0; i < steps; ++i) {
-            for (int which = 0; which < 2; ++which) {
-                Track& t = which == 0 ? th : to;
-                const hn_field* f = which == 0 ? hand : obj;
-                const float* ro = which == 0 ? rays_o : o_obj;
-                const float* rd = which == 0 ? rays_d : d_obj;
-                HN_TRY(upsample(t.z_a, t.sdf_a, n_rays, k, n_new, (float)(64 << i), t.z_new, nullptr, s));
-                hipLaunchKernelGGL(k_copy_cols, dim3((n_rays * n_new + 255) / 256), dim3(256), 0, s, t.z_new, n_rays,
+        if (side != nullptr) HN_TRY(fork_to(side, s));
+        // the two importance-sampling tracks (utils/renderer.py:463-496) are independent: hand on s, object on so
+        for (int which = 0; which < 2; ++which) {
+            Track& t = which == 0 ? th : to;
+            const hn_field* f = which == 0 ? hand : obj;
+            const float* ro = which == 0 ? rays_o : o_obj;
+            const float* rd = which == 0 ? rays_d : d_obj;
+            const hipStream_t st = which == 0 ? s : so;
+            void* fws = which == 0 ? fwsh : fwso;
+            const size_t fwb = which == 0 ? fws_h : fws_o;
+            const int nf = which == 0 ? n_frames : 1;
+            int k = n_samples;
+            HN_TRY(sample_points(ro, rd, t.z_a, n_rays, k, 0, 0.f, t.pts, nullptr, st));
+            HN_TRY(field_sdf(f, t.pts, n_rays * k, bt_inv, T_pose, nf, which == 0 ? rpf * k : n_rays * k, t.sdf_a, fws, fwb, st));
+            for (int i = 0; i < steps; ++i) {
+                HN_TRY(upsample(t.z_a, t.sdf_a, n_rays, k, n_new, (float)(64 << i), t.z_new, nullptr, st));
+                hipLaunchKernelGGL(k_copy_cols, dim3((n_rays * n_new + 255) / 256), dim3(256), 0, st, t.z_new, n_rays,
                                    n_new, zcat, S, n_samples + (2 * i + which) * n_new);
                 HN_LAUNCH_CHECK();
                 if (i + 1 < steps) {
-                    HN_TRY(sample_points(ro, rd, t.z_new, n_rays, n_new, 0, 0.f, t.pts, nullptr, s));
-                    HN_TRY(field_sdf(f, t.pts, n_rays * n_new, bt_inv, T_pose, n_frames, rpf * n_new, t.sdf_new, fws, fws_bytes, s));
-                    HN_TRY(merge(t.z_a, t.z_new, t.sdf_a, t.sdf_new, n_rays, k, n_new, quirk, t.z_b, t.sdf_b, nullptr, s));
+                    HN_TRY(sample_points(ro, rd, t.z_new, n_rays, n_new, 0, 0.f, t.pts, nullptr, st));
+                    HN_TRY(field_sdf(f, t.pts, n_rays * n_new, bt_inv, T_pose, nf, which == 0 ? rpf * n_new : n_rays * n_new, t.sdf_new,
+                                     fws, fwb, st));
+                    HN_TRY(merge(t.z_a, t.z_new, t.sdf_a, t.sdf_new, n_rays, k, n_new, quirk, t.z_b, t.sdf_b, nullptr, st));
                     float* tmp = t.z_a; t.z_a = t.z_b; t.z_b = tmp;
                     tmp = t.sdf_a; t.sdf_a = t.sdf_b; t.sdf_b = tmp;
                 }
+                k += n_new;
             }
-            k += n_new;
         }
+        if (side != nullptr) HN_TRY(join_from(side, s));
         HN_TRY(sort_rows(zcat, n_rays, S, z, s));
         z_final = z;
     }
-    // both fields at the shared sorted depths (utils/renderer.py:500-510)
+    // both fields at the shared sorted depths (utils/renderer.py:500-510), side by side
+    if (side != nullptr) HN_TRY(fork_to(side, s));
     HN_TRY(sample_points(rays_o, rays_d, z_final, n_rays, S, 1, sample_dist, pts, dists, s));
     HN_TRY(field_eval(hand, pts, rays_d, (int)N, S, bt_inv, T_pose, n_frames, rpf * S, sdf_hand, grad_hand, rgb_h, nullptr,
-                      fws, fws_bytes, s));
+                      fwsh, fws_h, s));
     HN_TRY(alpha(sdf_hand, grad_hand, rays_d, dists, (int)N, S, hand->inv_s, al_h, nullptr, s));
-    HN_TRY(sample_points(o_obj, d_obj, z_final, n_rays, S, 1, sample_dist, pts, dists, s));
-    HN_TRY(field_eval(obj, pts, d_obj, (int)N, S, nullptr, nullptr, 1, (int)N, sdf_obj, grad_obj, rgb_o, nullptr, fws,
-                      fws_bytes, s));
-    HN_TRY(alpha(sdf_obj, grad_obj, d_obj, dists, (int)N, S, obj->inv_s, al_o, nullptr, s));
+    HN_TRY(sample_points(o_obj, d_obj, z_final, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
+    HN_TRY(field_eval(obj, pts_o, d_obj, (int)N, S, nullptr, nullptr, 1, (int)N, sdf_obj, grad_obj, rgb_o, nullptr, fwso,
+                      fws_o, so));
+    HN_TRY(alpha(sdf_obj, grad_obj, d_obj, dists_o, (int)N, S, obj->inv_s, al_o, nullptr, so));
+    if (side != nullptr) HN_TRY(join_from(side, s));
     HN_CHECK_HIP(hipMemsetAsync(gradient_error, 0, 2 * sizeof(float), s));
     HN_TRY(composite2(al_h, rgb_h, grad_hand, al_o, rgb_o, grad_obj, n_rays, S, color, weight_sum, nullptr, nullptr,
                       gradient_error, s));
@@ -345,17 +434,89 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     return HN_OK;
 }
 
-}  // namespace hn
-
-using namespace hn;
-
-namespace hn {
 namespace bwd {
 size_t field_bwd_workspace_bytes(const hn_field* f, int n);
 int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
                    size_t workspace_bytes, hipStream_t s);
+}
+
+// Backward pass of the two-field render (what loss.backward() runs through NeuSRenderer_fitting.render in the fitting
+// loops: fitting_single.py:289-291, fitting_video.py:340-342).  Depths carry no gradient (sampled under no_grad), so it
+// runs through the compositing, the two alpha stages, the two field evaluations (fused adjoint kernels, hand on s and
+// object on the second stream) and the ray transforms.
+static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const float* rays_o, const float* rays_d, int n_frames,
+                                int rpf, int S, float sample_dist, const float* bt_inv, const float* T_pose, const float* Ro,
+                                const float* To, const float* z, const float* sdf_h, const float* grad_h, const float* rgb_h,
+                                const float* alpha_h, const float* sdf_o, const float* grad_o, const float* rgb_o,
+                                const float* alpha_o, const float* g_color, const float* g_wsum, const float* g_sdf_h,
+                                const float* g_sdf_o, const float* g_grad_h, const float* g_grad_o, const float* g_eik,
+                                float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose, float* g_Ro, float* g_To,
+                                void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need) {
+    HN_REQUIRE(hand->kind == HN_FIELD_HAND && obj->kind == HN_FIELD_OBJ, "field kinds (hand, obj) expected");
+    HN_REQUIRE(n_frames >= 1 && rpf >= 0 && S >= 1, "bad sizes");
+    const int n_rays = n_frames * rpf;
+    const size_t N = (size_t)n_rays * S, R3 = (size_t)n_rays * 3;
+    Arena ar(workspace, workspace_bytes);
+    float *o_l = ar.f(R3), *d_l = ar.f(R3);
+    float *g_ah = ar.f(N), *g_ao = ar.f(N), *g_rgbh = ar.f(N * 3), *g_rgbo = ar.f(N * 3);
+    float *pts_h = ar.f(N * 3), *dists_h = ar.f(N), *pts_o = ar.f(N * 3), *dists_o = ar.f(N);
+    float *gs_h = ar.f(N), *gg_h = ar.f(N * 3), *gd_h = ar.f(R3), *gs_o = ar.f(N), *gg_o = ar.f(N * 3), *gd_o = ar.f(R3);
+    float *gp_h = ar.f(N * 3), *gp_o = ar.f(N * 3), *gdir_h = ar.f(R3), *gdir_o = ar.f(R3);
+    float *go_h = ar.f(R3), *gdd_h = ar.f(R3), *go_l = ar.f(R3), *gdd_l = ar.f(R3), *gd_l = ar.f(R3), *g_ro2 = ar.f(R3), *g_rd2 = ar.f(R3);
+    const size_t bws_h = bwd::field_bwd_workspace_bytes(hand, (int)N), bws_o = bwd::field_bwd_workspace_bytes(obj, (int)N);
+    void* bwh = ar.take(bws_h);
+    void* bwo = ar.take(bws_o);
+    if (need != nullptr) {
+        *need = ar.used;
+        return HN_OK;
+    }
+    if (!ar.ok) {
+        set_error("render_dual_bwd workspace too small: %zu bytes given", workspace_bytes);
+        return HN_ENOMEM;
+    }
+    if (n_rays == 0) return HN_OK;
+    HN_REQUIRE(g_color && g_rays_o && g_rays_d && g_bt_inv && g_T_pose && g_Ro && g_To, "null output / upstream gradient");
+    const int n = (int)N;
+    SideStream* side = side_stream();
+    const hipStream_t so = side != nullptr ? side->s2 : s;
+    HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_l, d_l, s));
+    HN_TRY(composite2_bwd(alpha_h, rgb_h, alpha_o, rgb_o, g_color, g_wsum, n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo, s));
+    if (side != nullptr) HN_TRY(fork_to(side, s));
+    // hand branch (s)
+    HN_TRY(sample_points(rays_o, rays_d, z, n_rays, S, 1, sample_dist, pts_h, dists_h, s));
+    HN_TRY(alpha_bwd(sdf_h, grad_h, rays_d, dists_h, g_ah, nullptr, n, S, hand->inv_s, gs_h, gg_h, gd_h, s));
+    hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs_h, gg_h, g_sdf_h, g_grad_h, grad_h, g_eik, n);
+    HN_CHECK_HIP(hipMemsetAsync(g_bt_inv, 0, (size_t)n_frames * 21 * 16 * sizeof(float), s));
+    HN_CHECK_HIP(hipMemsetAsync(g_T_pose, 0, (size_t)n_frames * 21 * 3 * sizeof(float), s));
+    HN_TRY(bwd::field_eval_bwd(hand, pts_h, rays_d, n, S, bt_inv, T_pose, n_frames, rpf * S, gs_h, gg_h, g_rgbh, gp_h, gdir_h, g_bt_inv,
+                               g_T_pose, bwh, bws_h, s));
+    HN_TRY(sample_points_bwd(z, gp_h, n_rays, S, 1, sample_dist, go_h, gdd_h, s));
+    // object branch (so)
+    HN_TRY(sample_points(o_l, d_l, z, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
+    HN_TRY(alpha_bwd(sdf_o, grad_o, d_l, dists_o, g_ao, nullptr, n, S, obj->inv_s, gs_o, gg_o, gd_o, so));
+    hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, so, gs_o, gg_o, g_sdf_o, g_grad_o, grad_o,
+                       g_eik != nullptr ? g_eik + 1 : nullptr, n);
+    HN_TRY(bwd::field_eval_bwd(obj, pts_o, d_l, n, S, nullptr, nullptr, 1, n, gs_o, gg_o, g_rgbo, gp_o, gdir_o, nullptr, nullptr, bwo,
+                               bws_o, so));
+    HN_TRY(sample_points_bwd(z, gp_o, n_rays, S, 1, sample_dist, go_l, gdd_l, so));
+    hipLaunchKernelGGL(k_add4, dim3(((int)R3 + 255) / 256), dim3(256), 0, so, gdd_l, gd_o, gdir_o, (const float*)nullptr, gd_l, (int)R3);
+    HN_TRY(obj_local_bwd(rays_o, rays_d, Ro, To, go_l, gd_l, n_frames, rpf, g_ro2, g_rd2, g_Ro, g_To, so));
+    if (side != nullptr) HN_TRY(join_from(side, s));
+    hipLaunchKernelGGL(k_add4, dim3(((int)R3 + 255) / 256), dim3(256), 0, s, go_h, g_ro2, (const float*)nullptr, (const float*)nullptr,
+                       g_rays_o, (int)R3);
+    hipLaunchKernelGGL(k_add4, dim3(((int)R3 + 255) / 256), dim3(256), 0, s, gdd_h, gd_h, gdir_h, g_rd2, g_rays_d, (int)R3);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+}  // namespace hn
+
+using namespace hn;
+
+namespace hn {
+namespace bwd {
 int hand_features(const float*, int, const float*, const float*, int, int, float*, float*, float*, hipStream_t);
 size_t color_forward_workspace_bytes(const hn_field* f, int n);
 int color_forward(const hn_field*, const float*, const float*, const float*, const float*, int, float*, void*, size_t, hipStream_t);
@@ -539,6 +700,30 @@ size_t hn_render_dual_workspace_bytes(const hn_field* hand, const hn_field* obj,
                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &need) != HN_OK)
         return 0;
     return need;
+}
+size_t hn_render_dual_bwd_workspace_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray) {
+    size_t need = 0;
+    if (hand == nullptr || obj == nullptr) return 0;
+    if (render_dual_bwd_impl(hand, obj, nullptr, nullptr, 1, n_rays, samples_per_ray, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                             &need) != HN_OK)
+        return 0;
+    return need;
+}
+int hn_render_dual_bwd(const hn_field* hand, const hn_field* obj, const float* rays_o, const float* rays_d, int n_frames,
+                       int rays_per_frame, int samples_per_ray, float sample_dist, const float* bt_inv, const float* T_pose,
+                       const float* Ro, const float* To, const float* z_vals, const float* sdf_hand, const float* grad_hand,
+                       const float* rgb_hand, const float* alpha_hand, const float* sdf_obj, const float* grad_obj,
+                       const float* rgb_obj, const float* alpha_obj, const float* g_color, const float* g_weight_sum,
+                       const float* g_sdf_hand, const float* g_sdf_obj, const float* g_grad_hand, const float* g_grad_obj,
+                       const float* g_gradient_error, float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose,
+                       float* g_Ro, float* g_To, void* workspace, size_t workspace_bytes, hn_stream_t stream) {
+    HN_REQUIRE(hand != nullptr && obj != nullptr, "null field");
+    return render_dual_bwd_impl(hand, obj, rays_o, rays_d, n_frames, rays_per_frame, samples_per_ray, sample_dist, bt_inv, T_pose, Ro,
+                                To, z_vals, sdf_hand, grad_hand, rgb_hand, alpha_hand, sdf_obj, grad_obj, rgb_obj, alpha_obj,
+                                g_color, g_weight_sum, g_sdf_hand, g_sdf_obj, g_grad_hand, g_grad_obj, g_gradient_error, g_rays_o,
+                                g_rays_d, g_bt_inv, g_T_pose, g_Ro, g_To, workspace, workspace_bytes, (hipStream_t)stream, nullptr);
 }
 int hn_render_dual_aux_offsets(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples, int n_importance,
                                int up_sample_steps, size_t* offsets4) {

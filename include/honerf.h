@@ -251,7 +251,10 @@ int hn_render_single(const hn_field* f, const float* rays_o, const float* rays_d
                      float* weight_max, float* gradient_error, float* z_vals, void* workspace,
                      size_t workspace_bytes, hn_stream_t stream);
 
-/* NeuSRenderer_fitting.render (utils/renderer.py:434-535; frame-batched:
+/* (The hand and the object track of hn_render_dual are independent until their depths are merged and until the
+ * compositing: they run side by side, the hand's on the given stream, the object's on a library-owned second stream of
+ * the device, forked and joined with events -- the host is never blocked.)
+ * NeuSRenderer_fitting.render (utils/renderer.py:434-535; frame-batched:
  * utils/renderer_batch.py:184-281).  World rays [n_frames*P,3]; Ro, To [n_frames,..];
  * bt_inv [n_frames,21,4,4]; T_pose [n_frames,21,3].  S = n_samples + 2 n_importance.
  * Outputs: color [N,3], weight_sum [N], sdf_hand, sdf_obj [N*S], grad_hand,
@@ -271,6 +274,25 @@ int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_
  * of evaluating both fields again. */
 int hn_render_dual_aux_offsets(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples, int n_importance,
                                int up_sample_steps, size_t* offsets4);
+
+/* Backward pass of hn_render_dual: what loss.backward() runs through NeuSRenderer_fitting.render in the fitting loops
+ * (fitting_single.py:289-291, fitting_video.py:340-342; autograd through utils/renderer.py:434-535).  Depths carry no
+ * gradient (utils/renderer.py:461: sampled under no_grad).  Inputs: the render's inputs, its final depths z_vals
+ * [N,S] and per-sample results (sdf_*, grad_* as returned; rgb_*, alpha_* from hn_render_dual_aux_offsets), and the
+ * upstream gradients of every output: g_color [N,3], g_weight_sum [N] (may be NULL), g_sdf_* [N*S], g_grad_* [N*S,3],
+ * g_gradient_error [2] (hand, obj) -- each may be NULL.  Outputs (overwritten): g_rays_o, g_rays_d [N,3], g_bt_inv
+ * [n_frames,21,4,4], g_T_pose [n_frames,21,3], g_Ro [n_frames,3,3], g_To [n_frames,3].  The hand and the object branch
+ * run side by side on the given stream and on a library-owned second stream of the device (event fork / join; the host
+ * is never blocked). */
+size_t hn_render_dual_bwd_workspace_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray);
+int hn_render_dual_bwd(const hn_field* hand, const hn_field* obj, const float* rays_o, const float* rays_d, int n_frames,
+                       int rays_per_frame, int samples_per_ray, float sample_dist, const float* bt_inv, const float* T_pose,
+                       const float* Ro, const float* To, const float* z_vals, const float* sdf_hand, const float* grad_hand,
+                       const float* rgb_hand, const float* alpha_hand, const float* sdf_obj, const float* grad_obj,
+                       const float* rgb_obj, const float* alpha_obj, const float* g_color, const float* g_weight_sum,
+                       const float* g_sdf_hand, const float* g_sdf_obj, const float* g_grad_hand, const float* g_grad_obj,
+                       const float* g_gradient_error, float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose,
+                       float* g_Ro, float* g_To, void* workspace, size_t workspace_bytes, hn_stream_t stream);
 
 #ifdef __cplusplus
 }
