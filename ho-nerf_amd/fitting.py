@@ -63,15 +63,15 @@ def render_loss_terms(render_out, true_rgb, true_mask, fit_type='1', video=False
     zero = color_loss.new_zeros(())
     terms['contact'], terms['penetration'] = zero, zero
     if video or fit_type in ('12', '123', '1234'):
+        # Same sums as fitting_single.py:268-281, written with masks instead of boolean indexing: indexing makes
+        # tensors of data-dependent size, i.e. a device -> host synchronisation in the middle of every step
         sdf_hand = render_out['sdf_hand'][:, 0]
         sdf_obj = render_out['sdf_obj'][:, 0]
         sdf_abs_sum = sdf_hand.abs() + sdf_obj.abs()
-        contact_id = sdf_abs_sum < 1e-2
-        contact = sdf_abs_sum[contact_id].sum() / (contact_id.float().sum() + 1e-9)
-        inner = sdf_obj < 0
-        hs, os_ = sdf_hand[inner], sdf_obj[inner]
-        pen_id = hs < 0
-        penet = (hs[pen_id].abs() + os_[pen_id].abs()).sum() / (pen_id.float().sum() + 1e-9)
+        contact_id = (sdf_abs_sum < 1e-2).to(sdf_abs_sum.dtype)
+        contact = (sdf_abs_sum * contact_id).sum() / (contact_id.sum() + 1e-9)
+        pen_id = ((sdf_obj < 0) & (sdf_hand < 0)).to(sdf_abs_sum.dtype)
+        penet = (sdf_abs_sum * pen_id).sum() / (pen_id.sum() + 1e-9)
         terms['contact'], terms['penetration'] = contact, penet
         terms['loss'] = terms['loss'] + 30 * contact + 20 * penet
     return terms
