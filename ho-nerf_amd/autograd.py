@@ -30,7 +30,11 @@ class DualRenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, bt_inv, T_pose, Ro, To, renderer, near, far, t_rand):
         o = renderer._render_raw(rays_o.detach(), rays_d.detach(), near, far, bt_inv.detach(), T_pose.detach(), Ro.detach(),
-                                 To.detach(), t_rand)
+                                 To.detach(), t_rand, keep_tape=True)
+        # The tape buffer belongs to the renderer and is overwritten by its next differentiable render: a backward pass
+        # uses it only if it is still this render's (the usual forward -> backward order of a fitting step).
+        renderer._tape_serial = getattr(renderer, '_tape_serial', 0) + 1
+        ctx.tape, ctx.tape_serial = o['tape'], renderer._tape_serial
         ctx.renderer, ctx.near, ctx.far = renderer, float(near), float(far)
         # what the final evaluation left in the render workspace (rgb / alpha of both fields): copied out now, the
         # workspace is re-used by the next render
@@ -71,7 +75,9 @@ class DualRenderFn(torch.autograd.Function):
         sample_dist = float(torch.tensor((ctx.far - ctx.near) / ren.n_samples, dtype=torch.float32))
         sdf_h, sdf_o = L.f32(sdf_h).reshape(n), L.f32(sdf_o).reshape(n)
         grad_h, grad_o = L.f32(grad_h).reshape(n, 3), L.f32(grad_o).reshape(n, 3)
+        tape = ctx.tape if (ctx.tape is not None and ctx.tape_serial == getattr(ren, '_tape_serial', -1)) else None
         if getattr(ren, '_backward_depths', None) is not None:
+            tape = None
             # test hook: differentiate on GIVEN depths -- the per-sample values are evaluated there first
             z = L.f32(ren._backward_depths).reshape(N, S)
 
@@ -104,7 +110,8 @@ class DualRenderFn(torch.autograd.Function):
                                        L.ptr(To), L.ptr(z), L.ptr(sdf_h), L.ptr(grad_h), L.ptr(rgb_h), L.ptr(alpha_h),
                                        L.ptr(sdf_o), L.ptr(grad_o), L.ptr(rgb_o), L.ptr(alpha_o), L.ptr(g_color),
                                        L.ptr(ups[0]), L.ptr(ups[1]), L.ptr(ups[2]), L.ptr(ups[3]), L.ptr(ups[4]), L.ptr(ups[5]),
-                                       L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_bt), L.ptr(g_tp), L.ptr(g_Ro), L.ptr(g_To), L.ptr(ws), need, st),
+                                       L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_bt), L.ptr(g_tp), L.ptr(g_Ro), L.ptr(g_To), L.ptr(ws), need,
+                                       L.ptr(tape), st),
                 'hn_render_dual_bwd')
 
         def like(g, ref):          # an input shared by all frames (e.g. T_pose [21,3]) receives the sum over frames

@@ -51,10 +51,12 @@ int launch_field_hand(const hn_field*, const float*, int, const float*, const fl
 namespace v2 {
 size_t field2_obj_workspace_bytes(int n_pts, int n_cus);
 int launch_field2_obj(const hn_field*, const float*, const float*, int, int, float*, float*, float*, float*, void*, size_t,
-                      bool, hipStream_t);
+                      bool, hipStream_t, void* tape, size_t tape_bytes);
 size_t field2_hand_workspace_bytes(int n_pts, int n_cus);
 int launch_field2_hand(const hn_field*, const float*, int, const float*, const float*, int, int, float*, float*, float*,
-                       float*, void*, size_t, bool, hipStream_t);
+                       float*, void*, size_t, bool, hipStream_t, void* tape, size_t tape_bytes);
+size_t field2_obj_tape_bytes(int n_pts);
+size_t field2_hand_tape_bytes(int n_pts);
 }
 
 constexpr int MAX_DEVICES = 64;
@@ -210,19 +212,24 @@ static size_t field_ws(const hn_field* f, int n_pts) {
 static int field_sdf(const hn_field* f, const float* pts, int n, const float* bt, const float* Tp, int n_frames, int ppf,
                      float* sdf, void* ws, size_t ws_bytes, hipStream_t s) {
     if (f->precision == HN_PREC_F16X3 && f->kind == HN_FIELD_OBJ)
-        return v2::launch_field2_obj(f, pts, nullptr, n, 1, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
+        return v2::launch_field2_obj(f, pts, nullptr, n, 1, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s, nullptr, 0);
     if (f->precision == HN_PREC_F16X3)
-        return v2::launch_field2_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
+        return v2::launch_field2_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s, nullptr, 0);
     if (f->kind == HN_FIELD_OBJ) return launch_field_obj(f, pts, nullptr, n, 1, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
     return launch_field_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, nullptr, nullptr, nullptr, ws, ws_bytes, false, s);
 }
+// bytes of the tape a taped evaluation of n_pts points keeps for its adjoint (0: this field keeps none)
+static size_t field_tape(const hn_field* f, int n_pts) {
+    if (f->precision != HN_PREC_F16X3) return 0;
+    return f->kind == HN_FIELD_OBJ ? v2::field2_obj_tape_bytes(n_pts) : v2::field2_hand_tape_bytes(n_pts);
+}
 static int field_eval(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt,
                       const float* Tp, int n_frames, int ppf, float* sdf, float* grad, float* rgb, float* feat, void* ws,
-                      size_t ws_bytes, hipStream_t s) {
+                      size_t ws_bytes, hipStream_t s, void* tape = nullptr, size_t tape_bytes = 0) {
     if (f->precision == HN_PREC_F16X3 && f->kind == HN_FIELD_OBJ)
-        return v2::launch_field2_obj(f, pts, rays_d, n, spr, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
+        return v2::launch_field2_obj(f, pts, rays_d, n, spr, sdf, grad, rgb, feat, ws, ws_bytes, true, s, tape, tape_bytes);
     if (f->precision == HN_PREC_F16X3)
-        return v2::launch_field2_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
+        return v2::launch_field2_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, grad, rgb, feat, ws, ws_bytes, true, s, tape, tape_bytes);
     if (f->kind == HN_FIELD_OBJ) return launch_field_obj(f, pts, rays_d, n, spr, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
     return launch_field_hand(f, pts, n, bt, Tp, n_frames, ppf, sdf, grad, rgb, feat, ws, ws_bytes, true, s);
 }
@@ -319,7 +326,8 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
                             int n_importance, int steps, const float* bt_inv, const float* T_pose, const float* Ro,
                             const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand,
                             float* sdf_obj, float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals,
-                            void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need, size_t* aux_offsets = nullptr) {
+                            void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need, size_t* aux_offsets = nullptr,
+                            void* tape = nullptr, size_t tape_bytes = 0) {
     HN_REQUIRE(n_samples >= 2 && n_importance >= 0 && n_frames >= 1 && rpf >= 0, "bad sizes");
     HN_REQUIRE(n_importance == 0 || (steps >= 1 && n_importance % steps == 0), "n_importance must divide into steps");
     HN_REQUIRE(hand->kind == HN_FIELD_HAND && obj->kind == HN_FIELD_OBJ, "field kinds (hand, obj) expected");
@@ -414,15 +422,23 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
         HN_TRY(sort_rows(zcat, n_rays, S, z, s));
         z_final = z;
     }
-    // both fields at the shared sorted depths (utils/renderer.py:500-510), side by side
+    // both fields at the shared sorted depths (utils/renderer.py:500-510), side by side.  With a tape buffer the
+    // evaluations keep their tapes ([hand | object]) for hn_render_dual_bwd.
+    const size_t tape_h = field_tape(hand, (int)N), tape_o = field_tape(obj, (int)N);
+    void *tp_h = nullptr, *tp_o = nullptr;
+    if (tape != nullptr) {
+        HN_REQUIRE(tape_bytes >= tape_h + tape_o, "render_dual tape too small: %zu < %zu", tape_bytes, tape_h + tape_o);
+        tp_h = tape_h ? tape : nullptr;
+        tp_o = tape_o ? reinterpret_cast<char*>(tape) + tape_h : nullptr;
+    }
     if (side != nullptr) HN_TRY(fork_to(side, s));
     HN_TRY(sample_points(rays_o, rays_d, z_final, n_rays, S, 1, sample_dist, pts, dists, s));
     HN_TRY(field_eval(hand, pts, rays_d, (int)N, S, bt_inv, T_pose, n_frames, rpf * S, sdf_hand, grad_hand, rgb_h, nullptr,
-                      fwsh, fws_h, s));
+                      fwsh, fws_h, s, tp_h, tape_h));
     HN_TRY(alpha(sdf_hand, grad_hand, rays_d, dists, (int)N, S, hand->inv_s, al_h, nullptr, s));
     HN_TRY(sample_points(o_obj, d_obj, z_final, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
     HN_TRY(field_eval(obj, pts_o, d_obj, (int)N, S, nullptr, nullptr, 1, (int)N, sdf_obj, grad_obj, rgb_o, nullptr, fwso,
-                      fws_o, so));
+                      fws_o, so, tp_o, tape_o));
     HN_TRY(alpha(sdf_obj, grad_obj, d_obj, dists_o, (int)N, S, obj->inv_s, al_o, nullptr, so));
     if (side != nullptr) HN_TRY(join_from(side, s));
     HN_CHECK_HIP(hipMemsetAsync(gradient_error, 0, 2 * sizeof(float), s));
@@ -439,7 +455,7 @@ size_t field_bwd_workspace_bytes(const hn_field* f, int n);
 int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
-                   size_t workspace_bytes, hipStream_t s);
+                   size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb);
 }
 
 // Backward pass of the two-field render (what loss.backward() runs through NeuSRenderer_fitting.render in the fitting
@@ -453,7 +469,7 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
                                 const float* alpha_o, const float* g_color, const float* g_wsum, const float* g_sdf_h,
                                 const float* g_sdf_o, const float* g_grad_h, const float* g_grad_o, const float* g_eik,
                                 float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose, float* g_Ro, float* g_To,
-                                void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need) {
+                                void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need, const void* tape = nullptr) {
     HN_REQUIRE(hand->kind == HN_FIELD_HAND && obj->kind == HN_FIELD_OBJ, "field kinds (hand, obj) expected");
     HN_REQUIRE(n_frames >= 1 && rpf >= 0 && S >= 1, "bad sizes");
     const int n_rays = n_frames * rpf;
@@ -479,6 +495,10 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     if (n_rays == 0) return HN_OK;
     HN_REQUIRE(g_color && g_rays_o && g_rays_d && g_bt_inv && g_T_pose && g_Ro && g_To, "null output / upstream gradient");
     const int n = (int)N;
+    // the tapes the forward pass kept ([hand | object]): the adjoints then run alone, nothing is evaluated again
+    const size_t tape_h = field_tape(hand, n), tape_o = field_tape(obj, n);
+    const void* tp_h = (tape != nullptr && tape_h) ? tape : nullptr;
+    const void* tp_o = (tape != nullptr && tape_o) ? reinterpret_cast<const char*>(tape) + tape_h : nullptr;
     SideStream* side = side_stream();
     const hipStream_t so = side != nullptr ? side->s2 : s;
     HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_l, d_l, s));
@@ -491,7 +511,7 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     HN_CHECK_HIP(hipMemsetAsync(g_bt_inv, 0, (size_t)n_frames * 21 * 16 * sizeof(float), s));
     HN_CHECK_HIP(hipMemsetAsync(g_T_pose, 0, (size_t)n_frames * 21 * 3 * sizeof(float), s));
     HN_TRY(bwd::field_eval_bwd(hand, pts_h, rays_d, n, S, bt_inv, T_pose, n_frames, rpf * S, gs_h, gg_h, g_rgbh, gp_h, gdir_h, g_bt_inv,
-                               g_T_pose, bwh, bws_h, s));
+                               g_T_pose, bwh, bws_h, s, tp_h, grad_h, rgb_h));
     HN_TRY(sample_points_bwd(z, gp_h, n_rays, S, 1, sample_dist, go_h, gdd_h, s));
     // object branch (so)
     HN_TRY(sample_points(o_l, d_l, z, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
@@ -499,7 +519,7 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, so, gs_o, gg_o, g_sdf_o, g_grad_o, grad_o,
                        g_eik != nullptr ? g_eik + 1 : nullptr, n);
     HN_TRY(bwd::field_eval_bwd(obj, pts_o, d_l, n, S, nullptr, nullptr, 1, n, gs_o, gg_o, g_rgbo, gp_o, gdir_o, nullptr, nullptr, bwo,
-                               bws_o, so));
+                               bws_o, so, tp_o, grad_o, rgb_o));
     HN_TRY(sample_points_bwd(z, gp_o, n_rays, S, 1, sample_dist, go_l, gdd_l, so));
     hipLaunchKernelGGL(k_add4, dim3(((int)R3 + 255) / 256), dim3(256), 0, so, gdd_l, gd_o, gdir_o, (const float*)nullptr, gd_l, (int)R3);
     HN_TRY(obj_local_bwd(rays_o, rays_d, Ro, To, go_l, gd_l, n_frames, rpf, g_ro2, g_rd2, g_Ro, g_To, so));
@@ -558,6 +578,7 @@ int hn_field_destroy(hn_field* f) {
     if (f->v2_full != nullptr) (void)hipFree(f->v2_full);
     if (f->v2_sdf != nullptr) (void)hipFree(f->v2_sdf);
     if (f->v2_adj != nullptr) (void)hipFree(f->v2_adj);
+    if (f->v2_adjonly != nullptr) (void)hipFree(f->v2_adjonly);
     if (f->raw != nullptr) (void)hipFree(f->raw);
     delete f;
     return HN_OK;
@@ -572,7 +593,7 @@ int hn_field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, 
                       float* g_T_pose, void* workspace, size_t workspace_bytes, hn_stream_t stream) {
     return hn::bwd::field_eval_bwd(f, pts, rays_d, n_pts, samples_per_ray, bt_inv, T_pose, n_frames, pts_per_frame, g_sdf, g_grad,
                                    g_rgb, g_pts, g_rays_d, g_bt_inv, g_T_pose, workspace, workspace_bytes,
-                                   reinterpret_cast<hipStream_t>(stream));
+                                   reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, nullptr);
 }
 float hn_field_inv_s(const hn_field* f) { return f ? f->inv_s : 0.f; }
 int hn_field_set_culling(hn_field* f, int enabled) {
@@ -718,12 +739,12 @@ int hn_render_dual_bwd(const hn_field* hand, const hn_field* obj, const float* r
                        const float* rgb_obj, const float* alpha_obj, const float* g_color, const float* g_weight_sum,
                        const float* g_sdf_hand, const float* g_sdf_obj, const float* g_grad_hand, const float* g_grad_obj,
                        const float* g_gradient_error, float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose,
-                       float* g_Ro, float* g_To, void* workspace, size_t workspace_bytes, hn_stream_t stream) {
+                       float* g_Ro, float* g_To, void* workspace, size_t workspace_bytes, const void* tape, hn_stream_t stream) {
     HN_REQUIRE(hand != nullptr && obj != nullptr, "null field");
     return render_dual_bwd_impl(hand, obj, rays_o, rays_d, n_frames, rays_per_frame, samples_per_ray, sample_dist, bt_inv, T_pose, Ro,
                                 To, z_vals, sdf_hand, grad_hand, rgb_hand, alpha_hand, sdf_obj, grad_obj, rgb_obj, alpha_obj,
                                 g_color, g_weight_sum, g_sdf_hand, g_sdf_obj, g_grad_hand, g_grad_obj, g_gradient_error, g_rays_o,
-                                g_rays_d, g_bt_inv, g_T_pose, g_Ro, g_To, workspace, workspace_bytes, (hipStream_t)stream, nullptr);
+                                g_rays_d, g_bt_inv, g_T_pose, g_Ro, g_To, workspace, workspace_bytes, (hipStream_t)stream, nullptr, tape);
 }
 int hn_render_dual_aux_offsets(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples, int n_importance,
                                int up_sample_steps, size_t* offsets4) {
@@ -738,12 +759,16 @@ int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_
                    int n_importance, int up_sample_steps, const float* bt_inv, const float* T_pose, const float* Ro,
                    const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand, float* sdf_obj,
                    float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals, void* workspace,
-                   size_t workspace_bytes, hn_stream_t stream) {
+                   size_t workspace_bytes, void* tape, size_t tape_bytes, hn_stream_t stream) {
     HN_REQUIRE(hand != nullptr && obj != nullptr, "null field");
     return render_dual_impl(hand, obj, rays_o, rays_d, t_rand, n_frames, rays_per_frame, near, far, n_samples,
                             n_importance, up_sample_steps, bt_inv, T_pose, Ro, To, batch_quirk, color, weight_sum,
                             sdf_hand, sdf_obj, grad_hand, grad_obj, gradient_error, z_vals, workspace, workspace_bytes,
-                            (hipStream_t)stream, nullptr);
+                            (hipStream_t)stream, nullptr, nullptr, tape, tape_bytes);
+}
+size_t hn_render_dual_tape_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray) {
+    if (hand == nullptr || obj == nullptr || n_rays <= 0 || samples_per_ray <= 0) return 0;
+    return field_tape(hand, n_rays * samples_per_ray) + field_tape(obj, n_rays * samples_per_ray);
 }
 
 }  // extern "C"

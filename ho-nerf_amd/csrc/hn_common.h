@@ -112,6 +112,8 @@ struct hn_field {
     size_t v2_sdf_bytes = 0;
     void* v2_adj = nullptr;      // full evaluation followed by its adjoint (hn_field_eval_bwd)
     size_t v2_adj_bytes = 0;
+    void* v2_adjonly = nullptr;  // the adjoint alone, from the tape a taped evaluation left (hn_render_dual / _bwd)
+    size_t v2_adjonly_bytes = 0;
     // --- folded (weight-norm applied) weights and biases, row-major [out, in], for the adjoint (hn_field_bwd.hip)
     void* raw = nullptr;
     const float* raw_sdf_w[9] = {};

@@ -296,11 +296,18 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // MODE 0: sdf only (sampling passes); 1: full evaluation (sdf, d sdf / d p, colour); 2: full evaluation followed by its
 // adjoint (hn_field_eval_bwd): the sweeps of oracle/field_bwd.py in the same weight-stream / register-resident form,
 // per sample tile, with the tape in the wave's stash.
+// The fitting step splits mode 2 in two launches so that nothing is evaluated twice: 3 = full evaluation that keeps its
+// tape (stash slots per sample TILE, in a buffer the caller keeps until the backward pass), 4 = the adjoint alone, from
+// that tape.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     constexpr bool FULL = MODE >= 1;
-    constexpr bool ADJ = MODE == 2;
+    constexpr bool ADJ = MODE >= 2;                    // the forward pass writes the tape
+    constexpr bool RUN_FWD = MODE != 4;
+    constexpr bool RUN_ADJ = MODE == 2 || MODE == 4;
+    constexpr bool PER_TILE = MODE >= 3;               // stash indexed by tile (kept across launches), not by workgroup
     constexpr int N_SLOTS = ADJ ? HAND2_SLOTS_ADJ : HAND2_SLOTS;
+    constexpr int FIRST_CHUNK = MODE == 4 ? HB_W4ROWS : HB_BONE;   // first chunk of a tile's program
     extern __shared__ __attribute__((aligned(16))) char lds[];
     f16_flush_mode();
     const int lane = threadIdx.x & 63;
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     constexpr int TS = HS_TS * SLOT_BYTES;       // per-bone sums of d sdf / d features
     constexpr int QA = HS_QA * SLOT_BYTES;       // colour network's share of qbar per bone (3 floats per lane)
     constexpr int LEFTX = QA + 16384;            // leftover rows of an X-space adjoint, one float per bone and lane
+    constexpr int NZ_OFF = LEFT + 6144;          // the wave's live-bone mask `nz`, for the adjoint launch
     int feat_base = FEAT;                        // which block set load_bone reads (FEAT or GXB)
     const int n_tiles = (a.n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
 
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     ws.init(a.blob, a.blob_bytes, lds, wave, lane);
     char* const stage = lds + 2 * CHUNK_MAX + wave * STAGE_BYTES;   // per-wave staging of one bone's fragments
     ws.dbg_nofetch = (HN_DBG(a) & 4) ? 1 : 0;
-    if ((int)blockIdx.x < n_tiles) ws.fetch_all(HB_BONE);
+    if ((int)blockIdx.x < n_tiles) ws.fetch_all(FIRST_CHUNK);
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const bool more = tile + (int)gridDim.x < n_tiles;
@@ -348,11 +356,15 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 bone_to_p<false>(Sv, Sr, bn, M + 16 * b, g);
         };
 
+        if constexpr (PER_TILE) sh.init(a.scratch + ((size_t)tile * WG_WAVES + wave) * N_SLOTS * SLOT_F4, N_SLOTS, lane);
         // ---- F0: features of the 21 bones -> fragments in the stash -------------------------------------
         // nz bit b: some sample of this wave has a non-zero mask h for bone b.  Where none has, all 64
         // features of the bone are exactly 0 for the whole wave: nothing is generated or stored, and the
         // consumers substitute zero fragments instead of loading (the MFMAs still run: dense compute).
         unsigned nz = 0;
+        if constexpr (!RUN_FWD) {
+            nz = __builtin_bit_cast(unsigned, sh.f32_load(NZ_OFF));   // as the evaluation launch left it
+        } else {
 #pragma unroll 1
         for (int b = 0; b < N_BONES; ++b) {
             const Bone2 bn = coords(b);
@@ -382,6 +394,9 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 sh.frag_store(FEAT, FEAT_BLOCKS + u, fh, fl);
             }
         }
+        if constexpr (ADJ) sh.f32_store(NZ_OFF, __builtin_bit_cast(float, nz));
+        }   // RUN_FWD
+        nz = __builtin_amdgcn_readfirstlane(nz);
 
         // nzw: the bones whose weight chunks this workgroup runs.  Dense: all of them.  Culled: those that are live
         // in at least one of the 4 waves (the chunks are shared through LDS, so the skip has to be workgroup-wide),
@@ -550,6 +565,15 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         using BTrue = std::integral_constant<bool, true>;
         using BFalse = std::integral_constant<bool, false>;
 
+        float g[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
+        float sdf = 0.f;
+        if constexpr (!RUN_FWD) {   // the adjoint alone: the evaluation's outputs come from the forward launch
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                g[c] = a.grad[3 * nn + c];
+                rgb[c] = a.rgb[3 * nn + c];
+            }
+        } else {
         // ---- lin0: features -> a1 (one pass, 8 tile accumulators) ---------------------------------------------
         {
             f32x16 c1[8], c2[8];
@@ -624,7 +648,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 return NoData{};
             },
             no_store);
-        const float sdf = half_sum(sdf_acc) + a.b8;
+        sdf = half_sum(sdf_acc) + a.b8;
         if (!FULL) {
             if (valid && h == 0) a.sdf[n] = sdf;
             continue;
@@ -689,7 +713,6 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         if ((HN_DBG(a) >> 8) == 7) return;   // phase timing aid
         // ---- d sdf / d features contracted with the encoding Jacobian, bone by bone: first W0^T dz0 (dz0 is in
         //      bh/bl), then W4[:, 256:]^T dz4 (reloaded into ah/al)
-        float g[3] = {0.f, 0.f, 0.f};
         // G = W0^T dz0 + W4[:, 256:]^T dz4 accumulated per tile (chunks alternate between the two matrices),
         // so that the features and the Jacobian are visited once
 #pragma unroll
@@ -849,12 +872,11 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         }
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhRelu{}, to_regs_t(ah, al, HS_C + 1), no_store);   // colour lin1
         run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhRelu{}, to_regs_t(bh, bl, HS_C + 2), no_store);   // colour lin2
-        float rgb[3] = {0.f, 0.f, 0.f};
         struct W3 {
             f32x16 w[3];
         };
         run_layer<8, 16, 1, true, false>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
-            ws, HB_HID, ADJ ? HB_W4ROWS : (more ? HB_BONE : 0), bh, bl, lane, h,
+            ws, HB_HID, MODE == 2 ? HB_W4ROWS : (more ? HB_BONE : 0), bh, bl, lane, h,
             [&](auto, const char* tail) { return W3{{tail_tile(tail, 1, h), tail_tile(tail, 2, h), tail_tile(tail, 3, h)}}; },
             PhRelu{},
             [&](auto T, EpiState& st, const W3& w) {
@@ -869,7 +891,8 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             no_store);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_fast(half_sum(rgb[c]) + a.c_blast[c]);
-        if constexpr (ADJ) {
+        }   // RUN_FWD
+        if constexpr (RUN_ADJ) {
 #include "hn_field2_hand_adj.inl"
             continue;
         }
@@ -912,9 +935,16 @@ size_t field2_hand_workspace_bytes(int n_pts, int n_cus) {
     return (size_t)hand2_grid(n_pts, n_cus) * WG_WAVES * HAND2_SLOTS * SLOT_F4 * sizeof(float4);
 }
 
+int launch_field2_hand_taped(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
+                             int pts_per_frame, float* sdf, float* grad, float* rgb, void* tape, size_t tape_bytes, hipStream_t stream);
+
+// tape != NULL (full evaluation only): the evaluation keeps its tape there (field2_hand_tape_bytes) for a later
+// adjoint launch, instead of using the workspace (k_field2_hand<3>, compiled in hn_field2_hand_adj.hip)
 int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose,
                        int n_frames, int pts_per_frame, float* sdf, float* grad, float* rgb, float* feat, void* workspace,
-                       size_t workspace_bytes, bool full, hipStream_t stream) {
+                       size_t workspace_bytes, bool full, hipStream_t stream, void* tape = nullptr, size_t tape_bytes = 0) {
+    if (full && tape != nullptr && n_pts > 0)
+        return launch_field2_hand_taped(f, pts, n_pts, bt_inv, T_pose, n_frames, pts_per_frame, sdf, grad, rgb, tape, tape_bytes, stream);
     if (n_pts <= 0) return HN_OK;
     HN_REQUIRE(bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1,
                "hand field needs bt_inv / T_pose and frame sizes");
@@ -959,13 +989,48 @@ size_t field2_hand_adj_workspace_bytes(int n_pts, int n_cus) {
     return (size_t)hand2_grid(n_pts, n_cus) * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
 }
 
+// bytes of the tape a taped full evaluation leaves for the adjoint launch: the adjoint's stash slots per sample TILE
+size_t field2_hand_tape_bytes(int n_pts) {
+    const size_t n_tiles = ((size_t)(n_pts > 0 ? n_pts : 0) + WG_SAMPLES - 1) / WG_SAMPLES;
+    return n_tiles * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
+}
+
+// the full evaluation that keeps its tape (MODE 3)
+int launch_field2_hand_taped(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
+                             int pts_per_frame, float* sdf, float* grad, float* rgb, void* tape, size_t tape_bytes, hipStream_t stream) {
+    HN_REQUIRE(bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1,
+               "hand field needs bt_inv / T_pose and frame sizes");
+    HN_REQUIRE(f->v2_full != nullptr, "field was not created with HN_PREC_F16X3");
+    if (tape_bytes < field2_hand_tape_bytes(n_pts)) {
+        set_error("field tape too small: %zu < %zu", tape_bytes, field2_hand_tape_bytes(n_pts));
+        return HN_ENOMEM;
+    }
+    Hand2Args a{};
+    hand2_common_args(a, f, pts, n_pts, bt_inv, T_pose, n_frames, pts_per_frame, tape);
+    a.blob = reinterpret_cast<const char*>(f->v2_full);
+    a.blob_bytes = f->v2_full_bytes;
+    a.sdf = sdf;
+    a.grad = grad;
+    a.rgb = rgb;
+    int n_cus = device_cus();
+    if (n_cus <= 0) n_cus = 256;
+    static std::atomic<uint64_t> lds_tape{0};
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<3>), (int)HAND2_LDS, &lds_tape));
+    hipLaunchKernelGGL(k_field2_hand<3>, dim3(hand2_grid(n_pts, n_cus)), dim3(256), HAND2_LDS, stream, a);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
 // hn_field_eval_bwd for an HN_PREC_F16X3 hand field: one persistent launch (evaluation + adjoint per sample tile).
-// g_bt_inv / g_T_pose are accumulated into (the caller zeroes them).
+// g_bt_inv / g_T_pose are accumulated into (the caller zeroes them).  tape != NULL: the adjoint alone (MODE 4) from the
+// tape of a taped evaluation of the same points, whose outputs `grad`, `rgb` are passed back in.
 int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
                            int pts_per_frame, const float* g_sdf, const float* g_grad, const float* g_rgb, float* g_pts,
-                           float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                           float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                           const void* tape = nullptr, const float* grad = nullptr, const float* rgb = nullptr) {
     if (n_pts <= 0) return HN_OK;
-    HN_REQUIRE(f->v2_adj != nullptr, "field has no adjoint program");
+    HN_REQUIRE(f->v2_adj != nullptr && f->v2_adjonly != nullptr, "field has no adjoint program");
+    HN_REQUIRE(tape == nullptr || (grad != nullptr && rgb != nullptr), "the adjoint from a tape needs the evaluation's grad / rgb");
     Hand2Args a{};
     hand2_common_args(a, f, pts, n_pts, bt_inv, T_pose, n_frames, pts_per_frame, workspace);
     a.blob = reinterpret_cast<const char*>(f->v2_adj);
@@ -979,6 +1044,18 @@ int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const
     int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = hand2_grid(n_pts, n_cus);
+    if (tape != nullptr) {
+        a.blob = reinterpret_cast<const char*>(f->v2_adjonly);
+        a.blob_bytes = f->v2_adjonly_bytes;
+        a.scratch = reinterpret_cast<float4*>(const_cast<void*>(tape));
+        a.grad = const_cast<float*>(grad);   // read only in this mode
+        a.rgb = const_cast<float*>(rgb);
+        static std::atomic<uint64_t> lds_adjonly{0};
+        HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<4>), (int)HAND2_LDS, &lds_adjonly));
+        hipLaunchKernelGGL(k_field2_hand<4>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
+        HN_LAUNCH_CHECK();
+        return HN_OK;
+    }
     const size_t need = (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
     if (workspace == nullptr || workspace_bytes < need) {
         set_error("adjoint workspace too small: %zu < %zu", workspace_bytes, need);

@@ -390,7 +390,7 @@
                 mma_tile<16, 0, true>(ws, buf0, bh, bl, G1[u], G2[u], lane);
                 const char* buf4 = ws.template acquire<0>();
                 if constexpr (u == 1) ws.goff = jbase + nb * (4 * HB_BWD);
-                ws.begin((u == 1 && nb == N_BONES) ? (more ? HB_BONE : 0) : HB_BWD);   // after the last bone: the next tile's first chunk
+                ws.begin((u == 1 && nb == N_BONES) ? (more ? FIRST_CHUNK : 0) : HB_BWD);   // after the last bone: the next tile's first chunk
                 mma_tile<16, 0, true>(ws, buf4, ah, al, G1[u], G2[u], lane);
             });
             if (live) {

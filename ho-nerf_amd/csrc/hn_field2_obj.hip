@@ -108,7 +108,7 @@ struct Act1 {
     f32x16 v;
 };
 __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stash& sh, int lane, int h, int n, int nn, bool valid,
-                                            bool more, const float (&p)[3], const float (&d)[3], const float (&g)[3],
+                                            int next_first /* first chunk of the next tile's program, 0 = none */, const float (&p)[3], const float (&d)[3], const float (&g)[3],
                                             const float (&rgb)[3], h8 (&ah)[16], h8 (&al)[16], h8 (&bh)[16], h8 (&bl)[16]) {
     auto no_store = [](auto, const auto&) {};
     auto no_pre = [](auto, const char*) { return NoData{}; };
@@ -383,7 +383,7 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
     static_for<2>([&](auto U) {
         constexpr int u = decltype(U)::value;
         const char* buf = ws.template acquire<0>();
-        ws.begin(u == 0 ? CB_BWD : (more ? CB_L0 : 0));
+        ws.begin(u == 0 ? CB_BWD : next_first);
         mma_tile<16, 0, true>(ws, buf, ah, al, G1[u], G2[u], lane);
     });
     // ---- input map: g_pts = J^T Xb + sum_slots d2(slot) GX(slot) gb[channel of the slot]
@@ -439,12 +439,18 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
 
 // MODE 0: sdf only (sampling passes); 1: full evaluation (sdf, d sdf / d p, colour); 2: full evaluation followed by
 // its adjoint (hn_field_eval_bwd): the sweeps of oracle/field_bwd.py in the same weight-stream / register-resident
-// form, per sample tile, with the tape in the wave's stash.
+// form, per sample tile, with the tape in the wave's stash.  The fitting step splits mode 2 in two launches so that
+// nothing is evaluated twice: 3 = full evaluation that keeps its tape (stash slots per sample TILE, in a buffer the
+// caller keeps until the backward pass), 4 = the adjoint alone, from that tape.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     constexpr bool FULL = MODE >= 1;
-    constexpr bool ADJ = MODE == 2;
+    constexpr bool ADJ = MODE >= 2;                    // the forward pass writes the tape
+    constexpr bool RUN_FWD = MODE != 4;
+    constexpr bool RUN_ADJ = MODE == 2 || MODE == 4;
+    constexpr bool PER_TILE = MODE >= 3;               // stash indexed by tile (kept across launches), not by workgroup
     constexpr int N_SLOTS = ADJ ? OBJ2_SLOTS_ADJ : OBJ2_SLOTS;
+    constexpr int FIRST_CHUNK = MODE == 4 ? CB_W4ROWS : CB_L0;   // first chunk of a tile's program
     extern __shared__ __attribute__((aligned(16))) char lds[];
     f16_flush_mode();
     const int lane = threadIdx.x & 63;
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     WStream ws;
     ws.init(a.blob, a.blob_bytes, lds, wave, lane);
     ws.dbg_nofetch = (HN_DBG(a) & 4) ? 1 : 0;
-    if ((int)blockIdx.x < n_tiles) ws.fetch_all(CB_L0);
+    if ((int)blockIdx.x < n_tiles) ws.fetch_all(FIRST_CHUNK);
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const bool more = tile + (int)gridDim.x < n_tiles;
@@ -467,6 +473,19 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         const bool valid = n < a.n_pts;
         const int nn = valid ? n : a.n_pts - 1;
         const float p[3] = {a.pts[3 * nn], a.pts[3 * nn + 1], a.pts[3 * nn + 2]};
+        if constexpr (PER_TILE) sh.init(a.scratch + ((size_t)tile * WG_WAVES + wave) * N_SLOTS * SLOT_F4, N_SLOTS, lane);
+        h8 ah[16], al[16], bh[16], bl[16];   // ping-pong activation fragments
+        float g[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
+        float sdf = 0.f;
+        const int ray = nn / a.spr;
+        const float d[3] = {FULL ? a.rays_d[3 * ray] : 0.f, FULL ? a.rays_d[3 * ray + 1] : 0.f, FULL ? a.rays_d[3 * ray + 2] : 0.f};
+        if constexpr (!RUN_FWD) {   // the adjoint alone: the evaluation's outputs come from the forward launch
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                g[c] = a.grad[3 * nn + c];
+                rgb[c] = a.rgb[3 * nn + c];
+            }
+        } else {
 
         // X space fragments (lin0, lin4 skip, colour lin0).  The full kernel parks them in the stash
         // between uses (40 registers over ~150 chunks); the sdf-only kernel has room to keep them.
@@ -481,7 +500,6 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 for (int s = 0; s < 4; ++s) sh.frag_store(OS_X * SLOT_BYTES, s, xh[s], xl[s]);
             }
         }
-        h8 ah[16], al[16], bh[16], bl[16];   // ping-pong activation fragments
         struct Act {
             f32x16 v;
         };
@@ -614,7 +632,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 return NoData{};
             },
             no_store);
-        const float sdf = (half_sum(sdf_acc) + a.b8) * a.inv_scale;
+        sdf = (half_sum(sdf_acc) + a.b8) * a.inv_scale;
         if (!FULL) {
             if (valid && h == 0) a.sdf[n] = sdf;
             continue;
@@ -717,7 +735,6 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             mma_tile<16, 0, true>(ws, buf, ah, al, G1[u], G2[u], lane);
         });
         // ---- Jacobian of the encoding (in-lane: G row of tile u, register 8(s&1)+j <-> k-slot (s = 2u + .., h, j))
-        float g[3] = {0.f, 0.f, 0.f};
         {
             float f[4][8];
             encode_x(p, h, f);
@@ -756,8 +773,6 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             g[2] = half_sum(g[2]);
         }
         // ---- colour lin0: [enc(p) | enc(d) | feature vector | enc(g)] -> relu
-        const int ray = nn / a.spr;
-        const float d[3] = {a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]};
         h8 mh[8], ml[8];   // the 8 k-steps of chunk B: X (4), enc(d) (2), enc(g) (2)
         {
 #pragma unroll
@@ -840,12 +855,11 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         };
         run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, PhRelu{}, to_regs_c(ah, al, OS_C + 1), no_store);   // colour lin1
         run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, PhRelu{}, to_regs_c(bh, bl, OS_C + 2), no_store);   // colour lin2
-        float rgb[3] = {0.f, 0.f, 0.f};
         struct W3 {
             f32x16 w[3];
         };
         run_layer<8, 16, 1, true, false>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
-            ws, CB_HID, ADJ ? CB_W4ROWS : (more ? CB_L0 : 0), bh, bl, lane, h,
+            ws, CB_HID, MODE == 2 ? CB_W4ROWS : (more ? CB_L0 : 0), bh, bl, lane, h,
             [&](auto, const char* tail) { return W3{{tail_tile(tail, 1, h), tail_tile(tail, 2, h), tail_tile(tail, 3, h)}}; },
             PhRelu{},
             [&](auto T, EpiState& st, const W3& w) {
@@ -860,8 +874,9 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             no_store);
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_fast(half_sum(rgb[c]) + a.c_blast[c]);
-        if constexpr (ADJ) {
-            obj_adjoint(a, ws, sh, lane, h, n, nn, valid, more, p, d, g, rgb, ah, al, bh, bl);
+        }   // RUN_FWD
+        if constexpr (RUN_ADJ) {
+            obj_adjoint(a, ws, sh, lane, h, n, nn, valid, more ? FIRST_CHUNK : 0, p, d, g, rgb, ah, al, bh, bl);
             continue;
         }
         if (valid && h == 0) {
@@ -887,9 +902,17 @@ size_t field2_obj_workspace_bytes(int n_pts, int n_cus) {
     return (size_t)obj2_grid(n_pts, n_cus) * WG_WAVES * OBJ2_SLOTS * SLOT_F4 * sizeof(float4);
 }
 
+// bytes of the tape a taped full evaluation leaves for the adjoint launch: the adjoint's stash slots per sample TILE
+size_t field2_obj_tape_bytes(int n_pts) {
+    const size_t n_tiles = ((size_t)(n_pts > 0 ? n_pts : 0) + WG_SAMPLES - 1) / WG_SAMPLES;
+    return n_tiles * WG_WAVES * OBJ2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
+}
+
+// tape != NULL (full evaluation only): MODE 3, the evaluation keeps its tape there (field2_obj_tape_bytes) instead of
+// using the workspace
 int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int spr, float* sdf,
                       float* grad, float* rgb, float* feat, void* workspace, size_t workspace_bytes, bool full,
-                      hipStream_t stream) {
+                      hipStream_t stream, void* tape = nullptr, size_t tape_bytes = 0) {
     if (n_pts <= 0) return HN_OK;
     Obj2Args a{};
     a.pts = pts;
@@ -920,6 +943,18 @@ int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, 
     int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = obj2_grid(n_pts, n_cus);
+    if (full && tape != nullptr) {
+        if (tape_bytes < field2_obj_tape_bytes(n_pts)) {
+            set_error("field tape too small: %zu < %zu", tape_bytes, field2_obj_tape_bytes(n_pts));
+            return HN_ENOMEM;
+        }
+        a.scratch = reinterpret_cast<float4*>(tape);
+        static std::atomic<uint64_t> lds_tape{0};
+        HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<3>), (int)OBJ2_LDS, &lds_tape));
+        hipLaunchKernelGGL(k_field2_obj<3>, dim3(grid), dim3(256), OBJ2_LDS, stream, a);
+        HN_LAUNCH_CHECK();
+        return HN_OK;
+    }
     if (full) {
         const size_t need = (size_t)grid * WG_WAVES * OBJ2_SLOTS * SLOT_F4 * sizeof(float4);
         if (workspace == nullptr || workspace_bytes < need) {
@@ -942,12 +977,16 @@ size_t field2_obj_adj_workspace_bytes(int n_pts, int n_cus) {
     return (size_t)obj2_grid(n_pts, n_cus) * WG_WAVES * OBJ2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
 }
 
-// hn_field_eval_bwd for an HN_PREC_F16X3 object field: one persistent launch (evaluation + adjoint per sample tile)
+// hn_field_eval_bwd for an HN_PREC_F16X3 object field: one persistent launch (evaluation + adjoint per sample tile).
+// tape != NULL: the adjoint alone (MODE 4) from the tape of a taped evaluation of the same points, whose outputs
+// `grad`, `rgb` are passed back in.
 int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int spr, const float* g_sdf,
                           const float* g_grad, const float* g_rgb, float* g_pts, float* g_rays_d, void* workspace,
-                          size_t workspace_bytes, hipStream_t stream) {
+                          size_t workspace_bytes, hipStream_t stream, const void* tape = nullptr, const float* grad = nullptr,
+                          const float* rgb = nullptr) {
     if (n_pts <= 0) return HN_OK;
-    HN_REQUIRE(f->v2_adj != nullptr, "field has no adjoint program");
+    HN_REQUIRE(f->v2_adj != nullptr && f->v2_adjonly != nullptr, "field has no adjoint program");
+    HN_REQUIRE(tape == nullptr || (grad != nullptr && rgb != nullptr), "the adjoint from a tape needs the evaluation's grad / rgb");
     Obj2Args a{};
     a.pts = pts;
     a.rays_d = rays_d;
@@ -968,12 +1007,24 @@ int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays
     int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = obj2_grid(n_pts, n_cus);
+    if (g_rays_d != nullptr) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n_pts / a.spr) * 3 * sizeof(float), stream));
+    if (tape != nullptr) {
+        a.blob = reinterpret_cast<const char*>(f->v2_adjonly);
+        a.blob_bytes = f->v2_adjonly_bytes;
+        a.scratch = reinterpret_cast<float4*>(const_cast<void*>(tape));
+        a.grad = const_cast<float*>(grad);   // read only in this mode
+        a.rgb = const_cast<float*>(rgb);
+        static std::atomic<uint64_t> lds_adjonly{0};
+        HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<4>), (int)OBJ2_LDS, &lds_adjonly));
+        hipLaunchKernelGGL(k_field2_obj<4>, dim3(grid), dim3(256), OBJ2_LDS, stream, a);
+        HN_LAUNCH_CHECK();
+        return HN_OK;
+    }
     const size_t need = (size_t)grid * WG_WAVES * OBJ2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
     if (workspace == nullptr || workspace_bytes < need) {
         set_error("adjoint workspace too small: %zu < %zu", workspace_bytes, need);
         return HN_ENOMEM;
     }
-    if (g_rays_d != nullptr) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n_pts / a.spr) * 3 * sizeof(float), stream));
     static std::atomic<uint64_t> lds_adj{0};
     HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<2>), (int)OBJ2_LDS, &lds_adj));
     hipLaunchKernelGGL(k_field2_obj<2>, dim3(grid), dim3(256), OBJ2_LDS, stream, a);

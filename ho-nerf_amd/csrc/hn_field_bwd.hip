@@ -22,11 +22,12 @@ namespace v2 {
 size_t field2_obj_adj_workspace_bytes(int n_pts, int n_cus);
 int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int spr, const float* g_sdf,
                           const float* g_grad, const float* g_rgb, float* g_pts, float* g_rays_d, void* workspace,
-                          size_t workspace_bytes, hipStream_t stream);
+                          size_t workspace_bytes, hipStream_t stream, const void* tape, const float* grad, const float* rgb);
 size_t field2_hand_adj_workspace_bytes(int n_pts, int n_cus);
 int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
                            int pts_per_frame, const float* g_sdf, const float* g_grad, const float* g_rgb, float* g_pts,
-                           float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                           float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                           const void* tape, const float* grad, const float* rgb);
 }
 namespace bwd {
 
@@ -660,10 +661,12 @@ size_t field_bwd_workspace_bytes(const hn_field* f, int n) {
     return need;
 }
 
+// tape / grad / rgb (HN_PREC_F16X3 only, may be NULL): the tape a taped evaluation of the same points left and that
+// evaluation's outputs -- the adjoint then runs alone instead of re-evaluating the field first
 int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
-                   size_t workspace_bytes, hipStream_t s) {
+                   size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb) {
     HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");
     const bool obj = f->kind == HN_FIELD_OBJ;
     HN_REQUIRE(obj || (bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1),
@@ -675,11 +678,12 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     if (n == 0) return HN_OK;
     if (fused_adjoint(f, sdf_only)) {
         if (obj)
-            return v2::launch_field2_obj_adj(f, pts, rays_d, n, spr, g_sdf, g_grad, g_rgb, g_pts, g_rays_d, workspace, workspace_bytes, s);
+            return v2::launch_field2_obj_adj(f, pts, rays_d, n, spr, g_sdf, g_grad, g_rgb, g_pts, g_rays_d, workspace, workspace_bytes, s,
+                                             tape, grad, rgb);
         // the hand's colour network ignores the view direction (utils/fields.py:222-240): its gradient is exactly 0
         if (g_rays_d != nullptr) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n / spr) * 3 * sizeof(float), s));
         return v2::launch_field2_hand_adj(f, pts, n, bt_inv, T_pose, n_frames, pts_per_frame, g_sdf, g_grad, g_rgb, g_pts, g_bt_inv,
-                                          g_T_pose, workspace, workspace_bytes, s);
+                                          g_T_pose, workspace, workspace_bytes, s, tape, grad, rgb);
     }
     Arena ar{reinterpret_cast<char*>(workspace), 0, workspace_bytes};
     Bufs b;

@@ -237,9 +237,16 @@ static void obj_sdf_reverse_chunks(Builder& B, const HostMat* S) {
     slot_rows_T(B, S[4], rs2, xs, L3_OUT_OBJ);       // W4[:, 193:]^T over the X slots
 }
 
+static void obj_adjoint_chunks(Builder& B, const HostMat* S, const HostMat* C);
+
 // The obj program (contract with k_field2_obj): sdf forward [+ feature rows + reverse sweep + colour [+ adjoint]]
-// mode 0: sdf only; 1: full evaluation; 2: full evaluation followed by its adjoint (hn_field_eval_bwd)
+// mode 0: sdf only; 1: full evaluation; 2: full evaluation followed by its adjoint (hn_field_eval_bwd); 3: the adjoint
+// alone (from a kept tape)
 static void build_obj_stream(Builder& B, const HostMat* S, const HostMat* C, int mode) {
+    if (mode == 3) {
+        obj_adjoint_chunks(B, S, C);
+        return;
+    }
     const std::vector<int> xs = obj_x_slots();
     const std::vector<int> hs = hid_slots();
     obj_sdf_forward_chunks(B, S);
@@ -274,7 +281,14 @@ static void build_obj_stream(Builder& B, const HostMat* S, const HostMat* C, int
         fwd_tiles(B, C[3], 1.f, 8, 256, 0, hs, 16, extra, 3);
     }
     if (mode < 2) return;
-    // ---- adjoint (oracle/field_bwd.py steps 3b-6; contract with k_field2_obj<2>) -------------------------------
+    obj_adjoint_chunks(B, S, C);
+}
+
+// ---- adjoint (oracle/field_bwd.py steps 3b-6; contract with obj_adjoint in hn_field2_obj.hip) -------------------
+static void obj_adjoint_chunks(Builder& B, const HostMat* S, const HostMat* C) {
+    const std::vector<int> xs = obj_x_slots();
+    const std::vector<int> v4 = vec4_slots();
+    const std::vector<int> misc = cat(cat(xs, offset(v4, OBJ_IN)), offset(v4, OBJ_IN + 27 + H));
     // colour network backward: the three rows of lin4 (one tail-format KiB each: slot t = the row's 32 values of
     // tile t), C3^T, C2^T, C1^T, then C0^T over the feature-vector rows and over the [enc(p) | enc(d) | enc(g)]
     // slots (4 tiles: X, X, d, g)
@@ -329,15 +343,15 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
         if (rc != HN_OK) return rc;
     }
     HN_CHECK_HIP(hipStreamSynchronize(stream));
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         Builder B;
         if (f->kind == HN_FIELD_OBJ) {
             build_obj_stream(B, S, C, mode);
         } else {
             build_hand_stream(B, S, C, mode);
         }
-        void** dst = mode == 0 ? &f->v2_sdf : (mode == 1 ? &f->v2_full : &f->v2_adj);
-        size_t* nb = mode == 0 ? &f->v2_sdf_bytes : (mode == 1 ? &f->v2_full_bytes : &f->v2_adj_bytes);
+        void** dst = mode == 0 ? &f->v2_sdf : (mode == 1 ? &f->v2_full : (mode == 2 ? &f->v2_adj : &f->v2_adjonly));
+        size_t* nb = mode == 0 ? &f->v2_sdf_bytes : (mode == 1 ? &f->v2_full_bytes : (mode == 2 ? &f->v2_adj_bytes : &f->v2_adjonly_bytes));
         const int rc = upload(B.blob, dst, nb, stream);
         if (rc != HN_OK) return rc;
     }
@@ -468,9 +482,15 @@ static void hand_sdf_forward_chunks(Builder& B, const HostMat* S, bool lin0_bias
     }
 }
 
+static void hand_adjoint_chunks(Builder& B, const HostMat* S, const HostMat* C);
+
 // The hand program (contract with k_field2_hand).  mode 0: sdf only; 1: full evaluation; 2: full evaluation followed by
-// its adjoint (hn_field2_hand_adj.inl)
+// its adjoint (hn_field2_hand_adj.inl); 3: the adjoint alone (from a kept tape)
 void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, int mode) {
+    if (mode == 3) {
+        hand_adjoint_chunks(B, S, C);
+        return;
+    }
     const float rs2 = (float)(1.0 / sqrt(2.0));
     const std::vector<int> hs = hid_slots();
     hand_sdf_forward_chunks(B, S, true);
@@ -509,7 +529,12 @@ void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, int mode)
         fwd_tiles(B, C[3], 1.f, 8, 256, 0, hs, 16, extra, 3);
     }
     if (mode < 2) return;
-    // ---- adjoint ------------------------------------------------------------------------------------------------
+    hand_adjoint_chunks(B, S, C);
+}
+
+// ---- adjoint (contract with hn_field2_hand_adj.inl) ------------------------------------------------------------------
+static void hand_adjoint_chunks(Builder& B, const HostMat* S, const HostMat* C) {
+    const float rs2 = (float)(1.0 / sqrt(2.0));
     for (int c = 0; c < 3; ++c) {   // the three rows of colour lin4, one tail-format KiB each
         float tail[256];
         for (int t = 0; t < 8; ++t) {

@@ -83,9 +83,10 @@ SIGNATURES = {
     'hn_render_dual_aux_offsets': (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, ctypes.POINTER(c_sz)]),
     'hn_render_dual_bwd_workspace_bytes': (c_sz, [c_vp, c_vp, c_i, c_i]),
     'hn_render_dual_bwd': (c_i, [c_vp, c_vp, c_f, c_f, c_i, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
-                                 c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
+                                 c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp, c_vp]),
+    'hn_render_dual_tape_bytes': (c_sz, [c_vp, c_vp, c_i, c_i]),
     'hn_render_dual': (c_i, [c_vp, c_vp, c_f, c_f, c_f, c_i, c_i, c_db, c_db, c_i, c_i, c_i, c_f, c_f, c_f, c_f,
-                             c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),
+                             c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp, c_sz, c_vp]),
 }
 
 _lib = None

@@ -304,6 +304,7 @@ class NeuSRenderer_fitting:
         self._version = None
         self._ws = _Workspace()
         self._ws_bwd = _Workspace()      # workspace of the adjoint launches (autograd.DualRenderFn.backward)
+        self._tape = _Workspace()        # tape of the last differentiable render's final evaluation
         self.lib = _lib.load()
 
     def fields(self):
@@ -316,8 +317,9 @@ class NeuSRenderer_fitting:
             self._version = ver
         return self._fields
 
-    def _render_raw(self, rays_o, rays_d, near, far, bt_inv, T_pose_21, Ro, To, t_rand):
-        """rays [F,P,3] (F = 1 for the unbatched class) -> dict of flat device tensors."""
+    def _render_raw(self, rays_o, rays_d, near, far, bt_inv, T_pose_21, Ro, To, t_rand, keep_tape=False):
+        """rays [F,P,3] (F = 1 for the unbatched class) -> dict of flat device tensors.  keep_tape: a backward pass will
+        follow -- the final evaluation keeps its tape in self._tape for hn_render_dual_bwd."""
         hand, obj = self.fields()
         lib = self.lib
         F, P = rays_o.shape[0], rays_o.shape[1]
@@ -339,13 +341,18 @@ class NeuSRenderer_fitting:
         }
         need = lib.hn_render_dual_workspace_bytes(hand.handle, obj.handle, N, self.n_samples, self.n_importance)
         ws = self._ws.get(need, dev)
+        tape, tape_bytes = None, 0
+        if keep_tape:
+            tape_bytes = lib.hn_render_dual_tape_bytes(hand.handle, obj.handle, N, S)
+            tape = self._tape.get(tape_bytes, dev) if tape_bytes else None
+        out['tape'] = tape
         rc = lib.hn_render_dual(hand.handle, obj.handle, _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(tr), F, P,
                                 float(near), float(far), self.n_samples, self.n_importance, self.up_sample_steps,
                                 _lib.ptr(bt), _lib.ptr(tp), _lib.ptr(Ro_), _lib.ptr(To_),
                                 1 if (self.strict_reference and F > 1) else 0, _lib.ptr(out['color']),
                                 _lib.ptr(out['weight_sum']), _lib.ptr(out['sdf_hand']), _lib.ptr(out['sdf_obj']),
                                 _lib.ptr(out['grad_hand']), _lib.ptr(out['grad_obj']), _lib.ptr(out['gerr']),
-                                _lib.ptr(out['z_vals']), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                                _lib.ptr(out['z_vals']), _lib.ptr(ws), ws.numel(), _lib.ptr(tape), tape_bytes, _lib.stream_ptr())
         _lib.check(rc, 'hn_render_dual')
         self._last_z_raw = out['z_vals']
         return out

@@ -267,7 +267,13 @@ int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_
                    int n_importance, int up_sample_steps, const float* bt_inv, const float* T_pose, const float* Ro,
                    const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand,
                    float* sdf_obj, float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals,
-                   void* workspace, size_t workspace_bytes, hn_stream_t stream);
+                   void* workspace, size_t workspace_bytes, void* tape, size_t tape_bytes, hn_stream_t stream);
+/* `tape` (may be NULL): when a backward pass will follow (the fitting loops), the final evaluation of both fields
+ * keeps its tape -- activations, reverse-sweep values, feature fragments, per sample tile -- in this caller-owned buffer
+ * of hn_render_dual_tape_bytes(hand, obj, n_rays, n_samples + 2 n_importance) bytes; hn_render_dual_bwd given the same
+ * buffer then runs the adjoints alone instead of evaluating both fields a second time.  HN_PREC_F16X3 fields only
+ * (0 bytes otherwise). */
+size_t hn_render_dual_tape_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray);
 /* After hn_render_dual the caller's workspace still holds what the final evaluation produced for compositing:
  * rgb_hand, rgb_obj [n_rays*S,3] and alpha_hand, alpha_obj [n_rays*S] (S = n_samples + 2 n_importance).  Byte offsets
  * of the four arrays into the workspace, in that order (same sizes and up_sample_steps as the render call) -- the backward pass of a fitting step re-uses them instead
@@ -283,7 +289,8 @@ int hn_render_dual_aux_offsets(const hn_field* hand, const hn_field* obj, int n_
  * g_gradient_error [2] (hand, obj) -- each may be NULL.  Outputs (overwritten): g_rays_o, g_rays_d [N,3], g_bt_inv
  * [n_frames,21,4,4], g_T_pose [n_frames,21,3], g_Ro [n_frames,3,3], g_To [n_frames,3].  The hand and the object branch
  * run side by side on the given stream and on a library-owned second stream of the device (event fork / join; the host
- * is never blocked). */
+ * is never blocked).  `tape`: the buffer the forward hn_render_dual call filled (same rays, depths and fields), or NULL
+ * (then both fields are evaluated again inside their adjoint kernels). */
 size_t hn_render_dual_bwd_workspace_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray);
 int hn_render_dual_bwd(const hn_field* hand, const hn_field* obj, const float* rays_o, const float* rays_d, int n_frames,
                        int rays_per_frame, int samples_per_ray, float sample_dist, const float* bt_inv, const float* T_pose,
@@ -292,7 +299,8 @@ int hn_render_dual_bwd(const hn_field* hand, const hn_field* obj, const float* r
                        const float* rgb_obj, const float* alpha_obj, const float* g_color, const float* g_weight_sum,
                        const float* g_sdf_hand, const float* g_sdf_obj, const float* g_grad_hand, const float* g_grad_obj,
                        const float* g_gradient_error, float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose,
-                       float* g_Ro, float* g_To, void* workspace, size_t workspace_bytes, hn_stream_t stream);
+                       float* g_Ro, float* g_To, void* workspace, size_t workspace_bytes, const void* tape,
+                       hn_stream_t stream);
 
 #ifdef __cplusplus
 }
