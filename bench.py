@@ -162,14 +162,14 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup):
         return dt / steps
 
     ren, nets, chain, views, _ = build_fit(dev, 40 + rank, 1, FIT_RAYS, precision)
-    opt = torch.optim.Adam(chain.param_groups(video=False))
+    opt = F.make_optimizer(chain, video=False)
     for ft in ('1', '12'):
         sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, ft))
         res['single_' + ft] = {'ms_per_step': sec * 1e3, 'steps_per_frame': STEPS_PER_FRAME[ft],
                                'frames_per_s': world / (STEPS_PER_FRAME[ft] * sec)}
     single = (ren, nets, chain, views)
     renb, netsb, chainb, viewsb, ov = build_fit(dev, 60 + rank, VID_FRAMES, VID_RAYS, precision)
-    optb = torch.optim.Adam(chainb.param_groups(video=True))
+    optb = F.make_optimizer(chainb, video=True)
     idx = list(range(VID_FRAMES))
     sec = timed(lambda i: F.fit_step(renb, viewsb[i % 8], chainb, optb, NEAR, FAR, '1234', index=idx, smooth_ends=(True, False),
                                      obj_verts_for_stable=ov))

@@ -166,3 +166,48 @@ class HandSdfFn(torch.autograd.Function):
         sp, sb, st = ctx.shapes
         g_tp = g_tp.reshape(st) if g_tp.numel() == int(torch.Size(st).numel()) else g_tp.sum(0).reshape(st)
         return g_pts.reshape(sp), g_bt.reshape(sb), g_tp, None, None
+
+
+class FitLossFn(torch.autograd.Function):
+    """The four render-dependent loss terms of a fitting step (fitting_single.py:251-283) as two launches
+    (hn_fit_loss_sums / hn_fit_loss_grads): (color_fine [R,3], weight_sum [R,1], sdf_hand [n,1] | None, sdf_obj | None,
+    true_rgb, true_mask) -> (colour loss, mask loss, contact, penetration); the last two are 0 without sdfs."""
+
+    @staticmethod
+    def forward(ctx, color, wsum, sdf_h, sdf_o, true_rgb, true_mask):
+        L = _lib
+        lib = L.load()
+        dev = color.device
+        c, w = L.f32(color).reshape(-1, 3), L.f32(wsum).reshape(-1)
+        t, m = L.f32(true_rgb, dev).reshape(-1, 3), L.f32(true_mask, dev).reshape(-1)
+        sh = None if sdf_h is None else L.f32(sdf_h).reshape(-1)
+        so = None if sdf_o is None else L.f32(sdf_o).reshape(-1)
+        R, n = c.shape[0], 0 if sh is None else sh.shape[0]
+        sums = _empty(6, dev=dev)
+        L.check(lib.hn_fit_loss_sums(L.ptr(c), L.ptr(w), L.ptr(t), L.ptr(m), R, L.ptr(sh), L.ptr(so), n, L.ptr(sums), L.stream_ptr()),
+                'hn_fit_loss_sums')
+        ctx.save_for_backward(c, w, t, m, sums, *([sh, so] if sh is not None else []))
+        ctx.shapes = (color.shape, wsum.shape, None if sdf_h is None else sdf_h.shape)
+        den = torch.stack([sums.new_tensor(float(R)), sums.new_tensor(float(R)), sums[3] + 1e-9, sums[5] + 1e-9])
+        out = sums[[0, 1, 2, 4]] / den
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def backward(ctx, g_c, g_m, g_ct, g_p):
+        L = _lib
+        lib = L.load()
+        sv = ctx.saved_tensors
+        c, w, t, m, sums = sv[:5]
+        sh, so = (sv[5], sv[6]) if len(sv) > 5 else (None, None)
+        dev = c.device
+        z = torch.zeros((), device=dev)
+        g4 = torch.stack([z if g is None else g.to(torch.float32) for g in (g_c, g_m, g_ct, g_p)]).contiguous()
+        R, n = c.shape[0], 0 if sh is None else sh.shape[0]
+        gc, gw = _empty(R, 3, dev=dev), _empty(R, dev=dev)
+        gsh = _empty(n, dev=dev) if sh is not None else None
+        gso = _empty(n, dev=dev) if sh is not None else None
+        L.check(lib.hn_fit_loss_grads(L.ptr(c), L.ptr(w), L.ptr(t), L.ptr(m), R, L.ptr(sh), L.ptr(so), n, L.ptr(sums), L.ptr(g4), L.ptr(gc),
+                                      L.ptr(gw), L.ptr(gsh), L.ptr(gso), L.stream_ptr()), 'hn_fit_loss_grads')
+        s_c, s_w, s_s = ctx.shapes
+        return (gc.reshape(s_c), gw.reshape(s_w), None if gsh is None else gsh.reshape(s_s), None if gso is None else gso.reshape(s_s),
+                None, None)

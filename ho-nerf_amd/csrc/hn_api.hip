@@ -41,6 +41,9 @@ int composite1_bwd(const float*, const float*, const float*, const float*, const
                    hipStream_t);
 int composite2_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
                    float*, float*, float*, hipStream_t);
+int fit_loss_sums(const float*, const float*, const float*, const float*, int, const float*, const float*, int, float*, hipStream_t);
+int fit_loss_grads(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*,
+                   const float*, float*, float*, float*, float*, hipStream_t);
 size_t field_obj_workspace_bytes(int n_pts, int n_cus);
 size_t field_hand_workspace_bytes(int n_pts, int n_cus);
 int launch_field_obj(const hn_field*, const float*, const float*, int, int, float*, float*, float*, float*, void*, size_t,
@@ -503,13 +506,15 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     const hipStream_t so = side != nullptr ? side->s2 : s;
     HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_l, d_l, s));
     HN_TRY(composite2_bwd(alpha_h, rgb_h, alpha_o, rgb_o, g_color, g_wsum, n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo, s));
-    if (side != nullptr) HN_TRY(fork_to(side, s));
-    // hand branch (s)
+    // hand branch (s).  The object branch is released (fork) only when the hand's adjoint kernel is next in line: that
+    // kernel is the long pole (two rounds of sample tiles, the second 15 % full) and must get the CUs first; the object
+    // branch then runs in the shadow of its second round instead of delaying its start.
     HN_TRY(sample_points(rays_o, rays_d, z, n_rays, S, 1, sample_dist, pts_h, dists_h, s));
     HN_TRY(alpha_bwd(sdf_h, grad_h, rays_d, dists_h, g_ah, nullptr, n, S, hand->inv_s, gs_h, gg_h, gd_h, s));
     hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs_h, gg_h, g_sdf_h, g_grad_h, grad_h, g_eik, n);
     HN_CHECK_HIP(hipMemsetAsync(g_bt_inv, 0, (size_t)n_frames * 21 * 16 * sizeof(float), s));
     HN_CHECK_HIP(hipMemsetAsync(g_T_pose, 0, (size_t)n_frames * 21 * 3 * sizeof(float), s));
+    if (side != nullptr) HN_TRY(fork_to(side, s));
     HN_TRY(bwd::field_eval_bwd(hand, pts_h, rays_d, n, S, bt_inv, T_pose, n_frames, rpf * S, gs_h, gg_h, g_rgbh, gp_h, gdir_h, g_bt_inv,
                                g_T_pose, bwh, bws_h, s, tp_h, grad_h, rgb_h));
     HN_TRY(sample_points_bwd(z, gp_h, n_rays, S, 1, sample_dist, go_h, gdd_h, s));
@@ -691,6 +696,17 @@ int hn_composite2_bwd(const float* alpha_h, const float* rgb_h, const float* alp
                       float* g_alpha_o, float* g_rgb_o, hn_stream_t stream) {
     return composite2_bwd(alpha_h, rgb_h, alpha_o, rgb_o, g_color, g_weight_sum, n_rays, S, g_alpha_h, g_rgb_h, g_alpha_o,
                           g_rgb_o, (hipStream_t)stream);
+}
+
+int hn_fit_loss_sums(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays,
+                     const float* sdf_hand, const float* sdf_obj, int n_samples, float* sums6, hn_stream_t stream) {
+    return fit_loss_sums(color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, sums6, (hipStream_t)stream);
+}
+int hn_fit_loss_grads(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays,
+                      const float* sdf_hand, const float* sdf_obj, int n_samples, const float* sums6, const float* g4,
+                      float* g_color, float* g_weight_sum, float* g_sdf_hand, float* g_sdf_obj, hn_stream_t stream) {
+    return fit_loss_grads(color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, sums6, g4, g_color,
+                          g_weight_sum, g_sdf_hand, g_sdf_obj, (hipStream_t)stream);
 }
 
 size_t hn_render_single_workspace_bytes(const hn_field* f, int n_rays, int n_samples, int n_importance) {

@@ -586,4 +586,93 @@ int composite2_bwd(const float* ah, const float* rgbh, const float* ao, const fl
     return HN_OK;
 }
 
+
+// ---- render-dependent loss terms of a fitting step (fitting_single.py:251-283; fitting_video.py:285-309) ------------
+// colour: sum |(color - true_rgb) mask| / R;  mask: mean BCE(clip(weight_sum, 1e-3, 1 - 1e-3), mask);  contact: mean of
+// |s_h| + |s_o| where that sum < 1e-2;  penetration: mean of the same over s_o < 0 and s_h < 0.  One launch for the
+// sums (sums[6] = colour, bce, contact sum, contact count, penetration sum, penetration count; zeroed here) and one for
+// all four gradients, instead of ~35 + ~50 element-wise launches in a step that is a chain of dependent launches.
+__global__ void k_fit_loss_sums(const float* __restrict__ color, const float* __restrict__ wsum, const float* __restrict__ true_rgb,
+                                const float* __restrict__ true_mask, int n_rays, const float* __restrict__ sdf_h,
+                                const float* __restrict__ sdf_o, int n_samples, float* __restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < n_rays) {
+        const float m = true_mask[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[0] += fabsf((color[3 * (size_t)i + c] - true_rgb[3 * (size_t)i + c]) * m);
+        const float w = fminf(fmaxf(wsum[i], 1e-3f), 1.f - 1e-3f);
+        v[1] = -(m * logf(w) + (1.f - m) * logf(1.f - w));
+    }
+    if (sdf_h != nullptr && i < n_samples) {
+        const float sh = sdf_h[i], so = sdf_o[i];
+        const float a = fabsf(sh) + fabsf(so);
+        if (a < 1e-2f) {
+            v[2] = a;
+            v[3] = 1.f;
+        }
+        if (so < 0.f && sh < 0.f) {
+            v[4] = a;
+            v[5] = 1.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float t = wave_sum(v[k]);
+        if ((threadIdx.x & 63) == 0 && t != 0.f) atomicAdd(sums + k, t);
+    }
+}
+// g[4] = upstream gradients of (colour, mask, contact, penetration) losses (device scalars)
+__global__ void k_fit_loss_grads(const float* __restrict__ color, const float* __restrict__ wsum, const float* __restrict__ true_rgb,
+                                 const float* __restrict__ true_mask, int n_rays, const float* __restrict__ sdf_h,
+                                 const float* __restrict__ sdf_o, int n_samples, const float* __restrict__ sums,
+                                 const float* __restrict__ g, float* __restrict__ g_color, float* __restrict__ g_wsum,
+                                 float* __restrict__ g_sdf_h, float* __restrict__ g_sdf_o) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rays) {
+        const float m = true_mask[i], inv = 1.f / (float)n_rays;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float e = (color[3 * (size_t)i + c] - true_rgb[3 * (size_t)i + c]) * m;
+            g_color[3 * (size_t)i + c] = g[0] * inv * m * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+        }
+        const float w0 = wsum[i];
+        const float w = fminf(fmaxf(w0, 1e-3f), 1.f - 1e-3f);
+        const bool inside = w0 >= 1e-3f && w0 <= 1.f - 1e-3f;   // clip passes the gradient on its closed range, as torch
+        g_wsum[i] = inside ? g[1] * inv * (w - m) / (w * (1.f - w)) : 0.f;
+    }
+    if (sdf_h != nullptr && i < n_samples) {
+        const float sh = sdf_h[i], so = sdf_o[i];
+        const float a = fabsf(sh) + fabsf(so);
+        float k = 0.f;
+        if (a < 1e-2f) k += g[2] / (sums[3] + 1e-9f);
+        if (so < 0.f && sh < 0.f) k += g[3] / (sums[5] + 1e-9f);
+        g_sdf_h[i] = k * (sh > 0.f ? 1.f : (sh < 0.f ? -1.f : 0.f));
+        g_sdf_o[i] = k * (so > 0.f ? 1.f : (so < 0.f ? -1.f : 0.f));
+    }
+}
+int fit_loss_sums(const float* color, const float* wsum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_h,
+                  const float* sdf_o, int n_samples, float* sums6, hipStream_t s) {
+    HN_REQUIRE(color && wsum && true_rgb && true_mask && sums6 && n_rays >= 0 && (sdf_h == nullptr) == (sdf_o == nullptr), "bad arguments");
+    HN_CHECK_HIP(hipMemsetAsync(sums6, 0, 6 * sizeof(float), s));
+    const int n = n_rays > n_samples ? n_rays : (sdf_h != nullptr ? n_samples : n_rays);
+    if (n <= 0) return HN_OK;
+    hipLaunchKernelGGL(k_fit_loss_sums, dim3((n + 255) / 256), dim3(256), 0, s, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o,
+                       sdf_h != nullptr ? n_samples : 0, sums6);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+int fit_loss_grads(const float* color, const float* wsum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_h,
+                   const float* sdf_o, int n_samples, const float* sums6, const float* g4, float* g_color, float* g_wsum,
+                   float* g_sdf_h, float* g_sdf_o, hipStream_t s) {
+    HN_REQUIRE(color && wsum && true_rgb && true_mask && sums6 && g4 && g_color && g_wsum, "bad arguments");
+    HN_REQUIRE(sdf_h == nullptr || (sdf_o && g_sdf_h && g_sdf_o), "sdf gradients need both fields");
+    const int n = n_rays > n_samples ? n_rays : (sdf_h != nullptr ? n_samples : n_rays);
+    if (n <= 0) return HN_OK;
+    hipLaunchKernelGGL(k_fit_loss_grads, dim3((n + 255) / 256), dim3(256), 0, s, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o,
+                       sdf_h != nullptr ? n_samples : 0, sums6, g4, g_color, g_wsum, g_sdf_h, g_sdf_o);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
 }  // namespace hn

@@ -51,6 +51,19 @@ def render_loss_terms(render_out, true_rgb, true_mask, fit_type='1', video=False
     The pose-regularisation terms (joint / object-vertex losses) depend on the pose chain only: step_loss adds them."""
     color_fine = render_out['color_fine']
     weight_sum = render_out['weight_sum']
+    interaction = video or fit_type in ('12', '123', '1234')
+    if color_fine.is_cuda:
+        # on the device the same four terms come from two launches (hn_fit_loss_sums / _grads) instead of ~85
+        from .autograd import FitLossFn
+        color_loss, mask_loss, contact, penet = FitLossFn.apply(color_fine, weight_sum, render_out['sdf_hand'] if interaction else None,
+                                                                render_out['sdf_obj'] if interaction else None, true_rgb, true_mask)
+        render_loss = color_loss + 0.5 * mask_loss
+        if video:
+            render_loss = 0.5 * render_loss
+        terms = {'color': color_loss, 'mask': mask_loss, 'loss': render_loss, 'contact': contact, 'penetration': penet}
+        if interaction:
+            terms['loss'] = terms['loss'] + 30 * contact + 20 * penet
+        return terms
     color_error = (color_fine - true_rgb) * true_mask
     color_loss = F.l1_loss(color_error, torch.zeros_like(color_error), reduction='sum') / true_mask.shape[0]
     if video:
@@ -62,7 +75,7 @@ def render_loss_terms(render_out, true_rgb, true_mask, fit_type='1', video=False
     terms = {'color': color_loss, 'mask': mask_loss, 'loss': render_loss}
     zero = color_loss.new_zeros(())
     terms['contact'], terms['penetration'] = zero, zero
-    if video or fit_type in ('12', '123', '1234'):
+    if interaction:
         # Same sums as fitting_single.py:268-281, written with masks instead of boolean indexing: indexing makes
         # tensors of data-dependent size, i.e. a device -> host synchronisation in the middle of every step
         sdf_hand = render_out['sdf_hand'][:, 0]
@@ -310,13 +323,25 @@ def fit_step(renderer, view, pose_chain, optimizer, near, far, fit_type='1', ind
     return terms
 
 
+def make_optimizer(pose_chain, video=False):
+    """Adam over the chain's parameter groups with the learning rates of fitting_single.py:191-199 /
+    fitting_video.py:177-185.  On the GPU the fused multi-tensor form: one kernel per step for all parameter blocks
+    instead of ~10 element-wise launches per block (the step is a chain of dependent launches; every one counts)."""
+    groups = pose_chain.param_groups(video=video)
+    on_gpu = all(p.is_cuda for g in groups for p in ([g['params']] if isinstance(g['params'], torch.Tensor) else g['params']))
+    try:
+        return torch.optim.Adam(groups, fused=True) if on_gpu else torch.optim.Adam(groups)
+    except (RuntimeError, TypeError):      # a torch build without the fused implementation
+        return torch.optim.Adam(groups)
+
+
 def fit_frame(renderer, views, pose_chain, near, far, fit_type='1', n_iters=None, sample_view=None):
     """fitting_single.py:200-291 for one frame: `n_iters` (30 for fit type '1', 25 for '12'; 40 / 35 with 3 views,
     :124-132) passes over the views, one Adam step per view.  `sample_view(view_id, step) -> view dict` draws the
     step's pixels (the reference: get_rays_xy on the view's mask, 196 rays); default: the views as given."""
     if n_iters is None:
         n_iters = {('1', False): 30, ('1', True): 40, ('12', False): 25, ('12', True): 35}[(fit_type, len(views) == 3)]
-    opt = torch.optim.Adam(pose_chain.param_groups(video=False))
+    opt = make_optimizer(pose_chain, video=False)
     last, step = None, 0
     for _ in range(n_iters):
         for vid in range(len(views)):

@@ -76,6 +76,8 @@ SIGNATURES = {
     'hn_alpha_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_f, c_vp]),
     'hn_composite1_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_vp]),
     'hn_composite2_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_vp]),
+    'hn_fit_loss_sums': (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_vp]),
+    'hn_fit_loss_grads': (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_vp]),
     'hn_render_single_workspace_bytes': (c_sz, [c_vp, c_i, c_i, c_i]),
     'hn_render_single': (c_i, [c_vp, c_f, c_f, c_f, c_i, c_db, c_db, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f,
                                c_f, c_f, c_vp, c_sz, c_vp]),

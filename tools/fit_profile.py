@@ -13,7 +13,7 @@ from honerf_amd import fitting as F
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device('cuda')
 ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3')
-opt = torch.optim.Adam(chain.param_groups(video=False))
+opt = F.make_optimizer(chain, video=False)
 for i in range(3):
     F.fit_step(ren, views[i % 8], chain, opt, bench.NEAR, bench.FAR, '12')
 torch.cuda.synchronize()

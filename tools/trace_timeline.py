@@ -1,0 +1,29 @@
+"""Timeline of one step from a rocprofv3 kernel-trace CSV: start offset, duration, stream, name (kernels > min_us shown,
+runs of small ones summarised)."""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+step_idx = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+min_us = float(sys.argv[3]) if len(sys.argv) > 3 else 20.0
+ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:60], r.get('Queue_Id', '')) for r in rows)
+marks = [i for i, e in enumerate(ev) if 'k_field2_hand<3>' in e[2] or 'k_field2_hand<1>' in e[2]]
+a, b = marks[step_idx], marks[step_idx + 1]
+# start of step = first sdf-only hand kernel before the mark
+t0 = ev[a][0]
+small_n, small_t, small_start = 0, 0, None
+last_end = None
+for s, e, k, q in ev[a:b]:
+    d = (e - s) / 1e3
+    if d < min_us:
+        if small_n == 0:
+            small_start = s
+        small_n += 1
+        small_t += d
+        last_small_end = e
+        continue
+    if small_n:
+        print('  %9.1f us  [%3d small kernels, %.1f us busy, span %.1f us]' % ((small_start - t0) / 1e3, small_n, small_t, (last_small_end - small_start) / 1e3))
+        small_n, small_t = 0, 0
+    print('  %9.1f us  %8.1f us  q%s  %s' % ((s - t0) / 1e3, d, q, k))
+if small_n:
+    print('  %9.1f us  [%3d small kernels, %.1f us busy, span %.1f us]' % ((small_start - t0) / 1e3, small_n, small_t, (last_small_end - small_start) / 1e3))
+print('step span %.1f us' % ((ev[b][0] - t0) / 1e3))
