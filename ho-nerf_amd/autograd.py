@@ -188,9 +188,8 @@ class FitLossFn(torch.autograd.Function):
                 'hn_fit_loss_sums')
         ctx.save_for_backward(c, w, t, m, sums, *([sh, so] if sh is not None else []))
         ctx.shapes = (color.shape, wsum.shape, None if sdf_h is None else sdf_h.shape)
-        den = torch.stack([sums.new_tensor(float(R)), sums.new_tensor(float(R)), sums[3] + 1e-9, sums[5] + 1e-9])
-        out = sums[[0, 1, 2, 4]] / den
-        return out[0], out[1], out[2], out[3]
+        # views and two divisions: nothing here creates a tensor from host data (that would be a synchronising copy)
+        return sums[0], sums[1], sums[2] / (sums[3] + 1e-9), sums[4] / (sums[5] + 1e-9)
 
     @staticmethod
     def backward(ctx, g_c, g_m, g_ct, g_p):
@@ -200,8 +199,10 @@ class FitLossFn(torch.autograd.Function):
         c, w, t, m, sums = sv[:5]
         sh, so = (sv[5], sv[6]) if len(sv) > 5 else (None, None)
         dev = c.device
-        z = torch.zeros((), device=dev)
-        g4 = torch.stack([z if g is None else g.to(torch.float32) for g in (g_c, g_m, g_ct, g_p)]).contiguous()
+        g4 = torch.zeros(4, device=dev)
+        for k, gk in enumerate((g_c, g_m, g_ct, g_p)):
+            if gk is not None:
+                g4[k] = gk
         R, n = c.shape[0], 0 if sh is None else sh.shape[0]
         gc, gw = _empty(R, 3, dev=dev), _empty(R, dev=dev)
         gsh = _empty(n, dev=dev) if sh is not None else None

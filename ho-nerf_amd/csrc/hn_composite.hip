@@ -590,7 +590,8 @@ int composite2_bwd(const float* ah, const float* rgbh, const float* ao, const fl
 // ---- render-dependent loss terms of a fitting step (fitting_single.py:251-283; fitting_video.py:285-309) ------------
 // colour: sum |(color - true_rgb) mask| / R;  mask: mean BCE(clip(weight_sum, 1e-3, 1 - 1e-3), mask);  contact: mean of
 // |s_h| + |s_o| where that sum < 1e-2;  penetration: mean of the same over s_o < 0 and s_h < 0.  One launch for the
-// sums (sums[6] = colour, bce, contact sum, contact count, penetration sum, penetration count; zeroed here) and one for
+// sums (sums[6] = colour loss, bce loss (both already / R), contact sum, contact count, penetration sum, penetration
+// count; zeroed here) and one for
 // all four gradients, instead of ~35 + ~50 element-wise launches in a step that is a chain of dependent launches.
 __global__ void k_fit_loss_sums(const float* __restrict__ color, const float* __restrict__ wsum, const float* __restrict__ true_rgb,
                                 const float* __restrict__ true_mask, int n_rays, const float* __restrict__ sdf_h,
@@ -598,11 +599,12 @@ __global__ void k_fit_loss_sums(const float* __restrict__ color, const float* __
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i < n_rays) {
-        const float m = true_mask[i];
+        const float m = true_mask[i], inv = 1.f / (float)n_rays;
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[0] += fabsf((color[3 * (size_t)i + c] - true_rgb[3 * (size_t)i + c]) * m);
         const float w = fminf(fmaxf(wsum[i], 1e-3f), 1.f - 1e-3f);
-        v[1] = -(m * logf(w) + (1.f - m) * logf(1.f - w));
+        v[0] *= inv;
+        v[1] = -(m * logf(w) + (1.f - m) * logf(1.f - w)) * inv;
     }
     if (sdf_h != nullptr && i < n_samples) {
         const float sh = sdf_h[i], so = sdf_o[i];

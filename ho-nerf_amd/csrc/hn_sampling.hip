@@ -317,6 +317,82 @@ __global__ __launch_bounds__(64) void k_upsample(const float* __restrict__ z, co
     }
 }
 
+// One WAVE per ray, for the small batches of the fitting loops (196 rays: thread-per-ray leaves 252 of 256 CUs idle and
+// walks ~100 dependent steps of two exps each, ~50 us).  The element-wise part (slopes, the two sigmoids, alpha) is
+// computed by all lanes; the two prefix recurrences stay strictly sequential in lane 0, in the same order and with the
+// same operations as above (torch.cumprod / torch.cumsum order: the sample indices must not change), and the 16
+// inversions run one per lane.  Same results bit for bit as k_upsample / k_upsample_direct.
+__global__ __launch_bounds__(256) void k_upsample_wave(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays, int k,
+                                                       int n_new, float inv_s, float* __restrict__ z_new,
+                                                       int64_t* __restrict__ inds_out) {
+    __shared__ float lz[4][UPS_MAX_K], ls[4][UPS_MAX_K], lw[4][UPS_MAX_K];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    if (ray >= n_rays) return;
+    float* zr = lz[wv];
+    float* sr = ls[wv];
+    float* wr = lw[wv];
+    for (int i = lane; i < k; i += 64) {
+        zr[i] = z[(size_t)ray * k + i];
+        sr[i] = sdf[(size_t)ray * k + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // alpha of section i (element-wise in the reference too: utils/renderer.py:68-81)
+    for (int i = lane; i + 1 < k; i += 64) {
+        const float z0 = zr[i], z1 = zr[i + 1], s0 = sr[i], s1 = sr[i + 1];
+        const float mid_sdf = (s0 + s1) * 0.5f;
+        const float cosv = (s1 - s0) / (z1 - z0 + 1e-5f);
+        const float prev_cos = i > 0 ? (s0 - sr[i - 1]) / (z0 - zr[i - 1] + 1e-5f) : 0.f;
+        float c = fminf(prev_cos, cosv);
+        c = fminf(fmaxf(c, -1e3f), 0.f);
+        const float dist = z1 - z0;
+        const float prev_cdf = sigmoid_acc((mid_sdf - c * dist * 0.5f) * inv_s);
+        const float next_cdf = sigmoid_acc((mid_sdf + c * dist * 0.5f) * inv_s);
+        wr[i + 1] = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float sum = 0.f;
+    if (lane == 0) {   // sequential transmittance and weight sum (torch.cumprod / sum order)
+        float T = 1.f;
+        for (int i = 0; i + 1 < k; ++i) {
+            const float alpha = wr[i + 1];
+            const float w = alpha * T + 1e-5f;
+            T = T * (1.f - alpha + 1e-7f);
+            wr[i + 1] = w;
+            sum += w;
+        }
+    }
+    sum = __shfl(sum, 0, 64);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 1 + lane; i < k; i += 64) wr[i] = wr[i] / sum;   // pdf (element-wise)
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {   // cdf = [0, cumsum(pdf)], sequential
+        wr[0] = 0.f;
+        float run = 0.f;
+        for (int i = 1; i < k; ++i) {
+            run += wr[i];
+            wr[i] = run;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float u_start = 0.f + 0.5f / (float)n_new, u_end = 1.f - 0.5f / (float)n_new;
+    const float u_step = n_new > 1 ? (u_end - u_start) / (float)(n_new - 1) : 0.f;
+    for (int jj = lane; jj < n_new; jj += 64) {
+        const float u = (jj < n_new / 2) ? u_start + (float)jj * u_step : u_end - (float)(n_new - 1 - jj) * u_step;
+        int ptr = 0;   // searchsorted(right=True) on a non-decreasing cdf: the number of entries <= u
+        while (ptr < k && wr[ptr] <= u) ++ptr;
+        const int below = ptr - 1 > 0 ? ptr - 1 : 0;
+        const int above = ptr < k - 1 ? ptr : k - 1;
+        const float c_lo = wr[below], c_hi = wr[above];
+        const float b_lo = zr[below], b_hi = zr[above];
+        float denom = c_hi - c_lo;
+        denom = denom < 1e-5f ? 1.f : denom;
+        const float t = (u - c_lo) / denom;
+        z_new[(size_t)ray * n_new + jj] = b_lo + t * (b_hi - b_lo);
+        if (inds_out != nullptr) inds_out[(size_t)ray * n_new + jj] = ptr;
+    }
+}
+
 // ---- cat_z_vals (utils/renderer.py:88-105): stable merge of two sorted rows ----------------------
 __global__ void k_merge_serial(const float* __restrict__ z, const float* __restrict__ z_new, const float* __restrict__ sdf,
                         const float* __restrict__ sdf_new, int n_rays, int k, int m, int quirk_p,
@@ -493,6 +569,11 @@ int upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, flo
              hipStream_t s) {
     HN_REQUIRE(k >= 2 && k <= UPS_MAX_K && n_new >= 1 && n_new <= 64, "upsample: k=%d n_new=%d out of range", k, n_new);
     if (n_rays == 0) return HN_OK;
+    if (n_rays <= 8192) {   // small batches (the fitting loops): one wave per ray
+        hipLaunchKernelGGL(k_upsample_wave, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, sdf, n_rays, k, n_new, inv_s, z_new, inds);
+        HN_LAUNCH_CHECK();
+        return HN_OK;
+    }
     if (k <= 64) {   // staged: 2 x 64 x (k+1) floats of LDS per wave; beyond 64 columns the occupancy loss outweighs it (measured)
         hipLaunchKernelGGL(k_upsample, grid1d(n_rays, 64), dim3(64), (size_t)2 * 64 * (k + 1) * sizeof(float), s, z, sdf,
                            n_rays, k, n_new, inv_s, z_new, inds);

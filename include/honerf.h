@@ -284,9 +284,9 @@ int hn_render_dual_aux_offsets(const hn_field* hand, const hn_field* obj, int n_
 /* The render-dependent loss terms of one fitting step (fitting_single.py:251-283; fitting_video.py:285-309): the sums
  * behind colour L1, mask BCE, contact and penetration in one launch, and their gradients w.r.t. the render outputs in
  * another.  color [R,3], weight_sum [R], true_rgb [R,3], true_mask [R]; sdf_hand, sdf_obj [n_samples] (both NULL: no
- * interaction terms).  sums6 (zeroed here) = {sum |(color - true_rgb) mask|, sum BCE(clip(weight_sum, 1e-3, 1 - 1e-3),
- * mask), contact sum, contact count, penetration sum, penetration count}; the losses are sums6[0] / R, sums6[1] / R,
- * sums6[2] / (sums6[3] + 1e-9), sums6[4] / (sums6[5] + 1e-9).  g4: device scalars, upstream gradients of those four
+ * interaction terms).  sums6 (zeroed here) = {sum |(color - true_rgb) mask| / R, sum BCE(clip(weight_sum, 1e-3,
+ * 1 - 1e-3), mask) / R, contact sum, contact count, penetration sum, penetration count}; the losses are sums6[0],
+ * sums6[1], sums6[2] / (sums6[3] + 1e-9), sums6[4] / (sums6[5] + 1e-9).  g4: device scalars, upstream gradients of those four
  * losses. */
 int hn_fit_loss_sums(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays,
                      const float* sdf_hand, const float* sdf_obj, int n_samples, float* sums6, hn_stream_t stream);

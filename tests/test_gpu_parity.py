@@ -146,6 +146,13 @@ def test_upsample_merge_sort_golden(L, golden):
                 'upsample')
         bad = int((inds.cpu().numpy() != g['inds%d' % i]).sum())
         assert bad == 0, 'step %d: %d / %d searchsorted indices differ' % (i, bad, inds.numel())
+        # the same rows 100 times over (9 600 rays): beyond 8 192 rays the thread-per-ray kernels run instead of the
+        # wave-per-ray one -- identical indices and identical depths, bit for bit
+        zt, st_ = z.repeat(100, 1).contiguous(), sdf.repeat(100, 1).contiguous()
+        zn_t = torch.empty(100 * B, 16, device='cuda')
+        in_t = torch.empty(100 * B, 16, device='cuda', dtype=torch.int64)
+        L.check(lib.hn_upsample(L.ptr(zt), L.ptr(st_), 100 * B, k, 16, float(64 * 2 ** i), L.ptr(zn_t), L.ptr(in_t), st()), 'upsample')
+        assert torch.equal(in_t, inds.repeat(100, 1)) and torch.equal(zn_t, z_new.repeat(100, 1)), 'upsample kernels disagree'
         # depths: 1e-4 (the lerp divides by cdf gaps down to 1e-5, which amplifies the last-ulp
         # differences between the device's and the host's expf); the indices above are exact
         assert_close(z_new, g['znew%d' % i], RT, 'z_new %d' % i)
