@@ -220,7 +220,7 @@ def pmc_traffic(kernel):
             d = json.load(open(path))
         except Exception:
             continue
-        if kernel in str(d.get('kernel')) and 'derived' in d and 'hbm_bytes_per_launch' in d['derived']:
+        if (kernel in str(d.get('kernel')) or kernel.replace('<1>', '<true>') in str(d.get('kernel'))) and 'derived' in d and 'hbm_bytes_per_launch' in d['derived']:
             best = (d['derived']['hbm_bytes_per_launch'], os.path.relpath(path, ROOT))
     return best
 
@@ -345,7 +345,7 @@ def main():
     if args.precision == 'f16x3':
         # three f16 MFMA products per fp32-equivalent product: the algorithmic rate is priced against a
         # third of the dense f16 MFMA peak (equivalently: issued MFMA FLOP/s against the full peak)
-        peak, kname, dtype = PEAK_F16_MFMA_TFLOPS / 3.0, 'hn::v2::k_field2_hand<true>', 'f16x3'
+        peak, kname, dtype = PEAK_F16_MFMA_TFLOPS / 3.0, 'hn::v2::k_field2_hand<1>', 'f16x3'
     else:
         peak, kname, dtype = PEAK_F32_MFMA_TFLOPS, 'hn::k_field_hand<true>', 'f32'
 
