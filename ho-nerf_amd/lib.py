@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libhonerf.so')
+LIB_PATH = os.environ.get('HONERF_LIB') or os.path.join(_HERE, 'libhonerf.so')   # HONERF_LIB: an A/B build (tools/)
 
 HN_FIELD_OBJ = 0
 HN_FIELD_HAND = 1

@@ -6,9 +6,10 @@ Tolerances (north star: 1e-4 relative fp32, sample indices bit-exact):
   * per-stage comparisons on identical inputs: 1e-4 of the tensor's max magnitude
     (`rel_err`), typically observed ~1e-6;
   * integer outputs (searchsorted inds, sort index): exact;
-  * whole renders WITH importance sampling compare at 2e-3: the sampler is
-    ill-conditioned (a 1e-7 change of an SDF value moves samples by ~1e-5, see
-    DESIGN.md), so those are additionally checked stage-wise on the oracle's depths.
+  * whole renders WITH importance sampling carry their own measured bounds (E2E below, <= 4x the
+    value observed on MI355X, profiles/r02/parity_report.json): the sampler is ill-conditioned (a 1e-7
+    change of an SDF value moves samples by ~1e-5), so those are additionally checked
+    stage-wise at 1e-4 on the reference's own depths.
 """
 import ctypes
 
@@ -27,14 +28,18 @@ RT = 1e-4
 # value moves samples by 1e-5, so the end-to-end figure measures sample placement, not arithmetic; the same renders
 # are held to 1e-4 stage-wise on the reference's own depths (test_render_core_on_reference_depths,
 # test_dual_core_on_reference_depths).  Each bound is <= 4x the value observed on MI355X (parity_report.json).
+# observed (max over both precisions):       obj 7.8e-5 / 7.8e-5 / 2.5e-6, hand 1.8e-4 / 8.0e-5 / 9.2e-6,
+#                                            dual 4.5e-5 / 2.4e-5 / 3.1e-5, dual batch 9.8e-5 / 8.2e-5 / 3.0e-4
 E2E = {
-    'obj_64_64': {'color_fine': 2e-3, 'weight_sum': 2e-3, 'gradient_error': 2e-3},
-    'hand_64_64': {'color_fine': 2e-3, 'weight_sum': 2e-3, 'gradient_error': 2e-3},
-    'dual': {'color_fine': 2e-3, 'weight_sum': 2e-3, 'sdf_obj': 2e-3},
-    'dual_batch': {'color_fine': 2e-3, 'weight_sum': 2e-3, 'sdf_obj': 2e-3},
+    'obj_64_64': {'color_fine': 3e-4, 'weight_sum': 3e-4, 'gradient_error': 1e-4},
+    'hand_64_64': {'color_fine': 7e-4, 'weight_sum': 3e-4, 'gradient_error': 1e-4},
+    'dual': {'color_fine': 2e-4, 'weight_sum': 1e-4, 'sdf_obj': 1.2e-4},
+    'dual_batch': {'color_fine': 4e-4, 'weight_sum': 3.3e-4, 'sdf_obj': 1.2e-3},
 }
-E2E_GRAD = 6e-2            # gradients through our own importance-sampled depths vs the reference's gradients
-REF_DEPTH_GRAD = {'rays_o': 5e-3, 'rays_d': 5e-3, 'Ro': 5e-3, 'To': 5e-3, 'bt_inv': 5e-3}   # same, on the reference's depths
+E2E_GRAD = 6e-2            # gradients through our own importance-sampled depths vs the reference's gradients (observed 3.6e-2;
+                           # fp32 autograd of the oracle is itself 3e-2 from float64 here: test_dual_render_backward_coarse_only)
+# the same on the reference's depths (observed 3.4e-4, 3.4e-4, 1.2e-5, 2.3e-5, 4.6e-4)
+REF_DEPTH_GRAD = {'rays_o': 1.4e-3, 'rays_d': 1.4e-3, 'Ro': 1e-4, 'To': 1e-4, 'bt_inv': 1.9e-3}
 
 
 @pytest.fixture(scope='module')
@@ -446,8 +451,8 @@ def test_dual_core_on_reference_depths(golden, name, prec):
                               L.ptr(color), L.ptr(ws), None, None, L.ptr(eik), st()), 'composite2')
     assert_close(color.reshape(g['color_fine'].shape), g['color_fine'], RT, name + ' colour')
     assert_close(ws.reshape(g['weight_sum'].shape), g['weight_sum'], RT, name + ' weight_sum')
-    assert_close(eik[0] / (N * S), g['gradient_error_hand'], 5e-4, name + ' gradient_error_hand')
-    assert_close(eik[1] / (N * S), g['gradient_error_obj'], 2e-4, name + ' gradient_error_obj')
+    assert_close(eik[0] / (N * S), g['gradient_error_hand'], RT, name + ' gradient_error_hand')
+    assert_close(eik[1] / (N * S), g['gradient_error_obj'], RT, name + ' gradient_error_obj')
 
 
 def test_render_dual_golden(golden, prec):
@@ -837,9 +842,9 @@ def test_dual_render_backward_coarse_only():
         got = sel(name, dl[i].grad).detach().cpu().numpy()
         e_ref, e_ex = rel_err(got, sel(name, ref[i]).numpy()), rel_err(got, sel(name, ex[i]).numpy())
         from helpers import record
-        record('coarse-only d loss / d %s: hip vs fp32 autograd of the oracle' % name, e_ref, 1e-3, kind='rel, conditioning-aware',
+        record('coarse-only d loss / d %s: hip vs fp32 autograd of the oracle' % name, e_ref, 1e-4, kind='rel, conditioning-aware',
                hip_vs_fp64=e_ex, ref32_vs_fp64=rel_err(sel(name, ref[i]).numpy(), sel(name, ex[i]).numpy()))
-        assert e_ref < 1e-3 or e_ex < max(worst, 1e-2), 'd loss / d %s: %.3e / %.3e' % (name, e_ref, e_ex)
+        assert e_ref < 1e-4 or e_ex < max(worst, 1e-2), 'd loss / d %s: %.3e / %.3e' % (name, e_ref, e_ex)   # observed e_ref 2.7e-5
 
 
 def test_dual_render_backward_reference_golden(golden):
@@ -853,7 +858,7 @@ def test_dual_render_backward_reference_golden(golden):
                      leaves['Ro'], leaves['To'], t_rand=cu(g['t_rand']))
     loss = ((out['color_fine'] * cu(g['w_color'])).sum() + (out['weight_sum'] * cu(g['w_wsum'])).sum()
             + (out['sdf_hand'] * cu(g['w_sdf_hand'])).sum() + (out['sdf_obj'] * cu(g['w_sdf_obj'])).sum())
-    assert abs(float(loss) - float(g['loss'])) <= 2e-3 * abs(float(g['loss'])) + 1e-4
+    bounded('loss of the dual render vs the reference (end to end)', abs(float(loss.detach()) - float(g['loss'])) / abs(float(g['loss'])), 2e-3)
     loss.backward()
     for k in ('rays_o', 'rays_d', 'Ro', 'To'):
         e = rel_err(leaves[k].grad.detach().cpu().numpy(), g['g_' + k])
@@ -911,7 +916,7 @@ def test_dual_render_batch_backward(golden):
         if name == 'bt_inv':
             got, want = got[:, :, :3, :], want[:, :, :3, :]
         e = rel_err(got, want)
-        bounded('batched d loss / d %s vs fp32 autograd of the oracle' % name, e, 3e-3)
+        bounded('batched d loss / d %s vs fp32 autograd of the oracle' % name, e, 5e-4)   # observed 1.3e-4
 
 
 def test_pose_optimisation_recovers_object_translation():

@@ -45,7 +45,7 @@ def test_render_core_dict(golden, kind):
     assert_close(core['weights'], g['weights'], tol, kind + ' render_core weights')
     assert_close(core['cdf'], g['cdf_fine'], tol, kind + ' render_core cdf')
     assert_close(core['s_val'][:B], g['s_val'], RT, kind + ' render_core s_val')
-    assert_close(core['gradient_error'], g['gradient_error'], 5e-4 if kind == 'hand' else RT, kind + ' render_core gradient_error')
+    assert_close(core['gradient_error'], g['gradient_error'], RT, kind + ' render_core gradient_error')
 
 
 def test_convert_obj_to_local_matches_formula():
@@ -109,17 +109,17 @@ def test_get_alpha_sample_color_method(golden, name):
         ren.batch_size, ren.pixel_sample = z.shape[0], z.shape[1]
     a, c, s, ge, gr = ren.get_alpha_sample_color(o, d, g['bt_inv'], g['T_pose'], z, sample_dist, 'hand')
     assert a.shape == g['alpha_hand'].shape and c.shape == g['rgb_hand'].shape and s.shape == g['sdf_hand'].shape
-    assert_close(a, g['alpha_hand'], 3e-4, name + ' alpha_hand')          # hand noise floor, see test_gpu_parity
+    assert_close(a, g['alpha_hand'], 2e-4, name + ' alpha_hand')          # observed 4.9e-5; hand noise floor, see test_gpu_parity
     assert_close(c, g['rgb_hand'], 2e-3, name + ' rgb_hand')
     assert_close(s, g['sdf_hand'], RT, name + ' sdf_hand')
-    assert_close(ge, g['gradient_error_hand'], 5e-4, name + ' gradient_error_hand')
+    assert_close(ge, g['gradient_error_hand'], RT, name + ' gradient_error_hand')
     ol, dl = ren.convert_obj_to_local(o, d, g['Ro'], g['To'])
     a, c, s, ge, gr = ren.get_alpha_sample_color(ol, dl, g['bt_inv'], g['T_pose'], z, sample_dist, 'obj')
     assert_close(a, g['alpha_obj'], RT, name + ' alpha_obj')
     assert_close(c, g['rgb_obj'], RT, name + ' rgb_obj')
     assert_close(s, g['sdf_obj'], RT, name + ' sdf_obj')
     assert_close(gr, g['gradient_obj'], RT, name + ' gradient_obj')
-    assert_close(ge, g['gradient_error_obj'], 2e-4, name + ' gradient_error_obj')
+    assert_close(ge, g['gradient_error_obj'], RT, name + ' gradient_error_obj')
 
 
 def test_module_calls_obj(golden):
@@ -158,7 +158,7 @@ def test_module_calls_hand(golden):
     assert_close(h, g['h'], RT, 'SDFNetwork.forward h')
     assert_close(m['sdf_hand'].sdf(pts, g['bt_inv'], g['T_pose']), g['out'][:, :1], RT, 'SDFNetwork.sdf')
     grad = m['sdf_hand'].gradient(pts, g['bt_inv'], g['T_pose'])
-    assert_close(grad.squeeze(1), g['grad'], 1e-3, 'SDFNetwork.gradient')      # conditioning: see assert_parity in test_gpu_parity
+    assert_close(grad.squeeze(1), g['grad'], RT, 'SDFNetwork.gradient')
     rgb = m['color_hand'](cu(g['dirs']), X, cu(g['out'][:, 1:]), h, cu(g['grad']), 0)
     assert_close(rgb, g['rgb'], RT, 'RenderingNetwork.forward')
 
@@ -239,9 +239,9 @@ def test_stable_loss_cross(golden, strict):
     if strict:
         assert_close(loss, g['stable'], RT, 'stable loss')
         loss.backward()
-        assert_close(bt.grad[:, :, :3, :], g['g_bt_inv'][:, :, :3, :], 1e-3, 'stable d/d bt_inv')
-        assert_close(R.grad, g['g_obj_r'], 1e-3, 'stable d/d obj_r')
-        assert_close(T.grad, g['g_obj_t'], 1e-3, 'stable d/d obj_t')
+        assert_close(bt.grad[:, :, :3, :], g['g_bt_inv'][:, :, :3, :], 4.4e-4, 'stable d/d bt_inv')      # observed 1.1e-4
+        assert_close(R.grad, g['g_obj_r'], 3.5e-4, 'stable d/d obj_r')                                   # 8.7e-5
+        assert_close(T.grad, g['g_obj_t'], 3.1e-4, 'stable d/d obj_t')                                   # 7.7e-5
     else:
         sdf = t(g['hand_sdf'])
         pts = t(g['obj_verts'])[0, ::10]
