@@ -46,6 +46,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// One atomic per BLOCK for the eikonal sums: float atomics on a single address are served one at a time by the memory
+// side (~12 ns each); with one per wave the 16 384 waves of a 262 144-ray launch alone took ~200 us, whatever S was.
+__device__ __forceinline__ void block_atomic_add(float* dst, float wave_total) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) part[wv] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dst, part[0] + part[1] + part[2] + part[3]);
+    __syncthreads();
+}
+
 // single field: w_k = alpha_k * c_0 * prod_{j<k} (1 - alpha_j + 1e-7)
 __global__ __launch_bounds__(256) void k_composite1(const float* __restrict__ alpha, const float* __restrict__ c,
                                                     const float* __restrict__ rgb, const float* __restrict__ grad,
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(256) void k_composite1(const float* __restrict__ al
     }
     eik_total += eik;
     }
-    if (lane == 0 && eik_sum != nullptr && grad != nullptr) atomicAdd(eik_sum, eik_total);
+    if (eik_sum != nullptr && grad != nullptr) block_atomic_add(eik_sum, eik_total);
 }
 
 // two fields: T_k = prod_{j<k} (1 - a_h + 1e-7)(1 - a_o + 1e-7); w_h = a_h T, w_o = a_o T
@@ -167,9 +178,9 @@ __global__ __launch_bounds__(256) void k_composite2(const float* __restrict__ ah
     eh_total += eh;
     eo_total += eo;
     }
-    if (lane == 0 && eik_sum != nullptr) {
-        if (gh != nullptr) atomicAdd(eik_sum, eh_total);
-        if (go != nullptr) atomicAdd(eik_sum + 1, eo_total);
+    if (eik_sum != nullptr) {
+        if (gh != nullptr) block_atomic_add(eik_sum, eh_total);
+        if (go != nullptr) block_atomic_add(eik_sum + 1, eo_total);
     }
 }
 
@@ -229,58 +240,95 @@ __device__ __forceinline__ float wave_sum_rows(float v) {   // v is already a ro
     return v;
 }
 
-template <int CPS>
+// sum / max over a group of LPR (8 or 16) consecutive lanes, result in every lane of the group: xor butterflies as DPP
+// (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140): VALU only
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+    v += dpp<0xB1>(0.f, v);
+    v += dpp<0x4E>(0.f, v);
+    v += dpp<0x141>(0.f, v);
+    if (LPR == 16) v += dpp<0x140>(0.f, v);
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, dpp<0xB1>(0.f, v));
+    v = fmaxf(v, dpp<0x4E>(0.f, v));
+    v = fmaxf(v, dpp<0x141>(0.f, v));
+    if (LPR == 16) v = fmaxf(v, dpp<0x140>(0.f, v));
+    return v;
+}
+// exclusive product scan over the group (lane l of the group gets the product of lanes 0 .. l-1; lane 0 gets 1)
+template <int LPR>
+__device__ __forceinline__ float group_excl_prod(float v, int l) {
+    float t;
+    t = dpp<0x111>(1.f, v);
+    v *= (LPR == 16 || l >= 1) ? t : 1.f;
+    t = dpp<0x112>(1.f, v);
+    v *= (LPR == 16 || l >= 2) ? t : 1.f;
+    t = dpp<0x114>(1.f, v);
+    v *= (LPR == 16 || l >= 4) ? t : 1.f;
+    if (LPR == 16) v *= dpp<0x118>(1.f, v);
+    t = dpp<0x111>(1.f, v);          // shift the inclusive scan by one lane
+    return l >= 1 ? t : 1.f;
+}
+template <int N>
+__device__ __forceinline__ float eik_run(const float (&x)[3 * N]) {
+    float e = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float nrm = sqrtf(x[3 * i] * x[3 * i] + x[3 * i + 1] * x[3 * i + 1] + x[3 * i + 2] * x[3 * i + 2]) - 1.f;
+        e += nrm * nrm;
+    }
+    return e;
+}
+
+// LPR lanes per ray, CPS consecutive samples per lane (S = LPR * CPS), 64 / LPR rays per wave.  Every load of an
+// iteration is issued before the first use (16 bytes per lane each; 7 CPS / 4 of them per lane are in flight), the
+// transmittance is a sequential product inside the lane, an exclusive product scan over the group and group sums, all
+// DPP.  (Round 1 loaded rgb / grad after the scan: 0.39 - 0.57 of the HBM peak; the loads first: see profiles/r02.)
+template <int CPS, int LPR>
 __global__ __launch_bounds__(256) void k_composite1_rows(const float* __restrict__ alpha, const float* __restrict__ c,
                                                          const float* __restrict__ rgb, const float* __restrict__ grad,
                                                          int n_rays, float* __restrict__ color, float* __restrict__ weights,
                                                          float* __restrict__ weight_sum, float* __restrict__ weight_max,
                                                          float* __restrict__ eik_sum) {
-    constexpr int S = 16 * CPS;
-    const int lane = threadIdx.x & 63, l = lane & 15, row = lane >> 4;
+    constexpr int S = LPR * CPS, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, l = lane & (LPR - 1), row = lane / LPR;
     float eik_total = 0.f;
-    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g * 4 < n_rays; g += gridDim.x * 4) {
-        const int ray = g * 4 + row;
+    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g * RPW < n_rays; g += gridDim.x * 4) {
+        const int ray = g * RPW + row;
         const bool ok = ray < n_rays;
-        const size_t base = (size_t)(ok ? ray : n_rays - 1) * S + l * CPS;
-        float a[CPS], w[CPS], x[3 * CPS];
+        const size_t rbase = (size_t)(ok ? ray : n_rays - 1) * S;
+        const size_t base = rbase + l * CPS;
+        float a[CPS], w[CPS], x[3 * CPS], y[3 * CPS];
         load_run<CPS>(alpha + base, a);
+        load_run<3 * CPS>(rgb + 3 * base, x);
+        if (grad != nullptr) load_run<3 * CPS>(grad + 3 * base, y);
+        const float c0 = c[rbase];   // SURVEY B-3: the first factor is c_0, not 1
         float P = 1.f;
 #pragma unroll
         for (int i = 0; i < CPS; ++i) P *= 1.f - a[i] + 1e-7f;
-        const float incl = row_incl_prod(P);
-        float excl = dpp<0x111>(1.f, incl);                       // row_shr:1, lane 0 of the row keeps 1
-        float T = c[(size_t)(ok ? ray : n_rays - 1) * S] * excl;   // SURVEY B-3: the first factor is c_0, not 1
+        float T = c0 * group_excl_prod<LPR>(P, l);
         float wsum = 0.f, wmax = -1.f;
+        float col[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < CPS; ++i) {
             w[i] = a[i] * T;
             T *= 1.f - a[i] + 1e-7f;
             wsum += w[i];
             wmax = fmaxf(wmax, w[i]);
-        }
-        if (ok && weights != nullptr) store_run<CPS>(weights + base, w);
-        load_run<3 * CPS>(rgb + 3 * base, x);
-        float col[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < CPS; ++i) {
             col[0] += w[i] * x[3 * i];
             col[1] += w[i] * x[3 * i + 1];
             col[2] += w[i] * x[3 * i + 2];
         }
-        float eik = 0.f;
-        if (grad != nullptr) {
-            load_run<3 * CPS>(grad + 3 * base, x);
-#pragma unroll
-            for (int i = 0; i < CPS; ++i) {
-                const float nrm = sqrtf(x[3 * i] * x[3 * i] + x[3 * i + 1] * x[3 * i + 1] + x[3 * i + 2] * x[3 * i + 2]) - 1.f;
-                eik += nrm * nrm;
-            }
-        }
-        col[0] = row_sum(col[0]);
-        col[1] = row_sum(col[1]);
-        col[2] = row_sum(col[2]);
-        wsum = row_sum(wsum);
-        wmax = row_max(wmax);
+        if (ok && weights != nullptr) store_run<CPS>(weights + base, w);
+        const float eik = grad != nullptr ? eik_run<CPS>(y) : 0.f;
+        col[0] = group_sum<LPR>(col[0]);
+        col[1] = group_sum<LPR>(col[1]);
+        col[2] = group_sum<LPR>(col[2]);
+        wsum = group_sum<LPR>(wsum);
+        wmax = group_max<LPR>(wmax);
         if (ok && l == 0) {
             color[3 * ray] = col[0];
             color[3 * ray + 1] = col[1];
@@ -290,80 +338,56 @@ __global__ __launch_bounds__(256) void k_composite1_rows(const float* __restrict
         }
         eik_total += ok ? eik : 0.f;
     }
-    if (eik_sum != nullptr && grad != nullptr) {
-        const float t = wave_sum_rows(row_sum(eik_total));
-        if (lane == 0) atomicAdd(eik_sum, t);
-    }
+    if (eik_sum != nullptr && grad != nullptr) block_atomic_add(eik_sum, wave_sum(eik_total));
 }
 
-template <int CPS>
+template <int CPS, int LPR>
 __global__ __launch_bounds__(256) void k_composite2_rows(const float* __restrict__ ah, const float* __restrict__ rgbh,
                                                          const float* __restrict__ gh, const float* __restrict__ ao,
                                                          const float* __restrict__ rgbo, const float* __restrict__ go,
                                                          int n_rays, float* __restrict__ color, float* __restrict__ weight_sum,
                                                          float* __restrict__ w_hand, float* __restrict__ w_obj,
                                                          float* __restrict__ eik_sum) {
-    constexpr int S = 16 * CPS;
-    const int lane = threadIdx.x & 63, l = lane & 15, row = lane >> 4;
+    constexpr int S = LPR * CPS, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, l = lane & (LPR - 1), row = lane / LPR;
     float eh_total = 0.f, eo_total = 0.f;
-    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g * 4 < n_rays; g += gridDim.x * 4) {
-        const int ray = g * 4 + row;
+    for (int g = blockIdx.x * 4 + (threadIdx.x >> 6); g * RPW < n_rays; g += gridDim.x * 4) {
+        const int ray = g * RPW + row;
         const bool ok = ray < n_rays;
         const size_t base = (size_t)(ok ? ray : n_rays - 1) * S + l * CPS;
-        float a1[CPS], a2[CPS], w1[CPS], w2[CPS], x[3 * CPS];
+        float a1[CPS], a2[CPS], w1[CPS], w2[CPS], x1[3 * CPS], x2[3 * CPS];
         load_run<CPS>(ah + base, a1);
         load_run<CPS>(ao + base, a2);
+        load_run<3 * CPS>(rgbh + 3 * base, x1);
+        load_run<3 * CPS>(rgbo + 3 * base, x2);
         float P = 1.f;
 #pragma unroll
         for (int i = 0; i < CPS; ++i) P *= (1.f - a1[i] + 1e-7f) * (1.f - a2[i] + 1e-7f);
-        const float incl = row_incl_prod(P);
-        float T = dpp<0x111>(1.f, incl);
+        float T = group_excl_prod<LPR>(P, l);
         float ws = 0.f;
+        float col[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < CPS; ++i) {
             w1[i] = a1[i] * T;
             w2[i] = a2[i] * T;
             T *= (1.f - a1[i] + 1e-7f) * (1.f - a2[i] + 1e-7f);
             ws += w1[i] + w2[i];
+            col[0] += w1[i] * x1[3 * i] + w2[i] * x2[3 * i];
+            col[1] += w1[i] * x1[3 * i + 1] + w2[i] * x2[3 * i + 1];
+            col[2] += w1[i] * x1[3 * i + 2] + w2[i] * x2[3 * i + 2];
         }
         if (ok && w_hand != nullptr) store_run<CPS>(w_hand + base, w1);
         if (ok && w_obj != nullptr) store_run<CPS>(w_obj + base, w2);
-        float col[3] = {0.f, 0.f, 0.f};
-        load_run<3 * CPS>(rgbh + 3 * base, x);
-#pragma unroll
-        for (int i = 0; i < CPS; ++i) {
-            col[0] += w1[i] * x[3 * i];
-            col[1] += w1[i] * x[3 * i + 1];
-            col[2] += w1[i] * x[3 * i + 2];
-        }
-        load_run<3 * CPS>(rgbo + 3 * base, x);
-#pragma unroll
-        for (int i = 0; i < CPS; ++i) {
-            col[0] += w2[i] * x[3 * i];
-            col[1] += w2[i] * x[3 * i + 1];
-            col[2] += w2[i] * x[3 * i + 2];
-        }
+        // the gradients (eikonal term) re-use the colour registers
         float eh = 0.f, eo = 0.f;
-        if (gh != nullptr) {
-            load_run<3 * CPS>(gh + 3 * base, x);
-#pragma unroll
-            for (int i = 0; i < CPS; ++i) {
-                const float nrm = sqrtf(x[3 * i] * x[3 * i] + x[3 * i + 1] * x[3 * i + 1] + x[3 * i + 2] * x[3 * i + 2]) - 1.f;
-                eh += nrm * nrm;
-            }
-        }
-        if (go != nullptr) {
-            load_run<3 * CPS>(go + 3 * base, x);
-#pragma unroll
-            for (int i = 0; i < CPS; ++i) {
-                const float nrm = sqrtf(x[3 * i] * x[3 * i] + x[3 * i + 1] * x[3 * i + 1] + x[3 * i + 2] * x[3 * i + 2]) - 1.f;
-                eo += nrm * nrm;
-            }
-        }
-        col[0] = row_sum(col[0]);
-        col[1] = row_sum(col[1]);
-        col[2] = row_sum(col[2]);
-        ws = row_sum(ws);
+        if (gh != nullptr) load_run<3 * CPS>(gh + 3 * base, x1);
+        if (go != nullptr) load_run<3 * CPS>(go + 3 * base, x2);
+        if (gh != nullptr) eh = eik_run<CPS>(x1);
+        if (go != nullptr) eo = eik_run<CPS>(x2);
+        col[0] = group_sum<LPR>(col[0]);
+        col[1] = group_sum<LPR>(col[1]);
+        col[2] = group_sum<LPR>(col[2]);
+        ws = group_sum<LPR>(ws);
         if (ok && l == 0) {
             color[3 * ray] = col[0];
             color[3 * ray + 1] = col[1];
@@ -374,14 +398,8 @@ __global__ __launch_bounds__(256) void k_composite2_rows(const float* __restrict
         eo_total += ok ? eo : 0.f;
     }
     if (eik_sum != nullptr) {
-        if (gh != nullptr) {
-            const float t = wave_sum_rows(row_sum(eh_total));
-            if (lane == 0) atomicAdd(eik_sum, t);
-        }
-        if (go != nullptr) {
-            const float t = wave_sum_rows(row_sum(eo_total));
-            if (lane == 0) atomicAdd(eik_sum + 1, t);
-        }
+        if (gh != nullptr) block_atomic_add(eik_sum, wave_sum(eh_total));
+        if (go != nullptr) block_atomic_add(eik_sum + 1, wave_sum(eo_total));
     }
 }
 
@@ -518,15 +536,23 @@ int composite1(const float* alpha_in, const float* c, const float* rgb, const fl
                float* color, float* weights, float* weight_sum, float* weight_max, float* eik_sum, hipStream_t s) {
     HN_REQUIRE(S >= 1, "S must be positive");
     if (n_rays == 0) return HN_OK;
-    const int groups = (n_rays + 3) / 4;   // the row kernels take 4 rays per wave
-    const dim3 rgrid((groups + 3) / 4 < 4096 ? (groups + 3) / 4 : 4096);
-    // measured at 262144 rays: the row form wins at S = 128 (267 vs 294 us) and loses at S = 64 (242 vs 197 us)
-    if (S == 128)
-        hipLaunchKernelGGL(k_composite1_rows<8>, rgrid, dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, color, weights, weight_sum,
-                           weight_max, eik_sum);
+    // row kernels: LPR lanes per ray (64 / LPR rays per wave), 4 waves per block
+    auto rgrid = [&](int lpr) {
+        const int groups = (n_rays + 64 / lpr - 1) / (64 / lpr);
+        return dim3((groups + 3) / 4 < 2048 ? (groups + 3) / 4 : 2048);
+    };
+    if (S == 64)
+        hipLaunchKernelGGL((k_composite1_rows<4, 16>), rgrid(16), dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, color, weights,
+                           weight_sum, weight_max, eik_sum);
+    else if (S == 128)
+        hipLaunchKernelGGL((k_composite1_rows<8, 16>), rgrid(16), dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, color, weights,
+                           weight_sum, weight_max, eik_sum);
     else if (S == 192)
-        hipLaunchKernelGGL(k_composite1_rows<12>, rgrid, dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, color, weights, weight_sum,
-                           weight_max, eik_sum);
+        hipLaunchKernelGGL((k_composite1_rows<12, 16>), rgrid(16), dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, color, weights,
+                           weight_sum, weight_max, eik_sum);
+    else if (S == 32)
+        hipLaunchKernelGGL((k_composite1_rows<4, 8>), rgrid(8), dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, color, weights,
+                           weight_sum, weight_max, eik_sum);
     else
         hipLaunchKernelGGL(k_composite1, dim3(composite_grid(n_rays)), dim3(256), 0, s, alpha_in, c, rgb, grad, n_rays, S, color,
                            weights, weight_sum, weight_max, eik_sum);
@@ -539,13 +565,18 @@ int composite2(const float* ah, const float* rgbh, const float* gh, const float*
                hipStream_t s) {
     HN_REQUIRE(S >= 1, "S must be positive");
     if (n_rays == 0) return HN_OK;
-    const int groups = (n_rays + 3) / 4;
-    const dim3 rgrid((groups + 3) / 4 < 4096 ? (groups + 3) / 4 : 4096);
-    if (S == 128)
-        hipLaunchKernelGGL(k_composite2_rows<8>, rgrid, dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, color, weight_sum,
+    auto rgrid = [&](int lpr) {
+        const int groups = (n_rays + 64 / lpr - 1) / (64 / lpr);
+        return dim3((groups + 3) / 4 < 2048 ? (groups + 3) / 4 : 2048);
+    };
+    if (S == 64)
+        hipLaunchKernelGGL((k_composite2_rows<4, 16>), rgrid(16), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, color, weight_sum,
+                           w_hand, w_obj, eik_sum);
+    else if (S == 128)
+        hipLaunchKernelGGL((k_composite2_rows<8, 16>), rgrid(16), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, color, weight_sum,
                            w_hand, w_obj, eik_sum);
     else if (S == 192)
-        hipLaunchKernelGGL(k_composite2_rows<12>, rgrid, dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, color, weight_sum,
+        hipLaunchKernelGGL((k_composite2_rows<12, 16>), rgrid(16), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, color, weight_sum,
                            w_hand, w_obj, eik_sum);
     else
         hipLaunchKernelGGL(k_composite2, dim3(composite_grid(n_rays)), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, S,

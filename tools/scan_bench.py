@@ -39,8 +39,9 @@ for S in (64, 128):
     report('hn_composite1 S=%d' % S, n * (4 + 4 + 12 + 12 + 4) + B * 20,
            lambda: L.check(lib.hn_composite1(L.ptr(a2), L.ptr(c), L.ptr(rgb), L.ptr(grad), B, S, L.ptr(color), L.ptr(w), L.ptr(ws_), L.ptr(wm), L.ptr(eik), st), 'c1'))
     w2 = torch.empty(n, device=dev)
+    rgb2, grad2 = rnd(n, 3), rnd(n, 3) - 0.5      # the second field's own arrays (re-using the first's would be served by L2)
     report('hn_composite2 S=%d' % S, n * 2 * (4 + 12 + 12 + 4) + B * 16,
-           lambda: L.check(lib.hn_composite2(L.ptr(a2), L.ptr(rgb), L.ptr(grad), L.ptr(alpha), L.ptr(rgb), L.ptr(grad), B, S, L.ptr(color), L.ptr(ws_), L.ptr(w), L.ptr(w2), L.ptr(eik), st), 'c2'))
+           lambda: L.check(lib.hn_composite2(L.ptr(a2), L.ptr(rgb), L.ptr(grad), L.ptr(alpha), L.ptr(rgb2), L.ptr(grad2), B, S, L.ptr(color), L.ptr(ws_), L.ptr(w), L.ptr(w2), L.ptr(eik), st), 'c2'))
     ro = rnd(B, 3)
     z = torch.sort(rnd(B, S) * 1.1 + 0.4, dim=-1)[0].contiguous()
     pts, dd = torch.empty(n, 3, device=dev), torch.empty(n, device=dev)
