@@ -584,6 +584,7 @@ int hn_field_destroy(hn_field* f) {
     if (f->v2_sdf != nullptr) (void)hipFree(f->v2_sdf);
     if (f->v2_adj != nullptr) (void)hipFree(f->v2_adj);
     if (f->v2_adjonly != nullptr) (void)hipFree(f->v2_adjonly);
+    if (f->v2_tape != nullptr) (void)hipFree(f->v2_tape);
     if (f->raw != nullptr) (void)hipFree(f->raw);
     delete f;
     return HN_OK;

@@ -67,6 +67,17 @@ constexpr int N_GROUPS = 6;       // 5 full groups + 1 bone in the last
 
 // accumulator-tile geometry of v_mfma_f32_32x32x2_f32: lane l holds column l&31;
 // register r of lane half h = l>>5 holds row (r&3) + 8*(r>>2) + 4*h.
+// MFMA shape of the f16x3 evaluation kernels (hn_mlp2.h, HN_MFMA16): which translation units / weight streams use
+// v_mfma_f32_16x16x32_f16.  The adjoint kernels and the taped evaluation that feeds them stay on 32x32x16.
+// Measured (round 2, profiles/r02/README.md): the hand evaluation kernel on 16x16x32 passes every parity test and takes
+// 357.7 ms on the C2 frame against 278.5 ms on 32x32x16 -- half the filler budget per MFMA gap and 448 spilled
+// registers -- so 32x32x16 stays the product; -DHN_HAND_EVAL_MFMA16=1 rebuilds the other arm.
+#ifndef HN_HAND_EVAL_MFMA16
+#define HN_HAND_EVAL_MFMA16 0
+#endif
+#ifndef HN_OBJ_EVAL_MFMA16
+#define HN_OBJ_EVAL_MFMA16 0
+#endif
 __host__ __device__ inline int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // One packed matrix: float4 fragments [out_tiles][steps/4][64 lanes].
@@ -112,6 +123,8 @@ struct hn_field {
     size_t v2_sdf_bytes = 0;
     void* v2_adj = nullptr;      // full evaluation followed by its adjoint (hn_field_eval_bwd)
     size_t v2_adj_bytes = 0;
+    void* v2_tape = nullptr;     // the taped evaluation's program where it differs from v2_full (other MFMA shape); else NULL
+    size_t v2_tape_bytes = 0;
     void* v2_adjonly = nullptr;  // the adjoint alone, from the tape a taped evaluation left (hn_render_dual / _bwd)
     size_t v2_adjonly_bytes = 0;
     // --- folded (weight-norm applied) weights and biases, row-major [out, in], for the adjoint (hn_field_bwd.hip)

@@ -12,6 +12,10 @@
 
 #include <atomic>
 
+#include "hn_common.h"
+#if !defined(HN_HAND_ADJ_TU) && !defined(HN_MFMA16)
+#define HN_MFMA16 HN_HAND_EVAL_MFMA16   // the evaluation kernels (MODE 0, 1); the adjoint translation unit keeps 32x32x16
+#endif
 #include "hn_mlp2.h"
 #ifndef HN_JAC_VARIANT
 #define HN_JAC_VARIANT 2
@@ -86,8 +90,9 @@ constexpr int STAGE_BYTES = 8 * 1024;        // LDS staging of one bone's 4 frag
 constexpr int HB_HID = chunk_bytes(1, 16, true);
 constexpr int HB_BWD = chunk_bytes(1, 16, false);
 constexpr int HB_BONE = chunk_bytes(4, 4, false);
-constexpr int HB_LEFT_T = chunk_bytes(4, 3, true);    // leftover chunk with the 4 biases (lin0)
-constexpr int HB_LEFT = chunk_bytes(4, 3, false);
+constexpr int KS_LEFT = S16 ? 4 : 3;                  // k-steps of the leftover block (16x16x32: pairs, the fourth is empty)
+constexpr int HB_LEFT_T = chunk_bytes(4, KS_LEFT, true);    // leftover chunk with the 4 biases (lin0)
+constexpr int HB_LEFT = chunk_bytes(4, KS_LEFT, false);
 constexpr int HB_G = chunk_bytes(4, 2, true);         // colour lin0: enc(g) columns + the 4 biases
 constexpr int HB_W4ROWS = 3 * TAIL_BYTES;             // adjoint: the three rows of colour lin4, one tail-format KiB each
 
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     ws.init(a.blob, a.blob_bytes, lds, wave, lane);
     char* const stage = lds + 2 * CHUNK_MAX + wave * STAGE_BYTES;   // per-wave staging of one bone's fragments
     ws.dbg_nofetch = (HN_DBG(a) & 4) ? 1 : 0;
-    if ((int)blockIdx.x < n_tiles) ws.fetch_all(FIRST_CHUNK);
+    if ((int)blockIdx.x < n_tiles) ws.template fetch_all_c<FIRST_CHUNK>();
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const bool more = tile + (int)gridDim.x < n_tiles;
@@ -373,26 +378,36 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 nz |= 1u << b;
                 float f[4][8];
                 bone_features2(bn, h, f);
+                h8 fh[4], fl[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    h8 fh, fl;
-                    split8(f[s], fh, fl);
-                    sh.frag_store(FEAT, 4 * b + s, fh, fl);
+                for (int s = 0; s < 4; ++s) split8(f[s], fh[s], fl[s]);
+#pragma unroll
+                for (int s = 0; s < 4; s += 2) {   // (16x16x32: k-step pairs -> the two column blocks' fragments)
+                    frags_in(fh[s], fh[s + 1]);
+                    frags_in(fl[s], fl[s + 1]);
                 }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) sh.frag_store(FEAT, 4 * b + s, fh[s], fl[s]);
             }
             sh.f32_store(LEFT + b * 256, any ? (h ? bn.r[2] : bn.r[1]) * bn.hh : 0.f);
         }
         nz = __builtin_amdgcn_readfirstlane(nz);
         {   // leftover block: element j of k-step u belongs to bone 8u + j
+            h8 fh[4], fl[4];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 float f[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) f[jj] = (8 * u + jj < N_BONES) ? sh.f32_load(LEFT + (8 * u + jj) * 256) : 0.f;
-                h8 fh, fl;
-                split8(f, fh, fl);
-                sh.frag_store(FEAT, FEAT_BLOCKS + u, fh, fl);
+                for (int jj = 0; jj < 8; ++jj) f[jj] = (u < 3 && 8 * u + jj < N_BONES) ? sh.f32_load(LEFT + (8 * u + jj) * 256) : 0.f;
+                split8(f, fh[u], fl[u]);
             }
+#pragma unroll
+            for (int u = 0; u < 4; u += 2) {
+                frags_in(fh[u], fh[u + 1]);
+                frags_in(fl[u], fl[u + 1]);
+            }
+#pragma unroll
+            for (int u = 0; u < KS_LEFT; ++u) sh.frag_store(FEAT, FEAT_BLOCKS + u, fh[u], fl[u]);
         }
         if constexpr (ADJ) sh.f32_store(NZ_OFF, __builtin_bit_cast(float, nz));
         }   // RUN_FWD
@@ -478,8 +493,9 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 }
             }
         };
-        auto feature_pass = [&](auto NB_, auto BIAS_, auto& c1, auto& c2, int left_bytes, int next_after) {
+        auto feature_pass = [&](auto NB_, auto BIAS_, auto& c1, auto& c2, auto LB_, auto NA_) {
             constexpr int NB = decltype(NB_)::value;
+            constexpr int left_bytes = decltype(LB_)::value, next_after = decltype(NA_)::value;   // chunk sizes: constants
             constexpr bool BIAS = decltype(BIAS_)::value;
             h8 fh[2][4], fl[2][4];
             // bone b's NB chunks (fragments in uh/ul); the last one prefetches the first chunk of bone nb (the next
@@ -489,14 +505,28 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 static_for<NB>([&](auto BLK) {
                     constexpr int blk = decltype(BLK)::value;
                     const char* buf = ws.template acquire<0>();
-                    if constexpr (blk + 1 < NB) {
-                        ws.begin(HB_BONE);
-                    } else {
-                        ws.goff = base + nb * (NB * HB_BONE);
-                        ws.begin(nb < N_BONES ? HB_BONE : left_bytes);
-                    }
                     if constexpr (blk == 0) load_bone(nb, nh, nl);   // nb == 21: the leftover blocks 84..86
-                    mma_chunk<4, 4>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);   // one pipeline over the 16 blocks
+                    if constexpr (blk + 1 < NB) {
+                        ws.template begin_c<HB_BONE>();
+                        mma_chunk<4, 4, HB_BONE>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);   // one pipeline over the 16 blocks
+                    } else if constexpr (left_bytes <= HB_BONE) {
+                        // the first leftover chunk (nb == 21) is shorter than a bone chunk: fetched at the bone size all
+                        // the same (the size stays a constant; 7 - 8 KiB of the following chunk come along unused)
+                        ws.goff = base + nb * (NB * HB_BONE);
+                        ws.template begin_c<HB_BONE>();
+                        if (nb >= N_BONES) ws.goff += left_bytes - HB_BONE;
+                        mma_chunk<4, 4, HB_BONE>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);
+                    } else {
+                        // (16x16x32: the leftover chunk has four k-steps and is the longer one when it carries a tail)
+                        ws.goff = base + nb * (NB * HB_BONE);
+                        if (nb < N_BONES) {
+                            ws.template begin_c<HB_BONE>();
+                            mma_chunk<4, 4, HB_BONE>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);
+                        } else {
+                            ws.template begin_c<left_bytes>();
+                            mma_chunk<4, 4, left_bytes>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);
+                        }
+                    }
                 });
             };
             load_bone(0, fh[0], fl[0]);
@@ -529,15 +559,16 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             static_for<NB>([&](auto BLK) {
                 constexpr int blk = decltype(BLK)::value;
                 const char* buf = ws.template acquire<0>();
-                ws.begin(blk + 1 < NB ? left_bytes : next_after);
+                constexpr int nbytes = blk + 1 < NB ? left_bytes : next_after;
+                ws.template begin_c<nbytes>();
                 static_for<4>([&](auto TI) {
                     constexpr int ti = decltype(TI)::value;
                     if constexpr (ti == 0)
-                        mma_tile<3, 0, true>(ws, buf + ti * 3 * KS_BYTES, fh[0], fl[0], c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                        mma_tile<KS_LEFT, 0, nbytes>(ws, buf + ti * KS_LEFT * KS_BYTES, fh[0], fl[0], c1[4 * blk + ti], c2[4 * blk + ti], lane);
                     else
-                        mma_tile<3, 0, false>(ws, buf + ti * 3 * KS_BYTES, fh[0], fl[0], c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                        mma_tile<KS_LEFT, 0, 0>(ws, buf + ti * KS_LEFT * KS_BYTES, fh[0], fl[0], c1[4 * blk + ti], c2[4 * blk + ti], lane);
                     if constexpr (BIAS) {
-                        const f32x16 bias = tail_tile(buf + 4 * 3 * KS_BYTES, ti, h);
+                        const f32x16 bias = tail_tile(buf + 4 * KS_LEFT * KS_BYTES, ti, h);
 #pragma unroll
                         for (int i = 0; i < 16; ++i) c1[4 * blk + ti][i] += bias[i];
                     }
@@ -565,7 +596,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         using BTrue = std::integral_constant<bool, true>;
         using BFalse = std::integral_constant<bool, false>;
 
-        float g[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
+        float g[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f}, rgb1[3] = {0.f, 0.f, 0.f};
         float sdf = 0.f;
         if constexpr (!RUN_FWD) {   // the adjoint alone: the evaluation's outputs come from the forward launch
 #pragma unroll
@@ -582,13 +613,13 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 c1[ti] = zero16();
                 c2[ti] = zero16();
             }
-            feature_pass(I2{}, BTrue{}, c1, c2, HB_LEFT_T, HB_HID);
+            feature_pass(I2{}, BTrue{}, c1, c2, std::integral_constant<int, HB_LEFT_T>{}, std::integral_constant<int, HB_HID>{});
             block_epilogue(I8t{}, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 0));
         }
-        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 1), no_store);   // lin1
-        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 2), no_store);   // lin2
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 1), no_store);   // lin1
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 2), no_store);   // lin2
         // lin3 -> a4: kept as fragments in the stash too (lin4's hidden part reads them in both passes)
-        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhSoftplus{},
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{},
                                         [&](auto T, EpiState& st, const auto&) {
                                             constexpr int t = decltype(T)::value;
                                             if (FULL) sh.tile_store(HS_A1 + 3, t, st.vec());
@@ -607,21 +638,23 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 static_for<8>([&](auto TI) {
                     constexpr int ti = decltype(TI)::value;
                     const char* buf = ws.template acquire<0>();
-                    ws.begin(ti < 7 ? HB_HID : HB_BONE);
+                    constexpr int nbytes = ti < 7 ? HB_HID : HB_BONE;
+                    ws.template begin_c<nbytes>();
                     c1[ti] = tail_tile(buf + 16 * KS_BYTES, 0, h);
                     c2[ti] = zero16();
-                    mma_tile<16, 0, true>(ws, buf, xh, xl, c1[ti], c2[ti], lane);
+                    mma_tile<16, 0, nbytes>(ws, buf, xh, xl, c1[ti], c2[ti], lane);
                 });
             }
-            feature_pass(I2{}, BFalse{}, c1, c2, HB_LEFT, HB_HID);
+            feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_HID>{});
             block_epilogue(I8t{}, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 4));
         }
-        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 5), no_store);   // lin5
-        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 6), no_store);   // lin6
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 5), no_store);   // lin5
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 6), no_store);   // lin6
         // ---- lin7 -> a8; sdf = W8[0,:] a8 + b8; seed of the reverse sweep dz7 = sigma'(z7) W8[0,:] (scaled)
-        float sdf_acc = 0.f;
-        run_layer<8, 16, 1, true, true>(
-            ws, HB_HID, FULL ? HB_HID : (more ? HB_BONE : 0), ah, al, lane, h,
+        float sdf_acc = 0.f, sdf_acc1 = 0.f;   // (16x16x32: the lane's registers of column block 0 / 1 are two samples)
+        auto lin7 = [&](auto NA_) {   // NA_: the size of the chunk that follows the layer, a constant
+        run_layer_c<8, 16, 1, true, true, HB_HID, decltype(NA_)::value>(
+            ws, ah, al, lane, h,
             [&](auto, const char* tail) { return Act{tail_tile(tail, 1, h)}; }, PhSoftplus{},
             [&](auto T, EpiState& st, const Act& w8) {
                 constexpr int t = decltype(T)::value;
@@ -629,7 +662,10 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 f32x16 dz;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    sdf_acc = fmaf(w8.v[i], st.v[i], sdf_acc);
+                    if (S16 && ((i >> 2) & 1))
+                        sdf_acc1 = fmaf(w8.v[i], st.v[i], sdf_acc1);
+                    else
+                        sdf_acc = fmaf(w8.v[i], st.v[i], sdf_acc);
                     dz[i] = dsoftplus_from_act(st.v[i]) * w8.v[i] * BWD_SCALE;
                 }
                 if (FULL) {
@@ -648,7 +684,16 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 return NoData{};
             },
             no_store);
-        sdf = half_sum(sdf_acc) + a.b8;
+        };
+        if constexpr (FULL) {
+            lin7(std::integral_constant<int, HB_HID>{});
+        } else {
+            if (more)
+                lin7(std::integral_constant<int, HB_BONE>{});
+            else
+                lin7(std::integral_constant<int, 0>{});
+        }
+        sdf = (S16 ? sample_sum(sdf_acc, sdf_acc1) : half_sum(sdf_acc)) + a.b8;
         if (!FULL) {
             if (valid && h == 0) a.sdf[n] = sdf;
             continue;
@@ -656,11 +701,20 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 
         if ((HN_DBG(a) >> 8) == 5) return;   // phase timing aid
         // ---- lin8 rows 1..256: the feature vector (no activation) -> stash as fragments for colour lin0
-        run_layer<8, 16, 1, true, true>(
-            ws, HB_HID, HB_BWD, bh, bl, lane, h, no_pre, PhIdentity{},
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_BWD>(
+            ws, bh, bl, lane, h, no_pre, PhIdentity{},
             [&](auto T, EpiState& st, const auto&) {
                 constexpr int t = decltype(T)::value;
-                if (a.feat != nullptr && valid) {
+                if constexpr (S16) {
+                    if (a.feat != nullptr) {
+                        const int g4 = lane >> 4, n0 = tile * WG_SAMPLES + wave * 32 + (lane & 15);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int ni = n0 + 16 * ((i >> 2) & 1);
+                            if (ni < a.n_pts) a.feat[(size_t)ni * H + 32 * t + 16 * (i >> 3) + 4 * g4 + (i & 3)] = st.v[i];
+                        }
+                    }
+                } else if (a.feat != nullptr && valid) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) a.feat[(size_t)n * H + 32 * t + tile_row(i, h)] = st.v[i];
                 }
@@ -690,9 +744,9 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 return NoData{};
             };
         };
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 6), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 6), no_store);   // W7^T -> dz6
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 5), PhDsig{}, to_regs_t(ah, al, HS_DZ + 5), no_store);   // W6^T -> dz5
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 4), PhDsig{},                               // W5^T -> dz4 (kept)
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, act_of(HS_A1 + 6), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 6), no_store);   // W7^T -> dz6
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, act_of(HS_A1 + 5), PhDsig{}, to_regs_t(ah, al, HS_DZ + 5), no_store);   // W6^T -> dz5
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, act_of(HS_A1 + 4), PhDsig{},                               // W5^T -> dz4 (kept)
                                          [&](auto T, EpiState& st, const auto&) {
                                              constexpr int t = decltype(T)::value;
                                              asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
@@ -705,10 +759,10 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                                              return NoData{};
                                          },
                                          no_store);
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 3), PhDsig{}, to_regs_t(ah, al, HS_DZ + 3), no_store);   // W4h^T -> dz3
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 2), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 2), no_store);   // W3^T -> dz2
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, act_of(HS_A1 + 1), PhDsig{}, to_regs_t(ah, al, HS_DZ + 1), no_store);   // W2^T -> dz1
-        run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, act_of(HS_A1 + 0), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 0), no_store);   // W1^T -> dz0
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, act_of(HS_A1 + 3), PhDsig{}, to_regs_t(ah, al, HS_DZ + 3), no_store);   // W4h^T -> dz3
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, act_of(HS_A1 + 2), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 2), no_store);   // W3^T -> dz2
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, act_of(HS_A1 + 1), PhDsig{}, to_regs_t(ah, al, HS_DZ + 1), no_store);   // W2^T -> dz1
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, act_of(HS_A1 + 0), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 0), no_store);   // W1^T -> dz0
 
         if ((HN_DBG(a) >> 8) == 7) return;   // phase timing aid
         // ---- d sdf / d features contracted with the encoding Jacobian, bone by bone: first W0^T dz0 (dz0 is in
@@ -741,7 +795,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 static_for<2>([&](auto U) {
                     constexpr int u = decltype(U)::value;
                     const char* buf0 = ws.template acquire<0>();
-                    ws.begin(HB_BWD);
+                    ws.template begin_c<HB_BWD>();
                     // the bone's own features go stash -> LDS by DMA (no registers: loaded into VGPRs here they
                     // are spilled one load at a time, 8 serialised round trips per bone); they land under the
                     // bone's MFMAs, the next acquire's vmcnt(0) covers them
@@ -753,28 +807,41 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     }
                     G1[u] = zero16();
                     G2[u] = zero16();
-                    mma_tile<16, 0, true>(ws, buf0, bh, bl, G1[u], G2[u], lane);
+                    mma_tile<16, 0, HB_BWD>(ws, buf0, bh, bl, G1[u], G2[u], lane);
                     const char* buf4 = ws.template acquire<0>();
                     if constexpr (u == 1) ws.goff = jbase + nb * (4 * HB_BWD);
-                    ws.begin(HB_BWD);
-                    mma_tile<16, 0, true>(ws, buf4, ah, al, G1[u], G2[u], lane);
+                    ws.template begin_c<HB_BWD>();
+                    mma_tile<16, 0, HB_BWD>(ws, buf4, ah, al, G1[u], G2[u], lane);
                 });
                 if (live) {   // a bone whose mask is 0 for the whole wave contributes exactly 0
                     const Bone2 bn = coords(b);
                     const float kk = -TAU2 * (1.f - bn.hh);
                     float own[4][8];
+                    f32x16 Ga = combine(G1[0], G2[0]), Gb = combine(G1[1], G2[1]);
+                    tile_out(Ga);   // (16x16x32: back to the lane <-> sample map of the contraction below)
+                    tile_out(Gb);
+                    {
+                        h8 fh[4], fl[4];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const h8 fh = *reinterpret_cast<const h8*>(stage + (2 * s) * 1024 + lane * 16);
-                        const h8 fl = *reinterpret_cast<const h8*>(stage + (2 * s + 1) * 1024 + lane * 16);
+                        for (int s = 0; s < 4; ++s) {
+                            fh[s] = *reinterpret_cast<const h8*>(stage + (2 * s) * 1024 + lane * 16);
+                            fl[s] = *reinterpret_cast<const h8*>(stage + (2 * s + 1) * 1024 + lane * 16);
+                        }
 #pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) own[s][jj] = unsplit(fh[jj], fl[jj]);
+                        for (int s = 0; s < 4; s += 2) {
+                            frags_out(fh[s], fh[s + 1]);
+                            frags_out(fl[s], fl[s + 1]);
+                        }
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int jj = 0; jj < 8; ++jj) own[s][jj] = unsplit(fh[s][jj], fl[s][jj]);
                     }
                     if constexpr (ADJ) {
                         // the same contraction through the h-weighted sums, which the adjoint's second-order term needs
                         // again (unscaled: G carries BWD_SCALE)
                         BoneSums S;
-                        bone_sums<true>(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn.hh, h, S);
+                        bone_sums<true>(Ga, Gb, own, bn.hh, h, S);
                         float Sv = fmaf(kk, S.T0, S.T1[0]);
                         float Sr[3] = {S.T1[1], S.T1[2], S.T1[3]};
                         to_p(Sv, Sr, bn, b, g);
@@ -787,7 +854,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                         }
                     } else {
                         float Sv = 0.f, Sr[3] = {0.f, 0.f, 0.f};
-                        bone_jacobian(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn, kk, h, Sv, Sr);
+                        bone_jacobian(Ga, Gb, own, bn, kk, h, Sv, Sr);
                         to_p(Sv, Sr, bn, b, g);
                     }
                 }
@@ -798,15 +865,17 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             static_for<2>([&](auto U) {
                 constexpr int u = decltype(U)::value;
                 const char* buf0 = ws.template acquire<0>();
-                ws.begin(HB_BWD);
+                ws.template begin_c<HB_BWD>();
                 L1[u] = zero16();
                 L2[u] = zero16();
-                mma_tile<16, 0, true>(ws, buf0, bh, bl, L1[u], L2[u], lane);
+                mma_tile<16, 0, HB_BWD>(ws, buf0, bh, bl, L1[u], L2[u], lane);
                 const char* buf4 = ws.template acquire<0>();
-                ws.begin(HB_BWD);   // after the last one: colour lin0's first feature-vector chunk, same size
-                mma_tile<16, 0, true>(ws, buf4, ah, al, L1[u], L2[u], lane);
+                ws.template begin_c<HB_BWD>();   // after the last one: colour lin0's first feature-vector chunk, same size
+                mma_tile<16, 0, HB_BWD>(ws, buf4, ah, al, L1[u], L2[u], lane);
             });
-            const f32x16 La = combine(L1[0], L2[0]), Lb = combine(L1[1], L2[1]);
+            f32x16 La = combine(L1[0], L2[0]), Lb = combine(L1[1], L2[1]);
+            tile_out(La);
+            tile_out(Lb);
             static_for<N_BONES>([&](auto B_) {
                 constexpr int b = decltype(B_)::value;
                 if ((nz >> b) & 1u) {
@@ -837,6 +906,8 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             encode_v4h(g, h, fg);
             split8(fg[0], gh[0], gl[0]);
             split8(fg[1], gh[1], gl[1]);
+            frags_in(gh[0], gh[1]);
+            frags_in(gl[0], gl[1]);
         }
         {
             f32x16 c1[8], c2[8];
@@ -847,22 +918,24 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 static_for<8>([&](auto TI) {
                     constexpr int ti = decltype(TI)::value;
                     const char* buf = ws.template acquire<0>();
-                    ws.begin(ti < 7 ? HB_BWD : HB_BONE);
+                    constexpr int nbytes = ti < 7 ? HB_BWD : HB_BONE;
+                    ws.template begin_c<nbytes>();
                     c1[ti] = zero16();
                     c2[ti] = zero16();
-                    mma_tile<16, 0, true>(ws, buf, xh, xl, c1[ti], c2[ti], lane);
+                    mma_tile<16, 0, nbytes>(ws, buf, xh, xl, c1[ti], c2[ti], lane);
                 });
             }
-            feature_pass(I2{}, BFalse{}, c1, c2, HB_LEFT, HB_G);
+            feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_G>{});
             static_for<2>([&](auto BLK) {
                 constexpr int blk = decltype(BLK)::value;
                 const char* buf = ws.template acquire<0>();
-                ws.begin(blk == 0 ? HB_G : HB_HID);
-                ws.pieces_all();   // 6 MFMA slots per tile here: too few to spread the pieces over
+                constexpr int nbytes = blk == 0 ? HB_G : HB_HID;
+                ws.template begin_c<nbytes>();
+                ws.template pieces_all_c<nbytes>();   // 6 MFMA slots per tile here: too few to spread the pieces over
                 const char* tail = buf + 4 * 2 * KS_BYTES;
                 static_for<4>([&](auto TI) {
                     constexpr int ti = decltype(TI)::value;
-                    mma_tile<2, 0, false>(ws, buf + ti * 2 * KS_BYTES, gh, gl, c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                    mma_tile<2, 0, 0>(ws, buf + ti * 2 * KS_BYTES, gh, gl, c1[4 * blk + ti], c2[4 * blk + ti], lane);
                     const f32x16 bias = tail_tile(tail, ti, h);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) c1[4 * blk + ti][i] += bias[i];
@@ -870,27 +943,43 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             });
             block_epilogue(I8t{}, c1, c2, PhRelu{}, to_regs_t(bh, bl, HS_C + 0));
         }
-        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, no_pre, PhRelu{}, to_regs_t(ah, al, HS_C + 1), no_store);   // colour lin1
-        run_layer<8, 16, 1, true, true>(ws, HB_HID, HB_HID, ah, al, lane, h, no_pre, PhRelu{}, to_regs_t(bh, bl, HS_C + 2), no_store);   // colour lin2
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, bh, bl, lane, h, no_pre, PhRelu{}, to_regs_t(ah, al, HS_C + 1), no_store);   // colour lin1
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, ah, al, lane, h, no_pre, PhRelu{}, to_regs_t(bh, bl, HS_C + 2), no_store);   // colour lin2
         struct W3 {
             f32x16 w[3];
         };
-        run_layer<8, 16, 1, true, false>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
-            ws, HB_HID, MODE == 2 ? HB_W4ROWS : (more ? HB_BONE : 0), bh, bl, lane, h,
+        auto col3 = [&](auto NA_) {
+        run_layer_c<8, 16, 1, true, false, HB_HID, decltype(NA_)::value>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
+            ws, bh, bl, lane, h,
             [&](auto, const char* tail) { return W3{{tail_tile(tail, 1, h), tail_tile(tail, 2, h), tail_tile(tail, 3, h)}}; },
             PhRelu{},
             [&](auto T, EpiState& st, const W3& w) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) rgb[c] = fmaf(w.w[c][i], st.v[i], rgb[c]);
+                    for (int i = 0; i < 16; ++i) {
+                        if (S16 && ((i >> 2) & 1))
+                            rgb1[c] = fmaf(w.w[c][i], st.v[i], rgb1[c]);
+                        else
+                            rgb[c] = fmaf(w.w[c][i], st.v[i], rgb[c]);
+                    }
                 asm volatile("" : "+v"(rgb[0]), "+v"(rgb[1]), "+v"(rgb[2]));
+                if constexpr (S16) asm volatile("" : "+v"(rgb1[0]), "+v"(rgb1[1]), "+v"(rgb1[2]));
                 if constexpr (ADJ) sh.tile_store(HS_C + 3, decltype(T)::value, st.vec());
                 return NoData{};
             },
             no_store);
+        };
+        if constexpr (MODE == 2) {
+            col3(std::integral_constant<int, HB_W4ROWS>{});
+        } else {
+            if (more)
+                col3(std::integral_constant<int, HB_BONE>{});
+            else
+                col3(std::integral_constant<int, 0>{});
+        }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_fast(half_sum(rgb[c]) + a.c_blast[c]);
+        for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_fast((S16 ? sample_sum(rgb[c], rgb1[c]) : half_sum(rgb[c])) + a.c_blast[c]);
         }   // RUN_FWD
         if constexpr (RUN_ADJ) {
 #include "hn_field2_hand_adj.inl"
@@ -1007,8 +1096,8 @@ int launch_field2_hand_taped(const hn_field* f, const float* pts, int n_pts, con
     }
     Hand2Args a{};
     hand2_common_args(a, f, pts, n_pts, bt_inv, T_pose, n_frames, pts_per_frame, tape);
-    a.blob = reinterpret_cast<const char*>(f->v2_full);
-    a.blob_bytes = f->v2_full_bytes;
+    a.blob = reinterpret_cast<const char*>(f->v2_tape != nullptr ? f->v2_tape : f->v2_full);
+    a.blob_bytes = f->v2_tape != nullptr ? f->v2_tape_bytes : f->v2_full_bytes;
     a.sdf = sdf;
     a.grad = grad;
     a.rgb = rgb;

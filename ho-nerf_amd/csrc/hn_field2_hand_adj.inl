@@ -54,8 +54,8 @@
     // ---- colour lin4^T and the mask of c4: cb4 = (c4 > 0) * (W_c4^T xb)
     {
         const char* buf = ws.template acquire<0>();
-        ws.begin(HB_BWD);
-        ws.pieces_all();
+        ws.template begin_c<HB_BWD>();
+        ws.template pieces_all_c<HB_BWD>();
         static_for<8>([&](auto T) {
             constexpr int t = decltype(T)::value;
             const f32x16 c4 = sh.tile_load(HS_C + 3, t);
@@ -66,12 +66,12 @@
             split_tile(v, ah[2 * t], al[2 * t], ah[2 * t + 1], al[2 * t + 1]);
         });
     }
-    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, mask_of(HS_C + 2), PhMask{}, to_regs(bh, bl), no_store);   // C3^T -> cb3
-    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, mask_of(HS_C + 1), PhMask{}, to_regs(ah, al), no_store);   // C2^T -> cb2
-    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, mask_of(HS_C + 0), PhMask{}, to_regs(bh, bl), no_store);   // C1^T -> cb1
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, mask_of(HS_C + 2), PhMask{}, to_regs(bh, bl), no_store);   // C3^T -> cb3
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, mask_of(HS_C + 1), PhMask{}, to_regs(ah, al), no_store);   // C2^T -> cb2
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, mask_of(HS_C + 0), PhMask{}, to_regs(bh, bl), no_store);   // C1^T -> cb1
     // ---- colour lin0^T, feature-vector rows -> fb (fragments, kept in the HS_FVEC slot for the W8 product)
-    run_layer<8, 16, 1, false, true>(
-        ws, HB_BWD, HB_BWD, bh, bl, lane, h, no_pre, PhIdentity{},
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(
+        ws, bh, bl, lane, h, no_pre, PhIdentity{},
         [&](auto T, EpiState& st, const auto&) {
             constexpr int t = decltype(T)::value;
             sh.frag_store(HS_FVEC * SLOT_BYTES, 2 * t, st.hi[0], st.lo[0]);
@@ -83,9 +83,9 @@
     float gb[3] = {0.f, 0.f, 0.f};
     {
         const char* buf = ws.template acquire<0>();
-        ws.begin(HB_BWD);
+        ws.template begin_c<HB_BWD>();
         f32x16 m1 = zero16(), m2 = zero16();
-        mma_tile<16, 0, true>(ws, buf, bh, bl, m1, m2, lane);
+        mma_tile<16, 0, HB_BWD>(ws, buf, bh, bl, m1, m2, lane);
         const f32x16 Mg = combine(m1, m2);
         float f[2][8];
         encode_v4h(g, h, f);
@@ -144,10 +144,10 @@
         static_for<2>([&](auto U) {
             constexpr int u = decltype(U)::value;
             const char* buf = ws.template acquire<0>();
-            ws.begin(HB_BWD);
+            ws.template begin_c<HB_BWD>();
             L1[u] = zero16();
             L2[u] = zero16();
-            mma_tile<16, 0, true>(ws, buf, bh, bl, L1[u], L2[u], lane);
+            mma_tile<16, 0, HB_BWD>(ws, buf, bh, bl, L1[u], L2[u], lane);
         });
         park_leftover(combine(L1[0], L2[0]), combine(L1[1], L2[1]));
         const int jbase = ws.goff - HB_BWD;   // stream offset of bone 0's first chunk (in flight)
@@ -163,11 +163,12 @@
                 constexpr int u = decltype(U)::value;
                 const char* buf = ws.template acquire<0>();
                 if constexpr (u == 1) ws.goff = jbase + nb * (2 * HB_BWD);
-                ws.begin((u == 1 && nb == N_BONES) ? HB_BONE : HB_BWD);   // after the last bone: lin0 of the forward-direction sweep
+                static_assert(HB_BONE == HB_BWD, "one size");
+                ws.template begin_c<HB_BWD>();   // after the last bone: lin0 of the forward-direction sweep (a bone chunk, the same size)
                 if (u == 0 && live) stage_bone(b);
                 G1[u] = zero16();
                 G2[u] = zero16();
-                mma_tile<16, 0, true>(ws, buf, bh, bl, G1[u], G2[u], lane);
+                mma_tile<16, 0, HB_BWD>(ws, buf, bh, bl, G1[u], G2[u], lane);
             });
             if (live) {
                 // the staged features were requested before tile 0's MFMAs; the acquire of tile 1 waited for them
@@ -281,29 +282,30 @@
             c1[ti] = zero16();
             c2[ti] = zero16();
         }
-        feature_pass(I2{}, BFalse{}, c1, c2, HB_LEFT, HB_HID);
+        feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_HID>{});
         block_epilogue_pd(c1, c2, PhFwdDir{}, pre4(HS_A1 + 0, HS_DZ + 0), fin4(ah, al, HS_DZ + 0));
     }
-    run_layer<8, 16, 1, false, true>(ws, HB_HID, HB_HID, ah, al, lane, h, pre4(HS_A1 + 1, HS_DZ + 1), PhFwdDir{}, fin4(bh, bl, HS_DZ + 1), no_store);   // lin1
-    run_layer<8, 16, 1, false, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, pre4(HS_A1 + 2, HS_DZ + 2), PhFwdDir{}, fin4(ah, al, HS_DZ + 2), no_store);   // lin2
-    run_layer<8, 16, 1, false, true>(ws, HB_HID, HB_HID, ah, al, lane, h, pre4(HS_A1 + 3, HS_DZ + 3), PhFwdDir{}, fin4(bh, bl, HS_DZ + 3), no_store);   // lin3
+    run_layer_c<8, 16, 1, false, true, HB_HID, HB_HID>(ws, ah, al, lane, h, pre4(HS_A1 + 1, HS_DZ + 1), PhFwdDir{}, fin4(bh, bl, HS_DZ + 1), no_store);   // lin1
+    run_layer_c<8, 16, 1, false, true, HB_HID, HB_HID>(ws, bh, bl, lane, h, pre4(HS_A1 + 2, HS_DZ + 2), PhFwdDir{}, fin4(ah, al, HS_DZ + 2), no_store);   // lin2
+    run_layer_c<8, 16, 1, false, true, HB_HID, HB_HID>(ws, ah, al, lane, h, pre4(HS_A1 + 3, HS_DZ + 3), PhFwdDir{}, fin4(bh, bl, HS_DZ + 3), no_store);   // lin3
     {   // lin4 = [v3 | J gb] / sqrt2
         f32x16 c1[8], c2[8];
         static_for<8>([&](auto TI) {
             constexpr int ti = decltype(TI)::value;
             const char* buf = ws.template acquire<0>();
-            ws.begin(ti < 7 ? HB_HID : HB_BONE);
+            constexpr int nbytes = ti < 7 ? HB_HID : HB_BONE;
+            ws.template begin_c<nbytes>();
             c1[ti] = zero16();
             c2[ti] = zero16();
-            mma_tile<16, 0, true>(ws, buf, bh, bl, c1[ti], c2[ti], lane);
+            mma_tile<16, 0, nbytes>(ws, buf, bh, bl, c1[ti], c2[ti], lane);
         });
-        feature_pass(I2{}, BFalse{}, c1, c2, HB_LEFT, HB_HID);
+        feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_HID>{});
         block_epilogue_pd(c1, c2, PhFwdDir{}, pre4(HS_A1 + 4, HS_DZ + 4), fin4(ah, al, HS_DZ + 4));
     }
     feat_base = FEAT;
-    run_layer<8, 16, 1, false, true>(ws, HB_HID, HB_HID, ah, al, lane, h, pre4(HS_A1 + 5, HS_DZ + 5), PhFwdDir{}, fin4(bh, bl, HS_DZ + 5), no_store);   // lin5
-    run_layer<8, 16, 1, false, true>(ws, HB_HID, HB_HID, bh, bl, lane, h, pre4(HS_A1 + 6, HS_DZ + 6), PhFwdDir{}, fin4(ah, al, HS_DZ + 6), no_store);   // lin6
-    run_layer<8, 16, 1, false, false>(ws, HB_HID, HB_HID, ah, al, lane, h, pre4(HS_A8, HS_DZ + 7), PhFwdDir{},                                       // lin7: only w_7
+    run_layer_c<8, 16, 1, false, true, HB_HID, HB_HID>(ws, ah, al, lane, h, pre4(HS_A1 + 5, HS_DZ + 5), PhFwdDir{}, fin4(bh, bl, HS_DZ + 5), no_store);   // lin5
+    run_layer_c<8, 16, 1, false, true, HB_HID, HB_HID>(ws, bh, bl, lane, h, pre4(HS_A1 + 6, HS_DZ + 6), PhFwdDir{}, fin4(ah, al, HS_DZ + 6), no_store);   // lin6
+    run_layer_c<8, 16, 1, false, false, HB_HID, HB_HID>(ws, ah, al, lane, h, pre4(HS_A8, HS_DZ + 7), PhFwdDir{},                                       // lin7: only w_7
                                       [&](auto T, EpiState& st, const auto&) {
                                           sh.tile_store(HS_DZ + 7, decltype(T)::value, st.wvec());
                                           return NoData{};
@@ -319,8 +321,8 @@
     };
 #pragma unroll
     for (int s = 0; s < 16; ++s) sh.frag_load(HS_FVEC * SLOT_BYTES, s, bh[s], bl[s]);
-    run_layer<8, 16, 1, false, true>(
-        ws, HB_HID, HB_BWD, bh, bl, lane, h,
+    run_layer_c<8, 16, 1, false, true, HB_HID, HB_BWD>(
+        ws, bh, bl, lane, h,
         [&](auto T, const char* tail) {
             constexpr int t = decltype(T)::value;
             Act2 o{sh.tile_load(HS_A8, t), sh.tile_load(HS_DZ + 7, t)};
@@ -330,9 +332,9 @@
             return o;
         },
         PhRev2{}, to_regs(ah, al), no_store);
-    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, pre5(HS_A1 + 6, HS_DZ + 6), PhRev2{}, to_regs(bh, bl), no_store);   // W7^T -> zb6
-    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, pre5(HS_A1 + 5, HS_DZ + 5), PhRev2{}, to_regs(ah, al), no_store);   // W6^T -> zb5
-    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, pre5(HS_A1 + 4, HS_DZ + 4), PhRev2{},                               // W5^T -> zb4 (kept)
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 6, HS_DZ + 6), PhRev2{}, to_regs(bh, bl), no_store);   // W7^T -> zb6
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, pre5(HS_A1 + 5, HS_DZ + 5), PhRev2{}, to_regs(ah, al), no_store);   // W6^T -> zb5
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 4, HS_DZ + 4), PhRev2{},                               // W5^T -> zb4 (kept)
                                      [&](auto T, EpiState& st, const auto&) {
                                          constexpr int t = decltype(T)::value;
                                          asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
@@ -345,10 +347,10 @@
                                          return NoData{};
                                      },
                                      no_store);
-    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, pre5(HS_A1 + 3, HS_DZ + 3), PhRev2{}, to_regs(ah, al), no_store);   // W4h^T -> zb3
-    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, pre5(HS_A1 + 2, HS_DZ + 2), PhRev2{}, to_regs(bh, bl), no_store);   // W3^T -> zb2
-    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, bh, bl, lane, h, pre5(HS_A1 + 1, HS_DZ + 1), PhRev2{}, to_regs(ah, al), no_store);   // W2^T -> zb1
-    run_layer<8, 16, 1, false, true>(ws, HB_BWD, HB_BWD, ah, al, lane, h, pre5(HS_A1 + 0, HS_DZ + 0), PhRev2{}, to_regs(bh, bl), no_store);   // W1^T -> zb0
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, pre5(HS_A1 + 3, HS_DZ + 3), PhRev2{}, to_regs(ah, al), no_store);   // W4h^T -> zb3
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 2, HS_DZ + 2), PhRev2{}, to_regs(bh, bl), no_store);   // W3^T -> zb2
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, pre5(HS_A1 + 1, HS_DZ + 1), PhRev2{}, to_regs(ah, al), no_store);   // W2^T -> zb1
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 0, HS_DZ + 0), PhRev2{}, to_regs(bh, bl), no_store);   // W1^T -> zb0
 
     // ---- input map (pass B): X-adjoint rows W0^T zb0 + W4x^T zb4, leftover rows first, then bone by bone; per bone the
     //      pull, the Hessian-vector term and the pose gradients
@@ -362,13 +364,13 @@
         static_for<2>([&](auto U) {
             constexpr int u = decltype(U)::value;
             const char* buf0 = ws.template acquire<0>();
-            ws.begin(HB_BWD);
+            ws.template begin_c<HB_BWD>();
             L1[u] = zero16();
             L2[u] = zero16();
-            mma_tile<16, 0, true>(ws, buf0, bh, bl, L1[u], L2[u], lane);
+            mma_tile<16, 0, HB_BWD>(ws, buf0, bh, bl, L1[u], L2[u], lane);
             const char* buf4 = ws.template acquire<0>();
-            ws.begin(HB_BWD);
-            mma_tile<16, 0, true>(ws, buf4, ah, al, L1[u], L2[u], lane);
+            ws.template begin_c<HB_BWD>();
+            mma_tile<16, 0, HB_BWD>(ws, buf4, ah, al, L1[u], L2[u], lane);
         });
         park_leftover(combine(L1[0], L2[0]), combine(L1[1], L2[1]));
         const int jbase = ws.goff - HB_BWD;   // stream offset of bone 0's first chunk (in flight)
@@ -383,15 +385,20 @@
             static_for<2>([&](auto U) {
                 constexpr int u = decltype(U)::value;
                 const char* buf0 = ws.template acquire<0>();
-                ws.begin(HB_BWD);
+                ws.template begin_c<HB_BWD>();
                 if (u == 0 && live) stage_bone(b);
                 G1[u] = zero16();
                 G2[u] = zero16();
-                mma_tile<16, 0, true>(ws, buf0, bh, bl, G1[u], G2[u], lane);
+                mma_tile<16, 0, HB_BWD>(ws, buf0, bh, bl, G1[u], G2[u], lane);
                 const char* buf4 = ws.template acquire<0>();
                 if constexpr (u == 1) ws.goff = jbase + nb * (4 * HB_BWD);
-                ws.begin((u == 1 && nb == N_BONES) ? (more ? FIRST_CHUNK : 0) : HB_BWD);   // after the last bone: the next tile's first chunk
-                mma_tile<16, 0, true>(ws, buf4, ah, al, G1[u], G2[u], lane);
+                if constexpr (u == 1) {   // after the last bone: the next tile's first chunk (the one size that is not a constant)
+                    ws.begin(nb == N_BONES ? (more ? FIRST_CHUNK : 0) : HB_BWD);
+                    mma_tile<16, 0, 1>(ws, buf4, ah, al, G1[u], G2[u], lane);
+                } else {
+                    ws.template begin_c<HB_BWD>();
+                    mma_tile<16, 0, HB_BWD>(ws, buf4, ah, al, G1[u], G2[u], lane);
+                }
             });
             if (live) {
                 const Bone2 bn = coords(b);

@@ -79,6 +79,41 @@ __device__ __forceinline__ int lane_x16() {
     return v;
 }
 
+// ---- MFMA shape ------------------------------------------------------------------------------------------------
+// HN_MFMA16 (per translation unit): the matrix products run on v_mfma_f32_16x16x32_f16 instead of 32x32x16.  Same
+// MACs per cycle, same A-fragment bytes from LDS, same register counts -- but the chip holds a higher clock on this
+// shape and the wave loses fewer cycles around it (tools/cpp/layer_bench.hip, -DHN_EXP_MFMA16: a hidden layer 17 - 22 %
+// shorter in wall time, a feature pass 32 %; profiles/r02/README.md).  What changes is which lane holds what:
+//   32x32x16 ("old"): lane = (sample c of 32, half hh);  a C tile's register i is row (i&3) + 8 (i>>2) + 4 hh;  a B
+//                     fragment (k-step s of 16) holds k = 16 s + 8 hh + j.
+//   16x16x32 ("new"): lane = (c16, g) with g = lane >> 4;  a 32-row x 32-sample tile is four 16x16 blocks, register
+//                     i = 8 rb + 4 cb + ii is row 16 rb + 4 g + ii of sample 16 cb + c16;  the B fragment [2 s' + cb] of
+//                     k-step pair s' holds k = 32 s' + 8 g + j of sample 16 cb + c16.
+// The slot numbering kappa = 16 s + 8 h + j = 32 s' + 8 g + j (s = 2 s' + (g >> 1), h = g & 1) is common to both, and
+// so is the rule that a finished tile's registers ARE next layer's B fragments (new: fragment cb, element 4 rb + ii).
+// Everything inside the MLP stack is layout-agnostic (element-wise epilogues, stash tiles written and read in the
+// same layout); the per-sample code around it (encodings, Jacobian contractions, output sums) is written for the old
+// lane <-> sample map and crosses over with the two exchanges below: one v_permlane32_swap + one v_permlane16_swap
+// per register pair.
+#ifndef HN_MFMA16
+#define HN_MFMA16 0
+#endif
+constexpr bool S16 = HN_MFMA16 != 0;
+// (x0, x1): the two registers of a pair -- fragment dwords of k-steps (2 s', 2 s' + 1), or tile registers (i, i + 4).
+// old -> new: new x0 = the cb 0 member, x1 = the cb 1 member.  Rows = 16 lanes: row q + 2 hh <-> g.
+__device__ __forceinline__ void rows_to16(unsigned& x0, unsigned& x1) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);      // x0 rows 2,3 <-> x1 rows 0,1
+    const auto q = __builtin_amdgcn_permlane16_swap(r[0], r[1], false, false);  // x0 rows 1,3 <-> x1 rows 0,2
+    x0 = q[0];
+    x1 = q[1];
+}
+__device__ __forceinline__ void rows_to32(unsigned& x0, unsigned& x1) {   // the inverse
+    const auto q = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);
+    const auto r = __builtin_amdgcn_permlane32_swap(q[0], q[1], false, false);
+    x0 = r[0];
+    x1 = r[1];
+}
+
 // ---- weight stream ---------------------------------------------------------------------------
 // The stream is cyclic (after the last chunk of a sample tile comes the first again) and is read
 // through a buffer descriptor: buffer_load_dwordx4 ... offen lds with a scalar byte offset per 1 KiB
@@ -171,6 +206,64 @@ struct WStream {
         const int vo = (k < f_pieces) ? l16 : l16 + 0x7f000000;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(f_dst + k * 4096), 16, vo, f_goff + k * 4096, 0, 0);
     }
+    // ---- compile-time-sized fetch ------------------------------------------------------------------------------
+    // Where the size of the next chunk is a constant (every layer of the forward kernels), the fetch needs no
+    // per-piece presence logic: the chunk's whole 4 KiB multiples ("body") are split into four contiguous quarters,
+    // wave w moving quarter w in 1 KiB x4 pieces, and each remaining 1 KiB (tails) is moved by all four waves
+    // together, 256 B each, with dword pieces.  The lane offset is the caller's (the MFMA tile's own lane * 16), pieces
+    // of one 4 KiB group share their scalar offset and M0 and differ in the instruction's immediate offset: per piece
+    // one VMEM instruction and ~0.5 SALU, against 3 + 2 VALU, 2 SALU and the VMEM instruction of the run-time form
+    // (one wave per SIMD: every instruction of any kind costs the wave's in-order stream ~4 cycles beside the MFMAs).
+    int c_goff, c_rgoff;    // this wave's global offsets: body, remainder
+    char *c_dst, *c_rdst;   // and LDS destinations
+    template <int BYTES>
+    static constexpr int body_pieces() { return BYTES / 4096; }
+    template <int BYTES>
+    static constexpr int rem_pieces() { return (BYTES % 4096) / 1024; }
+    template <int BYTES>
+    static constexpr int n_pieces() { return body_pieces<BYTES>() + rem_pieces<BYTES>(); }
+    template <int BYTES>
+    __device__ __forceinline__ void begin_c() {
+        static_assert(BYTES % 1024 == 0 && BYTES <= CHUNK_MAX, "chunk size");
+        if (goff == total) goff = 0;
+        constexpr int Q = body_pieces<BYTES>() * 1024;   // bytes per wave in the body
+        char* const dst = lds + phase * CHUNK_MAX;
+        c_goff = goff + wave * Q;
+        c_dst = dst + wave * Q;
+        c_rgoff = goff + 4 * Q + wave * 256;
+        c_rdst = dst + 4 * Q + wave * 256;
+        goff += BYTES;
+        phase ^= 1;
+    }
+    template <int BYTES>
+    __device__ __forceinline__ void begin_at_c(int off) {
+        goff = off;
+        begin_c<BYTES>();
+    }
+    // piece K of n_pieces<BYTES>(); l16 = lane * 16
+    template <int BYTES, int K>
+    __device__ __forceinline__ void piece_c(int l16) {
+        constexpr int NB = body_pieces<BYTES>();
+        static_assert(K < n_pieces<BYTES>(), "piece index");
+        if constexpr (K < NB) {
+            constexpr int g = K / 4, i = K % 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(c_dst + g * 4096), 16, l16, c_goff + g * 4096, i * 1024, 0);
+        } else {
+            constexpr int j = K - NB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(c_rdst + j * 1024), 4, l16 >> 2, c_rgoff + j * 1024, 0, 0);
+        }
+    }
+    template <int BYTES>
+    __device__ __forceinline__ void pieces_all_c() {
+        const int l16 = lane_x16();
+        static_for<n_pieces<BYTES>()>([&](auto K) { piece_c<BYTES, decltype(K)::value>(l16); });
+    }
+    template <int BYTES>
+    __device__ __forceinline__ void fetch_all_c() {
+        begin_c<BYTES>();
+        const int l16 = lane_x16();
+        static_for<n_pieces<BYTES>()>([&](auto K) { piece_c<BYTES, decltype(K)::value>(l16); });
+    }
     __device__ __forceinline__ void pieces_all() {
 #pragma unroll
         for (int k = 0; k < 9; ++k) piece(k);
@@ -193,10 +286,14 @@ struct WStream {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt((ALLOW & 15) | (7 << 4) | (15 << 8) | ((ALLOW >> 4) << 14));
         } else {
+#ifndef HN_EXP_NOWAIT
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ALLOW) : "memory");
+#endif
         }
         stamp(2);
+#ifndef HN_EXP_NOBAR   // timing experiments only (tools/cpp/layer_bench.hip)
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         stamp(3);
         return lds + (phase ^ 1) * CHUNK_MAX;
@@ -228,8 +325,108 @@ __device__ __forceinline__ void f16_flush_mode() {
     __builtin_amdgcn_s_setreg(((4 - 1) << 11) | (4 << 6) | 1, 3);
 #endif
 }
+// The split of a PAIR of fp32 values in 5 VALU instructions (the plain form takes 10: two conversions each way, two
+// subtractions, two multiplications, two packs): hi pair = v_cvt_pk_f16_f32 (RTNE, like the scalar conversion);
+// residuals straight from the packed halves with v_fma_mix_f32 (x - float(hi), exact in fp32); scaled lo halves
+// written in place by v_fma_mixlo/hi_f16 (r * 2048 rounded once to fp16 -- the same value as the separate multiply
+// and conversion, the multiplication by a power of two being exact).  HN_SPLIT_MIX=0 keeps the plain form.
+#ifndef HN_SPLIT_MIX
+#define HN_SPLIT_MIX 1
+#endif
+__device__ __forceinline__ void split_pair_hi(float a, float b, unsigned& hp, float& r0, float& r1) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hp), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hp), "v"(b));
+}
+__device__ __forceinline__ unsigned split_pair_lo(float r0, float r1, float scale) {
+    unsigned lp;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(lp) : "v"(r0), "v"(scale));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lp) : "v"(r1), "v"(scale));
+    return lp;
+}
+using u32x4_ = unsigned __attribute__((ext_vector_type(4)));
+template <int J2>   // dword J2 of the fragment (halves 2*J2, 2*J2+1)
+__device__ __forceinline__ void set_pair(h8& f, unsigned v) {
+    u32x4_ t = __builtin_bit_cast(u32x4_, f);
+    t[J2] = v;
+    f = __builtin_bit_cast(h8, t);
+}
+// old <-> new layout of a pair of B fragments (k-steps 2 s', 2 s' + 1  <->  [cb 0], [cb 1]) and of an accumulator tile
+__device__ __forceinline__ void frags_to16(h8& f0, h8& f1) {
+    u32x4_ a = __builtin_bit_cast(u32x4_, f0), b = __builtin_bit_cast(u32x4_, f1);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        unsigned x0 = a[d], x1 = b[d];
+        rows_to16(x0, x1);
+        a[d] = x0;
+        b[d] = x1;
+    }
+    f0 = __builtin_bit_cast(h8, a);
+    f1 = __builtin_bit_cast(h8, b);
+}
+__device__ __forceinline__ void frags_to32(h8& f0, h8& f1) {
+    u32x4_ a = __builtin_bit_cast(u32x4_, f0), b = __builtin_bit_cast(u32x4_, f1);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        unsigned x0 = a[d], x1 = b[d];
+        rows_to32(x0, x1);
+        a[d] = x0;
+        b[d] = x1;
+    }
+    f0 = __builtin_bit_cast(h8, a);
+    f1 = __builtin_bit_cast(h8, b);
+}
+template <bool TO16>
+__device__ __forceinline__ void tile_convert(f32x16& t) {
+#pragma unroll
+    for (int A = 0; A < 2; ++A)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            // (through scalars: __builtin_bit_cast applied to a vector-element expression reads element 0)
+            const float f0 = t[8 * A + ii], f1 = t[8 * A + 4 + ii];
+            unsigned x0 = __builtin_bit_cast(unsigned, f0), x1 = __builtin_bit_cast(unsigned, f1);
+            if constexpr (TO16)
+                rows_to16(x0, x1);
+            else
+                rows_to32(x0, x1);
+            t[8 * A + ii] = __builtin_bit_cast(float, x0);
+            t[8 * A + 4 + ii] = __builtin_bit_cast(float, x1);
+        }
+}
+// Interface helpers of the kernels: no-ops on the 32x32x16 shape.  in: fragments / tile in the old (per-sample code's)
+// layout -> the MFMA layout of this translation unit; out: the reverse.
+__device__ __forceinline__ void frags_in(h8& f0, h8& f1) {
+    if constexpr (S16) frags_to16(f0, f1);
+}
+__device__ __forceinline__ void frags_out(h8& f0, h8& f1) {
+    if constexpr (S16) frags_to32(f0, f1);
+}
+__device__ __forceinline__ void tile_in(f32x16& t) {
+    if constexpr (S16) tile_convert<true>(t);
+}
+__device__ __forceinline__ void tile_out(f32x16& t) {
+    if constexpr (S16) tile_convert<false>(t);
+}
+// which fragment (of the tile's two) and which element register i of a finished tile becomes
+__host__ __device__ constexpr int frag_u(int i) { return S16 ? ((i >> 2) & 1) : (i >> 3); }
+__host__ __device__ constexpr int frag_j(int i) { return S16 ? (4 * (i >> 3) + (i & 3)) : (i & 7); }
 // fp16 hi / scaled-lo split of 8 fp32 values (one B fragment)
 __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
+#if HN_SPLIT_MIX && defined(__HIP_DEVICE_COMPILE__)
+    u32x4_ H, L;
+    float scale = LO_SCALE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r0, r1;
+        unsigned hp;
+        split_pair_hi(x[2 * j], x[2 * j + 1], hp, r0, r1);
+        H[j] = hp;
+        L[j] = split_pair_lo(r0, r1, scale);
+    }
+    hi = __builtin_bit_cast(h8, H);
+    lo = __builtin_bit_cast(h8, L);
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const _Float16 hj = hi_part(x[j]);
@@ -239,8 +436,9 @@ __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
 }
 // registers 8u..8u+7 of an accumulator tile -> B fragment of k-step 2t+u
 __device__ __forceinline__ void split_tile(const f32x16& a, h8& hi0, h8& lo0, h8& hi1, h8& lo1) {
-    const float x0[8] = {a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]};
-    const float x1[8] = {a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]};
+    // (16x16x32 shape: fragment cb = registers 4 cb + ii and 8 + 4 cb + ii, see frag_u / frag_j)
+    const float x0[8] = {a[0], a[1], a[2], a[3], S16 ? a[8] : a[4], S16 ? a[9] : a[5], S16 ? a[10] : a[6], S16 ? a[11] : a[7]};
+    const float x1[8] = {S16 ? a[4] : a[8], S16 ? a[5] : a[9], S16 ? a[6] : a[10], S16 ? a[7] : a[11], a[12], a[13], a[14], a[15]};
     split8(x0, hi0, lo0);
     split8(x1, hi1, lo1);
     // keep the conversion where it is written (beside the next tile's MFMAs) instead of letting the
@@ -251,7 +449,56 @@ __device__ __forceinline__ void split_tile(const f32x16& a, h8& hi0, h8& lo0, h8
 __device__ __forceinline__ float unsplit(_Float16 hi, _Float16 lo) { return fmaf((float)lo, LO_INV, (float)hi); }
 
 __device__ __forceinline__ f32x16 mfma16(const h8& a, const h8& b, const f32x16& c) {
+#ifdef HN_EXP_MFMA16   // timing experiment only (tools/cpp/layer_bench.hip): the same MACs as two 16x16x32 instructions; results meaningless
+    using f32x4_ = float __attribute__((ext_vector_type(4)));
+    f32x4_ c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    f32x16 r = c;
+    r[0] = c0[0]; r[1] = c0[1]; r[2] = c0[2]; r[3] = c0[3];
+    r[4] = c1[0]; r[5] = c1[1]; r[6] = c1[2]; r[7] = c1[3];
+    return r;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// 16x16x32 shape: row block RB of the tile against both column blocks: c[8 RB + 4 cb ..] += A(16 rows x 32 k) * b[cb]
+using f32x4v = float __attribute__((ext_vector_type(4)));
+template <int RB>
+__device__ __forceinline__ void mfma_blk(const h8& a, const h8& b0, const h8& b1, f32x16& c) {
+    f32x4v c0 = {c[8 * RB], c[8 * RB + 1], c[8 * RB + 2], c[8 * RB + 3]};
+    f32x4v c1 = {c[8 * RB + 4], c[8 * RB + 5], c[8 * RB + 6], c[8 * RB + 7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, c1, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        c[8 * RB + i] = c0[i];
+        c[8 * RB + 4 + i] = c1[i];
+    }
+}
+// one LDS block (2 KiB: hi + lo fragment) of the tile against the matching B fragments: 3 MFMAs (32x32x16: block =
+// k-step s) or 6 (16x16x32: block s = row block s & 1 of k-step pair s >> 1), with a filler slot after each third
+template <int S, int S0, int NX, typename Slot>
+__device__ __forceinline__ void mma_block(const h8& ah, const h8& al, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16& c1, f32x16& c2,
+                                          Slot&& slot) {
+    if constexpr (S16) {
+        static_assert(S0 % 2 == 0, "k-step pairs");
+        constexpr int b = S0 + (S & ~1), RB = S & 1;
+        mfma_blk<RB>(ah, xh[b], xh[b + 1], c1);
+        slot(std::integral_constant<int, 3 * S>{});
+        mfma_blk<RB>(ah, xl[b], xl[b + 1], c2);
+        slot(std::integral_constant<int, 3 * S + 1>{});
+        mfma_blk<RB>(al, xh[b], xh[b + 1], c2);
+        slot(std::integral_constant<int, 3 * S + 2>{});
+    } else {
+        c1 = mfma16(ah, xh[S0 + S], c1);
+        slot(std::integral_constant<int, 3 * S>{});
+        c2 = mfma16(ah, xl[S0 + S], c2);
+        slot(std::integral_constant<int, 3 * S + 1>{});
+        c2 = mfma16(al, xh[S0 + S], c2);
+        slot(std::integral_constant<int, 3 * S + 2>{});
+    }
 }
 
 // c1/c2 += W[tile rows, KS k-steps] * x[S0 .. S0+KS)  -- `blk` points at the tile's first k-step block in LDS.
@@ -279,18 +526,22 @@ struct NoEpi {
 };
 // FETCH: the DMA pieces of the next chunk are issued from this tile's MFMA slots (one piece per
 // stride of slots, all within the first ~half of the tile so that they land before the next barrier)
-template <int KS, int S0, bool FETCH, int NX, typename Epi>
+// FETCH: 0 none; 1 the run-time form (WStream::begin / piece); >= 1024: the size of the chunk being fetched, a
+// constant (WStream::begin_c / piece_c)
+template <int KS, int S0, int FETCH, int NX, typename Epi>
 __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16& c1,
                                          f32x16& c2, int lane, Epi& epi) {
     static_assert(S0 + KS <= NX, "k-step range");
     constexpr int NQ = 3 * KS;
-    constexpr int STRIDE = NQ >= 27 ? 3 : (NQ >= 18 ? 2 : 1);
-    static_assert(!FETCH || NQ >= MAX_PIECES_PER_WAVE, "not enough slots for the DMA pieces");
+    constexpr int NP = FETCH > 1 ? WStream::n_pieces<FETCH>() : MAX_PIECES_PER_WAVE;
+    constexpr int STRIDE = NQ >= 3 * NP ? 3 : (NQ >= 2 * NP ? 2 : 1);
+    static_assert(!FETCH || NQ >= NP, "not enough slots for the DMA pieces");
     h8 ah[3], al[3];
     // this lane's LDS read address is formed per tile (see lane_x16): kept across the kernel it gets spilled, and its
     // reload in front of every ds_read carries an s_waitcnt vmcnt(0) that also drains the weight stream's DMA
     (void)lane;
-    const char* const lblk = blk + lane_x16();
+    const int l16 = lane_x16();
+    const char* const lblk = blk + l16;
     auto load = [&](auto S) {
         constexpr int s = decltype(S)::value;
         ah[s % 3] = *reinterpret_cast<const h8*>(lblk + s * KS_BYTES);
@@ -298,25 +549,22 @@ __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 
     };
     auto slot = [&](auto Q_) {
         constexpr int Q = decltype(Q_)::value;
-        if constexpr (FETCH && Q % STRIDE == STRIDE - 1 && Q / STRIDE < MAX_PIECES_PER_WAVE) ws.template piece<Epi::branchy>(Q / STRIDE);
+        if constexpr (FETCH == 1 && Q % STRIDE == STRIDE - 1 && Q / STRIDE < NP) ws.template piece<Epi::branchy>(Q / STRIDE);
+        if constexpr (FETCH > 1 && Q % STRIDE == STRIDE - 1 && Q / STRIDE < NP) ws.template piece_c<FETCH, Q / STRIDE>(l16);
         epi.template run<Q, NQ>();
         __builtin_amdgcn_sched_barrier(0);
     };
     load(std::integral_constant<int, 0>{});
     if constexpr (KS > 1) load(std::integral_constant<int, 1>{});
+    static_assert(!S16 || KS % 2 == 0, "the 16x16x32 shape consumes k-steps in pairs");
     static_for<KS>([&](auto S) {
         constexpr int s = decltype(S)::value;
         if constexpr (s + 2 < KS) load(std::integral_constant<int, s + 2>{});
-        c1 = mfma16(ah[s % 3], xh[S0 + s], c1);
-        slot(std::integral_constant<int, 3 * s>{});
-        c2 = mfma16(ah[s % 3], xl[S0 + s], c2);
-        slot(std::integral_constant<int, 3 * s + 1>{});
-        c2 = mfma16(al[s % 3], xh[S0 + s], c2);
-        slot(std::integral_constant<int, 3 * s + 2>{});
+        mma_block<s, S0>(ah[s % 3], al[s % 3], xh, xl, c1, c2, slot);
     });
     ws.stamp(4);
 }
-template <int KS, int S0, bool FETCH, int NX>
+template <int KS, int S0, int FETCH, int NX>
 __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16& c1,
                                          f32x16& c2, int lane) {
     NoEpi e;
@@ -328,17 +576,20 @@ __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 
 // are contiguous in LDS): the A-fragment ring keeps running across the tile boundaries, where NT separate mma_tile
 // calls would each start with an empty ring and expose the LDS latency again.  The DMA pieces of the next chunk go
 // into the first slots.
-template <int NT, int KS, int NX>
+template <int NT, int KS, int FETCH = 1, int NX>
 __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16* c1,
                                           f32x16* c2, int lane) {
     static_assert(KS <= NX, "k-step range");
+    static_assert(!S16 || KS % 2 == 0, "the 16x16x32 shape consumes k-steps in pairs");
     constexpr int N = NT * KS;           // blocks in the chunk
     constexpr int NQ = 3 * N;
-    constexpr int STRIDE = NQ >= 27 ? 3 : (NQ >= 18 ? 2 : 1);
-    static_assert(NQ >= MAX_PIECES_PER_WAVE, "not enough slots for the DMA pieces");
+    constexpr int NP = FETCH > 1 ? WStream::n_pieces<FETCH>() : MAX_PIECES_PER_WAVE;
+    constexpr int STRIDE = NQ >= 3 * NP ? 3 : (NQ >= 2 * NP ? 2 : 1);
+    static_assert(NQ >= NP, "not enough slots for the DMA pieces");
     h8 ah[3], al[3];
     (void)lane;
-    const char* const lbuf = buf + lane_x16();   // see mma_tile
+    const int l16 = lane_x16();
+    const char* const lbuf = buf + l16;   // see mma_tile
     auto load = [&](auto S) {
         constexpr int s = decltype(S)::value;
         ah[s % 3] = *reinterpret_cast<const h8*>(lbuf + s * KS_BYTES);
@@ -346,7 +597,8 @@ __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8
     };
     auto slot = [&](auto Q_) {
         constexpr int Q = decltype(Q_)::value;
-        if constexpr (Q % STRIDE == STRIDE - 1 && Q / STRIDE < MAX_PIECES_PER_WAVE) ws.template piece<NoEpi::branchy>(Q / STRIDE);
+        if constexpr (FETCH == 1 && Q % STRIDE == STRIDE - 1 && Q / STRIDE < NP) ws.template piece<NoEpi::branchy>(Q / STRIDE);
+        if constexpr (FETCH > 1 && Q % STRIDE == STRIDE - 1 && Q / STRIDE < NP) ws.template piece_c<FETCH, Q / STRIDE>(l16);
         __builtin_amdgcn_sched_barrier(0);
     };
     load(std::integral_constant<int, 0>{});
@@ -356,12 +608,9 @@ __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8
         constexpr int t = s / KS, k = s % KS;
         if constexpr (s + 2 < N) load(std::integral_constant<int, s + 2>{});
         if constexpr (k == 0) ws.stamp(5);
-        c1[t] = mfma16(ah[s % 3], xh[k], c1[t]);
-        slot(std::integral_constant<int, 3 * s>{});
-        c2[t] = mfma16(ah[s % 3], xl[k], c2[t]);
-        slot(std::integral_constant<int, 3 * s + 1>{});
-        c2[t] = mfma16(al[s % 3], xh[k], c2[t]);
-        slot(std::integral_constant<int, 3 * s + 2>{});
+        // (slot indices continue over the tiles of the chunk: block k of tile t is slot base 3 (t KS + k))
+        auto slot_t = [&](auto Q_) { slot(std::integral_constant<int, decltype(Q_)::value + 3 * t * KS>{}); };
+        mma_block<k, 0>(ah[s % 3], al[s % 3], xh, xl, c1[t], c2[t], slot_t);
     });
     ws.stamp(4);
 }
@@ -369,6 +618,22 @@ __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8
 // tail helpers: 32 floats stored [half][16] so that lane half h reads its 16 rows as 4 float4
 // (row of register i, half h: (i&3) + 8 (i>>2) + 4 h)
 __device__ __forceinline__ f32x16 tail_tile(const char* tail, int slot, int h) {
+    if constexpr (S16) {
+        // stored [g][8]: the 8 rows 16 rb + 4 g + ii of lane group g; both column blocks get the same row values
+        const int g = lane_x16() >> 8;
+        const float4* p = reinterpret_cast<const float4*>(tail + slot * 128 + g * 32);
+        const float4 w0 = p[0], w1 = p[1];
+        f32x16 v;
+        v[0] = v[4] = w0.x;
+        v[1] = v[5] = w0.y;
+        v[2] = v[6] = w0.z;
+        v[3] = v[7] = w0.w;
+        v[8] = v[12] = w1.x;
+        v[9] = v[13] = w1.y;
+        v[10] = v[14] = w1.z;
+        v[11] = v[15] = w1.w;
+        return v;
+    }
     f32x16 v;
     const float4* p = reinterpret_cast<const float4*>(tail + slot * 128 + h * 64);
 #pragma unroll
@@ -445,9 +710,11 @@ struct EpiState {
     float r0, r1;    // residuals of the pair being converted
     f32x2 z2, t2, e2;   // pair pipeline (HN_EPI_PAIRS): pre-activation, scaled argument, exponential
     float inv;       // 1/2048, laundered behind the tile's barrier: ties every phase-0 to this side of it
+    float scale;     // 2048 in a register (the mix instructions take no literal)
 };
 template <int I, bool FRAGS>
 __device__ __forceinline__ void split_phase(EpiState& st) {
+    static_assert(!S16, "the scalar epilogue form is not kept for the 16x16x32 shape");
     if constexpr (FRAGS) {
         constexpr int u = I >> 3, j = I & 7;
         if constexpr ((I & 1) == 1) {
@@ -516,20 +783,30 @@ __device__ __forceinline__ void pair_phase(EpiState& st, const PD& pd) {
         st.v[i1] = v[1];
     } else if constexpr (P == 4) {
         if constexpr (FRAGS) {
-            constexpr int u = i0 >> 3, j = i0 & 7;
+            constexpr int u = frag_u(i0), j = frag_j(i0);
+#if HN_SPLIT_MIX
+            unsigned hp;
+            split_pair_hi(st.v[i0], st.v[i1], hp, st.r0, st.r1);
+            set_pair<j / 2>(st.hi[u], hp);
+#else
             const _Float16 h0 = hi_part(st.v[i0]), h1 = hi_part(st.v[i1]);
             st.hi[u][j] = h0;
             st.hi[u][j + 1] = h1;
             const f32x2 r = f32x2{st.v[i0], st.v[i1]} - f32x2{(float)h0, (float)h1};
             st.r0 = r[0];
             st.r1 = r[1];
+#endif
         }
     } else {
         if constexpr (FRAGS) {
-            constexpr int u = i0 >> 3, j = i0 & 7;
+            constexpr int u = frag_u(i0), j = frag_j(i0);
+#if HN_SPLIT_MIX
+            set_pair<j / 2>(st.lo[u], split_pair_lo(st.r0, st.r1, st.scale));
+#else
             const f32x2 l = f32x2{st.r0, st.r1} * f32x2{LO_SCALE, LO_SCALE};
             st.lo[u][j] = (_Float16)l[0];
             st.lo[u][j + 1] = (_Float16)l[1];
+#endif
         }
     }
 }
@@ -568,6 +845,7 @@ __device__ __forceinline__ void arm(EpiState& st) {
     float inv = LO_INV;
     asm volatile("" : "+v"(inv));
     st.inv = inv;
+    st.scale = LO_SCALE;
 }
 
 // OT output tiles of KS k-steps; TPC tiles share one chunk (+ 1 KiB tail if TAIL, whose slot (t % TPC) is
@@ -581,9 +859,11 @@ __device__ __forceinline__ void arm(EpiState& st) {
 //   - `held = fin(T-1, st, pd)`: the finished tile's fragments -> registers; returns what `store` needs.
 // next_same / next_after: bytes of the chunk that follows a chunk of this layer (another of the same
 // layer / the first of the next layer; 0 = none).
-template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, int NX, typename Pre, typename Ph, typename Fin, typename Store>
-__device__ __forceinline__ void run_layer(WStream& ws, int next_same, int next_after, const h8 (&xh)[NX], const h8 (&xl)[NX],
-                                          int lane, int h, Pre&& pre, Ph&& ph, Fin&& fin, Store&& store) {
+// NS / NA >= 0: next_same / next_after as constants (the compile-time-sized fetch of WStream); -1: the run-time arguments.
+template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, int NS, int NA, int NX, typename Pre, typename Ph, typename Fin, typename Store>
+__device__ __forceinline__ void run_layer_impl(WStream& ws, int next_same, int next_after, const h8 (&xh)[NX], const h8 (&xl)[NX],
+                                               int lane, int h, Pre&& pre, Ph&& ph, Fin&& fin, Store&& store) {
+    static_assert((NS >= 0) == (NA >= 0), "both sizes constant or both run-time");
     using I0 = std::integral_constant<int, 0>;
     using PD = decltype(pre(I0{}, (const char*)nullptr));
     f32x16 c1[2], c2[2];
@@ -597,7 +877,10 @@ __device__ __forceinline__ void run_layer(WStream& ws, int next_same, int next_a
         constexpr bool opens = t % TPC == 0;
         if constexpr (opens) buf = ws.template acquire<0>();
         if constexpr (t >= 2) store(std::integral_constant<int, t - 2>{}, held);
-        if constexpr (opens) ws.begin(t + TPC < OT ? next_same : next_after);
+        constexpr int nb = NS < 0 ? -1 : (t + TPC < OT ? NS : NA);   // constant size of the chunk fetched from here
+        constexpr int fetch = !opens ? 0 : (nb < 0 ? 1 : nb);
+        if constexpr (opens && nb < 0) ws.begin(t + TPC < OT ? next_same : next_after);
+        if constexpr (opens && nb > 0) ws.template begin_c<nb>();
         const char* tail = buf + TPC * KS * KS_BYTES;
         arm(st);
         if constexpr (t > 0) {
@@ -609,11 +892,11 @@ __device__ __forceinline__ void run_layer(WStream& ws, int next_same, int next_a
         pd[t & 1] = pre(T, tail);
         if constexpr (t > 0) {
             Epi<FRAGS, std::remove_reference_t<Ph>, PD> epi{st, ph, pd[(t - 1) & 1]};
-            mma_tile<KS, 0, opens>(ws, buf + (t % TPC) * KS * KS_BYTES, xh, xl, c1[t & 1], c2[t & 1], lane, epi);
+            mma_tile<KS, 0, fetch>(ws, buf + (t % TPC) * KS * KS_BYTES, xh, xl, c1[t & 1], c2[t & 1], lane, epi);
             split_finish<FRAGS>(st);
             held = fin(std::integral_constant<int, t - 1>{}, st, pd[(t - 1) & 1]);
         } else {
-            mma_tile<KS, 0, opens>(ws, buf + (t % TPC) * KS * KS_BYTES, xh, xl, c1[t & 1], c2[t & 1], lane);
+            mma_tile<KS, 0, fetch>(ws, buf + (t % TPC) * KS * KS_BYTES, xh, xl, c1[t & 1], c2[t & 1], lane);
         }
     });
     if constexpr (OT >= 2) store(std::integral_constant<int, OT - 2>{}, held);
@@ -625,6 +908,16 @@ __device__ __forceinline__ void run_layer(WStream& ws, int next_same, int next_a
     split_finish<FRAGS>(st);
     held = fin(std::integral_constant<int, OT - 1>{}, st, pd[(OT - 1) & 1]);
     store(std::integral_constant<int, OT - 1>{}, held);
+}
+template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, int NX, typename Pre, typename Ph, typename Fin, typename Store>
+__device__ __forceinline__ void run_layer(WStream& ws, int next_same, int next_after, const h8 (&xh)[NX], const h8 (&xl)[NX],
+                                          int lane, int h, Pre&& pre, Ph&& ph, Fin&& fin, Store&& store) {
+    run_layer_impl<OT, KS, TPC, TAIL, FRAGS, -1, -1>(ws, next_same, next_after, xh, xl, lane, h, pre, ph, fin, store);
+}
+template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, int NS, int NA, int NX, typename Pre, typename Ph, typename Fin, typename Store>
+__device__ __forceinline__ void run_layer_c(WStream& ws, const h8 (&xh)[NX], const h8 (&xl)[NX], int lane, int h, Pre&& pre,
+                                            Ph&& ph, Fin&& fin, Store&& store) {
+    run_layer_impl<OT, KS, TPC, TAIL, FRAGS, NS, NA>(ws, 0, 0, xh, xl, lane, h, pre, ph, fin, store);
 }
 
 // standard phases ---------------------------------------------------------------------------------
@@ -847,6 +1140,25 @@ __device__ __forceinline__ float half_sum(float v) {
     const unsigned x = __builtin_bit_cast(unsigned, v);
     const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
     return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// 16x16x32 shape: a lane's tile registers belong to two samples (cb = (i >> 2) & 1), four lanes (g) share a sample.
+// v[cb]: this lane's partial sums over its registers of column block cb -> the sample's total, returned in the lanes
+// that own the sample in the old map (sample c16 + 16 q  <->  lanes with (lane >> 4) & 1 == q)
+__device__ __forceinline__ float sample_sum(float v0, float v1) {
+    if constexpr (!S16) return v0 + v1;   // (callers on the old shape use half_sum)
+    unsigned a = __builtin_bit_cast(unsigned, v0), b = __builtin_bit_cast(unsigned, v1);
+    auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);   // rows (0,1) and (2,3) paired
+    const float s0 = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    const float s1 = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    a = __builtin_bit_cast(unsigned, s0);
+    b = __builtin_bit_cast(unsigned, s1);
+    r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    const float t0 = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    const float t1 = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    const int q = (lane_x16() >> 8) & 1;
+    return q ? t1 : t0;
 }
 // the other half's value of the same column: lane l <- lane l ^ 32  (h = l >> 5)
 __device__ __forceinline__ float other_half(float v, int h) {

@@ -424,6 +424,7 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
         if (f->v2_sdf) (void)hipFree(f->v2_sdf);
         if (f->v2_adj) (void)hipFree(f->v2_adj);
         if (f->v2_adjonly) (void)hipFree(f->v2_adjonly);
+        if (f->v2_tape) (void)hipFree(f->v2_tape);
         if (f->blob) (void)hipFree(f->blob);
         if (f->raw) (void)hipFree(f->raw);
         delete f;

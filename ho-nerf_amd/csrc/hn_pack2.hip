@@ -21,9 +21,19 @@ struct HostMat {
     float at(int r, int c) const { return w[(size_t)r * cols + c]; }
 };
 
+// The stream being built is for the 16x16x32 MFMA shape (hn_mlp2.h, "MFMA shape").  k-slots are numbered
+// kappa = 16 s + 8 h + j in both shapes (new: k-step pair s >> 1, lane group g = 2 (s & 1) + h); what differs is which
+// tile row a slot's neuron is (the rule "a finished tile's registers are the next layer's fragments"), the lane order
+// inside an A-fragment block, and the tail layout.
+static thread_local bool g_s16 = false;
 // neuron (row of a [256 x samples] activation) held in k-step s, lane half h, fragment element j
-static inline int hid_k(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+static inline int hid_k(int s, int h, int j) {
+    if (g_s16) return 32 * (s >> 1) + 16 * (j >> 2) + 4 * (2 * (s & 1) + h) + (j & 3);
+    return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+}
 // inverse for rows of an accumulator whose rows ARE k-slots: natural row n -> (s, h, j)
+// (the same on both shapes: such tiles are handed to the per-sample code in the old layout -- tile_out -- where
+// register 8 s + j of lane half h is k-slot (s, h, j))
 static inline void k_of_row(int n, int& s, int& h, int& j) {
     s = n >> 4;
     const int rem = n & 15;
@@ -40,6 +50,7 @@ struct Builder {
     void chunk(const HostMat& M, bool transposed, float scale, int tiles, int ks, const int* rowmap, const int* colslot,
                const float* tail /* 256 floats or nullptr */) {
         const size_t base = blob.size();
+        if (g_s16 && (ks & 1)) abort();   // k-steps come in pairs on this shape: the caller pads
         blob.resize(base + (size_t)tiles * ks * KS_BYTES + (tail ? TAIL_BYTES : 0));
         _Float16* dst = reinterpret_cast<_Float16*>(blob.data() + base);
         for (int ti = 0; ti < tiles; ++ti)
@@ -47,10 +58,13 @@ struct Builder {
                 _Float16* hi = dst + ((size_t)(ti * ks + s) * KS_BYTES) / 2;
                 _Float16* lo = hi + 512;
                 for (int l = 0; l < 64; ++l) {
-                    const int r = l & 31, h = l >> 5;
+                    // 32x32x16: block s = k-step s, lane = (row l & 31, half l >> 5).  16x16x32: block s = row block
+                    // s & 1 of k-step pair s >> 1, lane = (row l & 15 of the block, k-group g = l >> 4)
+                    const int r = g_s16 ? 16 * (s & 1) + (l & 15) : (l & 31);
+                    const int kbase = g_s16 ? 32 * (s >> 1) + 8 * (l >> 4) : s * 16 + 8 * (l >> 5);
                     const int row = rowmap[ti * 32 + r];
                     for (int j = 0; j < 8; ++j) {
-                        const int col = colslot[s * 16 + 8 * h + j];
+                        const int col = colslot[kbase + j];
                         float x = 0.f;
                         if (row >= 0 && col >= 0) x = (transposed ? M.at(col, row) : M.at(row, col)) * scale;
                         const _Float16 xh = (_Float16)x;   // IEEE, subnormals kept: the MFMA reads them as such
@@ -71,6 +85,11 @@ struct Builder {
 
 // tail slot k <- 32 values given in natural tile-row order, stored [half][16]
 static void tail_put(float* tail, int k, const float* v32) {
+    if (g_s16) {   // [g][8]: rows 16 rb + 4 g + ii (hn_mlp2.h tail_tile)
+        for (int g = 0; g < 4; ++g)
+            for (int m = 0; m < 8; ++m) tail[k * 32 + g * 8 + m] = v32[16 * (m >> 2) + 4 * g + (m & 3)];
+        return;
+    }
     for (int h = 0; h < 2; ++h)
         for (int i = 0; i < 16; ++i) tail[k * 32 + h * 16 + i] = v32[tile_row(i, h)];
 }
@@ -343,15 +362,22 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
         if (rc != HN_OK) return rc;
     }
     HN_CHECK_HIP(hipStreamSynchronize(stream));
-    for (int mode = 0; mode < 4; ++mode) {
+    // modes 0 .. 3 as the kernels' MODE 0, 1, 2, 4; "mode 4": the taped evaluation's copy of the mode-1 program on the
+    // adjoint kernels' MFMA shape, built only where the evaluation kernels use the other one
+    const bool eval16 = f->kind == HN_FIELD_OBJ ? (HN_OBJ_EVAL_MFMA16 != 0) : (HN_HAND_EVAL_MFMA16 != 0);
+    for (int mode = 0; mode < (eval16 ? 5 : 4); ++mode) {
         Builder B;
+        g_s16 = eval16 && mode < 2;
+        const int prog = mode == 4 ? 1 : mode;
         if (f->kind == HN_FIELD_OBJ) {
-            build_obj_stream(B, S, C, mode);
+            build_obj_stream(B, S, C, prog);
         } else {
-            build_hand_stream(B, S, C, mode);
+            build_hand_stream(B, S, C, prog);
         }
-        void** dst = mode == 0 ? &f->v2_sdf : (mode == 1 ? &f->v2_full : (mode == 2 ? &f->v2_adj : &f->v2_adjonly));
-        size_t* nb = mode == 0 ? &f->v2_sdf_bytes : (mode == 1 ? &f->v2_full_bytes : (mode == 2 ? &f->v2_adj_bytes : &f->v2_adjonly_bytes));
+        g_s16 = false;
+        void** dst = mode == 0 ? &f->v2_sdf : (mode == 1 ? &f->v2_full : (mode == 2 ? &f->v2_adj : (mode == 3 ? &f->v2_adjonly : &f->v2_tape)));
+        size_t* nb = mode == 0 ? &f->v2_sdf_bytes
+                               : (mode == 1 ? &f->v2_full_bytes : (mode == 2 ? &f->v2_adj_bytes : (mode == 3 ? &f->v2_adjonly_bytes : &f->v2_tape_bytes)));
         const int rc = upload(B.blob, dst, nb, stream);
         if (rc != HN_OK) return rc;
     }
@@ -403,9 +429,11 @@ static void feature_block(Builder& B, const HostMat& M, float scale, int col_off
         const std::vector<int> slots = offset(bone_slots(b), col_off);
         for (int blk = 0; blk < 2; ++blk) B.chunk(M, false, scale, 4, 4, rows[blk].data(), slots.data(), nullptr);
     }
-    const std::vector<int> ls = offset(left_slots(), col_off);
-    B.chunk(M, false, scale, 4, 3, rows[0].data(), ls.data(), tail0);
-    B.chunk(M, false, scale, 4, 3, rows[1].data(), ls.data(), tail1);
+    std::vector<int> ls = offset(left_slots(), col_off);
+    const int lks = g_s16 ? 4 : 3;   // the 16x16x32 shape takes k-steps in pairs: a fourth, empty one
+    ls.resize(16 * lks, -1);
+    B.chunk(M, false, scale, 4, lks, rows[0].data(), ls.data(), tail0);
+    B.chunk(M, false, scale, 4, lks, rows[1].data(), ls.data(), tail1);
 }
 static void tail_biases4(float* tail, const HostMat& M, int pass) {
     for (int ti = 0; ti < 4; ++ti) {

@@ -8,11 +8,21 @@
 #include "hn_common.h"
 #include "hn_mlp2.h"
 using namespace hn::v2;
+#ifdef CT
+#define RL(OT, KS, TPC, TAIL, FR) run_layer_c<OT, KS, TPC, TAIL, FR, HB, HB>(ws,
+#else
+#define RL(OT, KS, TPC, TAIL, FR) run_layer<OT, KS, TPC, TAIL, FR>(ws, HB, HB,
+#endif
 #ifndef VARIANT
 #define VARIANT 0
 #endif
 constexpr int HB = chunk_bytes(1, 16, true);
 constexpr int HBB = chunk_bytes(4, 4, false);
+#ifdef CT
+constexpr int FCH = HBB;
+#else
+constexpr int FCH = 1;
+#endif
 struct Act { f32x16 v; };
 __global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, int layers, float4* scratch, long long* cyc, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -22,7 +32,11 @@ __global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, i
     f16_flush_mode();
     WStream ws;
     ws.init(blob, bytes, lds, wave, lane);
+#ifdef CT
+    if (VARIANT == 5 || VARIANT == 6) ws.fetch_all_c<HBB>(); else ws.fetch_all_c<HB>();
+#else
     ws.fetch_all((VARIANT == 5 || VARIANT == 6) ? HBB : HB);
+#endif
     Stash sh;
     sh.init(scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * 2 * SLOT_F4, 2, lane);
     h8 ah[16], al[16], bh[16], bl[16];
@@ -55,14 +69,14 @@ __global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, i
 #pragma unroll 1
     for (int l = 0; l < layers; l += 2) {
         if (VARIANT == 0 || VARIANT == 3) {
-            run_layer<8, 16, 1, true, true>(ws, HB, HB, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs(bh, bl), no_store);
-            run_layer<8, 16, 1, true, true>(ws, HB, HB, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs(ah, al), no_store);
+            RL(8, 16, 1, true, true) ah, al, lane, h, no_pre, PhSoftplus{}, to_regs(bh, bl), no_store);
+            RL(8, 16, 1, true, true) bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs(ah, al), no_store);
         } else if (VARIANT == 1) {
-            run_layer<8, 16, 1, true, true>(ws, HB, HB, ah, al, lane, h, no_pre, PhRelu{}, to_regs(bh, bl), no_store);
-            run_layer<8, 16, 1, true, true>(ws, HB, HB, bh, bl, lane, h, no_pre, PhRelu{}, to_regs(ah, al), no_store);
+            RL(8, 16, 1, true, true) ah, al, lane, h, no_pre, PhRelu{}, to_regs(bh, bl), no_store);
+            RL(8, 16, 1, true, true) bh, bl, lane, h, no_pre, PhRelu{}, to_regs(ah, al), no_store);
         } else if (VARIANT == 2) {
-            run_layer<8, 16, 1, true, false>(ws, HB, HB, ah, al, lane, h, no_pre, PhIdentity{}, sink_fin, no_store);
-            run_layer<8, 16, 1, true, false>(ws, HB, HB, ah, al, lane, h, no_pre, PhIdentity{}, sink_fin, no_store);
+            RL(8, 16, 1, true, false) ah, al, lane, h, no_pre, PhIdentity{}, sink_fin, no_store);
+            RL(8, 16, 1, true, false) ah, al, lane, h, no_pre, PhIdentity{}, sink_fin, no_store);
         } else if (VARIANT == 5 || VARIANT == 6) {
             // feature-pass shape: chunks of 4 tiles x 4 k-steps sharing 4 fragments, 8 live accumulator pairs
             f32x16 c1[8], c2[8];
@@ -78,17 +92,21 @@ __global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, i
                 static_for<2>([&](auto BLK) {
                     constexpr int blk = decltype(BLK)::value;
                     const char* buf = ws.template acquire<0>();
+#ifdef CT
+                    ws.begin_c<HBB>();
+#else
                     ws.begin(HBB);
+#endif
                     if constexpr (VARIANT == 5) {
                         static_for<4>([&](auto TI) {
                             constexpr int ti = decltype(TI)::value;
                             if constexpr (ti == 0)
-                                mma_tile<4, 0, true>(ws, buf + ti * 4 * KS_BYTES, fh, fl, c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                                mma_tile<4, 0, FCH>(ws, buf + ti * 4 * KS_BYTES, fh, fl, c1[4 * blk + ti], c2[4 * blk + ti], lane);
                             else
-                                mma_tile<4, 0, false>(ws, buf + ti * 4 * KS_BYTES, fh, fl, c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                                mma_tile<4, 0, 0>(ws, buf + ti * 4 * KS_BYTES, fh, fl, c1[4 * blk + ti], c2[4 * blk + ti], lane);
                         });
                     } else {
-                        mma_chunk<4, 4>(ws, buf, fh, fl, &c1[4 * blk], &c2[4 * blk], lane);
+                        mma_chunk<4, 4, FCH>(ws, buf, fh, fl, &c1[4 * blk], &c2[4 * blk], lane);
                     }
                 });
             }
@@ -97,8 +115,8 @@ __global__ __launch_bounds__(256) void k_bench(const char* blob, size_t bytes, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc += c1[i][r] + c2[i][r];
         } else {
-            run_layer<8, 16, 1, true, true>(ws, HB, HB, ah, al, lane, h, act_of, PhDsig{}, to_regs(bh, bl), no_store);
-            run_layer<8, 16, 1, true, true>(ws, HB, HB, bh, bl, lane, h, act_of, PhDsig{}, to_regs(ah, al), no_store);
+            RL(8, 16, 1, true, true) ah, al, lane, h, act_of, PhDsig{}, to_regs(bh, bl), no_store);
+            RL(8, 16, 1, true, true) bh, bl, lane, h, act_of, PhDsig{}, to_regs(ah, al), no_store);
         }
     }
     const long long t1 = __builtin_readcyclecounter();
