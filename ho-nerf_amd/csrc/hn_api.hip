@@ -563,6 +563,14 @@ int hn_color_forward(const hn_field* f, const float* x, const float* view_dirs, 
     return hn::bwd::color_forward(f, x, view_dirs, feature_vectors, normals, n_pts, rgb, workspace, workspace_bytes,
                                   (hipStream_t)stream);
 }
+int hn_pose_chain(const float* ori_pose, const float* bone_len, const unsigned char* is_right, const float* params, int n_frames,
+                  float* bt_inv, float* joint_3d, float* jac, hn_stream_t stream) {
+    return hn::pose_chain(ori_pose, bone_len, is_right, params, n_frames, bt_inv, joint_3d, jac, (hipStream_t)stream);
+}
+int hn_pose_chain_bwd(const float* jac, const float* g_bt_inv, const float* g_joint_3d, int n_frames, float* g_params, hn_stream_t stream) {
+    return hn::pose_chain_bwd(jac, g_bt_inv, g_joint_3d, n_frames, g_params, (hipStream_t)stream);
+}
+
 int hn_nearest_masked(const float* pts, int n_verts, int n_sets, const unsigned char* query_mask, const unsigned char* cand_mask,
                       unsigned char* selected, int32_t* nearest, hn_stream_t stream) {
     return hn::bwd::nearest_masked(pts, n_verts, n_sets, query_mask, cand_mask, selected, nearest, (hipStream_t)stream);

@@ -40,6 +40,10 @@ int device_cus();              // CU count of the CURRENT device (cached per dev
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): `mask` is the kernel's own
 // bit set of devices already configured (a static std::atomic<uint64_t> next to the launch).
 int ensure_dynamic_lds(const void* kernel, int bytes, void* mask_atomic_u64);
+// hn_pose_chain.hip
+int pose_chain(const float* ori_pose, const float* bone_len, const unsigned char* is_right, const float* in, int n_frames, float* bt_inv,
+               float* joint_3d, float* jac, hipStream_t s);
+int pose_chain_bwd(const float* jac, const float* g_bt_inv, const float* g_joint_3d, int n_frames, float* g_in, hipStream_t s);
 
 // ---- network geometry (fixed by the reference confs; checked in hn_field_create) ---------
 constexpr int H = 256;           // d_hidden == d_feature

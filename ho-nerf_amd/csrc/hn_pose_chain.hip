@@ -1,0 +1,67 @@
+// hn_pose_chain / hn_pose_chain_bwd: the hand pose chain of the fitting loops (fitting_single.py:206-226 and the
+// halo_util functions it calls, ~4 000 torch operators per step in the reference) as two launches.  The chain itself is
+// hn_pose_chain.h; here one thread per (frame, input direction) evaluates it on dual numbers: thread 0 of a frame writes
+// the values, thread 1 + k the column d(outputs)/d(input k) of the Jacobian [N_OUT x N_IN], which the backward launch
+// contracts with the upstream gradient.  The work is a few kFLOP per thread; the point is the launch count.
+#include "hn_common.h"
+#include "hn_pose_chain.h"
+
+namespace hn {
+
+using pose::Dual;
+using pose::N_IN;
+using pose::N_OUT;
+
+__global__ __launch_bounds__(64) void k_pose_chain(const float* __restrict__ ori_pose, const float* __restrict__ bone_len,
+                                                   const unsigned char* __restrict__ is_right, const float* __restrict__ in, int n_frames,
+                                                   float* __restrict__ bt_inv, float* __restrict__ joint_3d, float* __restrict__ jac) {
+    const int f = blockIdx.x, k = threadIdx.x;   // k = 0: values; k = 1 + input index: that input's derivative
+    if (f >= n_frames || k > N_IN || (k > 0 && jac == nullptr)) return;
+    // In double: the chain is a few kFLOP per thread, and in fp32 its angle / normalisation steps leave 3e-4 of relative
+    // error on the Jacobian (measured against the reference's fp64 run; the reference's own fp32 run is 3e-5 off on the
+    // values).  Inputs and outputs stay fp32.
+    double pose[21][3], bl[20];
+    for (int i = 0; i < 63; ++i) pose[i / 3][i % 3] = (double)ori_pose[(size_t)f * 63 + i];
+    for (int i = 0; i < 20; ++i) bl[i] = (double)bone_len[(size_t)f * 20 + i];
+    Dual<double> x[N_IN], y[N_OUT];
+    for (int i = 0; i < N_IN; ++i) x[i] = Dual<double>((double)in[(size_t)f * N_IN + i], i == k - 1 ? 1.0 : 0.0);
+    pose::pose_chain<double>(pose, bl, is_right == nullptr || is_right[f] != 0, x, y);
+    if (k == 0) {
+        for (int i = 0; i < 21 * 16; ++i) bt_inv[(size_t)f * 336 + i] = (float)y[i].v;
+        for (int i = 0; i < 63; ++i) joint_3d[(size_t)f * 63 + i] = (float)y[336 + i].v;
+    } else {
+        for (int i = 0; i < N_OUT; ++i) jac[((size_t)f * N_OUT + i) * N_IN + (k - 1)] = (float)y[i].d;
+    }
+}
+
+// g_in[f][k] = sum_o jac[f][o][k] g_out[f][o];  g_out = [g_bt_inv 336 | g_joint_3d 63] (either may be NULL = zero)
+__global__ __launch_bounds__(64) void k_pose_chain_bwd(const float* __restrict__ jac, const float* __restrict__ g_bt, const float* __restrict__ g_j3,
+                                                       int n_frames, float* __restrict__ g_in) {
+    const int f = blockIdx.x, k = threadIdx.x;
+    if (f >= n_frames || k >= N_IN) return;
+    const float* J = jac + (size_t)f * N_OUT * N_IN;
+    float acc = 0.f;
+    if (g_bt != nullptr)
+        for (int o = 0; o < 336; ++o) acc = fmaf(J[o * N_IN + k], g_bt[(size_t)f * 336 + o], acc);
+    if (g_j3 != nullptr)
+        for (int o = 0; o < 63; ++o) acc = fmaf(J[(336 + o) * N_IN + k], g_j3[(size_t)f * 63 + o], acc);
+    g_in[(size_t)f * N_IN + k] = acc;
+}
+
+int pose_chain(const float* ori_pose, const float* bone_len, const unsigned char* is_right, const float* in, int n_frames, float* bt_inv,
+               float* joint_3d, float* jac, hipStream_t s) {
+    if (n_frames <= 0) return HN_OK;
+    HN_REQUIRE(ori_pose != nullptr && bone_len != nullptr && in != nullptr && bt_inv != nullptr && joint_3d != nullptr, "pose chain: NULL argument");
+    hipLaunchKernelGGL(k_pose_chain, dim3(n_frames), dim3(64), 0, s, ori_pose, bone_len, is_right, in, n_frames, bt_inv, joint_3d, jac);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+int pose_chain_bwd(const float* jac, const float* g_bt_inv, const float* g_joint_3d, int n_frames, float* g_in, hipStream_t s) {
+    if (n_frames <= 0) return HN_OK;
+    HN_REQUIRE(jac != nullptr && g_in != nullptr, "pose chain backward: NULL argument");
+    hipLaunchKernelGGL(k_pose_chain_bwd, dim3(n_frames), dim3(64), 0, s, jac, g_bt_inv, g_joint_3d, n_frames, g_in);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+}  // namespace hn

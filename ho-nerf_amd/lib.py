@@ -70,6 +70,8 @@ SIGNATURES = {
     'hn_color_forward_workspace_bytes': (c_sz, [c_vp, c_i]),
     'hn_color_forward': (c_i, [c_vp, c_f, c_f, c_f, c_f, c_i, c_f, c_vp, c_sz, c_vp]),
     'hn_nearest_masked': (c_i, [c_f, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'hn_pose_chain': (c_i, [c_f, c_f, c_vp, c_f, c_i, c_f, c_f, c_f, c_vp]),
+    'hn_pose_chain_bwd': (c_i, [c_f, c_f, c_f, c_i, c_f, c_vp]),
     'hn_alpha': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_vp]),
     'hn_composite1': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp]),
     'hn_composite2': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp]),

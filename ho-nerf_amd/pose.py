@@ -1,0 +1,88 @@
+"""The hand pose chain of the fitting loops as one differentiable op.
+
+Per optimisation step the reference turns its refine parameters into the hand field's `bone_transformation_inv` with
+(fitting_single.py:206-226, the same statements in fitting_video.py)
+
+    convert_joints -> transform_to_canonical -> PoseConverter.get_refine_3d_joint -> inverse canonical transform ->
+    rot6d_to_matrix / palm rotation + translation -> convert_joints -> transform_to_canonical -> PoseConverter.forward ->
+    convert_joints -> @ rot_then_swap_mat
+
+which is about 4 000 small torch operators forward (halo_util/converter_fit_batch.py) and as many backward: with the
+renderer at a few milliseconds per step it is the step's largest part.  `hn_pose_chain` evaluates the whole chain in one
+launch together with its exact Jacobian (forward-mode dual numbers, ho-nerf_amd/csrc/hn_pose_chain.h); the backward pass is
+one more launch (`hn_pose_chain_bwd`).  Parity: tests/golden/pose_chain.npz holds values and Jacobians produced by
+executing the reference's own statements (tests/golden/make_golden.py, pose_goldens).
+"""
+import torch
+
+from . import lib as _lib
+
+N_IN, N_OUT = 36, 399
+
+
+class PoseChainFn(torch.autograd.Function):
+    """(ori_pose [F,21,3], bone_len [F,20], params [F,36]) -> (bone_transformation_inv [F,21,4,4], joint_3d [F,21,3]);
+    params = [joint_refine_angle 20 | palm_refine_angle 7 | palm_rot_refine 6 | palm_trans_refine 3].  Gradients flow to
+    `params` only: the predicted joints and bone lengths are data in the reference's loop too."""
+
+    @staticmethod
+    def forward(ctx, ori_pose, bone_len, params):
+        L = _lib
+        lib = L.load()
+        ori, bl, prm = L.f32(ori_pose).reshape(-1, 21, 3), L.f32(bone_len).reshape(-1, 20), L.f32(params).reshape(-1, N_IN)
+        F, dev = ori.shape[0], ori.device
+        assert bl.shape[0] == F and prm.shape[0] == F, 'one row of bone lengths and parameters per frame'
+        bt = torch.empty(F, 21, 4, 4, device=dev, dtype=torch.float32)
+        j3 = torch.empty(F, 21, 3, device=dev, dtype=torch.float32)
+        need = params.requires_grad
+        jac = torch.empty(F, N_OUT, N_IN, device=dev, dtype=torch.float32) if need else None
+        L.check(lib.hn_pose_chain(L.ptr(ori), L.ptr(bl), None, L.ptr(prm), F, L.ptr(bt), L.ptr(j3), L.ptr(jac) if need else None,
+                                  L.stream_ptr()), 'hn_pose_chain')
+        ctx.jac, ctx.shape = jac, params.shape
+        return bt, j3
+
+    @staticmethod
+    def backward(ctx, g_bt, g_j3):
+        L = _lib
+        lib = L.load()
+        jac = ctx.jac
+        F = jac.shape[0]
+        g = torch.empty(F, N_IN, device=jac.device, dtype=torch.float32)
+        gb = L.f32(g_bt).reshape(F, 336) if g_bt is not None else None
+        gj = L.f32(g_j3).reshape(F, 63) if g_j3 is not None else None
+        L.check(lib.hn_pose_chain_bwd(L.ptr(jac), L.ptr(gb) if gb is not None else None, L.ptr(gj) if gj is not None else None, F,
+                                      L.ptr(g), L.stream_ptr()), 'hn_pose_chain_bwd')
+        return None, None, g.reshape(ctx.shape)
+
+
+def pose_chain(ori_3d_pose, cur_bone_length, joint_refine_angle, palm_refine_angle, palm_rot_refine, palm_trans_refine):
+    """fitting_single.py:206-226 with the reference's variable names: ori_3d_pose [F,21,3] (MANO order), cur_bone_length
+    [F,20], joint_refine_angle [F,20], palm_refine_angle [F,7], palm_rot_refine [F,3,2], palm_trans_refine [F,3] ->
+    (bone_transformation_inv [F,21,4,4], joint_3d [F,21,3])."""
+    F = ori_3d_pose.shape[0]
+    params = torch.cat([joint_refine_angle.reshape(F, 20), palm_refine_angle.reshape(F, 7), palm_rot_refine.reshape(F, 6),
+                        palm_trans_refine.reshape(F, 3)], dim=1)
+    return PoseChainFn.apply(ori_3d_pose, cur_bone_length, params)
+
+
+class HandPoseChain(torch.nn.Module):
+    """The hand half of the fitting loops' parameter set (fitting_single.py:183-198) over `hn_pose_chain`: the four refine
+    leaves as one [F,36] parameter (views with the reference's names), forward() -> (bone_transformation_inv, joint_3d)."""
+
+    def __init__(self, ori_3d_pose, cur_bone_length):
+        super().__init__()
+        ori = torch.as_tensor(ori_3d_pose, dtype=torch.float32).reshape(-1, 21, 3)
+        F = ori.shape[0]
+        self.register_buffer('ori_3d_pose', ori.clone())
+        self.register_buffer('cur_bone_length', torch.as_tensor(cur_bone_length, dtype=torch.float32).reshape(F, 20).clone())
+        init = torch.zeros(F, N_IN)
+        init[:, 27:33] = torch.eye(3)[:, :2].reshape(-1)   # palm_rot_refine = eye(3)[:, :2] (fitting_single.py:183-185)
+        self.params = torch.nn.Parameter(init)
+
+    joint_refine_angle = property(lambda self: self.params[:, 0:20])
+    palm_refine_angle = property(lambda self: self.params[:, 20:27])
+    palm_rot_refine = property(lambda self: self.params[:, 27:33].reshape(-1, 3, 2))
+    palm_trans_refine = property(lambda self: self.params[:, 33:36])
+
+    def forward(self):
+        return PoseChainFn.apply(self.ori_3d_pose, self.cur_bone_length, self.params)

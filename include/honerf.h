@@ -188,6 +188,24 @@ int hn_color_forward(const hn_field* f, const float* x, const float* view_dirs, 
 int hn_nearest_masked(const float* pts, int n_verts, int n_sets, const unsigned char* query_mask,
                       const unsigned char* cand_mask, unsigned char* selected, int32_t* nearest, hn_stream_t stream);
 
+/* ---- hand pose chain of the fitting loops ------------------------------------------------
+ * fitting_single.py:206-226 (= fitting_video.py's per-frame chain): predicted joints, bone lengths and the refine
+ * parameters -> refined joints -> `bone_transformation_inv`, i.e. convert_joints / transform_to_canonical /
+ * PoseConverter.get_refine_3d_joint / rot6d_to_matrix / PoseConverter.forward (halo_util/converter_fit_batch.py:103-162,
+ * 1109-1229; halo_util/utils.py:17-41; utils/utils.py:11-30) in one launch instead of ~4 000 torch operators.
+ *   ori_pose [F,21,3]  the predicted joints, MANO order (ori_3d_pose);  bone_len [F,20]  cur_bone_length;
+ *   is_right [F] bytes or NULL (all right hands, as the fitting scripts pass);
+ *   params [F,36] = [joint_refine_angle 20 | palm_refine_angle 7 | palm_rot_refine 6 (row-major [3][2]) | palm_trans_refine 3]
+ *   -> bt_inv [F,21,4,4] (bone_transformation_inv), joint_3d [F,21,3] (the refined joints, MANO order: the joint loss's
+ *   input), and, when jac != NULL, jac [F,399,36] = d [bt_inv | joint_3d] / d params (forward-mode, exact).
+ * hn_pose_chain_bwd: g_params [F,36] = jac^T [g_bt_inv | g_joint_3d] (either gradient may be NULL = zero). */
+#define HN_POSE_CHAIN_IN 36
+#define HN_POSE_CHAIN_OUT 399
+int hn_pose_chain(const float* ori_pose, const float* bone_len, const unsigned char* is_right, const float* params,
+                  int n_frames, float* bt_inv, float* joint_3d, float* jac, hn_stream_t stream);
+int hn_pose_chain_bwd(const float* jac, const float* g_bt_inv, const float* g_joint_3d, int n_frames, float* g_params,
+                      hn_stream_t stream);
+
 /* ---- SDF -> alpha, compositing --------------------------------------------------------
  * utils/renderer.py:147-161 (cos_anneal_ratio = 1): alpha [n] (clipped to [0,1]) and
  * c = sigmoid(prev_sdf * inv_s) [n] from sdf, grad, per-ray dirs and dists. */

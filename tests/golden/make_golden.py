@@ -302,8 +302,75 @@ def loss_goldens(nets, nets_b, g):
     save('loss_video', stable=stable.detach(), **outv)
 
 
+def pose_goldens():
+    """The hand pose chain of the fitting loops, fitting_single.py:206-226, executed as the reference has it (the
+    statements are read from the reference file here and run unmodified; halo_util is imported) on synthetic predicted
+    joints: bone_transformation_inv, the refined joints and the full Jacobian w.r.t. the four refine parameters.
+    Run in double precision (torch default dtype float64 while the reference's modules are constructed and executed), so
+    that the fixture is the chain's exact value; the fp32 run's distance from it is stored beside it as the noise floor."""
+    import types as _t
+    import torch.nn.functional as F_
+    from halo_util.converter_fit_batch import PoseConverter, transform_to_canonical
+    from halo_util.utils import convert_joints
+    blk = reference_block('fitting_single.py', "kps_local_cs = convert_joints(ori_3d_pose, source='mano', target='biomech')",
+                          'obj_rots = rot6d_to_matrix(obj_rot_refine)')
+    r6 = reference_block('utils/utils.py', 'def rot6d_to_matrix(rot_6d)', 'def _xy_to_ray_bundle')
+    m2b = np.array([0, 1, 5, 9, 13, 17, 2, 6, 10, 14, 18, 3, 7, 11, 15, 19, 4, 8, 12, 16, 20])   # halo_util/utils.py:20
+
+    def run(dtype, ori, bl, prm, want_jac):
+        torch.set_default_dtype(dtype)
+        try:
+            ns0 = {}
+            exec(r6, {'torch': torch, 'F': F_}, ns0)
+            pc = PoseConverter(dev=torch.device('cpu'))
+            ori_t, bl_t = torch.tensor(ori, dtype=dtype).unsqueeze(0), torch.tensor(bl, dtype=dtype).unsqueeze(0)
+
+            def chain(flat):
+                ns = dict(torch=torch, convert_joints=convert_joints, transform_to_canonical=transform_to_canonical,
+                          rot6d_to_matrix=ns0['rot6d_to_matrix'], self=_t.SimpleNamespace(pose_converter=pc, device=torch.device('cpu')),
+                          ori_3d_pose=ori_t, cur_bone_length=bl_t, joint_refine_angle=flat[0:20].unsqueeze(0),
+                          palm_refine_angle=flat[20:27].unsqueeze(0), palm_rot_refine=flat[27:33].reshape(1, 3, 2),
+                          palm_trans_refine=flat[33:36].unsqueeze(0))
+                exec(blk, ns)
+                return torch.cat([ns['bone_transformation_inv'].reshape(-1), ns['joint_3d'].reshape(-1)])
+
+            flat = torch.tensor(prm, dtype=dtype)
+            out = chain(flat).detach()
+            jac = torch.autograd.functional.jacobian(chain, flat).detach() if want_jac else None
+            return out.numpy().astype(np.float64), None if jac is None else jac.numpy().astype(np.float64)
+        finally:
+            torch.set_default_dtype(torch.float32)
+
+    rng = np.random.RandomState(2024)
+    N = 6
+    oris, bls, prms, outs, jacs, floor = [], [], [], [], [], []
+    for c in range(N):
+        _, _, joints = synth.synth_hand_pose(100 + c, center=(0.01 * c, -0.02, 0.9), flex=0.3 + 0.05 * c)
+        joints = joints.astype(np.float64) + 0.004 * rng.standard_normal((21, 3))       # off the synthetic hand's plane
+        kb = joints[m2b]
+        bl = np.array([np.linalg.norm(kb[i + 1] - kb[0 if i < 5 else i - 4]) for i in range(20)]) * (1.0 + 0.05 * rng.standard_normal(20))
+        prm = np.zeros(36)
+        prm[27:33] = np.eye(3)[:, :2].reshape(-1)
+        if c > 0:   # case 0: the initial state of the optimisation (all refinements zero)
+            prm[0:20] = 0.1 * rng.standard_normal(20)
+            prm[20:27] = 0.3 * rng.standard_normal(7)
+            prm[27:33] += 0.15 * rng.standard_normal(6)
+            prm[33:36] = 0.01 * rng.standard_normal(3)
+        o64, j64 = run(torch.float64, joints, bl, prm, True)
+        o32, _ = run(torch.float32, joints, bl, prm, False)
+        oris.append(joints); bls.append(bl); prms.append(prm); outs.append(o64); jacs.append(j64)
+        floor.append(np.abs(o32 - o64).max() / np.abs(o64).max())
+        print('pose chain case %d: |out| max %.3f, fp32 run vs fp64 run %.2e, |jac| max %.3f' % (c, np.abs(o64).max(), floor[-1], np.abs(j64).max()))
+    outs = np.stack(outs)
+    save('pose_chain', ori_pose=np.stack(oris), bone_len=np.stack(bls), params=np.stack(prms), bt_inv=outs[:, :336].reshape(N, 21, 4, 4),
+         joint_3d=outs[:, 336:].reshape(N, 21, 3), jac=np.stack(jacs), ref32_vs_ref64=np.array(floor))
+
+
 def main():
     only = os.environ.get('HONERF_GOLDEN_ONLY', '')
+    if only == 'pose':
+        pose_goldens()
+        return
     if only == 'loss':
         emb, nets = build_nets()
         emb_b, nets_b = build_nets(use_batch=True)

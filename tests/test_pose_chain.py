@@ -1,0 +1,67 @@
+"""The hand pose chain (fitting_single.py:206-226; halo_util/converter_fit_batch.py) -- oracle and HIP kernel against
+tests/golden/pose_chain.npz, which holds what the reference's own statements produce (values and the full Jacobian, fp64)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import record
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pose_chain.npz')
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / np.abs(b).max())
+
+
+def test_pose_chain_oracle_matches_reference():
+    from oracle.pose_chain import pose_chain
+    g = np.load(GOLD)
+    bt, j3, jac = pose_chain(g['ori_pose'], g['bone_len'], g['params'])
+    for name, got, want in (('bt_inv', bt, g['bt_inv']), ('joint_3d', j3, g['joint_3d']), ('jacobian', jac, g['jac'])):
+        e = rel(got, want)
+        record('pose chain oracle (fp64) vs reference fp64: ' + name, e, 1e-9)
+        assert e <= 1e-9, (name, e)   # observed 2e-12
+    # initial state of the optimisation: refined joints = the predicted joints moved to ... themselves (identity refinements)
+    assert np.isfinite(jac).all()
+
+
+# (No finite-difference check: the chain contains the reference's stop-gradients -- the canonical transforms and the local
+# coordinate systems are detached -- so its autograd Jacobian, which the fixture holds, is deliberately not the derivative
+# of the values.)
+
+
+@pytest.mark.gpu
+def test_pose_chain_kernel_matches_reference():
+    from honerf_amd.pose import PoseChainFn, pose_chain, HandPoseChain
+    g = np.load(GOLD)
+    dev = torch.device('cuda')
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    prm = t(g['params']).requires_grad_(True)
+    bt, j3 = PoseChainFn.apply(t(g['ori_pose']), t(g['bone_len']), prm)
+    floor = float(g['ref32_vs_ref64'].max())   # the reference's own fp32 run against its fp64 run: 2.7e-5
+    e_bt, e_j3 = rel(bt.detach().cpu().numpy(), g['bt_inv']), rel(j3.detach().cpu().numpy(), g['joint_3d'])
+    record('pose chain kernel vs reference fp64: bt_inv (the reference\'s own fp32 run: %.1e)' % floor, e_bt, 2e-5)
+    record('pose chain kernel vs reference fp64: joint_3d', e_j3, 2e-5)
+    assert e_bt <= 2e-5 and e_j3 <= 2e-5, (e_bt, e_j3)   # observed 6.5e-6 / 7.5e-8: the fixture's fp64 inputs rounded to fp32
+    # gradients: random cotangents against the reference's Jacobian
+    rng = np.random.RandomState(5)
+    gb, gj = rng.standard_normal(g['bt_inv'].shape), rng.standard_normal(g['joint_3d'].shape)
+    (bt * t(gb)).sum().backward(retain_graph=True)
+    want = np.einsum('fok,fo->fk', g['jac'][:, :336], gb.reshape(-1, 336))
+    e1 = rel(prm.grad.cpu().numpy(), want)
+    prm.grad = None
+    (j3 * t(gj)).sum().backward()
+    want2 = np.einsum('fok,fo->fk', g['jac'][:, 336:], gj.reshape(-1, 63))
+    e2 = rel(prm.grad.cpu().numpy(), want2)
+    record('pose chain kernel: d/d params through bt_inv vs reference autograd', e1, 1e-5)
+    record('pose chain kernel: d/d params through joint_3d vs reference autograd', e2, 1e-5)
+    assert e1 <= 1e-5 and e2 <= 1e-5, (e1, e2)
+    # the module with the reference's parameter names starts at the identity refinement: joint_3d = the predicted joints'
+    # refined pose of case 0 (all-zero parameters)
+    m = HandPoseChain(g['ori_pose'][:1], g['bone_len'][:1]).to(dev)
+    b0, j0 = m()
+    assert rel(b0.detach().cpu().numpy(), g['bt_inv'][:1]) <= 1e-4
+    b1, _ = pose_chain(t(g['ori_pose']), t(g['bone_len']), prm[:, 0:20], prm[:, 20:27], prm[:, 27:33].reshape(-1, 3, 2), prm[:, 33:36])
+    assert torch.equal(b1, bt)
