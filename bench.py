@@ -115,8 +115,9 @@ def fit_step_flop(n_rays, S=FIT_N + 2 * FIT_IMP):
     return final + adjoint + sampling
 
 
-def build_fit(dev, seed, n_frames, rays, precision):
-    """Both fields at conf size, a synthetic frame (window) with 8 ring cameras and the rigid pose chain."""
+def build_fit(dev, seed, n_frames, rays, precision, halo=False):
+    """Both fields at conf size, a synthetic frame (window) with 8 ring cameras and the rigid pose chain (halo: the
+    reference's full pose chain on the same synthetic joints, honerf_amd.fitting.HaloPoseChain)."""
     from honerf_amd import fitting as F, synth
     from honerf_amd.nets import (SDFNetwork, RenderingNetwork, SDFNetwork_OBJ, RenderingNetwork_OBJ, SingleVarianceNetwork)
     from honerf_amd.renderer import NeuSRenderer_fitting
@@ -134,7 +135,10 @@ def build_fit(dev, seed, n_frames, rays, precision):
     u = rng.standard_normal((2000, 3))
     verts = (u / np.linalg.norm(u, axis=1, keepdims=True) * 0.025).astype(np.float32)
     rep = lambda a: np.repeat(a[None], n_frames, 0)
-    chain = F.RigidPoseChain(rep(bt), rep(tp), rep(j), rep(R), rep(tt), verts, device=dev)
+    if halo:
+        chain = F.HaloPoseChain(rep(j), F.bone_lengths_of(rep(j)), None, rep(R), rep(tt), verts, device=dev)
+    else:
+        chain = F.RigidPoseChain(rep(bt), rep(tp), rep(j), rep(R), rep(tt), verts, device=dev)
     views = F.synthetic_views(8, n_frames, rays, seed, j[9], device=dev)
     return ren, nets, chain, views, torch.from_numpy(verts).to(dev)[None].expand(n_frames, -1, -1).contiguous()
 
@@ -167,6 +171,13 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup):
         sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, ft))
         res['single_' + ft] = {'ms_per_step': sec * 1e3, 'steps_per_frame': STEPS_PER_FRAME[ft],
                                'frames_per_s': world / (STEPS_PER_FRAME[ft] * sec)}
+    # the same step with the reference's full parameter set and pose chain (fitting_single.py:206-226 as hn_pose_chain)
+    ren_h, _, chain_h, views_h, _ = build_fit(dev, 40 + rank, 1, FIT_RAYS, precision, halo=True)
+    opt_h = F.make_optimizer(chain_h, video=False)
+    sec = timed(lambda i: F.fit_step(ren_h, views_h[i % 8], chain_h, opt_h, NEAR, FAR, '12'))
+    res['single_12_halo_chain'] = {'ms_per_step': sec * 1e3, 'steps_per_frame': STEPS_PER_FRAME['12'],
+                                   'frames_per_s': world / (STEPS_PER_FRAME['12'] * sec),
+                                   'what': 'fit type 12 with the six refine leaves of fitting_single.py:183-198 through hn_pose_chain'}
     single = (ren, nets, chain, views)
     renb, netsb, chainb, viewsb, ov = build_fit(dev, 60 + rank, VID_FRAMES, VID_RAYS, precision)
     optb = F.make_optimizer(chainb, video=True)

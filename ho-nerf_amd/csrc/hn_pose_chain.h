@@ -60,6 +60,16 @@ HN_PC_FN float acos_s(float x) { return acosf(x); }
 HN_PC_FN double acos_s(double x) { return acos(x); }
 HN_PC_FN float atan2_s(float y, float x) { return atan2f(y, x); }
 HN_PC_FN double atan2_s(double y, double x) { return atan2(y, x); }
+HN_PC_FN void sincos_s(float x, float& s, float& c) { sincosf(x, &s, &c); }
+HN_PC_FN void sincos_s(double x, double& s, double& c) { sincos(x, &s, &c); }
+// sin and cos of one angle from one argument reduction (the double-precision library routines are the bulk of the chain's
+// instructions: every angle is evaluated once and its pair handed to whatever rotates by it)
+template <typename S> struct SinCos { Dual<S> s, c; };
+template <typename S> HN_PC_FN SinCos<S> sincos_d(Dual<S> a) {
+    S sv, cv;
+    sincos_s(a.v, sv, cv);
+    return {{sv, cv * a.d}, {cv, -sv * a.d}};
+}
 template <typename S> HN_PC_FN Dual<S> sin_d(Dual<S> a) { return {sin_s(a.v), cos_s(a.v) * a.d}; }
 template <typename S> HN_PC_FN Dual<S> cos_d(Dual<S> a) { return {cos_s(a.v), -sin_s(a.v) * a.d}; }
 template <typename S> HN_PC_FN Dual<S> acos_d(Dual<S> a) { return {acos_s(a.v), -a.d / sqrt_s(S(1) - a.v * a.v)}; }
@@ -165,7 +175,8 @@ template <typename S> HN_PC_FN Dual<S> signed_angle(const V3<Dual<S>>& v1, const
 template <typename S> HN_PC_FN M3<Dual<S>> rotation_matrix(Dual<S> angle, const V3<Dual<S>>& axis_in) {
     using T = Dual<S>;
     const V3<T> a = unit(axis_in, S(1e-12));
-    const T s = sin_d(angle), c1 = S(1) - cos_d(angle), o = T(S(0));
+    const SinCos<S> sc = sincos_d(angle);
+    const T s = sc.s, c1 = S(1) - sc.c, o = T(S(0));
     M3<T> K;
     K.m[0][0] = o; K.m[0][1] = -a.x[2]; K.m[0][2] = a.x[1];
     K.m[1][0] = a.x[2]; K.m[1][1] = o; K.m[1][2] = -a.x[0];
@@ -177,10 +188,11 @@ template <typename S> HN_PC_FN M3<Dual<S>> rotation_matrix(Dual<S> angle, const 
     return R;
 }
 // rotate (:323-338) = rotate_axis_angle (:34-40): Rodrigues on a vector, the axis taken as given
+template <typename S> HN_PC_FN V3<Dual<S>> rotate(const V3<Dual<S>>& v, const V3<Dual<S>>& ax, const SinCos<S>& sc) {
+    return scale(v, sc.c) + scale(cross(ax, v), sc.s) + scale(ax, dot(ax, v) * (S(1) - sc.c));
+}
 template <typename S> HN_PC_FN V3<Dual<S>> rotate(const V3<Dual<S>>& v, const V3<Dual<S>>& ax, Dual<S> rad) {
-    using T = Dual<S>;
-    const T c = cos_d(rad), s = sin_d(rad);
-    return scale(v, c) + scale(cross(ax, v), s) + scale(ax, dot(ax, v) * (S(1) - c));
+    return rotate(v, ax, sincos_d(rad));
 }
 // get_alignment_mat (:94-101)
 template <typename S> HN_PC_FN M3<Dual<S>> alignment_mat(const V3<Dual<S>>& v1, const V3<Dual<S>>& v2) {
@@ -221,21 +233,16 @@ template <typename S> HN_PC_FN void canonical_transform(const V3<Dual<S>> (&kp_i
     t = mul(mul(R2, R1), scale(k0, T(S(-1))));
 }
 
-// kp3D_to_bones (:537-562)
-template <typename S> HN_PC_FN void kp_to_bones(const V3<Dual<S>> (&kp)[21], V3<Dual<S>> (&bones)[20], Dual<S> (&bl)[20], M4<Dual<S>> (&k2b)[20]) {
+// kp3D_to_bones (:537-562).  kp_to_bone_mat = scale(1 / length) . translate(-parent joint) is not formed: the only place
+// it is used multiplies it by scale(length) again (see converter_forward), so the parent joints are handed on instead.
+template <typename S> HN_PC_FN void kp_to_bones(const V3<Dual<S>> (&kp)[21], V3<Dual<S>> (&bones)[20], Dual<S> (&bl)[20], V3<Dual<S>> (&kpar)[20]) {
     using T = Dual<S>;
     for (int i = 0; i < 20; ++i) {
         const int p = i < 5 ? 0 : i - 4;   // idx_2: the parent joint
         const V3<T> b = kp[i + 1] - kp[p];
         bl[i] = max_c(norm(b), S(1e-9));
         bones[i] = scale(b, T(S(1)) / bl[i]);
-        M4<T> m = eye4<T>();
-        const T inv = T(S(1)) / bl[i];
-        for (int c = 0; c < 3; ++c) {
-            m.m[c][c] = inv;
-            m.m[c][3] = -kp[p].x[c] * inv;
-        }
-        k2b[i] = m;
+        kpar[i] = kp[p];
     }
 }
 
@@ -352,17 +359,18 @@ template <typename S> HN_PC_FN void local_coordinate_system(const V3<Dual<S>> (&
             T a_xz, a_yz;
             bone_angles(lbv2, false, a_xz, a_yz);
             const M3<T> pct = transpose(pc);
+            const SinCos<S> sc_xz = sincos_d(a_xz), sc_yz = sincos_d(-a_yz);
             const V3<T> axis_xz = mul(pct, y_axis);
-            const V3<T> axis_y = mul(pct, rotate(x_axis, y_axis, a_xz));
+            const V3<T> axis_y = mul(pct, rotate(x_axis, y_axis, sc_xz));
             if (!(fabs((double)a_xz.v) < 1e-6)) {
-                x[k] = rotate(x[k], axis_xz, a_xz);
-                y[k] = rotate(y[k], axis_xz, a_xz);
-                z[k] = rotate(z[k], axis_xz, a_xz);
+                x[k] = rotate(x[k], axis_xz, sc_xz);
+                y[k] = rotate(y[k], axis_xz, sc_xz);
+                z[k] = rotate(z[k], axis_xz, sc_xz);
             }
             if (!(fabs((double)a_yz.v) < 1e-6)) {
-                x[k] = rotate(x[k], axis_y, -a_yz);
-                y[k] = rotate(y[k], axis_y, -a_yz);
-                z[k] = rotate(z[k], axis_y, -a_yz);
+                x[k] = rotate(x[k], axis_y, sc_yz);
+                y[k] = rotate(y[k], axis_y, sc_yz);
+                z[k] = rotate(z[k], axis_y, sc_yz);
             }
             for (int c = 0; c < 3; ++c) {
                 cs[idx].m[0][c] = x[k].x[c];
@@ -397,7 +405,7 @@ template <typename S> HN_PC_FN void rotation_matrices(const Dual<S> (&a_xz)[20],
 // the per-bone matrix `trans_mat_without_scale_translation` (tm) and the root normalisation (rbn)
 template <typename S>
 HN_PC_FN void converter_core(const V3<Dual<S>> (&joints_in)[21], bool is_right, const Dual<S>* jra, const Dual<S> (&pra)[N_PRA], V3<Dual<S>> (&bones)[20],
-                             Dual<S> (&bl)[20], M4<Dual<S>> (&k2b)[20], M3<Dual<S>> (&rbn)[20], M3<Dual<S>> (&tm)[20]) {
+                             Dual<S> (&bl)[20], V3<Dual<S>> (&kpar)[20], M3<Dual<S>> (&rbn)[20], M3<Dual<S>> (&tm)[20]) {
     using T = Dual<S>;
     // preprocess_joints (:769-808): shift_factor = 0; left hands mirrored in x
     V3<T> joints[21];
@@ -406,7 +414,7 @@ HN_PC_FN void converter_core(const V3<Dual<S>> (&joints_in)[21], bool is_right, 
         if (!is_right) joints[i].x[0] = -joints[i].x[0];
     }
     V3<T> b0[20];
-    kp_to_bones(joints, b0, bl, k2b);
+    kp_to_bones(joints, b0, bl, kpar);
     V3<T> b1[20];
     M3<T> plane_mat[20], angle_mat[20];
     normalize_root_planes(b0, pra, b1, plane_mat);
@@ -427,25 +435,26 @@ HN_PC_FN void converter_core(const V3<Dual<S>> (&joints_in)[21], bool is_right, 
     }
 }
 
-// PoseConverter.forward (:1109-1179): canonical-frame joints (biomech order) -> trans_mat [21][4][4]
-template <typename S> HN_PC_FN void converter_forward(const V3<Dual<S>> (&joints)[21], bool is_right, M4<Dual<S>> (&out)[21]) {
+// PoseConverter.forward (:1109-1179): canonical-frame joints (biomech order) -> trans_mat [21] as affine maps (R | t); the
+// fourth row is (0, 0, 0, 1).  trans_mat = bone_to_kp . tm . root_norm . kp_to_bone (:1157-1162) with
+//   kp_to_bone = scale(1 / l) translate(-parent),  bone_to_kp = translate(tr) scale(l)   (compute_bone_to_kp_mat :564-594,
+//   tr = the unposed bones accumulated along the finger):   R = l (tm rbn) / l = tm rbn,   t = tr - R parent
+// -- the four 4 x 4 products of the reference collapse to one 3 x 3 product and one matrix-vector product per bone.
+template <typename S> HN_PC_FN void converter_forward(const V3<Dual<S>> (&joints)[21], bool is_right, M3<Dual<S>> (&outR)[21], V3<Dual<S>> (&outT)[21]) {
     using T = Dual<S>;
-    V3<T> bones[20];
+    V3<T> bones[20], kpar[20];
     T bl[20], pra[N_PRA];
-    M4<T> k2b[20];
     M3<T> rbn[20], tm[20];
-    converter_core(joints, is_right, (const T*)nullptr, pra, bones, bl, k2b, rbn, tm);
-    V3<T> lc[20];   // local_coords_after_unpose
-    for (int i = 0; i < 20; ++i) lc[i] = mul(tm[i], bones[i]);
-    out[0] = eye4<T>();
+    converter_core(joints, is_right, (const T*)nullptr, pra, bones, bl, kpar, rbn, tm);
+    V3<T> lc[20];   // local_coords_after_unpose, times the bone length
+    for (int i = 0; i < 20; ++i) lc[i] = scale(mul(tm[i], bones[i]), bl[i]);
+    outR[0] = eye3<T>();
+    outT[0] = {{T(S(0)), T(S(0)), T(S(0))}};
     for (int i = 0; i < 20; ++i) {
-        // compute_bone_to_kp_mat (:564-594): scale by the bone length, translation accumulated along the finger
-        M4<T> b2k = eye4<T>();
-        for (int c = 0; c < 3; ++c) b2k.m[c][c] = bl[i];
         V3<T> tr = {{T(S(0)), T(S(0)), T(S(0))}};
-        for (int p = i - 5; p >= 0; p -= 5) tr = tr + scale(lc[p], bl[p]);
-        for (int c = 0; c < 3; ++c) b2k.m[c][3] = tr.x[c];
-        out[i + 1] = mul(b2k, mul(to44(tm[i]), mul(to44(rbn[i]), k2b[i])));
+        for (int p = i - 5; p >= 0; p -= 5) tr = tr + lc[p];
+        outR[i + 1] = mul(tm[i], rbn[i]);
+        outT[i + 1] = tr - mul(outR[i + 1], kpar[i]);
     }
 }
 
@@ -463,11 +472,10 @@ HN_PC_FN void refine_3d_joint(const V3<Dual<S>> (&joints)[21], bool is_right, co
                           {1.9870e-06, -1.0000e+00, 2.3842e-07},   {-1.9471e-01, -9.8007e-01, -3.9470e-02}, {-3.7001e-01, -9.2185e-01, -1.1528e-01},
                           {4.4889e-01, -8.4880e-01, -2.7935e-01},  {1.9867e-01, -9.8007e-01, 8.9407e-08},  {-3.4117e-06, -1.0000e+00, -2.1979e-07},
                           {-1.9471e-01, -9.8007e-01, -3.9469e-02}, {-3.7001e-01, -9.2185e-01, -1.1528e-01}};
-    V3<T> bones[20];
+    V3<T> bones[20], kpar[20];
     T bl[20];
-    M4<T> k2b[20];
     M3<T> rbn[20], tm[20];
-    converter_core(joints, is_right, jra, pra, bones, bl, k2b, rbn, tm);
+    converter_core(joints, is_right, jra, pra, bones, bl, kpar, rbn, tm);
     V3<T> p_bone[20];
     for (int i = 0; i < 20; ++i) {
         const M3<T> inv = inverse(mul(tm[i], rbn[i]));
@@ -544,15 +552,19 @@ HN_PC_FN void pose_chain(const S (&ori_pose)[21][3], const S (&mean_bl)[20], boo
     canonical_transform(kps2, is_right, R2, t2);
     V3<T> pal2[21];
     for (int i = 0; i < 21; ++i) pal2[i] = mul(R2, kps2[i]) + t2;
-    M4<T> tmat[21];
-    converter_forward(pal2, is_right, tmat);
-    // :223-226  back to MANO order, times the canonical transform
-    M4<T> G = to44(R2);
-    for (int c = 0; c < 3; ++c) G.m[c][3] = t2.x[c];
+    M3<T> tR[21];
+    V3<T> tT[21];
+    converter_forward(pal2, is_right, tR, tT);
+    // :223-226  back to MANO order, times the canonical transform (R2 | t2)
     for (int i = 0; i < 21; ++i) {
-        const M4<T> m = mul(tmat[biomech_to_mano(i)], G);
-        for (int r = 0; r < 4; ++r)
-            for (int c = 0; c < 4; ++c) out[16 * i + 4 * r + c] = m.m[r][c];
+        const int b = biomech_to_mano(i);
+        const M3<T> R = mul(tR[b], R2);
+        const V3<T> t = mul(tR[b], t2) + tT[b];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) out[16 * i + 4 * r + c] = R.m[r][c];
+            out[16 * i + 4 * r + 3] = t.x[r];
+        }
+        for (int c = 0; c < 4; ++c) out[16 * i + 12 + c] = T(S(c == 3 ? 1 : 0));
     }
     for (int i = 0; i < 21; ++i)
         for (int c = 0; c < 3; ++c) out[21 * 16 + 3 * i + c] = j3[i].x[c];

@@ -250,6 +250,75 @@ class RigidPoseChain:
                 'pred_obj_v_w': pred_v, 'compare_obj_v_w': comp_v}
 
 
+class HaloPoseChain:
+    """The reference's own parameter set and pose chain (fitting_single.py:160-235): the six refine leaves
+    obj_rot_refine, obj_trans_refine, palm_rot_refine, palm_trans_refine, joint_refine_angle, palm_refine_angle; the hand
+    half -- convert_joints / transform_to_canonical / PoseConverter.get_refine_3d_joint / palm motion /
+    PoseConverter.forward, ~4 000 torch operators in the reference -- is ONE launch here (honerf_amd.pose, hn_pose_chain) and
+    one more for its backward pass; the object half (fitting_single.py:227-235) is the few torch operators it is there.
+    Same interface as RigidPoseChain: a callable returning the renderer's pose inputs and the loss's joint / vertex sets.
+
+    ori_3d_pose [n,21,3]: the predicted joints (MANO order); cur_bone_length [n,20]; T_pose_21 [n,21,3] or None: the rest
+    position of every bone's joint -- None derives it from the chain's initial state (T_b = bt_inv0[b] joint_b, so that
+    the bone-local coordinate of utils/fields.py:30-31 vanishes at joint b, the role the dataset's T_pose_21 plays)."""
+
+    def __init__(self, ori_3d_pose, cur_bone_length, T_pose_21, Ro_pred, To_pred, obj_verts, device='cuda'):
+        from .pose import PoseChainFn
+        self._fn = PoseChainFn
+        t = lambda x, *s: torch.as_tensor(x, dtype=torch.float32).to(device).reshape(*s)
+        self.joints0 = t(ori_3d_pose, -1, 21, 3)
+        n = self.joints0.shape[0]
+        self.bone_len, self.Ro_pred, self.To_pred = t(cur_bone_length, n, 20), t(Ro_pred, n, 3, 3), t(To_pred, n, 3)
+        self.obj_verts = t(obj_verts, -1, 3)
+        eye62 = torch.eye(3, device=device)[:, :2].expand(n, 3, 2).contiguous()
+        self.obj_rot = torch.nn.Parameter(eye62.clone())
+        self.obj_trans = torch.nn.Parameter(torch.zeros(n, 3, device=device))
+        self.palm_rot = torch.nn.Parameter(eye62.clone())
+        self.palm_trans = torch.nn.Parameter(torch.zeros(n, 3, device=device))
+        self.joint_refine_angle = torch.nn.Parameter(torch.zeros(n, 20, device=device))
+        self.palm_refine_angle = torch.nn.Parameter(torch.zeros(n, 7, device=device))
+        if T_pose_21 is None:
+            with torch.no_grad():
+                bt0, j0 = self._hand(slice(None))
+                T_pose_21 = (bt0[..., :3, :3] @ j0.unsqueeze(-1))[..., 0] + bt0[..., :3, 3]
+        self.T_pose_21 = t(T_pose_21, -1, 21, 3)
+        if self.T_pose_21.shape[0] != n:
+            self.T_pose_21 = self.T_pose_21[:1].expand(n, 21, 3).contiguous()
+
+    def param_groups(self, video=False):
+        """fitting_single.py:191-198 (fitting_video.py:177-184 uses 1e-4 for the four rigid leaves)."""
+        lr = (1e-4, 1e-4, 1e-4, 1e-4, 1e-3, 1e-3) if video else (5e-4, 5e-4, 5e-4, 3e-4, 1e-3, 1e-3)
+        return [{'params': p, 'lr': l} for p, l in zip(self.parameters(), lr)]
+
+    def parameters(self):
+        return [self.obj_rot, self.obj_trans, self.palm_rot, self.palm_trans, self.joint_refine_angle, self.palm_refine_angle]
+
+    def _hand(self, idx):
+        F = self.joints0[idx].shape[0]
+        params = torch.cat([self.joint_refine_angle[idx], self.palm_refine_angle[idx], self.palm_rot[idx].reshape(F, 6), self.palm_trans[idx]], dim=1)
+        return self._fn.apply(self.joints0[idx], self.bone_len[idx], params)
+
+    def __call__(self, index=None):
+        idx = slice(None) if index is None else torch.as_tensor(index, device=self.joints0.device)
+        bt_inv, joint_3d = self._hand(idx)
+        obj_r = rot6d_to_matrix(self.obj_rot[idx]) @ self.Ro_pred[idx]
+        obj_t = self.To_pred[idx] + self.obj_trans[idx]
+        pred_v = (obj_r.unsqueeze(1) @ self.obj_verts[None, :, :, None])[..., 0] + obj_t.unsqueeze(1)
+        comp_v = (self.Ro_pred[idx].unsqueeze(1) @ self.obj_verts[None, :, :, None])[..., 0] + self.To_pred[idx].unsqueeze(1)
+        return {'bt_inv': bt_inv, 'T_pose_21': self.T_pose_21[idx], 'joint_3d': joint_3d, 'joint3d_pred': self.joints0[idx], 'obj_r': obj_r,
+                'obj_t': obj_t, 'pred_obj_v_w': pred_v, 'compare_obj_v_w': comp_v}
+
+
+def bone_lengths_of(joints_mano):
+    """cur_bone_length for a set of MANO-order joints [n,21,3]: the 20 bone lengths in the biomech bone order the converter
+    uses (kp3D_to_bones, halo_util/converter_fit_batch.py:537-562, on convert_joints(..., 'mano', 'biomech'))."""
+    j = torch.as_tensor(joints_mano, dtype=torch.float32).reshape(-1, 21, 3)
+    m2b = torch.tensor([0, 1, 5, 9, 13, 17, 2, 6, 10, 14, 18, 3, 7, 11, 15, 19, 4, 8, 12, 16, 20], device=j.device)
+    kb = j[:, m2b]
+    parent = torch.tensor([0] * 5 + list(range(1, 16)), device=j.device)
+    return (kb[:, 1:] - kb[:, parent]).norm(dim=-1)
+
+
 # ---- one optimisation step --------------------------------------------------------------------------------------------
 def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, smooth_ends=(False, False), stable=None):
     """The full loss of one step: fitting_single.py:251-283 (video=False) or fitting_video.py:285-334 (video=True:

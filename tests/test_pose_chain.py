@@ -65,3 +65,25 @@ def test_pose_chain_kernel_matches_reference():
     assert rel(b0.detach().cpu().numpy(), g['bt_inv'][:1]) <= 1e-4
     b1, _ = pose_chain(t(g['ori_pose']), t(g['bone_len']), prm[:, 0:20], prm[:, 20:27], prm[:, 27:33].reshape(-1, 3, 2), prm[:, 33:36])
     assert torch.equal(b1, bt)
+
+
+@pytest.mark.gpu
+def test_fit_step_with_the_reference_pose_chain():
+    """fit_step (fit type 12) over HaloPoseChain: the six refine leaves of fitting_single.py:183-198 all receive gradients
+    through hn_pose_chain_bwd, the initial state reproduces the predicted joints' refined pose, and a few Adam steps run."""
+    import bench
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, 64, 'f16x3', halo=True)
+    pose0 = chain()
+    # T_pose_21 was derived from the initial state: every bone's local coordinate vanishes at its joint
+    q = (pose0['bt_inv'][0, :, :3, :3] @ pose0['joint_3d'][0].unsqueeze(-1))[..., 0] + pose0['bt_inv'][0, :, :3, 3] - pose0['T_pose_21'][0]
+    assert float(q.abs().max()) < 1e-5
+    opt = F.make_optimizer(chain, video=False)
+    first = None
+    for i in range(3):
+        terms = F.fit_step(ren, views[i % 8], chain, opt, bench.NEAR, bench.FAR, '12')
+        first = first or {k: float(v) for k, v in terms.items() if torch.is_tensor(v) and v.numel() == 1}
+        assert all(np.isfinite(float(v)) for v in terms.values() if torch.is_tensor(v) and v.numel() == 1)
+    moved = [float((p.detach() - p0).abs().max()) for p, p0 in zip(chain.parameters(), (torch.eye(3, device=dev)[:, :2][None], 0, torch.eye(3, device=dev)[:, :2][None], 0, 0, 0))]
+    assert all(m > 0 for m in moved), moved   # every leaf took a step: its gradient arrived
