@@ -90,6 +90,17 @@ def test_ray_gen_and_obj_local(L):
     centre = -cams['T'][0] @ cams['R'][0].T
     assert_close(o0[0], centre, 1e-5, 'camera centre')
     assert_close(d0[0], cams['R'][0][:, 2], 1e-5, 'optical axis')
+    # round trip: project(unproject) = identity.  Any point of a generated ray, pushed through the
+    # PROJECTION side of the same documented PyTorch3D convention (X_view = X_world R + T, row vectors;
+    # xy_ndc = f * X_view[:2] / X_view[2] + p), lands on the ray's own NDC coordinate -- an independent formula, not the
+    # unprojection the kernel and the oracle both restate.
+    for c in range(3):
+        Rc, Tc, fc, pc = (t(cams[k][c]).double() for k in ('R', 'T', 'focal', 'principal'))
+        oc_, dc_ = o[c * P:(c + 1) * P].cpu().double(), d[c * P:(c + 1) * P].cpu().double()
+        for depth in (0.4, 1.0, 1.5):
+            xv = (oc_ + depth * dc_) @ Rc + Tc
+            back = fc * xv[:, :2] / xv[:, 2:3] + pc
+            assert_close(back.float(), t(xy[c * P:(c + 1) * P]), 1e-5, 'ray_gen round trip project(unproject) (depth %.1f)' % depth)
     # obj-local forward + adjoint against autograd of the oracle
     Ro = torch.from_numpy(synth.synth_obj_pose(1)[0]).T.contiguous()
     To = torch.from_numpy(synth.synth_obj_pose(1)[1])
