@@ -59,6 +59,7 @@ struct Hand2Args {
     float* g_pts;          // [n,3]
     float* g_bt_inv;       // [n_frames,21,4,4] accumulated (atomics), or NULL
     float* g_T_pose;       // [n_frames,21,3] accumulated (atomics), or NULL
+    unsigned* xsync;       // 16 zeroed counters (8 XCDs x {members, arrivals}) or NULL: see "XCD pacing" in the kernel
 };
 
 // stash slots of one wave (32 KiB each)
@@ -338,7 +339,13 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     ws.dbg_nofetch = (HN_DBG(a) & 4) ? 1 : 0;
     if ((int)blockIdx.x < n_tiles) ws.template fetch_all_c<FIRST_CHUNK>();
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // XCD pacing (hn_mlp2.h): the workgroups of an XCD meet at every tile start of a long launch.  (Further meeting points
+    // inside the tile program were tried -- before the reverse sweep, before colour lin0 -- and lose 0.5 - 1 %.)
+    XcdPace xp;
+    xp.init(a.xsync);
+    const int full_rounds = n_tiles / (int)gridDim.x;
+    for (int tile = blockIdx.x, it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
+        if (a.xsync != nullptr && it >= 1 && it < full_rounds) xp.meet(it);
         const bool more = tile + (int)gridDim.x < n_tiles;
         const int n = tile * WG_SAMPLES + wave * 32 + j;
         const bool valid = n < a.n_pts;
@@ -1017,11 +1024,12 @@ static void hand2_common_args(Hand2Args& a, const hn_field* f, const float* pts,
     a.scratch = reinterpret_cast<float4*>(workspace);
     a.dbg = 0;
     a.cull = f->cull_far_field;
+    a.xsync = nullptr;
 }
 
 #ifndef HN_HAND_ADJ_TU   // this translation unit: the evaluation kernels (MODE 0, 1); hn_field2_hand_adj.hip: MODE 2
 size_t field2_hand_workspace_bytes(int n_pts, int n_cus) {
-    return (size_t)hand2_grid(n_pts, n_cus) * WG_WAVES * HAND2_SLOTS * SLOT_F4 * sizeof(float4);
+    return (size_t)hand2_grid(n_pts, n_cus) * WG_WAVES * HAND2_SLOTS * SLOT_F4 * sizeof(float4) + 256;   // + the XCD pacing counters
 }
 
 int launch_field2_hand_taped(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
@@ -1062,6 +1070,11 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
     if (workspace == nullptr || workspace_bytes < need) {
         set_error("field workspace too small: %zu < %zu", workspace_bytes, need);
         return HN_ENOMEM;
+    }
+    // XCD pacing: launches of many tiles per workgroup (the image-sized ones), where the workspace has the room
+    if (HN_XCD_PACING && (n_pts + WG_SAMPLES - 1) / WG_SAMPLES >= XCD_PACE_MIN_ROUNDS * grid && workspace_bytes >= need + 64) {
+        a.xsync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + need);
+        HN_CHECK_HIP(hipMemsetAsync(a.xsync, 0, 64, stream));
     }
     static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};   // devices on which the LDS size attribute is set
     HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<1>), (int)HAND2_LDS, &lds_full));

@@ -33,6 +33,7 @@ struct Obj2Args {
     float* feat;           // optional [n,256]
     float4* scratch;       // per-wave stash slots (FULL only)
     int dbg;               // timing experiments only (HN_DBG): 1 = no stash stores, 2 = no stash loads
+    unsigned* xsync;       // XCD pacing counters (hn_mlp2.h XcdPace) or NULL
     // adjoint (MODE 2): upstream gradients in, input gradients out
     const float* g_sdf;    // [n]
     const float* g_grad;   // [n,3]
@@ -467,7 +468,11 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     ws.dbg_nofetch = (HN_DBG(a) & 4) ? 1 : 0;
     if ((int)blockIdx.x < n_tiles) ws.fetch_all(FIRST_CHUNK);
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    XcdPace xp;   // the workgroups of an XCD meet at every tile start of a long launch (hn_mlp2.h)
+    xp.init(a.xsync);
+    const int full_rounds = n_tiles / (int)gridDim.x;
+    for (int tile = blockIdx.x, it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
+        if (a.xsync != nullptr && it >= 1 && it < full_rounds) xp.meet(it);
         const bool more = tile + (int)gridDim.x < n_tiles;
         const int n = tile * WG_SAMPLES + wave * 32 + j;
         const bool valid = n < a.n_pts;
@@ -899,7 +904,7 @@ static int obj2_grid(int n_pts, int n_cus) {
 }
 
 size_t field2_obj_workspace_bytes(int n_pts, int n_cus) {
-    return (size_t)obj2_grid(n_pts, n_cus) * WG_WAVES * OBJ2_SLOTS * SLOT_F4 * sizeof(float4);
+    return (size_t)obj2_grid(n_pts, n_cus) * WG_WAVES * OBJ2_SLOTS * SLOT_F4 * sizeof(float4) + 256;   // + the XCD pacing counters
 }
 
 // bytes of the tape a taped full evaluation leaves for the adjoint launch: the adjoint's stash slots per sample TILE
@@ -960,6 +965,10 @@ int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, 
         if (workspace == nullptr || workspace_bytes < need) {
             set_error("field workspace too small: %zu < %zu", workspace_bytes, need);
             return HN_ENOMEM;
+        }
+        if (HN_XCD_PACING && (n_pts + WG_SAMPLES - 1) / WG_SAMPLES >= XCD_PACE_MIN_ROUNDS * grid && workspace_bytes >= need + 64) {
+            a.xsync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + need);
+            HN_CHECK_HIP(hipMemsetAsync(a.xsync, 0, 64, stream));
         }
     }
     static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};   // devices on which the LDS size attribute is set
