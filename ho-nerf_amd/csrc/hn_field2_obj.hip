@@ -161,8 +161,8 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
     // ---- colour lin4^T and the mask of c4:  cb4 = (c4 > 0) * (W_c4^T xb)   (the three rows arrive as one small chunk)
     {
         const char* buf = ws.template acquire<0>();
-        ws.begin(CB_BWD);
-        ws.pieces_all();
+        ws.template begin_c<CB_BWD>();
+        ws.template pieces_all_c<CB_BWD>();
         static_for<8>([&](auto T) {
             constexpr int t = decltype(T)::value;
             const f32x16 c4 = sh.tile_load(OS_C + 3, t);
@@ -173,12 +173,12 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
             split_tile(v, ah[2 * t], al[2 * t], ah[2 * t + 1], al[2 * t + 1]);
         });
     }
-    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, mask_of(OS_C + 2), PhMask{}, to_regs(bh, bl), no_store);   // C3^T -> cb3
-    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, mask_of(OS_C + 1), PhMask{}, to_regs(ah, al), no_store);   // C2^T -> cb2
-    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, mask_of(OS_C + 0), PhMask{}, to_regs(bh, bl), no_store);   // C1^T -> cb1
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, mask_of(OS_C + 2), PhMask{}, to_regs(bh, bl), no_store);   // C3^T -> cb3
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, bh, bl, lane, h, mask_of(OS_C + 1), PhMask{}, to_regs(ah, al), no_store);   // C2^T -> cb2
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, mask_of(OS_C + 0), PhMask{}, to_regs(bh, bl), no_store);   // C1^T -> cb1
     // ---- colour lin0^T: feature-vector rows -> fb (kept as fragments in the OS_FVEC slot for the W8 product) ...
-    run_layer<8, 16, 1, false, true>(
-        ws, CB_BWD, CB_BWD, bh, bl, lane, h, no_pre, PhIdentity{},
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(
+        ws, bh, bl, lane, h, no_pre, PhIdentity{},
         [&](auto T, EpiState& st, const auto&) {
             constexpr int t = decltype(T)::value;
             sh.frag_store(OS_FVEC * SLOT_BYTES, 2 * t, st.hi[0], st.lo[0]);
@@ -192,9 +192,10 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
     static_for<4>([&](auto U) {
         constexpr int u = decltype(U)::value;
         const char* buf = ws.template acquire<0>();
-        ws.begin(u < 3 ? CB_BWD : CB_L0);   // after the last one: lin0 of the forward-direction sweep
+        constexpr int nbytes = u < 3 ? CB_BWD : CB_L0;   // after the last one: lin0 of the forward-direction sweep
+        ws.template begin_c<nbytes>();
         f32x16 m1 = zero16(), m2 = zero16();
-        mma_tile<16, 0, true>(ws, buf, bh, bl, m1, m2, lane);
+        mma_tile<16, 0, nbytes>(ws, buf, bh, bl, m1, m2, lane);
         const f32x16 M = combine(m1, m2);
         if constexpr (u < 2) {
             sh.tile_store(OS_GX, 2 + u, M);
@@ -277,12 +278,12 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
             split8(jg[s], x16h[s], x16l[s]);
             sh.frag_store(OS_X * SLOT_BYTES, s, x16h[s], x16l[s]);   // again for lin4's skip columns
         }
-        run_layer<8, 4, 4, false, true>(ws, CB_L0, CB_HID, x16h, x16l, lane, h, pre4(OS_A1 + 0, OS_DZ + 0), PhFwdDir{}, fin4(ah, al, OS_DZ + 0), no_store);
+        run_layer_c<8, 4, 4, false, true, CB_L0, CB_HID>(ws, x16h, x16l, lane, h, pre4(OS_A1 + 0, OS_DZ + 0), PhFwdDir{}, fin4(ah, al, OS_DZ + 0), no_store);
     }
-    run_layer<8, 16, 1, false, true>(ws, CB_HID, CB_HID, ah, al, lane, h, pre4(OS_A1 + 1, OS_DZ + 1), PhFwdDir{}, fin4(bh, bl, OS_DZ + 1), no_store);   // lin1
-    run_layer<8, 16, 1, false, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, pre4(OS_A1 + 2, OS_DZ + 2), PhFwdDir{}, fin4(ah, al, OS_DZ + 2), no_store);   // lin2
+    run_layer_c<8, 16, 1, false, true, CB_HID, CB_HID>(ws, ah, al, lane, h, pre4(OS_A1 + 1, OS_DZ + 1), PhFwdDir{}, fin4(bh, bl, OS_DZ + 1), no_store);   // lin1
+    run_layer_c<8, 16, 1, false, true, CB_HID, CB_HID>(ws, bh, bl, lane, h, pre4(OS_A1 + 2, OS_DZ + 2), PhFwdDir{}, fin4(ah, al, OS_DZ + 2), no_store);   // lin2
     float v3_192 = 0.f;
-    run_layer<7, 16, 1, false, true>(ws, CB_HID, CB_HID, ah, al, lane, h, pre4(OS_A1 + 3, OS_DZ + 3), PhFwdDir{},                                    // lin3 (193 rows)
+    run_layer_c<7, 16, 1, false, true, CB_HID, CB_HID>(ws, ah, al, lane, h, pre4(OS_A1 + 3, OS_DZ + 3), PhFwdDir{},                                    // lin3 (193 rows)
                                      [&](auto T, EpiState& st, const auto&) {
                                          constexpr int t = decltype(T)::value;
                                          asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
@@ -307,10 +308,10 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
         bh[15][7] = h ? vh : bh[15][7];
         bl[15][7] = h ? vl : bl[15][7];
     }
-    run_layer<8, 16, 1, false, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, pre4(OS_A1 + 4, OS_DZ + 4), PhFwdDir{}, fin4(ah, al, OS_DZ + 4), no_store);   // lin4
-    run_layer<8, 16, 1, false, true>(ws, CB_HID, CB_HID, ah, al, lane, h, pre4(OS_A1 + 5, OS_DZ + 5), PhFwdDir{}, fin4(bh, bl, OS_DZ + 5), no_store);   // lin5
-    run_layer<8, 16, 1, false, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, pre4(OS_A1 + 6, OS_DZ + 6), PhFwdDir{}, fin4(ah, al, OS_DZ + 6), no_store);   // lin6
-    run_layer<8, 16, 1, false, false>(ws, CB_HID, CB_HID, ah, al, lane, h, pre4(OS_A8, OS_DZ + 7), PhFwdDir{},                                       // lin7: only w_7
+    run_layer_c<8, 16, 1, false, true, CB_HID, CB_HID>(ws, bh, bl, lane, h, pre4(OS_A1 + 4, OS_DZ + 4), PhFwdDir{}, fin4(ah, al, OS_DZ + 4), no_store);   // lin4
+    run_layer_c<8, 16, 1, false, true, CB_HID, CB_HID>(ws, ah, al, lane, h, pre4(OS_A1 + 5, OS_DZ + 5), PhFwdDir{}, fin4(bh, bl, OS_DZ + 5), no_store);   // lin5
+    run_layer_c<8, 16, 1, false, true, CB_HID, CB_HID>(ws, bh, bl, lane, h, pre4(OS_A1 + 6, OS_DZ + 6), PhFwdDir{}, fin4(ah, al, OS_DZ + 6), no_store);   // lin6
+    run_layer_c<8, 16, 1, false, false, CB_HID, CB_HID>(ws, ah, al, lane, h, pre4(OS_A8, OS_DZ + 7), PhFwdDir{},                                       // lin7: only w_7
                                       [&](auto T, EpiState& st, const auto&) {
                                           sh.tile_store(OS_DZ + 7, decltype(T)::value, st.wvec());
                                           return NoData{};
@@ -326,8 +327,8 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
     };
 #pragma unroll
     for (int s = 0; s < 16; ++s) sh.frag_load(OS_FVEC * SLOT_BYTES, s, bh[s], bl[s]);
-    run_layer<8, 16, 1, false, true>(
-        ws, CB_HID, CB_BWD, bh, bl, lane, h,
+    run_layer_c<8, 16, 1, false, true, CB_HID, CB_BWD>(
+        ws, bh, bl, lane, h,
         [&](auto T, const char* tail) {
             constexpr int t = decltype(T)::value;
             Act2 o{sh.tile_load(OS_A8, t), sh.tile_load(OS_DZ + 7, t)};
@@ -337,9 +338,9 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
             return o;
         },
         PhRev2{}, to_regs(ah, al), no_store);
-    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, pre5(OS_A1 + 6, OS_DZ + 6), PhRev2{}, to_regs(bh, bl), no_store);   // W7^T -> zb6
-    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, pre5(OS_A1 + 5, OS_DZ + 5), PhRev2{}, to_regs(ah, al), no_store);   // W6^T -> zb5
-    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, pre5(OS_A1 + 4, OS_DZ + 4), PhRev2{},                               // W5^T -> zb4 (kept)
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, pre5(OS_A1 + 6, OS_DZ + 6), PhRev2{}, to_regs(bh, bl), no_store);   // W7^T -> zb6
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, bh, bl, lane, h, pre5(OS_A1 + 5, OS_DZ + 5), PhRev2{}, to_regs(ah, al), no_store);   // W6^T -> zb5
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, pre5(OS_A1 + 4, OS_DZ + 4), PhRev2{},                               // W5^T -> zb4 (kept)
                                      [&](auto T, EpiState& st, const auto&) {
                                          constexpr int t = decltype(T)::value;
                                          asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
@@ -352,7 +353,7 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
                                          return NoData{};
                                      },
                                      no_store);
-    run_layer<7, 16, 1, false, true>(ws, CB_BWD, CB_BWD3, bh, bl, lane, h, pre5(OS_A1 + 3, OS_DZ + 3), PhRev2{},                              // W4h^T -> zb3 (193 rows)
+    run_layer_c<7, 16, 1, false, true, CB_BWD, CB_BWD3>(ws, bh, bl, lane, h, pre5(OS_A1 + 3, OS_DZ + 3), PhRev2{},                              // W4h^T -> zb3 (193 rows)
                                      [&](auto T, EpiState& st, const auto&) {
                                          constexpr int t = decltype(T)::value;
                                          asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
@@ -368,24 +369,29 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
                                          return NoData{};
                                      },
                                      no_store);
-    run_layer<8, 13, 1, false, true>(ws, CB_BWD3, CB_BWD, ah, al, lane, h, pre5(OS_A1 + 2, OS_DZ + 2), PhRev2{}, to_regs(bh, bl), no_store);   // W3^T -> zb2
-    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, pre5(OS_A1 + 1, OS_DZ + 1), PhRev2{}, to_regs(ah, al), no_store);    // W2^T -> zb1
-    run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, pre5(OS_A1 + 0, OS_DZ + 0), PhRev2{}, to_regs(bh, bl), no_store);    // W1^T -> zb0
+    run_layer_c<8, 13, 1, false, true, CB_BWD3, CB_BWD>(ws, ah, al, lane, h, pre5(OS_A1 + 2, OS_DZ + 2), PhRev2{}, to_regs(bh, bl), no_store);   // W3^T -> zb2
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, bh, bl, lane, h, pre5(OS_A1 + 1, OS_DZ + 1), PhRev2{}, to_regs(ah, al), no_store);    // W2^T -> zb1
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, pre5(OS_A1 + 0, OS_DZ + 0), PhRev2{}, to_regs(bh, bl), no_store);    // W1^T -> zb0
     // X adjoint = W0^T zb0 + W4[:, 193:]^T zb4 + the colour net's share
     f32x16 G1[2] = {zero16(), zero16()}, G2[2] = {zero16(), zero16()};
     static_for<2>([&](auto U) {
         constexpr int u = decltype(U)::value;
         const char* buf = ws.template acquire<0>();
-        ws.begin(CB_BWD);
-        mma_tile<16, 0, true>(ws, buf, bh, bl, G1[u], G2[u], lane);
+        ws.template begin_c<CB_BWD>();
+        mma_tile<16, 0, CB_BWD>(ws, buf, bh, bl, G1[u], G2[u], lane);
     });
 #pragma unroll
     for (int s = 0; s < 16; ++s) sh.frag_load(OS_ZB4 * SLOT_BYTES, s, ah[s], al[s]);
     static_for<2>([&](auto U) {
         constexpr int u = decltype(U)::value;
         const char* buf = ws.template acquire<0>();
-        ws.begin(u == 0 ? CB_BWD : next_first);
-        mma_tile<16, 0, true>(ws, buf, ah, al, G1[u], G2[u], lane);
+        if constexpr (u == 0) {
+            ws.template begin_c<CB_BWD>();
+            mma_tile<16, 0, CB_BWD>(ws, buf, ah, al, G1[u], G2[u], lane);
+        } else {   // the next tile's first chunk: the one size that is not a constant
+            ws.begin(next_first);
+            mma_tile<16, 0, 1>(ws, buf, ah, al, G1[u], G2[u], lane);
+        }
     });
     // ---- input map: g_pts = J^T Xb + sum_slots d2(slot) GX(slot) gb[channel of the slot]
     float gp[3] = {0.f, 0.f, 0.f};
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     WStream ws;
     ws.init(a.blob, a.blob_bytes, lds, wave, lane);
     ws.dbg_nofetch = (HN_DBG(a) & 4) ? 1 : 0;
-    if ((int)blockIdx.x < n_tiles) ws.fetch_all(FIRST_CHUNK);
+    if ((int)blockIdx.x < n_tiles) ws.template fetch_all_c<FIRST_CHUNK>();
 
     XcdPace xp;   // the workgroups of an XCD meet at every tile start of a long launch (hn_mlp2.h)
     xp.init(a.xsync);
@@ -561,13 +567,13 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 x16h[s] = xh[s];
                 x16l[s] = xl[s];
             }
-            run_layer<8, 4, 4, true, true>(ws, CB_L0, CB_HID, x16h, x16l, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 0), no_store);
+            run_layer_c<8, 4, 4, true, true, CB_L0, CB_HID>(ws, x16h, x16l, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 0), no_store);
         }
-        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, OS_A1 + 1), no_store);   // lin1
-        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 2), no_store);   // lin2
+        run_layer_c<8, 16, 1, true, true, CB_HID, CB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, OS_A1 + 1), no_store);   // lin1
+        run_layer_c<8, 16, 1, true, true, CB_HID, CB_HID>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 2), no_store);   // lin2
         // ---- lin3: 193 outputs = 7 tiles (tile 6 holds neuron 192 in row 0)
         float a4_192 = 0.f;
-        run_layer<7, 16, 1, true, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, PhSoftplus{},
+        run_layer_c<7, 16, 1, true, true, CB_HID, CB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{},
                                         [&](auto T, EpiState& st, const auto&) {
                                             constexpr int t = decltype(T)::value;
                                             asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
@@ -604,13 +610,14 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             bh[15][7] = h ? vh : bh[15][7];
             bl[15][7] = h ? vl : bl[15][7];
         }
-        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 4), no_store);   // lin4
-        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, OS_A1 + 5), no_store);   // lin5
-        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 6), no_store);   // lin6
+        run_layer_c<8, 16, 1, true, true, CB_HID, CB_HID>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 4), no_store);   // lin4
+        run_layer_c<8, 16, 1, true, true, CB_HID, CB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, OS_A1 + 5), no_store);   // lin5
+        run_layer_c<8, 16, 1, true, true, CB_HID, CB_HID>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, OS_A1 + 6), no_store);   // lin6
         // ---- lin7 -> a8; sdf = W8[0,:] a8 + b8; seed of the reverse sweep dz7 = sigma'(z7) W8[0,:] / scale
         float sdf_acc = 0.f;
-        run_layer<8, 16, 1, true, true>(
-            ws, CB_HID, FULL ? CB_HID : (more ? CB_L0 : 0), ah, al, lane, h,
+        auto lin7 = [&](auto NA_) {   // NA_: the size of the chunk that follows the layer, a constant
+        run_layer_c<8, 16, 1, true, true, CB_HID, decltype(NA_)::value>(
+            ws, ah, al, lane, h,
             [&](auto, const char* tail) { return Act{tail_tile(tail, 1, h)}; }, PhSoftplus{},
             [&](auto T, EpiState& st, const Act& w8) {
                 constexpr int t = decltype(T)::value;
@@ -637,6 +644,15 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 return NoData{};
             },
             no_store);
+        };
+        if constexpr (FULL) {
+            lin7(std::integral_constant<int, CB_HID>{});
+        } else {
+            if (more)
+                lin7(std::integral_constant<int, CB_L0>{});
+            else
+                lin7(std::integral_constant<int, 0>{});
+        }
         sdf = (half_sum(sdf_acc) + a.b8) * a.inv_scale;
         if (!FULL) {
             if (valid && h == 0) a.sdf[n] = sdf;
@@ -648,8 +664,8 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         }
 
         // ---- lin8 rows 1..256: the feature vector (no activation) -> stash as fragments for colour lin0
-        run_layer<8, 16, 1, true, true>(
-            ws, CB_HID, CB_BWD, bh, bl, lane, h, no_pre, PhIdentity{},
+        run_layer_c<8, 16, 1, true, true, CB_HID, CB_BWD>(
+            ws, bh, bl, lane, h, no_pre, PhIdentity{},
             [&](auto T, EpiState& st, const auto&) {
                 constexpr int t = decltype(T)::value;
                 if (a.feat != nullptr && valid) {
@@ -687,9 +703,9 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 return NoData{};
             };
         };
-        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 6), PhDsig{}, to_regs_dz(bh, bl, OS_DZ + 6), no_store);   // W7^T -> dz6
-        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 5), PhDsig{}, to_regs_dz(ah, al, OS_DZ + 5), no_store);   // W6^T -> dz5
-        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 4), PhDsig{},                          // W5^T -> dz4 (kept)
+        run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, act_of(OS_A1 + 6), PhDsig{}, to_regs_dz(bh, bl, OS_DZ + 6), no_store);   // W7^T -> dz6
+        run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, bh, bl, lane, h, act_of(OS_A1 + 5), PhDsig{}, to_regs_dz(ah, al, OS_DZ + 5), no_store);   // W6^T -> dz5
+        run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, act_of(OS_A1 + 4), PhDsig{},                          // W5^T -> dz4 (kept)
                                          [&](auto T, EpiState& st, const auto&) {
                                              constexpr int t = decltype(T)::value;
                                              asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
@@ -703,7 +719,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                                          },
                                          no_store);
         // W4[:, :193]^T: dz4 -> dz3 (193 rows = 7 tiles; a4's padding rows were stashed as 0 => sigma' = 0)
-        run_layer<7, 16, 1, false, true>(ws, CB_BWD, CB_BWD3, bh, bl, lane, h, act_of(OS_A1 + 3), PhDsig{},
+        run_layer_c<7, 16, 1, false, true, CB_BWD, CB_BWD3>(ws, bh, bl, lane, h, act_of(OS_A1 + 3), PhDsig{},
                                          [&](auto T, EpiState& st, const auto&) {
                                              constexpr int t = decltype(T)::value;
                                              asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
@@ -720,24 +736,25 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                                              return NoData{};
                                          },
                                          no_store);
-        run_layer<8, 13, 1, false, true>(ws, CB_BWD3, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 2), PhDsig{}, to_regs_dz(bh, bl, OS_DZ + 2), no_store);   // W3^T -> dz2
-        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, bh, bl, lane, h, act_of(OS_A1 + 1), PhDsig{}, to_regs_dz(ah, al, OS_DZ + 1), no_store);    // W2^T -> dz1
-        run_layer<8, 16, 1, false, true>(ws, CB_BWD, CB_BWD, ah, al, lane, h, act_of(OS_A1 + 0), PhDsig{}, to_regs_dz(bh, bl, OS_DZ + 0), no_store);    // W1^T -> dz0
+        run_layer_c<8, 13, 1, false, true, CB_BWD3, CB_BWD>(ws, ah, al, lane, h, act_of(OS_A1 + 2), PhDsig{}, to_regs_dz(bh, bl, OS_DZ + 2), no_store);   // W3^T -> dz2
+        run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, bh, bl, lane, h, act_of(OS_A1 + 1), PhDsig{}, to_regs_dz(ah, al, OS_DZ + 1), no_store);    // W2^T -> dz1
+        run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, act_of(OS_A1 + 0), PhDsig{}, to_regs_dz(bh, bl, OS_DZ + 0), no_store);    // W1^T -> dz0
         // d sdf / d X-space = W0^T dz0 + W4[:, 193:]^T dz4   (64 rows = 2 tiles; row <-> k-slot of the same lane)
         f32x16 G1[2] = {zero16(), zero16()}, G2[2] = {zero16(), zero16()};
         static_for<2>([&](auto U) {
             constexpr int u = decltype(U)::value;
             const char* buf = ws.template acquire<0>();
-            ws.begin(CB_BWD);
-            mma_tile<16, 0, true>(ws, buf, bh, bl, G1[u], G2[u], lane);
+            ws.template begin_c<CB_BWD>();
+            mma_tile<16, 0, CB_BWD>(ws, buf, bh, bl, G1[u], G2[u], lane);
         });
 #pragma unroll
         for (int s = 0; s < 16; ++s) sh.frag_load(OS_DZ4 * SLOT_BYTES, s, ah[s], al[s]);
         static_for<2>([&](auto U) {
             constexpr int u = decltype(U)::value;
             const char* buf = ws.template acquire<0>();
-            ws.begin(u == 0 ? CB_BWD : CB_C0A);
-            mma_tile<16, 0, true>(ws, buf, ah, al, G1[u], G2[u], lane);
+            constexpr int nbytes = u == 0 ? CB_BWD : CB_C0A;
+            ws.template begin_c<nbytes>();
+            mma_tile<16, 0, nbytes>(ws, buf, ah, al, G1[u], G2[u], lane);
         });
         // ---- Jacobian of the encoding (in-lane: G row of tile u, register 8(s&1)+j <-> k-slot (s = 2u + .., h, j))
         {
@@ -811,7 +828,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             static_for<8>([&](auto T) {
                 constexpr int t = decltype(T)::value;
                 const char* bufa = ws.template acquire<0>();
-                ws.begin(CB_C0B);
+                ws.template begin_c<CB_C0B>();
                 arm(st);
                 if constexpr (t > 0) {
                     st.c1 = c1[(t - 1) & 1];
@@ -821,16 +838,17 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 c2[t & 1] = zero16();
                 if constexpr (t > 0) {
                     Epi<true, PhRelu, NoData> epi{st, relu, nd};
-                    mma_tile<16, 0, true>(ws, bufa, ah, al, c1[t & 1], c2[t & 1], lane, epi);
+                    mma_tile<16, 0, CB_C0B>(ws, bufa, ah, al, c1[t & 1], c2[t & 1], lane, epi);
                     split_finish<true>(st);
                     put(std::integral_constant<int, t - 1>{});
                 } else {
-                    mma_tile<16, 0, true>(ws, bufa, ah, al, c1[t & 1], c2[t & 1], lane);
+                    mma_tile<16, 0, CB_C0B>(ws, bufa, ah, al, c1[t & 1], c2[t & 1], lane);
                 }
                 const char* bufb = ws.template acquire<0>();
-                ws.begin(t + 1 < 8 ? CB_C0A : CB_HID);
+                constexpr int nbytes = t + 1 < 8 ? CB_C0A : CB_HID;
+                ws.template begin_c<nbytes>();
                 const f32x16 bias = tail_tile(bufb + 8 * KS_BYTES, 0, h);
-                mma_tile<8, 0, true>(ws, bufb, mh, ml, c1[t & 1], c2[t & 1], lane);
+                mma_tile<8, 0, nbytes>(ws, bufb, mh, ml, c1[t & 1], c2[t & 1], lane);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) c1[t & 1][i] += bias[i];
             });
@@ -858,13 +876,14 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 return NoData{};
             };
         };
-        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, bh, bl, lane, h, no_pre, PhRelu{}, to_regs_c(ah, al, OS_C + 1), no_store);   // colour lin1
-        run_layer<8, 16, 1, true, true>(ws, CB_HID, CB_HID, ah, al, lane, h, no_pre, PhRelu{}, to_regs_c(bh, bl, OS_C + 2), no_store);   // colour lin2
+        run_layer_c<8, 16, 1, true, true, CB_HID, CB_HID>(ws, bh, bl, lane, h, no_pre, PhRelu{}, to_regs_c(ah, al, OS_C + 1), no_store);   // colour lin1
+        run_layer_c<8, 16, 1, true, true, CB_HID, CB_HID>(ws, ah, al, lane, h, no_pre, PhRelu{}, to_regs_c(bh, bl, OS_C + 2), no_store);   // colour lin2
         struct W3 {
             f32x16 w[3];
         };
-        run_layer<8, 16, 1, true, false>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
-            ws, CB_HID, MODE == 2 ? CB_W4ROWS : (more ? CB_L0 : 0), bh, bl, lane, h,
+        auto col3 = [&](auto NA_) {
+        run_layer_c<8, 16, 1, true, false, CB_HID, decltype(NA_)::value>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
+            ws, bh, bl, lane, h,
             [&](auto, const char* tail) { return W3{{tail_tile(tail, 1, h), tail_tile(tail, 2, h), tail_tile(tail, 3, h)}}; },
             PhRelu{},
             [&](auto T, EpiState& st, const W3& w) {
@@ -877,6 +896,15 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
                 return NoData{};
             },
             no_store);
+        };
+        if constexpr (MODE == 2) {
+            col3(std::integral_constant<int, CB_W4ROWS>{});
+        } else {
+            if (more)
+                col3(std::integral_constant<int, CB_L0>{});
+            else
+                col3(std::integral_constant<int, 0>{});
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_fast(half_sum(rgb[c]) + a.c_blast[c]);
         }   // RUN_FWD
