@@ -333,15 +333,21 @@ __device__ __forceinline__ void f16_flush_mode() {
 #ifndef HN_SPLIT_MIX
 #define HN_SPLIT_MIX 1
 #endif
+// (one asm statement per group: between separate, dependent asm statements the compiler puts an s_nop -- it cannot see
+// what they contain -- and every instruction of any kind is an issue slot of the one wave that also feeds the MFMAs)
 __device__ __forceinline__ void split_pair_hi(float a, float b, unsigned& hp, float& r0, float& r1) {
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hp), "v"(a));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hp), "v"(b));
+    asm("v_cvt_pk_f16_f32 %0, %3, %4\n\t"
+        "v_fma_mix_f32 %1, %0, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hp), "=&v"(r0), "=&v"(r1)
+        : "v"(a), "v"(b));
 }
 __device__ __forceinline__ unsigned split_pair_lo(float r0, float r1, float scale) {
     unsigned lp;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(lp) : "v"(r0), "v"(scale));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lp) : "v"(r1), "v"(scale));
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]"
+        : "=&v"(lp)
+        : "v"(r0), "v"(r1), "v"(scale));
     return lp;
 }
 using u32x4_ = unsigned __attribute__((ext_vector_type(4)));
