@@ -571,6 +571,18 @@ int hn_pose_chain_bwd(const float* jac, const float* g_bt_inv, const float* g_jo
     return hn::pose_chain_bwd(jac, g_bt_inv, g_joint_3d, n_frames, g_params, (hipStream_t)stream);
 }
 
+int hn_rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pred, const float* To_pred, const float* params, int n_frames,
+                  int with_palm, float* out, float* jac, hn_stream_t stream) {
+    return hn::rigid_pose(bt_inv0, joints0, Ro_pred, To_pred, params, n_frames, with_palm, out, jac, (hipStream_t)stream);
+}
+int hn_verts_loss(const float* Ra, const float* ta, const float* Rb, const float* tb, const float* verts, int n_verts, int n_pairs, float* loss,
+                  float* gR, float* gt, hn_stream_t stream) {
+    return hn::verts_loss(Ra, ta, Rb, tb, verts, n_verts, n_pairs, loss, gR, gt, (hipStream_t)stream);
+}
+int hn_jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int n_in, float* out, hn_stream_t stream) {
+    return hn::jacobian_vjp(jac, g, n_frames, n_out, n_in, out, (hipStream_t)stream);
+}
+
 int hn_nearest_masked(const float* pts, int n_verts, int n_sets, const unsigned char* query_mask, const unsigned char* cand_mask,
                       unsigned char* selected, int32_t* nearest, hn_stream_t stream) {
     return hn::bwd::nearest_masked(pts, n_verts, n_sets, query_mask, cand_mask, selected, nearest, (hipStream_t)stream);

@@ -44,6 +44,12 @@ int ensure_dynamic_lds(const void* kernel, int bytes, void* mask_atomic_u64);
 int pose_chain(const float* ori_pose, const float* bone_len, const unsigned char* is_right, const float* in, int n_frames, float* bt_inv,
                float* joint_3d, float* jac, hipStream_t s);
 int pose_chain_bwd(const float* jac, const float* g_bt_inv, const float* g_joint_3d, int n_frames, float* g_in, hipStream_t s);
+// hn_pose_rigid.hip
+int rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pred, const float* To_pred, const float* params, int n_frames, int with_palm,
+               float* out, float* jac, hipStream_t s);
+int verts_loss(const float* Ra, const float* ta, const float* Rb, const float* tb, const float* verts, int n_verts, int n_pairs, float* loss, float* gR,
+               float* gt, hipStream_t s);
+int jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int n_in, float* out, hipStream_t s);
 
 // ---- network geometry (fixed by the reference confs; checked in hn_field_create) ---------
 constexpr int H = 256;           // d_hidden == d_feature

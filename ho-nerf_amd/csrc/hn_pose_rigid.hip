@@ -1,0 +1,155 @@
+// The non-skeleton part of the fitting loops' pose side as launches instead of ~200 small torch operators per step:
+//   hn_rigid_pose   palm rigid motion of the predicted joints and its inverse folded into the bone transformations
+//                   (fitting_single.py:213-217), object refinement obj_r = rot6d(obj_rot_refine) ori_obj_r,
+//                   obj_t = ori_obj_t + obj_trans_refine (:227-231), joint loss pose_loss(joint3d_pred, joint_3d) (:119-122,
+//                   :260) -- values and the exact Jacobian (forward-mode dual numbers, one thread per input), like
+//                   hn_pose_chain
+//   hn_verts_loss   pose_loss over the object's vertices (:232-233: mean distance between the vertex sets of two rigid
+//                   poses) with its closed-form gradient w.r.t. the first pose
+//   hn_jacobian_vjp g_in = J^T g_out for a stored Jacobian (the backward pass of the two dual-number ops)
+#include "hn_common.h"
+#include "hn_pose_chain.h"
+
+namespace hn {
+
+using pose::Dual;
+using pose::M3;
+using pose::V3;
+constexpr int RIGID_IN = 18;    // [obj_rot6 | obj_trans3 | palm_rot6 | palm_trans3]
+constexpr int RIGID_OUT = 412;  // [bt_inv 336 | joint_3d 63 | obj_r 9 | obj_t 3 | joint_loss 1]
+
+// with_palm = 0: the object half only (outputs 399 .. 410; the others are left untouched) -- the hand half then comes from
+// hn_pose_chain
+__global__ __launch_bounds__(32) void k_rigid_pose(const float* __restrict__ bt_inv0, const float* __restrict__ joints0, const float* __restrict__ Ro_pred,
+                                                   const float* __restrict__ To_pred, const float* __restrict__ params, int n_frames, int with_palm,
+                                                   float* __restrict__ out, float* __restrict__ jac) {
+    using T = Dual<double>;
+    const int f = blockIdx.x, k = threadIdx.x;   // k = 0: values; 1 + input: that input's derivative
+    if (f >= n_frames || k > RIGID_IN || (k > 0 && jac == nullptr)) return;
+    T x[RIGID_IN];
+    for (int i = 0; i < RIGID_IN; ++i) x[i] = T((double)params[(size_t)f * RIGID_IN + i], i == k - 1 ? 1.0 : 0.0);
+    float* o = out + (size_t)f * RIGID_OUT;
+    float* J = jac != nullptr ? jac + (size_t)f * RIGID_OUT * RIGID_IN : nullptr;
+    auto put = [&](int idx, const T& v) {
+        if (k == 0)
+            o[idx] = (float)v.v;
+        else
+            J[idx * RIGID_IN + (k - 1)] = (float)v.d;
+    };
+    {   // object: obj_r = rot6d(obj_rot) @ Ro_pred, obj_t = To_pred + obj_trans
+        const T r6[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
+        const M3<T> R = pose::rot6d_to_matrix<double>(r6);
+        M3<T> P;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) P.m[i][j] = T((double)Ro_pred[(size_t)f * 9 + 3 * i + j]);
+        const M3<T> Ro = pose::mul(R, P);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) put(399 + 3 * i + j, Ro.m[i][j]);
+        for (int c = 0; c < 3; ++c) put(408 + c, x[6 + c] + (double)To_pred[(size_t)f * 3 + c]);
+    }
+    if (!with_palm) return;
+    const T r6[6] = {x[9], x[10], x[11], x[12], x[13], x[14]};
+    const M3<T> Rp = pose::rot6d_to_matrix<double>(r6);
+    const V3<T> tp = {{x[15], x[16], x[17]}};
+    const float* j0 = joints0 + (size_t)f * 63;
+    const V3<T> root = {{T((double)j0[0]), T((double)j0[1]), T((double)j0[2])}};
+    // joint_3d = R_palm (joints - root) + root + T_palm ; joint loss = sum_j |joints_j - joint_3d_j| / 21
+    T jl = T(0.0);
+    for (int j = 0; j < 21; ++j) {
+        const V3<T> p = {{T((double)j0[3 * j]), T((double)j0[3 * j + 1]), T((double)j0[3 * j + 2])}};
+        const V3<T> q = pose::mul(Rp, p - root) + root + tp;
+        for (int c = 0; c < 3; ++c) put(336 + 3 * j + c, q.x[c]);
+        jl = jl + pose::norm(p - q);
+    }
+    put(411, jl * (1.0 / 21.0));
+    // G p = R_palm (p - root) + root + T  ->  G^-1 = (R^T | root - R^T (root + T));  bt_inv = bt_inv0 G^-1
+    const M3<T> Rt = pose::transpose(Rp);
+    const V3<T> ti = root - pose::mul(Rt, root + tp);
+    for (int b = 0; b < 21; ++b) {
+        const float* m = bt_inv0 + ((size_t)f * 21 + b) * 16;
+        for (int r = 0; r < 4; ++r) {
+            const T m0 = T((double)m[4 * r]), m1 = T((double)m[4 * r + 1]), m2 = T((double)m[4 * r + 2]), m3 = T((double)m[4 * r + 3]);
+            for (int c = 0; c < 3; ++c) put(16 * b + 4 * r + c, m0 * Rt.m[0][c] + m1 * Rt.m[1][c] + m2 * Rt.m[2][c]);
+            put(16 * b + 4 * r + 3, m0 * ti.x[0] + m1 * ti.x[1] + m2 * ti.x[2] + m3);
+        }
+    }
+}
+
+// loss[p] = (1 / V) sum_v |(Ra - Rb) v + (ta - tb)|;  gR[p] = d loss / d Ra = (1 / V) sum_v u_v v^T,  gt[p] = (1 / V) sum_v u_v
+// with u_v the unit residual (0 where the residual is 0: torch.norm's convention).  One 256-thread block per pair.
+__global__ __launch_bounds__(256) void k_verts_loss(const float* __restrict__ Ra, const float* __restrict__ ta, const float* __restrict__ Rb,
+                                                    const float* __restrict__ tb, const float* __restrict__ verts, int n_verts, float* __restrict__ loss,
+                                                    float* __restrict__ gR, float* __restrict__ gt) {
+    const int p = blockIdx.x;
+    float D[9], d[3];
+    for (int i = 0; i < 9; ++i) D[i] = Ra[p * 9 + i] - Rb[p * 9 + i];
+    for (int i = 0; i < 3; ++i) d[i] = ta[p * 3 + i] - tb[p * 3 + i];
+    float acc[13];
+    for (int i = 0; i < 13; ++i) acc[i] = 0.f;
+    for (int v = threadIdx.x; v < n_verts; v += blockDim.x) {
+        const float x = verts[3 * v], y = verts[3 * v + 1], z = verts[3 * v + 2];
+        const float e0 = D[0] * x + D[1] * y + D[2] * z + d[0], e1 = D[3] * x + D[4] * y + D[5] * z + d[1], e2 = D[6] * x + D[7] * y + D[8] * z + d[2];
+        const float n = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+        const float inv = n > 0.f ? 1.f / n : 0.f;
+        const float u0 = e0 * inv, u1 = e1 * inv, u2 = e2 * inv;
+        acc[0] += n;
+        acc[1] += u0 * x; acc[2] += u0 * y; acc[3] += u0 * z;
+        acc[4] += u1 * x; acc[5] += u1 * y; acc[6] += u1 * z;
+        acc[7] += u2 * x; acc[8] += u2 * y; acc[9] += u2 * z;
+        acc[10] += u0; acc[11] += u1; acc[12] += u2;
+    }
+    __shared__ float red[13][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = 0; i < 13; ++i) {
+        float s = acc[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[i][wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 13) {
+        const float s = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) / (float)n_verts;
+        if (threadIdx.x == 0)
+            loss[p] = s;
+        else if (threadIdx.x < 10)
+            gR[p * 9 + threadIdx.x - 1] = s;
+        else
+            gt[p * 3 + threadIdx.x - 10] = s;
+    }
+}
+
+__global__ void k_jacobian_vjp(const float* __restrict__ jac, const float* __restrict__ g, int n_frames, int n_out, int n_in, float* __restrict__ out) {
+    const int f = blockIdx.x, k = threadIdx.x;
+    if (f >= n_frames || k >= n_in) return;
+    const float* J = jac + (size_t)f * n_out * n_in;
+    const float* gg = g + (size_t)f * n_out;
+    float acc = 0.f;
+    for (int o = 0; o < n_out; ++o) acc = fmaf(J[o * n_in + k], gg[o], acc);
+    out[(size_t)f * n_in + k] = acc;
+}
+
+int rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pred, const float* To_pred, const float* params, int n_frames, int with_palm,
+               float* out, float* jac, hipStream_t s) {
+    if (n_frames <= 0) return HN_OK;
+    HN_REQUIRE(Ro_pred != nullptr && To_pred != nullptr && params != nullptr && out != nullptr, "rigid pose: NULL argument");
+    HN_REQUIRE(!with_palm || (bt_inv0 != nullptr && joints0 != nullptr), "rigid pose: the palm half needs bt_inv0 and joints0");
+    hipLaunchKernelGGL(k_rigid_pose, dim3(n_frames), dim3(32), 0, s, bt_inv0, joints0, Ro_pred, To_pred, params, n_frames, with_palm, out, jac);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+int verts_loss(const float* Ra, const float* ta, const float* Rb, const float* tb, const float* verts, int n_verts, int n_pairs, float* loss, float* gR,
+               float* gt, hipStream_t s) {
+    if (n_pairs <= 0) return HN_OK;
+    HN_REQUIRE(n_verts >= 1, "verts loss: no vertices");
+    hipLaunchKernelGGL(k_verts_loss, dim3(n_pairs), dim3(256), 0, s, Ra, ta, Rb, tb, verts, n_verts, loss, gR, gt);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+int jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int n_in, float* out, hipStream_t s) {
+    if (n_frames <= 0) return HN_OK;
+    HN_REQUIRE(n_in >= 1 && n_in <= 64 && n_out >= 1, "jacobian vjp: n_in %d n_out %d out of range", n_in, n_out);
+    hipLaunchKernelGGL(k_jacobian_vjp, dim3(n_frames), dim3(64), 0, s, jac, g, n_frames, n_out, n_in, out);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+}  // namespace hn

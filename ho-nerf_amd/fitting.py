@@ -232,6 +232,17 @@ class RigidPoseChain:
 
     def __call__(self, index=None):
         idx = slice(None) if index is None else torch.as_tensor(index, device=self.bt_inv0.device)
+        if self.bt_inv0.is_cuda:
+            # one launch (hn_rigid_pose) instead of ~60 operators forward and ~100 backward; the vertex sets are not formed:
+            # the losses that used them take the poses (step_loss, honerf_amd.pose.VertsLossFn)
+            from .pose import RigidPoseFn
+            F_ = self.joints0[idx].shape[0]
+            params = torch.cat([self.obj_rot[idx].reshape(F_, 6), self.obj_trans[idx], self.palm_rot[idx].reshape(F_, 6), self.palm_trans[idx]], dim=1)
+            out = RigidPoseFn.apply(params, self.bt_inv0[idx].contiguous(), self.joints0[idx].contiguous(), self.Ro_pred[idx].contiguous(),
+                                    self.To_pred[idx].contiguous(), True)
+            return {'bt_inv': out[:, :336].reshape(F_, 21, 4, 4), 'T_pose_21': self.T_pose_21[idx], 'joint_3d': out[:, 336:399].reshape(F_, 21, 3),
+                    'joint3d_pred': self.joints0[idx], 'obj_r': out[:, 399:408].reshape(F_, 3, 3), 'obj_t': out[:, 408:411], 'joint_loss': out[:, 411],
+                    'Ro_pred': self.Ro_pred[idx], 'To_pred': self.To_pred[idx], 'obj_verts': self.obj_verts}
         R_palm = rot6d_to_matrix(self.palm_rot[idx])                               # [F,3,3]
         root = self.joints0[idx][:, :1, :]
         joint_3d = (R_palm.unsqueeze(1) @ (self.joints0[idx] - root).unsqueeze(-1))[..., 0] + root + self.palm_trans[idx].unsqueeze(1)
@@ -301,6 +312,14 @@ class HaloPoseChain:
     def __call__(self, index=None):
         idx = slice(None) if index is None else torch.as_tensor(index, device=self.joints0.device)
         bt_inv, joint_3d = self._hand(idx)
+        if self.joints0.is_cuda:
+            from .pose import RigidPoseFn
+            F_ = self.joints0[idx].shape[0]
+            params = torch.cat([self.obj_rot[idx].reshape(F_, 6), self.obj_trans[idx], torch.zeros(F_, 9, device=self.joints0.device)], dim=1)
+            out = RigidPoseFn.apply(params, None, None, self.Ro_pred[idx].contiguous(), self.To_pred[idx].contiguous(), False)
+            return {'bt_inv': bt_inv, 'T_pose_21': self.T_pose_21[idx], 'joint_3d': joint_3d, 'joint3d_pred': self.joints0[idx],
+                    'obj_r': out[:, 399:408].reshape(F_, 3, 3), 'obj_t': out[:, 408:411], 'Ro_pred': self.Ro_pred[idx], 'To_pred': self.To_pred[idx],
+                    'obj_verts': self.obj_verts}
         obj_r = rot6d_to_matrix(self.obj_rot[idx]) @ self.Ro_pred[idx]
         obj_t = self.To_pred[idx] + self.obj_trans[idx]
         pred_v = (obj_r.unsqueeze(1) @ self.obj_verts[None, :, :, None])[..., 0] + obj_t.unsqueeze(1)
@@ -325,23 +344,36 @@ def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, 
     + smoothness over the window's frames x50, anchored to the prediction at the sequence ends; + 100 x the stable
     term for fit type '1234').  `pose` is the pose chain's output dict."""
     terms = render_loss_terms(render_out, true_rgb, true_mask, fit_type, video)
+    fused = 'obj_verts' in pose        # the chains' device form: vertex losses from the poses (VertsLossFn), no vertex sets
+    if fused:
+        from .pose import VertsLossFn
+        v_pred = VertsLossFn.apply(pose['obj_r'], pose['obj_t'], pose['Ro_pred'], pose['To_pred'], pose['obj_verts'])   # [F]
     if not video:
-        joint_loss = pose_loss(pose['joint3d_pred'][0], pose['joint_3d'][0])
-        verts_loss = pose_loss(pose['compare_obj_v_w'][0], pose['pred_obj_v_w'][0])
+        joint_loss = pose['joint_loss'][0] if 'joint_loss' in pose else pose_loss(pose['joint3d_pred'][0], pose['joint_3d'][0])
+        verts_loss = v_pred[0] if fused else pose_loss(pose['compare_obj_v_w'][0], pose['pred_obj_v_w'][0])
         w = (100.0, 5.0) if fit_type == '1' else (30.0, 20.0)
     else:
-        joint_loss = pose_loss(pose['joint_3d'], pose['joint3d_pred'], mean=True)
-        verts_loss = pose_loss(pose['pred_obj_v_w'], pose['compare_obj_v_w'], mean=True)
+        joint_loss = pose['joint_loss'].mean() if 'joint_loss' in pose else pose_loss(pose['joint_3d'], pose['joint3d_pred'], mean=True)
+        verts_loss = v_pred.mean() if fused else pose_loss(pose['pred_obj_v_w'], pose['compare_obj_v_w'], mean=True)
         w = (30.0, 20.0)
     terms['joint'], terms['obj_verts'] = joint_loss, verts_loss
     terms['loss'] = terms['loss'] + w[0] * joint_loss + w[1] * verts_loss
     if video:
-        j, v = pose['joint_3d'], pose['pred_obj_v_w']
-        smooth = pose_loss(j[1:], j[:-1], mean=True) + pose_loss(v[1:], v[:-1], mean=True)
-        if smooth_ends[0]:
-            smooth = smooth + pose_loss(j[:1], pose['joint3d_pred'][:1], mean=True) + pose_loss(v[:1], pose['compare_obj_v_w'][:1], mean=True)
-        elif smooth_ends[1]:
-            smooth = smooth + pose_loss(j[-1:], pose['joint3d_pred'][-1:], mean=True) + pose_loss(v[-1:], pose['compare_obj_v_w'][-1:], mean=True)
+        j = pose['joint_3d']
+        if fused:
+            r, t_ = pose['obj_r'], pose['obj_t']
+            smooth = pose_loss(j[1:], j[:-1], mean=True) + VertsLossFn.apply(r[1:], t_[1:], r[:-1], t_[:-1], pose['obj_verts']).mean()
+            if smooth_ends[0]:
+                smooth = smooth + pose_loss(j[:1], pose['joint3d_pred'][:1], mean=True) + v_pred[0]
+            elif smooth_ends[1]:
+                smooth = smooth + pose_loss(j[-1:], pose['joint3d_pred'][-1:], mean=True) + v_pred[-1]
+        else:
+            v = pose['pred_obj_v_w']
+            smooth = pose_loss(j[1:], j[:-1], mean=True) + pose_loss(v[1:], v[:-1], mean=True)
+            if smooth_ends[0]:
+                smooth = smooth + pose_loss(j[:1], pose['joint3d_pred'][:1], mean=True) + pose_loss(v[:1], pose['compare_obj_v_w'][:1], mean=True)
+            elif smooth_ends[1]:
+                smooth = smooth + pose_loss(j[-1:], pose['joint3d_pred'][-1:], mean=True) + pose_loss(v[-1:], pose['compare_obj_v_w'][-1:], mean=True)
         terms['smooth'] = 50.0 * smooth
         terms['loss'] = terms['loss'] + terms['smooth']
         if stable is not None:

@@ -72,6 +72,9 @@ SIGNATURES = {
     'hn_nearest_masked': (c_i, [c_f, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'hn_pose_chain': (c_i, [c_f, c_f, c_vp, c_f, c_i, c_f, c_f, c_f, c_vp]),
     'hn_pose_chain_bwd': (c_i, [c_f, c_f, c_f, c_i, c_f, c_vp]),
+    'hn_rigid_pose': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
+    'hn_verts_loss': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_vp]),
+    'hn_jacobian_vjp': (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_vp]),
     'hn_alpha': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_vp]),
     'hn_composite1': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp]),
     'hn_composite2': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp]),

@@ -86,3 +86,64 @@ class HandPoseChain(torch.nn.Module):
 
     def forward(self):
         return PoseChainFn.apply(self.ori_3d_pose, self.cur_bone_length, self.params)
+
+
+class RigidPoseFn(torch.autograd.Function):
+    """hn_rigid_pose: params [F,18] = [obj_rot 6 | obj_trans 3 | palm_rot 6 | palm_trans 3] -> out [F,412] =
+    [bt_inv 336 | joint_3d 63 | obj_r 9 | obj_t 3 | joint loss 1] (fitting_single.py:213-217, 227-231, 260); with_palm False:
+    the object half only (the hand half then comes from PoseChainFn).  Backward = hn_jacobian_vjp on the stored Jacobian."""
+
+    @staticmethod
+    def forward(ctx, params, bt_inv0, joints0, Ro_pred, To_pred, with_palm):
+        L = _lib
+        lib = L.load()
+        prm = L.f32(params).reshape(-1, 18)
+        F, dev = prm.shape[0], prm.device
+        out = torch.zeros(F, 412, device=dev, dtype=torch.float32) if not with_palm else torch.empty(F, 412, device=dev, dtype=torch.float32)
+        need = params.requires_grad
+        jac = (torch.zeros if not with_palm else torch.empty)(F, 412, 18, device=dev, dtype=torch.float32) if need else None
+        L.check(lib.hn_rigid_pose(L.ptr(bt_inv0) if with_palm else None, L.ptr(joints0) if with_palm else None, L.ptr(Ro_pred), L.ptr(To_pred),
+                                  L.ptr(prm), F, 1 if with_palm else 0, L.ptr(out), L.ptr(jac) if need else None, L.stream_ptr()), 'hn_rigid_pose')
+        ctx.jac, ctx.shape = jac, params.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        L = _lib
+        lib = L.load()
+        jac = ctx.jac
+        F = jac.shape[0]
+        g = torch.empty(F, 18, device=jac.device, dtype=torch.float32)
+        go = L.f32(g_out).reshape(F, 412)
+        L.check(lib.hn_jacobian_vjp(L.ptr(jac), L.ptr(go), F, 412, 18, L.ptr(g), L.stream_ptr()), 'hn_jacobian_vjp')
+        return g.reshape(ctx.shape), None, None, None, None, None
+
+
+class VertsLossFn(torch.autograd.Function):
+    """pose_loss between the vertex sets of two rigid poses (fitting_single.py:232-233, fitting_video.py's vertex smoothness):
+    (Ra [P,3,3], ta [P,3], Rb, tb, verts [V,3]) -> loss [P] = mean_v |(Ra - Rb) v + (ta - tb)|, one launch with the
+    closed-form gradient (hn_verts_loss); the vertex sets themselves are never formed."""
+
+    @staticmethod
+    def forward(ctx, Ra, ta, Rb, tb, verts):
+        L = _lib
+        lib = L.load()
+        a, b, c, d = L.f32(Ra).reshape(-1, 9), L.f32(ta).reshape(-1, 3), L.f32(Rb).reshape(-1, 9), L.f32(tb).reshape(-1, 3)
+        P, dev = a.shape[0], a.device
+        loss = torch.empty(P, device=dev, dtype=torch.float32)
+        gR, gt = torch.empty(P, 9, device=dev, dtype=torch.float32), torch.empty(P, 3, device=dev, dtype=torch.float32)
+        L.check(lib.hn_verts_loss(L.ptr(a), L.ptr(b), L.ptr(c), L.ptr(d), L.ptr(verts), verts.shape[0], P, L.ptr(loss), L.ptr(gR), L.ptr(gt),
+                                  L.stream_ptr()), 'hn_verts_loss')
+        ctx.save_for_backward(gR, gt)
+        ctx.shapes = (Ra.shape, ta.shape, Rb.shape, tb.shape)
+        ctx.needs = (Ra.requires_grad, ta.requires_grad, Rb.requires_grad, tb.requires_grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        gR, gt = ctx.saved_tensors
+        g = g_loss.reshape(-1, 1)
+        dR, dt = gR * g, gt * g
+        sh, nd = ctx.shapes, ctx.needs
+        return (dR.reshape(sh[0]) if nd[0] else None, dt.reshape(sh[1]) if nd[1] else None,
+                (-dR).reshape(sh[2]) if nd[2] else None, (-dt).reshape(sh[3]) if nd[3] else None, None)

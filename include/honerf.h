@@ -206,6 +206,24 @@ int hn_pose_chain(const float* ori_pose, const float* bone_len, const unsigned c
 int hn_pose_chain_bwd(const float* jac, const float* g_bt_inv, const float* g_joint_3d, int n_frames, float* g_params,
                       hn_stream_t stream);
 
+/* The rest of the fitting loops' pose side (fitting_single.py:213-217, 227-233, 119-122, 260), ~200 small torch operators
+ * per step in the reference's form:
+ * hn_rigid_pose: params [F,18] = [obj_rot_refine 6 (row-major [3][2]) | obj_trans_refine 3 | palm_rot_refine 6 | palm_trans_refine 3];
+ *   bt_inv0 [F,21,4,4], joints0 [F,21,3] (used when with_palm != 0), Ro_pred [F,3,3], To_pred [F,3] ->
+ *   out [F,412] = [bt_inv 336 = bt_inv0 G^-1 | joint_3d 63 = G joints0 | obj_r 9 = rot6d(obj_rot) Ro_pred | obj_t 3 |
+ *   joint loss 1 = sum_j |joints0_j - joint_3d_j| / 21] with G p = R_palm (p - root) + root + T_palm, and, when jac != NULL,
+ *   jac [F,412,18].  with_palm == 0: the object half only (entries 399 .. 410 of out / jac are written).
+ * hn_verts_loss: pose_loss between the vertex sets of two rigid poses, loss[p] = mean_v |(Ra - Rb) v + (ta - tb)|, with
+ *   its gradient w.r.t. (Ra, ta) (the gradient w.r.t. (Rb, tb) is its negative): Ra, Rb [P,3,3], ta, tb [P,3], verts [V,3].
+ * hn_jacobian_vjp: out [F,n_in] = jac[F,n_out,n_in]^T g [F,n_out] (n_in <= 64): the backward pass of a dual-number op. */
+#define HN_RIGID_POSE_IN 18
+#define HN_RIGID_POSE_OUT 412
+int hn_rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pred, const float* To_pred,
+                  const float* params, int n_frames, int with_palm, float* out, float* jac, hn_stream_t stream);
+int hn_verts_loss(const float* Ra, const float* ta, const float* Rb, const float* tb, const float* verts, int n_verts,
+                  int n_pairs, float* loss, float* gR, float* gt, hn_stream_t stream);
+int hn_jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int n_in, float* out, hn_stream_t stream);
+
 /* ---- SDF -> alpha, compositing --------------------------------------------------------
  * utils/renderer.py:147-161 (cos_anneal_ratio = 1): alpha [n] (clipped to [0,1]) and
  * c = sigmoid(prev_sdf * inv_s) [n] from sdf, grad, per-ray dirs and dists. */

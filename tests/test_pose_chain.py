@@ -87,3 +87,62 @@ def test_fit_step_with_the_reference_pose_chain():
         assert all(np.isfinite(float(v)) for v in terms.values() if torch.is_tensor(v) and v.numel() == 1)
     moved = [float((p.detach() - p0).abs().max()) for p, p0 in zip(chain.parameters(), (torch.eye(3, device=dev)[:, :2][None], 0, torch.eye(3, device=dev)[:, :2][None], 0, 0, 0))]
     assert all(m > 0 for m in moved), moved   # every leaf took a step: its gradient arrived
+
+
+@pytest.mark.gpu
+def test_rigid_pose_ops_match_the_torch_form():
+    """hn_rigid_pose / hn_verts_loss / hn_jacobian_vjp (RigidPoseChain on the device) against the same chain written as torch
+    operators (the class's CPU form, fitting_single.py:213-217, 227-233, 119-122): values and the gradients of the step's
+    pose-side loss terms w.r.t. the four rigid leaves."""
+    from honerf_amd import fitting as F, synth
+    rng = np.random.RandomState(3)
+    bt, tp, j = synth.synth_hand_pose(7)
+    R, tt = synth.synth_obj_pose(8)
+    verts = (rng.standard_normal((500, 3)) * 0.02).astype(np.float32)
+    rep = lambda a, n=2: np.repeat(a[None], n, 0)
+    chains = {}
+    for dev in ('cpu', 'cuda'):
+        c = F.RigidPoseChain(rep(bt), rep(tp), rep(j), rep(R), rep(tt), verts, device=dev)
+        with torch.no_grad():
+            r2 = np.random.RandomState(11)
+            for p in c.parameters():
+                p.add_(torch.tensor(r2.standard_normal(tuple(p.shape)) * 0.05, dtype=torch.float32, device=dev))
+        chains[dev] = c
+    gb, gr, gt = (torch.tensor(rng.standard_normal(s), dtype=torch.float32) for s in ((2, 21, 4, 4), (2, 3, 3), (2, 3)))
+    res = {}
+    for dev, c in chains.items():
+        pose = c()
+        rnd = {'color_fine': torch.zeros(4, 3, device=dev), 'weight_sum': torch.full((4, 1), 0.5, device=dev)}
+        for video in (False, True):
+            terms = {}
+            fused = 'obj_verts' in pose
+            # the pose-side part of step_loss (the render terms are exercised elsewhere): call it through a stub render
+            loss = (pose['bt_inv'] * gb.to(dev)).sum() + (pose['obj_r'] * gr.to(dev)).sum() + (pose['obj_t'] * gt.to(dev)).sum()
+            from honerf_amd.fitting import pose_loss
+            if fused:
+                from honerf_amd.pose import VertsLossFn
+                vp = VertsLossFn.apply(pose['obj_r'], pose['obj_t'], pose['Ro_pred'], pose['To_pred'], pose['obj_verts'])
+                jl = pose['joint_loss'].mean() if video else pose['joint_loss'][0]
+                vl = vp.mean() if video else vp[0]
+                sm = VertsLossFn.apply(pose['obj_r'][1:], pose['obj_t'][1:], pose['obj_r'][:-1], pose['obj_t'][:-1], pose['obj_verts']).mean()
+            else:
+                jl = pose_loss(pose['joint_3d'], pose['joint3d_pred'], mean=True) if video else pose_loss(pose['joint3d_pred'][0], pose['joint_3d'][0])
+                vl = (pose_loss(pose['pred_obj_v_w'], pose['compare_obj_v_w'], mean=True) if video
+                      else pose_loss(pose['compare_obj_v_w'][0], pose['pred_obj_v_w'][0]))
+                sm = pose_loss(pose['pred_obj_v_w'][1:], pose['pred_obj_v_w'][:-1], mean=True)
+            total = loss + 30.0 * jl + 20.0 * vl + 50.0 * sm
+            grads = torch.autograd.grad(total, c.parameters(), retain_graph=True)
+            res[(dev, video)] = ([pose[k].detach().cpu().numpy() for k in ('bt_inv', 'joint_3d', 'obj_r', 'obj_t')], float(jl), float(vl), float(sm),
+                                 [g_.cpu().numpy() for g_ in grads])
+    for video in (False, True):
+        a, b = res[('cuda', video)], res[('cpu', video)]
+        for name, x, y in zip(('bt_inv', 'joint_3d', 'obj_r', 'obj_t'), a[0], b[0]):
+            e = rel(x, y.astype(np.float64))
+            record('rigid pose op vs torch form: ' + name, e, 1e-5)
+            assert e <= 1e-5, (name, e)
+        for name, x, y in zip(('joint loss', 'vertex loss', 'vertex smoothness'), a[1:4], b[1:4]):
+            assert abs(x - y) <= 1e-5 * max(abs(y), 1e-3), (name, x, y)
+        for name, x, y in zip(('obj_rot', 'obj_trans', 'palm_rot', 'palm_trans'), a[4], b[4]):
+            e = rel(x, y.astype(np.float64))
+            record('rigid pose op vs torch autograd: d/d %s (video=%s)' % (name, video), e, 1e-4)
+            assert e <= 1e-4, (name, e)
