@@ -117,14 +117,28 @@ __global__ __launch_bounds__(256) void k_verts_loss(const float* __restrict__ Ra
     }
 }
 
-__global__ void k_jacobian_vjp(const float* __restrict__ jac, const float* __restrict__ g, int n_frames, int n_out, int n_in, float* __restrict__ out) {
-    const int f = blockIdx.x, k = threadIdx.x;
-    if (f >= n_frames || k >= n_in) return;
-    const float* J = jac + (size_t)f * n_out * n_in;
-    const float* gg = g + (size_t)f * n_out;
-    float acc = 0.f;
-    for (int o = 0; o < n_out; ++o) acc = fmaf(J[o * n_in + k], gg[o], acc);
-    out[(size_t)f * n_in + k] = acc;
+// one block of 256 per frame: wave w sums the outputs o = w (mod 4), four independent accumulators each (the loads of a
+// single dependent chain over 412 outputs were the kernel's whole time: 61 us), then the waves' partial sums meet in LDS
+__global__ __launch_bounds__(256) void k_jacobian_vjp(const float* __restrict__ jac, const float* __restrict__ g, int n_frames, int n_out, int n_in,
+                                                      float* __restrict__ out) {
+    const int f = blockIdx.x, k = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ float part[4][64];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (f < n_frames && k < n_in) {
+        const float* J = jac + (size_t)f * n_out * n_in;
+        const float* gg = g + (size_t)f * n_out;
+        int o = w;
+        for (; o + 12 < n_out; o += 16) {
+            a0 = fmaf(J[(size_t)o * n_in + k], gg[o], a0);
+            a1 = fmaf(J[(size_t)(o + 4) * n_in + k], gg[o + 4], a1);
+            a2 = fmaf(J[(size_t)(o + 8) * n_in + k], gg[o + 8], a2);
+            a3 = fmaf(J[(size_t)(o + 12) * n_in + k], gg[o + 12], a3);
+        }
+        for (; o < n_out; o += 4) a0 = fmaf(J[(size_t)o * n_in + k], gg[o], a0);
+    }
+    part[w][k] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (f < n_frames && w == 0 && k < n_in) out[(size_t)f * n_in + k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
 }
 
 int rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pred, const float* To_pred, const float* params, int n_frames, int with_palm,
@@ -147,7 +161,7 @@ int verts_loss(const float* Ra, const float* ta, const float* Rb, const float* t
 int jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int n_in, float* out, hipStream_t s) {
     if (n_frames <= 0) return HN_OK;
     HN_REQUIRE(n_in >= 1 && n_in <= 64 && n_out >= 1, "jacobian vjp: n_in %d n_out %d out of range", n_in, n_out);
-    hipLaunchKernelGGL(k_jacobian_vjp, dim3(n_frames), dim3(64), 0, s, jac, g, n_frames, n_out, n_in, out);
+    hipLaunchKernelGGL(k_jacobian_vjp, dim3(n_frames), dim3(256), 0, s, jac, g, n_frames, n_out, n_in, out);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

@@ -48,10 +48,9 @@ class PoseChainFn(torch.autograd.Function):
         jac = ctx.jac
         F = jac.shape[0]
         g = torch.empty(F, N_IN, device=jac.device, dtype=torch.float32)
-        gb = L.f32(g_bt).reshape(F, 336) if g_bt is not None else None
-        gj = L.f32(g_j3).reshape(F, 63) if g_j3 is not None else None
-        L.check(lib.hn_pose_chain_bwd(L.ptr(jac), L.ptr(gb) if gb is not None else None, L.ptr(gj) if gj is not None else None, F,
-                                      L.ptr(g), L.stream_ptr()), 'hn_pose_chain_bwd')
+        z = lambda t, n: torch.zeros(F, n, device=jac.device) if t is None else L.f32(t).reshape(F, n)
+        go = torch.cat([z(g_bt, 336), z(g_j3, 63)], dim=1)
+        L.check(lib.hn_jacobian_vjp(L.ptr(jac), L.ptr(go), F, N_OUT, N_IN, L.ptr(g), L.stream_ptr()), 'hn_jacobian_vjp')
         return None, None, g.reshape(ctx.shape)
 
 
