@@ -17,6 +17,12 @@
 #define HN_MFMA16 HN_HAND_EVAL_MFMA16   // the evaluation kernels (MODE 0, 1); the adjoint translation unit keeps 32x32x16
 #endif
 #include "hn_mlp2.h"
+#ifndef HN_FEAT_ACQUIRE_VISIBLE
+#define HN_FEAT_ACQUIRE_VISIBLE true
+#endif
+#ifndef HN_FEAT_LOADS_BEHIND
+#define HN_FEAT_LOADS_BEHIND 1
+#endif
 #ifndef HN_JAC_VARIANT
 #define HN_JAC_VARIANT 2
 #endif
@@ -330,6 +336,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     constexpr int QA = HS_QA * SLOT_BYTES;       // colour network's share of qbar per bone (3 floats per lane)
     constexpr int LEFTX = QA + 16384;            // leftover rows of an X-space adjoint, one float per bone and lane
     constexpr int NZ_OFF = LEFT + 6144;          // the wave's live-bone mask `nz`, for the adjoint launch
+    constexpr int LEFTJ = LEFT + 16384;          // the Jacobian pass's leftover rows, one float per bone and lane
     int feat_base = FEAT;                        // which block set load_bone reads (FEAT or GXB)
     const int n_tiles = (a.n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
 
@@ -485,6 +492,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         //      sharing the bone's fragments, then NB leftover chunks (4 tiles x 3 k-steps [+ tail: the 4 biases,
         //      added here when BIAS]).  c1/c2[4 blk + ti] += W[tile, features] * feat.  Bone b+1's fragments are
         //      loaded while bone b's MFMAs run.
+        auto bone_loads = [&](int b) { return b >= N_BONES || ((nz >> b) & 1u); };   // load_bone issues its 8 loads
         auto load_bone = [&](int b, h8(&oh)[4], h8(&ol)[4]) {
             if (b >= N_BONES || ((nz >> b) & 1u)) {
 #pragma unroll
@@ -511,11 +519,21 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             auto step = [&](int nb, const h8(&uh)[4], const h8(&ul)[4], h8(&nh)[4], h8(&nl)[4]) {
                 static_for<NB>([&](auto BLK) {
                     constexpr int blk = decltype(BLK)::value;
-                    const char* buf = ws.template acquire<0>();
-                    if constexpr (blk == 0) load_bone(nb, nh, nl);   // nb == 21: the leftover blocks 84..86
+                    // The next bone's 8 fragment loads are issued one step ahead, from the slot BEHIND this chunk's DMA
+                    // pieces (mma_chunk's mid): they are then the youngest vector-memory operations, and the acquire of
+                    // the bone's second chunk lets exactly those 8 stay in flight (vmcnt(8)) -- they get a whole chunk
+                    // more to come back from HBM.  The drains are the s_waitcnt builtin (VISIBLE): with the opaque asm
+                    // form the compiler guards this bone's first use with counted waits that only the loads issued
+                    // AFTER it can satisfy (in-kernel stamps: blk-0 chunks 3 000 - 5 000 cycles against 2 400).
+                    const bool ahead = blk == 1 && NB == 2 && HN_FEAT_LOADS_BEHIND && bone_loads(nb);
+                    const char* buf = ahead ? ws.template acquire<8, HN_FEAT_ACQUIRE_VISIBLE>() : ws.template acquire<0, HN_FEAT_ACQUIRE_VISIBLE>();
+                    if constexpr (blk == 0 && !(NB == 2 && HN_FEAT_LOADS_BEHIND)) load_bone(nb, nh, nl);   // nb == 21: the leftover blocks 84..86
                     if constexpr (blk + 1 < NB) {
                         ws.template begin_c<HB_BONE>();
-                        mma_chunk<4, 4, HB_BONE>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);   // one pipeline over the 16 blocks
+                        if constexpr (blk == 0 && NB == 2 && HN_FEAT_LOADS_BEHIND)
+                            mma_chunk<4, 4, HB_BONE>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane, [&]() { load_bone(nb, nh, nl); });
+                        else
+                            mma_chunk<4, 4, HB_BONE>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);   // one pipeline over the 16 blocks
                     } else if constexpr (left_bytes <= HB_BONE) {
                         // the first leftover chunk (nb == 21) is shorter than a bone chunk: fetched at the bone size all
                         // the same (the size stays a constant; 7 - 8 KiB of the following chunk come along unused)
@@ -790,12 +808,37 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(bh[s]), "+v"(bl[s]), "+a"(ah[s]), "+a"(al[s]));
 #endif
         {
+            // The leftover block first (2 tiles; register 8 (u & 1) + j of tile u >> 1 <-> bone 8 u + j : (r_1 | r_2) h): its
+            // per-bone values are parked in the stash and join the bone's own sums below, so that every bone is visited
+            // ONCE (coordinates, d/dq, R_b^T) -- as a block behind the bones it cost a second round over all 21 of them,
+            // 41 000 cycles per tile in the in-kernel stamps.
+            {
+                f32x16 L1[2], L2[2];
+                static_for<2>([&](auto U) {
+                    constexpr int u = decltype(U)::value;
+                    const char* buf0 = ws.template acquire<0>();
+                    ws.template begin_c<HB_BWD>();
+                    L1[u] = zero16();
+                    L2[u] = zero16();
+                    mma_tile<16, 0, HB_BWD>(ws, buf0, bh, bl, L1[u], L2[u], lane);
+                    const char* buf4 = ws.template acquire<0>();
+                    ws.template begin_c<HB_BWD>();   // after the last one: bone 0's first chunk
+                    mma_tile<16, 0, HB_BWD>(ws, buf4, ah, al, L1[u], L2[u], lane);
+                });
+                f32x16 La = combine(L1[0], L2[0]), Lb = combine(L1[1], L2[1]);
+                tile_out(La);
+                tile_out(Lb);
+                static_for<N_BONES>([&](auto B_) {
+                    constexpr int b = decltype(B_)::value;
+                    if ((nz >> b) & 1u) sh.f32_store(LEFTJ + b * 256, b < 16 ? La[b] : Lb[b - 16]);
+                });
+            }
             const int jbase = ws.goff - HB_BWD;   // stream offset of bone 0's first chunk (in flight)
             unsigned rem = nzw & ~1u;
             int b = 0;
 #pragma unroll 1
             while (b < N_BONES) {
-                const int nb = rem ? __builtin_ctz(rem) : N_BONES;   // the next bone that is run (21: leftover chunks)
+                const int nb = rem ? __builtin_ctz(rem) : N_BONES;   // the next bone that is run (21: what follows the bones: colour lin0's first chunk, the same size)
                 rem &= rem - 1u;
                 f32x16 G1[2], G2[2];
                 const bool live = (nz >> b) & 1u;
@@ -844,11 +887,17 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 #pragma unroll
                             for (int jj = 0; jj < 8; ++jj) own[s][jj] = unsplit(fh[s][jj], fl[s][jj]);
                     }
+                    // the leftover pair (r_1 | r_2) h of this bone: own value and its row of the leftover block
+                    const float Gl = sh.f32_load(LEFTJ + b * 256);
+                    const float ownl = (h ? bn.r[2] : bn.r[1]) * bn.hh;
                     if constexpr (ADJ) {
                         // the same contraction through the h-weighted sums, which the adjoint's second-order term needs
                         // again (unscaled: G carries BWD_SCALE)
                         BoneSums S;
                         bone_sums<true>(Ga, Gb, own, bn.hh, h, S);
+                        S.T0 = fmaf(Gl, ownl, S.T0);
+                        S.T1[2] += h ? 0.f : Gl * bn.hh;
+                        S.T1[3] += h ? Gl * bn.hh : 0.f;
                         float Sv = fmaf(kk, S.T0, S.T1[0]);
                         float Sr[3] = {S.T1[1], S.T1[2], S.T1[3]};
                         to_p(Sv, Sr, bn, b, g);
@@ -862,44 +911,14 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     } else {
                         float Sv = 0.f, Sr[3] = {0.f, 0.f, 0.f};
                         bone_jacobian(Ga, Gb, own, bn, kk, h, Sv, Sr);
+                        Sv = fmaf(Gl * ownl, kk, Sv);
+                        Sr[1] += h ? 0.f : Gl * bn.hh;
+                        Sr[2] += h ? Gl * bn.hh : 0.f;
                         to_p(Sv, Sr, bn, b, g);
                     }
                 }
                 b = nb;
             }
-            // leftover block: 2 tiles; register 8 (u & 1) + j of tile u >> 1 <-> bone 8 u + j : (r_1 | r_2) h
-            f32x16 L1[2], L2[2];
-            static_for<2>([&](auto U) {
-                constexpr int u = decltype(U)::value;
-                const char* buf0 = ws.template acquire<0>();
-                ws.template begin_c<HB_BWD>();
-                L1[u] = zero16();
-                L2[u] = zero16();
-                mma_tile<16, 0, HB_BWD>(ws, buf0, bh, bl, L1[u], L2[u], lane);
-                const char* buf4 = ws.template acquire<0>();
-                ws.template begin_c<HB_BWD>();   // after the last one: colour lin0's first feature-vector chunk, same size
-                mma_tile<16, 0, HB_BWD>(ws, buf4, ah, al, L1[u], L2[u], lane);
-            });
-            f32x16 La = combine(L1[0], L2[0]), Lb = combine(L1[1], L2[1]);
-            tile_out(La);
-            tile_out(Lb);
-            static_for<N_BONES>([&](auto B_) {
-                constexpr int b = decltype(B_)::value;
-                if ((nz >> b) & 1u) {
-                    const float Gv = b < 16 ? La[b] : Lb[b - 16];
-                    const Bone2 bn = coords(b);
-                    const float kk = -TAU2 * (1.f - bn.hh);
-                    const float own = (h ? bn.r[2] : bn.r[1]) * bn.hh;
-                    float Sv = Gv * own * kk;
-                    float Sr[3] = {0.f, h ? 0.f : Gv * bn.hh, h ? Gv * bn.hh : 0.f};
-                    to_p(Sv, Sr, bn, b, g);
-                    if constexpr (ADJ) {   // the leftover pair's share of the bone's sums: T0, T1[r_1], T1[r_2]
-                        sh.f32_store(TS + (9 * b) * 256, sh.f32_load(TS + (9 * b) * 256) + half_sum(Gv * own) * BWD_INV);
-                        sh.f32_store(TS + (9 * b + 3) * 256, sh.f32_load(TS + (9 * b + 3) * 256) + half_sum(Sr[1]) * BWD_INV);
-                        sh.f32_store(TS + (9 * b + 4) * 256, sh.f32_load(TS + (9 * b + 4) * 256) + half_sum(Sr[2]) * BWD_INV);
-                    }
-                }
-            });
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) g[c] *= BWD_INV;
@@ -1174,7 +1193,7 @@ int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const
 }  // namespace v2
 }  // namespace hn
 
-#ifdef HN_TS
+#if defined(HN_TS) && !defined(HN_HAND_ADJ_TU)
 extern "C" int hn_debug_ts(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hn::v2::g_hn_ts), sizeof(unsigned long long) * n);
 }

@@ -532,6 +532,11 @@ struct NoEpi {
 };
 // FETCH: the DMA pieces of the next chunk are issued from this tile's MFMA slots (one piece per
 // stride of slots, all within the first ~half of the tile so that they land before the next barrier)
+// how far apart the DMA pieces of the next chunk are placed in the MFMA slots of this one (3: every third slot, over the
+// first ~60 % of a 16-k-step tile; 1: in its first slots, so that they have the whole tile to land)
+#ifndef HN_PIECE_STRIDE_MAX
+#define HN_PIECE_STRIDE_MAX 3
+#endif
 // FETCH: 0 none; 1 the run-time form (WStream::begin / piece); >= 1024: the size of the chunk being fetched, a
 // constant (WStream::begin_c / piece_c)
 template <int KS, int S0, int FETCH, int NX, typename Epi>
@@ -540,7 +545,7 @@ __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 
     static_assert(S0 + KS <= NX, "k-step range");
     constexpr int NQ = 3 * KS;
     constexpr int NP = FETCH > 1 ? WStream::n_pieces<FETCH>() : MAX_PIECES_PER_WAVE;
-    constexpr int STRIDE = NQ >= 3 * NP ? 3 : (NQ >= 2 * NP ? 2 : 1);
+    constexpr int STRIDE = HN_PIECE_STRIDE_MAX >= 3 && NQ >= 3 * NP ? 3 : (HN_PIECE_STRIDE_MAX >= 2 && NQ >= 2 * NP ? 2 : 1);
     static_assert(!FETCH || NQ >= NP, "not enough slots for the DMA pieces");
     h8 ah[3], al[3];
     // this lane's LDS read address is formed per tile (see lane_x16): kept across the kernel it gets spilled, and its
@@ -582,15 +587,20 @@ __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 
 // are contiguous in LDS): the A-fragment ring keeps running across the tile boundaries, where NT separate mma_tile
 // calls would each start with an empty ring and expose the LDS latency again.  The DMA pieces of the next chunk go
 // into the first slots.
-template <int NT, int KS, int FETCH = 1, int NX>
+struct NoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+// mid(): called once, in the slot behind the last DMA piece -- vector-memory work issued there is YOUNGER than the pieces,
+// so the next acquire can let it stay in flight (acquire<ALLOW>)
+template <int NT, int KS, int FETCH = 1, int NX, typename Mid = NoMid>
 __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16* c1,
-                                          f32x16* c2, int lane) {
+                                          f32x16* c2, int lane, Mid&& mid = Mid{}) {
     static_assert(KS <= NX, "k-step range");
     static_assert(!S16 || KS % 2 == 0, "the 16x16x32 shape consumes k-steps in pairs");
     constexpr int N = NT * KS;           // blocks in the chunk
     constexpr int NQ = 3 * N;
     constexpr int NP = FETCH > 1 ? WStream::n_pieces<FETCH>() : MAX_PIECES_PER_WAVE;
-    constexpr int STRIDE = NQ >= 3 * NP ? 3 : (NQ >= 2 * NP ? 2 : 1);
+    constexpr int STRIDE = HN_PIECE_STRIDE_MAX >= 3 && NQ >= 3 * NP ? 3 : (HN_PIECE_STRIDE_MAX >= 2 && NQ >= 2 * NP ? 2 : 1);
     static_assert(NQ >= NP, "not enough slots for the DMA pieces");
     h8 ah[3], al[3];
     (void)lane;
@@ -605,8 +615,10 @@ __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8
         constexpr int Q = decltype(Q_)::value;
         if constexpr (FETCH == 1 && Q % STRIDE == STRIDE - 1 && Q / STRIDE < NP) ws.template piece<NoEpi::branchy>(Q / STRIDE);
         if constexpr (FETCH > 1 && Q % STRIDE == STRIDE - 1 && Q / STRIDE < NP) ws.template piece_c<FETCH, Q / STRIDE>(l16);
+        if constexpr (Q == STRIDE * NP) mid();
         __builtin_amdgcn_sched_barrier(0);
     };
+    static_assert(STRIDE * NP < NQ, "no slot left behind the pieces");
     load(std::integral_constant<int, 0>{});
     load(std::integral_constant<int, 1>{});
     static_for<N>([&](auto S) {

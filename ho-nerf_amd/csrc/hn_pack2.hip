@@ -455,19 +455,8 @@ static void one_slot_tile_T(Builder& B, const HostMat& M, float scale, const std
     }
     B.chunk(M, true, scale, 1, 16, rows.data(), slots.data(), nullptr);
 }
-static void feature_rows_T(Builder& B, const HostMat& M0, const HostMat& M4, float scale4, int col_off4) {
-    for (int b = 0; b <= N_BONES; ++b) {
-        std::vector<int> sl = b < N_BONES ? bone_slots(b) : left_slots();
-        sl.resize(64, -1);
-        for (int u = 0; u < 2; ++u) {
-            one_slot_tile_T(B, M0, 1.f, sl, 0, u);
-            one_slot_tile_T(B, M4, scale4, sl, col_off4, u);
-        }
-    }
-}
-
-// the adjoint's order of the same rows: the leftover block first (its per-bone values are parked while the bones are
-// visited), then the bones; one matrix (M4 == nullptr) or the two of feature_rows_T
+// d sdf / d features rows in the order every Jacobian pass consumes them: the leftover block first (its per-bone values
+// are parked while the bones are visited), then the bones; one matrix (M4 == nullptr) or two
 static void feature_rows_T_adj(Builder& B, const HostMat& M0, const HostMat* M4, float scale4, int col_off4) {
     for (int k = 0; k <= N_BONES; ++k) {
         const int b = k == 0 ? N_BONES : k - 1;
@@ -525,7 +514,7 @@ void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, int mode)
     if (mode == 0) return;
     fwd_tiles(B, S[8], 1.f, 8, 256, 1, hs, 16, nullptr, 0);
     for (int l = 7; l >= 1; --l) bwd_tiles(B, S[l], l == 4 ? rs2 : 1.f, 8, 256, 0, 256, 16);
-    feature_rows_T(B, S[0], S[4], rs2, H);
+    feature_rows_T_adj(B, S[0], &S[4], rs2, H);   // leftover block first: its rows join the bones' sums (hn_field2_hand.hip)
     // colour lin0 = [features 1386 | feature vector 256 | enc4(g) 27] (utils/fields.py:224-229)
     {
         const std::vector<int> v4 = vec4_slots();

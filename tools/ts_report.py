@@ -11,11 +11,11 @@ lib = L.load()
 m = product_modules()
 f = PackedField('hand', m['sdf_hand'], m['color_hand'], m['var_hand'], precision='f16x3')
 gen = torch.Generator().manual_seed(3)
-n = 32768 * int(os.environ.get('TILES', '1'))
+n = int(os.environ.get('N_SAMPLES', str(32768 * int(os.environ.get('TILES', '1')))))   # N_SAMPLES=3200: the 25-tile launches of a fitting step
 bt_inv, T_pose, joints = synth.synth_hand_pose(5)
 j = torch.from_numpy(joints)
 p = j[torch.randint(0, 21, (n,), generator=gen)] + 0.03 * torch.randn(n, 3, generator=gen)
-d = torch.nn.functional.normalize(torch.randn(n // 64, 3, generator=gen), dim=-1)
+d = torch.nn.functional.normalize(torch.randn(max(n // 64, 1), 3, generator=gen), dim=-1)
 pc, dc = p.cuda(), d.cuda()
 bt, tp = torch.from_numpy(bt_inv).cuda().reshape(1, 21, 4, 4), torch.from_numpy(T_pose).cuda().reshape(1, 21, 3)
 sdf, grad, rgb = torch.empty(n, device='cuda'), torch.empty(n, 3, device='cuda'), torch.empty(n, 3, device='cuda')
@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); full(); e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-raw = ctypes.CDLL(os.path.join(R, 'ho-nerf_amd', 'libhonerf.so'))
+raw = ctypes.CDLL(L.LIB_PATH)
 buf = (ctypes.c_ulonglong * (4 * 8192))()
 raw.hn_debug_ts.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert raw.hn_debug_ts(buf, 4 * 8192) == 0
