@@ -1136,19 +1136,27 @@ struct XcdPace {
             if (threadIdx.x == 0) atomicAdd(&c[xcd], 1u);
         }
     }
-    // meeting number e (1, 2, ...; every workgroup passes them in the same order): arrive, wait for members * e arrivals
-    __device__ __forceinline__ void meet(int e) const {
+    // meeting number e (1, 2, ...; every workgroup passes them in the same order): arrive, wait for members * e arrivals.
+    // A meeting that times out (a workgroup of the XCD is not running beside the others: a shared or partitioned device)
+    // switches the pacing of this workgroup off for the rest of the launch -- the others follow one timeout later.
+    __device__ __forceinline__ void meet(int e) {
+        __shared__ int timed_out;
         if (threadIdx.x == 0) {
             const unsigned members = __hip_atomic_load(&c[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atomicAdd(&c[8 + xcd], 1u);
             const unsigned target = members * (unsigned)e;
-            for (int spin = 0; spin < 3000; ++spin) {
+            int spin = 0;
+            for (; spin < 3000; ++spin) {
                 if (__hip_atomic_load(&c[8 + xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
                 __builtin_amdgcn_s_sleep(16);
             }
+            timed_out = spin == 3000;
         }
         __syncthreads();
+        if (timed_out) c = nullptr;
+        __syncthreads();   // (the flag is rewritten at the next meeting)
     }
+    __device__ __forceinline__ bool on() const { return c != nullptr; }
 };
 #ifndef HN_XCD_PACING
 #define HN_XCD_PACING 1
