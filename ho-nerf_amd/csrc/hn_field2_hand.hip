@@ -298,11 +298,25 @@ __device__ __forceinline__ void hv_from_sums(const BoneSums& S, const Bone2& q, 
                 ((Sr[c] - dot * q.r[c]) / q.v * rw + dot * wt[c]) / q.v - sr_wt * q.r[c] / q.v;
     }
 }
-// sum over the wave's lanes (64): butterfly through the LDS crossbar; cold path (12 values per live bone and tile)
+// sum over the wave's 64 lanes, every lane gets the total: four DPP steps inside the 16-lane rows (quad swaps, half-row and
+// row mirrors: after each step the lanes of the group reached hold the group's sum), then the rows with the two lane-row
+// swaps of gfx950.  All VALU: the LDS-crossbar butterfly it replaces (6 dependent ds_bpermute per value, 12 values per live
+// bone) was most of the 12 900 cycles a bone of the adjoint's second pass took in the in-kernel stamps.
+template <int CTRL>
+__device__ __forceinline__ float dpp_xadd(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v = dpp_xadd<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_xadd<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_xadd<0x141>(v);   // row_half_mirror
+    v = dpp_xadd<0x140>(v);   // row_mirror
+    unsigned x = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    x = __builtin_bit_cast(unsigned, v);
+    r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 
 // MODE 0: sdf only (sampling passes); 1: full evaluation (sdf, d sdf / d p, colour); 2: full evaluation followed by its
@@ -1193,6 +1207,11 @@ int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const
 }  // namespace v2
 }  // namespace hn
 
+#if defined(HN_TS) && defined(HN_HAND_ADJ_TU)
+extern "C" int hn_debug_ts_adj(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hn::v2::g_hn_ts), sizeof(unsigned long long) * n);
+}
+#endif
 #if defined(HN_TS) && !defined(HN_HAND_ADJ_TU)
 extern "C" int hn_debug_ts(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hn::v2::g_hn_ts), sizeof(unsigned long long) * n);
