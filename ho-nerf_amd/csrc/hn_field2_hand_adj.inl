@@ -387,6 +387,26 @@
             rem &= rem - 1u;
             f32x16 G1[2], G2[2];
             const bool live = (nz >> b) & 1u;
+            // the bone's 14 per-lane scalars of the tape (sums of the forward pass, the colour net's share of qbar, its
+            // leftover row): requested here, four chunks ahead of their use -- at the use they were one more HBM round trip
+            // per bone in front of 1 500 dependent instructions
+            BoneSums X;
+            float qa[3], Gl_b = 0.f;
+            X.T0 = 0.f;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) X.T1[q4] = X.T2[q4] = 0.f;
+            qa[0] = qa[1] = qa[2] = 0.f;
+            if (live) {
+                X.T0 = sh.f32_load(TS + (9 * b) * 256);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    X.T1[q4] = sh.f32_load(TS + (9 * b + 1 + q4) * 256);
+                    X.T2[q4] = sh.f32_load(TS + (9 * b + 5 + q4) * 256);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) qa[c] = sh.f32_load(QA + (3 * b + c) * 256);
+                Gl_b = sh.f32_load(LEFTX + b * 256);
+            }
             static_for<2>([&](auto U) {
                 constexpr int u = decltype(U)::value;
                 const char* buf0 = ws.template acquire<0>();
@@ -414,18 +434,13 @@
                 staged_features(own);
                 BoneSums S;
                 bone_sums<false>(combine(G1[0], G2[0]), combine(G1[1], G2[1]), own, bn.hh, h, S);
-                add_leftover(S, bn, b);
+                S.T0 = fmaf(Gl_b, (h ? bn.r[2] : bn.r[1]) * bn.hh, S.T0);   // the leftover pair's share (add_leftover)
+                S.T1[2] += h ? 0.f : Gl_b * bn.hh;
+                S.T1[3] += h ? Gl_b * bn.hh : 0.f;
                 sums_reduce(S, false);
                 float dqB[3];
                 dq_from_sums(S, bn, kk, dqB);
-                // d sdf / d features of the forward pass (the tape): its own d/dq and its Hessian-vector product along R_b gb
-                BoneSums X;
-                X.T0 = sh.f32_load(TS + (9 * b) * 256);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    X.T1[q4] = sh.f32_load(TS + (9 * b + 1 + q4) * 256);
-                    X.T2[q4] = sh.f32_load(TS + (9 * b + 5 + q4) * 256);
-                }
+                // d sdf / d features of the forward pass (the tape, X): its own d/dq and its Hessian-vector product along R_b gb
                 float dqX[3], hv[3], w[3];
                 dq_from_sums(X, bn, kk, dqX);
 #pragma unroll
@@ -433,7 +448,7 @@
                 hv_from_sums(X, bn, kk, k2, w, hv);
                 float qbar[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) qbar[c] = (dqB[c] + hv[c] + sh.f32_load(QA + (3 * b + c) * 256)) * inv_kappa;
+                for (int c = 0; c < 3; ++c) qbar[c] = (dqB[c] + hv[c] + qa[c]) * inv_kappa;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) gp[c] += pose(b, c) * qbar[0] + pose(b, 4 + c) * qbar[1] + pose(b, 8 + c) * qbar[2];
                 if (a.g_bt_inv != nullptr || a.g_T_pose != nullptr) {
