@@ -856,6 +856,8 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 rem &= rem - 1u;
                 f32x16 G1[2], G2[2];
                 const bool live = (nz >> b) & 1u;
+                // the bone's row of the leftover block: requested four chunks ahead of its use
+                const float Gl = live ? sh.f32_load(LEFTJ + b * 256) : 0.f;
                 static_for<2>([&](auto U) {
                     constexpr int u = decltype(U)::value;
                     const char* buf0 = ws.template acquire<0>();
@@ -901,8 +903,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 #pragma unroll
                             for (int jj = 0; jj < 8; ++jj) own[s][jj] = unsplit(fh[s][jj], fl[s][jj]);
                     }
-                    // the leftover pair (r_1 | r_2) h of this bone: own value and its row of the leftover block
-                    const float Gl = sh.f32_load(LEFTJ + b * 256);
+                    // the leftover pair (r_1 | r_2) h of this bone: own value and its row of the leftover block (Gl)
                     const float ownl = (h ? bn.r[2] : bn.r[1]) * bn.hh;
                     if constexpr (ADJ) {
                         // the same contraction through the h-weighted sums, which the adjoint's second-order term needs
