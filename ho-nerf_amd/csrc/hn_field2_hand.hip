@@ -139,18 +139,35 @@ __device__ __forceinline__ float sc_half2(float ang, int h) {
     return h ? c : s;
 }
 // the 4 k-steps x 8 values of one bone for this lane (bone_slots in hn_pack2.hip), already times h
+// The two lanes of a sample need the sine (half 0) and the cosine (half 1) of the same 31 angles.  Each computes the pair
+// for HALF of them -- half 0 the angles of k-steps 0 and 1, half 1 those of k-steps 2 and 3 -- keeps the member it needs
+// and hands the other one to its partner (v_permlane32_swap): 16 sincos per lane and bone instead of 32, the same values
+// bit for bit (the same routine on the same angle).  Feature generation runs with the matrix pipe idle (138 000 cycles per
+// tile in the in-kernel stamps at full load).
 __device__ __forceinline__ void bone_features2(const Bone2& bn, int h, float (&f)[4][8]) {
+    // angle of slot (s, j), s < 2 for half 0 / slot (s + 2, j) for half 1
+    float keep[2][8], give[2][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[0][j] = sc_half2(bn.v * (float)(1 << j), h) * bn.hh;
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) f[1][j] = sc_half2(bn.v * (float)(256 << j), h) * bn.hh;
+        for (int j = 0; j < 8; ++j) {
+            // slot (s, j):     s = 0: v 2^j;  s = 1: j < 2: v 2^(8+j), else r_0 2^(j-2)
+            // slot (s + 2, j): s = 0: j < 1: r_0 64, else r_1 2^(j-1);  s = 1: r_2 2^j (j < 7; (3, 7) is the raw pair)
+            const float a_lo = s == 0 ? bn.v * (float)(1 << j) : (j < 2 ? bn.v * (float)(256 << j) : bn.r[0] * (float)(1 << (j - 2)));
+            const float a_hi = s == 0 ? (j < 1 ? bn.r[0] * 64.f : bn.r[1] * (float)(1 << (j - 1))) : bn.r[2] * (float)(1 << (j & 7));
+            float sn, cs;
+            sincos_cw(h ? a_hi : a_lo, sn, cs);
+            keep[s][j] = h ? cs : sn;    // this half's function of its own angle
+            give[s][j] = h ? sn : cs;    // the partner's function of that angle
+        }
 #pragma unroll
-    for (int j = 2; j < 8; ++j) f[1][j] = sc_half2(bn.r[0] * (float)(1 << (j - 2)), h) * bn.hh;
-    f[2][0] = sc_half2(bn.r[0] * 64.f, h) * bn.hh;
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int j = 1; j < 8; ++j) f[2][j] = sc_half2(bn.r[1] * (float)(1 << (j - 1)), h) * bn.hh;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) f[3][j] = sc_half2(bn.r[2] * (float)(1 << j), h) * bn.hh;
+        for (int j = 0; j < 8; ++j) {
+            const float got = other_half(give[s][j], h);   // half 0 receives sin of slot (s + 2, j), half 1 cos of slot (s, j)
+            f[s][j] = (h ? got : keep[s][j]) * bn.hh;
+            f[s + 2][j] = (h ? keep[s][j] : got) * bn.hh;
+        }
     f[3][7] = (h ? bn.r[0] : bn.v) * bn.hh;
 }
 __device__ __forceinline__ void encode_v4h(const float v[3], int h, float (&f)[2][8]) {
