@@ -74,7 +74,7 @@ enum {
     HS_DZ7 = 7,     // fragments
     HS_FVEC = 8,    // fragments
     HS_DZ4 = 9,     // fragments
-    HS_A4F = 10,    // a4 as fragments (input of lin4's hidden part, needed in both passes)
+    HS_A4F = 10,    // (free: a4 used to pass through here as fragments)
     HS_FEAT = 11,   // 87 k-step blocks of feature fragments (84 bone + 3 leftover) = 174 KiB -> 6 slots
     HS_LEFT = 17,   // 21 x 64 floats: the leftover (r_1 | r_2) h values while the bones are generated
     HAND2_SLOTS = 18,
@@ -674,33 +674,23 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         }
         run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 1), no_store);   // lin1
         run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 2), no_store);   // lin2
-        // lin3 -> a4: kept as fragments in the stash too (lin4's hidden part reads them in both passes)
-        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{},
-                                        [&](auto T, EpiState& st, const auto&) {
-                                            constexpr int t = decltype(T)::value;
-                                            if (FULL) sh.tile_store(HS_A1 + 3, t, st.vec());
-                                            stash_frags(HS_A4F)(T, Frags{{st.hi[0], st.hi[1]}, {st.lo[0], st.lo[1]}});
-                                            return NoData{};
-                                        },
-                                        no_store);
+        // lin3 -> a4, in bh / bl like every layer's output: lin4's hidden part reads them from there.  (They used to go
+        // through the stash -- 32 KB written and read back at once per tile, an HBM round trip of ~10 000 cycles in front
+        // of lin4 in the in-kernel stamps.)
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 3), no_store);   // lin3
         if ((HN_DBG(a) >> 8) == 3) return;   // phase timing aid
         // ---- lin4 = [a4 | features] / sqrt2 -> a5: 8 hidden tiles (bias from the tail), then the feature pass
         {
             f32x16 c1[8], c2[8];
-            {
-                h8 xh[16], xl[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) sh.frag_load(HS_A4F * SLOT_BYTES, s, xh[s], xl[s]);
-                static_for<8>([&](auto TI) {
-                    constexpr int ti = decltype(TI)::value;
-                    const char* buf = ws.template acquire<0>();
-                    constexpr int nbytes = ti < 7 ? HB_HID : HB_BONE;
-                    ws.template begin_c<nbytes>();
-                    c1[ti] = tail_tile(buf + 16 * KS_BYTES, 0, h);
-                    c2[ti] = zero16();
-                    mma_tile<16, 0, nbytes>(ws, buf, xh, xl, c1[ti], c2[ti], lane);
-                });
-            }
+            static_for<8>([&](auto TI) {
+                constexpr int ti = decltype(TI)::value;
+                const char* buf = ws.template acquire<0>();
+                constexpr int nbytes = ti < 7 ? HB_HID : HB_BONE;
+                ws.template begin_c<nbytes>();
+                c1[ti] = tail_tile(buf + 16 * KS_BYTES, 0, h);
+                c2[ti] = zero16();
+                mma_tile<16, 0, nbytes>(ws, buf, bh, bl, c1[ti], c2[ti], lane);
+            });
             feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_HID>{});
             block_epilogue(I8t{}, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 4));
         }
