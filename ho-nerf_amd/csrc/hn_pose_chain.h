@@ -53,15 +53,55 @@ template <typename S> HN_PC_FN Dual<S> detach(Dual<S> a) { return {a.v, S(0)}; }
 HN_PC_FN float sqrt_s(float x) { return sqrtf(x); }
 HN_PC_FN double sqrt_s(double x) { return sqrt(x); }
 HN_PC_FN float sin_s(float x) { return sinf(x); }
-HN_PC_FN double sin_s(double x) { return sin(x); }
+HN_PC_FN double sin_s(double x) { return sin(x); }   // (the chain itself goes through sincos_s)
 HN_PC_FN float cos_s(float x) { return cosf(x); }
 HN_PC_FN double cos_s(double x) { return cos(x); }
 HN_PC_FN float acos_s(float x) { return acosf(x); }
+#if defined(__HIP_DEVICE_COMPILE__)
+// acos by fdlibm's rational approximation of asin (no hi / lo tail correction: ~1e-16 relative); arguments are clipped to
+// [-1 + 1e-6, 1 - 1e-6] by the chain before they get here
+HN_PC_FN double acos_s(double x) {
+    auto R = [](double z) {
+        const double p = z * (1.66666666666666657415e-01 + z * (-3.25565818622400915405e-01 + z * (2.01212532134862925881e-01 +
+                         z * (-4.00555345006794114027e-02 + z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
+        const double q = 1.0 + z * (-2.40339491173441421878e+00 + z * (2.02094576023350569471e+00 + z * (-6.88283971605453293030e-01 +
+                         z * 7.70381505559019352791e-02)));
+        return p / q;
+    };
+    if (fabs(x) < 0.5) return 1.57079632679489655800e+00 - (x + x * R(x * x));
+    const double z = (1.0 - fabs(x)) * 0.5, sq = sqrt(z);
+    const double a = 2.0 * (sq + sq * R(z));
+    return x > 0.0 ? a : 3.14159265358979311600e+00 - a;
+}
+#else
 HN_PC_FN double acos_s(double x) { return acos(x); }
+#endif
 HN_PC_FN float atan2_s(float y, float x) { return atan2f(y, x); }
 HN_PC_FN double atan2_s(double y, double x) { return atan2(y, x); }
 HN_PC_FN void sincos_s(float x, float& s, float& c) { sincosf(x, &s, &c); }
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device build: the chain's angles are a few radians at most, and the library's double-precision sincos / acos (huge-argument
+// reduction, special cases: ~200 instructions each, ~450 calls per evaluation) were most of the kernel.  Two-term Cody-Waite
+// reduction by pi/2 and the fdlibm kernel polynomials: < 2 ulp for |x| < 1e4.
+HN_PC_FN void sincos_s(double x, double& s, double& c) {
+    const double k = rint(x * 0.63661977236758134308);
+    double r = fma(-k, 1.57079632679489655800e+00, x);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double sr = fma(r * z, ps, r), cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    s = (q & 1) ? cr : sr;
+    c = (q & 1) ? sr : cr;
+    if (q == 1 || q == 2) c = -c;
+    if (q >= 2) s = -s;
+}
+#else
 HN_PC_FN void sincos_s(double x, double& s, double& c) { sincos(x, &s, &c); }
+#endif
 // sin and cos of one angle from one argument reduction (the double-precision library routines are the bulk of the chain's
 // instructions: every angle is evaluated once and its pair handed to whatever rotates by it)
 template <typename S> struct SinCos { Dual<S> s, c; };
