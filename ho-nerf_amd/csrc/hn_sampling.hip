@@ -476,6 +476,7 @@ __global__ void k_merge_serial(const float* __restrict__ z, const float* __restr
 // b_j at j + #{i: a_i <= b_j} (ties: the old sample first, as the stable sort of cat([z, z_new]) places them).
 // Rows are read and written with consecutive lanes on consecutive addresses; the serial kernel above walks one
 // row per lane (row stride k floats: every access its own cache line) and runs at 4 % of the HBM rate.
+template <int R>   // R = ceil(k / 64): 64-element slices of the old row per lane (a k = 64 row needs one, not four)
 __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ z, const float* __restrict__ z_new,
                                                const float* __restrict__ sdf, const float* __restrict__ sdf_new, int n_rays,
                                                int k, int m, int quirk_p, float* __restrict__ z_out,
@@ -487,10 +488,10 @@ __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ z, cons
         const float* a = z + (size_t)ray * k;
         const float* b = z_new + (size_t)ray * m;
         const size_t ob = (size_t)ray * (k + m);
-        float av[4], as[4];
-        int cnt[4];
+        float av[R], as[R];
+        int cnt[R];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < R; ++r) {
             const int e = r * 64 + lane;
             const bool ok = e < k;
             av[r] = ok ? a[e] : 0.f;
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ z, cons
             const float bj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), j));
             int le = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < R; ++r) {
                 const bool ok = r * 64 + lane < k;
                 cnt[r] += (ok && bj < av[r]) ? 1 : 0;
                 le += __popcll(__ballot(ok && av[r] <= bj));
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ z, cons
             if (lane == j) bcnt = le;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < R; ++r) {
             const int e = r * 64 + lane;
             if (e < k) {
                 const int o = e + cnt[r];
@@ -642,8 +643,13 @@ int merge(const float* z, const float* z_new, const float* sdf, const float* sdf
     if (n_rays == 0) return HN_OK;
     if (k <= 256 && m <= 64) {
         const int blocks = (n_rays + 3) / 4 < 8192 ? (n_rays + 3) / 4 : 8192;
-        hipLaunchKernelGGL(k_merge, dim3(blocks), dim3(256), 0, s, z, z_new, sdf, sdf_new, n_rays, k, m, quirk_p, z_out,
-                           sdf_out, index);
+        const int slices = (k + 63) / 64;
+        if (slices <= 1)
+            hipLaunchKernelGGL(k_merge<1>, dim3(blocks), dim3(256), 0, s, z, z_new, sdf, sdf_new, n_rays, k, m, quirk_p, z_out, sdf_out, index);
+        else if (slices == 2)
+            hipLaunchKernelGGL(k_merge<2>, dim3(blocks), dim3(256), 0, s, z, z_new, sdf, sdf_new, n_rays, k, m, quirk_p, z_out, sdf_out, index);
+        else
+            hipLaunchKernelGGL(k_merge<4>, dim3(blocks), dim3(256), 0, s, z, z_new, sdf, sdf_new, n_rays, k, m, quirk_p, z_out, sdf_out, index);
     } else {
         hipLaunchKernelGGL(k_merge_serial, grid1d(n_rays, 64), dim3(64), 0, s, z, z_new, sdf, sdf_new, n_rays, k, m, quirk_p,
                            z_out, sdf_out, index);
