@@ -383,7 +383,8 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     xp.init(a.xsync);
     const int full_rounds = n_tiles / (int)gridDim.x;
     for (int tile = blockIdx.x, it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
-        if (xp.on() && it >= 1 && it < full_rounds) xp.meet(it);
+        if (xp.on() && it >= 1 && it < full_rounds && it % XCD_PACE_EVERY == 0) xp.meet(it / XCD_PACE_EVERY);
+        ws.stamp(6);   // (timing builds: tile start)
         const bool more = tile + (int)gridDim.x < n_tiles;
         const int n = tile * WG_SAMPLES + wave * 32 + j;
         const bool valid = n < a.n_pts;
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
         // nz bit b: some sample of this wave has a non-zero mask h for bone b.  Where none has, all 64
         // features of the bone are exactly 0 for the whole wave: nothing is generated or stored, and the
         // consumers substitute zero fragments instead of loading (the MFMAs still run: dense compute).
+        ws.stamp(7);   // (points and frame known)
         unsigned nz = 0;
         if constexpr (!RUN_FWD) {
             nz = __builtin_bit_cast(unsigned, sh.f32_load(NZ_OFF));   // as the evaluation launch left it
@@ -437,6 +439,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             sh.f32_store(LEFT + b * 256, any ? (h ? bn.r[2] : bn.r[1]) * bn.hh : 0.f);
         }
         nz = __builtin_amdgcn_readfirstlane(nz);
+        ws.stamp(8);   // (bone loop of the feature generation done)
         {   // leftover block: element j of k-step u belongs to bone 8u + j
             h8 fh[4], fl[4];
 #pragma unroll
@@ -469,6 +472,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             nzw = __builtin_amdgcn_readfirstlane(ex[0] | ex[1] | ex[2] | ex[3] | 1u);
         }
         if ((HN_DBG(a) >> 8) == 1) return;   // phase timing aid
+        ws.stamp(9);   // (feature generation done)
         h8 ah[16], al[16], bh[16], bl[16];   // ping-pong activation fragments
         struct Act {
             f32x16 v;

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     xp.init(a.xsync);
     const int full_rounds = n_tiles / (int)gridDim.x;
     for (int tile = blockIdx.x, it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
-        if (xp.on() && it >= 1 && it < full_rounds) xp.meet(it);
+        if (xp.on() && it >= 1 && it < full_rounds && it % XCD_PACE_EVERY == 0) xp.meet(it / XCD_PACE_EVERY);
         const bool more = tile + (int)gridDim.x < n_tiles;
         const int n = tile * WG_SAMPLES + wave * 32 + j;
         const bool valid = n < a.n_pts;

@@ -1162,6 +1162,10 @@ struct XcdPace {
 #define HN_XCD_PACING 1
 #endif
 constexpr int XCD_PACE_MIN_ROUNDS = 8;   // tiles per workgroup from which a launch is paced
+#ifndef HN_XCD_PACE_EVERY
+#define HN_XCD_PACE_EVERY 1
+#endif
+constexpr int XCD_PACE_EVERY = HN_XCD_PACE_EVERY;   // meet at every n-th tile start
 
 // Re-materialises a wave-uniform pointer in SGPRs behind an opaque asm so that the compiler cannot
 // hoist the (hundreds of) addresses derived from it out of the persistent tile loop -- hoisted, they

@@ -67,3 +67,14 @@ if os.environ.get('RAW'):
     for ci in range(lo, hi):
         s0, e0 = starts[ci], starts[ci + 1]
         print('chunk', ci, ' '.join('%d:%d' % (ids[k], t[k] - t[s0]) for k in range(s0, e0)))
+
+# tile prologue (stamps 6..9 of the timing build): tile start -> points known -> bone loop done -> features done -> first acquire
+if os.environ.get('PROLOGUE'):
+    ids0 = (a[0] >> np.uint64(60)).astype(int); t0 = (a[0] & np.uint64((1 << 60) - 1)).astype(np.int64)
+    k0 = int(np.argmax(ids0 == 0)) if (ids0 == 0).any() else 8192
+    ids0, t0 = ids0[:k0], t0[:k0]
+    for s6 in np.nonzero(ids0 == 6)[0]:
+        seg = [(int(ids0[x]), int(t0[x])) for x in range(s6, min(s6 + 6, k0))]
+        prev4 = [x for x in range(max(s6 - 3, 0), s6) if ids0[x] == 4]
+        base = t0[prev4[-1]] if prev4 else t0[s6]
+        print('tile start: since last mma end %6d | ' % (t0[s6] - base) + ' '.join('id%d +%d' % (i, tt - t0[s6]) for i, tt in seg[1:]))
