@@ -287,7 +287,7 @@ template <typename S> HN_PC_FN void kp_to_bones(const V3<Dual<S>> (&kp)[21], V3<
 }
 
 // normalize_root_planes (:964-1031); pra: palm_refine_angle (entries 0..2 used)
-template <typename S> HN_PC_FN void normalize_root_planes(const V3<Dual<S>> (&bones)[20], const Dual<S> (&pra)[N_PRA], V3<Dual<S>> (&out)[20], M3<Dual<S>> (&mat)[20]) {
+template <typename S, int N> HN_PC_FN void normalize_root_planes(const V3<Dual<S>> (&bones)[N], const Dual<S> (&pra)[N_PRA], V3<Dual<S>> (&out)[N], M3<Dual<S>> (&mat)[N]) {
     using T = Dual<S>;
     const S canon[3] = {S(0.8), S(0.2), S(0.2)};   // self.root_plane_angles without a canonical pose (:405)
     V3<T> b0 = bones[0], b1 = bones[1], b2 = bones[2], b3 = bones[3], b4 = bones[4];
@@ -308,13 +308,13 @@ template <typename S> HN_PC_FN void normalize_root_planes(const V3<Dual<S>> (&bo
     const T a32 = signed_angle(n3, n2, b3);
     const M3<T> pinky = rotation_matrix(a32 + canon[2] + pra[2], b3);
     root[4] = mul(pinky, ring);
-    for (int i = 0; i < 20; ++i) {
+    for (int i = 0; i < N; ++i) {   // N = 20: all bones (the kinematic chains inherit their root's matrix); 5: the roots alone
         mat[i] = root[i % 5];
         out[i] = mul(mat[i], bones[i]);
     }
 }
 // normalize_root_bone_angles (:1033-1107); pra entries 3..6
-template <typename S> HN_PC_FN void normalize_root_bone_angles(const V3<Dual<S>> (&bones)[20], const Dual<S> (&pra)[N_PRA], V3<Dual<S>> (&out)[20], M3<Dual<S>> (&mat)[20]) {
+template <typename S, int N> HN_PC_FN void normalize_root_bone_angles(const V3<Dual<S>> (&bones)[N], const Dual<S> (&pra)[N_PRA], V3<Dual<S>> (&out)[N], M3<Dual<S>> (&mat)[N]) {
     using T = Dual<S>;
     const S canon[4] = {S(0.4), S(0.2), S(0.2), S(0.2)};
     V3<T> b0 = bones[0], b1 = bones[1], b2 = bones[2], b3 = bones[3], b4 = bones[4];
@@ -340,7 +340,7 @@ template <typename S> HN_PC_FN void normalize_root_bone_angles(const V3<Dual<S>>
     const T f43 = signed_angle(b4, b3, n3);
     const M3<T> pinky_t = rotation_matrix(f43 - canon[3] + pra[6], n3);
     root[4] = mul(pinky_t, ring_t);
-    for (int i = 0; i < 20; ++i) {
+    for (int i = 0; i < N; ++i) {   // N = 20: all bones (the kinematic chains inherit their root's matrix); 5: the roots alone
         mat[i] = root[i % 5];
         out[i] = mul(mat[i], bones[i]);
     }
@@ -608,6 +608,232 @@ HN_PC_FN void pose_chain(const S (&ori_pose)[21][3], const S (&mean_bl)[20], boo
     }
     for (int i = 0; i < 21; ++i)
         for (int c = 0; c < 3; ++c) out[21 * 16 + 3 * i + c] = j3[i].x[c];
+}
+
+// ---- the same chain, one FINGER at a time --------------------------------------------------------------------------------
+// Everything above bone level is per finger (bone i = 5 L + f: level L of finger f; its joint is biomech joint i + 1 =
+// MANO joint 1 + 4 f + L); only three things cross fingers: the five raw root bones (twice: the root normalisations and the
+// finger planes of each PoseConverter pass need all of them) and the level-0 joints of fingers 1 and 2 (the second
+// canonical transform).  So the chain splits into four phases per (input direction, finger) with three exchanges between
+// them: the device kernel runs one THREAD per (direction, finger) -- a fifth of the serial work, arrays of 4 instead of 20
+// -- and the host oracle runs the phases in loops.  Same arithmetic, statement for statement, as pose_chain() above (the
+// host oracle checks the two against each other).
+template <typename T> struct FingerState {
+    V3<T> raw[4], kpar[4], bones[4];   // raw unit bones, parent joints, normalised bones
+    T bl[4];
+    M3<T> rbn, tm[4];                  // the finger's root normalisation; per bone trans_mat_without_scale_translation
+    M3<T> Rc;                          // canonical transform in use (R | t)
+    V3<T> tc;
+    V3<T> J[4], J0;                    // phase B: the finger's refined joints and the root joint (world frame)
+};
+// own joints (canonical frame) -> raw bones; returns the finger's raw root bone
+template <typename S> HN_PC_FN V3<Dual<S>> finger_bones(int f, const V3<Dual<S>>& root, const V3<Dual<S>> (&jt)[4], bool is_right, FingerState<Dual<S>>& st) {
+    using T = Dual<S>;
+    V3<T> r0 = root, j[4];
+    for (int L = 0; L < 4; ++L) j[L] = jt[L];
+    if (!is_right) {
+        r0.x[0] = -r0.x[0];
+        for (int L = 0; L < 4; ++L) j[L].x[0] = -j[L].x[0];
+    }
+    for (int L = 0; L < 4; ++L) {
+        const V3<T> par = L == 0 ? r0 : j[L - 1];
+        const V3<T> b = j[L] - par;
+        st.bl[L] = max_c(norm(b), S(1e-9));
+        st.raw[L] = scale(b, T(S(1)) / st.bl[L]);
+        st.kpar[L] = par;
+    }
+    (void)f;
+    return st.raw[0];
+}
+// all five raw root bones -> this finger's normalised bones, frames and tm (converter_core from normalize_root_planes on)
+template <typename S> HN_PC_FN void finger_core(int f, const V3<Dual<S>> (&RB)[5], const Dual<S>* jra, const Dual<S> (&pra)[N_PRA], FingerState<Dual<S>>& st) {
+    using T = Dual<S>;
+    // the two root normalisations on the root bones alone (their matrices are per finger; levels 1..3 inherit them)
+    V3<T> o1[5], o2[5];
+    M3<T> pm[5], am[5];
+    normalize_root_planes(RB, pra, o1, pm);
+    normalize_root_bone_angles(o1, pra, o2, am);
+    st.rbn = mul(am[f], pm[f]);
+    for (int L = 0; L < 4; ++L) st.bones[L] = mul(am[f], mul(pm[f], st.raw[L]));
+    // compute_local_coordinate_system, this finger's chain (detached)
+    V3<T> nb[5];
+    for (int k = 0; k < 5; ++k) nb[k] = detach3(o2[k]);
+    V3<T> pn[4];
+    for (int k = 0; k < 4; ++k) pn[k] = unit(cross(nb[k], nb[k + 1]), S(1e-9));
+    const V3<T> fpn = f == 0 ? pn[0] : (f == 1 ? pn[1] : (f == 2 ? scale(pn[1] + pn[2], T(S(0.5))) : (f == 3 ? scale(pn[2] + pn[3], T(S(0.5))) : pn[3])));
+    V3<T> bd[4];
+    for (int L = 0; L < 4; ++L) bd[L] = detach3(st.bones[L]);
+    M3<T> cs[4];
+    cs[0] = eye3<T>();
+    V3<T> z = bd[0], y = cross(bd[0], fpn), x = cross(y, z);
+    x = unit(x, S(1e-9));
+    y = unit(y, S(1e-9));
+    for (int c = 0; c < 3; ++c) {
+        cs[1].m[0][c] = x.x[c];
+        cs[1].m[1][c] = y.x[c];
+        cs[1].m[2][c] = z.x[c];
+    }
+    const V3<T> y_axis = {{T(S(0)), T(S(1)), T(S(0))}}, x_axis = {{T(S(1)), T(S(0)), T(S(0))}};
+    for (int L = 2; L < 4; ++L) {
+        const M3<T>& pc = cs[L - 1];
+        const V3<T> lbv2 = mul(pc, bd[L - 1]);
+        T a_xz, a_yz;
+        bone_angles(lbv2, false, a_xz, a_yz);
+        const M3<T> pct = transpose(pc);
+        const SinCos<S> sc_xz = sincos_d(a_xz), sc_yz = sincos_d(-a_yz);
+        const V3<T> axis_xz = mul(pct, y_axis);
+        const V3<T> axis_y = mul(pct, rotate(x_axis, y_axis, sc_xz));
+        if (!(fabs((double)a_xz.v) < 1e-6)) {
+            x = rotate(x, axis_xz, sc_xz);
+            y = rotate(y, axis_xz, sc_xz);
+            z = rotate(z, axis_xz, sc_xz);
+        }
+        if (!(fabs((double)a_yz.v) < 1e-6)) {
+            x = rotate(x, axis_y, sc_yz);
+            y = rotate(y, axis_y, sc_yz);
+            z = rotate(z, axis_y, sc_yz);
+        }
+        for (int c = 0; c < 3; ++c) {
+            cs[L].m[0][c] = x.x[c];
+            cs[L].m[1][c] = y.x[c];
+            cs[L].m[2][c] = z.x[c];
+        }
+    }
+    for (int L = 0; L < 4; ++L) cs[L] = detachM(cs[L]);
+    // angles, rotation matrices (compute_rotation_matrix), adjusted transpose, tm
+    M3<T> rot[4];
+    const V3<T> ex = {{T(S(1)), T(S(0)), T(S(0))}}, ey = {{T(S(0)), T(S(1)), T(S(0))}};
+    rot[0] = eye3<T>();
+    for (int L = 1; L < 4; ++L) {
+        T a_xz, a_yz;
+        bone_angles(mul(cs[L], st.bones[L]), true, a_xz, a_yz);
+        const int i = 5 * L + f;
+        const V3<T> rotated_x = rotate(ex, ey, a_xz);
+        T abduction = -a_yz;
+        if (jra != nullptr && i < 10) abduction = abduction + jra[i - 5];
+        const M3<T> r1 = rotation_matrix(abduction, rotated_x);
+        T flexion = -a_xz;
+        if (jra != nullptr) flexion = flexion + jra[i];
+        rot[L] = mul(rotation_matrix(flexion, ey), r1);
+    }
+    for (int L = 0; L < 4; ++L) {
+        M3<T> lct = transpose(cs[L]);
+        if (L == 2) lct = mul(lct, rot[1]);
+        if (L == 3) lct = mul(lct, mul(rot[2], rot[1]));
+        st.tm[L] = mul(lct, mul(rot[L], cs[L]));
+    }
+}
+// inputs of one (direction) evaluation, shared by the phases
+template <typename S> struct ChainIn {
+    const S (*ori_pose)[3];
+    const S* mean_bl;
+    bool is_right;
+    Dual<S> jra[N_JRA], pra[N_PRA], r6[6];
+    V3<Dual<S>> t_palm;
+};
+template <typename S> HN_PC_FN void chain_inputs(const S (&ori_pose)[21][3], const S (&mean_bl)[20], bool is_right, const Dual<S> (&in)[N_IN], ChainIn<S>& ci) {
+    ci.ori_pose = ori_pose;
+    ci.mean_bl = mean_bl;
+    ci.is_right = is_right;
+    for (int i = 0; i < N_JRA; ++i) ci.jra[i] = in[i];
+    for (int i = 0; i < N_PRA; ++i) ci.pra[i] = in[N_JRA + i] * S(0.1);
+    for (int i = 0; i < 6; ++i) ci.r6[i] = in[N_JRA + N_PRA + i];
+    ci.t_palm = {{in[N_JRA + N_PRA + 6], in[N_JRA + N_PRA + 7], in[N_JRA + N_PRA + 8]}};
+}
+// phase A: predicted joints -> canonical frame -> this finger's raw bones; returns its raw root bone
+template <typename S> HN_PC_FN V3<Dual<S>> chain_phase_a(int f, const ChainIn<S>& ci, FingerState<Dual<S>>& st) {
+    using T = Dual<S>;
+    V3<T> kps[21];   // (values only: the predicted joints are data)
+    for (int i = 0; i < 21; ++i) {
+        const int m = mano_to_biomech(i);
+        kps[i] = {{T(ci.ori_pose[m][0]), T(ci.ori_pose[m][1]), T(ci.ori_pose[m][2])}};
+    }
+    canonical_transform(kps, ci.is_right, st.Rc, st.tc);
+    V3<T> jt[4];
+    for (int L = 0; L < 4; ++L) jt[L] = mul(st.Rc, kps[5 * L + f + 1]) + st.tc;
+    return finger_bones(f, mul(st.Rc, kps[0]) + st.tc, jt, ci.is_right, st);
+}
+// phase B: refine (get_refine_3d_joint), back to the world frame, palm motion; returns the finger's level-0 joint
+template <typename S> HN_PC_FN V3<Dual<S>> chain_phase_b(int f, const ChainIn<S>& ci, const V3<Dual<S>> (&RB)[5], FingerState<Dual<S>>& st) {
+    using T = Dual<S>;
+    const S ibv[20][3] = {{4.4889e-01, -8.4880e-01, -2.7935e-01}, {1.9867e-01, -9.8007e-01, 0.0000e+00},  {2.0004e-07, -1.0000e+00, 0.0000e+00},
+                          {-1.9471e-01, -9.8007e-01, -3.9469e-02}, {-3.7001e-01, -9.2185e-01, -1.1528e-01}, {4.4889e-01, -8.4880e-01, -2.7935e-01},
+                          {1.9867e-01, -9.8007e-01, 1.1921e-07},   {2.8685e-07, -1.0000e+00, 0.0000e+00},  {-1.9471e-01, -9.8007e-01, -3.9470e-02},
+                          {-3.7001e-01, -9.2185e-01, -1.1528e-01}, {4.4889e-01, -8.4880e-01, -2.7935e-01}, {1.9867e-01, -9.8007e-01, 1.4901e-07},
+                          {1.9870e-06, -1.0000e+00, 2.3842e-07},   {-1.9471e-01, -9.8007e-01, -3.9470e-02}, {-3.7001e-01, -9.2185e-01, -1.1528e-01},
+                          {4.4889e-01, -8.4880e-01, -2.7935e-01},  {1.9867e-01, -9.8007e-01, 8.9407e-08},  {-3.4117e-06, -1.0000e+00, -2.1979e-07},
+                          {-1.9471e-01, -9.8007e-01, -3.9469e-02}, {-3.7001e-01, -9.2185e-01, -1.1528e-01}};
+    finger_core(f, RB, ci.jra, ci.pra, st);
+    const M3<T> R1i = inverse(st.Rc);
+    const V3<T> t1i = scale(mul(R1i, st.tc), T(S(-1)));
+    const M3<T> Rp = rot6d_to_matrix(ci.r6);
+    const V3<T> root = t1i;   // the refined pose's root joint is the canonical origin
+    V3<T> start = {{T(S(0)), T(S(0)), T(S(0))}};
+    for (int L = 0; L < 4; ++L) {
+        const int i = 5 * L + f;
+        const M3<T> inv = inverse(mul(st.tm[L], st.rbn));
+        const V3<T> v = {{T(ibv[i][0]), T(ibv[i][1]), T(ibv[i][2])}};
+        start = start + scale(mul(inv, v), T(ci.mean_bl[i]));
+        const V3<T> w = mul(R1i, start) + t1i;                     // back through the inverse canonical transform
+        st.J[L] = mul(Rp, w - root) + root + ci.t_palm;             // palm rotation about the root joint + translation
+    }
+    st.J0 = root + ci.t_palm;
+    return st.J[0];
+}
+// phase C: the refined joints -> second canonical frame -> raw bones; J1, J2: the level-0 joints of fingers 1 and 2
+template <typename S> HN_PC_FN V3<Dual<S>> chain_phase_c(int f, const ChainIn<S>& ci, const V3<Dual<S>>& J1, const V3<Dual<S>>& J2, FingerState<Dual<S>>& st) {
+    using T = Dual<S>;
+    V3<T> kp[21];
+    for (int i = 0; i < 21; ++i) kp[i] = {{T(S(0)), T(S(0)), T(S(0))}};
+    kp[0] = st.J0;   // canonical_transform reads joints 0, 2, 3 (biomech): the root and the level-0 joints of fingers 1, 2
+    kp[2] = J1;
+    kp[3] = J2;
+    canonical_transform(kp, ci.is_right, st.Rc, st.tc);
+    V3<T> jt[4];
+    for (int L = 0; L < 4; ++L) jt[L] = mul(st.Rc, st.J[L]) + st.tc;
+    return finger_bones(f, mul(st.Rc, st.J0) + st.tc, jt, ci.is_right, st);
+}
+// phase D: PoseConverter.forward for this finger -> its rows of bone_transformation_inv and joint_3d.  put(index, value)
+// receives output `index` of the N_OUT (finger 0 also writes the root's rows).
+template <typename S, typename Put> HN_PC_FN void chain_phase_d(int f, const ChainIn<S>& ci, const V3<Dual<S>> (&RB)[5], FingerState<Dual<S>>& st, Put&& put) {
+    using T = Dual<S>;
+    T pra0[N_PRA];
+    finger_core(f, RB, (const T*)nullptr, pra0, st);
+    auto put_affine = [&](int im, const M3<T>& R, const V3<T>& t) {
+        const M3<T> RR = mul(R, st.Rc);
+        const V3<T> tt = mul(R, st.tc) + t;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) put(16 * im + 4 * r + c, RR.m[r][c]);
+            put(16 * im + 4 * r + 3, tt.x[r]);
+        }
+        for (int c = 0; c < 4; ++c) put(16 * im + 12 + c, T(S(c == 3 ? 1 : 0)));
+    };
+    V3<T> tr = {{T(S(0)), T(S(0)), T(S(0))}};
+    for (int L = 0; L < 4; ++L) {
+        const M3<T> R = mul(st.tm[L], st.rbn);
+        put_affine(1 + 4 * f + L, R, tr - mul(R, st.kpar[L]));
+        tr = tr + scale(mul(st.tm[L], st.bones[L]), st.bl[L]);
+        for (int c = 0; c < 3; ++c) put(21 * 16 + 3 * (1 + 4 * f + L) + c, st.J[L].x[c]);
+    }
+    if (f == 0) {
+        put_affine(0, eye3<T>(), V3<T>{{T(S(0)), T(S(0)), T(S(0))}});
+        for (int c = 0; c < 3; ++c) put(21 * 16 + c, st.J0.x[c]);
+    }
+    (void)ci;
+}
+
+// the four phases in loops over the fingers: what the device kernel does with one thread per finger and three exchanges
+template <typename S>
+HN_PC_FN void pose_chain_by_finger(const S (&ori_pose)[21][3], const S (&mean_bl)[20], bool is_right, const Dual<S> (&in)[N_IN], Dual<S> (&out)[N_OUT]) {
+    using T = Dual<S>;
+    ChainIn<S> ci;
+    chain_inputs(ori_pose, mean_bl, is_right, in, ci);
+    FingerState<T> st[5];
+    V3<T> RB[5], J[5];
+    for (int f = 0; f < 5; ++f) RB[f] = chain_phase_a(f, ci, st[f]);
+    for (int f = 0; f < 5; ++f) J[f] = chain_phase_b(f, ci, RB, st[f]);
+    for (int f = 0; f < 5; ++f) RB[f] = chain_phase_c(f, ci, J[1], J[2], st[f]);
+    for (int f = 0; f < 5; ++f) chain_phase_d(f, ci, RB, st[f], [&](int idx, const T& v) { out[idx] = v; });
 }
 
 }  // namespace pose

@@ -1,7 +1,7 @@
 // hn_pose_chain / hn_pose_chain_bwd: the hand pose chain of the fitting loops (fitting_single.py:206-226 and the
 // halo_util functions it calls, ~4 000 torch operators per step in the reference) as two launches.  The chain itself is
-// hn_pose_chain.h; here one thread per (frame, input direction) evaluates it on dual numbers: thread 0 of a frame writes
-// the values, thread 1 + k the column d(outputs)/d(input k) of the Jacobian [N_OUT x N_IN], which the backward launch
+// hn_pose_chain.h; here one thread per (frame, input direction, finger) evaluates it on dual numbers: direction 0 writes
+// the values, direction 1 + k the column d(outputs)/d(input k) of the Jacobian [N_OUT x N_IN], which the backward launch
 // contracts with the upstream gradient.  The work is a few kFLOP per thread; the point is the launch count.
 #include "hn_common.h"
 #include "hn_pose_chain.h"
@@ -12,25 +12,72 @@ using pose::Dual;
 using pose::N_IN;
 using pose::N_OUT;
 
-__global__ __launch_bounds__(64) void k_pose_chain(const float* __restrict__ ori_pose, const float* __restrict__ bone_len,
-                                                   const unsigned char* __restrict__ is_right, const float* __restrict__ in, int n_frames,
-                                                   float* __restrict__ bt_inv, float* __restrict__ joint_3d, float* __restrict__ jac) {
-    const int f = blockIdx.x, k = threadIdx.x;   // k = 0: values; k = 1 + input index: that input's derivative
-    if (f >= n_frames || k > N_IN || (k > 0 && jac == nullptr)) return;
-    // In double: the chain is a few kFLOP per thread, and in fp32 its angle / normalisation steps leave 3e-4 of relative
-    // error on the Jacobian (measured against the reference's fp64 run; the reference's own fp32 run is 3e-5 off on the
-    // values).  Inputs and outputs stay fp32.
+// One block per frame, one thread per (input direction k, finger f): 37 x 5 = 185 threads.  The chain's four phases
+// (hn_pose_chain.h, "one FINGER at a time") with three exchanges through LDS between them.
+constexpr int PC_DIRS = N_IN + 1;
+__global__ __launch_bounds__(192) void k_pose_chain(const float* __restrict__ ori_pose, const float* __restrict__ bone_len,
+                                                    const unsigned char* __restrict__ is_right, const float* __restrict__ in, int n_frames,
+                                                    float* __restrict__ bt_inv, float* __restrict__ joint_3d, float* __restrict__ jac) {
+    using T = Dual<double>;
+    using pose::V3;
+    __shared__ double xb[PC_DIRS][5][6];
+    const int fr = blockIdx.x, tid = threadIdx.x;
+    const int k = tid % PC_DIRS, f = tid / PC_DIRS;   // k = 0: values; 1 + input index: that input's derivative
+    const bool active = fr < n_frames && f < 5 && (k == 0 || jac != nullptr);
+    // In double: in fp32 the chain's angle / normalisation steps leave 3e-4 of relative error on the Jacobian (measured against
+    // the reference's fp64 run; the reference's own fp32 run is 3e-5 off on the values).  Inputs and outputs stay fp32.
     double pose[21][3], bl[20];
-    for (int i = 0; i < 63; ++i) pose[i / 3][i % 3] = (double)ori_pose[(size_t)f * 63 + i];
-    for (int i = 0; i < 20; ++i) bl[i] = (double)bone_len[(size_t)f * 20 + i];
-    Dual<double> x[N_IN], y[N_OUT];
-    for (int i = 0; i < N_IN; ++i) x[i] = Dual<double>((double)in[(size_t)f * N_IN + i], i == k - 1 ? 1.0 : 0.0);
-    pose::pose_chain<double>(pose, bl, is_right == nullptr || is_right[f] != 0, x, y);
-    if (k == 0) {
-        for (int i = 0; i < 21 * 16; ++i) bt_inv[(size_t)f * 336 + i] = (float)y[i].v;
-        for (int i = 0; i < 63; ++i) joint_3d[(size_t)f * 63 + i] = (float)y[336 + i].v;
-    } else {
-        for (int i = 0; i < N_OUT; ++i) jac[((size_t)f * N_OUT + i) * N_IN + (k - 1)] = (float)y[i].d;
+    pose::ChainIn<double> ci;
+    pose::FingerState<T> st;
+    if (active) {
+        for (int i = 0; i < 63; ++i) pose[i / 3][i % 3] = (double)ori_pose[(size_t)fr * 63 + i];
+        for (int i = 0; i < 20; ++i) bl[i] = (double)bone_len[(size_t)fr * 20 + i];
+        T x[N_IN];
+        for (int i = 0; i < N_IN; ++i) x[i] = T((double)in[(size_t)fr * N_IN + i], i == k - 1 ? 1.0 : 0.0);
+        pose::chain_inputs<double>(pose, bl, is_right == nullptr || is_right[fr] != 0, x, ci);
+    }
+    auto publish = [&](const V3<T>& v) {
+        for (int c = 0; c < 3; ++c) {
+            xb[k][f][2 * c] = v.x[c].v;
+            xb[k][f][2 * c + 1] = v.x[c].d;
+        }
+    };
+    auto fetch = [&](int g) {
+        V3<T> v;
+        for (int c = 0; c < 3; ++c) v.x[c] = T(xb[k][g][2 * c], xb[k][g][2 * c + 1]);
+        return v;
+    };
+    V3<T> RB[5];
+    if (active) publish(pose::chain_phase_a<double>(f, ci, st));
+    __syncthreads();
+    if (active)
+        for (int g = 0; g < 5; ++g) RB[g] = fetch(g);
+    __syncthreads();
+    if (active) publish(pose::chain_phase_b<double>(f, ci, RB, st));
+    __syncthreads();
+    V3<T> J1, J2;
+    if (active) {
+        J1 = fetch(1);
+        J2 = fetch(2);
+    }
+    __syncthreads();
+    if (active) publish(pose::chain_phase_c<double>(f, ci, J1, J2, st));
+    __syncthreads();
+    if (active) {
+        for (int g = 0; g < 5; ++g) RB[g] = fetch(g);
+        float* bt = bt_inv + (size_t)fr * 336;
+        float* j3 = joint_3d + (size_t)fr * 63;
+        float* J = jac != nullptr ? jac + (size_t)fr * N_OUT * N_IN : nullptr;
+        pose::chain_phase_d<double>(f, ci, RB, st, [&](int idx, const T& v) {
+            if (k == 0) {
+                if (idx < 336)
+                    bt[idx] = (float)v.v;
+                else
+                    j3[idx - 336] = (float)v.v;
+            } else {
+                J[(size_t)idx * N_IN + (k - 1)] = (float)v.d;
+            }
+        });
     }
 }
 
@@ -52,7 +99,7 @@ int pose_chain(const float* ori_pose, const float* bone_len, const unsigned char
                float* joint_3d, float* jac, hipStream_t s) {
     if (n_frames <= 0) return HN_OK;
     HN_REQUIRE(ori_pose != nullptr && bone_len != nullptr && in != nullptr && bt_inv != nullptr && joint_3d != nullptr, "pose chain: NULL argument");
-    hipLaunchKernelGGL(k_pose_chain, dim3(n_frames), dim3(64), 0, s, ori_pose, bone_len, is_right, in, n_frames, bt_inv, joint_3d, jac);
+    hipLaunchKernelGGL(k_pose_chain, dim3(n_frames), dim3(192), 0, s, ori_pose, bone_len, is_right, in, n_frames, bt_inv, joint_3d, jac);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
