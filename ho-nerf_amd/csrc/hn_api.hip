@@ -37,6 +37,8 @@ int composite2(const float*, const float*, const float*, const float*, const flo
                float*, float*, float*, float*, hipStream_t);
 int alpha_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float, float*,
               float*, float*, hipStream_t);
+int alpha_inv_s_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float, float*,
+                    hipStream_t);
 int composite1_bwd(const float*, const float*, const float*, const float*, const float*, int, int, float*, float*, float*,
                    hipStream_t);
 int composite2_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
@@ -458,7 +460,8 @@ size_t field_bwd_workspace_bytes(const hn_field* f, int n);
 int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
-                   size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb);
+                   size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb,
+                   float* g_params = nullptr);
 }
 
 // Backward pass of the two-field render (what loss.backward() runs through NeuSRenderer_fitting.render in the fitting
@@ -532,6 +535,66 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     hipLaunchKernelGGL(k_add4, dim3(((int)R3 + 255) / 256), dim3(256), 0, s, go_h, g_ro2, (const float*)nullptr, (const float*)nullptr,
                        g_rays_o, (int)R3);
     hipLaunchKernelGGL(k_add4, dim3(((int)R3 + 255) / 256), dim3(256), 0, s, gdd_h, gd_h, gdir_h, g_rd2, g_rays_d, (int)R3);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+// Backward pass of the single-field render into the field's PARAMETERS (what loss.backward() runs through
+// NeuSRenderer.render in exp_runner.train, exp_runner.py:208-242) and into the rays / pose inputs.  The
+// depths carry no gradient (utils/renderer.py:215 no_grad), so it runs through render_core at the depths z the
+// forward pass produced (utils/renderer.py:107-177): the field is evaluated there again, then
+// composite1_bwd -> alpha_bwd (+ d/d inv_s) -> eikonal term -> field adjoint with parameter gradients -> ray map.
+static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const float* rays_d, int n_rays, int S, float sample_dist,
+                                  const float* bt_inv, const float* T_pose, const float* z, const float* g_color,
+                                  const float* g_wsum, const float* g_eik, float* g_params, float* g_inv_s, float* g_rays_o,
+                                  float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes,
+                                  hipStream_t s, size_t* need) {
+    HN_REQUIRE(n_rays >= 0 && S >= 1, "bad sizes");
+    const size_t N = (size_t)n_rays * S, R3 = (size_t)n_rays * 3;
+    Arena ar(workspace, workspace_bytes);
+    float *pts = ar.f(N * 3), *dists = ar.f(N), *sdf = ar.f(N), *grad = ar.f(N * 3), *rgb = ar.f(N * 3), *al = ar.f(N), *c = ar.f(N);
+    float *g_al = ar.f(N), *g_c = ar.f(N), *g_rgb = ar.f(N * 3), *gs = ar.f(N), *gg = ar.f(N * 3), *gd = ar.f(R3);
+    float *gp = ar.f(N * 3), *gdir = ar.f(R3), *gdd = ar.f(R3), *go = ar.f(R3);
+    const size_t fws_bytes = field_ws(f, (int)N), bws_bytes = bwd::field_bwd_workspace_bytes(f, (int)N);
+    void* fws = ar.take(fws_bytes);
+    void* bws = ar.take(bws_bytes);
+    if (need != nullptr) {
+        *need = ar.used;
+        return HN_OK;
+    }
+    if (!ar.ok) {
+        set_error("render_single_bwd workspace too small: %zu bytes given", workspace_bytes);
+        return HN_ENOMEM;
+    }
+    if (n_rays == 0) return HN_OK;
+    const bool hand = f->kind == HN_FIELD_HAND;
+    HN_REQUIRE(rays_o && rays_d && z && g_color && g_params, "null argument");
+    HN_REQUIRE(!hand || (bt_inv && T_pose), "hand field needs bt_inv / T_pose");
+    const int n = (int)N;
+    HN_TRY(sample_points(rays_o, rays_d, z, n_rays, S, 1, sample_dist, pts, dists, s));
+    HN_TRY(field_eval(f, pts, rays_d, n, S, bt_inv, T_pose, 1, n, sdf, grad, rgb, nullptr, fws, fws_bytes, s));
+    HN_TRY(alpha(sdf, grad, rays_d, dists, n, S, f->inv_s, al, c, s));
+    HN_TRY(composite1_bwd(al, c, rgb, g_color, g_wsum, n_rays, S, g_al, g_c, g_rgb, s));
+    HN_TRY(alpha_bwd(sdf, grad, rays_d, dists, g_al, g_c, n, S, f->inv_s, gs, gg, gd, s));
+    if (g_inv_s != nullptr) {
+        HN_CHECK_HIP(hipMemsetAsync(g_inv_s, 0, sizeof(float), s));
+        HN_TRY(alpha_inv_s_bwd(sdf, grad, rays_d, dists, g_al, g_c, n, S, f->inv_s, g_inv_s, s));
+    }
+    hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs, gg, (const float*)nullptr, (const float*)nullptr, grad, g_eik, n);
+    float *gbt = g_bt_inv, *gtp = g_T_pose;
+    if (hand) {   // the adjoint accumulates the pose gradients: into the caller's arrays when given, else into scratch
+        if (gbt == nullptr) gbt = g_al;            // 336 floats of a finished array
+        if (gtp == nullptr) gtp = g_c;
+        HN_REQUIRE(N >= 336, "too few samples");
+        HN_CHECK_HIP(hipMemsetAsync(gbt, 0, 21 * 16 * sizeof(float), s));
+        HN_CHECK_HIP(hipMemsetAsync(gtp, 0, 21 * 3 * sizeof(float), s));
+    }
+    HN_TRY(bwd::field_eval_bwd(f, pts, rays_d, n, S, bt_inv, T_pose, 1, n, gs, gg, g_rgb, gp, gdir, gbt, gtp, bws, bws_bytes, s, nullptr,
+                               nullptr, nullptr, g_params));
+    HN_TRY(sample_points_bwd(z, gp, n_rays, S, 1, sample_dist, go, gdd, s));
+    if (g_rays_o != nullptr) HN_CHECK_HIP(hipMemcpyAsync(g_rays_o, go, R3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (g_rays_d != nullptr)
+        hipLaunchKernelGGL(k_add4, dim3(((int)R3 + 255) / 256), dim3(256), 0, s, gdd, gd, gdir, (const float*)nullptr, g_rays_d, (int)R3);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -620,6 +683,46 @@ int hn_field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, 
     return hn::bwd::field_eval_bwd(f, pts, rays_d, n_pts, samples_per_ray, bt_inv, T_pose, n_frames, pts_per_frame, g_sdf, g_grad,
                                    g_rgb, g_pts, g_rays_d, g_bt_inv, g_T_pose, workspace, workspace_bytes,
                                    reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, nullptr);
+}
+size_t hn_field_param_floats(const hn_field* f) { return (f == nullptr || f->raw == nullptr) ? 0 : f->raw_floats; }
+int hn_field_param_offset(const hn_field* f, int net, int layer, size_t* w_off, size_t* b_off, int* out_dim, int* in_dim, int* ld) {
+    HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");
+    HN_REQUIRE((net == 0 && layer >= 0 && layer < 9) || (net == 1 && layer >= 0 && layer < 5), "no such layer: net %d layer %d", net, layer);
+    const float* base = reinterpret_cast<const float*>(f->raw);
+    const float* w = net == 0 ? f->raw_sdf_w[layer] : f->raw_col_w[layer];
+    const float* b = net == 0 ? f->raw_sdf_b[layer] : f->raw_col_b[layer];
+    if (w_off) *w_off = (size_t)(w - base);
+    if (b_off) *b_off = (size_t)(b - base);
+    if (out_dim) *out_dim = net == 0 ? f->sdf_out[layer] : f->col_out[layer];
+    if (in_dim) *in_dim = net == 0 ? f->sdf_in[layer] : f->col_in[layer];
+    if (ld) *ld = net == 0 ? f->sdf_ld[layer] : f->col_ld[layer];
+    return HN_OK;
+}
+int hn_field_param_bwd(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray,
+                       const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf,
+                       const float* g_grad, const float* g_rgb, float* g_params, float* g_pts, float* g_rays_d, float* g_bt_inv,
+                       float* g_T_pose, void* workspace, size_t workspace_bytes, hn_stream_t stream) {
+    HN_REQUIRE(g_params != nullptr, "g_params is NULL");
+    return hn::bwd::field_eval_bwd(f, pts, rays_d, n_pts, samples_per_ray, bt_inv, T_pose, n_frames, pts_per_frame, g_sdf, g_grad,
+                                   g_rgb, g_pts, g_rays_d, g_bt_inv, g_T_pose, workspace, workspace_bytes,
+                                   reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, nullptr, g_params);
+}
+size_t hn_render_single_bwd_workspace_bytes(const hn_field* f, int n_rays, int samples_per_ray) {
+    if (f == nullptr || n_rays <= 0 || samples_per_ray <= 0) return 0;
+    size_t need = 0;
+    (void)render_single_bwd_impl(f, nullptr, nullptr, n_rays, samples_per_ray, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &need);
+    return need;
+}
+int hn_render_single_bwd(const hn_field* f, const float* rays_o, const float* rays_d, int n_rays, int samples_per_ray,
+                         float sample_dist, const float* bt_inv, const float* T_pose, const float* z_vals, const float* g_color,
+                         const float* g_weight_sum, const float* g_gradient_error, float* g_params, float* g_inv_s, float* g_rays_o,
+                         float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes,
+                         hn_stream_t stream) {
+    HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");
+    return render_single_bwd_impl(f, rays_o, rays_d, n_rays, samples_per_ray, sample_dist, bt_inv, T_pose, z_vals, g_color,
+                                  g_weight_sum, g_gradient_error, g_params, g_inv_s, g_rays_o, g_rays_d, g_bt_inv, g_T_pose, workspace,
+                                  workspace_bytes, reinterpret_cast<hipStream_t>(stream), nullptr);
 }
 float hn_field_inv_s(const hn_field* f) { return f ? f->inv_s : 0.f; }
 int hn_field_set_culling(hn_field* f, int enabled) {

@@ -139,6 +139,7 @@ struct hn_field {
     size_t v2_adjonly_bytes = 0;
     // --- folded (weight-norm applied) weights and biases, row-major [out, in], for the adjoint (hn_field_bwd.hip)
     void* raw = nullptr;
+    size_t raw_floats = 0;       // length of the retained block = length of a parameter-gradient vector (hn_field_param_floats)
     const float* raw_sdf_w[9] = {};
     const float* raw_sdf_b[9] = {};
     const float* raw_col_w[5] = {};

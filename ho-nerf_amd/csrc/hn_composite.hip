@@ -596,6 +596,47 @@ int alpha_bwd(const float* sdf, const float* grad, const float* rays_d, const fl
     return HN_OK;
 }
 
+// d loss / d inv_s of the alpha stage (utils/renderer.py:144-161: inv_s = exp(10 variance) is a trained parameter,
+// exp_runner.py:208-242): sum over the samples of gc c (1 - c) x1 / inv_s ... written on the pre-sigmoid arguments
+// x1 = (s - half) inv_s, x2 = (s + half) inv_s.  One atomic per block (caller zeroes g_inv_s).
+__global__ void k_alpha_inv_s_bwd(const float* __restrict__ sdf, const float* __restrict__ grad, const float* __restrict__ rays_d,
+                                  const float* __restrict__ dists, const float* __restrict__ g_alpha, const float* __restrict__ g_c,
+                                  int n, int spr, float inv_s, float* __restrict__ g_inv_s) {
+    __shared__ float part[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.f;
+    if (i < n) {
+        const int ray = i / spr;
+        const float tc = rays_d[3 * ray] * grad[3 * (size_t)i] + rays_d[3 * ray + 1] * grad[3 * (size_t)i + 1] +
+                         rays_d[3 * ray + 2] * grad[3 * (size_t)i + 2];
+        const float ic = -fmaxf(-tc, 0.f);
+        const float s = sdf[i];
+        const float half = ic * dists[i] * 0.5f;
+        const float c = sigmoid_e((s - half) * inv_s);
+        const float nx = sigmoid_e((s + half) * inv_s);
+        const float A = (c - nx) + 1e-5f, B = c + 1e-5f;
+        const float a_raw = A / B;
+        const float ga = (a_raw > 0.f && a_raw < 1.f) ? g_alpha[i] : 0.f;
+        const float gc = ga * (B - A) / (B * B) + (g_c != nullptr ? g_c[i] : 0.f);
+        const float gnx = -ga / B;
+        v = gc * c * (1.f - c) * (s - half) + gnx * nx * (1.f - nx) * (s + half);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(g_inv_s, part[0] + part[1] + part[2] + part[3]);
+}
+int alpha_inv_s_bwd(const float* sdf, const float* grad, const float* rays_d, const float* dists, const float* g_alpha,
+                    const float* g_c, int n, int spr, float inv_s, float* g_inv_s, hipStream_t s) {
+    HN_REQUIRE(spr > 0 && g_inv_s != nullptr, "bad arguments");
+    if (n == 0) return HN_OK;
+    hipLaunchKernelGGL(k_alpha_inv_s_bwd, dim3((n + 255) / 256), dim3(256), 0, s, sdf, grad, rays_d, dists, g_alpha, g_c, n, spr,
+                       inv_s, g_inv_s);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
 int composite1_bwd(const float* alpha_in, const float* c, const float* rgb, const float* g_color, const float* g_wsum,
                    int n_rays, int S, float* g_alpha, float* g_c, float* g_rgb, hipStream_t s) {
     HN_REQUIRE(S >= 1, "S must be positive");

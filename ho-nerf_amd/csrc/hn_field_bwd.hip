@@ -155,6 +155,76 @@ __global__ __launch_bounds__(256) void k_dense(const DenseArgs a) {
     }
 }
 
+// ---- parameter gradients (`loss.backward()` into the networks, exp_runner.py:208-242) ---------------
+// dW[m, k] += alpha * sum_i A[i, m] B[i, k]  (i < n): the outer products of a layer's adjoint signal with its input,
+// reduced over the samples.  Workgroup = 64 x 64 tile of dW over one slice of the samples (grid z), 4 waves as 2 x 2
+// MFMA tiles (v_mfma_f32_32x32x2_f32: the sample index is the MFMA's k), operands staged through LDS 32 samples at a
+// time, partial tiles added with atomics (the caller zeroes dW).  With db != NULL the column K of B is taken as the
+// constant 1: dW's column K is the bias gradient db[m] += alpha_b * sum_i A[i, m].
+struct OuterArgs {
+    const float* A;
+    int lda, M;
+    const float* B;
+    int ldb, K;
+    float* dW;
+    int ldw;
+    float* db;
+    float alpha, alpha_b;
+    int n, chunk;
+};
+__global__ __launch_bounds__(256) void k_outer(const OuterArgs a) {
+    __shared__ float As[32][65];
+    __shared__ float Bs[32][65];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, j = lane & 31;
+    const int m0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const int KB = a.db != nullptr ? a.K + 1 : a.K;
+    const int i_begin = blockIdx.z * a.chunk;
+    const int i_end = min(a.n, i_begin + a.chunk);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int si = t >> 3, c8 = (t & 7) * 8;       // thread = (sample of the step, 8 consecutive columns)
+    for (int i0 = i_begin; i0 < i_end; i0 += 32) {
+        const int i = i0 + si;
+        const bool live = i < i_end;
+        const float* pa = a.A + (size_t)i * a.lda + m0 + c8;
+        const float* pb = a.B + (size_t)i * a.ldb + k0 + c8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            As[si][c8 + e] = (live && m0 + c8 + e < a.M) ? pa[e] : 0.f;
+            const int col = k0 + c8 + e;
+            Bs[si][c8 + e] = !live ? 0.f : col < a.K ? pb[e] : col < KB ? 1.f : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * ks + h][wr * 32 + j], Bs[2 * ks + h][wc * 32 + j], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int col = k0 + wc * 32 + j;
+    if (col >= KB) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < a.M) {
+            if (col < a.K)
+                atomicAdd(a.dW + (size_t)m * a.ldw + col, a.alpha * acc[r]);
+            else
+                atomicAdd(a.db + m, a.alpha_b * acc[r]);
+        }
+    }
+}
+// out[c] += scale * sum_i x[i, c]   (c < width <= 256; the gradient of the row W_8[0, :] that seeds the reverse sweep)
+__global__ void k_colsum(const float* __restrict__ x, int n, int ld, int width, float scale, float* __restrict__ out) {
+    const int c = threadIdx.x;
+    const int i0 = blockIdx.x * 256, i1 = min(n, i0 + 256);
+    if (c >= width) return;
+    float s = 0.f;
+    for (int i = i0; i < i1; ++i) s += x[(size_t)i * ld + c];
+    atomicAdd(out + c, scale * s);
+}
+
 // ---- element-wise --------------------------------------------------------------------------------------------
 __device__ __forceinline__ float softplus(float z) {   // nn.Softplus(beta=100, threshold=20)
     return BETA * z > 20.f ? z : log1pf(expf(BETA * z)) / BETA;
@@ -605,6 +675,21 @@ struct Ctx {
     void nn(const float* A, int lda, int K, const float* W, int ldw, int c0, int M, float alpha, float* C, int ldc, bool acc) const {
         dense(A, lda, K, W + c0, ldw, 1, M, nullptr, alpha, C, ldc, acc);
     }
+    // dW[M, K] += alpha * A^T B over the samples (+ db[M] += sum A when db != NULL)
+    void outer(const float* A, int lda, int M, const float* B, int ldb, int K, float alpha, float* dW, int ldw, float* db) const {
+        const int KB = db != nullptr ? K + 1 : K;
+        const int tiles = ((M + 63) / 64) * ((KB + 63) / 64);
+        // enough sample slices to fill the chip a few times over, each at least 256 samples long
+        int slices = (2048 + tiles - 1) / tiles;
+        const int max_slices = (n + 255) / 256;
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+        int chunk = (n + slices - 1) / slices;
+        chunk = (chunk + 31) & ~31;
+        slices = (n + chunk - 1) / chunk;
+        OuterArgs a{A, lda, M, B, ldb, K, dW, ldw, db, alpha, 1.f, n, chunk};
+        hipLaunchKernelGGL(k_outer, dim3((KB + 63) / 64, (M + 63) / 64, slices), dim3(256), 0, s, a);
+    }
 };
 
 size_t field_bwd_workspace(const hn_field* f, int n, Arena* out_layout);
@@ -666,7 +751,7 @@ size_t field_bwd_workspace_bytes(const hn_field* f, int n) {
 int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
-                   size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb) {
+                   size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb, float* g_params) {
     HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");
     const bool obj = f->kind == HN_FIELD_OBJ;
     HN_REQUIRE(obj || (bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1),
@@ -676,7 +761,10 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     const bool sdf_only = g_grad == nullptr && g_rgb == nullptr;
     HN_REQUIRE(pts && g_sdf && g_pts && (sdf_only || (g_grad && g_rgb)) && spr >= 1 && n % spr == 0, "bad arguments");
     if (n == 0) return HN_OK;
-    if (fused_adjoint(f, sdf_only)) {
+    HN_REQUIRE(g_params == nullptr || !sdf_only, "parameter gradients need g_grad and g_rgb");
+    // g_params: gradients w.r.t. the folded weights / biases in the layout of f->raw (hn_field_param_offset), accumulated.
+    // They are formed by the launch sequence below for either precision (the fused kernels keep no per-layer arrays).
+    if (g_params == nullptr && fused_adjoint(f, sdf_only)) {
         if (obj)
             return v2::launch_field2_obj_adj(f, pts, rays_d, n, spr, g_sdf, g_grad, g_rgb, g_pts, g_rays_d, workspace, workspace_bytes, s,
                                              tape, grad, rgb);
@@ -704,6 +792,9 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     const float* const* Bv = f->raw_sdf_b;
     const int H4 = f->sdf_in[4] - Din;   // hidden columns of lin4's input (193)
     auto width = [&](int l) { return f->sdf_out[l]; };
+    // the gradient slot of a retained matrix / bias: same offset in g_params as in f->raw
+    float* const gp = g_params;
+    auto G = [&](const float* w) { return gp + (w - reinterpret_cast<const float*>(f->raw)); };
 
     // 1. forward tape -------------------------------------------------------------------------------------------
     if (obj)
@@ -776,15 +867,23 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     }
     cx.nt(b.c[4], H, H, C[4], H, 0, 3, Cb[4], 1.f, b.xb, 3, false);
     hipLaunchKernelGGL(k_rgb_seed, g1(N * 3), dim3(256), 0, s, b.xb, g_rgb, b.xb, N * 3);
+    if (gp) cx.outer(b.xb, 3, 3, b.c[4], H, H, 1.f, G(C[4]), f->col_ld[4], G(Cb[4]));
     cx.nn(b.xb, 3, 3, C[4], H, 0, H, 1.f, b.cb[0], H, false);
     hipLaunchKernelGGL(k_relu_mask, g1((N * H + 3) / 4), dim3(256), 0, s, b.c[4], b.cb[0], N * H);
     int cur = 0;
-    for (int l = 3; l >= 1; --l) {
+    for (int l = 3; l >= 1; --l) {   // cb[cur]: adjoint of layer l's pre-activation
+        if (gp) cx.outer(b.cb[cur], H, H, b.c[l], H, H, 1.f, G(C[l]), f->col_ld[l], G(Cb[l]));
         cx.nn(b.cb[cur], H, H, C[l], H, 0, H, 1.f, b.cb[cur ^ 1], H, false);
         cur ^= 1;
         hipLaunchKernelGGL(k_relu_mask, g1((N * H + 3) / 4), dim3(256), 0, s, b.c[l], b.cb[cur], N * H);
     }
     const float* cb1 = b.cb[cur];
+    if (gp) {   // lin0 by input block: [X | enc(dir) (obj) | feature vector | enc(gradient)]
+        cx.outer(cb1, H, H, b.X, DP, Din, 1.f, G(C[0]), LC0, G(Cb[0]));
+        if (obj) cx.outer(cb1, H, H, b.din, 27, 27, 1.f, G(C[0]) + o_d, LC0, nullptr);
+        cx.outer(cb1, H, H, b.z8 + 1, 257, H, 1.f, G(C[0]) + o_f, LC0, nullptr);
+        cx.outer(cb1, H, H, b.gin, 27, 27, 1.f, G(C[0]) + o_g, LC0, nullptr);
+    }
     cx.nn(cb1, H, H, C[0], LC0, 0, Din, 1.f, b.Xb, DP, false);                    // Xb starts as the colour net's share
     hipLaunchKernelGGL(k_z8_bar, g1(n), dim3(256), 0, s, g_sdf, inv_scale, b.z8b, n);
     cx.nn(cb1, H, H, C[0], LC0, o_f, H, 1.f, b.z8b + 1, 257, false);               // fb
@@ -805,9 +904,14 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     else
         hipLaunchKernelGGL(k_hand_push, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.gb, b.GXb, DP);
     cx.nt(b.GXb, DP, Din, W[0], LW[0], 0, H, nullptr, 1.f, b.dzb, H, false);
+    if (gp) {   // the reverse sweep's own use of the matrices: GX = dz_0 W_0 + dz_4 W_4[:, skip] / sqrt2, u_{l-1} = dz_l W_l
+        cx.outer(b.dz[0], H, H, b.GXb, DP, Din, 1.f, G(W[0]), LW[0], nullptr);
+        cx.outer(b.dz[4], H, H, b.GXb, DP, Din, rs2, G(W[4]) + H4, LW[4], nullptr);
+    }
     for (int l = 1; l <= 7; ++l) {
         const int wprev = width(l - 1);
         hipLaunchKernelGGL(k_fwd_dir, g1((N * wprev + 3) / 4), dim3(256), 0, s, b.a[l], b.u[l - 1], b.dzb, b.sb[l - 1], b.v, N * wprev);
+        if (gp) cx.outer(b.dz[l], width(l), width(l), b.v, wprev, wprev, l == 4 ? rs2 : 1.f, G(W[l]), LW[l], nullptr);
         if (l == 4) {
             cx.nt(b.v, H4, H4, W[4], LW[4], 0, H, nullptr, rs2, b.dzb, H, false);
             cx.nt(b.GXb, DP, Din, W[4], LW[4], H4, H, nullptr, rs2, b.dzb, H, true);
@@ -815,11 +919,24 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
             cx.nt(b.v, wprev, wprev, W[l], LW[l], 0, width(l), nullptr, 1.f, b.dzb, width(l), false);
         }
     }
-    hipLaunchKernelGGL(k_fwd_dir, g1((N * H + 3) / 4), dim3(256), 0, s, b.a[8], b.u[7], b.dzb, b.sb[7], (float*)nullptr, N * H);
+    hipLaunchKernelGGL(k_fwd_dir, g1((N * H + 3) / 4), dim3(256), 0, s, b.a[8], b.u[7], b.dzb, b.sb[7], gp ? b.v : (float*)nullptr, N * H);
+    if (gp)     // u_7 = W_8[0, :] / scale
+        hipLaunchKernelGGL(k_colsum, dim3((n + 255) / 256), dim3(256), 0, s, b.v, n, H, H, inv_scale, G(W[8]));
     // 5. first-order reverse sweep with the second-order sources ---------------------------------------------------
     cx.nn(b.z8b, 257, 257, W[8], LW[8], 0, H, 1.f, b.ab, H, false);
+    if (gp) cx.outer(b.z8b, 257, 257, b.a[8], H, H, 1.f, G(W[8]), LW[8], G(Bv[8]));
     for (int l = 7; l >= 0; --l) {
         hipLaunchKernelGGL(k_zb, g1((N * width(l) + 3) / 4), dim3(256), 0, s, b.a[l + 1], b.ab, b.sb[l], b.zb, N * width(l));
+        if (gp) {   // z_l = W_l [a_l (, X)] + b_l
+            if (l == 4) {
+                cx.outer(b.zb, H, H, b.a[4], H4, H4, rs2, G(W[4]), LW[4], G(Bv[4]));
+                cx.outer(b.zb, H, H, b.X, DP, Din, rs2, G(W[4]) + H4, LW[4], nullptr);
+            } else if (l == 0) {
+                cx.outer(b.zb, H, H, b.X, DP, Din, 1.f, G(W[0]), LW[0], G(Bv[0]));
+            } else {
+                cx.outer(b.zb, width(l), width(l), b.a[l], f->sdf_in[l], f->sdf_in[l], 1.f, G(W[l]), LW[l], G(Bv[l]));
+            }
+        }
         if (l == 4) {
             cx.nn(b.zb, H, H, W[4], LW[4], H4, Din, rs2, b.Xb, DP, true);
             cx.nn(b.zb, H, H, W[4], LW[4], 0, H4, rs2, b.ab, H4, false);

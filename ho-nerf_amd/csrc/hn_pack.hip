@@ -382,6 +382,7 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
             rc = HN_ENOMEM;
         } else {
             (void)hipMemsetAsync(f->raw, 0, total * sizeof(float), stream);
+            f->raw_floats = total;
             float* q = reinterpret_cast<float*>(f->raw);
             auto keep_mat = [&](const float* src, int out, int in) {
                 const float* dst = q;

@@ -1,0 +1,236 @@
+"""Offline-stage training of one field over the C ABI: `exp_runner.train`'s
+`render -> loss -> loss.backward() -> optimizer.step()` (exp_runner.py:126-242) with the renderer's HIP path on both
+sides of the loss.
+
+The reference differentiates `NeuSRenderer.render` w.r.t. every parameter of `sdf_network`, `color_network` and
+`deviation_network` (Adam over them, exp_runner.py:97-104).  Sampling is under `no_grad` (utils/renderer.py:215), so the
+backward pass runs through `render_core` at the final depths only: here one call, `hn_render_single_bwd`, which returns
+
+  * d loss / d (folded weights W_l = g_l v_l / |v_l|, biases) of both networks as one flat vector in the layout of
+    `hn_field_param_offset` (first-order path and the path through `.gradient()`),
+  * d loss / d inv_s (inv_s = exp(10 variance)),
+  * d loss / d rays (field frame), d loss / d bt_inv, T_pose (hand).
+
+What is left for the host is element-wise over the parameter blocks: the weight-norm chain rule
+(d/d weight_g, d/d weight_v from d/d W; old-style `nn.utils.weight_norm`, dim 0) and the optimiser (torch's Adam, as the
+reference).  The VGG term of exp_runner.py:213-224 stays a torch module on `color_fine` ("gated on VGG loss
+staying in torch"); it composes with this Function through autograd like any other loss on the render outputs.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import lib as _lib
+
+
+def trainable_parameters(renderer):
+    """The parameters `exp_runner` hands to Adam (exp_runner.py:97-103), in the fixed order SingleRenderFn uses:
+    per SDF layer (weight_g, weight_v, bias), per colour layer the same, then `variance`."""
+    ps = []
+    for net in (renderer.sdf_network, renderer.color_network):
+        for lin in net.layers():
+            ps += [lin.weight_g, lin.weight_v, lin.bias]
+    ps.append(renderer.deviation_network.variance)
+    return ps
+
+
+def _layer_slots(lib, field):
+    """[(net, layer, w_off, b_off, out, in, ld)] of a packed field (hn_field_param_offset)."""
+    slots = []
+    for net, n_layers in ((0, 9), (1, 5)):
+        for l in range(n_layers):
+            w, b = ctypes.c_size_t(), ctypes.c_size_t()
+            o, i, ld = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            _lib.check(lib.hn_field_param_offset(field.handle, net, l, ctypes.byref(w), ctypes.byref(b), ctypes.byref(o),
+                                                 ctypes.byref(i), ctypes.byref(ld)), 'hn_field_param_offset')
+            slots.append((net, l, w.value, b.value, o.value, i.value, ld.value))
+    return slots
+
+
+def folded_gradients(lib, field, g_params):
+    """Views of the flat gradient vector: [(dW [out,in], db [out])] in the order of `_layer_slots`."""
+    out = []
+    for _, _, w, b, o, i, ld in _layer_slots(lib, field):
+        out.append((g_params[w:w + o * ld].view(o, ld)[:, :i], g_params[b:b + o]))
+    return out
+
+
+def weight_norm_backward(g, v, dW):
+    """d/d weight_g [out,1], d/d weight_v [out,in] from d/d W for W = g v / |v| (row norms; torch's `_weight_norm`
+    backward, utils/fields.py:113-121 `nn.utils.weight_norm(lin)`)."""
+    nrm = v.norm(dim=1, keepdim=True)
+    vh = v / nrm
+    proj = (dW * vh).sum(dim=1, keepdim=True)
+    return proj, (g / nrm) * (dW - vh * proj)
+
+
+class SingleRenderFn(torch.autograd.Function):
+    """(rays_o [B,3], rays_d [B,3] in the FIELD's frame, bt_inv [21,4,4] | None, T_pose [21,3] | None, *parameters) ->
+    (color_fine [B,3], weight_sum [B,1], gradient_error [], cdf_fine [B,S], weight_max [B,1]); the last two carry no
+    gradient (they are logged only, exp_runner.py:237-238)."""
+
+    @staticmethod
+    def forward(ctx, renderer, near, far, t_rand, z_given, rays_o, rays_d, bt_inv, T_pose, *params):
+        L = _lib
+        lib = L.load()
+        f = renderer.field()
+        ro, rd = L.f32(rays_o).reshape(-1, 3), L.f32(rays_d).reshape(-1, 3)
+        dev = ro.device
+        B = ro.shape[0]
+        S = renderer.n_samples + renderer.n_importance
+        hand = f.kind == 'hand'
+        bt = L.f32(bt_inv, dev).reshape(1, 21, 4, 4) if hand else None
+        tp = L.f32(T_pose, dev).reshape(1, 21, 3) if hand else None
+        sample_dist = float(torch.tensor((float(far) - float(near)) / renderer.n_samples, dtype=torch.float32))
+        if z_given is not None:
+            # render_core at the caller's depths (utils/renderer.py:107-177): the staged form of the same evaluation
+            z = L.f32(z_given, dev).reshape(B, -1)
+            S = z.shape[1]
+            core = renderer.render_core(ro, rd, bt, tp, None, z, sample_dist)
+            color, cdf, gerr = core['color'], core['cdf'], core['gradient_error'].reshape(1)
+            wsum, wmax = core['weights'].sum(dim=-1, keepdim=True), core['weights'].max(dim=-1, keepdim=True)[0]
+        else:
+            from .renderer import _t_rand
+            tr = _t_rand(t_rand, (B, 1), dev)
+            color, cdf = torch.empty(B, 3, device=dev), torch.empty(B, S, device=dev)
+            wsum, wmax = torch.empty(B, 1, device=dev), torch.empty(B, 1, device=dev)
+            gerr, z = torch.empty(1, device=dev), torch.empty(B, S, device=dev)
+            need = lib.hn_render_single_workspace_bytes(f.handle, B, renderer.n_samples, renderer.n_importance)
+            ws = renderer._ws.get(need, dev)
+            L.check(lib.hn_render_single(f.handle, L.ptr(ro), L.ptr(rd), L.ptr(tr), B, float(near), float(far), renderer.n_samples,
+                                         renderer.n_importance, renderer.up_sample_steps, L.ptr(bt), L.ptr(tp), L.ptr(color),
+                                         L.ptr(cdf), L.ptr(wsum), L.ptr(wmax), L.ptr(gerr), L.ptr(z), L.ptr(ws), ws.numel(),
+                                         L.stream_ptr()), 'hn_render_single')
+        renderer.last_z_vals = z
+        ctx.renderer, ctx.field, ctx.S = renderer, f, S
+        ctx.sample_dist = sample_dist
+        ctx.n_params = len(params)
+        ctx.save_for_backward(ro, rd, z, *([bt, tp] if hand else []))
+        ctx.mark_non_differentiable(cdf, wmax)
+        return color, wsum, gerr.reshape(()), cdf, wmax
+
+    @staticmethod
+    def backward(ctx, g_color, g_wsum, g_gerr, _g_cdf, _g_wmax):
+        L = _lib
+        lib = L.load()
+        ren, f, S = ctx.renderer, ctx.field, ctx.S
+        sv = ctx.saved_tensors
+        ro, rd, z = sv[:3]
+        hand = f.kind == 'hand'
+        bt, tp = (sv[3], sv[4]) if hand else (None, None)
+        dev = ro.device
+        B = ro.shape[0]
+        gc = L.f32(g_color).reshape(B, 3) if g_color is not None else torch.zeros(B, 3, device=dev)
+        gw = None if g_wsum is None else L.f32(g_wsum).reshape(B)
+        ge = None if g_gerr is None else L.f32(g_gerr).reshape(1)
+        n_floats = lib.hn_field_param_floats(f.handle)
+        g_params = torch.zeros(n_floats, device=dev)
+        g_inv_s = torch.empty(1, device=dev)
+        g_ro, g_rd = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
+        g_bt = torch.empty(21, 4, 4, device=dev) if hand else None
+        g_tp = torch.empty(21, 3, device=dev) if hand else None
+        need = lib.hn_render_single_bwd_workspace_bytes(f.handle, B, S)
+        ws = ren._ws_train.get(need, dev)
+        L.check(lib.hn_render_single_bwd(f.handle, L.ptr(ro), L.ptr(rd), B, S, ctx.sample_dist, L.ptr(bt), L.ptr(tp), L.ptr(z), L.ptr(gc),
+                                         L.ptr(gw), L.ptr(ge), L.ptr(g_params), L.ptr(g_inv_s), L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_bt),
+                                         L.ptr(g_tp), L.ptr(ws), need, L.stream_ptr()), 'hn_render_single_bwd')
+        # weight-norm chain rule per layer, in the parameter order of trainable_parameters()
+        grads = []
+        layers = list(ren.sdf_network.layers()) + list(ren.color_network.layers())
+        for lin, (dW, db) in zip(layers, folded_gradients(lib, f, g_params)):
+            dg, dv = weight_norm_backward(lin.weight_g.detach(), lin.weight_v.detach(), dW)
+            grads += [dg, dv, db.clone()]
+        # inv_s = clip(exp(10 variance), 1e-6, 1e6) (utils/fields.py:248-249, utils/renderer.py:144)
+        inv_s = float(f.inv_s)
+        grads.append((g_inv_s * (10.0 * inv_s if 1e-6 < inv_s < 1e6 else 0.0)).reshape(()))
+        assert len(grads) == ctx.n_params, 'pass trainable_parameters(renderer) as the parameter list'
+        return (None, None, None, None, None, g_ro, g_rd, g_bt, g_tp, *grads)
+
+
+class ObjLocalFn(torch.autograd.Function):
+    """convert_obj_to_local (utils/renderer.py:180-188): o' = Ro (o - To), d' = Ro d, with its adjoint
+    (hn_obj_local_fwd / hn_obj_local_bwd) -- the path of the object's `se3_refine` leaves (exp_runner.py:155-161)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, Ro, To):
+        L = _lib
+        lib = L.load()
+        ro, rd = L.f32(rays_o).reshape(-1, 3), L.f32(rays_d).reshape(-1, 3)
+        R, T = L.f32(Ro, ro.device).reshape(1, 3, 3), L.f32(To, ro.device).reshape(1, 3)
+        o2, d2 = torch.empty_like(ro), torch.empty_like(rd)
+        L.check(lib.hn_obj_local_fwd(L.ptr(ro), L.ptr(rd), L.ptr(R), L.ptr(T), 1, ro.shape[0], L.ptr(o2), L.ptr(d2), L.stream_ptr()),
+                'hn_obj_local_fwd')
+        ctx.save_for_backward(ro, rd, R, T)
+        ctx.shapes = (rays_o.shape, rays_d.shape, Ro.shape, To.shape)
+        return o2, d2
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        L = _lib
+        lib = L.load()
+        ro, rd, R, T = ctx.saved_tensors
+        dev = ro.device
+        go, gd = L.f32(g_o).reshape(-1, 3), L.f32(g_d).reshape(-1, 3)
+        g_ro, g_rd = torch.empty_like(ro), torch.empty_like(rd)
+        g_R, g_T = torch.empty(1, 3, 3, device=dev), torch.empty(1, 3, device=dev)
+        L.check(lib.hn_obj_local_bwd(L.ptr(ro), L.ptr(rd), L.ptr(R), L.ptr(T), L.ptr(go), L.ptr(gd), 1, ro.shape[0], L.ptr(g_ro),
+                                     L.ptr(g_rd), L.ptr(g_R), L.ptr(g_T), L.stream_ptr()), 'hn_obj_local_bwd')
+        s = ctx.shapes
+        return g_ro.reshape(s[0]), g_rd.reshape(s[1]), g_R.reshape(s[2]), g_T.reshape(s[3])
+
+
+def render_train(renderer, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, Ro, To, index=0, t_rand=None, z_vals=None):
+    """`NeuSRenderer.render` (utils/renderer.py:190-258) as a differentiable function of the networks' parameters (and of
+    bt_inv / T_pose_21 for the hand, Ro / To for the object through `convert_obj_to_local`): the render of a training
+    step (exp_runner.py:196-201).  Same return keys as `render`.  With `z_vals` [B,S] the sampling is skipped and
+    `render_core` runs at those depths (utils/renderer.py:107-177)."""
+    from .renderer import _Workspace
+    if renderer.perturb <= 0:
+        raise ValueError('render requires perturb > 0, as the reference does')
+    if not hasattr(renderer, '_ws_train'):
+        renderer._ws_train = _Workspace()
+    renderer.index = index
+    dev = rays_o.device
+    if renderer.model_type == 'obj':
+        rays_o, rays_d = ObjLocalFn.apply(rays_o, rays_d, torch.as_tensor(Ro, device=dev), torch.as_tensor(To, device=dev))
+        bt_inv = T_pose_21 = None
+    color, wsum, gerr, cdf, wmax = SingleRenderFn.apply(renderer, near, far, t_rand, z_vals, rays_o, rays_d, bt_inv, T_pose_21,
+                                                        *trainable_parameters(renderer))
+    B = color.shape[0]
+    return {
+        'color_fine': color,
+        's_val': torch.full((B, 1), 1.0 / renderer.field().inv_s, device=dev),
+        'cdf_fine': cdf,
+        'weight_sum': wsum,
+        'weight_max': wmax,
+        'gradient_error': gerr,
+    }
+
+
+def train_step(renderer, optimizer, rays_o, rays_d, near, far, bt_inv, T_pose_21, Ro, To, true_rgb, true_mask, igr_weight=0.1,
+               mask_weight=0.1, t_rand=None, extra_loss=None):
+    """One iteration of exp_runner.train's inner loop (exp_runner.py:196-232): render, loss, backward, optimiser step.
+    `extra_loss(render_out)` adds a torch term on the render outputs (the VGG loss of :213-224)."""
+    out = render_train(renderer, rays_o, rays_d, near, far, bt_inv, T_pose_21, None, Ro, To, t_rand=t_rand)
+    terms = train_loss(out, true_rgb, true_mask, igr_weight, mask_weight)
+    if extra_loss is not None:
+        terms['loss'] = terms['loss'] + extra_loss(out)
+    optimizer.zero_grad(set_to_none=True)
+    terms['loss'].backward()
+    optimizer.step()
+    return terms
+
+
+def train_loss(render_out, true_rgb, true_mask, igr_weight=0.1, mask_weight=0.1):
+    """The loss of exp_runner.py:202-212 without the VGG term (:213-224, a torch module on color_fine)."""
+    color_fine, weight_sum = render_out['color_fine'], render_out['weight_sum']
+    true_mask = (true_mask > 0.5).float()
+    mask_sum = true_mask.sum() + 1e-5
+    color_error = (color_fine - true_rgb) * true_mask
+    color_fine_loss = F.l1_loss(color_error, torch.zeros_like(color_error), reduction='sum') / mask_sum
+    psnr = 20.0 * torch.log10(1.0 / (((color_fine - true_rgb) ** 2 * true_mask).sum() / (mask_sum * 3.0)).sqrt())
+    mask_loss = F.binary_cross_entropy(weight_sum.clip(1e-3, 1.0 - 1e-3), true_mask)
+    eikonal_loss = render_out['gradient_error']
+    loss = color_fine_loss + mask_loss * mask_weight + eikonal_loss * igr_weight
+    return dict(loss=loss, color_fine_loss=color_fine_loss, mask_loss=mask_loss, eikonal_loss=eikonal_loss, psnr=psnr.detach())

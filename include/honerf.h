@@ -351,6 +351,39 @@ int hn_render_dual_bwd(const hn_field* hand, const hn_field* obj, const float* r
                        float* g_Ro, float* g_To, void* workspace, size_t workspace_bytes, const void* tape,
                        hn_stream_t stream);
 
+/* ---- parameter gradients: training the networks (exp_runner.py:208-242 `loss.backward()` into
+ * sdf_network / color_network / deviation_network, optimiser step at :230-232).
+ * A field's trainable state as this library sees it is the FOLDED weights W_l = g_l v_l / |v_l| (old weight-norm API,
+ * utils/fields.py:113-121, 296-306) and biases, row-major [out, ld] per layer (ld = in rounded up to 4), in one flat
+ * block of hn_field_param_floats(f) floats; hn_field_param_offset gives a layer's place in it (net 0 = SDF network,
+ * layers 0..8; net 1 = colour network, layers 0..4).  A gradient vector has the same layout.  The weight-norm chain rule
+ * (d/d weight_g, d/d weight_v) and the optimiser are the caller's: element-wise over these blocks
+ * (honerf_amd/training.py does it with torch's Adam, as exp_runner.py:97-104).
+ *
+ * hn_field_param_bwd: the adjoint of hn_field_eval (same arguments as hn_field_eval_bwd) that also ACCUMULATES
+ * d loss / d (folded weights, biases) into g_params (zero it first); g_pts etc. as hn_field_eval_bwd.  Both the
+ * first-order path and the path through `.gradient()` (create_graph=True in the reference) are included.
+ *
+ * hn_render_single_bwd: the whole backward pass of NeuSRenderer.render (utils/renderer.py:190-258) at the depths
+ * z_vals [B,S] the forward pass returned (sampling is under no_grad, :215): g_color [B,3], g_weight_sum [B] (may be
+ * NULL), g_gradient_error [1] (may be NULL) -> g_params (accumulated), g_inv_s [1] (d/d inv_s; inv_s = exp(10 variance),
+ * utils/fields.py SingleVarianceNetwork; may be NULL), g_rays_o / g_rays_d [B,3] (in the field's frame; may be NULL),
+ * g_bt_inv [21,4,4] / g_T_pose [21,3] (hand; may be NULL).  rays are in the field's frame (obj: after
+ * hn_obj_local_fwd). */
+size_t hn_field_param_floats(const hn_field* f);
+int hn_field_param_offset(const hn_field* f, int net, int layer, size_t* w_off, size_t* b_off, int* out_dim, int* in_dim,
+                          int* ld);
+int hn_field_param_bwd(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray,
+                       const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf,
+                       const float* g_grad, const float* g_rgb, float* g_params, float* g_pts, float* g_rays_d,
+                       float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes, hn_stream_t stream);
+size_t hn_render_single_bwd_workspace_bytes(const hn_field* f, int n_rays, int samples_per_ray);
+int hn_render_single_bwd(const hn_field* f, const float* rays_o, const float* rays_d, int n_rays, int samples_per_ray,
+                         float sample_dist, const float* bt_inv, const float* T_pose, const float* z_vals,
+                         const float* g_color, const float* g_weight_sum, const float* g_gradient_error, float* g_params,
+                         float* g_inv_s, float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose,
+                         void* workspace, size_t workspace_bytes, hn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+GPU_TESTS = set()     # node ids of the tests that carry the gpu marker (the parity report covers exactly these)
 
 
 def pytest_configure(config):
@@ -26,6 +27,8 @@ def golden():
 def _release_device_temporaries(request):
     import helpers
     helpers.CURRENT_TEST[0] = request.node.nodeid
+    if request.node.get_closest_marker('gpu') is not None:
+        GPU_TESTS.add(request.node.nodeid)
     yield
     helpers._KEEP.clear()
 
@@ -35,7 +38,7 @@ def pytest_sessionfinish(session, exitstatus):
     tests ran (gpurun merges gpurun_out/ back; the copy that is judged is committed under profiles/rNN/)."""
     import json
     import helpers
-    rows = [r for r in helpers.REPORT if 'gpu' in r['test']]
+    rows = [r for r in helpers.REPORT if r['test'] in GPU_TESTS or 'gpu' in r['test']]
     if not rows:
         return
     out_dir = os.path.join(ROOT, 'gpurun_out')

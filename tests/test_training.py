@@ -1,0 +1,203 @@
+"""parameter gradients of a training iteration (exp_runner.py:196-229).
+
+CPU: the oracle's iteration (oracle/train.py) against the reference's own autograd (tests/golden/train_*.npz,
+tests/golden/make_golden_train.py).  GPU: the product path (honerf_amd.training over hn_render_single /
+hn_render_single_bwd) against the same fixtures, gradient by gradient.
+
+Measure: max |a - b| / max |b| per parameter tensor (the north star's "relative fp32").  The weight gradients are sums
+over ~5 000 samples of products of fp32 signals; the bounds below are <= 4x the errors observed on MI355X
+(profiles/r02/parity_report.json) and each is recorded there.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import SEEDS, VAR_HAND, VAR_OBJ, assert_close, record, rel_err, state_dicts, t
+
+
+def _golden_grads(g):
+    step = int(g['col_step'])
+    return {k: g[k] for k in (g.files if hasattr(g, 'files') else g) if k.startswith(('sdf.', 'color.', 'var.'))}, step
+
+
+def _compare(grads, g, bound_of, tag, floor=None, cap=2e-3):
+    """grads: {leaf name: tensor} -> compares every stored golden slice; returns the worst error."""
+    gold, step = _golden_grads(g)
+    worst = 0.0
+    for key, ref in sorted(gold.items()):
+        scale = None
+        if key.endswith('.cols'):
+            name = key[:-5]
+            got = grads[name][:, ::step]
+        elif key.endswith('.rowsum'):      # sums of signed terms: the error is measured against the sum of magnitudes
+            name = key[:-7]
+            got = grads[name].sum(dim=1)
+            scale = float(grads[name].abs().sum(dim=1).max())
+        elif key.endswith('.colsum'):
+            name = key[:-7]
+            got = grads[name].sum(dim=0)
+            scale = float(grads[name].abs().sum(dim=0).max())
+        else:
+            name = key
+            got = grads[name]
+        got = got.detach().cpu().double().numpy().reshape(ref.shape)
+        e = rel_err(got, ref) if scale is None else float(np.abs(got - ref).max() / max(scale, 1e-30))
+        b = bound_of(name) if floor is None else max(1e-4, min(cap, 4.0 * floor[key]))
+        record('%s %s' % (tag, key), e, b)
+        assert e <= b, '%s %s: rel err %.3e > %.1e' % (tag, key, e, b)
+        worst = max(worst, e)
+    return worst
+
+
+def _slices(grads, key, step):
+    """(value of the stored slice `key`, its magnitude scale or None) from full gradients."""
+    if key.endswith('.cols'):
+        return grads[key[:-5]][:, ::step], None
+    if key.endswith('.rowsum'):
+        return grads[key[:-7]].sum(dim=1), float(grads[key[:-7]].abs().sum(dim=1).max())
+    if key.endswith('.colsum'):
+        return grads[key[:-7]].sum(dim=0), float(grads[key[:-7]].abs().sum(dim=0).max())
+    return grads[key], None
+
+
+def reference_noise_floor(kind, g):
+    """How far the fp32 REFERENCE's own gradients (the fixture) are from the float64 evaluation of the same iteration
+    at the same depths: {stored slice: error}.  Same measure as _compare."""
+    from oracle.train import core_iteration, trainable_field
+    sd = state_dicts()
+    field, leaves = trainable_field(kind, sd['sdf_' + kind], sd['color_' + kind], VAR_OBJ if kind == 'obj' else VAR_HAND,
+                                    dtype=torch.float64)
+    kw = dict(Ro=g['Ro'], To=g['To']) if kind == 'obj' else dict(bt_inv=g['bt_inv'], T_pose=g['T_pose'])
+    sample_dist = float(np.float32((float(g['far']) - float(g['near'])) / int(g['n_samples'])))
+    _, _, grads = core_iteration(field, leaves, g['rays_o'], g['rays_d'], g['z_vals'], sample_dist, g['true_rgb'], g['true_mask'],
+                                 float(g['igr_weight']), float(g['mask_weight']), **kw)
+    gold, step = _golden_grads(g)
+    floor = {}
+    for key, ref in gold.items():
+        exact, scale = _slices(grads, key, step)
+        exact = exact.detach().numpy().reshape(ref.shape)
+        floor[key] = rel_err(ref, exact) if scale is None else float(np.abs(ref - exact).max() / max(scale, 1e-30))
+    return floor
+
+
+def _oracle_iteration(kind, g):
+    from oracle.train import trainable_field, train_iteration
+    sd = state_dicts()
+    field, leaves = trainable_field(kind, sd['sdf_' + kind], sd['color_' + kind], VAR_OBJ if kind == 'obj' else VAR_HAND)
+    kw = dict(Ro=t(g['Ro']), To=t(g['To'])) if kind == 'obj' else dict(bt_inv=t(g['bt_inv']), T_pose=t(g['T_pose']))
+    return train_iteration(field, leaves, t(g['rays_o']), t(g['rays_d']), float(g['near']), float(g['far']), t(g['t_rand']),
+                           int(g['n_samples']), int(g['n_importance']), t(g['true_rgb']), t(g['true_mask']),
+                           float(g['igr_weight']), float(g['mask_weight']), **kw)
+
+
+@pytest.mark.parametrize('kind', ['obj', 'hand'])
+def test_train_iteration_oracle_golden(golden, kind):
+    """Pins oracle/train.py: same torch CPU kernels as the reference in almost the same order."""
+    g = golden('train_' + kind)
+    out, terms, grads = _oracle_iteration(kind, g)
+    assert_close(out['z_vals'], g['z_vals'], 1e-6, 'train %s oracle z_vals' % kind)
+    for k in ('loss', 'color_fine_loss', 'mask_loss', 'eikonal_loss'):
+        assert_close(terms[k].reshape(()), g[k], 2e-5, 'train %s oracle %s' % (kind, k))
+    _compare(grads, g, lambda name: 2e-4, 'train %s oracle' % kind)
+
+
+def test_weight_norm_backward_matches_autograd():
+    """honerf_amd.training.weight_norm_backward against autograd through torch._weight_norm (the reference's
+    nn.utils.weight_norm, utils/fields.py:113-121)."""
+    from honerf_amd.training import weight_norm_backward
+    gen = torch.Generator().manual_seed(3)
+    v = torch.randn(17, 29, generator=gen, dtype=torch.float64, requires_grad=True)
+    gg = torch.randn(17, 1, generator=gen, dtype=torch.float64, requires_grad=True)
+    dW = torch.randn(17, 29, generator=gen, dtype=torch.float64)
+    W = torch._weight_norm(v, gg, 0)
+    dg_ref, dv_ref = torch.autograd.grad(W, [gg, v], dW)
+    dg, dv = weight_norm_backward(gg.detach(), v.detach(), dW)
+    assert rel_err(dg, dg_ref) < 1e-12 and rel_err(dv, dv_ref) < 1e-12
+
+
+# ---- GPU: the product path ---------------------------------------------------------------------------------------------
+def _product_iteration(kind, g, precision, at_golden_depths):
+    from honerf_amd import training
+    from honerf_amd.nets import (RenderingNetwork, RenderingNetwork_OBJ, SDFNetwork, SDFNetwork_OBJ, SingleVarianceNetwork)
+    from honerf_amd.renderer import NeuSRenderer
+    dev = torch.device('cuda:0')
+    if kind == 'obj':
+        sdf_net, col_net, var = SDFNetwork_OBJ().to(dev), RenderingNetwork_OBJ().to(dev), SingleVarianceNetwork(VAR_OBJ).to(dev)
+    else:
+        sdf_net, col_net, var = SDFNetwork().to(dev), RenderingNetwork(use_gradients=True).to(dev), SingleVarianceNetwork(VAR_HAND).to(dev)
+    sdf_net.reset_parameters(SEEDS['sdf_' + kind])
+    col_net.reset_parameters(SEEDS['color_' + kind])
+    ren = NeuSRenderer(sdf_net, var, col_net, kind, int(g['n_samples']), int(g['n_importance']), 0, 4, 1.0)
+    ren.precision = precision
+    c = lambda k: t(g[k]).to(dev)
+    if kind == 'obj':
+        bt = tp = None
+        Ro, To = c('Ro'), c('To')
+    else:
+        bt, tp = c('bt_inv'), c('T_pose')
+        Ro = To = None
+    out = training.render_train(ren, c('rays_o'), c('rays_d'), float(g['near']), float(g['far']), bt, tp, None, Ro, To,
+                                t_rand=c('t_rand'), z_vals=c('z_vals') if at_golden_depths else None)
+    terms = training.train_loss(out, c('true_rgb'), c('true_mask'), float(g['igr_weight']), float(g['mask_weight']))
+    terms['loss'].backward()
+    grads = {}
+    for prefix, net in (('sdf', sdf_net), ('color', col_net)):
+        for l, lin in enumerate(net.layers()):
+            for nm in ('weight_g', 'weight_v', 'bias'):
+                grads['%s.lin%d.%s' % (prefix, l, nm)] = getattr(lin, nm).grad
+    grads['var.variance'] = var.variance.grad
+    return ren, out, terms, grads
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
+@pytest.mark.parametrize('kind', ['obj', 'hand'])
+def test_train_iteration_product_golden(golden, kind, precision):
+    """One training iteration through honerf_amd.training against the reference's autograd: loss terms and the gradient
+    of every parameter tensor (weight_g, weight_v, bias of the 9 + 5 layers, variance)."""
+    g = golden('train_' + kind)
+    # (i) the whole iteration on the product's own depths: the importance samples are placed from f16x3 / fp32 SDF values,
+    # so depths (and with them the losses) agree to the whole-render tolerance of test_gpu_parity.py
+    ren, out, terms, _ = _product_iteration(kind, g, precision, False)
+    assert_close(ren.last_z_vals, g['z_vals'], 2e-3, 'train %s %s z_vals' % (kind, precision))
+    for k in ('loss', 'color_fine_loss', 'mask_loss', 'eikonal_loss'):
+        assert_close(terms[k].reshape(()), g[k], 2e-3, 'train %s %s %s (own depths)' % (kind, precision, k))
+    # (ii) render_core at the reference's depths: outputs, losses and every parameter gradient
+    ren, out, terms, grads = _product_iteration(kind, g, precision, True)
+    assert_close(out['color_fine'], g['color_fine'], 1e-4, 'train %s %s color_fine' % (kind, precision))
+    assert_close(out['weight_sum'], g['weight_sum'], 1e-4, 'train %s %s weight_sum' % (kind, precision))
+    for k in ('loss', 'color_fine_loss', 'mask_loss', 'eikonal_loss'):
+        assert_close(terms[k].reshape(()), g[k], 1e-4, 'train %s %s %s' % (kind, precision, k))
+    # Bound per stored slice: the north star's 1e-4, or -- where the fp32 reference itself is further than that from
+    # the float64 value of the same iteration (measured here, recorded in the parity report: up to 1e-3 (obj) / 1.9e-3
+    # (hand) on the colour network's layers, where a ReLU unit of one near-surface sample flipping moves a whole row) --
+    # 4x the reference's own distance, capped at 4x the largest error observed on MI355X (obj 9.1e-5, hand 4.6e-4).
+    floor = reference_noise_floor(kind, g)
+    for key, v in sorted(floor.items()):
+        record('train %s reference fp32 vs fp64 %s' % (kind, key), v, float('inf'), kind='noise floor')
+    _compare(grads, g, None, 'train %s %s' % (kind, precision), floor=floor, cap=4e-4 if kind == 'obj' else 1.9e-3)
+
+
+@pytest.mark.gpu
+def test_train_step_decreases_loss():
+    """A few Adam steps of honerf_amd.training.train_step on a fixed batch: the loss goes down and the packed field
+    follows the parameters (the renderer re-packs when Adam's in-place update bumps their versions)."""
+    from honerf_amd import training
+    g = np.load(__import__('os').path.join(__import__('os').path.dirname(__file__), 'golden', 'train_obj.npz'))
+    from honerf_amd.nets import RenderingNetwork_OBJ, SDFNetwork_OBJ, SingleVarianceNetwork
+    from honerf_amd.renderer import NeuSRenderer
+    dev = torch.device('cuda:0')
+    sdf_net, col_net, var = SDFNetwork_OBJ().to(dev), RenderingNetwork_OBJ().to(dev), SingleVarianceNetwork(VAR_OBJ).to(dev)
+    sdf_net.reset_parameters(SEEDS['sdf_obj'])
+    col_net.reset_parameters(SEEDS['color_obj'])
+    ren = NeuSRenderer(sdf_net, var, col_net, 'obj', 64, 64, 0, 4, 1.0)
+    opt = torch.optim.Adam(training.trainable_parameters(ren), lr=5e-4)
+    c = lambda k: t(g[k]).to(dev)
+    losses = []
+    for _ in range(6):
+        terms = training.train_step(ren, opt, c('rays_o'), c('rays_d'), 0.4, 1.5, None, None, c('Ro'), c('To'), c('true_rgb'),
+                                    c('true_mask'), 1.0, 1.0, t_rand=c('t_rand'))
+        losses.append(float(terms['loss'].detach()))
+    record('train_step loss first', losses[0], float('inf'), kind='value')
+    record('train_step loss last', losses[-1], losses[0], kind='value')
+    assert losses[-1] < losses[0], losses
