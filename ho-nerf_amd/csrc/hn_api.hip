@@ -2,6 +2,7 @@
 // whole renders.  Nothing here allocates or synchronises (except field create/destroy).
 #include <stdarg.h>
 #include <atomic>
+#include <functional>
 #include <string.h>
 
 #include "hn_common.h"
@@ -225,7 +226,7 @@ static int field_sdf(const hn_field* f, const float* pts, int n, const float* bt
 }
 // bytes of the tape a taped evaluation of n_pts points keeps for its adjoint (0: this field keeps none)
 static size_t field_tape(const hn_field* f, int n_pts) {
-    if (f->precision != HN_PREC_F16X3) return 0;
+    if (f->precision != HN_PREC_F16X3 || f->v2_adjonly == nullptr) return 0;
     return f->kind == HN_FIELD_OBJ ? v2::field2_obj_tape_bytes(n_pts) : v2::field2_hand_tape_bytes(n_pts);
 }
 static int field_eval(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt,
@@ -456,12 +457,13 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
 }
 
 namespace bwd {
+typedef std::function<int(const float* z8, const float* grad, const float* rgb_pre)> MidHook;
 size_t field_bwd_workspace_bytes(const hn_field* f, int n);
 int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
                    size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb,
-                   float* g_params = nullptr);
+                   float* g_params = nullptr, const MidHook* mid = nullptr);
 }
 
 // Backward pass of the two-field render (what loss.backward() runs through NeuSRenderer_fitting.render in the fitting
@@ -539,6 +541,16 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     return HN_OK;
 }
 
+// sdf = z8[:, 0] / scale, rgb = sigmoid(pre) from the adjoint's forward tape
+__global__ void k_tape_outputs(const float* __restrict__ z8, const float* __restrict__ pre, float inv_scale, int n,
+                               float* __restrict__ sdf, float* __restrict__ rgb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sdf[i] = z8[(size_t)i * 257] * inv_scale;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[3 * (size_t)i + c] = 1.f / (1.f + expf(-pre[3 * (size_t)i + c]));
+}
+
 // Backward pass of the single-field render into the field's PARAMETERS (what loss.backward() runs through
 // NeuSRenderer.render in exp_runner.train, exp_runner.py:208-242) and into the rays / pose inputs.  The
 // depths carry no gradient (utils/renderer.py:215 no_grad), so it runs through render_core at the depths z the
@@ -572,25 +584,32 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
     HN_REQUIRE(!hand || (bt_inv && T_pose), "hand field needs bt_inv / T_pose");
     const int n = (int)N;
     HN_TRY(sample_points(rays_o, rays_d, z, n_rays, S, 1, sample_dist, pts, dists, s));
-    HN_TRY(field_eval(f, pts, rays_d, n, S, bt_inv, T_pose, 1, n, sdf, grad, rgb, nullptr, fws, fws_bytes, s));
-    HN_TRY(alpha(sdf, grad, rays_d, dists, n, S, f->inv_s, al, c, s));
-    HN_TRY(composite1_bwd(al, c, rgb, g_color, g_wsum, n_rays, S, g_al, g_c, g_rgb, s));
-    HN_TRY(alpha_bwd(sdf, grad, rays_d, dists, g_al, g_c, n, S, f->inv_s, gs, gg, gd, s));
-    if (g_inv_s != nullptr) {
-        HN_CHECK_HIP(hipMemsetAsync(g_inv_s, 0, sizeof(float), s));
-        HN_TRY(alpha_inv_s_bwd(sdf, grad, rays_d, dists, g_al, g_c, n, S, f->inv_s, g_inv_s, s));
-    }
-    hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs, gg, (const float*)nullptr, (const float*)nullptr, grad, g_eik, n);
+    (void)fws;
+    // The field is NOT evaluated again: the adjoint's own forward tape (exact fp32) supplies sdf / gradient / colour;
+    // the alpha stage, the compositing and their adjoints run in the hook, between the tape and the sweeps.
+    const bwd::MidHook mid = [&](const float* z8, const float* g_field, const float* rgb_pre) -> int {
+        hipLaunchKernelGGL(k_tape_outputs, dim3((n + 255) / 256), dim3(256), 0, s, z8, rgb_pre, 1.f / f->scale, n, sdf, rgb);
+        HN_TRY(alpha(sdf, g_field, rays_d, dists, n, S, f->inv_s, al, c, s));
+        HN_TRY(composite1_bwd(al, c, rgb, g_color, g_wsum, n_rays, S, g_al, g_c, g_rgb, s));
+        HN_TRY(alpha_bwd(sdf, g_field, rays_d, dists, g_al, g_c, n, S, f->inv_s, gs, gg, gd, s));
+        if (g_inv_s != nullptr) {
+            HN_CHECK_HIP(hipMemsetAsync(g_inv_s, 0, sizeof(float), s));
+            HN_TRY(alpha_inv_s_bwd(sdf, g_field, rays_d, dists, g_al, g_c, n, S, f->inv_s, g_inv_s, s));
+        }
+        hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs, gg, (const float*)nullptr, (const float*)nullptr, g_field,
+                           g_eik, n);
+        return HN_OK;
+    };
     float *gbt = g_bt_inv, *gtp = g_T_pose;
     if (hand) {   // the adjoint accumulates the pose gradients: into the caller's arrays when given, else into scratch
-        if (gbt == nullptr) gbt = g_al;            // 336 floats of a finished array
-        if (gtp == nullptr) gtp = g_c;
-        HN_REQUIRE(N >= 336, "too few samples");
+        HN_REQUIRE(N >= 256, "too few samples");
+        if (gbt == nullptr) gbt = grad;            // `grad` is free on this path (the tape's own gradient array is used)
+        if (gtp == nullptr) gtp = grad + 512;
         HN_CHECK_HIP(hipMemsetAsync(gbt, 0, 21 * 16 * sizeof(float), s));
         HN_CHECK_HIP(hipMemsetAsync(gtp, 0, 21 * 3 * sizeof(float), s));
     }
     HN_TRY(bwd::field_eval_bwd(f, pts, rays_d, n, S, bt_inv, T_pose, 1, n, gs, gg, g_rgb, gp, gdir, gbt, gtp, bws, bws_bytes, s, nullptr,
-                               nullptr, nullptr, g_params));
+                               nullptr, nullptr, g_params, &mid));
     HN_TRY(sample_points_bwd(z, gp, n_rays, S, 1, sample_dist, go, gdd, s));
     if (g_rays_o != nullptr) HN_CHECK_HIP(hipMemcpyAsync(g_rays_o, go, R3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (g_rays_d != nullptr)

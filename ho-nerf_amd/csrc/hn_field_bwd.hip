@@ -13,6 +13,7 @@
 //     second-order terms.
 // This first version favours being checkable step by step over speed: the fitting configurations evaluate ~4e4 samples
 // per step, where the whole adjoint is a few milliseconds.
+#include <functional>
 #include <type_traits>
 
 #include "hn_common.h"
@@ -157,9 +158,10 @@ __global__ __launch_bounds__(256) void k_dense(const DenseArgs a) {
 
 // ---- parameter gradients (`loss.backward()` into the networks, exp_runner.py:208-242) ---------------
 // dW[m, k] += alpha * sum_i A[i, m] B[i, k]  (i < n): the outer products of a layer's adjoint signal with its input,
-// reduced over the samples.  Workgroup = 64 x 64 tile of dW over one slice of the samples (grid z), 4 waves as 2 x 2
-// MFMA tiles (v_mfma_f32_32x32x2_f32: the sample index is the MFMA's k), operands staged through LDS 32 samples at a
-// time, partial tiles added with atomics (the caller zeroes dW).  With db != NULL the column K of B is taken as the
+// reduced over the samples.  Workgroup = 128 x 128 tile of dW over one slice of the samples (grid z), 4 waves as 2 x 2
+// quadrants of 2 x 2 MFMA tiles (v_mfma_f32_32x32x2_f32: the sample index is the MFMA's k; 4 MFMAs per 4 LDS reads),
+// operands staged through LDS 32 samples at a time with row-contiguous (coalesced) global reads, the next step's reads
+// issued before the barrier; partial tiles added with atomics (the caller zeroes dW).  With db != NULL the column K of B is taken as the
 // constant 1: dW's column K is the bias gradient db[m] += alpha_b * sum_i A[i, m].
 struct OuterArgs {
     const float* A;
@@ -173,46 +175,74 @@ struct OuterArgs {
     int n, chunk;
 };
 __global__ __launch_bounds__(256) void k_outer(const OuterArgs a) {
-    __shared__ float As[32][65];
-    __shared__ float Bs[32][65];
+    constexpr int T = 128;                         // workgroup tile of dW: T x T, one 64 x 64 quadrant per wave
+    __shared__ float As[32][T + 1];
+    __shared__ float Bs[32][T + 1];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, j = lane & 31;
-    const int m0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * T, k0 = blockIdx.x * T;
     const int KB = a.db != nullptr ? a.K + 1 : a.K;
     const int i_begin = blockIdx.z * a.chunk;
     const int i_end = min(a.n, i_begin + a.chunk);
-    f32x16 acc;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int si = t >> 3, c8 = (t & 7) * 8;       // thread = (sample of the step, 8 consecutive columns)
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    // staging: thread = (column of the tile, samples s0, s0 + 2, ...): a wave reads 64 consecutive floats of a row
+    const int col = t & (T - 1), s0 = t >> 7;
+    const bool a_col = m0 + col < a.M;
+    const int kc = k0 + col;
+    const int b_kind = kc < a.K ? 0 : kc < KB ? 1 : 2;     // 0: column of B, 1: the constant 1 (bias gradient), 2: padding
+    const float* pa = a.A + m0 + col;
+    const float* pb = a.B + kc;
     for (int i0 = i_begin; i0 < i_end; i0 += 32) {
-        const int i = i0 + si;
-        const bool live = i < i_end;
-        const float* pa = a.A + (size_t)i * a.lda + m0 + c8;
-        const float* pb = a.B + (size_t)i * a.ldb + k0 + c8;
+        float va[16], vb[16];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            As[si][c8 + e] = (live && m0 + c8 + e < a.M) ? pa[e] : 0.f;
-            const int col = k0 + c8 + e;
-            Bs[si][c8 + e] = !live ? 0.f : col < a.K ? pb[e] : col < KB ? 1.f : 0.f;
+        for (int e = 0; e < 16; ++e) {
+            const int i = i0 + s0 + 2 * e;
+            const bool live = i < i_end;
+            va[e] = (live && a_col) ? pa[(size_t)i * a.lda] : 0.f;
+            vb[e] = !live ? 0.f : b_kind == 0 ? pb[(size_t)i * a.ldb] : b_kind == 1 ? 1.f : 0.f;
+        }
+        __syncthreads();                           // the previous step's MFMAs have read the tiles
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            As[s0 + 2 * e][col] = va[e];
+            Bs[s0 + 2 * e][col] = vb[e];
         }
         __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * ks + h][wr * 32 + j], Bs[2 * ks + h][wc * 32 + j], acc, 0, 0, 0);
-        __syncthreads();
+        for (int ks = 0; ks < 16; ++ks) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) av[x] = As[2 * ks + h][wr * 64 + x * 32 + j];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) bv[y] = Bs[2 * ks + h][wc * 64 + y * 32 + j];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+        }
     }
-    const int col = k0 + wc * 32 + j;
-    if (col >= KB) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < a.M) {
-            if (col < a.K)
-                atomicAdd(a.dW + (size_t)m * a.ldw + col, a.alpha * acc[r]);
-            else
-                atomicAdd(a.db + m, a.alpha_b * acc[r]);
-        }
+    for (int y = 0; y < 2; ++y) {
+        const int c = k0 + wc * 64 + y * 32 + j;
+        if (c >= KB) continue;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < a.M) {
+                    if (c < a.K)
+                        atomicAdd(a.dW + (size_t)m * a.ldw + c, a.alpha * acc[x][y][r]);
+                    else
+                        atomicAdd(a.db + m, a.alpha_b * acc[x][y][r]);
+                }
+            }
     }
 }
 // out[c] += scale * sum_i x[i, c]   (c < width <= 256; the gradient of the row W_8[0, :] that seeds the reverse sweep)
@@ -678,9 +708,9 @@ struct Ctx {
     // dW[M, K] += alpha * A^T B over the samples (+ db[M] += sum A when db != NULL)
     void outer(const float* A, int lda, int M, const float* B, int ldb, int K, float alpha, float* dW, int ldw, float* db) const {
         const int KB = db != nullptr ? K + 1 : K;
-        const int tiles = ((M + 63) / 64) * ((KB + 63) / 64);
-        // enough sample slices to fill the chip a few times over, each at least 256 samples long
-        int slices = (2048 + tiles - 1) / tiles;
+        const int tiles = ((M + 127) / 128) * ((KB + 127) / 128);
+        // ~1024 workgroups (two per CU, twice over), a slice at least 256 samples long
+        int slices = (1024 + tiles - 1) / tiles;
         const int max_slices = (n + 255) / 256;
         if (slices > max_slices) slices = max_slices;
         if (slices < 1) slices = 1;
@@ -688,7 +718,7 @@ struct Ctx {
         chunk = (chunk + 31) & ~31;
         slices = (n + chunk - 1) / chunk;
         OuterArgs a{A, lda, M, B, ldb, K, dW, ldw, db, alpha, 1.f, n, chunk};
-        hipLaunchKernelGGL(k_outer, dim3((KB + 63) / 64, (M + 63) / 64, slices), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_outer, dim3((KB + 127) / 128, (M + 127) / 128, slices), dim3(256), 0, s, a);
     }
 };
 
@@ -746,12 +776,19 @@ size_t field_bwd_workspace_bytes(const hn_field* f, int n) {
     return need;
 }
 
+// mid (with g_params only): called once the forward tape stands (z8 [n,257]: column 0 = sdf * scale, then the feature
+// vector; d sdf / d pts [n,3]; the colour network's pre-sigmoid output [n,3]) and before any upstream gradient is read:
+// the caller derives g_sdf / g_grad / g_rgb from these values there (hn_render_single_bwd: alpha stage and compositing
+// and their adjoints), so a training step's backward pass does not evaluate the field a second time.
+typedef std::function<int(const float* z8, const float* grad, const float* rgb_pre)> MidHook;
+
 // tape / grad / rgb (HN_PREC_F16X3 only, may be NULL): the tape a taped evaluation of the same points left and that
 // evaluation's outputs -- the adjoint then runs alone instead of re-evaluating the field first
 int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
-                   size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb, float* g_params) {
+                   size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb, float* g_params,
+                   const MidHook* mid) {
     HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");
     const bool obj = f->kind == HN_FIELD_OBJ;
     HN_REQUIRE(obj || (bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1),
@@ -762,6 +799,7 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     HN_REQUIRE(pts && g_sdf && g_pts && (sdf_only || (g_grad && g_rgb)) && spr >= 1 && n % spr == 0, "bad arguments");
     if (n == 0) return HN_OK;
     HN_REQUIRE(g_params == nullptr || !sdf_only, "parameter gradients need g_grad and g_rgb");
+    HN_REQUIRE(mid == nullptr || g_params != nullptr, "the mid hook belongs to the parameter-gradient path");
     // g_params: gradients w.r.t. the folded weights / biases in the layout of f->raw (hn_field_param_offset), accumulated.
     // They are formed by the launch sequence below for either precision (the fused kernels keep no per-layer arrays).
     if (g_params == nullptr && fused_adjoint(f, sdf_only)) {
@@ -866,6 +904,11 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
         hipLaunchKernelGGL(k_relu, g1((N * H + 3) / 4), dim3(256), 0, s, b.c[l + 1], N * H);
     }
     cx.nt(b.c[4], H, H, C[4], H, 0, 3, Cb[4], 1.f, b.xb, 3, false);
+    if (mid != nullptr) {
+        HN_LAUNCH_CHECK();
+        const int rc = (*mid)(b.z8, b.g, b.xb);
+        if (rc != HN_OK) return rc;
+    }
     hipLaunchKernelGGL(k_rgb_seed, g1(N * 3), dim3(256), 0, s, b.xb, g_rgb, b.xb, N * 3);
     if (gp) cx.outer(b.xb, 3, 3, b.c[4], H, H, 1.f, G(C[4]), f->col_ld[4], G(Cb[4]));
     cx.nn(b.xb, 3, 3, C[4], H, 0, H, 1.f, b.cb[0], H, false);

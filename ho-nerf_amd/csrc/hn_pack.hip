@@ -302,13 +302,17 @@ static int build(hn_field* f, Packer& pk, const hn_mlp_desc* sdf, const hn_mlp_d
 
 namespace v2 {
 int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float* const* w_sdf,
-                     float* const* w_col, hipStream_t stream);
+                     float* const* w_col, hipStream_t stream, bool eval_only);
 }
 
 int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float variance, float scale, int precision,
                  hn_field** out, hipStream_t stream) {
     HN_REQUIRE(out != nullptr && sdf != nullptr && col != nullptr, "null argument");
     HN_REQUIRE(kind == HN_FIELD_OBJ || kind == HN_FIELD_HAND, "unknown field kind %d", kind);
+    // HN_PACK_EVAL_ONLY: no adjoint weight streams (training re-packs every step and differentiates through
+    // hn_field_param_bwd, which works on the retained row-major matrices)
+    const bool eval_only = (precision & HN_PACK_EVAL_ONLY) != 0;
+    precision &= ~HN_PACK_EVAL_ONLY;
     HN_REQUIRE(precision == HN_PREC_FP32 || precision == HN_PREC_F16X3, "unsupported precision %d", precision);
     int rc = check_shapes(kind, sdf, col);
     if (rc != HN_OK) return rc;
@@ -418,7 +422,7 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
             }
         }
     }
-    if (rc == HN_OK && precision == HN_PREC_F16X3) rc = v2::build_v2_streams(f, sdf, col, w_sdf, w_col, stream);
+    if (rc == HN_OK && precision == HN_PREC_F16X3) rc = v2::build_v2_streams(f, sdf, col, w_sdf, w_col, stream, eval_only);
     pk.free_temps();
     if (rc != HN_OK) {
         if (f->v2_full) (void)hipFree(f->v2_full);

@@ -342,7 +342,7 @@ void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, int mode)
 
 // w_sdf / w_col: device pointers to the folded matrices (row-major [out][in])
 int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float* const* w_sdf,
-                     float* const* w_col, hipStream_t stream) {
+                     float* const* w_col, hipStream_t stream, bool eval_only) {
     HostMat S[9], C[5];
     auto fetch = [&](const hn_mlp_desc* d, int l, float* dev_w, HostMat& M) -> int {
         M.rows = d->out_dim[l];
@@ -366,6 +366,7 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
     // adjoint kernels' MFMA shape, built only where the evaluation kernels use the other one
     const bool eval16 = f->kind == HN_FIELD_OBJ ? (HN_OBJ_EVAL_MFMA16 != 0) : (HN_HAND_EVAL_MFMA16 != 0);
     for (int mode = 0; mode < (eval16 ? 5 : 4); ++mode) {
+        if (eval_only && mode >= 2) break;   // sdf-only and evaluation programs only (HN_PACK_EVAL_ONLY)
         Builder B;
         g_s16 = eval16 && mode < 2;
         const int prog = mode == 4 ? 1 : mode;

@@ -292,7 +292,7 @@ class PackedField:
     state dicts in the reference layout; `variance` a SingleVarianceNetwork, a
     tensor or a float."""
 
-    def __init__(self, kind, sdf, color, variance, scale=None, precision=None):
+    def __init__(self, kind, sdf, color, variance, scale=None, precision=None, eval_only=False):
         self.lib = _lib.load()
         self.kind = kind
         precision = precision or _lib.DEFAULT_PRECISION
@@ -308,7 +308,8 @@ class PackedField:
         handle = ctypes.c_void_p()
         torch.cuda.synchronize()
         rc = self.lib.hn_field_create(_lib.HN_FIELD_OBJ if kind == 'obj' else _lib.HN_FIELD_HAND,
-                                      ctypes.byref(d_sdf), ctypes.byref(d_col), var, float(scale), _lib.PRECISIONS[precision],
+                                      ctypes.byref(d_sdf), ctypes.byref(d_col), var, float(scale),
+                                      _lib.PRECISIONS[precision] | (_lib.HN_PACK_EVAL_ONLY if eval_only else 0),
                                       ctypes.byref(handle), _lib.stream_ptr())
         _lib.check(rc, 'hn_field_create')
         del keep

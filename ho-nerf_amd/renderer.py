@@ -147,10 +147,11 @@ class NeuSRenderer:
     # the renderer keeps references to the modules (utils/renderer.py:50-52); the packed copy is
     # rebuilt lazily whenever their parameters change (checkpoints are loaded after construction)
     def field(self):
-        ver = params_version(self.sdf_network, self.color_network, self.deviation_network) + (self.precision,)
+        eval_only = bool(getattr(self, 'pack_eval_only', False))      # set by training.render_train
+        ver = params_version(self.sdf_network, self.color_network, self.deviation_network) + (self.precision, eval_only)
         if self._field is None or ver != self._version:
             self._field = PackedField(self.model_type, self.sdf_network, self.color_network, self.deviation_network,
-                                      precision=self.precision)
+                                      precision=self.precision, eval_only=eval_only)
             self._version = ver
         return self._field
 

@@ -191,6 +191,7 @@ def render_train(renderer, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, 
     if not hasattr(renderer, '_ws_train'):
         renderer._ws_train = _Workspace()
     renderer.index = index
+    renderer.pack_eval_only = True     # the per-step re-pack builds the evaluation programs only (HN_PACK_EVAL_ONLY)
     dev = rays_o.device
     if renderer.model_type == 'obj':
         rays_o, rays_d = ObjLocalFn.apply(rays_o, rays_d, torch.as_tensor(Ro, device=dev), torch.as_tensor(To, device=dev))

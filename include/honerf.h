@@ -41,6 +41,11 @@ extern "C" {
 #define HN_PREC_FP32 0   /* exact fp32: v_mfma_f32_32x32x2_f32 == fmaf chains */
 #define HN_PREC_F16X3 1  /* fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16 per product, fp32
                           * accumulate: fp32-equivalent results (22-bit operands) at 16/3 x the rate */
+/* OR-ed into `precision` at hn_field_create: pack the evaluation programs only, no adjoint weight streams.  For fields
+ * that are re-packed every optimiser step (training, honerf_amd/training.py): their backward pass is
+ * hn_field_param_bwd / hn_render_single_bwd, which work on the retained row-major matrices; hn_field_eval_bwd and
+ * hn_render_dual_bwd still work on such a field (launch sequence instead of the fused adjoint kernels). */
+#define HN_PACK_EVAL_ONLY 0x100
 
 #define HN_MAX_LAYERS 9
 #define HN_N_BONES 21

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Times one iteration of exp_runner.train's inner loop on the native path (honerf_amd.training.train_step):
+the reference's training batch (confs/wmask_realhand_hand1.conf: batch_size 441 rays = a 21 x 21 patch, 64 + 64 samples),
+random-init networks of the conf shape, synthetic rays / targets.  Prints one JSON line per field kind with the step time
+and its parts (render forward, backward incl. the parameter gradients, re-pack of the updated weights, optimiser)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build(kind, dev):
+    from honerf_amd import synth
+    from honerf_amd.nets import (RenderingNetwork, RenderingNetwork_OBJ, SDFNetwork, SDFNetwork_OBJ, SingleVarianceNetwork)
+    from honerf_amd.renderer import NeuSRenderer
+    if kind == 'obj':
+        sdf, col = SDFNetwork_OBJ().to(dev), RenderingNetwork_OBJ().to(dev)
+    else:
+        sdf, col = SDFNetwork().to(dev), RenderingNetwork(use_gradients=True).to(dev)
+    var = SingleVarianceNetwork(0.3).to(dev)
+    sdf.reset_parameters(21 if kind == 'hand' else 11)
+    col.reset_parameters(22 if kind == 'hand' else 12)
+    ren = NeuSRenderer(sdf, var, col, kind, 64, 64, 0, 4, 1.0)
+    return ren, synth
+
+
+def rays(kind, synth, n, dev, seed=3):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    rng = np.random.RandomState(seed)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    from honerf_amd import lib as L
+    lib = L.load()
+    if kind == 'hand':
+        bt_inv, T_pose, joints = synth.synth_hand_pose(9)
+        cam = synth.front_camera(dist=0.0, focal=2.0)
+        tgt = joints[rng.randint(0, 21, size=n)] + 0.012 * rng.standard_normal((n, 3))
+        xy = np.stack([tgt[:, 0] / tgt[:, 2] * 2.0, tgt[:, 1] / tgt[:, 2] * 2.0], -1).astype(np.float32)
+        extra = dict(bt_inv=t(bt_inv), T_pose=t(T_pose), Ro=None, To=None)
+    else:
+        cam = synth.front_camera(dist=1.0, focal=2.0)
+        xy = (rng.rand(n, 2).astype(np.float32) - 0.5) * 1.2
+        R_obj, t_obj = synth.synth_obj_pose(2, center=(0.02, -0.01, 0.0))
+        extra = dict(bt_inv=None, T_pose=None, Ro=t(R_obj.T.copy()), To=t(t_obj))
+    o, d = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+    c = {k: t(v) for k, v in cam.items()}
+    L.check(lib.hn_ray_gen(L.ptr(t(xy)), L.ptr(c['R']), L.ptr(c['T']), L.ptr(c['focal']), L.ptr(c['principal']), 1, n, L.ptr(o), L.ptr(d),
+                           L.stream_ptr()), 'hn_ray_gen')
+    return o, d, extra
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rays', type=int, default=441)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--kinds', default='obj,hand')
+    ap.add_argument('--out', default=None)
+    ap.add_argument('--precision', default='f16x3')
+    a = ap.parse_args()
+    from honerf_amd import training
+    dev = torch.device('cuda:0')
+    lines = []
+    for kind in a.kinds.split(','):
+        ren, synth = build(kind, dev)
+        ren.precision = a.precision
+        ren.pack_eval_only = True
+        o, d, ex = rays(kind, synth, a.rays, dev)
+        g = torch.Generator(device='cpu').manual_seed(5)
+        true_rgb = torch.rand(a.rays, 3, generator=g).to(dev)
+        true_mask = (torch.rand(a.rays, 1, generator=g) > 0.3).float().to(dev)
+        params = training.trainable_parameters(ren)
+        opt = torch.optim.Adam(params, lr=1e-4)          # exp_runner.py:97-104, confs learning_rate = 1e-4
+
+        def step(parts=None):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            ev[0].record()
+            ren.field()                                   # re-pack of the weights the previous step updated
+            ev[1].record()
+            out = training.render_train(ren, o, d, 0.4, 1.5, ex['bt_inv'], ex['T_pose'], None, ex['Ro'], ex['To'])
+            terms = training.train_loss(out, true_rgb, true_mask, 1.0, 1.0)
+            ev[2].record()
+            opt.zero_grad(set_to_none=True)
+            terms['loss'].backward()
+            ev[3].record()
+            opt.step()
+            ev[4].record()
+            if parts is not None:
+                torch.cuda.synchronize()
+                for i, k in enumerate(('repack', 'forward', 'backward', 'optimizer')):
+                    parts[k] = parts.get(k, 0.0) + ev[i].elapsed_time(ev[i + 1])
+            return terms
+
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            terms = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / a.steps
+        parts = {}
+        for _ in range(a.steps):
+            step(parts)
+        S = 128
+        line = {'workload': 'exp_runner.train iteration, %s nets, %d rays x (64+64) samples' % (kind, a.rays), 'ms_per_step': round(ms, 3),
+                'ray_samples_per_s': round(a.rays * S / ms * 1e3), 'parts_ms': {k: round(v / a.steps, 3) for k, v in parts.items()},
+                'loss': float(terms['loss'].detach()), 'precision': a.precision}
+        print(json.dumps(line))
+        lines.append(line)
+    if a.out:
+        with open(a.out, 'w') as f:
+            json.dump(lines, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
