@@ -456,6 +456,8 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     return HN_OK;
 }
 
+hipError_t pool_alloc(void** p, size_t bytes);   // hn_pack.hip
+void pool_free(void* p);
 namespace bwd {
 typedef std::function<int(const float* z8, const float* grad, const float* rgb_pre)> MidHook;
 size_t field_bwd_workspace_bytes(const hn_field* f, int n);
@@ -681,13 +683,13 @@ int hn_field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* color, 
 }
 int hn_field_destroy(hn_field* f) {
     if (f == nullptr) return HN_OK;
-    if (f->blob != nullptr) (void)hipFree(f->blob);
-    if (f->v2_full != nullptr) (void)hipFree(f->v2_full);
-    if (f->v2_sdf != nullptr) (void)hipFree(f->v2_sdf);
-    if (f->v2_adj != nullptr) (void)hipFree(f->v2_adj);
-    if (f->v2_adjonly != nullptr) (void)hipFree(f->v2_adjonly);
-    if (f->v2_tape != nullptr) (void)hipFree(f->v2_tape);
-    if (f->raw != nullptr) (void)hipFree(f->raw);
+    if (f->blob != nullptr) pool_free(f->blob);
+    if (f->v2_full != nullptr) pool_free(f->v2_full);
+    if (f->v2_sdf != nullptr) pool_free(f->v2_sdf);
+    if (f->v2_adj != nullptr) pool_free(f->v2_adj);
+    if (f->v2_adjonly != nullptr) pool_free(f->v2_adjonly);
+    if (f->v2_tape != nullptr) pool_free(f->v2_tape);
+    if (f->raw != nullptr) pool_free(f->raw);
     delete f;
     return HN_OK;
 }

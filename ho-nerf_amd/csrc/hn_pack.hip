@@ -4,11 +4,66 @@
 // A-fragment order (hn_mlp.h): float4 [out_tile][step/4][lane], where the fragment of
 // lane l for k-step s is  scale * W[rowmap[32 t + (l&31)]][colmap[2 s + (l>>5)]].
 // Row maps and column maps describe our own orderings of neurons / input columns; -1 = pad.
+#include <chrono>
+#include <map>
+#include <mutex>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "hn_common.h"
 
 namespace hn {
+
+// ---- device memory of packed fields: a size-keyed cache in front of hipMalloc / hipFree -------------------------------
+// A training loop re-packs its field after every optimiser step (honerf_amd/training.py): ~70 allocations and as many
+// frees per pack.  hipFree synchronises the device and both calls cost from tens of microseconds to several
+// milliseconds depending on the state of the driver's pools (measured: 3 - 36 ms per re-pack of a hand field with the
+// same code, profiles/r02/README.md "training step").  Freed blocks are therefore kept, keyed by (device, size), and
+// handed out again: after the first two packs a re-pack allocates nothing.  The cache only ever holds what fields of
+// this process have released; hn_field_destroy's contract is unchanged (no work that uses the field may be in flight).
+namespace {
+struct PoolKey {
+    int dev;
+    size_t bytes;
+    bool operator<(const PoolKey& o) const { return dev != o.dev ? dev < o.dev : bytes < o.bytes; }
+};
+std::mutex g_pool_mu;
+std::multimap<PoolKey, void*> g_pool_free;
+std::map<void*, PoolKey> g_pool_live;
+}  // namespace
+hipError_t pool_alloc(void** p, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bytes = (bytes + 255) & ~size_t(255);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_free.find(PoolKey{dev, bytes});
+        if (it != g_pool_free.end()) {
+            *p = it->second;
+            g_pool_free.erase(it);
+            g_pool_live[*p] = PoolKey{dev, bytes};
+            return hipSuccess;
+        }
+    }
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_pool_live[*p] = PoolKey{dev, bytes};
+    }
+    return e;
+}
+void pool_free(void* p) {
+    if (p == nullptr) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_live.find(p);
+    if (it == g_pool_live.end()) {   // not ours: straight to the driver
+        (void)hipFree(p);
+        return;
+    }
+    g_pool_free.insert({it->second, p});
+    g_pool_live.erase(it);
+}
 
 // effective weight of one layer, row-major [out][in]
 __global__ void k_fold_weight_norm(const float* __restrict__ g, const float* __restrict__ v, int out, int in,
@@ -149,15 +204,28 @@ struct Packer {
         used += bytes;
         return p;
     }
+    // Row / column maps of a packed matrix depend on the field kind only, not on the weights: uploaded once per
+    // (device, content) and kept for the life of the process (a few hundred KiB), so that a re-pack issues no
+    // host-to-device copies of its own here (~60 small pageable copies per pack, each a blocking staged transfer).
     int* upload(const std::vector<int>& v) {
+        static std::mutex mu;
+        static std::map<std::pair<int, std::vector<int>>, int*> cache;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find({dev, v});
+        if (it != cache.end()) return it->second;
         int* d = nullptr;
         if (hipMalloc(&d, v.size() * sizeof(int)) != hipSuccess) {
             status = HN_ENOMEM;
             return nullptr;
         }
-        temps.push_back(d);
-        if (hipMemcpyAsync(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess)
+        if (hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
             status = HN_EHIP;
+            (void)hipFree(d);
+            return nullptr;
+        }
+        cache[{dev, v}] = d;
         return d;
     }
     PackedMat mat(const float* w_eff, int src_cols, bool transposed, const std::vector<int>& rowmap,
@@ -186,7 +254,7 @@ struct Packer {
         return dst;
     }
     void free_temps() {
-        for (void* p : temps) (void)hipFree(p);
+        for (void* p : temps) pool_free(p);
         temps.clear();
     }
 };
@@ -305,6 +373,13 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
                      float* const* w_col, hipStream_t stream, bool eval_only);
 }
 
+__global__ void k_copy_rows(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst, int ld) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[(size_t)r * ld + c] = src[i];
+}
+
 int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float variance, float scale, int precision,
                  hn_field** out, hipStream_t stream) {
     HN_REQUIRE(out != nullptr && sdf != nullptr && col != nullptr, "null argument");
@@ -317,6 +392,14 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
     int rc = check_shapes(kind, sdf, col);
     if (rc != HN_OK) return rc;
 
+    const bool timing = getenv("HN_PACK_TIMING") != nullptr;     // stage times of a pack on stderr (not a launch path)
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) {
+        if (!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hn pack] %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     hn_field* f = new hn_field();
     f->kind = kind;
     f->precision = precision;
@@ -333,7 +416,7 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
     float* w_col[5] = {};
     auto fold = [&](const hn_mlp_desc* d, int l, float** dst) -> int {
         const size_t n = (size_t)d->out_dim[l] * d->in_dim[l];
-        HN_CHECK_HIP(hipMalloc(dst, n * sizeof(float)));
+        HN_CHECK_HIP(pool_alloc(reinterpret_cast<void**>(dst), n * sizeof(float)));
         pk.temps.push_back(*dst);
         hipLaunchKernelGGL(k_fold_weight_norm, dim3(d->out_dim[l]), dim3(256), 0, stream, d->weight_g[l], d->weight_v[l],
                            d->out_dim[l], d->in_dim[l], *dst);
@@ -351,12 +434,13 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
             rc = HN_EHIP;
         }
     }
+    stage("fold + last-layer biases to host");
     if (rc == HN_OK) {
         pk.dry = true;
         pk.used = 0;
         build(f, pk, sdf, col, w_sdf, w_col, hostb);
         f->blob_bytes = pk.used;
-        if (hipMalloc(&f->blob, f->blob_bytes) != hipSuccess) {
+        if (pool_alloc(&f->blob, f->blob_bytes) != hipSuccess) {
             set_error("hipMalloc of %zu bytes for packed weights failed", f->blob_bytes);
             rc = HN_ENOMEM;
         }
@@ -375,13 +459,14 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
             rc = HN_EHIP;
         }
     }
+    stage("fp32 fragments (sizing pass, allocation, k_pack launches, sync)");
     if (rc == HN_OK) {   // keep the folded matrices and biases (row-major) for the adjoint path
         size_t total = 0;
         auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
         auto pitch = [](int in) { return (in + 3) & ~3; };   // rows start 16-byte aligned: vector loads in k_dense
         for (int l = 0; l < 9; ++l) total += pad((size_t)sdf->out_dim[l] * pitch(sdf->in_dim[l])) + pad(sdf->out_dim[l]);
         for (int l = 0; l < 5; ++l) total += pad((size_t)col->out_dim[l] * pitch(col->in_dim[l])) + pad(col->out_dim[l]);
-        if (hipMalloc(&f->raw, total * sizeof(float)) != hipSuccess) {
+        if (pool_alloc(&f->raw, total * sizeof(float)) != hipSuccess) {
             set_error("hipMalloc of %zu bytes for the folded weights failed", total * sizeof(float));
             rc = HN_ENOMEM;
         } else {
@@ -391,8 +476,9 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
             auto keep_mat = [&](const float* src, int out, int in) {
                 const float* dst = q;
                 const int ld = pitch(in);
-                (void)hipMemcpy2DAsync(q, (size_t)ld * sizeof(float), src, (size_t)in * sizeof(float), (size_t)in * sizeof(float), out,
-                                       hipMemcpyDeviceToDevice, stream);
+                // a kernel, not hipMemcpy2DAsync: the rows are 4-byte aligned only, which the copy engines' rectangle
+                // path handles slowly and erratically (3 - 34 ms per pack of a hand field, measured)
+                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)(((size_t)out * in + 255) / 256)), dim3(256), 0, stream, src, out, in, q, ld);
                 q += pad((size_t)out * ld);
                 return dst;
             };
@@ -422,16 +508,18 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
             }
         }
     }
+    stage("retained row-major matrices");
     if (rc == HN_OK && precision == HN_PREC_F16X3) rc = v2::build_v2_streams(f, sdf, col, w_sdf, w_col, stream, eval_only);
     pk.free_temps();
+    stage("f16x3 programs");
     if (rc != HN_OK) {
-        if (f->v2_full) (void)hipFree(f->v2_full);
-        if (f->v2_sdf) (void)hipFree(f->v2_sdf);
-        if (f->v2_adj) (void)hipFree(f->v2_adj);
-        if (f->v2_adjonly) (void)hipFree(f->v2_adjonly);
-        if (f->v2_tape) (void)hipFree(f->v2_tape);
-        if (f->blob) (void)hipFree(f->blob);
-        if (f->raw) (void)hipFree(f->raw);
+        if (f->v2_full) pool_free(f->v2_full);
+        if (f->v2_sdf) pool_free(f->v2_sdf);
+        if (f->v2_adj) pool_free(f->v2_adj);
+        if (f->v2_adjonly) pool_free(f->v2_adjonly);
+        if (f->v2_tape) pool_free(f->v2_tape);
+        if (f->blob) pool_free(f->blob);
+        if (f->raw) pool_free(f->raw);
         delete f;
         return rc;
     }

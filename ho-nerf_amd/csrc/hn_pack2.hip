@@ -1,22 +1,33 @@
 // v2 weight streams (HN_PREC_F16X3): every matrix of a field re-laid as the sequence of LDS
-// chunks the v2 kernels consume, fp16 hi / scaled-lo MFMA A fragments (hn_mlp2.h).  Packing
-// runs once per field on the host (a few MB; the networks are frozen on every path this
-// library serves): the weight-norm-folded matrices are copied back from the device, laid out
-// here and uploaded as one blob per program.
+// chunks the v2 kernels consume, fp16 hi / scaled-lo MFMA A fragments (hn_mlp2.h).  The host
+// lays a program out (which matrix element goes where: descriptors and index maps, plus the few
+// hundred bias / row values of the chunk tails); the fragments themselves -- the fp16 hi / lo
+// split of every matrix element, 5 - 27 MB per program -- are written on the device by
+// k_fill_fragments from the folded matrices that are already there.  (Done on the host, as in
+// round 1, a hand field took 230 ms to pack: fine for frozen networks, not for a training step
+// that re-packs after every optimiser update; profiles/r02/README.md, "training step".)
 //
 // Reads the reference's state-dict layout through hn_mlp_desc (utils/fields.py:120-121,
 // 216-217, 307-308, 382-383).
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <chrono>
+#include <mutex>
 
 #include "hn_mlp2.h"
 
 namespace hn {
+hipError_t pool_alloc(void** p, size_t bytes);   // hn_pack.hip: size-keyed cache in front of hipMalloc / hipFree
+void pool_free(void* p);
 namespace v2 {
 
 struct HostMat {
-    std::vector<float> w;   // row-major [rows][cols], weight-norm folded
-    std::vector<float> b;   // [rows]
+    const float* w = nullptr;   // row-major [rows][cols], weight-norm folded (a slice of the pinned fetch buffer)
+    const float* b = nullptr;   // [rows]
+    const float* dev = nullptr;   // the same matrix on the device (what k_fill_fragments reads)
     int rows = 0, cols = 0;
     float at(int r, int c) const { return w[(size_t)r * cols + c]; }
 };
@@ -41,8 +52,20 @@ static inline void k_of_row(int n, int& s, int& h, int& j) {
     j = 4 * (rem >> 3) + (rem & 3);
 }
 
+// One 2 KiB A-fragment block (tile ti, k-step s of a chunk) for k_fill_fragments
+struct FragBlock {
+    const float* mat;          // folded matrix on the device, row-major [rows][cols]
+    unsigned long long dst;    // byte offset of the block in the program
+    int cols, transposed;
+    float scale;
+    int rowmap, colslot;       // offsets into the program's index-map array: 32 tile rows; the chunk's k-slot columns
+    int s, s16;
+};
+
 struct Builder {
-    std::vector<char> blob;
+    std::vector<char> blob;    // the program with its fragment blocks left zero (tails and side data in place)
+    std::vector<FragBlock> blocks;
+    std::vector<int> maps;
 
     // One chunk: tiles x ks k-step blocks (+ tail).  rowmap[ti*32 + r] = matrix row of tile ti's row r
     // (-1 pad); colslot[s*16 + 8h + j] = matrix column of k-slot (s,h,j) (-1 pad).  transposed:
@@ -52,27 +75,14 @@ struct Builder {
         const size_t base = blob.size();
         if (g_s16 && (ks & 1)) abort();   // k-steps come in pairs on this shape: the caller pads
         blob.resize(base + (size_t)tiles * ks * KS_BYTES + (tail ? TAIL_BYTES : 0));
-        _Float16* dst = reinterpret_cast<_Float16*>(blob.data() + base);
+        const int rm = (int)maps.size();
+        maps.insert(maps.end(), rowmap, rowmap + tiles * 32);
+        const int cs = (int)maps.size();
+        maps.insert(maps.end(), colslot, colslot + ks * 16);
         for (int ti = 0; ti < tiles; ++ti)
-            for (int s = 0; s < ks; ++s) {
-                _Float16* hi = dst + ((size_t)(ti * ks + s) * KS_BYTES) / 2;
-                _Float16* lo = hi + 512;
-                for (int l = 0; l < 64; ++l) {
-                    // 32x32x16: block s = k-step s, lane = (row l & 31, half l >> 5).  16x16x32: block s = row block
-                    // s & 1 of k-step pair s >> 1, lane = (row l & 15 of the block, k-group g = l >> 4)
-                    const int r = g_s16 ? 16 * (s & 1) + (l & 15) : (l & 31);
-                    const int kbase = g_s16 ? 32 * (s >> 1) + 8 * (l >> 4) : s * 16 + 8 * (l >> 5);
-                    const int row = rowmap[ti * 32 + r];
-                    for (int j = 0; j < 8; ++j) {
-                        const int col = colslot[kbase + j];
-                        float x = 0.f;
-                        if (row >= 0 && col >= 0) x = (transposed ? M.at(col, row) : M.at(row, col)) * scale;
-                        const _Float16 xh = (_Float16)x;   // IEEE, subnormals kept: the MFMA reads them as such
-                        hi[l * 8 + j] = xh;
-                        lo[l * 8 + j] = (_Float16)((x - (float)xh) * LO_SCALE);
-                    }
-                }
-            }
+            for (int s = 0; s < ks; ++s)
+                blocks.push_back(FragBlock{M.dev, (unsigned long long)(base + (size_t)(ti * ks + s) * KS_BYTES), M.cols, transposed ? 1 : 0,
+                                           scale, rm + ti * 32, cs, s, g_s16 ? 1 : 0});
         if (tail) memcpy(blob.data() + base + (size_t)tiles * ks * KS_BYTES, tail, TAIL_BYTES);
     }
     // side data only (a multiple of 1 KiB)
@@ -330,10 +340,89 @@ static void obj_adjoint_chunks(Builder& B, const HostMat* S, const HostMat* C) {
     obj_sdf_reverse_chunks(B, S);         // second reverse sweep
 }
 
-static int upload(const std::vector<char>& blob, void** dev, size_t* bytes, hipStream_t stream) {
-    HN_CHECK_HIP(hipMalloc(dev, blob.size()));
-    HN_CHECK_HIP(hipMemcpyAsync(*dev, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
-    HN_CHECK_HIP(hipStreamSynchronize(stream));
+// One wave per block: lane l writes the 8 hi and 8 lo halves of its fragment (16 B each).
+// 32x32x16: block s = k-step s, lane = (row l & 31, half l >> 5).  16x16x32: block s = row block s & 1 of k-step pair
+// s >> 1, lane = (row l & 15 of the block, k-group g = l >> 4).  hi = fp16(x) (IEEE, subnormals kept: the MFMA reads
+// them as such), lo = fp16((x - hi) * LO_SCALE).
+__global__ __launch_bounds__(256) void k_fill_fragments(const FragBlock* __restrict__ blocks, int n_blocks, const int* __restrict__ maps,
+                                                        char* __restrict__ prog) {
+    const int bi = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (bi >= n_blocks) return;
+    const FragBlock d = blocks[bi];
+    const int r = d.s16 ? 16 * (d.s & 1) + (l & 15) : (l & 31);
+    const int kbase = d.s16 ? 32 * (d.s >> 1) + 8 * (l >> 4) : d.s * 16 + 8 * (l >> 5);
+    const int row = maps[d.rowmap + r];
+    typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+    h8v hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int col = maps[d.colslot + kbase + j];
+        float x = 0.f;
+        if (row >= 0 && col >= 0) x = (d.transposed ? d.mat[(size_t)col * d.cols + row] : d.mat[(size_t)row * d.cols + col]) * d.scale;
+        const _Float16 xh = (_Float16)x;
+        hi[j] = xh;
+        lo[j] = (_Float16)((x - (float)xh) * LO_SCALE);
+    }
+    _Float16* out = reinterpret_cast<_Float16*>(prog + d.dst);
+    *reinterpret_cast<h8v*>(out + l * 8) = hi;
+    *reinterpret_cast<h8v*>(out + 512 + l * 8) = lo;
+}
+
+// Host staging of a pack: two pinned buffers kept for the life of the process (grow-only).  Everything that crosses the
+// bus here goes through them.  A copy to or from PAGEABLE memory makes the driver register those pages for DMA, and when
+// the pages are released afterwards (a std::vector of a few MB is an mmap that free() unmaps) the MMU notifier evicts
+// and restores the process's GPU queues: a 25 - 35 ms stall of the next launch, seen as a hand field's re-pack "taking"
+// 3, 9 or 35 ms from one process to the next (profiles/r02/README.md, "training step").
+struct Pinned {
+    void* p = nullptr;
+    size_t cap = 0;
+    void* get(size_t n) {
+        if (n <= cap) return p;
+        if (p != nullptr) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = (n + n / 4 + 4095) & ~size_t(4095);
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+        cap = want;
+        return p;
+    }
+};
+static std::mutex g_pack_mu;          // packs of one process take turns (they share the staging buffers)
+static Pinned g_pin_fetch, g_pin_up;
+
+static int upload(const Builder& B, void** dev, size_t* bytes, hipStream_t stream) {
+    const std::vector<char>& blob = B.blob;
+    const size_t nbk = B.blocks.size() * sizeof(FragBlock), nm = B.maps.size() * sizeof(int);
+    const size_t blob_pad = (blob.size() + 255) & ~size_t(255), nb_pad = (nbk + 255) & ~size_t(255);
+    char* stage = reinterpret_cast<char*>(g_pin_up.get(blob_pad + nb_pad + nm + 256));
+    if (stage == nullptr) {
+        set_error("hipHostMalloc of %zu bytes for the pack staging buffer failed", blob_pad + nb_pad + nm);
+        return HN_ENOMEM;
+    }
+    memcpy(stage, blob.data(), blob.size());
+    memcpy(stage + blob_pad, B.blocks.data(), nbk);
+    memcpy(stage + blob_pad + nb_pad, B.maps.data(), nm);
+    HN_CHECK_HIP(pool_alloc(dev, blob.size()));
+    HN_CHECK_HIP(hipMemcpyAsync(*dev, stage, blob.size(), hipMemcpyHostToDevice, stream));
+    void* tmp = nullptr;
+    if (!B.blocks.empty()) {
+        HN_CHECK_HIP(pool_alloc(&tmp, nb_pad + nm));
+        hipError_t e = hipMemcpyAsync(tmp, stage + blob_pad, nb_pad + nm, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) {
+            const int n_blocks = (int)B.blocks.size();
+            hipLaunchKernelGGL(k_fill_fragments, dim3((n_blocks + 3) / 4), dim3(256), 0, stream, reinterpret_cast<const FragBlock*>(tmp),
+                               n_blocks, reinterpret_cast<const int*>(reinterpret_cast<char*>(tmp) + nb_pad), reinterpret_cast<char*>(*dev));
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            pool_free(tmp);
+            set_error("packing a weight stream on the device failed: %s", hipGetErrorString(e));
+            return HN_EHIP;
+        }
+    }
+    const hipError_t e = hipStreamSynchronize(stream);     // the staging buffer is free again after this
+    if (tmp != nullptr) pool_free(tmp);
+    HN_CHECK_HIP(e);
     *bytes = blob.size();
     return HN_OK;
 }
@@ -344,13 +433,26 @@ void build_hand_stream(Builder& B, const HostMat* S, const HostMat* C, int mode)
 int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float* const* w_sdf,
                      float* const* w_col, hipStream_t stream, bool eval_only) {
     HostMat S[9], C[5];
+    std::lock_guard<std::mutex> pack_lock(g_pack_mu);
+    const auto t_begin = std::chrono::steady_clock::now();
+    size_t total = 0;
+    for (int l = 0; l < 9; ++l) total += (size_t)sdf->out_dim[l] * sdf->in_dim[l] + sdf->out_dim[l];
+    for (int l = 0; l < 5; ++l) total += (size_t)col->out_dim[l] * col->in_dim[l] + col->out_dim[l];
+    float* host = reinterpret_cast<float*>(g_pin_fetch.get(total * sizeof(float)));
+    if (host == nullptr) {
+        set_error("hipHostMalloc of %zu bytes for the weight fetch buffer failed", total * sizeof(float));
+        return HN_ENOMEM;
+    }
     auto fetch = [&](const hn_mlp_desc* d, int l, float* dev_w, HostMat& M) -> int {
         M.rows = d->out_dim[l];
         M.cols = d->in_dim[l];
-        M.w.resize((size_t)M.rows * M.cols);
-        M.b.resize(M.rows);
-        HN_CHECK_HIP(hipMemcpyAsync(M.w.data(), dev_w, M.w.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
-        HN_CHECK_HIP(hipMemcpyAsync(M.b.data(), d->bias[l], M.b.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        M.dev = dev_w;
+        const size_t nw = (size_t)M.rows * M.cols;
+        M.w = host;
+        M.b = host + nw;
+        HN_CHECK_HIP(hipMemcpyAsync(host, dev_w, nw * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HN_CHECK_HIP(hipMemcpyAsync(host + nw, d->bias[l], (size_t)M.rows * sizeof(float), hipMemcpyDeviceToHost, stream));
+        host += nw + M.rows;
         return HN_OK;
     };
     for (int l = 0; l < 9; ++l) {
@@ -362,11 +464,19 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
         if (rc != HN_OK) return rc;
     }
     HN_CHECK_HIP(hipStreamSynchronize(stream));
+    const bool timing = getenv("HN_PACK_TIMING") != nullptr;     // stage times of a pack on stderr (not a launch path)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_fetch = now();
+    if (timing) fprintf(stderr, "[hn pack] weights to host %.2f ms\n", ms(t_begin, t_fetch));
     // modes 0 .. 3 as the kernels' MODE 0, 1, 2, 4; "mode 4": the taped evaluation's copy of the mode-1 program on the
     // adjoint kernels' MFMA shape, built only where the evaluation kernels use the other one
     const bool eval16 = f->kind == HN_FIELD_OBJ ? (HN_OBJ_EVAL_MFMA16 != 0) : (HN_HAND_EVAL_MFMA16 != 0);
     for (int mode = 0; mode < (eval16 ? 5 : 4); ++mode) {
         if (eval_only && mode >= 2) break;   // sdf-only and evaluation programs only (HN_PACK_EVAL_ONLY)
+        const auto t_mode = now();
         Builder B;
         g_s16 = eval16 && mode < 2;
         const int prog = mode == 4 ? 1 : mode;
@@ -379,8 +489,12 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
         void** dst = mode == 0 ? &f->v2_sdf : (mode == 1 ? &f->v2_full : (mode == 2 ? &f->v2_adj : (mode == 3 ? &f->v2_adjonly : &f->v2_tape)));
         size_t* nb = mode == 0 ? &f->v2_sdf_bytes
                                : (mode == 1 ? &f->v2_full_bytes : (mode == 2 ? &f->v2_adj_bytes : (mode == 3 ? &f->v2_adjonly_bytes : &f->v2_tape_bytes)));
-        const int rc = upload(B.blob, dst, nb, stream);
+        const auto t_laid = now();
+        const int rc = upload(B, dst, nb, stream);
         if (rc != HN_OK) return rc;
+        if (timing)
+            fprintf(stderr, "[hn pack] program %d: %zu bytes, %zu fragment blocks, layout %.2f ms, upload + fill %.2f ms\n", mode, B.blob.size(),
+                    B.blocks.size(), ms(t_mode, t_laid), ms(t_laid, now()));
     }
     return HN_OK;
 }
