@@ -20,6 +20,8 @@ depths, both fields, forward + losses + backward into the pose parameters + Adam
 fitting_video (C5: a window of 4 frames x 40 rays, fit type '1234' incl. the stable
 loss), every rank fitting its own frame / window (frame-sharded, weak scaling).
 
+`training` (rank 0): one iteration of exp_runner.train's inner loop per field kind.
+
 `--gpus N` without a torch.distributed environment starts the N ranks itself
 (`python -m torch.distributed.run`, as a child process, before anything touches the
 GPU) and relays rank 0's line.
@@ -256,6 +258,7 @@ def main():
     ap.add_argument('--no-culled', action='store_true', help='skip the secondary culled measurement')
     ap.add_argument('--precision', default='f16x3', choices=['f16x3', 'fp32'])
     ap.add_argument('--no-fitting', action='store_true', help='skip the fitting-loop measurements')
+    ap.add_argument('--no-training', action='store_true', help='skip the training-iteration measurement')
     ap.add_argument('--fit-steps', type=int, default=10)
     args = ap.parse_args()
 
@@ -375,6 +378,13 @@ def main():
                              % (FIT_RAYS, FIT_N + 2 * FIT_IMP, VID_FRAMES, VID_RAYS))
         if rank == 0 and not args.no_cpu_baseline:
             fitting['cpu_baseline'] = cpu_fit_baseline(single)
+    training = None
+    if rank == 0 and not args.no_training and args.precision == 'f16x3':
+        # one iteration of exp_runner.train (render, loss, backward into every network parameter, Adam,
+        # re-pack) at the reference's batch (confs: 441 rays, 64 + 64 samples); secondary to the headline
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import train_step_bench
+        training = {k: train_step_bench.measure(k, dev, 441, 10, 3, args.precision) for k in ('obj', 'hand')}
     if rank == 0:
         res = {
             'metric': 'ray-samples/sec/GPU (512x512x64)', 'value': value, 'unit': 'ray-samples/s',
@@ -393,6 +403,8 @@ def main():
         }
         if fitting is not None:
             res['fitting'] = fitting
+        if training is not None:
+            res['training'] = training
         if culled is not None:
             res['value_culled'] = culled   # rank 0's frame, far-field early-out on (bit-identical output)
         if not args.no_cpu_baseline:

@@ -195,3 +195,45 @@ def test_bench_gpus_flag_spawns_ranks_or_refuses_a_mismatch():
     env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and 'WORLD_SIZE=2' in r.stderr
+
+
+def _train_grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from honerf_amd import training
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)                                              # identical replicas of the parameters
+        params = [torch.nn.Parameter(torch.randn(5, 7)), torch.nn.Parameter(torch.randn(5, 1)), torch.nn.Parameter(torch.randn(()))]
+        opt = torch.optim.Adam(params, lr=1e-2)
+        torch.manual_seed(100 + rank)                                     # a different "ray batch" on every rank
+        for _ in range(3):
+            x = torch.randn(11, 7)
+            loss = ((x @ params[0].T * params[1].T).sum(dim=1) * params[2]).pow(2).mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            training.allreduce_gradients(params, dist)
+            opt.step()
+        q.put((rank, [p.detach().numpy().copy() for p in params], [p.grad.numpy().copy() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_training_gradients_are_averaged_and_replicas_identical():
+    """honerf_amd.training.allreduce_gradients: one all-reduce of the flattened gradient block; both ranks end up with
+    the same (averaged) gradients and therefore bit-identical parameters after Adam."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, g0), (_, p1, g1) = res
+    for a, b in zip(p0 + g0, p1 + g1):
+        assert np.array_equal(a, b)

@@ -55,6 +55,55 @@ def rays(kind, synth, n, dev, seed=3):
     return o, d, extra
 
 
+def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3'):
+    """-> dict(workload, ms_per_step, ray_samples_per_s, parts_ms, loss, precision) for one field kind."""
+    from honerf_amd import training
+    ren, synth = build(kind, dev)
+    ren.precision = precision
+    ren.pack_eval_only = True
+    o, d, ex = rays(kind, synth, n_rays, dev)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    true_rgb = torch.rand(n_rays, 3, generator=g).to(dev)
+    true_mask = (torch.rand(n_rays, 1, generator=g) > 0.3).float().to(dev)
+    params = training.trainable_parameters(ren)
+    opt = torch.optim.Adam(params, lr=1e-4)          # exp_runner.py:97-104, confs learning_rate = 1e-4
+
+    def step(parts=None):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        ren.field()                                   # re-pack of the weights the previous step updated
+        ev[1].record()
+        out = training.render_train(ren, o, d, 0.4, 1.5, ex['bt_inv'], ex['T_pose'], None, ex['Ro'], ex['To'])
+        terms = training.train_loss(out, true_rgb, true_mask, 1.0, 1.0)
+        ev[2].record()
+        opt.zero_grad(set_to_none=True)
+        terms['loss'].backward()
+        ev[3].record()
+        opt.step()
+        ev[4].record()
+        if parts is not None:
+            torch.cuda.synchronize()
+            for i, k in enumerate(('repack', 'forward', 'backward', 'optimizer')):
+                parts[k] = parts.get(k, 0.0) + ev[i].elapsed_time(ev[i + 1])
+        return terms
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        terms = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    parts = {}
+    for _ in range(steps):
+        step(parts)
+    S = 128
+    return {'workload': 'exp_runner.train iteration, %s nets, %d rays x (64+64) samples' % (kind, n_rays), 'ms_per_step': round(ms, 3),
+            'iterations_per_s': round(1e3 / ms, 2), 'ray_samples_per_s': round(n_rays * S / ms * 1e3),
+            'parts_ms': {k: round(v / steps, 3) for k, v in parts.items()}, 'loss': float(terms['loss'].detach()), 'precision': precision}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rays', type=int, default=441)
@@ -64,54 +113,10 @@ def main():
     ap.add_argument('--out', default=None)
     ap.add_argument('--precision', default='f16x3')
     a = ap.parse_args()
-    from honerf_amd import training
     dev = torch.device('cuda:0')
     lines = []
     for kind in a.kinds.split(','):
-        ren, synth = build(kind, dev)
-        ren.precision = a.precision
-        ren.pack_eval_only = True
-        o, d, ex = rays(kind, synth, a.rays, dev)
-        g = torch.Generator(device='cpu').manual_seed(5)
-        true_rgb = torch.rand(a.rays, 3, generator=g).to(dev)
-        true_mask = (torch.rand(a.rays, 1, generator=g) > 0.3).float().to(dev)
-        params = training.trainable_parameters(ren)
-        opt = torch.optim.Adam(params, lr=1e-4)          # exp_runner.py:97-104, confs learning_rate = 1e-4
-
-        def step(parts=None):
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-            ev[0].record()
-            ren.field()                                   # re-pack of the weights the previous step updated
-            ev[1].record()
-            out = training.render_train(ren, o, d, 0.4, 1.5, ex['bt_inv'], ex['T_pose'], None, ex['Ro'], ex['To'])
-            terms = training.train_loss(out, true_rgb, true_mask, 1.0, 1.0)
-            ev[2].record()
-            opt.zero_grad(set_to_none=True)
-            terms['loss'].backward()
-            ev[3].record()
-            opt.step()
-            ev[4].record()
-            if parts is not None:
-                torch.cuda.synchronize()
-                for i, k in enumerate(('repack', 'forward', 'backward', 'optimizer')):
-                    parts[k] = parts.get(k, 0.0) + ev[i].elapsed_time(ev[i + 1])
-            return terms
-
-        for _ in range(a.warmup):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            terms = step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) * 1e3 / a.steps
-        parts = {}
-        for _ in range(a.steps):
-            step(parts)
-        S = 128
-        line = {'workload': 'exp_runner.train iteration, %s nets, %d rays x (64+64) samples' % (kind, a.rays), 'ms_per_step': round(ms, 3),
-                'ray_samples_per_s': round(a.rays * S / ms * 1e3), 'parts_ms': {k: round(v / a.steps, 3) for k, v in parts.items()},
-                'loss': float(terms['loss'].detach()), 'precision': a.precision}
+        line = measure(kind, dev, a.rays, a.steps, a.warmup, a.precision)
         print(json.dumps(line))
         lines.append(line)
     if a.out:
