@@ -566,11 +566,10 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
     HN_REQUIRE(n_rays >= 0 && S >= 1, "bad sizes");
     const size_t N = (size_t)n_rays * S, R3 = (size_t)n_rays * 3;
     Arena ar(workspace, workspace_bytes);
-    float *pts = ar.f(N * 3), *dists = ar.f(N), *sdf = ar.f(N), *grad = ar.f(N * 3), *rgb = ar.f(N * 3), *al = ar.f(N), *c = ar.f(N);
+    float *pts = ar.f(N * 3), *dists = ar.f(N), *sdf = ar.f(N), *rgb = ar.f(N * 3), *al = ar.f(N), *c = ar.f(N);
     float *g_al = ar.f(N), *g_c = ar.f(N), *g_rgb = ar.f(N * 3), *gs = ar.f(N), *gg = ar.f(N * 3), *gd = ar.f(R3);
-    float *gp = ar.f(N * 3), *gdir = ar.f(R3), *gdd = ar.f(R3), *go = ar.f(R3);
-    const size_t fws_bytes = field_ws(f, (int)N), bws_bytes = bwd::field_bwd_workspace_bytes(f, (int)N);
-    void* fws = ar.take(fws_bytes);
+    float *gp = ar.f(N * 3), *gdir = ar.f(R3), *gdd = ar.f(R3), *go = ar.f(R3), *pose_scratch = ar.f(21 * 16 + 21 * 3);
+    const size_t bws_bytes = bwd::field_bwd_workspace_bytes(f, (int)N);
     void* bws = ar.take(bws_bytes);
     if (need != nullptr) {
         *need = ar.used;
@@ -586,7 +585,6 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
     HN_REQUIRE(!hand || (bt_inv && T_pose), "hand field needs bt_inv / T_pose");
     const int n = (int)N;
     HN_TRY(sample_points(rays_o, rays_d, z, n_rays, S, 1, sample_dist, pts, dists, s));
-    (void)fws;
     // The field is NOT evaluated again: the adjoint's own forward tape (exact fp32) supplies sdf / gradient / colour;
     // the alpha stage, the compositing and their adjoints run in the hook, between the tape and the sweeps.
     const bwd::MidHook mid = [&](const float* z8, const float* g_field, const float* rgb_pre) -> int {
@@ -604,9 +602,8 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
     };
     float *gbt = g_bt_inv, *gtp = g_T_pose;
     if (hand) {   // the adjoint accumulates the pose gradients: into the caller's arrays when given, else into scratch
-        HN_REQUIRE(N >= 256, "too few samples");
-        if (gbt == nullptr) gbt = grad;            // `grad` is free on this path (the tape's own gradient array is used)
-        if (gtp == nullptr) gtp = grad + 512;
+        if (gbt == nullptr) gbt = pose_scratch;
+        if (gtp == nullptr) gtp = pose_scratch + 21 * 16;
         HN_CHECK_HIP(hipMemsetAsync(gbt, 0, 21 * 16 * sizeof(float), s));
         HN_CHECK_HIP(hipMemsetAsync(gtp, 0, 21 * 3 * sizeof(float), s));
     }

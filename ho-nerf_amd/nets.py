@@ -33,9 +33,11 @@ class _WNLinear(nn.Module):
 
     def __init__(self, cin, cout):
         super().__init__()
+        # registration order of a weight-normalised nn.Linear (bias, weight_g, weight_v): `parameters()` then enumerates
+        # like the reference's modules, so an optimiser state dict (index-based) is interchangeable with exp_runner's
+        self.bias = nn.Parameter(torch.zeros(cout))
         self.weight_g = nn.Parameter(torch.ones(cout, 1))
         self.weight_v = nn.Parameter(torch.zeros(cout, cin))
-        self.bias = nn.Parameter(torch.zeros(cout))
 
 
 class _MLPParams(nn.Module):

@@ -17,6 +17,8 @@ reference).  The VGG term of exp_runner.py:213-224 stays a torch module on `colo
 staying in torch"); it composes with this Function through autograd like any other loss on the render outputs.
 """
 import ctypes
+import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -261,3 +263,61 @@ def train_loss(render_out, true_rgb, true_mask, igr_weight=0.1, mask_weight=0.1)
     eikonal_loss = render_out['gradient_error']
     loss = color_fine_loss + mask_loss * mask_weight + eikonal_loss * igr_weight
     return dict(loss=loss, color_fine_loss=color_fine_loss, mask_loss=mask_loss, eikonal_loss=eikonal_loss, psnr=psnr.detach())
+
+
+# ---- the rest of exp_runner's training surface: optimiser, learning-rate schedule, checkpoints (host code) ------------
+def make_optimizer(renderer, learning_rate, extra_params=()):
+    """Adam over `sdf_network.parameters() + deviation_network.parameters() + color_network.parameters()` in that order
+    (exp_runner.py:107-110; `se3_refine` is one of sdf_network's parameters), so that the optimiser state of a
+    reference checkpoint loads by index.  On the GPU the fused multi-tensor form (one launch per step)."""
+    params = list(renderer.sdf_network.parameters()) + list(renderer.deviation_network.parameters()) + \
+        list(renderer.color_network.parameters()) + list(extra_params)
+    try:
+        return torch.optim.Adam(params, lr=learning_rate, fused=all(p.is_cuda for p in params))
+    except (RuntimeError, TypeError):
+        return torch.optim.Adam(params, lr=learning_rate)
+
+
+def learning_rate_factor(iter_step, warm_up_end, end_iter, learning_rate_alpha):
+    """exp_runner.py:266-272: linear warm-up, then cosine decay to `learning_rate_alpha`."""
+    if iter_step < warm_up_end:
+        return iter_step / warm_up_end
+    progress = (iter_step - warm_up_end) / (end_iter - warm_up_end)
+    return (math.cos(math.pi * progress) + 1.0) * 0.5 * (1 - learning_rate_alpha) + learning_rate_alpha
+
+
+def update_learning_rate(optimizer, iter_step, learning_rate, warm_up_end, end_iter, learning_rate_alpha):
+    """exp_runner.py:266-274."""
+    f = learning_rate_factor(iter_step, warm_up_end, end_iter, learning_rate_alpha)
+    for g in optimizer.param_groups:
+        g['lr'] = learning_rate * f
+    return learning_rate * f
+
+
+def save_checkpoint(base_exp_dir, renderer, optimizer, iter_step):
+    """exp_runner.py:296-306: same keys, same file name (`checkpoints/ckpt_{iter:06d}.pth`); the reference loads it."""
+    ckpt = {
+        'sdf_network_fine': renderer.sdf_network.state_dict(),
+        'variance_network_fine': renderer.deviation_network.state_dict(),
+        'color_network_fine': renderer.color_network.state_dict(),
+        'barf_encoding': {},                      # the reference's Embedding has no parameters or buffers
+        'optimizer': optimizer.state_dict(),
+        'iter_step': int(iter_step),
+    }
+    d = os.path.join(base_exp_dir, 'checkpoints')
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, 'ckpt_{:0>6d}.pth'.format(int(iter_step)))
+    torch.save(ckpt, path)
+    return path
+
+
+def load_checkpoint(path, renderer, optimizer=None, map_location=None):
+    """exp_runner.py:288-294 (+ the optimiser state when an optimiser is given) -> iter_step.  The renderer re-packs its
+    field on the next call (the parameters' versions change)."""
+    ckpt = torch.load(path, map_location=map_location)
+    renderer.sdf_network.load_state_dict(ckpt['sdf_network_fine'], strict=False)
+    renderer.deviation_network.load_state_dict(ckpt['variance_network_fine'])
+    renderer.color_network.load_state_dict(ckpt['color_network_fine'], strict=False)
+    if optimizer is not None and 'optimizer' in ckpt:
+        optimizer.load_state_dict(ckpt['optimizer'])
+    return int(ckpt['iter_step'])

@@ -101,5 +101,13 @@ def main():
             col_step=COL_STEP, color_fine=out['color_fine'], weight_sum=out['weight_sum'], **terms, **rec)
 
 
+    # the order in which the reference's modules enumerate their parameters (exp_runner.py:107-110 hands them to Adam in
+    # this order; optimiser state dicts are index-based)
+    order = {}
+    for k in ('sdf_obj', 'color_obj', 'sdf_hand', 'color_hand'):
+        order[k] = np.array(['%s %s' % (n, 'x'.join(str(d) for d in p.shape)) for n, p in nets[k].named_parameters()])
+    np.savez_compressed(os.path.join(HERE, 'param_order.npz'), **order)
+
+
 if __name__ == '__main__':
     main()
