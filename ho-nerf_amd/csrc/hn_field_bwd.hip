@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256) void k_outer(const OuterArgs a) {
     const int b_kind = kc < a.K ? 0 : kc < KB ? 1 : 2;     // 0: column of B, 1: the constant 1 (bias gradient), 2: padding
     const float* pa = a.A + m0 + col;
     const float* pb = a.B + kc;
-    for (int i0 = i_begin; i0 < i_end; i0 += 32) {
-        float va[16], vb[16];
+    float va[16], vb[16];
+    auto fetch = [&](int i0) {                     // 32 samples x this thread's column of both operands -> registers
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int i = i0 + s0 + 2 * e;
@@ -207,6 +207,9 @@ __global__ __launch_bounds__(256) void k_outer(const OuterArgs a) {
             va[e] = (live && a_col) ? pa[(size_t)i * a.lda] : 0.f;
             vb[e] = !live ? 0.f : b_kind == 0 ? pb[(size_t)i * a.ldb] : b_kind == 1 ? 1.f : 0.f;
         }
+    };
+    if (i_begin < i_end) fetch(i_begin);
+    for (int i0 = i_begin; i0 < i_end; i0 += 32) {
         __syncthreads();                           // the previous step's MFMAs have read the tiles
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(256) void k_outer(const OuterArgs a) {
             Bs[s0 + 2 * e][col] = vb[e];
         }
         __syncthreads();
+        if (i0 + 32 < i_end) fetch(i0 + 32);       // the next step's reads are in flight under this step's MFMAs
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             float av[2], bv[2];
