@@ -73,10 +73,15 @@ const char* hn_last_error(void);
 int hn_device_cus(void);
 
 /* ---- weights --------------------------------------------------------------------------
- * Folds weight-norm and re-lays every matrix in MFMA fragment order (once; the
- * networks are frozen on every path this library serves).  `variance` is
- * SingleVarianceNetwork.variance (utils/fields.py:243-249); `scale` is
- * SDFNetwork_OBJ.scale (:328).  Synchronises the stream before returning. */
+ * Folds weight-norm and re-lays every matrix in MFMA fragment order: once for the frozen
+ * networks of rendering and pose fitting, after every optimiser step when training
+ * (exp_runner.py:230-232; ~2 - 3 ms with HN_PACK_EVAL_ONLY: all fragments are written on the
+ * device).  `variance` is SingleVarianceNetwork.variance (utils/fields.py:243-249); `scale` is
+ * SDFNetwork_OBJ.scale (:328).  Synchronises the stream before returning.
+ * hn_field_destroy: no work that uses the field may be in flight.  Its device blocks go to a
+ * size-keyed cache of the process and are handed to the next hn_field_create of the same shape
+ * (a re-pack allocates nothing); host staging is two pinned buffers kept for the life of the
+ * process.  Packs of one process are serialised. */
 int hn_field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* color, float variance, float scale,
                     int precision, hn_field** out, hn_stream_t stream);
 int hn_field_destroy(hn_field* f);

@@ -336,3 +336,43 @@ def test_field_param_bwd_matches_render_single_bwd_pieces(kind):
             record('param_bwd %s %s (fp32 autograd vs fp64: %.1e)' % (kind, key, floor), e, bound)
             assert e <= bound, '%s: %.3e > %.1e (fp32 autograd is %.1e from fp64)' % (key, e, bound, floor)
             worst = max(worst, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['obj', 'hand'])
+def test_repack_is_bit_reproducible_and_eval_only_equals_full(kind):
+    """The device-side packer (k_fill_fragments) and the block cache: packing the same weights twice -- the second time
+    into recycled device blocks that held OTHER weights in between -- gives bit-identical evaluations, and a field
+    packed with HN_PACK_EVAL_ONLY evaluates bit-identically to a fully packed one (same evaluation programs)."""
+    from honerf_amd import synth
+    from honerf_amd.nets import PackedField
+    dev = torch.device('cuda:0')
+    sd = state_dicts()
+    var = VAR_OBJ if kind == 'obj' else VAR_HAND
+    gen = torch.Generator().manual_seed(2)
+    n = 300
+    if kind == 'obj':
+        pts = ((torch.rand(n, 3, generator=gen) - 0.5) * 0.8).to(dev)
+        kw = {}
+    else:
+        bt_np, tp_np, joints = synth.synth_hand_pose(9)
+        idx = torch.randint(0, 21, (n,), generator=gen)
+        pts = (torch.from_numpy(joints).float()[idx] + 0.02 * torch.randn(n, 3, generator=gen)).to(dev)
+        kw = dict(bt_inv=torch.from_numpy(bt_np).to(dev), T_pose=torch.from_numpy(tp_np).to(dev))
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1).to(dev)
+
+    def evaluate(f):
+        s, g, c = f.evaluate(pts, dirs, 1, **kw)
+        return torch.cat([s.reshape(n, 1), g, c, f.sdf(pts, *kw.values())], dim=1).clone()
+
+    full = PackedField(kind, sd['sdf_' + kind], sd['color_' + kind], var)
+    ref = evaluate(full)
+    del full
+    other = {k: (v * 1.01 if 'weight_v' in k else v) for k, v in synth.synth_state_dict('sdf_' + kind, 77).items()}
+    tmp = PackedField(kind, other, sd['color_' + kind], var, eval_only=True)     # other weights through the same blocks
+    assert not torch.equal(evaluate(tmp), ref)
+    del tmp
+    again = PackedField(kind, sd['sdf_' + kind], sd['color_' + kind], var, eval_only=True)
+    out = evaluate(again)
+    record('repack %s: eval-only re-pack vs first pack (max abs diff)' % kind, float((out - ref).abs().max()), 0.0, kind='abs')
+    assert torch.equal(out, ref)

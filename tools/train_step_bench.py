@@ -99,7 +99,16 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3'):
     for _ in range(steps):
         step(parts)
     S = 128
-    return {'workload': 'exp_runner.train iteration, %s nets, %d rays x (64+64) samples' % (kind, n_rays), 'ms_per_step': round(ms, 3),
+    # algorithmic work of the backward pass: four sweeps over the SDF network (tape, reverse, forward-direction, second
+    # reverse), colour network forward + backward, and the outer products (two per SDF layer, one per colour layer)
+    from honerf_amd import synth as _synth
+    macs = lambda k: sum(o * i for o, i in _synth.layer_shapes(k, 256))
+    p_sdf, p_col = macs('sdf_' + kind), macs('color_' + kind)
+    flop = 2.0 * (6 * p_sdf + 3 * p_col) * n_rays * S
+    bwd_s = parts['backward'] / steps * 1e-3
+    roof = {'bound': 'mfma', 'what': 'backward pass: launch sequence on v_mfma_f32_32x32x2_f32 (k_dense, k_outer)', 'flop_per_step': flop,
+            'achieved': flop / bwd_s / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': flop / bwd_s / 1e12 / 157.3}
+    return {'roofline': roof, 'workload': 'exp_runner.train iteration, %s nets, %d rays x (64+64) samples' % (kind, n_rays), 'ms_per_step': round(ms, 3),
             'iterations_per_s': round(1e3 / ms, 2), 'ray_samples_per_s': round(n_rays * S / ms * 1e3),
             'parts_ms': {k: round(v / steps, 3) for k, v in parts.items()}, 'loss': float(terms['loss'].detach()), 'precision': precision}
 
