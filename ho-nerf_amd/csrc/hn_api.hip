@@ -575,11 +575,11 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
         *need = ar.used;
         return HN_OK;
     }
+    if (n_rays == 0) return HN_OK;      // an empty batch: nothing to add to g_params, nothing to launch
     if (!ar.ok) {
         set_error("render_single_bwd workspace too small: %zu bytes given", workspace_bytes);
         return HN_ENOMEM;
     }
-    if (n_rays == 0) return HN_OK;
     const bool hand = f->kind == HN_FIELD_HAND;
     HN_REQUIRE(rays_o && rays_d && z && g_color && g_params, "null argument");
     HN_REQUIRE(!hand || (bt_inv && T_pose), "hand field needs bt_inv / T_pose");

@@ -128,10 +128,10 @@ class SingleRenderFn(torch.autograd.Function):
         ge = None if g_gerr is None else L.f32(g_gerr).reshape(1)
         n_floats = lib.hn_field_param_floats(f.handle)
         g_params = torch.zeros(n_floats, device=dev)
-        g_inv_s = torch.empty(1, device=dev)
+        g_inv_s = torch.zeros(1, device=dev)
         g_ro, g_rd = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
-        g_bt = torch.empty(21, 4, 4, device=dev) if hand else None
-        g_tp = torch.empty(21, 3, device=dev) if hand else None
+        g_bt = torch.zeros(21, 4, 4, device=dev) if hand else None
+        g_tp = torch.zeros(21, 3, device=dev) if hand else None
         need = lib.hn_render_single_bwd_workspace_bytes(f.handle, B, S)
         ws = ren._ws_train.get(need, dev)
         L.check(lib.hn_render_single_bwd(f.handle, L.ptr(ro), L.ptr(rd), B, S, ctx.sample_dist, L.ptr(bt), L.ptr(tp), L.ptr(z), L.ptr(gc),

@@ -376,3 +376,48 @@ def test_repack_is_bit_reproducible_and_eval_only_equals_full(kind):
     out = evaluate(again)
     record('repack %s: eval-only re-pack vs first pack (max abs diff)' % kind, float((out - ref).abs().max()), 0.0, kind='abs')
     assert torch.equal(out, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['obj', 'hand'])
+def test_train_iteration_ragged_and_empty_batches(golden, kind):
+    """Sizes that do not fill a tile, a slice or a wave: 3 rays x 128 samples against the float64 evaluation of the
+    same iteration at the product's own depths (bound: 4x the float32 evaluation's own distance, as above), and an
+    empty batch (zero gradients, no launch)."""
+    from honerf_amd import training
+    from oracle.train import core_iteration, trainable_field
+    g = dict(golden('train_' + kind))
+    for k in ('rays_o', 'rays_d', 't_rand', 'true_rgb', 'true_mask'):
+        g[k] = g[k][:3]
+    ren, out, terms, grads = _product_iteration(kind, g, 'f16x3', False)
+    z = ren.last_z_vals.cpu().numpy()
+    sd = state_dicts()
+    var = VAR_OBJ if kind == 'obj' else VAR_HAND
+    kw = dict(Ro=g['Ro'], To=g['To']) if kind == 'obj' else dict(bt_inv=g['bt_inv'], T_pose=g['T_pose'])
+    sample_dist = float(np.float32((float(g['far']) - float(g['near'])) / int(g['n_samples'])))
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        field, leaves = trainable_field(kind, sd['sdf_' + kind], sd['color_' + kind], var, dtype=dt)
+        _, t_or, g_or = core_iteration(field, leaves, g['rays_o'], g['rays_d'], z, sample_dist, g['true_rgb'], g['true_mask'],
+                                       float(g['igr_weight']), float(g['mask_weight']), **kw)
+        res[dt] = (t_or, g_or)
+    t64, g64 = res[torch.float64]
+    _, g32 = res[torch.float32]
+    assert_close(terms['loss'].reshape(()), t64['loss'].reshape(()), 1e-4, 'train %s 3 rays: loss vs fp64' % kind)
+    for name, ref in g64.items():
+        e = rel_err(grads[name].detach().cpu().double().numpy().reshape(ref.shape), ref.numpy())
+        floor = rel_err(g32[name].double().numpy(), ref.numpy())
+        bound = max(1e-4, min(4.0 * floor, 5e-3))
+        record('train %s 3 rays %s (fp32 autograd vs fp64: %.1e)' % (kind, name, floor), e, bound)
+        assert e <= bound, '%s: %.3e > %.1e' % (name, e, bound)
+    # empty batch
+    dev = torch.device('cuda:0')
+    e3 = torch.empty(0, 3, device=dev)
+    c = lambda k: t(g[k]).to(dev)
+    bt, tp, Ro, To = (None, None, c('Ro'), c('To')) if kind == 'obj' else (c('bt_inv'), c('T_pose'), None, None)
+    out0 = training.render_train(ren, e3, e3, 0.4, 1.5, bt, tp, None, Ro, To, t_rand=torch.empty(0, 1, device=dev))
+    assert out0['color_fine'].shape == (0, 3)
+    for p in training.trainable_parameters(ren):
+        p.grad = None
+    (out0['color_fine'].sum() + out0['weight_sum'].sum()).backward()
+    assert all(float(p.grad.abs().max()) == 0.0 for p in training.trainable_parameters(ren))
