@@ -458,6 +458,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
 
 hipError_t pool_alloc(void** p, size_t bytes);   // hn_pack.hip
 void pool_free(void* p);
+size_t pool_trim();
 namespace bwd {
 typedef std::function<int(const float* z8, const float* grad, const float* rgb_pre)> MidHook;
 size_t field_bwd_workspace_bytes(const hn_field* f, int n);
@@ -702,6 +703,7 @@ int hn_field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, 
                                    g_rgb, g_pts, g_rays_d, g_bt_inv, g_T_pose, workspace, workspace_bytes,
                                    reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, nullptr);
 }
+size_t hn_release_cached_memory(void) { return hn::pool_trim(); }
 size_t hn_field_param_floats(const hn_field* f) { return (f == nullptr || f->raw == nullptr) ? 0 : f->raw_floats; }
 int hn_field_param_offset(const hn_field* f, int net, int layer, size_t* w_off, size_t* b_off, int* out_dim, int* in_dim, int* ld) {
     HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");

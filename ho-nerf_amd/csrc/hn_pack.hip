@@ -53,6 +53,20 @@ hipError_t pool_alloc(void** p, size_t bytes) {
     }
     return e;
 }
+size_t pool_trim() {   // hn_release_cached_memory: every cached (released) block back to the driver
+    std::vector<void*> blocks;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (auto& kv : g_pool_free) {
+            blocks.push_back(kv.second);
+            bytes += kv.first.bytes;
+        }
+        g_pool_free.clear();
+    }
+    for (void* p : blocks) (void)hipFree(p);
+    return bytes;
+}
 void pool_free(void* p) {
     if (p == nullptr) return;
     std::lock_guard<std::mutex> lk(g_pool_mu);

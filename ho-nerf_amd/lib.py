@@ -93,6 +93,7 @@ SIGNATURES = {
     'hn_render_dual_bwd': (c_i, [c_vp, c_vp, c_f, c_f, c_i, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
                                  c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp, c_vp]),
     'hn_render_dual_tape_bytes': (c_sz, [c_vp, c_vp, c_i, c_i]),
+    'hn_release_cached_memory': (c_sz, []),
     'hn_field_param_floats': (c_sz, [c_vp]),
     'hn_field_param_offset': (c_i, [c_vp, c_i, c_i, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz), ctypes.POINTER(c_i),
                                     ctypes.POINTER(c_i), ctypes.POINTER(c_i)]),

@@ -28,7 +28,8 @@ from . import lib as _lib
 
 def trainable_parameters(renderer):
     """The parameters `exp_runner` hands to Adam (exp_runner.py:97-103), in the fixed order SingleRenderFn uses:
-    per SDF layer (weight_g, weight_v, bias), per colour layer the same, then `variance`."""
+    per SDF layer (weight_g, weight_v, bias), per colour layer the same, then `variance`.  (`se3_refine`, the other
+    parameter of sdf_network, enters the render through `Ro / To` or `bt_inv` and receives its gradient from there.)"""
     ps = []
     for net in (renderer.sdf_network, renderer.color_network):
         for lin in net.layers():
@@ -133,6 +134,9 @@ class SingleRenderFn(torch.autograd.Function):
         g_bt = torch.zeros(21, 4, 4, device=dev) if hand else None
         g_tp = torch.zeros(21, 3, device=dev) if hand else None
         need = lib.hn_render_single_bwd_workspace_bytes(f.handle, B, S)
+        if not hasattr(ren, '_ws_train'):
+            from .renderer import _Workspace
+            ren._ws_train = _Workspace()
         ws = ren._ws_train.get(need, dev)
         L.check(lib.hn_render_single_bwd(f.handle, L.ptr(ro), L.ptr(rd), B, S, ctx.sample_dist, L.ptr(bt), L.ptr(tp), L.ptr(z), L.ptr(gc),
                                          L.ptr(gw), L.ptr(ge), L.ptr(g_params), L.ptr(g_inv_s), L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_bt),

@@ -85,6 +85,9 @@ int hn_device_cus(void);
 int hn_field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* color, float variance, float scale,
                     int precision, hn_field** out, hn_stream_t stream);
 int hn_field_destroy(hn_field* f);
+/* Returns the device blocks that destroyed fields left in the cache to the driver (hipFree: synchronises the device);
+ * -> bytes released.  Optional: the cache is bounded by what this process's fields have held. */
+size_t hn_release_cached_memory(void);
 /* clip(exp(10 * variance), 1e-6, 1e6): utils/renderer.py:144. */
 float hn_field_inv_s(const hn_field* f);
 

@@ -421,3 +421,22 @@ def test_train_iteration_ragged_and_empty_batches(golden, kind):
         p.grad = None
     (out0['color_fine'].sum() + out0['weight_sum'].sum()).backward()
     assert all(float(p.grad.abs().max()) == 0.0 for p in training.trainable_parameters(ren))
+
+
+@pytest.mark.gpu
+def test_release_cached_memory():
+    """hn_release_cached_memory: a destroyed field's device blocks sit in the cache (so that a re-pack allocates nothing)
+    until released; packing works again afterwards."""
+    from honerf_amd import lib as L
+    from honerf_amd.nets import PackedField
+    lib = L.load()
+    sd = state_dicts()
+    lib.hn_release_cached_memory()
+    f = PackedField('obj', sd['sdf_obj'], sd['color_obj'], VAR_OBJ, eval_only=True)
+    del f
+    released = lib.hn_release_cached_memory()
+    assert released > 1 << 20, released
+    assert lib.hn_release_cached_memory() == 0
+    f = PackedField('obj', sd['sdf_obj'], sd['color_obj'], VAR_OBJ, eval_only=True)
+    s = f.sdf(torch.zeros(4, 3, device='cuda:0'))
+    assert torch.isfinite(s).all()
