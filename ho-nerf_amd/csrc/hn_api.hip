@@ -460,6 +460,7 @@ hipError_t pool_alloc(void** p, size_t bytes);   // hn_pack.hip
 void pool_free(void* p);
 size_t pool_trim();
 namespace bwd {
+int weight_norm_bwd(const hn_field*, const hn_mlp_desc*, const hn_mlp_desc*, const float*, const hn_mlp_desc*, const hn_mlp_desc*, hipStream_t);
 typedef std::function<int(const float* z8, const float* grad, const float* rgb_pre)> MidHook;
 size_t field_bwd_workspace_bytes(const hn_field* f, int n);
 int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
@@ -704,6 +705,10 @@ int hn_field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, 
                                    reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, nullptr);
 }
 size_t hn_release_cached_memory(void) { return hn::pool_trim(); }
+int hn_weight_norm_bwd(const hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* color, const float* g_params,
+                       const hn_mlp_desc* g_sdf, const hn_mlp_desc* g_color, hn_stream_t stream) {
+    return hn::bwd::weight_norm_bwd(f, sdf, color, g_params, g_sdf, g_color, reinterpret_cast<hipStream_t>(stream));
+}
 size_t hn_field_param_floats(const hn_field* f) { return (f == nullptr || f->raw == nullptr) ? 0 : f->raw_floats; }
 int hn_field_param_offset(const hn_field* f, int net, int layer, size_t* w_off, size_t* b_off, int* out_dim, int* in_dim, int* ld) {
     HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");

@@ -1082,6 +1082,69 @@ int color_forward(const hn_field* f, const float* x, const float* view_dirs, con
     return HN_OK;
 }
 
+// ---- weight-norm chain rule (the last step of a training iteration's backward pass; utils/fields.py:113-121) -----------
+// W[r, :] = g[r] v[r, :] / |v[r, :]|: from dW (row pitch ld, the layout of g_params) one workgroup per row forms
+//   dg[r] = dW[r, :] . vhat,   dv[r, :] = (g[r] / |v|) (dW[r, :] - vhat (dW[r, :] . vhat)),   db[r] = dB[r]
+// (what torch's `_weight_norm` backward computes).  g == NULL: a plain nn.Linear, dv = dW.
+__global__ __launch_bounds__(256) void k_weight_norm_bwd(const float* __restrict__ g, const float* __restrict__ v, const float* __restrict__ dW,
+                                                         const float* __restrict__ dB, int cols, int ld, float* __restrict__ dg,
+                                                         float* __restrict__ dv, float* __restrict__ db) {
+    __shared__ float red[2][4];
+    const int r = blockIdx.x, t = threadIdx.x;
+    const float* vr = v + (size_t)r * cols;
+    const float* wr = dW + (size_t)r * ld;
+    if (t == 0 && db != nullptr) db[r] = dB[r];
+    if (g == nullptr) {
+        for (int c = t; c < cols; c += 256) dv[(size_t)r * cols + c] = wr[c];
+        return;
+    }
+    float n2 = 0.f, dot = 0.f;
+    for (int c = t; c < cols; c += 256) {
+        const float x = vr[c];
+        n2 = fmaf(x, x, n2);
+        dot = fmaf(wr[c], x, dot);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        n2 += __shfl_xor(n2, o);
+        dot += __shfl_xor(dot, o);
+    }
+    if ((t & 63) == 0) {
+        red[0][t >> 6] = n2;
+        red[1][t >> 6] = dot;
+    }
+    __syncthreads();
+    n2 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    dot = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float nrm = sqrtf(n2), proj = dot / nrm, k = g[r] / nrm;
+    if (t == 0) dg[r] = proj;
+    for (int c = t; c < cols; c += 256) dv[(size_t)r * cols + c] = k * (wr[c] - (vr[c] / nrm) * proj);
+}
+
+int weight_norm_bwd(const hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col, const float* g_params, const hn_mlp_desc* g_sdf,
+                    const hn_mlp_desc* g_col, hipStream_t s) {
+    HN_REQUIRE(f != nullptr && f->raw != nullptr && sdf && col && g_params && g_sdf && g_col, "null argument");
+    const float* base = reinterpret_cast<const float*>(f->raw);
+    for (int net = 0; net < 2; ++net) {
+        const hn_mlp_desc* d = net == 0 ? sdf : col;
+        const hn_mlp_desc* o = net == 0 ? g_sdf : g_col;
+        const int nl = net == 0 ? 9 : 5;
+        HN_REQUIRE(d->n_layers == nl && o->n_layers == nl, "layer count");
+        for (int l = 0; l < nl; ++l) {
+            const int rows = net == 0 ? f->sdf_out[l] : f->col_out[l], cols = net == 0 ? f->sdf_in[l] : f->col_in[l];
+            const int ld = net == 0 ? f->sdf_ld[l] : f->col_ld[l];
+            HN_REQUIRE(d->out_dim[l] == rows && d->in_dim[l] == cols, "shape of layer %d differs from the packed field", l);
+            const float* dW = g_params + ((net == 0 ? f->raw_sdf_w[l] : f->raw_col_w[l]) - base);
+            const float* dB = g_params + ((net == 0 ? f->raw_sdf_b[l] : f->raw_col_b[l]) - base);
+            HN_REQUIRE(o->weight_v[l] != nullptr && (d->weight_g[l] == nullptr || o->weight_g[l] != nullptr), "missing output of layer %d", l);
+            hipLaunchKernelGGL(k_weight_norm_bwd, dim3(rows), dim3(256), 0, s, d->weight_g[l], d->weight_v[l], dW, dB, cols, ld,
+                               const_cast<float*>(o->weight_g[l]), const_cast<float*>(o->weight_v[l]), const_cast<float*>(o->bias[l]));
+        }
+    }
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
 // ---- nearest candidate vertex (get_stable_loss_cross: scipy cKDTree.query(k=1), utils/renderer_batch.py:355-358) ------
 // One wave per (set t, query vertex i) with query_mask[t,i] != 0: argmin over the vertices j with cand_mask[t,j] != 0
 // of |p_i - p_j|^2 (ties: lowest j); selected[t, argmin] = 1 (the np.unique of the reference = a set).  A few thousand

@@ -99,6 +99,8 @@ SIGNATURES = {
                                     ctypes.POINTER(c_i), ctypes.POINTER(c_i)]),
     'hn_field_param_bwd': (c_i, [c_vp, c_f, c_f, c_i, c_i, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz,
                                  c_vp]),
+    'hn_weight_norm_bwd': (c_i, [c_vp, ctypes.POINTER(MlpDesc), ctypes.POINTER(MlpDesc), c_f, ctypes.POINTER(MlpDesc),
+                                 ctypes.POINTER(MlpDesc), c_vp]),
     'hn_render_single_bwd_workspace_bytes': (c_sz, [c_vp, c_i, c_i]),
     'hn_render_single_bwd': (c_i, [c_vp, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp,
                                    c_sz, c_vp]),

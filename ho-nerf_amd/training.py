@@ -11,9 +11,8 @@ backward pass runs through `render_core` at the final depths only: here one call
   * d loss / d inv_s (inv_s = exp(10 variance)),
   * d loss / d rays (field frame), d loss / d bt_inv, T_pose (hand).
 
-What is left for the host is element-wise over the parameter blocks: the weight-norm chain rule
-(d/d weight_g, d/d weight_v from d/d W; old-style `nn.utils.weight_norm`, dim 0) and the optimiser (torch's Adam, as the
-reference).  The VGG term of exp_runner.py:213-224 stays a torch module on `color_fine` ("gated on VGG loss
+The weight-norm chain rule (d/d weight_g, d/d weight_v from d/d W; old-style `nn.utils.weight_norm`, dim 0) is one more
+call (`hn_weight_norm_bwd`, all 14 layers); what is left for the host is the optimiser (torch's Adam, as the reference).  The VGG term of exp_runner.py:213-224 stays a torch module on `color_fine` ("gated on VGG loss
 staying in torch"); it composes with this Function through autograd like any other loss on the render outputs.
 """
 import ctypes
@@ -61,7 +60,8 @@ def folded_gradients(lib, field, g_params):
 
 def weight_norm_backward(g, v, dW):
     """d/d weight_g [out,1], d/d weight_v [out,in] from d/d W for W = g v / |v| (row norms; torch's `_weight_norm`
-    backward, utils/fields.py:113-121 `nn.utils.weight_norm(lin)`)."""
+    backward, utils/fields.py:113-121 `nn.utils.weight_norm(lin)`).  The torch statement of what hn_weight_norm_bwd
+    computes on the device for all layers at once (kept for callers that hold folded gradients, and for the tests)."""
     nrm = v.norm(dim=1, keepdim=True)
     vh = v / nrm
     proj = (dW * vh).sum(dim=1, keepdim=True)
@@ -141,12 +141,26 @@ class SingleRenderFn(torch.autograd.Function):
         L.check(lib.hn_render_single_bwd(f.handle, L.ptr(ro), L.ptr(rd), B, S, ctx.sample_dist, L.ptr(bt), L.ptr(tp), L.ptr(z), L.ptr(gc),
                                          L.ptr(gw), L.ptr(ge), L.ptr(g_params), L.ptr(g_inv_s), L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_bt),
                                          L.ptr(g_tp), L.ptr(ws), need, L.stream_ptr()), 'hn_render_single_bwd')
-        # weight-norm chain rule per layer, in the parameter order of trainable_parameters()
-        grads = []
-        layers = list(ren.sdf_network.layers()) + list(ren.color_network.layers())
-        for lin, (dW, db) in zip(layers, folded_gradients(lib, f, g_params)):
-            dg, dv = weight_norm_backward(lin.weight_g.detach(), lin.weight_v.detach(), dW)
-            grads += [dg, dv, db.clone()]
+        # weight-norm chain rule of all 14 layers: one C-ABI call (hn_weight_norm_bwd), outputs in the parameter order of
+        # trainable_parameters()
+        from .nets import _mlp_desc
+        keep = []
+        d_sdf = _mlp_desc(ren.sdf_network.state_dict(), keep)
+        d_col = _mlp_desc(ren.color_network.state_dict(), keep)
+        grads, descs = [], []
+        for net in (ren.sdf_network, ren.color_network):
+            d = L.MlpDesc()
+            layers = net.layers()
+            d.n_layers = len(layers)
+            for l, lin in enumerate(layers):
+                dg, dv, db = torch.empty_like(lin.weight_g), torch.empty_like(lin.weight_v), torch.empty_like(lin.bias)
+                d.weight_g[l], d.weight_v[l], d.bias[l] = dg.data_ptr(), dv.data_ptr(), db.data_ptr()
+                d.out_dim[l], d.in_dim[l] = lin.weight_v.shape
+                grads += [dg, dv, db]
+            descs.append(d)
+        L.check(lib.hn_weight_norm_bwd(f.handle, ctypes.byref(d_sdf), ctypes.byref(d_col), L.ptr(g_params), ctypes.byref(descs[0]),
+                                       ctypes.byref(descs[1]), L.stream_ptr()), 'hn_weight_norm_bwd')
+        del keep
         # inv_s = clip(exp(10 variance), 1e-6, 1e6) (utils/fields.py:248-249, utils/renderer.py:144)
         inv_s = float(f.inv_s)
         grads.append((g_inv_s * (10.0 * inv_s if 1e-6 < inv_s < 1e6 else 0.0)).reshape(()))

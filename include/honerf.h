@@ -390,6 +390,12 @@ int hn_field_param_bwd(const hn_field* f, const float* pts, const float* rays_d,
                        const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf,
                        const float* g_grad, const float* g_rgb, float* g_params, float* g_pts, float* g_rays_d,
                        float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes, hn_stream_t stream);
+/* The weight-norm chain rule for all 14 layers (utils/fields.py:113-121; torch's `_weight_norm` backward): from g_params
+ * (the layout above) and the current parameters `sdf` / `color` (as given to hn_field_create) to the gradients of
+ * weight_g [out,1], weight_v [out,in] and bias [out], written through the pointers of `g_sdf` / `g_color` (same struct;
+ * its pointers are OUTPUTS here).  A layer without weight_g (plain nn.Linear) gets d/d weight = dW in weight_v. */
+int hn_weight_norm_bwd(const hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* color, const float* g_params,
+                       const hn_mlp_desc* g_sdf, const hn_mlp_desc* g_color, hn_stream_t stream);
 size_t hn_render_single_bwd_workspace_bytes(const hn_field* f, int n_rays, int samples_per_ray);
 int hn_render_single_bwd(const hn_field* f, const float* rays_o, const float* rays_d, int n_rays, int samples_per_ray,
                          float sample_dist, const float* bt_inv, const float* T_pose, const float* z_vals,

@@ -65,8 +65,7 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3'):
     g = torch.Generator(device='cpu').manual_seed(5)
     true_rgb = torch.rand(n_rays, 3, generator=g).to(dev)
     true_mask = (torch.rand(n_rays, 1, generator=g) > 0.3).float().to(dev)
-    params = training.trainable_parameters(ren)
-    opt = torch.optim.Adam(params, lr=1e-4)          # exp_runner.py:97-104, confs learning_rate = 1e-4
+    opt = training.make_optimizer(ren, 1e-4)          # exp_runner.py:107-110, confs learning_rate = 1e-4
 
     def step(parts=None):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
