@@ -146,6 +146,12 @@ class NeuSRenderer:
 
     # the renderer keeps references to the modules (utils/renderer.py:50-52); the packed copy is
     # rebuilt lazily whenever their parameters change (checkpoints are loaded after construction)
+    def mark_parameters_changed(self):
+        """Forces a re-pack at the next call.  `field()` notices in-place parameter updates through the tensors' version
+        counters; a fused optimiser step (`torch.optim.Adam(fused=True)`) does not advance them, so the training path
+        (training.render_train) calls this before every render instead of relying on them."""
+        self._version = None
+
     def field(self):
         eval_only = bool(getattr(self, 'pack_eval_only', False))      # set by training.render_train
         ver = params_version(self.sdf_network, self.color_network, self.deviation_network) + (self.precision, eval_only)

@@ -200,11 +200,14 @@ class ObjLocalFn(torch.autograd.Function):
         return g_ro.reshape(s[0]), g_rd.reshape(s[1]), g_R.reshape(s[2]), g_T.reshape(s[3])
 
 
-def render_train(renderer, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, Ro, To, index=0, t_rand=None, z_vals=None):
+def render_train(renderer, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, Ro, To, index=0, t_rand=None, z_vals=None,
+                 repack=True):
     """`NeuSRenderer.render` (utils/renderer.py:190-258) as a differentiable function of the networks' parameters (and of
     bt_inv / T_pose_21 for the hand, Ro / To for the object through `convert_obj_to_local`): the render of a training
     step (exp_runner.py:196-201).  Same return keys as `render`.  With `z_vals` [B,S] the sampling is skipped and
-    `render_core` runs at those depths (utils/renderer.py:107-177)."""
+    `render_core` runs at those depths (utils/renderer.py:107-177).  The field is re-packed from the modules' current
+    parameters first (`repack=False`: the caller has just done so): a training render follows an optimiser step, and a
+    fused step does not advance the version counters `renderer.field()` watches."""
     from .renderer import _Workspace
     if renderer.perturb <= 0:
         raise ValueError('render requires perturb > 0, as the reference does')
@@ -212,6 +215,8 @@ def render_train(renderer, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, 
         renderer._ws_train = _Workspace()
     renderer.index = index
     renderer.pack_eval_only = True     # the per-step re-pack builds the evaluation programs only (HN_PACK_EVAL_ONLY)
+    if repack:
+        renderer.mark_parameters_changed()
     dev = rays_o.device
     if renderer.model_type == 'obj':
         rays_o, rays_d = ObjLocalFn.apply(rays_o, rays_d, torch.as_tensor(Ro, device=dev), torch.as_tensor(To, device=dev))

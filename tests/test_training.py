@@ -191,7 +191,9 @@ def test_train_step_decreases_loss():
     sdf_net.reset_parameters(SEEDS['sdf_obj'])
     col_net.reset_parameters(SEEDS['color_obj'])
     ren = NeuSRenderer(sdf_net, var, col_net, 'obj', 64, 64, 0, 4, 1.0)
-    opt = torch.optim.Adam(training.trainable_parameters(ren), lr=5e-4)
+    # the fused multi-tensor Adam of training.make_optimizer: its in-place update does not advance the parameters'
+    # version counters, which is why render_train re-packs unconditionally
+    opt = training.make_optimizer(ren, 5e-4)
     c = lambda k: t(g[k]).to(dev)
     losses = []
     for _ in range(6):

@@ -70,9 +70,10 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3'):
     def step(parts=None):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
+        ren.mark_parameters_changed()
         ren.field()                                   # re-pack of the weights the previous step updated
         ev[1].record()
-        out = training.render_train(ren, o, d, 0.4, 1.5, ex['bt_inv'], ex['T_pose'], None, ex['Ro'], ex['To'])
+        out = training.render_train(ren, o, d, 0.4, 1.5, ex['bt_inv'], ex['T_pose'], None, ex['Ro'], ex['To'], repack=False)
         terms = training.train_loss(out, true_rgb, true_mask, 1.0, 1.0)
         ev[2].record()
         opt.zero_grad(set_to_none=True)
