@@ -442,3 +442,44 @@ def test_release_cached_memory():
     f = PackedField('obj', sd['sdf_obj'], sd['color_obj'], VAR_OBJ, eval_only=True)
     s = f.sdf(torch.zeros(4, 3, device='cuda:0'))
     assert torch.isfinite(s).all()
+
+
+@pytest.mark.gpu
+def test_weight_norm_bwd_kernel_matches_autograd():
+    """hn_weight_norm_bwd (all 14 layers, one call) against float64 autograd through torch._weight_norm on random
+    folded gradients in the library's padded layout."""
+    import ctypes
+    from honerf_amd import lib as L
+    from honerf_amd import training
+    from honerf_amd.nets import PackedField, _mlp_desc
+    lib = L.load()
+    dev = torch.device('cuda:0')
+    sd = state_dicts()
+    pf = PackedField('hand', sd['sdf_hand'], sd['color_hand'], VAR_HAND, eval_only=True)
+    gen = torch.Generator().manual_seed(8)
+    g_params = torch.randn(lib.hn_field_param_floats(pf.handle), generator=gen).to(dev)
+    keep = []
+    d_sdf, d_col = _mlp_desc(sd['sdf_hand'], keep), _mlp_desc(sd['color_hand'], keep)
+    outs, descs = [], []
+    for key, n_layers in (('sdf_hand', 9), ('color_hand', 5)):
+        d = L.MlpDesc()
+        d.n_layers = n_layers
+        for l in range(n_layers):
+            v = sd[key]['lin%d.weight_v' % l]
+            dg, dv, db = torch.empty(v.shape[0], 1, device=dev), torch.empty(*v.shape, device=dev), torch.empty(v.shape[0], device=dev)
+            d.weight_g[l], d.weight_v[l], d.bias[l] = dg.data_ptr(), dv.data_ptr(), db.data_ptr()
+            d.out_dim[l], d.in_dim[l] = v.shape
+            outs.append((key, l, dg, dv, db))
+        descs.append(d)
+    L.check(lib.hn_weight_norm_bwd(pf.handle, ctypes.byref(d_sdf), ctypes.byref(d_col), L.ptr(g_params), ctypes.byref(descs[0]),
+                                   ctypes.byref(descs[1]), L.stream_ptr()), 'hn_weight_norm_bwd')
+    folded = training.folded_gradients(lib, pf, g_params)
+    worst = 0.0
+    for (key, l, dg, dv, db), (dW, dB) in zip(outs, folded):
+        v = torch.from_numpy(sd[key]['lin%d.weight_v' % l]).double().requires_grad_(True)
+        g = torch.from_numpy(sd[key]['lin%d.weight_g' % l]).double().requires_grad_(True)
+        rg, rv = torch.autograd.grad(torch._weight_norm(v, g, 0), [g, v], dW.double().cpu())
+        worst = max(worst, rel_err(dg.cpu().numpy(), rg.numpy()), rel_err(dv.cpu().numpy(), rv.numpy()))
+        assert torch.equal(db, dB)
+    record('hn_weight_norm_bwd vs float64 autograd (14 layers)', worst, 1e-5)
+    assert worst <= 1e-5, worst
