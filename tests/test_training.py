@@ -483,3 +483,30 @@ def test_weight_norm_bwd_kernel_matches_autograd():
         assert torch.equal(db, dB)
     record('hn_weight_norm_bwd vs float64 autograd (14 layers)', worst, 1e-5)
     assert worst <= 1e-5, worst
+
+
+@pytest.mark.gpu
+def test_extra_torch_loss_composes_with_render_train(golden):
+    """A torch term on the render outputs (the place of the VGG loss, exp_runner.py:213-224) back-propagates through
+    SingleRenderFn like the built-in terms: with L = L0 + w * mean(color_fine^2) the parameter gradients are
+    g(L0) + w * g(mean(color_fine^2)) (linearity of the backward pass in the upstream gradients)."""
+    g = golden('train_obj')
+
+    def grads_for(loss_fn):
+        from honerf_amd import training
+        ren, out, _, _ = _product_iteration('obj', g, 'f16x3', True)
+        ps = training.trainable_parameters(ren)
+        for p in ps:
+            p.grad = None
+        out = training.render_train(ren, t(g['rays_o']).cuda(), t(g['rays_d']).cuda(), 0.4, 1.5, None, None, None, t(g['Ro']).cuda(),
+                                    t(g['To']).cuda(), z_vals=t(g['z_vals']).cuda())
+        loss_fn(out).backward()
+        return torch.cat([p.grad.reshape(-1) for p in ps]).double().cpu()
+
+    base = lambda o: o['weight_sum'].sum() * 0.01 + o['gradient_error']
+    extra = lambda o: (o['color_fine'] ** 2).mean()
+    g0, g1, g01 = grads_for(base), grads_for(extra), grads_for(lambda o: base(o) + 3.0 * extra(o))
+    e = rel_err((g0 + 3.0 * g1).numpy(), g01.numpy())
+    record('render_train: gradient of base + 3 extra vs g(base) + 3 g(extra)', e, 2e-5)
+    assert e <= 2e-5, e
+    assert float(g1.abs().max()) > 0
