@@ -344,3 +344,53 @@ def load_checkpoint(path, renderer, optimizer=None, map_location=None):
     if optimizer is not None and 'optimizer' in ckpt:
         optimizer.load_state_dict(ckpt['optimizer'])
     return int(ckpt['iter_step'])
+
+
+def latest_checkpoint(base_exp_dir):
+    """The newest `checkpoints/ckpt_*.pth` (exp_runner.py:112-123 picks the last one by name when `is_continue`)."""
+    d = os.path.join(base_exp_dir, 'checkpoints')
+    if not os.path.isdir(d):
+        return None
+    names = sorted(n for n in os.listdir(d) if n.startswith('ckpt_') and n.endswith('.pth'))
+    return os.path.join(d, names[-1]) if names else None
+
+
+def train(renderer, batches, end_iter, base_exp_dir, learning_rate=1e-4, learning_rate_alpha=0.05, warm_up_end=5000,
+          igr_weight=1.0, mask_weight=1.0, near=0.4, far=1.5, save_freq=10000, report_freq=100, is_continue=False,
+          extra_loss=None, step_fn=None, dist=None):
+    """The loop of exp_runner.train (exp_runner.py:126-264) without its dataset side: `batches` yields dicts with
+    `rays_o, rays_d [B,3], true_rgb [B,3], true_mask [B,1]` and the frame's `bt_inv, T_pose_21` (hand) or `Ro, To`
+    (object) -- what exp_runner.py:136-201 prepares per iteration.  Learning-rate schedule, checkpoints (same keys and
+    names, resumable with `is_continue`) and one JSON line of metrics per `report_freq` iterations in
+    `<base_exp_dir>/metrics.jsonl` (the scalars the reference sends to TensorBoard, :233-241).  `step_fn` replaces
+    `train_step` in host-only tests."""
+    import json
+    step_fn = step_fn or train_step
+    optimizer = make_optimizer(renderer, learning_rate)
+    iter_step = 0
+    if is_continue:
+        ck = latest_checkpoint(base_exp_dir)
+        if ck is not None:
+            iter_step = load_checkpoint(ck, renderer)      # networks and iteration count; Adam's moments restart, as in the reference (:288-293)
+    os.makedirs(base_exp_dir, exist_ok=True)
+    log_path = os.path.join(base_exp_dir, 'metrics.jsonl')
+    update_learning_rate(optimizer, iter_step, learning_rate, warm_up_end, end_iter, learning_rate_alpha)
+    it = iter(batches)
+    while iter_step < end_iter:
+        try:
+            b = next(it)
+        except StopIteration:          # one epoch of the dataloader is over: start the next (exp_runner.py:133-134)
+            it = iter(batches)
+            b = next(it)
+        terms = step_fn(renderer, optimizer, b['rays_o'], b['rays_d'], near, far, b.get('bt_inv'), b.get('T_pose_21'), b.get('Ro'),
+                        b.get('To'), b['true_rgb'], b['true_mask'], igr_weight, mask_weight, extra_loss=extra_loss, dist=dist)
+        iter_step += 1
+        if iter_step % report_freq == 0:
+            rec = {'iter': iter_step, 'lr': optimizer.param_groups[0]['lr']}
+            rec.update({k: float(v.detach()) if isinstance(v, torch.Tensor) else float(v) for k, v in terms.items()})
+            with open(log_path, 'a') as f:
+                f.write(json.dumps(rec) + '\n')
+        if iter_step % save_freq == 0:
+            save_checkpoint(base_exp_dir, renderer, optimizer, iter_step)
+        update_learning_rate(optimizer, iter_step, learning_rate, warm_up_end, end_iter, learning_rate_alpha)
+    return iter_step

@@ -8,6 +8,8 @@ Measure: max |a - b| / max |b| per parameter tensor (the north star's "relative 
 over ~5 000 samples of products of fp32 signals; the bounds below are <= 4x the errors observed on MI355X
 (profiles/r02/parity_report.json) and each is recorded there.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -510,3 +512,37 @@ def test_extra_torch_loss_composes_with_render_train(golden):
     record('render_train: gradient of base + 3 extra vs g(base) + 3 g(extra)', e, 2e-5)
     assert e <= 2e-5, e
     assert float(g1.abs().max()) > 0
+
+
+def test_train_loop_logs_checkpoints_and_resumes(tmp_path):
+    """training.train with a host-only step: the learning-rate schedule follows the iteration count, metrics.jsonl gets
+    one line per report interval, checkpoints are written every save_freq iterations and `is_continue` resumes from the
+    newest one (exp_runner.py:112-123, 126-264)."""
+    import json
+    from honerf_amd import training
+    from honerf_amd.nets import RenderingNetwork_OBJ, SDFNetwork_OBJ, SingleVarianceNetwork
+
+    class R:
+        pass
+    r = R()
+    r.sdf_network, r.color_network, r.deviation_network = SDFNetwork_OBJ(), RenderingNetwork_OBJ(), SingleVarianceNetwork(0.3)
+    seen = []
+
+    def fake_step(renderer, optimizer, *a, **k):
+        seen.append(optimizer.param_groups[0]['lr'])
+        return {'loss': torch.tensor(1.0 / (len(seen))), 'psnr': 20.0}
+
+    batch = dict(rays_o=None, rays_d=None, true_rgb=None, true_mask=None, Ro=None, To=None)
+    n = training.train(r, [batch, batch, batch], 10, str(tmp_path), learning_rate=1e-3, learning_rate_alpha=0.1, warm_up_end=4,
+                       save_freq=5, report_freq=2, step_fn=fake_step)
+    assert n == 10 and len(seen) == 10
+    for i, lr in enumerate(seen):
+        assert abs(lr - 1e-3 * training.learning_rate_factor(i, 4, 10, 0.1)) < 1e-12
+    lines = [json.loads(x) for x in open(tmp_path / 'metrics.jsonl')]
+    assert [x['iter'] for x in lines] == [2, 4, 6, 8, 10] and abs(lines[0]['loss'] - 0.5) < 1e-7
+    assert sorted(os.listdir(tmp_path / 'checkpoints')) == ['ckpt_000005.pth', 'ckpt_000010.pth']
+    assert training.latest_checkpoint(str(tmp_path)).endswith('ckpt_000010.pth')
+    seen.clear()
+    n = training.train(r, [batch], 13, str(tmp_path), learning_rate=1e-3, learning_rate_alpha=0.1, warm_up_end=4, save_freq=5,
+                       report_freq=2, is_continue=True, step_fn=fake_step)
+    assert n == 13 and len(seen) == 3          # resumed at iteration 10
