@@ -9,7 +9,11 @@ collective -- the only exchange is the sum of a small loss/metric vector per log
 
 `fitting_video` updates shared pose parameters window by window (fitting_video.py:146-149, 340-342);
 `window_schedule` gives the synchronous window-parallel assignment of SURVEY 8(e) (rank r takes
-window step*world + r); its gradient all-reduce belongs to the backward kernels.
+window step*world + r).  A step is split into `fit_backward` (pose chain -> render -> losses -> backward into
+the pose parameters) and `fit_apply` (one SUM all-reduce of the flattened pose-gradient block, then Adam), so
+that the collective sits between the backward pass and the optimiser; `fit_sequence_video` is the sequence loop
+over them (5 outer iterations x windows x 4 sub-iterations x views) and `fit_frames_sharded` the per-frame loop
+of fitting_single with its skip-if-done restart rule.  With one rank both are the reference's sequential loops.
 """
 import os
 
@@ -117,7 +121,8 @@ class FrameShardedRunner:
             terms = frame_fn(f)
             for k, key in enumerate(LOSS_KEYS[:-1]):
                 if key in terms:
-                    self.totals[k] += float(terms[key])
+                    v = terms[key]
+                    self.totals[k] += float(v.detach()) if isinstance(v, torch.Tensor) else float(v)
             self.totals[-1] += 1
         return self.reduce()
 
@@ -194,6 +199,20 @@ def pose_loss(target, pred, mean=False):
     return err.mean() if mean else err.sum() / err.shape[0]
 
 
+def _index_tensor(owner, index, device):
+    """The window's frame ids as a device tensor, cached on the chain: a window is visited sub_iters x views times per
+    pass, and a fresh host list would be a host -> device copy in front of every step."""
+    if isinstance(index, torch.Tensor):
+        return index.to(device)
+    cache = owner.__dict__.setdefault('_idx_cache', {})
+    key = tuple(int(i) for i in index)
+    if key not in cache:
+        if len(cache) > 4096:
+            cache.clear()
+        cache[key] = torch.tensor(key, dtype=torch.long, device=device)
+    return cache[key]
+
+
 class RigidPoseChain:
     """Host-side differentiable map from the optimised parameters to the renderer's pose inputs.
 
@@ -231,7 +250,7 @@ class RigidPoseChain:
         return [self.obj_rot, self.obj_trans, self.palm_rot, self.palm_trans]
 
     def __call__(self, index=None):
-        idx = slice(None) if index is None else torch.as_tensor(index, device=self.bt_inv0.device)
+        idx = slice(None) if index is None else _index_tensor(self, index, self.bt_inv0.device)
         if self.bt_inv0.is_cuda:
             # one launch (hn_rigid_pose) instead of ~60 operators forward and ~100 backward; the vertex sets are not formed:
             # the losses that used them take the poses (step_loss, honerf_amd.pose.VertsLossFn)
@@ -297,8 +316,8 @@ class HaloPoseChain:
             self.T_pose_21 = self.T_pose_21[:1].expand(n, 21, 3).contiguous()
 
     def param_groups(self, video=False):
-        """fitting_single.py:191-198 (fitting_video.py:177-184 uses 1e-4 for the four rigid leaves)."""
-        lr = (1e-4, 1e-4, 1e-4, 1e-4, 1e-3, 1e-3) if video else (5e-4, 5e-4, 5e-4, 3e-4, 1e-3, 1e-3)
+        """fitting_single.py:191-198; fitting_video.py:177-184: 1e-4 for all leaves but palm_refine_angle (5e-4)."""
+        lr = (1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 5e-4) if video else (5e-4, 5e-4, 5e-4, 3e-4, 1e-3, 1e-3)
         return [{'params': p, 'lr': l} for p, l in zip(self.parameters(), lr)]
 
     def parameters(self):
@@ -310,7 +329,7 @@ class HaloPoseChain:
         return self._fn.apply(self.joints0[idx], self.bone_len[idx], params)
 
     def __call__(self, index=None):
-        idx = slice(None) if index is None else torch.as_tensor(index, device=self.joints0.device)
+        idx = slice(None) if index is None else _index_tensor(self, index, self.joints0.device)
         bt_inv, joint_3d = self._hand(idx)
         if self.joints0.is_cuda:
             from .pose import RigidPoseFn
@@ -392,20 +411,27 @@ def _rays(lib_mod, xy, cam, n_cams, rays_per_cam):
     return o, d
 
 
-def fit_step(renderer, view, pose_chain, optimizer, near, far, fit_type='1', index=None, smooth_ends=(False, False),
-             obj_verts_for_stable=None, t_rand=None):
-    """One optimiser step of the fitting loops: pose chain -> rays of the view's sampled pixels (`_xy_to_ray_bundle` ->
-    hn_ray_gen) -> renderer.render -> losses -> backward into the pose parameters -> Adam step
-    (fitting_single.py:201-291; batched renderer: fitting_video.py:212-342).
+def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None, smooth_ends=(False, False),
+                 obj_verts_for_stable=None, t_rand=None, rays_fn=None):
+    """The forward + backward half of one optimiser step of the fitting loops: pose chain -> rays of the view's sampled
+    pixels (`_xy_to_ray_bundle` -> hn_ray_gen) -> renderer.render -> losses -> backward into the pose parameters
+    (fitting_single.py:201-290; batched renderer: fitting_video.py:212-341).  The parameters' `.grad` are cleared first
+    (`optimizer.zero_grad()` of the reference) and hold this step's gradient afterwards; nothing is applied.
 
     view: dict(cam={'R','T','focal','principal'} device tensors [n_cams,..], xy [n_cams*P,2] NDC, true_rgb, true_mask)
-    with n_cams = 1 for fitting_single and the window's 4 cameras for fitting_video."""
-    from . import lib as L
+    with n_cams = 1 for fitting_single and the window's 4 cameras for fitting_video.  `rays_fn(xy, cam, n_cams, P)`
+    replaces hn_ray_gen (host-logic tests over a stub renderer; the product path never passes it)."""
     video = bool(getattr(renderer, 'batched', False))
+    for p in pose_chain.parameters():
+        p.grad = None
     pose = pose_chain(index)
     n_cams = view['cam']['R'].shape[0]
     P = view['xy'].shape[0] // n_cams
-    rays_o, rays_d = _rays(L, view['xy'], view['cam'], n_cams, P)
+    if rays_fn is None:
+        from . import lib as L
+        rays_o, rays_d = _rays(L, view['xy'], view['cam'], n_cams, P)
+    else:
+        rays_o, rays_d = rays_fn(view['xy'], view['cam'], n_cams, P)
     T_pose = pose['T_pose_21']
     if video:
         Ro_arg = torch.inverse(pose['obj_r'])                                          # fitting_video.py:284
@@ -418,9 +444,28 @@ def fit_step(renderer, view, pose_chain, optimizer, near, far, fit_type='1', ind
     if video and fit_type == '1234':
         stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
     terms = step_loss(out, view['true_rgb'], view['true_mask'], pose, fit_type, video, smooth_ends, stable)
-    optimizer.zero_grad(set_to_none=True)
     terms['loss'].backward()
+    return terms
+
+
+def fit_apply(optimizer, pose_chain=None, dist=None, sync=False):
+    """The second half of a step: with `sync`, one SUM all-reduce of the flattened pose-gradient block over all ranks
+    (`allreduce_pose_gradients`; a rank that had no window this step contributes zeros), then the Adam step
+    (fitting_single.py:291, fitting_video.py:342).  Returns the number of floats exchanged (0 without a collective).
+    With sync every parameter receives a (possibly zero) gradient on every rank, so all replicas take the same step."""
+    n = 0
+    if sync:
+        n = allreduce_pose_gradients(pose_chain.parameters(), dist)
     optimizer.step()
+    return n
+
+
+def fit_step(renderer, view, pose_chain, optimizer, near, far, fit_type='1', index=None, smooth_ends=(False, False),
+             obj_verts_for_stable=None, t_rand=None, rays_fn=None):
+    """One optimiser step of the fitting loops on one rank: `fit_backward` then `fit_apply` without a collective
+    (fitting_single.py:201-291; fitting_video.py:212-342)."""
+    terms = fit_backward(renderer, view, pose_chain, near, far, fit_type, index, smooth_ends, obj_verts_for_stable, t_rand, rays_fn)
+    fit_apply(optimizer)
     return terms
 
 
@@ -436,7 +481,7 @@ def make_optimizer(pose_chain, video=False):
         return torch.optim.Adam(groups)
 
 
-def fit_frame(renderer, views, pose_chain, near, far, fit_type='1', n_iters=None, sample_view=None):
+def fit_frame(renderer, views, pose_chain, near, far, fit_type='1', n_iters=None, sample_view=None, rays_fn=None):
     """fitting_single.py:200-291 for one frame: `n_iters` (30 for fit type '1', 25 for '12'; 40 / 35 with 3 views,
     :124-132) passes over the views, one Adam step per view.  `sample_view(view_id, step) -> view dict` draws the
     step's pixels (the reference: get_rays_xy on the view's mask, 196 rays); default: the views as given."""
@@ -447,26 +492,111 @@ def fit_frame(renderer, views, pose_chain, near, far, fit_type='1', n_iters=None
     for _ in range(n_iters):
         for vid in range(len(views)):
             view = sample_view(vid, step) if sample_view is not None else views[vid]
-            last = fit_step(renderer, view, pose_chain, opt, near, far, fit_type)
+            last = fit_step(renderer, view, pose_chain, opt, near, far, fit_type, rays_fn=rays_fn)
             step += 1
     return last, step
 
 
 def fit_window(renderer, views, pose_chain, optimizer, near, far, index, data_num, fit_type='1234', first_pass=False,
-               obj_verts=None, sample_view=None, sub_iters=4):
+               obj_verts=None, sample_view=None, sub_iters=4, rays_fn=None, n_views=None):
     """fitting_video.py:211-342 for one window of 4 consecutive frames `index`: 4 sub-iterations x the views, an
     Adam step each on the shared [data_num, ..] parameters.  The smoothness term is anchored to the prediction when
     the window touches either end of the sequence (not on the very first step, :312)."""
     last, step = None, 0
     for sub in range(sub_iters):
-        for vid in range(len(views)):
+        for vid in range(n_views if n_views is not None else len(views)):
             view = sample_view(vid, step) if sample_view is not None else views[vid]
             later = not (first_pass and sub == 0 and vid == 0)
             ends = (later and int(index[0]) == 0, later and int(index[-1]) == data_num - 1)
             last = fit_step(renderer, view, pose_chain, optimizer, near, far, fit_type, index=index, smooth_ends=ends,
-                            obj_verts_for_stable=obj_verts)
+                            obj_verts_for_stable=obj_verts, rays_fn=rays_fn)
             step += 1
     return last, step
+
+
+def _dist_state(dist):
+    """(dist module or None, rank, world) of the initialised process group; (None, 0, 1) without one."""
+    if dist is None:
+        import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def fit_sequence_video(renderer, window_views, pose_chain, near, far, data_num, fit_type='1234', outer_iters=5, sub_iters=4,
+                       obj_verts=None, dist=None, optimizer=None, rays_fn=None, on_outer=None):
+    """fitting_video.py:157, 186-342 for a whole sequence of `data_num` frames: `outer_iters` (5) passes over the
+    data_num - 3 sliding windows, per window `sub_iters` (4) x the views, an Adam step each on the shared
+    `[data_num, ..]` pose parameters of `pose_chain`.
+
+    One rank: the reference's strictly sequential schedule.  `world` ranks: the windows of a pass are taken
+    `world` at a time -- at round s rank r owns window s*world + r (`window_schedule`) -- and every one of the round's
+    sub_iters x views steps is `fit_backward` on the rank's own window, ONE all-reduce (SUM) of the data_num x 45 pose
+    gradient block, and the same Adam step on every replica (Jacobi over the `world` concurrent windows instead of
+    Gauss-Seidel; a rank whose window list has run out contributes zeros).  Replicas stay bit-identical.
+
+    window_views(index, view_id, step) -> the view dict of window `index` (list of 4 frame ids) for camera `view_id`
+    (the reference draws 40 mask pixels per frame there, fitting_video.py:261-272); it must also report the number of
+    views as `window_views.n_views`.  on_outer(iter_id) runs after every pass (the reference dumps all poses there,
+    :350-425).  Returns dict(steps, windows, allreduce_calls, allreduce_floats, last=terms of the last step with a window)."""
+    dist, rank, world = _dist_state(dist)
+    if optimizer is None:
+        optimizer = make_optimizer(pose_chain, video=True)
+    sched = window_schedule(data_num, rank, world)
+    n_views = window_views.n_views
+    stats = {'steps': 0, 'windows': 0, 'allreduce_calls': 0, 'allreduce_floats': 0, 'last': None}
+    for iter_id in range(outer_iters):
+        for index in sched:
+            step = 0
+            for sub in range(sub_iters):
+                for vid in range(n_views):
+                    if index is not None:
+                        # fitting_video.py:312, 316: anchored at the sequence ends, not on the very first step
+                        later = iter_id + sub + vid > 0
+                        ends = (later and index[0] == 0, later and index[-1] == data_num - 1)
+                        stats['last'] = fit_backward(renderer, window_views(index, vid, step), pose_chain, near, far, fit_type,
+                                                     index=index, smooth_ends=ends, obj_verts_for_stable=obj_verts, rays_fn=rays_fn)
+                    else:
+                        for p in pose_chain.parameters():
+                            p.grad = None
+                    n = fit_apply(optimizer, pose_chain, dist, sync=world > 1)
+                    stats['allreduce_calls'] += int(n > 0)
+                    stats['allreduce_floats'] += n
+                    stats['steps'] += 1
+                    step += 1
+            stats['windows'] += int(index is not None)
+        if on_outer is not None:
+            on_outer(iter_id)
+    return stats
+
+
+def fit_frames_sharded(renderer, n_frames, make_frame, near, far, fit_type='12', n_iters=None, done=None, save=None, dist=None,
+                       rays_fn=None):
+    """fitting_single.py:134-315 over a set of frames, sharded over the ranks: every frame is its own optimisation
+    problem (own six parameters and Adam state, :177-199), so rank r fits frames r, r + world, .. with NO data-path
+    collective; a frame whose result already exists is skipped (`done(frame_id)`, :156-158: a restarted or re-sharded
+    run picks up what is missing); `save(frame_id, pose_chain, terms)` is the pose dump of :293-315.  The only
+    exchange is the SUM of the small loss vector at the end (`FrameShardedRunner.reduce`).
+
+    make_frame(frame_id) -> (views, pose_chain[, sample_view]).  Returns the reduced means + 'frames' + 'steps' of this rank."""
+    dist, rank, world = _dist_state(dist)
+    runner = FrameShardedRunner(n_frames, rank=rank, world=world, done=done)
+    steps = [0]
+
+    def frame_fn(f):
+        made = make_frame(f)
+        views, chain = made[0], made[1]
+        sample_view = made[2] if len(made) > 2 else None
+        terms, n = fit_frame(renderer, views, chain, near, far, fit_type, n_iters, sample_view, rays_fn=rays_fn)
+        steps[0] += n
+        if save is not None:
+            save(f, chain, terms)
+        return terms
+
+    out = runner.run(frame_fn)
+    out['steps'] = steps[0]
+    out['rank_frames'] = list(runner.frames)
+    return out
 
 
 def synthetic_views(n_views, n_frames, rays_per_frame, seed, joints_center, device='cuda', H=230, W=266):

@@ -237,3 +237,231 @@ def test_data_parallel_training_gradients_are_averaged_and_replicas_identical():
     (_, p0, g0), (_, p1, g1) = res
     for a, b in zip(p0 + g0, p1 + g1):
         assert np.array_equal(a, b)
+
+
+# ---- the real fitting loops under two ranks (stub renderer, CPU pose chain) -------------------------------------------
+class _StubRenderer:
+    """A few differentiable torch operators with NeuSRenderer_fitting.render's signature and return keys
+    (utils/renderer_batch.py:184-281): enough for the loop, loss and all-reduce code to run on the CPU."""
+    batched = True
+    S = 6
+
+    def render(self, rays_o, rays_d, near, far, bt_inv, T_pose, verts, Ro, To, t_rand=None):
+        z = torch.linspace(near, far, self.S)
+        pts = rays_o[:, :, None, :] + rays_d[:, :, None, :] * z[None, None, :, None]              # [F,P,S,3]
+        q = (bt_inv[:, None, None, 9, :3, :3] @ pts[..., None])[..., 0] + bt_inv[:, None, None, 9, :3, 3] - T_pose[:, None, None, 9]
+        sdf_h = q.norm(dim=-1) - 0.05
+        po = (Ro[:, None, None] @ (pts - To[:, None, None, :])[..., None])[..., 0]
+        sdf_o = po.norm(dim=-1) - 0.03
+        w_h, w_o = torch.sigmoid(-20 * sdf_h), torch.sigmoid(-20 * sdf_o)
+        color = (w_h[..., None] * torch.sigmoid(q) + w_o[..., None] * torch.sigmoid(po)).mean(2)
+        wsum = (0.5 * (w_h + w_o)).mean(2, keepdim=True)
+        return {'color_fine': color, 'weight_sum': wsum, 'sdf_hand': sdf_h.reshape(-1, 1), 'sdf_obj': sdf_o.reshape(-1, 1)}
+
+    def get_stable_loss_cross(self, obj_verts, bt_inv, T_pose, obj_r, obj_t):
+        v = (obj_r[:, None] @ obj_verts[..., None])[..., 0] + obj_t[:, None]                        # [F,V,3]
+        q = (bt_inv[:, None, 9, :3, :3] @ v[..., None])[..., 0] + bt_inv[:, None, 9, :3, 3]
+        d = q.norm(dim=-1)
+        return (d[1:] - d[:-1]).abs().mean()
+
+
+def _stub_rays(xy, cam, n_cams, P):
+    from oracle import render as orr
+    o, d = zip(*[orr.rays_from_xy(xy[c * P:(c + 1) * P], cam['R'][c], cam['T'][c], cam['focal'][c], cam['principal'][c]) for c in range(n_cams)])
+    return torch.cat(o), torch.cat(d)
+
+
+_SEQ = dict(data_num=8, n_views=2, rays=5, outer=2, sub=2)
+
+
+def _sequence_problem():
+    from honerf_amd import synth
+    n = _SEQ['data_num']
+    rng = np.random.RandomState(5)
+    bt, tp, j = synth.synth_hand_pose(3)
+    R, tt = synth.synth_obj_pose(4, center=tuple(j[9] + np.array([0.02, 0.0, 0.01])))
+    rep = lambda a: np.repeat(a[None], n, 0) + 0.002 * rng.standard_normal((n,) + a.shape).astype(np.float32)
+    u = rng.standard_normal((40, 3))
+    verts = (u / np.linalg.norm(u, axis=1, keepdims=True) * 0.025).astype(np.float32)
+    chain = fitting.RigidPoseChain(np.repeat(bt[None], n, 0), np.repeat(tp[None], n, 0), rep(j), np.repeat(R[None], n, 0), rep(tt), verts, device='cpu')
+    per_window = {}
+
+    def window_views(index, vid, step):
+        key = tuple(index)
+        if key not in per_window:
+            per_window[key] = fitting.synthetic_views(_SEQ['n_views'], 4, _SEQ['rays'], 100 + index[0], j[9], device='cpu')
+        return per_window[key][vid]
+    window_views.n_views = _SEQ['n_views']
+    ov = torch.from_numpy(verts)[None].expand(4, -1, -1).contiguous()
+    return chain, window_views, ov
+
+
+def _run_sequence(dist=None):
+    chain, window_views, ov = _sequence_problem()
+    stats = fitting.fit_sequence_video(_StubRenderer(), window_views, chain, 0.4, 1.5, _SEQ['data_num'], '1234', outer_iters=_SEQ['outer'],
+                                       sub_iters=_SEQ['sub'], obj_verts=ov, dist=dist, rays_fn=_stub_rays)
+    return [p.detach().clone() for p in chain.parameters()], stats
+
+
+def _sequence_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        params, stats = _run_sequence(dist)
+        q.put((rank, [p.numpy() for p in params], {k: v for k, v in stats.items() if k != 'last'}))
+    finally:
+        dist.destroy_process_group()
+
+
+def _jacobi_single_process(world):
+    """The same synchronous schedule in one process: per step the gradients of the `world` concurrent windows are
+    summed (rank order) before one Adam step."""
+    chain, window_views, ov = _sequence_problem()
+    opt = fitting.make_optimizer(chain, video=True)
+    n = _SEQ['data_num']
+    scheds = [fitting.window_schedule(n, r, world) for r in range(world)]
+    ren = _StubRenderer()
+    for iter_id in range(_SEQ['outer']):
+        for s in range(len(scheds[0])):
+            step = 0
+            for sub in range(_SEQ['sub']):
+                for vid in range(_SEQ['n_views']):
+                    total = [torch.zeros_like(p) for p in chain.parameters()]
+                    for r in range(world):
+                        index = scheds[r][s]
+                        if index is None:
+                            continue
+                        later = iter_id + sub + vid > 0
+                        fitting.fit_backward(ren, window_views(index, vid, step), chain, 0.4, 1.5, '1234', index=index,
+                                             smooth_ends=(later and index[0] == 0, later and index[-1] == n - 1),
+                                             obj_verts_for_stable=ov, rays_fn=_stub_rays)
+                        for t, p in zip(total, chain.parameters()):
+                            if p.grad is not None:
+                                t += p.grad
+                    for t, p in zip(total, chain.parameters()):
+                        p.grad = t
+                    opt.step()
+                    step += 1
+    return [p.detach().clone() for p in chain.parameters()]
+
+
+def test_fit_sequence_video_two_ranks_match_the_jacobi_schedule():
+    """fit_sequence_video (the loop bench.py --gpus N runs) under 2 gloo ranks: one all-reduce per step, replicas
+    bit-identical, and equal to a single process that sums the two concurrent windows' gradients per step; with one
+    rank the loop is the reference's sequential schedule (fitting_video.py:186-342) = fit_window per window."""
+    torch.set_num_threads(1)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sequence_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, st0), (_, p1, st1) = res
+    n_win = _SEQ['data_num'] - 3                       # 5 windows -> 3 rounds of 2 ranks, the last half empty
+    rounds = (n_win + 1) // 2
+    steps = _SEQ['outer'] * rounds * _SEQ['sub'] * _SEQ['n_views']
+    assert st0['steps'] == st1['steps'] == steps
+    assert st0['allreduce_calls'] == st1['allreduce_calls'] == steps
+    assert st0['allreduce_floats'] == steps * _SEQ['data_num'] * 18      # the rigid chain's 18 floats per frame
+    assert st0['windows'] + st1['windows'] == _SEQ['outer'] * n_win
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)                    # replicas bit-identical
+    ref = _jacobi_single_process(2)
+    moved = 0.0
+    for a, b in zip(p0, ref):
+        assert np.allclose(a, b.numpy(), rtol=0, atol=1e-7), np.abs(a - b.numpy()).max()
+        moved = max(moved, float(np.abs(a - np.round(a)).max()))
+    assert moved > 1e-4                                # the parameters did move away from their identity / zero start
+    # world = 1: the loop is the sequential schedule, i.e. fit_window per window with one optimiser
+    seq, st = _run_sequence(None)
+    assert st['allreduce_calls'] == 0 and st['windows'] == _SEQ['outer'] * n_win
+    chain, window_views, ov = _sequence_problem()
+    opt = fitting.make_optimizer(chain, video=True)
+    for iter_id in range(_SEQ['outer']):
+        for index in fitting.sliding_windows(_SEQ['data_num']):
+            fitting.fit_window(_StubRenderer(), None, chain, opt, 0.4, 1.5, index, _SEQ['data_num'], '1234', first_pass=iter_id == 0, obj_verts=ov,
+                               sample_view=lambda vid, step, index=index: window_views(index, vid, step), sub_iters=_SEQ['sub'],
+                               rays_fn=_stub_rays, n_views=_SEQ['n_views'])
+    for a, b in zip(seq, chain.parameters()):
+        assert torch.equal(a, b.detach())
+
+
+def _frames_worker(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        q.put((rank, _run_frames(dist, tmp)))
+    finally:
+        dist.destroy_process_group()
+
+
+class _StubSingle(_StubRenderer):
+    batched = False
+
+    def render(self, rays_o, rays_d, near, far, bt_inv, T_pose, verts, Ro, To, t_rand=None):
+        out = super().render(rays_o[None], rays_d[None], near, far, bt_inv[None], T_pose[None], None, Ro[None], To[None])
+        return {k: (v[0] if k in ('color_fine', 'weight_sum') else v) for k, v in out.items()}
+
+
+def _run_frames(dist, tmp):
+    from honerf_amd import synth
+
+    def make_frame(f):
+        bt, tp, j = synth.synth_hand_pose(10 + f)
+        R, tt = synth.synth_obj_pose(20 + f, center=tuple(j[9] + np.array([0.02, 0.0, 0.01])))
+        verts = (np.random.RandomState(f).standard_normal((30, 3)) * 0.02).astype(np.float32)
+        chain = fitting.RigidPoseChain(bt[None], tp[None], j[None], R[None], tt[None], verts, device='cpu')
+        return fitting.synthetic_views(2, 1, 7, 50 + f, j[9], device='cpu'), chain
+
+    def done(f):
+        return os.path.exists(os.path.join(tmp, 'pose_%d.npy' % f))
+
+    def save(f, chain, terms):
+        np.save(os.path.join(tmp, 'pose_%d.npy' % f), np.concatenate([p.detach().reshape(-1).numpy() for p in chain.parameters()]))
+
+    return fitting.fit_frames_sharded(_StubSingle(), 5, make_frame, 0.4, 1.5, '12', n_iters=2, done=done, save=save, dist=dist, rays_fn=_stub_rays)
+
+
+def test_fit_frames_sharded_two_ranks_and_restart(tmp_path):
+    """fit_frames_sharded (fitting_single.py:134-315 over frames): two ranks fit disjoint frames, the reduced loss
+    means equal the 1-rank run's, the per-frame results are identical files, and a second run skips what exists."""
+    torch.set_num_threads(1)
+    one = str(tmp_path / 'one')
+    two = str(tmp_path / 'two')
+    os.makedirs(one)
+    os.makedirs(two)
+    np.save(os.path.join(one, 'pose_3.npy'), np.zeros(1))           # frame 3 "already fitted": skipped (fitting_single.py:156-158)
+    np.save(os.path.join(two, 'pose_3.npy'), np.zeros(1))
+    single = _run_frames(None, one)
+    assert single['frames'] == 4 and single['steps'] == 4 * 2 * 2 and single['rank_frames'] == [0, 1, 2, 4]
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_frames_worker, args=(r, 2, port, q, two)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1]['rank_frames'] == [0, 2, 4] and res[1][1]['rank_frames'] == [1]
+    for _, red in res:
+        assert red['frames'] == 4
+        for k in fitting.LOSS_KEYS[:-1]:
+            assert abs(red[k] - single[k]) < 1e-6, (k, red[k], single[k])
+    for f in (0, 1, 2, 4):
+        assert np.array_equal(np.load(os.path.join(one, 'pose_%d.npy' % f)), np.load(os.path.join(two, 'pose_%d.npy' % f)))
+    again = _run_frames(None, one)
+    assert again['frames'] == 0 and again['steps'] == 0
