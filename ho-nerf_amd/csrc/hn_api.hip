@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <atomic>
 #include <functional>
+#include <mutex>
 #include <string.h>
 
 #include "hn_common.h"
@@ -124,6 +125,16 @@ struct SideStream {
     hipEvent_t fork = nullptr, join = nullptr;
 };
 static SideStream g_side[MAX_DEVICES];
+// The side stream and its two events are one set per device, shared by every caller stream: the host-side enqueue of a
+// fork ... join section must not interleave with another host thread's (its join could otherwise wait on the other
+// thread's record).  The lock covers the ENQUEUE only; the device-side order is the streams' own.
+static std::mutex g_side_mutex[MAX_DEVICES];
+struct SideLock {
+    std::unique_lock<std::mutex> lk;
+    explicit SideLock(SideStream* x) {
+        if (x != nullptr) lk = std::unique_lock<std::mutex>(g_side_mutex[x - g_side]);
+    }
+};
 static std::atomic<int> g_side_state[MAX_DEVICES];   // 0 unknown, 1 being created, 2 ready, 3 unavailable
 static SideStream* side_stream() {
     const int dev = current_device();
@@ -384,6 +395,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     const float sample_dist = (float)((far - near) / (double)n_samples);
     const int quirk = (batch_quirk && n_frames > 1) ? rpf : 0;
     SideStream* side = side_stream();
+    SideLock side_lock(side);
     const hipStream_t so = side != nullptr ? side->s2 : s;   // the object track's stream (s itself if no second stream)
     HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_obj, d_obj, s));
     HN_TRY(coarse_z(t_rand, n_rays, n_samples, (float)near, (float)(far - near), sample_dist, th.z_a, s));
@@ -512,6 +524,7 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     const void* tp_h = (tape != nullptr && tape_h) ? tape : nullptr;
     const void* tp_o = (tape != nullptr && tape_o) ? reinterpret_cast<const char*>(tape) + tape_h : nullptr;
     SideStream* side = side_stream();
+    SideLock side_lock(side);
     const hipStream_t so = side != nullptr ? side->s2 : s;
     HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_l, d_l, s));
     HN_TRY(composite2_bwd(alpha_h, rgb_h, alpha_o, rgb_o, g_color, g_wsum, n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo, s));

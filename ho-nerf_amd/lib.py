@@ -23,6 +23,7 @@ PRECISIONS = {'fp32': HN_PREC_FP32, 'f16x3': HN_PREC_F16X3}
 # 'fp32': the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32), 5x slower, kept as a second opinion
 DEFAULT_PRECISION = os.environ.get('HONERF_PRECISION', 'f16x3')
 HN_MAX_LAYERS = 9
+HN_VERSION = 103          # the include/honerf.h revision SIGNATURES below was written for
 
 c_f = ctypes.c_void_p     # device float*
 c_i = ctypes.c_int
@@ -126,6 +127,10 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
+    got = lib.hn_version()
+    if got != HN_VERSION:           # same symbol names, different argument lists: binding them would pass garbage pointers
+        raise RuntimeError('libhonerf.so at %s is ABI version %d, these bindings are for %d: rebuild it (`make -C %s`)'
+                           % (LIB_PATH, got, HN_VERSION, os.path.join(_HERE, 'csrc')))
     _lib = lib
     return lib
 

@@ -244,17 +244,23 @@ def allreduce_gradients(params, dist=None, average=True):
         import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
-    ps = [p for p in params if p.grad is not None]
+    # every parameter takes part, a missing .grad as zeros: the block has the same size on all ranks whatever each
+    # rank's batch touched (a rank-dependent block size would mismatch or hang the collective)
+    ps = list(params)
     if not ps:
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat /= dist.get_world_size()
     off = 0
     for p in ps:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].reshape(p.grad.shape))
+        n = p.numel()
+        g = flat[off:off + n].reshape(p.shape)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
         off += n
 
 
@@ -269,8 +275,10 @@ def train_step(renderer, optimizer, rays_o, rays_d, near, far, bt_inv, T_pose_21
         terms['loss'] = terms['loss'] + extra_loss(out)
     optimizer.zero_grad(set_to_none=True)
     terms['loss'].backward()
-    allreduce_gradients(trainable_parameters(renderer), dist)
+    # everything the optimiser steps (se3_refine and a caller's extra parameters included), so that no replica drifts
+    allreduce_gradients([p for g in optimizer.param_groups for p in g['params']], dist)
     optimizer.step()
+    renderer.mark_parameters_changed()     # a fused step does not advance the version counters renderer.field() watches
     return terms
 
 
@@ -372,6 +380,8 @@ def train(renderer, batches, end_iter, base_exp_dir, learning_rate=1e-4, learnin
         ck = latest_checkpoint(base_exp_dir)
         if ck is not None:
             iter_step = load_checkpoint(ck, renderer)      # networks and iteration count; Adam's moments restart, as in the reference (:288-293)
+    multi = dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank0 = not multi or dist.get_rank() == 0
     os.makedirs(base_exp_dir, exist_ok=True)
     log_path = os.path.join(base_exp_dir, 'metrics.jsonl')
     update_learning_rate(optimizer, iter_step, learning_rate, warm_up_end, end_iter, learning_rate_alpha)
@@ -388,9 +398,16 @@ def train(renderer, batches, end_iter, base_exp_dir, learning_rate=1e-4, learnin
         if iter_step % report_freq == 0:
             rec = {'iter': iter_step, 'lr': optimizer.param_groups[0]['lr']}
             rec.update({k: float(v.detach()) if isinstance(v, torch.Tensor) else float(v) for k, v in terms.items()})
-            with open(log_path, 'a') as f:
-                f.write(json.dumps(rec) + '\n')
+            if rank0:
+                with open(log_path, 'a') as f:
+                    f.write(json.dumps(rec) + '\n')
         if iter_step % save_freq == 0:
-            save_checkpoint(base_exp_dir, renderer, optimizer, iter_step)
+            if rank0:                  # replicas are identical: one writer, and nobody runs ahead of a half-written file
+                save_checkpoint(base_exp_dir, renderer, optimizer, iter_step)
+            if multi:
+                dist.barrier()
         update_learning_rate(optimizer, iter_step, learning_rate, warm_up_end, end_iter, learning_rate_alpha)
+    renderer.pack_eval_only = False        # leaving the training path: the next pack builds every program again
+    if hasattr(renderer, 'mark_parameters_changed'):
+        renderer.mark_parameters_changed()
     return iter_step

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 100 /* 0.1.0 */
+#define HN_VERSION 103 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
