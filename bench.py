@@ -99,6 +99,83 @@ def cpu_baseline(sdf, col, scene, crop=96, threads=32):
                       % (crop, crop, n_done * N_SAMPLES, dt)}
 
 
+# ---- C1 (BASELINE configs[0]): the reference's own CPU-runnable case ------------------------------------
+C1_H = C1_W = 128
+C1_SAMPLES = 32
+
+
+def build_scene_c1(dev, precision='f16x3'):
+    """`exp_runner.py --mode test` on the object conf: obj nets at conf size, one view 128 x 128, 32 samples per ray
+    (n_importance = 0), camera R = I, T = (0,0,1), f = 2, Ro = I, To = 0 (exp_runner.py:336-367)."""
+    from honerf_amd import synth
+    from honerf_amd.nets import SDFNetwork_OBJ, RenderingNetwork_OBJ, SingleVarianceNetwork
+    from honerf_amd.renderer import NeuSRenderer
+    sdf, col, var = SDFNetwork_OBJ().to(dev), RenderingNetwork_OBJ().to(dev), SingleVarianceNetwork(0.3).to(dev)
+    sdf.reset_parameters(11)
+    col.reset_parameters(12)
+    ren = NeuSRenderer(sdf, var, col, 'obj', C1_SAMPLES, 0, 0, 4, 1.0)
+    ren.precision = precision
+    cam = synth.front_camera(dist=1.0, focal=2.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    B = C1_H * C1_W
+    sc = dict(xy=t(synth.ndc_grid(C1_H, C1_W)), R=t(cam['R']), T=t(cam['T']), focal=t(cam['focal']), principal=t(cam['principal']),
+              Ro=torch.eye(3, device=dev), To=torch.zeros(3, device=dev),
+              t_rand=torch.rand(B, 1, generator=torch.Generator('cpu').manual_seed(1)).to(dev))
+    return ren, sdf, col, sc
+
+
+def c1_oracle(sdf, col, sc, sel=None, threads=32, chunk=441):
+    """The CPU oracle on C1 (rows `sel` of the frame, default all), in the reference's chunks of 441 rays
+    (exp_runner.py:356-367) -> (colours, seconds)."""
+    from oracle.nets import Field
+    from oracle import render as orr
+    torch.set_num_threads(min(threads, os.cpu_count() or 1))
+    cpu = lambda v: v.detach().cpu()
+    field = Field('obj', {k: cpu(v) for k, v in sdf.state_dict().items()}, {k: cpu(v) for k, v in col.state_dict().items()}, 0.3)
+    xy, tr = cpu(sc['xy']), cpu(sc['t_rand'])
+    if sel is not None:
+        xy, tr = xy[sel], tr[sel]
+    o, d = orr.rays_from_xy(xy, cpu(sc['R'])[0], cpu(sc['T'])[0], cpu(sc['focal'])[0], cpu(sc['principal'])[0])
+    t0 = time.perf_counter()
+    outs = [orr.render_single(field, o[s:s + chunk], d[s:s + chunk], NEAR, FAR, tr[s:s + chunk], C1_SAMPLES, 0, 4,
+                              Ro=cpu(sc['Ro']), To=cpu(sc['To']))['color_fine'].detach() for s in range(0, o.shape[0], chunk)]
+    return torch.cat(outs), time.perf_counter() - t0
+
+
+def render_c1(ren, sc, lib_mod):
+    lib = lib_mod.load()
+    B = sc['xy'].shape[0]
+    o, d = torch.empty(B, 3, device=sc['xy'].device), torch.empty(B, 3, device=sc['xy'].device)
+    lib_mod.check(lib.hn_ray_gen(lib_mod.ptr(sc['xy']), lib_mod.ptr(sc['R']), lib_mod.ptr(sc['T']), lib_mod.ptr(sc['focal']),
+                                 lib_mod.ptr(sc['principal']), 1, B, lib_mod.ptr(o), lib_mod.ptr(d), lib_mod.stream_ptr()), 'hn_ray_gen')
+    return ren.render(o, d, NEAR, FAR, None, None, None, sc['Ro'], sc['To'], 0, t_rand=sc['t_rand'])
+
+
+def time_c1(dev, precision, with_cpu):
+    """C1 in full on the GPU (ms per frame) and, with_cpu, on the host cores through the oracle (the reference's own
+    CPU-runnable configuration: BASELINE.md section 3)."""
+    from honerf_amd import lib as L
+    ren, sdf, col, sc = build_scene_c1(dev, precision)
+    out = render_c1(ren, sc, L)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        out = render_c1(ren, sc, L)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / reps
+    n = C1_H * C1_W * C1_SAMPLES
+    res = {'workload': 'C1: obj nets (conf size), 128x128 rays x 32 samples, n_importance=0, one view', 'ms_per_frame': sec * 1e3,
+           'value': n / sec, 'unit': 'ray-samples/s', 'weight_sum_mean': float(out['weight_sum'].mean())}
+    if with_cpu:
+        ref, dt = c1_oracle(sdf, col, sc)
+        err = float((out['color_fine'].cpu() - ref).abs().max() / ref.abs().max())
+        res['cpu_baseline'] = {'value': n / dt, 'unit': 'ray-samples/s', 'cores': min(32, os.cpu_count() or 1), 'kind': 'port',
+                               'sample': 'the whole C1 frame (%d ray-samples, %.1f s), chunks of 441 rays' % (n, dt)}
+        res['colour_rel_err_vs_cpu'] = err
+    return res
+
+
 # ---- the fitting loops (BASELINE configs[2..4]) --------------------------------------------------------------
 FIT_RAYS, FIT_N, FIT_IMP = 196, 64, 64            # fit_confs/fit_1_8views.conf:24, 86-92 -> 192 shared depths
 VID_FRAMES, VID_RAYS = 4, 40                      # fitting_video.py:146-149, 264-266
@@ -314,6 +391,7 @@ def main():
     ap.add_argument('--cpu-crop', type=int, default=96)
     ap.add_argument('--no-culled', action='store_true', help='skip the secondary culled measurement')
     ap.add_argument('--precision', default='f16x3', choices=['f16x3', 'fp32'])
+    ap.add_argument('--no-c1', action='store_true', help='skip the C1 (128x128x32 obj) measurement')
     ap.add_argument('--no-fitting', action='store_true', help='skip the fitting-loop measurements')
     ap.add_argument('--no-training', action='store_true', help='skip the training-iteration measurement')
     ap.add_argument('--fit-steps', type=int, default=10)
@@ -443,6 +521,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         import train_step_bench
         training = {k: train_step_bench.measure(k, dev, 441, 10, 3, args.precision) for k in ('obj', 'hand')}
+    c1 = time_c1(dev, args.precision, not args.no_cpu_baseline) if rank == 0 and not args.no_c1 else None
     if rank == 0:
         res = {
             'metric': 'ray-samples/sec/GPU (512x512x64)', 'value': value, 'unit': 'ray-samples/s',
@@ -459,6 +538,8 @@ def main():
                          'mfma_peak_tflops': PEAK_F16_MFMA_TFLOPS if args.precision == 'f16x3' else PEAK_F32_MFMA_TFLOPS},
             'weight_sum_mean': float(out['weight_sum'].mean()),
         }
+        if c1 is not None:
+            res['c1'] = c1
         if fitting is not None:
             res['fitting'] = fitting
         if training is not None:

@@ -124,6 +124,8 @@ struct SideStream {
     hipStream_t s2 = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
+std::atomic<int> g_pace_phantom{0};
+int pace_phantom_members() { return g_pace_phantom.load(std::memory_order_relaxed); }
 static SideStream g_side[MAX_DEVICES];
 // The side stream and its two events are one set per device, shared by every caller stream: the host-side enqueue of a
 // fork ... join section must not interleave with another host thread's (its join could otherwise wait on the other
@@ -686,6 +688,10 @@ int hn_nearest_masked(const float* pts, int n_verts, int n_sets, const unsigned 
 
 
 int hn_version(void) { return HN_VERSION; }
+int hn_debug_pace_phantom(int members) {
+    hn::g_pace_phantom.store(members < 0 ? 0 : members);
+    return HN_OK;
+}
 const char* hn_last_error(void) { return g_err; }
 int hn_device_cus(void) { return device_cus(); }
 

@@ -997,6 +997,7 @@ int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, 
         if (HN_XCD_PACING && (n_pts + WG_SAMPLES - 1) / WG_SAMPLES >= XCD_PACE_MIN_ROUNDS * grid && workspace_bytes >= need + 64) {
             a.xsync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + need);
             HN_CHECK_HIP(hipMemsetAsync(a.xsync, 0, 64, stream));
+        if (const int ph = pace_phantom_members()) HN_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.xsync), ph, 8, stream));
         }
     }
     static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};   // devices on which the LDS size attribute is set

@@ -54,6 +54,7 @@ SIGNATURES = {
     'hn_field_destroy': (c_i, [c_vp]),
     'hn_field_inv_s': (c_fl, [c_vp]),
     'hn_field_set_culling': (c_i, [c_vp, c_i]),
+    'hn_debug_pace_phantom': (c_i, [c_i]),
     'hn_ray_gen': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
     'hn_obj_local_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
     'hn_obj_local_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_vp]),

@@ -97,6 +97,11 @@ float hn_field_inv_s(const hn_field* f);
  * weight chunks (results are bit-identical to the dense evaluation).  Off by default: throughput figures are
  * quoted dense.  Set it before launching work on the field; no effect on obj fields and on HN_PREC_FP32. */
 int hn_field_set_culling(hn_field* f, int enabled);
+/* Test hook for the XCD pacing of the f16x3 field kernels (image-sized launches: the 32 workgroups of an XCD meet at every
+ * tile start, bounded spin): `members` > 0 registers that many members per XCD that never arrive, so that the first
+ * meeting of every workgroup runs into its timeout and the launch continues unpaced -- results must be bit-identical.
+ * 0 switches the hook off.  Process-wide; not for production use. */
+int hn_debug_pace_phantom(int members);
 
 /* ---- rays -----------------------------------------------------------------------------
  * _xy_to_ray_bundle (utils/utils.py:31-115): NDC xy -> unproject at depth 1 and

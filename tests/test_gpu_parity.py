@@ -685,6 +685,32 @@ def test_error_paths_return_status_and_message(L):
     assert lib.hn_merge(L.ptr(z), L.ptr(z), None, None, 0, 64, 16, 0, L.ptr(z), None, None, st()) == 0
 
 
+def test_c1_full_frame_against_oracle(prec):
+    """BASELINE configs[0] (C1) at full size -- obj nets, 128 x 128 rays x 32 samples, the plumbing configuration of
+    `exp_runner.py --mode test` (exp_runner.py:336-372) -- against the pinned oracle on a subsample of its rays, and
+    chunk invariance of the whole frame (the reference renders it in chunks of 441 rays, :356-367)."""
+    import bench
+    from honerf_amd import lib as Lm
+    dev = torch.device('cuda')
+    ren, sdf, col, sc = bench.build_scene_c1(dev, prec)
+    out = bench.render_c1(ren, sc, Lm)
+    B = bench.C1_H * bench.C1_W
+    assert out['color_fine'].shape == (B, 3) and out['cdf_fine'].shape == (B, bench.C1_SAMPLES)
+    assert torch.isfinite(out['color_fine']).all()
+    assert 0.3 < float(out['weight_sum'].mean()) <= 1.0 + 1e-4      # the geometric-init sphere is in view
+    sel = torch.arange(0, B, 37)                                     # 443 rays spread over the image
+    ref, _ = bench.c1_oracle(sdf, col, sc, sel=sel, threads=16)
+    assert_close(out['color_fine'][sel.to(dev)], ref, RT, 'C1 full frame colour vs oracle (ray subsample)')
+    # the reference's chunking: 441 rays per call, concatenated
+    lib = Lm.load()
+    o, d = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
+    Lm.check(lib.hn_ray_gen(Lm.ptr(sc['xy']), Lm.ptr(sc['R']), Lm.ptr(sc['T']), Lm.ptr(sc['focal']), Lm.ptr(sc['principal']), 1, B,
+                            Lm.ptr(o), Lm.ptr(d), Lm.stream_ptr()), 'hn_ray_gen')
+    parts = [ren.render(o[s:s + 441], d[s:s + 441], bench.NEAR, bench.FAR, None, None, None, sc['Ro'], sc['To'], 0,
+                        t_rand=sc['t_rand'][s:s + 441])['color_fine'].clone() for s in range(0, B, 441)]
+    assert torch.equal(torch.cat(parts), out['color_fine'])
+
+
 def test_full_size_frame_properties():
     """BASELINE configs[1] at full size (512 x 512 rays x 64 samples, hand nets): size-independent properties.
     One call over all rays == the same frame rendered in 8 chunks (bit for bit: no result may depend on how
@@ -719,6 +745,41 @@ def test_full_size_frame_properties():
         ren.field().set_culling(False)
     for k in whole:
         assert torch.equal(whole[k], culled[k]), 'culled frame differs in %s' % k
+
+
+def test_xcd_pacing_timeout_is_bit_identical():
+    """XCD pacing (hn_mlp2.h XcdPace): an image-sized launch whose workgroups meet at every tile start must give the
+    same bits when a meeting runs into its timeout (a member of the XCD that never arrives: hn_debug_pace_phantom) and
+    the launch carries on unpaced -- both field kinds, evaluation and sdf-only kernels."""
+    import time
+    from honerf_amd import lib as Lm, synth
+    lib = Lm.load()
+    hand, obj = packed_fields('cuda', 'f16x3')
+    bt_inv, T_pose, joints = synth.synth_hand_pose(7)
+    n = 128 * 256 * 9 + 57                                          # >= 8 tile rounds on 256 workgroups: paced
+    gen = torch.Generator().manual_seed(3)
+    j = t(joints)
+    pts = cu(j[torch.randint(0, 21, (n,), generator=gen)] + 0.03 * torch.randn(n, 3, generator=gen))
+    d = cu(torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1))
+    bt, tp = t(bt_inv)[None], t(T_pose)[None]
+
+    def run():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = [x.clone() for x in hand.evaluate(pts, d, 1, bt, tp)] + [hand.sdf(pts, bt, tp).clone()]
+        out += [x.clone() for x in obj.evaluate(pts, d, 1)] + [obj.sdf(pts).clone()]
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+    run()
+    paced, t_paced = run()
+    Lm.check(lib.hn_debug_pace_phantom(1), 'hn_debug_pace_phantom')
+    try:
+        timed_out, t_out = run()
+    finally:
+        Lm.check(lib.hn_debug_pace_phantom(0), 'hn_debug_pace_phantom')
+    for a, b, what in zip(paced, timed_out, ('hand sdf', 'hand grad', 'hand rgb', 'hand sdf-only', 'obj sdf', 'obj grad', 'obj rgb', 'obj sdf-only')):
+        assert torch.equal(a, b), 'a pacing timeout changed %s' % what
+    bounded('XCD pacing: seconds of the 4 launches, paced vs first meeting timed out', t_out / t_paced, 50.0)
 
 
 # ---------------------------------------------------------------------------------------------

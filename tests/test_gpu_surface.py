@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close, assert_parity, bounded, cu, oracle_fields, product_modules, rel_err, t
+from helpers import assert_close, assert_parity, bounded, cu, oracle_fields, oracle_fields_fp64, product_modules, rel_err, t
 
 pytestmark = pytest.mark.gpu
 RT = 1e-4
@@ -110,7 +110,17 @@ def test_get_alpha_sample_color_method(golden, name):
     a, c, s, ge, gr = ren.get_alpha_sample_color(o, d, g['bt_inv'], g['T_pose'], z, sample_dist, 'hand')
     assert a.shape == g['alpha_hand'].shape and c.shape == g['rgb_hand'].shape and s.shape == g['sdf_hand'].shape
     assert_close(a, g['alpha_hand'], 2e-4, name + ' alpha_hand')          # observed 4.9e-5; hand noise floor, see test_gpu_parity
-    assert_close(c, g['rgb_hand'], 2e-3, name + ' rgb_hand')
+    # near the joints the fp32 reference is itself 2.5e-4 ... 5.9e-4 from the float64 value: the conditioning-aware bound
+    # of test_gpu_parity.py (no further from float64 than the reference is), not a bare tolerance
+    h64, _ = oracle_fields_fp64()
+    F_ = z.shape[0] if batched else 1
+    N, S = (z.shape[0] * z.shape[1], z.shape[2]) if batched else z.shape
+    zz = z.reshape(N, S)
+    dists = torch.cat([zz[:, 1:] - zz[:, :-1], torch.full((N, 1), sample_dist, device=z.device)], -1)
+    pts = (o.reshape(N, 1, 3) + d.reshape(N, 1, 3) * (zz + 0.5 * dists).unsqueeze(-1)).cpu().double()
+    dirs = d.reshape(N, 1, 3).expand(N, S, 3).reshape(-1, 3).cpu().double()
+    _, _, c64 = h64.evaluate(pts.reshape(F_, -1, 3), dirs, t(g['bt_inv']).double().reshape(F_, 21, 4, 4), t(g['T_pose']).double().reshape(-1, 21, 3))
+    assert_parity(c, g['rgb_hand'], c64, name + ' rgb_hand (method)', cap=2e-3)
     assert_close(s, g['sdf_hand'], RT, name + ' sdf_hand')
     assert_close(ge, g['gradient_error_hand'], RT, name + ' gradient_error_hand')
     ol, dl = ren.convert_obj_to_local(o, d, g['Ro'], g['To'])
@@ -288,6 +298,48 @@ def test_fit_step_single_and_video():
     assert steps == 2 and {'smooth', 'stable', 'contact', 'penetration'} <= set(last)
     assert all(torch.isfinite(v).all() for v in last.values())
     assert all(not torch.equal(a, b.detach()) for a, b in zip(before, chain.parameters()))
+
+
+def test_fit_sequence_video_one_rank_is_the_sequential_schedule():
+    """fit_sequence_video with one rank (no process group) on the device == fit_step applied window by window in the
+    reference's order (fitting_video.py:186-342) over the reference's six-leaf pose chain; and
+    fit_backward + fit_apply == fit_step."""
+    import bench
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    data_num, n_views, outer, sub = 6, 2, 2, 1
+    renb = _dual(True)
+
+    def problem():
+        chain, j, verts = bench.build_fit_data(dev, 60, data_num, halo=True, drift=0.002)
+        per_window = {tuple(w): F.synthetic_views(n_views, 4, 6, 300 + w[0], j[9], device=dev) for w in F.sliding_windows(data_num)}
+        return chain, per_window, verts[:400][None].expand(4, -1, -1).contiguous()
+
+    chain_a, wins_a, ov = problem()
+
+    def window_views(index, vid, step):
+        return wins_a[tuple(index)][vid]
+    window_views.n_views = n_views
+    torch.manual_seed(11)                                           # the renders draw their jitter from torch's generator
+    st = F.fit_sequence_video(renb, window_views, chain_a, 0.4, 1.5, data_num, '1234', outer_iters=outer, sub_iters=sub, obj_verts=ov)
+    assert st['steps'] == outer * 3 * sub * n_views and st['windows'] == outer * 3 and st['allreduce_calls'] == 0
+    assert all(torch.isfinite(v).all() for v in st['last'].values())
+
+    chain_b, wins_b, _ = problem()
+    opt = F.make_optimizer(chain_b, video=True)
+    torch.manual_seed(11)
+    for it in range(outer):
+        for index in F.sliding_windows(data_num):
+            for s_ in range(sub):
+                for vid in range(n_views):
+                    later = it + s_ + vid > 0
+                    F.fit_step(renb, wins_b[tuple(index)][vid], chain_b, opt, 0.4, 1.5, '1234', index=index,
+                               smooth_ends=(later and index[0] == 0, later and index[-1] == data_num - 1), obj_verts_for_stable=ov)
+    # (the pose gradients are accumulated with float atomics: two runs agree to rounding, not to the bit)
+    moved = max(float((a.detach() - a.detach().round()).abs().max()) for a in chain_a.parameters())
+    diff = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(chain_a.parameters(), chain_b.parameters()))
+    bounded('fit_sequence_video (1 rank) vs fit_step in the reference order: max parameter difference / movement', diff / moved, 2e-2)
+    assert moved > 1e-5
 
 
 @pytest.mark.parametrize('fit_type', ['1', '12'])
