@@ -409,12 +409,20 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # HONERF_BENCH_SHARE_GPU=1: all ranks on device 0 with the gloo backend -- a functional check of the N > 1 code path
+    # (sharding, the pose-gradient all-reduce between backward and Adam) on a box with ONE GPU; its timings mean nothing.
+    share = os.environ.get('HONERF_BENCH_SHARE_GPU') == '1'
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from honerf_amd import lib as L
     lib = L.load()
@@ -538,6 +546,8 @@ def main():
                          'mfma_peak_tflops': PEAK_F16_MFMA_TFLOPS if args.precision == 'f16x3' else PEAK_F32_MFMA_TFLOPS},
             'weight_sum_mean': float(out['weight_sum'].mean()),
         }
+        if share:
+            res['note'] = 'HONERF_BENCH_SHARE_GPU=1: all ranks on ONE device over gloo -- functional check only, timings are not a measurement'
         if c1 is not None:
             res['c1'] = c1
         if fitting is not None:

@@ -697,7 +697,7 @@ def test_c1_full_frame_against_oracle(prec):
     B = bench.C1_H * bench.C1_W
     assert out['color_fine'].shape == (B, 3) and out['cdf_fine'].shape == (B, bench.C1_SAMPLES)
     assert torch.isfinite(out['color_fine']).all()
-    assert 0.3 < float(out['weight_sum'].mean()) <= 1.0 + 1e-4      # the geometric-init sphere is in view
+    assert float(out['weight_sum'].max()) > 0.7 and 0.05 < float(out['weight_sum'].mean()) < 0.9   # the geometric-init sphere is in view, with background around it
     sel = torch.arange(0, B, 37)                                     # 443 rays spread over the image
     ref, _ = bench.c1_oracle(sdf, col, sc, sel=sel, threads=16)
     assert_close(out['color_fine'][sel.to(dev)], ref, RT, 'C1 full frame colour vs oracle (ray subsample)')

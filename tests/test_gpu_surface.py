@@ -320,13 +320,17 @@ def test_fit_sequence_video_one_rank_is_the_sequential_schedule():
     def window_views(index, vid, step):
         return wins_a[tuple(index)][vid]
     window_views.n_views = n_views
+    # plain SGD for the comparison: the pose gradients are accumulated with float atomics, so two runs agree to rounding,
+    # and Adam's normalisation would turn rounding-level gradients of flat directions into full-size steps of random sign
+    sgd = lambda chain: torch.optim.SGD(chain.parameters(), lr=2e-6)
     torch.manual_seed(11)                                           # the renders draw their jitter from torch's generator
-    st = F.fit_sequence_video(renb, window_views, chain_a, 0.4, 1.5, data_num, '1234', outer_iters=outer, sub_iters=sub, obj_verts=ov)
+    st = F.fit_sequence_video(renb, window_views, chain_a, 0.4, 1.5, data_num, '1234', outer_iters=outer, sub_iters=sub, obj_verts=ov,
+                              optimizer=sgd(chain_a))
     assert st['steps'] == outer * 3 * sub * n_views and st['windows'] == outer * 3 and st['allreduce_calls'] == 0
     assert all(torch.isfinite(v).all() for v in st['last'].values())
 
     chain_b, wins_b, _ = problem()
-    opt = F.make_optimizer(chain_b, video=True)
+    opt = sgd(chain_b)
     torch.manual_seed(11)
     for it in range(outer):
         for index in F.sliding_windows(data_num):
@@ -335,11 +339,10 @@ def test_fit_sequence_video_one_rank_is_the_sequential_schedule():
                     later = it + s_ + vid > 0
                     F.fit_step(renb, wins_b[tuple(index)][vid], chain_b, opt, 0.4, 1.5, '1234', index=index,
                                smooth_ends=(later and index[0] == 0, later and index[-1] == data_num - 1), obj_verts_for_stable=ov)
-    # (the pose gradients are accumulated with float atomics: two runs agree to rounding, not to the bit)
     moved = max(float((a.detach() - a.detach().round()).abs().max()) for a in chain_a.parameters())
     diff = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(chain_a.parameters(), chain_b.parameters()))
-    bounded('fit_sequence_video (1 rank) vs fit_step in the reference order: max parameter difference / movement', diff / moved, 2e-2)
-    assert moved > 1e-5
+    assert moved > 1e-7, moved
+    bounded('fit_sequence_video (1 rank) vs fit_step in the reference order: max parameter difference / movement', diff / moved, 1e-3)
 
 
 @pytest.mark.parametrize('fit_type', ['1', '12'])
