@@ -147,5 +147,6 @@ struct hn_field {
     const float* raw_col_b[5] = {};
     int sdf_out[9] = {}, sdf_in[9] = {}, col_out[5] = {}, col_in[5] = {};
     int sdf_ld[9] = {}, col_ld[5] = {};   // row pitch of the retained matrices (in_dim rounded up to a multiple of 4)
+    int single_pass = 0;         // HN_PREC_F16: the evaluation kernels run their hidden layers on one f16 MFMA per product
     int cull_far_field = 0;      // hn_field_set_culling: skip the chunks of bones whose mask is 0 for a whole workgroup
 };

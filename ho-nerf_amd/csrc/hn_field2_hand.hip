@@ -13,7 +13,7 @@
 #include <atomic>
 
 #include "hn_common.h"
-#if !defined(HN_HAND_ADJ_TU) && !defined(HN_MFMA16)
+#if !defined(HN_HAND_ADJ_TU) && !defined(HN_HAND_F16_TU) && !defined(HN_MFMA16)
 #define HN_MFMA16 HN_HAND_EVAL_MFMA16   // the evaluation kernels (MODE 0, 1); the adjoint translation unit keeps 32x32x16
 #endif
 #include "hn_mlp2.h"
@@ -342,8 +342,31 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // The fitting step splits mode 2 in two launches so that nothing is evaluated twice: 3 = full evaluation that keeps its
 // tape (stash slots per sample TILE, in a buffer the caller keeps until the backward pass), 4 = the adjoint alone, from
 // that tape.
-template <int MODE>
+// HP: MFMA passes per product of the hidden layers -- 3: fp32-equivalent (HN_PREC_F16X3); 1: HN_PREC_F16, the single-pass
+// throughput mode (evaluation modes 0 / 1 only; which layer groups drop to one pass: the HN_F16_* macros below)
+#ifndef HN_F16_FEAT_PASSES
+#define HN_F16_FEAT_PASSES 3   // lin0 and the lin4 skip columns: the 1386 encoded features (sin / cos up to 2^9 v)
+#endif
+#ifndef HN_F16_JAC_PASSES
+#define HN_F16_JAC_PASSES 3    // W0^T dz0 + W4x^T dz4 in front of the encoding Jacobian (entries are multiplied by up to 2^9)
+#endif
+#ifndef HN_F16_LIN7_PASSES
+#define HN_F16_LIN7_PASSES 3   // the last hidden layer of the SDF network (-> a8 -> sdf, the seed of the reverse sweep)
+#endif
+#ifndef HN_F16_COLOR_PASSES
+#define HN_F16_COLOR_PASSES 3  // the colour network (measured at one pass: rgb 3e-2 from the reference on the fixture; at three: see tests)
+#endif
+template <int MODE, int HP = 3>
 __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
+    static_assert(HP == 3 || MODE <= 1, "the single-pass mode exists for the evaluation kernels");
+    constexpr int PH = HP;                                  // hidden layers, reverse sweep, colour network
+    constexpr int PF = HP == 1 ? HN_F16_FEAT_PASSES : 3;
+    constexpr int PJ = HP == 1 ? HN_F16_JAC_PASSES : 3;
+    constexpr int P7 = HP == 1 ? HN_F16_LIN7_PASSES : 3;
+    constexpr int PC = HP == 1 ? HN_F16_COLOR_PASSES : 3;
+    using IPF = std::integral_constant<int, PF>;
+    using IPC = std::integral_constant<int, PC>;
+    using IP3 = std::integral_constant<int, 3>;
     constexpr bool FULL = MODE >= 1;
     constexpr bool ADJ = MODE >= 2;                    // the forward pass writes the tape
     constexpr bool RUN_FWD = MODE != 4;
@@ -543,8 +566,9 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 }
             }
         };
-        auto feature_pass = [&](auto NB_, auto BIAS_, auto& c1, auto& c2, auto LB_, auto NA_) {
+        auto feature_pass = [&](auto NB_, auto BIAS_, auto& c1, auto& c2, auto LB_, auto NA_, auto PS_) {
             constexpr int NB = decltype(NB_)::value;
+            constexpr int PS = decltype(PS_)::value;   // MFMA passes per product
             constexpr int left_bytes = decltype(LB_)::value, next_after = decltype(NA_)::value;   // chunk sizes: constants
             constexpr bool BIAS = decltype(BIAS_)::value;
             h8 fh[2][4], fl[2][4];
@@ -566,25 +590,25 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     if constexpr (blk + 1 < NB) {
                         ws.template begin_c<HB_BONE>();
                         if constexpr (blk == 0 && NB == 2 && HN_FEAT_LOADS_BEHIND)
-                            mma_chunk<4, 4, HB_BONE>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane, [&]() { load_bone(nb, nh, nl); });
+                            mma_chunk<4, 4, HB_BONE, PS>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane, [&]() { load_bone(nb, nh, nl); });
                         else
-                            mma_chunk<4, 4, HB_BONE>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);   // one pipeline over the 16 blocks
+                            mma_chunk<4, 4, HB_BONE, PS>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);   // one pipeline over the 16 blocks
                     } else if constexpr (left_bytes <= HB_BONE) {
                         // the first leftover chunk (nb == 21) is shorter than a bone chunk: fetched at the bone size all
                         // the same (the size stays a constant; 7 - 8 KiB of the following chunk come along unused)
                         ws.goff = base + nb * (NB * HB_BONE);
                         ws.template begin_c<HB_BONE>();
                         if (nb >= N_BONES) ws.goff += left_bytes - HB_BONE;
-                        mma_chunk<4, 4, HB_BONE>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);
+                        mma_chunk<4, 4, HB_BONE, PS>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);
                     } else {
                         // (16x16x32: the leftover chunk has four k-steps and is the longer one when it carries a tail)
                         ws.goff = base + nb * (NB * HB_BONE);
                         if (nb < N_BONES) {
                             ws.template begin_c<HB_BONE>();
-                            mma_chunk<4, 4, HB_BONE>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);
+                            mma_chunk<4, 4, HB_BONE, PS>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);
                         } else {
                             ws.template begin_c<left_bytes>();
-                            mma_chunk<4, 4, left_bytes>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);
+                            mma_chunk<4, 4, left_bytes, PS>(ws, buf, uh, ul, &c1[HN_EXP_ACC * blk], &c2[HN_EXP_ACC * blk], lane);
                         }
                     }
                 });
@@ -624,9 +648,9 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 static_for<4>([&](auto TI) {
                     constexpr int ti = decltype(TI)::value;
                     if constexpr (ti == 0)
-                        mma_tile<KS_LEFT, 0, nbytes>(ws, buf + ti * KS_LEFT * KS_BYTES, fh[0], fl[0], c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                        mma_tile<KS_LEFT, 0, nbytes, PS>(ws, buf + ti * KS_LEFT * KS_BYTES, fh[0], fl[0], c1[4 * blk + ti], c2[4 * blk + ti], lane);
                     else
-                        mma_tile<KS_LEFT, 0, 0>(ws, buf + ti * KS_LEFT * KS_BYTES, fh[0], fl[0], c1[4 * blk + ti], c2[4 * blk + ti], lane);
+                        mma_tile<KS_LEFT, 0, 0, PS>(ws, buf + ti * KS_LEFT * KS_BYTES, fh[0], fl[0], c1[4 * blk + ti], c2[4 * blk + ti], lane);
                     if constexpr (BIAS) {
                         const f32x16 bias = tail_tile(buf + 4 * KS_LEFT * KS_BYTES, ti, h);
 #pragma unroll
@@ -673,15 +697,15 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 c1[ti] = zero16();
                 c2[ti] = zero16();
             }
-            feature_pass(I2{}, BTrue{}, c1, c2, std::integral_constant<int, HB_LEFT_T>{}, std::integral_constant<int, HB_HID>{});
+            feature_pass(I2{}, BTrue{}, c1, c2, std::integral_constant<int, HB_LEFT_T>{}, std::integral_constant<int, HB_HID>{}, IPF{});
             block_epilogue(I8t{}, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 0));
         }
-        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 1), no_store);   // lin1
-        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 2), no_store);   // lin2
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 1), no_store);   // lin1
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 2), no_store);   // lin2
         // lin3 -> a4, in bh / bl like every layer's output: lin4's hidden part reads them from there.  (They used to go
         // through the stash -- 32 KB written and read back at once per tile, an HBM round trip of ~10 000 cycles in front
         // of lin4 in the in-kernel stamps.)
-        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 3), no_store);   // lin3
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 3), no_store);   // lin3
         if ((HN_DBG(a) >> 8) == 3) return;   // phase timing aid
         // ---- lin4 = [a4 | features] / sqrt2 -> a5: 8 hidden tiles (bias from the tail), then the feature pass
         {
@@ -693,17 +717,17 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 ws.template begin_c<nbytes>();
                 c1[ti] = tail_tile(buf + 16 * KS_BYTES, 0, h);
                 c2[ti] = zero16();
-                mma_tile<16, 0, nbytes>(ws, buf, bh, bl, c1[ti], c2[ti], lane);
+                mma_tile<16, 0, nbytes, PH>(ws, buf, bh, bl, c1[ti], c2[ti], lane);
             });
-            feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_HID>{});
+            feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_HID>{}, IPF{});
             block_epilogue(I8t{}, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 4));
         }
-        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 5), no_store);   // lin5
-        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 6), no_store);   // lin6
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 5), no_store);   // lin5
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 6), no_store);   // lin6
         // ---- lin7 -> a8; sdf = W8[0,:] a8 + b8; seed of the reverse sweep dz7 = sigma'(z7) W8[0,:] (scaled)
         float sdf_acc = 0.f, sdf_acc1 = 0.f;   // (16x16x32: the lane's registers of column block 0 / 1 are two samples)
         auto lin7 = [&](auto NA_) {   // NA_: the size of the chunk that follows the layer, a constant
-        run_layer_c<8, 16, 1, true, true, HB_HID, decltype(NA_)::value>(
+        run_layer_c<8, 16, 1, true, true, HB_HID, decltype(NA_)::value, P7>(
             ws, ah, al, lane, h,
             [&](auto, const char* tail) { return Act{tail_tile(tail, 1, h)}; }, PhSoftplus{},
             [&](auto T, EpiState& st, const Act& w8) {
@@ -751,7 +775,7 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
 
         if ((HN_DBG(a) >> 8) == 5) return;   // phase timing aid
         // ---- lin8 rows 1..256: the feature vector (no activation) -> stash as fragments for colour lin0
-        run_layer_c<8, 16, 1, true, true, HB_HID, HB_BWD>(
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_BWD, PH>(
             ws, bh, bl, lane, h, no_pre, PhIdentity{},
             [&](auto T, EpiState& st, const auto&) {
                 constexpr int t = decltype(T)::value;
@@ -794,9 +818,9 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                 return NoData{};
             };
         };
-        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, act_of(HS_A1 + 6), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 6), no_store);   // W7^T -> dz6
-        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, act_of(HS_A1 + 5), PhDsig{}, to_regs_t(ah, al, HS_DZ + 5), no_store);   // W6^T -> dz5
-        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, act_of(HS_A1 + 4), PhDsig{},                               // W5^T -> dz4 (kept)
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD, PH>(ws, ah, al, lane, h, act_of(HS_A1 + 6), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 6), no_store);   // W7^T -> dz6
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD, PH>(ws, bh, bl, lane, h, act_of(HS_A1 + 5), PhDsig{}, to_regs_t(ah, al, HS_DZ + 5), no_store);   // W6^T -> dz5
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD, PH>(ws, ah, al, lane, h, act_of(HS_A1 + 4), PhDsig{},                               // W5^T -> dz4 (kept)
                                          [&](auto T, EpiState& st, const auto&) {
                                              constexpr int t = decltype(T)::value;
                                              asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
@@ -809,10 +833,10 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                                              return NoData{};
                                          },
                                          no_store);
-        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, act_of(HS_A1 + 3), PhDsig{}, to_regs_t(ah, al, HS_DZ + 3), no_store);   // W4h^T -> dz3
-        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, act_of(HS_A1 + 2), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 2), no_store);   // W3^T -> dz2
-        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, act_of(HS_A1 + 1), PhDsig{}, to_regs_t(ah, al, HS_DZ + 1), no_store);   // W2^T -> dz1
-        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, act_of(HS_A1 + 0), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 0), no_store);   // W1^T -> dz0
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD, PH>(ws, bh, bl, lane, h, act_of(HS_A1 + 3), PhDsig{}, to_regs_t(ah, al, HS_DZ + 3), no_store);   // W4h^T -> dz3
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD, PH>(ws, ah, al, lane, h, act_of(HS_A1 + 2), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 2), no_store);   // W3^T -> dz2
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD, PH>(ws, bh, bl, lane, h, act_of(HS_A1 + 1), PhDsig{}, to_regs_t(ah, al, HS_DZ + 1), no_store);   // W2^T -> dz1
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD, PH>(ws, ah, al, lane, h, act_of(HS_A1 + 0), PhDsig{}, to_regs_t(bh, bl, HS_DZ + 0), no_store);   // W1^T -> dz0
 
         if ((HN_DBG(a) >> 8) == 7) return;   // phase timing aid
         // ---- d sdf / d features contracted with the encoding Jacobian, bone by bone: first W0^T dz0 (dz0 is in
@@ -845,10 +869,10 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     ws.template begin_c<HB_BWD>();
                     L1[u] = zero16();
                     L2[u] = zero16();
-                    mma_tile<16, 0, HB_BWD>(ws, buf0, bh, bl, L1[u], L2[u], lane);
+                    mma_tile<16, 0, HB_BWD, PJ>(ws, buf0, bh, bl, L1[u], L2[u], lane);
                     const char* buf4 = ws.template acquire<0>();
                     ws.template begin_c<HB_BWD>();   // after the last one: bone 0's first chunk
-                    mma_tile<16, 0, HB_BWD>(ws, buf4, ah, al, L1[u], L2[u], lane);
+                    mma_tile<16, 0, HB_BWD, PJ>(ws, buf4, ah, al, L1[u], L2[u], lane);
                 });
                 f32x16 La = combine(L1[0], L2[0]), Lb = combine(L1[1], L2[1]);
                 tile_out(La);
@@ -884,11 +908,11 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     }
                     G1[u] = zero16();
                     G2[u] = zero16();
-                    mma_tile<16, 0, HB_BWD>(ws, buf0, bh, bl, G1[u], G2[u], lane);
+                    mma_tile<16, 0, HB_BWD, PJ>(ws, buf0, bh, bl, G1[u], G2[u], lane);
                     const char* buf4 = ws.template acquire<0>();
                     if constexpr (u == 1) ws.goff = jbase + nb * (4 * HB_BWD);
                     ws.template begin_c<HB_BWD>();
-                    mma_tile<16, 0, HB_BWD>(ws, buf4, ah, al, G1[u], G2[u], lane);
+                    mma_tile<16, 0, HB_BWD, PJ>(ws, buf4, ah, al, G1[u], G2[u], lane);
                 });
                 if (live) {   // a bone whose mask is 0 for the whole wave contributes exactly 0
                     const Bone2 bn = coords(b);
@@ -974,10 +998,10 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
                     ws.template begin_c<nbytes>();
                     c1[ti] = zero16();
                     c2[ti] = zero16();
-                    mma_tile<16, 0, nbytes>(ws, buf, xh, xl, c1[ti], c2[ti], lane);
+                    mma_tile<16, 0, nbytes, PC>(ws, buf, xh, xl, c1[ti], c2[ti], lane);
                 });
             }
-            feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_G>{});
+            feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_G>{}, IPC{});
             static_for<2>([&](auto BLK) {
                 constexpr int blk = decltype(BLK)::value;
                 const char* buf = ws.template acquire<0>();
@@ -995,13 +1019,13 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
             });
             block_epilogue(I8t{}, c1, c2, PhRelu{}, to_regs_t(bh, bl, HS_C + 0));
         }
-        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, bh, bl, lane, h, no_pre, PhRelu{}, to_regs_t(ah, al, HS_C + 1), no_store);   // colour lin1
-        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID>(ws, ah, al, lane, h, no_pre, PhRelu{}, to_regs_t(bh, bl, HS_C + 2), no_store);   // colour lin2
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PC>(ws, bh, bl, lane, h, no_pre, PhRelu{}, to_regs_t(ah, al, HS_C + 1), no_store);   // colour lin1
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PC>(ws, ah, al, lane, h, no_pre, PhRelu{}, to_regs_t(bh, bl, HS_C + 2), no_store);   // colour lin2
         struct W3 {
             f32x16 w[3];
         };
         auto col3 = [&](auto NA_) {
-        run_layer_c<8, 16, 1, true, false, HB_HID, decltype(NA_)::value>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
+        run_layer_c<8, 16, 1, true, false, HB_HID, decltype(NA_)::value, PC>(   // colour lin3 + the 3 rows of lin4 (tail slots 1..3)
             ws, bh, bl, lane, h,
             [&](auto, const char* tail) { return W3{{tail_tile(tail, 1, h), tail_tile(tail, 2, h), tail_tile(tail, 3, h)}}; },
             PhRelu{},
@@ -1072,7 +1096,20 @@ static void hand2_common_args(Hand2Args& a, const hn_field* f, const float* pts,
     a.xsync = nullptr;
 }
 
-#ifndef HN_HAND_ADJ_TU   // this translation unit: the evaluation kernels (MODE 0, 1); hn_field2_hand_adj.hip: MODE 2
+#if defined(HN_HAND_F16_TU)   // hn_field2_hand_f16.hip: the evaluation kernels of HN_PREC_F16 (single-pass hidden layers)
+int launch_field2_hand_f16(const Hand2Args& a, int grid, bool full, hipStream_t stream) {
+    static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<1, 1>), (int)HAND2_LDS, &lds_full));
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<0, 1>), (int)HAND2_LDS, &lds_sdf));
+    if (full)
+        hipLaunchKernelGGL((k_field2_hand<1, 1>), dim3(grid), dim3(256), HAND2_LDS, stream, a);
+    else
+        hipLaunchKernelGGL((k_field2_hand<0, 1>), dim3(grid), dim3(256), HAND2_LDS, stream, a);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+#elif !defined(HN_HAND_ADJ_TU)   // this translation unit: the evaluation kernels (MODE 0, 1); hn_field2_hand_adj.hip: MODE 2
+int launch_field2_hand_f16(const Hand2Args& a, int grid, bool full, hipStream_t stream);
 size_t field2_hand_workspace_bytes(int n_pts, int n_cus) {
     return (size_t)hand2_grid(n_pts, n_cus) * WG_WAVES * HAND2_SLOTS * SLOT_F4 * sizeof(float4) + 256;   // + the XCD pacing counters
 }
@@ -1122,6 +1159,7 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
         HN_CHECK_HIP(hipMemsetAsync(a.xsync, 0, 64, stream));
         if (const int ph = pace_phantom_members()) HN_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.xsync), ph, 8, stream));
     }
+    if (f->single_pass) return launch_field2_hand_f16(a, grid, full, stream);   // HN_PREC_F16
     static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};   // devices on which the LDS size attribute is set
     HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<1>), (int)HAND2_LDS, &lds_full));
     HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<0>), (int)HAND2_LDS, &lds_sdf));

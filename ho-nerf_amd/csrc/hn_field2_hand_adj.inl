@@ -287,7 +287,7 @@
             c1[ti] = zero16();
             c2[ti] = zero16();
         }
-        feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_HID>{});
+        feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_HID>{}, IP3{});
         block_epilogue_pd(c1, c2, PhFwdDir{}, pre4(HS_A1 + 0, HS_DZ + 0), fin4(ah, al, HS_DZ + 0));
     }
     run_layer_c<8, 16, 1, false, true, HB_HID, HB_HID>(ws, ah, al, lane, h, pre4(HS_A1 + 1, HS_DZ + 1), PhFwdDir{}, fin4(bh, bl, HS_DZ + 1), no_store);   // lin1
@@ -304,7 +304,7 @@
             c2[ti] = zero16();
             mma_tile<16, 0, nbytes>(ws, buf, bh, bl, c1[ti], c2[ti], lane);
         });
-        feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_HID>{});
+        feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_HID>{}, IP3{});
         block_epilogue_pd(c1, c2, PhFwdDir{}, pre4(HS_A1 + 4, HS_DZ + 4), fin4(ah, al, HS_DZ + 4));
     }
     feat_base = FEAT;

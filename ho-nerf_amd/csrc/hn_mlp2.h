@@ -485,10 +485,20 @@ __device__ __forceinline__ void mfma_blk(const h8& a, const h8& b0, const h8& b1
 }
 // one LDS block (2 KiB: hi + lo fragment) of the tile against the matching B fragments: 3 MFMAs (32x32x16: block =
 // k-step s) or 6 (16x16x32: block s = row block s & 1 of k-step pair s >> 1), with a filler slot after each third
-template <int S, int S0, int NX, typename Slot>
+// PASSES: 3 = the fp32-equivalent product (hi*hi, hi*lo, lo*hi); 1 = the single-pass throughput mode of HN_PREC_F16 (hi*hi
+// only: fp16 operands, fp32 accumulation; the three filler slots are kept so that epilogue slices and DMA pieces are issued
+// exactly as in the 3-pass form)
+template <int S, int S0, int PASSES = 3, int NX, typename Slot>
 __device__ __forceinline__ void mma_block(const h8& ah, const h8& al, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16& c1, f32x16& c2,
                                           Slot&& slot) {
-    if constexpr (S16) {
+    static_assert(PASSES == 1 || PASSES == 3, "1 or 3 MFMAs per product");
+    if constexpr (PASSES == 1) {
+        static_assert(!S16, "the single-pass mode is built on the 32x32x16 shape");
+        c1 = mfma16(ah, xh[S0 + S], c1);
+        slot(std::integral_constant<int, 3 * S>{});
+        slot(std::integral_constant<int, 3 * S + 1>{});
+        slot(std::integral_constant<int, 3 * S + 2>{});
+    } else if constexpr (S16) {
         static_assert(S0 % 2 == 0, "k-step pairs");
         constexpr int b = S0 + (S & ~1), RB = S & 1;
         mfma_blk<RB>(ah, xh[b], xh[b + 1], c1);
@@ -539,7 +549,7 @@ struct NoEpi {
 #endif
 // FETCH: 0 none; 1 the run-time form (WStream::begin / piece); >= 1024: the size of the chunk being fetched, a
 // constant (WStream::begin_c / piece_c)
-template <int KS, int S0, int FETCH, int NX, typename Epi>
+template <int KS, int S0, int FETCH, int PASSES = 3, int NX, typename Epi>
 __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16& c1,
                                          f32x16& c2, int lane, Epi& epi) {
     static_assert(S0 + KS <= NX, "k-step range");
@@ -556,7 +566,7 @@ __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 
     auto load = [&](auto S) {
         constexpr int s = decltype(S)::value;
         ah[s % 3] = *reinterpret_cast<const h8*>(lblk + s * KS_BYTES);
-        al[s % 3] = *reinterpret_cast<const h8*>(lblk + s * KS_BYTES + 1024);
+        if constexpr (PASSES == 3) al[s % 3] = *reinterpret_cast<const h8*>(lblk + s * KS_BYTES + 1024);
     };
     auto slot = [&](auto Q_) {
         constexpr int Q = decltype(Q_)::value;
@@ -571,15 +581,15 @@ __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 
     static_for<KS>([&](auto S) {
         constexpr int s = decltype(S)::value;
         if constexpr (s + 2 < KS) load(std::integral_constant<int, s + 2>{});
-        mma_block<s, S0>(ah[s % 3], al[s % 3], xh, xl, c1, c2, slot);
+        mma_block<s, S0, PASSES>(ah[s % 3], al[s % 3], xh, xl, c1, c2, slot);
     });
     ws.stamp(4);
 }
-template <int KS, int S0, int FETCH, int NX>
+template <int KS, int S0, int FETCH, int PASSES = 3, int NX>
 __device__ __forceinline__ void mma_tile(WStream& ws, const char* blk, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16& c1,
                                          f32x16& c2, int lane) {
     NoEpi e;
-    mma_tile<KS, S0, FETCH>(ws, blk, xh, xl, c1, c2, lane, e);
+    mma_tile<KS, S0, FETCH, PASSES>(ws, blk, xh, xl, c1, c2, lane, e);
 }
 
 // A whole chunk of NT tiles x KS k-steps that share the KS fragments xh/xl (the hand field's feature passes):
@@ -592,7 +602,7 @@ struct NoMid {
 };
 // mid(): called once, in the slot behind the last DMA piece -- vector-memory work issued there is YOUNGER than the pieces,
 // so the next acquire can let it stay in flight (acquire<ALLOW>)
-template <int NT, int KS, int FETCH = 1, int NX, typename Mid = NoMid>
+template <int NT, int KS, int FETCH = 1, int PASSES = 3, int NX, typename Mid = NoMid>
 __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8 (&xh)[NX], const h8 (&xl)[NX], f32x16* c1,
                                           f32x16* c2, int lane, Mid&& mid = Mid{}) {
     static_assert(KS <= NX, "k-step range");
@@ -609,7 +619,7 @@ __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8
     auto load = [&](auto S) {
         constexpr int s = decltype(S)::value;
         ah[s % 3] = *reinterpret_cast<const h8*>(lbuf + s * KS_BYTES);
-        al[s % 3] = *reinterpret_cast<const h8*>(lbuf + s * KS_BYTES + 1024);
+        if constexpr (PASSES == 3) al[s % 3] = *reinterpret_cast<const h8*>(lbuf + s * KS_BYTES + 1024);
     };
     auto slot = [&](auto Q_) {
         constexpr int Q = decltype(Q_)::value;
@@ -628,7 +638,7 @@ __device__ __forceinline__ void mma_chunk(WStream& ws, const char* buf, const h8
         if constexpr (k == 0) ws.stamp(5);
         // (slot indices continue over the tiles of the chunk: block k of tile t is slot base 3 (t KS + k))
         auto slot_t = [&](auto Q_) { slot(std::integral_constant<int, decltype(Q_)::value + 3 * t * KS>{}); };
-        mma_block<k, 0>(ah[s % 3], al[s % 3], xh, xl, c1[t], c2[t], slot_t);
+        mma_block<k, 0, PASSES>(ah[s % 3], al[s % 3], xh, xl, c1[t], c2[t], slot_t);
     });
     ws.stamp(4);
 }
@@ -878,7 +888,7 @@ __device__ __forceinline__ void arm(EpiState& st) {
 // next_same / next_after: bytes of the chunk that follows a chunk of this layer (another of the same
 // layer / the first of the next layer; 0 = none).
 // NS / NA >= 0: next_same / next_after as constants (the compile-time-sized fetch of WStream); -1: the run-time arguments.
-template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, int NS, int NA, int NX, typename Pre, typename Ph, typename Fin, typename Store>
+template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, int NS, int NA, int PASSES, int NX, typename Pre, typename Ph, typename Fin, typename Store>
 __device__ __forceinline__ void run_layer_impl(WStream& ws, int next_same, int next_after, const h8 (&xh)[NX], const h8 (&xl)[NX],
                                                int lane, int h, Pre&& pre, Ph&& ph, Fin&& fin, Store&& store) {
     static_assert((NS >= 0) == (NA >= 0), "both sizes constant or both run-time");
@@ -910,11 +920,11 @@ __device__ __forceinline__ void run_layer_impl(WStream& ws, int next_same, int n
         pd[t & 1] = pre(T, tail);
         if constexpr (t > 0) {
             Epi<FRAGS, std::remove_reference_t<Ph>, PD> epi{st, ph, pd[(t - 1) & 1]};
-            mma_tile<KS, 0, fetch>(ws, buf + (t % TPC) * KS * KS_BYTES, xh, xl, c1[t & 1], c2[t & 1], lane, epi);
+            mma_tile<KS, 0, fetch, PASSES>(ws, buf + (t % TPC) * KS * KS_BYTES, xh, xl, c1[t & 1], c2[t & 1], lane, epi);
             split_finish<FRAGS>(st);
             held = fin(std::integral_constant<int, t - 1>{}, st, pd[(t - 1) & 1]);
         } else {
-            mma_tile<KS, 0, fetch>(ws, buf + (t % TPC) * KS * KS_BYTES, xh, xl, c1[t & 1], c2[t & 1], lane);
+            mma_tile<KS, 0, fetch, PASSES>(ws, buf + (t % TPC) * KS * KS_BYTES, xh, xl, c1[t & 1], c2[t & 1], lane);
         }
     });
     if constexpr (OT >= 2) store(std::integral_constant<int, OT - 2>{}, held);
@@ -930,12 +940,12 @@ __device__ __forceinline__ void run_layer_impl(WStream& ws, int next_same, int n
 template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, int NX, typename Pre, typename Ph, typename Fin, typename Store>
 __device__ __forceinline__ void run_layer(WStream& ws, int next_same, int next_after, const h8 (&xh)[NX], const h8 (&xl)[NX],
                                           int lane, int h, Pre&& pre, Ph&& ph, Fin&& fin, Store&& store) {
-    run_layer_impl<OT, KS, TPC, TAIL, FRAGS, -1, -1>(ws, next_same, next_after, xh, xl, lane, h, pre, ph, fin, store);
+    run_layer_impl<OT, KS, TPC, TAIL, FRAGS, -1, -1, 3>(ws, next_same, next_after, xh, xl, lane, h, pre, ph, fin, store);
 }
-template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, int NS, int NA, int NX, typename Pre, typename Ph, typename Fin, typename Store>
+template <int OT, int KS, int TPC, bool TAIL, bool FRAGS, int NS, int NA, int PASSES = 3, int NX, typename Pre, typename Ph, typename Fin, typename Store>
 __device__ __forceinline__ void run_layer_c(WStream& ws, const h8 (&xh)[NX], const h8 (&xl)[NX], int lane, int h, Pre&& pre,
                                             Ph&& ph, Fin&& fin, Store&& store) {
-    run_layer_impl<OT, KS, TPC, TAIL, FRAGS, NS, NA>(ws, 0, 0, xh, xl, lane, h, pre, ph, fin, store);
+    run_layer_impl<OT, KS, TPC, TAIL, FRAGS, NS, NA, PASSES>(ws, 0, 0, xh, xl, lane, h, pre, ph, fin, store);
 }
 
 // standard phases ---------------------------------------------------------------------------------

@@ -402,6 +402,10 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
     // hn_field_param_bwd, which works on the retained row-major matrices)
     const bool eval_only = (precision & HN_PACK_EVAL_ONLY) != 0;
     precision &= ~HN_PACK_EVAL_ONLY;
+    // HN_PREC_F16 is HN_PREC_F16X3 (same packed streams, same adjoint / tape kernels) whose evaluation kernels take one
+    // MFMA pass per product in the hidden layers
+    const bool single_pass = precision == HN_PREC_F16;
+    if (single_pass) precision = HN_PREC_F16X3;
     HN_REQUIRE(precision == HN_PREC_FP32 || precision == HN_PREC_F16X3, "unsupported precision %d", precision);
     int rc = check_shapes(kind, sdf, col);
     if (rc != HN_OK) return rc;
@@ -417,6 +421,7 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
     hn_field* f = new hn_field();
     f->kind = kind;
     f->precision = precision;
+    f->single_pass = single_pass ? 1 : 0;
     f->variance = variance;
     f->scale = scale;
     {

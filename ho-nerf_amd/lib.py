@@ -17,8 +17,9 @@ HN_FIELD_OBJ = 0
 HN_FIELD_HAND = 1
 HN_PREC_FP32 = 0
 HN_PREC_F16X3 = 1
+HN_PREC_F16 = 2           # single-pass throughput mode of the evaluation kernels (include/honerf.h)
 HN_PACK_EVAL_ONLY = 0x100     # no adjoint weight streams (fields re-packed every training step)
-PRECISIONS = {'fp32': HN_PREC_FP32, 'f16x3': HN_PREC_F16X3}
+PRECISIONS = {'fp32': HN_PREC_FP32, 'f16x3': HN_PREC_F16X3, 'f16': HN_PREC_F16}
 # 'f16x3': fp16 hi/lo split operands on the f16 MFMA, fp32-equivalent results (the default);
 # 'fp32': the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32), 5x slower, kept as a second opinion
 DEFAULT_PRECISION = os.environ.get('HONERF_PRECISION', 'f16x3')

@@ -41,6 +41,11 @@ extern "C" {
 #define HN_PREC_FP32 0   /* exact fp32: v_mfma_f32_32x32x2_f32 == fmaf chains */
 #define HN_PREC_F16X3 1  /* fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16 per product, fp32
                           * accumulate: fp32-equivalent results (22-bit operands) at 16/3 x the rate */
+#define HN_PREC_F16 2    /* throughput mode: an HN_PREC_F16X3 field whose EVALUATION kernels (hn_field_sdf / hn_field_eval, the
+                          * renders without a tape) run the hidden layers of both networks on ONE f16 MFMA per product (fp16
+                          * operands, fp32 accumulation); the encodings, the feature layers, the last SDF layer, the alpha
+                          * stage and every adjoint / taped kernel stay fp32-equivalent.  Error ~1e-3 (tests pin it):
+                          * a secondary figure, never the parity path.  Hand fields; an obj field behaves as F16X3. */
 /* OR-ed into `precision` at hn_field_create: pack the evaluation programs only, no adjoint weight streams.  For fields
  * that are re-packed every optimiser step (training, honerf_amd/training.py): their backward pass is
  * hn_field_param_bwd / hn_render_single_bwd, which work on the retained row-major matrices; hn_field_eval_bwd and

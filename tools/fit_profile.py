@@ -12,7 +12,8 @@ from honerf_amd import fitting as F
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device('cuda')
-ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3')
+halo = (sys.argv[2] if len(sys.argv) > 2 else 'halo') == 'halo'     # the reference's six-leaf pose chain (default) or the rigid one
+ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3', halo=halo)
 opt = F.make_optimizer(chain, video=False)
 for i in range(3):
     F.fit_step(ren, views[i % 8], chain, opt, bench.NEAR, bench.FAR, '12')
