@@ -212,3 +212,67 @@ class FitLossFn(torch.autograd.Function):
         s_c, s_w, s_s = ctx.shapes
         return (gc.reshape(s_c), gw.reshape(s_w), None if gsh is None else gsh.reshape(s_s), None if gso is None else gso.reshape(s_s),
                 None, None)
+
+
+class FitStepLossFn(torch.autograd.Function):
+    """The whole loss of one fitting_single step (fitting_single.py:251-288) as three launches forward (hn_fit_loss_sums,
+    hn_verts_loss, hn_fit_total) and two backward (hn_fit_total_bwd, hn_fit_loss_grads), instead of ~25 + ~35 element-wise
+    torch launches in a step that is a chain of dependent launches:
+      (color_fine [R,3], weight_sum [R,1], sdf_hand [n,1] | None, sdf_obj | None, joint_3d [1,21,3], obj_r [1,3,3], obj_t [1,3])
+      -> (loss [], terms [8] = loss, colour, mask, contact, penetration, joint, verts, 0  -- not differentiable).
+    weights = (w_render, w_contact, w_penetration, w_joint, w_verts)."""
+
+    @staticmethod
+    def forward(ctx, color, wsum, sdf_h, sdf_o, joint_3d, obj_r, obj_t, true_rgb, true_mask, joint_pred, Ro_pred, To_pred, verts, weights):
+        L = _lib
+        lib = L.load()
+        dev = color.device
+        st = L.stream_ptr()
+        c, w = L.f32(color).reshape(-1, 3), L.f32(wsum).reshape(-1)
+        t, m = L.f32(true_rgb, dev).reshape(-1, 3), L.f32(true_mask, dev).reshape(-1)
+        sh = None if sdf_h is None else L.f32(sdf_h).reshape(-1)
+        so = None if sdf_o is None else L.f32(sdf_o).reshape(-1)
+        R, n = c.shape[0], 0 if sh is None else sh.shape[0]
+        j3, jp = L.f32(joint_3d).reshape(-1, 3), L.f32(joint_pred, dev).reshape(-1, 3)
+        nj = j3.shape[0]
+        assert jp.shape[0] == nj and nj <= 64, 'one frame of joints'
+        Ra, ta = L.f32(obj_r).reshape(1, 9), L.f32(obj_t).reshape(1, 3)
+        Rb, tb = L.f32(Ro_pred, dev).reshape(1, 9), L.f32(To_pred, dev).reshape(1, 3)
+        buf = _empty(6 + 1 + 9 + 3 + 8 + 3 * nj, dev=dev)          # one allocation: sums | verts loss | gR | gt | terms | g_joint
+        sums, vloss, gR, gt, terms, gj = buf[0:6], buf[6:7], buf[7:16], buf[16:19], buf[19:27], buf[27:27 + 3 * nj]
+        L.check(lib.hn_fit_loss_sums(L.ptr(c), L.ptr(w), L.ptr(t), L.ptr(m), R, L.ptr(sh), L.ptr(so), n, L.ptr(sums), st), 'hn_fit_loss_sums')
+        L.check(lib.hn_verts_loss(L.ptr(Ra), L.ptr(ta), L.ptr(Rb), L.ptr(tb), L.ptr(verts), verts.shape[0], 1, L.ptr(vloss), L.ptr(gR), L.ptr(gt), st),
+                'hn_verts_loss')
+        w5 = (ctypes.c_float * 5)(*[float(x) for x in weights])
+        L.check(lib.hn_fit_total(L.ptr(sums), L.ptr(vloss), L.ptr(j3), L.ptr(jp), nj, w5, L.ptr(terms), L.ptr(gj), st), 'hn_fit_total')
+        ctx.save_for_backward(c, w, t, m, buf, *([sh, so] if sh is not None else []))
+        ctx.w5, ctx.nj = w5, nj
+        ctx.shapes = (color.shape, wsum.shape, None if sdf_h is None else sdf_h.shape, joint_3d.shape, obj_r.shape, obj_t.shape)
+        ctx.mark_non_differentiable(terms)
+        return terms[0], terms
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        L = _lib
+        lib = L.load()
+        sv = ctx.saved_tensors
+        c, w, t, m, buf = sv[:5]
+        sh, so = (sv[5], sv[6]) if len(sv) > 5 else (None, None)
+        nj = ctx.nj
+        sums, gR, gt, gj = buf[0:6], buf[7:16], buf[16:19], buf[27:27 + 3 * nj]
+        dev = c.device
+        st = L.stream_ptr()
+        R, n = c.shape[0], 0 if sh is None else sh.shape[0]
+        out = _empty(4 + 3 * nj + 9 + 3, dev=dev)
+        g4, gj_o, gR_o, gt_o = out[0:4], out[4:4 + 3 * nj], out[4 + 3 * nj:13 + 3 * nj], out[13 + 3 * nj:16 + 3 * nj]
+        gl = L.f32(g_loss).reshape(1)
+        L.check(lib.hn_fit_total_bwd(L.ptr(gl), ctx.w5, L.ptr(gj), L.ptr(gR), L.ptr(gt), nj, L.ptr(g4), L.ptr(gj_o), L.ptr(gR_o), L.ptr(gt_o), st),
+                'hn_fit_total_bwd')
+        gc, gw = _empty(R, 3, dev=dev), _empty(R, dev=dev)
+        gsh = _empty(n, dev=dev) if sh is not None else None
+        gso = _empty(n, dev=dev) if sh is not None else None
+        L.check(lib.hn_fit_loss_grads(L.ptr(c), L.ptr(w), L.ptr(t), L.ptr(m), R, L.ptr(sh), L.ptr(so), n, L.ptr(sums), L.ptr(g4), L.ptr(gc),
+                                      L.ptr(gw), L.ptr(gsh), L.ptr(gso), st), 'hn_fit_loss_grads')
+        s_c, s_w, s_s, s_j, s_r, s_t = ctx.shapes
+        return (gc.reshape(s_c), gw.reshape(s_w), None if gsh is None else gsh.reshape(s_s), None if gso is None else gso.reshape(s_s),
+                gj_o.reshape(s_j), gR_o.reshape(s_r), gt_o.reshape(s_t), None, None, None, None, None, None, None)

@@ -46,6 +46,8 @@ int composite1_bwd(const float*, const float*, const float*, const float*, const
 int composite2_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
                    float*, float*, float*, hipStream_t);
 int fit_loss_sums(const float*, const float*, const float*, const float*, int, const float*, const float*, int, float*, hipStream_t);
+int fit_total(const float*, const float*, const float*, const float*, int, const float*, float*, float*, hipStream_t);
+int fit_total_bwd(const float*, const float*, const float*, const float*, const float*, int, float*, float*, float*, float*, hipStream_t);
 int fit_loss_grads(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*,
                    const float*, float*, float*, float*, float*, hipStream_t);
 size_t field_obj_workspace_bytes(int n_pts, int n_cus);
@@ -875,6 +877,15 @@ int hn_fit_loss_grads(const float* color, const float* weight_sum, const float* 
                       float* g_color, float* g_weight_sum, float* g_sdf_hand, float* g_sdf_obj, hn_stream_t stream) {
     return fit_loss_grads(color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, sums6, g4, g_color,
                           g_weight_sum, g_sdf_hand, g_sdf_obj, (hipStream_t)stream);
+}
+
+int hn_fit_total(const float* sums6, const float* verts_loss, const float* joint_3d, const float* joint3d_pred, int n_joints,
+                 const float* weights5, float* terms8, float* g_joint, hn_stream_t stream) {
+    return fit_total(sums6, verts_loss, joint_3d, joint3d_pred, n_joints, weights5, terms8, g_joint, (hipStream_t)stream);
+}
+int hn_fit_total_bwd(const float* g_loss, const float* weights5, const float* g_joint, const float* gR, const float* gt, int n_joints,
+                     float* g4, float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream) {
+    return fit_total_bwd(g_loss, weights5, g_joint, gR, gt, n_joints, g4, g_joint_out, gR_out, gt_out, (hipStream_t)stream);
 }
 
 size_t hn_render_single_workspace_bytes(const hn_field* f, int n_rays, int n_samples, int n_importance) {

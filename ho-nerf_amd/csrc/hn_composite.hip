@@ -412,7 +412,7 @@ __global__ void k_alpha_bwd(const float* __restrict__ sdf, const float* __restri
                             const float* __restrict__ g_c, int n, int spr, float inv_s, float* __restrict__ g_sdf,
                             float* __restrict__ g_grad, float* __restrict__ g_rays_d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n) return;   // (the wave-level reduction below checks that all 64 lanes are present)
     const int ray = i / spr;
     const float d0 = rays_d[3 * ray], d1 = rays_d[3 * ray + 1], d2 = rays_d[3 * ray + 2];
     const float q0 = grad[3 * (size_t)i], q1 = grad[3 * (size_t)i + 1], q2 = grad[3 * (size_t)i + 2];
@@ -437,9 +437,22 @@ __global__ void k_alpha_bwd(const float* __restrict__ sdf, const float* __restri
     g_grad[3 * (size_t)i + 1] = gtc * d1;
     g_grad[3 * (size_t)i + 2] = gtc * d2;
     if (g_rays_d != nullptr) {
-        atomicAdd(g_rays_d + 3 * ray, gtc * q0);
-        atomicAdd(g_rays_d + 3 * ray + 1, gtc * q1);
-        atomicAdd(g_rays_d + 3 * ray + 2, gtc * q2);
+        // the 64 samples of a wave usually belong to one ray (spr a multiple of 64: 3 atomics per wave instead of 192);
+        // S adders on one address were the kernel's whole time at the fitting sizes (78 of 80 us for 196 x 192 samples)
+        const int ray0 = __shfl(ray, 0, 64);
+        const bool whole = __all(ray == ray0) && __popcll(__ballot(1)) == 64;
+        if (whole) {
+            const float r0 = wave_sum(gtc * q0), r1 = wave_sum(gtc * q1), r2 = wave_sum(gtc * q2);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(g_rays_d + 3 * ray, r0);
+                atomicAdd(g_rays_d + 3 * ray + 1, r1);
+                atomicAdd(g_rays_d + 3 * ray + 2, r2);
+            }
+        } else {
+            atomicAdd(g_rays_d + 3 * ray, gtc * q0);
+            atomicAdd(g_rays_d + 3 * ray + 1, gtc * q1);
+            atomicAdd(g_rays_d + 3 * ray + 2, gtc * q2);
+        }
     }
 }
 
@@ -513,6 +526,93 @@ __global__ void k_composite2_bwd(const float* __restrict__ ah, const float* __re
         g_ah[base + k] = Tk * u1 - Tk * P * f2;     // df/da1 = -f2
         g_ao[base + k] = Tk * u2 - Tk * P * f1;     // df/da2 = -f1
         P = (a1 * u1 + a2 * u2) + f1 * f2 * P;
+    }
+}
+
+// The same adjoint with one WAVE per ray (S <= 64 * CPL): lane l owns the CPL consecutive samples CPL l .. CPL l + CPL - 1,
+// the transmittance is an exclusive product scan over the lanes, and the suffix recurrence P_k = c_k + m_k P_{k+1} is a
+// suffix scan of the affine maps x -> c + m x (composition (m1, c1) o (m2, c2) = (m1 m2, c1 + m1 c2)).  The one-thread-per-ray
+// form above walks 192 dependent, uncoalesced rows per ray: 152 us at the fitting size (196 rays), against ~6 us here.
+template <int CPL>
+__global__ __launch_bounds__(256) void k_composite2_bwd_wave(const float* __restrict__ ah, const float* __restrict__ rgbh,
+                                                             const float* __restrict__ ao, const float* __restrict__ rgbo,
+                                                             const float* __restrict__ g_color, const float* __restrict__ g_wsum,
+                                                             int n_rays, int S, float* __restrict__ g_ah, float* __restrict__ g_rgbh,
+                                                             float* __restrict__ g_ao, float* __restrict__ g_rgbo) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const size_t base = (size_t)ray * S;
+    const float gC0 = g_color[3 * ray], gC1 = g_color[3 * ray + 1], gC2 = g_color[3 * ray + 2];
+    const float gW = g_wsum != nullptr ? g_wsum[ray] : 0.f;
+    float a1[CPL], a2[CPL], u1[CPL], u2[CPL], f1[CPL], f2[CPL];
+    float Fl = 1.f;   // product of this lane's factors
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int k = lane * CPL + j;
+        const bool in = k < S;
+        a1[j] = in ? ah[base + k] : 0.f;
+        a2[j] = in ? ao[base + k] : 0.f;
+        u1[j] = u2[j] = 0.f;
+        if (in) {
+            const float* r1 = rgbh + 3 * (base + k);
+            const float* r2 = rgbo + 3 * (base + k);
+            u1[j] = gC0 * r1[0] + gC1 * r1[1] + gC2 * r1[2] + gW;
+            u2[j] = gC0 * r2[0] + gC1 * r2[1] + gC2 * r2[2] + gW;
+        }
+        f1[j] = in ? 1.f - a1[j] + 1e-7f : 1.f;
+        f2[j] = in ? 1.f - a2[j] + 1e-7f : 1.f;
+        Fl *= f1[j] * f2[j];
+    }
+    // exclusive product scan over the lanes -> transmittance in front of this lane's first sample
+    float incl = Fl;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl *= o;
+    }
+    float T = __shfl_up(incl, 1, 64);
+    if (lane == 0) T = 1.f;
+    float Tk[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        Tk[j] = T;
+        T *= f1[j] * f2[j];
+    }
+    // this lane's composite map x -> C + M x (its samples applied last to first), then the suffix scan over the lanes
+    float M = 1.f, C = 0.f;
+#pragma unroll
+    for (int j = CPL - 1; j >= 0; --j) {
+        const float m = f1[j] * f2[j], c = a1[j] * u1[j] + a2[j] * u2[j];
+        C = c + m * C;
+        M = m * M;
+    }
+    float sm = M, sc = C;   // inclusive: lanes l .. 63
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float om = __shfl_down(sm, off, 64), oc = __shfl_down(sc, off, 64);
+        if (lane + off < 64) {
+            sc = sc + sm * oc;
+            sm = sm * om;
+        }
+    }
+    float P = __shfl_down(sc, 1, 64);   // the recurrence's value behind this lane's last sample (maps applied to 0)
+    if (lane == 63) P = 0.f;
+#pragma unroll
+    for (int j = CPL - 1; j >= 0; --j) {
+        const int k = lane * CPL + j;
+        if (k < S) {
+            g_ah[base + k] = Tk[j] * u1[j] - Tk[j] * P * f2[j];
+            g_ao[base + k] = Tk[j] * u2[j] - Tk[j] * P * f1[j];
+            const float w1 = a1[j] * Tk[j], w2 = a2[j] * Tk[j];
+            g_rgbh[3 * (base + k)] = w1 * gC0;
+            g_rgbh[3 * (base + k) + 1] = w1 * gC1;
+            g_rgbh[3 * (base + k) + 2] = w1 * gC2;
+            g_rgbo[3 * (base + k)] = w2 * gC0;
+            g_rgbo[3 * (base + k) + 1] = w2 * gC1;
+            g_rgbo[3 * (base + k) + 2] = w2 * gC2;
+        }
+        P = (a1[j] * u1[j] + a2[j] * u2[j]) + f1[j] * f2[j] * P;
     }
 }
 
@@ -652,8 +752,18 @@ int composite2_bwd(const float* ah, const float* rgbh, const float* ao, const fl
                    hipStream_t s) {
     HN_REQUIRE(S >= 1, "S must be positive");
     if (n_rays == 0) return HN_OK;
-    hipLaunchKernelGGL(k_composite2_bwd, dim3((n_rays + 63) / 64), dim3(64), 0, s, ah, rgbh, ao, rgbo, g_color, g_wsum,
-                       n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo);
+    const dim3 wgrid((n_rays + 3) / 4);   // 4 rays (waves) per block
+    if (S <= 64)
+        hipLaunchKernelGGL(k_composite2_bwd_wave<1>, wgrid, dim3(256), 0, s, ah, rgbh, ao, rgbo, g_color, g_wsum, n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo);
+    else if (S <= 128)
+        hipLaunchKernelGGL(k_composite2_bwd_wave<2>, wgrid, dim3(256), 0, s, ah, rgbh, ao, rgbo, g_color, g_wsum, n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo);
+    else if (S <= 192)
+        hipLaunchKernelGGL(k_composite2_bwd_wave<3>, wgrid, dim3(256), 0, s, ah, rgbh, ao, rgbo, g_color, g_wsum, n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo);
+    else if (S <= 256)
+        hipLaunchKernelGGL(k_composite2_bwd_wave<4>, wgrid, dim3(256), 0, s, ah, rgbh, ao, rgbo, g_color, g_wsum, n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo);
+    else
+        hipLaunchKernelGGL(k_composite2_bwd, dim3((n_rays + 63) / 64), dim3(64), 0, s, ah, rgbh, ao, rgbo, g_color, g_wsum,
+                           n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -745,6 +855,76 @@ int fit_loss_grads(const float* color, const float* wsum, const float* true_rgb,
     if (n <= 0) return HN_OK;
     hipLaunchKernelGGL(k_fit_loss_grads, dim3((n + 255) / 256), dim3(256), 0, s, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o,
                        sdf_h != nullptr ? n_samples : 0, sums6, g4, g_color, g_wsum, g_sdf_h, g_sdf_o);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+// ---- the whole loss of a fitting_single step in one launch (fitting_single.py:251-288) ------------------------------------
+// terms8 = {loss, colour, mask, contact, penetration, joint, verts, 0} from the sums of k_fit_loss_sums, the vertex loss of
+// k_verts_loss and the joint loss  sum_j |joint3d_pred_j - joint_3d_j| / n_joints  (pose_loss, :119-122), combined as
+//   loss = w0 (colour + 0.5 mask) + w1 contact + w2 penetration + w3 joint + w4 verts
+// (w = {1, 30, 20, 30, 20} for fit type 12, {1, 0, 0, 100, 5} for fit type 1).  g_joint [n_joints,3] = d joint / d joint_3d.
+// As torch operators this was ~25 element-wise launches forward and ~35 backward in a step that is a chain of dependent launches.
+__global__ __launch_bounds__(64) void k_fit_total(const float* __restrict__ sums6, const float* __restrict__ verts_loss,
+                                                  const float* __restrict__ joint_3d, const float* __restrict__ joint_pred, int n_joints,
+                                                  float w0, float w1, float w2, float w3, float w4, float* __restrict__ terms8,
+                                                  float* __restrict__ g_joint) {
+    const int j = threadIdx.x;
+    float nrm = 0.f;
+    if (j < n_joints) {
+        const float e0 = joint_3d[3 * j] - joint_pred[3 * j], e1 = joint_3d[3 * j + 1] - joint_pred[3 * j + 1],
+                    e2 = joint_3d[3 * j + 2] - joint_pred[3 * j + 2];
+        nrm = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+        const float inv = nrm > 0.f ? 1.f / (nrm * (float)n_joints) : 0.f;   // torch.norm's subgradient at 0 is 0
+        g_joint[3 * j] = e0 * inv;
+        g_joint[3 * j + 1] = e1 * inv;
+        g_joint[3 * j + 2] = e2 * inv;
+    }
+    const float joint = wave_sum(nrm) / (float)n_joints;
+    if (j == 0) {
+        const float colour = sums6[0], mask = sums6[1];
+        const float contact = sums6[2] / (sums6[3] + 1e-9f), penet = sums6[4] / (sums6[5] + 1e-9f);
+        const float verts = verts_loss[0];
+        terms8[0] = w0 * (colour + 0.5f * mask) + (w1 * contact + w2 * penet) + (w3 * joint + w4 * verts);
+        terms8[1] = colour;
+        terms8[2] = mask;
+        terms8[3] = contact;
+        terms8[4] = penet;
+        terms8[5] = joint;
+        terms8[6] = verts;
+        terms8[7] = 0.f;
+    }
+}
+// upstream gradient of the loss (a device scalar) -> g4 for k_fit_loss_grads and the scaled pose-side gradients
+__global__ __launch_bounds__(64) void k_fit_total_bwd(const float* __restrict__ g_loss, float w0, float w1, float w2, float w3, float w4,
+                                                      const float* __restrict__ g_joint, const float* __restrict__ gR,
+                                                      const float* __restrict__ gt, int n_joints, float* __restrict__ g4,
+                                                      float* __restrict__ g_joint_out, float* __restrict__ gR_out, float* __restrict__ gt_out) {
+    const float g = g_loss[0];
+    const int i = threadIdx.x;
+    if (i == 0) {
+        g4[0] = g * w0;
+        g4[1] = g * w0 * 0.5f;
+        g4[2] = g * w1;
+        g4[3] = g * w2;
+    }
+    for (int k = i; k < 3 * n_joints; k += 64) g_joint_out[k] = g * w3 * g_joint[k];
+    if (i < 9) gR_out[i] = g * w4 * gR[i];
+    if (i < 3) gt_out[i] = g * w4 * gt[i];
+}
+int fit_total(const float* sums6, const float* verts_loss, const float* joint_3d, const float* joint_pred, int n_joints, const float* w5,
+              float* terms8, float* g_joint, hipStream_t s) {
+    HN_REQUIRE(sums6 && verts_loss && joint_3d && joint_pred && w5 && terms8 && g_joint && n_joints >= 1 && n_joints <= 64, "bad arguments");
+    hipLaunchKernelGGL(k_fit_total, dim3(1), dim3(64), 0, s, sums6, verts_loss, joint_3d, joint_pred, n_joints, w5[0], w5[1], w5[2], w5[3], w5[4],
+                       terms8, g_joint);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+int fit_total_bwd(const float* g_loss, const float* w5, const float* g_joint, const float* gR, const float* gt, int n_joints, float* g4,
+                  float* g_joint_out, float* gR_out, float* gt_out, hipStream_t s) {
+    HN_REQUIRE(g_loss && w5 && g_joint && gR && gt && g4 && g_joint_out && gR_out && gt_out && n_joints >= 1 && n_joints <= 64, "bad arguments");
+    hipLaunchKernelGGL(k_fit_total_bwd, dim3(1), dim3(64), 0, s, g_loss, w5[0], w5[1], w5[2], w5[3], w5[4], g_joint, gR, gt, n_joints, g4,
+                       g_joint_out, gR_out, gt_out);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

@@ -356,8 +356,8 @@ __device__ __forceinline__ float wave_sum64(float v) {
 #ifndef HN_F16_COLOR_PASSES
 #define HN_F16_COLOR_PASSES 3  // the colour network (measured at one pass: rgb 3e-2 from the reference on the fixture; at three: see tests)
 #endif
-template <int MODE, int HP = 3>
-__global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
+template <int MODE, int HP>
+__device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
     static_assert(HP == 3 || MODE <= 1, "the single-pass mode exists for the evaluation kernels");
     constexpr int PH = HP;                                  // hidden layers, reverse sweep, colour network
     constexpr int PF = HP == 1 ? HN_F16_FEAT_PASSES : 3;
@@ -1073,6 +1073,17 @@ __global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
     }
 }
 
+// the kernels proper: k_field2_hand<MODE> (fp32-equivalent, the names the profiles of every round carry) and the
+// single-pass evaluation kernels of HN_PREC_F16
+template <int MODE>
+__global__ __launch_bounds__(256) void k_field2_hand(const Hand2Args a) {
+    field2_hand_body<MODE, 3>(a);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_field2_hand_f16(const Hand2Args a) {
+    field2_hand_body<MODE, 1>(a);
+}
+
 constexpr size_t HAND2_LDS = 2 * CHUNK_MAX + WG_WAVES * STAGE_BYTES + 16;   // + the 4 per-wave bone masks (culling)
 
 static int hand2_grid(int n_pts, int n_cus) {
@@ -1099,12 +1110,12 @@ static void hand2_common_args(Hand2Args& a, const hn_field* f, const float* pts,
 #if defined(HN_HAND_F16_TU)   // hn_field2_hand_f16.hip: the evaluation kernels of HN_PREC_F16 (single-pass hidden layers)
 int launch_field2_hand_f16(const Hand2Args& a, int grid, bool full, hipStream_t stream) {
     static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};
-    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<1, 1>), (int)HAND2_LDS, &lds_full));
-    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<0, 1>), (int)HAND2_LDS, &lds_sdf));
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand_f16<1>), (int)HAND2_LDS, &lds_full));
+    HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand_f16<0>), (int)HAND2_LDS, &lds_sdf));
     if (full)
-        hipLaunchKernelGGL((k_field2_hand<1, 1>), dim3(grid), dim3(256), HAND2_LDS, stream, a);
+        hipLaunchKernelGGL(k_field2_hand_f16<1>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
     else
-        hipLaunchKernelGGL((k_field2_hand<0, 1>), dim3(grid), dim3(256), HAND2_LDS, stream, a);
+        hipLaunchKernelGGL(k_field2_hand_f16<0>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

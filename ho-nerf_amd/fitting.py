@@ -362,6 +362,15 @@ def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, 
     """The full loss of one step: fitting_single.py:251-283 (video=False) or fitting_video.py:285-334 (video=True:
     + smoothness over the window's frames x50, anchored to the prediction at the sequence ends; + 100 x the stable
     term for fit type '1234').  `pose` is the pose chain's output dict."""
+    if not video and render_out['color_fine'].is_cuda and 'obj_verts' in pose and pose['joint_3d'].shape[0] == 1:
+        # fitting_single on the device: the whole loss is one autograd node over five launches (autograd.FitStepLossFn)
+        from .autograd import FitStepLossFn
+        interaction = fit_type in ('12', '123', '1234')
+        weights = (1.0, 30.0, 20.0, 30.0, 20.0) if interaction else (1.0, 0.0, 0.0, 100.0, 5.0)
+        loss, tv = FitStepLossFn.apply(render_out['color_fine'], render_out['weight_sum'], render_out['sdf_hand'] if interaction else None,
+                                       render_out['sdf_obj'] if interaction else None, pose['joint_3d'], pose['obj_r'], pose['obj_t'], true_rgb,
+                                       true_mask, pose['joint3d_pred'], pose['Ro_pred'], pose['To_pred'], pose['obj_verts'], weights)
+        return {'loss': loss, 'color': tv[1], 'mask': tv[2], 'contact': tv[3], 'penetration': tv[4], 'joint': tv[5], 'obj_verts': tv[6]}
     terms = render_loss_terms(render_out, true_rgb, true_mask, fit_type, video)
     fused = 'obj_verts' in pose        # the chains' device form: vertex losses from the poses (VertsLossFn), no vertex sets
     if fused:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 103 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 104 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -352,6 +352,18 @@ int hn_fit_loss_sums(const float* color, const float* weight_sum, const float* t
 int hn_fit_loss_grads(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays,
                       const float* sdf_hand, const float* sdf_obj, int n_samples, const float* sums6, const float* g4,
                       float* g_color, float* g_weight_sum, float* g_sdf_hand, float* g_sdf_obj, hn_stream_t stream);
+
+/* The whole loss of a fitting_single step from those sums (fitting_single.py:251-288), one launch:
+ *   loss = w0 (colour + 0.5 mask) + w1 contact + w2 penetration + w3 joint + w4 verts,
+ * joint = sum_j |joint3d_pred_j - joint_3d_j| / n_joints (pose_loss, :119-122), verts = verts_loss[0] (hn_verts_loss).
+ * weights5 is a HOST array {w0..w4} ({1, 30, 20, 30, 20} for fit type 12; {1, 0, 0, 100, 5} for fit type 1).
+ * terms8 (device) = {loss, colour, mask, contact, penetration, joint, verts, 0}; g_joint [n_joints,3] = d joint / d joint_3d.
+ * hn_fit_total_bwd: the upstream gradient of the loss (device scalar g_loss) -> g4 for hn_fit_loss_grads and the scaled
+ * pose-side gradients g_joint_out = g w3 g_joint, gR_out [9] = g w4 gR, gt_out [3] = g w4 gt (gR, gt from hn_verts_loss). */
+int hn_fit_total(const float* sums6, const float* verts_loss, const float* joint_3d, const float* joint3d_pred, int n_joints,
+                 const float* weights5, float* terms8, float* g_joint, hn_stream_t stream);
+int hn_fit_total_bwd(const float* g_loss, const float* weights5, const float* g_joint, const float* gR, const float* gt, int n_joints,
+                     float* g4, float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream);
 
 /* Backward pass of hn_render_dual: what loss.backward() runs through NeuSRenderer_fitting.render in the fitting loops
  * (fitting_single.py:289-291, fitting_video.py:340-342; autograd through utils/renderer.py:434-535).  Depths carry no

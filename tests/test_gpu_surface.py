@@ -371,6 +371,60 @@ def test_device_loss_terms_match_reference(golden, fit_type):
             assert_close(gr, ref, 1e-5, pre + 'g_' + name + ' (device)')
 
 
+@pytest.mark.parametrize('fit_type', ['1', '12'])
+def test_fused_step_loss_matches_reference_statements(golden, fit_type):
+    """step_loss on the device for fitting_single is ONE autograd node (autograd.FitStepLossFn: hn_fit_loss_sums, hn_verts_loss,
+    hn_fit_total / hn_fit_total_bwd, hn_fit_loss_grads): the render terms and their gradients against what the REFERENCE's
+    statements produced (tests/golden/loss_single.npz), the pose terms and the total against fitting_single.py:231-235,
+    257-288 restated in torch on the same tensors, under a non-trivial upstream gradient."""
+    from honerf_amd import fitting as F
+    g = golden('loss_single')
+    gen = torch.Generator().manual_seed(3)
+    ro = {k: cu(g['in_' + k]).clone().requires_grad_(True) for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj')}
+    j_pred = torch.randn(1, 21, 3, generator=gen) * 0.05
+    j3 = (j_pred + 0.004 * torch.randn(1, 21, 3, generator=gen)).cuda().requires_grad_(True)
+    Ro_pred = torch.linalg.qr(torch.randn(3, 3, generator=gen))[0][None]
+    To_pred = torch.randn(1, 3, generator=gen) * 0.1
+    obj_r = (Ro_pred + 0.01 * torch.randn(1, 3, 3, generator=gen)).cuda().requires_grad_(True)
+    obj_t = (To_pred + 0.003 * torch.randn(1, 3, generator=gen)).cuda().requires_grad_(True)
+    verts = (torch.randn(300, 3, generator=gen) * 0.03).cuda()
+    pose = {'joint_3d': j3, 'joint3d_pred': j_pred.cuda(), 'obj_r': obj_r, 'obj_t': obj_t, 'Ro_pred': Ro_pred.cuda(), 'To_pred': To_pred.cuda(),
+            'obj_verts': verts}
+    terms = F.step_loss(ro, cu(g['true_rgb']), cu(g['true_mask']), pose, fit_type)
+    pre = 's%s_' % fit_type
+    assert_close(terms['color'], g[pre + 'color'], 1e-5, pre + 'color (fused)')
+    assert_close(terms['mask'], g[pre + 'mask'], 1e-5, pre + 'mask (fused)')
+    if fit_type == '12':
+        assert_close(terms['contact'], g['s12_contact'], 1e-5, 'contact (fused)')
+        assert_close(terms['penetration'], g['s12_penet'], 1e-5, 'penetration (fused)')
+    # the pose terms, as the reference writes them
+    j3r, orr_, otr = (x.detach().clone().requires_grad_(True) for x in (j3, obj_r, obj_t))
+    pl = lambda a, b: (torch.norm(a - b, dim=-1).sum() / torch.norm(a - b, dim=-1).shape[0])          # fitting_single.py:119-122
+    joint = pl(j_pred.cuda()[0], j3r[0])
+    pred_v = (orr_[0].unsqueeze(0) @ verts.unsqueeze(-1))[..., 0] + otr[0]
+    comp_v = (Ro_pred.cuda()[0].unsqueeze(0) @ verts.unsqueeze(-1))[..., 0] + To_pred.cuda()[0]
+    vl = pl(comp_v, pred_v)
+    wj, wv = (100.0, 5.0) if fit_type == '1' else (30.0, 20.0)
+    assert_close(terms['joint'], joint, 1e-5, 'joint loss (fused)')
+    assert_close(terms['obj_verts'], vl, 1e-5, 'vertex loss (fused)')
+    ref_loss = float(g[pre + 'color']) + 0.5 * float(g[pre + 'mask']) + wj * float(joint) + wv * float(vl)
+    if fit_type == '12':
+        ref_loss += 30 * float(g['s12_contact']) + 20 * float(g['s12_penet'])
+    assert abs(float(terms['loss']) - ref_loss) <= 2e-5 * abs(ref_loss)
+    up = 0.37                                                               # a non-trivial upstream gradient
+    (terms['loss'] * up).backward()
+    for name in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj'):
+        ref = g[pre + 'g_' + name] * up
+        if np.abs(ref).max() == 0:
+            assert ro[name].grad is None or float(ro[name].grad.abs().max()) == 0.0, name
+        else:
+            assert_close(ro[name].grad, ref, 1e-5, pre + 'g_' + name + ' (fused)')
+    (up * (wj * joint + wv * vl)).backward()
+    assert_close(j3.grad, j3r.grad, 1e-5, 'd loss / d joint_3d (fused)')
+    assert_close(obj_r.grad, orr_.grad, 2e-5, 'd loss / d obj_r (fused)')
+    assert_close(obj_t.grad, otr.grad, 2e-5, 'd loss / d obj_t (fused)')
+
+
 def test_device_loss_terms_video(golden):
     from honerf_amd import fitting as F
     g = golden('loss_video')
