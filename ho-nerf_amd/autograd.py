@@ -13,6 +13,7 @@ side by side on two streams; the per-field forward values it needs (rgb, alpha) 
 in the render workspace.  Nothing here computes on the host; torch only owns the buffers.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -23,12 +24,28 @@ def _empty(*shape, dev):
     return torch.empty(*shape, device=dev, dtype=torch.float32)
 
 
+class _AuxHolder:
+    """rgb / alpha of both fields of one differentiable render: views into the renderer's tape (owned=False) or copies."""
+
+    def __init__(self, tensors, owned):
+        self.t, self.owned = tensors, owned
+
+    def own(self):
+        if not self.owned:
+            self.t = tuple(x.clone() for x in self.t)
+            self.owned = True
+
+
 class DualRenderFn(torch.autograd.Function):
     """(rays_o [F,P,3], rays_d [F,P,3], bt_inv [F,21,4,4], T_pose [F,21,3], Ro [F,3,3], To [F,3]) ->
     (color [N,3], weight_sum [N,1], sdf_hand [N*S,1], sdf_obj [N*S,1], grad_hand [N*S,3], grad_obj [N*S,3], gerr [2])."""
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, bt_inv, T_pose, Ro, To, renderer, near, far, t_rand):
+        prev = getattr(renderer, '_pending_aux', None)
+        prev = prev() if prev is not None else None
+        if prev is not None:
+            prev.own()        # an earlier render's backward pass has not run yet: its arrays leave the tape before it is overwritten
         o = renderer._render_raw(rays_o.detach(), rays_d.detach(), near, far, bt_inv.detach(), T_pose.detach(), Ro.detach(),
                                  To.detach(), t_rand, keep_tape=True)
         # The tape buffer belongs to the renderer and is overwritten by its next differentiable render: a backward pass
@@ -36,22 +53,31 @@ class DualRenderFn(torch.autograd.Function):
         renderer._tape_serial = getattr(renderer, '_tape_serial', 0) + 1
         ctx.tape, ctx.tape_serial = o['tape'], renderer._tape_serial
         ctx.renderer, ctx.near, ctx.far = renderer, float(near), float(far)
-        # what the final evaluation left in the render workspace (rgb / alpha of both fields): copied out now, the
-        # workspace is re-used by the next render
         hand, obj = renderer.fields()
         lib = _lib.load()
         N = rays_o.shape[0] * rays_o.shape[1]
         S = o['z_vals'].shape[-1]
-        offs = (ctypes.c_size_t * 4)()
-        _lib.check(lib.hn_render_dual_aux_offsets(hand.handle, obj.handle, N, renderer.n_samples, renderer.n_importance,
-                                                  renderer.up_sample_steps, offs),
-                   'hn_render_dual_aux_offsets')
-        ws = renderer._ws.buf
         n = N * S
-        view = lambda off, cnt: ws[off:off + 4 * cnt].view(torch.float32).clone()
-        aux = (view(offs[0], 3 * n).reshape(n, 3), view(offs[1], 3 * n).reshape(n, 3), view(offs[2], n), view(offs[3], n))
+        aux_off = lib.hn_render_dual_tape_aux_offset(hand.handle, obj.handle, N, S) if o['tape'] is not None else 0
+        if aux_off:
+            # rgb / alpha of both fields were written into the tape: views, no copies.  They stay valid as long as the tape
+            # does; the renderer's next differentiable render takes ownership away first (_AuxHolder.own)
+            a = o['tape'][aux_off:aux_off + 32 * n].view(torch.float32)
+            ctx.aux = _AuxHolder((a[:3 * n].view(n, 3), a[3 * n:6 * n].view(n, 3), a[6 * n:7 * n], a[7 * n:8 * n]), owned=False)
+        else:
+            # no tape (fp32 fields): what the final evaluation left in the render workspace, copied out now -- the
+            # workspace is re-used by the next render
+            offs = (ctypes.c_size_t * 4)()
+            _lib.check(lib.hn_render_dual_aux_offsets(hand.handle, obj.handle, N, renderer.n_samples, renderer.n_importance,
+                                                      renderer.up_sample_steps, offs),
+                       'hn_render_dual_aux_offsets')
+            ws = renderer._ws.buf
+            view = lambda off, cnt: ws[off:off + 4 * cnt].view(torch.float32).clone()
+            ctx.aux = _AuxHolder((view(offs[0], 3 * n).reshape(n, 3), view(offs[1], 3 * n).reshape(n, 3), view(offs[2], n), view(offs[3], n)),
+                                 owned=True)
+        renderer._pending_aux = weakref.ref(ctx.aux)
         ctx.save_for_backward(rays_o.detach(), rays_d.detach(), bt_inv.detach(), T_pose.detach(), Ro.detach(), To.detach(),
-                              o['z_vals'], o['sdf_hand'], o['sdf_obj'], o['grad_hand'], o['grad_obj'], *aux)
+                              o['z_vals'], o['sdf_hand'], o['sdf_obj'], o['grad_hand'], o['grad_obj'])
         return o['color'], o['weight_sum'], o['sdf_hand'], o['sdf_obj'], o['grad_hand'], o['grad_obj'], o['gerr']
 
     @staticmethod
@@ -59,7 +85,8 @@ class DualRenderFn(torch.autograd.Function):
         L = _lib
         lib = L.load()
         ren = ctx.renderer
-        rays_o, rays_d, bt, tp, Ro, To, z, sdf_h, sdf_o, grad_h, grad_o, rgb_h, rgb_o, alpha_h, alpha_o = ctx.saved_tensors
+        rays_o, rays_d, bt, tp, Ro, To, z, sdf_h, sdf_o, grad_h, grad_o = ctx.saved_tensors
+        rgb_h, rgb_o, alpha_h, alpha_o = ctx.aux.t
         hand, obj = ren.fields()
         F, P = rays_o.shape[0], rays_o.shape[1]
         N, S = F * P, z.shape[-1]

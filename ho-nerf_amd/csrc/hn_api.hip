@@ -47,6 +47,7 @@ int composite2_bwd(const float*, const float*, const float*, const float*, const
                    float*, float*, float*, hipStream_t);
 int fit_loss_sums(const float*, const float*, const float*, const float*, int, const float*, const float*, int, float*, hipStream_t);
 int fit_total(const float*, const float*, const float*, const float*, int, const float*, float*, float*, hipStream_t);
+int adam_step(int, float* const*, const float* const*, float* const*, float* const*, const int*, const float*, float, float, float, int, hipStream_t);
 int fit_total_bwd(const float*, const float*, const float*, const float*, const float*, int, float*, float*, float*, float*, hipStream_t);
 int fit_loss_grads(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*,
                    const float*, float*, float*, float*, float*, hipStream_t);
@@ -381,6 +382,16 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     const size_t fws_h = field_ws(hand, (int)N), fws_o = field_ws(obj, (int)N);
     void* fwsh = ar.take(fws_h);
     void* fwso = ar.take(fws_o);
+    // With a tape the four arrays live in the TAPE (behind the two fields' tapes): the caller keeps that buffer until the
+    // backward pass, so nothing has to be copied out of the workspace (4 copy launches per fitting step).
+    const size_t tapes_bytes = field_tape(hand, (int)N) + field_tape(obj, (int)N);
+    if (tape != nullptr && tapes_bytes != 0 && tape_bytes >= tapes_bytes + 8 * N * sizeof(float)) {
+        float* aux = reinterpret_cast<float*>(reinterpret_cast<char*>(tape) + tapes_bytes);
+        rgb_h = aux;
+        rgb_o = aux + 3 * N;
+        al_h = aux + 6 * N;
+        al_o = aux + 7 * N;
+    }
     if (aux_offsets != nullptr) {   // where the final evaluation leaves rgb / alpha of both fields (bytes into the workspace)
         aux_offsets[0] = off_rgb_h;
         aux_offsets[1] = off_rgb_o;
@@ -879,6 +890,10 @@ int hn_fit_loss_grads(const float* color, const float* weight_sum, const float* 
                           g_weight_sum, g_sdf_hand, g_sdf_obj, (hipStream_t)stream);
 }
 
+int hn_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const int* sizes, const float* lr, float beta1, float beta2, float eps, int step, hn_stream_t stream) {
+    return adam_step(n_tensors, params, grads, exp_avg, exp_avg_sq, sizes, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+}
 int hn_fit_total(const float* sums6, const float* verts_loss, const float* joint_3d, const float* joint3d_pred, int n_joints,
                  const float* weights5, float* terms8, float* g_joint, hn_stream_t stream) {
     return fit_total(sums6, verts_loss, joint_3d, joint3d_pred, n_joints, weights5, terms8, g_joint, (hipStream_t)stream);
@@ -962,6 +977,11 @@ int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_
                             (hipStream_t)stream, nullptr, nullptr, tape, tape_bytes);
 }
 size_t hn_render_dual_tape_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray) {
+    if (hand == nullptr || obj == nullptr || n_rays <= 0 || samples_per_ray <= 0) return 0;
+    const size_t t = field_tape(hand, n_rays * samples_per_ray) + field_tape(obj, n_rays * samples_per_ray);
+    return t == 0 ? 0 : t + (size_t)8 * n_rays * samples_per_ray * sizeof(float);   // + rgb / alpha of both fields
+}
+size_t hn_render_dual_tape_aux_offset(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray) {
     if (hand == nullptr || obj == nullptr || n_rays <= 0 || samples_per_ray <= 0) return 0;
     return field_tape(hand, n_rays * samples_per_ray) + field_tape(obj, n_rays * samples_per_ray);
 }

@@ -7,6 +7,8 @@
 //   hn_verts_loss   pose_loss over the object's vertices (:232-233: mean distance between the vertex sets of two rigid
 //                   poses) with its closed-form gradient w.r.t. the first pose
 //   hn_jacobian_vjp g_in = J^T g_out for a stored Jacobian (the backward pass of the two dual-number ops)
+#include <math.h>
+
 #include "hn_common.h"
 #include "hn_pose_chain.h"
 
@@ -162,6 +164,64 @@ int jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int 
     if (n_frames <= 0) return HN_OK;
     HN_REQUIRE(n_in >= 1 && n_in <= 64 && n_out >= 1, "jacobian vjp: n_in %d n_out %d out of range", n_in, n_out);
     hipLaunchKernelGGL(k_jacobian_vjp, dim3(n_frames), dim3(256), 0, s, jac, g, n_frames, n_out, n_in, out);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+// ---- Adam over the handful of small pose-parameter blocks of a fitting loop, one launch ------------------------------------
+// torch.optim.Adam's update (defaults: no weight decay, no amsgrad), written as torch writes it:
+//   m += (g - m) (1 - b1);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+// The reference steps six blocks with six learning rates (fitting_single.py:191-199); as a torch optimiser that is one
+// fused launch PER parameter group plus the step counters: 12 - 13 dependent launches of a few microseconds of work.
+struct AdamArgs {
+    float* p[16];
+    const float* g[16];
+    float* m[16];
+    float* v[16];
+    int n[16];
+    float lr[16];
+    int n_tensors;
+    float b1, b2, eps, bc1, bc2_sqrt;
+};
+__global__ __launch_bounds__(256) void k_pose_adam(const AdamArgs a) {
+    for (int t = 0; t < a.n_tensors; ++t) {
+        const float step_size = a.lr[t] / a.bc1;
+        for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < a.n[t]; i += blockDim.x * gridDim.x) {
+            const float g = a.g[t][i];
+            float m = a.m[t][i], v = a.v[t][i];
+            m = m + (g - m) * (1.f - a.b1);
+            v = v * a.b2 + (1.f - a.b2) * g * g;
+            a.m[t][i] = m;
+            a.v[t][i] = v;
+            const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+            a.p[t][i] = a.p[t][i] - step_size * (m / denom);
+        }
+    }
+}
+int adam_step(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int* sizes, const float* lr,
+              float beta1, float beta2, float eps, int step, hipStream_t s) {
+    if (n_tensors <= 0) return HN_OK;
+    HN_REQUIRE(n_tensors <= 16 && p && g && m && v && sizes && lr && step >= 1, "adam_step: at most 16 blocks, step >= 1");
+    AdamArgs a{};
+    int total = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+        HN_REQUIRE(p[t] && g[t] && m[t] && v[t] && sizes[t] >= 0, "adam_step: null block %d", t);
+        a.p[t] = p[t];
+        a.g[t] = g[t];
+        a.m[t] = m[t];
+        a.v[t] = v[t];
+        a.n[t] = sizes[t];
+        a.lr[t] = lr[t];
+        total += sizes[t];
+    }
+    a.n_tensors = n_tensors;
+    a.b1 = beta1;
+    a.b2 = beta2;
+    a.eps = eps;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    const int blocks = total > 65536 ? 64 : (total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1;
+    hipLaunchKernelGGL(k_pose_adam, dim3(blocks), dim3(256), 0, s, a);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

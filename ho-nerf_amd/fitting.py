@@ -329,6 +329,14 @@ class HaloPoseChain:
         return self._fn.apply(self.joints0[idx], self.bone_len[idx], params)
 
     def __call__(self, index=None):
+        if index is None and self.joints0.is_cuda:
+            # every frame of the chain (fitting_single: the one frame): one autograd node for the whole pose side
+            from .pose import HaloChainFn
+            bt_inv, joint_3d, obj_r, obj_t = HaloChainFn.apply(self.obj_rot, self.obj_trans, self.palm_rot, self.palm_trans,
+                                                               self.joint_refine_angle, self.palm_refine_angle, self.joints0, self.bone_len,
+                                                               self.Ro_pred, self.To_pred)
+            return {'bt_inv': bt_inv, 'T_pose_21': self.T_pose_21, 'joint_3d': joint_3d, 'joint3d_pred': self.joints0, 'obj_r': obj_r, 'obj_t': obj_t,
+                    'Ro_pred': self.Ro_pred, 'To_pred': self.To_pred, 'obj_verts': self.obj_verts}
         idx = slice(None) if index is None else _index_tensor(self, index, self.joints0.device)
         bt_inv, joint_3d = self._hand(idx)
         if self.joints0.is_cuda:
@@ -484,10 +492,57 @@ def make_optimizer(pose_chain, video=False):
     instead of ~10 element-wise launches per block (the step is a chain of dependent launches; every one counts)."""
     groups = pose_chain.param_groups(video=video)
     on_gpu = all(p.is_cuda for g in groups for p in ([g['params']] if isinstance(g['params'], torch.Tensor) else g['params']))
-    try:
-        return torch.optim.Adam(groups, fused=True) if on_gpu else torch.optim.Adam(groups)
-    except (RuntimeError, TypeError):      # a torch build without the fused implementation
-        return torch.optim.Adam(groups)
+    if on_gpu and sum(len([g['params']] if isinstance(g['params'], torch.Tensor) else g['params']) for g in groups) <= 16:
+        return PoseAdam(groups)
+    return torch.optim.Adam(groups)
+
+
+class PoseAdam:
+    """torch.optim.Adam (its defaults: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) over the few small
+    pose-parameter blocks of a fitting loop as ONE launch per step (hn_adam_step).  The reference gives each of its six
+    blocks its own learning rate (fitting_single.py:191-199), which as a torch optimiser is one fused launch per group plus
+    the step counters -- a dozen dependent launches for 45 floats.  Same update formula, same skip of parameters whose
+    `.grad` is None; `param_groups` / `zero_grad` / `step` as an Optimizer has them."""
+
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8):
+        self.param_groups = []
+        for g in groups:
+            ps = [g['params']] if isinstance(g['params'], torch.Tensor) else list(g['params'])
+            self.param_groups.append({'params': ps, 'lr': float(g['lr'])})
+        self.betas, self.eps = betas, eps
+        self.state = {}
+        self.steps = 0
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g['params']:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        import ctypes
+        from . import lib as L
+        todo = [(p, g['lr']) for g in self.param_groups for p in g['params'] if p.grad is not None]
+        if not todo:
+            return
+        self.steps += 1
+        n = len(todo)
+        P, G, M, V = ((ctypes.c_void_p * n)() for _ in range(4))
+        sizes, lrs = (ctypes.c_int * n)(), (ctypes.c_float * n)()
+        keep = []
+        for i, (p, lr) in enumerate(todo):
+            st = self.state.get(id(p))
+            if st is None:
+                st = self.state[id(p)] = (torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format))
+            g = p.grad if (p.grad.is_contiguous() and p.grad.dtype == torch.float32) else p.grad.contiguous().float()
+            keep.append(g)
+            assert p.is_contiguous() and p.dtype == torch.float32 and p.is_cuda, 'PoseAdam: contiguous fp32 device parameters'
+            P[i], G[i], M[i], V[i] = p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr()
+            sizes[i], lrs[i] = p.numel(), lr
+        L.check(L.load().hn_adam_step(n, P, G, M, V, sizes, lrs, self.betas[0], self.betas[1], self.eps, self.steps, L.stream_ptr()), 'hn_adam_step')
 
 
 def fit_frame(renderer, views, pose_chain, near, far, fit_type='1', n_iters=None, sample_view=None, rays_fn=None):

@@ -24,7 +24,7 @@ PRECISIONS = {'fp32': HN_PREC_FP32, 'f16x3': HN_PREC_F16X3, 'f16': HN_PREC_F16}
 # 'fp32': the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32), 5x slower, kept as a second opinion
 DEFAULT_PRECISION = os.environ.get('HONERF_PRECISION', 'f16x3')
 HN_MAX_LAYERS = 9
-HN_VERSION = 104          # the include/honerf.h revision SIGNATURES below was written for
+HN_VERSION = 105          # the include/honerf.h revision SIGNATURES below was written for
 
 c_f = ctypes.c_void_p     # device float*
 c_i = ctypes.c_int
@@ -87,6 +87,8 @@ SIGNATURES = {
     'hn_composite2_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_vp]),
     'hn_fit_loss_sums': (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_vp]),
     'hn_fit_loss_grads': (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_vp]),
+    'hn_adam_step': (c_i, [c_i, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_i),
+                           ctypes.POINTER(c_fl), c_fl, c_fl, c_fl, c_i, c_vp]),
     'hn_fit_total': (c_i, [c_f, c_f, c_f, c_f, c_i, ctypes.POINTER(c_fl), c_f, c_f, c_vp]),
     'hn_fit_total_bwd': (c_i, [c_f, ctypes.POINTER(c_fl), c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_vp]),
     'hn_render_single_workspace_bytes': (c_sz, [c_vp, c_i, c_i, c_i]),
@@ -98,6 +100,7 @@ SIGNATURES = {
     'hn_render_dual_bwd': (c_i, [c_vp, c_vp, c_f, c_f, c_i, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
                                  c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp, c_vp]),
     'hn_render_dual_tape_bytes': (c_sz, [c_vp, c_vp, c_i, c_i]),
+    'hn_render_dual_tape_aux_offset': (c_sz, [c_vp, c_vp, c_i, c_i]),
     'hn_release_cached_memory': (c_sz, []),
     'hn_field_param_floats': (c_sz, [c_vp]),
     'hn_field_param_offset': (c_i, [c_vp, c_i, c_i, ctypes.POINTER(c_sz), ctypes.POINTER(c_sz), ctypes.POINTER(c_i),

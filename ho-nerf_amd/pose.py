@@ -146,3 +146,68 @@ class VertsLossFn(torch.autograd.Function):
         sh, nd = ctx.shapes, ctx.needs
         return (dR.reshape(sh[0]) if nd[0] else None, dt.reshape(sh[1]) if nd[1] else None,
                 (-dR).reshape(sh[2]) if nd[2] else None, (-dt).reshape(sh[3]) if nd[3] else None, None)
+
+
+class HaloChainFn(torch.autograd.Function):
+    """The whole pose side of a fitting_single step as ONE autograd node over the six refine leaves (fitting_single.py:177-235):
+    (obj_rot [F,3,2], obj_trans [F,3], palm_rot [F,3,2], palm_trans [F,3], joint_refine_angle [F,20], palm_refine_angle [F,7])
+    -> (bone_transformation_inv [F,21,4,4], joint_3d [F,21,3], obj_r [F,3,3], obj_t [F,3]) -- hn_pose_chain + hn_rigid_pose forward,
+    two hn_jacobian_vjp backward.  As separate nodes joined by cat / slice operators the same graph was ~12 small launches
+    forward and ~25 backward (every slice's backward is a zero fill and a copy)."""
+
+    @staticmethod
+    def forward(ctx, obj_rot, obj_trans, palm_rot, palm_trans, joint_angle, palm_angle, ori_pose, bone_len, Ro_pred, To_pred):
+        L = _lib
+        lib = L.load()
+        F, dev = ori_pose.shape[0], ori_pose.device
+        st = L.stream_ptr()
+        prm = torch.cat([joint_angle.reshape(F, 20), palm_angle.reshape(F, 7), palm_rot.reshape(F, 6), palm_trans.reshape(F, 3),
+                         obj_rot.reshape(F, 6), obj_trans.reshape(F, 3)], dim=1)                     # [F, 45]: one launch
+        prm_h = prm[:, :36].contiguous() if F > 1 else prm[:, :36]
+        prm_o = torch.zeros(F, 18, device=dev, dtype=torch.float32)
+        prm_o[:, :9] = prm[:, 36:45]
+        need = any(x.requires_grad for x in (obj_rot, obj_trans, palm_rot, palm_trans, joint_angle, palm_angle))
+        bt = torch.empty(F, 21, 4, 4, device=dev, dtype=torch.float32)
+        j3 = torch.empty(F, 21, 3, device=dev, dtype=torch.float32)
+        jac_h = torch.empty(F, N_OUT, N_IN, device=dev, dtype=torch.float32) if need else None
+        L.check(lib.hn_pose_chain(L.ptr(ori_pose), L.ptr(bone_len), None, L.ptr(prm_h), F, L.ptr(bt), L.ptr(j3), L.ptr(jac_h) if need else None, st),
+                'hn_pose_chain')
+        out = torch.zeros(F, 412, device=dev, dtype=torch.float32)
+        jac_o = torch.zeros(F, 412, 18, device=dev, dtype=torch.float32) if need else None
+        L.check(lib.hn_rigid_pose(None, None, L.ptr(Ro_pred), L.ptr(To_pred), L.ptr(prm_o), F, 0, L.ptr(out), L.ptr(jac_o) if need else None, st),
+                'hn_rigid_pose')
+        ctx.jac_h, ctx.jac_o, ctx.F = jac_h, jac_o, F
+        ctx.shapes = tuple(x.shape for x in (obj_rot, obj_trans, palm_rot, palm_trans, joint_angle, palm_angle))
+        return bt, j3, out[:, 399:408].reshape(F, 3, 3), out[:, 408:411]
+
+    @staticmethod
+    def backward(ctx, g_bt, g_j3, g_or, g_ot):
+        L = _lib
+        lib = L.load()
+        F = ctx.F
+        dev = ctx.jac_h.device
+        st = L.stream_ptr()
+        z = lambda t, n: torch.zeros(F, n, device=dev) if t is None else L.f32(t).reshape(F, n)
+        g = torch.empty(F, 45, device=dev, dtype=torch.float32)
+        gh, go = g[:, :36], g[:, 36:45]
+        go_h = torch.cat([z(g_bt, 336), z(g_j3, 63)], dim=1)
+        if F == 1:
+            L.check(lib.hn_jacobian_vjp(L.ptr(ctx.jac_h), L.ptr(go_h), 1, N_OUT, N_IN, L.ptr(g), st), 'hn_jacobian_vjp')      # -> g[0, :36]
+            go_o = torch.cat([z(g_or, 9), z(g_ot, 3)], dim=1)                                   # rows 399..410 of the object Jacobian
+            tmp = torch.empty(1, 18, device=dev, dtype=torch.float32)
+            L.check(lib.hn_jacobian_vjp(L.ptr(ctx.jac_o[:, 399:411]), L.ptr(go_o), 1, 12, 18, L.ptr(tmp), st), 'hn_jacobian_vjp')
+            g[:, 36:45] = tmp[:, :9]
+        else:
+            tmp_h = torch.empty(F, 36, device=dev, dtype=torch.float32)
+            L.check(lib.hn_jacobian_vjp(L.ptr(ctx.jac_h), L.ptr(go_h), F, N_OUT, N_IN, L.ptr(tmp_h), st), 'hn_jacobian_vjp')
+            go_o = torch.zeros(F, 412, device=dev, dtype=torch.float32)
+            go_o[:, 399:408] = z(g_or, 9)
+            go_o[:, 408:411] = z(g_ot, 3)
+            tmp = torch.empty(F, 18, device=dev, dtype=torch.float32)
+            L.check(lib.hn_jacobian_vjp(L.ptr(ctx.jac_o), L.ptr(go_o), F, 412, 18, L.ptr(tmp), st), 'hn_jacobian_vjp')
+            g[:, :36] = tmp_h
+            g[:, 36:45] = tmp[:, :9]
+        sh = ctx.shapes
+        # views of one block (for F = 1 every slice is contiguous: autograd keeps them as the leaves' .grad without a copy)
+        return (go[:, 0:6].reshape(sh[0]), go[:, 6:9].reshape(sh[1]), gh[:, 27:33].reshape(sh[2]), gh[:, 33:36].reshape(sh[3]),
+                gh[:, 0:20].reshape(sh[4]), gh[:, 20:27].reshape(sh[5]), None, None, None, None)

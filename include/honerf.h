@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 104 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 105 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -333,6 +333,10 @@ int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_
  * buffer then runs the adjoints alone instead of evaluating both fields a second time.  HN_PREC_F16X3 fields only
  * (0 bytes otherwise). */
 size_t hn_render_dual_tape_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray);
+/* With a tape, rgb_hand, rgb_obj [n_rays*S,3] and alpha_hand, alpha_obj [n_rays*S] of the final evaluation (what
+ * hn_render_dual_bwd takes back) are written INTO the tape, contiguous and in that order, at this byte offset -- the
+ * caller keeps the tape until the backward pass anyway, so nothing needs to be copied out of the workspace. */
+size_t hn_render_dual_tape_aux_offset(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray);
 /* After hn_render_dual the caller's workspace still holds what the final evaluation produced for compositing:
  * rgb_hand, rgb_obj [n_rays*S,3] and alpha_hand, alpha_obj [n_rays*S] (S = n_samples + 2 n_importance).  Byte offsets
  * of the four arrays into the workspace, in that order (same sizes and up_sample_steps as the render call) -- the backward pass of a fitting step re-uses them instead
@@ -364,6 +368,13 @@ int hn_fit_total(const float* sums6, const float* verts_loss, const float* joint
                  const float* weights5, float* terms8, float* g_joint, hn_stream_t stream);
 int hn_fit_total_bwd(const float* g_loss, const float* weights5, const float* g_joint, const float* gR, const float* gt, int n_joints,
                      float* g4, float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream);
+
+/* torch.optim.Adam's step (defaults: betas as given, no weight decay, no amsgrad) over up to 16 small parameter blocks
+ * with one learning rate each, ONE launch: the six pose-parameter groups of fitting_single.py:191-199 /
+ * fitting_video.py:177-185.  All pointer arrays are HOST arrays of device pointers (params, grads, the two moment
+ * buffers -- caller-owned, zero-initialised), sizes in floats; `step` = 1, 2, ... (the bias corrections). */
+int hn_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const int* sizes, const float* lr, float beta1, float beta2, float eps, int step, hn_stream_t stream);
 
 /* Backward pass of hn_render_dual: what loss.backward() runs through NeuSRenderer_fitting.render in the fitting loops
  * (fitting_single.py:289-291, fitting_video.py:340-342; autograd through utils/renderer.py:434-535).  Depths carry no

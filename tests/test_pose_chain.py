@@ -146,3 +146,61 @@ def test_rigid_pose_ops_match_the_torch_form():
             e = rel(x, y.astype(np.float64))
             record('rigid pose op vs torch autograd: d/d %s (video=%s)' % (name, video), e, 1e-4)
             assert e <= 1e-4, (name, e)
+
+
+@pytest.mark.gpu
+def test_pose_adam_is_torch_adam():
+    """fitting.PoseAdam (hn_adam_step: all parameter blocks, one launch) against torch.optim.Adam with the reference's six
+    groups and learning rates (fitting_single.py:191-199), including a block whose .grad is None in one step."""
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    gen = torch.Generator().manual_seed(1)
+    shapes = [(1, 3, 2), (1, 3), (1, 3, 2), (1, 3), (1, 20), (1, 7)]
+    lrs = [5e-4, 5e-4, 5e-4, 3e-4, 1e-3, 1e-3]
+    init = [torch.randn(*s, generator=gen) for s in shapes]
+    pa = [torch.nn.Parameter(x.clone().to(dev)) for x in init]
+    pb = [torch.nn.Parameter(x.clone().to(dev)) for x in init]
+    oa = F.PoseAdam([{'params': p, 'lr': l} for p, l in zip(pa, lrs)])
+    ob = torch.optim.Adam([{'params': p, 'lr': l} for p, l in zip(pb, lrs)])
+    for step in range(7):
+        oa.zero_grad(set_to_none=True)
+        ob.zero_grad(set_to_none=True)
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            if step == 3 and k == 4:
+                continue                                             # no gradient this step: both skip the block
+            g = (torch.randn(*shapes[k], generator=gen) * 10.0 ** float(torch.randint(-6, 2, (1,), generator=gen))).to(dev)
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for k, (a, b) in enumerate(zip(pa, pb)):
+        e = float((a.detach() - b.detach()).abs().max() / (b.detach() - init[k].to(dev)).abs().max())
+        record('PoseAdam vs torch.optim.Adam after 7 steps, block %d (difference / movement)' % k, e, 1e-5)
+        assert e <= 1e-5, (k, e)
+
+
+@pytest.mark.gpu
+def test_halo_chain_single_node_matches_the_separate_ops():
+    """HaloPoseChain() with no index (fitting_single) is one autograd node (pose.HaloChainFn); with an index it is PoseChainFn +
+    RigidPoseFn joined by cat / slice operators (the frame-batched loop): same values, same gradients of all six leaves."""
+    import bench
+    dev = torch.device('cuda')
+    rng = np.random.RandomState(2)
+    res = []
+    for use_index in (False, True):
+        chain, j, verts = bench.build_fit_data(dev, 40, 1, halo=True)
+        with torch.no_grad():
+            r2 = np.random.RandomState(11)
+            for p in chain.parameters():
+                p.add_(torch.tensor(r2.standard_normal(tuple(p.shape)) * 0.02, dtype=torch.float32, device=dev))
+        pose = chain([0]) if use_index else chain()
+        gb, gj, gr, gt = (torch.tensor(np.random.RandomState(5 + i).standard_normal(s), dtype=torch.float32, device=dev)
+                          for i, s in enumerate(((1, 21, 4, 4), (1, 21, 3), (1, 3, 3), (1, 3))))
+        loss = (pose['bt_inv'] * gb).sum() + (pose['joint_3d'] * gj).sum() + (pose['obj_r'] * gr).sum() + (pose['obj_t'] * gt).sum()
+        grads = torch.autograd.grad(loss, chain.parameters())
+        res.append(([pose[k].detach().cpu().numpy() for k in ('bt_inv', 'joint_3d', 'obj_r', 'obj_t')], [g.cpu().numpy() for g in grads]))
+    for x, y in zip(res[0][0], res[1][0]):
+        assert np.array_equal(x, y)
+    for name, x, y in zip(('obj_rot', 'obj_trans', 'palm_rot', 'palm_trans', 'joint_refine_angle', 'palm_refine_angle'), res[0][1], res[1][1]):
+        e = rel(x, y.astype(np.float64))
+        record('HaloChainFn vs separate ops: d/d ' + name, e, 1e-6)
+        assert e <= 1e-6, (name, e)
