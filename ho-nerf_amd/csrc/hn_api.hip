@@ -4,6 +4,7 @@
 #include <atomic>
 #include <functional>
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 
 #include "hn_common.h"
@@ -47,7 +48,7 @@ int composite2_bwd(const float*, const float*, const float*, const float*, const
                    float*, float*, float*, hipStream_t);
 int fit_loss_sums(const float*, const float*, const float*, const float*, int, const float*, const float*, int, float*, hipStream_t);
 int fit_total(const float*, const float*, const float*, const float*, int, const float*, float*, float*, hipStream_t);
-int adam_step(int, float* const*, const float* const*, float* const*, float* const*, const int*, const float*, float, float, float, int, hipStream_t);
+int adam_step(int, float* const*, const float* const*, float* const*, float* const*, const int*, const float*, float, float, float, const int*, hipStream_t);
 int fit_total_bwd(const float*, const float*, const float*, const float*, const float*, int, float*, float*, float*, float*, hipStream_t);
 int fit_loss_grads(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*,
                    const float*, float*, float*, float*, float*, hipStream_t);
@@ -127,6 +128,11 @@ struct SideStream {
     hipStream_t s2 = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
+static std::atomic<int> g_quad_max_blocks{[] {
+    const char* e = getenv("HN_QUAD_MAX_BLOCKS");
+    return e ? atoi(e) : -1;
+}()};
+int quad_max_blocks_override() { return g_quad_max_blocks.load(std::memory_order_relaxed); }
 std::atomic<int> g_pace_phantom{0};
 int pace_phantom_members() { return g_pace_phantom.load(std::memory_order_relaxed); }
 static SideStream g_side[MAX_DEVICES];
@@ -701,6 +707,10 @@ int hn_nearest_masked(const float* pts, int n_verts, int n_sets, const unsigned 
 
 
 int hn_version(void) { return HN_VERSION; }
+int hn_debug_quad_max_blocks(int max_blocks) {
+    hn::g_quad_max_blocks.store(max_blocks);
+    return HN_OK;
+}
 int hn_debug_pace_phantom(int members) {
     hn::g_pace_phantom.store(members < 0 ? 0 : members);
     return HN_OK;
@@ -891,8 +901,8 @@ int hn_fit_loss_grads(const float* color, const float* weight_sum, const float* 
 }
 
 int hn_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                 const int* sizes, const float* lr, float beta1, float beta2, float eps, int step, hn_stream_t stream) {
-    return adam_step(n_tensors, params, grads, exp_avg, exp_avg_sq, sizes, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+                 const int* sizes, const float* lr, float beta1, float beta2, float eps, const int* steps, hn_stream_t stream) {
+    return adam_step(n_tensors, params, grads, exp_avg, exp_avg_sq, sizes, lr, beta1, beta2, eps, steps, (hipStream_t)stream);
 }
 int hn_fit_total(const float* sums6, const float* verts_loss, const float* joint_3d, const float* joint3d_pred, int n_joints,
                  const float* weights5, float* terms8, float* g_joint, hn_stream_t stream) {

@@ -37,6 +37,7 @@ void set_error(const char* fmt, ...);
 // Per-device state (one process may drive several GPUs, from several threads).
 int current_device();          // hipGetDevice, -1 on failure
 int device_cus();              // CU count of the CURRENT device (cached per device; 0 if none)
+int quad_max_blocks_override();   // hn_debug_quad_max_blocks: -1 = default selection of the latency-form kernels
 int pace_phantom_members();    // hn_debug_pace_phantom: members that never arrive at the XCD meetings (timeout-path test hook), 0 = off
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): `mask` is the kernel's own
 // bit set of devices already configured (a static std::atomic<uint64_t> next to the launch).

@@ -13,7 +13,7 @@
 #include <atomic>
 
 #include "hn_common.h"
-#if !defined(HN_HAND_ADJ_TU) && !defined(HN_HAND_F16_TU) && !defined(HN_MFMA16)
+#if !defined(HN_HAND_ADJ_TU) && !defined(HN_HAND_F16_TU) && !defined(HN_HAND_QUAD_TU) && !defined(HN_MFMA16)
 #define HN_MFMA16 HN_HAND_EVAL_MFMA16   // the evaluation kernels (MODE 0, 1); the adjoint translation unit keeps 32x32x16
 #endif
 #include "hn_mlp2.h"
@@ -1107,7 +1107,8 @@ static void hand2_common_args(Hand2Args& a, const hn_field* f, const float* pts,
     a.xsync = nullptr;
 }
 
-#if defined(HN_HAND_F16_TU)   // hn_field2_hand_f16.hip: the evaluation kernels of HN_PREC_F16 (single-pass hidden layers)
+#if defined(HN_HAND_QUAD_TU)    // hn_field2_hand_q.hip: only the device helpers above are wanted
+#elif defined(HN_HAND_F16_TU)   // hn_field2_hand_f16.hip: the evaluation kernels of HN_PREC_F16 (single-pass hidden layers)
 int launch_field2_hand_f16(const Hand2Args& a, int grid, bool full, hipStream_t stream) {
     static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};
     HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand_f16<1>), (int)HAND2_LDS, &lds_full));
@@ -1121,6 +1122,14 @@ int launch_field2_hand_f16(const Hand2Args& a, int grid, bool full, hipStream_t 
 }
 #elif !defined(HN_HAND_ADJ_TU)   // this translation unit: the evaluation kernels (MODE 0, 1); hn_field2_hand_adj.hip: MODE 2
 int launch_field2_hand_f16(const Hand2Args& a, int grid, bool full, hipStream_t stream);
+int launch_field2_hand_q(const Hand2Args& a, int n_blocks, int n_cus, hipStream_t stream);   // hn_field2_hand_q.hip
+size_t field2_hand_q_workspace_bytes(int n_blocks, int n_cus);
+// sdf-only launches of at most this many 32-sample blocks take the latency form (four waves per block): up to two rounds of
+// quarter-length blocks beat one round of whole tiles.  hn_debug_quad_max_blocks(0) switches it off (tests, A/B runs).
+static int quad_max_blocks(int n_cus) {
+    const int v = quad_max_blocks_override();   // hn_debug_quad_max_blocks; -1: the default
+    return v >= 0 ? v : 2 * n_cus;
+}
 size_t field2_hand_workspace_bytes(int n_pts, int n_cus) {
     return (size_t)hand2_grid(n_pts, n_cus) * WG_WAVES * HAND2_SLOTS * SLOT_F4 * sizeof(float4) + 256;   // + the XCD pacing counters
 }
@@ -1164,6 +1173,10 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
         set_error("field workspace too small: %zu < %zu", workspace_bytes, need);
         return HN_ENOMEM;
     }
+    // a launch too small to fill the chip: the latency form (bit-identical results; its stash fits the same workspace)
+    const int n_blocks = (n_pts + 31) / 32;
+    if (!full && !f->single_pass && !a.cull && n_blocks <= quad_max_blocks(n_cus) && field2_hand_q_workspace_bytes(n_blocks, n_cus) <= workspace_bytes)
+        return launch_field2_hand_q(a, n_blocks, n_cus, stream);
     // XCD pacing: launches of many tiles per workgroup (the image-sized ones), where the workspace has the room
     if (HN_XCD_PACING && (n_pts + WG_SAMPLES - 1) / WG_SAMPLES >= XCD_PACE_MIN_ROUNDS * grid && workspace_bytes >= need + 64) {
         a.xsync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + need);
@@ -1274,7 +1287,7 @@ extern "C" int hn_debug_ts_adj(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hn::v2::g_hn_ts), sizeof(unsigned long long) * n);
 }
 #endif
-#if defined(HN_TS) && !defined(HN_HAND_ADJ_TU)
+#if defined(HN_TS) && !defined(HN_HAND_ADJ_TU) && !defined(HN_HAND_QUAD_TU) && !defined(HN_HAND_F16_TU)
 extern "C" int hn_debug_ts(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hn::v2::g_hn_ts), sizeof(unsigned long long) * n);
 }

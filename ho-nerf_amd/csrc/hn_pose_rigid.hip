@@ -181,11 +181,13 @@ struct AdamArgs {
     int n[16];
     float lr[16];
     int n_tensors;
-    float b1, b2, eps, bc1, bc2_sqrt;
+    float bc1[16], bc2_sqrt[16];   // per block: torch keeps one step count per parameter (a block without a gradient is skipped)
+    float b1, b2, eps;
 };
 __global__ __launch_bounds__(256) void k_pose_adam(const AdamArgs a) {
     for (int t = 0; t < a.n_tensors; ++t) {
-        const float step_size = a.lr[t] / a.bc1;
+        const float step_size = a.lr[t] / a.bc1[t];
+        const float bc2s = a.bc2_sqrt[t];
         for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < a.n[t]; i += blockDim.x * gridDim.x) {
             const float g = a.g[t][i];
             float m = a.m[t][i], v = a.v[t][i];
@@ -193,19 +195,21 @@ __global__ __launch_bounds__(256) void k_pose_adam(const AdamArgs a) {
             v = v * a.b2 + (1.f - a.b2) * g * g;
             a.m[t][i] = m;
             a.v[t][i] = v;
-            const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+            const float denom = sqrtf(v) / bc2s + a.eps;
             a.p[t][i] = a.p[t][i] - step_size * (m / denom);
         }
     }
 }
 int adam_step(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int* sizes, const float* lr,
-              float beta1, float beta2, float eps, int step, hipStream_t s) {
+              float beta1, float beta2, float eps, const int* steps, hipStream_t s) {
     if (n_tensors <= 0) return HN_OK;
-    HN_REQUIRE(n_tensors <= 16 && p && g && m && v && sizes && lr && step >= 1, "adam_step: at most 16 blocks, step >= 1");
+    HN_REQUIRE(n_tensors <= 16 && p && g && m && v && sizes && lr && steps, "adam_step: at most 16 blocks");
     AdamArgs a{};
     int total = 0;
     for (int t = 0; t < n_tensors; ++t) {
-        HN_REQUIRE(p[t] && g[t] && m[t] && v[t] && sizes[t] >= 0, "adam_step: null block %d", t);
+        HN_REQUIRE(p[t] && g[t] && m[t] && v[t] && sizes[t] >= 0 && steps[t] >= 1, "adam_step: null block %d or step < 1", t);
+        a.bc1[t] = (float)(1.0 - pow((double)beta1, (double)steps[t]));
+        a.bc2_sqrt[t] = (float)sqrt(1.0 - pow((double)beta2, (double)steps[t]));
         a.p[t] = p[t];
         a.g[t] = g[t];
         a.m[t] = m[t];
@@ -218,8 +222,6 @@ int adam_step(int n_tensors, float* const* p, const float* const* g, float* cons
     a.b1 = beta1;
     a.b2 = beta2;
     a.eps = eps;
-    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     const int blocks = total > 65536 ? 64 : (total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1;
     hipLaunchKernelGGL(k_pose_adam, dim3(blocks), dim3(256), 0, s, a);
     HN_LAUNCH_CHECK();

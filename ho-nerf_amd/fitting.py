@@ -511,7 +511,6 @@ class PoseAdam:
             self.param_groups.append({'params': ps, 'lr': float(g['lr'])})
         self.betas, self.eps = betas, eps
         self.state = {}
-        self.steps = 0
 
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
@@ -528,21 +527,21 @@ class PoseAdam:
         todo = [(p, g['lr']) for g in self.param_groups for p in g['params'] if p.grad is not None]
         if not todo:
             return
-        self.steps += 1
         n = len(todo)
         P, G, M, V = ((ctypes.c_void_p * n)() for _ in range(4))
-        sizes, lrs = (ctypes.c_int * n)(), (ctypes.c_float * n)()
+        sizes, lrs, steps = (ctypes.c_int * n)(), (ctypes.c_float * n)(), (ctypes.c_int * n)()
         keep = []
         for i, (p, lr) in enumerate(todo):
             st = self.state.get(id(p))
             if st is None:
-                st = self.state[id(p)] = (torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format))
+                st = self.state[id(p)] = [torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format), 0]
+            st[2] += 1                                   # torch counts the steps per parameter
             g = p.grad if (p.grad.is_contiguous() and p.grad.dtype == torch.float32) else p.grad.contiguous().float()
             keep.append(g)
             assert p.is_contiguous() and p.dtype == torch.float32 and p.is_cuda, 'PoseAdam: contiguous fp32 device parameters'
             P[i], G[i], M[i], V[i] = p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr()
-            sizes[i], lrs[i] = p.numel(), lr
-        L.check(L.load().hn_adam_step(n, P, G, M, V, sizes, lrs, self.betas[0], self.betas[1], self.eps, self.steps, L.stream_ptr()), 'hn_adam_step')
+            sizes[i], lrs[i], steps[i] = p.numel(), lr, st[2]
+        L.check(L.load().hn_adam_step(n, P, G, M, V, sizes, lrs, self.betas[0], self.betas[1], self.eps, steps, L.stream_ptr()), 'hn_adam_step')
 
 
 def fit_frame(renderer, views, pose_chain, near, far, fit_type='1', n_iters=None, sample_view=None, rays_fn=None):

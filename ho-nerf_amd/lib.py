@@ -56,6 +56,7 @@ SIGNATURES = {
     'hn_field_inv_s': (c_fl, [c_vp]),
     'hn_field_set_culling': (c_i, [c_vp, c_i]),
     'hn_debug_pace_phantom': (c_i, [c_i]),
+    'hn_debug_quad_max_blocks': (c_i, [c_i]),
     'hn_ray_gen': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
     'hn_obj_local_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
     'hn_obj_local_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_vp]),
@@ -88,7 +89,7 @@ SIGNATURES = {
     'hn_fit_loss_sums': (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_vp]),
     'hn_fit_loss_grads': (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_vp]),
     'hn_adam_step': (c_i, [c_i, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_i),
-                           ctypes.POINTER(c_fl), c_fl, c_fl, c_fl, c_i, c_vp]),
+                           ctypes.POINTER(c_fl), c_fl, c_fl, c_fl, ctypes.POINTER(c_i), c_vp]),
     'hn_fit_total': (c_i, [c_f, c_f, c_f, c_f, c_i, ctypes.POINTER(c_fl), c_f, c_f, c_vp]),
     'hn_fit_total_bwd': (c_i, [c_f, ctypes.POINTER(c_fl), c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_vp]),
     'hn_render_single_workspace_bytes': (c_sz, [c_vp, c_i, c_i, c_i]),

@@ -107,6 +107,11 @@ int hn_field_set_culling(hn_field* f, int enabled);
  * meeting of every workgroup runs into its timeout and the launch continues unpaced -- results must be bit-identical.
  * 0 switches the hook off.  Process-wide; not for production use. */
 int hn_debug_pace_phantom(int members);
+/* Selection of the LATENCY-FORM kernels (hn_field2_hand_q.hip: the four waves of a workgroup share one 32-sample block and
+ * split every layer's output tiles): by default sdf-only launches of a hand field of at most 2 x (CU count) blocks take it,
+ * because they cannot fill the chip with whole 128-sample tiles.  Results are bit-identical either way.  max_blocks = 0:
+ * never; > 0: up to that many blocks; -1: the default.  Process-wide; for tests and A/B timing. */
+int hn_debug_quad_max_blocks(int max_blocks);
 
 /* ---- rays -----------------------------------------------------------------------------
  * _xy_to_ray_bundle (utils/utils.py:31-115): NDC xy -> unproject at depth 1 and
@@ -372,9 +377,10 @@ int hn_fit_total_bwd(const float* g_loss, const float* weights5, const float* g_
 /* torch.optim.Adam's step (defaults: betas as given, no weight decay, no amsgrad) over up to 16 small parameter blocks
  * with one learning rate each, ONE launch: the six pose-parameter groups of fitting_single.py:191-199 /
  * fitting_video.py:177-185.  All pointer arrays are HOST arrays of device pointers (params, grads, the two moment
- * buffers -- caller-owned, zero-initialised), sizes in floats; `step` = 1, 2, ... (the bias corrections). */
+ * buffers -- caller-owned, zero-initialised), sizes in floats; steps[i] = 1, 2, ...: the number of updates block i has
+ * received including this one (torch keeps the count per parameter: a block without a gradient is skipped). */
 int hn_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                 const int* sizes, const float* lr, float beta1, float beta2, float eps, int step, hn_stream_t stream);
+                 const int* sizes, const float* lr, float beta1, float beta2, float eps, const int* steps, hn_stream_t stream);
 
 /* Backward pass of hn_render_dual: what loss.backward() runs through NeuSRenderer_fitting.render in the fitting loops
  * (fitting_single.py:289-291, fitting_video.py:340-342; autograd through utils/renderer.py:434-535).  Depths carry no

@@ -778,6 +778,34 @@ def test_full_size_frame_properties():
         assert torch.equal(whole[k], culled[k]), 'culled frame differs in %s' % k
 
 
+def test_latency_form_sdf_kernel_is_bit_identical():
+    """hn_field2_hand_q.hip: small sdf-only launches of the hand field run with the four waves of a workgroup sharing one
+    32-sample block (every layer's output tiles split between them, activations exchanged through LDS).  Same MFMA
+    sequences per accumulator, same epilogues, same summation order: the sdf must equal the throughput kernel's bit for
+    bit -- ragged sizes, one and several rounds of blocks per workgroup, several frames, far-field points."""
+    from honerf_amd import lib as Lm, synth
+    lib = Lm.load()
+    hand, _ = packed_fields('cuda', 'f16x3')
+    gen = torch.Generator().manual_seed(11)
+    poses = [synth.synth_hand_pose(s) for s in (7, 8, 9)]
+    bt = torch.stack([t(p[0]) for p in poses])
+    tp = torch.stack([t(p[1]) for p in poses])
+    for n_per_frame in (1, 37, 1045, 5461, 16384 + 19):            # 3 frames each: 1 .. 1537 blocks
+        n = 3 * n_per_frame
+        j = torch.cat([t(p[2])[torch.randint(0, 21, (n_per_frame,), generator=gen)] for p in poses])
+        pts = j + 0.03 * torch.randn(n, 3, generator=gen)
+        pts[::7] += 0.5                                            # far-field samples: every bone mask exactly 0
+        out = {}
+        for tag, mb in (('throughput', 0), ('latency', 1 << 20)):
+            Lm.check(lib.hn_debug_quad_max_blocks(mb), 'hn_debug_quad_max_blocks')
+            try:
+                out[tag] = hand.sdf(cu(pts), bt, tp).clone()
+            finally:
+                Lm.check(lib.hn_debug_quad_max_blocks(-1), 'hn_debug_quad_max_blocks')
+        assert torch.isfinite(out['latency']).all()
+        assert torch.equal(out['throughput'], out['latency']), 'latency form differs at n = %d' % n
+
+
 def test_xcd_pacing_timeout_is_bit_identical():
     """XCD pacing (hn_mlp2.h XcdPace): an image-sized launch whose workgroups meet at every tile start must give the
     same bits when a meeting runs into its timeout (a member of the XCD that never arrives: hn_debug_pace_phantom) and
