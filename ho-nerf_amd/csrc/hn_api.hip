@@ -429,7 +429,10 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
         HN_CHECK_HIP(hipMemcpyAsync(to.z_a, th.z_a, (size_t)n_rays * n_samples * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (side != nullptr) HN_TRY(fork_to(side, s));
         // the two importance-sampling tracks (utils/renderer.py:463-496) are independent: hand on s, object on so
-        for (int which = 0; which < 2; ++which) {
+        // (the object track is queued first: its sdf-only launches are the short ones -- 72 us on 98 CUs -- and must not wait
+        // behind the hand's latency-form launch, which takes every CU it can get for its 392 blocks)
+        for (int order = 0; order < 2; ++order) {
+            const int which = 1 - order;
             Track& t = which == 0 ? th : to;
             const hn_field* f = which == 0 ? hand : obj;
             const float* ro = which == 0 ? rays_o : o_obj;

@@ -77,8 +77,9 @@ def test_fit_step_with_the_reference_pose_chain():
     ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, 64, 'f16x3', halo=True)
     pose0 = chain()
     # T_pose_21 was derived from the initial state: every bone's local coordinate vanishes at its joint
-    q = (pose0['bt_inv'][0, :, :3, :3] @ pose0['joint_3d'][0].unsqueeze(-1))[..., 0] + pose0['bt_inv'][0, :, :3, 3] - pose0['T_pose_21'][0]
-    assert float(q.abs().max()) < 1e-5
+    bt0, j0, tp0 = (pose0[k][0].detach().double().cpu() for k in ('bt_inv', 'joint_3d', 'T_pose_21'))    # (float64 on the host: the check itself adds no rounding)
+    q = torch.einsum('bij,bj->bi', bt0[:, :3, :3], j0) + bt0[:, :3, 3] - tp0
+    assert float(q.abs().max()) < 1e-5, (float(q.abs().max()), float(bt0.abs().max()), float(j0.abs().max()), float(tp0.abs().max()))
     opt = F.make_optimizer(chain, video=False)
     first = None
     for i in range(3):
