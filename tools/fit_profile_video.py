@@ -7,7 +7,7 @@ import bench
 from honerf_amd import fitting as F
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device('cuda')
-renb, netsb, chainb, viewsb, ov = bench.build_fit(dev, 60, bench.VID_FRAMES, bench.VID_RAYS, 'f16x3')
+renb, netsb, chainb, viewsb, ov = bench.build_fit(dev, 60, bench.VID_FRAMES, bench.VID_RAYS, 'f16x3', halo=(sys.argv[2] if len(sys.argv) > 2 else 'halo') == 'halo')
 optb = F.make_optimizer(chainb, video=True)
 idx = list(range(bench.VID_FRAMES))
 def step(i):

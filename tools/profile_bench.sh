@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-culled --no-fitting --no-training"
+ARGS="$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-culled --no-fitting --no-training --no-c1 --no-f16"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/stats.log 2>&1
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"; do
   N=$(echo $P | tr ' ' '_')

@@ -1,0 +1,18 @@
+#!/bin/bash
+# kernel-trace of the fitting_video window step + timeline.  Usage: bash tools/profile_fit_video_timeline.sh <tag>
+set -u
+TAG=${1:-run}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_fitv_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+python3 $R/tools/fit_profile_video.py 40 > $OUT/unprofiled.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pfv_stats_$TAG -- python3 $R/tools/fit_profile_video.py 20 > $OUT/stats.log 2>&1
+find /tmp/pfv_stats_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
+T=$(find /tmp/pfv_stats_$TAG -name "*kernel_trace.csv" | head -1)
+python3 $R/tools/trace_gaps.py $T 12 4 > $OUT/busy_idle.txt 2>&1
+python3 $R/tools/trace_timeline.py $T 8 15 > $OUT/timeline.txt 2>&1
+cd $R
+tail -1 $OUT/unprofiled.log
+head -16 $OUT/busy_idle.txt
