@@ -310,7 +310,9 @@ class HaloPoseChain:
         if T_pose_21 is None:
             with torch.no_grad():
                 bt0, j0 = self._hand(slice(None))
-                T_pose_21 = (bt0[..., :3, :3] @ j0.unsqueeze(-1))[..., 0] + bt0[..., :3, 3]
+                # element-wise (no BLAS call: a batched 3 x 3 product through the GEMM library may pick a reduced-precision
+                # algorithm, and this derived constant enters every bone coordinate of the hand field)
+                T_pose_21 = (bt0[..., :3, :3] * j0.unsqueeze(-2)).sum(-1) + bt0[..., :3, 3]
         self.T_pose_21 = t(T_pose_21, -1, 21, 3)
         if self.T_pose_21.shape[0] != n:
             self.T_pose_21 = self.T_pose_21[:1].expand(n, 21, 3).contiguous()
