@@ -429,35 +429,41 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
         HN_CHECK_HIP(hipMemcpyAsync(to.z_a, th.z_a, (size_t)n_rays * n_samples * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (side != nullptr) HN_TRY(fork_to(side, s));
         // the two importance-sampling tracks (utils/renderer.py:463-496) are independent: hand on s, object on so
-        // (the object track is queued first: its sdf-only launches are the short ones -- 72 us on 98 CUs -- and must not wait
-        // behind the hand's latency-form launch, which takes every CU it can get for its 392 blocks)
-        for (int order = 0; order < 2; ++order) {
-            const int which = 1 - order;
-            Track& t = which == 0 ? th : to;
-            const hn_field* f = which == 0 ? hand : obj;
-            const float* ro = which == 0 ? rays_o : o_obj;
-            const float* rd = which == 0 ? rays_d : d_obj;
-            const hipStream_t st = which == 0 ? s : so;
-            void* fws = which == 0 ? fwsh : fwso;
-            const size_t fwb = which == 0 ? fws_h : fws_o;
-            const int nf = which == 0 ? n_frames : 1;
-            int k = n_samples;
-            HN_TRY(sample_points(ro, rd, t.z_a, n_rays, k, 0, 0.f, t.pts, nullptr, st));
-            HN_TRY(field_sdf(f, t.pts, n_rays * k, bt_inv, T_pose, nf, which == 0 ? rpf * k : n_rays * k, t.sdf_a, fws, fwb, st));
-            for (int i = 0; i < steps; ++i) {
-                HN_TRY(upsample(t.z_a, t.sdf_a, n_rays, k, n_new, (float)(64 << i), t.z_new, nullptr, st));
-                hipLaunchKernelGGL(k_copy_cols, dim3((n_rays * n_new + 255) / 256), dim3(256), 0, st, t.z_new, n_rays,
-                                   n_new, zcat, S, n_samples + (2 * i + which) * n_new);
+        // The two tracks are queued STAGE BY STAGE (coarse pass, then each importance round), the object's launches of a
+        // stage first: queued track by track, the second track's first kernel reached its stream only after the ~25
+        // launches of the first had been issued by the host (~120 us of a 650 us phase); and the object's launches must not
+        // wait behind the hand's coarse launch, which takes every CU it can get for its 392 blocks.
+        struct TrackRun {
+            Track* t;
+            const hn_field* f;
+            const float *ro, *rd;
+            hipStream_t st;
+            void* fws;
+            size_t fwb;
+            int nf, which, k;
+        };
+        TrackRun runs[2] = {{&to, obj, o_obj, d_obj, so, fwso, fws_o, 1, 1, n_samples}, {&th, hand, rays_o, rays_d, s, fwsh, fws_h, n_frames, 0, n_samples}};
+        for (TrackRun& r : runs) {   // coarse pass
+            Track& t = *r.t;
+            HN_TRY(sample_points(r.ro, r.rd, t.z_a, n_rays, r.k, 0, 0.f, t.pts, nullptr, r.st));
+            HN_TRY(field_sdf(r.f, t.pts, n_rays * r.k, bt_inv, T_pose, r.nf, r.which == 0 ? rpf * r.k : n_rays * r.k, t.sdf_a, r.fws, r.fwb, r.st));
+        }
+        for (int i = 0; i < steps; ++i) {
+            for (TrackRun& r : runs) {
+                Track& t = *r.t;
+                HN_TRY(upsample(t.z_a, t.sdf_a, n_rays, r.k, n_new, (float)(64 << i), t.z_new, nullptr, r.st));
+                hipLaunchKernelGGL(k_copy_cols, dim3((n_rays * n_new + 255) / 256), dim3(256), 0, r.st, t.z_new, n_rays, n_new, zcat, S,
+                                   n_samples + (2 * i + r.which) * n_new);
                 HN_LAUNCH_CHECK();
                 if (i + 1 < steps) {
-                    HN_TRY(sample_points(ro, rd, t.z_new, n_rays, n_new, 0, 0.f, t.pts, nullptr, st));
-                    HN_TRY(field_sdf(f, t.pts, n_rays * n_new, bt_inv, T_pose, nf, which == 0 ? rpf * n_new : n_rays * n_new, t.sdf_new,
-                                     fws, fwb, st));
-                    HN_TRY(merge(t.z_a, t.z_new, t.sdf_a, t.sdf_new, n_rays, k, n_new, quirk, t.z_b, t.sdf_b, nullptr, st));
+                    HN_TRY(sample_points(r.ro, r.rd, t.z_new, n_rays, n_new, 0, 0.f, t.pts, nullptr, r.st));
+                    HN_TRY(field_sdf(r.f, t.pts, n_rays * n_new, bt_inv, T_pose, r.nf, r.which == 0 ? rpf * n_new : n_rays * n_new, t.sdf_new,
+                                     r.fws, r.fwb, r.st));
+                    HN_TRY(merge(t.z_a, t.z_new, t.sdf_a, t.sdf_new, n_rays, r.k, n_new, quirk, t.z_b, t.sdf_b, nullptr, r.st));
                     float* tmp = t.z_a; t.z_a = t.z_b; t.z_b = tmp;
                     tmp = t.sdf_a; t.sdf_a = t.sdf_b; t.sdf_b = tmp;
                 }
-                k += n_new;
+                r.k += n_new;
             }
         }
         if (side != nullptr) HN_TRY(join_from(side, s));

@@ -924,8 +924,10 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     }
 }
 
+#ifndef HN_OBJ_QUAD_TU   // hn_field2_obj_q.hip includes this file for its device helpers only
 constexpr size_t OBJ2_LDS = 2 * CHUNK_MAX;
 
+int launch_field2_obj_q(const Obj2Args& a, int n_blocks, int n_cus, hipStream_t stream);   // hn_field2_obj_q.hip
 static int obj2_grid(int n_pts, int n_cus) {
     const int n_tiles = (n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
     return n_tiles < n_cus ? n_tiles : n_cus;
@@ -1000,6 +1002,12 @@ int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, 
         if (const int ph = pace_phantom_members()) HN_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.xsync), ph, 8, stream));
         }
     }
+    // an sdf-only launch too small to fill the chip: the latency form (hn_field2_obj_q.hip; bit-identical results)
+    {
+        const int n_blocks = (n_pts + 31) / 32;
+        const int qmax = quad_max_blocks_override();
+        if (!full && n_blocks <= (qmax >= 0 ? qmax : 2 * n_cus)) return launch_field2_obj_q(a, n_blocks, n_cus, stream);
+    }
     static std::atomic<uint64_t> lds_full{0}, lds_sdf{0};   // devices on which the LDS size attribute is set
     HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<1>), (int)OBJ2_LDS, &lds_full));
     HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<0>), (int)OBJ2_LDS, &lds_sdf));
@@ -1070,5 +1078,6 @@ int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays
     return HN_OK;
 }
 
+#endif   // HN_OBJ_QUAD_TU
 }  // namespace v2
 }  // namespace hn

@@ -785,7 +785,7 @@ def test_latency_form_sdf_kernel_is_bit_identical():
     bit -- ragged sizes, one and several rounds of blocks per workgroup, several frames, far-field points."""
     from honerf_amd import lib as Lm, synth
     lib = Lm.load()
-    hand, _ = packed_fields('cuda', 'f16x3')
+    hand, obj = packed_fields('cuda', 'f16x3')
     gen = torch.Generator().manual_seed(11)
     poses = [synth.synth_hand_pose(s) for s in (7, 8, 9)]
     bt = torch.stack([t(p[0]) for p in poses])
@@ -804,6 +804,16 @@ def test_latency_form_sdf_kernel_is_bit_identical():
                 Lm.check(lib.hn_debug_quad_max_blocks(-1), 'hn_debug_quad_max_blocks')
         assert torch.isfinite(out['latency']).all()
         assert torch.equal(out['throughput'], out['latency']), 'latency form differs at n = %d' % n
+        # the object field's latency form (hn_field2_obj_q.hip), same points
+        oo = {}
+        for tag, mb in (('throughput', 0), ('latency', 1 << 20)):
+            Lm.check(lib.hn_debug_quad_max_blocks(mb), 'hn_debug_quad_max_blocks')
+            try:
+                oo[tag] = obj.sdf(cu(pts - t(poses[0][2]).mean(0))).clone()
+            finally:
+                Lm.check(lib.hn_debug_quad_max_blocks(-1), 'hn_debug_quad_max_blocks')
+        assert torch.isfinite(oo['latency']).all()
+        assert torch.equal(oo['throughput'], oo['latency']), 'object latency form differs at n = %d' % n
 
 
 def test_xcd_pacing_timeout_is_bit_identical():
