@@ -177,6 +177,129 @@ static int join_from(SideStream* x, hipStream_t s) {
     return HN_OK;
 }
 
+static thread_local const int* g_launch_n_pts_dev = nullptr;
+const int* launch_n_pts_dev() { return g_launch_n_pts_dev; }
+void set_launch_n_pts_dev(const int* p) { g_launch_n_pts_dev = p; }
+
+// ---- exact far-field skip of the hand field (SURVEY B-11, hn_field_set_compaction) ---------------------------------------
+// A sample whose bone masks h_b = 1 - sigmoid(200 (v_b - cutoff_b)) (utils/fields.py:33-35) are ALL exactly 0 in fp32 sees
+// an all-zero 1386-wide input: its sdf and colour are the same constants for every such sample, its gradient is exactly 0,
+// and it contributes exactly 0 to every adjoint output.  Along the rays of a fitting step 40 - 60 % of the samples are of
+// that kind, scattered through every 128-sample tile.  The two-field render therefore evaluates the hand field on the
+// COMPACTED list of the other samples plus ONE far sample (whose outputs are the constants) and scatters the results back:
+// 110 - 172 tiles instead of 294, i.e. one round of tiles on 256 CUs instead of two.  Results are bit-identical to the
+// dense evaluation (no result depends on how samples are grouped into tiles: tested).  The classification is conservative:
+// dead only if 200 (v_b - cutoff_b) > 20 for every bone, where the kernel's own sigmoid has been exactly 1 since ~16.7.
+__constant__ float c_cutoff_api[21] = {0.08f, 0.03f, 0.03f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f,
+                                       0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f};
+// counter[0]: running count of live samples; idx[k]: sample of compact slot k; pos[i]: compact slot of sample i or -1
+__global__ void k_hand_compact(const float* __restrict__ pts, int n, const float* __restrict__ bt_inv, const float* __restrict__ T_pose,
+                               int* __restrict__ counter, int* __restrict__ idx, int* __restrict__ pos, float* __restrict__ pts_c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool live = false;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (i < n) {
+        p0 = pts[3 * (size_t)i];
+        p1 = pts[3 * (size_t)i + 1];
+        p2 = pts[3 * (size_t)i + 2];
+        for (int b = 0; b < 21; ++b) {
+            const float* m = bt_inv + 16 * b;
+            const float q0 = m[0] * p0 + m[1] * p1 + m[2] * p2 + m[3] - T_pose[3 * b];
+            const float q1 = m[4] * p0 + m[5] * p1 + m[6] * p2 + m[7] - T_pose[3 * b + 1];
+            const float q2 = m[8] * p0 + m[9] * p1 + m[10] * p2 + m[11] - T_pose[3 * b + 2];
+            const float v = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+            live = live || !(200.f * (v - c_cutoff_api[b]) > 20.f);   // (a NaN coordinate counts as live)
+        }
+    }
+    const unsigned long long m = __ballot(live);
+    const int cnt = __popcll(m);
+    int base = 0;
+    if (lane == 0 && cnt > 0) base = atomicAdd(counter, cnt);
+    base = __shfl(base, 0, 64);
+    if (i < n) {
+        if (live) {
+            const int k = base + __popcll(m & ((1ull << lane) - 1ull));
+            idx[k] = i;
+            pos[i] = k;
+            pts_c[3 * (size_t)k] = p0;
+            pts_c[3 * (size_t)k + 1] = p1;
+            pts_c[3 * (size_t)k + 2] = p2;
+        } else {
+            pos[i] = -1;
+        }
+    }
+}
+// the far sample behind the M live ones; n_dev = M + 1 is what the field kernels read as their sample count
+__global__ void k_hand_compact_seal(const int* __restrict__ counter, int* __restrict__ n_dev, float* __restrict__ pts_c) {
+    const int M = counter[0];
+    if (threadIdx.x < 3) pts_c[3 * (size_t)M + threadIdx.x] = 10.f;   // 17 m from everything: every mask is exactly 0
+    if (threadIdx.x == 0) n_dev[0] = M + 1;
+}
+// compact results -> the dense per-sample arrays (dead samples: the far sample's values)
+__global__ void k_hand_scatter(const int* __restrict__ pos, int n, const int* __restrict__ n_dev, const float* __restrict__ sdf_c,
+                               const float* __restrict__ grad_c, const float* __restrict__ rgb_c, float* __restrict__ sdf,
+                               float* __restrict__ grad, float* __restrict__ rgb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = pos[i] >= 0 ? pos[i] : n_dev[0] - 1;
+    sdf[i] = sdf_c[k];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        grad[3 * (size_t)i + c] = grad_c[3 * (size_t)k + c];
+        rgb[3 * (size_t)i + c] = rgb_c[3 * (size_t)k + c];
+    }
+}
+// upstream gradients of the dense arrays -> compact (the far sample's are 0: it stands for samples that contribute nothing)
+__global__ void k_hand_gather_up(const int* __restrict__ idx, int n_max, const int* __restrict__ n_dev, const float* __restrict__ gs,
+                                 const float* __restrict__ gg, const float* __restrict__ gr, float* __restrict__ gs_c,
+                                 float* __restrict__ gg_c, float* __restrict__ gr_c) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_max || k >= n_dev[0]) return;
+    const bool far = k == n_dev[0] - 1;
+    const int i = far ? 0 : idx[k];
+    gs_c[k] = far ? 0.f : gs[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gg_c[3 * (size_t)k + c] = far ? 0.f : gg[3 * (size_t)i + c];
+        gr_c[3 * (size_t)k + c] = far ? 0.f : gr[3 * (size_t)i + c];
+    }
+}
+// d loss / d pts of the compact list -> dense (dead samples: exactly 0)
+__global__ void k_hand_scatter3(const int* __restrict__ pos, int n, const float* __restrict__ v_c, float* __restrict__ v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = pos[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[3 * (size_t)i + c] = k >= 0 ? v_c[3 * (size_t)k + c] : 0.f;
+}
+// samples the hand field's tape / workspace are sized for in the two-field renders (one more with compaction: the far sample)
+static int hand_cap(const hn_field* hand, size_t N) { return (int)N + ((hand != nullptr && hand->compact_far_field) ? 1 : 0); }
+// whether the two-field render of these sizes compacts the hand field's samples (the same answer in the forward pass, the
+// backward pass and the size queries)
+static bool hand_compaction(const hn_field* hand, int n_frames, size_t N) {
+    return hand != nullptr && hand->compact_far_field && hand->kind == HN_FIELD_HAND && hand->precision == HN_PREC_F16X3 && n_frames == 1 &&
+           N >= 4096;
+}
+// the compaction record kept with the tape (the backward pass needs it): [counter, n_dev, pad, pad | idx N | pos N | pts_c | grad_c |
+// rgb_c | sdf_c], the per-sample arrays N + 1 long
+struct CompactRec {
+    int *counter, *n_dev, *idx, *pos;
+    float *pts_c, *grad_c, *rgb_c, *sdf_c;
+    static size_t bytes(size_t N) { return 16 + 2 * N * sizeof(int) + (N + 1) * 10 * sizeof(float) + 64; }
+    void at(void* base, size_t N) {
+        char* p = reinterpret_cast<char*>(base);
+        counter = reinterpret_cast<int*>(p);
+        n_dev = counter + 1;
+        idx = reinterpret_cast<int*>(p + 16);
+        pos = idx + N;
+        pts_c = reinterpret_cast<float*>(pos + N);
+        grad_c = pts_c + 3 * (N + 1);
+        rgb_c = grad_c + 3 * (N + 1);
+        sdf_c = rgb_c + 3 * (N + 1);
+    }
+};
+
 // bump allocator over the caller's workspace
 struct Arena {
     char* base;
@@ -385,12 +508,13 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     float* al_h = ar.f(N);
     const size_t off_al_o = ar.used;
     float* al_o = ar.f(N);
-    const size_t fws_h = field_ws(hand, (int)N), fws_o = field_ws(obj, (int)N);
+    const size_t fws_h = field_ws(hand, hand_cap(hand, N)), fws_o = field_ws(obj, (int)N);
     void* fwsh = ar.take(fws_h);
     void* fwso = ar.take(fws_o);
+    void* crec_ws = hand->compact_far_field ? ar.take(CompactRec::bytes(N)) : nullptr;   // (without a tape the record lives here)
     // With a tape the four arrays live in the TAPE (behind the two fields' tapes): the caller keeps that buffer until the
     // backward pass, so nothing has to be copied out of the workspace (4 copy launches per fitting step).
-    const size_t tapes_bytes = field_tape(hand, (int)N) + field_tape(obj, (int)N);
+    const size_t tapes_bytes = field_tape(hand, hand_cap(hand, N)) + field_tape(obj, (int)N);
     if (tape != nullptr && tapes_bytes != 0 && tape_bytes >= tapes_bytes + 8 * N * sizeof(float)) {
         float* aux = reinterpret_cast<float*>(reinterpret_cast<char*>(tape) + tapes_bytes);
         rgb_h = aux;
@@ -472,7 +596,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     }
     // both fields at the shared sorted depths (utils/renderer.py:500-510), side by side.  With a tape buffer the
     // evaluations keep their tapes ([hand | object]) for hn_render_dual_bwd.
-    const size_t tape_h = field_tape(hand, (int)N), tape_o = field_tape(obj, (int)N);
+    const size_t tape_h = field_tape(hand, hand_cap(hand, N)), tape_o = field_tape(obj, (int)N);
     void *tp_h = nullptr, *tp_o = nullptr;
     if (tape != nullptr) {
         HN_REQUIRE(tape_bytes >= tape_h + tape_o, "render_dual tape too small: %zu < %zu", tape_bytes, tape_h + tape_o);
@@ -481,8 +605,28 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     }
     if (side != nullptr) HN_TRY(fork_to(side, s));
     HN_TRY(sample_points(rays_o, rays_d, z_final, n_rays, S, 1, sample_dist, pts, dists, s));
-    HN_TRY(field_eval(hand, pts, rays_d, (int)N, S, bt_inv, T_pose, n_frames, rpf * S, sdf_hand, grad_hand, rgb_h, nullptr,
-                      fwsh, fws_h, s, tp_h, tape_h));
+    if (hand_compaction(hand, n_frames, N)) {
+        // the hand field on the samples with a live bone + one far sample; the record stays with the tape for the backward pass
+        const size_t rec_off = tape_h + tape_o + 8 * N * sizeof(float);
+        const bool in_tape = tape != nullptr && tape_h + tape_o != 0 && tape_bytes >= rec_off + CompactRec::bytes(N);
+        CompactRec cr;
+        cr.at(in_tape ? reinterpret_cast<char*>(tape) + rec_off : crec_ws, N);
+        HN_CHECK_HIP(hipMemsetAsync(cr.counter, 0, 16, s));
+        hipLaunchKernelGGL(k_hand_compact, dim3(((int)N + 255) / 256), dim3(256), 0, s, pts, (int)N, bt_inv, T_pose, cr.counter, cr.idx, cr.pos, cr.pts_c);
+        hipLaunchKernelGGL(k_hand_compact_seal, dim3(1), dim3(64), 0, s, cr.counter, cr.n_dev, cr.pts_c);
+        HN_LAUNCH_CHECK();
+        set_launch_n_pts_dev(cr.n_dev);
+        const int rc = field_eval(hand, cr.pts_c, rays_d, (int)N + 1, S, bt_inv, T_pose, 1, (int)N + 1, cr.sdf_c, cr.grad_c, cr.rgb_c, nullptr, fwsh, fws_h, s,
+                                  in_tape ? tp_h : nullptr, in_tape ? tape_h : 0);
+        set_launch_n_pts_dev(nullptr);
+        HN_TRY(rc);
+        hipLaunchKernelGGL(k_hand_scatter, dim3(((int)N + 255) / 256), dim3(256), 0, s, cr.pos, (int)N, cr.n_dev, cr.sdf_c, cr.grad_c, cr.rgb_c, sdf_hand,
+                           grad_hand, rgb_h);
+        HN_LAUNCH_CHECK();
+    } else {
+        HN_TRY(field_eval(hand, pts, rays_d, (int)N, S, bt_inv, T_pose, n_frames, rpf * S, sdf_hand, grad_hand, rgb_h, nullptr,
+                          fwsh, fws_h, s, tp_h, tape_h));
+    }
     HN_TRY(alpha(sdf_hand, grad_hand, rays_d, dists, (int)N, S, hand->inv_s, al_h, nullptr, s));
     HN_TRY(sample_points(o_obj, d_obj, z_final, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
     HN_TRY(field_eval(obj, pts_o, d_obj, (int)N, S, nullptr, nullptr, 1, (int)N, sdf_obj, grad_obj, rgb_o, nullptr, fwso,
@@ -535,9 +679,17 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     float *gs_h = ar.f(N), *gg_h = ar.f(N * 3), *gd_h = ar.f(R3), *gs_o = ar.f(N), *gg_o = ar.f(N * 3), *gd_o = ar.f(R3);
     float *gp_h = ar.f(N * 3), *gp_o = ar.f(N * 3), *gdir_h = ar.f(R3), *gdir_o = ar.f(R3);
     float *go_h = ar.f(R3), *gdd_h = ar.f(R3), *go_l = ar.f(R3), *gdd_l = ar.f(R3), *gd_l = ar.f(R3), *g_ro2 = ar.f(R3), *g_rd2 = ar.f(R3);
-    const size_t bws_h = bwd::field_bwd_workspace_bytes(hand, (int)N), bws_o = bwd::field_bwd_workspace_bytes(obj, (int)N);
+    const size_t bws_h = bwd::field_bwd_workspace_bytes(hand, hand_cap(hand, N)), bws_o = bwd::field_bwd_workspace_bytes(obj, (int)N);
     void* bwh = ar.take(bws_h);
     void* bwo = ar.take(bws_o);
+    // compacted upstream gradients / d loss / d pts of the hand field (hn_field_set_compaction)
+    float *gs_c = nullptr, *gg_c = nullptr, *gr_c = nullptr, *gp_c = nullptr;
+    if (hand->compact_far_field) {
+        gs_c = ar.f(N + 1);
+        gg_c = ar.f((N + 1) * 3);
+        gr_c = ar.f((N + 1) * 3);
+        gp_c = ar.f((N + 1) * 3);
+    }
     if (need != nullptr) {
         *need = ar.used;
         return HN_OK;
@@ -550,9 +702,13 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     HN_REQUIRE(g_color && g_rays_o && g_rays_d && g_bt_inv && g_T_pose && g_Ro && g_To, "null output / upstream gradient");
     const int n = (int)N;
     // the tapes the forward pass kept ([hand | object]): the adjoints then run alone, nothing is evaluated again
-    const size_t tape_h = field_tape(hand, n), tape_o = field_tape(obj, n);
+    const size_t tape_h = field_tape(hand, hand_cap(hand, N)), tape_o = field_tape(obj, n);
     const void* tp_h = (tape != nullptr && tape_h) ? tape : nullptr;
     const void* tp_o = (tape != nullptr && tape_o) ? reinterpret_cast<const char*>(tape) + tape_h : nullptr;
+    // the forward pass compacted the hand's samples (same predicate; its record sits behind the tapes and the rgb / alpha block)
+    const bool compact = tape != nullptr && tape_h + tape_o != 0 && hand_compaction(hand, n_frames, N);
+    CompactRec cr{};
+    if (compact) cr.at(const_cast<char*>(reinterpret_cast<const char*>(tape)) + tape_h + tape_o + 8 * N * sizeof(float), N);
     SideStream* side = side_stream();
     SideLock side_lock(side);
     const hipStream_t so = side != nullptr ? side->s2 : s;
@@ -567,8 +723,22 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     HN_CHECK_HIP(hipMemsetAsync(g_bt_inv, 0, (size_t)n_frames * 21 * 16 * sizeof(float), s));
     HN_CHECK_HIP(hipMemsetAsync(g_T_pose, 0, (size_t)n_frames * 21 * 3 * sizeof(float), s));
     if (side != nullptr) HN_TRY(fork_to(side, s));
-    HN_TRY(bwd::field_eval_bwd(hand, pts_h, rays_d, n, S, bt_inv, T_pose, n_frames, rpf * S, gs_h, gg_h, g_rgbh, gp_h, gdir_h, g_bt_inv,
-                               g_T_pose, bwh, bws_h, s, tp_h, grad_h, rgb_h));
+    if (compact) {
+        hipLaunchKernelGGL(k_hand_gather_up, dim3((n + 1 + 255) / 256), dim3(256), 0, s, cr.idx, n + 1, cr.n_dev, gs_h, gg_h, g_rgbh, gs_c, gg_c, gr_c);
+        HN_LAUNCH_CHECK();
+        set_launch_n_pts_dev(cr.n_dev);
+        // (the hand's colour network ignores the view direction, utils/fields.py:222-240: its gradient is exactly 0)
+        HN_CHECK_HIP(hipMemsetAsync(gdir_h, 0, R3 * sizeof(float), s));
+        const int rc = bwd::field_eval_bwd(hand, cr.pts_c, rays_d, n + 1, 1, bt_inv, T_pose, 1, n + 1, gs_c, gg_c, gr_c, gp_c, nullptr, g_bt_inv, g_T_pose, bwh,
+                                           bws_h, s, tp_h, cr.grad_c, cr.rgb_c);
+        set_launch_n_pts_dev(nullptr);
+        HN_TRY(rc);
+        hipLaunchKernelGGL(k_hand_scatter3, dim3((n + 255) / 256), dim3(256), 0, s, cr.pos, n, gp_c, gp_h);
+        HN_LAUNCH_CHECK();
+    } else {
+        HN_TRY(bwd::field_eval_bwd(hand, pts_h, rays_d, n, S, bt_inv, T_pose, n_frames, rpf * S, gs_h, gg_h, g_rgbh, gp_h, gdir_h, g_bt_inv,
+                                   g_T_pose, bwh, bws_h, s, tp_h, grad_h, rgb_h));
+    }
     HN_TRY(sample_points_bwd(z, gp_h, n_rays, S, 1, sample_dist, go_h, gdd_h, s));
     // object branch (so)
     HN_TRY(sample_points(o_l, d_l, z, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
@@ -801,6 +971,14 @@ int hn_render_single_bwd(const hn_field* f, const float* rays_o, const float* ra
                                   workspace_bytes, reinterpret_cast<hipStream_t>(stream), nullptr);
 }
 float hn_field_inv_s(const hn_field* f) { return f ? f->inv_s : 0.f; }
+int hn_field_set_compaction(hn_field* f, int enabled) {
+    if (f == nullptr) {
+        hn::set_error("hn_field_set_compaction: null field");
+        return HN_EINVAL;
+    }
+    f->compact_far_field = enabled ? 1 : 0;
+    return HN_OK;
+}
 int hn_field_set_culling(hn_field* f, int enabled) {
     if (f == nullptr) {
         hn::set_error("hn_field_set_culling: null field");
@@ -997,12 +1175,15 @@ int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_
 }
 size_t hn_render_dual_tape_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray) {
     if (hand == nullptr || obj == nullptr || n_rays <= 0 || samples_per_ray <= 0) return 0;
-    const size_t t = field_tape(hand, n_rays * samples_per_ray) + field_tape(obj, n_rays * samples_per_ray);
-    return t == 0 ? 0 : t + (size_t)8 * n_rays * samples_per_ray * sizeof(float);   // + rgb / alpha of both fields
+    const size_t N = (size_t)n_rays * samples_per_ray;
+    const size_t t = field_tape(hand, hand_cap(hand, N)) + field_tape(obj, (int)N);
+    // + rgb / alpha of both fields (+ the compaction record of the hand's samples, hn_field_set_compaction)
+    return t == 0 ? 0 : t + 8 * N * sizeof(float) + (hand->compact_far_field ? CompactRec::bytes(N) : 0);
 }
 size_t hn_render_dual_tape_aux_offset(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray) {
     if (hand == nullptr || obj == nullptr || n_rays <= 0 || samples_per_ray <= 0) return 0;
-    return field_tape(hand, n_rays * samples_per_ray) + field_tape(obj, n_rays * samples_per_ray);
+    const size_t N = (size_t)n_rays * samples_per_ray;
+    return field_tape(hand, hand_cap(hand, N)) + field_tape(obj, (int)N);
 }
 
 }  // extern "C"

@@ -37,6 +37,10 @@ void set_error(const char* fmt, ...);
 // Per-device state (one process may drive several GPUs, from several threads).
 int current_device();          // hipGetDevice, -1 on failure
 int device_cus();              // CU count of the CURRENT device (cached per device; 0 if none)
+// Device-side sample count of the NEXT hand-field launches of this host thread (hn_api.hip sets it around the launches over a
+// compacted sample list and clears it again); NULL otherwise.
+const int* launch_n_pts_dev();
+void set_launch_n_pts_dev(const int* p);
 int quad_max_blocks_override();   // hn_debug_quad_max_blocks: -1 = default selection of the latency-form kernels
 int pace_phantom_members();    // hn_debug_pace_phantom: members that never arrive at the XCD meetings (timeout-path test hook), 0 = off
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): `mask` is the kernel's own
@@ -148,6 +152,7 @@ struct hn_field {
     const float* raw_col_b[5] = {};
     int sdf_out[9] = {}, sdf_in[9] = {}, col_out[5] = {}, col_in[5] = {};
     int sdf_ld[9] = {}, col_ld[5] = {};   // row pitch of the retained matrices (in_dim rounded up to a multiple of 4)
+    int compact_far_field = 0;   // hn_field_set_compaction: the two-field renders evaluate only the samples with a live bone
     int single_pass = 0;         // HN_PREC_F16: the evaluation kernels run their hidden layers on one f16 MFMA per product
     int cull_far_field = 0;      // hn_field_set_culling: skip the chunks of bones whose mask is 0 for a whole workgroup
 };

@@ -66,6 +66,7 @@ struct Hand2Args {
     float* g_bt_inv;       // [n_frames,21,4,4] accumulated (atomics), or NULL
     float* g_T_pose;       // [n_frames,21,3] accumulated (atomics), or NULL
     unsigned* xsync;       // 16 zeroed counters (8 XCDs x {members, arrivals}) or NULL: see "XCD pacing" in the kernel
+    const int* n_pts_dev;  // NULL, or the sample count on the DEVICE (<= n_pts): a compacted list whose length the host does not know
 };
 
 // stash slots of one wave (32 KiB each)
@@ -392,7 +393,8 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
     constexpr int NZ_OFF = LEFT + 6144;          // the wave's live-bone mask `nz`, for the adjoint launch
     constexpr int LEFTJ = LEFT + 16384;          // the Jacobian pass's leftover rows, one float per bone and lane
     int feat_base = FEAT;                        // which block set load_bone reads (FEAT or GXB)
-    const int n_tiles = (a.n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
+    const int n_pts = a.n_pts_dev != nullptr ? __builtin_amdgcn_readfirstlane(*a.n_pts_dev) : a.n_pts;
+    const int n_tiles = (n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
 
     WStream ws;
     ws.init(a.blob, a.blob_bytes, lds, wave, lane);
@@ -410,8 +412,8 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
         ws.stamp(6);   // (timing builds: tile start)
         const bool more = tile + (int)gridDim.x < n_tiles;
         const int n = tile * WG_SAMPLES + wave * 32 + j;
-        const bool valid = n < a.n_pts;
-        const int nn = valid ? n : a.n_pts - 1;
+        const bool valid = n < n_pts;
+        const int nn = valid ? n : n_pts - 1;
         const float p[3] = {a.pts[3 * nn], a.pts[3 * nn + 1], a.pts[3 * nn + 2]};
         int frame = nn / a.pts_per_frame;
         frame = frame < a.n_frames ? frame : a.n_frames - 1;
@@ -785,7 +787,7 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             const int ni = n0 + 16 * ((i >> 2) & 1);
-                            if (ni < a.n_pts) a.feat[(size_t)ni * H + 32 * t + 16 * (i >> 3) + 4 * g4 + (i & 3)] = st.v[i];
+                            if (ni < n_pts) a.feat[(size_t)ni * H + 32 * t + 16 * (i >> 3) + 4 * g4 + (i & 3)] = st.v[i];
                         }
                     }
                 } else if (a.feat != nullptr && valid) {
@@ -1105,6 +1107,7 @@ static void hand2_common_args(Hand2Args& a, const hn_field* f, const float* pts,
     a.dbg = 0;
     a.cull = f->cull_far_field;
     a.xsync = nullptr;
+    a.n_pts_dev = launch_n_pts_dev();   // (set by the caller around a launch over a compacted sample list, else NULL)
 }
 
 #if defined(HN_HAND_QUAD_TU)    // hn_field2_hand_q.hip: only the device helpers above are wanted
@@ -1175,7 +1178,7 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
     }
     // a launch too small to fill the chip: the latency form (bit-identical results; its stash fits the same workspace)
     const int n_blocks = (n_pts + 31) / 32;
-    if (!full && !f->single_pass && !a.cull && n_blocks <= quad_max_blocks(n_cus) && field2_hand_q_workspace_bytes(n_blocks, n_cus) <= workspace_bytes)
+    if (!full && !f->single_pass && !a.cull && a.n_pts_dev == nullptr && n_blocks <= quad_max_blocks(n_cus) && field2_hand_q_workspace_bytes(n_blocks, n_cus) <= workspace_bytes)
         return launch_field2_hand_q(a, n_blocks, n_cus, stream);
     // XCD pacing: launches of many tiles per workgroup (the image-sized ones), where the workspace has the room
     if (HN_XCD_PACING && (n_pts + WG_SAMPLES - 1) / WG_SAMPLES >= XCD_PACE_MIN_ROUNDS * grid && workspace_bytes >= need + 64) {

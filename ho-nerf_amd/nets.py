@@ -334,6 +334,10 @@ class PackedField:
         torch.cuda.synchronize()
         _lib.check(self.lib.hn_field_set_culling(self.handle, 1 if enabled else 0), 'hn_field_set_culling')
 
+    def set_compaction(self, enabled):
+        """Exact far-field skip in the two-field renders (hn_field_set_compaction); results stay bit-identical."""
+        _lib.check(self.lib.hn_field_set_compaction(self.handle, 1 if enabled else 0), 'hn_field_set_compaction')
+
     # ---- direct field queries (utils/fields.py .sdf / forward+gradient+colour) ----------
     def _frames(self, pts, bt_inv, T_pose):
         n = pts.shape[0]

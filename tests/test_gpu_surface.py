@@ -300,6 +300,44 @@ def test_fit_step_single_and_video():
     assert all(not torch.equal(a, b.detach()) for a, b in zip(before, chain.parameters()))
 
 
+def test_far_field_compaction_is_exact():
+    """NeuSRenderer_fitting.compact_far_field (hn_field_set_compaction): the hand field is evaluated only on the samples with a
+    live bone mask (+ one far sample whose outputs stand for all the others).  Every output of the differentiable two-field
+    render must be bit-identical to the dense evaluation, the gradients equal up to the order of the pose-gradient atomics."""
+    import bench
+    from honerf_amd import fitting as F, lib as Lm
+    dev = torch.device('cuda')
+    res = {}
+    for compact in (False, True):
+        ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3', halo=True)
+        ren.compact_far_field = compact
+        v = views[0]
+        pose = chain()
+        o, d = F._rays(Lm, v['xy'], v['cam'], 1, bench.FIT_RAYS)
+        leaves = [pose['bt_inv'][0].detach().clone().requires_grad_(True), pose['obj_r'][0].T.detach().clone().contiguous().requires_grad_(True),
+                  pose['obj_t'][0].detach().clone().requires_grad_(True), o.clone().requires_grad_(True), d.clone().requires_grad_(True)]
+        tr = torch.rand(bench.FIT_RAYS, 1, generator=torch.Generator().manual_seed(3)).to(dev)
+        out = ren.render(leaves[3], leaves[4], bench.NEAR, bench.FAR, leaves[0], pose['T_pose_21'][0], None, leaves[1], leaves[2], t_rand=tr)
+        g = torch.Generator().manual_seed(5)
+        loss = sum((out[k] * torch.randn(out[k].shape, generator=g).to(dev)).sum() for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj', 'gradient_hand'))
+        grads = torch.autograd.grad(loss, leaves)
+        res[compact] = ({k: out[k].detach().clone() for k in out}, [x.clone() for x in grads], ren.last_z_vals.clone())
+    dense, comp = res[False], res[True]
+    assert torch.equal(dense[2], comp[2])
+    for k in dense[0]:
+        if k.startswith('gradient_error'):      # a sum accumulated with float atomics: equal to rounding, not to the bit, in ANY two runs
+            assert abs(float(dense[0][k]) - float(comp[0][k])) <= 1e-6 * abs(float(dense[0][k])), k
+        else:
+            assert torch.equal(dense[0][k], comp[0][k]), 'compaction changed ' + k
+    sh = dense[0]['sdf_hand'].reshape(-1)
+    far = float((sh == sh.mode().values).float().mean())
+    assert 0.2 < far < 0.9, far                                   # the scene has far-field samples to skip, and live ones
+    names = ('bt_inv', 'Ro', 'To', 'rays_o', 'rays_d')
+    for name, a, b in zip(names, dense[1], comp[1]):
+        e = rel_err(b.cpu().numpy(), a.cpu().numpy())
+        bounded('far-field compaction: d loss / d %s vs dense' % name, e, 2e-5)
+
+
 def test_fit_sequence_video_one_rank_is_the_sequential_schedule():
     """fit_sequence_video with one rank (no process group) on the device == fit_step applied window by window in the
     reference's order (fitting_video.py:186-342) over the reference's six-leaf pose chain; and
