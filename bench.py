@@ -275,6 +275,12 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
         sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, ft))
         res['single_' + ft] = {'ms_per_step': sec * 1e3, 'steps_per_frame': STEPS_PER_FRAME[ft],
                                'frames_per_s': world / (STEPS_PER_FRAME[ft] * sec), 'pose_chain': 'halo (six refine leaves, hn_pose_chain)'}
+    # the same step with every sample of the hand field evaluated ("dense": NeuSRenderer_fitting.compact_far_field = False; the
+    # default skips the samples whose bone masks are all exactly 0 -- bit-identical outputs)
+    ren.compact_far_field = False
+    sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, '12'))
+    res['single_12_dense'] = {'ms_per_step': sec * 1e3, 'what': 'secondary: no far-field skip (every one of the 196 x 192 samples through the hand field)'}
+    ren.compact_far_field = True
     chain_r, _, _ = build_fit_data(dev, 40 + rank, 1, halo=False)
     opt_r = F.make_optimizer(chain_r, video=False)
     sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain_r, opt_r, NEAR, FAR, '12'))

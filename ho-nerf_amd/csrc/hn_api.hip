@@ -250,6 +250,12 @@ __global__ void k_hand_scatter(const int* __restrict__ pos, int n, const int* __
         rgb[3 * (size_t)i + c] = rgb_c[3 * (size_t)k + c];
     }
 }
+__global__ void k_hand_scatter_sdf(const int* __restrict__ pos, int n, const int* __restrict__ n_dev, const float* __restrict__ sdf_c,
+                                   float* __restrict__ sdf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sdf[i] = sdf_c[pos[i] >= 0 ? pos[i] : n_dev[0] - 1];
+}
 // upstream gradients of the dense arrays -> compact (the far sample's are 0: it stands for samples that contribute nothing)
 __global__ void k_hand_gather_up(const int* __restrict__ idx, int n_max, const int* __restrict__ n_dev, const float* __restrict__ gs,
                                  const float* __restrict__ gg, const float* __restrict__ gr, float* __restrict__ gs_c,
@@ -570,7 +576,24 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
         for (TrackRun& r : runs) {   // coarse pass
             Track& t = *r.t;
             HN_TRY(sample_points(r.ro, r.rd, t.z_a, n_rays, r.k, 0, 0.f, t.pts, nullptr, r.st));
-            HN_TRY(field_sdf(r.f, t.pts, n_rays * r.k, bt_inv, T_pose, r.nf, r.which == 0 ? rpf * r.k : n_rays * r.k, t.sdf_a, r.fws, r.fwb, r.st));
+            const int nc = n_rays * r.k;
+            if (r.which == 0 && crec_ws != nullptr && hand_compaction(hand, n_frames, (size_t)nc)) {
+                // the hand's coarse pass on the samples with a live bone (the record of the final evaluation is written later)
+                CompactRec cr;
+                cr.at(crec_ws, (size_t)nc);
+                HN_CHECK_HIP(hipMemsetAsync(cr.counter, 0, 16, r.st));
+                hipLaunchKernelGGL(k_hand_compact, dim3((nc + 255) / 256), dim3(256), 0, r.st, t.pts, nc, bt_inv, T_pose, cr.counter, cr.idx, cr.pos, cr.pts_c);
+                hipLaunchKernelGGL(k_hand_compact_seal, dim3(1), dim3(64), 0, r.st, cr.counter, cr.n_dev, cr.pts_c);
+                HN_LAUNCH_CHECK();
+                set_launch_n_pts_dev(cr.n_dev);
+                const int rc = field_sdf(r.f, cr.pts_c, nc + 1, bt_inv, T_pose, 1, nc + 1, cr.sdf_c, r.fws, r.fwb, r.st);
+                set_launch_n_pts_dev(nullptr);
+                HN_TRY(rc);
+                hipLaunchKernelGGL(k_hand_scatter_sdf, dim3((nc + 255) / 256), dim3(256), 0, r.st, cr.pos, nc, cr.n_dev, cr.sdf_c, t.sdf_a);
+                HN_LAUNCH_CHECK();
+            } else {
+                HN_TRY(field_sdf(r.f, t.pts, nc, bt_inv, T_pose, r.nf, r.which == 0 ? rpf * r.k : nc, t.sdf_a, r.fws, r.fwb, r.st));
+            }
         }
         for (int i = 0; i < steps; ++i) {
             for (TrackRun& r : runs) {
@@ -603,7 +626,10 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
         tp_h = tape_h ? tape : nullptr;
         tp_o = tape_o ? reinterpret_cast<char*>(tape) + tape_h : nullptr;
     }
-    if (side != nullptr) HN_TRY(fork_to(side, s));
+    // The object branch is released (fork) only when the hand's evaluation kernel is next in line on s: released earlier, its
+    // 294-tile kernel takes every CU (one 512-register workgroup per CU) and the small launches in front of the hand's
+    // evaluation -- its sample points, the compaction -- wait a whole tile time for a wave slot (measured: 245 us).
+    bool forked = false;
     HN_TRY(sample_points(rays_o, rays_d, z_final, n_rays, S, 1, sample_dist, pts, dists, s));
     if (hand_compaction(hand, n_frames, N)) {
         // the hand field on the samples with a live bone + one far sample; the record stays with the tape for the backward pass
@@ -615,6 +641,8 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
         hipLaunchKernelGGL(k_hand_compact, dim3(((int)N + 255) / 256), dim3(256), 0, s, pts, (int)N, bt_inv, T_pose, cr.counter, cr.idx, cr.pos, cr.pts_c);
         hipLaunchKernelGGL(k_hand_compact_seal, dim3(1), dim3(64), 0, s, cr.counter, cr.n_dev, cr.pts_c);
         HN_LAUNCH_CHECK();
+        if (side != nullptr) HN_TRY(fork_to(side, s));
+        forked = true;
         set_launch_n_pts_dev(cr.n_dev);
         const int rc = field_eval(hand, cr.pts_c, rays_d, (int)N + 1, S, bt_inv, T_pose, 1, (int)N + 1, cr.sdf_c, cr.grad_c, cr.rgb_c, nullptr, fwsh, fws_h, s,
                                   in_tape ? tp_h : nullptr, in_tape ? tape_h : 0);
@@ -624,9 +652,12 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
                            grad_hand, rgb_h);
         HN_LAUNCH_CHECK();
     } else {
+        if (side != nullptr) HN_TRY(fork_to(side, s));
+        forked = true;
         HN_TRY(field_eval(hand, pts, rays_d, (int)N, S, bt_inv, T_pose, n_frames, rpf * S, sdf_hand, grad_hand, rgb_h, nullptr,
                           fwsh, fws_h, s, tp_h, tape_h));
     }
+    (void)forked;
     HN_TRY(alpha(sdf_hand, grad_hand, rays_d, dists, (int)N, S, hand->inv_s, al_h, nullptr, s));
     HN_TRY(sample_points(o_obj, d_obj, z_final, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
     HN_TRY(field_eval(obj, pts_o, d_obj, (int)N, S, nullptr, nullptr, 1, (int)N, sdf_obj, grad_obj, rgb_o, nullptr, fwso,
@@ -722,13 +753,15 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs_h, gg_h, g_sdf_h, g_grad_h, grad_h, g_eik, n);
     HN_CHECK_HIP(hipMemsetAsync(g_bt_inv, 0, (size_t)n_frames * 21 * 16 * sizeof(float), s));
     HN_CHECK_HIP(hipMemsetAsync(g_T_pose, 0, (size_t)n_frames * 21 * 3 * sizeof(float), s));
-    if (side != nullptr) HN_TRY(fork_to(side, s));
     if (compact) {
         hipLaunchKernelGGL(k_hand_gather_up, dim3((n + 1 + 255) / 256), dim3(256), 0, s, cr.idx, n + 1, cr.n_dev, gs_h, gg_h, g_rgbh, gs_c, gg_c, gr_c);
         HN_LAUNCH_CHECK();
-        set_launch_n_pts_dev(cr.n_dev);
-        // (the hand's colour network ignores the view direction, utils/fields.py:222-240: its gradient is exactly 0)
         HN_CHECK_HIP(hipMemsetAsync(gdir_h, 0, R3 * sizeof(float), s));
+    }
+    if (side != nullptr) HN_TRY(fork_to(side, s));
+    if (compact) {
+        set_launch_n_pts_dev(cr.n_dev);
+        // (gdir_h zeroed above: the hand's colour network ignores the view direction, utils/fields.py:222-240)
         const int rc = bwd::field_eval_bwd(hand, cr.pts_c, rays_d, n + 1, 1, bt_inv, T_pose, 1, n + 1, gs_c, gg_c, gr_c, gp_c, nullptr, g_bt_inv, g_T_pose, bwh,
                                            bws_h, s, tp_h, cr.grad_c, cr.rgb_c);
         set_launch_n_pts_dev(nullptr);
