@@ -180,6 +180,9 @@ static int join_from(SideStream* x, hipStream_t s) {
 static thread_local const int* g_launch_n_pts_dev = nullptr;
 const int* launch_n_pts_dev() { return g_launch_n_pts_dev; }
 void set_launch_n_pts_dev(const int* p) { g_launch_n_pts_dev = p; }
+static thread_local const int* g_launch_orig_idx = nullptr;
+const int* launch_orig_idx() { return g_launch_orig_idx; }
+void set_launch_orig_idx(const int* p) { g_launch_orig_idx = p; }
 
 // ---- exact far-field skip of the hand field (SURVEY B-11, hn_field_set_compaction) ---------------------------------------
 // A sample whose bone masks h_b = 1 - sigmoid(200 (v_b - cutoff_b)) (utils/fields.py:33-35) are ALL exactly 0 in fp32 sees
@@ -192,49 +195,90 @@ void set_launch_n_pts_dev(const int* p) { g_launch_n_pts_dev = p; }
 // dead only if 200 (v_b - cutoff_b) > 20 for every bone, where the kernel's own sigmoid has been exactly 1 since ~16.7.
 __constant__ float c_cutoff_api[21] = {0.08f, 0.03f, 0.03f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f,
                                        0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f};
-// counter[0]: running count of live samples; idx[k]: sample of compact slot k; pos[i]: compact slot of sample i or -1
-__global__ void k_hand_compact(const float* __restrict__ pts, int n, const float* __restrict__ bt_inv, const float* __restrict__ T_pose,
-                               int* __restrict__ counter, int* __restrict__ idx, int* __restrict__ pos, float* __restrict__ pts_c) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    bool live = false;
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-    if (i < n) {
-        p0 = pts[3 * (size_t)i];
-        p1 = pts[3 * (size_t)i + 1];
-        p2 = pts[3 * (size_t)i + 2];
-        for (int b = 0; b < 21; ++b) {
-            const float* m = bt_inv + 16 * b;
-            const float q0 = m[0] * p0 + m[1] * p1 + m[2] * p2 + m[3] - T_pose[3 * b];
-            const float q1 = m[4] * p0 + m[5] * p1 + m[6] * p2 + m[7] - T_pose[3 * b + 1];
-            const float q2 = m[8] * p0 + m[9] * p1 + m[10] * p2 + m[11] - T_pose[3 * b + 2];
-            const float v = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
-            live = live || !(200.f * (v - c_cutoff_api[b]) > 20.f);   // (a NaN coordinate counts as live)
+// Order-preserving compaction in two launches of COMPACT_SPB-sample blocks (the compact list keeps the dense order, so the
+// samples of one frame stay together and a wave's 32 samples share their pose except at the frame boundaries).
+// idx[k]: dense index of compact slot k; pos[i]: compact slot of sample i or -1.
+constexpr int COMPACT_SPB = 2048;
+// pass 1: pos[i] = 1 (live) / 0, counts[block] = live samples of the block
+__global__ __launch_bounds__(256) void k_hand_live_count(const float* __restrict__ pts, int n, const float* __restrict__ bt_inv,
+                                                         const float* __restrict__ T_pose, int n_frames, int pts_per_frame,
+                                                         int* __restrict__ pos, int* __restrict__ counts) {
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int it = 0; it < COMPACT_SPB / 256; ++it) {
+        const int i = blockIdx.x * COMPACT_SPB + it * 256 + threadIdx.x;
+        bool live = false;
+        if (i < n) {
+            const float p0 = pts[3 * (size_t)i], p1 = pts[3 * (size_t)i + 1], p2 = pts[3 * (size_t)i + 2];
+            int frame = i / pts_per_frame;
+            frame = frame < n_frames ? frame : n_frames - 1;
+            const float* M = bt_inv + (size_t)frame * 21 * 16;
+            const float* T = T_pose + (size_t)frame * 21 * 3;
+            for (int b = 0; b < 21; ++b) {
+                const float* m = M + 16 * b;
+                const float q0 = m[0] * p0 + m[1] * p1 + m[2] * p2 + m[3] - T[3 * b];
+                const float q1 = m[4] * p0 + m[5] * p1 + m[6] * p2 + m[7] - T[3 * b + 1];
+                const float q2 = m[8] * p0 + m[9] * p1 + m[10] * p2 + m[11] - T[3 * b + 2];
+                const float v = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+                live = live || !(200.f * (v - c_cutoff_api[b]) > 20.f);   // (a NaN coordinate counts as live)
+            }
+            pos[i] = live ? 1 : 0;
         }
+        mine += __popcll(__ballot(live));
     }
-    const unsigned long long m = __ballot(live);
-    const int cnt = __popcll(m);
-    int base = 0;
-    if (lane == 0 && cnt > 0) base = atomicAdd(counter, cnt);
-    base = __shfl(base, 0, 64);
-    if (i < n) {
-        if (live) {
-            const int k = base + __popcll(m & ((1ull << lane) - 1ull));
-            idx[k] = i;
-            pos[i] = k;
-            pts_c[3 * (size_t)k] = p0;
-            pts_c[3 * (size_t)k + 1] = p1;
-            pts_c[3 * (size_t)k + 2] = p2;
-        } else {
-            pos[i] = -1;
-        }
-    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
 }
-// the far sample behind the M live ones; n_dev = M + 1 is what the field kernels read as their sample count
-__global__ void k_hand_compact_seal(const int* __restrict__ counter, int* __restrict__ n_dev, float* __restrict__ pts_c) {
-    const int M = counter[0];
-    if (threadIdx.x < 3) pts_c[3 * (size_t)M + threadIdx.x] = 10.f;   // 17 m from everything: every mask is exactly 0
-    if (threadIdx.x == 0) n_dev[0] = M + 1;
+// pass 2: slots in dense order; the last block appends the far sample behind the M live ones and writes n_dev = M + 1, the
+// sample count the field kernels read
+__global__ __launch_bounds__(256) void k_hand_compact_write(const float* __restrict__ pts, int n, const int* __restrict__ counts,
+                                                            int* __restrict__ idx, int* __restrict__ pos, float* __restrict__ pts_c,
+                                                            int* __restrict__ n_dev) {
+    __shared__ int red[4];
+    __shared__ int wcnt[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int part = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) part += counts[t];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    int run = red[0] + red[1] + red[2] + red[3];
+    for (int it = 0; it < COMPACT_SPB / 256; ++it) {
+        const int i = blockIdx.x * COMPACT_SPB + it * 256 + threadIdx.x;
+        const bool live = i < n && pos[i] != 0;
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) wcnt[it & 1][wave] = __popcll(m);
+        __syncthreads();   // (double-buffered: the next iteration's writes cannot pass this iteration's reads)
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c = wcnt[it & 1][w];
+            before += w < wave ? c : 0;
+            all += c;
+        }
+        if (i < n) {
+            if (live) {
+                const int k = run + before + __popcll(m & ((1ull << lane) - 1ull));
+                idx[k] = i;
+                pos[i] = k;
+                pts_c[3 * (size_t)k] = pts[3 * (size_t)i];
+                pts_c[3 * (size_t)k + 1] = pts[3 * (size_t)i + 1];
+                pts_c[3 * (size_t)k + 2] = pts[3 * (size_t)i + 2];
+            } else {
+                pos[i] = -1;
+            }
+        }
+        run += all;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        idx[run] = 0;
+        pts_c[3 * (size_t)run] = pts_c[3 * (size_t)run + 1] = pts_c[3 * (size_t)run + 2] = 10.f;   // 17 m from everything: every mask exactly 0
+        n_dev[0] = run + 1;
+    }
 }
 // compact results -> the dense per-sample arrays (dead samples: the far sample's values)
 __global__ void k_hand_scatter(const int* __restrict__ pos, int n, const int* __restrict__ n_dev, const float* __restrict__ sdf_c,
@@ -284,27 +328,37 @@ static int hand_cap(const hn_field* hand, size_t N) { return (int)N + ((hand != 
 // whether the two-field render of these sizes compacts the hand field's samples (the same answer in the forward pass, the
 // backward pass and the size queries)
 static bool hand_compaction(const hn_field* hand, int n_frames, size_t N) {
-    return hand != nullptr && hand->compact_far_field && hand->kind == HN_FIELD_HAND && hand->precision == HN_PREC_F16X3 && n_frames == 1 &&
+    return hand != nullptr && hand->compact_far_field && hand->kind == HN_FIELD_HAND && hand->precision == HN_PREC_F16X3 && n_frames >= 1 &&
            N >= 4096;
 }
-// the compaction record kept with the tape (the backward pass needs it): [counter, n_dev, pad, pad | idx N | pos N | pts_c | grad_c |
-// rgb_c | sdf_c], the per-sample arrays N + 1 long
+// the compaction record kept with the tape (the backward pass needs it): [n_dev, pad x3 | counts | idx N + 1 | pos N | pts_c | grad_c |
+// rgb_c | sdf_c], the per-sample float arrays N + 1 long
 struct CompactRec {
-    int *counter, *n_dev, *idx, *pos;
+    int *n_dev, *counts, *idx, *pos;
     float *pts_c, *grad_c, *rgb_c, *sdf_c;
-    static size_t bytes(size_t N) { return 16 + 2 * N * sizeof(int) + (N + 1) * 10 * sizeof(float) + 64; }
+    static size_t n_counts(size_t N) { return ((N + COMPACT_SPB - 1) / COMPACT_SPB + 3) & ~size_t(3); }
+    static size_t bytes(size_t N) { return 16 + (n_counts(N) + 2 * N + 4) * sizeof(int) + (N + 1) * 10 * sizeof(float) + 64; }
     void at(void* base, size_t N) {
         char* p = reinterpret_cast<char*>(base);
-        counter = reinterpret_cast<int*>(p);
-        n_dev = counter + 1;
-        idx = reinterpret_cast<int*>(p + 16);
-        pos = idx + N;
+        n_dev = reinterpret_cast<int*>(p);
+        counts = reinterpret_cast<int*>(p + 16);
+        idx = counts + n_counts(N);
+        pos = idx + N + 4;
         pts_c = reinterpret_cast<float*>(pos + N);
         grad_c = pts_c + 3 * (N + 1);
         rgb_c = grad_c + 3 * (N + 1);
         sdf_c = rgb_c + 3 * (N + 1);
     }
 };
+// the compact list of the hand's live samples of `pts` (dense order) + the far sample
+static int compact_hand(CompactRec& cr, const float* pts, int n, const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame,
+                        hipStream_t s) {
+    const int nb = (n + COMPACT_SPB - 1) / COMPACT_SPB;
+    hipLaunchKernelGGL(k_hand_live_count, dim3(nb), dim3(256), 0, s, pts, n, bt_inv, T_pose, n_frames, pts_per_frame, cr.pos, cr.counts);
+    hipLaunchKernelGGL(k_hand_compact_write, dim3(nb), dim3(256), 0, s, pts, n, cr.counts, cr.idx, cr.pos, cr.pts_c, cr.n_dev);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
 
 // bump allocator over the caller's workspace
 struct Arena {
@@ -581,13 +635,12 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
                 // the hand's coarse pass on the samples with a live bone (the record of the final evaluation is written later)
                 CompactRec cr;
                 cr.at(crec_ws, (size_t)nc);
-                HN_CHECK_HIP(hipMemsetAsync(cr.counter, 0, 16, r.st));
-                hipLaunchKernelGGL(k_hand_compact, dim3((nc + 255) / 256), dim3(256), 0, r.st, t.pts, nc, bt_inv, T_pose, cr.counter, cr.idx, cr.pos, cr.pts_c);
-                hipLaunchKernelGGL(k_hand_compact_seal, dim3(1), dim3(64), 0, r.st, cr.counter, cr.n_dev, cr.pts_c);
-                HN_LAUNCH_CHECK();
+                HN_TRY(compact_hand(cr, t.pts, nc, bt_inv, T_pose, r.nf, rpf * r.k, r.st));
                 set_launch_n_pts_dev(cr.n_dev);
-                const int rc = field_sdf(r.f, cr.pts_c, nc + 1, bt_inv, T_pose, 1, nc + 1, cr.sdf_c, r.fws, r.fwb, r.st);
+                set_launch_orig_idx(cr.idx);
+                const int rc = field_sdf(r.f, cr.pts_c, nc + 1, bt_inv, T_pose, r.nf, rpf * r.k, cr.sdf_c, r.fws, r.fwb, r.st);
                 set_launch_n_pts_dev(nullptr);
+                set_launch_orig_idx(nullptr);
                 HN_TRY(rc);
                 hipLaunchKernelGGL(k_hand_scatter_sdf, dim3((nc + 255) / 256), dim3(256), 0, r.st, cr.pos, nc, cr.n_dev, cr.sdf_c, t.sdf_a);
                 HN_LAUNCH_CHECK();
@@ -637,16 +690,15 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
         const bool in_tape = tape != nullptr && tape_h + tape_o != 0 && tape_bytes >= rec_off + CompactRec::bytes(N);
         CompactRec cr;
         cr.at(in_tape ? reinterpret_cast<char*>(tape) + rec_off : crec_ws, N);
-        HN_CHECK_HIP(hipMemsetAsync(cr.counter, 0, 16, s));
-        hipLaunchKernelGGL(k_hand_compact, dim3(((int)N + 255) / 256), dim3(256), 0, s, pts, (int)N, bt_inv, T_pose, cr.counter, cr.idx, cr.pos, cr.pts_c);
-        hipLaunchKernelGGL(k_hand_compact_seal, dim3(1), dim3(64), 0, s, cr.counter, cr.n_dev, cr.pts_c);
-        HN_LAUNCH_CHECK();
+        HN_TRY(compact_hand(cr, pts, (int)N, bt_inv, T_pose, n_frames, rpf * S, s));
         if (side != nullptr) HN_TRY(fork_to(side, s));
         forked = true;
         set_launch_n_pts_dev(cr.n_dev);
-        const int rc = field_eval(hand, cr.pts_c, rays_d, (int)N + 1, S, bt_inv, T_pose, 1, (int)N + 1, cr.sdf_c, cr.grad_c, cr.rgb_c, nullptr, fwsh, fws_h, s,
-                                  in_tape ? tp_h : nullptr, in_tape ? tape_h : 0);
+        set_launch_orig_idx(cr.idx);
+        const int rc = field_eval(hand, cr.pts_c, rays_d, (int)N + 1, S, bt_inv, T_pose, n_frames, rpf * S, cr.sdf_c, cr.grad_c, cr.rgb_c, nullptr, fwsh,
+                                  fws_h, s, in_tape ? tp_h : nullptr, in_tape ? tape_h : 0);
         set_launch_n_pts_dev(nullptr);
+        set_launch_orig_idx(nullptr);
         HN_TRY(rc);
         hipLaunchKernelGGL(k_hand_scatter, dim3(((int)N + 255) / 256), dim3(256), 0, s, cr.pos, (int)N, cr.n_dev, cr.sdf_c, cr.grad_c, cr.rgb_c, sdf_hand,
                            grad_hand, rgb_h);
@@ -761,10 +813,12 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     if (side != nullptr) HN_TRY(fork_to(side, s));
     if (compact) {
         set_launch_n_pts_dev(cr.n_dev);
+        set_launch_orig_idx(cr.idx);
         // (gdir_h zeroed above: the hand's colour network ignores the view direction, utils/fields.py:222-240)
-        const int rc = bwd::field_eval_bwd(hand, cr.pts_c, rays_d, n + 1, 1, bt_inv, T_pose, 1, n + 1, gs_c, gg_c, gr_c, gp_c, nullptr, g_bt_inv, g_T_pose, bwh,
-                                           bws_h, s, tp_h, cr.grad_c, cr.rgb_c);
+        const int rc = bwd::field_eval_bwd(hand, cr.pts_c, rays_d, n + 1, 1, bt_inv, T_pose, n_frames, rpf * S, gs_c, gg_c, gr_c, gp_c, nullptr, g_bt_inv,
+                                           g_T_pose, bwh, bws_h, s, tp_h, cr.grad_c, cr.rgb_c);
         set_launch_n_pts_dev(nullptr);
+        set_launch_orig_idx(nullptr);
         HN_TRY(rc);
         hipLaunchKernelGGL(k_hand_scatter3, dim3((n + 255) / 256), dim3(256), 0, s, cr.pos, n, gp_c, gp_h);
         HN_LAUNCH_CHECK();

@@ -67,6 +67,7 @@ struct Hand2Args {
     float* g_T_pose;       // [n_frames,21,3] accumulated (atomics), or NULL
     unsigned* xsync;       // 16 zeroed counters (8 XCDs x {members, arrivals}) or NULL: see "XCD pacing" in the kernel
     const int* n_pts_dev;  // NULL, or the sample count on the DEVICE (<= n_pts): a compacted list whose length the host does not know
+    const int* orig_idx;   // NULL, or per sample of a compacted list its index in the dense list (what the frame is taken from)
 };
 
 // stash slots of one wave (32 KiB each)
@@ -415,7 +416,7 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
         const bool valid = n < n_pts;
         const int nn = valid ? n : n_pts - 1;
         const float p[3] = {a.pts[3 * nn], a.pts[3 * nn + 1], a.pts[3 * nn + 2]};
-        int frame = nn / a.pts_per_frame;
+        int frame = (a.orig_idx != nullptr ? a.orig_idx[nn] : nn) / a.pts_per_frame;
         frame = frame < a.n_frames ? frame : a.n_frames - 1;
         const float* M = a.bt_inv + (size_t)frame * N_BONES * 16;
         const float* Tp = a.T_pose + (size_t)frame * N_BONES * 3;
@@ -1108,6 +1109,7 @@ static void hand2_common_args(Hand2Args& a, const hn_field* f, const float* pts,
     a.cull = f->cull_far_field;
     a.xsync = nullptr;
     a.n_pts_dev = launch_n_pts_dev();   // (set by the caller around a launch over a compacted sample list, else NULL)
+    a.orig_idx = launch_orig_idx();
 }
 
 #if defined(HN_HAND_QUAD_TU)    // hn_field2_hand_q.hip: only the device helpers above are wanted

@@ -102,8 +102,8 @@ float hn_field_inv_s(const hn_field* f);
  * weight chunks (results are bit-identical to the dense evaluation).  Off by default: throughput figures are
  * quoted dense.  Set it before launching work on the field; no effect on obj fields and on HN_PREC_FP32. */
 int hn_field_set_culling(hn_field* f, int enabled);
-/* Exact far-field skip in the two-field renders (hn_render_dual / hn_render_dual_bwd; hand fields of HN_PREC_F16X3, one
- * frame): a sample whose 21 bone masks are all exactly 0 has a constant sdf / colour, a zero gradient and contributes
+/* Exact far-field skip in the two-field renders (hn_render_dual / hn_render_dual_bwd; hand fields of HN_PREC_F16X3, any
+ * number of frames, launches of >= 4096 samples): a sample whose 21 bone masks are all exactly 0 has a constant sdf / colour, a zero gradient and contributes
  * exactly 0 to every adjoint output, so the hand field is evaluated on the compacted list of the other samples plus one far
  * sample and the results are scattered back -- bit-identical outputs, 40 - 60 % fewer samples in a fitting step (one round
  * of sample tiles on the chip instead of two).  Set it before sizing workspaces / tapes with the hn_render_dual_* queries

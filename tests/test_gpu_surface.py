@@ -338,6 +338,34 @@ def test_far_field_compaction_is_exact():
         bounded('far-field compaction: d loss / d %s vs dense' % name, e, 2e-5)
 
 
+def test_far_field_compaction_is_exact_over_a_window_of_frames():
+    """The same over the frame-batched renderer (fitting_video: 4 frames x 40 rays, every frame its own hand pose): the compact
+    list keeps the dense order and every compact sample carries its dense index, from which the kernels take its frame."""
+    import bench
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    res = {}
+    for compact in (False, True):
+        ren, nets, chain, views, verts = bench.build_fit(dev, 41, 4, bench.VID_RAYS, 'f16x3', halo=True)
+        with torch.no_grad():                                       # four different poses, not four copies of one
+            for i, p in enumerate(chain.parameters()):
+                p.add_(1e-2 * torch.randn(p.shape, generator=torch.Generator().manual_seed(20 + i)).to(dev))
+        ren.compact_far_field = compact
+        tr = torch.rand(4 * bench.VID_RAYS, 1, generator=torch.Generator().manual_seed(3)).to(dev)
+        terms = F.fit_backward(ren, views[0], chain, bench.NEAR, bench.FAR, '1234', index=[0, 1, 2, 3], obj_verts_for_stable=verts[:, :400],
+                               t_rand=tr)
+        res[compact] = ({k: v.detach().clone() for k, v in terms.items()}, [p.grad.clone() for p in chain.parameters()],
+                        ren.last_z_vals.clone())
+    dense, comp = res[False], res[True]
+    assert torch.equal(dense[2], comp[2])
+    for k in dense[0]:
+        a, b = float(dense[0][k]), float(comp[0][k])
+        assert abs(a - b) <= 2e-6 * max(abs(a), 1e-6), (k, a, b)    # (sums over samples with float atomics)
+    for i, (a, b) in enumerate(zip(dense[1], comp[1])):
+        e = rel_err(b.cpu().numpy(), a.cpu().numpy())
+        bounded('far-field compaction over 4 frames: gradient of pose leaf %d vs dense' % i, e, 5e-5)
+
+
 def test_fit_sequence_video_one_rank_is_the_sequential_schedule():
     """fit_sequence_video with one rank (no process group) on the device == fit_step applied window by window in the
     reference's order (fitting_video.py:186-342) over the reference's six-leaf pose chain; and
