@@ -39,7 +39,7 @@ int composite1(const float*, const float*, const float*, const float*, int, int,
 int composite2(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
                float*, float*, float*, float*, hipStream_t);
 int alpha_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float, float*,
-              float*, float*, hipStream_t);
+              float*, float*, hipStream_t, bool g_rays_d_zeroed = false);
 int alpha_inv_s_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float, float*,
                     hipStream_t);
 int composite1_bwd(const float*, const float*, const float*, const float*, const float*, int, int, float*, float*, float*,
@@ -120,13 +120,49 @@ __global__ void k_add4(const float* __restrict__ a, const float* __restrict__ b,
     out[i] = v;
 }
 
+// two sums in one launch: out0 = a0 + b0, out1 = a1 + b1 + c1 + d1
+__global__ void k_add4x2(const float* __restrict__ a0, const float* __restrict__ b0, float* __restrict__ out0, const float* __restrict__ a1,
+                         const float* __restrict__ b1, const float* __restrict__ c1, const float* __restrict__ d1, float* __restrict__ out1,
+                         int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out0[i] = a0[i] + b0[i];
+    out1[i] = a1[i] + b1[i] + c1[i] + d1[i];
+}
+// up to four small buffers zeroed by one launch (a launch of a dependent chain costs ~5 us whatever it does)
+struct ZeroList {
+    float* p[4];
+    int n[4];
+};
+__global__ void k_zero_many(ZeroList z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        if (z.p[b] != nullptr && i < z.n[b]) z.p[b][i] = 0.f;
+}
+static int zero_many(std::initializer_list<std::pair<float*, size_t>> bufs, hipStream_t s) {
+    ZeroList z{};
+    int k = 0, most = 0;
+    for (const auto& b : bufs) {
+        if (b.first == nullptr || b.second == 0) continue;
+        z.p[k] = b.first;
+        z.n[k] = (int)b.second;
+        most = most > (int)b.second ? most : (int)b.second;
+        ++k;
+    }
+    if (k == 0) return HN_OK;
+    hipLaunchKernelGGL(k_zero_many, dim3((most + 255) / 256), dim3(256), 0, s, z);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
 // ---- a second stream per device: the hand and the object track of the two-field renders are independent until
 // their results meet (the sorted depths; the compositing), and each of them alone leaves most CUs idle at the fitting
 // sizes (294 sample tiles on 256 CUs = two rounds, the second 15 % full).  Fork / join are event waits on the device:
 // nothing here blocks the host.  Created once per device on first use (the only allocation outside field_create).
 struct SideStream {
     hipStream_t s2 = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, gate = nullptr;
 };
 static std::atomic<int> g_quad_max_blocks{[] {
     const char* e = getenv("HN_QUAD_MAX_BLOCKS");
@@ -157,7 +193,8 @@ static SideStream* side_stream() {
             SideStream& x = g_side[dev];
             const bool ok = hipStreamCreateWithFlags(&x.s2, hipStreamNonBlocking) == hipSuccess &&
                             hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-                            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+                            hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess &&
+                            hipEventCreateWithFlags(&x.gate, hipEventDisableTiming) == hipSuccess;
             g_side_state[dev].store(ok ? 2 : 3, std::memory_order_release);
         }
         while ((st = g_side_state[dev].load(std::memory_order_acquire)) == 1) {
@@ -169,6 +206,12 @@ static SideStream* side_stream() {
 static int fork_to(SideStream* x, hipStream_t s) {
     HN_CHECK_HIP(hipEventRecord(x->fork, s));
     HN_CHECK_HIP(hipStreamWaitEvent(x->s2, x->fork, 0));
+    return HN_OK;
+}
+// s2 goes on only when s has reached this point (a second meeting inside a fork ... join section)
+static int gate_to(SideStream* x, hipStream_t s) {
+    HN_CHECK_HIP(hipEventRecord(x->gate, s));
+    HN_CHECK_HIP(hipStreamWaitEvent(x->s2, x->gate, 0));
     return HN_OK;
 }
 static int join_from(SideStream* x, hipStream_t s) {
@@ -715,13 +758,14 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     HN_TRY(field_eval(obj, pts_o, d_obj, (int)N, S, nullptr, nullptr, 1, (int)N, sdf_obj, grad_obj, rgb_o, nullptr, fwso,
                       fws_o, so, tp_o, tape_o));
     HN_TRY(alpha(sdf_obj, grad_obj, d_obj, dists_o, (int)N, S, obj->inv_s, al_o, nullptr, so));
-    if (side != nullptr) HN_TRY(join_from(side, s));
+    // (on s while it waits for the object branch: off the critical path)
     HN_CHECK_HIP(hipMemsetAsync(gradient_error, 0, 2 * sizeof(float), s));
+    if (z_vals != nullptr) HN_CHECK_HIP(hipMemcpyAsync(z_vals, z_final, N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (side != nullptr) HN_TRY(join_from(side, s));
     HN_TRY(composite2(al_h, rgb_h, grad_hand, al_o, rgb_o, grad_obj, n_rays, S, color, weight_sum, nullptr, nullptr,
                       gradient_error, s));
     hipLaunchKernelGGL(k_scale, dim3(1), dim3(64), 0, s, gradient_error, 2, 1.f / (float)N);
     HN_LAUNCH_CHECK();
-    if (z_vals != nullptr) HN_CHECK_HIP(hipMemcpyAsync(z_vals, z_final, N * sizeof(float), hipMemcpyDeviceToDevice, s));
     return HN_OK;
 }
 
@@ -795,22 +839,26 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     SideStream* side = side_stream();
     SideLock side_lock(side);
     const hipStream_t so = side != nullptr ? side->s2 : s;
-    HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_l, d_l, s));
     HN_TRY(composite2_bwd(alpha_h, rgb_h, alpha_o, rgb_o, g_color, g_wsum, n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo, s));
-    // hand branch (s).  The object branch is released (fork) only when the hand's adjoint kernel is next in line: that
-    // kernel is the long pole (two rounds of sample tiles, the second 15 % full) and must get the CUs first; the object
-    // branch then runs in the shadow of its second round instead of delaying its start.
-    HN_TRY(sample_points(rays_o, rays_d, z, n_rays, S, 1, sample_dist, pts_h, dists_h, s));
-    HN_TRY(alpha_bwd(sdf_h, grad_h, rays_d, dists_h, g_ah, nullptr, n, S, hand->inv_s, gs_h, gg_h, gd_h, s));
-    hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs_h, gg_h, g_sdf_h, g_grad_h, grad_h, g_eik, n);
-    HN_CHECK_HIP(hipMemsetAsync(g_bt_inv, 0, (size_t)n_frames * 21 * 16 * sizeof(float), s));
-    HN_CHECK_HIP(hipMemsetAsync(g_T_pose, 0, (size_t)n_frames * 21 * 3 * sizeof(float), s));
-    if (compact) {
-        hipLaunchKernelGGL(k_hand_gather_up, dim3((n + 1 + 255) / 256), dim3(256), 0, s, cr.idx, n + 1, cr.n_dev, gs_h, gg_h, g_rgbh, gs_c, gg_c, gr_c);
-        HN_LAUNCH_CHECK();
-        HN_CHECK_HIP(hipMemsetAsync(gdir_h, 0, R3 * sizeof(float), s));
-    }
+    // The object branch's small launches are released here (fork) and run beside the hand's; its adjoint kernel itself waits at
+    // a second meeting point (gate) until the hand's adjoint kernel is next in line on s: that kernel's tiles are the long ones
+    // and must get their CUs first, the object's 294 shorter tiles then take what is left at once.
     if (side != nullptr) HN_TRY(fork_to(side, s));
+    // hand branch (s)
+    HN_TRY(zero_many({{g_bt_inv, (size_t)n_frames * 21 * 16}, {g_T_pose, (size_t)n_frames * 21 * 3}, {gd_h, R3}, {compact ? gdir_h : nullptr, R3}}, s));
+    HN_TRY(sample_points(rays_o, rays_d, z, n_rays, S, 1, sample_dist, pts_h, dists_h, s));
+    HN_TRY(alpha_bwd(sdf_h, grad_h, rays_d, dists_h, g_ah, nullptr, n, S, hand->inv_s, gs_h, gg_h, gd_h, s, true));
+    hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs_h, gg_h, g_sdf_h, g_grad_h, grad_h, g_eik, n);
+    if (compact) hipLaunchKernelGGL(k_hand_gather_up, dim3((n + 1 + 255) / 256), dim3(256), 0, s, cr.idx, n + 1, cr.n_dev, gs_h, gg_h, g_rgbh, gs_c, gg_c, gr_c);
+    HN_LAUNCH_CHECK();
+    // object branch (so) up to its adjoint kernel
+    HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_l, d_l, so));
+    HN_TRY(sample_points(o_l, d_l, z, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
+    HN_TRY(alpha_bwd(sdf_o, grad_o, d_l, dists_o, g_ao, nullptr, n, S, obj->inv_s, gs_o, gg_o, gd_o, so));
+    hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, so, gs_o, gg_o, g_sdf_o, g_grad_o, grad_o,
+                       g_eik != nullptr ? g_eik + 1 : nullptr, n);
+    HN_LAUNCH_CHECK();
+    if (side != nullptr) HN_TRY(gate_to(side, s));
     if (compact) {
         set_launch_n_pts_dev(cr.n_dev);
         set_launch_orig_idx(cr.idx);
@@ -827,20 +875,13 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
                                    g_T_pose, bwh, bws_h, s, tp_h, grad_h, rgb_h));
     }
     HN_TRY(sample_points_bwd(z, gp_h, n_rays, S, 1, sample_dist, go_h, gdd_h, s));
-    // object branch (so)
-    HN_TRY(sample_points(o_l, d_l, z, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
-    HN_TRY(alpha_bwd(sdf_o, grad_o, d_l, dists_o, g_ao, nullptr, n, S, obj->inv_s, gs_o, gg_o, gd_o, so));
-    hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, so, gs_o, gg_o, g_sdf_o, g_grad_o, grad_o,
-                       g_eik != nullptr ? g_eik + 1 : nullptr, n);
     HN_TRY(bwd::field_eval_bwd(obj, pts_o, d_l, n, S, nullptr, nullptr, 1, n, gs_o, gg_o, g_rgbo, gp_o, gdir_o, nullptr, nullptr, bwo,
                                bws_o, so, tp_o, grad_o, rgb_o));
     HN_TRY(sample_points_bwd(z, gp_o, n_rays, S, 1, sample_dist, go_l, gdd_l, so));
     hipLaunchKernelGGL(k_add4, dim3(((int)R3 + 255) / 256), dim3(256), 0, so, gdd_l, gd_o, gdir_o, (const float*)nullptr, gd_l, (int)R3);
     HN_TRY(obj_local_bwd(rays_o, rays_d, Ro, To, go_l, gd_l, n_frames, rpf, g_ro2, g_rd2, g_Ro, g_To, so));
     if (side != nullptr) HN_TRY(join_from(side, s));
-    hipLaunchKernelGGL(k_add4, dim3(((int)R3 + 255) / 256), dim3(256), 0, s, go_h, g_ro2, (const float*)nullptr, (const float*)nullptr,
-                       g_rays_o, (int)R3);
-    hipLaunchKernelGGL(k_add4, dim3(((int)R3 + 255) / 256), dim3(256), 0, s, gdd_h, gd_h, gdir_h, g_rd2, g_rays_d, (int)R3);
+    hipLaunchKernelGGL(k_add4x2, dim3(((int)R3 + 255) / 256), dim3(256), 0, s, go_h, g_ro2, g_rays_o, gdd_h, gd_h, gdir_h, g_rd2, g_rays_d, (int)R3);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

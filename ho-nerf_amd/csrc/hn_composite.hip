@@ -686,10 +686,11 @@ int composite2(const float* ah, const float* rgbh, const float* gh, const float*
 }
 
 int alpha_bwd(const float* sdf, const float* grad, const float* rays_d, const float* dists, const float* g_alpha,
-              const float* g_c, int n, int spr, float inv_s, float* g_sdf, float* g_grad, float* g_rays_d, hipStream_t s) {
+              const float* g_c, int n, int spr, float inv_s, float* g_sdf, float* g_grad, float* g_rays_d, hipStream_t s,
+              bool g_rays_d_zeroed) {
     HN_REQUIRE(spr > 0, "samples_per_ray must be positive");
     if (n == 0) return HN_OK;
-    if (g_rays_d != nullptr) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n / spr) * 3 * sizeof(float), s));
+    if (g_rays_d != nullptr && !g_rays_d_zeroed) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n / spr) * 3 * sizeof(float), s));
     hipLaunchKernelGGL(k_alpha_bwd, dim3((n + 255) / 256), dim3(256), 0, s, sdf, grad, rays_d, dists, g_alpha, g_c, n, spr,
                        inv_s, g_sdf, g_grad, g_rays_d);
     HN_LAUNCH_CHECK();

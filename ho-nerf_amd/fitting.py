@@ -457,8 +457,11 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
         out = renderer.render(rays_o.reshape(n_cams, P, 3), rays_d.reshape(n_cams, P, 3), near, far, pose['bt_inv'], T_pose, None,
                               Ro_arg, pose['obj_t'], t_rand=t_rand)
     else:
-        Ro_arg = pose['obj_r'][0].T                                                    # fitting_single.py:250
-        out = renderer.render(rays_o, rays_d, near, far, pose['bt_inv'][0], T_pose[0], None, Ro_arg, pose['obj_t'][0], t_rand=t_rand)
+        # frame 0 of a one-frame chain as a reshape: the backward of `x[0]` is a zero fill and a copy per tensor, that of a view is free
+        one = pose['bt_inv'].shape[0] == 1
+        first = lambda x: x.reshape(x.shape[1:]) if one else x[0]
+        Ro_arg = first(pose['obj_r']).T                                                # fitting_single.py:250
+        out = renderer.render(rays_o, rays_d, near, far, first(pose['bt_inv']), first(T_pose), None, Ro_arg, first(pose['obj_t']), t_rand=t_rand)
     stable = None
     if video and fit_type == '1234':
         stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])

@@ -148,6 +148,17 @@ class VertsLossFn(torch.autograd.Function):
                 (-dR).reshape(sh[2]) if nd[2] else None, (-dt).reshape(sh[3]) if nd[3] else None, None)
 
 
+_ZEROS9 = {}
+
+
+def _zeros9(F, dev):
+    """A cached [F, 9] zero block (the unused inputs of hn_rigid_pose); never written."""
+    key = (F, str(dev))
+    if key not in _ZEROS9:
+        _ZEROS9[key] = torch.zeros(F, 9, device=dev, dtype=torch.float32)
+    return _ZEROS9[key]
+
+
 class HaloChainFn(torch.autograd.Function):
     """The whole pose side of a fitting_single step as ONE autograd node over the six refine leaves (fitting_single.py:177-235):
     (obj_rot [F,3,2], obj_trans [F,3], palm_rot [F,3,2], palm_trans [F,3], joint_refine_angle [F,20], palm_refine_angle [F,7])
@@ -162,10 +173,9 @@ class HaloChainFn(torch.autograd.Function):
         F, dev = ori_pose.shape[0], ori_pose.device
         st = L.stream_ptr()
         prm = torch.cat([joint_angle.reshape(F, 20), palm_angle.reshape(F, 7), palm_rot.reshape(F, 6), palm_trans.reshape(F, 3),
-                         obj_rot.reshape(F, 6), obj_trans.reshape(F, 3)], dim=1)                     # [F, 45]: one launch
+                         obj_rot.reshape(F, 6), obj_trans.reshape(F, 3), _zeros9(F, dev)], dim=1)    # [F, 45 + 9]: one launch
         prm_h = prm[:, :36].contiguous() if F > 1 else prm[:, :36]
-        prm_o = torch.zeros(F, 18, device=dev, dtype=torch.float32)
-        prm_o[:, :9] = prm[:, 36:45]
+        prm_o = prm[:, 36:54].contiguous() if F > 1 else prm[:, 36:54]                               # hn_rigid_pose's 18 inputs: 9 used here
         need = any(x.requires_grad for x in (obj_rot, obj_trans, palm_rot, palm_trans, joint_angle, palm_angle))
         bt = torch.empty(F, 21, 4, 4, device=dev, dtype=torch.float32)
         j3 = torch.empty(F, 21, 3, device=dev, dtype=torch.float32)
