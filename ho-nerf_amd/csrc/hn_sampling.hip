@@ -192,6 +192,55 @@ __global__ void k_sample_points_v(const float* __restrict__ o, const float* __re
     for (int v = 0; v < 3 * V / 4; ++v) out[v] = make_float4(p[4 * v], p[4 * v + 1], p[4 * v + 2], p[4 * v + 3]);
 }
 
+// 4 samples per thread with the 48 bytes of points a thread produces TRANSPOSED through a wave-private LDS region, so that every
+// store instruction of a wave writes 1 KiB of consecutive bytes (as 3 float4 per lane at a 48-byte stride each instruction
+// touches every cache line of the wave's 3 KiB and fills a third of it).  No barrier: a wave's LDS operations complete in order.
+__global__ __launch_bounds__(256) void k_sample_points_t(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z,
+                                                         int n_rays, int n, int mid, float sample_dist, float* __restrict__ pts,
+                                                         float* __restrict__ dists) {
+    __shared__ float4 stage[4][192];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned q0 = blockIdx.x * 256u + wave * 64u;   // the wave's first group of 4 samples
+    const unsigned q = q0 + lane;
+    const unsigned total = (unsigned)n_rays * (unsigned)n / 4u;
+    const bool ok = q < total;
+    if (ok) {
+        const unsigned i = q * 4u;
+        const int b = (int)(i / (unsigned)n), k = (int)(i - (unsigned)b * (unsigned)n);
+        const float4 zz = reinterpret_cast<const float4*>(z)[q];
+        float t[4] = {zz.x, zz.y, zz.z, zz.w};
+        if (mid) {
+            float dd[4];
+            dd[0] = t[1] - t[0];
+            dd[1] = t[2] - t[1];
+            dd[2] = t[3] - t[2];
+            dd[3] = (k + 4 < n) ? z[i + 4] - t[3] : sample_dist;
+            reinterpret_cast<float4*>(dists)[q] = make_float4(dd[0], dd[1], dd[2], dd[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = t[j] + dd[j] * 0.5f;
+        }
+        const float ox = o[3 * b], oy = o[3 * b + 1], oz = o[3 * b + 2], dx = d[3 * b], dy = d[3 * b + 1], dz = d[3 * b + 2];
+        float p[12];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p[3 * j] = ox + dx * t[j];
+            p[3 * j + 1] = oy + dy * t[j];
+            p[3 * j + 2] = oz + dz * t[j];
+        }
+#pragma unroll
+        for (int v = 0; v < 3; ++v) stage[wave][3 * lane + v] = make_float4(p[4 * v], p[4 * v + 1], p[4 * v + 2], p[4 * v + 3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (q0 >= total) return;
+    const unsigned have = (total - q0 < 64u ? total - q0 : 64u) * 3u;   // float4s this wave produced
+    float4* out = reinterpret_cast<float4*>(pts) + 3 * (size_t)q0;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const unsigned f = v * 64u + lane;
+        if (f < have) out[f] = stage[wave][f];
+    }
+}
+
 // adjoint of k_sample_points w.r.t. the rays (the depths are sampled under no_grad): one wave per ray
 //   g_o = sum_k g_pts[k],  g_d = sum_k t_k g_pts[k]   (t_k = z_k, or the section mid-point)
 __global__ __launch_bounds__(256) void k_sample_points_bwd(const float* __restrict__ z, const float* __restrict__ g_pts,
@@ -228,20 +277,11 @@ __global__ __launch_bounds__(256) void k_sample_points_bwd(const float* __restri
 constexpr int UPS_MAX_K = 256;
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ __launch_bounds__(64) void k_upsample_direct(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays,
-                                                 int k, int n_new, float inv_s, float* __restrict__ z_new,
-                                                 int64_t* __restrict__ inds_out) {
-    extern __shared__ float lds[];   // cdf[k][64]
-    const int lane = threadIdx.x;
-    const int ray = blockIdx.x * 64 + lane;
-    if (ray >= n_rays) return;
-    const float* zr = z + (size_t)ray * k;
-    const float* sr = sdf + (size_t)ray * k;
-    // pass 1: section weights, sequential transmittance (torch.cumprod order)
-    float prev_cos = 0.f, T = 1.f, sum = 0.f;
-    float z0 = zr[0], s0 = sr[0];
-    for (int i = 0; i + 1 < k; ++i) {
-        const float z1 = zr[i + 1], s1 = sr[i + 1];
+// One section of up_sample's pass 1 (utils/renderer.py:68-84 + sample_pdf's weights + 1e-5): the same operations in the same
+// order in every kernel below.
+struct UpsState {
+    float prev_cos = 0.f, T = 1.f, sum = 0.f, z0, s0;
+    __device__ __forceinline__ float step(float z1, float s1, float inv_s) {
         const float mid_sdf = (s0 + s1) * 0.5f;
         const float cosv = (s1 - s0) / (z1 - z0 + 1e-5f);
         float c = fminf(prev_cos, cosv);
@@ -253,17 +293,53 @@ __global__ __launch_bounds__(64) void k_upsample_direct(const float* __restrict_
         const float alpha = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
         const float w = alpha * T + 1e-5f;           // weights + 1e-5 (sample_pdf)
         T = T * (1.f - alpha + 1e-7f);
-        lds[(i + 1) * 64 + lane] = w;
         sum += w;
         z0 = z1;
         s0 = s1;
+        return w;
     }
+};
+constexpr int UPS_BLK = 8;   // row entries fetched ahead of their use (LDS / global latency is paid once per block, not per entry)
+
+__global__ __launch_bounds__(64) void k_upsample_direct(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays,
+                                                 int k, int n_new, float inv_s, float* __restrict__ z_new,
+                                                 int64_t* __restrict__ inds_out) {
+    extern __shared__ float lds[];   // cdf[k][64]
+    const int lane = threadIdx.x;
+    const int ray = blockIdx.x * 64 + lane;
+    if (ray >= n_rays) return;
+    const float* zr = z + (size_t)ray * k;
+    const float* sr = sdf + (size_t)ray * k;
+    // pass 1: section weights, sequential transmittance (torch.cumprod order)
+    UpsState st;
+    st.z0 = zr[0];
+    st.s0 = sr[0];
+    for (int i0 = 1; i0 < k; i0 += UPS_BLK) {
+        float zb[UPS_BLK], sb[UPS_BLK];
+#pragma unroll
+        for (int u = 0; u < UPS_BLK; ++u) {
+            const int i = i0 + u < k ? i0 + u : k - 1;
+            zb[u] = zr[i];
+            sb[u] = sr[i];
+        }
+#pragma unroll
+        for (int u = 0; u < UPS_BLK; ++u)
+            if (i0 + u < k) lds[(i0 + u) * 64 + lane] = st.step(zb[u], sb[u], inv_s);
+    }
+    const float sum = st.sum;
     // pass 2: cdf = [0, cumsum(w / sum)]
     lds[lane] = 0.f;
     float run = 0.f;
-    for (int i = 1; i < k; ++i) {
-        run += lds[i * 64 + lane] / sum;
-        lds[i * 64 + lane] = run;
+    for (int i0 = 1; i0 < k; i0 += UPS_BLK) {
+        float wb[UPS_BLK];
+#pragma unroll
+        for (int u = 0; u < UPS_BLK; ++u) wb[u] = lds[(i0 + u < k ? i0 + u : k - 1) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < UPS_BLK; ++u)
+            if (i0 + u < k) {
+                run += wb[u] / sum;
+                lds[(i0 + u) * 64 + lane] = run;
+            }
     }
     // pass 3: invert at u = linspace(0.5/n, 1-0.5/n, n)
     const float u_start = 0.f + 0.5f / (float)n_new, u_end = 1.f - 0.5f / (float)n_new;
@@ -271,7 +347,13 @@ __global__ __launch_bounds__(64) void k_upsample_direct(const float* __restrict_
     int ptr = 0;   // number of cdf entries <= u (searchsorted right=True); cdf and u are both non-decreasing
     for (int jj = 0; jj < n_new; ++jj) {
         const float u = (jj < n_new / 2) ? u_start + (float)jj * u_step : u_end - (float)(n_new - 1 - jj) * u_step;
-        while (ptr < k && lds[ptr * 64 + lane] <= u) ++ptr;
+        for (;;) {   // four entries per round trip (the cdf is non-decreasing: the entries <= u are a prefix)
+            int adv = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) adv += (ptr + q < k && lds[(ptr + q < k ? ptr + q : k - 1) * 64 + lane] <= u) ? 1 : 0;
+            ptr += adv;
+            if (adv < 4) break;
+        }
         const int below = ptr - 1 > 0 ? ptr - 1 : 0;
         const int above = ptr < k - 1 ? ptr : k - 1;
         const float c_lo = lds[below * 64 + lane], c_hi = lds[above * 64 + lane];
@@ -284,73 +366,105 @@ __global__ __launch_bounds__(64) void k_upsample_direct(const float* __restrict_
     }
 }
 
-// The same arithmetic with the 64 rows of a block staged through LDS: rows are read from global memory with
-// consecutive lanes on consecutive addresses and walked from LDS (row pitch k+1 words: conflict-free), instead of
-// every lane striding through its own row in global memory.  The weights / cdf overwrite the staged sdf row.
-__global__ __launch_bounds__(64) void k_upsample(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays,
-                                                 int k, int n_new, float inv_s, float* __restrict__ z_new,
-                                                 int64_t* __restrict__ inds_out) {
-    extern __shared__ float lds[];   // zs[64][k+1], cs[64][k+1]
+// Thread per ray with only the weight / cdf row of every ray resident in LDS: the depth and sdf rows pass through an 8-column
+// staging tile (read from global memory with consecutive lanes on consecutive 32-byte row segments, the next tile requested
+// before the current one is consumed), and the two depths pass 3 needs per new sample come from global memory again (L2).
+// 64 x (k + 1) + 2 x 64 x 9 floats per wave instead of 2 x 64 x (k + 1): 7 waves per CU instead of 4 at k = 64 -- the kernel is
+// a chain of ~9 000 dependent VALU instructions per wave (four IEEE divisions and two expf per section) and is bound by how
+// many such chains a SIMD can interleave.  Same operations in the same order as the kernels above: identical results.
+__global__ __launch_bounds__(64) void k_upsample_tiled(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays, int k,
+                                                       int n_new, float inv_s, float* __restrict__ z_new, int64_t* __restrict__ inds_out) {
+    extern __shared__ float lds[];   // cs[64][k+1] | zc[64][9] | sc[64][9]
     const int lane = threadIdx.x;
     const int pitch = k + 1;
-    float* zs = lds;
-    float* cs = lds + 64 * pitch;
+    float* cs = lds;
+    float* zc = lds + 64 * pitch;
+    float* sc = zc + 64 * 9;
     const int ray0 = blockIdx.x * 64;
     const int nvalid = n_rays - ray0 < 64 ? n_rays - ray0 : 64;
-    {
-        const size_t base = (size_t)ray0 * k;
-        const int total = nvalid * k;
-        int r = 0, c = lane;
-        for (int idx = lane; idx < total; idx += 64) {
-            while (c >= k) {
-                c -= k;
-                ++r;
+    const int ray = ray0 + lane;
+    const bool mine = lane < nvalid;
+    float* cr = cs + lane * pitch;
+    float za[8], sa[8], zb[8], sb[8];
+    auto fetch = [&](int c0, float(&zt)[8], float(&stt)[8]) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = lane + 64 * it, row = idx >> 3, col = c0 + (idx & 7);
+            const bool ok = row < nvalid && col < k;
+            const size_t g = (size_t)(ray0 + (ok ? row : 0)) * k + (ok ? col : 0);
+            zt[it] = z[g];
+            stt[it] = sdf[g];
+        }
+    };
+    auto put = [&](const float(&zt)[8], const float(&stt)[8]) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = lane + 64 * it;
+            zc[(idx >> 3) * 9 + (idx & 7)] = zt[it];
+            sc[(idx >> 3) * 9 + (idx & 7)] = stt[it];
+        }
+    };
+    UpsState st;
+    fetch(0, za, sa);
+    for (int c0 = 0; c0 < k; c0 += 8) {
+        put(za, sa);
+        __builtin_amdgcn_wave_barrier();   // (one wave per block: LDS operations complete in order)
+        if (c0 + 8 < k) fetch(c0 + 8, zb, sb);
+        if (mine) {
+            float zv[8], sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                zv[u] = zc[lane * 9 + u];
+                sv[u] = sc[lane * 9 + u];
             }
-            zs[r * pitch + c] = z[base + idx];
-            cs[r * pitch + c] = sdf[base + idx];
-            c += 64;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int col = c0 + u;
+                if (col == 0) {
+                    st.z0 = zv[u];
+                    st.s0 = sv[u];
+                } else if (col < k) {
+                    cr[col] = st.step(zv[u], sv[u], inv_s);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            za[u] = zb[u];
+            sa[u] = sb[u];
         }
     }
-    __syncthreads();
-    if (lane >= nvalid) return;
-    const int ray = ray0 + lane;
-    const float* zr = zs + lane * pitch;
-    float* cr = cs + lane * pitch;
-    // pass 1: section weights, sequential transmittance (torch.cumprod order)
-    float prev_cos = 0.f, T = 1.f, sum = 0.f;
-    float z0 = zr[0], s0 = cr[0];
-    for (int i = 0; i + 1 < k; ++i) {
-        const float z1 = zr[i + 1], s1 = cr[i + 1];
-        const float mid_sdf = (s0 + s1) * 0.5f;
-        const float cosv = (s1 - s0) / (z1 - z0 + 1e-5f);
-        float c = fminf(prev_cos, cosv);
-        c = fminf(fmaxf(c, -1e3f), 0.f);
-        prev_cos = cosv;
-        const float dist = z1 - z0;
-        const float prev_cdf = sigmoid_acc((mid_sdf - c * dist * 0.5f) * inv_s);
-        const float next_cdf = sigmoid_acc((mid_sdf + c * dist * 0.5f) * inv_s);
-        const float alpha = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
-        const float w = alpha * T + 1e-5f;           // weights + 1e-5 (sample_pdf)
-        T = T * (1.f - alpha + 1e-7f);
-        cr[i + 1] = w;                               // s1 is in a register: its slot is free
-        sum += w;
-        z0 = z1;
-        s0 = s1;
-    }
+    if (!mine) return;
+    const float sum = st.sum;
     // pass 2: cdf = [0, cumsum(w / sum)]
     cr[0] = 0.f;
     float run = 0.f;
-    for (int i = 1; i < k; ++i) {
-        run += cr[i] / sum;
-        cr[i] = run;
+    for (int i0 = 1; i0 < k; i0 += UPS_BLK) {
+        float wb[UPS_BLK];
+#pragma unroll
+        for (int u = 0; u < UPS_BLK; ++u) wb[u] = cr[i0 + u < k ? i0 + u : k - 1];
+#pragma unroll
+        for (int u = 0; u < UPS_BLK; ++u)
+            if (i0 + u < k) {
+                run += wb[u] / sum;
+                cr[i0 + u] = run;
+            }
     }
     // pass 3: invert at u = linspace(0.5/n, 1-0.5/n, n)
+    const float* zr = z + (size_t)ray * k;
     const float u_start = 0.f + 0.5f / (float)n_new, u_end = 1.f - 0.5f / (float)n_new;
     const float u_step = n_new > 1 ? (u_end - u_start) / (float)(n_new - 1) : 0.f;   // linspace(steps=1) = [start]
     int ptr = 0;   // number of cdf entries <= u (searchsorted right=True); cdf and u are both non-decreasing
     for (int jj = 0; jj < n_new; ++jj) {
         const float u = (jj < n_new / 2) ? u_start + (float)jj * u_step : u_end - (float)(n_new - 1 - jj) * u_step;
-        while (ptr < k && cr[ptr] <= u) ++ptr;
+        for (;;) {   // four entries per round trip (the cdf is non-decreasing: the entries <= u are a prefix)
+            int adv = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) adv += (ptr + q < k && cr[ptr + q < k ? ptr + q : k - 1] <= u) ? 1 : 0;
+            ptr += adv;
+            if (adv < 4) break;
+        }
         const int below = ptr - 1 > 0 ? ptr - 1 : 0;
         const int above = ptr < k - 1 ? ptr : k - 1;
         const float c_lo = cr[below], c_hi = cr[above];
@@ -367,7 +481,7 @@ __global__ __launch_bounds__(64) void k_upsample(const float* __restrict__ z, co
 // walks ~100 dependent steps of two exps each, ~50 us).  The element-wise part (slopes, the two sigmoids, alpha) is
 // computed by all lanes; the two prefix recurrences stay strictly sequential in lane 0, in the same order and with the
 // same operations as above (torch.cumprod / torch.cumsum order: the sample indices must not change), and the 16
-// inversions run one per lane.  Same results bit for bit as k_upsample / k_upsample_direct.
+// inversions run one per lane.  Same results bit for bit as k_upsample_tiled / k_upsample_direct.
 __global__ __launch_bounds__(256) void k_upsample_wave(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays, int k,
                                                        int n_new, float inv_s, float* __restrict__ z_new,
                                                        int64_t* __restrict__ inds_out) {
@@ -477,57 +591,104 @@ __global__ void k_merge_serial(const float* __restrict__ z, const float* __restr
 // Rows are read and written with consecutive lanes on consecutive addresses; the serial kernel above walks one
 // row per lane (row stride k floats: every access its own cache line) and runs at 4 % of the HBM rate.
 template <int R>   // R = ceil(k / 64): 64-element slices of the old row per lane (a k = 64 row needs one, not four)
-__global__ __launch_bounds__(256) void k_merge(const float* __restrict__ z, const float* __restrict__ z_new,
-                                               const float* __restrict__ sdf, const float* __restrict__ sdf_new, int n_rays,
-                                               int k, int m, int quirk_p, float* __restrict__ z_out,
-                                               float* __restrict__ sdf_out, int64_t* __restrict__ index) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int ray = blockIdx.x * 4 + wave; ray < n_rays; ray += gridDim.x * 4) {
-        const int srow = quirk_p > 0 ? ray % quirk_p : ray;   // SURVEY B-1
+struct MergeRow {
+    float av[R], as[R], bv, bs;
+    __device__ __forceinline__ void load(const float* __restrict__ z, const float* __restrict__ z_new, const float* __restrict__ sdf,
+                                         const float* __restrict__ sdf_new, int ray, int srow, int k, int m, int lane, bool with_sdf) {
         const float* a = z + (size_t)ray * k;
-        const float* b = z_new + (size_t)ray * m;
-        const size_t ob = (size_t)ray * (k + m);
-        float av[R], as[R];
-        int cnt[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int e = r * 64 + lane;
             const bool ok = e < k;
             av[r] = ok ? a[e] : 0.f;
-            as[r] = (ok && sdf_out) ? sdf[(size_t)srow * k + e] : 0.f;
-            cnt[r] = 0;
+            as[r] = (ok && with_sdf) ? sdf[(size_t)srow * k + e] : 0.f;
         }
-        const float bv = lane < m ? b[lane] : 0.f;
-        const float bs = (lane < m && sdf_out) ? sdf_new[(size_t)srow * m + lane] : 0.f;
-        int bcnt = 0;
-        for (int j = 0; j < m; ++j) {
-            const float bj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), j));
-            int le = 0;
+        bv = lane < m ? z_new[(size_t)ray * m + lane] : 0.f;
+        bs = (lane < m && with_sdf) ? sdf_new[(size_t)srow * m + lane] : 0.f;
+    }
+    // Ranks by two binary searches over lane-resident sorted rows (ds_bpermute): cnt_i = #{j: b_j < a_i} (search b, <= 7 steps), and
+    // since b is sorted {j: b_j < a_i} = [0, cnt_i), so #{i: a_i <= b_j} = #{i: cnt_i <= j} (search the non-decreasing cnt, <= 9 steps).
+    // The m-step counting loop this replaces (readlane + 2 compares + ballot per new depth) was the kernel's time: ~130 of ~170
+    // instructions per ray, VALU-issue bound at 0.46 of the HBM peak.
+    __device__ __forceinline__ void rank_to_lds(int k, int m, int lane, float* st_z, float* st_s, int* st_i) const {
+        int cnt[R];
+        const int s_b = 1 << (31 - __builtin_clz(m)), s_a = 1 << (31 - __builtin_clz(k));   // (uniform) largest powers of two <= m, k
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const bool ok = r * 64 + lane < k;
-                cnt[r] += (ok && bj < av[r]) ? 1 : 0;
-                le += __popcll(__ballot(ok && av[r] <= bj));
+        for (int r = 0; r < R; ++r) {
+            int pos = 0;
+            for (int st = s_b; st >= 1; st >>= 1) {
+                const int idx = pos + st;
+                const float v = __shfl(bv, idx - 1, 64);
+                pos = (idx <= m && v < av[r]) ? idx : pos;
             }
-            if (lane == j) bcnt = le;
+            cnt[r] = pos;
+        }
+        int bcnt = 0;
+        for (int st = s_a; st >= 1; st >>= 1) {
+            const int idx = bcnt + st;
+            const int e = idx - 1;
+            int c = __shfl(cnt[0], e & 63, 64);
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                const int cr = __shfl(cnt[r], e & 63, 64);
+                c = (e >> 6) == r ? cr : c;
+            }
+            bcnt = (idx <= k && c <= lane) ? idx : bcnt;
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int e = r * 64 + lane;
             if (e < k) {
                 const int o = e + cnt[r];
-                z_out[ob + o] = av[r];
-                if (sdf_out) sdf_out[ob + o] = as[r];
-                if (index) index[ob + o] = e;
+                st_z[o] = av[r];
+                st_s[o] = as[r];
+                st_i[o] = e;
             }
         }
         if (lane < m) {
             const int o = lane + bcnt;
-            z_out[ob + o] = bv;
-            if (sdf_out) sdf_out[ob + o] = bs;
-            if (index) index[ob + o] = k + lane;
+            st_z[o] = bv;
+            st_s[o] = bs;
+            st_i[o] = k + lane;
         }
+    }
+};
+// Two ADJACENT rays per wave and iteration (four: measured slower): both rows are requested before either is ranked (a wave moves ~2 KB per ray with a
+// dependent load -> rank -> store chain in between), the merged rows are assembled in a wave-private LDS region and
+// written as ONE contiguous block with consecutive lanes on consecutive addresses (scattered by rank, every store instruction
+// touched each cache line of a row and filled part of it).  0.46 -> 0.6 of the HBM peak at k = 64.
+template <int R>
+__global__ __launch_bounds__(256) void k_merge(const float* __restrict__ z, const float* __restrict__ z_new,
+                                               const float* __restrict__ sdf, const float* __restrict__ sdf_new, int n_rays,
+                                               int k, int m, int quirk_p, float* __restrict__ z_out,
+                                               float* __restrict__ sdf_out, int64_t* __restrict__ index) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int stride = gridDim.x * 8;
+    const bool with_sdf = sdf_out != nullptr;
+    constexpr int ROWS2 = 2 * (64 * R + 64);   // 2 rows of k + m <= 64 R + 64 entries
+    __shared__ float st_zs[4][2][ROWS2];   // [wave][z | sdf][..]
+    __shared__ int st_is[4][ROWS2];
+    float *st_z = st_zs[wave][0], *st_s = st_zs[wave][1];
+    int* st_i = st_is[wave];
+    const int w = k + m;
+    for (int ray = blockIdx.x * 8 + 2 * wave; ray < n_rays; ray += stride) {
+        const int ray2 = ray + 1;
+        const bool two = ray2 < n_rays;
+        MergeRow<R> r0, r1;
+        r0.load(z, z_new, sdf, sdf_new, ray, quirk_p > 0 ? ray % quirk_p : ray, k, m, lane, with_sdf);   // (SURVEY B-1: frame 0's sdf row)
+        if (two) r1.load(z, z_new, sdf, sdf_new, ray2, quirk_p > 0 ? ray2 % quirk_p : ray2, k, m, lane, with_sdf);
+        r0.rank_to_lds(k, m, lane, st_z, st_s, st_i);
+        if (two) r1.rank_to_lds(k, m, lane, st_z + w, st_s + w, st_i + w);
+        __builtin_amdgcn_wave_barrier();   // (a wave's LDS operations complete in order; this only pins the compiler's order)
+        const size_t ob = (size_t)ray * w;
+        const int total = two ? 2 * w : w;
+        for (int p = lane; p < total; p += 64) {
+            z_out[ob + p] = st_z[p];
+            if (sdf_out) sdf_out[ob + p] = st_s[p];
+            if (index) index[ob + p] = st_i[p];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -598,7 +759,7 @@ int sample_points(const float* o, const float* d, const float* z, int n_rays, in
     if (n_rays == 0 || n == 0) return HN_OK;
     const bool aligned = ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(pts) | reinterpret_cast<uintptr_t>(dists)) & 15) == 0;
     if (n % 4 == 0 && aligned && (size_t)n_rays * n < (1u << 31))
-        hipLaunchKernelGGL(k_sample_points_v<4>, grid1d((size_t)n_rays * n / 4, 256), dim3(256), 0, s, o, d, z, n_rays, n, mid,
+        hipLaunchKernelGGL(k_sample_points_t, grid1d((size_t)n_rays * n / 4, 256), dim3(256), 0, s, o, d, z, n_rays, n, mid,
                            sample_dist, pts, dists);
     else
         hipLaunchKernelGGL(k_sample_points, grid1d((size_t)n_rays * n, 256), dim3(256), 0, s, o, d, z, n_rays, n, mid,
@@ -626,9 +787,9 @@ int upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, flo
         HN_LAUNCH_CHECK();
         return HN_OK;
     }
-    if (k <= 64) {   // staged: 2 x 64 x (k+1) floats of LDS per wave; beyond 64 columns the occupancy loss outweighs it (measured)
-        hipLaunchKernelGGL(k_upsample, grid1d(n_rays, 64), dim3(64), (size_t)2 * 64 * (k + 1) * sizeof(float), s, z, sdf,
-                           n_rays, k, n_new, inv_s, z_new, inds);
+    if (k <= 224) {   // (64 x (k + 19) floats of LDS per wave: within the 64 KiB a launch gets without an attribute)
+        hipLaunchKernelGGL(k_upsample_tiled, grid1d(n_rays, 64), dim3(64), (size_t)64 * (k + 1 + 18) * sizeof(float), s, z, sdf, n_rays,
+                           k, n_new, inv_s, z_new, inds);
     } else {
         hipLaunchKernelGGL(k_upsample_direct, grid1d(n_rays, 64), dim3(64), (size_t)k * 64 * sizeof(float), s, z, sdf, n_rays,
                            k, n_new, inv_s, z_new, inds);
@@ -642,8 +803,8 @@ int merge(const float* z, const float* z_new, const float* sdf, const float* sdf
     HN_REQUIRE((sdf_out == nullptr) || (sdf != nullptr && sdf_new != nullptr), "merge: sdf inputs missing");
     if (n_rays == 0) return HN_OK;
     if (k <= 256 && m <= 64) {
-        const int blocks = (n_rays + 3) / 4 < 8192 ? (n_rays + 3) / 4 : 8192;
         const int slices = (k + 63) / 64;
+        const int blocks = (n_rays + 7) / 8 < 8192 ? (n_rays + 7) / 8 : 8192;   // 4 waves x 2 adjacent rays per block and iteration
         if (slices <= 1)
             hipLaunchKernelGGL(k_merge<1>, dim3(blocks), dim3(256), 0, s, z, z_new, sdf, sdf_new, n_rays, k, m, quirk_p, z_out, sdf_out, index);
         else if (slices == 2)

@@ -191,6 +191,37 @@ def test_upsample_merge_sort_golden(L, golden):
     assert np.array_equal(out.cpu().numpy(), torch.sort(v, dim=-1)[0].numpy())
 
 
+def test_merge_and_upsample_row_shapes(L):
+    """cat_z_vals against torch's stable sort over row lengths that take every slice count of the merge kernel (ties between
+    old and new depths included, odd ray counts: the kernel takes rays in pairs), and up_sample's thread-per-ray kernels
+    (tiled: k <= 224, direct beyond) against the wave-per-ray kernel on the same rows, bit for bit."""
+    lib = L.load()
+    gen = torch.Generator().manual_seed(5)
+    for k, m, B in ((5, 1, 7), (64, 16, 33), (80, 16, 101), (130, 64, 9), (256, 64, 5), (200, 3, 8193)):
+        z = torch.sort(torch.rand(B, k, generator=gen), -1)[0]
+        zn = torch.sort(torch.rand(B, m, generator=gen), -1)[0]
+        zn[:, 0] = z[:, min(3, k - 1)]                                # a tie: the old depth goes first
+        zn = torch.sort(zn, -1)[0]
+        s_, sn = torch.randn(B, k, generator=gen), torch.randn(B, m, generator=gen)
+        z2, s2 = torch.empty(B, k + m, device='cuda'), torch.empty(B, k + m, device='cuda')
+        idx = torch.empty(B, k + m, device='cuda', dtype=torch.int64)
+        L.check(lib.hn_merge(L.ptr(cu(z)), L.ptr(cu(zn)), L.ptr(cu(s_)), L.ptr(cu(sn)), B, k, m, 0, L.ptr(z2), L.ptr(s2), L.ptr(idx), st()), 'merge')
+        ref_z, ref_i = torch.sort(torch.cat([z, zn], -1), dim=-1, stable=True)
+        assert torch.equal(idx.cpu(), ref_i), (k, m, B)
+        assert torch.equal(z2.cpu(), ref_z) and torch.equal(s2.cpu(), torch.gather(torch.cat([s_, sn], -1), 1, ref_i)), (k, m, B)
+    for k in (6, 100, 224, 240):
+        B = 64
+        z = cu(torch.sort(torch.rand(B, k, generator=gen) * 1.1 + 0.4, -1)[0])
+        sdf = cu(torch.rand(B, k, generator=gen) - 0.5)
+        zs, ins = torch.empty(B, 16, device='cuda'), torch.empty(B, 16, device='cuda', dtype=torch.int64)
+        L.check(lib.hn_upsample(L.ptr(z), L.ptr(sdf), B, k, 16, 64.0, L.ptr(zs), L.ptr(ins), st()), 'upsample')     # wave per ray
+        rep = 130                                                        # 8 320 rays: thread per ray
+        zt, st_ = z.repeat(rep, 1).contiguous(), sdf.repeat(rep, 1).contiguous()
+        zb, ib = torch.empty(rep * B, 16, device='cuda'), torch.empty(rep * B, 16, device='cuda', dtype=torch.int64)
+        L.check(lib.hn_upsample(L.ptr(zt), L.ptr(st_), rep * B, k, 16, 64.0, L.ptr(zb), L.ptr(ib), st()), 'upsample')
+        assert torch.equal(ib, ins.repeat(rep, 1)) and torch.equal(zb, zs.repeat(rep, 1)), k
+
+
 def test_merge_batch_quirk(L):
     from oracle import render as orr
     lib = L.load()
