@@ -340,15 +340,20 @@ class HaloPoseChain:
             return {'bt_inv': bt_inv, 'T_pose_21': self.T_pose_21, 'joint_3d': joint_3d, 'joint3d_pred': self.joints0, 'obj_r': obj_r, 'obj_t': obj_t,
                     'Ro_pred': self.Ro_pred, 'To_pred': self.To_pred, 'obj_verts': self.obj_verts}
         idx = slice(None) if index is None else _index_tensor(self, index, self.joints0.device)
-        bt_inv, joint_3d = self._hand(idx)
         if self.joints0.is_cuda:
-            from .pose import RigidPoseFn
-            F_ = self.joints0[idx].shape[0]
-            params = torch.cat([self.obj_rot[idx].reshape(F_, 6), self.obj_trans[idx], torch.zeros(F_, 9, device=self.joints0.device)], dim=1)
-            out = RigidPoseFn.apply(params, None, None, self.Ro_pred[idx].contiguous(), self.To_pred[idx].contiguous(), False)
-            return {'bt_inv': bt_inv, 'T_pose_21': self.T_pose_21[idx], 'joint_3d': joint_3d, 'joint3d_pred': self.joints0[idx],
-                    'obj_r': out[:, 399:408].reshape(F_, 3, 3), 'obj_t': out[:, 408:411], 'Ro_pred': self.Ro_pred[idx], 'To_pred': self.To_pred[idx],
-                    'obj_verts': self.obj_verts}
+            # a window of frames (fitting_video): the same single node on the window's rows of the leaves; the window's constants
+            # are gathered once per index set
+            from .pose import HaloChainFn
+            key = tuple(int(i) for i in index)
+            cache = self.__dict__.setdefault('_window_consts', {})
+            if key not in cache:
+                cache[key] = tuple(x[idx].contiguous() for x in (self.joints0, self.bone_len, self.Ro_pred, self.To_pred, self.T_pose_21))
+            j0, bl, Rp, Tp, T21 = cache[key]
+            bt_inv, joint_3d, obj_r, obj_t = HaloChainFn.apply(self.obj_rot, self.obj_trans, self.palm_rot, self.palm_trans, self.joint_refine_angle,
+                                                               self.palm_refine_angle, j0, bl, Rp, Tp, idx)
+            return {'bt_inv': bt_inv, 'T_pose_21': T21, 'joint_3d': joint_3d, 'joint3d_pred': j0, 'obj_r': obj_r, 'obj_t': obj_t,
+                    'Ro_pred': Rp, 'To_pred': Tp, 'obj_verts': self.obj_verts}
+        bt_inv, joint_3d = self._hand(idx)
         obj_r = rot6d_to_matrix(self.obj_rot[idx]) @ self.Ro_pred[idx]
         obj_t = self.To_pred[idx] + self.obj_trans[idx]
         pred_v = (obj_r.unsqueeze(1) @ self.obj_verts[None, :, :, None])[..., 0] + obj_t.unsqueeze(1)

@@ -167,13 +167,20 @@ class HaloChainFn(torch.autograd.Function):
     forward and ~25 backward (every slice's backward is a zero fill and a copy)."""
 
     @staticmethod
-    def forward(ctx, obj_rot, obj_trans, palm_rot, palm_trans, joint_angle, palm_angle, ori_pose, bone_len, Ro_pred, To_pred):
+    def forward(ctx, obj_rot, obj_trans, palm_rot, palm_trans, joint_angle, palm_angle, ori_pose, bone_len, Ro_pred, To_pred, rows=None):
+        """rows (int64 [F] or None): the leaves hold n >= F frames and the chain runs on these rows of them (a fitting_video
+        window; ori_pose .. To_pred are already the window's): one gather forward, one scatter backward, instead of an advanced
+        index per leaf whose backward is a sort-based index_put each."""
         L = _lib
         lib = L.load()
         F, dev = ori_pose.shape[0], ori_pose.device
         st = L.stream_ptr()
-        prm = torch.cat([joint_angle.reshape(F, 20), palm_angle.reshape(F, 7), palm_rot.reshape(F, 6), palm_trans.reshape(F, 3),
-                         obj_rot.reshape(F, 6), obj_trans.reshape(F, 3), _zeros9(F, dev)], dim=1)    # [F, 45 + 9]: one launch
+        n = obj_rot.shape[0]
+        prm = torch.cat([joint_angle.reshape(n, 20), palm_angle.reshape(n, 7), palm_rot.reshape(n, 6), palm_trans.reshape(n, 3),
+                         obj_rot.reshape(n, 6), obj_trans.reshape(n, 3), _zeros9(n, dev)], dim=1)    # [n, 45 + 9]: one launch
+        if rows is not None:
+            prm = prm.index_select(0, rows)
+        ctx.rows, ctx.n = rows, n
         prm_h = prm[:, :36].contiguous() if F > 1 else prm[:, :36]
         prm_o = prm[:, 36:54].contiguous() if F > 1 else prm[:, 36:54]                               # hn_rigid_pose's 18 inputs: 9 used here
         need = any(x.requires_grad for x in (obj_rot, obj_trans, palm_rot, palm_trans, joint_angle, palm_angle))
@@ -218,6 +225,10 @@ class HaloChainFn(torch.autograd.Function):
             g[:, :36] = tmp_h
             g[:, 36:45] = tmp[:, :9]
         sh = ctx.shapes
+        if ctx.rows is not None:     # the window's rows of the [n, 45] gradient block, zero elsewhere
+            full = torch.zeros(ctx.n, 45, device=dev, dtype=torch.float32)
+            full.index_copy_(0, ctx.rows, g)
+            gh, go = full[:, :36], full[:, 36:45]
         # views of one block (for F = 1 every slice is contiguous: autograd keeps them as the leaves' .grad without a copy)
         return (go[:, 0:6].reshape(sh[0]), go[:, 6:9].reshape(sh[1]), gh[:, 27:33].reshape(sh[2]), gh[:, 33:36].reshape(sh[3]),
-                gh[:, 0:20].reshape(sh[4]), gh[:, 20:27].reshape(sh[5]), None, None, None, None)
+                gh[:, 0:20].reshape(sh[4]), gh[:, 20:27].reshape(sh[5]), None, None, None, None, None)

@@ -181,27 +181,48 @@ def test_pose_adam_is_torch_adam():
 
 @pytest.mark.gpu
 def test_halo_chain_single_node_matches_the_separate_ops():
-    """HaloPoseChain() with no index (fitting_single) is one autograd node (pose.HaloChainFn); with an index it is PoseChainFn +
-    RigidPoseFn joined by cat / slice operators (the frame-batched loop): same values, same gradients of all six leaves."""
+    """HaloPoseChain on the device is one autograd node (pose.HaloChainFn) -- over all frames without an index (fitting_single),
+    over the window's rows of the leaves with one (fitting_video).  Both against the same chain written as separate nodes
+    (PoseChainFn + RigidPoseFn joined by advanced indexing / cat / slice operators): same values, same gradients of all six
+    leaves, zero gradient rows outside the window."""
     import bench
+    from honerf_amd.pose import RigidPoseFn
     dev = torch.device('cuda')
-    rng = np.random.RandomState(2)
-    res = []
-    for use_index in (False, True):
-        chain, j, verts = bench.build_fit_data(dev, 40, 1, halo=True)
+    n, window = 6, [1, 2, 3, 4]
+    ups = [torch.tensor(np.random.RandomState(5 + i).standard_normal(s), dtype=torch.float32, device=dev)
+           for i, s in enumerate(((n, 21, 4, 4), (n, 21, 3), (n, 3, 3), (n, 3)))]
+
+    def problem():
+        chain, j, verts = bench.build_fit_data(dev, 40, n, halo=True, drift=0.003)
         with torch.no_grad():
             r2 = np.random.RandomState(11)
             for p in chain.parameters():
                 p.add_(torch.tensor(r2.standard_normal(tuple(p.shape)) * 0.02, dtype=torch.float32, device=dev))
-        pose = chain([0]) if use_index else chain()
-        gb, gj, gr, gt = (torch.tensor(np.random.RandomState(5 + i).standard_normal(s), dtype=torch.float32, device=dev)
-                          for i, s in enumerate(((1, 21, 4, 4), (1, 21, 3), (1, 3, 3), (1, 3))))
-        loss = (pose['bt_inv'] * gb).sum() + (pose['joint_3d'] * gj).sum() + (pose['obj_r'] * gr).sum() + (pose['obj_t'] * gt).sum()
-        grads = torch.autograd.grad(loss, chain.parameters())
-        res.append(([pose[k].detach().cpu().numpy() for k in ('bt_inv', 'joint_3d', 'obj_r', 'obj_t')], [g.cpu().numpy() for g in grads]))
-    for x, y in zip(res[0][0], res[1][0]):
-        assert np.array_equal(x, y)
-    for name, x, y in zip(('obj_rot', 'obj_trans', 'palm_rot', 'palm_trans', 'joint_refine_angle', 'palm_refine_angle'), res[0][1], res[1][1]):
-        e = rel(x, y.astype(np.float64))
-        record('HaloChainFn vs separate ops: d/d ' + name, e, 1e-6)
-        assert e <= 1e-6, (name, e)
+        return chain
+
+    def separate(chain, rows):
+        idx = torch.tensor(rows, device=dev)
+        bt_inv, joint_3d = chain._hand(idx)
+        F_ = len(rows)
+        params = torch.cat([chain.obj_rot[idx].reshape(F_, 6), chain.obj_trans[idx], torch.zeros(F_, 9, device=dev)], dim=1)
+        out = RigidPoseFn.apply(params, None, None, chain.Ro_pred[idx].contiguous(), chain.To_pred[idx].contiguous(), False)
+        return {'bt_inv': bt_inv, 'joint_3d': joint_3d, 'obj_r': out[:, 399:408].reshape(F_, 3, 3), 'obj_t': out[:, 408:411]}
+
+    keys = ('bt_inv', 'joint_3d', 'obj_r', 'obj_t')
+    names = ('obj_rot', 'obj_trans', 'palm_rot', 'palm_trans', 'joint_refine_angle', 'palm_refine_angle')
+    for rows, call in ((list(range(n)), lambda c: c()), (window, lambda c: c(window))):
+        res = []
+        for node in (True, False):
+            chain = problem()
+            pose = call(chain) if node else separate(chain, rows)
+            loss = sum((pose[k] * u[rows]).sum() for k, u in zip(keys, ups))
+            grads = torch.autograd.grad(loss, chain.parameters())
+            res.append(([pose[k].detach().cpu().numpy() for k in keys], [g.cpu().numpy() for g in grads]))
+        for x, y in zip(res[0][0], res[1][0]):
+            assert np.array_equal(x, y)
+        outside = [i for i in range(n) if i not in rows]
+        for name, x, y in zip(names, res[0][1], res[1][1]):
+            e = rel(x, y.astype(np.float64))
+            record('HaloChainFn (%d of %d frames) vs separate ops: d/d %s' % (len(rows), n, name), e, 1e-6)
+            assert e <= 1e-6, (name, e)
+            assert not outside or float(np.abs(x[outside]).max()) == 0.0, name

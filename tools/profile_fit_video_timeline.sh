@@ -13,6 +13,7 @@ find /tmp/pfv_stats_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} 
 T=$(find /tmp/pfv_stats_$TAG -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/trace_gaps.py $T 12 4 > $OUT/busy_idle.txt 2>&1
 python3 $R/tools/trace_timeline.py $T 8 15 > $OUT/timeline.txt 2>&1
+python3 $R/tools/trace_timeline.py $T 8 0 > $OUT/timeline_all.txt 2>&1
 cd $R
 tail -1 $OUT/unprofiled.log
 head -16 $OUT/busy_idle.txt
