@@ -373,7 +373,7 @@ def bone_lengths_of(joints_mano):
 
 
 # ---- one optimisation step --------------------------------------------------------------------------------------------
-def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, smooth_ends=(False, False), stable=None):
+def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, smooth_ends=(False, False), stable=None, pose_terms=None):
     """The full loss of one step: fitting_single.py:251-283 (video=False) or fitting_video.py:285-334 (video=True:
     + smoothness over the window's frames x50, anchored to the prediction at the sequence ends; + 100 x the stable
     term for fit type '1234').  `pose` is the pose chain's output dict."""
@@ -387,6 +387,21 @@ def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, 
                                        true_mask, pose['joint3d_pred'], pose['Ro_pred'], pose['To_pred'], pose['obj_verts'], weights)
         return {'loss': loss, 'color': tv[1], 'mask': tv[2], 'contact': tv[3], 'penetration': tv[4], 'joint': tv[5], 'obj_verts': tv[6]}
     terms = render_loss_terms(render_out, true_rgb, true_mask, fit_type, video)
+    pt = pose_terms if pose_terms is not None else pose_loss_terms(pose, fit_type, video, smooth_ends)
+    terms['joint'], terms['obj_verts'] = pt['joint'], pt['obj_verts']
+    terms['loss'] = terms['loss'] + pt['sum']
+    if video:
+        terms['smooth'] = pt['smooth']
+        if stable is not None:
+            terms['stable'] = 100.0 * stable
+            terms['loss'] = terms['loss'] + terms['stable']
+    return terms
+
+
+def pose_loss_terms(pose, fit_type='1', video=False, smooth_ends=(False, False)):
+    """The terms of a step's loss that depend on the pose chain alone (fitting_single.py:206-235, 283; fitting_video.py:310-334):
+    the joint and object-vertex regularisers and, for a window, the smoothness term x50.  Returns them with 'sum' = their
+    weighted sum as it enters the loss.  Independent of the render: the device loops evaluate them beside it (fit_backward)."""
     fused = 'obj_verts' in pose        # the chains' device form: vertex losses from the poses (VertsLossFn), no vertex sets
     if fused:
         from .pose import VertsLossFn
@@ -399,8 +414,7 @@ def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, 
         joint_loss = pose['joint_loss'].mean() if 'joint_loss' in pose else pose_loss(pose['joint_3d'], pose['joint3d_pred'], mean=True)
         verts_loss = v_pred.mean() if fused else pose_loss(pose['pred_obj_v_w'], pose['compare_obj_v_w'], mean=True)
         w = (30.0, 20.0)
-    terms['joint'], terms['obj_verts'] = joint_loss, verts_loss
-    terms['loss'] = terms['loss'] + w[0] * joint_loss + w[1] * verts_loss
+    out = {'joint': joint_loss, 'obj_verts': verts_loss, 'sum': w[0] * joint_loss + w[1] * verts_loss}
     if video:
         j = pose['joint_3d']
         if fused:
@@ -417,12 +431,9 @@ def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, 
                 smooth = smooth + pose_loss(j[:1], pose['joint3d_pred'][:1], mean=True) + pose_loss(v[:1], pose['compare_obj_v_w'][:1], mean=True)
             elif smooth_ends[1]:
                 smooth = smooth + pose_loss(j[-1:], pose['joint3d_pred'][-1:], mean=True) + pose_loss(v[-1:], pose['compare_obj_v_w'][-1:], mean=True)
-        terms['smooth'] = 50.0 * smooth
-        terms['loss'] = terms['loss'] + terms['smooth']
-        if stable is not None:
-            terms['stable'] = 100.0 * stable
-            terms['loss'] = terms['loss'] + terms['stable']
-    return terms
+        out['smooth'] = 50.0 * smooth
+        out['sum'] = out['sum'] + out['smooth']
+    return out
 
 
 def _rays(lib_mod, xy, cam, n_cams, rays_per_cam):
@@ -433,6 +444,17 @@ def _rays(lib_mod, xy, cam, n_cams, rays_per_cam):
                                  lib_mod.ptr(cam['principal']), n_cams, rays_per_cam, lib_mod.ptr(o), lib_mod.ptr(d),
                                  lib_mod.stream_ptr()), 'hn_ray_gen')
     return o, d
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One extra torch stream per device for branches of a step that are independent of the render."""
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
 
 
 def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None, smooth_ends=(False, False),
@@ -457,6 +479,24 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
     else:
         rays_o, rays_d = rays_fn(view['xy'], view['cam'], n_cams, P)
     T_pose = pose['T_pose_21']
+    stable, pterms, side = None, None, None
+    want_stable = video and fit_type == '1234'
+    if video and rays_o.is_cuda and rays_fn is None:
+        # What depends on the pose only -- the stable term (hand SDF on the object's vertices, ~50 small launches forward and ~70
+        # backward) and the pose regularisers / smoothness (~40 + ~60) -- runs on a second stream beside the render; autograd runs
+        # the backward passes on that stream too, beside the render's.  They join the loss below.
+        main = torch.cuda.current_stream()
+        side = _side_stream(rays_o.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if want_stable:
+                stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
+            pterms = pose_loss_terms(pose, fit_type, True, smooth_ends)
+        for x in pose.values():
+            if isinstance(x, torch.Tensor) and x.is_cuda:
+                x.record_stream(side)
+    elif want_stable:
+        stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
     if video:
         Ro_arg = torch.inverse(pose['obj_r'])                                          # fitting_video.py:284
         out = renderer.render(rays_o.reshape(n_cams, P, 3), rays_d.reshape(n_cams, P, 3), near, far, pose['bt_inv'], T_pose, None,
@@ -467,10 +507,12 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
         first = lambda x: x.reshape(x.shape[1:]) if one else x[0]
         Ro_arg = first(pose['obj_r']).T                                                # fitting_single.py:250
         out = renderer.render(rays_o, rays_d, near, far, first(pose['bt_inv']), first(T_pose), None, Ro_arg, first(pose['obj_t']), t_rand=t_rand)
-    stable = None
-    if video and fit_type == '1234':
-        stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
-    terms = step_loss(out, view['true_rgb'], view['true_mask'], pose, fit_type, video, smooth_ends, stable)
+    if side is not None:
+        main = torch.cuda.current_stream()
+        main.wait_stream(side)
+        for x in ([stable] if stable is not None else []) + list(pterms.values()):
+            x.record_stream(main)
+    terms = step_loss(out, view['true_rgb'], view['true_mask'], pose, fit_type, video, smooth_ends, stable, pterms)
     terms['loss'].backward()
     return terms
 

@@ -58,7 +58,10 @@ class NeuSRenderer_fitting(_Unbatched):
         tp = g(T_pose_21).reshape(-1, 21, 3)
         pts_world = (Ro.unsqueeze(1) @ pts.unsqueeze(-1))[..., 0] + To.unsqueeze(1)
         hand = self.fields()[0]
-        sdf = HandSdfFn.apply(pts_world.contiguous(), bt, tp, hand, self._ws_bwd)             # [F,V]
+        if not hasattr(self, '_ws_stable'):
+            from .renderer import _Workspace
+            self._ws_stable = _Workspace()       # its own workspace: this term may run on a second stream beside the render
+        sdf = HandSdfFn.apply(pts_world.contiguous(), bt, tp, hand, self._ws_stable)          # [F,V]
         with torch.no_grad():
             inside = sdf < 0                                                                    # in_id_list
             pen = inside.any(dim=1)                                                             # frames that penetrate
