@@ -401,7 +401,7 @@ def main():
     ap.add_argument('--no-c1', action='store_true', help='skip the C1 (128x128x32 obj) measurement')
     ap.add_argument('--no-fitting', action='store_true', help='skip the fitting-loop measurements')
     ap.add_argument('--no-training', action='store_true', help='skip the training-iteration measurement')
-    ap.add_argument('--fit-steps', type=int, default=10)
+    ap.add_argument('--fit-steps', type=int, default=80, help='timed steps per fitting leg (after 10 untimed ones)')
     ap.add_argument('--fit-outer', type=int, default=5, help='passes over the video sequence (fitting_video.py:157: 5)')
     args = ap.parse_args()
 
@@ -507,6 +507,21 @@ def main():
         torch.cuda.synchronize()
         culled = samples_per_step * args.steps / (time.perf_counter() - tc)
         field.set_culling(False)
+    # ---- secondary figure: the same step with the exact sample-level far-field skip (hn_field_set_compaction: the field runs on
+    #      the compacted list of the samples that have a live bone mask; bit-identical output).  Never the headline.
+    compact = None
+    if args.precision == 'f16x3' and not args.no_culled:
+        field.set_compaction(True)
+        step()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(step()['color_fine'], out['color_fine']))
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        compact = {'value': samples_per_step * args.steps / (time.perf_counter() - tc), 'bit_identical_to_dense': same}
+        field.set_compaction(False)
     # ---- secondary figure (BASELINE configs[1] names "bf16"): the same step with precision = 'f16' -- hidden SDF layers and
     #      reverse sweep on ONE f16 MFMA per product (HN_PREC_F16) -- with its measured difference from the headline frame
     f16 = None
@@ -537,7 +552,7 @@ def main():
     traffic, traffic_src = pmc_traffic(kname)
     fitting = None
     if not args.no_fitting and args.precision == 'f16x3':
-        fitting, single = time_fit(dev, dist, rank, world, args.precision, args.fit_steps, 3, args.fit_outer)
+        fitting, single = time_fit(dev, dist, rank, world, args.precision, args.fit_steps, 10, args.fit_outer)
         sec = fitting['single_12']['ms_per_step'] * 1e-3
         flop = fit_step_flop(FIT_RAYS)
         fitting['roofline'] = {'bound': 'mfma', 'what': 'one fitting_single step (fit type 12), all kernels', 'flop_per_step': flop,
@@ -586,6 +601,9 @@ def main():
             res['f16_mode'] = f16
         if culled is not None:
             res['value_culled'] = culled   # rank 0's frame, far-field early-out on (bit-identical output)
+        if compact is not None:
+            res['value_compact'] = compact['value']   # rank 0's frame, sample-level far-field skip on (bit-identical output)
+            res['compact_bit_identical_to_dense'] = compact['bit_identical_to_dense']
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(sdf, col, sc, args.cpu_crop)
         print(json.dumps(res))

@@ -238,42 +238,37 @@ void set_launch_orig_idx(const int* p) { g_launch_orig_idx = p; }
 // dead only if 200 (v_b - cutoff_b) > 20 for every bone, where the kernel's own sigmoid has been exactly 1 since ~16.7.
 __constant__ float c_cutoff_api[21] = {0.08f, 0.03f, 0.03f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f,
                                        0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f};
-// Order-preserving compaction in two launches of COMPACT_SPB-sample blocks (the compact list keeps the dense order, so the
+// Order-preserving compaction in two launches (classify + count per 256 samples; slots per COMPACT_SPB-sample block): the compact list keeps the dense order, so the
 // samples of one frame stay together and a wave's 32 samples share their pose except at the frame boundaries).
 // idx[k]: dense index of compact slot k; pos[i]: compact slot of sample i or -1.
 constexpr int COMPACT_SPB = 2048;
-// pass 1: pos[i] = 1 (live) / 0, counts[block] = live samples of the block
+// pass 1 (one sample per thread): pos[i] = 1 (live) / 0, counts[b] = live samples of the 256-sample block b
 __global__ __launch_bounds__(256) void k_hand_live_count(const float* __restrict__ pts, int n, const float* __restrict__ bt_inv,
                                                          const float* __restrict__ T_pose, int n_frames, int pts_per_frame,
                                                          int* __restrict__ pos, int* __restrict__ counts) {
-    __shared__ int total;
-    if (threadIdx.x == 0) total = 0;
-    __syncthreads();
-    int mine = 0;
-    for (int it = 0; it < COMPACT_SPB / 256; ++it) {
-        const int i = blockIdx.x * COMPACT_SPB + it * 256 + threadIdx.x;
-        bool live = false;
-        if (i < n) {
-            const float p0 = pts[3 * (size_t)i], p1 = pts[3 * (size_t)i + 1], p2 = pts[3 * (size_t)i + 2];
-            int frame = i / pts_per_frame;
-            frame = frame < n_frames ? frame : n_frames - 1;
-            const float* M = bt_inv + (size_t)frame * 21 * 16;
-            const float* T = T_pose + (size_t)frame * 21 * 3;
-            for (int b = 0; b < 21; ++b) {
-                const float* m = M + 16 * b;
-                const float q0 = m[0] * p0 + m[1] * p1 + m[2] * p2 + m[3] - T[3 * b];
-                const float q1 = m[4] * p0 + m[5] * p1 + m[6] * p2 + m[7] - T[3 * b + 1];
-                const float q2 = m[8] * p0 + m[9] * p1 + m[10] * p2 + m[11] - T[3 * b + 2];
-                const float v = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
-                live = live || !(200.f * (v - c_cutoff_api[b]) > 20.f);   // (a NaN coordinate counts as live)
-            }
-            pos[i] = live ? 1 : 0;
+    __shared__ int wave_cnt[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool live = false;
+    if (i < n) {
+        const float p0 = pts[3 * (size_t)i], p1 = pts[3 * (size_t)i + 1], p2 = pts[3 * (size_t)i + 2];
+        int frame = i / pts_per_frame;
+        frame = frame < n_frames ? frame : n_frames - 1;
+        const float* M = bt_inv + (size_t)frame * 21 * 16;
+        const float* T = T_pose + (size_t)frame * 21 * 3;
+        for (int b = 0; b < 21; ++b) {
+            const float* m = M + 16 * b;
+            const float q0 = m[0] * p0 + m[1] * p1 + m[2] * p2 + m[3] - T[3 * b];
+            const float q1 = m[4] * p0 + m[5] * p1 + m[6] * p2 + m[7] - T[3 * b + 1];
+            const float q2 = m[8] * p0 + m[9] * p1 + m[10] * p2 + m[11] - T[3 * b + 2];
+            const float v = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+            live = live || !(200.f * (v - c_cutoff_api[b]) > 20.f);   // (a NaN coordinate counts as live)
         }
-        mine += __popcll(__ballot(live));
+        pos[i] = live ? 1 : 0;
     }
-    if ((threadIdx.x & 63) == 0) atomicAdd(&total, mine);
+    const int c = __popcll(__ballot(live));
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+    if (threadIdx.x == 0) counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 // pass 2: slots in dense order; the last block appends the far sample behind the M live ones and writes n_dev = M + 1, the
 // sample count the field kernels read
@@ -283,8 +278,8 @@ __global__ __launch_bounds__(256) void k_hand_compact_write(const float* __restr
     __shared__ int red[4];
     __shared__ int wcnt[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int part = 0;
-    for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) part += counts[t];
+    int part = 0;   // live samples in front of this block: the counts of its (COMPACT_SPB / 256) x blockIdx.x preceding 256-sample blocks
+    for (int t = threadIdx.x; t < (int)blockIdx.x * (COMPACT_SPB / 256); t += 256) part += counts[t];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
     if (lane == 0) red[wave] = part;
@@ -379,7 +374,7 @@ static bool hand_compaction(const hn_field* hand, int n_frames, size_t N) {
 struct CompactRec {
     int *n_dev, *counts, *idx, *pos;
     float *pts_c, *grad_c, *rgb_c, *sdf_c;
-    static size_t n_counts(size_t N) { return ((N + COMPACT_SPB - 1) / COMPACT_SPB + 3) & ~size_t(3); }
+    static size_t n_counts(size_t N) { return ((N + 255) / 256 + 3) & ~size_t(3); }
     static size_t bytes(size_t N) { return 16 + (n_counts(N) + 2 * N + 4) * sizeof(int) + (N + 1) * 10 * sizeof(float) + 64; }
     void at(void* base, size_t N) {
         char* p = reinterpret_cast<char*>(base);
@@ -397,7 +392,7 @@ struct CompactRec {
 static int compact_hand(CompactRec& cr, const float* pts, int n, const float* bt_inv, const float* T_pose, int n_frames, int pts_per_frame,
                         hipStream_t s) {
     const int nb = (n + COMPACT_SPB - 1) / COMPACT_SPB;
-    hipLaunchKernelGGL(k_hand_live_count, dim3(nb), dim3(256), 0, s, pts, n, bt_inv, T_pose, n_frames, pts_per_frame, cr.pos, cr.counts);
+    hipLaunchKernelGGL(k_hand_live_count, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, bt_inv, T_pose, n_frames, pts_per_frame, cr.pos, cr.counts);
     hipLaunchKernelGGL(k_hand_compact_write, dim3(nb), dim3(256), 0, s, pts, n, cr.counts, cr.idx, cr.pos, cr.pts_c, cr.n_dev);
     HN_LAUNCH_CHECK();
     return HN_OK;
@@ -529,8 +524,12 @@ static int render_single_impl(const hn_field* f, const float* rays_o, const floa
     float* grad = ar.f(N * 3);
     float* rgb = ar.f(N * 3);
     float* al = ar.f(N);
-    const size_t fws_bytes = field_ws(f, (int)N);
+    // hand field with hn_field_set_compaction: every evaluation runs on the compacted list of the samples with a live bone mask
+    // (+ one far sample), bit-identical results (the two-field renders do the same: see the kernels above)
+    const bool may_compact = f->kind == HN_FIELD_HAND && f->compact_far_field;
+    const size_t fws_bytes = field_ws(f, may_compact ? hand_cap(f, N) : (int)N);
     void* fws = ar.take(fws_bytes);
+    void* crec_ws = may_compact ? ar.take(CompactRec::bytes(N)) : nullptr;
     if (need != nullptr) {
         *need = ar.used;
         return HN_OK;
@@ -542,18 +541,34 @@ static int render_single_impl(const hn_field* f, const float* rays_o, const floa
     if (n_rays == 0) return HN_OK;
     const float sample_dist = (float)((far - near) / (double)n_samples);
     const int hand_ppf = n_rays * S;   // single field: one frame
+    // sdf at n points: dense, or through the compacted list
+    auto sdf_pass = [&](const float* p, int n, float* out) -> int {
+        if (!(may_compact && hand_compaction(f, 1, (size_t)n))) return field_sdf(f, p, n, bt_inv, T_pose, 1, n, out, fws, fws_bytes, s);
+        CompactRec cr;
+        cr.at(crec_ws, (size_t)n);
+        HN_TRY(compact_hand(cr, p, n, bt_inv, T_pose, 1, n, s));
+        set_launch_n_pts_dev(cr.n_dev);
+        set_launch_orig_idx(cr.idx);
+        const int rc = field_sdf(f, cr.pts_c, n + 1, bt_inv, T_pose, 1, n, cr.sdf_c, fws, fws_bytes, s);
+        set_launch_n_pts_dev(nullptr);
+        set_launch_orig_idx(nullptr);
+        HN_TRY(rc);
+        hipLaunchKernelGGL(k_hand_scatter_sdf, dim3((n + 255) / 256), dim3(256), 0, s, cr.pos, n, cr.n_dev, cr.sdf_c, out);
+        HN_LAUNCH_CHECK();
+        return HN_OK;
+    };
     HN_TRY(coarse_z(t_rand, n_rays, n_samples, (float)near, (float)(far - near), sample_dist, t.z_a, s));
     float* z_cur = t.z_a;
     if (n_importance > 0) {
         int k = n_samples;
         HN_TRY(sample_points(rays_o, rays_d, t.z_a, n_rays, k, 0, 0.f, t.pts, nullptr, s));
-        HN_TRY(field_sdf(f, t.pts, n_rays * k, bt_inv, T_pose, 1, n_rays * k, t.sdf_a, fws, fws_bytes, s));
+        HN_TRY(sdf_pass(t.pts, n_rays * k, t.sdf_a));
         float *za = t.z_a, *zb = t.z_b, *sa = t.sdf_a, *sb = t.sdf_b;
         for (int i = 0; i < steps; ++i) {
             HN_TRY(upsample(za, sa, n_rays, k, n_new, (float)(64 << i), t.z_new, nullptr, s));
             if (i + 1 < steps) {
                 HN_TRY(sample_points(rays_o, rays_d, t.z_new, n_rays, n_new, 0, 0.f, t.pts, nullptr, s));
-                HN_TRY(field_sdf(f, t.pts, n_rays * n_new, bt_inv, T_pose, 1, n_rays * n_new, t.sdf_new, fws, fws_bytes, s));
+                HN_TRY(sdf_pass(t.pts, n_rays * n_new, t.sdf_new));
                 HN_TRY(merge(za, t.z_new, sa, t.sdf_new, n_rays, k, n_new, 0, zb, sb, nullptr, s));
             } else {
                 HN_TRY(merge(za, t.z_new, nullptr, nullptr, n_rays, k, n_new, 0, zb, nullptr, nullptr, s));
@@ -565,7 +580,21 @@ static int render_single_impl(const hn_field* f, const float* rays_o, const floa
         z_cur = za;
     }
     HN_TRY(sample_points(rays_o, rays_d, z_cur, n_rays, S, 1, sample_dist, t.pts, dists, s));
-    HN_TRY(field_eval(f, t.pts, rays_d, (int)N, S, bt_inv, T_pose, 1, hand_ppf, sdf, grad, rgb, nullptr, fws, fws_bytes, s));
+    if (may_compact && hand_compaction(f, 1, N)) {
+        CompactRec cr;
+        cr.at(crec_ws, N);
+        HN_TRY(compact_hand(cr, t.pts, (int)N, bt_inv, T_pose, 1, hand_ppf, s));
+        set_launch_n_pts_dev(cr.n_dev);
+        set_launch_orig_idx(cr.idx);
+        const int rc = field_eval(f, cr.pts_c, rays_d, (int)N + 1, S, bt_inv, T_pose, 1, hand_ppf, cr.sdf_c, cr.grad_c, cr.rgb_c, nullptr, fws, fws_bytes, s);
+        set_launch_n_pts_dev(nullptr);
+        set_launch_orig_idx(nullptr);
+        HN_TRY(rc);
+        hipLaunchKernelGGL(k_hand_scatter, dim3(((int)N + 255) / 256), dim3(256), 0, s, cr.pos, (int)N, cr.n_dev, cr.sdf_c, cr.grad_c, cr.rgb_c, sdf, grad, rgb);
+        HN_LAUNCH_CHECK();
+    } else {
+        HN_TRY(field_eval(f, t.pts, rays_d, (int)N, S, bt_inv, T_pose, 1, hand_ppf, sdf, grad, rgb, nullptr, fws, fws_bytes, s));
+    }
     HN_TRY(alpha(sdf, grad, rays_d, dists, (int)N, S, f->inv_s, al, cdf, s));
     HN_CHECK_HIP(hipMemsetAsync(gradient_error, 0, sizeof(float), s));
     HN_TRY(composite1(al, cdf, rgb, grad, n_rays, S, color, nullptr, weight_sum, weight_max, gradient_error, s));

@@ -139,6 +139,9 @@ class NeuSRenderer:
         self.up_sample_steps = up_sample_steps
         self.perturb = perturb
         self.precision = None            # None -> lib.DEFAULT_PRECISION ('f16x3'); 'fp32' selects the exact-fp32 kernels
+        # exact far-field skip of the hand field (hn_field_set_compaction): samples whose 21 bone masks are all exactly 0 are not
+        # evaluated, bit-identical results.  Off here (throughput is quoted dense); the fitting renderers have it on.
+        self.compact_far_field = False
         self._field = None
         self._version = None
         self._ws = _Workspace()
@@ -154,10 +157,13 @@ class NeuSRenderer:
 
     def field(self):
         eval_only = bool(getattr(self, 'pack_eval_only', False))      # set by training.render_train
-        ver = params_version(self.sdf_network, self.color_network, self.deviation_network) + (self.precision, eval_only)
+        compact = bool(getattr(self, 'compact_far_field', False)) and self.model_type == 'hand'
+        ver = params_version(self.sdf_network, self.color_network, self.deviation_network) + (self.precision, eval_only, compact)
         if self._field is None or ver != self._version:
             self._field = PackedField(self.model_type, self.sdf_network, self.color_network, self.deviation_network,
                                       precision=self.precision, eval_only=eval_only)
+            if compact:
+                self._field.set_compaction(True)
             self._version = ver
         return self._field
 

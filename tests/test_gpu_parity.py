@@ -807,6 +807,47 @@ def test_full_size_frame_properties():
         ren.field().set_culling(False)
     for k in whole:
         assert torch.equal(whole[k], culled[k]), 'culled frame differs in %s' % k
+    # sample-level far-field skip (hn_field_set_compaction: the field runs on the compacted list of live samples): the same frame
+    ren.field().set_compaction(True)
+    try:
+        compact = render(0, B)
+    finally:
+        ren.field().set_compaction(False)
+    for k in whole:
+        assert torch.equal(whole[k], compact[k]), 'compacted frame differs in %s' % k
+
+
+def test_single_render_far_field_compaction_with_importance_sampling():
+    """hn_render_single with hn_field_set_compaction and importance sampling: the coarse and fine sdf passes and the final
+    evaluation all run on compacted lists -- depths and every output bit-identical to the dense render."""
+    import bench
+    dev = torch.device('cuda')
+    ren, sdf, col, sc = bench.build_scene(dev, seed=9)
+    ren.n_importance, ren.up_sample_steps = 64, 4
+    from honerf_amd import lib as Lm
+    lib = Lm.load()
+    B = 97 * 53                                                     # 5 141 rays: 329 024 coarse samples, 82 256 per fine round
+    sel = torch.randperm(bench.H_IMG * bench.W_IMG, generator=torch.Generator().manual_seed(1))[:B].to(dev)
+    xy = sc['xy'][sel].contiguous()
+    rays_o, rays_d = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
+    Lm.check(lib.hn_ray_gen(Lm.ptr(xy), Lm.ptr(sc['R']), Lm.ptr(sc['T']), Lm.ptr(sc['focal']), Lm.ptr(sc['principal']),
+                            1, B, Lm.ptr(rays_o), Lm.ptr(rays_d), Lm.stream_ptr()), 'hn_ray_gen')
+    tr = sc['t_rand'][sel].contiguous()
+    res = {}
+    for on in (False, True):
+        ren.field().set_compaction(on)
+        try:
+            o = ren.render(rays_o, rays_d, bench.NEAR, bench.FAR, sc['bt_inv'], sc['T_pose'], None, None, None, 0, t_rand=tr)
+            res[on] = {k: o[k].clone() for k in ('color_fine', 'weight_sum', 'weight_max', 'cdf_fine', 'gradient_error')}
+            res[on]['z'] = ren.last_z_vals.clone() if hasattr(ren, 'last_z_vals') and ren.last_z_vals is not None else torch.zeros(1)
+        finally:
+            ren.field().set_compaction(False)
+    for k in res[False]:
+        if k == 'gradient_error':                                   # (a sum accumulated with float atomics)
+            assert abs(float(res[False][k]) - float(res[True][k])) <= 1e-6 * abs(float(res[False][k]))
+        else:
+            assert torch.equal(res[False][k], res[True][k]), 'compacted render differs in %s' % k
+    assert float(res[False]['weight_sum'].max()) > 0.5              # the rays do hit the hand
 
 
 def test_latency_form_sdf_kernel_is_bit_identical():
