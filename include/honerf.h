@@ -102,13 +102,15 @@ float hn_field_inv_s(const hn_field* f);
  * weight chunks (results are bit-identical to the dense evaluation).  Off by default: throughput figures are
  * quoted dense.  Set it before launching work on the field; no effect on obj fields and on HN_PREC_FP32. */
 int hn_field_set_culling(hn_field* f, int enabled);
-/* Exact far-field skip in the two-field renders (hn_render_dual / hn_render_dual_bwd; hand fields of HN_PREC_F16X3, any
- * number of frames, launches of >= 4096 samples): a sample whose 21 bone masks are all exactly 0 has a constant sdf / colour, a zero gradient and contributes
- * exactly 0 to every adjoint output, so the hand field is evaluated on the compacted list of the other samples plus one far
- * sample and the results are scattered back -- bit-identical outputs, 40 - 60 % fewer samples in a fitting step (one round
- * of sample tiles on the chip instead of two).  Set it before sizing workspaces / tapes with the hn_render_dual_* queries
- * (they grow by the compaction record) and do not change it between a render and its backward pass.  Off by default; the
- * single-field renders and the stand-alone evaluations (and every throughput figure quoted as "dense") never compact. */
+/* Exact sample-level far-field skip of the hand field in the renders (hn_render_single, hn_render_dual / hn_render_dual_bwd; hand
+ * fields of HN_PREC_F16X3, any number of frames, launches of >= 4096 samples): a sample whose 21 bone masks are all exactly
+ * 0 has a constant sdf / colour, a zero gradient and contributes exactly 0 to every adjoint output, so the hand field is
+ * evaluated on the compacted list of the other samples plus one far sample and the results are scattered back --
+ * bit-identical outputs, 40 - 60 % fewer samples in a fitting step (one round of sample tiles on the chip instead of two),
+ * ~5x on a 512 x 512 x 64 hand frame.  Set it before sizing workspaces / tapes with the hn_render_*_workspace_bytes /
+ * _tape_bytes queries (they grow by the compaction record) and do not change it between a render and its backward pass.
+ * Off by default; the stand-alone evaluations (hn_field_sdf / hn_field_eval) and every throughput figure quoted as "dense"
+ * never compact. */
 int hn_field_set_compaction(hn_field* f, int enabled);
 /* Test hook for the XCD pacing of the f16x3 field kernels (image-sized launches: the 32 workgroups of an XCD meet at every
  * tile start, bounded spin): `members` > 0 registers that many members per XCD that never arrive, so that the first
