@@ -353,6 +353,48 @@ __global__ void k_hand_gather_up(const int* __restrict__ idx, int n_max, const i
         gr_c[3 * (size_t)k + c] = far ? 0.f : gr[3 * (size_t)i + c];
     }
 }
+// Training (parameter gradients): upstream gradients of the dense arrays -> compact.  The far sample stands for ALL dead
+// samples: they share its input (all-zero features), so their parameter-gradient contributions are (sum of their upstream
+// d loss / d sdf) x d f(0) / d theta and likewise for the colour -- its upstream values are the SUMS over the dead samples.
+// Their d loss / d gradient multiplies d gradient / d theta = 0 (the encoding's Jacobian is exactly 0 there): left 0.
+__global__ void k_hand_gather_up_sum(const int* __restrict__ idx, const int* __restrict__ pos, int n, const int* __restrict__ n_dev,
+                                     const float* __restrict__ gs, const float* __restrict__ gg, const float* __restrict__ gr,
+                                     float* __restrict__ gs_c, float* __restrict__ gg_c, float* __restrict__ gr_c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = n_dev[0] - 1;
+    // live slots k < M: a straight gather (thread i serves slot i)
+    if (i < M) {
+        const int src = idx[i];
+        gs_c[i] = gs[src];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gg_c[3 * (size_t)i + c] = gg[3 * (size_t)src + c];
+            gr_c[3 * (size_t)i + c] = gr[3 * (size_t)src + c];
+        }
+    }
+    // dead samples: wave-reduced sums into slot M (zeroed by the caller)
+    const bool dead = i < n && pos[i] < 0;
+    float v[4] = {dead ? gs[i] : 0.f, dead ? gr[3 * (size_t)i] : 0.f, dead ? gr[3 * (size_t)i + 1] : 0.f, dead ? gr[3 * (size_t)i + 2] : 0.f};
+    if (__ballot(dead) != 0ull) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_xor(v[c], off, 64);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(gs_c + M, v[0]);
+            atomicAdd(gr_c + 3 * (size_t)M, v[1]);
+            atomicAdd(gr_c + 3 * (size_t)M + 1, v[2]);
+            atomicAdd(gr_c + 3 * (size_t)M + 2, v[3]);
+        }
+    }
+}
+__global__ void k_zero_slot(const int* __restrict__ n_dev, float* __restrict__ gs_c, float* __restrict__ gg_c, float* __restrict__ gr_c) {
+    const int M = n_dev[0] - 1;
+    if (threadIdx.x == 0) gs_c[M] = 0.f;
+    if (threadIdx.x < 3) {
+        gg_c[3 * (size_t)M + threadIdx.x] = 0.f;
+        gr_c[3 * (size_t)M + threadIdx.x] = 0.f;
+    }
+}
 // d loss / d pts of the compact list -> dense (dead samples: exactly 0)
 __global__ void k_hand_scatter3(const int* __restrict__ pos, int n, const float* __restrict__ v_c, float* __restrict__ v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -941,8 +983,21 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
     float *pts = ar.f(N * 3), *dists = ar.f(N), *sdf = ar.f(N), *rgb = ar.f(N * 3), *al = ar.f(N), *c = ar.f(N);
     float *g_al = ar.f(N), *g_c = ar.f(N), *g_rgb = ar.f(N * 3), *gs = ar.f(N), *gg = ar.f(N * 3), *gd = ar.f(R3);
     float *gp = ar.f(N * 3), *gdir = ar.f(R3), *gdd = ar.f(R3), *go = ar.f(R3), *pose_scratch = ar.f(21 * 16 + 21 * 3);
-    const size_t bws_bytes = bwd::field_bwd_workspace_bytes(f, (int)N);
+    const size_t bws_bytes = bwd::field_bwd_workspace_bytes(f, f->kind == HN_FIELD_HAND ? hand_cap(f, N) : (int)N);
     void* bws = ar.take(bws_bytes);
+    // hn_field_set_compaction (hand): the adjoint runs on the live samples + ONE far sample that carries the summed upstream
+    // gradients of all dead ones (k_hand_gather_up_sum)
+    const bool may_compact = f->kind == HN_FIELD_HAND && f->compact_far_field;
+    void* crec_ws = nullptr;
+    float *grad_d = nullptr, *gs_c = nullptr, *gg_c = nullptr, *gr_c = nullptr, *gp_c = nullptr;
+    if (may_compact) {
+        crec_ws = ar.take(CompactRec::bytes(N));
+        grad_d = ar.f(N * 3);
+        gs_c = ar.f(N + 1);
+        gg_c = ar.f((N + 1) * 3);
+        gr_c = ar.f((N + 1) * 3);
+        gp_c = ar.f((N + 1) * 3);
+    }
     if (need != nullptr) {
         *need = ar.used;
         return HN_OK;
@@ -957,9 +1012,28 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
     HN_REQUIRE(!hand || (bt_inv && T_pose), "hand field needs bt_inv / T_pose");
     const int n = (int)N;
     HN_TRY(sample_points(rays_o, rays_d, z, n_rays, S, 1, sample_dist, pts, dists, s));
+    const bool compact = may_compact && hand_compaction(f, 1, N);
+    CompactRec cr{};
+    int n_c = n;   // rows the adjoint runs on
+    if (compact) {
+        cr.at(crec_ws, N);
+        HN_TRY(compact_hand(cr, pts, n, bt_inv, T_pose, 1, n, s));
+        // The launch sequence of the parameter-gradient adjoint is sized on the host: the live count is read back (the one
+        // place this library waits for a stream; a training iteration is ~20 ms of device time behind it).
+        HN_CHECK_HIP(hipMemcpyAsync(&n_c, cr.n_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+        HN_CHECK_HIP(hipStreamSynchronize(s));
+        HN_REQUIRE(n_c >= 1 && n_c <= n + 1, "compaction count out of range: %d", n_c);
+    }
     // The field is NOT evaluated again: the adjoint's own forward tape (exact fp32) supplies sdf / gradient / colour;
     // the alpha stage, the compositing and their adjoints run in the hook, between the tape and the sweeps.
-    const bwd::MidHook mid = [&](const float* z8, const float* g_field, const float* rgb_pre) -> int {
+    const bwd::MidHook mid = [&](const float* z8, const float* g_field_in, const float* rgb_pre) -> int {
+        const float* g_field = g_field_in;
+        if (compact) {   // tape rows -> dense per-sample arrays (dead samples: the far sample's values)
+            hipLaunchKernelGGL(k_tape_outputs, dim3((n_c + 255) / 256), dim3(256), 0, s, z8, rgb_pre, 1.f / f->scale, n_c, cr.sdf_c, cr.rgb_c);
+            hipLaunchKernelGGL(k_hand_scatter, dim3((n + 255) / 256), dim3(256), 0, s, cr.pos, n, cr.n_dev, cr.sdf_c, g_field_in, cr.rgb_c, sdf, grad_d, rgb);
+            HN_LAUNCH_CHECK();
+            g_field = grad_d;
+        } else
         hipLaunchKernelGGL(k_tape_outputs, dim3((n + 255) / 256), dim3(256), 0, s, z8, rgb_pre, 1.f / f->scale, n, sdf, rgb);
         HN_TRY(alpha(sdf, g_field, rays_d, dists, n, S, f->inv_s, al, c, s));
         HN_TRY(composite1_bwd(al, c, rgb, g_color, g_wsum, n_rays, S, g_al, g_c, g_rgb, s));
@@ -970,6 +1044,11 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
         }
         hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs, gg, (const float*)nullptr, (const float*)nullptr, g_field,
                            g_eik, n);
+        if (compact) {   // dense upstream gradients -> the compact rows; the far sample's = the sums over the dead samples
+            hipLaunchKernelGGL(k_zero_slot, dim3(1), dim3(64), 0, s, cr.n_dev, gs_c, gg_c, gr_c);
+            hipLaunchKernelGGL(k_hand_gather_up_sum, dim3((n + 255) / 256), dim3(256), 0, s, cr.idx, cr.pos, n, cr.n_dev, gs, gg, g_rgb, gs_c, gg_c, gr_c);
+        }
+        HN_LAUNCH_CHECK();
         return HN_OK;
     };
     float *gbt = g_bt_inv, *gtp = g_T_pose;
@@ -979,8 +1058,17 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
         HN_CHECK_HIP(hipMemsetAsync(gbt, 0, 21 * 16 * sizeof(float), s));
         HN_CHECK_HIP(hipMemsetAsync(gtp, 0, 21 * 3 * sizeof(float), s));
     }
-    HN_TRY(bwd::field_eval_bwd(f, pts, rays_d, n, S, bt_inv, T_pose, 1, n, gs, gg, g_rgb, gp, gdir, gbt, gtp, bws, bws_bytes, s, nullptr,
-                               nullptr, nullptr, g_params, &mid));
+    if (compact) {
+        // (the hand's colour network ignores the view direction: d loss / d rays_d through it is exactly 0)
+        HN_CHECK_HIP(hipMemsetAsync(gdir, 0, R3 * sizeof(float), s));
+        HN_TRY(bwd::field_eval_bwd(f, cr.pts_c, rays_d, n_c, 1, bt_inv, T_pose, 1, n_c, gs_c, gg_c, gr_c, gp_c, nullptr, gbt, gtp, bws, bws_bytes, s,
+                                   nullptr, nullptr, nullptr, g_params, &mid));
+        hipLaunchKernelGGL(k_hand_scatter3, dim3((n + 255) / 256), dim3(256), 0, s, cr.pos, n, gp_c, gp);
+        HN_LAUNCH_CHECK();
+    } else {
+        HN_TRY(bwd::field_eval_bwd(f, pts, rays_d, n, S, bt_inv, T_pose, 1, n, gs, gg, g_rgb, gp, gdir, gbt, gtp, bws, bws_bytes, s, nullptr,
+                                   nullptr, nullptr, g_params, &mid));
+    }
     HN_TRY(sample_points_bwd(z, gp, n_rays, S, 1, sample_dist, go, gdd, s));
     if (g_rays_o != nullptr) HN_CHECK_HIP(hipMemcpyAsync(g_rays_o, go, R3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (g_rays_d != nullptr)

@@ -215,6 +215,11 @@ def render_train(renderer, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, 
         renderer._ws_train = _Workspace()
     renderer.index = index
     renderer.pack_eval_only = True     # the per-step re-pack builds the evaluation programs only (HN_PACK_EVAL_ONLY)
+    if renderer.model_type == 'hand' and getattr(renderer, 'train_compact', True):
+        # exact far-field aggregation (hn_field_set_compaction): render and backward pass run on the samples with a live bone mask
+        # plus ONE far sample that carries the summed upstream gradients of all the others (they share its all-zero input, so
+        # their parameter-gradient contributions are that sum times one Jacobian).  `renderer.train_compact = False`: dense.
+        renderer.compact_far_field = True
     if repack:
         renderer.mark_parameters_changed()
     dev = rays_o.device

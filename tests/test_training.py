@@ -181,6 +181,45 @@ def test_train_iteration_product_golden(golden, kind, precision):
 
 
 @pytest.mark.gpu
+def test_far_field_aggregation_in_the_training_backward_is_exact():
+    """training.render_train on the hand nets with `train_compact` (hn_field_set_compaction): render and backward pass run on
+    the samples with a live bone mask plus ONE far sample that carries the summed upstream gradients of all the others.  On the
+    bench's training batch (441 rays x 128 depths, ~40 % of the samples dead): outputs bit-identical to the dense iteration,
+    the gradient of every parameter tensor equal to rounding (sums over samples in a different order)."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import train_step_bench as T
+    from honerf_amd import training
+    dev = torch.device('cuda:0')
+    res = {}
+    for compact in (False, True):
+        ren, synth = T.build('hand', dev)
+        ren.precision = 'f16x3'
+        ren.train_compact = compact
+        o, d, ex = T.rays('hand', synth, 441, dev)
+        gen = torch.Generator(device='cpu').manual_seed(5)
+        true_rgb = torch.rand(441, 3, generator=gen).to(dev)
+        true_mask = (torch.rand(441, 1, generator=gen) > 0.3).float().to(dev)
+        tr = torch.rand(441, 1, generator=torch.Generator().manual_seed(8)).to(dev)
+        out = training.render_train(ren, o, d, 0.4, 1.5, ex['bt_inv'], ex['T_pose'], None, None, None, t_rand=tr)
+        terms = training.train_loss(out, true_rgb, true_mask, 1.0, 1.0)
+        params = training.trainable_parameters(ren)
+        grads = torch.autograd.grad(terms['loss'], params)
+        res[compact] = ({k: out[k].detach().clone() for k in ('color_fine', 'weight_sum', 'cdf_fine')}, [x.detach().cpu().numpy().astype(np.float64) for x in grads],
+                        float(terms['loss'].detach()))
+    for k in res[False][0]:
+        assert torch.equal(res[False][0][k], res[True][0][k]), k
+    assert abs(res[False][2] - res[True][2]) <= 1e-6 * abs(res[False][2])
+    worst = 0.0
+    for a, b in zip(res[False][1], res[True][1]):
+        e = float(np.abs(a - b).max() / max(np.abs(a).max(), 1e-30))
+        worst = max(worst, e)
+    record('training backward: far-field aggregation vs dense, worst parameter tensor', worst, 2e-5)
+    assert worst <= 2e-5, worst
+
+
+@pytest.mark.gpu
 def test_train_step_decreases_loss():
     """A few Adam steps of honerf_amd.training.train_step on a fixed batch: the loss goes down and the packed field
     follows the parameters (the renderer re-packs when Adam's in-place update bumps their versions)."""
