@@ -431,7 +431,9 @@ int hn_render_dual_bwd(const hn_field* hand, const hn_field* obj, const float* r
  * NULL), g_gradient_error [1] (may be NULL) -> g_params (accumulated), g_inv_s [1] (d/d inv_s; inv_s = exp(10 variance),
  * utils/fields.py SingleVarianceNetwork; may be NULL), g_rays_o / g_rays_d [B,3] (in the field's frame; may be NULL),
  * g_bt_inv [21,4,4] / g_T_pose [21,3] (hand; may be NULL).  rays are in the field's frame (obj: after
- * hn_obj_local_fwd). */
+ * hn_obj_local_fwd).  On a hand field with hn_field_set_compaction the launch sequence runs on the samples with a live bone
+ * mask plus one far sample that carries the summed upstream gradients of all the others (exact: they share its input); the
+ * sequence is sized on the host, so this call then waits for `stream` once (the live count is read back). */
 size_t hn_field_param_floats(const hn_field* f);
 int hn_field_param_offset(const hn_field* f, int net, int layer, size_t* w_off, size_t* b_off, int* out_dim, int* in_dim,
                           int* ld);

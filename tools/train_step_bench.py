@@ -55,11 +55,13 @@ def rays(kind, synth, n, dev, seed=3):
     return o, d, extra
 
 
-def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3'):
-    """-> dict(workload, ms_per_step, ray_samples_per_s, parts_ms, loss, precision) for one field kind."""
+def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3', compact=True):
+    """-> dict(workload, ms_per_step, ray_samples_per_s, parts_ms, loss, precision) for one field kind.  compact (hand only): the
+    exact far-field aggregation of training.render_train (the product's default); False: every sample evaluated."""
     from honerf_amd import training
     ren, synth = build(kind, dev)
     ren.precision = precision
+    ren.train_compact = bool(compact)
     ren.pack_eval_only = True
     o, d, ex = rays(kind, synth, n_rays, dev)
     g = torch.Generator(device='cpu').manual_seed(5)
@@ -108,7 +110,10 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3'):
     bwd_s = parts['backward'] / steps * 1e-3
     roof = {'bound': 'mfma', 'what': 'backward pass: launch sequence on v_mfma_f32_32x32x2_f32 (k_dense, k_outer)', 'flop_per_step': flop,
             'achieved': flop / bwd_s / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': flop / bwd_s / 1e12 / 157.3}
+    if compact and kind == 'hand':      # the work of the aggregated iteration depends on the batch's live fraction: priced in `hand_dense`
+        roof = {'note': 'far-field aggregation on: fewer samples than the dense FLOP count assumes; the roofline entry is on the dense iteration (hand_dense)'}
     return {'roofline': roof, 'workload': 'exp_runner.train iteration, %s nets, %d rays x (64+64) samples' % (kind, n_rays), 'ms_per_step': round(ms, 3),
+            'far_field_aggregation': bool(compact and kind == 'hand'),
             'iterations_per_s': round(1e3 / ms, 2), 'ray_samples_per_s': round(n_rays * S / ms * 1e3),
             'parts_ms': {k: round(v / steps, 3) for k, v in parts.items()}, 'loss': float(terms['loss'].detach()), 'precision': precision}
 
