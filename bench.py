@@ -574,6 +574,22 @@ def main():
         # secondary: the hand iteration with every sample evaluated (the product's default aggregates the far field exactly)
         training['hand_dense'] = train_step_bench.measure('hand', dev, 441, 10, 3, args.precision, compact=False)
     c1 = time_c1(dev, args.precision, not args.no_cpu_baseline) if rank == 0 and not args.no_c1 else None
+    # ---- the rate the matrix pipe SUSTAINS on this box (hn_debug_mfma_probe: a kernel of nothing but f16 MFMAs on random
+    #      operands, ~0.2 s per launch so that the power controller settles): the chip is power-limited well below the
+    #      guide's 2.4 GHz figure, so the roofline entry states the fraction of this measured rate beside the nominal one
+    sustained = None
+    if rank == 0 and args.precision == 'f16x3' and not share:
+        import ctypes
+        flop = ctypes.c_double(0.0)
+        iters = 300000
+        L.check(lib.hn_debug_mfma_probe(1, iters // 10, ctypes.byref(flop), L.stream_ptr()), 'hn_debug_mfma_probe')     # warm
+        p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        p0.record()
+        for _ in range(2):
+            L.check(lib.hn_debug_mfma_probe(1, iters, ctypes.byref(flop), L.stream_ptr()), 'hn_debug_mfma_probe')
+        p1.record()
+        torch.cuda.synchronize()
+        sustained = 2.0 * flop.value / (p0.elapsed_time(p1) * 1e-3) / 1e12        # TFLOP/s of issued f16 MFMA
     if rank == 0:
         res = {
             'metric': 'ray-samples/sec/GPU (512x512x64)', 'value': value, 'unit': 'ray-samples/s',
@@ -590,6 +606,12 @@ def main():
                          'mfma_peak_tflops': PEAK_F16_MFMA_TFLOPS if args.precision == 'f16x3' else PEAK_F32_MFMA_TFLOPS},
             'weight_sum_mean': float(out['weight_sum'].mean()),
         }
+        if sustained is not None:
+            # `peak` / `frac` above are the guide's nominal figures, as the contract asks; these two are measured in this run
+            res['roofline']['mfma_sustained_tflops'] = sustained
+            res['roofline']['frac_of_sustained'] = achieved * 3.0 / sustained
+            res['roofline']['sustained_what'] = ('hn_debug_mfma_probe: v_mfma_f32_32x32x16_f16 alone on random operands, one wave per SIMD on every CU, '
+                                                  '2 x 0.2 s: the rate the power-limited matrix pipe holds on this box')
         if share:
             res['note'] = 'HONERF_BENCH_SHARE_GPU=1: all ranks on ONE device over gloo -- functional check only, timings are not a measurement'
         if c1 is not None:

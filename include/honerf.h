@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 106 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 107 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -112,6 +112,11 @@ int hn_field_set_culling(hn_field* f, int enabled);
  * Off by default; the stand-alone evaluations (hn_field_sdf / hn_field_eval) and every throughput figure quoted as "dense"
  * never compact. */
 int hn_field_set_compaction(hn_field* f, int enabled);
+/* Measurement aid (bench.py): launches a kernel of nothing but v_mfma_f32_32x32x16_f16 on pseudo-random operands on every CU
+ * (waves_per_simd = 1 or 2 workgroups of four waves per CU, `iters` x 32 MFMAs per wave) and returns the FLOP it issues in
+ * *flop (may be NULL).  Timed by the caller on `stream`: the rate the power-limited matrix pipe sustains, which the roofline
+ * entry of the bench line states beside the guide's nominal peak.  Not a product path. */
+int hn_debug_mfma_probe(int waves_per_simd, int iters, double* flop, hn_stream_t stream);
 /* Test hook for the XCD pacing of the f16x3 field kernels (image-sized launches: the 32 workgroups of an XCD meet at every
  * tile start, bounded spin): `members` > 0 registers that many members per XCD that never arrive, so that the first
  * meeting of every workgroup runs into its timeout and the launch continues unpaced -- results must be bit-identical.
