@@ -713,8 +713,8 @@ struct Ctx {
     void outer(const float* A, int lda, int M, const float* B, int ldb, int K, float alpha, float* dW, int ldw, float* db) const {
         const int KB = db != nullptr ? K + 1 : K;
         const int tiles = ((M + 127) / 128) * ((KB + 127) / 128);
-        // ~1024 workgroups (two per CU, twice over), a slice at least 256 samples long
-        int slices = (1024 + tiles - 1) / tiles;
+        // ~512 workgroups (two per CU), a slice at least 256 samples long
+        int slices = (512 + tiles - 1) / tiles;   // (1024: 5 % slower -- twice the atomics per output; 128: too few workgroups)
         const int max_slices = (n + 255) / 256;
         if (slices > max_slices) slices = max_slices;
         if (slices < 1) slices = 1;
