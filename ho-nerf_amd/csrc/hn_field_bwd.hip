@@ -41,6 +41,9 @@ static bool fused_adjoint(const hn_field* f, bool sdf_only) {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float BETA = 100.f;
 
+__device__ __forceinline__ float softplus(float z) {   // nn.Softplus(beta=100, threshold=20)
+    return BETA * z > 20.f ? z : log1pf(expf(BETA * z)) / BETA;
+}
 // ---- C[n,M] (+)= alpha * A[n,K] * B (+ bias),  B(k, col) = W[k * wsk + col * wsc] --------------------------------
 struct DenseArgs {
     const float* A;
@@ -53,6 +56,7 @@ struct DenseArgs {
     int n, K, M;
     float alpha;
     int accumulate;
+    int act;   // applied to the stored value: 0 none, 1 softplus(beta = 100), 2 ReLU (the tape's activations: no separate pass over C)
 };
 // Workgroup tile 128 x BN (BN = 128, or 64 for narrow outputs), K step 32; 4 waves as 2 x 2, each 64 x BN/2 outputs
 // = 2 x (BN/64) MFMA tiles.  At 128 x 128 the operand traffic is 32 flop per byte of L2 read (the 64 x 64 tile of
@@ -149,6 +153,8 @@ __global__ __launch_bounds__(256) void k_dense(const DenseArgs a) {
                         float v = a.alpha * acc[x][y][r] + b;
                         float* c = a.C + (size_t)row * a.ldc + col;
                         if (a.accumulate) v += *c;
+                        if (a.act == 1) v = softplus(v);
+                        if (a.act == 2) v = fmaxf(v, 0.f);
                         *c = v;
                     }
                 }
@@ -260,9 +266,6 @@ __global__ void k_colsum(const float* __restrict__ x, int n, int ld, int width, 
 }
 
 // ---- element-wise --------------------------------------------------------------------------------------------
-__device__ __forceinline__ float softplus(float z) {   // nn.Softplus(beta=100, threshold=20)
-    return BETA * z > 20.f ? z : log1pf(expf(BETA * z)) / BETA;
-}
 __device__ __forceinline__ float sig_from_act(float a) { return 1.f - expf(-BETA * a); }   // sigma'(z) from a = softplus(z)
 
 // The tape arrays are multiples of 4 floats only by luck of the widths (193-wide rows are not), so the element-wise
@@ -695,15 +698,15 @@ struct Ctx {
     hipStream_t s;
     int n;
     void dense(const float* A, int lda, int K, const float* W, int wsk, int wsc, int M, const float* bias, float alpha,
-               float* C, int ldc, bool accumulate) const {
-        DenseArgs a{A, lda, W, wsk, wsc, bias, C, ldc, n, K, M, alpha, accumulate ? 1 : 0};
+               float* C, int ldc, bool accumulate, int act = 0) const {
+        DenseArgs a{A, lda, W, wsk, wsc, bias, C, ldc, n, K, M, alpha, accumulate ? 1 : 0, act};
         // 128 x 64 workgroup tiles measure ~5 % faster than 128 x 128 on the fitting sizes (more workgroups per CU)
         hipLaunchKernelGGL(k_dense<64>, dim3((M + 63) / 64, (n + 127) / 128), dim3(256), 0, s, a);
     }
     // C = A * W[:, c0:c0+K]^T  (W row-major [M, ldw])          "forward" use of a weight block
     void nt(const float* A, int lda, int K, const float* W, int ldw, int c0, int M, const float* bias, float alpha, float* C,
-            int ldc, bool acc) const {
-        dense(A, lda, K, W + c0, 1, ldw, M, bias, alpha, C, ldc, acc);
+            int ldc, bool acc, int act = 0) const {
+        dense(A, lda, K, W + c0, 1, ldw, M, bias, alpha, C, ldc, acc, act);
     }
     // C = A * W[:, c0:c0+M]      (A [n, rows of W])            "transposed" use of the same block
     void nn(const float* A, int lda, int K, const float* W, int ldw, int c0, int M, float alpha, float* C, int ldc, bool acc) const {
@@ -845,15 +848,14 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
         hipLaunchKernelGGL(k_hand_feat, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.X, DP,
                            (float*)nullptr, (float*)nullptr);
     b.a[0] = b.X;
-    for (int l = 0; l < 8; ++l) {
+    for (int l = 0; l < 8; ++l) {   // (the softplus is the last product's epilogue: no separate pass over the activations)
         if (l == 4) {
             cx.nt(b.a[4], H4, H4, W[4], LW[4], 0, width(4), Bv[4], rs2, b.a[5], width(4), false);
-            cx.nt(b.X, DP, Din, W[4], LW[4], H4, width(4), nullptr, rs2, b.a[5], width(4), true);
+            cx.nt(b.X, DP, Din, W[4], LW[4], H4, width(4), nullptr, rs2, b.a[5], width(4), true, 1);
         } else {
             const int K = l == 0 ? Din : f->sdf_in[l];
-            cx.nt(b.a[l], l == 0 ? DP : K, K, W[l], LW[l], 0, width(l), Bv[l], 1.f, b.a[l + 1], width(l), false);
+            cx.nt(b.a[l], l == 0 ? DP : K, K, W[l], LW[l], 0, width(l), Bv[l], 1.f, b.a[l + 1], width(l), false, 1);
         }
-        hipLaunchKernelGGL(k_softplus, g1((N * width(l) + 3) / 4), dim3(256), 0, s, b.a[l + 1], N * width(l));
     }
     cx.nt(b.a[8], H, H, W[8], LW[8], 0, 257, Bv[8], 1.f, b.z8, 257, false);
     // 2. reverse sweep ------------------------------------------------------------------------------------------
@@ -901,12 +903,8 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
         cx.nt(b.din, 27, 27, C[0], LC0, o_d, H, nullptr, 1.f, b.c[1], H, true);
     }
     cx.nt(b.z8 + 1, 257, H, C[0], LC0, o_f, H, nullptr, 1.f, b.c[1], H, true);
-    cx.nt(b.gin, 27, 27, C[0], LC0, o_g, H, nullptr, 1.f, b.c[1], H, true);
-    hipLaunchKernelGGL(k_relu, g1((N * H + 3) / 4), dim3(256), 0, s, b.c[1], N * H);
-    for (int l = 1; l <= 3; ++l) {
-        cx.nt(b.c[l], H, H, C[l], H, 0, H, Cb[l], 1.f, b.c[l + 1], H, false);
-        hipLaunchKernelGGL(k_relu, g1((N * H + 3) / 4), dim3(256), 0, s, b.c[l + 1], N * H);
-    }
+    cx.nt(b.gin, 27, 27, C[0], LC0, o_g, H, nullptr, 1.f, b.c[1], H, true, 2);   // (+ ReLU)
+    for (int l = 1; l <= 3; ++l) cx.nt(b.c[l], H, H, C[l], H, 0, H, Cb[l], 1.f, b.c[l + 1], H, false, 2);
     cx.nt(b.c[4], H, H, C[4], H, 0, 3, Cb[4], 1.f, b.xb, 3, false);
     if (mid != nullptr) {
         HN_LAUNCH_CHECK();
