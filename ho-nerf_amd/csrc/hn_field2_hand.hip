@@ -49,8 +49,8 @@ struct Hand2Args {
     int n_frames;
     const char* blob;
     size_t blob_bytes;
-    float b8;
-    float c_blast[3];
+    const float* b8;       // &bias of lin8's sdf row (the field's retained copy: read on the device, a re-pack waits for nothing)
+    const float* c_blast;  // the three biases of colour lin4 (the field's retained copy, read on the device)
     float* sdf;
     float* grad;
     float* rgb;
@@ -770,7 +770,7 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
             else
                 lin7(std::integral_constant<int, 0>{});
         }
-        sdf = (S16 ? sample_sum(sdf_acc, sdf_acc1) : half_sum(sdf_acc)) + a.b8;
+        sdf = (S16 ? sample_sum(sdf_acc, sdf_acc1) : half_sum(sdf_acc)) + a.b8[0];
         if (!FULL) {
             if (valid && h == 0) a.sdf[n] = sdf;
             continue;
@@ -1102,8 +1102,8 @@ static void hand2_common_args(Hand2Args& a, const hn_field* f, const float* pts,
     a.n_pts = n_pts;
     a.pts_per_frame = pts_per_frame;
     a.n_frames = n_frames;
-    a.b8 = f->sdf_b8;
-    for (int c = 0; c < 3; ++c) a.c_blast[c] = f->col_blast[c];
+    a.b8 = f->raw_sdf_b[8];
+    a.c_blast = f->raw_col_b[4];
     a.scratch = reinterpret_cast<float4*>(workspace);
     a.dbg = 0;
     a.cull = f->cull_far_field;

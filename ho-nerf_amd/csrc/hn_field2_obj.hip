@@ -25,8 +25,8 @@ struct Obj2Args {
     float inv_scale;
     const char* blob;      // weight stream (FULL or SDF-only program)
     size_t blob_bytes;
-    float b8;
-    float c_blast[3];
+    const float* b8;   // &bias of lin8's sdf row (the field's retained copy, read on the device)
+    const float* c_blast;   // the three biases of colour lin4 (the field's retained copy, read on the device)
     float* sdf;
     float* grad;
     float* rgb;
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
             else
                 lin7(std::integral_constant<int, 0>{});
         }
-        sdf = (half_sum(sdf_acc) + a.b8) * a.inv_scale;
+        sdf = (half_sum(sdf_acc) + a.b8[0]) * a.inv_scale;
         if (!FULL) {
             if (valid && h == 0) a.sdf[n] = sdf;
             continue;
@@ -961,8 +961,8 @@ int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, 
         set_error("field was not created with HN_PREC_F16X3");
         return HN_EINVAL;
     }
-    a.b8 = f->sdf_b8;
-    for (int c = 0; c < 3; ++c) a.c_blast[c] = f->col_blast[c];
+    a.b8 = f->raw_sdf_b[8];
+    a.c_blast = f->raw_col_b[4];
     a.sdf = sdf;
     a.grad = grad;
     a.rgb = rgb;
@@ -1041,8 +1041,8 @@ int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays
     a.inv_scale = 1.f / f->scale;
     a.blob = reinterpret_cast<const char*>(f->v2_adj);
     a.blob_bytes = f->v2_adj_bytes;
-    a.b8 = f->sdf_b8;
-    for (int c = 0; c < 3; ++c) a.c_blast[c] = f->col_blast[c];
+    a.b8 = f->raw_sdf_b[8];
+    a.c_blast = f->raw_col_b[4];
     a.scratch = reinterpret_cast<float4*>(workspace);
     a.dbg = 0;
     a.g_sdf = g_sdf;

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_field2_obj_q(const Obj2Args a) {
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) sdf_acc = fmaf(ew[(t * 16 + i) * 64 + lane], ex[(t * 16 + i) * 64 + lane], sdf_acc);
-                const float sdf = (half_sum(sdf_acc) + a.b8) * a.inv_scale;
+                const float sdf = (half_sum(sdf_acc) + a.b8[0]) * a.inv_scale;
                 if (valid && h == 0) a.sdf[n] = sdf;
             }
         }

@@ -444,8 +444,12 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
     };
     for (int l = 0; l < 9 && rc == HN_OK; ++l) rc = fold(sdf, l, &w_sdf[l]);
     for (int l = 0; l < 5 && rc == HN_OK; ++l) rc = fold(col, l, &w_col[l]);
+    // The fp32 kernel family's fragment programs (and the two last-layer biases it keeps on the host) are built for HN_PREC_FP32
+    // fields only: an f16x3 field never launches those kernels, and its re-pack -- the per-iteration cost of a training loop --
+    // then waits for nothing on the host (the f16x3 kernels read lin8's bias from the retained copy on the device).
+    const bool fp32_programs = precision == HN_PREC_FP32;
     float hostb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (rc == HN_OK) {
+    if (rc == HN_OK && fp32_programs) {
         if (hipMemcpyAsync(&hostb[0], sdf->bias[8], sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipMemcpyAsync(&hostb[1], col->bias[4], 3 * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess) {
@@ -454,7 +458,7 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
         }
     }
     stage("fold + last-layer biases to host");
-    if (rc == HN_OK) {
+    if (rc == HN_OK && fp32_programs) {
         pk.dry = true;
         pk.used = 0;
         build(f, pk, sdf, col, w_sdf, w_col, hostb);
@@ -464,7 +468,7 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
             rc = HN_ENOMEM;
         }
     }
-    if (rc == HN_OK) {
+    if (rc == HN_OK && fp32_programs) {
         pk.dry = false;
         pk.base = reinterpret_cast<char*>(f->blob);
         pk.used = 0;
@@ -521,7 +525,7 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
                 f->raw_col_w[l] = keep_mat(w_col[l], col->out_dim[l], col->in_dim[l]);
                 f->raw_col_b[l] = keep_vec(reinterpret_cast<const float*>(col->bias[l]), col->out_dim[l]);
             }
-            if (hipStreamSynchronize(stream) != hipSuccess) {
+            if (fp32_programs && hipStreamSynchronize(stream) != hipSuccess) {   // (f16x3: stream order is all the later launches need)
                 set_error("copying the folded weights failed");
                 rc = HN_EHIP;
             }
