@@ -14,7 +14,8 @@
  *     int64, to match torch) unless a parameter is documented as host;
  *   - the last argument is the hipStream_t to launch on (as void*); no entry
  *     point synchronises, allocates or frees device memory except
- *     hn_field_create / hn_field_destroy / hn_workspace_*;
+ *     hn_field_create / hn_field_destroy / hn_workspace_* (and hn_render_single_bwd
+ *     on a hand field with hn_field_set_compaction, which reads one count back);
  *   - outputs and workspaces are caller-owned; sizes come from the
  *     *_workspace_bytes queries.
  */
@@ -80,13 +81,16 @@ int hn_device_cus(void);
 /* ---- weights --------------------------------------------------------------------------
  * Folds weight-norm and re-lays every matrix in MFMA fragment order: once for the frozen
  * networks of rendering and pose fitting, after every optimiser step when training
- * (exp_runner.py:230-232; ~2 - 3 ms with HN_PACK_EVAL_ONLY: all fragments are written on the
- * device).  `variance` is SingleVarianceNetwork.variance (utils/fields.py:243-249); `scale` is
- * SDFNetwork_OBJ.scale (:328).  Synchronises the stream before returning.
- * hn_field_destroy: no work that uses the field may be in flight.  Its device blocks go to a
- * size-keyed cache of the process and are handed to the next hn_field_create of the same shape
- * (a re-pack allocates nothing); host staging is two pinned buffers kept for the life of the
- * process.  Packs of one process are serialised. */
+ * (exp_runner.py:230-232).  `variance` is SingleVarianceNetwork.variance (utils/fields.py:243-249); `scale` is
+ * SDFNetwork_OBJ.scale (:328).  The first pack of a field kind (and every HN_PREC_FP32 pack) lays the programs out on the
+ * host and synchronises the stream; it also leaves a checked PLAN of the layout on the device, from which every later
+ * f16x3 pack of that kind fills its programs with a memset and two launches each (~0.5 ms with HN_PACK_EVAL_ONLY) and
+ * waits for nothing.
+ * hn_field_destroy: the field's device blocks go to a size-keyed cache of the process and are handed to the next
+ * hn_field_create of the same shape (a re-pack allocates nothing).  Work that uses the field may still be QUEUED on the stream
+ * the next pack is issued on (a training loop destroys the old field while its backward pass is in flight): the new pack's
+ * writes are ordered behind it.  Work in flight on ANOTHER stream must be waited for first.  Host staging is two pinned
+ * buffers kept for the life of the process.  Packs of one process are serialised. */
 int hn_field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* color, float variance, float scale,
                     int precision, hn_field** out, hn_stream_t stream);
 int hn_field_destroy(hn_field* f);
