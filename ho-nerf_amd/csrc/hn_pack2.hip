@@ -398,7 +398,7 @@ struct PackPlan {
     int n_tails = 0;
     bool usable = false, tried = false;
 };
-static std::map<long long, PackPlan> g_plans;   // key: kind, mode, MFMA shape, eval_only-independent
+static std::map<long long, PackPlan> g_plans;   // key: device, kind, mode, MFMA shape
 __global__ __launch_bounds__(256) void k_fill_fragments_plan(const FragBlock* __restrict__ blocks, int n_blocks, const int* __restrict__ maps,
                                                              const SrcTable tab, char* __restrict__ prog) {
     const int bi = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
@@ -499,7 +499,8 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
     const auto t_begin = std::chrono::steady_clock::now();
     const bool eval16_ = f->kind == HN_FIELD_OBJ ? (HN_OBJ_EVAL_MFMA16 != 0) : (HN_HAND_EVAL_MFMA16 != 0);
     const int n_modes = eval_only ? 2 : (eval16_ ? 5 : 4);
-    auto plan_key = [&](int mode) { return (long long)f->kind * 100 + mode * 10 + (eval16_ ? 1 : 0); };
+    const int plan_dev = current_device();   // (a plan's arrays live on the device it was derived on)
+    auto plan_key = [&](int mode) { return (long long)(plan_dev + 1) * 100000 + (long long)f->kind * 100 + mode * 10 + (eval16_ ? 1 : 0); };
     auto slot_of = [&](int mode, void*** dst, size_t** nb) {
         *dst = mode == 0 ? &f->v2_sdf : (mode == 1 ? &f->v2_full : (mode == 2 ? &f->v2_adj : (mode == 3 ? &f->v2_adjonly : &f->v2_tape)));
         *nb = mode == 0 ? &f->v2_sdf_bytes
