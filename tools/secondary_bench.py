@@ -58,7 +58,7 @@ fo, fd = rays_o[idx].contiguous(), rays_d[idx].contiguous()
 tr = torch.rand(n, 1, device=dev, generator=torch.Generator(dev).manual_seed(4))
 To2 = torch.tensor([0.0, 0.0, 0.9], device=dev)
 dt = timed(lambda: renf.render(fo, fd, bench.NEAR, bench.FAR, sc['bt_inv'], sc['T_pose'], None, Ro, To2, 0, t_rand=tr), 20)
-out['c3_step_forward_196x192_dual'] = {'s_per_step': dt, 'steps_per_s': 1.0 / dt, 'note': 'forward only: the field adjoint is not built yet'}
+out['c3_step_forward_196x192_dual'] = {'s_per_step': dt, 'steps_per_s': 1.0 / dt, 'note': 'the forward render of a fitting step alone; the whole step (forward + losses + backward + Adam) is bench.py fitting.single_12'}
 print('C3-style step forward (196 rays x 192 samples, both fields): %.2f ms' % (dt * 1e3))
 if len(sys.argv) > 1:
     json.dump(out, open(sys.argv[1], 'w'), indent=1)
