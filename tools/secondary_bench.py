@@ -34,6 +34,13 @@ full, sdf_only = B * 128, B * (64 + 16 * 3)
 out['c2_hand_64+64'] = {'s_per_frame': dt, 'full_samples': full, 'sdf_only_samples': sdf_only,
                         'full_ray_samples_per_s': full / dt, 'all_field_evaluations_per_s': (full + sdf_only) / dt}
 print('C2 hand 64+64: %.3f s per frame, %.1f M full ray-samples/s (+ %.1f M sdf-only samples per frame)' % (dt, full / dt / 1e6, sdf_only / 1e6))
+# the same frame with the exact sample-level far-field skip (hn_field_set_compaction): bit-identical image
+dense_img = ren64.render(rays_o, rays_d, bench.NEAR, bench.FAR, sc['bt_inv'], sc['T_pose'], None, None, None, 0, t_rand=sc['t_rand'])['color_fine'].clone()
+ren64.compact_far_field = True
+same = bool(torch.equal(dense_img, ren64.render(rays_o, rays_d, bench.NEAR, bench.FAR, sc['bt_inv'], sc['T_pose'], None, None, None, 0, t_rand=sc['t_rand'])['color_fine']))
+dtc = timed(lambda: ren64.render(rays_o, rays_d, bench.NEAR, bench.FAR, sc['bt_inv'], sc['T_pose'], None, None, None, 0, t_rand=sc['t_rand']), 3)
+out['c2_hand_64+64_compact'] = {'s_per_frame': dtc, 'full_ray_samples_per_s': full / dtc, 'bit_identical_to_dense': same}
+print('C2 hand 64+64 with the far-field skip: %.3f s per frame, %.1f M full ray-samples/s, identical image: %s' % (dtc, full / dtc / 1e6, same))
 
 # ---- object, 512x512, 64 + 64
 so, co, vo = SDFNetwork_OBJ().to(dev), RenderingNetwork_OBJ().to(dev), SingleVarianceNetwork(0.3).to(dev)
