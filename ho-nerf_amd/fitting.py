@@ -447,6 +447,7 @@ def _rays(lib_mod, xy, cam, n_cams, rays_per_cam):
 
 
 _SIDE_STREAMS = {}
+USE_SIDE_STREAM = True    # fit_backward (frame-batched renderer): the pose-only terms of a step on a second stream beside the render
 
 
 def _side_stream(device):
@@ -481,7 +482,7 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
     T_pose = pose['T_pose_21']
     stable, pterms, side = None, None, None
     want_stable = video and fit_type == '1234'
-    if video and rays_o.is_cuda and rays_fn is None:
+    if video and rays_o.is_cuda and rays_fn is None and USE_SIDE_STREAM:
         # What depends on the pose only -- the stable term (hand SDF on the object's vertices, ~50 small launches forward and ~70
         # backward) and the pose regularisers / smoothness (~40 + ~60) -- runs on a second stream beside the render; autograd runs
         # the backward passes on that stream too, beside the render's.  They join the loss below.

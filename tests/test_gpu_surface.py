@@ -366,6 +366,35 @@ def test_far_field_compaction_is_exact_over_a_window_of_frames():
         bounded('far-field compaction over 4 frames: gradient of pose leaf %d vs dense' % i, e, 5e-5)
 
 
+def test_window_step_side_stream_equals_single_stream():
+    """fit_backward on a fitting_video window evaluates the stable term and the pose regularisers on a second stream beside the
+    render (forward and backward).  The same step with everything on one stream: same loss terms, same gradients of the six
+    leaves (to the rounding of the atomics-accumulated sums)."""
+    import bench
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    res = {}
+    for side in (True, False):
+        ren, nets, chain, views, verts = bench.build_fit(dev, 43, 4, bench.VID_RAYS, 'f16x3', halo=True)
+        with torch.no_grad():
+            for i, p in enumerate(chain.parameters()):
+                p.add_(5e-3 * torch.randn(p.shape, generator=torch.Generator().manual_seed(30 + i)).to(dev))
+        tr = torch.rand(4 * bench.VID_RAYS, 1, generator=torch.Generator().manual_seed(4)).to(dev)
+        F.USE_SIDE_STREAM = side
+        try:
+            terms = F.fit_backward(ren, views[1], chain, bench.NEAR, bench.FAR, '1234', index=[0, 1, 2, 3], smooth_ends=(True, False),
+                                   obj_verts_for_stable=verts[:, :400], t_rand=tr)
+            torch.cuda.synchronize()
+        finally:
+            F.USE_SIDE_STREAM = True
+        res[side] = ({k: float(v.detach()) for k, v in terms.items()}, [p.grad.clone() for p in chain.parameters()])
+    for k in res[True][0]:
+        a, b = res[True][0][k], res[False][0][k]
+        assert abs(a - b) <= 2e-6 * max(abs(a), 1e-6), (k, a, b)
+    for i, (a, b) in enumerate(zip(res[True][1], res[False][1])):
+        bounded('window step, side stream vs one stream: gradient of pose leaf %d' % i, rel_err(a.cpu().numpy(), b.cpu().numpy()), 5e-5)
+
+
 def test_fit_sequence_video_one_rank_is_the_sequential_schedule():
     """fit_sequence_video with one rank (no process group) on the device == fit_step applied window by window in the
     reference's order (fitting_video.py:186-342) over the reference's six-leaf pose chain; and
