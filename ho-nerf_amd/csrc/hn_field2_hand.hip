@@ -1180,7 +1180,7 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
     }
     // a launch too small to fill the chip: the latency form (bit-identical results; its stash fits the same workspace)
     const int n_blocks = (n_pts + 31) / 32;
-    if (!full && !f->single_pass && !a.cull && n_blocks <= quad_max_blocks(n_cus) && field2_hand_q_workspace_bytes(n_blocks, n_cus) <= workspace_bytes)
+    if (!full && !f->single_pass && n_blocks <= quad_max_blocks(n_cus) && field2_hand_q_workspace_bytes(n_blocks, n_cus) <= workspace_bytes)
         return launch_field2_hand_q(a, n_blocks, n_cus, stream);
     // XCD pacing: launches of many tiles per workgroup (the image-sized ones), where the workspace has the room
     if (HN_XCD_PACING && (n_pts + WG_SAMPLES - 1) / WG_SAMPLES >= XCD_PACE_MIN_ROUNDS * grid && workspace_bytes >= need + 64) {
