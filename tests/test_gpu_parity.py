@@ -690,6 +690,20 @@ def test_hand_far_field_culling_is_exact(prec):
 
 
 # ---------------------------------------------------------------------------------------------
+def test_mfma_probe_launches_and_counts_its_work(L):
+    """hn_debug_mfma_probe (bench.py's sustained-rate measurement): runs on every CU, reports the FLOP it issues, rejects bad arguments."""
+    import ctypes
+    lib = L.load()
+    flop = ctypes.c_double(0.0)
+    L.check(lib.hn_debug_mfma_probe(1, 100, ctypes.byref(flop), st()), 'probe')
+    torch.cuda.synchronize()
+    cus = lib.hn_device_cus()
+    assert flop.value == cus * 4 * 100 * 32 * 32768.0
+    L.check(lib.hn_debug_mfma_probe(2, 10, None, st()), 'probe')
+    torch.cuda.synchronize()
+    assert lib.hn_debug_mfma_probe(3, 10, None, st()) < 0 and lib.hn_debug_mfma_probe(1, 0, None, st()) < 0
+
+
 def test_error_paths_return_status_and_message(L):
     """C ABI error behaviour: int status < 0 + hn_last_error(), nothing launched."""
     lib = L.load()
