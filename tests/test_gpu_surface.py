@@ -322,8 +322,14 @@ def test_far_field_compaction_is_exact():
         loss = sum((out[k] * torch.randn(out[k].shape, generator=g).to(dev)).sum() for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj', 'gradient_hand'))
         grads = torch.autograd.grad(loss, leaves)
         res[compact] = ({k: out[k].detach().clone() for k in out}, [x.clone() for x in grads], ren.last_z_vals.clone())
+        with torch.no_grad():                                       # the render without a tape (its compaction record lives in the workspace)
+            plain = ren.render(leaves[3].detach(), leaves[4].detach(), bench.NEAR, bench.FAR, leaves[0].detach(), pose['T_pose_21'][0], None,
+                               leaves[1].detach(), leaves[2].detach(), t_rand=tr)
+        res[compact] = res[compact] + ({k: plain[k].clone() for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj', 'gradient_hand', 'gradient_obj')},)
     dense, comp = res[False], res[True]
     assert torch.equal(dense[2], comp[2])
+    for k in dense[3]:
+        assert torch.equal(dense[3][k], comp[3][k]), 'compaction changed %s of the render without a tape' % k
     for k in dense[0]:
         if k.startswith('gradient_error'):      # a sum accumulated with float atomics: equal to rounding, not to the bit, in ANY two runs
             assert abs(float(dense[0][k]) - float(comp[0][k])) <= 1e-6 * abs(float(dense[0][k])), k
