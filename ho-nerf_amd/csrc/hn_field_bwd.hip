@@ -1084,11 +1084,23 @@ int color_forward(const hn_field* f, const float* x, const float* view_dirs, con
 // W[r, :] = g[r] v[r, :] / |v[r, :]|: from dW (row pitch ld, the layout of g_params) one workgroup per row forms
 //   dg[r] = dW[r, :] . vhat,   dv[r, :] = (g[r] / |v|) (dW[r, :] - vhat (dW[r, :] . vhat)),   db[r] = dB[r]
 // (what torch's `_weight_norm` backward computes).  g == NULL: a plain nn.Linear, dv = dW.
-__global__ __launch_bounds__(256) void k_weight_norm_bwd(const float* __restrict__ g, const float* __restrict__ v, const float* __restrict__ dW,
-                                                         const float* __restrict__ dB, int cols, int ld, float* __restrict__ dg,
-                                                         float* __restrict__ dv, float* __restrict__ db) {
+// all 14 layers in ONE launch (blockIdx.y = layer, blockIdx.x = matrix row: a launch of a dependent chain costs ~5 us whatever it does)
+struct WnbLayer {
+    const float *g, *v, *dW, *dB;
+    float *dg, *dv, *db;
+    int rows, cols, ld;
+};
+struct WnbTable {
+    WnbLayer l[14];
+};
+__global__ __launch_bounds__(256) void k_weight_norm_bwd(const WnbTable tab) {
     __shared__ float red[2][4];
+    const WnbLayer& L_ = tab.l[blockIdx.y];
     const int r = blockIdx.x, t = threadIdx.x;
+    if (r >= L_.rows) return;
+    const float *g = L_.g, *v = L_.v, *dW = L_.dW, *dB = L_.dB;
+    float *dg = L_.dg, *dv = L_.dv, *db = L_.db;
+    const int cols = L_.cols, ld = L_.ld;
     const float* vr = v + (size_t)r * cols;
     const float* wr = dW + (size_t)r * ld;
     if (t == 0 && db != nullptr) db[r] = dB[r];
@@ -1123,6 +1135,8 @@ int weight_norm_bwd(const hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc
                     const hn_mlp_desc* g_col, hipStream_t s) {
     HN_REQUIRE(f != nullptr && f->raw != nullptr && sdf && col && g_params && g_sdf && g_col, "null argument");
     const float* base = reinterpret_cast<const float*>(f->raw);
+    WnbTable tab;
+    int max_rows = 0, li = 0;
     for (int net = 0; net < 2; ++net) {
         const hn_mlp_desc* d = net == 0 ? sdf : col;
         const hn_mlp_desc* o = net == 0 ? g_sdf : g_col;
@@ -1135,10 +1149,12 @@ int weight_norm_bwd(const hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc
             const float* dW = g_params + ((net == 0 ? f->raw_sdf_w[l] : f->raw_col_w[l]) - base);
             const float* dB = g_params + ((net == 0 ? f->raw_sdf_b[l] : f->raw_col_b[l]) - base);
             HN_REQUIRE(o->weight_v[l] != nullptr && (d->weight_g[l] == nullptr || o->weight_g[l] != nullptr), "missing output of layer %d", l);
-            hipLaunchKernelGGL(k_weight_norm_bwd, dim3(rows), dim3(256), 0, s, d->weight_g[l], d->weight_v[l], dW, dB, cols, ld,
-                               const_cast<float*>(o->weight_g[l]), const_cast<float*>(o->weight_v[l]), const_cast<float*>(o->bias[l]));
+            tab.l[li++] = WnbLayer{d->weight_g[l], d->weight_v[l], dW, dB, const_cast<float*>(o->weight_g[l]), const_cast<float*>(o->weight_v[l]),
+                                   const_cast<float*>(o->bias[l]), rows, cols, ld};
+            max_rows = rows > max_rows ? rows : max_rows;
         }
     }
+    hipLaunchKernelGGL(k_weight_norm_bwd, dim3(max_rows, 14), dim3(256), 0, s, tab);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

@@ -80,13 +80,22 @@ void pool_free(void* p) {
 }
 
 // effective weight of one layer, row-major [out][in]
-__global__ void k_fold_weight_norm(const float* __restrict__ g, const float* __restrict__ v, int out, int in,
-                                   float* __restrict__ w) {
-    const int row = blockIdx.x;
-    if (row >= out) return;
-    const float* vr = v + (size_t)row * in;
+// the per-layer launches of a pack batched into one each (blockIdx.y = layer): a re-pack is a chain of dependent launches
+struct PackLayer {
+    const float *g, *v, *b;   // weight_g (or NULL), weight_v, bias of the layer
+    float *w, *raw_w, *raw_b; // folded matrix; its retained row-pitched copy; the retained bias
+    int out, in, ld;
+};
+struct PackTable {
+    PackLayer l[14];
+};
+__global__ void k_fold_weight_norm_all(const PackTable tab) {
+    const PackLayer& L_ = tab.l[blockIdx.y];
+    const int row = blockIdx.x, in = L_.in;
+    if (row >= L_.out) return;
+    const float* vr = L_.v + (size_t)row * in;
     float scale = 1.f;
-    if (g != nullptr) {
+    if (L_.g != nullptr) {
         float ss = 0.f;
         for (int i = threadIdx.x; i < in; i += blockDim.x) ss = fmaf(vr[i], vr[i], ss);
         for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
@@ -94,10 +103,15 @@ __global__ void k_fold_weight_norm(const float* __restrict__ g, const float* __r
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
         __syncthreads();
         ss = part[0] + part[1] + part[2] + part[3];
-        // torch._weight_norm: v * (g / ||v||)
-        scale = g[row] / sqrtf(ss);
+        scale = L_.g[row] / sqrtf(ss);   // torch._weight_norm: v * (g / ||v||)
     }
-    for (int i = threadIdx.x; i < in; i += blockDim.x) w[(size_t)row * in + i] = vr[i] * scale;
+    // the folded row, its copy in the retained row-pitched block (pad columns stay zero: the block is cleared first) and the bias
+    for (int i = threadIdx.x; i < in; i += blockDim.x) {
+        const float x = vr[i] * scale;
+        L_.w[(size_t)row * in + i] = x;
+        if (L_.raw_w != nullptr) L_.raw_w[(size_t)row * L_.ld + i] = x;
+    }
+    if (threadIdx.x == 0 && L_.raw_b != nullptr) L_.raw_b[row] = L_.b[row];
 }
 
 // dst fragment order; src row-major [src_rows][src_cols]; transposed: element (row, col) = src[col][row]
@@ -387,13 +401,6 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
                      float* const* w_col, hipStream_t stream, bool eval_only);
 }
 
-__global__ void k_copy_rows(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst, int ld) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= (size_t)rows * cols) return;
-    const int r = (int)(i / cols), c = (int)(i % cols);
-    dst[(size_t)r * ld + c] = src[i];
-}
-
 int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float variance, float scale, int precision,
                  hn_field** out, hipStream_t stream) {
     HN_REQUIRE(out != nullptr && sdf != nullptr && col != nullptr, "null argument");
@@ -433,17 +440,66 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
     pk.stream = stream;
     float* w_sdf[9] = {};
     float* w_col[5] = {};
-    auto fold = [&](const hn_mlp_desc* d, int l, float** dst) -> int {
-        const size_t n = (size_t)d->out_dim[l] * d->in_dim[l];
-        HN_CHECK_HIP(pool_alloc(reinterpret_cast<void**>(dst), n * sizeof(float)));
-        pk.temps.push_back(*dst);
-        hipLaunchKernelGGL(k_fold_weight_norm, dim3(d->out_dim[l]), dim3(256), 0, stream, d->weight_g[l], d->weight_v[l],
-                           d->out_dim[l], d->in_dim[l], *dst);
-        HN_LAUNCH_CHECK();
-        return HN_OK;
-    };
-    for (int l = 0; l < 9 && rc == HN_OK; ++l) rc = fold(sdf, l, &w_sdf[l]);
-    for (int l = 0; l < 5 && rc == HN_OK; ++l) rc = fold(col, l, &w_col[l]);
+    // The retained row-major block (folded matrices with 16-byte aligned rows, biases: what the adjoint path reads) is laid
+    // out first, so that ONE launch folds the weight norm of all 14 layers, writes the folded matrices the packers read and
+    // fills the retained block (it was 14 + 14 launches and 14 copies).
+    {
+        size_t total = 0;
+        auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
+        auto pitch = [](int in) { return (in + 3) & ~3; };   // rows start 16-byte aligned: vector loads in k_dense
+        for (int l = 0; l < 9; ++l) total += pad((size_t)sdf->out_dim[l] * pitch(sdf->in_dim[l])) + pad(sdf->out_dim[l]);
+        for (int l = 0; l < 5; ++l) total += pad((size_t)col->out_dim[l] * pitch(col->in_dim[l])) + pad(col->out_dim[l]);
+        if (pool_alloc(&f->raw, total * sizeof(float)) != hipSuccess) {
+            set_error("hipMalloc of %zu bytes for the folded weights failed", total * sizeof(float));
+            rc = HN_ENOMEM;
+        } else {
+            (void)hipMemsetAsync(f->raw, 0, total * sizeof(float), stream);
+            f->raw_floats = total;
+            PackTable tab;
+            float* q = reinterpret_cast<float*>(f->raw);
+            int max_out = 0;
+            for (int li = 0; li < 14 && rc == HN_OK; ++li) {
+                const bool is_sdf = li < 9;
+                const hn_mlp_desc* d = is_sdf ? sdf : col;
+                const int l = is_sdf ? li : li - 9;
+                const int out = d->out_dim[l], in = d->in_dim[l], ld = pitch(in);
+                float** dst = is_sdf ? &w_sdf[l] : &w_col[l];
+                if (pool_alloc(reinterpret_cast<void**>(dst), (size_t)out * in * sizeof(float)) != hipSuccess) {
+                    set_error("hipMalloc of a folded matrix failed");
+                    rc = HN_ENOMEM;
+                    break;
+                }
+                pk.temps.push_back(*dst);
+                float* raw_w = q;
+                q += pad((size_t)out * ld);
+                float* raw_b = q;
+                q += pad((size_t)out);
+                tab.l[li] = PackLayer{reinterpret_cast<const float*>(d->weight_g[l]), reinterpret_cast<const float*>(d->weight_v[l]),
+                                      reinterpret_cast<const float*>(d->bias[l]), *dst, raw_w, raw_b, out, in, ld};
+                max_out = out > max_out ? out : max_out;
+                if (is_sdf) {
+                    f->sdf_out[l] = out;
+                    f->sdf_in[l] = in;
+                    f->sdf_ld[l] = ld;
+                    f->raw_sdf_w[l] = raw_w;
+                    f->raw_sdf_b[l] = raw_b;
+                } else {
+                    f->col_out[l] = out;
+                    f->col_in[l] = in;
+                    f->col_ld[l] = ld;
+                    f->raw_col_w[l] = raw_w;
+                    f->raw_col_b[l] = raw_b;
+                }
+            }
+            if (rc == HN_OK) {
+                hipLaunchKernelGGL(k_fold_weight_norm_all, dim3(max_out, 14), dim3(256), 0, stream, tab);
+                if (hipGetLastError() != hipSuccess) {
+                    set_error("folding the weight norm failed to launch");
+                    rc = HN_EHIP;
+                }
+            }
+        }
+    }
     // The fp32 kernel family's fragment programs (and the two last-layer biases it keeps on the host) are built for HN_PREC_FP32
     // fields only: an f16x3 field never launches those kernels, and its re-pack -- the per-iteration cost of a training loop --
     // then waits for nothing on the host (the f16x3 kernels read lin8's bias from the retained copy on the device).
@@ -483,53 +539,9 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
         }
     }
     stage("fp32 fragments (sizing pass, allocation, k_pack launches, sync)");
-    if (rc == HN_OK) {   // keep the folded matrices and biases (row-major) for the adjoint path
-        size_t total = 0;
-        auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
-        auto pitch = [](int in) { return (in + 3) & ~3; };   // rows start 16-byte aligned: vector loads in k_dense
-        for (int l = 0; l < 9; ++l) total += pad((size_t)sdf->out_dim[l] * pitch(sdf->in_dim[l])) + pad(sdf->out_dim[l]);
-        for (int l = 0; l < 5; ++l) total += pad((size_t)col->out_dim[l] * pitch(col->in_dim[l])) + pad(col->out_dim[l]);
-        if (pool_alloc(&f->raw, total * sizeof(float)) != hipSuccess) {
-            set_error("hipMalloc of %zu bytes for the folded weights failed", total * sizeof(float));
-            rc = HN_ENOMEM;
-        } else {
-            (void)hipMemsetAsync(f->raw, 0, total * sizeof(float), stream);
-            f->raw_floats = total;
-            float* q = reinterpret_cast<float*>(f->raw);
-            auto keep_mat = [&](const float* src, int out, int in) {
-                const float* dst = q;
-                const int ld = pitch(in);
-                // a kernel, not hipMemcpy2DAsync: the rows are 4-byte aligned only, which the copy engines' rectangle
-                // path handles slowly and erratically (3 - 34 ms per pack of a hand field, measured)
-                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)(((size_t)out * in + 255) / 256)), dim3(256), 0, stream, src, out, in, q, ld);
-                q += pad((size_t)out * ld);
-                return dst;
-            };
-            auto keep_vec = [&](const float* src, size_t n) {
-                const float* dst = q;
-                (void)hipMemcpyAsync(q, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream);
-                q += pad(n);
-                return dst;
-            };
-            for (int l = 0; l < 9; ++l) {
-                f->sdf_out[l] = sdf->out_dim[l];
-                f->sdf_in[l] = sdf->in_dim[l];
-                f->sdf_ld[l] = pitch(sdf->in_dim[l]);
-                f->raw_sdf_w[l] = keep_mat(w_sdf[l], sdf->out_dim[l], sdf->in_dim[l]);
-                f->raw_sdf_b[l] = keep_vec(reinterpret_cast<const float*>(sdf->bias[l]), sdf->out_dim[l]);
-            }
-            for (int l = 0; l < 5; ++l) {
-                f->col_out[l] = col->out_dim[l];
-                f->col_in[l] = col->in_dim[l];
-                f->col_ld[l] = pitch(col->in_dim[l]);
-                f->raw_col_w[l] = keep_mat(w_col[l], col->out_dim[l], col->in_dim[l]);
-                f->raw_col_b[l] = keep_vec(reinterpret_cast<const float*>(col->bias[l]), col->out_dim[l]);
-            }
-            if (fp32_programs && hipStreamSynchronize(stream) != hipSuccess) {   // (f16x3: stream order is all the later launches need)
-                set_error("copying the folded weights failed");
-                rc = HN_EHIP;
-            }
-        }
+    if (rc == HN_OK && fp32_programs && hipStreamSynchronize(stream) != hipSuccess) {   // (f16x3: stream order is all the later launches need)
+        set_error("copying the folded weights failed");
+        rc = HN_EHIP;
     }
     stage("retained row-major matrices");
     if (rc == HN_OK && precision == HN_PREC_F16X3) rc = v2::build_v2_streams(f, sdf, col, w_sdf, w_col, stream, eval_only);
