@@ -79,7 +79,6 @@ void pool_free(void* p) {
     g_pool_live.erase(it);
 }
 
-// effective weight of one layer, row-major [out][in]
 // the per-layer launches of a pack batched into one each (blockIdx.y = layer): a re-pack is a chain of dependent launches
 struct PackLayer {
     const float *g, *v, *b;   // weight_g (or NULL), weight_v, bias of the layer
