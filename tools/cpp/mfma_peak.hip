@@ -45,6 +45,31 @@ __global__ __launch_bounds__(256) void k_mfma(int iters, float* sink, long long*
     }
 }
 
+// the same for v_mfma_f32_32x32x2_f32 (the training backward's launch sequence runs on it): nominal 157.3 TFLOP/s
+__global__ __launch_bounds__(256) void k_mfma_f32(int iters, float* sink) {
+    float a[8], b[8];
+    unsigned x = 7654321u + 7919u * (blockIdx.x * 256u + threadIdx.x);
+    for (int u = 0; u < 8; ++u) {
+        x = x * 1664525u + 1013904223u;
+        a[u] = (float)(int)(x >> 8) * (1.f / 8388608.f) - 1.f;
+        x = x * 1664525u + 1013904223u;
+        b[u] = (float)(int)(x >> 8) * (1.f / 8388608.f) - 1.f;
+    }
+    f32x16 acc[4];
+    for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[(u + t) & 7], acc[t], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < 16; ++i) s += acc[t][i];
+    if (s == 123.456f) sink[0] = s;
+}
+
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 300000;   // ~150 - 300 ms per launch: long enough for the power controller to settle
     hipDeviceProp_t p;
@@ -80,6 +105,21 @@ int main(int argc, char** argv) {
                    wps, ms, tflops, tflops / 2500.0, ghz);
             first = false;
         }
+    }
+    printf("], \"f32_nominal_peak_tflops\": 157.3, \"f32_runs\": [");
+    first = true;
+    for (int rep = 0; rep < 3; ++rep) {
+        const int blocks = cus, it32 = iters / 2;   // 64 cycles per MFMA: half the iterations for the same duration
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_mfma_f32, dim3(blocks), dim3(256), 0, 0, it32, sink);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double tflops = (double)blocks * 4 * it32 * 32 * 4096.0 / (ms * 1e-3) / 1e12;   // 32x32x2 x 2 FLOP per MFMA
+        if (rep == 0) continue;
+        printf("%s{\"ms\": %.3f, \"tflops\": %.1f, \"frac_of_nominal\": %.3f}", first ? "" : ", ", ms, tflops, tflops / 157.3);
+        first = false;
     }
     printf("]}\n");
     return 0;
