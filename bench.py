@@ -148,7 +148,8 @@ def render_c1(ren, sc, lib_mod):
     o, d = torch.empty(B, 3, device=sc['xy'].device), torch.empty(B, 3, device=sc['xy'].device)
     lib_mod.check(lib.hn_ray_gen(lib_mod.ptr(sc['xy']), lib_mod.ptr(sc['R']), lib_mod.ptr(sc['T']), lib_mod.ptr(sc['focal']),
                                  lib_mod.ptr(sc['principal']), 1, B, lib_mod.ptr(o), lib_mod.ptr(d), lib_mod.stream_ptr()), 'hn_ray_gen')
-    return ren.render(o, d, NEAR, FAR, None, None, None, sc['Ro'], sc['To'], 0, t_rand=sc['t_rand'])
+    with torch.no_grad():      # `--mode test`: no graph (NeuSRenderer.render is differentiable when the caller can differentiate it)
+        return ren.render(o, d, NEAR, FAR, None, None, None, sc['Ro'], sc['To'], 0, t_rand=sc['t_rand'])
 
 
 def time_c1(dev, precision, with_cpu):
@@ -187,11 +188,33 @@ OBJ_FLOP_PER_SAMPLE = 2.0 * (2 * 524544 + 292864)
 HAND_SDF_FLOP, OBJ_SDF_FLOP = 2.0 * 1234176, 2.0 * 524544
 
 
-def fit_step_flop(n_rays, S=FIT_N + 2 * FIT_IMP):
-    final = n_rays * S * (HAND_FLOP_PER_SAMPLE + OBJ_FLOP_PER_SAMPLE)
-    adjoint = n_rays * S * (HAND_FLOP_PER_SAMPLE + OBJ_FLOP_PER_SAMPLE + 2.0 * 2 * 257 * 256)
-    sampling = n_rays * (FIT_N + 3 * (FIT_IMP // 4)) * (HAND_SDF_FLOP + OBJ_SDF_FLOP)
+def fit_step_flop(n_rays, S=FIT_N + 2 * FIT_IMP, hand_final=None, hand_coarse=None):
+    """Algorithmic FLOP of one fitting_single step.  hand_final / hand_coarse: the samples the hand field EXECUTES in the final
+    evaluation (+ its adjoint) and in the coarse sdf pass when the exact far-field skip is on (None: every sample, "dense")."""
+    n_final = n_rays * S
+    hf = n_final if hand_final is None else hand_final
+    hc = n_rays * FIT_N if hand_coarse is None else hand_coarse
+    final = hf * HAND_FLOP_PER_SAMPLE + n_final * OBJ_FLOP_PER_SAMPLE
+    adjoint = hf * (HAND_FLOP_PER_SAMPLE + 2.0 * 257 * 256) + n_final * (OBJ_FLOP_PER_SAMPLE + 2.0 * 257 * 256)
+    sampling = (hc + n_rays * 3 * (FIT_IMP // 4)) * HAND_SDF_FLOP + n_rays * (FIT_N + 3 * (FIT_IMP // 4)) * OBJ_SDF_FLOP
     return final + adjoint + sampling
+
+
+def executed_hand_samples(ren, n_rays):
+    """(final evaluation, coarse pass): the hand samples the LAST differentiable render of `ren` evaluated, read from the compaction
+    records it left on the device (hn_render_dual_compact_offsets); None where that launch ran dense."""
+    import ctypes
+    from honerf_amd import lib as L
+    lib = L.load()
+    hand, obj = ren.fields()
+    offs = (ctypes.c_size_t * 2)()
+    L.check(lib.hn_render_dual_compact_offsets(hand.handle, obj.handle, n_rays, ren.n_samples, ren.n_importance, ren.up_sample_steps, offs),
+            'hn_render_dual_compact_offsets')
+    none = ctypes.c_size_t(-1).value
+    out = []
+    for off, buf in ((offs[0], ren._tape.buf), (offs[1], ren._ws.buf)):
+        out.append(None if (off == none or buf is None) else int(buf[off:off + 4].view(torch.int32).item()))
+    return tuple(out)
 
 
 def build_fit_nets(dev, n_frames, precision):
@@ -239,11 +262,17 @@ def build_fit(dev, seed, n_frames, rays, precision, halo=False):
     return ren, nets, chain, views, verts[None].expand(n_frames, -1, -1).contiguous()
 
 
-def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, windows_per_rank=2):
+C4_FRAMES = 8        # BASELINE configs[3]: the 8-frame batch of fitting_single fit_12_8views, the SAME eight frames at every N
+C5_FRAMES = 32       # a 32-frame sequence, 29 sliding windows, 5 passes, the SAME sequence at every N
+
+
+def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, windows_per_rank=2, quick=False):
     """The fitting half of BASELINE's metric.  Per-step times (every rank its own frame / window, no collective, max over
-    ranks) on the reference's six-leaf pose chain, then the two sharded loops as the product runs them:
-    C4 `fit_frames_sharded` (one fit_12 frame per rank, all 25 x 8 steps) and C5 `fit_sequence_video` (a sequence of
-    3 + windows_per_rank x world frames, `outer_iters` passes, window-parallel with the pose-gradient all-reduce per step)."""
+    ranks) on the reference's six-leaf pose chain, then the two sharded loops as the product runs them, on workloads that do
+    not depend on the number of GPUs (strong scaling: the N = 1, 2, 4, 8 lines fit the same frames):
+    C4 `fit_frames_sharded`: the same C4_FRAMES fit_12 frames dealt out over the ranks (all 25 x 8 steps of each);
+    C5 `fit_sequence_video`: the same C5_FRAMES-frame sequence, `outer_iters` passes over its 29 windows, window-parallel with
+    the pose-gradient all-reduce per step.  (`video_1234_weak`: the round-3 variant, 3 + windows_per_rank x world frames.)"""
     from honerf_amd import fitting as F
     res = {}
 
@@ -275,6 +304,16 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
         sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, ft))
         res['single_' + ft] = {'ms_per_step': sec * 1e3, 'steps_per_frame': STEPS_PER_FRAME[ft],
                                'frames_per_s': world / (STEPS_PER_FRAME[ft] * sec), 'pose_chain': 'halo (six refine leaves, hn_pose_chain)'}
+    # what the hand field executed in those steps (the exact far-field skip): mean over the 8 views of the live-sample counts
+    live = []
+    for v in range(8):
+        F.fit_backward(ren, views[v], chain, NEAR, FAR, '12')
+        torch.cuda.synchronize()
+        live.append(executed_hand_samples(ren, FIT_RAYS))
+    mean_of = lambda k: (None if any(x[k] is None for x in live) else float(np.mean([x[k] for x in live])))
+    res['single_12']['hand_samples_executed'] = {'final_evaluation': mean_of(0), 'coarse_pass': mean_of(1),
+                                                  'of': [FIT_RAYS * (FIT_N + 2 * FIT_IMP), FIT_RAYS * FIT_N],
+                                                  'what': 'mean over the 8 views of the device-side counts of the compacted launches (live samples + 1)'}
     # the same step with every sample of the hand field evaluated ("dense": NeuSRenderer_fitting.compact_far_field = False; the
     # default skips the samples whose bone masks are all exactly 0 -- bit-identical outputs)
     ren.compact_far_field = False
@@ -287,22 +326,28 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
     res['single_12_rigid_chain'] = {'ms_per_step': sec * 1e3, 'what': 'secondary: palm + object motion only (RigidPoseChain)'}
     single = (ren, nets, chain_r, views)
 
-    # ---- C4: fit_12 frames sharded one per rank, the whole 25 x 8-step loop of every frame ---------------------------
+    # ---- C4: the same C4_FRAMES fit_12 frames at every N, dealt out over the ranks, the whole 25 x 8-step loop of every frame ------
+    n_c4 = 2 if quick else C4_FRAMES
+
     def make_frame(f):
         ch, jf, _ = build_fit_data(dev, 140 + f, 1, halo=True)
         return F.synthetic_views(8, 1, FIT_RAYS, 140 + f, jf[9], device=dev), ch
-    made = {f: make_frame(f) for f in F.shard_frames(world, rank, world)}           # data "loading" is not timed
-    dt, red = wall(lambda: F.fit_frames_sharded(ren, world, lambda f: made[f], NEAR, FAR, '12', dist=dist))
+    made = {f: make_frame(f) for f in F.shard_frames(n_c4, rank, world)}           # data "loading" is not timed
+    dt, red = wall(lambda: F.fit_frames_sharded(ren, n_c4, lambda f: made[f], NEAR, FAR, '12', dist=dist))
     res['frames_sharded_12'] = {'frames': red['frames'], 'steps_per_frame': STEPS_PER_FRAME['12'], 'seconds': dt,
-                                'frames_per_s': red['frames'] / dt, 'ms_per_step': dt / STEPS_PER_FRAME['12'] * 1e3,
+                                'frames_per_s': red['frames'] / dt, 'ms_per_step': dt / (STEPS_PER_FRAME['12'] * max(len(made), 1)) * 1e3,
+                                'frames_per_rank': len(made), 'scaling': 'strong (the same %d frames at every N)' % n_c4,
                                 'collectives': 'one SUM all-reduce of %d loss values at the end' % len(F.LOSS_KEYS), 'loss_mean': red['loss'],
-                                'what': 'C4: fitting_single fit_12_8views, one frame per GPU, fit_frames_sharded end to end'}
+                                'what': 'C4: fitting_single fit_12_8views, %d frames dealt out over the GPUs, fit_frames_sharded end to end' % n_c4}
 
     # ---- C5 per step (one window per rank, no collective) ---------------------------------------------------------
     renb, netsb = build_fit_nets(dev, VID_FRAMES, precision)
+
+    def sequence(data_num):
+        chain_s, j_s, v_s = build_fit_data(dev, 60, data_num, halo=True, drift=0.002)      # the SAME sequence on every rank
+        return chain_s, j_s, v_s[None].expand(VID_FRAMES, -1, -1).contiguous()
     data_num = 3 + windows_per_rank * world
-    chainb, jb, vb = build_fit_data(dev, 60, data_num, halo=True, drift=0.002)      # the SAME sequence on every rank
-    ov = vb[None].expand(VID_FRAMES, -1, -1).contiguous()
+    chainb, jb, ov = sequence(data_num)
     optb = F.make_optimizer(chainb, video=True)
     wins = F.sliding_windows(data_num)
     my = wins[rank % len(wins)]
@@ -313,22 +358,28 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
                               'what': 'one window per rank, no collective (the N = 1 step)'}
 
     # ---- C5: the sequence loop, window-parallel, pose-gradient all-reduce between backward and Adam --------------------
-    chains, _, _ = build_fit_data(dev, 60, data_num, halo=True, drift=0.002)
-    per_window = {tuple(w): F.synthetic_views(8, VID_FRAMES, VID_RAYS, 300 + w[0], jb[9], device=dev)
-                  for w in F.window_schedule(data_num, rank, world) if w is not None}
+    def run_sequence(n_frames, passes, what):
+        chains, js, ovs = sequence(n_frames)
+        per_window = {tuple(w): F.synthetic_views(8, VID_FRAMES, VID_RAYS, 300 + w[0], js[9], device=dev)
+                      for w in F.window_schedule(n_frames, rank, world) if w is not None}          # data "loading" is not timed
 
-    def window_views(index, vid, step):
-        return per_window[tuple(index)][vid]
-    window_views.n_views = 8
-    dt, st = wall(lambda: F.fit_sequence_video(renb, window_views, chains, NEAR, FAR, data_num, '1234', outer_iters=outer_iters, obj_verts=ov,
-                                               dist=dist))
-    n_win = len(wins)
-    res['video_1234'] = {'ms_per_step': dt / st['steps'] * 1e3, 'steps': st['steps'], 'data_num': data_num, 'windows': n_win, 'outer_iters': outer_iters,
-                         'seconds': dt, 'windows_per_s': n_win * outer_iters / dt, 'frames_per_s': data_num / dt,
-                         'allreduce_calls': st['allreduce_calls'], 'allreduce_floats_per_step': st['allreduce_floats'] // max(st['allreduce_calls'], 1),
-                         'efficiency_vs_unsynced_step': sec_v / (dt / st['steps']), 'pose_chain': 'halo (six refine leaves, hn_pose_chain)',
-                         'what': 'C5: fitting_video fit_1234_8views over a %d-frame sequence (%d windows per rank and pass), fit_sequence_video: '
-                                 'window-parallel, one SUM all-reduce of the data_num x 45 pose-gradient block per step' % (data_num, windows_per_rank)}
+        def window_views(index, vid, step):
+            return per_window[tuple(index)][vid]
+        window_views.n_views = 8
+        dt, st = wall(lambda: F.fit_sequence_video(renb, window_views, chains, NEAR, FAR, n_frames, '1234', outer_iters=passes, obj_verts=ovs,
+                                                   dist=dist))
+        n_win = len(F.sliding_windows(n_frames))
+        return {'ms_per_step': dt / st['steps'] * 1e3, 'steps': st['steps'], 'data_num': n_frames, 'windows': n_win, 'outer_iters': passes,
+                'seconds': dt, 'windows_per_s': n_win * passes / dt, 'frames_per_s': n_frames / dt,
+                'allreduce_calls': st['allreduce_calls'], 'allreduce_floats_per_step': st['allreduce_floats'] // max(st['allreduce_calls'], 1),
+                'efficiency_vs_unsynced_step': sec_v / (dt / st['steps']), 'pose_chain': 'halo (six refine leaves, hn_pose_chain)', 'what': what}
+    n_c5 = 8 if quick else C5_FRAMES
+    res['video_1234'] = run_sequence(n_c5, 1 if quick else outer_iters,
+                                     'C5: fitting_video fit_1234_8views over the SAME %d-frame sequence at every N (strong scaling over its %d windows; rounds of '
+                                     '`world` concurrent windows), fit_sequence_video: one SUM all-reduce of the data_num x 45 pose-gradient block per step'
+                                     % (n_c5, n_c5 - 3))
+    res['video_1234_weak'] = run_sequence(data_num, 1 if quick else outer_iters,
+                                          'secondary (round 3\'s workload): a %d-frame sequence = %d windows per rank and pass' % (data_num, windows_per_rank))
     return res, single
 
 
@@ -364,18 +415,28 @@ def cpu_fit_baseline(single, rays=49, threads=32):
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of the dominant kernel, from the committed PMC summary of this same workload
     (profiles/r*/pmc_bench_*.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc passes,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot collect counters itself;
-    the newest summary for this kernel is quoted, or None."""
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot collect counters itself; the newest
+    summary for this kernel is quoted ONLY IF it was collected on the kernel sources of this tree (tools/pmc_summary.py stamps
+    their hash, tools/srchash.py): a summary of other sources is reported as stale, not as `traffic`.
+    -> (bytes or None, source path or None, note or None)"""
     import glob
-    best = (None, None)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import srchash
+    now = srchash.source_hash()
+    newest = None
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'pmc_bench_*.json'))):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         if (kernel in str(d.get('kernel')) or kernel.replace('<1>', '<true>') in str(d.get('kernel'))) and 'derived' in d and 'hbm_bytes_per_launch' in d['derived']:
-            best = (d['derived']['hbm_bytes_per_launch'], os.path.relpath(path, ROOT))
-    return best
+            newest = (d['derived']['hbm_bytes_per_launch'], os.path.relpath(path, ROOT), d.get('csrc_sha16'))
+    if newest is None:
+        return None, None, 'no PMC summary of this kernel is committed'
+    if newest[2] != now:
+        return None, newest[1], ('STALE: %s was collected on kernel sources %s, this tree is %s (%.4g bytes per launch there); re-run tools/profile_bench.sh'
+                                 % (newest[1], newest[2] or 'unstamped', now, newest[0]))
+    return newest[0], newest[1], 'collected on the kernel sources of this tree (csrc_sha16 %s)' % now
 
 
 def spawn_command(n_gpus, argv):
@@ -403,6 +464,7 @@ def main():
     ap.add_argument('--no-training', action='store_true', help='skip the training-iteration measurement')
     ap.add_argument('--fit-steps', type=int, default=80, help='timed steps per fitting leg (after 10 untimed ones)')
     ap.add_argument('--fit-outer', type=int, default=5, help='passes over the video sequence (fitting_video.py:157: 5)')
+    ap.add_argument('--fit-quick', action='store_true', help='functional check of the fitting legs: 2 frames, an 8-frame sequence, one pass')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -425,11 +487,24 @@ def main():
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        if share:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=dev)
+        backend = 'gloo' if share else 'nccl'
+        try:
+            # an explicit, generous timeout: the fitting legs below keep the ranks apart for tens of seconds between collectives
+            if share:
+                dist.init_process_group('gloo', timeout=datetime.timedelta(minutes=20))
+            else:
+                dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(minutes=20))
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)                # the first collective builds the communicator: fail here, with a message, not mid-run
+            torch.cuda.synchronize()
+            assert int(probe.item()) == world
+        except Exception as e:
+            sys.stderr.write('bench.py: rank %d could not bring up the %s process group of %d ranks on 127.0.0.1 (%s: %s).  RCCL needs one visible GPU per '
+                             'rank and HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool; HONERF_BENCH_SHARE_GPU=1 runs the N > 1 code path on ONE GPU over gloo '
+                             '(functional check only).\n' % (rank, backend, world, type(e).__name__, e))
+            sys.exit(3)
 
     from honerf_amd import lib as L
     lib = L.load()
@@ -441,8 +516,9 @@ def main():
     def step():
         L.check(lib.hn_ray_gen(L.ptr(sc['xy']), L.ptr(sc['R']), L.ptr(sc['T']), L.ptr(sc['focal']),
                                L.ptr(sc['principal']), 1, B, L.ptr(rays_o), L.ptr(rays_d), L.stream_ptr()), 'hn_ray_gen')
-        return ren.render(rays_o, rays_d, NEAR, FAR, sc['bt_inv'], sc['T_pose'], None, None, None, 0,
-                          t_rand=sc['t_rand'])
+        with torch.no_grad():      # offline rendering: the plain launch sequence, nothing kept for a backward pass
+            return ren.render(rays_o, rays_d, NEAR, FAR, sc['bt_inv'], sc['T_pose'], None, None, None, 0,
+                              t_rand=sc['t_rand'])
 
     for _ in range(args.warmup):
         out = step()
@@ -464,6 +540,18 @@ def main():
         dt = float(tt.item())
     samples_per_step = B * N_SAMPLES
     value = world * samples_per_step * args.steps / dt
+
+    # ---- the fitting loops: every leg that has a collective runs HERE, on all ranks; after it the process group is torn down and
+    #      rank 0 alone takes the secondary measurements (no rank waits in a collective while rank 0 times a CPU oracle)
+    fitting, single = None, None
+    if not args.no_fitting and args.precision == 'f16x3':
+        fitting, single = time_fit(dev, dist, rank, world, args.precision, args.fit_steps, 10, args.fit_outer, quick=args.fit_quick)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+    if rank != 0:
+        return
 
     # ---- dominant kernel alone (k_field_hand<true>), HIP events on the launch stream ----------
     field = ren.field()
@@ -525,7 +613,7 @@ def main():
     # ---- secondary figure (BASELINE configs[1] names "bf16"): the same step with precision = 'f16' -- hidden SDF layers and
     #      reverse sweep on ONE f16 MFMA per product (HN_PREC_F16) -- with its measured difference from the headline frame
     f16 = None
-    if args.precision == 'f16x3' and not args.no_f16 and rank == 0:
+    if args.precision == 'f16x3' and not args.no_f16:
         ref_col, ref_ws = out['color_fine'].clone(), out['weight_sum'].clone()
         ren.precision = 'f16'
         o16 = step()
@@ -549,23 +637,30 @@ def main():
     else:
         peak, kname, dtype = PEAK_F32_MFMA_TFLOPS, 'hn::k_field_hand<true>', 'f32'
 
-    traffic, traffic_src = pmc_traffic(kname)
-    fitting = None
-    if not args.no_fitting and args.precision == 'f16x3':
-        fitting, single = time_fit(dev, dist, rank, world, args.precision, args.fit_steps, 10, args.fit_outer)
+    traffic, traffic_src, traffic_note = pmc_traffic(kname)
+    if fitting is not None:
+        # `roofline`: priced on the FLOP the step EXECUTES (the hand field runs on the samples with a live bone mask: the counts are
+        # read from the compaction records of the timed configuration); `roofline_dense`: the same step with every sample evaluated
+        # (single_12_dense), priced on the dense FLOP
+        f16x3_peak = PEAK_F16_MFMA_TFLOPS / 3.0
+        ex = fitting['single_12']['hand_samples_executed']
         sec = fitting['single_12']['ms_per_step'] * 1e-3
-        flop = fit_step_flop(FIT_RAYS)
-        fitting['roofline'] = {'bound': 'mfma', 'what': 'one fitting_single step (fit type 12), all kernels', 'flop_per_step': flop,
-                               'achieved': flop / sec / 1e12, 'peak': PEAK_F16_MFMA_TFLOPS / 3.0, 'unit': 'TFLOP/s',
-                               'frac': flop / sec / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0)}
+        flop = fit_step_flop(FIT_RAYS, hand_final=ex['final_evaluation'], hand_coarse=ex['coarse_pass'])
+        fitting['roofline'] = {'bound': 'mfma', 'what': 'one fitting_single step (fit type 12), all kernels; FLOP of the samples the step executes '
+                                                        '(exact far-field skip of the hand field on)', 'flop_per_step': flop,
+                               'achieved': flop / sec / 1e12, 'peak': f16x3_peak, 'unit': 'TFLOP/s', 'frac': flop / sec / 1e12 / f16x3_peak}
+        sec_d = fitting['single_12_dense']['ms_per_step'] * 1e-3
+        flop_d = fit_step_flop(FIT_RAYS)
+        fitting['roofline_dense'] = {'bound': 'mfma', 'what': 'the same step with every sample evaluated (single_12_dense)', 'flop_per_step': flop_d,
+                                     'achieved': flop_d / sec_d / 1e12, 'peak': f16x3_peak, 'unit': 'TFLOP/s', 'frac': flop_d / sec_d / 1e12 / f16x3_peak}
         fitting['n_gpus'] = world
-        fitting['config'] = ('C3/C4: fitting_single, %d rays x %d shared depths, both fields, 8 synthetic views, the reference\'s six-leaf pose chain; '
-                             'C5: fitting_video windows of %d frames x %d rays, fit type 1234, windows sharded over the GPUs with the pose-gradient all-reduce'
-                             % (FIT_RAYS, FIT_N + 2 * FIT_IMP, VID_FRAMES, VID_RAYS))
-        if rank == 0 and not args.no_cpu_baseline:
+        fitting['config'] = ('C3/C4: fitting_single, %d rays x %d shared depths, both fields, 8 synthetic views, the reference\'s six-leaf pose chain, %d frames; '
+                             'C5: fitting_video windows of %d frames x %d rays over a %d-frame sequence, fit type 1234, windows sharded over the GPUs with the '
+                             'pose-gradient all-reduce' % (FIT_RAYS, FIT_N + 2 * FIT_IMP, C4_FRAMES, VID_FRAMES, VID_RAYS, C5_FRAMES))
+        if not args.no_cpu_baseline:
             fitting['cpu_baseline'] = cpu_fit_baseline(single)
     training = None
-    if rank == 0 and not args.no_training and args.precision == 'f16x3':
+    if not args.no_training and args.precision == 'f16x3':
         # one iteration of exp_runner.train (render, loss, backward into every network parameter, Adam,
         # re-pack) at the reference's batch (confs: 441 rays, 64 + 64 samples); secondary to the headline
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
@@ -573,12 +668,12 @@ def main():
         training = {k: train_step_bench.measure(k, dev, 441, 10, 3, args.precision) for k in ('obj', 'hand')}
         # secondary: the hand iteration with every sample evaluated (the product's default aggregates the far field exactly)
         training['hand_dense'] = train_step_bench.measure('hand', dev, 441, 10, 3, args.precision, compact=False)
-    c1 = time_c1(dev, args.precision, not args.no_cpu_baseline) if rank == 0 and not args.no_c1 else None
+    c1 = time_c1(dev, args.precision, not args.no_cpu_baseline) if not args.no_c1 else None
     # ---- the rate the matrix pipe SUSTAINS on this box (hn_debug_mfma_probe: a kernel of nothing but f16 MFMAs on random
     #      operands, ~0.2 s per launch so that the power controller settles): the chip is power-limited well below the
     #      guide's 2.4 GHz figure, so the roofline entry states the fraction of this measured rate beside the nominal one
     sustained = None
-    if rank == 0 and args.precision == 'f16x3' and not share:
+    if args.precision == 'f16x3' and not share:
         import ctypes
         flop = ctypes.c_double(0.0)
         iters = 300000
@@ -590,50 +685,46 @@ def main():
         p1.record()
         torch.cuda.synchronize()
         sustained = 2.0 * flop.value / (p0.elapsed_time(p1) * 1e-3) / 1e12        # TFLOP/s of issued f16 MFMA
-    if rank == 0:
-        res = {
-            'metric': 'ray-samples/sec/GPU (512x512x64)', 'value': value, 'unit': 'ray-samples/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
-            'config': {'workload': 'C2: hand nets (conf size, random init), 512x512 rays x 64 samples, '
-                                   'n_importance=0, dense (no far-field culling), one frame per GPU',
-                       'rays': B, 'samples_per_ray': N_SAMPLES, 'frames_per_step': world},
-            'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': achieved,
-                         'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': kernel_ms,
-                         'flop_per_launch': n * HAND_FLOP_PER_SAMPLE,
-                         'mfma_issued_tflops': achieved * (3.0 if args.precision == 'f16x3' else 1.0),
-                         'mfma_peak_tflops': PEAK_F16_MFMA_TFLOPS if args.precision == 'f16x3' else PEAK_F32_MFMA_TFLOPS},
-            'weight_sum_mean': float(out['weight_sum'].mean()),
-        }
-        if sustained is not None:
-            # `peak` / `frac` above are the guide's nominal figures, as the contract asks; these two are measured in this run
-            res['roofline']['mfma_sustained_tflops'] = sustained
-            res['roofline']['frac_of_sustained'] = achieved * 3.0 / sustained
-            res['roofline']['sustained_what'] = ('hn_debug_mfma_probe: v_mfma_f32_32x32x16_f16 alone on random operands, one wave per SIMD on every CU, '
-                                                  '2 x 0.2 s: the rate the power-limited matrix pipe holds on this box')
-        if share:
-            res['note'] = 'HONERF_BENCH_SHARE_GPU=1: all ranks on ONE device over gloo -- functional check only, timings are not a measurement'
-        if c1 is not None:
-            res['c1'] = c1
-        if fitting is not None:
-            res['fitting'] = fitting
-        if training is not None:
-            res['training'] = training
-        if f16 is not None:
-            res['value_f16'] = f16['value']      # secondary: never the headline (config C2 names bf16; parity needs fp32-equivalence)
-            res['f16_mode'] = f16
-        if culled is not None:
-            res['value_culled'] = culled   # rank 0's frame, far-field early-out on (bit-identical output)
-        if compact is not None:
-            res['value_compact'] = compact['value']   # rank 0's frame, sample-level far-field skip on (bit-identical output)
-            res['compact_bit_identical_to_dense'] = compact['bit_identical_to_dense']
-        if not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(sdf, col, sc, args.cpu_crop)
-        print(json.dumps(res))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    res = {
+        'metric': 'ray-samples/sec/GPU (512x512x64)', 'value': value, 'unit': 'ray-samples/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+        'config': {'workload': 'C2: hand nets (conf size, random init), 512x512 rays x 64 samples, '
+                               'n_importance=0, dense (no far-field culling), one frame per GPU',
+                   'rays': B, 'samples_per_ray': N_SAMPLES, 'frames_per_step': world},
+        'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': achieved,
+                     'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                     'traffic': traffic, 'traffic_source': traffic_src, 'traffic_note': traffic_note, 'kernel_ms': kernel_ms,
+                     'flop_per_launch': n * HAND_FLOP_PER_SAMPLE,
+                     'mfma_issued_tflops': achieved * (3.0 if args.precision == 'f16x3' else 1.0),
+                     'mfma_peak_tflops': PEAK_F16_MFMA_TFLOPS if args.precision == 'f16x3' else PEAK_F32_MFMA_TFLOPS},
+        'weight_sum_mean': float(out['weight_sum'].mean()),
+    }
+    if sustained is not None:
+        # `peak` / `frac` above are the guide's nominal figures, as the contract asks; these two are measured in this run
+        res['roofline']['mfma_sustained_tflops'] = sustained
+        res['roofline']['frac_of_sustained'] = achieved * 3.0 / sustained
+        res['roofline']['sustained_what'] = ('hn_debug_mfma_probe: v_mfma_f32_32x32x16_f16 alone on random operands, one wave per SIMD on every CU, '
+                                              '2 x 0.2 s: the rate the power-limited matrix pipe holds on this box')
+    if share:
+        res['note'] = 'HONERF_BENCH_SHARE_GPU=1: all ranks on ONE device over gloo -- functional check only, timings are not a measurement'
+    if c1 is not None:
+        res['c1'] = c1
+    if fitting is not None:
+        res['fitting'] = fitting
+    if training is not None:
+        res['training'] = training
+    if f16 is not None:
+        res['value_f16'] = f16['value']      # secondary: never the headline (config C2 names bf16; parity needs fp32-equivalence)
+        res['f16_mode'] = f16
+    if culled is not None:
+        res['value_culled'] = culled   # rank 0's frame, far-field early-out on (bit-identical output)
+    if compact is not None:
+        res['value_compact'] = compact['value']   # rank 0's frame, sample-level far-field skip on (bit-identical output)
+        res['compact_bit_identical_to_dense'] = compact['bit_identical_to_dense']
+    if not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(sdf, col, sc, args.cpu_crop)
+    print(json.dumps(res))
 
 
 if __name__ == '__main__':

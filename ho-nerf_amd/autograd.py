@@ -54,6 +54,10 @@ class DualRenderFn(torch.autograd.Function):
         ctx.tape, ctx.tape_serial = o['tape'], renderer._tape_serial
         ctx.renderer, ctx.near, ctx.far = renderer, float(near), float(far)
         hand, obj = renderer.fields()
+        # The backward pass runs on THESE packed fields: the tape's layout (hand samples + the far-field stand-in, the compaction
+        # record behind it) follows the hand field's compaction setting at the time of this render, and a renderer whose
+        # `compact_far_field` / precision / parameters change before the backward pass builds new fields.
+        ctx.fields, ctx.compaction = (hand, obj), bool(getattr(hand, 'compaction', False))
         lib = _lib.load()
         N = rays_o.shape[0] * rays_o.shape[1]
         S = o['z_vals'].shape[-1]
@@ -87,7 +91,10 @@ class DualRenderFn(torch.autograd.Function):
         ren = ctx.renderer
         rays_o, rays_d, bt, tp, Ro, To, z, sdf_h, sdf_o, grad_h, grad_o = ctx.saved_tensors
         rgb_h, rgb_o, alpha_h, alpha_o = ctx.aux.t
-        hand, obj = ren.fields()
+        hand, obj = ctx.fields
+        if bool(getattr(hand, 'compaction', False)) != ctx.compaction:
+            raise RuntimeError('the hand field\'s far-field compaction was switched between a render and its backward pass: '
+                               'the tape of that render cannot be read with the other setting')
         F, P = rays_o.shape[0], rays_o.shape[1]
         N, S = F * P, z.shape[-1]
         n = N * S

@@ -242,6 +242,25 @@ __constant__ float c_cutoff_api[21] = {0.08f, 0.03f, 0.03f, 0.02f, 0.02f, 0.03f,
 // samples of one frame stay together and a wave's 32 samples share their pose except at the frame boundaries).
 // idx[k]: dense index of compact slot k; pos[i]: compact slot of sample i or -1.
 constexpr int COMPACT_SPB = 2048;
+// the classification of one sample: live unless every bone mask is certainly exactly 0
+__device__ __forceinline__ bool hand_sample_live(const float* __restrict__ pts, int i, const float* __restrict__ bt_inv,
+                                                 const float* __restrict__ T_pose, int n_frames, int pts_per_frame) {
+    const float p0 = pts[3 * (size_t)i], p1 = pts[3 * (size_t)i + 1], p2 = pts[3 * (size_t)i + 2];
+    int frame = i / pts_per_frame;
+    frame = frame < n_frames ? frame : n_frames - 1;
+    const float* M = bt_inv + (size_t)frame * 21 * 16;
+    const float* T = T_pose + (size_t)frame * 21 * 3;
+    bool live = false;
+    for (int b = 0; b < 21; ++b) {
+        const float* m = M + 16 * b;
+        const float q0 = m[0] * p0 + m[1] * p1 + m[2] * p2 + m[3] - T[3 * b];
+        const float q1 = m[4] * p0 + m[5] * p1 + m[6] * p2 + m[7] - T[3 * b + 1];
+        const float q2 = m[8] * p0 + m[9] * p1 + m[10] * p2 + m[11] - T[3 * b + 2];
+        const float v = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+        live = live || !(200.f * (v - c_cutoff_api[b]) > 20.f);   // (a NaN coordinate counts as live)
+    }
+    return live;
+}
 // pass 1 (one sample per thread): pos[i] = 1 (live) / 0, counts[b] = live samples of the 256-sample block b
 __global__ __launch_bounds__(256) void k_hand_live_count(const float* __restrict__ pts, int n, const float* __restrict__ bt_inv,
                                                          const float* __restrict__ T_pose, int n_frames, int pts_per_frame,
@@ -250,19 +269,7 @@ __global__ __launch_bounds__(256) void k_hand_live_count(const float* __restrict
     const int i = blockIdx.x * 256 + threadIdx.x;
     bool live = false;
     if (i < n) {
-        const float p0 = pts[3 * (size_t)i], p1 = pts[3 * (size_t)i + 1], p2 = pts[3 * (size_t)i + 2];
-        int frame = i / pts_per_frame;
-        frame = frame < n_frames ? frame : n_frames - 1;
-        const float* M = bt_inv + (size_t)frame * 21 * 16;
-        const float* T = T_pose + (size_t)frame * 21 * 3;
-        for (int b = 0; b < 21; ++b) {
-            const float* m = M + 16 * b;
-            const float q0 = m[0] * p0 + m[1] * p1 + m[2] * p2 + m[3] - T[3 * b];
-            const float q1 = m[4] * p0 + m[5] * p1 + m[6] * p2 + m[7] - T[3 * b + 1];
-            const float q2 = m[8] * p0 + m[9] * p1 + m[10] * p2 + m[11] - T[3 * b + 2];
-            const float v = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
-            live = live || !(200.f * (v - c_cutoff_api[b]) > 20.f);   // (a NaN coordinate counts as live)
-        }
+        live = hand_sample_live(pts, i, bt_inv, T_pose, n_frames, pts_per_frame);
         pos[i] = live ? 1 : 0;
     }
     const int c = __popcll(__ballot(live));
@@ -271,19 +278,56 @@ __global__ __launch_bounds__(256) void k_hand_live_count(const float* __restrict
     if (threadIdx.x == 0) counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 // pass 2: slots in dense order; the last block appends the far sample behind the M live ones and writes n_dev = M + 1, the
-// sample count the field kernels read
+// sample count the field kernels read.  The far sample -- the stand-in whose outputs every skipped sample receives -- is
+// the FIRST DEAD SAMPLE of the launch itself (classified by the predicate above, under its own frame's pose: idx[M] is its
+// dense index, which is where the field kernels take a compact sample's frame from), so that it is dead by construction
+// whatever the scene's scale or frame of reference; a launch without a dead sample has nobody to stand in for and gets a
+// placeholder that nothing reads.
 __global__ __launch_bounds__(256) void k_hand_compact_write(const float* __restrict__ pts, int n, const int* __restrict__ counts,
                                                             int* __restrict__ idx, int* __restrict__ pos, float* __restrict__ pts_c,
-                                                            int* __restrict__ n_dev) {
+                                                            int* __restrict__ n_dev, const float* __restrict__ bt_inv,
+                                                            const float* __restrict__ T_pose, int n_frames, int pts_per_frame) {
     __shared__ int red[4];
     __shared__ int wcnt[2][4];
+    __shared__ int far_blk[4], far_lane[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool last = blockIdx.x == gridDim.x - 1;
     int part = 0;   // live samples in front of this block: the counts of its (COMPACT_SPB / 256) x blockIdx.x preceding 256-sample blocks
     for (int t = threadIdx.x; t < (int)blockIdx.x * (COMPACT_SPB / 256); t += 256) part += counts[t];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
     if (lane == 0) red[wave] = part;
+    int first_dead_blk = 0x7fffffff;   // (last block) the first 256-sample block of pass 1 that holds a dead sample
+    if (last) {
+        const int n256 = (n + 255) / 256;
+        for (int t = threadIdx.x; t < n256; t += 256) {
+            const int valid = n - t * 256 < 256 ? n - t * 256 : 256;
+            if (counts[t] < valid) first_dead_blk = first_dead_blk < t ? first_dead_blk : t;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int other = __shfl_xor(first_dead_blk, o, 64);
+            first_dead_blk = first_dead_blk < other ? first_dead_blk : other;
+        }
+        if (lane == 0) far_blk[wave] = first_dead_blk;
+    }
     __syncthreads();
+    int far_i = -1;
+    if (last) {
+        int b = far_blk[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) b = b < far_blk[w] ? b : far_blk[w];
+        if (b != 0x7fffffff) {   // re-classify that block's samples (pos[] may already hold another block's slots): first dead one
+            const int i = b * 256 + threadIdx.x;
+            const bool dead = i < n && !hand_sample_live(pts, i, bt_inv, T_pose, n_frames, pts_per_frame);
+            const unsigned long long m = __ballot(dead);
+            if (lane == 0) far_lane[wave] = m != 0ull ? __ffsll((long long)m) - 1 : -1;
+            __syncthreads();
+#pragma unroll
+            for (int w = 3; w >= 0; --w)
+                if (far_lane[w] >= 0) far_i = b * 256 + w * 64 + far_lane[w];
+        }
+    }
     int run = red[0] + red[1] + red[2] + red[3];
     for (int it = 0; it < COMPACT_SPB / 256; ++it) {
         const int i = blockIdx.x * COMPACT_SPB + it * 256 + threadIdx.x;
@@ -312,10 +356,12 @@ __global__ __launch_bounds__(256) void k_hand_compact_write(const float* __restr
         }
         run += all;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        idx[run] = 0;
-        pts_c[3 * (size_t)run] = pts_c[3 * (size_t)run + 1] = pts_c[3 * (size_t)run + 2] = 10.f;   // 17 m from everything: every mask exactly 0
+    if (last && threadIdx.x == 0) {
+        idx[run] = far_i >= 0 ? far_i : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pts_c[3 * (size_t)run + c] = far_i >= 0 ? pts[3 * (size_t)far_i + c] : 10.f;
         n_dev[0] = run + 1;
+        n_dev[1] = far_i;   // dense index of the stand-in (-1: the launch has no dead sample)
     }
 }
 // compact results -> the dense per-sample arrays (dead samples: the far sample's values)
@@ -435,7 +481,8 @@ static int compact_hand(CompactRec& cr, const float* pts, int n, const float* bt
                         hipStream_t s) {
     const int nb = (n + COMPACT_SPB - 1) / COMPACT_SPB;
     hipLaunchKernelGGL(k_hand_live_count, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, bt_inv, T_pose, n_frames, pts_per_frame, cr.pos, cr.counts);
-    hipLaunchKernelGGL(k_hand_compact_write, dim3(nb), dim3(256), 0, s, pts, n, cr.counts, cr.idx, cr.pos, cr.pts_c, cr.n_dev);
+    hipLaunchKernelGGL(k_hand_compact_write, dim3(nb), dim3(256), 0, s, pts, n, cr.counts, cr.idx, cr.pos, cr.pts_c, cr.n_dev, bt_inv, T_pose, n_frames,
+                       pts_per_frame);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -652,7 +699,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
                             const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand,
                             float* sdf_obj, float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals,
                             void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need, size_t* aux_offsets = nullptr,
-                            void* tape = nullptr, size_t tape_bytes = 0) {
+                            void* tape = nullptr, size_t tape_bytes = 0, size_t* compact_offsets = nullptr) {
     HN_REQUIRE(n_samples >= 2 && n_importance >= 0 && n_frames >= 1 && rpf >= 0, "bad sizes");
     HN_REQUIRE(n_importance == 0 || (steps >= 1 && n_importance % steps == 0), "n_importance must divide into steps");
     HN_REQUIRE(hand->kind == HN_FIELD_HAND && obj->kind == HN_FIELD_OBJ, "field kinds (hand, obj) expected");
@@ -685,6 +732,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     const size_t fws_h = field_ws(hand, hand_cap(hand, N)), fws_o = field_ws(obj, (int)N);
     void* fwsh = ar.take(fws_h);
     void* fwso = ar.take(fws_o);
+    const size_t crec_off = ar.used;
     void* crec_ws = hand->compact_far_field ? ar.take(CompactRec::bytes(N)) : nullptr;   // (without a tape the record lives here)
     // With a tape the four arrays live in the TAPE (behind the two fields' tapes): the caller keeps that buffer until the
     // backward pass, so nothing has to be copied out of the workspace (4 copy launches per fitting step).
@@ -695,6 +743,12 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
         rgb_o = aux + 3 * N;
         al_h = aux + 6 * N;
         al_o = aux + 7 * N;
+    }
+    if (compact_offsets != nullptr) {   // where the compaction records' device-side counts live (hn_render_dual_compact_offsets)
+        const bool fin = hand_compaction(hand, n_frames, N) && tapes_bytes != 0;
+        const bool coarse = n_importance > 0 && hand_compaction(hand, n_frames, (size_t)n_rays * n_samples);
+        compact_offsets[0] = fin ? tapes_bytes + 8 * N * sizeof(float) : (size_t)-1;
+        compact_offsets[1] = coarse ? crec_off : (size_t)-1;
     }
     if (aux_offsets != nullptr) {   // where the final evaluation leaves rgb / alpha of both fields (bytes into the workspace)
         aux_offsets[0] = off_rgb_h;
@@ -1405,6 +1459,14 @@ int hn_render_dual_aux_offsets(const hn_field* hand, const hn_field* obj, int n_
     return render_dual_impl(hand, obj, nullptr, nullptr, nullptr, 1, n_rays, 0.0, 1.0, n_samples, n_importance,
                             n_importance > 0 ? up_sample_steps : 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
                             nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &need, offsets4);
+}
+int hn_render_dual_compact_offsets(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples, int n_importance,
+                                   int up_sample_steps, size_t* offsets2) {
+    HN_REQUIRE(hand != nullptr && obj != nullptr && offsets2 != nullptr, "null argument");
+    size_t need = 0;
+    return render_dual_impl(hand, obj, nullptr, nullptr, nullptr, 1, n_rays, 0.0, 1.0, n_samples, n_importance,
+                            n_importance > 0 ? up_sample_steps : 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &need, nullptr, nullptr, 0, offsets2);
 }
 int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_o, const float* rays_d,
                    const float* t_rand, int n_frames, int rays_per_frame, double near, double far, int n_samples,

@@ -26,7 +26,8 @@ LOSS_KEYS = ('loss', 'color', 'mask', 'contact', 'penetration', 'frames')
 
 def shard_frames(n_frames, rank, world):
     """Frames of this rank: strided assignment (frame f -> rank f % world), so that a growing
-    sequence keeps every rank busy and a restart with another world size re-shards trivially."""
+    sequence keeps every rank busy and a restart with another world size re-shards trivially.
+    (FrameShardedRunner deals out the frames that are still to do, i.e. applies this to their positions.)"""
     if not (0 <= rank < world):
         raise ValueError('rank %d outside world of %d' % (rank, world))
     return list(range(rank, n_frames, world))
@@ -113,7 +114,14 @@ class FrameShardedRunner:
             on_gpu = self.dist is not None and self.dist.get_backend() == 'nccl'
             device = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
         self.device = device
-        self.frames = [f for f in shard_frames(n_frames, self.rank, self.world) if not (done and done(f))]
+        # what is left to do is decided BEFORE the frames are dealt out, so that a restart (or a re-sharded run) spreads the
+        # missing frames over all ranks instead of leaving the ranks whose frames exist idle; rank 0's view of `done` is the
+        # one every rank uses (a frame finishing between two ranks' directory scans must not be dealt twice or not at all)
+        todo = torch.tensor([0 if (done and done(f)) else 1 for f in range(n_frames)], dtype=torch.int32, device=device)
+        if self.dist is not None and self.world > 1 and n_frames > 0:
+            self.dist.broadcast(todo, src=0)
+        left = [f for f, t in enumerate(todo.tolist()) if t]
+        self.frames = [left[i] for i in shard_frames(len(left), self.rank, self.world)]
         self.totals = torch.zeros(len(LOSS_KEYS), dtype=torch.float64)
 
     def run(self, frame_fn):
@@ -691,7 +699,7 @@ def fit_frames_sharded(renderer, n_frames, make_frame, near, far, fit_type='12',
     """fitting_single.py:134-315 over a set of frames, sharded over the ranks: every frame is its own optimisation
     problem (own six parameters and Adam state, :177-199), so rank r fits frames r, r + world, .. with NO data-path
     collective; a frame whose result already exists is skipped (`done(frame_id)`, :156-158: a restarted or re-sharded
-    run picks up what is missing); `save(frame_id, pose_chain, terms)` is the pose dump of :293-315.  The only
+    run picks up what is missing, dealt out evenly over the ranks); `save(frame_id, pose_chain, terms)` is the pose dump of :293-315.  The only
     exchange is the SUM of the small loss vector at the end (`FrameShardedRunner.reduce`).
 
     make_frame(frame_id) -> (views, pose_chain[, sample_view]).  Returns the reduced means + 'frames' + 'steps' of this rank."""

@@ -337,6 +337,7 @@ class PackedField:
     def set_compaction(self, enabled):
         """Exact far-field skip in the two-field renders (hn_field_set_compaction); results stay bit-identical."""
         _lib.check(self.lib.hn_field_set_compaction(self.handle, 1 if enabled else 0), 'hn_field_set_compaction')
+        self.compaction = bool(enabled)
 
     # ---- direct field queries (utils/fields.py .sdf / forward+gradient+colour) ----------
     def _frames(self, pts, bt_inv, T_pose):

@@ -124,6 +124,10 @@ def _marching_cubes(u, threshold, resolution, b_min_np, b_max_np):
     return vertices, triangles
 
 
+def _wants_grad(*xs):
+    return torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs)
+
+
 class NeuSRenderer:
     """Single-field renderer (utils/renderer.py:39-284)."""
 
@@ -167,12 +171,31 @@ class NeuSRenderer:
             self._version = ver
         return self._field
 
+    def _needs_graph(self, *inputs):
+        """True when the caller can differentiate this render: grad mode is on and a pose-side input or a parameter of the
+        three modules requires grad (exp_runner.train; `--mode test` runs under no_grad or with frozen inputs)."""
+        if not torch.is_grad_enabled():
+            return False
+        if _wants_grad(*inputs):
+            return True
+        return any(p.requires_grad for m in (self.sdf_network, self.color_network, self.deviation_network)
+                   for p in m.parameters())
+
     def render(self, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, Ro, To, index, t_rand=None):
         """utils/renderer.py:190-258.  Returns color_fine [B,3], s_val [B,1], cdf_fine [B,S],
-        weight_sum [B,1], weight_max [B,1], gradient_error []."""
+        weight_sum [B,1], weight_max [B,1], gradient_error [].  Differentiable as the reference's is (dispatch on
+        `_needs_graph`): under `torch.no_grad()` -- every test / validation call site -- it is the plain launch sequence."""
         if self.perturb <= 0:
             # the reference only works with perturb > 0 as well (SURVEY B-2)
             raise ValueError('render requires perturb > 0, as the reference does')
+        if self._needs_graph(rays_o, rays_d, bt_inv, T_pose_21, Ro, To):
+            # the reference's render carries autograd into the three modules and into whatever Ro / To / bt_inv were
+            # computed from (`se3_refine`, exp_runner.py:155-161, 196-232): the same call, attached to the graph
+            # (re-packing is left to field()'s version check, as in the plain path: the reference's optimiser is torch's
+            # default Adam, whose in-place updates advance the parameters' version counters)
+            from .training import render_train
+            return render_train(self, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, Ro, To, index=index, t_rand=t_rand,
+                                repack=False, keep_far_field_setting=True)
         f = self.field()
         lib = self.lib
         rays_o = _lib.f32(rays_o).reshape(-1, 3)
@@ -285,10 +308,6 @@ class NeuSRenderer:
         _, bmin, bmax = _grid_points(bound_min, bound_max, 2, torch.device('cpu'))
         u = self.extract_fields(bound_min, bound_max, resolution, bt_inv, T_pose_21)
         return _marching_cubes(u, threshold, resolution, bmin, bmax)
-
-
-def _wants_grad(*xs):
-    return torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs)
 
 
 class NeuSRenderer_fitting:

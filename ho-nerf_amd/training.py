@@ -201,13 +201,15 @@ class ObjLocalFn(torch.autograd.Function):
 
 
 def render_train(renderer, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, Ro, To, index=0, t_rand=None, z_vals=None,
-                 repack=True):
+                 repack=True, keep_far_field_setting=False):
     """`NeuSRenderer.render` (utils/renderer.py:190-258) as a differentiable function of the networks' parameters (and of
     bt_inv / T_pose_21 for the hand, Ro / To for the object through `convert_obj_to_local`): the render of a training
     step (exp_runner.py:196-201).  Same return keys as `render`.  With `z_vals` [B,S] the sampling is skipped and
     `render_core` runs at those depths (utils/renderer.py:107-177).  The field is re-packed from the modules' current
     parameters first (`repack=False`: the caller has just done so): a training render follows an optimiser step, and a
-    fused step does not advance the version counters `renderer.field()` watches."""
+    fused step does not advance the version counters `renderer.field()` watches.  `keep_far_field_setting`: leave
+    `renderer.compact_far_field` as the caller set it (`NeuSRenderer.render`'s dispatch; the training loop switches the exact
+    far-field aggregation on)."""
     from .renderer import _Workspace
     if renderer.perturb <= 0:
         raise ValueError('render requires perturb > 0, as the reference does')
@@ -215,7 +217,7 @@ def render_train(renderer, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, 
         renderer._ws_train = _Workspace()
     renderer.index = index
     renderer.pack_eval_only = True     # the per-step re-pack builds the evaluation programs only (HN_PACK_EVAL_ONLY)
-    if renderer.model_type == 'hand' and getattr(renderer, 'train_compact', True):
+    if renderer.model_type == 'hand' and getattr(renderer, 'train_compact', True) and not keep_far_field_setting:
         # exact far-field aggregation (hn_field_set_compaction): render and backward pass run on the samples with a live bone mask
         # plus ONE far sample that carries the summed upstream gradients of all the others (they share its all-zero input, so
         # their parameter-gradient contributions are that sum times one Jacobian).  `renderer.train_compact = False`: dense.
@@ -385,7 +387,11 @@ def train(renderer, batches, end_iter, base_exp_dir, learning_rate=1e-4, learnin
         ck = latest_checkpoint(base_exp_dir)
         if ck is not None:
             iter_step = load_checkpoint(ck, renderer)      # networks and iteration count; Adam's moments restart, as in the reference (:288-293)
-    multi = dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # the process group as train_step -> allreduce_gradients resolves it (an initialised torch.distributed counts whether or
+    # not the caller passed the module), so that logging, checkpoints and the barrier agree with what the gradients do
+    if dist is None:
+        import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank0 = not multi or dist.get_rank() == 0
     os.makedirs(base_exp_dir, exist_ok=True)
     log_path = os.path.join(base_exp_dir, 'metrics.jsonl')

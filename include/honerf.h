@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 107 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 108 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -111,7 +111,8 @@ int hn_field_set_culling(hn_field* f, int enabled);
  * 0 has a constant sdf / colour, a zero gradient and contributes exactly 0 to every adjoint output, so the hand field is
  * evaluated on the compacted list of the other samples plus one far sample and the results are scattered back --
  * bit-identical outputs, 40 - 60 % fewer samples in a fitting step (one round of sample tiles on the chip instead of two),
- * ~5x on a 512 x 512 x 64 hand frame.  Set it before sizing workspaces / tapes with the hn_render_*_workspace_bytes /
+ * ~5x on a 512 x 512 x 64 hand frame.  The stand-in ("far") sample is the first skipped sample of the launch itself, so it
+ * is dead by the same predicate whatever the scene's scale.  Set it before sizing workspaces / tapes with the hn_render_*_workspace_bytes /
  * _tape_bytes queries (they grow by the compaction record) and do not change it between a render and its backward pass.
  * Off by default; the stand-alone evaluations (hn_field_sdf / hn_field_eval) and every throughput figure quoted as "dense"
  * never compact. */
@@ -367,6 +368,14 @@ size_t hn_render_dual_tape_aux_offset(const hn_field* hand, const hn_field* obj,
  * of evaluating both fields again. */
 int hn_render_dual_aux_offsets(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples, int n_importance,
                                int up_sample_steps, size_t* offsets4);
+
+/* Measurement aid (bench.py prices a fitting step on the samples it EXECUTES): with hn_field_set_compaction the hand field is
+ * evaluated on the samples that have a live bone mask; the device-side count of each compacted launch (an int32: live
+ * samples + 1, the stand-in) is kept at offsets2[0] bytes into the TAPE (the final evaluation of a taped render) and at
+ * offsets2[1] bytes into the WORKSPACE (the coarse sdf pass of the importance sampling); (size_t)-1 where that launch of a
+ * render of these sizes does not compact.  Valid after hn_render_dual until the buffers are re-used. */
+int hn_render_dual_compact_offsets(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples, int n_importance,
+                                   int up_sample_steps, size_t* offsets2);
 
 /* The render-dependent loss terms of one fitting step (fitting_single.py:251-283; fitting_video.py:285-309): the sums
  * behind colour L1, mask BCE, contact and penetration in one launch, and their gradients w.r.t. the render outputs in

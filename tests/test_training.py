@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import SEEDS, VAR_HAND, VAR_OBJ, assert_close, record, rel_err, state_dicts, t
+from helpers import SEEDS, VAR_HAND, VAR_OBJ, assert_close, bounded, record, rel_err, state_dicts, t
 
 
 def _golden_grads(g):
@@ -178,6 +178,64 @@ def test_train_iteration_product_golden(golden, kind, precision):
     for key, v in sorted(floor.items()):
         record('train %s reference fp32 vs fp64 %s' % (kind, key), v, float('inf'), kind='noise floor')
     _compare(grads, g, None, 'train %s %s' % (kind, precision), floor=floor, cap=4e-4 if kind == 'obj' else 1.9e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['obj', 'hand'])
+def test_render_is_differentiable_by_dispatch(golden, kind):
+    """`NeuSRenderer.render` itself carries autograd into the modules and the pose inputs when the caller can
+    differentiate it (utils/renderer.py:190-258 under exp_runner.py:196-232: the import swap alone must do): the
+    reference's loss + `loss.backward()` through `renderer.render(...)` gives the loss terms of the fixture and the SAME
+    parameter gradients as `training.render_train`; under `torch.no_grad()` the same call returns detached, bit-identical
+    outputs."""
+    from honerf_amd import training
+    g = golden('train_' + kind)
+    dev = torch.device('cuda:0')
+    c = lambda k: t(g[k]).to(dev)
+
+    def run(through_render):
+        from honerf_amd.nets import (RenderingNetwork, RenderingNetwork_OBJ, SDFNetwork, SDFNetwork_OBJ, SingleVarianceNetwork)
+        from honerf_amd.renderer import NeuSRenderer
+        if kind == 'obj':
+            sdf_net, col_net, var = SDFNetwork_OBJ().to(dev), RenderingNetwork_OBJ().to(dev), SingleVarianceNetwork(VAR_OBJ).to(dev)
+        else:
+            sdf_net, col_net, var = SDFNetwork().to(dev), RenderingNetwork(use_gradients=True).to(dev), SingleVarianceNetwork(VAR_HAND).to(dev)
+        sdf_net.reset_parameters(SEEDS['sdf_' + kind])
+        col_net.reset_parameters(SEEDS['color_' + kind])
+        ren = NeuSRenderer(sdf_net, var, col_net, kind, int(g['n_samples']), int(g['n_importance']), 0, 4, 1.0)
+        pose = {}
+        if kind == 'obj':
+            pose = dict(Ro=c('Ro').clone().requires_grad_(True), To=c('To').clone().requires_grad_(True))
+            args = (None, None, None, pose['Ro'], pose['To'])
+        else:
+            pose = dict(bt=c('bt_inv').clone().requires_grad_(True))
+            args = (pose['bt'], c('T_pose'), None, None, None)
+        if through_render:
+            out = ren.render(c('rays_o'), c('rays_d'), float(g['near']), float(g['far']), *args, 0, t_rand=c('t_rand'))
+        else:
+            out = training.render_train(ren, c('rays_o'), c('rays_d'), float(g['near']), float(g['far']), *args, t_rand=c('t_rand'))
+        terms = training.train_loss(out, c('true_rgb'), c('true_mask'), float(g['igr_weight']), float(g['mask_weight']))
+        terms['loss'].backward()
+        grads = [p.grad.detach().clone() for p in training.trainable_parameters(ren)] + [v.grad.detach().clone() for v in pose.values()]
+        with torch.no_grad():
+            plain = ren.render(c('rays_o'), c('rays_d'), float(g['near']), float(g['far']), *[a.detach() if isinstance(a, torch.Tensor) else a for a in args],
+                               0, t_rand=c('t_rand'))
+        return out, terms, grads, plain
+
+    out_r, terms_r, grads_r, plain = run(True)
+    out_t, terms_t, grads_t, _ = run(False)
+    assert out_r['color_fine'].requires_grad and out_r['weight_sum'].requires_grad and out_r['gradient_error'].requires_grad
+    assert set(out_r) == {'color_fine', 's_val', 'cdf_fine', 'weight_sum', 'weight_max', 'gradient_error'}
+    for k in ('color_fine', 'weight_sum', 'cdf_fine', 'weight_max', 'gradient_error', 's_val'):
+        assert not plain[k].requires_grad
+        assert torch.equal(plain[k], out_r[k].detach().reshape(plain[k].shape)), k
+        assert torch.equal(out_t[k].detach(), out_r[k].detach()), k
+    for k in ('loss', 'color_fine_loss', 'mask_loss', 'eikonal_loss'):
+        assert_close(terms_r[k].reshape(()), g[k], 2e-3, 'render dispatch %s %s vs the reference (own depths)' % (kind, k))
+    worst = 0.0
+    for a, b in zip(grads_r, grads_t):      # the same launch sequence twice: equal up to the order of the float atomics
+        worst = max(worst, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)))
+    bounded('render dispatch %s: gradients through renderer.render vs render_train, worst tensor' % kind, worst, 2e-5)
 
 
 @pytest.mark.gpu
