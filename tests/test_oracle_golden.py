@@ -134,3 +134,71 @@ def test_render_dual_batch(golden):
     for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj', 'gradient_error_hand', 'gradient_error_obj',
               'gradient_hand', 'gradient_obj'):
         assert_close(res[k], g[k], RT, k)
+
+
+# ---- the loss half of an oracle fitting step (oracle/losses.py) against the reference's own statements ------------------
+def _leaf(a):
+    return t(a).clone().requires_grad_(True)
+
+
+def test_single_step_loss_oracle(golden):
+    """oracle.losses.single_step_loss against loss_single.npz (fitting_single.py:251-288 executed on synthetic render
+    outputs): every term and the gradient w.r.t. every tensor the block consumes, both fit types."""
+    from oracle import losses as ol
+    g = golden('loss_single')
+    for ft in ('1', '12'):
+        ro = {k: _leaf(g['in_' + k]) for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj')}
+        j3 = _leaf(g['joint_3d'])
+        terms = ol.single_step_loss(ro, t(g['true_rgb']), t(g['true_mask']), j3, t(g['joint3d_pred']), torch.tensor(float(g['obj_verts_loss'])), ft)
+        pre = 's%s_' % ft
+        for key, name in (('loss', 'loss'), ('color', 'color'), ('mask', 'mask'), ('joint', 'joint')):
+            assert_close(terms[key], g[pre + name], 2e-6, 'oracle ' + pre + name)
+        if ft == '12':
+            assert_close(terms['contact'], g['s12_contact'], 2e-6, 'oracle contact')
+            assert_close(terms['penetration'], g['s12_penet'], 2e-6, 'oracle penetration')
+        leaves = [ro['color_fine'], ro['weight_sum'], ro['sdf_hand'], ro['sdf_obj'], j3]
+        grads = torch.autograd.grad(terms['loss'], leaves, allow_unused=True)
+        for name, gr, like in zip(('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj', 'joint_3d'), grads, leaves):
+            gr = torch.zeros_like(like) if gr is None else gr
+            ref = g[pre + 'g_' + name]
+            if np.abs(ref).max() == 0:
+                assert float(gr.abs().max()) == 0.0, name
+            else:
+                assert_close(gr, ref, 2e-6, 'oracle ' + pre + 'g_' + name)
+
+
+def test_video_step_loss_oracle(golden):
+    """oracle.losses.video_step_loss against loss_video.npz (fitting_video.py:285-339): a middle window, both sequence ends
+    and the very first step."""
+    from oracle import losses as ol
+    g = golden('loss_video')
+    for tag in ('mid', 'head', 'tail', 'first'):
+        ro = {k: _leaf(g['in_' + k]) for k in ('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj')}
+        j3, pv = _leaf(g['joint_3d']), _leaf(g['pred_obj_v_w'])
+        terms = ol.video_step_loss(ro, t(g['true_rgb']), t(g['true_mask']), j3, t(g['joint3d_pred']), pv, t(g['compare_obj_v_w']),
+                                   g[tag + '_index'], 10, not bool(g[tag + '_first']), stable=t(g['stable']).reshape(()))
+        for key, name in (('loss', 'loss'), ('smooth', 'smooth'), ('color', 'color'), ('mask', 'mask'), ('contact', 'contact'),
+                          ('penetration', 'penet')):
+            assert_close(terms[key], g[tag + '_' + name], 3e-6, 'oracle %s_%s' % (tag, name))
+        grads = torch.autograd.grad(terms['loss'], [ro['color_fine'], ro['weight_sum'], ro['sdf_hand'], ro['sdf_obj'], j3, pv])
+        for name, gr in zip(('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj', 'joint_3d', 'pred_obj_v_w'), grads):
+            assert_close(gr, g['%s_g_%s' % (tag, name)], 3e-6, 'oracle %s_g_%s' % (tag, name))
+
+
+def test_stable_loss_oracle(golden):
+    """oracle.losses.stable_loss_cross over the oracle hand field against stable_loss.npz (the reference's
+    get_stable_loss_cross on its batched renderer): value and gradients w.r.t. bt_inv, the object rotation and translation."""
+    from oracle import losses as ol
+    g = golden('stable_loss')
+    hand, _ = oracle_fields()
+    bt, R, T = _leaf(g['bt_inv']), _leaf(g['obj_r']), _leaf(g['obj_t'])
+    sdf_fn = lambda p, b, tp: hand.sdf_only(p, b, tp)
+    with torch.no_grad():
+        pw = (R.unsqueeze(1) @ t(g['obj_verts'])[:, ::10, :].unsqueeze(-1))[..., 0] + T.unsqueeze(1)
+        assert_close(sdf_fn(pw, bt, t(g['T_pose'])).reshape(4, -1), g['hand_sdf'], RT, 'oracle hand sdf on the object vertices')
+    loss = ol.stable_loss_cross(sdf_fn, t(g['obj_verts']), bt, t(g['T_pose']), R, T)
+    assert_close(loss, g['stable'], RT, 'oracle stable loss')
+    gb, gR, gT = torch.autograd.grad(loss, [bt, R, T])
+    assert_close(gb, g['g_bt_inv'], 5e-5, 'oracle stable d/d bt_inv')
+    assert_close(gR, g['g_obj_r'], 5e-5, 'oracle stable d/d obj_r')
+    assert_close(gT, g['g_obj_t'], 5e-5, 'oracle stable d/d obj_t')
