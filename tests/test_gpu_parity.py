@@ -379,7 +379,7 @@ def test_render_single_golden_importance(golden, tag, prec):
     ren = _single_renderer(kind, 64, 64, prec)
     out = ren.render(cu(g['rays_o']), cu(g['rays_d']), float(g['near']), float(g['far']), g.get('bt_inv'),
                      g.get('T_pose'), None, g.get('Ro'), g.get('To'), 0, t_rand=cu(g['t_rand']))
-    errs = {k: rel_err(out[k].cpu().numpy().reshape(g[k].shape), g[k]) for k in KEYS1}
+    errs = {k: rel_err(out[k].detach().cpu().numpy().reshape(g[k].shape), g[k]) for k in KEYS1}
     for k in ('color_fine', 'weight_sum', 'gradient_error'):
         bounded('%s %s (end to end, 4 importance rounds)' % (tag, k), errs[k], E2E[tag][k])
     for k in KEYS1:
@@ -756,7 +756,7 @@ def test_f16_throughput_mode_error_is_pinned(golden):
     out = ren.render(cu(gr['rays_o']), cu(gr['rays_d']), float(gr['near']), float(gr['far']), gr.get('bt_inv'), gr.get('T_pose'), None, None, None, 0,
                      t_rand=cu(gr['t_rand']))
     for k, bound in (('color_fine', 2e-3), ('weight_sum', 1.5e-3), ('cdf_fine', 1.5e-3), ('weight_max', 1.5e-3)):
-        bounded('f16 mode: render_hand_64_0 %s vs reference' % k, rel_err(out[k].cpu().numpy().reshape(gr[k].shape), gr[k]), bound)
+        bounded('f16 mode: render_hand_64_0 %s vs reference' % k, rel_err(out[k].detach().cpu().numpy().reshape(gr[k].shape), gr[k]), bound)
     # the differentiable / taped kernels of such a field are the fp32-equivalent ones: a fitting render is unchanged
     assert f.lib.hn_field_bwd_workspace_bytes(f.handle, 128) == f3.lib.hn_field_bwd_workspace_bytes(f3.handle, 128)
 

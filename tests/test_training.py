@@ -203,6 +203,7 @@ def test_render_is_differentiable_by_dispatch(golden, kind):
         sdf_net.reset_parameters(SEEDS['sdf_' + kind])
         col_net.reset_parameters(SEEDS['color_' + kind])
         ren = NeuSRenderer(sdf_net, var, col_net, kind, int(g['n_samples']), int(g['n_importance']), 0, 4, 1.0)
+        ren.train_compact = False      # both runs dense (render() leaves the far-field setting to the caller; the exact aggregation has its own test)
         pose = {}
         if kind == 'obj':
             pose = dict(Ro=c('Ro').clone().requires_grad_(True), To=c('To').clone().requires_grad_(True))

@@ -18,7 +18,8 @@ star's 1e-4 of the tensor's maximum against the fp32 oracle, or -- where the fp3
 float64 value (measured here, recorded in the parity report) -- at least as close to float64 as the fp32 oracle is
 (helpers.assert_parity).  The contact / penetration terms select samples by thresholds (|s_h| + |s_o| < 1e-2; s < 0): a sample
 within rounding of a threshold may be selected on one side only, which moves a mean over ~10^3 selected samples by ~1e-3 of
-itself; the number of such samples is recorded with the comparison.
+itself; the number of such samples (fp32 vs float64 oracle) is recorded with the comparison, and the three terms that depend on
+them are held to 5e-3 only when it is non-zero.
 """
 import numpy as np
 import pytest
@@ -152,9 +153,10 @@ def _perturb(chain, scale, seed):
             p.add_(scale * torch.randn(p.shape, generator=torch.Generator().manual_seed(seed + i)).to(p.device))
 
 
-# What a leaf gradient may differ from the fp32 oracle's by when neither of the other two criteria holds (max-norm, relative to
-# the tensor's maximum): set from the errors observed on MI355X (profiles/r04/parity_report.json), <= 4x the largest.
-GRAD_ABS = 2e-3
+# Observed on MI355X (profiles/r04/parity_report.json): loss terms 0 ... 9e-7; leaf gradients 4.7e-6 ... 6.8e-4 from the fp32 oracle
+# where the fp32 oracle is itself 5.5e-6 ... 1.7e-2 from float64 and the product 5.2e-6 ... 1.7e-2 (never further than 1.17x the fp32
+# oracle's distance; closer than it on 7 of the 18 gradients).  GRAD_CAP: 4x the largest product-vs-fp32-oracle error.
+GRAD_CAP = 2.8e-3
 LEAVES = ('obj_rot_refine', 'obj_trans_refine', 'palm_rot_refine', 'palm_trans_refine', 'joint_refine_angle', 'palm_refine_angle')
 TERM_KEYS_SINGLE = ('loss', 'color', 'mask', 'contact', 'penetration', 'joint', 'obj_verts')
 
@@ -167,7 +169,7 @@ def _compare(tag, got_terms, got_grads, ref32, ref64, keys, threshold_flips, gra
         scale = max(abs(b), 1e-12)
         err, floor = abs(a - b) / scale, abs(b - e) / scale
         # contact / penetration (and with them the loss): means over threshold-selected samples, see the module docstring
-        bound = max(1e-4, 4.0 * floor) if k in ('color', 'mask', 'joint', 'obj_verts', 'smooth', 'stable') else 5e-3
+        bound = max(1e-4, 4.0 * floor) if (threshold_flips == 0 or k in ('color', 'mask', 'joint', 'obj_verts', 'smooth', 'stable')) else 5e-3
         record('%s term %s' % (tag, k), err, bound, ref32_vs_fp64=floor, value=b, threshold_flips=threshold_flips)
         assert err <= bound, '%s %s: %.6g vs oracle %.6g (rel %.2e > %.1e)' % (tag, k, a, b, err, bound)
     for name, a, b, e in zip(LEAVES, got_grads, g32, g64):
@@ -175,7 +177,7 @@ def _compare(tag, got_terms, got_grads, ref32, ref64, keys, threshold_flips, gra
         e_hr, e_ref, e_hip = rel_err(a, b.double().numpy()), rel_err(b.double().numpy(), e.numpy()), rel_err(a, e.numpy())
         record('%s d loss / d %s' % (tag, name), e_hr, grad_cap, kind='rel, conditioning-aware', ref32_vs_fp64=e_ref, hip_vs_fp64=e_hip)
         # north star, or (where the fp32 oracle itself is further than that from float64) as close to float64 as the fp32 oracle is
-        ok = e_hr <= 1e-4 or (e_hr <= grad_cap and e_hip <= 2.0 * e_ref + 1e-5) or e_hr <= GRAD_ABS
+        ok = e_hr <= 1e-4 or (e_hr <= grad_cap and e_hip <= 1.5 * e_ref + 1e-5)
         assert ok, '%s d/d %s: product vs fp32 oracle %.3e, fp32 oracle vs float64 %.3e, product vs float64 %.3e' % (tag, name, e_hr, e_ref, e_hip)
 
 
@@ -209,7 +211,7 @@ def test_fitting_single_step_matches_the_oracle_composition():
     flips = int(sum((a != b).sum() for a, b in zip(sel(ref32[2]), sel(ref64[2]))))
     for compact in (True, False):
         _compare('C3 step (compaction %s)' % ('on' if compact else 'off'), runs[compact][0], runs[compact][1], ref32, ref64, TERM_KEYS_SINGLE, flips,
-                 grad_cap=5e-3)
+                 grad_cap=GRAD_CAP)
 
 
 def test_fitting_video_window_step_matches_the_oracle_composition():
@@ -239,4 +241,4 @@ def test_fitting_video_window_step_matches_the_oracle_composition():
     if float(ref32[0].get('stable', torch.zeros(()))) != 0.0:
         keys.append('stable')
     record('C5 window step: stable term of the oracle', float(ref32[0].get('stable', torch.zeros(()))), float('inf'), kind='value')
-    _compare('C5 window step', got_terms, got_grads, ref32, ref64, keys, flips, grad_cap=5e-3)
+    _compare('C5 window step', got_terms, got_grads, ref32, ref64, keys, flips, grad_cap=GRAD_CAP)
