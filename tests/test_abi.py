@@ -57,3 +57,17 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+
+
+def test_host_side_code_is_clean_under_address_and_ub_sanitizers():
+    """SURVEY 5 (sanitizers on the CPU side only: GPU ASan is not available on the pool): the pure-host pieces of the library
+    -- the layout planner of the f16x3 weight-stream packer (hn_pack2.hip compiled host-only) and the pose-chain header through
+    the oracle's double-precision entry points -- built with -fsanitize=address,undefined and run (tests/san/)."""
+    import subprocess
+    san = os.path.join(ROOT, 'tests', 'san')
+    subprocess.check_call(['make', '-C', san, '-s'], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1:halt_on_error=1')
+    for exe, ok in (('pose_chain_san', 'pose chain: ok'), ('pack_layout_san', 'pack layout: ok')):
+        r = subprocess.run([os.path.join(san, '_build', exe)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and ok in r.stdout and 'Sanitizer' not in r.stderr and 'runtime error' not in r.stderr, \
+            '%s: rc %d\n%s\n%s' % (exe, r.returncode, r.stdout[-2000:], r.stderr[-4000:])
