@@ -82,6 +82,9 @@ class DualRenderFn(torch.autograd.Function):
         renderer._pending_aux = weakref.ref(ctx.aux)
         ctx.save_for_backward(rays_o.detach(), rays_d.detach(), bt_inv.detach(), T_pose.detach(), Ro.detach(), To.detach(),
                               o['z_vals'], o['sdf_hand'], o['sdf_obj'], o['grad_hand'], o['grad_obj'])
+        # outputs the loss does not use arrive as None in backward, not as zero tensors (three fills and two adds of zeros per step)
+        ctx.set_materialize_grads(False)
+        ctx.want_rays = bool(rays_o.requires_grad or rays_d.requires_grad)
         return o['color'], o['weight_sum'], o['sdf_hand'], o['sdf_obj'], o['grad_hand'], o['grad_obj'], o['gerr']
 
     @staticmethod
@@ -135,7 +138,10 @@ class DualRenderFn(torch.autograd.Function):
         opt = lambda g, shape: None if g is None else L.f32(g).reshape(shape)
         g_color = L.f32(g_color).reshape(N, 3) if g_color is not None else torch.zeros(N, 3, device=dev)
         ups = (opt(g_wsum, (N,)), opt(g_sdf_h, (n,)), opt(g_sdf_o, (n,)), opt(g_grad_h, (n, 3)), opt(g_grad_o, (n, 3)), opt(g_gerr, (2,)))
-        g_ro, g_rd = _empty(N, 3, dev=dev), _empty(N, 3, dev=dev)
+        # d loss / d the world rays only when a caller differentiates w.r.t. them (the fitting loops' rays come from fixed cameras)
+        want_rays = ctx.want_rays
+        g_ro = _empty(N, 3, dev=dev) if want_rays else None
+        g_rd = _empty(N, 3, dev=dev) if want_rays else None
         g_bt, g_tp = _empty(F, 21, 4, 4, dev=dev), _empty(F, 21, 3, dev=dev)
         g_Ro, g_To = _empty(F, 3, 3, dev=dev), _empty(F, 3, dev=dev)
         need = lib.hn_render_dual_bwd_workspace_bytes(hand.handle, obj.handle, N, S)
@@ -152,8 +158,8 @@ class DualRenderFn(torch.autograd.Function):
             return g.reshape(ref.shape) if g.numel() == ref.numel() else g.reshape(F, *ref.shape[-(ref.dim()):]).sum(0).reshape(ref.shape)
 
         sv = ctx.saved_tensors
-        return (g_ro.reshape(rays_o.shape), g_rd.reshape(rays_d.shape), like(g_bt, sv[2]), like(g_tp, sv[3]), like(g_Ro, sv[4]),
-                like(g_To, sv[5]), None, None, None, None)
+        return (g_ro.reshape(rays_o.shape) if want_rays else None, g_rd.reshape(rays_d.shape) if want_rays else None, like(g_bt, sv[2]),
+                like(g_tp, sv[3]), like(g_Ro, sv[4]), like(g_To, sv[5]), None, None, None, None)
 
 
 class HandSdfFn(torch.autograd.Function):
@@ -248,10 +254,24 @@ class FitLossFn(torch.autograd.Function):
                 None, None)
 
 
+_LOSS_SCRATCH = {}
+
+
+def _loss_scratch(lib, n_rays, n_samples, dev):
+    """The partial-sum slots + counter of hn_fit_step_loss: zeroed once, every launch leaves it ready for the next.  One per
+    (device, stream): steps of two streams must not share a counter."""
+    need = lib.hn_fit_step_loss_scratch_bytes(n_rays, n_samples)
+    key = (str(dev), torch.cuda.current_stream().cuda_stream)
+    buf = _LOSS_SCRATCH.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _LOSS_SCRATCH[key] = torch.zeros(int(need), dtype=torch.uint8, device=dev)
+    return buf, need
+
+
 class FitStepLossFn(torch.autograd.Function):
-    """The whole loss of one fitting_single step (fitting_single.py:251-288) as three launches forward (hn_fit_loss_sums,
-    hn_verts_loss, hn_fit_total) and two backward (hn_fit_total_bwd, hn_fit_loss_grads), instead of ~25 + ~35 element-wise
-    torch launches in a step that is a chain of dependent launches:
+    """The whole loss of one fitting_single step (fitting_single.py:251-288) as ONE launch forward (hn_fit_step_loss: the sums of
+    the render terms, the vertex loss, the joint loss, the weighted total) and ONE backward (hn_fit_step_loss_bwd), instead of
+    ~25 + ~35 element-wise torch launches in a step that is a chain of dependent launches:
       (color_fine [R,3], weight_sum [R,1], sdf_hand [n,1] | None, sdf_obj | None, joint_3d [1,21,3], obj_r [1,3,3], obj_t [1,3])
       -> (loss [], terms [8] = loss, colour, mask, contact, penetration, joint, verts, 0  -- not differentiable).
     weights = (w_render, w_contact, w_penetration, w_joint, w_verts)."""
@@ -272,13 +292,13 @@ class FitStepLossFn(torch.autograd.Function):
         assert jp.shape[0] == nj and nj <= 64, 'one frame of joints'
         Ra, ta = L.f32(obj_r).reshape(1, 9), L.f32(obj_t).reshape(1, 3)
         Rb, tb = L.f32(Ro_pred, dev).reshape(1, 9), L.f32(To_pred, dev).reshape(1, 3)
-        buf = _empty(6 + 1 + 9 + 3 + 8 + 3 * nj, dev=dev)          # one allocation: sums | verts loss | gR | gt | terms | g_joint
-        sums, vloss, gR, gt, terms, gj = buf[0:6], buf[6:7], buf[7:16], buf[16:19], buf[19:27], buf[27:27 + 3 * nj]
-        L.check(lib.hn_fit_loss_sums(L.ptr(c), L.ptr(w), L.ptr(t), L.ptr(m), R, L.ptr(sh), L.ptr(so), n, L.ptr(sums), st), 'hn_fit_loss_sums')
-        L.check(lib.hn_verts_loss(L.ptr(Ra), L.ptr(ta), L.ptr(Rb), L.ptr(tb), L.ptr(verts), verts.shape[0], 1, L.ptr(vloss), L.ptr(gR), L.ptr(gt), st),
-                'hn_verts_loss')
+        buf = _empty(6 + 1 + 9 + 3 + 8 + 3 * nj, dev=dev)          # one allocation: sums | (unused) | gR | gt | terms | g_joint
+        sums, gR, gt, terms, gj = buf[0:6], buf[7:16], buf[16:19], buf[19:27], buf[27:27 + 3 * nj]
+        scratch, need = _loss_scratch(lib, R, n, dev)
         w5 = (ctypes.c_float * 5)(*[float(x) for x in weights])
-        L.check(lib.hn_fit_total(L.ptr(sums), L.ptr(vloss), L.ptr(j3), L.ptr(jp), nj, w5, L.ptr(terms), L.ptr(gj), st), 'hn_fit_total')
+        L.check(lib.hn_fit_step_loss(L.ptr(c), L.ptr(w), L.ptr(t), L.ptr(m), R, L.ptr(sh), L.ptr(so), n, L.ptr(j3), L.ptr(jp), nj, L.ptr(Ra), L.ptr(ta),
+                                     L.ptr(Rb), L.ptr(tb), L.ptr(verts), verts.shape[0], w5, L.ptr(scratch), need, L.ptr(sums), L.ptr(terms), L.ptr(gj),
+                                     L.ptr(gR), L.ptr(gt), st), 'hn_fit_step_loss')
         ctx.save_for_backward(c, w, t, m, buf, *([sh, so] if sh is not None else []))
         ctx.w5, ctx.nj = w5, nj
         ctx.shapes = (color.shape, wsum.shape, None if sdf_h is None else sdf_h.shape, joint_3d.shape, obj_r.shape, obj_t.shape)
@@ -295,18 +315,16 @@ class FitStepLossFn(torch.autograd.Function):
         nj = ctx.nj
         sums, gR, gt, gj = buf[0:6], buf[7:16], buf[16:19], buf[27:27 + 3 * nj]
         dev = c.device
-        st = L.stream_ptr()
         R, n = c.shape[0], 0 if sh is None else sh.shape[0]
-        out = _empty(4 + 3 * nj + 9 + 3, dev=dev)
-        g4, gj_o, gR_o, gt_o = out[0:4], out[4:4 + 3 * nj], out[4 + 3 * nj:13 + 3 * nj], out[13 + 3 * nj:16 + 3 * nj]
+        out = _empty(3 * nj + 9 + 3, dev=dev)
+        gj_o, gR_o, gt_o = out[0:3 * nj], out[3 * nj:9 + 3 * nj], out[9 + 3 * nj:12 + 3 * nj]
         gl = L.f32(g_loss).reshape(1)
-        L.check(lib.hn_fit_total_bwd(L.ptr(gl), ctx.w5, L.ptr(gj), L.ptr(gR), L.ptr(gt), nj, L.ptr(g4), L.ptr(gj_o), L.ptr(gR_o), L.ptr(gt_o), st),
-                'hn_fit_total_bwd')
         gc, gw = _empty(R, 3, dev=dev), _empty(R, dev=dev)
         gsh = _empty(n, dev=dev) if sh is not None else None
         gso = _empty(n, dev=dev) if sh is not None else None
-        L.check(lib.hn_fit_loss_grads(L.ptr(c), L.ptr(w), L.ptr(t), L.ptr(m), R, L.ptr(sh), L.ptr(so), n, L.ptr(sums), L.ptr(g4), L.ptr(gc),
-                                      L.ptr(gw), L.ptr(gsh), L.ptr(gso), st), 'hn_fit_loss_grads')
+        L.check(lib.hn_fit_step_loss_bwd(L.ptr(c), L.ptr(w), L.ptr(t), L.ptr(m), R, L.ptr(sh), L.ptr(so), n, L.ptr(sums), L.ptr(gl), ctx.w5, L.ptr(gj),
+                                         L.ptr(gR), L.ptr(gt), nj, L.ptr(gc), L.ptr(gw), L.ptr(gsh), L.ptr(gso), L.ptr(gj_o), L.ptr(gR_o), L.ptr(gt_o),
+                                         L.stream_ptr()), 'hn_fit_step_loss_bwd')
         s_c, s_w, s_s, s_j, s_r, s_t = ctx.shapes
         return (gc.reshape(s_c), gw.reshape(s_w), None if gsh is None else gsh.reshape(s_s), None if gso is None else gso.reshape(s_s),
                 gj_o.reshape(s_j), gR_o.reshape(s_r), gt_o.reshape(s_t), None, None, None, None, None, None, None)

@@ -37,7 +37,7 @@ int alpha(const float*, const float*, const float*, const float*, int, int, floa
 int composite1(const float*, const float*, const float*, const float*, int, int, float*, float*, float*, float*, float*,
                hipStream_t);
 int composite2(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
-               float*, float*, float*, float*, hipStream_t);
+               float*, float*, float*, float*, hipStream_t, float eik_scale = 1.f);
 int alpha_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float, float*,
               float*, float*, hipStream_t, bool g_rays_d_zeroed = false);
 int alpha_inv_s_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float, float*,
@@ -46,6 +46,17 @@ int composite1_bwd(const float*, const float*, const float*, const float*, const
                    hipStream_t);
 int composite2_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
                    float*, float*, float*, hipStream_t);
+int alpha_bwd_up(const float*, const float*, const float*, const float*, const float*, int, int, float, float, const float*, const float*, const float*,
+                 float*, float*, float*, const int*, const int*, const float*, float*, float*, float*, float* const*, const size_t*, int, hipStream_t);
+int obj_rays_bwd(const float*, const float*, int, int, int, float, const float*, const float*, const float*, const float*, const float*, const float*,
+                 float*, float*, float*, float*, hipStream_t);
+int dual_prologue(const float*, const float*, const float*, const float*, int, int, float*, float*, const float*, int, float, float, float, float*, float*,
+                  float*, int, hipStream_t);
+size_t fit_step_loss_scratch_bytes(int, int);
+int fit_step_loss(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*, int, const float*,
+                  const float*, const float*, const float*, const float*, int, const float*, void*, size_t, float*, float*, float*, float*, float*, hipStream_t);
+int fit_step_loss_bwd(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*, const float*,
+                      const float*, const float*, const float*, int, float*, float*, float*, float*, float*, float*, float*, hipStream_t);
 int fit_loss_sums(const float*, const float*, const float*, const float*, int, const float*, const float*, int, float*, hipStream_t);
 int fit_total(const float*, const float*, const float*, const float*, int, const float*, float*, float*, hipStream_t);
 int adam_step(int, float* const*, const float* const*, float* const*, float* const*, const int*, const float*, float, float, float, const int*, hipStream_t);
@@ -291,33 +302,39 @@ __global__ __launch_bounds__(256) void k_hand_compact_write(const float* __restr
     __shared__ int wcnt[2][4];
     __shared__ int far_blk[4], far_lane[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool last = blockIdx.x == gridDim.x - 1;
+    // the block behind the COMPACT_SPB-sample blocks appends the far sample (beside them, not after them: the launch is on the
+    // critical path of a fitting step twice)
+    const bool tail = blockIdx.x == gridDim.x - 1;
+    const int n256 = (n + 255) / 256;
     int part = 0;   // live samples in front of this block: the counts of its (COMPACT_SPB / 256) x blockIdx.x preceding 256-sample blocks
-    for (int t = threadIdx.x; t < (int)blockIdx.x * (COMPACT_SPB / 256); t += 256) part += counts[t];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
-    if (lane == 0) red[wave] = part;
-    int first_dead_blk = 0x7fffffff;   // (last block) the first 256-sample block of pass 1 that holds a dead sample
-    if (last) {
-        const int n256 = (n + 255) / 256;
-        for (int t = threadIdx.x; t < n256; t += 256) {
+    const int n_before = tail ? n256 : (int)blockIdx.x * (COMPACT_SPB / 256);
+    int first_dead_blk = 0x7fffffff;   // (tail block) the first 256-sample block of pass 1 that holds a dead sample
+    for (int t = threadIdx.x; t < n_before; t += 256) {
+        const int c = counts[t];
+        part += c;
+        if (tail) {
             const int valid = n - t * 256 < 256 ? n - t * 256 : 256;
-            if (counts[t] < valid) first_dead_blk = first_dead_blk < t ? first_dead_blk : t;
+            if (c < valid) first_dead_blk = first_dead_blk < t ? first_dead_blk : t;
         }
+    }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const int other = __shfl_xor(first_dead_blk, o, 64);
-            first_dead_blk = first_dead_blk < other ? first_dead_blk : other;
-        }
-        if (lane == 0) far_blk[wave] = first_dead_blk;
+    for (int o = 32; o >= 1; o >>= 1) {
+        part += __shfl_xor(part, o, 64);
+        const int other = __shfl_xor(first_dead_blk, o, 64);
+        first_dead_blk = first_dead_blk < other ? first_dead_blk : other;
+    }
+    if (lane == 0) {
+        red[wave] = part;
+        far_blk[wave] = first_dead_blk;
     }
     __syncthreads();
-    int far_i = -1;
-    if (last) {
+    int run = red[0] + red[1] + red[2] + red[3];
+    if (tail) {
+        int far_i = -1;
         int b = far_blk[0];
 #pragma unroll
         for (int w = 1; w < 4; ++w) b = b < far_blk[w] ? b : far_blk[w];
-        if (b != 0x7fffffff) {   // re-classify that block's samples (pos[] may already hold another block's slots): first dead one
+        if (b != 0x7fffffff) {   // re-classify that block's samples (pos[] is being rewritten by the other blocks): its first dead one
             const int i = b * 256 + threadIdx.x;
             const bool dead = i < n && !hand_sample_live(pts, i, bt_inv, T_pose, n_frames, pts_per_frame);
             const unsigned long long m = __ballot(dead);
@@ -327,8 +344,15 @@ __global__ __launch_bounds__(256) void k_hand_compact_write(const float* __restr
             for (int w = 3; w >= 0; --w)
                 if (far_lane[w] >= 0) far_i = b * 256 + w * 64 + far_lane[w];
         }
+        if (threadIdx.x == 0) {
+            idx[run] = far_i >= 0 ? far_i : 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pts_c[3 * (size_t)run + c] = far_i >= 0 ? pts[3 * (size_t)far_i + c] : 10.f;
+            n_dev[0] = run + 1;
+            n_dev[1] = far_i;   // dense index of the stand-in (-1: the launch has no dead sample)
+        }
+        return;
     }
-    int run = red[0] + red[1] + red[2] + red[3];
     for (int it = 0; it < COMPACT_SPB / 256; ++it) {
         const int i = blockIdx.x * COMPACT_SPB + it * 256 + threadIdx.x;
         const bool live = i < n && pos[i] != 0;
@@ -355,13 +379,6 @@ __global__ __launch_bounds__(256) void k_hand_compact_write(const float* __restr
             }
         }
         run += all;
-    }
-    if (last && threadIdx.x == 0) {
-        idx[run] = far_i >= 0 ? far_i : 0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) pts_c[3 * (size_t)run + c] = far_i >= 0 ? pts[3 * (size_t)far_i + c] : 10.f;
-        n_dev[0] = run + 1;
-        n_dev[1] = far_i;   // dense index of the stand-in (-1: the launch has no dead sample)
     }
 }
 // compact results -> the dense per-sample arrays (dead samples: the far sample's values)
@@ -481,7 +498,7 @@ static int compact_hand(CompactRec& cr, const float* pts, int n, const float* bt
                         hipStream_t s) {
     const int nb = (n + COMPACT_SPB - 1) / COMPACT_SPB;
     hipLaunchKernelGGL(k_hand_live_count, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, bt_inv, T_pose, n_frames, pts_per_frame, cr.pos, cr.counts);
-    hipLaunchKernelGGL(k_hand_compact_write, dim3(nb), dim3(256), 0, s, pts, n, cr.counts, cr.idx, cr.pos, cr.pts_c, cr.n_dev, bt_inv, T_pose, n_frames,
+    hipLaunchKernelGGL(k_hand_compact_write, dim3(nb + 1), dim3(256), 0, s, pts, n, cr.counts, cr.idx, cr.pos, cr.pts_c, cr.n_dev, bt_inv, T_pose, n_frames,
                        pts_per_frame);
     HN_LAUNCH_CHECK();
     return HN_OK;
@@ -770,15 +787,11 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     SideStream* side = side_stream();
     SideLock side_lock(side);
     const hipStream_t so = side != nullptr ? side->s2 : s;   // the object track's stream (s itself if no second stream)
-    HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_obj, d_obj, s));
-    HN_TRY(coarse_z(t_rand, n_rays, n_samples, (float)near, (float)(far - near), sample_dist, th.z_a, s));
-    // shared coarse depths: start the concatenated list with them
-    hipLaunchKernelGGL(k_copy_cols, dim3((n_rays * n_samples + 255) / 256), dim3(256), 0, s, th.z_a, n_rays, n_samples,
-                       zcat, S, 0);
-    HN_LAUNCH_CHECK();
+    // object-local rays, the shared coarse depths of both tracks, the first columns of the concatenated depth list: one launch
+    HN_TRY(dual_prologue(rays_o, rays_d, Ro, To, n_frames, rpf, o_obj, d_obj, t_rand, n_samples, (float)near, (float)(far - near), sample_dist, th.z_a,
+                         n_importance > 0 ? to.z_a : nullptr, zcat, S, s));
     const float* z_final = zcat;
     if (n_importance > 0) {
-        HN_CHECK_HIP(hipMemcpyAsync(to.z_a, th.z_a, (size_t)n_rays * n_samples * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (side != nullptr) HN_TRY(fork_to(side, s));
         // the two importance-sampling tracks (utils/renderer.py:463-496) are independent: hand on s, object on so
         // The two tracks are queued STAGE BY STAGE (coarse pass, then each importance round), the object's launches of a
@@ -795,26 +808,37 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
             int nf, which, k;
         };
         TrackRun runs[2] = {{&to, obj, o_obj, d_obj, so, fwso, fws_o, 1, 1, n_samples}, {&th, hand, rays_o, rays_d, s, fwsh, fws_h, n_frames, 0, n_samples}};
-        for (TrackRun& r : runs) {   // coarse pass
-            Track& t = *r.t;
-            HN_TRY(sample_points(r.ro, r.rd, t.z_a, n_rays, r.k, 0, 0.f, t.pts, nullptr, r.st));
-            const int nc = n_rays * r.k;
-            if (r.which == 0 && crec_ws != nullptr && hand_compaction(hand, n_frames, (size_t)nc)) {
-                // the hand's coarse pass on the samples with a live bone (the record of the final evaluation is written later)
-                CompactRec cr;
-                cr.at(crec_ws, (size_t)nc);
-                HN_TRY(compact_hand(cr, t.pts, nc, bt_inv, T_pose, r.nf, rpf * r.k, r.st));
-                set_launch_n_pts_dev(cr.n_dev);
-                set_launch_orig_idx(cr.idx);
-                const int rc = field_sdf(r.f, cr.pts_c, nc + 1, bt_inv, T_pose, r.nf, rpf * r.k, cr.sdf_c, r.fws, r.fwb, r.st);
-                set_launch_n_pts_dev(nullptr);
-                set_launch_orig_idx(nullptr);
-                HN_TRY(rc);
-                hipLaunchKernelGGL(k_hand_scatter_sdf, dim3((nc + 255) / 256), dim3(256), 0, r.st, cr.pos, nc, cr.n_dev, cr.sdf_c, t.sdf_a);
-                HN_LAUNCH_CHECK();
-            } else {
-                HN_TRY(field_sdf(r.f, t.pts, nc, bt_inv, T_pose, r.nf, r.which == 0 ? rpf * r.k : nc, t.sdf_a, r.fws, r.fwb, r.st));
-            }
+        // Coarse pass.  With the far-field skip the hand's coarse launch is ~120 live blocks of the latency form behind three small
+        // kernels (points, classify, compact); the object's 392 blocks, released first, take every CU (one 512-register workgroup
+        // each) and the hand's small kernels wait a whole block time for a wave slot -- and the hand's track is the longer one (its
+        // fine rounds cost twice the object's).  So: the hand's small kernels first, the object's track held back (gate) until they
+        // are done, then the hand's field launch queued ahead of the object's.  Without the skip (392 dense hand blocks): the
+        // object's launches first, as before.
+        const int nc = n_rays * n_samples;
+        const bool coarse_compact = crec_ws != nullptr && hand_compaction(hand, n_frames, (size_t)nc);
+        auto obj_coarse = [&]() -> int {
+            HN_TRY(sample_points(o_obj, d_obj, to.z_a, n_rays, n_samples, 0, 0.f, to.pts, nullptr, so));
+            return field_sdf(obj, to.pts, nc, bt_inv, T_pose, 1, nc, to.sdf_a, fwso, fws_o, so);
+        };
+        HN_TRY(sample_points(rays_o, rays_d, th.z_a, n_rays, n_samples, 0, 0.f, th.pts, nullptr, s));
+        if (coarse_compact) {
+            // the hand's coarse pass on the samples with a live bone (the record of the final evaluation is written later)
+            CompactRec cr;
+            cr.at(crec_ws, (size_t)nc);
+            HN_TRY(compact_hand(cr, th.pts, nc, bt_inv, T_pose, n_frames, rpf * n_samples, s));
+            if (side != nullptr) HN_TRY(gate_to(side, s));
+            set_launch_n_pts_dev(cr.n_dev);
+            set_launch_orig_idx(cr.idx);
+            const int rc = field_sdf(hand, cr.pts_c, nc + 1, bt_inv, T_pose, n_frames, rpf * n_samples, cr.sdf_c, fwsh, fws_h, s);
+            set_launch_n_pts_dev(nullptr);
+            set_launch_orig_idx(nullptr);
+            HN_TRY(rc);
+            HN_TRY(obj_coarse());
+            hipLaunchKernelGGL(k_hand_scatter_sdf, dim3((nc + 255) / 256), dim3(256), 0, s, cr.pos, nc, cr.n_dev, cr.sdf_c, th.sdf_a);
+            HN_LAUNCH_CHECK();
+        } else {
+            HN_TRY(obj_coarse());
+            HN_TRY(field_sdf(hand, th.pts, nc, bt_inv, T_pose, n_frames, rpf * n_samples, th.sdf_a, fwsh, fws_h, s));
         }
         for (int i = 0; i < steps; ++i) {
             for (TrackRun& r : runs) {
@@ -888,9 +912,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     if (z_vals != nullptr) HN_CHECK_HIP(hipMemcpyAsync(z_vals, z_final, N * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (side != nullptr) HN_TRY(join_from(side, s));
     HN_TRY(composite2(al_h, rgb_h, grad_hand, al_o, rgb_o, grad_obj, n_rays, S, color, weight_sum, nullptr, nullptr,
-                      gradient_error, s));
-    hipLaunchKernelGGL(k_scale, dim3(1), dim3(64), 0, s, gradient_error, 2, 1.f / (float)N);
-    HN_LAUNCH_CHECK();
+                      gradient_error, s, 1.f / (float)N));
     return HN_OK;
 }
 
@@ -951,7 +973,8 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
         return HN_ENOMEM;
     }
     if (n_rays == 0) return HN_OK;
-    HN_REQUIRE(g_color && g_rays_o && g_rays_d && g_bt_inv && g_T_pose && g_Ro && g_To, "null output / upstream gradient");
+    HN_REQUIRE(g_color && g_bt_inv && g_T_pose && g_Ro && g_To, "null output / upstream gradient");
+    HN_REQUIRE((g_rays_o == nullptr) == (g_rays_d == nullptr), "g_rays_o and g_rays_d: both or neither");
     const int n = (int)N;
     // the tapes the forward pass kept ([hand | object]): the adjoints then run alone, nothing is evaluated again
     const size_t tape_h = field_tape(hand, hand_cap(hand, N)), tape_o = field_tape(obj, n);
@@ -964,50 +987,64 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     SideStream* side = side_stream();
     SideLock side_lock(side);
     const hipStream_t so = side != nullptr ? side->s2 : s;
+    // d loss / d the WORLD rays is optional (both NULL: the fitting loops' rays come from fixed cameras and carry no gradient):
+    // without it the hand branch ends with its adjoint kernel
+    const bool want_rays = g_rays_o != nullptr;
     HN_TRY(composite2_bwd(alpha_h, rgb_h, alpha_o, rgb_o, g_color, g_wsum, n_rays, S, g_ah, g_rgbh, g_ao, g_rgbo, s));
     // The object branch's small launches are released here (fork) and run beside the hand's; its adjoint kernel itself waits at
     // a second meeting point (gate) until the hand's adjoint kernel is next in line on s: that kernel's tiles are the long ones
     // and must get their CUs first, the object's 294 shorter tiles then take what is left at once.
     if (side != nullptr) HN_TRY(fork_to(side, s));
-    // hand branch (s)
-    HN_TRY(zero_many({{g_bt_inv, (size_t)n_frames * 21 * 16}, {g_T_pose, (size_t)n_frames * 21 * 3}, {gd_h, R3}, {compact ? gdir_h : nullptr, R3}}, s));
-    HN_TRY(sample_points(rays_o, rays_d, z, n_rays, S, 1, sample_dist, pts_h, dists_h, s));
-    HN_TRY(alpha_bwd(sdf_h, grad_h, rays_d, dists_h, g_ah, nullptr, n, S, hand->inv_s, gs_h, gg_h, gd_h, s, true));
-    hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs_h, gg_h, g_sdf_h, g_grad_h, grad_h, g_eik, n);
-    if (compact) hipLaunchKernelGGL(k_hand_gather_up, dim3((n + 1 + 255) / 256), dim3(256), 0, s, cr.idx, n + 1, cr.n_dev, gs_h, gg_h, g_rgbh, gs_c, gg_c, gr_c);
-    HN_LAUNCH_CHECK();
+    // hand branch (s): ONE launch in front of the adjoint kernel (k_alpha_bwd_up: alpha stage, the caller's direct gradients, the
+    // eikonal term, the gather onto the compact list, the zero fills of what the adjoint accumulates into)
+    if (want_rays) HN_TRY(zero_many({{gd_h, R3}, {compact ? gdir_h : nullptr, R3}}, s));
+    if (!compact) HN_TRY(sample_points(rays_o, rays_d, z, n_rays, S, 1, sample_dist, pts_h, dists_h, s));   // (the compact list carries its points)
+    {
+        float* zb[2] = {g_bt_inv, g_T_pose};
+        const size_t zn[2] = {(size_t)n_frames * 21 * 16, (size_t)n_frames * 21 * 3};
+        HN_TRY(alpha_bwd_up(sdf_h, grad_h, rays_d, z, g_ah, n, S, sample_dist, hand->inv_s, g_sdf_h, g_grad_h, g_eik, gs_h, gg_h, want_rays ? gd_h : nullptr,
+                            compact ? cr.pos : nullptr, compact ? cr.n_dev : nullptr, g_rgbh, gs_c, gg_c, gr_c, zb, zn, 2, s));
+    }
     // object branch (so) up to its adjoint kernel
     HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_l, d_l, so));
     HN_TRY(sample_points(o_l, d_l, z, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
-    HN_TRY(alpha_bwd(sdf_o, grad_o, d_l, dists_o, g_ao, nullptr, n, S, obj->inv_s, gs_o, gg_o, gd_o, so));
-    hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, so, gs_o, gg_o, g_sdf_o, g_grad_o, grad_o,
-                       g_eik != nullptr ? g_eik + 1 : nullptr, n);
-    HN_LAUNCH_CHECK();
+    {
+        float* zb[3] = {gd_o, g_Ro, g_To};
+        const size_t zn[3] = {R3, (size_t)n_frames * 9, (size_t)n_frames * 3};
+        // (gd_o is accumulated into by this very launch: zeroed by its own fill in front)
+        HN_CHECK_HIP(hipMemsetAsync(gd_o, 0, R3 * sizeof(float), so));
+        HN_TRY(alpha_bwd_up(sdf_o, grad_o, d_l, z, g_ao, n, S, sample_dist, obj->inv_s, g_sdf_o, g_grad_o, g_eik != nullptr ? g_eik + 1 : nullptr, gs_o, gg_o, gd_o,
+                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, zb + 1, zn + 1, 2, so));
+    }
     if (side != nullptr) HN_TRY(gate_to(side, s));
     if (compact) {
         set_launch_n_pts_dev(cr.n_dev);
         set_launch_orig_idx(cr.idx);
-        // (gdir_h zeroed above: the hand's colour network ignores the view direction, utils/fields.py:222-240)
+        // (the hand's colour network ignores the view direction, utils/fields.py:222-240: no d loss / d rays_d through it)
         const int rc = bwd::field_eval_bwd(hand, cr.pts_c, rays_d, n + 1, 1, bt_inv, T_pose, n_frames, rpf * S, gs_c, gg_c, gr_c, gp_c, nullptr, g_bt_inv,
                                            g_T_pose, bwh, bws_h, s, tp_h, cr.grad_c, cr.rgb_c);
         set_launch_n_pts_dev(nullptr);
         set_launch_orig_idx(nullptr);
         HN_TRY(rc);
-        hipLaunchKernelGGL(k_hand_scatter3, dim3((n + 255) / 256), dim3(256), 0, s, cr.pos, n, gp_c, gp_h);
-        HN_LAUNCH_CHECK();
+        if (want_rays) {
+            hipLaunchKernelGGL(k_hand_scatter3, dim3((n + 255) / 256), dim3(256), 0, s, cr.pos, n, gp_c, gp_h);
+            HN_LAUNCH_CHECK();
+        }
     } else {
         HN_TRY(bwd::field_eval_bwd(hand, pts_h, rays_d, n, S, bt_inv, T_pose, n_frames, rpf * S, gs_h, gg_h, g_rgbh, gp_h, gdir_h, g_bt_inv,
                                    g_T_pose, bwh, bws_h, s, tp_h, grad_h, rgb_h));
     }
-    HN_TRY(sample_points_bwd(z, gp_h, n_rays, S, 1, sample_dist, go_h, gdd_h, s));
+    if (want_rays) HN_TRY(sample_points_bwd(z, gp_h, n_rays, S, 1, sample_dist, go_h, gdd_h, s));
     HN_TRY(bwd::field_eval_bwd(obj, pts_o, d_l, n, S, nullptr, nullptr, 1, n, gs_o, gg_o, g_rgbo, gp_o, gdir_o, nullptr, nullptr, bwo,
                                bws_o, so, tp_o, grad_o, rgb_o));
-    HN_TRY(sample_points_bwd(z, gp_o, n_rays, S, 1, sample_dist, go_l, gdd_l, so));
-    hipLaunchKernelGGL(k_add4, dim3(((int)R3 + 255) / 256), dim3(256), 0, so, gdd_l, gd_o, gdir_o, (const float*)nullptr, gd_l, (int)R3);
-    HN_TRY(obj_local_bwd(rays_o, rays_d, Ro, To, go_l, gd_l, n_frames, rpf, g_ro2, g_rd2, g_Ro, g_To, so));
+    // behind the object's adjoint: the ray map and the adjoint of convert_obj_to_local in one launch
+    HN_TRY(obj_rays_bwd(z, gp_o, n_frames, rpf, S, sample_dist, gd_o, gdir_o, rays_o, rays_d, Ro, To, want_rays ? g_ro2 : nullptr,
+                        want_rays ? g_rd2 : nullptr, g_Ro, g_To, so));
     if (side != nullptr) HN_TRY(join_from(side, s));
-    hipLaunchKernelGGL(k_add4x2, dim3(((int)R3 + 255) / 256), dim3(256), 0, s, go_h, g_ro2, g_rays_o, gdd_h, gd_h, gdir_h, g_rd2, g_rays_d, (int)R3);
-    HN_LAUNCH_CHECK();
+    if (want_rays) {
+        hipLaunchKernelGGL(k_add4x2, dim3(((int)R3 + 255) / 256), dim3(256), 0, s, go_h, g_ro2, g_rays_o, gdd_h, gd_h, gdir_h, g_rd2, g_rays_d, (int)R3);
+        HN_LAUNCH_CHECK();
+    }
     return HN_OK;
 }
 
@@ -1173,6 +1210,10 @@ int hn_rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pr
 int hn_verts_loss(const float* Ra, const float* ta, const float* Rb, const float* tb, const float* verts, int n_verts, int n_pairs, float* loss,
                   float* gR, float* gt, hn_stream_t stream) {
     return hn::verts_loss(Ra, ta, Rb, tb, verts, n_verts, n_pairs, loss, gR, gt, (hipStream_t)stream);
+}
+int hn_pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt_inv, const float* g_joint_3d, const float* g_obj_r, const float* g_obj_t,
+                     int n_frames, float* out, hn_stream_t stream) {
+    return hn::pose_side_vjp(jac_h, jac_o, g_bt_inv, g_joint_3d, g_obj_r, g_obj_t, n_frames, out, (hipStream_t)stream);
 }
 int hn_jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int n_in, float* out, hn_stream_t stream) {
     return hn::jacobian_vjp(jac, g, n_frames, n_out, n_in, out, (hipStream_t)stream);
@@ -1393,6 +1434,21 @@ int hn_adam_step(int n_tensors, float* const* params, const float* const* grads,
 int hn_fit_total(const float* sums6, const float* verts_loss, const float* joint_3d, const float* joint3d_pred, int n_joints,
                  const float* weights5, float* terms8, float* g_joint, hn_stream_t stream) {
     return fit_total(sums6, verts_loss, joint_3d, joint3d_pred, n_joints, weights5, terms8, g_joint, (hipStream_t)stream);
+}
+size_t hn_fit_step_loss_scratch_bytes(int n_rays, int n_samples) { return hn::fit_step_loss_scratch_bytes(n_rays, n_samples); }
+int hn_fit_step_loss(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_hand,
+                     const float* sdf_obj, int n_samples, const float* joint_3d, const float* joint3d_pred, int n_joints, const float* Ra, const float* ta,
+                     const float* Rb, const float* tb, const float* verts, int n_verts, const float* weights5, void* scratch, size_t scratch_bytes,
+                     float* sums6, float* terms8, float* g_joint, float* gR, float* gt, hn_stream_t stream) {
+    return hn::fit_step_loss(color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, joint_3d, joint3d_pred, n_joints, Ra, ta, Rb, tb,
+                             verts, n_verts, weights5, scratch, scratch_bytes, sums6, terms8, g_joint, gR, gt, (hipStream_t)stream);
+}
+int hn_fit_step_loss_bwd(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_hand,
+                         const float* sdf_obj, int n_samples, const float* sums6, const float* g_loss, const float* weights5, const float* g_joint,
+                         const float* gR, const float* gt, int n_joints, float* g_color, float* g_weight_sum, float* g_sdf_hand, float* g_sdf_obj,
+                         float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream) {
+    return hn::fit_step_loss_bwd(color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, sums6, g_loss, weights5, g_joint, gR, gt,
+                                 n_joints, g_color, g_weight_sum, g_sdf_hand, g_sdf_obj, g_joint_out, gR_out, gt_out, (hipStream_t)stream);
 }
 int hn_fit_total_bwd(const float* g_loss, const float* weights5, const float* g_joint, const float* gR, const float* gt, int n_joints,
                      float* g4, float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream) {

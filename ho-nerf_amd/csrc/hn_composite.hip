@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_composite2(const float* __restrict__ ah
                                                     const float* __restrict__ rgbo, const float* __restrict__ go,
                                                     int n_rays, int S, float* __restrict__ color,
                                                     float* __restrict__ weight_sum, float* __restrict__ w_hand,
-                                                    float* __restrict__ w_obj, float* __restrict__ eik_sum) {
+                                                    float* __restrict__ w_obj, float* __restrict__ eik_sum, float eik_scale) {
     const int lane = threadIdx.x & 63;
     float eh_total = 0.f, eo_total = 0.f;
     for (int ray = blockIdx.x * 4 + (threadIdx.x >> 6); ray < n_rays; ray += gridDim.x * 4) {
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void k_composite2(const float* __restrict__ ah
     eo_total += eo;
     }
     if (eik_sum != nullptr) {
-        if (gh != nullptr) block_atomic_add(eik_sum, eh_total);
-        if (go != nullptr) block_atomic_add(eik_sum + 1, eo_total);
+        if (gh != nullptr) block_atomic_add(eik_sum, eh_total * eik_scale);
+        if (go != nullptr) block_atomic_add(eik_sum + 1, eo_total * eik_scale);
     }
 }
 
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_composite2_rows(const float* __restrict
                                                          const float* __restrict__ rgbo, const float* __restrict__ go,
                                                          int n_rays, float* __restrict__ color, float* __restrict__ weight_sum,
                                                          float* __restrict__ w_hand, float* __restrict__ w_obj,
-                                                         float* __restrict__ eik_sum) {
+                                                         float* __restrict__ eik_sum, float eik_scale) {
     constexpr int S = LPR * CPS, RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, l = lane & (LPR - 1), row = lane / LPR;
     float eh_total = 0.f, eo_total = 0.f;
@@ -398,8 +398,8 @@ __global__ __launch_bounds__(256) void k_composite2_rows(const float* __restrict
         eo_total += ok ? eo : 0.f;
     }
     if (eik_sum != nullptr) {
-        if (gh != nullptr) block_atomic_add(eik_sum, wave_sum(eh_total));
-        if (go != nullptr) block_atomic_add(eik_sum + 1, wave_sum(eo_total));
+        if (gh != nullptr) block_atomic_add(eik_sum, wave_sum(eh_total) * eik_scale);
+        if (go != nullptr) block_atomic_add(eik_sum + 1, wave_sum(eo_total) * eik_scale);
     }
 }
 
@@ -660,9 +660,11 @@ int composite1(const float* alpha_in, const float* c, const float* rgb, const fl
     return HN_OK;
 }
 
+// eik_scale: what the two eikonal sums are multiplied by as they are accumulated (1: the plain sums of hn_composite2; the
+// two-field render passes 1 / (rays x S), the mean of utils/renderer.py:417, instead of a scaling launch behind this one)
 int composite2(const float* ah, const float* rgbh, const float* gh, const float* ao, const float* rgbo, const float* go,
                int n_rays, int S, float* color, float* weight_sum, float* w_hand, float* w_obj, float* eik_sum,
-               hipStream_t s) {
+               hipStream_t s, float eik_scale) {
     HN_REQUIRE(S >= 1, "S must be positive");
     if (n_rays == 0) return HN_OK;
     auto rgrid = [&](int lpr) {
@@ -671,16 +673,16 @@ int composite2(const float* ah, const float* rgbh, const float* gh, const float*
     };
     if (S == 64)
         hipLaunchKernelGGL((k_composite2_rows<4, 16>), rgrid(16), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, color, weight_sum,
-                           w_hand, w_obj, eik_sum);
+                           w_hand, w_obj, eik_sum, eik_scale);
     else if (S == 128)
         hipLaunchKernelGGL((k_composite2_rows<8, 16>), rgrid(16), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, color, weight_sum,
-                           w_hand, w_obj, eik_sum);
+                           w_hand, w_obj, eik_sum, eik_scale);
     else if (S == 192)
         hipLaunchKernelGGL((k_composite2_rows<12, 16>), rgrid(16), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, color, weight_sum,
-                           w_hand, w_obj, eik_sum);
+                           w_hand, w_obj, eik_sum, eik_scale);
     else
         hipLaunchKernelGGL(k_composite2, dim3(composite_grid(n_rays)), dim3(256), 0, s, ah, rgbh, gh, ao, rgbo, go, n_rays, S,
-                           color, weight_sum, w_hand, w_obj, eik_sum);
+                           color, weight_sum, w_hand, w_obj, eik_sum, eik_scale);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -693,6 +695,129 @@ int alpha_bwd(const float* sdf, const float* grad, const float* rays_d, const fl
     if (g_rays_d != nullptr && !g_rays_d_zeroed) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n / spr) * 3 * sizeof(float), s));
     hipLaunchKernelGGL(k_alpha_bwd, dim3((n + 255) / 256), dim3(256), 0, s, sdf, grad, rays_d, dists, g_alpha, g_c, n, spr,
                        inv_s, g_sdf, g_grad, g_rays_d);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+// The preamble of a field's adjoint in the two-field backward pass as ONE launch (it was alpha_bwd + k_upstream [+ the gather
+// onto the compacted sample list] [+ a zero fill] [+ a sample_points launch for the dists]: a step is a chain of dependent
+// launches, ~5 us each whatever they do).  Per sample: k_alpha_bwd's values, with the section length taken from the depths
+// (utils/renderer.py:119-120: z_{k+1} - z_k, the last one sample_dist) instead of a dists array;
+//   gs = d/d sdf through alpha + the caller's direct gradient on the sdf output,
+//   gg = d/d gradient through alpha + the caller's direct gradient + the eikonal term (k_upstream, hn_api.hip);
+// with `pos` (hn_field_set_compaction) the live samples' (gs, gg, g_rgb) also go to their slots of the compact list and the
+// stand-in's slot n_dev[0] - 1 is zeroed (it stands for samples that contribute nothing); `zero`: buffers the adjoint kernel
+// behind this launch accumulates into.
+struct AlphaUpZero {
+    float* p[4];
+    int n[4];
+};
+__global__ __launch_bounds__(256) void k_alpha_bwd_up(const float* __restrict__ sdf, const float* __restrict__ grad, const float* __restrict__ rays_d,
+                                                      const float* __restrict__ z, const float* __restrict__ g_alpha, int n, int spr, float sample_dist,
+                                                      float inv_s, const float* __restrict__ g_sdf_out, const float* __restrict__ g_grad_out,
+                                                      const float* __restrict__ g_eik, float* __restrict__ gs, float* __restrict__ gg,
+                                                      float* __restrict__ g_rays_d, const int* __restrict__ pos, const int* __restrict__ n_dev,
+                                                      const float* __restrict__ g_rgb, float* __restrict__ gs_c, float* __restrict__ gg_c,
+                                                      float* __restrict__ gr_c, AlphaUpZero zero) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        if (zero.p[b] != nullptr && i < zero.n[b]) zero.p[b][i] = 0.f;
+    if (pos != nullptr && i == 0) {
+        const int M = n_dev[0] - 1;
+        gs_c[M] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gg_c[3 * (size_t)M + c] = 0.f;
+            gr_c[3 * (size_t)M + c] = 0.f;
+        }
+    }
+    if (i >= n) return;
+    const int ray = i / spr, k = i - ray * spr;
+    const float d0 = rays_d[3 * ray], d1 = rays_d[3 * ray + 1], d2 = rays_d[3 * ray + 2];
+    const float q0 = grad[3 * (size_t)i], q1 = grad[3 * (size_t)i + 1], q2 = grad[3 * (size_t)i + 2];
+    const float tc = d0 * q0 + d1 * q1 + d2 * q2;
+    const float ic = -fmaxf(-tc, 0.f);
+    const float sv = sdf[i];
+    const float dist = (k + 1 < spr) ? z[i + 1] - z[i] : sample_dist;
+    const float half = ic * dist * 0.5f;
+    const float c = sigmoid_e((sv - half) * inv_s);
+    const float nx = sigmoid_e((sv + half) * inv_s);
+    const float A = (c - nx) + 1e-5f, B = c + 1e-5f;
+    const float a_raw = A / B;
+    const float ga = (a_raw > 0.f && a_raw < 1.f) ? g_alpha[i] : 0.f;   // clip(0, 1)
+    const float gc = ga * (B - A) / (B * B);
+    const float gnx = -ga / B;
+    const float gx1 = gc * inv_s * c * (1.f - c);
+    const float gx2 = gnx * inv_s * nx * (1.f - nx);
+    float o_s = gx1 + gx2;
+    const float ghalf = gx2 - gx1;
+    const float gtc = (tc < 0.f) ? ghalf * dist * 0.5f : 0.f;
+    float o_g[3] = {gtc * d0, gtc * d1, gtc * d2};
+    // (the same association as the two launches this replaces: (alpha part) + direct, then + eikonal)
+    if (g_sdf_out != nullptr) o_s += g_sdf_out[i];
+    float a3[3] = {0.f, 0.f, 0.f};
+    if (g_grad_out != nullptr) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) a3[cc] = g_grad_out[3 * (size_t)i + cc];
+    }
+    if (g_eik != nullptr) {
+        const float nrm = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+        const float kk = (2.f / (float)n) * g_eik[0] * (nrm - 1.f) / fmaxf(nrm, 1e-30f);
+        a3[0] += kk * q0;
+        a3[1] += kk * q1;
+        a3[2] += kk * q2;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) o_g[cc] += a3[cc];
+    gs[i] = o_s;
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) gg[3 * (size_t)i + cc] = o_g[cc];
+    if (pos != nullptr) {
+        const int slot = pos[i];
+        if (slot >= 0) {
+            gs_c[slot] = o_s;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                gg_c[3 * (size_t)slot + cc] = o_g[cc];
+                gr_c[3 * (size_t)slot + cc] = g_rgb[3 * (size_t)i + cc];
+            }
+        }
+    }
+    if (g_rays_d != nullptr) {
+        const int ray0 = __shfl(ray, 0, 64);
+        const bool whole = __all(ray == ray0) && __popcll(__ballot(1)) == 64;
+        if (whole) {
+            const float r0 = wave_sum(gtc * q0), r1 = wave_sum(gtc * q1), r2 = wave_sum(gtc * q2);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(g_rays_d + 3 * ray, r0);
+                atomicAdd(g_rays_d + 3 * ray + 1, r1);
+                atomicAdd(g_rays_d + 3 * ray + 2, r2);
+            }
+        } else {
+            atomicAdd(g_rays_d + 3 * ray, gtc * q0);
+            atomicAdd(g_rays_d + 3 * ray + 1, gtc * q1);
+            atomicAdd(g_rays_d + 3 * ray + 2, gtc * q2);
+        }
+    }
+}
+// g_rays_d (may be NULL) must be zeroed by the caller -- or listed in `zero_bufs`, when no sample's atomics can precede its zero
+// fill: that holds only for buffers this launch does not accumulate into, so g_rays_d is NOT to be listed there.
+int alpha_bwd_up(const float* sdf, const float* grad, const float* rays_d, const float* z, const float* g_alpha, int n, int spr, float sample_dist,
+                 float inv_s, const float* g_sdf_out, const float* g_grad_out, const float* g_eik, float* gs, float* gg, float* g_rays_d,
+                 const int* pos, const int* n_dev, const float* g_rgb, float* gs_c, float* gg_c, float* gr_c, float* const* zero_bufs,
+                 const size_t* zero_sizes, int n_zero, hipStream_t s) {
+    HN_REQUIRE(spr > 0 && n_zero <= 4, "samples_per_ray must be positive, at most four buffers to zero");
+    if (n == 0) return HN_OK;
+    AlphaUpZero zl{};
+    int most = n;
+    for (int b = 0; b < n_zero; ++b) {
+        zl.p[b] = zero_bufs[b];
+        zl.n[b] = (int)zero_sizes[b];
+        most = most > zl.n[b] ? most : zl.n[b];
+    }
+    hipLaunchKernelGGL(k_alpha_bwd_up, dim3((most + 255) / 256), dim3(256), 0, s, sdf, grad, rays_d, z, g_alpha, n, spr, sample_dist, inv_s, g_sdf_out,
+                       g_grad_out, g_eik, gs, gg, g_rays_d, pos, n_dev, g_rgb, gs_c, gg_c, gr_c, zl);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -926,6 +1051,213 @@ int fit_total_bwd(const float* g_loss, const float* w5, const float* g_joint, co
     HN_REQUIRE(g_loss && w5 && g_joint && gR && gt && g4 && g_joint_out && gR_out && gt_out && n_joints >= 1 && n_joints <= 64, "bad arguments");
     hipLaunchKernelGGL(k_fit_total_bwd, dim3(1), dim3(64), 0, s, g_loss, w5[0], w5[1], w5[2], w5[3], w5[4], g_joint, gR, gt, n_joints, g4,
                        g_joint_out, gR_out, gt_out);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+// ---- the whole loss of a fitting_single step as ONE launch forward and ONE backward (fitting_single.py:251-288) -------------
+// Forward (k_fit_step_loss): every block reduces its share of the six sums of k_fit_loss_sums to a slot of `partials`; the block
+// that finishes last (a counter it resets for the next call) adds the slots IN INDEX ORDER -- the sums do not depend on the order
+// the blocks ran in: two runs of a step give the same loss terms bit for bit -- and goes on to the vertex loss (k_verts_loss's
+// statements for one pose pair), the joint loss and the weighted total (k_fit_total's).  As separate launches (memset, sums,
+// vertex loss, total) it was four links of the dependent-launch chain between the render and its backward pass.
+__global__ __launch_bounds__(256) void k_fit_step_loss(const float* __restrict__ color, const float* __restrict__ wsum, const float* __restrict__ true_rgb,
+                                                       const float* __restrict__ true_mask, int n_rays, const float* __restrict__ sdf_h,
+                                                       const float* __restrict__ sdf_o, int n_samples, const float* __restrict__ joint_3d,
+                                                       const float* __restrict__ joint_pred, int n_joints, const float* __restrict__ Ra,
+                                                       const float* __restrict__ ta, const float* __restrict__ Rb, const float* __restrict__ tb,
+                                                       const float* __restrict__ verts, int n_verts, float w0, float w1, float w2, float w3, float w4,
+                                                       float* __restrict__ partials, unsigned* __restrict__ counter, float* __restrict__ sums6,
+                                                       float* __restrict__ terms8, float* __restrict__ g_joint, float* __restrict__ gR,
+                                                       float* __restrict__ gt) {
+    __shared__ float red[13][4];
+    __shared__ bool is_last;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < n_rays) {
+        const float m = true_mask[i], inv = 1.f / (float)n_rays;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[0] += fabsf((color[3 * (size_t)i + c] - true_rgb[3 * (size_t)i + c]) * m);
+        const float w = fminf(fmaxf(wsum[i], 1e-3f), 1.f - 1e-3f);
+        v[0] *= inv;
+        v[1] = -(m * logf(w) + (1.f - m) * logf(1.f - w)) * inv;
+    }
+    if (sdf_h != nullptr && i < n_samples) {
+        const float sh = sdf_h[i], so = sdf_o[i];
+        const float a = fabsf(sh) + fabsf(so);
+        if (a < 1e-2f) {
+            v[2] = a;
+            v[3] = 1.f;
+        }
+        if (so < 0.f && sh < 0.f) {
+            v[4] = a;
+            v[5] = 1.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float t = wave_sum(v[k]);
+        if (lane == 0) red[k][wave] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) partials[6 * (size_t)blockIdx.x + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    // ---- the last block: the six sums, in block order
+    float acc = 0.f;
+    if (threadIdx.x < 6)
+        for (unsigned b = 0; b < gridDim.x; ++b) acc += reinterpret_cast<const volatile float*>(partials)[6 * (size_t)b + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        red[threadIdx.x][0] = acc;
+        sums6[threadIdx.x] = acc;
+    }
+    if (threadIdx.x == 0) *counter = 0u;
+    __syncthreads();
+    const float colour = red[0][0], mask = red[1][0];
+    const float contact = red[2][0] / (red[3][0] + 1e-9f), penet = red[4][0] / (red[5][0] + 1e-9f);
+    __syncthreads();
+    // ---- vertex loss of the pose pair (k_verts_loss, one pair) and its gradient w.r.t. (Ra, ta)
+    float D[9], dd[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) D[k] = Ra[k] - Rb[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dd[k] = ta[k] - tb[k];
+    float a13[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) a13[k] = 0.f;
+    for (int q = threadIdx.x; q < n_verts; q += blockDim.x) {
+        const float x = verts[3 * q], y = verts[3 * q + 1], z = verts[3 * q + 2];
+        const float e0 = D[0] * x + D[1] * y + D[2] * z + dd[0], e1 = D[3] * x + D[4] * y + D[5] * z + dd[1], e2 = D[6] * x + D[7] * y + D[8] * z + dd[2];
+        const float nn = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+        const float inv = nn > 0.f ? 1.f / nn : 0.f;
+        const float u0 = e0 * inv, u1 = e1 * inv, u2 = e2 * inv;
+        a13[0] += nn;
+        a13[1] += u0 * x; a13[2] += u0 * y; a13[3] += u0 * z;
+        a13[4] += u1 * x; a13[5] += u1 * y; a13[6] += u1 * z;
+        a13[7] += u2 * x; a13[8] += u2 * y; a13[9] += u2 * z;
+        a13[10] += u0; a13[11] += u1; a13[12] += u2;
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const float t = wave_sum(a13[k]);
+        if (lane == 0) red[k][wave] = t;
+    }
+    __syncthreads();
+    float verts_loss = 0.f;
+    if (threadIdx.x < 13) {
+        const float t = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) / (float)n_verts;
+        if (threadIdx.x == 0)
+            verts_loss = t;
+        else if (threadIdx.x < 10)
+            gR[threadIdx.x - 1] = t;
+        else
+            gt[threadIdx.x - 10] = t;
+    }
+    // ---- joint loss (k_fit_total's statements) and the total, by the first wave
+    if (wave != 0) return;
+    float nrm = 0.f;
+    if (lane < n_joints) {
+        const float e0 = joint_3d[3 * lane] - joint_pred[3 * lane], e1 = joint_3d[3 * lane + 1] - joint_pred[3 * lane + 1],
+                    e2 = joint_3d[3 * lane + 2] - joint_pred[3 * lane + 2];
+        nrm = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+        const float inv = nrm > 0.f ? 1.f / (nrm * (float)n_joints) : 0.f;
+        g_joint[3 * lane] = e0 * inv;
+        g_joint[3 * lane + 1] = e1 * inv;
+        g_joint[3 * lane + 2] = e2 * inv;
+    }
+    const float joint = wave_sum(nrm) / (float)n_joints;
+    if (lane == 0) {
+        terms8[0] = w0 * (colour + 0.5f * mask) + (w1 * contact + w2 * penet) + (w3 * joint + w4 * verts_loss);
+        terms8[1] = colour;
+        terms8[2] = mask;
+        terms8[3] = contact;
+        terms8[4] = penet;
+        terms8[5] = joint;
+        terms8[6] = verts_loss;
+        terms8[7] = 0.f;
+    }
+}
+// Backward: k_fit_loss_grads with the four upstream factors formed from the loss's upstream gradient and the weights in the
+// kernel (k_fit_total_bwd's statements), and the pose-side gradients scaled by block 0.
+__global__ __launch_bounds__(256) void k_fit_step_loss_bwd(const float* __restrict__ color, const float* __restrict__ wsum, const float* __restrict__ true_rgb,
+                                                           const float* __restrict__ true_mask, int n_rays, const float* __restrict__ sdf_h,
+                                                           const float* __restrict__ sdf_o, int n_samples, const float* __restrict__ sums,
+                                                           const float* __restrict__ g_loss, float w0, float w1, float w2, float w3, float w4,
+                                                           const float* __restrict__ g_joint, const float* __restrict__ gR, const float* __restrict__ gt,
+                                                           int n_joints, float* __restrict__ g_color, float* __restrict__ g_wsum,
+                                                           float* __restrict__ g_sdf_h, float* __restrict__ g_sdf_o, float* __restrict__ g_joint_out,
+                                                           float* __restrict__ gR_out, float* __restrict__ gt_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float gl = g_loss[0];
+    const float g0 = gl * w0, g1 = gl * w0 * 0.5f, g2 = gl * w1, g3 = gl * w2;
+    if (blockIdx.x == 0) {
+        for (int k = threadIdx.x; k < 3 * n_joints; k += blockDim.x) g_joint_out[k] = gl * w3 * g_joint[k];
+        if (threadIdx.x < 9) gR_out[threadIdx.x] = gl * w4 * gR[threadIdx.x];
+        if (threadIdx.x < 3) gt_out[threadIdx.x] = gl * w4 * gt[threadIdx.x];
+    }
+    if (i < n_rays) {
+        const float m = true_mask[i], inv = 1.f / (float)n_rays;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float e = (color[3 * (size_t)i + c] - true_rgb[3 * (size_t)i + c]) * m;
+            g_color[3 * (size_t)i + c] = g0 * inv * m * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+        }
+        const float wv = wsum[i];
+        const float w = fminf(fmaxf(wv, 1e-3f), 1.f - 1e-3f);
+        const bool inside = wv >= 1e-3f && wv <= 1.f - 1e-3f;
+        g_wsum[i] = inside ? g1 * inv * (w - m) / (w * (1.f - w)) : 0.f;
+    }
+    if (sdf_h != nullptr && i < n_samples) {
+        const float sh = sdf_h[i], so = sdf_o[i];
+        const float a = fabsf(sh) + fabsf(so);
+        float k = 0.f;
+        if (a < 1e-2f) k += g2 / (sums[3] + 1e-9f);
+        if (so < 0.f && sh < 0.f) k += g3 / (sums[5] + 1e-9f);
+        g_sdf_h[i] = k * (sh > 0.f ? 1.f : (sh < 0.f ? -1.f : 0.f));
+        g_sdf_o[i] = k * (so > 0.f ? 1.f : (so < 0.f ? -1.f : 0.f));
+    }
+}
+size_t fit_step_loss_scratch_bytes(int n_rays, int n_samples) {
+    const int n = n_rays > n_samples ? n_rays : n_samples;
+    return ((size_t)((n + 255) / 256 + 1) * 6 + 16) * sizeof(float);
+}
+int fit_step_loss(const float* color, const float* wsum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_h, const float* sdf_o,
+                  int n_samples, const float* joint_3d, const float* joint_pred, int n_joints, const float* Ra, const float* ta, const float* Rb,
+                  const float* tb, const float* verts, int n_verts, const float* w5, void* scratch, size_t scratch_bytes, float* sums6, float* terms8,
+                  float* g_joint, float* gR, float* gt, hipStream_t s) {
+    HN_REQUIRE(color && wsum && true_rgb && true_mask && joint_3d && joint_pred && Ra && ta && Rb && tb && verts && w5 && scratch && sums6 && terms8 &&
+                   g_joint && gR && gt,
+               "fit_step_loss: null argument");
+    HN_REQUIRE(n_rays >= 1 && (sdf_h == nullptr) == (sdf_o == nullptr) && n_joints >= 1 && n_joints <= 64 && n_verts >= 1, "fit_step_loss: bad sizes");
+    const int ns = sdf_h != nullptr ? n_samples : 0;
+    HN_REQUIRE(scratch_bytes >= fit_step_loss_scratch_bytes(n_rays, ns), "fit_step_loss: scratch too small");
+    const int n = n_rays > ns ? n_rays : ns;
+    const int blocks = (n + 255) / 256;
+    float* partials = reinterpret_cast<float*>(scratch) + 16;
+    unsigned* counter = reinterpret_cast<unsigned*>(scratch);   // zero when the scratch is first handed over; every launch leaves it zero
+    hipLaunchKernelGGL(k_fit_step_loss, dim3(blocks), dim3(256), 0, s, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o, ns, joint_3d, joint_pred,
+                       n_joints, Ra, ta, Rb, tb, verts, n_verts, w5[0], w5[1], w5[2], w5[3], w5[4], partials, counter, sums6, terms8, g_joint, gR, gt);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+int fit_step_loss_bwd(const float* color, const float* wsum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_h,
+                      const float* sdf_o, int n_samples, const float* sums6, const float* g_loss, const float* w5, const float* g_joint, const float* gR,
+                      const float* gt, int n_joints, float* g_color, float* g_wsum, float* g_sdf_h, float* g_sdf_o, float* g_joint_out, float* gR_out,
+                      float* gt_out, hipStream_t s) {
+    HN_REQUIRE(color && wsum && true_rgb && true_mask && sums6 && g_loss && w5 && g_joint && gR && gt && g_color && g_wsum && g_joint_out && gR_out && gt_out,
+               "fit_step_loss_bwd: null argument");
+    HN_REQUIRE(sdf_h == nullptr || (sdf_o && g_sdf_h && g_sdf_o), "sdf gradients need both fields");
+    const int ns = sdf_h != nullptr ? n_samples : 0;
+    const int n = n_rays > ns ? n_rays : ns;
+    if (n <= 0) return HN_OK;
+    hipLaunchKernelGGL(k_fit_step_loss_bwd, dim3((n + 255) / 256), dim3(256), 0, s, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o, ns, sums6, g_loss,
+                       w5[0], w5[1], w5[2], w5[3], w5[4], g_joint, gR, gt, n_joints, g_color, g_wsum, g_sdf_h, g_sdf_o, g_joint_out, gR_out, gt_out);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

@@ -129,6 +129,37 @@ __global__ void k_coarse_z(const float* __restrict__ t_rand, int n_rays, int n, 
     z[i] = (near + span * lin) + (t_rand[b] - 0.5f) * sample_dist;
 }
 
+// The opening of the two-field render as ONE launch (it was obj_local_fwd + coarse_z + a column copy + a device copy, four
+// dependent launches in front of the first field kernel): the object-local rays (k_obj_local_fwd's statements), the shared
+// coarse depths (k_coarse_z's statements) written to both sampling tracks and to columns 0 .. n-1 of the [n_rays, S] list
+// that collects every round's depths.
+__global__ void k_dual_prologue(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ Ro, const float* __restrict__ To,
+                                int n_rays, int rays_per_frame, float* __restrict__ o_out, float* __restrict__ d_out,
+                                const float* __restrict__ t_rand, int n, float near, float span, float sample_dist, float* __restrict__ z_hand,
+                                float* __restrict__ z_obj, float* __restrict__ zcat, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rays) {
+        const int f = i / rays_per_frame;
+        const float* R = Ro + 9 * f;
+        const float* T = To + 3 * f;
+        const float a[3] = {o[3 * i] - T[0], o[3 * i + 1] - T[1], o[3 * i + 2] - T[2]};
+        const float b[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            o_out[3 * i + r] = R[3 * r] * a[0] + R[3 * r + 1] * a[1] + R[3 * r + 2] * a[2];
+            d_out[3 * i + r] = R[3 * r] * b[0] + R[3 * r + 1] * b[1] + R[3 * r + 2] * b[2];
+        }
+    }
+    if (i >= n_rays * n) return;
+    const int b = i / n, k = i % n;
+    const float step = 1.f / (float)(n - 1);
+    const float lin = (k < n / 2) ? (float)k * step : 1.f - (float)(n - 1 - k) * step;
+    const float zv = (near + span * lin) + (t_rand[b] - 0.5f) * sample_dist;
+    z_hand[i] = zv;
+    if (z_obj != nullptr) z_obj[i] = zv;
+    zcat[(size_t)b * S + k] = zv;
+}
+
 // ---- sample positions (utils/renderer.py:216 / 119-123) -----------------------------------------
 __global__ void k_sample_points(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z,
                                 int n_rays, int n, int mid, float sample_dist, float* __restrict__ pts,
@@ -270,6 +301,56 @@ __global__ __launch_bounds__(256) void k_sample_points_bwd(const float* __restri
             g_o[3 * ray + c] = acc[c];
             g_d[3 * ray + c] = acc[3 + c];
         }
+    }
+}
+
+// The object branch behind its adjoint kernel as ONE launch (it was sample_points_bwd + an add + obj_local_bwd): one wave per ray;
+//   go = sum_k g_pts[k],  gd = sum_k t_k g_pts[k] + gd_alpha + gd_colour   (d loss / d the object-local ray),
+// then the adjoint of o' = Ro (o - To), d' = Ro d:  g_Ro += go (o - To)^T + gd d^T,  g_To -= Ro^T go  (atomics: the caller zeroes
+// g_Ro [F,3,3] and g_To [F,3]);  g_o = Ro^T go, g_d = Ro^T gd when the world rays' gradients are wanted.
+__global__ __launch_bounds__(256) void k_obj_rays_bwd(const float* __restrict__ z, const float* __restrict__ g_pts, int n_rays, int n, float sample_dist,
+                                                      const float* __restrict__ gd_alpha, const float* __restrict__ gd_colour,
+                                                      const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ Ro,
+                                                      const float* __restrict__ To, int rays_per_frame, float* __restrict__ g_o,
+                                                      float* __restrict__ g_d, float* __restrict__ g_Ro, float* __restrict__ g_To) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < n; k += 64) {
+        const size_t i = (size_t)ray * n + k;
+        float t = z[i];
+        t = t + ((k + 1 < n) ? z[i + 1] - t : sample_dist) * 0.5f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = g_pts[3 * i + c];
+            acc[c] += g;
+            acc[3 + c] += t * g;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+        for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
+    const int f = ray / rays_per_frame;
+    const float* R = Ro + 9 * f;
+    const float* T = To + 3 * f;
+    const float go[3] = {acc[0], acc[1], acc[2]};
+    float gd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gd[c] = acc[3 + c] + gd_alpha[3 * ray + c] + (gd_colour != nullptr ? gd_colour[3 * ray + c] : 0.f);
+    // lanes 0..8: an element of g_Ro; 9..11: of g_To; 12..14 / 15..17: of g_o / g_d
+    if (lane < 9) {
+        const int r = lane / 3, c = lane % 3;
+        atomicAdd(g_Ro + 9 * f + lane, go[r] * (o[3 * ray + c] - T[c]) + gd[r] * d[3 * ray + c]);
+    } else if (lane < 12) {
+        const int c = lane - 9;
+        atomicAdd(g_To + 3 * f + c, -(R[c] * go[0] + R[3 + c] * go[1] + R[6 + c] * go[2]));
+    } else if (lane < 15 && g_o != nullptr) {
+        const int c = lane - 12;
+        g_o[3 * ray + c] = R[c] * go[0] + R[3 + c] * go[1] + R[6 + c] * go[2];
+    } else if (lane >= 15 && lane < 18 && g_d != nullptr) {
+        const int c = lane - 15;
+        g_d[3 * ray + c] = R[c] * gd[0] + R[3 + c] * gd[1] + R[6 + c] * gd[2];
     }
 }
 
@@ -774,6 +855,29 @@ int sample_points_bwd(const float* z, const float* g_pts, int n_rays, int n, int
     HN_REQUIRE(n >= 1, "n must be positive");
     hipLaunchKernelGGL(k_sample_points_bwd, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, g_pts, n_rays, n, mid, sample_dist,
                        g_o, g_d);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int dual_prologue(const float* o, const float* d, const float* Ro, const float* To, int n_frames, int rpf, float* o_out, float* d_out,
+                  const float* t_rand, int n, float near, float span, float sample_dist, float* z_hand, float* z_obj, float* zcat, int S,
+                  hipStream_t s) {
+    HN_REQUIRE(n >= 2 && n_frames > 0 && rpf >= 0, "bad prologue sizes");
+    const size_t n_rays = (size_t)n_frames * rpf;
+    if (n_rays == 0) return HN_OK;
+    hipLaunchKernelGGL(k_dual_prologue, grid1d(n_rays * n, 256), dim3(256), 0, s, o, d, Ro, To, (int)n_rays, rpf, o_out, d_out, t_rand, n, near, span,
+                       sample_dist, z_hand, z_obj, zcat, S);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+
+int obj_rays_bwd(const float* z, const float* g_pts, int n_frames, int rpf, int n, float sample_dist, const float* gd_alpha, const float* gd_colour,
+                 const float* o, const float* d, const float* Ro, const float* To, float* g_o, float* g_d, float* g_Ro, float* g_To, hipStream_t s) {
+    const int n_rays = n_frames * rpf;
+    if (n_rays == 0) return HN_OK;
+    HN_REQUIRE(n >= 1 && rpf >= 1 && g_Ro != nullptr && g_To != nullptr && gd_alpha != nullptr, "obj_rays_bwd: bad arguments");
+    hipLaunchKernelGGL(k_obj_rays_bwd, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, g_pts, n_rays, n, sample_dist, gd_alpha, gd_colour, o, d, Ro, To, rpf,
+                       g_o, g_d, g_Ro, g_To);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

@@ -189,8 +189,9 @@ class HaloChainFn(torch.autograd.Function):
         jac_h = torch.empty(F, N_OUT, N_IN, device=dev, dtype=torch.float32) if need else None
         L.check(lib.hn_pose_chain(L.ptr(ori_pose), L.ptr(bone_len), None, L.ptr(prm_h), F, L.ptr(bt), L.ptr(j3), L.ptr(jac_h) if need else None, st),
                 'hn_pose_chain')
-        out = torch.zeros(F, 412, device=dev, dtype=torch.float32)
-        jac_o = torch.zeros(F, 412, 18, device=dev, dtype=torch.float32) if need else None
+        # (object half only: entries 399 .. 410 of out / jac_o are written, and only those are read below)
+        out = torch.empty(F, 412, device=dev, dtype=torch.float32)
+        jac_o = torch.empty(F, 412, 18, device=dev, dtype=torch.float32) if need else None
         L.check(lib.hn_rigid_pose(None, None, L.ptr(Ro_pred), L.ptr(To_pred), L.ptr(prm_o), F, 0, L.ptr(out), L.ptr(jac_o) if need else None, st),
                 'hn_rigid_pose')
         ctx.jac_h, ctx.jac_o, ctx.F = jac_h, jac_o, F
@@ -203,27 +204,13 @@ class HaloChainFn(torch.autograd.Function):
         lib = L.load()
         F = ctx.F
         dev = ctx.jac_h.device
-        st = L.stream_ptr()
-        z = lambda t, n: torch.zeros(F, n, device=dev) if t is None else L.f32(t).reshape(F, n)
+        c = lambda t, n: None if t is None else L.f32(t).reshape(F, n)
+        gb, gj, gr, gt = c(g_bt, 336), c(g_j3, 63), c(g_or, 9), c(g_ot, 3)
         g = torch.empty(F, 45, device=dev, dtype=torch.float32)
+        # both Jacobian products in one launch (hn_pose_side_vjp); a missing upstream gradient counts as zero there
+        L.check(lib.hn_pose_side_vjp(L.ptr(ctx.jac_h), L.ptr(ctx.jac_o), L.ptr(gb), L.ptr(gj), L.ptr(gr), L.ptr(gt), F, L.ptr(g), L.stream_ptr()),
+                'hn_pose_side_vjp')
         gh, go = g[:, :36], g[:, 36:45]
-        go_h = torch.cat([z(g_bt, 336), z(g_j3, 63)], dim=1)
-        if F == 1:
-            L.check(lib.hn_jacobian_vjp(L.ptr(ctx.jac_h), L.ptr(go_h), 1, N_OUT, N_IN, L.ptr(g), st), 'hn_jacobian_vjp')      # -> g[0, :36]
-            go_o = torch.cat([z(g_or, 9), z(g_ot, 3)], dim=1)                                   # rows 399..410 of the object Jacobian
-            tmp = torch.empty(1, 18, device=dev, dtype=torch.float32)
-            L.check(lib.hn_jacobian_vjp(L.ptr(ctx.jac_o[:, 399:411]), L.ptr(go_o), 1, 12, 18, L.ptr(tmp), st), 'hn_jacobian_vjp')
-            g[:, 36:45] = tmp[:, :9]
-        else:
-            tmp_h = torch.empty(F, 36, device=dev, dtype=torch.float32)
-            L.check(lib.hn_jacobian_vjp(L.ptr(ctx.jac_h), L.ptr(go_h), F, N_OUT, N_IN, L.ptr(tmp_h), st), 'hn_jacobian_vjp')
-            go_o = torch.zeros(F, 412, device=dev, dtype=torch.float32)
-            go_o[:, 399:408] = z(g_or, 9)
-            go_o[:, 408:411] = z(g_ot, 3)
-            tmp = torch.empty(F, 18, device=dev, dtype=torch.float32)
-            L.check(lib.hn_jacobian_vjp(L.ptr(ctx.jac_o), L.ptr(go_o), F, 412, 18, L.ptr(tmp), st), 'hn_jacobian_vjp')
-            g[:, :36] = tmp_h
-            g[:, 36:45] = tmp[:, :9]
         sh = ctx.shapes
         if ctx.rows is not None:     # the window's rows of the [n, 45] gradient block, zero elsewhere
             full = torch.zeros(ctx.n, 45, device=dev, dtype=torch.float32)

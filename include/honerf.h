@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 108 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 109 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -271,6 +271,11 @@ int hn_rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pr
 int hn_verts_loss(const float* Ra, const float* ta, const float* Rb, const float* tb, const float* verts, int n_verts,
                   int n_pairs, float* loss, float* gR, float* gt, hn_stream_t stream);
 int hn_jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int n_in, float* out, hn_stream_t stream);
+/* The backward pass of the whole pose side of a fitting step (fitting_single.py:206-235 under loss.backward()) in one launch:
+ * out [F,45] = [ [g_bt_inv 336 | g_joint_3d 63] . jac_h (hn_pose_chain's Jacobian [F,399,36]) | [g_obj_r 9 | g_obj_t 3] . rows
+ * 399..410, columns 0..8 of jac_o (hn_rigid_pose's Jacobian [F,412,18], with_palm == 0) ]; a NULL upstream gradient is zero. */
+int hn_pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt_inv, const float* g_joint_3d, const float* g_obj_r,
+                     const float* g_obj_t, int n_frames, float* out, hn_stream_t stream);
 
 /* ---- SDF -> alpha, compositing --------------------------------------------------------
  * utils/renderer.py:147-161 (cos_anneal_ratio = 1): alpha [n] (clipped to [0,1]) and
@@ -401,6 +406,22 @@ int hn_fit_total(const float* sums6, const float* verts_loss, const float* joint
                  const float* weights5, float* terms8, float* g_joint, hn_stream_t stream);
 int hn_fit_total_bwd(const float* g_loss, const float* weights5, const float* g_joint, const float* gR, const float* gt, int n_joints,
                      float* g4, float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream);
+/* The same loss (fitting_single.py:251-288) as ONE launch forward and ONE backward -- what the fitting loop runs: the sums, the
+ * vertex loss of the pose pair (Ra, ta) / (Rb, tb) over `verts` [n_verts,3] (fitting_single.py:232-233), the joint loss and the
+ * weighted total in hn_fit_step_loss (sums6 [6], terms8 [8], g_joint [n_joints,3], gR [9], gt [3] as above; the sums are
+ * reduced in a fixed order, so two runs give the same terms bit for bit); hn_fit_step_loss_bwd takes the upstream gradient of the
+ * loss (device scalar) and returns the gradients w.r.t. the render outputs and the scaled pose-side gradients.  `scratch`:
+ * hn_fit_step_loss_scratch_bytes(n_rays, n_samples) bytes the caller ZEROES ONCE and then keeps handing over (every launch
+ * leaves it ready for the next); weights5: host array. */
+size_t hn_fit_step_loss_scratch_bytes(int n_rays, int n_samples);
+int hn_fit_step_loss(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_hand,
+                     const float* sdf_obj, int n_samples, const float* joint_3d, const float* joint3d_pred, int n_joints, const float* Ra, const float* ta,
+                     const float* Rb, const float* tb, const float* verts, int n_verts, const float* weights5, void* scratch, size_t scratch_bytes,
+                     float* sums6, float* terms8, float* g_joint, float* gR, float* gt, hn_stream_t stream);
+int hn_fit_step_loss_bwd(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_hand,
+                         const float* sdf_obj, int n_samples, const float* sums6, const float* g_loss, const float* weights5, const float* g_joint,
+                         const float* gR, const float* gt, int n_joints, float* g_color, float* g_weight_sum, float* g_sdf_hand, float* g_sdf_obj,
+                         float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream);
 
 /* torch.optim.Adam's step (defaults: betas as given, no weight decay, no amsgrad) over up to 16 small parameter blocks
  * with one learning rate each, ONE launch: the six pose-parameter groups of fitting_single.py:191-199 /
@@ -415,8 +436,10 @@ int hn_adam_step(int n_tensors, float* const* params, const float* const* grads,
  * gradient (utils/renderer.py:461: sampled under no_grad).  Inputs: the render's inputs, its final depths z_vals
  * [N,S] and per-sample results (sdf_*, grad_* as returned; rgb_*, alpha_* from hn_render_dual_aux_offsets), and the
  * upstream gradients of every output: g_color [N,3], g_weight_sum [N] (may be NULL), g_sdf_* [N*S], g_grad_* [N*S,3],
- * g_gradient_error [2] (hand, obj) -- each may be NULL.  Outputs (overwritten): g_rays_o, g_rays_d [N,3], g_bt_inv
- * [n_frames,21,4,4], g_T_pose [n_frames,21,3], g_Ro [n_frames,3,3], g_To [n_frames,3].  The hand and the object branch
+ * g_gradient_error [2] (hand, obj) -- each may be NULL.  Outputs (overwritten): g_rays_o, g_rays_d [N,3] (both NULL: the
+ * world rays' gradients are not wanted -- the fitting loops' rays come from fixed cameras -- and the launches that only
+ * serve them are skipped), g_bt_inv [n_frames,21,4,4], g_T_pose [n_frames,21,3], g_Ro [n_frames,3,3], g_To [n_frames,3]
+ * (the last two accumulated with float atomics: equal to rounding between runs).  The hand and the object branch
  * run side by side on the given stream and on a library-owned second stream of the device (event fork / join; the host
  * is never blocked).  `tape`: the buffer the forward hn_render_dual call filled (same rays, depths and fields), or NULL
  * (then both fields are evaluated again inside their adjoint kernels). */

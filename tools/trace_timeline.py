@@ -4,7 +4,21 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 step_idx = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 min_us = float(sys.argv[3]) if len(sys.argv) > 3 else 20.0
-ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:60], r.get('Queue_Id', '')) for r in rows)
+import re
+
+
+def short(name):
+    """hn:: kernels by their name; torch's element-wise kernels by the functor they apply (the template argument that says what they do)."""
+    if 'at::native' in name:
+        m = re.findall(r'at::native::(?:\(anonymous namespace\)::)?([A-Za-z_0-9]*(?:Functor|Func|Op|functor|_kernel_cuda|Kernel)[A-Za-z_0-9]*)', name)
+        m = [x for x in m if x not in ('vectorized_elementwise_kernel', 'elementwise_kernel_manual_unroll', 'unrolled_elementwise_kernel', 'reduce_kernel',
+                                       'ReduceOp', 'elementwise_kernel')]
+        kind = 'reduce' if 'reduce_kernel' in name else 'ew'
+        return 'torch %s: %s' % (kind, ','.join(dict.fromkeys(m)) if m else name.split('(')[0][:70])
+    return name.split('(')[0][:70]
+
+
+ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']), r.get('Queue_Id', '')) for r in rows)
 marks = [i for i, e in enumerate(ev) if 'k_field2_hand<3>' in e[2] or 'k_field2_hand<1>' in e[2]]
 a, b = marks[step_idx], marks[step_idx + 1]
 # start of step = first sdf-only hand kernel before the mark
