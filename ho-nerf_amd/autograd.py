@@ -151,7 +151,7 @@ class DualRenderFn(torch.autograd.Function):
                                        L.ptr(sdf_o), L.ptr(grad_o), L.ptr(rgb_o), L.ptr(alpha_o), L.ptr(g_color),
                                        L.ptr(ups[0]), L.ptr(ups[1]), L.ptr(ups[2]), L.ptr(ups[3]), L.ptr(ups[4]), L.ptr(ups[5]),
                                        L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_bt), L.ptr(g_tp), L.ptr(g_Ro), L.ptr(g_To), L.ptr(ws), need,
-                                       L.ptr(tape), st),
+                                       L.ptr(tape), 0, st),
                 'hn_render_dual_bwd')
 
         def like(g, ref):          # an input shared by all frames (e.g. T_pose [21,3]) receives the sum over frames

@@ -23,7 +23,7 @@ void set_error(const char* fmt, ...) {
 int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float variance, float scale, int precision,
                  hn_field** out, hipStream_t stream);
 int ray_gen(const float*, const float*, const float*, const float*, const float*, int, int, float*, float*, hipStream_t);
-int obj_local_fwd(const float*, const float*, const float*, const float*, int, int, float*, float*, hipStream_t);
+int obj_local_fwd(const float*, const float*, const float*, const float*, int, int, float*, float*, hipStream_t, bool transposed = false);
 int obj_local_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
                   float*, float*, float*, hipStream_t);
 int coarse_z(const float*, int, int, float, float, float, float*, hipStream_t);
@@ -49,9 +49,9 @@ int composite2_bwd(const float*, const float*, const float*, const float*, const
 int alpha_bwd_up(const float*, const float*, const float*, const float*, const float*, int, int, float, float, const float*, const float*, const float*,
                  float*, float*, float*, const int*, const int*, const float*, float*, float*, float*, float* const*, const size_t*, int, hipStream_t);
 int obj_rays_bwd(const float*, const float*, int, int, int, float, const float*, const float*, const float*, const float*, const float*, const float*,
-                 float*, float*, float*, float*, hipStream_t);
+                 float*, float*, float*, float*, hipStream_t, bool transposed = false);
 int dual_prologue(const float*, const float*, const float*, const float*, int, int, float*, float*, const float*, int, float, float, float, float*, float*,
-                  float*, int, hipStream_t);
+                  float*, int, hipStream_t, bool transposed = false);
 size_t fit_step_loss_scratch_bytes(int, int);
 int fit_step_loss(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*, int, const float*,
                   const float*, const float*, const float*, const float*, int, const float*, void*, size_t, float*, float*, float*, float*, float*, hipStream_t);
@@ -716,7 +716,9 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
                             const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand,
                             float* sdf_obj, float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals,
                             void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need, size_t* aux_offsets = nullptr,
-                            void* tape = nullptr, size_t tape_bytes = 0, size_t* compact_offsets = nullptr) {
+                            void* tape = nullptr, size_t tape_bytes = 0, size_t* compact_offsets = nullptr, int flags = 0) {
+    const bool ro_t = (flags & HN_DUAL_RO_TRANSPOSED) != 0;        // Ro holds obj_r: its transpose is the rotation to apply
+    const bool obj_side = (flags & HN_DUAL_OBJ_POSE_ON_SIDE) != 0;  // Ro / To are produced on the side stream (pipelined fitting step)
     HN_REQUIRE(n_samples >= 2 && n_importance >= 0 && n_frames >= 1 && rpf >= 0, "bad sizes");
     HN_REQUIRE(n_importance == 0 || (steps >= 1 && n_importance % steps == 0), "n_importance must divide into steps");
     HN_REQUIRE(hand->kind == HN_FIELD_HAND && obj->kind == HN_FIELD_OBJ, "field kinds (hand, obj) expected");
@@ -788,11 +790,17 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     SideLock side_lock(side);
     const hipStream_t so = side != nullptr ? side->s2 : s;   // the object track's stream (s itself if no second stream)
     // object-local rays, the shared coarse depths of both tracks, the first columns of the concatenated depth list: one launch
-    HN_TRY(dual_prologue(rays_o, rays_d, Ro, To, n_frames, rpf, o_obj, d_obj, t_rand, n_samples, (float)near, (float)(far - near), sample_dist, th.z_a,
-                         n_importance > 0 ? to.z_a : nullptr, zcat, S, s));
+    HN_REQUIRE(!obj_side || side != nullptr, "HN_DUAL_OBJ_POSE_ON_SIDE needs the device's second stream");
+    HN_TRY(dual_prologue(rays_o, rays_d, obj_side ? nullptr : Ro, To, n_frames, rpf, o_obj, d_obj, t_rand, n_samples, (float)near, (float)(far - near),
+                         sample_dist, th.z_a, n_importance > 0 ? to.z_a : nullptr, zcat, S, s, ro_t));
     const float* z_final = zcat;
+    bool obj_rays_made = !obj_side;
     if (n_importance > 0) {
         if (side != nullptr) HN_TRY(fork_to(side, s));
+        if (obj_side) {   // the object's pose comes from the side stream: its local rays are made there, behind whatever produced Ro / To
+            HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_obj, d_obj, so, ro_t));
+            obj_rays_made = true;
+        }
         // the two importance-sampling tracks (utils/renderer.py:463-496) are independent: hand on s, object on so
         // The two tracks are queued STAGE BY STAGE (coarse pass, then each importance round), the object's launches of a
         // stage first: queued track by track, the second track's first kernel reached its stream only after the ~25
@@ -903,6 +911,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     }
     (void)forked;
     HN_TRY(alpha(sdf_hand, grad_hand, rays_d, dists, (int)N, S, hand->inv_s, al_h, nullptr, s));
+    if (!obj_rays_made) HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_obj, d_obj, so, ro_t));
     HN_TRY(sample_points(o_obj, d_obj, z_final, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
     HN_TRY(field_eval(obj, pts_o, d_obj, (int)N, S, nullptr, nullptr, 1, (int)N, sdf_obj, grad_obj, rgb_o, nullptr, fwso,
                       fws_o, so, tp_o, tape_o));
@@ -941,7 +950,9 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
                                 const float* alpha_o, const float* g_color, const float* g_wsum, const float* g_sdf_h,
                                 const float* g_sdf_o, const float* g_grad_h, const float* g_grad_o, const float* g_eik,
                                 float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose, float* g_Ro, float* g_To,
-                                void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need, const void* tape = nullptr) {
+                                void* workspace, size_t workspace_bytes, hipStream_t s, size_t* need, const void* tape = nullptr, int flags = 0) {
+    const bool ro_t = (flags & HN_DUAL_RO_TRANSPOSED) != 0;
+    const bool no_join = (flags & HN_DUAL_BWD_NO_JOIN) != 0;   // the object branch's results stay on the side stream (pipelined fitting step)
     HN_REQUIRE(hand->kind == HN_FIELD_HAND && obj->kind == HN_FIELD_OBJ, "field kinds (hand, obj) expected");
     HN_REQUIRE(n_frames >= 1 && rpf >= 0 && S >= 1, "bad sizes");
     const int n_rays = n_frames * rpf;
@@ -1006,7 +1017,7 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
                             compact ? cr.pos : nullptr, compact ? cr.n_dev : nullptr, g_rgbh, gs_c, gg_c, gr_c, zb, zn, 2, s));
     }
     // object branch (so) up to its adjoint kernel
-    HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_l, d_l, so));
+    HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_l, d_l, so, ro_t));
     HN_TRY(sample_points(o_l, d_l, z, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
     {
         float* zb[3] = {gd_o, g_Ro, g_To};
@@ -1039,8 +1050,9 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
                                bws_o, so, tp_o, grad_o, rgb_o));
     // behind the object's adjoint: the ray map and the adjoint of convert_obj_to_local in one launch
     HN_TRY(obj_rays_bwd(z, gp_o, n_frames, rpf, S, sample_dist, gd_o, gdir_o, rays_o, rays_d, Ro, To, want_rays ? g_ro2 : nullptr,
-                        want_rays ? g_rd2 : nullptr, g_Ro, g_To, so));
-    if (side != nullptr) HN_TRY(join_from(side, s));
+                        want_rays ? g_rd2 : nullptr, g_Ro, g_To, so, ro_t));
+    HN_REQUIRE(!no_join || (!want_rays && side != nullptr), "HN_DUAL_BWD_NO_JOIN: no ray gradients, and the device's second stream");
+    if (side != nullptr && !no_join) HN_TRY(join_from(side, s));
     if (want_rays) {
         hipLaunchKernelGGL(k_add4x2, dim3(((int)R3 + 255) / 256), dim3(256), 0, s, go_h, g_ro2, g_rays_o, gdd_h, gd_h, gdir_h, g_rd2, g_rays_d, (int)R3);
         HN_LAUNCH_CHECK();
@@ -1212,8 +1224,8 @@ int hn_verts_loss(const float* Ra, const float* ta, const float* Rb, const float
     return hn::verts_loss(Ra, ta, Rb, tb, verts, n_verts, n_pairs, loss, gR, gt, (hipStream_t)stream);
 }
 int hn_pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt_inv, const float* g_joint_3d, const float* g_obj_r, const float* g_obj_t,
-                     int n_frames, float* out, hn_stream_t stream) {
-    return hn::pose_side_vjp(jac_h, jac_o, g_bt_inv, g_joint_3d, g_obj_r, g_obj_t, n_frames, out, (hipStream_t)stream);
+                     const float* g_obj_r2, const float* g_obj_t2, int n_frames, int which, float* out, hn_stream_t stream) {
+    return hn::pose_side_vjp(jac_h, jac_o, g_bt_inv, g_joint_3d, g_obj_r, g_obj_t, g_obj_r2, g_obj_t2, n_frames, which, out, (hipStream_t)stream);
 }
 int hn_jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int n_in, float* out, hn_stream_t stream) {
     return hn::jacobian_vjp(jac, g, n_frames, n_out, n_in, out, (hipStream_t)stream);
@@ -1226,6 +1238,26 @@ int hn_nearest_masked(const float* pts, int n_verts, int n_sets, const unsigned 
 
 
 int hn_version(void) { return HN_VERSION; }
+int hn_side_stream(hn_stream_t* out) {
+    HN_REQUIRE(out != nullptr, "null argument");
+    SideStream* x = side_stream();
+    HN_REQUIRE(x != nullptr, "the device's second stream could not be created");
+    *out = (hn_stream_t)x->s2;
+    return HN_OK;
+}
+int hn_stream_wait(hn_stream_t waiter, hn_stream_t on) {
+    // `waiter` goes on only when everything queued on `on` so far has finished (an event of the library's, recorded and waited for at
+    // once: the record is consumed by the wait before the next call re-records it)
+    static std::mutex mu;
+    static hipEvent_t ev[MAX_DEVICES] = {};
+    const int dev = current_device();
+    HN_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "bad device");
+    std::lock_guard<std::mutex> lk(mu);
+    if (ev[dev] == nullptr) HN_CHECK_HIP(hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming));
+    HN_CHECK_HIP(hipEventRecord(ev[dev], (hipStream_t)on));
+    HN_CHECK_HIP(hipStreamWaitEvent((hipStream_t)waiter, ev[dev], 0));
+    return HN_OK;
+}
 int hn_debug_quad_max_blocks(int max_blocks) {
     hn::g_quad_max_blocks.store(max_blocks);
     return HN_OK;
@@ -1501,12 +1533,12 @@ int hn_render_dual_bwd(const hn_field* hand, const hn_field* obj, const float* r
                        const float* rgb_obj, const float* alpha_obj, const float* g_color, const float* g_weight_sum,
                        const float* g_sdf_hand, const float* g_sdf_obj, const float* g_grad_hand, const float* g_grad_obj,
                        const float* g_gradient_error, float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose,
-                       float* g_Ro, float* g_To, void* workspace, size_t workspace_bytes, const void* tape, hn_stream_t stream) {
+                       float* g_Ro, float* g_To, void* workspace, size_t workspace_bytes, const void* tape, int flags, hn_stream_t stream) {
     HN_REQUIRE(hand != nullptr && obj != nullptr, "null field");
     return render_dual_bwd_impl(hand, obj, rays_o, rays_d, n_frames, rays_per_frame, samples_per_ray, sample_dist, bt_inv, T_pose, Ro,
                                 To, z_vals, sdf_hand, grad_hand, rgb_hand, alpha_hand, sdf_obj, grad_obj, rgb_obj, alpha_obj,
                                 g_color, g_weight_sum, g_sdf_hand, g_sdf_obj, g_grad_hand, g_grad_obj, g_gradient_error, g_rays_o,
-                                g_rays_d, g_bt_inv, g_T_pose, g_Ro, g_To, workspace, workspace_bytes, (hipStream_t)stream, nullptr, tape);
+                                g_rays_d, g_bt_inv, g_T_pose, g_Ro, g_To, workspace, workspace_bytes, (hipStream_t)stream, nullptr, tape, flags);
 }
 int hn_render_dual_aux_offsets(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples, int n_importance,
                                int up_sample_steps, size_t* offsets4) {
@@ -1529,12 +1561,12 @@ int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_
                    int n_importance, int up_sample_steps, const float* bt_inv, const float* T_pose, const float* Ro,
                    const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand, float* sdf_obj,
                    float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals, void* workspace,
-                   size_t workspace_bytes, void* tape, size_t tape_bytes, hn_stream_t stream) {
+                   size_t workspace_bytes, void* tape, size_t tape_bytes, int flags, hn_stream_t stream) {
     HN_REQUIRE(hand != nullptr && obj != nullptr, "null field");
     return render_dual_impl(hand, obj, rays_o, rays_d, t_rand, n_frames, rays_per_frame, near, far, n_samples,
                             n_importance, up_sample_steps, bt_inv, T_pose, Ro, To, batch_quirk, color, weight_sum,
                             sdf_hand, sdf_obj, grad_hand, grad_obj, gradient_error, z_vals, workspace, workspace_bytes,
-                            (hipStream_t)stream, nullptr, nullptr, tape, tape_bytes);
+                            (hipStream_t)stream, nullptr, nullptr, tape, tape_bytes, nullptr, flags);
 }
 size_t hn_render_dual_tape_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int samples_per_ray) {
     if (hand == nullptr || obj == nullptr || n_rays <= 0 || samples_per_ray <= 0) return 0;

@@ -58,8 +58,8 @@ int rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pred,
 int verts_loss(const float* Ra, const float* ta, const float* Rb, const float* tb, const float* verts, int n_verts, int n_pairs, float* loss, float* gR,
                float* gt, hipStream_t s);
 int jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int n_in, float* out, hipStream_t s);
-int pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt, const float* g_j3, const float* g_or, const float* g_ot, int n_frames,
-                  float* out, hipStream_t s);
+int pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt, const float* g_j3, const float* g_or, const float* g_ot, const float* g_or2,
+                  const float* g_ot2, int n_frames, int which, float* out, hipStream_t s);
 
 // ---- network geometry (fixed by the reference confs; checked in hn_field_create) ---------
 constexpr int H = 256;           // d_hidden == d_feature

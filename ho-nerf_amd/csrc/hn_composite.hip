@@ -1108,17 +1108,30 @@ __global__ __launch_bounds__(256) void k_fit_step_loss(const float* __restrict__
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    // ---- the last block: the six sums, in block order
-    float acc = 0.f;
-    if (threadIdx.x < 6)
-        for (unsigned b = 0; b < gridDim.x; ++b) acc += reinterpret_cast<const volatile float*>(partials)[6 * (size_t)b + threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        red[threadIdx.x][0] = acc;
-        sums6[threadIdx.x] = acc;
+    // ---- the last block: the six sums over the slots -- thread t the slots t, t + 256, .., then the fixed tree of wave_sum and the
+    //      four waves in order: the result does not depend on which block came last or in what order the others ran
+    {
+        float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const volatile float* ps = reinterpret_cast<const volatile float*>(partials);
+        for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] += ps[6 * (size_t)b + k];
+        }
+        __syncthreads();   // (red[] of the first phase has been read by everyone)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float t = wave_sum(acc[k]);
+            if (lane == 0) red[k][wave] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            const float t = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+            sums6[threadIdx.x] = t;
+            red[threadIdx.x][0] = t;
+        }
+        if (threadIdx.x == 0) *counter = 0u;
+        __syncthreads();
     }
-    if (threadIdx.x == 0) *counter = 0u;
-    __syncthreads();
     const float colour = red[0][0], mask = red[1][0];
     const float contact = red[2][0] / (red[3][0] + 1e-9f), penet = red[4][0] / (red[5][0] + 1e-9f);
     __syncthreads();

@@ -145,15 +145,17 @@ __global__ __launch_bounds__(256) void k_jacobian_vjp(const float* __restrict__ 
 
 // The backward pass of the whole pose side of a fitting step as ONE launch (it was a cat, two k_jacobian_vjp, a cat and a copy):
 //   out[f, 0:36]  = [g_bt_inv | g_joint_3d] . jac_h[f]            (hn_pose_chain's Jacobian [399, 36])
-//   out[f, 36:45] = [g_obj_r | g_obj_t] . jac_o[f, 399:411, 0:9]  (hn_rigid_pose's Jacobian [412, 18], object half)
-// Missing upstream gradients (NULL) count as zero.  One block of 256 per frame, the split of k_jacobian_vjp.
+//   out[f, 36:45] = [g_obj_r (+ g_or2) | g_obj_t (+ g_ot2)] . jac_o[f, 399:411, 0:9]  (hn_rigid_pose's Jacobian [412, 18], object half)
+// Missing upstream gradients (NULL) count as zero; `which` bit 0: the hand columns, bit 1: the object columns (a pipelined step forms
+// them on two streams).  One block of 256 per frame, the split of k_jacobian_vjp.
 __global__ __launch_bounds__(256) void k_pose_side_vjp(const float* __restrict__ jac_h, const float* __restrict__ jac_o, const float* __restrict__ g_bt,
                                                        const float* __restrict__ g_j3, const float* __restrict__ g_or, const float* __restrict__ g_ot,
-                                                       int n_frames, float* __restrict__ out) {
+                                                       const float* __restrict__ g_or2, const float* __restrict__ g_ot2, int n_frames, int which,
+                                                       float* __restrict__ out) {
     const int f = blockIdx.x, k = threadIdx.x & 63, w = threadIdx.x >> 6;
     __shared__ float part[4][64];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (f < n_frames && k < 36) {
+    if (f < n_frames && k < 36 && (which & 1)) {
         const float* J = jac_h + (size_t)f * 399 * 36;
         auto gg = [&](int o) { return o < 336 ? (g_bt != nullptr ? g_bt[(size_t)f * 336 + o] : 0.f) : (g_j3 != nullptr ? g_j3[(size_t)f * 63 + o - 336] : 0.f); };
         int o = w;
@@ -164,16 +166,18 @@ __global__ __launch_bounds__(256) void k_pose_side_vjp(const float* __restrict__
             a3 = fmaf(J[(size_t)(o + 12) * 36 + k], gg(o + 12), a3);
         }
         for (; o < 399; o += 4) a0 = fmaf(J[(size_t)o * 36 + k], gg(o), a0);
-    } else if (f < n_frames && k < 45 && w == 0) {
+    } else if (f < n_frames && k >= 36 && k < 45 && w == 0 && (which & 2)) {
         const float* J = jac_o + (size_t)f * 412 * 18 + (size_t)399 * 18 + (k - 36);
         for (int o = 0; o < 12; ++o) {
-            const float g = o < 9 ? (g_or != nullptr ? g_or[(size_t)f * 9 + o] : 0.f) : (g_ot != nullptr ? g_ot[(size_t)f * 3 + o - 9] : 0.f);
+            float g = o < 9 ? (g_or != nullptr ? g_or[(size_t)f * 9 + o] : 0.f) : (g_ot != nullptr ? g_ot[(size_t)f * 3 + o - 9] : 0.f);
+            g += o < 9 ? (g_or2 != nullptr ? g_or2[(size_t)f * 9 + o] : 0.f) : (g_ot2 != nullptr ? g_ot2[(size_t)f * 3 + o - 9] : 0.f);
             a0 = fmaf(J[(size_t)o * 18], g, a0);
         }
     }
     part[w][k] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (f < n_frames && w == 0 && k < 45) out[(size_t)f * 45 + k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
+    if (f < n_frames && w == 0 && ((k < 36 && (which & 1)) || (k >= 36 && k < 45 && (which & 2))))
+        out[(size_t)f * 45 + k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
 }
 
 int rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pred, const float* To_pred, const float* params, int n_frames, int with_palm,
@@ -193,11 +197,12 @@ int verts_loss(const float* Ra, const float* ta, const float* Rb, const float* t
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
-int pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt, const float* g_j3, const float* g_or, const float* g_ot, int n_frames,
-                  float* out, hipStream_t s) {
+int pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt, const float* g_j3, const float* g_or, const float* g_ot, const float* g_or2,
+                  const float* g_ot2, int n_frames, int which, float* out, hipStream_t s) {
     if (n_frames <= 0) return HN_OK;
-    HN_REQUIRE(jac_h != nullptr && jac_o != nullptr && out != nullptr, "pose_side_vjp: NULL argument");
-    hipLaunchKernelGGL(k_pose_side_vjp, dim3(n_frames), dim3(256), 0, s, jac_h, jac_o, g_bt, g_j3, g_or, g_ot, n_frames, out);
+    HN_REQUIRE(out != nullptr && (which & 3) != 0 && (!(which & 1) || jac_h != nullptr) && (!(which & 2) || jac_o != nullptr),
+               "pose_side_vjp: NULL argument");
+    hipLaunchKernelGGL(k_pose_side_vjp, dim3(n_frames), dim3(256), 0, s, jac_h, jac_o, g_bt, g_j3, g_or, g_ot, g_or2, g_ot2, n_frames, which, out);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

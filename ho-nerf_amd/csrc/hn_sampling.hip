@@ -44,9 +44,11 @@ __global__ void k_ray_gen(const float* __restrict__ xy, const float* __restrict_
 }
 
 // ---- convert_obj_to_local (utils/renderer.py:180-188) -----------------------------------------
+// tr != 0: `Ro` holds the matrix whose TRANSPOSE is the rotation to apply (the caller hands over obj_r where the reference passes
+// obj_r.T, fitting_single.py:250): the same products in the same order, read through the transposed index
 __global__ void k_obj_local_fwd(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ Ro,
                                 const float* __restrict__ To, int n, int rays_per_frame, float* __restrict__ o_out,
-                                float* __restrict__ d_out) {
+                                float* __restrict__ d_out, int tr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int f = i / rays_per_frame;
@@ -54,10 +56,11 @@ __global__ void k_obj_local_fwd(const float* __restrict__ o, const float* __rest
     const float* T = To + 3 * f;
     const float a[3] = {o[3 * i] - T[0], o[3 * i + 1] - T[1], o[3 * i + 2] - T[2]};
     const float b[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+    const int sr = tr ? 1 : 3, sc = tr ? 3 : 1;   // element (r, c) of the rotation = R[sr r + sc c]
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        o_out[3 * i + r] = R[3 * r] * a[0] + R[3 * r + 1] * a[1] + R[3 * r + 2] * a[2];
-        d_out[3 * i + r] = R[3 * r] * b[0] + R[3 * r + 1] * b[1] + R[3 * r + 2] * b[2];
+        o_out[3 * i + r] = R[sr * r] * a[0] + R[sr * r + sc] * a[1] + R[sr * r + 2 * sc] * a[2];
+        d_out[3 * i + r] = R[sr * r] * b[0] + R[sr * r + sc] * b[1] + R[sr * r + 2 * sc] * b[2];
     }
 }
 
@@ -136,18 +139,19 @@ __global__ void k_coarse_z(const float* __restrict__ t_rand, int n_rays, int n, 
 __global__ void k_dual_prologue(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ Ro, const float* __restrict__ To,
                                 int n_rays, int rays_per_frame, float* __restrict__ o_out, float* __restrict__ d_out,
                                 const float* __restrict__ t_rand, int n, float near, float span, float sample_dist, float* __restrict__ z_hand,
-                                float* __restrict__ z_obj, float* __restrict__ zcat, int S) {
+                                float* __restrict__ z_obj, float* __restrict__ zcat, int S, int tr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_rays) {
+    if (Ro != nullptr && i < n_rays) {   // (NULL: the object-local rays are made elsewhere -- on the object branch's own stream)
         const int f = i / rays_per_frame;
         const float* R = Ro + 9 * f;
         const float* T = To + 3 * f;
         const float a[3] = {o[3 * i] - T[0], o[3 * i + 1] - T[1], o[3 * i + 2] - T[2]};
         const float b[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+        const int sr = tr ? 1 : 3, sc = tr ? 3 : 1;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            o_out[3 * i + r] = R[3 * r] * a[0] + R[3 * r + 1] * a[1] + R[3 * r + 2] * a[2];
-            d_out[3 * i + r] = R[3 * r] * b[0] + R[3 * r + 1] * b[1] + R[3 * r + 2] * b[2];
+            o_out[3 * i + r] = R[sr * r] * a[0] + R[sr * r + sc] * a[1] + R[sr * r + 2 * sc] * a[2];
+            d_out[3 * i + r] = R[sr * r] * b[0] + R[sr * r + sc] * b[1] + R[sr * r + 2 * sc] * b[2];
         }
     }
     if (i >= n_rays * n) return;
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256) void k_obj_rays_bwd(const float* __restrict__ 
                                                       const float* __restrict__ gd_alpha, const float* __restrict__ gd_colour,
                                                       const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ Ro,
                                                       const float* __restrict__ To, int rays_per_frame, float* __restrict__ g_o,
-                                                      float* __restrict__ g_d, float* __restrict__ g_Ro, float* __restrict__ g_To) {
+                                                      float* __restrict__ g_d, float* __restrict__ g_Ro, float* __restrict__ g_To, int tr) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
@@ -338,19 +342,21 @@ __global__ __launch_bounds__(256) void k_obj_rays_bwd(const float* __restrict__ 
     float gd[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) gd[c] = acc[3 + c] + gd_alpha[3 * ray + c] + (gd_colour != nullptr ? gd_colour[3 * ray + c] : 0.f);
-    // lanes 0..8: an element of g_Ro; 9..11: of g_To; 12..14 / 15..17: of g_o / g_d
+    // lanes 0..8: an element of g_Ro; 9..11: of g_To; 12..14 / 15..17: of g_o / g_d.  tr: `Ro` (and g_Ro) hold the transpose of
+    // the rotation that was applied (k_obj_local_fwd): element (r, c) of the rotation is R[sr r + sc c]
+    const int sr = tr ? 1 : 3, sc = tr ? 3 : 1;
     if (lane < 9) {
         const int r = lane / 3, c = lane % 3;
-        atomicAdd(g_Ro + 9 * f + lane, go[r] * (o[3 * ray + c] - T[c]) + gd[r] * d[3 * ray + c]);
+        atomicAdd(g_Ro + 9 * f + sr * r + sc * c, go[r] * (o[3 * ray + c] - T[c]) + gd[r] * d[3 * ray + c]);
     } else if (lane < 12) {
         const int c = lane - 9;
-        atomicAdd(g_To + 3 * f + c, -(R[c] * go[0] + R[3 + c] * go[1] + R[6 + c] * go[2]));
+        atomicAdd(g_To + 3 * f + c, -(R[sc * c] * go[0] + R[sr + sc * c] * go[1] + R[2 * sr + sc * c] * go[2]));
     } else if (lane < 15 && g_o != nullptr) {
         const int c = lane - 12;
-        g_o[3 * ray + c] = R[c] * go[0] + R[3 + c] * go[1] + R[6 + c] * go[2];
+        g_o[3 * ray + c] = R[sc * c] * go[0] + R[sr + sc * c] * go[1] + R[2 * sr + sc * c] * go[2];
     } else if (lane >= 15 && lane < 18 && g_d != nullptr) {
         const int c = lane - 15;
-        g_d[3 * ray + c] = R[c] * gd[0] + R[3 + c] * gd[1] + R[6 + c] * gd[2];
+        g_d[3 * ray + c] = R[sc * c] * gd[0] + R[sr + sc * c] * gd[1] + R[2 * sr + sc * c] * gd[2];
     }
 }
 
@@ -806,11 +812,11 @@ int ray_gen(const float* xy, const float* R, const float* T, const float* focal,
 }
 
 int obj_local_fwd(const float* o, const float* d, const float* Ro, const float* To, int n_frames, int rpf, float* oo,
-                  float* dd, hipStream_t s) {
+                  float* dd, hipStream_t s, bool transposed) {
     HN_REQUIRE(n_frames > 0 && rpf >= 0, "bad obj_local sizes");
     const size_t n = (size_t)n_frames * rpf;
     if (n == 0) return HN_OK;
-    hipLaunchKernelGGL(k_obj_local_fwd, grid1d(n, 256), dim3(256), 0, s, o, d, Ro, To, (int)n, rpf, oo, dd);
+    hipLaunchKernelGGL(k_obj_local_fwd, grid1d(n, 256), dim3(256), 0, s, o, d, Ro, To, (int)n, rpf, oo, dd, transposed ? 1 : 0);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -861,23 +867,24 @@ int sample_points_bwd(const float* z, const float* g_pts, int n_rays, int n, int
 
 int dual_prologue(const float* o, const float* d, const float* Ro, const float* To, int n_frames, int rpf, float* o_out, float* d_out,
                   const float* t_rand, int n, float near, float span, float sample_dist, float* z_hand, float* z_obj, float* zcat, int S,
-                  hipStream_t s) {
+                  hipStream_t s, bool transposed) {
     HN_REQUIRE(n >= 2 && n_frames > 0 && rpf >= 0, "bad prologue sizes");
     const size_t n_rays = (size_t)n_frames * rpf;
     if (n_rays == 0) return HN_OK;
     hipLaunchKernelGGL(k_dual_prologue, grid1d(n_rays * n, 256), dim3(256), 0, s, o, d, Ro, To, (int)n_rays, rpf, o_out, d_out, t_rand, n, near, span,
-                       sample_dist, z_hand, z_obj, zcat, S);
+                       sample_dist, z_hand, z_obj, zcat, S, transposed ? 1 : 0);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
 
 int obj_rays_bwd(const float* z, const float* g_pts, int n_frames, int rpf, int n, float sample_dist, const float* gd_alpha, const float* gd_colour,
-                 const float* o, const float* d, const float* Ro, const float* To, float* g_o, float* g_d, float* g_Ro, float* g_To, hipStream_t s) {
+                 const float* o, const float* d, const float* Ro, const float* To, float* g_o, float* g_d, float* g_Ro, float* g_To, hipStream_t s,
+                 bool transposed) {
     const int n_rays = n_frames * rpf;
     if (n_rays == 0) return HN_OK;
     HN_REQUIRE(n >= 1 && rpf >= 1 && g_Ro != nullptr && g_To != nullptr && gd_alpha != nullptr, "obj_rays_bwd: bad arguments");
     hipLaunchKernelGGL(k_obj_rays_bwd, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, g_pts, n_rays, n, sample_dist, gd_alpha, gd_colour, o, d, Ro, To, rpf,
-                       g_o, g_d, g_Ro, g_To);
+                       g_o, g_d, g_Ro, g_To, transposed ? 1 : 0);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

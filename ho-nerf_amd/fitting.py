@@ -454,6 +454,7 @@ def _rays(lib_mod, xy, cam, n_cams, rays_per_cam):
     return o, d
 
 
+PIPELINE_SINGLE = True    # fit_frame: the two-stream step (PipelinedSingleFit) where it applies; False: fit_backward + fit_apply through autograd
 _SIDE_STREAMS = {}
 USE_SIDE_STREAM = True    # fit_backward (frame-batched renderer): the pose-only terms of a step on a second stream beside the render
 
@@ -539,9 +540,14 @@ def fit_apply(optimizer, pose_chain=None, dist=None, sync=False):
 
 
 def fit_step(renderer, view, pose_chain, optimizer, near, far, fit_type='1', index=None, smooth_ends=(False, False),
-             obj_verts_for_stable=None, t_rand=None, rays_fn=None):
+             obj_verts_for_stable=None, t_rand=None, rays_fn=None, pipelined=False):
     """One optimiser step of the fitting loops on one rank: `fit_backward` then `fit_apply` without a collective
-    (fitting_single.py:201-291; fitting_video.py:212-342)."""
+    (fitting_single.py:201-291; fitting_video.py:212-342).  pipelined: where it applies (fitting_single on the device, the
+    reference's pose chain, PoseAdam) the step runs as PipelinedSingleFit -- same kernels, the hand's and the object's halves on two
+    streams that stay apart across steps; call `finish_pipeline(optimizer)` (or synchronise the device) before reading the
+    parameters.  `fit_frame` does both."""
+    if pipelined and PipelinedSingleFit.applicable(renderer, pose_chain, optimizer, fit_type, index, rays_fn):
+        return pipelined_fit(renderer, pose_chain, optimizer, near, far, fit_type).step(view, t_rand)
     terms = fit_backward(renderer, view, pose_chain, near, far, fit_type, index, smooth_ends, obj_verts_for_stable, t_rand, rays_fn)
     fit_apply(optimizer)
     return terms
@@ -582,10 +588,14 @@ class PoseAdam:
                     p.grad.zero_()
 
     @torch.no_grad()
-    def step(self):
+    def step(self, only=None, stream=None):
+        """only: restrict the step to these parameters (the pipelined fitting step updates the hand's and the object's leaves on
+        two streams); stream: the raw stream handle to launch on (default: torch's current stream)."""
         import ctypes
         from . import lib as L
-        todo = [(p, g['lr']) for g in self.param_groups for p in g['params'] if p.grad is not None]
+        keep_ids = None if only is None else {id(p) for p in only}
+        todo = [(p, g['lr']) for g in self.param_groups for p in g['params']
+                if p.grad is not None and (keep_ids is None or id(p) in keep_ids)]
         if not todo:
             return
         n = len(todo)
@@ -602,7 +612,190 @@ class PoseAdam:
             assert p.is_contiguous() and p.dtype == torch.float32 and p.is_cuda, 'PoseAdam: contiguous fp32 device parameters'
             P[i], G[i], M[i], V[i] = p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr()
             sizes[i], lrs[i], steps[i] = p.numel(), lr, st[2]
-        L.check(L.load().hn_adam_step(n, P, G, M, V, sizes, lrs, self.betas[0], self.betas[1], self.eps, steps, L.stream_ptr()), 'hn_adam_step')
+        L.check(L.load().hn_adam_step(n, P, G, M, V, sizes, lrs, self.betas[0], self.betas[1], self.eps, steps,
+                                      L.stream_ptr() if stream is None else stream), 'hn_adam_step')
+
+
+class PipelinedSingleFit:
+    """One optimisation step of fitting_single (fitting_single.py:201-291) as explicit launches on TWO streams that stay apart
+    across steps -- the same kernels and the same arithmetic as `fit_backward` + `fit_apply`, without autograd in between.
+
+    Why: a step is `pose chain -> sampling -> both fields -> loss -> both adjoints -> Adam`, and the object's kernels are the long
+    pole of both field phases (294 tiles on the CUs the hand leaves free: `k_field2_obj<4>` ends ~0.35 ms after
+    `k_field2_hand<4>`).  But the hand's half of what follows -- its leaf gradients, Adam on its four leaves, the pose chain of the
+    NEXT step (0.19 ms) and that step's hand sampling track (0.5 ms, the longer of the two tracks) -- needs nothing from the
+    object's adjoint.  So the hand's half lives on the caller's stream and the object's half (its adjoint, its leaf gradients,
+    Adam on the two object leaves, `hn_rigid_pose`, its local rays, its sampling track) on the library's second stream
+    (`hn_side_stream`), and the two meet only where the data does: at the sort of the merged depths and at the compositing
+    (`hn_render_dual` with HN_DUAL_OBJ_POSE_ON_SIDE, `hn_render_dual_bwd` with HN_DUAL_BWD_NO_JOIN).  Every buffer a step touches
+    is owned here and lives as long as the object; the one buffer the next step's hand side would overwrite while the object's
+    adjoint of this step still reads it -- the world rays -- is double-buffered.
+
+    Call `finish()` before reading the parameters from another stream (or synchronise the device): the object's leaves are
+    updated on the second stream."""
+
+    HAND_LEAVES = ('palm_rot', 'palm_trans', 'joint_refine_angle', 'palm_refine_angle')
+    OBJ_LEAVES = ('obj_rot', 'obj_trans')
+
+    @staticmethod
+    def applicable(renderer, pose_chain, optimizer, fit_type, index, rays_fn):
+        from .renderer import NeuSRenderer_fitting
+        return (isinstance(renderer, NeuSRenderer_fitting) and not renderer.batched and isinstance(pose_chain, HaloPoseChain)
+                and isinstance(optimizer, PoseAdam) and index is None and rays_fn is None and fit_type in ('1', '12')
+                and pose_chain.joints0.is_cuda and pose_chain.joints0.shape[0] == 1
+                and (renderer.precision or 'f16x3') == 'f16x3' and renderer.n_importance > 0)
+
+    def __init__(self, renderer, pose_chain, optimizer, near, far, fit_type):
+        import ctypes
+        from . import lib as L
+        self.L, self.lib = L, L.load()
+        self.ren, self.chain, self.opt = renderer, pose_chain, optimizer
+        self.near, self.far, self.fit_type = float(near), float(far), fit_type
+        dev = pose_chain.joints0.device
+        self.dev = dev
+        sp = ctypes.c_void_p()
+        L.check(self.lib.hn_side_stream(ctypes.byref(sp)), 'hn_side_stream')
+        self.side_ptr = ctypes.c_void_p(sp.value)
+        self.side = torch.cuda.ExternalStream(sp.value, device=dev)
+        e = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        self.prm_h, self.prm_o = e(1, 36), torch.zeros(1, 18, device=dev)
+        self.bt, self.j3, self.jac_h = e(1, 21, 4, 4), e(1, 21, 3), e(1, 399, 36)
+        self.out_o, self.jac_o = e(1, 412), e(1, 412, 18)
+        self.obj_r, self.obj_t = self.out_o[:, 399:408], self.out_o[:, 408:411]          # views: contiguous 9 / 3 floats
+        self.g45 = torch.zeros(1, 45, device=dev)
+        self.g_loss = torch.ones(1, device=dev)
+        self.g_bt, self.g_tp, self.g_Ro, self.g_To = e(1, 21, 4, 4), e(1, 21, 3), e(1, 3, 3), e(1, 3)
+        self.loss_buf = e(6 + 63 + 9 + 3 + 63 + 9 + 3)
+        self._rays = None
+        self._n_rays = -1
+        self._step = 0
+        interaction = fit_type in ('12', '123', '1234')
+        self.interaction = interaction
+        self.w5 = (ctypes.c_float * 5)(*((1.0, 30.0, 20.0, 30.0, 20.0) if interaction else (1.0, 0.0, 0.0, 100.0, 5.0)))
+        ch = pose_chain
+        g = self.g45
+        self.grads = {'obj_rot': g[:, 36:42].view(1, 3, 2), 'obj_trans': g[:, 42:45], 'palm_rot': g[:, 27:33].view(1, 3, 2), 'palm_trans': g[:, 33:36],
+                      'joint_refine_angle': g[:, 0:20], 'palm_refine_angle': g[:, 20:27]}
+        self.hand_params = [getattr(ch, k) for k in self.HAND_LEAVES]
+        self.obj_params = [getattr(ch, k) for k in self.OBJ_LEAVES]
+        # whatever the caller's stream has queued so far (the leaves' initial values, earlier steps through autograd) comes first
+        L.check(self.lib.hn_stream_wait(self.side_ptr, L.stream_ptr()), 'hn_stream_wait')
+
+    def _sized(self, R, S):
+        if R == self._n_rays:
+            return
+        dev = self.dev
+        e = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        n = R * S
+        self._n_rays = R
+        self._rays = [(e(R, 3), e(R, 3)), (e(R, 3), e(R, 3))]
+        self.color, self.wsum, self.gerr, self.z = e(R, 3), e(R, 1), e(2), e(R, S)
+        self.sdf_h, self.sdf_o, self.grad_h, self.grad_o = e(n, 1), e(n, 1), e(n, 3), e(n, 3)
+        self.gc, self.gw, self.gsh, self.gso = e(R, 3), e(R), e(n), e(n)
+
+    def step(self, view, t_rand=None):
+        """-> the step's loss terms (device scalars, as fit_step returns them).  The six leaves' .grad hold the step's gradient."""
+        L, lib, ren, ch = self.L, self.lib, self.ren, self.chain
+        dev = self.dev
+        hand, obj = ren.fields()
+        s, so = L.stream_ptr(), self.side_ptr
+        n_cams = view['cam']['R'].shape[0]
+        R = view['xy'].shape[0] // n_cams
+        assert n_cams == 1, 'fitting_single: one camera per step'
+        S = ren.n_samples + 2 * ren.n_importance
+        n = R * S
+        self._sized(R, S)
+        rays_o, rays_d = self._rays[self._step & 1]
+        self._step += 1
+        # ---- pose side: the hand's chain on the caller's stream, the object's on the second stream
+        torch.cat([ch.joint_refine_angle, ch.palm_refine_angle, ch.palm_rot.reshape(1, 6), ch.palm_trans], dim=1, out=self.prm_h)
+        L.check(lib.hn_pose_chain(L.ptr(ch.joints0), L.ptr(ch.bone_len), None, L.ptr(self.prm_h), 1, L.ptr(self.bt), L.ptr(self.j3), L.ptr(self.jac_h), s),
+                'hn_pose_chain')
+        with torch.cuda.stream(self.side):
+            torch.cat([ch.obj_rot.reshape(1, 6), ch.obj_trans], dim=1, out=self.prm_o[:, :9])
+        L.check(lib.hn_rigid_pose(None, None, L.ptr(ch.Ro_pred), L.ptr(ch.To_pred), L.ptr(self.prm_o), 1, 0, L.ptr(self.out_o), L.ptr(self.jac_o), so),
+                'hn_rigid_pose')
+        cam = view['cam']
+        L.check(lib.hn_ray_gen(L.ptr(view['xy']), L.ptr(cam['R']), L.ptr(cam['T']), L.ptr(cam['focal']), L.ptr(cam['principal']), 1, R, L.ptr(rays_o),
+                               L.ptr(rays_d), s), 'hn_ray_gen')
+        # ---- the two-field render, taped; the object's pose comes from the second stream, as obj_r (its transpose is applied)
+        tr = torch.rand(R, 1, device=dev) if t_rand is None else L.f32(t_rand, dev).reshape(R, 1)
+        need = lib.hn_render_dual_workspace_bytes(hand.handle, obj.handle, R, ren.n_samples, ren.n_importance)
+        ws = ren._ws.get(need, dev)
+        tape_bytes = lib.hn_render_dual_tape_bytes(hand.handle, obj.handle, R, S)
+        tape = ren._tape.get(tape_bytes, dev)
+        flags = L.HN_DUAL_RO_TRANSPOSED | L.HN_DUAL_OBJ_POSE_ON_SIDE
+        prev = getattr(ren, '_pending_aux', None)
+        prev = prev() if prev is not None else None
+        if prev is not None:
+            prev.own()        # an autograd render of this renderer whose backward pass has not run yet: its arrays leave the tape first
+        L.check(lib.hn_render_dual(hand.handle, obj.handle, L.ptr(rays_o), L.ptr(rays_d), L.ptr(tr), 1, R, self.near, self.far, ren.n_samples,
+                                   ren.n_importance, ren.up_sample_steps, L.ptr(self.bt), L.ptr(ch.T_pose_21), L.ptr(self.obj_r), L.ptr(self.obj_t), 0,
+                                   L.ptr(self.color), L.ptr(self.wsum), L.ptr(self.sdf_h), L.ptr(self.sdf_o), L.ptr(self.grad_h), L.ptr(self.grad_o),
+                                   L.ptr(self.gerr), L.ptr(self.z), L.ptr(ws), ws.numel(), L.ptr(tape), tape_bytes, flags, s), 'hn_render_dual')
+        ren._last_z_raw = ren.last_z_vals = self.z
+        ren._tape_serial = getattr(ren, '_tape_serial', 0) + 1     # (an autograd render's pending backward must not read this tape)
+        # ---- the loss and its gradient w.r.t. the render outputs and the pose-side values, one launch each
+        lb = self.loss_buf
+        sums, gj, gR, gt = lb[0:6], lb[6:69], lb[69:78], lb[78:81]
+        gj_o, gR_o, gt_o = lb[81:144], lb[144:153], lb[153:156]
+        terms = torch.empty(8, device=dev, dtype=torch.float32)
+        from .autograd import _loss_scratch
+        scratch, sneed = _loss_scratch(lib, R, n if self.interaction else 0, dev)
+        sh = L.ptr(self.sdf_h) if self.interaction else None
+        so_ = L.ptr(self.sdf_o) if self.interaction else None
+        tm, tc = L.f32(view['true_mask'], dev).reshape(-1), L.f32(view['true_rgb'], dev).reshape(-1, 3)
+        L.check(lib.hn_fit_step_loss(L.ptr(self.color), L.ptr(self.wsum), L.ptr(tc), L.ptr(tm), R, sh, so_, n, L.ptr(self.j3), L.ptr(ch.joints0), 21,
+                                     L.ptr(self.obj_r), L.ptr(self.obj_t), L.ptr(ch.Ro_pred), L.ptr(ch.To_pred), L.ptr(ch.obj_verts), ch.obj_verts.shape[0],
+                                     self.w5, L.ptr(scratch), sneed, L.ptr(sums), L.ptr(terms), L.ptr(gj), L.ptr(gR), L.ptr(gt), s), 'hn_fit_step_loss')
+        L.check(lib.hn_fit_step_loss_bwd(L.ptr(self.color), L.ptr(self.wsum), L.ptr(tc), L.ptr(tm), R, sh, so_, n, L.ptr(sums), L.ptr(self.g_loss), self.w5,
+                                         L.ptr(gj), L.ptr(gR), L.ptr(gt), 21, L.ptr(self.gc), L.ptr(self.gw), L.ptr(self.gsh) if self.interaction else None,
+                                         L.ptr(self.gso) if self.interaction else None, L.ptr(gj_o), L.ptr(gR_o), L.ptr(gt_o), s), 'hn_fit_step_loss_bwd')
+        # ---- backward pass of the render: the hand's branch ends on s, the object's on the second stream (no join)
+        aux_off = lib.hn_render_dual_tape_aux_offset(hand.handle, obj.handle, R, S)
+        a = tape[aux_off:aux_off + 32 * n].view(torch.float32)
+        rgb_h, rgb_o, al_h, al_o = a[:3 * n], a[3 * n:6 * n], a[6 * n:7 * n], a[7 * n:8 * n]
+        bneed = lib.hn_render_dual_bwd_workspace_bytes(hand.handle, obj.handle, R, S)
+        wsb = ren._ws_bwd.get(bneed, dev)
+        sample_dist = float(torch.tensor((self.far - self.near) / ren.n_samples, dtype=torch.float32))
+        flags = L.HN_DUAL_RO_TRANSPOSED | L.HN_DUAL_BWD_NO_JOIN
+        gsh_p = L.ptr(self.gsh) if self.interaction else None
+        gso_p = L.ptr(self.gso) if self.interaction else None
+        L.check(lib.hn_render_dual_bwd(hand.handle, obj.handle, L.ptr(rays_o), L.ptr(rays_d), 1, R, S, sample_dist, L.ptr(self.bt), L.ptr(ch.T_pose_21),
+                                       L.ptr(self.obj_r), L.ptr(self.obj_t), L.ptr(self.z), L.ptr(self.sdf_h), L.ptr(self.grad_h), L.ptr(rgb_h), L.ptr(al_h),
+                                       L.ptr(self.sdf_o), L.ptr(self.grad_o), L.ptr(rgb_o), L.ptr(al_o), L.ptr(self.gc), L.ptr(self.gw), gsh_p, gso_p, None, None,
+                                       None, None, None, L.ptr(self.g_bt), L.ptr(self.g_tp), L.ptr(self.g_Ro), L.ptr(self.g_To), L.ptr(wsb), bneed, L.ptr(tape),
+                                       flags, s), 'hn_render_dual_bwd')
+        # ---- leaf gradients and Adam: the hand's four leaves on s, the object's two on the second stream
+        L.check(lib.hn_pose_side_vjp(L.ptr(self.jac_h), None, L.ptr(self.g_bt), L.ptr(gj_o), None, None, None, None, 1, 1, L.ptr(self.g45), s), 'hn_pose_side_vjp')
+        L.check(lib.hn_pose_side_vjp(None, L.ptr(self.jac_o), None, None, L.ptr(self.g_Ro), L.ptr(self.g_To), L.ptr(gR_o), L.ptr(gt_o), 1, 2, L.ptr(self.g45), so),
+                'hn_pose_side_vjp')
+        for k, gview in self.grads.items():
+            getattr(ch, k).grad = gview
+        self.opt.step(only=self.hand_params, stream=s)
+        self.opt.step(only=self.obj_params, stream=so)
+        return {'loss': terms[0], 'color': terms[1], 'mask': terms[2], 'contact': terms[3], 'penetration': terms[4], 'joint': terms[5], 'obj_verts': terms[6]}
+
+    def finish(self):
+        """The caller's stream waits for the second stream's tail: from here on the parameters (all six leaves) and their .grad are
+        visible to work queued on the caller's stream (and to a host read that synchronises with it)."""
+        self.L.check(self.lib.hn_stream_wait(self.L.stream_ptr(), self.side_ptr), 'hn_stream_wait')
+
+
+def pipelined_fit(renderer, pose_chain, optimizer, near, far, fit_type):
+    """The PipelinedSingleFit of this (renderer, chain, optimiser), made on first use and kept on the optimiser."""
+    key = (id(renderer), id(pose_chain), float(near), float(far), fit_type)
+    cur = getattr(optimizer, '_pipeline', None)
+    if cur is None or cur[0] != key:
+        cur = (key, PipelinedSingleFit(renderer, pose_chain, optimizer, near, far, fit_type))
+        optimizer._pipeline = cur
+    return cur[1]
+
+
+def finish_pipeline(optimizer):
+    cur = getattr(optimizer, '_pipeline', None)
+    if cur is not None:
+        cur[1].finish()
 
 
 def fit_frame(renderer, views, pose_chain, near, far, fit_type='1', n_iters=None, sample_view=None, rays_fn=None):
@@ -616,8 +809,9 @@ def fit_frame(renderer, views, pose_chain, near, far, fit_type='1', n_iters=None
     for _ in range(n_iters):
         for vid in range(len(views)):
             view = sample_view(vid, step) if sample_view is not None else views[vid]
-            last = fit_step(renderer, view, pose_chain, opt, near, far, fit_type, rays_fn=rays_fn)
+            last = fit_step(renderer, view, pose_chain, opt, near, far, fit_type, rays_fn=rays_fn, pipelined=PIPELINE_SINGLE)
             step += 1
+    finish_pipeline(opt)
     return last, step
 
 

@@ -18,13 +18,14 @@ HN_FIELD_HAND = 1
 HN_PREC_FP32 = 0
 HN_PREC_F16X3 = 1
 HN_PREC_F16 = 2           # single-pass throughput mode of the evaluation kernels (include/honerf.h)
+HN_DUAL_RO_TRANSPOSED, HN_DUAL_OBJ_POSE_ON_SIDE, HN_DUAL_BWD_NO_JOIN = 1, 2, 4      # flags of hn_render_dual / _bwd
 HN_PACK_EVAL_ONLY = 0x100     # no adjoint weight streams (fields re-packed every training step)
 PRECISIONS = {'fp32': HN_PREC_FP32, 'f16x3': HN_PREC_F16X3, 'f16': HN_PREC_F16}
 # 'f16x3': fp16 hi/lo split operands on the f16 MFMA, fp32-equivalent results (the default);
 # 'fp32': the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32), 5x slower, kept as a second opinion
 DEFAULT_PRECISION = os.environ.get('HONERF_PRECISION', 'f16x3')
 HN_MAX_LAYERS = 9
-HN_VERSION = 109          # the include/honerf.h revision SIGNATURES below was written for
+HN_VERSION = 110          # the include/honerf.h revision SIGNATURES below was written for
 
 c_f = ctypes.c_void_p     # device float*
 c_i = ctypes.c_int
@@ -81,7 +82,7 @@ SIGNATURES = {
     'hn_pose_chain_bwd': (c_i, [c_f, c_f, c_f, c_i, c_f, c_vp]),
     'hn_rigid_pose': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
     'hn_verts_loss': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_vp]),
-    'hn_pose_side_vjp': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_vp]),
+    'hn_pose_side_vjp': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_vp]),
     'hn_jacobian_vjp': (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_vp]),
     'hn_alpha': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_vp]),
     'hn_composite1': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp]),
@@ -108,7 +109,7 @@ SIGNATURES = {
     'hn_render_dual_compact_offsets': (c_i, [c_vp, c_vp, c_i, c_i, c_i, c_i, ctypes.POINTER(c_sz)]),
     'hn_render_dual_bwd_workspace_bytes': (c_sz, [c_vp, c_vp, c_i, c_i]),
     'hn_render_dual_bwd': (c_i, [c_vp, c_vp, c_f, c_f, c_i, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f,
-                                 c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp, c_vp]),
+                                 c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp, c_i, c_vp]),
     'hn_render_dual_tape_bytes': (c_sz, [c_vp, c_vp, c_i, c_i]),
     'hn_render_dual_tape_aux_offset': (c_sz, [c_vp, c_vp, c_i, c_i]),
     'hn_release_cached_memory': (c_sz, []),
@@ -123,7 +124,9 @@ SIGNATURES = {
     'hn_render_single_bwd': (c_i, [c_vp, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp,
                                    c_sz, c_vp]),
     'hn_render_dual': (c_i, [c_vp, c_vp, c_f, c_f, c_f, c_i, c_i, c_db, c_db, c_i, c_i, c_i, c_f, c_f, c_f, c_f,
-                             c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp, c_sz, c_vp]),
+                             c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp, c_sz, c_i, c_vp]),
+    'hn_side_stream': (c_i, [ctypes.POINTER(c_vp)]),
+    'hn_stream_wait': (c_i, [c_vp, c_vp]),
 }
 
 _lib = None

@@ -208,7 +208,8 @@ class HaloChainFn(torch.autograd.Function):
         gb, gj, gr, gt = c(g_bt, 336), c(g_j3, 63), c(g_or, 9), c(g_ot, 3)
         g = torch.empty(F, 45, device=dev, dtype=torch.float32)
         # both Jacobian products in one launch (hn_pose_side_vjp); a missing upstream gradient counts as zero there
-        L.check(lib.hn_pose_side_vjp(L.ptr(ctx.jac_h), L.ptr(ctx.jac_o), L.ptr(gb), L.ptr(gj), L.ptr(gr), L.ptr(gt), F, L.ptr(g), L.stream_ptr()),
+        L.check(lib.hn_pose_side_vjp(L.ptr(ctx.jac_h), L.ptr(ctx.jac_o), L.ptr(gb), L.ptr(gj), L.ptr(gr), L.ptr(gt), None, None, F, 3, L.ptr(g),
+                                     L.stream_ptr()),
                 'hn_pose_side_vjp')
         gh, go = g[:, :36], g[:, 36:45]
         sh = ctx.shapes

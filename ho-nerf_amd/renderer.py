@@ -389,7 +389,7 @@ class NeuSRenderer_fitting:
                                 1 if (self.strict_reference and F > 1) else 0, _lib.ptr(out['color']),
                                 _lib.ptr(out['weight_sum']), _lib.ptr(out['sdf_hand']), _lib.ptr(out['sdf_obj']),
                                 _lib.ptr(out['grad_hand']), _lib.ptr(out['grad_obj']), _lib.ptr(out['gerr']),
-                                _lib.ptr(out['z_vals']), _lib.ptr(ws), ws.numel(), _lib.ptr(tape), tape_bytes, _lib.stream_ptr())
+                                _lib.ptr(out['z_vals']), _lib.ptr(ws), ws.numel(), _lib.ptr(tape), tape_bytes, 0, _lib.stream_ptr())
         _lib.check(rc, 'hn_render_dual')
         self._last_z_raw = out['z_vals']
         return out

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 109 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 110 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -273,9 +273,12 @@ int hn_verts_loss(const float* Ra, const float* ta, const float* Rb, const float
 int hn_jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int n_in, float* out, hn_stream_t stream);
 /* The backward pass of the whole pose side of a fitting step (fitting_single.py:206-235 under loss.backward()) in one launch:
  * out [F,45] = [ [g_bt_inv 336 | g_joint_3d 63] . jac_h (hn_pose_chain's Jacobian [F,399,36]) | [g_obj_r 9 | g_obj_t 3] . rows
- * 399..410, columns 0..8 of jac_o (hn_rigid_pose's Jacobian [F,412,18], with_palm == 0) ]; a NULL upstream gradient is zero. */
+ * 399..410, columns 0..8 of jac_o (hn_rigid_pose's Jacobian [F,412,18], with_palm == 0) ]; a NULL upstream gradient is zero;
+ * g_obj_r2 / g_obj_t2: second addends of the object's upstream gradients (the render's and the loss's shares, summed in the
+ * kernel); `which`: 1 the hand columns 0..35 only, 2 the object columns 36..44 only, 3 both. */
 int hn_pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt_inv, const float* g_joint_3d, const float* g_obj_r,
-                     const float* g_obj_t, int n_frames, float* out, hn_stream_t stream);
+                     const float* g_obj_t, const float* g_obj_r2, const float* g_obj_t2, int n_frames, int which, float* out,
+                     hn_stream_t stream);
 
 /* ---- SDF -> alpha, compositing --------------------------------------------------------
  * utils/renderer.py:147-161 (cos_anneal_ratio = 1): alpha [n] (clipped to [0,1]) and
@@ -356,7 +359,23 @@ int hn_render_dual(const hn_field* hand, const hn_field* obj, const float* rays_
                    int n_importance, int up_sample_steps, const float* bt_inv, const float* T_pose, const float* Ro,
                    const float* To, int batch_quirk, float* color, float* weight_sum, float* sdf_hand,
                    float* sdf_obj, float* grad_hand, float* grad_obj, float* gradient_error, float* z_vals,
-                   void* workspace, size_t workspace_bytes, void* tape, size_t tape_bytes, hn_stream_t stream);
+                   void* workspace, size_t workspace_bytes, void* tape, size_t tape_bytes, int flags, hn_stream_t stream);
+/* flags of hn_render_dual / hn_render_dual_bwd (0: the reference's call as it stands):
+ * HN_DUAL_RO_TRANSPOSED: `Ro` holds the matrix whose TRANSPOSE is the rotation of convert_obj_to_local -- the caller passes obj_r
+ *   itself where the reference passes obj_r.T (fitting_single.py:250) -- and hn_render_dual_bwd's g_Ro is the gradient w.r.t. that
+ *   matrix (same products in the same order; a transpose launch less on either side);
+ * HN_DUAL_OBJ_POSE_ON_SIDE (hn_render_dual): Ro / To are produced on the device's second stream (hn_side_stream), where the
+ *   object branch runs anyway: the object-local rays are made there instead of on `stream`;
+ * HN_DUAL_BWD_NO_JOIN (hn_render_dual_bwd; needs g_rays_o = g_rays_d = NULL): `stream` does NOT wait for the object branch at the
+ *   end: g_Ro / g_To are ready on the second stream, g_bt_inv / g_T_pose on `stream`.
+ * Together they let a fitting loop keep the hand's and the object's halves of a step on two streams ACROSS steps (the hand's pose
+ * chain and sampling track of step i + 1 start while the object's adjoint of step i is still running): honerf_amd.fitting. */
+#define HN_DUAL_RO_TRANSPOSED 1
+#define HN_DUAL_OBJ_POSE_ON_SIDE 2
+#define HN_DUAL_BWD_NO_JOIN 4
+/* The device's second stream (created on first use) and a device-side wait of one stream on another's current tail. */
+int hn_side_stream(hn_stream_t* out);
+int hn_stream_wait(hn_stream_t waiter, hn_stream_t on);
 /* `tape` (may be NULL): when a backward pass will follow (the fitting loops), the final evaluation of both fields
  * keeps its tape -- activations, reverse-sweep values, feature fragments, per sample tile -- in this caller-owned buffer
  * of hn_render_dual_tape_bytes(hand, obj, n_rays, n_samples + 2 n_importance) bytes; hn_render_dual_bwd given the same
@@ -451,7 +470,7 @@ int hn_render_dual_bwd(const hn_field* hand, const hn_field* obj, const float* r
                        const float* rgb_obj, const float* alpha_obj, const float* g_color, const float* g_weight_sum,
                        const float* g_sdf_hand, const float* g_sdf_obj, const float* g_grad_hand, const float* g_grad_obj,
                        const float* g_gradient_error, float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose,
-                       float* g_Ro, float* g_To, void* workspace, size_t workspace_bytes, const void* tape,
+                       float* g_Ro, float* g_To, void* workspace, size_t workspace_bytes, const void* tape, int flags,
                        hn_stream_t stream);
 
 /* ---- parameter gradients: training the networks (exp_runner.py:208-242 `loss.backward()` into

@@ -539,3 +539,46 @@ def test_device_loss_terms_video(golden):
     grads = torch.autograd.grad(loss, [ro['color_fine'], ro['weight_sum'], ro['sdf_hand'], ro['sdf_obj']])
     for name, gr in zip(('color_fine', 'weight_sum', 'sdf_hand', 'sdf_obj'), grads):
         assert_close(gr, g['mid_g_' + name], 1e-5, 'video g_%s (device)' % name)
+
+
+def test_pipelined_single_fit_equals_the_autograd_step():
+    """fitting.PipelinedSingleFit -- fitting_single's step as explicit launches on two streams that stay apart across steps -- against
+    `fit_backward` + `fit_apply` through autograd: the same kernels on the same inputs.  First step from identical parameters: the
+    loss terms bit for bit (fixed-order sums), the six leaf gradients to the rounding of the float atomics; after that step the
+    parameters of both equal to an Adam step of that rounding; several more steps keep the losses together."""
+    import bench
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    res = {}
+    for pipelined in (False, True):
+        ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3', halo=True)
+        with torch.no_grad():
+            for i, p in enumerate(chain.parameters()):
+                p.add_(4e-3 * torch.randn(p.shape, generator=torch.Generator().manual_seed(70 + i)).to(dev))
+        opt = F.make_optimizer(chain, video=False)
+        assert F.PipelinedSingleFit.applicable(ren, chain, opt, '12', None, None)
+        trs = [torch.rand(bench.FIT_RAYS, 1, generator=torch.Generator().manual_seed(90 + k)).to(dev) for k in range(6)]
+        terms = F.fit_step(ren, views[0], chain, opt, bench.NEAR, bench.FAR, '12', t_rand=trs[0], pipelined=pipelined)
+        F.finish_pipeline(opt)
+        torch.cuda.synchronize()
+        first = ({k: float(v) for k, v in terms.items()}, [p.grad.detach().clone() for p in chain.parameters()], [p.detach().clone() for p in chain.parameters()],
+                 ren.last_z_vals.clone())
+        losses = []
+        for k in range(1, 6):
+            t = F.fit_step(ren, views[k % 8], chain, opt, bench.NEAR, bench.FAR, '12', t_rand=trs[k], pipelined=pipelined)
+            losses.append(t['loss'])
+        F.finish_pipeline(opt)
+        torch.cuda.synchronize()
+        res[pipelined] = (first, [float(x) for x in losses])
+    (ta, ga, pa, za), la = res[False]
+    (tb, gb, pb, zb), lb = res[True]
+    assert torch.equal(za, zb)
+    for k in ta:
+        assert abs(ta[k] - tb[k]) <= 2e-6 * max(abs(ta[k]), 1e-6), (k, ta[k], tb[k])
+    for i, (a, b) in enumerate(zip(ga, gb)):
+        bounded('pipelined step vs autograd step: gradient of pose leaf %d' % i, rel_err(b.cpu().numpy(), a.cpu().numpy()), 5e-5)
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        # one Adam step from equal parameters: |update| = lr exactly where the gradient is well above its rounding noise
+        assert float((a - b).abs().max()) <= 2.1e-3, i
+    for x, y in zip(la, lb):
+        bounded('pipelined vs autograd: loss after further steps (relative difference)', abs(x - y) / abs(x), 2e-2)

@@ -225,6 +225,7 @@ def test_render_is_differentiable_by_dispatch(golden, kind):
 
     out_r, terms_r, grads_r, plain = run(True)
     out_t, terms_t, grads_t, _ = run(False)
+    _, _, grads_t2, _ = run(False)      # the same path once more: what the float atomics of the backward pass alone change
     assert out_r['color_fine'].requires_grad and out_r['weight_sum'].requires_grad and out_r['gradient_error'].requires_grad
     assert set(out_r) == {'color_fine', 's_val', 'cdf_fine', 'weight_sum', 'weight_max', 'gradient_error'}
     for k in ('color_fine', 'weight_sum', 'cdf_fine', 'weight_max', 'gradient_error', 's_val'):
@@ -233,10 +234,11 @@ def test_render_is_differentiable_by_dispatch(golden, kind):
         assert torch.equal(out_t[k].detach(), out_r[k].detach()), k
     for k in ('loss', 'color_fine_loss', 'mask_loss', 'eikonal_loss'):
         assert_close(terms_r[k].reshape(()), g[k], 2e-3, 'render dispatch %s %s vs the reference (own depths)' % (kind, k))
-    worst = 0.0
-    for a, b in zip(grads_r, grads_t):      # the same launch sequence twice: equal up to the order of the float atomics
-        worst = max(worst, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)))
-    bounded('render dispatch %s: gradients through renderer.render vs render_train, worst tensor' % kind, worst, 2e-5)
+    diff = lambda xs, ys: max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(xs, ys))
+    noise = diff(grads_t2, grads_t)
+    record('render dispatch %s: render_train vs render_train (run-to-run, float atomics), worst tensor' % kind, noise, float('inf'), kind='noise floor')
+    # the same launch sequence: equal up to the order of the float atomics, i.e. to what two runs of ONE path differ by
+    bounded('render dispatch %s: gradients through renderer.render vs render_train, worst tensor' % kind, diff(grads_r, grads_t), max(2e-5, 4.0 * noise))
 
 
 @pytest.mark.gpu
