@@ -301,9 +301,15 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
     views = F.synthetic_views(8, 1, FIT_RAYS, 40 + rank, j[9], device=dev)
     opt = F.make_optimizer(chain, video=False)
     for ft in ('1', '12'):
-        sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, ft))
+        # the step as fit_frame runs it: PipelinedSingleFit (the hand's and the object's halves on two streams that stay apart across
+        # steps); `single_12_autograd`: the same step through autograd on one stream + the library's fork / join inside the render
+        sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, ft, pipelined=True))
         res['single_' + ft] = {'ms_per_step': sec * 1e3, 'steps_per_frame': STEPS_PER_FRAME[ft],
-                               'frames_per_s': world / (STEPS_PER_FRAME[ft] * sec), 'pose_chain': 'halo (six refine leaves, hn_pose_chain)'}
+                               'frames_per_s': world / (STEPS_PER_FRAME[ft] * sec), 'pose_chain': 'halo (six refine leaves, hn_pose_chain)',
+                               'form': 'PipelinedSingleFit (two streams across steps)'}
+    F.finish_pipeline(opt)
+    sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, '12'))
+    res['single_12_autograd'] = {'ms_per_step': sec * 1e3, 'what': 'secondary: fit_backward + fit_apply through autograd (what round 3 timed)'}
     # what the hand field executed in those steps (the exact far-field skip): mean over the 8 views of the live-sample counts
     live = []
     for v in range(8):
@@ -317,7 +323,8 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
     # the same step with every sample of the hand field evaluated ("dense": NeuSRenderer_fitting.compact_far_field = False; the
     # default skips the samples whose bone masks are all exactly 0 -- bit-identical outputs)
     ren.compact_far_field = False
-    sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, '12'))
+    sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, '12', pipelined=True))
+    F.finish_pipeline(opt)
     res['single_12_dense'] = {'ms_per_step': sec * 1e3, 'what': 'secondary: no far-field skip (every one of the 196 x 192 samples through the hand field)'}
     ren.compact_far_field = True
     chain_r, _, _ = build_fit_data(dev, 40 + rank, 1, halo=False)

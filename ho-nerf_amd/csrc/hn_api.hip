@@ -30,6 +30,7 @@ int coarse_z(const float*, int, int, float, float, float, float*, hipStream_t);
 int sample_points(const float*, const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
 int sample_points_bwd(const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
 int upsample(const float*, const float*, int, int, int, float, float*, int64_t*, hipStream_t);
+bool upsample_fused(const float*, const float*, int, int, int, float, float*, float*, int, int, const float*, const float*, float*, hipStream_t);
 int merge(const float*, const float*, const float*, const float*, int, int, int, int, float*, float*, int64_t*,
           hipStream_t);
 int sort_rows(const float*, int, int, float*, hipStream_t);
@@ -202,7 +203,12 @@ static SideStream* side_stream() {
         int expect = 0;
         if (g_side_state[dev].compare_exchange_strong(expect, 1)) {
             SideStream& x = g_side[dev];
-            const bool ok = hipStreamCreateWithFlags(&x.s2, hipStreamNonBlocking) == hipSuccess &&
+            // the LOWEST priority the device offers: where workgroups of both streams are waiting for a CU, the caller's stream goes
+            // first -- it carries the hand's branch, the longer one of a fitting step (its small launches must not queue behind the
+            // object's 392-block coarse pass)
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+            const bool ok = hipStreamCreateWithPriority(&x.s2, hipStreamNonBlocking, least) == hipSuccess &&
                             hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
                             hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess &&
                             hipEventCreateWithFlags(&x.gate, hipEventDisableTiming) == hipSuccess;
@@ -851,12 +857,17 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
         for (int i = 0; i < steps; ++i) {
             for (TrackRun& r : runs) {
                 Track& t = *r.t;
-                HN_TRY(upsample(t.z_a, t.sdf_a, n_rays, r.k, n_new, (float)(64 << i), t.z_new, nullptr, r.st));
-                hipLaunchKernelGGL(k_copy_cols, dim3((n_rays * n_new + 255) / 256), dim3(256), 0, r.st, t.z_new, n_rays, n_new, zcat, S,
-                                   n_samples + (2 * i + r.which) * n_new);
-                HN_LAUNCH_CHECK();
+                // up_sample, the new depths' columns of the concatenated list and (unless this is the last round) the new sample
+                // positions: one launch for the fitting loops' batch sizes, three otherwise
+                const int col = n_samples + (2 * i + r.which) * n_new;
+                const bool more = i + 1 < steps;
+                if (!upsample_fused(t.z_a, t.sdf_a, n_rays, r.k, n_new, (float)(64 << i), t.z_new, zcat, S, col, r.ro, r.rd, more ? t.pts : nullptr, r.st)) {
+                    HN_TRY(upsample(t.z_a, t.sdf_a, n_rays, r.k, n_new, (float)(64 << i), t.z_new, nullptr, r.st));
+                    hipLaunchKernelGGL(k_copy_cols, dim3((n_rays * n_new + 255) / 256), dim3(256), 0, r.st, t.z_new, n_rays, n_new, zcat, S, col);
+                    HN_LAUNCH_CHECK();
+                    if (more) HN_TRY(sample_points(r.ro, r.rd, t.z_new, n_rays, n_new, 0, 0.f, t.pts, nullptr, r.st));
+                }
                 if (i + 1 < steps) {
-                    HN_TRY(sample_points(r.ro, r.rd, t.z_new, n_rays, n_new, 0, 0.f, t.pts, nullptr, r.st));
                     HN_TRY(field_sdf(r.f, t.pts, n_rays * n_new, bt_inv, T_pose, r.nf, r.which == 0 ? rpf * n_new : n_rays * n_new, t.sdf_new,
                                      r.fws, r.fwb, r.st));
                     HN_TRY(merge(t.z_a, t.z_new, t.sdf_a, t.sdf_new, n_rays, r.k, n_new, quirk, t.z_b, t.sdf_b, nullptr, r.st));

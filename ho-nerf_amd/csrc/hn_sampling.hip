@@ -569,9 +569,18 @@ __global__ __launch_bounds__(64) void k_upsample_tiled(const float* __restrict__
 // computed by all lanes; the two prefix recurrences stay strictly sequential in lane 0, in the same order and with the
 // same operations as above (torch.cumprod / torch.cumsum order: the sample indices must not change), and the 16
 // inversions run one per lane.  Same results bit for bit as k_upsample_tiled / k_upsample_direct.
+// UpsExtra (the two-field render's importance rounds, where this launch sat in front of a column copy and a sample-point launch in a
+// chain of dependent launches): the new depths also go to columns col .. col + n_new - 1 of the [n_rays, ld] list `zcat`, and, with
+// `pts`, the new sample positions o + d z (k_sample_points' statement, mid = 0) are written as well.
+struct UpsExtra {
+    float* zcat;
+    int ld, col;
+    const float *o, *d;
+    float* pts;
+};
 __global__ __launch_bounds__(256) void k_upsample_wave(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays, int k,
                                                        int n_new, float inv_s, float* __restrict__ z_new,
-                                                       int64_t* __restrict__ inds_out) {
+                                                       int64_t* __restrict__ inds_out, UpsExtra ex) {
     __shared__ float lz[4][UPS_MAX_K], ls[4][UPS_MAX_K], lw[4][UPS_MAX_K];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wv;
@@ -635,8 +644,15 @@ __global__ __launch_bounds__(256) void k_upsample_wave(const float* __restrict__
         float denom = c_hi - c_lo;
         denom = denom < 1e-5f ? 1.f : denom;
         const float t = (u - c_lo) / denom;
-        z_new[(size_t)ray * n_new + jj] = b_lo + t * (b_hi - b_lo);
+        const float zn = b_lo + t * (b_hi - b_lo);
+        z_new[(size_t)ray * n_new + jj] = zn;
         if (inds_out != nullptr) inds_out[(size_t)ray * n_new + jj] = ptr;
+        if (ex.zcat != nullptr) ex.zcat[(size_t)ray * ex.ld + ex.col + jj] = zn;
+        if (ex.pts != nullptr) {
+            const size_t q = (size_t)ray * n_new + jj;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ex.pts[3 * q + c] = ex.o[3 * ray + c] + ex.d[3 * ray + c] * zn;
+        }
     }
 }
 
@@ -894,7 +910,7 @@ int upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, flo
     HN_REQUIRE(k >= 2 && k <= UPS_MAX_K && n_new >= 1 && n_new <= 64, "upsample: k=%d n_new=%d out of range", k, n_new);
     if (n_rays == 0) return HN_OK;
     if (n_rays <= 8192) {   // small batches (the fitting loops): one wave per ray
-        hipLaunchKernelGGL(k_upsample_wave, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, sdf, n_rays, k, n_new, inv_s, z_new, inds);
+        hipLaunchKernelGGL(k_upsample_wave, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, sdf, n_rays, k, n_new, inv_s, z_new, inds, UpsExtra{});
         HN_LAUNCH_CHECK();
         return HN_OK;
     }
@@ -907,6 +923,16 @@ int upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, flo
     }
     HN_LAUNCH_CHECK();
     return HN_OK;
+}
+
+// up_sample of a small batch (<= 8192 rays: the fitting loops) with the round's follow-up writes in the same launch (UpsExtra);
+// HN_EINVAL-free fallback for larger batches: false is returned and the caller runs the three launches
+bool upsample_fused(const float* z, const float* sdf, int n_rays, int k, int n_new, float inv_s, float* z_new, float* zcat, int ld, int col,
+                    const float* o, const float* d, float* pts, hipStream_t s) {
+    if (n_rays <= 0 || n_rays > 8192 || k < 2 || k > UPS_MAX_K || n_new < 1 || n_new > 64) return false;
+    hipLaunchKernelGGL(k_upsample_wave, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, sdf, n_rays, k, n_new, inv_s, z_new, (int64_t*)nullptr,
+                       UpsExtra{zcat, ld, col, o, d, pts});
+    return hipGetLastError() == hipSuccess;
 }
 
 int merge(const float* z, const float* z_new, const float* sdf, const float* sdf_new, int n_rays, int k, int m,

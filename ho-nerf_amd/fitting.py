@@ -693,6 +693,7 @@ class PipelinedSingleFit:
         self.sdf_h, self.sdf_o, self.grad_h, self.grad_o = e(n, 1), e(n, 1), e(n, 3), e(n, 3)
         self.gc, self.gw, self.gsh, self.gso = e(R, 3), e(R), e(n), e(n)
 
+    @torch.no_grad()
     def step(self, view, t_rand=None):
         """-> the step's loss terms (device scalars, as fit_step returns them).  The six leaves' .grad hold the step's gradient."""
         L, lib, ren, ch = self.L, self.lib, self.ren, self.chain

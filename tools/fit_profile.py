@@ -15,11 +15,12 @@ dev = torch.device('cuda')
 halo = (sys.argv[2] if len(sys.argv) > 2 else 'halo') == 'halo'     # the reference's six-leaf pose chain (default) or the rigid one
 ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3', halo=halo)
 opt = F.make_optimizer(chain, video=False)
+pipe = (sys.argv[3] if len(sys.argv) > 3 else 'pipe') == 'pipe'     # the two-stream step (fit_frame's default) or the autograd step
 for i in range(3):
-    F.fit_step(ren, views[i % 8], chain, opt, bench.NEAR, bench.FAR, '12')
+    F.fit_step(ren, views[i % 8], chain, opt, bench.NEAR, bench.FAR, '12', pipelined=pipe)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(steps):
-    F.fit_step(ren, views[i % 8], chain, opt, bench.NEAR, bench.FAR, '12')
+    F.fit_step(ren, views[i % 8], chain, opt, bench.NEAR, bench.FAR, '12', pipelined=pipe)
 torch.cuda.synchronize()
 print('ms per step: %.3f' % ((time.perf_counter() - t0) / steps * 1e3))
