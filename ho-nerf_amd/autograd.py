@@ -328,3 +328,161 @@ class FitStepLossFn(torch.autograd.Function):
         s_c, s_w, s_s, s_j, s_r, s_t = ctx.shapes
         return (gc.reshape(s_c), gw.reshape(s_w), None if gsh is None else gsh.reshape(s_s), None if gso is None else gso.reshape(s_s),
                 gj_o.reshape(s_j), gR_o.reshape(s_r), gt_o.reshape(s_t), None, None, None, None, None, None, None)
+
+
+class Mat3InverseFn(torch.autograd.Function):
+    """torch.inverse on [F,3,3] (fitting_video.py:284 `torch.inverse(obj_r)`) as one launch each way (hn_mat3_inverse / _bwd); as
+    torch operators the LU factorisation, the solve and their backward passes were ~15 launches of a launch-bound step."""
+
+    @staticmethod
+    def forward(ctx, R):
+        L = _lib
+        lib = L.load()
+        r = L.f32(R).reshape(-1, 9)
+        out = torch.empty_like(r)
+        L.check(lib.hn_mat3_inverse(L.ptr(r), r.shape[0], L.ptr(out), L.stream_ptr()), 'hn_mat3_inverse')
+        ctx.save_for_backward(out)
+        ctx.shape = R.shape
+        return out.reshape(R.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib
+        lib = L.load()
+        (y,) = ctx.saved_tensors
+        gy = L.f32(g).reshape(-1, 9)
+        gr = torch.empty_like(y)
+        L.check(lib.hn_mat3_inverse_bwd(L.ptr(y), L.ptr(gy), y.shape[0], L.ptr(gr), L.stream_ptr()), 'hn_mat3_inverse_bwd')
+        return gr.reshape(ctx.shape)
+
+
+class StableLossFn(torch.autograd.Function):
+    """`get_stable_loss_cross` (utils/renderer_batch.py:318-371) as one autograd node: (obj verts [F,Vfull,3], bt_inv [F,21,4,4], T_pose
+    [F,21,3], obj_r [F,3,3], obj_t [F,3]) -> the stable term.  Forward: hn_stable_pts (every 10th vertex to the world), the hand field's
+    TAPED evaluation on those points, hn_stable_value (inside sets, nearest outside vertices, weights, the value and d value / d sdf):
+    three launches; backward: the hand field's adjoint from the tape with d value / d sdf as the upstream gradient of the sdf, then
+    hn_stable_pts_bwd.  (As torch operators around a layer-by-layer sdf adjoint: ~50 + ~90 launches.)"""
+
+    @staticmethod
+    def forward(ctx, pts, bt_inv, T_pose, obj_r, obj_t, field, state, strict):
+        L = _lib
+        lib = L.load()
+        dev = torch.device('cuda')
+        st = L.stream_ptr()
+        p = L.f32(pts, dev)
+        Fr, Vfull = p.shape[0], p.shape[1]
+        stride = 10
+        V = (Vfull + stride - 1) // stride
+        n = Fr * V
+        bt, tp = L.f32(bt_inv, dev).reshape(Fr, 21, 4, 4), L.f32(T_pose, dev).reshape(-1, 21, 3)
+        if tp.shape[0] != Fr:
+            tp = tp.expand(Fr, 21, 3).contiguous()
+        R, t = L.f32(obj_r, dev).reshape(Fr, 9), L.f32(obj_t, dev).reshape(Fr, 3)
+        pw, p0 = _empty(n, 3, dev=dev), _empty(V, 3, dev=dev)
+        L.check(lib.hn_stable_pts(L.ptr(p), Fr, Vfull, stride, L.ptr(R), L.ptr(t), L.ptr(pw), L.ptr(p0), st), 'hn_stable_pts')
+        sdf, grad, rgb = _empty(n, dev=dev), _empty(n, 3, dev=dev), _empty(n, 3, dev=dev)
+        tape_bytes = lib.hn_field_tape_bytes(field.handle, n)
+        need = lib.hn_field_workspace_bytes(field.handle, n)
+        tape = state['tape'].get(max(tape_bytes, 16), dev)
+        ws = state['ws'].get(max(need, 16), dev)
+        dirs = state.setdefault('dirs', {})
+        if n not in dirs:
+            dirs[n] = torch.zeros(n, 3, device=dev)          # (the hand's colour network ignores the view direction; also the zero upstream gradients)
+        L.check(lib.hn_field_eval_taped(field.handle, L.ptr(pw), L.ptr(dirs[n]), n, 1, L.ptr(bt), L.ptr(tp), Fr, V, L.ptr(sdf), L.ptr(grad), L.ptr(rgb),
+                                        L.ptr(ws), need, L.ptr(tape), tape_bytes, st), 'hn_field_eval_taped')
+        val_d = _empty(1 + n, dev=dev)
+        value, dsdf = val_d[0:1], val_d[1:]
+        scratch = torch.empty(n, dtype=torch.uint8, device=dev)
+        L.check(lib.hn_stable_value(L.ptr(sdf), L.ptr(p0), Fr, V, 1 if strict else 0, L.ptr(value), L.ptr(dsdf), L.ptr(scratch), st), 'hn_stable_value')
+        state['serial'] = state.get('serial', 0) + 1
+        ctx.serial, ctx.state, ctx.field = state['serial'], state, field
+        ctx.sizes = (Fr, Vfull, stride, V)
+        ctx.shapes = (bt_inv.shape, T_pose.shape, obj_r.shape, obj_t.shape)
+        ctx.save_for_backward(p, pw, bt, tp, dsdf, grad, rgb)
+        return value.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib
+        lib = L.load()
+        p, pw, bt, tp, dsdf, grad, rgb = ctx.saved_tensors
+        if ctx.serial != ctx.state.get('serial'):
+            raise RuntimeError('the stable term\'s tape was overwritten by a later evaluation before its backward pass ran')
+        Fr, Vfull, stride, V = ctx.sizes
+        n = Fr * V
+        dev = p.device
+        st = L.stream_ptr()
+        gs = dsdf * g                                           # upstream gradient of the sdf
+        zeros = ctx.state['dirs'][n]
+        g_pts = _empty(n, 3, dev=dev)
+        g_bt, g_tp = torch.zeros(Fr, 21, 4, 4, device=dev), torch.zeros(Fr, 21, 3, device=dev)
+        need = lib.hn_field_bwd_workspace_bytes(ctx.field.handle, n)
+        ws = ctx.state['ws_bwd'].get(max(need, 16), dev)
+        tape = ctx.state['tape'].buf
+        L.check(lib.hn_field_eval_bwd_taped(ctx.field.handle, L.ptr(pw), L.ptr(zeros), n, 1, L.ptr(bt), L.ptr(tp), Fr, V, L.ptr(gs), L.ptr(zeros),
+                                            L.ptr(zeros), L.ptr(grad), L.ptr(rgb), L.ptr(tape), L.ptr(g_pts), None, L.ptr(g_bt), L.ptr(g_tp), L.ptr(ws), need,
+                                            st), 'hn_field_eval_bwd_taped')
+        gR, gt = _empty(Fr, 9, dev=dev), _empty(Fr, 3, dev=dev)
+        L.check(lib.hn_stable_pts_bwd(L.ptr(p), Fr, Vfull, stride, L.ptr(g_pts), L.ptr(gR), L.ptr(gt), st), 'hn_stable_pts_bwd')
+        s_bt, s_tp, s_r, s_t = ctx.shapes
+        g_tp_out = g_tp.reshape(s_tp) if g_tp.numel() == int(torch.Size(s_tp).numel()) else g_tp.sum(0).reshape(s_tp)
+        return None, g_bt.reshape(s_bt), g_tp_out, gR.reshape(s_r), gt.reshape(s_t), None, None, None
+
+
+class FitWindowLossFn(torch.autograd.Function):
+    """The whole loss of one fitting_video window step (fitting_video.py:285-334) as ONE launch forward (hn_window_loss) and ONE
+    backward (hn_window_loss_bwd): (color_fine [F,P,3], weight_sum [F,P,1], sdf_hand [n,1], sdf_obj [n,1], joint_3d [F,21,3], obj_r
+    [F,3,3], obj_t [F,3], stable [] | None) -> (loss [], terms [10] = loss, colour, mask, contact, penetration, joint, verts,
+    50 x smooth, 100 x stable, 0 -- not differentiable).  anchor: 1 / 2 = the window starts / ends the sequence (not on the very
+    first step).  As torch operators (render terms, pose regularisers, smoothness): ~60 launches forward, ~80 backward."""
+
+    WEIGHTS = (0.5, 30.0, 20.0, 30.0, 20.0, 50.0, 100.0)
+
+    @staticmethod
+    def forward(ctx, color, wsum, sdf_h, sdf_o, joint_3d, obj_r, obj_t, stable, true_rgb, true_mask, joint_pred, Ro_pred, To_pred, verts, anchor):
+        L = _lib
+        lib = L.load()
+        dev = color.device
+        c, w = L.f32(color).reshape(-1, 3), L.f32(wsum).reshape(-1)
+        t, m = L.f32(true_rgb, dev).reshape(-1, 3), L.f32(true_mask, dev).reshape(-1)
+        sh, so = L.f32(sdf_h).reshape(-1), L.f32(sdf_o).reshape(-1)
+        R, n = c.shape[0], sh.shape[0]
+        j3, jp = L.f32(joint_3d).reshape(-1, 21, 3), L.f32(joint_pred, dev).reshape(-1, 21, 3)
+        Fr = j3.shape[0]
+        Ra, ta = L.f32(obj_r).reshape(Fr, 9), L.f32(obj_t).reshape(Fr, 3)
+        Rb, tb = L.f32(Ro_pred, dev).reshape(Fr, 9), L.f32(To_pred, dev).reshape(Fr, 3)
+        st_ = None if stable is None else L.f32(stable).reshape(1)
+        buf = _empty(6 + 10 + 75 * Fr, dev=dev)          # sums | terms | g_joint [F,63] | gR [F,9] | gt [F,3]
+        sums, terms = buf[0:6], buf[6:16]
+        gj, gR, gt = buf[16:16 + 63 * Fr], buf[16 + 63 * Fr:16 + 72 * Fr], buf[16 + 72 * Fr:16 + 75 * Fr]
+        scratch, need = _loss_scratch(lib, R, n, dev)
+        w7 = (ctypes.c_float * 7)(*FitWindowLossFn.WEIGHTS)
+        L.check(lib.hn_window_loss(L.ptr(c), L.ptr(w), L.ptr(t), L.ptr(m), R, L.ptr(sh), L.ptr(so), n, L.ptr(j3), L.ptr(jp), Fr, L.ptr(Ra), L.ptr(ta),
+                                   L.ptr(Rb), L.ptr(tb), L.ptr(verts), verts.shape[0], L.ptr(st_), int(anchor), w7, L.ptr(scratch), need, L.ptr(sums),
+                                   L.ptr(terms), L.ptr(gj), L.ptr(gR), L.ptr(gt), L.stream_ptr()), 'hn_window_loss')
+        ctx.save_for_backward(c, w, t, m, buf, sh, so)
+        ctx.w7, ctx.Fr, ctx.has_stable = w7, Fr, stable is not None
+        ctx.shapes = (color.shape, wsum.shape, sdf_h.shape, sdf_o.shape, joint_3d.shape, obj_r.shape, obj_t.shape)
+        ctx.mark_non_differentiable(terms)
+        return terms[0], terms
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_terms):
+        L = _lib
+        lib = L.load()
+        c, w, t, m, buf, sh, so = ctx.saved_tensors
+        Fr = ctx.Fr
+        sums = buf[0:6]
+        gj, gR, gt = buf[16:16 + 63 * Fr], buf[16 + 63 * Fr:16 + 72 * Fr], buf[16 + 72 * Fr:16 + 75 * Fr]
+        dev = c.device
+        R, n = c.shape[0], sh.shape[0]
+        out = _empty(75 * Fr + 1, dev=dev)
+        gj_o, gR_o, gt_o, gst = out[0:63 * Fr], out[63 * Fr:72 * Fr], out[72 * Fr:75 * Fr], out[75 * Fr:75 * Fr + 1]
+        gl = L.f32(g_loss).reshape(1)
+        gc, gw, gsh, gso = _empty(R, 3, dev=dev), _empty(R, dev=dev), _empty(n, dev=dev), _empty(n, dev=dev)
+        L.check(lib.hn_window_loss_bwd(L.ptr(c), L.ptr(w), L.ptr(t), L.ptr(m), R, L.ptr(sh), L.ptr(so), n, L.ptr(sums), L.ptr(gl), ctx.w7, L.ptr(gj),
+                                       L.ptr(gR), L.ptr(gt), Fr, L.ptr(gc), L.ptr(gw), L.ptr(gsh), L.ptr(gso), L.ptr(gj_o), L.ptr(gR_o), L.ptr(gt_o),
+                                       L.ptr(gst), L.stream_ptr()), 'hn_window_loss_bwd')
+        s_c, s_w, s_h, s_o, s_j, s_r, s_t = ctx.shapes
+        return (gc.reshape(s_c), gw.reshape(s_w), gsh.reshape(s_h), gso.reshape(s_o), gj_o.reshape(s_j), gR_o.reshape(s_r), gt_o.reshape(s_t),
+                gst.reshape(()) if ctx.has_stable else None, None, None, None, None, None, None, None)

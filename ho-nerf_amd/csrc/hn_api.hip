@@ -53,6 +53,17 @@ int obj_rays_bwd(const float*, const float*, int, int, int, float, const float*,
                  float*, float*, float*, float*, hipStream_t, bool transposed = false);
 int dual_prologue(const float*, const float*, const float*, const float*, int, int, float*, float*, const float*, int, float, float, float, float*, float*,
                   float*, int, hipStream_t, bool transposed = false);
+int mat3_inverse(const float*, int, float*, hipStream_t);
+int mat3_inverse_bwd(const float*, const float*, int, float*, hipStream_t);
+int stable_pts(const float*, int, int, int, const float*, const float*, float*, float*, hipStream_t);
+int stable_pts_bwd(const float*, int, int, int, const float*, float*, float*, hipStream_t);
+int stable_value(const float*, const float*, int, int, int, float*, float*, unsigned char*, hipStream_t);
+size_t window_loss_scratch_bytes(int, int);
+int window_loss(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*, int, const float*,
+                const float*, const float*, const float*, const float*, int, const float*, int, const float*, void*, size_t, float*, float*, float*, float*,
+                float*, hipStream_t);
+int window_loss_bwd(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*, const float*,
+                    const float*, const float*, const float*, int, float*, float*, float*, float*, float*, float*, float*, float*, hipStream_t);
 size_t fit_step_loss_scratch_bytes(int, int);
 int fit_step_loss(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*, int, const float*,
                   const float*, const float*, const float*, const float*, int, const float*, void*, size_t, float*, float*, float*, float*, float*, hipStream_t);
@@ -1477,6 +1488,57 @@ int hn_adam_step(int n_tensors, float* const* params, const float* const* grads,
 int hn_fit_total(const float* sums6, const float* verts_loss, const float* joint_3d, const float* joint3d_pred, int n_joints,
                  const float* weights5, float* terms8, float* g_joint, hn_stream_t stream) {
     return fit_total(sums6, verts_loss, joint_3d, joint3d_pred, n_joints, weights5, terms8, g_joint, (hipStream_t)stream);
+}
+int hn_mat3_inverse(const float* R, int n, float* out, hn_stream_t stream) { return hn::mat3_inverse(R, n, out, (hipStream_t)stream); }
+int hn_mat3_inverse_bwd(const float* R_inv, const float* g_out, int n, float* g_R, hn_stream_t stream) {
+    return hn::mat3_inverse_bwd(R_inv, g_out, n, g_R, (hipStream_t)stream);
+}
+int hn_stable_pts(const float* pts, int n_frames, int n_verts, int stride, const float* obj_r, const float* obj_t, float* pts_world, float* p0,
+                  hn_stream_t stream) {
+    return hn::stable_pts(pts, n_frames, n_verts, stride, obj_r, obj_t, pts_world, p0, (hipStream_t)stream);
+}
+int hn_stable_pts_bwd(const float* pts, int n_frames, int n_verts, int stride, const float* g_pts_world, float* g_obj_r, float* g_obj_t,
+                      hn_stream_t stream) {
+    return hn::stable_pts_bwd(pts, n_frames, n_verts, stride, g_pts_world, g_obj_r, g_obj_t, (hipStream_t)stream);
+}
+int hn_stable_value(const float* sdf, const float* p0, int n_frames, int n_sel, int strict_reference, float* value, float* d_sdf, void* scratch,
+                    hn_stream_t stream) {
+    return hn::stable_value(sdf, p0, n_frames, n_sel, strict_reference, value, d_sdf, reinterpret_cast<unsigned char*>(scratch), (hipStream_t)stream);
+}
+size_t hn_window_loss_scratch_bytes(int n_rays, int n_samples) { return hn::window_loss_scratch_bytes(n_rays, n_samples); }
+int hn_window_loss(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_hand,
+                   const float* sdf_obj, int n_samples, const float* joint_3d, const float* joint3d_pred, int n_frames, const float* obj_r,
+                   const float* obj_t, const float* Ro_pred, const float* To_pred, const float* verts, int n_verts, const float* stable, int anchor,
+                   const float* weights7, void* scratch, size_t scratch_bytes, float* sums6, float* terms10, float* g_joint, float* gR, float* gt,
+                   hn_stream_t stream) {
+    return hn::window_loss(color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, joint_3d, joint3d_pred, n_frames, obj_r, obj_t,
+                           Ro_pred, To_pred, verts, n_verts, stable, anchor, weights7, scratch, scratch_bytes, sums6, terms10, g_joint, gR, gt,
+                           (hipStream_t)stream);
+}
+int hn_window_loss_bwd(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_hand,
+                       const float* sdf_obj, int n_samples, const float* sums6, const float* g_loss, const float* weights7, const float* g_joint,
+                       const float* gR, const float* gt, int n_frames, float* g_color, float* g_weight_sum, float* g_sdf_hand, float* g_sdf_obj,
+                       float* g_joint_out, float* gR_out, float* gt_out, float* g_stable, hn_stream_t stream) {
+    return hn::window_loss_bwd(color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, sums6, g_loss, weights7, g_joint, gR, gt,
+                               n_frames, g_color, g_weight_sum, g_sdf_hand, g_sdf_obj, g_joint_out, gR_out, gt_out, g_stable, (hipStream_t)stream);
+}
+size_t hn_field_tape_bytes(const hn_field* f, int n_pts) { return (f == nullptr || n_pts <= 0) ? 0 : field_tape(f, n_pts); }
+int hn_field_eval_taped(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray, const float* bt_inv,
+                        const float* T_pose, int n_frames, int pts_per_frame, float* sdf, float* grad, float* rgb, void* workspace,
+                        size_t workspace_bytes, void* tape, size_t tape_bytes, hn_stream_t stream) {
+    HN_REQUIRE(f != nullptr && tape != nullptr && tape_bytes >= field_tape(f, n_pts) && field_tape(f, n_pts) != 0,
+               "hn_field_eval_taped: an HN_PREC_F16X3 field with its adjoint programs and a tape of hn_field_tape_bytes");
+    return field_eval(f, pts, rays_d, n_pts, samples_per_ray, bt_inv, T_pose, n_frames, pts_per_frame, sdf, grad, rgb, nullptr, workspace,
+                      workspace_bytes, (hipStream_t)stream, tape, tape_bytes);
+}
+int hn_field_eval_bwd_taped(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray, const float* bt_inv,
+                            const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad, const float* g_rgb,
+                            const float* grad, const float* rgb, const void* tape, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose,
+                            void* workspace, size_t workspace_bytes, hn_stream_t stream) {
+    HN_REQUIRE(f != nullptr && tape != nullptr && g_grad != nullptr && g_rgb != nullptr && grad != nullptr && rgb != nullptr,
+               "hn_field_eval_bwd_taped: tape, upstream gradients of all three outputs, and the evaluation's grad / rgb");
+    return bwd::field_eval_bwd(f, pts, rays_d, n_pts, samples_per_ray, bt_inv, T_pose, n_frames, pts_per_frame, g_sdf, g_grad, g_rgb, g_pts, g_rays_d,
+                               g_bt_inv, g_T_pose, workspace, workspace_bytes, (hipStream_t)stream, tape, grad, rgb);
 }
 size_t hn_fit_step_loss_scratch_bytes(int n_rays, int n_samples) { return hn::fit_step_loss_scratch_bytes(n_rays, n_samples); }
 int hn_fit_step_loss(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_hand,

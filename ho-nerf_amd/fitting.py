@@ -394,6 +394,17 @@ def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, 
                                        render_out['sdf_obj'] if interaction else None, pose['joint_3d'], pose['obj_r'], pose['obj_t'], true_rgb,
                                        true_mask, pose['joint3d_pred'], pose['Ro_pred'], pose['To_pred'], pose['obj_verts'], weights)
         return {'loss': loss, 'color': tv[1], 'mask': tv[2], 'contact': tv[3], 'penetration': tv[4], 'joint': tv[5], 'obj_verts': tv[6]}
+    if _fused_window_loss(render_out, pose, video):
+        # fitting_video on the device: the whole loss of the window is one autograd node, one launch each way (autograd.FitWindowLossFn)
+        from .autograd import FitWindowLossFn
+        anchor = 1 if smooth_ends[0] else (2 if smooth_ends[1] else 0)
+        loss, tv = FitWindowLossFn.apply(render_out['color_fine'], render_out['weight_sum'], render_out['sdf_hand'], render_out['sdf_obj'], pose['joint_3d'],
+                                         pose['obj_r'], pose['obj_t'], stable, true_rgb, true_mask, pose['joint3d_pred'], pose['Ro_pred'], pose['To_pred'],
+                                         pose['obj_verts'], anchor)
+        terms = {'loss': loss, 'color': tv[1], 'mask': tv[2], 'contact': tv[3], 'penetration': tv[4], 'joint': tv[5], 'obj_verts': tv[6], 'smooth': tv[7]}
+        if stable is not None:
+            terms['stable'] = tv[8]
+        return terms
     terms = render_loss_terms(render_out, true_rgb, true_mask, fit_type, video)
     pt = pose_terms if pose_terms is not None else pose_loss_terms(pose, fit_type, video, smooth_ends)
     terms['joint'], terms['obj_verts'] = pt['joint'], pt['obj_verts']
@@ -404,6 +415,14 @@ def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, 
             terms['stable'] = 100.0 * stable
             terms['loss'] = terms['loss'] + terms['stable']
     return terms
+
+
+FUSED_WINDOW_LOSS = True   # fitting_video on the device: the window's loss as one launch each way (False: the torch-operator form)
+
+
+def _fused_window_loss(render_out, pose, video):
+    return (FUSED_WINDOW_LOSS and video and render_out['color_fine'].is_cuda and 'obj_verts' in pose and 'sdf_hand' in render_out
+            and 2 <= pose['joint_3d'].shape[0] <= 8)
 
 
 def pose_loss_terms(pose, fit_type='1', video=False, smooth_ends=(False, False)):
@@ -491,24 +510,31 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
     T_pose = pose['T_pose_21']
     stable, pterms, side = None, None, None
     want_stable = video and fit_type == '1234'
-    if video and rays_o.is_cuda and rays_fn is None and USE_SIDE_STREAM:
-        # What depends on the pose only -- the stable term (hand SDF on the object's vertices, ~50 small launches forward and ~70
-        # backward) and the pose regularisers / smoothness (~40 + ~60) -- runs on a second stream beside the render; autograd runs
-        # the backward passes on that stream too, beside the render's.  They join the loss below.
+    fused_loss = video and rays_o.is_cuda and FUSED_WINDOW_LOSS and 'obj_verts' in pose and 2 <= pose['joint_3d'].shape[0] <= 8
+    if video and rays_o.is_cuda and rays_fn is None and USE_SIDE_STREAM and (want_stable or not fused_loss):
+        # What depends on the pose only -- the stable term (the hand field's taped evaluation on the object's vertices: a few
+        # launches, but ~0.6 ms of one round of tiles forward and ~1 ms backward) and, in the torch-operator form of the loss, the
+        # pose regularisers / smoothness -- runs on a second stream beside the render; autograd runs the backward passes on that
+        # stream too, beside the render's.  They join the loss below.
         main = torch.cuda.current_stream()
         side = _side_stream(rays_o.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             if want_stable:
                 stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
-            pterms = pose_loss_terms(pose, fit_type, True, smooth_ends)
+            if not fused_loss:
+                pterms = pose_loss_terms(pose, fit_type, True, smooth_ends)
         for x in pose.values():
             if isinstance(x, torch.Tensor) and x.is_cuda:
                 x.record_stream(side)
     elif want_stable:
         stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
     if video:
-        Ro_arg = torch.inverse(pose['obj_r'])                                          # fitting_video.py:284
+        if rays_o.is_cuda and rays_fn is None:
+            from .autograd import Mat3InverseFn
+            Ro_arg = Mat3InverseFn.apply(pose['obj_r'])                                # fitting_video.py:284, one launch each way
+        else:
+            Ro_arg = torch.inverse(pose['obj_r'])                                      # fitting_video.py:284
         out = renderer.render(rays_o.reshape(n_cams, P, 3), rays_d.reshape(n_cams, P, 3), near, far, pose['bt_inv'], T_pose, None,
                               Ro_arg, pose['obj_t'], t_rand=t_rand)
     else:
@@ -520,7 +546,7 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
     if side is not None:
         main = torch.cuda.current_stream()
         main.wait_stream(side)
-        for x in ([stable] if stable is not None else []) + list(pterms.values()):
+        for x in ([stable] if stable is not None else []) + (list(pterms.values()) if pterms is not None else []):
             x.record_stream(main)
     terms = step_loss(out, view['true_rgb'], view['true_mask'], pose, fit_type, video, smooth_ends, stable, pterms)
     terms['loss'].backward()

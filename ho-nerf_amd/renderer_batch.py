@@ -49,6 +49,15 @@ class NeuSRenderer_fitting(_Unbatched):
         is applied to the boolean MASK, not to indices, so what is removed from the vertex list are the integer values
         the mask takes (vertex 1 if any vertex is inside, vertex 0 if any is outside) and the 'outside' candidates
         include the inside vertices themselves; with strict_reference = False the complement of the inside set is used."""
+        hand = self.fields()[0]
+        if getattr(self, 'fused_stable', True) and (hand.precision or 'f16x3') == 'f16x3' and _lib.f32(pts).shape[0] <= 8:
+            # the whole term as one autograd node over a handful of launches (autograd.StableLossFn)
+            from .autograd import StableLossFn
+            from .renderer import _Workspace
+            if not hasattr(self, '_stable_state'):
+                self._stable_state = {'tape': _Workspace(), 'ws': _Workspace(), 'ws_bwd': _Workspace()}
+            g_ = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(x)).to(device='cuda', dtype=torch.float32)
+            return StableLossFn.apply(g_(pts), g_(bt_inv), g_(T_pose_21), g_(Ro), g_(To), hand, self._stable_state, bool(self.strict_reference))
         from .autograd import HandSdfFn
         dev = torch.device('cuda')
         g = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(x)).to(device=dev, dtype=torch.float32)
@@ -57,7 +66,6 @@ class NeuSRenderer_fitting(_Unbatched):
         Ro, To, bt = g(Ro).reshape(Fr, 3, 3), g(To).reshape(Fr, 3), g(bt_inv).reshape(Fr, 21, 4, 4)
         tp = g(T_pose_21).reshape(-1, 21, 3)
         pts_world = (Ro.unsqueeze(1) @ pts.unsqueeze(-1))[..., 0] + To.unsqueeze(1)
-        hand = self.fields()[0]
         if not hasattr(self, '_ws_stable'):
             from .renderer import _Workspace
             self._ws_stable = _Workspace()       # its own workspace: this term may run on a second stream beside the render

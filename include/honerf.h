@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 110 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 111 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -400,6 +400,54 @@ int hn_render_dual_aux_offsets(const hn_field* hand, const hn_field* obj, int n_
  * render of these sizes does not compact.  Valid after hn_render_dual until the buffers are re-used. */
 int hn_render_dual_compact_offsets(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples, int n_importance,
                                    int up_sample_steps, size_t* offsets2);
+
+/* ---- the pose-only and loss side of a fitting_video window step in a handful of launches (hn_fit_window.hip) ----------------
+ * hn_mat3_inverse / _bwd: torch.inverse(obj_r) of fitting_video.py:284 for n 3 x 3 matrices (adjugate), and its adjoint
+ *   g_R = -Y^T g_out Y^T with Y the inverse.
+ * get_stable_loss_cross (utils/renderer_batch.py:318-371) around the hand SDF:
+ *   hn_stable_pts: every stride-th vertex of pts [n_frames, n_verts, 3] taken to the world with (obj_r, obj_t) (:319-321) ->
+ *     pts_world [n_frames, ceil(n_verts / stride), 3]; p0 [ceil(n_verts / stride), 3] (may be NULL): frame 0's selected vertices
+ *     in object coordinates (what the nearest-vertex query runs on, :352-353); hn_stable_pts_bwd: its adjoint w.r.t. obj_r, obj_t;
+ *   hn_stable_value: sdf [n_frames, n_sel] of the hand on those points -> value[0] = the stable term, d_sdf [n_frames, n_sel] =
+ *     d value / d sdf (inside sets, the nearest 'outside' vertex of every inside vertex -- the reference's cKDTree query --,
+ *     weights: constants, as in the reference).  strict_reference != 0: the reference's 'outside' set (np.setdiff1d applied to the
+ *     boolean mask).  n_frames <= 8; scratch: n_frames x n_sel bytes.
+ * hn_field_tape_bytes / hn_field_eval_taped / hn_field_eval_bwd_taped: hn_field_eval that keeps its tape (HN_PREC_F16X3 fields
+ *   with adjoint programs) and the adjoint alone from that tape (the taped pair hn_render_dual / _bwd use, for a caller's own
+ *   points: the hand SDF on the object's vertices); g_grad / g_rgb: upstream gradients of all three outputs (zeros where unused).
+ * hn_window_loss / _bwd: the whole loss of a window (fitting_video.py:285-334) in one launch each way:
+ *   loss = w0 (colour + 0.5 mask) + w1 contact + w2 penetration + w3 joint + w4 verts + w5 smooth + w6 stable  (weights7: host
+ *   array; the reference: {0.5, 30, 20, 30, 20, 50, 100}), joint / verts / smooth over the window's n_frames (<= 8) frames as
+ *   pose_loss (mean) of fitting_video.py:123-126, :310-321; anchor bit 0 / bit 1: the window starts / ends the sequence and the
+ *   smoothness term is anchored to the prediction there (:312-320); stable: device scalar or NULL.
+ *   terms10 = {loss, colour, mask, contact, penetration, joint, verts, w5 smooth, w6 stable, 0}; g_joint [n_frames,21,3], gR
+ *   [n_frames,9], gt [n_frames,3]: d (weighted pose part) / d (joint_3d, obj_r, obj_t); scratch as hn_fit_step_loss's. */
+int hn_mat3_inverse(const float* R, int n, float* out, hn_stream_t stream);
+int hn_mat3_inverse_bwd(const float* R_inv, const float* g_out, int n, float* g_R, hn_stream_t stream);
+int hn_stable_pts(const float* pts, int n_frames, int n_verts, int stride, const float* obj_r, const float* obj_t, float* pts_world, float* p0,
+                  hn_stream_t stream);
+int hn_stable_pts_bwd(const float* pts, int n_frames, int n_verts, int stride, const float* g_pts_world, float* g_obj_r, float* g_obj_t,
+                      hn_stream_t stream);
+int hn_stable_value(const float* sdf, const float* p0, int n_frames, int n_sel, int strict_reference, float* value, float* d_sdf, void* scratch,
+                    hn_stream_t stream);
+size_t hn_field_tape_bytes(const hn_field* f, int n_pts);
+int hn_field_eval_taped(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray, const float* bt_inv,
+                        const float* T_pose, int n_frames, int pts_per_frame, float* sdf, float* grad, float* rgb, void* workspace,
+                        size_t workspace_bytes, void* tape, size_t tape_bytes, hn_stream_t stream);
+int hn_field_eval_bwd_taped(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray, const float* bt_inv,
+                            const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad, const float* g_rgb,
+                            const float* grad, const float* rgb, const void* tape, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose,
+                            void* workspace, size_t workspace_bytes, hn_stream_t stream);
+size_t hn_window_loss_scratch_bytes(int n_rays, int n_samples);
+int hn_window_loss(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_hand,
+                   const float* sdf_obj, int n_samples, const float* joint_3d, const float* joint3d_pred, int n_frames, const float* obj_r,
+                   const float* obj_t, const float* Ro_pred, const float* To_pred, const float* verts, int n_verts, const float* stable, int anchor,
+                   const float* weights7, void* scratch, size_t scratch_bytes, float* sums6, float* terms10, float* g_joint, float* gR, float* gt,
+                   hn_stream_t stream);
+int hn_window_loss_bwd(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_hand,
+                       const float* sdf_obj, int n_samples, const float* sums6, const float* g_loss, const float* weights7, const float* g_joint,
+                       const float* gR, const float* gt, int n_frames, float* g_color, float* g_weight_sum, float* g_sdf_hand, float* g_sdf_obj,
+                       float* g_joint_out, float* gR_out, float* gt_out, float* g_stable, hn_stream_t stream);
 
 /* The render-dependent loss terms of one fitting step (fitting_single.py:251-283; fitting_video.py:285-309): the sums
  * behind colour L1, mask BCE, contact and penetration in one launch, and their gradients w.r.t. the render outputs in

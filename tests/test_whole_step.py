@@ -214,9 +214,10 @@ def test_fitting_single_step_matches_the_oracle_composition():
                  grad_cap=GRAD_CAP)
 
 
-def test_fitting_video_window_step_matches_the_oracle_composition():
+@pytest.mark.parametrize('ends', [(True, False), (False, True)])
+def test_fitting_video_window_step_matches_the_oracle_composition(ends):
     """C5: one fit_backward of a fitting_video window -- 4 frames x 40 rays, fit type 1234 (stable term on the object's vertices),
-    anchored at the sequence start, batched renderer with the reference's SDF-row quirk B-1 in the sampling."""
+    anchored at the sequence start / at its end, batched renderer with the reference's SDF-row quirk B-1 in the sampling."""
     import bench
     from honerf_amd import fitting as F
     dev = torch.device('cuda')
@@ -226,13 +227,13 @@ def test_fitting_video_window_step_matches_the_oracle_composition():
     tr = torch.rand(4 * bench.VID_RAYS, 1, generator=torch.Generator().manual_seed(8)).to(dev)
     view = views[0]
     ov = verts[:, :400].contiguous()
-    terms = F.fit_backward(ren, view, chain, bench.NEAR, bench.FAR, '1234', index=[0, 1, 2, 3], smooth_ends=(True, False), obj_verts_for_stable=ov,
+    terms = F.fit_backward(ren, view, chain, bench.NEAR, bench.FAR, '1234', index=[0, 1, 2, 3], smooth_ends=ends, obj_verts_for_stable=ov,
                            t_rand=tr)
     torch.cuda.synchronize()
     got_terms = {k: v.detach().cpu() for k, v in terms.items()}
     got_grads = [p.grad.detach().clone() for p in chain.parameters()]
     z = ren.last_z_vals.detach().reshape(4 * bench.VID_RAYS, -1)
-    kw = dict(video=True, ends=(True, False), obj_verts_stable=ov, chunk_rays=bench.VID_RAYS)
+    kw = dict(video=True, ends=ends, obj_verts_stable=ov, chunk_rays=bench.VID_RAYS)
     ref32 = _oracle_step(nets, chain, [0, 1, 2, 3], view, z, '1234', torch.float32, **kw)
     ref64 = _oracle_step(nets, chain, [0, 1, 2, 3], view, z, '1234', torch.float64, **kw)
     sel = lambda d: ((d['sdf_hand'].abs() + d['sdf_obj'].abs()) < 1e-2, (d['sdf_hand'] < 0) & (d['sdf_obj'] < 0))
@@ -241,4 +242,4 @@ def test_fitting_video_window_step_matches_the_oracle_composition():
     if float(ref32[0].get('stable', torch.zeros(()))) != 0.0:
         keys.append('stable')
     record('C5 window step: stable term of the oracle', float(ref32[0].get('stable', torch.zeros(()))), float('inf'), kind='value')
-    _compare('C5 window step', got_terms, got_grads, ref32, ref64, keys, flips, grad_cap=GRAD_CAP)
+    _compare('C5 window step (anchor %s)' % ('first' if ends[0] else 'last'), got_terms, got_grads, ref32, ref64, keys, flips, grad_cap=GRAD_CAP)
