@@ -392,8 +392,11 @@ class StableLossFn(torch.autograd.Function):
                                         L.ptr(ws), need, L.ptr(tape), tape_bytes, st), 'hn_field_eval_taped')
         val_d = _empty(1 + n, dev=dev)
         value, dsdf = val_d[0:1], val_d[1:]
-        scratch = torch.empty(n, dtype=torch.uint8, device=dev)
-        L.check(lib.hn_stable_value(L.ptr(sdf), L.ptr(p0), Fr, V, 1 if strict else 0, L.ptr(value), L.ptr(dsdf), L.ptr(scratch), st), 'hn_stable_value')
+        sneed = lib.hn_stable_value_scratch_bytes(Fr, V)
+        scr = state.get('value_scratch')
+        if scr is None or scr.numel() < sneed:
+            scr = state['value_scratch'] = torch.zeros(int(sneed), dtype=torch.uint8, device=dev)     # zeroed once: every launch leaves its counter zero
+        L.check(lib.hn_stable_value(L.ptr(sdf), L.ptr(p0), Fr, V, 1 if strict else 0, L.ptr(value), L.ptr(dsdf), L.ptr(scr), sneed, st), 'hn_stable_value')
         state['serial'] = state.get('serial', 0) + 1
         ctx.serial, ctx.state, ctx.field = state['serial'], state, field
         ctx.sizes = (Fr, Vfull, stride, V)

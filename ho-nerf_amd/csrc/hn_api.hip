@@ -57,7 +57,8 @@ int mat3_inverse(const float*, int, float*, hipStream_t);
 int mat3_inverse_bwd(const float*, const float*, int, float*, hipStream_t);
 int stable_pts(const float*, int, int, int, const float*, const float*, float*, float*, hipStream_t);
 int stable_pts_bwd(const float*, int, int, int, const float*, float*, float*, hipStream_t);
-int stable_value(const float*, const float*, int, int, int, float*, float*, unsigned char*, hipStream_t);
+size_t stable_value_scratch_bytes(int, int);
+int stable_value(const float*, const float*, int, int, int, float*, float*, void*, size_t, hipStream_t);
 size_t window_loss_scratch_bytes(int, int);
 int window_loss(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*, int, const float*,
                 const float*, const float*, const float*, const float*, int, const float*, int, const float*, void*, size_t, float*, float*, float*, float*,
@@ -1501,9 +1502,10 @@ int hn_stable_pts_bwd(const float* pts, int n_frames, int n_verts, int stride, c
                       hn_stream_t stream) {
     return hn::stable_pts_bwd(pts, n_frames, n_verts, stride, g_pts_world, g_obj_r, g_obj_t, (hipStream_t)stream);
 }
+size_t hn_stable_value_scratch_bytes(int n_frames, int n_sel) { return hn::stable_value_scratch_bytes(n_frames, n_sel); }
 int hn_stable_value(const float* sdf, const float* p0, int n_frames, int n_sel, int strict_reference, float* value, float* d_sdf, void* scratch,
-                    hn_stream_t stream) {
-    return hn::stable_value(sdf, p0, n_frames, n_sel, strict_reference, value, d_sdf, reinterpret_cast<unsigned char*>(scratch), (hipStream_t)stream);
+                    size_t scratch_bytes, hn_stream_t stream) {
+    return hn::stable_value(sdf, p0, n_frames, n_sel, strict_reference, value, d_sdf, scratch, scratch_bytes, (hipStream_t)stream);
 }
 size_t hn_window_loss_scratch_bytes(int n_rays, int n_samples) { return hn::window_loss_scratch_bytes(n_rays, n_samples); }
 int hn_window_loss(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_hand,

@@ -51,7 +51,7 @@ __global__ void k_mat3_inverse_bwd(const float* __restrict__ Y, const float* __r
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gR[9 * f + 3 * r + c] = -(t[3 * r] * y[c] + t[3 * r + 1] * y[3 + c] + t[3 * r + 2] * y[6 + c]);
+        for (int c = 0; c < 3; ++c) gR[9 * f + 3 * r + c] = -(t[3 * r] * y[3 * c] + t[3 * r + 1] * y[3 * c + 1] + t[3 * r + 2] * y[3 * c + 2]);   // (t Y^T)[r][c]
 }
 
 // ---- world positions of every `stride`-th object vertex: p_w[f,v] = R_f p[f, stride v] + t_f -------------------------------------
@@ -113,16 +113,22 @@ __global__ __launch_bounds__(256) void k_stable_pts_bwd(const float* __restrict_
 // inside and vertex 0 if any is outside, and keeps the inside vertices; else the complement of the inside set.
 // Outputs: value[0], dsdf [F,V] = d value / d sdf (the sets and weights are constants, as under the reference's .cpu() / numpy).
 constexpr int STABLE_MAX_F = 8, STABLE_MAX_V = 1024;
+constexpr int STABLE_QPB = 16;   // queries per block (4 per wave)
+// Many blocks for the nearest-vertex queries (one wave per query: 800 of them in a window of 4 x 200 vertices all inside the hand,
+// ~1 us each: 0.35 ms in one block), the block that finishes last does the rest.  nearest [F V] ints and the counter (zero at the
+// first launch, left zero by every launch) live in the caller's scratch.
 __global__ __launch_bounds__(256) void k_stable_value(const float* __restrict__ sdf, const float* __restrict__ p0, int F, int V, int strict,
-                                                      float* __restrict__ value, float* __restrict__ dsdf, unsigned char* __restrict__ sel_scratch) {
+                                                      float* __restrict__ value, float* __restrict__ dsdf, int* __restrict__ nearest,
+                                                      unsigned* __restrict__ counter) {
     __shared__ int n_in[STABLE_MAX_F], any_out[STABLE_MAX_F];
     __shared__ float red[4];
+    __shared__ bool is_last;
+    __shared__ unsigned char sel[STABLE_MAX_F * STABLE_MAX_V];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < STABLE_MAX_F) {
         n_in[tid] = 0;
         any_out[tid] = 0;
     }
-    for (int q = tid; q < F * V; q += blockDim.x) sel_scratch[q] = 0;
     __syncthreads();
     for (int q = tid; q < F * V; q += blockDim.x) {
         const int f = q / V;
@@ -132,41 +138,57 @@ __global__ __launch_bounds__(256) void k_stable_value(const float* __restrict__ 
             atomicOr(&any_out[f], 1);
     }
     __syncthreads();
-    int in_time = 0;
-    for (int f = 0; f < F; ++f) in_time += n_in[f] > 0 ? 1 : 0;
-    // nearest candidate of every inside vertex of every penetrating frame: one wave per query (brute force over V candidates)
-    for (int q = wave; q < F * V; q += 4) {
+    // nearest candidate of every inside vertex of every penetrating frame (brute force over the V candidates; ties: lowest index)
+    for (int k = 0; k < STABLE_QPB / 4; ++k) {
+        const int q = blockIdx.x * STABLE_QPB + wave * (STABLE_QPB / 4) + k;
+        if (q >= F * V) break;
         const int f = q / V, i = q % V;
-        if (!(n_in[f] > 0 && sdf[q] < 0.f)) continue;
-        const float px = p0[3 * i], py = p0[3 * i + 1], pz = p0[3 * i + 2];
-        float best = INFINITY;
         int arg = -1;
-        for (int j = lane; j < V; j += 64) {
-            bool cand;
-            if (strict)
-                cand = !((j == 1 && n_in[f] > 0) || (j == 0 && any_out[f] != 0));
-            else
-                cand = !(sdf[f * V + j] < 0.f);
-            if (!cand) continue;
-            const float dx = p0[3 * j] - px, dy = p0[3 * j + 1] - py, dz = p0[3 * j + 2] - pz;
-            const float d = dx * dx + dy * dy + dz * dz;
-            if (d < best) {
-                best = d;
-                arg = j;
+        if (n_in[f] > 0 && sdf[q] < 0.f) {
+            const float px = p0[3 * i], py = p0[3 * i + 1], pz = p0[3 * i + 2];
+            float best = INFINITY;
+            for (int j = lane; j < V; j += 64) {
+                bool cand;
+                if (strict)
+                    cand = !((j == 1 && n_in[f] > 0) || (j == 0 && any_out[f] != 0));
+                else
+                    cand = !(sdf[f * V + j] < 0.f);
+                if (!cand) continue;
+                const float dx = p0[3 * j] - px, dy = p0[3 * j + 1] - py, dz = p0[3 * j + 2] - pz;
+                const float d = dx * dx + dy * dy + dz * dz;
+                if (d < best) {
+                    best = d;
+                    arg = j;
+                }
             }
-        }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ob = __shfl_xor(best, off, 64);
-            const int oa = __shfl_xor(arg, off, 64);
-            if (oa >= 0 && (arg < 0 || ob < best || (ob == best && oa < arg))) {
-                best = ob;
-                arg = oa;
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ob = __shfl_xor(best, off, 64);
+                const int oa = __shfl_xor(arg, off, 64);
+                if (oa >= 0 && (arg < 0 || ob < best || (ob == best && oa < arg))) {
+                    best = ob;
+                    arg = oa;
+                }
             }
         }
-        if (lane == 0 && arg >= 0) sel_scratch[f * V + arg] = 1;
+        if (lane == 0) nearest[q] = arg;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) is_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (tid == 0) *counter = 0u;
+    for (int q = tid; q < F * V; q += blockDim.x) sel[q] = 0;
+    __syncthreads();
+    for (int q = tid; q < F * V; q += blockDim.x) {
+        const int a = reinterpret_cast<const volatile int*>(nearest)[q];
+        if (a >= 0) sel[(q / V) * V + a] = 1;   // (several queries may name the same vertex: the same byte, the same value)
     }
     __syncthreads();
+    int in_time = 0;
+    for (int f = 0; f < F; ++f) in_time += n_in[f] > 0 ? 1 : 0;
     // per vertex: Win = sum_cid inside[cid,v] / denom[cid], Wout = sum_cid selected[cid,v] / denom[cid]; pos / neg over the penetrating frames
     float total = 0.f;
     const float inv_time = in_time > 1 ? 1.f / (float)in_time : 0.f;
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(256) void k_stable_value(const float* __restrict__ 
             const float denom = fmaxf((float)(in_time - 1) * (float)n_in[f], 1.f);
             const float s = sdf[f * V + v];
             if (s < 0.f) Win += 1.f / denom;
-            if (sel_scratch[f * V + v]) Wout += 1.f / denom;
+            if (sel[f * V + v]) Wout += 1.f / denom;
             pos += fminf(fmaxf(s, 0.f), 1e7f);
             neg += fabsf(fmaxf(fminf(s, 0.f), -1e7f));
         }
@@ -478,10 +500,17 @@ int stable_pts_bwd(const float* pts, int n_frames, int n_full, int stride, const
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
-int stable_value(const float* sdf, const float* p0, int n_frames, int V, int strict, float* value, float* dsdf, unsigned char* scratch, hipStream_t s) {
+size_t stable_value_scratch_bytes(int n_frames, int V) { return ((size_t)n_frames * V + 16) * sizeof(int); }
+int stable_value(const float* sdf, const float* p0, int n_frames, int V, int strict, float* value, float* dsdf, void* scratch, size_t scratch_bytes,
+                 hipStream_t s) {
     HN_REQUIRE(sdf && p0 && value && dsdf && scratch, "stable_value: NULL argument");
-    HN_REQUIRE(n_frames >= 1 && n_frames <= STABLE_MAX_F && V >= 1, "stable_value: at most %d frames", STABLE_MAX_F);
-    hipLaunchKernelGGL(k_stable_value, dim3(1), dim3(256), 0, s, sdf, p0, n_frames, V, strict, value, dsdf, scratch);
+    HN_REQUIRE(n_frames >= 1 && n_frames <= STABLE_MAX_F && V >= 1 && V <= STABLE_MAX_V, "stable_value: at most %d frames of %d vertices", STABLE_MAX_F,
+               STABLE_MAX_V);
+    HN_REQUIRE(scratch_bytes >= stable_value_scratch_bytes(n_frames, V), "stable_value: scratch too small");
+    unsigned* counter = reinterpret_cast<unsigned*>(scratch);   // zero when the scratch is first handed over; every launch leaves it zero
+    int* nearest = reinterpret_cast<int*>(scratch) + 16;
+    hipLaunchKernelGGL(k_stable_value, dim3((n_frames * V + STABLE_QPB - 1) / STABLE_QPB), dim3(256), 0, s, sdf, p0, n_frames, V, strict, value, dsdf, nearest,
+                       counter);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

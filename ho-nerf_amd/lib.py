@@ -25,7 +25,7 @@ PRECISIONS = {'fp32': HN_PREC_FP32, 'f16x3': HN_PREC_F16X3, 'f16': HN_PREC_F16}
 # 'fp32': the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32), 5x slower, kept as a second opinion
 DEFAULT_PRECISION = os.environ.get('HONERF_PRECISION', 'f16x3')
 HN_MAX_LAYERS = 9
-HN_VERSION = 111          # the include/honerf.h revision SIGNATURES below was written for
+HN_VERSION = 112          # the include/honerf.h revision SIGNATURES below was written for
 
 c_f = ctypes.c_void_p     # device float*
 c_i = ctypes.c_int
@@ -100,7 +100,8 @@ SIGNATURES = {
     'hn_mat3_inverse_bwd': (c_i, [c_f, c_f, c_i, c_f, c_vp]),
     'hn_stable_pts': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_vp]),
     'hn_stable_pts_bwd': (c_i, [c_f, c_i, c_i, c_i, c_f, c_f, c_f, c_vp]),
-    'hn_stable_value': (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_vp, c_vp]),
+    'hn_stable_value_scratch_bytes': (c_sz, [c_i, c_i]),
+    'hn_stable_value': (c_i, [c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_vp, c_sz, c_vp]),
     'hn_field_tape_bytes': (c_sz, [c_vp, c_i]),
     'hn_field_eval_taped': (c_i, [c_vp, c_f, c_f, c_i, c_i, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_vp, c_sz, c_vp, c_sz, c_vp]),
     'hn_field_eval_bwd_taped': (c_i, [c_vp, c_f, c_f, c_i, c_i, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_vp, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp]),

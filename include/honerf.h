@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 111 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 112 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -411,7 +411,8 @@ int hn_render_dual_compact_offsets(const hn_field* hand, const hn_field* obj, in
  *   hn_stable_value: sdf [n_frames, n_sel] of the hand on those points -> value[0] = the stable term, d_sdf [n_frames, n_sel] =
  *     d value / d sdf (inside sets, the nearest 'outside' vertex of every inside vertex -- the reference's cKDTree query --,
  *     weights: constants, as in the reference).  strict_reference != 0: the reference's 'outside' set (np.setdiff1d applied to the
- *     boolean mask).  n_frames <= 8; scratch: n_frames x n_sel bytes.
+ *     boolean mask).  n_frames <= 8, n_sel <= 1024; scratch: hn_stable_value_scratch_bytes bytes the caller
+ *     ZEROES ONCE and keeps handing over (every launch leaves it ready for the next).
  * hn_field_tape_bytes / hn_field_eval_taped / hn_field_eval_bwd_taped: hn_field_eval that keeps its tape (HN_PREC_F16X3 fields
  *   with adjoint programs) and the adjoint alone from that tape (the taped pair hn_render_dual / _bwd use, for a caller's own
  *   points: the hand SDF on the object's vertices); g_grad / g_rgb: upstream gradients of all three outputs (zeros where unused).
@@ -428,8 +429,9 @@ int hn_stable_pts(const float* pts, int n_frames, int n_verts, int stride, const
                   hn_stream_t stream);
 int hn_stable_pts_bwd(const float* pts, int n_frames, int n_verts, int stride, const float* g_pts_world, float* g_obj_r, float* g_obj_t,
                       hn_stream_t stream);
+size_t hn_stable_value_scratch_bytes(int n_frames, int n_sel);
 int hn_stable_value(const float* sdf, const float* p0, int n_frames, int n_sel, int strict_reference, float* value, float* d_sdf, void* scratch,
-                    hn_stream_t stream);
+                    size_t scratch_bytes, hn_stream_t stream);
 size_t hn_field_tape_bytes(const hn_field* f, int n_pts);
 int hn_field_eval_taped(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int samples_per_ray, const float* bt_inv,
                         const float* T_pose, int n_frames, int pts_per_frame, float* sdf, float* grad, float* rgb, void* workspace,

@@ -6,7 +6,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps, skip = int(sys.argv[2]), int(sys.argv[3])
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
 # find step boundaries: the forward hand full kernel appears once per step
-marks = [i for i, e in enumerate(ev) if 'k_field2_hand<1>' in e[2] or 'k_field2_hand<3>' in e[2]]
+import os
+_mark = os.environ.get('HN_TRACE_MARK')      # kernel that runs once per step (default: the hand's final evaluation)
+marks = [i for i, e in enumerate(ev) if ((_mark in e[2]) if _mark else ('k_field2_hand<1>' in e[2] or 'k_field2_hand<3>' in e[2]))]
 marks = marks[skip:skip + steps + 1]
 a, b = ev[marks[0]][0], ev[marks[-1]][0]
 sel = [e for e in ev if a <= e[0] < b]

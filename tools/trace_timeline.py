@@ -19,7 +19,9 @@ def short(name):
 
 
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']), r.get('Queue_Id', '')) for r in rows)
-marks = [i for i, e in enumerate(ev) if 'k_field2_hand<3>' in e[2] or 'k_field2_hand<1>' in e[2]]
+import os
+_mark = os.environ.get('HN_TRACE_MARK')      # kernel that runs once per step (default: the hand's final evaluation)
+marks = [i for i, e in enumerate(ev) if ((_mark in e[2]) if _mark else ('k_field2_hand<3>' in e[2] or 'k_field2_hand<1>' in e[2]))]
 a, b = marks[step_idx], marks[step_idx + 1]
 # start of step = first sdf-only hand kernel before the mark
 t0 = ev[a][0]
