@@ -511,14 +511,16 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
     stable, pterms, side = None, None, None
     want_stable = video and fit_type == '1234'
     fused_loss = video and rays_o.is_cuda and FUSED_WINDOW_LOSS and 'obj_verts' in pose and 2 <= pose['joint_3d'].shape[0] <= 8
-    if video and rays_o.is_cuda and rays_fn is None and USE_SIDE_STREAM and (want_stable or not fused_loss):
-        # What depends on the pose only -- the stable term (the hand field's taped evaluation on the object's vertices: a few
-        # launches, but ~0.6 ms of one round of tiles forward and ~1 ms backward) and, in the torch-operator form of the loss, the
-        # pose regularisers / smoothness -- runs on a second stream beside the render; autograd runs the backward passes on that
-        # stream too, beside the render's.  They join the loss below.
-        main = torch.cuda.current_stream()
+    pose_ready = None
+
+    def pose_only_terms():
+        """What depends on the pose only -- the stable term (the hand field's taped evaluation on the object's vertices: a few
+        launches, but ~0.5 ms of one round of tiles forward and ~0.9 ms backward) and, in the torch-operator form of the loss, the
+        pose regularisers / smoothness -- on a second stream beside the render; autograd runs their backward passes on that stream
+        too, beside the render's.  They join the loss below."""
+        nonlocal stable, pterms, side
         side = _side_stream(rays_o.device)
-        side.wait_stream(main)
+        side.wait_event(pose_ready)
         with torch.cuda.stream(side):
             if want_stable:
                 stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
@@ -527,6 +529,12 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
         for x in pose.values():
             if isinstance(x, torch.Tensor) and x.is_cuda:
                 x.record_stream(side)
+    use_side = video and rays_o.is_cuda and rays_fn is None and USE_SIDE_STREAM and (want_stable or not fused_loss)
+    if use_side:
+        pose_ready = torch.cuda.Event()
+        pose_ready.record()                      # the pose chain's outputs are complete here (the render's launches come after)
+        if not fused_loss:
+            pose_only_terms()
     elif want_stable:
         stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
     if video:
@@ -543,6 +551,12 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
         first = lambda x: x.reshape(x.shape[1:]) if one else x[0]
         Ro_arg = first(pose['obj_r']).T                                                # fitting_single.py:250
         out = renderer.render(rays_o, rays_d, near, far, first(pose['bt_inv']), first(T_pose), None, Ro_arg, first(pose['obj_t']), t_rand=t_rand)
+    if use_side and fused_loss:
+        # Queued AFTER the render: autograd runs the node created last first, so the stable term's backward pass (three small
+        # launches and a 7-tile adjoint, ~0.9 ms on 7 CUs) is in its stream BEFORE the render's adjoint kernels take every CU --
+        # queued behind them, its small launches waited ~0.3 ms for a free CU and its adjoint ended ~0.35 ms after the render's.
+        # On the device the forward work still starts as soon as the pose chain is done (it waits for `pose_ready` only).
+        pose_only_terms()
     if side is not None:
         main = torch.cuda.current_stream()
         main.wait_stream(side)

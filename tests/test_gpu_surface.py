@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close, assert_parity, bounded, cu, oracle_fields, oracle_fields_fp64, product_modules, rel_err, t
+from helpers import record, assert_close, assert_parity, bounded, cu, oracle_fields, oracle_fields_fp64, product_modules, rel_err, t
 
 pytestmark = pytest.mark.gpu
 RT = 1e-4
@@ -430,22 +430,29 @@ def test_fit_sequence_video_one_rank_is_the_sequential_schedule():
     assert st['steps'] == outer * 3 * sub * n_views and st['windows'] == outer * 3 and st['allreduce_calls'] == 0
     assert all(torch.isfinite(v).all() for v in st['last'].values())
 
-    chain_b, wins_b, _ = problem()
-    opt = sgd(chain_b)
-    torch.manual_seed(11)
-    for it in range(outer):
-        for index in F.sliding_windows(data_num):
-            for s_ in range(sub):
-                for vid in range(n_views):
-                    later = it + s_ + vid > 0
-                    F.fit_step(renb, wins_b[tuple(index)][vid], chain_b, opt, 0.4, 1.5, '1234', index=index,
-                               smooth_ends=(later and index[0] == 0, later and index[-1] == data_num - 1), obj_verts_for_stable=ov)
+    def reference_order():
+        chain_b, wins_b, _ = problem()
+        opt = sgd(chain_b)
+        torch.manual_seed(11)
+        for it in range(outer):
+            for index in F.sliding_windows(data_num):
+                for s_ in range(sub):
+                    for vid in range(n_views):
+                        later = it + s_ + vid > 0
+                        F.fit_step(renb, wins_b[tuple(index)][vid], chain_b, opt, 0.4, 1.5, '1234', index=index,
+                                   smooth_ends=(later and index[0] == 0, later and index[-1] == data_num - 1), obj_verts_for_stable=ov)
+        return chain_b
+    chain_b, chain_c = reference_order(), reference_order()
     moved = max(float((a.detach() - a.detach().round()).abs().max()) for a in chain_a.parameters())
-    diff = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(chain_a.parameters(), chain_b.parameters()))
+    dist = lambda x, y: max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(x.parameters(), y.parameters()))
     assert moved > 1e-7, moved
-    # (two runs of the SAME code differ at this level: the pose gradients are accumulated with float atomics and a 1e-7 change of a
-    # pose moves importance samples; observed 2e-4 ... 1.1e-3)
-    bounded('fit_sequence_video (1 rank) vs fit_step in the reference order: max parameter difference / movement', diff / moved, 1e-2)
+    # Two runs of the SAME code differ: the pose gradients are accumulated with float atomics and a 1e-7 change of a pose moves
+    # importance samples.  That run-to-run distance is measured here (the reference-order loop twice) and the loop under test may be
+    # 4x as far from either run (never more than 5 % of the parameters' movement).
+    noise = dist(chain_b, chain_c) / moved
+    record('fit_step in the reference order, two runs of the same loop: max parameter difference / movement', noise, float('inf'), kind='noise floor')
+    bounded('fit_sequence_video (1 rank) vs fit_step in the reference order: max parameter difference / movement', dist(chain_a, chain_b) / moved,
+            min(max(1e-2, 4.0 * noise), 5e-2))
 
 
 @pytest.mark.parametrize('fit_type', ['1', '12'])
