@@ -154,6 +154,8 @@ class DualRenderFn(torch.autograd.Function):
                                        L.ptr(tape), 0, st),
                 'hn_render_dual_bwd')
 
+        _join_pending_side()       # (the stable term's backward pass, queued on its own stream by the loss node: see _PENDING_SIDE)
+
         def like(g, ref):          # an input shared by all frames (e.g. T_pose [21,3]) receives the sum over frames
             return g.reshape(ref.shape) if g.numel() == ref.numel() else g.reshape(F, *ref.shape[-(ref.dim()):]).sum(0).reshape(ref.shape)
 
@@ -356,15 +358,16 @@ class Mat3InverseFn(torch.autograd.Function):
         return gr.reshape(ctx.shape)
 
 
-class StableLossFn(torch.autograd.Function):
-    """`get_stable_loss_cross` (utils/renderer_batch.py:318-371) as one autograd node: (obj verts [F,Vfull,3], bt_inv [F,21,4,4], T_pose
-    [F,21,3], obj_r [F,3,3], obj_t [F,3]) -> the stable term.  Forward: hn_stable_pts (every 10th vertex to the world), the hand field's
-    TAPED evaluation on those points, hn_stable_value (inside sets, nearest outside vertices, weights, the value and d value / d sdf):
-    three launches; backward: the hand field's adjoint from the tape with d value / d sdf as the upstream gradient of the sdf, then
-    hn_stable_pts_bwd.  (As torch operators around a layer-by-layer sdf adjoint: ~50 + ~90 launches.)"""
+class StableTerm:
+    """`get_stable_loss_cross` (utils/renderer_batch.py:318-371) in explicit halves, no autograd: `StableTerm(...)` runs the forward
+    -- hn_stable_pts (every 10th vertex to the world), the hand field's TAPED evaluation on those points, hn_stable_value (inside sets,
+    nearest outside vertices, weights, the value and d value / d sdf): three launches -- and `.backward(g)` the rest: the hand field's
+    adjoint from the tape with g x d value / d sdf as the upstream gradient of the sdf, then hn_stable_pts_bwd
+    -> (g_bt_inv, g_T_pose, g_obj_r, g_obj_t).  (As torch operators around a layer-by-layer sdf adjoint: ~50 + ~90 launches.)
+    `StableLossFn` wraps it as an autograd node; the fitting_video loss node (`FitWindowLossFn`) drives it directly, so that its
+    backward launches are queued FIRST in a step's backward pass."""
 
-    @staticmethod
-    def forward(ctx, pts, bt_inv, T_pose, obj_r, obj_t, field, state, strict):
+    def __init__(self, pts, bt_inv, T_pose, obj_r, obj_t, field, state, strict):
         L = _lib
         lib = L.load()
         dev = torch.device('cuda')
@@ -398,38 +401,67 @@ class StableLossFn(torch.autograd.Function):
             scr = state['value_scratch'] = torch.zeros(int(sneed), dtype=torch.uint8, device=dev)     # zeroed once: every launch leaves its counter zero
         L.check(lib.hn_stable_value(L.ptr(sdf), L.ptr(p0), Fr, V, 1 if strict else 0, L.ptr(value), L.ptr(dsdf), L.ptr(scr), sneed, st), 'hn_stable_value')
         state['serial'] = state.get('serial', 0) + 1
-        ctx.serial, ctx.state, ctx.field = state['serial'], state, field
-        ctx.sizes = (Fr, Vfull, stride, V)
-        ctx.shapes = (bt_inv.shape, T_pose.shape, obj_r.shape, obj_t.shape)
-        ctx.save_for_backward(p, pw, bt, tp, dsdf, grad, rgb)
-        return value.reshape(())
+        self.serial, self.state, self.field = state['serial'], state, field
+        self.sizes = (Fr, Vfull, stride, V)
+        self.saved = (p, pw, bt, tp, dsdf, grad, rgb)
+        self.value = value.reshape(())
+        self.stream = torch.cuda.current_stream()
 
-    @staticmethod
-    def backward(ctx, g):
+    def backward(self, g):
+        """g: upstream gradient of the value (device scalar) -> (g_bt_inv [F,21,4,4], g_T_pose [F,21,3], g_obj_r [F,9], g_obj_t [F,3])."""
         L = _lib
         lib = L.load()
-        p, pw, bt, tp, dsdf, grad, rgb = ctx.saved_tensors
-        if ctx.serial != ctx.state.get('serial'):
+        p, pw, bt, tp, dsdf, grad, rgb = self.saved
+        if self.serial != self.state.get('serial'):
             raise RuntimeError('the stable term\'s tape was overwritten by a later evaluation before its backward pass ran')
-        Fr, Vfull, stride, V = ctx.sizes
+        Fr, Vfull, stride, V = self.sizes
         n = Fr * V
         dev = p.device
         st = L.stream_ptr()
         gs = dsdf * g                                           # upstream gradient of the sdf
-        zeros = ctx.state['dirs'][n]
+        zeros = self.state['dirs'][n]
         g_pts = _empty(n, 3, dev=dev)
-        g_bt, g_tp = torch.zeros(Fr, 21, 4, 4, device=dev), torch.zeros(Fr, 21, 3, device=dev)
-        need = lib.hn_field_bwd_workspace_bytes(ctx.field.handle, n)
-        ws = ctx.state['ws_bwd'].get(max(need, 16), dev)
-        tape = ctx.state['tape'].buf
-        L.check(lib.hn_field_eval_bwd_taped(ctx.field.handle, L.ptr(pw), L.ptr(zeros), n, 1, L.ptr(bt), L.ptr(tp), Fr, V, L.ptr(gs), L.ptr(zeros),
-                                            L.ptr(zeros), L.ptr(grad), L.ptr(rgb), L.ptr(tape), L.ptr(g_pts), None, L.ptr(g_bt), L.ptr(g_tp), L.ptr(ws), need,
-                                            st), 'hn_field_eval_bwd_taped')
+        g_pose = torch.zeros(Fr * (21 * 16 + 21 * 3), device=dev)  # (one fill: the adjoint accumulates into both blocks)
+        g_bt_c, g_tp_c = g_pose[:Fr * 336].view(Fr, 21, 4, 4), g_pose[Fr * 336:].view(Fr, 21, 3)
+        need = lib.hn_field_bwd_workspace_bytes(self.field.handle, n)
+        ws = self.state['ws_bwd'].get(max(need, 16), dev)
+        tape = self.state['tape'].buf
+        L.check(lib.hn_field_eval_bwd_taped(self.field.handle, L.ptr(pw), L.ptr(zeros), n, 1, L.ptr(bt), L.ptr(tp), Fr, V, L.ptr(gs), L.ptr(zeros),
+                                            L.ptr(zeros), L.ptr(grad), L.ptr(rgb), L.ptr(tape), L.ptr(g_pts), None, L.ptr(g_bt_c), L.ptr(g_tp_c), L.ptr(ws),
+                                            need, st), 'hn_field_eval_bwd_taped')
         gR, gt = _empty(Fr, 9, dev=dev), _empty(Fr, 3, dev=dev)
         L.check(lib.hn_stable_pts_bwd(L.ptr(p), Fr, Vfull, stride, L.ptr(g_pts), L.ptr(gR), L.ptr(gt), st), 'hn_stable_pts_bwd')
+        return g_bt_c, g_tp_c, gR, gt
+
+
+class StableLossFn(torch.autograd.Function):
+    """`get_stable_loss_cross` as one autograd node over StableTerm: (obj verts [F,Vfull,3], bt_inv [F,21,4,4], T_pose [F,21,3], obj_r
+    [F,3,3], obj_t [F,3]) -> the stable term."""
+
+    @staticmethod
+    def forward(ctx, pts, bt_inv, T_pose, obj_r, obj_t, field, state, strict):
+        ctx.term = StableTerm(pts, bt_inv, T_pose, obj_r, obj_t, field, state, strict)
+        ctx.shapes = (bt_inv.shape, T_pose.shape, obj_r.shape, obj_t.shape)
+        return ctx.term.value
+
+    @staticmethod
+    def backward(ctx, g):
+        g_bt, g_tp, gR, gt = ctx.term.backward(g)
         s_bt, s_tp, s_r, s_t = ctx.shapes
         g_tp_out = g_tp.reshape(s_tp) if g_tp.numel() == int(torch.Size(s_tp).numel()) else g_tp.sum(0).reshape(s_tp)
         return None, g_bt.reshape(s_bt), g_tp_out, gR.reshape(s_r), gt.reshape(s_t), None, None, None
+
+
+# streams whose tail a step's main stream has still to wait for before gradients produced there are consumed: the stable term's
+# backward launches (FitWindowLossFn.backward, on the step's side stream); DualRenderFn.backward inserts the wait behind its own
+# launches -- the render's adjoint kernels are then already queued, and the wait costs nothing (they run longer)
+_PENDING_SIDE = []
+
+
+def _join_pending_side():
+    cur = torch.cuda.current_stream()
+    while _PENDING_SIDE:
+        cur.wait_stream(_PENDING_SIDE.pop())
 
 
 class FitWindowLossFn(torch.autograd.Function):
@@ -442,10 +474,18 @@ class FitWindowLossFn(torch.autograd.Function):
     WEIGHTS = (0.5, 30.0, 20.0, 30.0, 20.0, 50.0, 100.0)
 
     @staticmethod
-    def forward(ctx, color, wsum, sdf_h, sdf_o, joint_3d, obj_r, obj_t, stable, true_rgb, true_mask, joint_pred, Ro_pred, To_pred, verts, anchor):
+    def forward(ctx, color, wsum, sdf_h, sdf_o, joint_3d, obj_r, obj_t, stable, true_rgb, true_mask, joint_pred, Ro_pred, To_pred, verts, anchor,
+                bt_inv=None, stable_term=None):
+        """stable: the stable term as a tensor (an autograd input), or None with `stable_term`: a StableTerm evaluated earlier on
+        `stable_term.stream` (no autograd) whose backward this node's backward drives -- its gradients w.r.t. bt_inv, obj_r, obj_t
+        are returned with this node's (bt_inv is an input for that purpose only)."""
         L = _lib
         lib = L.load()
         dev = color.device
+        ctx.stable_term = stable_term
+        if stable_term is not None:
+            assert stable is None
+            stable = stable_term.value
         c, w = L.f32(color).reshape(-1, 3), L.f32(wsum).reshape(-1)
         t, m = L.f32(true_rgb, dev).reshape(-1, 3), L.f32(true_mask, dev).reshape(-1)
         sh, so = L.f32(sdf_h).reshape(-1), L.f32(sdf_o).reshape(-1)
@@ -465,7 +505,7 @@ class FitWindowLossFn(torch.autograd.Function):
                                    L.ptr(terms), L.ptr(gj), L.ptr(gR), L.ptr(gt), L.stream_ptr()), 'hn_window_loss')
         ctx.save_for_backward(c, w, t, m, buf, sh, so)
         ctx.w7, ctx.Fr, ctx.has_stable = w7, Fr, stable is not None
-        ctx.shapes = (color.shape, wsum.shape, sdf_h.shape, sdf_o.shape, joint_3d.shape, obj_r.shape, obj_t.shape)
+        ctx.shapes = (color.shape, wsum.shape, sdf_h.shape, sdf_o.shape, joint_3d.shape, obj_r.shape, obj_t.shape, None if bt_inv is None else bt_inv.shape)
         ctx.mark_non_differentiable(terms)
         return terms[0], terms
 
@@ -486,6 +526,26 @@ class FitWindowLossFn(torch.autograd.Function):
         L.check(lib.hn_window_loss_bwd(L.ptr(c), L.ptr(w), L.ptr(t), L.ptr(m), R, L.ptr(sh), L.ptr(so), n, L.ptr(sums), L.ptr(gl), ctx.w7, L.ptr(gj),
                                        L.ptr(gR), L.ptr(gt), Fr, L.ptr(gc), L.ptr(gw), L.ptr(gsh), L.ptr(gso), L.ptr(gj_o), L.ptr(gR_o), L.ptr(gt_o),
                                        L.ptr(gst), L.stream_ptr()), 'hn_window_loss_bwd')
-        s_c, s_w, s_h, s_o, s_j, s_r, s_t = ctx.shapes
+        s_c, s_w, s_h, s_o, s_j, s_r, s_t, s_b = ctx.shapes
+        g_bt = None
+        term = ctx.stable_term
+        if term is not None:
+            # the stable term's backward pass, on the stream its forward ran on, queued NOW -- ahead of the render's adjoint kernels,
+            # which take every CU for a millisecond (queued behind them its three small launches waited ~0.3 ms for a free CU and its
+            # 7-tile adjoint ended ~0.35 ms after the render's).  The main stream waits for it behind the render's launches
+            # (_PENDING_SIDE), before anything adds these gradients to the render's.
+            cur = torch.cuda.current_stream()
+            side = term.stream
+            if side != cur:
+                side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                gb, _gtp, gRs, gts = term.backward(gst)
+                gRt = gR_o.reshape(Fr, 9) + gRs
+                gtt = gt_o.reshape(Fr, 3) + gts
+            if side != cur:
+                for x in (gb, gRt, gtt):
+                    x.record_stream(cur)
+                _PENDING_SIDE.append(side)
+            gR_o, gt_o, g_bt = gRt, gtt, (gb.reshape(s_b) if s_b is not None else None)
         return (gc.reshape(s_c), gw.reshape(s_w), gsh.reshape(s_h), gso.reshape(s_o), gj_o.reshape(s_j), gR_o.reshape(s_r), gt_o.reshape(s_t),
-                gst.reshape(()) if ctx.has_stable else None, None, None, None, None, None, None, None)
+                gst.reshape(()) if (ctx.has_stable and term is None) else None, None, None, None, None, None, None, None, g_bt, None)

@@ -398,9 +398,10 @@ def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, 
         # fitting_video on the device: the whole loss of the window is one autograd node, one launch each way (autograd.FitWindowLossFn)
         from .autograd import FitWindowLossFn
         anchor = 1 if smooth_ends[0] else (2 if smooth_ends[1] else 0)
+        term = stable if (stable is not None and not isinstance(stable, torch.Tensor)) else None       # autograd.StableTerm: the explicit form
         loss, tv = FitWindowLossFn.apply(render_out['color_fine'], render_out['weight_sum'], render_out['sdf_hand'], render_out['sdf_obj'], pose['joint_3d'],
-                                         pose['obj_r'], pose['obj_t'], stable, true_rgb, true_mask, pose['joint3d_pred'], pose['Ro_pred'], pose['To_pred'],
-                                         pose['obj_verts'], anchor)
+                                         pose['obj_r'], pose['obj_t'], None if term is not None else stable, true_rgb, true_mask, pose['joint3d_pred'],
+                                         pose['Ro_pred'], pose['To_pred'], pose['obj_verts'], anchor, pose['bt_inv'] if term is not None else None, term)
         terms = {'loss': loss, 'color': tv[1], 'mask': tv[2], 'contact': tv[3], 'penetration': tv[4], 'joint': tv[5], 'obj_verts': tv[6], 'smooth': tv[7]}
         if stable is not None:
             terms['stable'] = tv[8]
@@ -523,18 +524,22 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
         side.wait_event(pose_ready)
         with torch.cuda.stream(side):
             if want_stable:
-                stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
+                # with the fused loss node: the explicit form (autograd.StableTerm) -- the loss node's backward, the first node of the
+                # backward pass, queues the term's backward launches itself, ahead of the render's adjoint kernels
+                stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'],
+                                                        **({'as_term': True} if term_form else {}))
             if not fused_loss:
                 pterms = pose_loss_terms(pose, fit_type, True, smooth_ends)
         for x in pose.values():
             if isinstance(x, torch.Tensor) and x.is_cuda:
                 x.record_stream(side)
     use_side = video and rays_o.is_cuda and rays_fn is None and USE_SIDE_STREAM and (want_stable or not fused_loss)
+    term_form = use_side and fused_loss and want_stable and getattr(renderer, 'fused_stable', True) and \
+        (getattr(renderer, 'precision', None) or 'f16x3') == 'f16x3'
     if use_side:
         pose_ready = torch.cuda.Event()
         pose_ready.record()                      # the pose chain's outputs are complete here (the render's launches come after)
-        if not fused_loss:
-            pose_only_terms()
+        pose_only_terms()
     elif want_stable:
         stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
     if video:
@@ -551,16 +556,11 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
         first = lambda x: x.reshape(x.shape[1:]) if one else x[0]
         Ro_arg = first(pose['obj_r']).T                                                # fitting_single.py:250
         out = renderer.render(rays_o, rays_d, near, far, first(pose['bt_inv']), first(T_pose), None, Ro_arg, first(pose['obj_t']), t_rand=t_rand)
-    if use_side and fused_loss:
-        # Queued AFTER the render: autograd runs the node created last first, so the stable term's backward pass (three small
-        # launches and a 7-tile adjoint, ~0.9 ms on 7 CUs) is in its stream BEFORE the render's adjoint kernels take every CU --
-        # queued behind them, its small launches waited ~0.3 ms for a free CU and its adjoint ended ~0.35 ms after the render's.
-        # On the device the forward work still starts as soon as the pose chain is done (it waits for `pose_ready` only).
-        pose_only_terms()
     if side is not None:
         main = torch.cuda.current_stream()
         main.wait_stream(side)
-        for x in ([stable] if stable is not None else []) + (list(pterms.values()) if pterms is not None else []):
+        shared = [stable] if isinstance(stable, torch.Tensor) else ([stable.value] if stable is not None else [])
+        for x in shared + (list(pterms.values()) if pterms is not None else []):
             x.record_stream(main)
     terms = step_loss(out, view['true_rgb'], view['true_mask'], pose, fit_type, video, smooth_ends, stable, pterms)
     terms['loss'].backward()

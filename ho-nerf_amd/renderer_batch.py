@@ -36,7 +36,7 @@ class NeuSRenderer_fitting(_Unbatched):
             'gradient_obj': o['grad_obj'],
         }
 
-    def get_stable_loss_cross(self, pts, bt_inv, T_pose_21, Ro, To):
+    def get_stable_loss_cross(self, pts, bt_inv, T_pose_21, Ro, To, as_term=False):
         """utils/renderer_batch.py:318-371: the 'stable' term of fitting_video (fit type '1234', weight x100 at
         fitting_video.py:322-324).  pts [F,V,3]: the object's vertices per frame of the window; every 10th vertex is
         taken to the world with (Ro, To), the hand SDF is evaluated there, and over the frames in which the hand
@@ -52,12 +52,16 @@ class NeuSRenderer_fitting(_Unbatched):
         hand = self.fields()[0]
         if getattr(self, 'fused_stable', True) and (hand.precision or 'f16x3') == 'f16x3' and _lib.f32(pts).shape[0] <= 8:
             # the whole term as one autograd node over a handful of launches (autograd.StableLossFn)
-            from .autograd import StableLossFn
+            from .autograd import StableLossFn, StableTerm
             from .renderer import _Workspace
             if not hasattr(self, '_stable_state'):
                 self._stable_state = {'tape': _Workspace(), 'ws': _Workspace(), 'ws_bwd': _Workspace()}
             g_ = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(x)).to(device='cuda', dtype=torch.float32)
+            if as_term:      # the explicit halves (no autograd): the fitting loop's loss node drives the backward pass
+                with torch.no_grad():
+                    return StableTerm(g_(pts), g_(bt_inv), g_(T_pose_21), g_(Ro), g_(To), hand, self._stable_state, bool(self.strict_reference))
             return StableLossFn.apply(g_(pts), g_(bt_inv), g_(T_pose_21), g_(Ro), g_(To), hand, self._stable_state, bool(self.strict_reference))
+        assert not as_term, 'the explicit form of the stable term needs an f16x3 hand field and at most 8 frames'
         from .autograd import HandSdfFn
         dev = torch.device('cuda')
         g = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(x)).to(device=dev, dtype=torch.float32)
