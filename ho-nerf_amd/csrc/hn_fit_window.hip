@@ -240,8 +240,9 @@ __global__ __launch_bounds__(256) void k_window_loss(const float* __restrict__ c
                                                      const float* __restrict__ joint_pred, int F, const float* __restrict__ R, const float* __restrict__ t,
                                                      const float* __restrict__ Rp, const float* __restrict__ tp, const float* __restrict__ verts,
                                                      int n_verts, const float* __restrict__ stable, int anchor, WindowW w, float* __restrict__ partials,
-                                                     unsigned* __restrict__ counter, float* __restrict__ sums6, float* __restrict__ terms10,
-                                                     float* __restrict__ g_joint, float* __restrict__ gR, float* __restrict__ gt) {
+                                                     unsigned* __restrict__ counter, float* __restrict__ pose3, float* __restrict__ sums6,
+                                                     float* __restrict__ terms10, float* __restrict__ g_joint, float* __restrict__ gR,
+                                                     float* __restrict__ gt) {
     __shared__ float red[13][4];
     __shared__ float pair_out[2 * STABLE_MAX_F][13];
     __shared__ bool is_last;
@@ -275,13 +276,133 @@ __global__ __launch_bounds__(256) void k_window_loss(const float* __restrict__ c
     }
     __syncthreads();
     if (threadIdx.x < 6) partials[6 * (size_t)blockIdx.x + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        // ---- the pose part (does not depend on the render: block 0 does it while the other blocks reduce their sums) ------------
+        // vertex pairs: p < F: (R_p, t_p) against the prediction; p >= F: (R_{q+1}, t_{q+1}) against (R_q, t_q), q = p - F.
+        // pair_out[p] = {mean |e|, mean u v^T (9), mean u (3)} (k_verts_loss)
+        const int n_pairs = 2 * F - 1;
+        for (int p = 0; p < n_pairs; ++p) {
+            const float *Ra, *ta, *Rb, *tb;
+            if (p < F) {
+                Ra = R + 9 * p; ta = t + 3 * p; Rb = Rp + 9 * p; tb = tp + 3 * p;
+            } else {
+                const int q = p - F;
+                Ra = R + 9 * (q + 1); ta = t + 3 * (q + 1); Rb = R + 9 * q; tb = t + 3 * q;
+            }
+            float D[9], dd[3];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) D[k] = Ra[k] - Rb[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dd[k] = ta[k] - tb[k];
+            float a13[13];
+#pragma unroll
+            for (int k = 0; k < 13; ++k) a13[k] = 0.f;
+            for (int q = threadIdx.x; q < n_verts; q += blockDim.x) {
+                const float x = verts[3 * q], y = verts[3 * q + 1], z = verts[3 * q + 2];
+                const float e0 = D[0] * x + D[1] * y + D[2] * z + dd[0], e1 = D[3] * x + D[4] * y + D[5] * z + dd[1], e2 = D[6] * x + D[7] * y + D[8] * z + dd[2];
+                const float nn = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+                const float inv = nn > 0.f ? 1.f / nn : 0.f;
+                const float u0 = e0 * inv, u1 = e1 * inv, u2 = e2 * inv;
+                a13[0] += nn;
+                a13[1] += u0 * x; a13[2] += u0 * y; a13[3] += u0 * z;
+                a13[4] += u1 * x; a13[5] += u1 * y; a13[6] += u1 * z;
+                a13[7] += u2 * x; a13[8] += u2 * y; a13[9] += u2 * z;
+                a13[10] += u0; a13[11] += u1; a13[12] += u2;
+            }
+#pragma unroll
+            for (int k = 0; k < 13; ++k) {
+                const float s = wsum64(a13[k]);
+                if (lane == 0) red[k][wave] = s;
+            }
+            __syncthreads();
+            if (threadIdx.x < 13) pair_out[p][threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) / (float)n_verts;
+            __syncthreads();
+        }
+        // joints: thread (f, k) for f < F, k < 21 (F <= 8: 168 threads)
+        const int NJ = 21;
+        const bool first = (anchor & 1) != 0, last = !first && (anchor & 2) != 0;
+        float jl = 0.f, js = 0.f, ja = 0.f;   // this thread's |j - jp|, |j_{f+1} - j_f|, anchor term
+        float gj[3] = {0.f, 0.f, 0.f};
+        const int tf = threadIdx.x / NJ, tk = threadIdx.x % NJ;
+        const float cj = w.joint / (float)(NJ * F), cs = F > 1 ? w.smooth / (float)(NJ * (F - 1)) : 0.f, ca = w.smooth / (float)NJ;
+        if (threadIdx.x < NJ * F) {
+            const float* a = joint_3d + (size_t)(tf * NJ + tk) * 3;
+            const float* b = joint_pred + (size_t)(tf * NJ + tk) * 3;
+            auto unit = [](const float* x, const float* y, float (&u)[3]) {
+                const float e0 = x[0] - y[0], e1 = x[1] - y[1], e2 = x[2] - y[2];
+                const float n = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+                const float inv = n > 0.f ? 1.f / n : 0.f;   // torch.norm's subgradient at 0 is 0
+                u[0] = e0 * inv;
+                u[1] = e1 * inv;
+                u[2] = e2 * inv;
+                return n;
+            };
+            float u[3];
+            jl = unit(a, b, u);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gj[c] += cj * u[c];
+            if ((first && tf == 0) || (last && tf == F - 1)) {
+                ja = jl;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gj[c] += ca * u[c];
+            }
+            if (tf + 1 < F) {   // |j_{f+1} - j_f|: this thread owns the pair's value; -gradient to j_f
+                js = unit(a + NJ * 3, a, u);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gj[c] -= cs * u[c];
+            }
+            if (tf > 0) {       // +gradient of the pair (f - 1, f) to j_f
+                unit(a, a - NJ * 3, u);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gj[c] += cs * u[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g_joint[(size_t)(tf * NJ + tk) * 3 + c] = gj[c];
+        }
+        const float s_jl = wsum64(jl), s_js = wsum64(js), s_ja = wsum64(ja);
+        if (lane == 0) {
+            red[0][wave] = s_jl;
+            red[1][wave] = s_js;
+            red[2][wave] = s_ja;
+        }
+        __syncthreads();
+        // pose gradients w.r.t. (R_f, t_f): thread (f, e), e < 12
+        if (threadIdx.x < 12 * F) {
+            const int f = threadIdx.x / 12, e = threadIdx.x % 12;
+            const int col = 1 + e;   // pair_out column of element e of (gR | gt)
+            float g = (w.verts / (float)F) * pair_out[f][col];
+            if ((first && f == 0) || (last && f == F - 1)) g += w.smooth * pair_out[f][col];
+            const float csv = F > 1 ? w.smooth / (float)(F - 1) : 0.f;
+            if (f > 0) g += csv * pair_out[F + f - 1][col];          // pair (f - 1, f): this frame is the `a` side
+            if (f + 1 < F) g -= csv * pair_out[F + f][col];          // pair (f, f + 1): the `b` side
+            if (e < 9)
+                gR[9 * f + e] = g;
+            else
+                gt[3 * f + e - 9] = g;
+        }
+        if (threadIdx.x == 0) {
+            const float joint = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)(NJ * F);
+            float verts_l = 0.f, sm_v = 0.f;
+            for (int f = 0; f < F; ++f) verts_l += pair_out[f][0];
+            verts_l /= (float)F;
+            for (int q = 0; q + 1 < F; ++q) sm_v += pair_out[F + q][0];
+            float smooth = F > 1 ? ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)(NJ * (F - 1)) + sm_v / (float)(F - 1) : 0.f;
+            if (first) smooth += ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) / (float)NJ + pair_out[0][0];
+            if (last) smooth += ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) / (float)NJ + pair_out[F - 1][0];
+            pose3[0] = joint;
+            pose3[1] = verts_l;
+            pose3[2] = smooth;
+        }
+        __syncthreads();
+    }
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) is_last = atomicAdd(counter, 1u) == gridDim.x - 1;
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    {
+    {   // the six sums over the blocks' slots, in a fixed order
         float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const volatile float* ps = reinterpret_cast<const volatile float*>(partials);
         for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) {
@@ -303,120 +424,11 @@ __global__ __launch_bounds__(256) void k_window_loss(const float* __restrict__ c
         if (threadIdx.x == 0) *counter = 0u;
         __syncthreads();
     }
-    const float colour = red[0][0], mask = red[1][0];
-    const float contact = red[2][0] / (red[3][0] + 1e-9f), penet = red[4][0] / (red[5][0] + 1e-9f);
-    __syncthreads();
-    // ---- vertex pairs: p < F: (R_p, t_p) against the prediction; p >= F: (R_{q+1}, t_{q+1}) against (R_q, t_q), q = p - F.
-    //      pair_out[p] = {mean |e|, mean u v^T (9), mean u (3)} (k_verts_loss)
-    const int n_pairs = 2 * F - 1;
-    for (int p = 0; p < n_pairs; ++p) {
-        const float *Ra, *ta, *Rb, *tb;
-        if (p < F) {
-            Ra = R + 9 * p; ta = t + 3 * p; Rb = Rp + 9 * p; tb = tp + 3 * p;
-        } else {
-            const int q = p - F;
-            Ra = R + 9 * (q + 1); ta = t + 3 * (q + 1); Rb = R + 9 * q; tb = t + 3 * q;
-        }
-        float D[9], dd[3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) D[k] = Ra[k] - Rb[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dd[k] = ta[k] - tb[k];
-        float a13[13];
-#pragma unroll
-        for (int k = 0; k < 13; ++k) a13[k] = 0.f;
-        for (int q = threadIdx.x; q < n_verts; q += blockDim.x) {
-            const float x = verts[3 * q], y = verts[3 * q + 1], z = verts[3 * q + 2];
-            const float e0 = D[0] * x + D[1] * y + D[2] * z + dd[0], e1 = D[3] * x + D[4] * y + D[5] * z + dd[1], e2 = D[6] * x + D[7] * y + D[8] * z + dd[2];
-            const float nn = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
-            const float inv = nn > 0.f ? 1.f / nn : 0.f;
-            const float u0 = e0 * inv, u1 = e1 * inv, u2 = e2 * inv;
-            a13[0] += nn;
-            a13[1] += u0 * x; a13[2] += u0 * y; a13[3] += u0 * z;
-            a13[4] += u1 * x; a13[5] += u1 * y; a13[6] += u1 * z;
-            a13[7] += u2 * x; a13[8] += u2 * y; a13[9] += u2 * z;
-            a13[10] += u0; a13[11] += u1; a13[12] += u2;
-        }
-#pragma unroll
-        for (int k = 0; k < 13; ++k) {
-            const float s = wsum64(a13[k]);
-            if (lane == 0) red[k][wave] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x < 13) pair_out[p][threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) / (float)n_verts;
-        __syncthreads();
-    }
-    // ---- joints: thread (f, k) for f < F, k < 21 (F <= 8: 168 threads); sums over the first three waves
-    const int NJ = 21;
-    const bool first = (anchor & 1) != 0, last = !first && (anchor & 2) != 0;
-    float jl = 0.f, js = 0.f, ja = 0.f;   // this thread's |j - jp|, |j_{f+1} - j_f|, anchor term
-    float gj[3] = {0.f, 0.f, 0.f};
-    const int tf = threadIdx.x / NJ, tk = threadIdx.x % NJ;
-    const float cj = w.joint / (float)(NJ * F), cs = F > 1 ? w.smooth / (float)(NJ * (F - 1)) : 0.f, ca = w.smooth / (float)NJ;
-    if (threadIdx.x < NJ * F) {
-        const float* a = joint_3d + (size_t)(tf * NJ + tk) * 3;
-        const float* b = joint_pred + (size_t)(tf * NJ + tk) * 3;
-        auto unit = [](const float* x, const float* y, float (&u)[3]) {
-            const float e0 = x[0] - y[0], e1 = x[1] - y[1], e2 = x[2] - y[2];
-            const float n = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
-            const float inv = n > 0.f ? 1.f / n : 0.f;   // torch.norm's subgradient at 0 is 0
-            u[0] = e0 * inv;
-            u[1] = e1 * inv;
-            u[2] = e2 * inv;
-            return n;
-        };
-        float u[3];
-        jl = unit(a, b, u);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gj[c] += cj * u[c];
-        if ((first && tf == 0) || (last && tf == F - 1)) {
-            ja = jl;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gj[c] += ca * u[c];
-        }
-        if (tf + 1 < F) {   // |j_{f+1} - j_f|: this thread owns the pair's value; -gradient to j_f
-            js = unit(a + NJ * 3, a, u);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gj[c] -= cs * u[c];
-        }
-        if (tf > 0) {       // +gradient of the pair (f - 1, f) to j_f
-            unit(a, a - NJ * 3, u);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gj[c] += cs * u[c];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) g_joint[(size_t)(tf * NJ + tk) * 3 + c] = gj[c];
-    }
-    const float s_jl = wsum64(jl), s_js = wsum64(js), s_ja = wsum64(ja);
-    if (lane == 0) {
-        red[0][wave] = s_jl;
-        red[1][wave] = s_js;
-        red[2][wave] = s_ja;
-    }
-    __syncthreads();
-    // ---- pose gradients w.r.t. (R_f, t_f): thread (f, e), e < 12
-    if (threadIdx.x < 12 * F) {
-        const int f = threadIdx.x / 12, e = threadIdx.x % 12;
-        const int col = 1 + e;   // pair_out column of element e of (gR | gt)
-        float g = (w.verts / (float)F) * pair_out[f][col];
-        if ((first && f == 0) || (last && f == F - 1)) g += w.smooth * pair_out[f][col];
-        const float csv = F > 1 ? w.smooth / (float)(F - 1) : 0.f;
-        if (f > 0) g += csv * pair_out[F + f - 1][col];          // pair (f - 1, f): this frame is the `a` side
-        if (f + 1 < F) g -= csv * pair_out[F + f][col];          // pair (f, f + 1): the `b` side
-        if (e < 9)
-            gR[9 * f + e] = g;
-        else
-            gt[3 * f + e - 9] = g;
-    }
     if (threadIdx.x == 0) {
-        const float joint = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)(NJ * F);
-        float verts_l = 0.f, sm_v = 0.f;
-        for (int f = 0; f < F; ++f) verts_l += pair_out[f][0];
-        verts_l /= (float)F;
-        for (int q = 0; q + 1 < F; ++q) sm_v += pair_out[F + q][0];
-        float smooth = F > 1 ? ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)(NJ * (F - 1)) + sm_v / (float)(F - 1) : 0.f;
-        if (first) smooth += ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) / (float)NJ + pair_out[0][0];
-        if (last) smooth += ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) / (float)NJ + pair_out[F - 1][0];
+        const float colour = red[0][0], mask = red[1][0];
+        const float contact = red[2][0] / (red[3][0] + 1e-9f), penet = red[4][0] / (red[5][0] + 1e-9f);
+        const volatile float* pz = reinterpret_cast<const volatile float*>(pose3);
+        const float joint = pz[0], verts_l = pz[1], smooth = pz[2];
         const float st = stable != nullptr ? stable[0] : 0.f;
         terms10[0] = w.render * (colour + 0.5f * mask) + (w.contact * contact + w.penet * penet) + (w.joint * joint + w.verts * verts_l) + w.smooth * smooth +
                      w.stable * st;
@@ -532,7 +544,7 @@ int window_loss(const float* color, const float* wsum, const float* true_rgb, co
     WindowW w{w7[0], w7[1], w7[2], w7[3], w7[4], w7[5], w7[6]};
     hipLaunchKernelGGL(k_window_loss, dim3((n + 255) / 256), dim3(256), 0, s, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o, ns, joint_3d, joint_pred,
                        n_frames, R, t, Rp, tp, verts, n_verts, stable, anchor, w, reinterpret_cast<float*>(scratch) + 16, reinterpret_cast<unsigned*>(scratch),
-                       sums6, terms10, g_joint, gR, gt);
+                       reinterpret_cast<float*>(scratch) + 4, sums6, terms10, g_joint, gR, gt);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
