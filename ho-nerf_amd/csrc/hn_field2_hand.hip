@@ -32,6 +32,9 @@
 #ifndef HN_EXP_ACC
 #define HN_EXP_ACC 4
 #endif
+#ifndef HN_DEFER_STASH
+#define HN_DEFER_STASH 0   // 1: the fp32 activation tiles of the hidden layers go to the stash one chunk late (to_regs_hold): measured, no gain
+#endif
 
 namespace hn {
 namespace v2 {
@@ -535,6 +538,29 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
                 return NoData{};
             };
         };
+        // The same with the fp32 tile handed to run_layer's deferred `store` instead of being stored here: the store of tile t is
+        // then issued right BEHIND the next chunk's barrier, a whole chunk ahead of the barrier after it (-DHN_DEFER_STASH=1).
+        // Round-4 A/B on the C2 frame: with the a1..a7 stores REMOVED (wrong gradients, -DHN_STASH_HALF=2) the kernel
+        // runs 250.5 -> 226.5 ms -- in the SAME number of cycles (in-kernel stamps) at a higher clock, 1932 -> 2052 MHz: the stores
+        // cost power, not issue slots or waits; issued one chunk late (this form): no change; as half as many bytes (fp16,
+        // -DHN_STASH_HALF=1, not parity-preserving): no change either.
+        auto to_regs_hold = [&](h8(&oh)[16], h8(&ol)[16]) {
+            return [&oh, &ol, &park](auto T, EpiState& st, const auto&) {
+                constexpr int t = decltype(T)::value;
+                asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                oh[2 * t] = st.hi[0];
+                ol[2 * t] = st.lo[0];
+                oh[2 * t + 1] = st.hi[1];
+                ol[2 * t + 1] = st.lo[1];
+                park(oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
+                return Act{st.vec()};
+            };
+        };
+        auto store_tile = [&](int stash_slot) {
+            return [stash_slot, &sh](auto T, const Act& held) {
+                if (FULL) sh.tile_store(stash_slot, decltype(T)::value, held.v);
+            };
+        };
         auto to_regs_keep = [&](h8(&oh)[16], h8(&ol)[16], int stash_slot) {
             return [&oh, &ol, stash_slot, &sh, &park](auto T, EpiState& st, const auto&) {
                 constexpr int t = decltype(T)::value;
@@ -544,7 +570,17 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
                 oh[2 * t + 1] = st.hi[1];
                 ol[2 * t + 1] = st.lo[1];
                 park(oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
+#if defined(HN_STASH_HALF) && HN_STASH_HALF
+                if (FULL) {   // (measurement builds: 1 = half-width values, see Stash::tile_store_half; 2 = no store at all: wrong gradients,
+                              //  the issue-slot cost of the stores alone)
+                    if constexpr (MODE == 1) {
+                        if (HN_STASH_HALF == 1) sh.tile_store_half(stash_slot, t, st.vec());
+                    } else
+                        sh.tile_store(stash_slot, t, st.vec());
+                }
+#else
                 if (FULL) sh.tile_store(stash_slot, t, st.vec());
+#endif
                 return NoData{};
             };
         };
@@ -703,12 +739,24 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
             feature_pass(I2{}, BTrue{}, c1, c2, std::integral_constant<int, HB_LEFT_T>{}, std::integral_constant<int, HB_HID>{}, IPF{});
             block_epilogue(I8t{}, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 0));
         }
+#if HN_DEFER_STASH
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_hold(bh, bl), store_tile(HS_A1 + 1));   // lin1
+#else
         run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 1), no_store);   // lin1
+#endif
+#if HN_DEFER_STASH
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_hold(ah, al), store_tile(HS_A1 + 2));   // lin2
+#else
         run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 2), no_store);   // lin2
+#endif
         // lin3 -> a4, in bh / bl like every layer's output: lin4's hidden part reads them from there.  (They used to go
         // through the stash -- 32 KB written and read back at once per tile, an HBM round trip of ~10 000 cycles in front
         // of lin4 in the in-kernel stamps.)
+#if HN_DEFER_STASH
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_hold(bh, bl), store_tile(HS_A1 + 3));   // lin3
+#else
         run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 3), no_store);   // lin3
+#endif
         if ((HN_DBG(a) >> 8) == 3) return;   // phase timing aid
         // ---- lin4 = [a4 | features] / sqrt2 -> a5: 8 hidden tiles (bias from the tail), then the feature pass
         {
@@ -725,8 +773,16 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
             feature_pass(I2{}, BFalse{}, c1, c2, std::integral_constant<int, HB_LEFT>{}, std::integral_constant<int, HB_HID>{}, IPF{});
             block_epilogue(I8t{}, c1, c2, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 4));
         }
+#if HN_DEFER_STASH
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_hold(bh, bl), store_tile(HS_A1 + 5));   // lin5
+#else
         run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, ah, al, lane, h, no_pre, PhSoftplus{}, to_regs_keep(bh, bl, HS_A1 + 5), no_store);   // lin5
+#endif
+#if HN_DEFER_STASH
+        run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_hold(ah, al), store_tile(HS_A1 + 6));   // lin6
+#else
         run_layer_c<8, 16, 1, true, true, HB_HID, HB_HID, PH>(ws, bh, bl, lane, h, no_pre, PhSoftplus{}, to_regs_keep(ah, al, HS_A1 + 6), no_store);   // lin6
+#endif
         // ---- lin7 -> a8; sdf = W8[0,:] a8 + b8; seed of the reverse sweep dz7 = sigma'(z7) W8[0,:] (scaled)
         float sdf_acc = 0.f, sdf_acc1 = 0.f;   // (16x16x32: the lane's registers of column block 0 / 1 are two samples)
         auto lin7 = [&](auto NA_) {   // NA_: the size of the chunk that follows the layer, a constant
@@ -803,7 +859,16 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
         if ((HN_DBG(a) >> 8) == 6) return;   // phase timing aid
         // ---- reverse sweep: dz_{l-1} = sigma'(z_{l-1}) * (W_l^T dz_l); sigma' from the stashed activation a_l
         auto act_of = [&](int act_slot) {
+#if defined(HN_STASH_HALF) && HN_STASH_HALF
+            return [&sh, act_slot](auto T, const char*) {
+                if constexpr (MODE == 1)
+                    return Act{sh.tile_load_half(act_slot, decltype(T)::value)};
+                else
+                    return Act{sh.tile_load(act_slot, decltype(T)::value)};
+            };
+#else
             return [&sh, act_slot](auto T, const char*) { return Act{sh.tile_load(act_slot, decltype(T)::value)}; };
+#endif
         };
 #pragma unroll
         for (int s = 0; s < 16; ++s) sh.frag_load(HS_DZ7 * SLOT_BYTES, s, ah[s], al[s]);

@@ -1053,6 +1053,13 @@ constexpr int SLOT_BYTES = 32768;
 #define HN_STASH_AUX 2
 #endif
 constexpr int STASH_AUX = HN_STASH_AUX;
+// The stash STORES use the default (write-back) policy, the loads stay nt: round-4 A/B on the C2 frame, same box, two runs each --
+// stores nt 248.6 / 249.8 ms, default 242.3 / 244.5, sc0 244.3 / 243.4, sc1 + nt 251.7 / 251.9.  (Both on the default policy was
+// 9 % slower in round 2: it is the LOADS' allocation that evicts the weight stream from L2.)
+#ifndef HN_STASH_ST_AUX
+#define HN_STASH_ST_AUX 0
+#endif
+constexpr int STASH_ST_AUX = HN_STASH_ST_AUX;
 struct Stash {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff;   // lane * 16
@@ -1075,7 +1082,7 @@ struct Stash {
     template <typename T16>
     __device__ __forceinline__ void st16_at(const T16& v, int vo) const {
         static_assert(sizeof(T16) == 16, "16-byte values only");
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, vo, 0, STASH_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, vo, 0, STASH_ST_AUX);
     }
     template <typename T16>
     __device__ __forceinline__ void st16(const T16& v, int off) const {
@@ -1104,6 +1111,32 @@ struct Stash {
         const f32x8 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
         const f32x8 cd = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    }
+    // MEASUREMENT BUILD ONLY (-DHN_STASH_HALF=1; not parity-preserving): the same tile as 16 fp16 values, two 16-byte accesses instead
+    // of four -- what halving the a1..a7 stash traffic of the evaluation kernel would be worth
+    __device__ __forceinline__ void tile_store_half(int slot, int t, const f32x16& y) const {
+        const int vo = fresh_voff() + (slot * SLOT_BYTES + t * 4096);
+        h8 a, b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a[i] = (_Float16)y[i];
+            b[i] = (_Float16)y[8 + i];
+        }
+        st16_at(a, vo);
+        st16_at(b, vo + 1024);
+    }
+    __device__ __forceinline__ f32x16 tile_load_half(int slot, int t) const {
+        const int off = slot * SLOT_BYTES + t * 4096;
+        const int vo = lane_x16();
+        const h8 a = __builtin_bit_cast(h8, ld16_at(vo, off));
+        const h8 b = __builtin_bit_cast(h8, ld16_at(vo, off + 1024));
+        f32x16 y;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            y[i] = (float)a[i];
+            y[8 + i] = (float)b[i];
+        }
+        return y;
     }
     // fragment block s (byte offset `base` + s * 2 KiB): [hi | lo][lane] 16 B
     __device__ __forceinline__ void frag_store(int base, int s, const h8& hi, const h8& lo) const {
