@@ -385,7 +385,7 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31;
     const int h = lane >> 5;
-    Stash sh;
+    StashT<(MODE <= 1) ? STASH_ST_AUX : STASH_AUX> sh;   // (evaluation kernels: write-back stores; taped / adjoint kernels: nt -- hn_mlp2.h)
     sh.init(a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * N_SLOTS * SLOT_F4, N_SLOTS, lane);
     constexpr int FEAT = HS_FEAT * SLOT_BYTES;   // byte offset of the feature fragment blocks
     constexpr int LEFT = HS_LEFT * SLOT_BYTES;   // ... of the leftover values

@@ -1053,14 +1053,18 @@ constexpr int SLOT_BYTES = 32768;
 #define HN_STASH_AUX 2
 #endif
 constexpr int STASH_AUX = HN_STASH_AUX;
-// The stash STORES use the default (write-back) policy, the loads stay nt: round-4 A/B on the C2 frame, same box, two runs each --
-// stores nt 248.6 / 249.8 ms, default 242.3 / 244.5, sc0 244.3 / 243.4, sc1 + nt 251.7 / 251.9.  (Both on the default policy was
-// 9 % slower in round 2: it is the LOADS' allocation that evicts the weight stream from L2.)
+// The stash STORES of the per-workgroup stash (evaluation kernels: written and read back within a tile) use the default
+// (write-back) policy, the loads stay nt: round-4 A/B on the C2 frame, same box, two runs each -- stores nt 248.6 / 249.8 ms,
+// default 242.3 / 244.5, sc0 244.3 / 243.4, sc1 + nt 251.7 / 251.9.  (Both on the default policy was 9 % slower in round 2: it
+// is the LOADS' allocation that evicts the weight stream from L2.)  The per-TILE stash of the taped kernels (a fitting step's
+// 2.6 GB tape, read back a millisecond later by another launch) stays nt: written back through L2 the fitting step was 8 - 10 %
+// slower (2.64 -> 2.91 ms).  ST_AUX: the stores' policy, per kernel.
 #ifndef HN_STASH_ST_AUX
 #define HN_STASH_ST_AUX 0
 #endif
 constexpr int STASH_ST_AUX = HN_STASH_ST_AUX;
-struct Stash {
+template <int ST_AUX>
+struct StashT {
     __amdgpu_buffer_rsrc_t rsrc;
     int voff;   // lane * 16
 
@@ -1082,7 +1086,7 @@ struct Stash {
     template <typename T16>
     __device__ __forceinline__ void st16_at(const T16& v, int vo) const {
         static_assert(sizeof(T16) == 16, "16-byte values only");
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, vo, 0, STASH_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, vo, 0, ST_AUX);
     }
     template <typename T16>
     __device__ __forceinline__ void st16(const T16& v, int off) const {
@@ -1159,6 +1163,7 @@ struct Stash {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_x16() >> 2, off, 0));
     }
 };
+using Stash = StashT<STASH_AUX>;   // (the taped kernels and every kernel that did not ask for another policy)
 
 // ---- XCD pacing ------------------------------------------------------------------------------------------------
 // The weight stream of a tile program (5.4 MB object, 12.4 MB hand) is larger than an XCD's 4 MB of L2: it is served from
