@@ -30,7 +30,9 @@ int coarse_z(const float*, int, int, float, float, float, float*, hipStream_t);
 int sample_points(const float*, const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
 int sample_points_bwd(const float*, const float*, int, int, int, float, float*, float*, hipStream_t);
 int upsample(const float*, const float*, int, int, int, float, float*, int64_t*, hipStream_t);
-bool upsample_fused(const float*, const float*, int, int, int, float, float*, float*, int, int, const float*, const float*, float*, hipStream_t);
+bool upsample_fused(const float*, const float*, int, int, int, float, float*, float*, int, int, const float*, const float*, float*, hipStream_t,
+                    const UpsPre* pre = nullptr);
+bool upsample_fused_ok(int n_rays, int k, int n_new);
 int merge(const float*, const float*, const float*, const float*, int, int, int, int, float*, float*, int64_t*,
           hipStream_t);
 int sort_rows(const float*, int, int, float*, hipStream_t);
@@ -617,7 +619,7 @@ static int field_eval(const hn_field* f, const float* pts, const float* rays_d, 
 // {up_sample, cat_z_vals}.  On return z_cur [n_rays, n_samples + n_importance] is sorted.
 // new_z_all (optional) collects every step's new depths, [n_rays, cat_stride] at column cat_off + 2*i*n_new
 struct Track {
-    float *z_a, *z_b, *sdf_a, *sdf_b, *z_new, *sdf_new, *pts;
+    float *z_a, *z_b, *sdf_a, *sdf_b, *z_new, *z_new2, *sdf_new, *pts;
 };
 static void track_alloc(Arena& ar, Track& t, size_t n_rays, int S, int n_new) {
     t.z_a = ar.f(n_rays * S);
@@ -625,6 +627,7 @@ static void track_alloc(Arena& ar, Track& t, size_t n_rays, int S, int n_new) {
     t.sdf_a = ar.f(n_rays * S);
     t.sdf_b = ar.f(n_rays * S);
     t.z_new = ar.f(n_rays * n_new);
+    t.z_new2 = ar.f(n_rays * n_new);
     t.sdf_new = ar.f(n_rays * n_new);
     t.pts = ar.f(n_rays * S * 3);
 }
@@ -847,6 +850,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
             return field_sdf(obj, to.pts, nc, bt_inv, T_pose, 1, nc, to.sdf_a, fwso, fws_o, so);
         };
         HN_TRY(sample_points(rays_o, rays_d, th.z_a, n_rays, n_samples, 0, 0.f, th.pts, nullptr, s));
+        UpsPre coarse_gather{};
         if (coarse_compact) {
             // the hand's coarse pass on the samples with a live bone (the record of the final evaluation is written later)
             CompactRec cr;
@@ -860,12 +864,20 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
             set_launch_orig_idx(nullptr);
             HN_TRY(rc);
             HN_TRY(obj_coarse());
-            hipLaunchKernelGGL(k_hand_scatter_sdf, dim3((nc + 255) / 256), dim3(256), 0, s, cr.pos, nc, cr.n_dev, cr.sdf_c, th.sdf_a);
-            HN_LAUNCH_CHECK();
+            if (steps >= 1 && upsample_fused_ok(n_rays, n_samples, n_new)) {
+                coarse_gather = UpsPre{nullptr, nullptr, 0, 0, nullptr, th.sdf_a, cr.pos, cr.n_dev, cr.sdf_c};   // the first up_sample launch reads through the record
+            } else {
+                hipLaunchKernelGGL(k_hand_scatter_sdf, dim3((nc + 255) / 256), dim3(256), 0, s, cr.pos, nc, cr.n_dev, cr.sdf_c, th.sdf_a);
+                HN_LAUNCH_CHECK();
+            }
         } else {
             HN_TRY(obj_coarse());
             HN_TRY(field_sdf(hand, th.pts, nc, bt_inv, T_pose, n_frames, rpf * n_samples, th.sdf_a, fwsh, fws_h, s));
         }
+        // A round is up_sample -> sdf of the new depths -> cat_z_vals; in the wave form of up_sample (the fitting loops' batch sizes)
+        // a round's cat_z_vals runs at the head of the NEXT round's up_sample launch (UpsPre: `pending`), and the hand's coarse sdf row is
+        // read through the compaction record by the first one: one launch per round and track beside the field's instead of two / three.
+        bool pending[2] = {false, false};
         for (int i = 0; i < steps; ++i) {
             for (TrackRun& r : runs) {
                 Track& t = *r.t;
@@ -873,18 +885,40 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
                 // positions: one launch for the fitting loops' batch sizes, three otherwise
                 const int col = n_samples + (2 * i + r.which) * n_new;
                 const bool more = i + 1 < steps;
-                if (!upsample_fused(t.z_a, t.sdf_a, n_rays, r.k, n_new, (float)(64 << i), t.z_new, zcat, S, col, r.ro, r.rd, more ? t.pts : nullptr, r.st)) {
+                UpsPre pre{};
+                const UpsPre* pp = nullptr;
+                float* z_out = t.z_new;
+                if (pending[r.which]) {
+                    // (r.k counts the merged row already; the new depths of this round go to the other small buffer)
+                    pre = UpsPre{t.z_new, t.sdf_new, n_new, quirk, t.z_b, t.sdf_b, nullptr, nullptr, nullptr};
+                    pp = &pre;
+                    z_out = t.z_new2;
+                } else if (i == 0 && r.which == 0 && coarse_gather.pos != nullptr) {
+                    pp = &coarse_gather;
+                }
+                if (!upsample_fused(t.z_a, t.sdf_a, n_rays, r.k, n_new, (float)(64 << i), z_out, zcat, S, col, r.ro, r.rd, more ? t.pts : nullptr, r.st, pp)) {
+                    HN_REQUIRE(pp == nullptr, "render_dual: the fused up_sample launch failed");
                     HN_TRY(upsample(t.z_a, t.sdf_a, n_rays, r.k, n_new, (float)(64 << i), t.z_new, nullptr, r.st));
                     hipLaunchKernelGGL(k_copy_cols, dim3((n_rays * n_new + 255) / 256), dim3(256), 0, r.st, t.z_new, n_rays, n_new, zcat, S, col);
                     HN_LAUNCH_CHECK();
                     if (more) HN_TRY(sample_points(r.ro, r.rd, t.z_new, n_rays, n_new, 0, 0.f, t.pts, nullptr, r.st));
                 }
+                if (pending[r.which]) {
+                    float* tmp = t.z_a; t.z_a = t.z_b; t.z_b = tmp;
+                    tmp = t.sdf_a; t.sdf_a = t.sdf_b; t.sdf_b = tmp;
+                    tmp = t.z_new; t.z_new = t.z_new2; t.z_new2 = tmp;
+                    pending[r.which] = false;
+                }
                 if (i + 1 < steps) {
                     HN_TRY(field_sdf(r.f, t.pts, n_rays * n_new, bt_inv, T_pose, r.nf, r.which == 0 ? rpf * n_new : n_rays * n_new, t.sdf_new,
                                      r.fws, r.fwb, r.st));
-                    HN_TRY(merge(t.z_a, t.z_new, t.sdf_a, t.sdf_new, n_rays, r.k, n_new, quirk, t.z_b, t.sdf_b, nullptr, r.st));
-                    float* tmp = t.z_a; t.z_a = t.z_b; t.z_b = tmp;
-                    tmp = t.sdf_a; t.sdf_a = t.sdf_b; t.sdf_b = tmp;
+                    if (upsample_fused_ok(n_rays, r.k + n_new, n_new)) {
+                        pending[r.which] = true;
+                    } else {
+                        HN_TRY(merge(t.z_a, t.z_new, t.sdf_a, t.sdf_new, n_rays, r.k, n_new, quirk, t.z_b, t.sdf_b, nullptr, r.st));
+                        float* tmp = t.z_a; t.z_a = t.z_b; t.z_b = tmp;
+                        tmp = t.sdf_a; t.sdf_a = t.sdf_b; t.sdf_b = tmp;
+                    }
                 }
                 r.k += n_new;
             }
@@ -986,7 +1020,7 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     float *pts_h = ar.f(N * 3), *dists_h = ar.f(N), *pts_o = ar.f(N * 3), *dists_o = ar.f(N);
     float *gs_h = ar.f(N), *gg_h = ar.f(N * 3), *gd_h = ar.f(R3), *gs_o = ar.f(N), *gg_o = ar.f(N * 3), *gd_o = ar.f(R3);
     float *gp_h = ar.f(N * 3), *gp_o = ar.f(N * 3), *gdir_h = ar.f(R3), *gdir_o = ar.f(R3);
-    float *go_h = ar.f(R3), *gdd_h = ar.f(R3), *go_l = ar.f(R3), *gdd_l = ar.f(R3), *gd_l = ar.f(R3), *g_ro2 = ar.f(R3), *g_rd2 = ar.f(R3);
+    float *go_h = ar.f(R3), *gdd_h = ar.f(R3), *g_ro2 = ar.f(R3), *g_rd2 = ar.f(R3);
     const size_t bws_h = bwd::field_bwd_workspace_bytes(hand, hand_cap(hand, N)), bws_o = bwd::field_bwd_workspace_bytes(obj, (int)N);
     void* bwh = ar.take(bws_h);
     void* bwo = ar.take(bws_o);
@@ -1245,6 +1279,12 @@ int hn_rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pr
 int hn_verts_loss(const float* Ra, const float* ta, const float* Rb, const float* tb, const float* verts, int n_verts, int n_pairs, float* loss,
                   float* gR, float* gt, hn_stream_t stream) {
     return hn::verts_loss(Ra, ta, Rb, tb, verts, n_verts, n_pairs, loss, gR, gt, (hipStream_t)stream);
+}
+int hn_leaf_rows_gather(const float* const* leaves6, const long long* rows, int n_rows, float* prm_hand, float* prm_obj, hn_stream_t stream) {
+    return hn::leaf_rows_gather(leaves6, rows, n_rows, prm_hand, prm_obj, (hipStream_t)stream);
+}
+int hn_leaf_rows_scatter(const float* g, const long long* rows, int n_rows, int n_frames, float* out, hn_stream_t stream) {
+    return hn::leaf_rows_scatter(g, rows, n_rows, n_frames, out, (hipStream_t)stream);
 }
 int hn_pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt_inv, const float* g_joint_3d, const float* g_obj_r, const float* g_obj_t,
                      const float* g_obj_r2, const float* g_obj_t2, int n_frames, int which, float* out, hn_stream_t stream) {

@@ -58,6 +58,18 @@ int rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pred,
 int verts_loss(const float* Ra, const float* ta, const float* Rb, const float* tb, const float* verts, int n_verts, int n_pairs, float* loss, float* gR,
                float* gt, hipStream_t s);
 int jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, int n_in, float* out, hipStream_t s);
+// what the wave form of up_sample can do in front of the round itself (hn_sampling.hip, UpsExtra): the previous round's cat_z_vals
+// (m_prev > 0: merge zp / sp [n_rays, m_prev] into the old rows, merged rows -> z_out / sdf_out) or the gather of the hand's coarse
+// sdf row through a compaction record (pos, n_dev, sdf_c; dense row -> sdf_out)
+struct UpsPre {
+    const float *zp, *sp;
+    int m_prev, quirk_p;
+    float *z_out, *sdf_out;
+    const int *pos, *n_dev;
+    const float* sdf_c;
+};
+int leaf_rows_gather(const float* const* leaves6, const long long* rows, int F, float* prm_h, float* prm_o, hipStream_t s);
+int leaf_rows_scatter(const float* g, const long long* rows, int F, int n, float* out, hipStream_t s);
 int pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt, const float* g_j3, const float* g_or, const float* g_ot, const float* g_or2,
                   const float* g_ot2, int n_frames, int which, float* out, hipStream_t s);
 

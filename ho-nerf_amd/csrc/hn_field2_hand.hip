@@ -544,7 +544,7 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
         // runs 250.5 -> 226.5 ms -- in the SAME number of cycles (in-kernel stamps) at a higher clock, 1932 -> 2052 MHz: the stores
         // cost power, not issue slots or waits; issued one chunk late (this form): no change; as half as many bytes (fp16,
         // -DHN_STASH_HALF=1, not parity-preserving): no change either.
-        auto to_regs_hold = [&](h8(&oh)[16], h8(&ol)[16]) {
+        [[maybe_unused]] auto to_regs_hold = [&](h8(&oh)[16], h8(&ol)[16]) {
             return [&oh, &ol, &park](auto T, EpiState& st, const auto&) {
                 constexpr int t = decltype(T)::value;
                 asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
@@ -556,7 +556,7 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
                 return Act{st.vec()};
             };
         };
-        auto store_tile = [&](int stash_slot) {
+        [[maybe_unused]] auto store_tile = [&](int stash_slot) {
             return [stash_slot, &sh](auto T, const Act& held) {
                 if (FULL) sh.tile_store(stash_slot, decltype(T)::value, held.v);
             };
@@ -882,6 +882,8 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
                 oh[2 * t + 1] = st.hi[1];
                 ol[2 * t + 1] = st.lo[1];
                 park(oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
+                (void)tile_slot;
+                (void)sh;
                 if constexpr (ADJ) sh.tile_store(tile_slot, t, st.vec());
                 return NoData{};
             };

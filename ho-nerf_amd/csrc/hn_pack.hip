@@ -6,6 +6,7 @@
 // Row maps and column maps describe our own orderings of neurons / input columns; -1 = pad.
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <math.h>
 #include <stdio.h>
@@ -22,20 +23,33 @@ namespace hn {
 // same code, profiles/r02/README.md "training step").  Freed blocks are therefore kept, keyed by (device, size), and
 // handed out again: after the first two packs a re-pack allocates nothing.  The cache only ever holds what fields of
 // this process have released; hn_field_destroy's contract is unchanged (no work that uses the field may be in flight).
+// A pack's own temporaries (the folded matrices) go back while the pack's kernels may still be reading them: those blocks
+// carry a fence (an event recorded on the pack's stream at release time).  Taking such a block on the same stream is
+// ordered by the stream; on another stream the taker's stream waits for the event; a taker that names no stream waits on
+// the host.
 namespace {
 struct PoolKey {
     int dev;
     size_t bytes;
     bool operator<(const PoolKey& o) const { return dev != o.dev ? dev < o.dev : bytes < o.bytes; }
 };
+struct PoolFence {
+    hipEvent_t ev = nullptr;
+    hipStream_t s = nullptr;
+    ~PoolFence() {
+        if (ev != nullptr) (void)hipEventDestroy(ev);
+    }
+};
 std::mutex g_pool_mu;
 std::multimap<PoolKey, void*> g_pool_free;
 std::map<void*, PoolKey> g_pool_live;
-}  // namespace
-hipError_t pool_alloc(void** p, size_t bytes) {
+std::map<void*, std::shared_ptr<PoolFence>> g_pool_fence;   // released blocks whose last reader may still be in flight
+hipError_t pool_take(void** p, size_t bytes, bool ordered, hipStream_t s) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     bytes = (bytes + 255) & ~size_t(255);
+    std::shared_ptr<PoolFence> fence;
+    bool hit = false;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         auto it = g_pool_free.find(PoolKey{dev, bytes});
@@ -43,8 +57,20 @@ hipError_t pool_alloc(void** p, size_t bytes) {
             *p = it->second;
             g_pool_free.erase(it);
             g_pool_live[*p] = PoolKey{dev, bytes};
-            return hipSuccess;
+            auto fi = g_pool_fence.find(*p);
+            if (fi != g_pool_fence.end()) {
+                fence = fi->second;
+                g_pool_fence.erase(fi);
+            }
+            hit = true;
         }
+    }
+    if (hit) {
+        if (fence && fence->ev != nullptr) {
+            if (!ordered) return hipEventSynchronize(fence->ev);
+            if (fence->s != s) return hipStreamWaitEvent(s, fence->ev, 0);
+        }
+        return hipSuccess;
     }
     const hipError_t e = hipMalloc(p, bytes);
     if (e == hipSuccess) {
@@ -53,6 +79,22 @@ hipError_t pool_alloc(void** p, size_t bytes) {
     }
     return e;
 }
+void pool_give(void* p, const std::shared_ptr<PoolFence>& fence) {
+    if (p == nullptr) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_live.find(p);
+    if (it == g_pool_live.end()) {   // not ours: straight to the driver
+        (void)hipFree(p);
+        return;
+    }
+    g_pool_free.insert({it->second, p});
+    g_pool_live.erase(it);
+    if (fence) g_pool_fence[p] = fence;
+}
+}  // namespace
+hipError_t pool_alloc(void** p, size_t bytes) { return pool_take(p, bytes, false, nullptr); }
+// the block's first use is enqueued on `s`
+hipError_t pool_alloc_on(void** p, size_t bytes, hipStream_t s) { return pool_take(p, bytes, true, s); }
 size_t pool_trim() {   // hn_release_cached_memory: every cached (released) block back to the driver
     std::vector<void*> blocks;
     size_t bytes = 0;
@@ -63,20 +105,23 @@ size_t pool_trim() {   // hn_release_cached_memory: every cached (released) bloc
             bytes += kv.first.bytes;
         }
         g_pool_free.clear();
+        g_pool_fence.clear();
     }
-    for (void* p : blocks) (void)hipFree(p);
+    for (void* p : blocks) (void)hipFree(p);   // (hipFree waits for the device: the fences are moot)
     return bytes;
 }
-void pool_free(void* p) {
-    if (p == nullptr) return;
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool_live.find(p);
-    if (it == g_pool_live.end()) {   // not ours: straight to the driver
-        (void)hipFree(p);
-        return;
+void pool_free(void* p) { pool_give(p, nullptr); }
+// release blocks that work already enqueued on `s` may still read
+void pool_free_after(void* const* blocks, size_t n, hipStream_t s) {
+    if (n == 0) return;
+    auto fence = std::make_shared<PoolFence>();
+    fence->s = s;
+    if (hipEventCreateWithFlags(&fence->ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(fence->ev, s) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(s);   // no event to be had: wait here, release unfenced
+        fence.reset();
     }
-    g_pool_free.insert({it->second, p});
-    g_pool_live.erase(it);
+    for (size_t i = 0; i < n; ++i) pool_give(blocks[i], fence);
 }
 
 // the per-layer launches of a pack batched into one each (blockIdx.y = layer): a re-pack is a chain of dependent launches
@@ -280,8 +325,8 @@ struct Packer {
                            (int)map.size(), dst);
         return dst;
     }
-    void free_temps() {
-        for (void* p : temps) pool_free(p);
+    void free_temps() {   // the pack's kernels on `stream` may still be reading them: released behind a fence
+        pool_free_after(temps.data(), temps.size(), stream);
         temps.clear();
     }
 };
@@ -448,7 +493,7 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
         auto pitch = [](int in) { return (in + 3) & ~3; };   // rows start 16-byte aligned: vector loads in k_dense
         for (int l = 0; l < 9; ++l) total += pad((size_t)sdf->out_dim[l] * pitch(sdf->in_dim[l])) + pad(sdf->out_dim[l]);
         for (int l = 0; l < 5; ++l) total += pad((size_t)col->out_dim[l] * pitch(col->in_dim[l])) + pad(col->out_dim[l]);
-        if (pool_alloc(&f->raw, total * sizeof(float)) != hipSuccess) {
+        if (pool_alloc_on(&f->raw, total * sizeof(float), stream) != hipSuccess) {
             set_error("hipMalloc of %zu bytes for the folded weights failed", total * sizeof(float));
             rc = HN_ENOMEM;
         } else {
@@ -463,7 +508,7 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
                 const int l = is_sdf ? li : li - 9;
                 const int out = d->out_dim[l], in = d->in_dim[l], ld = pitch(in);
                 float** dst = is_sdf ? &w_sdf[l] : &w_col[l];
-                if (pool_alloc(reinterpret_cast<void**>(dst), (size_t)out * in * sizeof(float)) != hipSuccess) {
+                if (pool_alloc_on(reinterpret_cast<void**>(dst), (size_t)out * in * sizeof(float), stream) != hipSuccess) {
                     set_error("hipMalloc of a folded matrix failed");
                     rc = HN_ENOMEM;
                     break;
@@ -518,7 +563,7 @@ int field_create(int kind, const hn_mlp_desc* sdf, const hn_mlp_desc* col, float
         pk.used = 0;
         build(f, pk, sdf, col, w_sdf, w_col, hostb);
         f->blob_bytes = pk.used;
-        if (pool_alloc(&f->blob, f->blob_bytes) != hipSuccess) {
+        if (pool_alloc_on(&f->blob, f->blob_bytes, stream) != hipSuccess) {
             set_error("hipMalloc of %zu bytes for packed weights failed", f->blob_bytes);
             rc = HN_ENOMEM;
         }

@@ -22,7 +22,7 @@
 #include "hn_mlp2.h"
 
 namespace hn {
-hipError_t pool_alloc(void** p, size_t bytes);   // hn_pack.hip: size-keyed cache in front of hipMalloc / hipFree
+hipError_t pool_alloc_on(void** p, size_t bytes, hipStream_t s);   // hn_pack.hip: size-keyed cache in front of hipMalloc / hipFree
 void pool_free(void* p);
 namespace v2 {
 
@@ -464,11 +464,11 @@ static int upload(const Builder& B, void** dev, size_t* bytes, hipStream_t strea
     memcpy(stage, blob.data(), blob.size());
     memcpy(stage + blob_pad, B.blocks.data(), nbk);
     memcpy(stage + blob_pad + nb_pad, B.maps.data(), nm);
-    HN_CHECK_HIP(pool_alloc(dev, blob.size()));
+    HN_CHECK_HIP(pool_alloc_on(dev, blob.size(), stream));
     HN_CHECK_HIP(hipMemcpyAsync(*dev, stage, blob.size(), hipMemcpyHostToDevice, stream));
     void* tmp = nullptr;
     if (!B.blocks.empty()) {
-        HN_CHECK_HIP(pool_alloc(&tmp, nb_pad + nm));
+        HN_CHECK_HIP(pool_alloc_on(&tmp, nb_pad + nm, stream));
         hipError_t e = hipMemcpyAsync(tmp, stage + blob_pad, nb_pad + nm, hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) {
             const int n_blocks = (int)B.blocks.size();
@@ -527,7 +527,7 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
                 void** dst;
                 size_t* nb;
                 slot_of(mode, &dst, &nb);
-                HN_CHECK_HIP(pool_alloc(dst, P.bytes));
+                HN_CHECK_HIP(pool_alloc_on(dst, P.bytes, stream));
                 HN_CHECK_HIP(hipMemsetAsync(*dst, 0, P.bytes, stream));
                 hipLaunchKernelGGL(k_fill_fragments_plan, dim3((P.n_blocks + 3) / 4), dim3(256), 0, stream, P.blocks, P.n_blocks, P.maps, tab,
                                    reinterpret_cast<char*>(*dst));

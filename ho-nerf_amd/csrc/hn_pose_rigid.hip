@@ -180,6 +180,62 @@ __global__ __launch_bounds__(256) void k_pose_side_vjp(const float* __restrict__
         out[(size_t)f * 45 + k] = (part[0][k] + part[1][k]) + (part[2][k] + part[3][k]);
 }
 
+// ---- the window's rows of the six pose leaves of a fitting_video sequence <-> the chain's input blocks (one launch each way) ------
+// leaves (fitting_video.py:159-176): obj_rot [n,6], obj_trans [n,3], palm_rot [n,6], palm_trans [n,3], joint_refine_angle [n,20],
+// palm_refine_angle [n,7].  gather: prm_h [F,36] = [joint 20 | palm_angle 7 | palm_rot 6 | palm_trans 3] (hn_pose_chain's inputs),
+// prm_o [F,18] = [obj_rot 6 | obj_trans 3 | 0 x 9] (hn_rigid_pose's) of rows[f].  scatter: g [F,45] = [hand 36 | obj 9] -> the rows of
+// six CONTIGUOUS gradient blocks laid out one behind the other in `out` (n x 45 floats, zeroed by the caller): [n,6] [n,3] [n,6] [n,3]
+// [n,20] [n,7].  (As torch operators: a 7-tensor cat, an index_select and two slices forward; a zero fill, an index_copy and six
+// strided copies backward.)
+struct LeafPtrs {
+    const float* p[6];
+};
+__global__ void k_leaf_rows_gather(LeafPtrs L, const long long* __restrict__ rows, int F, float* __restrict__ prm_h, float* __restrict__ prm_o) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F * 54) return;
+    const int f = i / 54, c = i % 54;
+    const long long r = rows[f];
+    float v = 0.f;
+    if (c < 20)
+        v = L.p[4][r * 20 + c];
+    else if (c < 27)
+        v = L.p[5][r * 7 + c - 20];
+    else if (c < 33)
+        v = L.p[2][r * 6 + c - 27];
+    else if (c < 36)
+        v = L.p[3][r * 3 + c - 33];
+    else if (c < 42)
+        v = L.p[0][r * 6 + c - 36];
+    else if (c < 45)
+        v = L.p[1][r * 3 + c - 42];
+    if (c < 36)
+        prm_h[f * 36 + c] = v;
+    else
+        prm_o[f * 18 + c - 36] = v;
+}
+__global__ void k_leaf_rows_scatter(const float* __restrict__ g, const long long* __restrict__ rows, int F, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F * 45) return;
+    const int f = i / 45, c = i % 45;
+    const long long r = rows[f];
+    const float v = g[i];
+    // block offsets in `out`: obj_rot 0, obj_trans 6 n, palm_rot 9 n, palm_trans 15 n, joint 18 n, palm_angle 38 n
+    size_t o;
+    if (c < 20)
+        o = (size_t)18 * n + r * 20 + c;
+    else if (c < 27)
+        o = (size_t)38 * n + r * 7 + c - 20;
+    else if (c < 33)
+        o = (size_t)9 * n + r * 6 + c - 27;
+    else if (c < 36)
+        o = (size_t)15 * n + r * 3 + c - 33;
+    else if (c < 42)
+        o = r * 6 + c - 36;
+    else
+        o = (size_t)6 * n + r * 3 + c - 42;
+    out[o] = v;
+}
+
 int rigid_pose(const float* bt_inv0, const float* joints0, const float* Ro_pred, const float* To_pred, const float* params, int n_frames, int with_palm,
                float* out, float* jac, hipStream_t s) {
     if (n_frames <= 0) return HN_OK;
@@ -203,6 +259,22 @@ int pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt, con
     HN_REQUIRE(out != nullptr && (which & 3) != 0 && (!(which & 1) || jac_h != nullptr) && (!(which & 2) || jac_o != nullptr),
                "pose_side_vjp: NULL argument");
     hipLaunchKernelGGL(k_pose_side_vjp, dim3(n_frames), dim3(256), 0, s, jac_h, jac_o, g_bt, g_j3, g_or, g_ot, g_or2, g_ot2, n_frames, which, out);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+int leaf_rows_gather(const float* const* leaves6, const long long* rows, int F, float* prm_h, float* prm_o, hipStream_t s) {
+    if (F <= 0) return HN_OK;
+    HN_REQUIRE(leaves6 != nullptr && rows != nullptr && prm_h != nullptr && prm_o != nullptr, "leaf_rows_gather: NULL argument");
+    LeafPtrs L;
+    for (int i = 0; i < 6; ++i) L.p[i] = leaves6[i];
+    hipLaunchKernelGGL(k_leaf_rows_gather, dim3((F * 54 + 255) / 256), dim3(256), 0, s, L, rows, F, prm_h, prm_o);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+int leaf_rows_scatter(const float* g, const long long* rows, int F, int n, float* out, hipStream_t s) {
+    if (F <= 0) return HN_OK;
+    HN_REQUIRE(g != nullptr && rows != nullptr && out != nullptr && n >= 1, "leaf_rows_scatter: NULL argument");
+    hipLaunchKernelGGL(k_leaf_rows_scatter, dim3((F * 45 + 255) / 256), dim3(256), 0, s, g, rows, F, n, out);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

@@ -572,25 +572,104 @@ __global__ __launch_bounds__(64) void k_upsample_tiled(const float* __restrict__
 // UpsExtra (the two-field render's importance rounds, where this launch sat in front of a column copy and a sample-point launch in a
 // chain of dependent launches): the new depths also go to columns col .. col + n_new - 1 of the [n_rays, ld] list `zcat`, and, with
 // `pts`, the new sample positions o + d z (k_sample_points' statement, mid = 0) are written as well.
+// Pre-merge (the same rounds: cat_z_vals of the PREVIOUS round, utils/renderer.py:88-105, sat between that round's sdf launch and
+// this launch): with m_prev > 0 the row is the stable merge of z / sdf [k - m_prev] with zp / sp [m_prev] -- k_merge's ranks: old
+// sample a_i at i + #{j: b_j < a_i}, new sample b_j at j + #{i: a_i <= b_j}, the sdf rows taken from ray % quirk_p when quirk_p > 0
+// (SURVEY B-1) -- assembled in LDS, used from there, and written to z_out / sdf_out [n_rays, k] for the rounds after this one.
+// Gather (the hand's coarse round under the far-field skip): with `pos` the sdf row is read through the compaction record --
+// sdf_c[pos[i]], the far sample's value sdf_c[n_dev - 1] where pos[i] < 0 (k_hand_scatter_sdf's statement) -- and the dense row
+// goes to sdf_out.
 struct UpsExtra {
     float* zcat;
     int ld, col;
     const float *o, *d;
     float* pts;
+    const float *zp, *sp;
+    int m_prev, quirk_p;
+    float *z_out, *sdf_out;
+    const int *pos, *n_dev;
+    const float* sdf_c;
 };
 __global__ __launch_bounds__(256) void k_upsample_wave(const float* __restrict__ z, const float* __restrict__ sdf, int n_rays, int k,
                                                        int n_new, float inv_s, float* __restrict__ z_new,
                                                        int64_t* __restrict__ inds_out, UpsExtra ex) {
-    __shared__ float lz[4][UPS_MAX_K], ls[4][UPS_MAX_K], lw[4][UPS_MAX_K];
+    __shared__ float lz[4][UPS_MAX_K], ls[4][UPS_MAX_K], lw[4][UPS_MAX_K], lb[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wv;
     if (ray >= n_rays) return;
     float* zr = lz[wv];
     float* sr = ls[wv];
     float* wr = lw[wv];
-    for (int i = lane; i < k; i += 64) {
-        zr[i] = z[(size_t)ray * k + i];
-        sr[i] = sdf[(size_t)ray * k + i];
+    if (ex.m_prev > 0) {
+        // the previous round's cat_z_vals: a = the old row (staged in wr, free until the weights are formed), b = that round's depths
+        const int m = ex.m_prev, k0 = k - m;
+        const int srow = ex.quirk_p > 0 ? ray % ex.quirk_p : ray;
+        float* br = lb[wv];
+        constexpr int RMAX = UPS_MAX_K / 64;
+        float as[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int i = r * 64 + lane;
+            const bool ok = i < k0;
+            if (ok) wr[i] = z[(size_t)ray * k0 + i];
+            as[r] = ok ? sdf[(size_t)srow * k0 + i] : 0.f;
+        }
+        float bv = 0.f, bs = 0.f;
+        if (lane < m) {
+            bv = ex.zp[(size_t)ray * m + lane];
+            bs = ex.sp[(size_t)srow * m + lane];
+            br[lane] = bv;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int i = r * 64 + lane;
+            if (i < k0) {
+                const float a = wr[i];
+                int lo = 0, hi = m;   // #{j: b_j < a} (b sorted)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (br[mid] < a)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                zr[i + lo] = a;
+                sr[i + lo] = as[r];
+            }
+        }
+        if (lane < m) {
+            int lo = 0, hi = k0;   // #{i: a_i <= b} (a sorted)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (wr[mid] <= bv)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            zr[lane + lo] = bv;
+            sr[lane + lo] = bs;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < k; i += 64) {
+            ex.z_out[(size_t)ray * k + i] = zr[i];
+            ex.sdf_out[(size_t)ray * k + i] = sr[i];
+        }
+    } else if (ex.pos != nullptr) {
+        const int far = ex.n_dev[0] - 1;
+        for (int i = lane; i < k; i += 64) {
+            const size_t g = (size_t)ray * k + i;
+            const int q = ex.pos[g];
+            const float v = ex.sdf_c[q >= 0 ? q : far];
+            zr[i] = z[g];
+            sr[i] = v;
+            ex.sdf_out[g] = v;
+        }
+    } else {
+        for (int i = lane; i < k; i += 64) {
+            zr[i] = z[(size_t)ray * k + i];
+            sr[i] = sdf[(size_t)ray * k + i];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     // alpha of section i (element-wise in the reference too: utils/renderer.py:68-81)
@@ -910,7 +989,8 @@ int upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, flo
     HN_REQUIRE(k >= 2 && k <= UPS_MAX_K && n_new >= 1 && n_new <= 64, "upsample: k=%d n_new=%d out of range", k, n_new);
     if (n_rays == 0) return HN_OK;
     if (n_rays <= 8192) {   // small batches (the fitting loops): one wave per ray
-        hipLaunchKernelGGL(k_upsample_wave, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, sdf, n_rays, k, n_new, inv_s, z_new, inds, UpsExtra{});
+        hipLaunchKernelGGL(k_upsample_wave, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, sdf, n_rays, k, n_new, inv_s, z_new, inds,
+                           UpsExtra{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr});
         HN_LAUNCH_CHECK();
         return HN_OK;
     }
@@ -927,11 +1007,22 @@ int upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, flo
 
 // up_sample of a small batch (<= 8192 rays: the fitting loops) with the round's follow-up writes in the same launch (UpsExtra);
 // HN_EINVAL-free fallback for larger batches: false is returned and the caller runs the three launches
+bool upsample_fused_ok(int n_rays, int k, int n_new) { return n_rays > 0 && n_rays <= 8192 && k >= 2 && k <= UPS_MAX_K && n_new >= 1 && n_new <= 64; }
 bool upsample_fused(const float* z, const float* sdf, int n_rays, int k, int n_new, float inv_s, float* z_new, float* zcat, int ld, int col,
-                    const float* o, const float* d, float* pts, hipStream_t s) {
-    if (n_rays <= 0 || n_rays > 8192 || k < 2 || k > UPS_MAX_K || n_new < 1 || n_new > 64) return false;
-    hipLaunchKernelGGL(k_upsample_wave, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, sdf, n_rays, k, n_new, inv_s, z_new, (int64_t*)nullptr,
-                       UpsExtra{zcat, ld, col, o, d, pts});
+                    const float* o, const float* d, float* pts, hipStream_t s, const UpsPre* pre) {
+    if (!upsample_fused_ok(n_rays, k, n_new)) return false;
+    UpsExtra ex{zcat, ld, col, o, d, pts, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (pre != nullptr) {
+        if (pre->m_prev > 0) {
+            if (pre->m_prev > 64 || pre->m_prev >= k || pre->zp == nullptr || pre->sp == nullptr || pre->z_out == nullptr || pre->sdf_out == nullptr)
+                return false;
+            ex.zp = pre->zp, ex.sp = pre->sp, ex.m_prev = pre->m_prev, ex.quirk_p = pre->quirk_p, ex.z_out = pre->z_out, ex.sdf_out = pre->sdf_out;
+        } else if (pre->pos != nullptr) {
+            if (pre->n_dev == nullptr || pre->sdf_c == nullptr || pre->sdf_out == nullptr) return false;
+            ex.pos = pre->pos, ex.n_dev = pre->n_dev, ex.sdf_c = pre->sdf_c, ex.sdf_out = pre->sdf_out;
+        }
+    }
+    hipLaunchKernelGGL(k_upsample_wave, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, sdf, n_rays, k, n_new, inv_s, z_new, (int64_t*)nullptr, ex);
     return hipGetLastError() == hipSuccess;
 }
 

@@ -352,10 +352,15 @@ class HaloPoseChain:
             # a window of frames (fitting_video): the same single node on the window's rows of the leaves; the window's constants
             # are gathered once per index set
             from .pose import HaloChainFn
-            key = tuple(int(i) for i in index)
+            consts = (self.joints0, self.bone_len, self.Ro_pred, self.To_pred, self.T_pose_21)
+            rows = index.tolist() if isinstance(index, torch.Tensor) else [int(i) for i in index]      # (a tensor index: one transfer)
+            # keyed on the constants' storage and version as well as on the rows: replacing or editing a constant drops its windows
+            key = (tuple(rows), tuple((x.data_ptr(), x._version) for x in consts))
             cache = self.__dict__.setdefault('_window_consts', {})
             if key not in cache:
-                cache[key] = tuple(x[idx].contiguous() for x in (self.joints0, self.bone_len, self.Ro_pred, self.To_pred, self.T_pose_21))
+                if len(cache) > 4096:
+                    cache.clear()
+                cache[key] = tuple(x[idx].contiguous() for x in consts)
             j0, bl, Rp, Tp, T21 = cache[key]
             bt_inv, joint_3d, obj_r, obj_t = HaloChainFn.apply(self.obj_rot, self.obj_trans, self.palm_rot, self.palm_trans, self.joint_refine_angle,
                                                                self.palm_refine_angle, j0, bl, Rp, Tp, idx)
@@ -475,16 +480,17 @@ def _rays(lib_mod, xy, cam, n_cams, rays_per_cam):
 
 
 PIPELINE_SINGLE = True    # fit_frame: the two-stream step (PipelinedSingleFit) where it applies; False: fit_backward + fit_apply through autograd
-_SIDE_STREAMS = {}
 USE_SIDE_STREAM = True    # fit_backward (frame-batched renderer): the pose-only terms of a step on a second stream beside the render
 
 
 def _side_stream(device):
-    """One extra torch stream per device for branches of a step that are independent of the render."""
-    key = str(device)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
+    """ONE extra torch stream per device for branches of a step that are independent of the render -- the same stream the pose
+    chain's Jacobian launches use (pose._aux_stream): with the caller's stream and the library's second stream that makes three.
+    Every further stream of the process shares a hardware queue with one of those (the runtime multiplexes streams onto 4 queues),
+    and work queued behind a 1 ms adjoint kernel of another stream is what that costs (measured: a stream per pipelined fit object
+    took the 2.6 ms step to 4.4 ms by the third object)."""
+    from .pose import _aux_stream
+    return _aux_stream(device)
 
 
 def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None, smooth_ends=(False, False),
@@ -627,6 +633,43 @@ class PoseAdam:
                 elif p.grad is not None:
                     p.grad.zero_()
 
+    def add_param_group(self, group):
+        ps = [group['params']] if isinstance(group['params'], torch.Tensor) else list(group['params'])
+        self.param_groups.append({'params': ps, 'lr': float(group['lr'])})
+
+    def state_dict(self):
+        """torch.optim.Optimizer.state_dict's layout: parameters numbered in group order, per-parameter 'step' / 'exp_avg' /
+        'exp_avg_sq' (what torch.optim.Adam checkpoints, so a state saved from either loads into the other)."""
+        ids, groups, n = {}, [], 0
+        # (the other keys a torch.optim.Adam group carries, at the defaults this optimiser implements)
+        defaults = dict(torch.optim.Adam([torch.zeros(1)]).defaults)
+        for g in self.param_groups:
+            idx = []
+            for p in g['params']:
+                ids[id(p)] = n
+                idx.append(n)
+                n += 1
+            groups.append(dict(defaults, lr=g['lr'], betas=tuple(self.betas), eps=self.eps, params=idx))
+        state = {ids[k]: {'step': torch.tensor(float(st[2])), 'exp_avg': st[0].clone(), 'exp_avg_sq': st[1].clone()}
+                 for k, st in self.state.items() if k in ids}
+        return {'state': state, 'param_groups': groups}
+
+    def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        if len(groups) != len(self.param_groups) or any(len(a['params']) != len(b['params']) for a, b in zip(groups, self.param_groups)):
+            raise ValueError('PoseAdam.load_state_dict: the parameter groups do not match')
+        params = [p for g in self.param_groups for p in g['params']]
+        for g, src in zip(self.param_groups, groups):
+            g['lr'] = float(src['lr'])
+        if groups:
+            self.betas, self.eps = tuple(groups[0].get('betas', self.betas)), float(groups[0].get('eps', self.eps))
+        self.state = {}
+        for k, st in sd['state'].items():
+            p = params[int(k)]
+            m = st['exp_avg'].to(device=p.device, dtype=torch.float32).reshape(p.shape).contiguous().clone()
+            v = st['exp_avg_sq'].to(device=p.device, dtype=torch.float32).reshape(p.shape).contiguous().clone()
+            self.state[id(p)] = [m, v, int(float(st['step']))]
+
     @torch.no_grad()
     def step(self, only=None, stream=None):
         """only: restrict the step to these parameters (the pipelined fitting step updates the hand's and the object's leaves on
@@ -674,6 +717,7 @@ class PipelinedSingleFit:
     Call `finish()` before reading the parameters from another stream (or synchronise the device): the object's leaves are
     updated on the second stream."""
 
+    JITTER_BLOCK = 64
     HAND_LEAVES = ('palm_rot', 'palm_trans', 'joint_refine_angle', 'palm_refine_angle')
     OBJ_LEAVES = ('obj_rot', 'obj_trans')
 
@@ -697,6 +741,8 @@ class PipelinedSingleFit:
         L.check(self.lib.hn_side_stream(ctypes.byref(sp)), 'hn_side_stream')
         self.side_ptr = ctypes.c_void_p(sp.value)
         self.side = torch.cuda.ExternalStream(sp.value, device=dev)
+        self.aux = _side_stream(dev)                          # the pose chain's Jacobian (see step); one such stream per device
+        self.ev_prm, self.ev_jac = torch.cuda.Event(), torch.cuda.Event()
         e = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         self.prm_h, self.prm_o = e(1, 36), torch.zeros(1, 18, device=dev)
         self.bt, self.j3, self.jac_h = e(1, 21, 4, 4), e(1, 21, 3), e(1, 399, 36)
@@ -713,6 +759,17 @@ class PipelinedSingleFit:
         self.interaction = interaction
         self.w5 = (ctypes.c_float * 5)(*((1.0, 30.0, 20.0, 30.0, 20.0) if interaction else (1.0, 0.0, 0.0, 100.0, 5.0)))
         ch = pose_chain
+        # the six leaves move into the two parameter blocks the chain kernels read (views of them from here on: same values, same
+        # shapes, contiguous), so that a step does not gather them (a cat launch on each stream)
+        homes = {'joint_refine_angle': self.prm_h[:, 0:20], 'palm_refine_angle': self.prm_h[:, 20:27], 'palm_rot': self.prm_h[:, 27:33].view(1, 3, 2),
+                 'palm_trans': self.prm_h[:, 33:36], 'obj_rot': self.prm_o[:, 0:6].view(1, 3, 2), 'obj_trans': self.prm_o[:, 6:9]}
+        with torch.no_grad():
+            for k, view in homes.items():
+                p = getattr(ch, k)
+                view.copy_(p.detach().reshape(view.shape))
+                p.data = view
+        self._homes = tuple((getattr(ch, k), view.data_ptr()) for k, view in homes.items())
+        self._jitter, self._jitter_at = None, 0
         g = self.g45
         self.grads = {'obj_rot': g[:, 36:42].view(1, 3, 2), 'obj_trans': g[:, 42:45], 'palm_rot': g[:, 27:33].view(1, 3, 2), 'palm_trans': g[:, 33:36],
                       'joint_refine_angle': g[:, 0:20], 'palm_refine_angle': g[:, 20:27]}
@@ -749,18 +806,34 @@ class PipelinedSingleFit:
         rays_o, rays_d = self._rays[self._step & 1]
         self._step += 1
         # ---- pose side: the hand's chain on the caller's stream, the object's on the second stream
-        torch.cat([ch.joint_refine_angle, ch.palm_refine_angle, ch.palm_rot.reshape(1, 6), ch.palm_trans], dim=1, out=self.prm_h)
-        L.check(lib.hn_pose_chain(L.ptr(ch.joints0), L.ptr(ch.bone_len), None, L.ptr(self.prm_h), 1, L.ptr(self.bt), L.ptr(self.j3), L.ptr(self.jac_h), s),
+        homed = all(p.data_ptr() == at for p, at in self._homes)      # (a caller that re-assigned a leaf's storage: gather as before)
+        if not homed:
+            torch.cat([ch.joint_refine_angle, ch.palm_refine_angle, ch.palm_rot.reshape(1, 6), ch.palm_trans], dim=1, out=self.prm_h)
+        # (values and Jacobian as two launches: the render waits for the values, a third of the chain's time; the Jacobian is read
+        # by this step's hn_pose_side_vjp, ~2 ms from here, and runs beside the sampling on a stream of its own)
+        self.ev_prm.record()
+        L.check(lib.hn_pose_chain(L.ptr(ch.joints0), L.ptr(ch.bone_len), None, L.ptr(self.prm_h), 1, L.ptr(self.bt), L.ptr(self.j3), None, s), 'hn_pose_chain')
+        self.aux.wait_event(self.ev_prm)
+        L.check(lib.hn_pose_chain(L.ptr(ch.joints0), L.ptr(ch.bone_len), None, L.ptr(self.prm_h), 1, None, None, L.ptr(self.jac_h), self.aux.cuda_stream),
                 'hn_pose_chain')
-        with torch.cuda.stream(self.side):
-            torch.cat([ch.obj_rot.reshape(1, 6), ch.obj_trans], dim=1, out=self.prm_o[:, :9])
+        self.ev_jac.record(self.aux)
+        if not homed:
+            with torch.cuda.stream(self.side):
+                torch.cat([ch.obj_rot.reshape(1, 6), ch.obj_trans], dim=1, out=self.prm_o[:, :9])
         L.check(lib.hn_rigid_pose(None, None, L.ptr(ch.Ro_pred), L.ptr(ch.To_pred), L.ptr(self.prm_o), 1, 0, L.ptr(self.out_o), L.ptr(self.jac_o), so),
                 'hn_rigid_pose')
         cam = view['cam']
         L.check(lib.hn_ray_gen(L.ptr(view['xy']), L.ptr(cam['R']), L.ptr(cam['T']), L.ptr(cam['focal']), L.ptr(cam['principal']), 1, R, L.ptr(rays_o),
                                L.ptr(rays_d), s), 'hn_ray_gen')
         # ---- the two-field render, taped; the object's pose comes from the second stream, as obj_r (its transpose is applied)
-        tr = torch.rand(R, 1, device=dev) if t_rand is None else L.f32(t_rand, dev).reshape(R, 1)
+        if t_rand is None:
+            # the jitter of JITTER_BLOCK steps in one launch (fresh uniform numbers every step, as torch.rand per render gives)
+            if self._jitter is None or self._jitter_at >= self._jitter.shape[0] or self._jitter.shape[1] != R:
+                self._jitter, self._jitter_at = torch.rand(self.JITTER_BLOCK, R, 1, device=dev), 0
+            tr = self._jitter[self._jitter_at]
+            self._jitter_at += 1
+        else:
+            tr = L.f32(t_rand, dev).reshape(R, 1)
         need = lib.hn_render_dual_workspace_bytes(hand.handle, obj.handle, R, ren.n_samples, ren.n_importance)
         ws = ren._ws.get(need, dev)
         tape_bytes = lib.hn_render_dual_tape_bytes(hand.handle, obj.handle, R, S)
@@ -808,6 +881,7 @@ class PipelinedSingleFit:
                                        None, None, None, L.ptr(self.g_bt), L.ptr(self.g_tp), L.ptr(self.g_Ro), L.ptr(self.g_To), L.ptr(wsb), bneed, L.ptr(tape),
                                        flags, s), 'hn_render_dual_bwd')
         # ---- leaf gradients and Adam: the hand's four leaves on s, the object's two on the second stream
+        torch.cuda.current_stream().wait_event(self.ev_jac)
         L.check(lib.hn_pose_side_vjp(L.ptr(self.jac_h), None, L.ptr(self.g_bt), L.ptr(gj_o), None, None, None, None, 1, 1, L.ptr(self.g45), s), 'hn_pose_side_vjp')
         L.check(lib.hn_pose_side_vjp(None, L.ptr(self.jac_o), None, None, L.ptr(self.g_Ro), L.ptr(self.g_To), L.ptr(gR_o), L.ptr(gt_o), 1, 2, L.ptr(self.g45), so),
                 'hn_pose_side_vjp')

@@ -159,6 +159,17 @@ def _zeros9(F, dev):
     return _ZEROS9[key]
 
 
+_AUX_STREAMS = {}
+
+
+def _aux_stream(dev):
+    """The stream the pose chain's Jacobian launches run on (one per device)."""
+    key = str(dev)
+    if key not in _AUX_STREAMS:
+        _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _AUX_STREAMS[key]
+
+
 class HaloChainFn(torch.autograd.Function):
     """The whole pose side of a fitting_single step as ONE autograd node over the six refine leaves (fitting_single.py:177-235):
     (obj_rot [F,3,2], obj_trans [F,3], palm_rot [F,3,2], palm_trans [F,3], joint_refine_angle [F,20], palm_refine_angle [F,7])
@@ -176,19 +187,40 @@ class HaloChainFn(torch.autograd.Function):
         F, dev = ori_pose.shape[0], ori_pose.device
         st = L.stream_ptr()
         n = obj_rot.shape[0]
-        prm = torch.cat([joint_angle.reshape(n, 20), palm_angle.reshape(n, 7), palm_rot.reshape(n, 6), palm_trans.reshape(n, 3),
-                         obj_rot.reshape(n, 6), obj_trans.reshape(n, 3), _zeros9(n, dev)], dim=1)    # [n, 45 + 9]: one launch
-        if rows is not None:
-            prm = prm.index_select(0, rows)
         ctx.rows, ctx.n = rows, n
-        prm_h = prm[:, :36].contiguous() if F > 1 else prm[:, :36]
-        prm_o = prm[:, 36:54].contiguous() if F > 1 else prm[:, 36:54]                               # hn_rigid_pose's 18 inputs: 9 used here
+        leaves = (obj_rot, obj_trans, palm_rot, palm_trans, joint_angle, palm_angle)
+        if rows is not None and all(x.is_contiguous() and x.dtype == torch.float32 for x in leaves):
+            # a window of a sequence: the rows of the six leaves -> the two input blocks, one launch (hn_leaf_rows_gather)
+            import ctypes
+            prm_h = torch.empty(F, 36, device=dev, dtype=torch.float32)
+            prm_o = torch.empty(F, 18, device=dev, dtype=torch.float32)
+            ptrs = (ctypes.c_void_p * 6)(*[x.data_ptr() for x in leaves])
+            L.check(lib.hn_leaf_rows_gather(ptrs, L.ptr(rows), F, L.ptr(prm_h), L.ptr(prm_o), st), 'hn_leaf_rows_gather')
+        else:
+            prm = torch.cat([joint_angle.reshape(n, 20), palm_angle.reshape(n, 7), palm_rot.reshape(n, 6), palm_trans.reshape(n, 3),
+                             obj_rot.reshape(n, 6), obj_trans.reshape(n, 3), _zeros9(n, dev)], dim=1)    # [n, 45 + 9]: one launch
+            if rows is not None:
+                prm = prm.index_select(0, rows)
+            prm_h = prm[:, :36].contiguous() if F > 1 else prm[:, :36]
+            prm_o = prm[:, 36:54].contiguous() if F > 1 else prm[:, 36:54]                           # hn_rigid_pose's 18 inputs: 9 used here
         need = any(x.requires_grad for x in (obj_rot, obj_trans, palm_rot, palm_trans, joint_angle, palm_angle))
         bt = torch.empty(F, 21, 4, 4, device=dev, dtype=torch.float32)
         j3 = torch.empty(F, 21, 3, device=dev, dtype=torch.float32)
         jac_h = torch.empty(F, N_OUT, N_IN, device=dev, dtype=torch.float32) if need else None
-        L.check(lib.hn_pose_chain(L.ptr(ori_pose), L.ptr(bone_len), None, L.ptr(prm_h), F, L.ptr(bt), L.ptr(j3), L.ptr(jac_h) if need else None, st),
-                'hn_pose_chain')
+        # values and Jacobian as two launches: what follows (the render) waits for the values, a third of the chain's time; the
+        # Jacobian is read by backward() and runs on a stream of its own beside the render's sampling
+        ctx.jac_ev = None
+        if need:
+            aux = _aux_stream(dev)
+            ready = torch.cuda.Event()
+            ready.record()
+            aux.wait_event(ready)
+            L.check(lib.hn_pose_chain(L.ptr(ori_pose), L.ptr(bone_len), None, L.ptr(prm_h), F, None, None, L.ptr(jac_h), aux.cuda_stream), 'hn_pose_chain')
+            ctx.jac_ev = torch.cuda.Event()
+            ctx.jac_ev.record(aux)
+            for t in (prm_h, jac_h, ori_pose, bone_len):
+                t.record_stream(aux)
+        L.check(lib.hn_pose_chain(L.ptr(ori_pose), L.ptr(bone_len), None, L.ptr(prm_h), F, L.ptr(bt), L.ptr(j3), None, st), 'hn_pose_chain')
         # (object half only: entries 399 .. 410 of out / jac_o are written, and only those are read below)
         out = torch.empty(F, 412, device=dev, dtype=torch.float32)
         jac_o = torch.empty(F, 412, 18, device=dev, dtype=torch.float32) if need else None
@@ -207,16 +239,22 @@ class HaloChainFn(torch.autograd.Function):
         c = lambda t, n: None if t is None else L.f32(t).reshape(F, n)
         gb, gj, gr, gt = c(g_bt, 336), c(g_j3, 63), c(g_or, 9), c(g_ot, 3)
         g = torch.empty(F, 45, device=dev, dtype=torch.float32)
+        if ctx.jac_ev is not None:
+            torch.cuda.current_stream().wait_event(ctx.jac_ev)
         # both Jacobian products in one launch (hn_pose_side_vjp); a missing upstream gradient counts as zero there
         L.check(lib.hn_pose_side_vjp(L.ptr(ctx.jac_h), L.ptr(ctx.jac_o), L.ptr(gb), L.ptr(gj), L.ptr(gr), L.ptr(gt), None, None, F, 3, L.ptr(g),
                                      L.stream_ptr()),
                 'hn_pose_side_vjp')
         gh, go = g[:, :36], g[:, 36:45]
         sh = ctx.shapes
-        if ctx.rows is not None:     # the window's rows of the [n, 45] gradient block, zero elsewhere
-            full = torch.zeros(ctx.n, 45, device=dev, dtype=torch.float32)
-            full.index_copy_(0, ctx.rows, g)
-            gh, go = full[:, :36], full[:, 36:45]
+        if ctx.rows is not None:
+            # the window's rows of six contiguous gradient blocks (zero elsewhere): one fill and one launch (hn_leaf_rows_scatter);
+            # contiguous, so autograd keeps them as the leaves' .grad without a copy each
+            n = ctx.n
+            out = torch.zeros(n * 45, device=dev, dtype=torch.float32)
+            L.check(lib.hn_leaf_rows_scatter(L.ptr(g), L.ptr(ctx.rows), F, n, L.ptr(out), L.stream_ptr()), 'hn_leaf_rows_scatter')
+            return (out[:6 * n].view(sh[0]), out[6 * n:9 * n].view(sh[1]), out[9 * n:15 * n].view(sh[2]), out[15 * n:18 * n].view(sh[3]),
+                    out[18 * n:38 * n].view(sh[4]), out[38 * n:45 * n].view(sh[5]), None, None, None, None, None)
         # views of one block (for F = 1 every slice is contiguous: autograd keeps them as the leaves' .grad without a copy)
         return (go[:, 0:6].reshape(sh[0]), go[:, 6:9].reshape(sh[1]), gh[:, 27:33].reshape(sh[2]), gh[:, 33:36].reshape(sh[3]),
                 gh[:, 0:20].reshape(sh[4]), gh[:, 20:27].reshape(sh[5]), None, None, None, None, None)

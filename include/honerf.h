@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 112 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 113 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -246,6 +246,8 @@ int hn_nearest_masked(const float* pts, int n_verts, int n_sets, const unsigned 
  *   params [F,36] = [joint_refine_angle 20 | palm_refine_angle 7 | palm_rot_refine 6 (row-major [3][2]) | palm_trans_refine 3]
  *   -> bt_inv [F,21,4,4] (bone_transformation_inv), joint_3d [F,21,3] (the refined joints, MANO order: the joint loss's
  *   input), and, when jac != NULL, jac [F,399,36] = d [bt_inv | joint_3d] / d params (forward-mode, exact).
+ *   jac == NULL runs the values alone (a third of the time: what a fitting step's render waits for); bt_inv == joint_3d == NULL
+ *   with jac != NULL the Jacobian alone (a caller that needs it later than the values asks for the two separately).
  * hn_pose_chain_bwd: g_params [F,36] = jac^T [g_bt_inv | g_joint_3d] (either gradient may be NULL = zero). */
 #define HN_POSE_CHAIN_IN 36
 #define HN_POSE_CHAIN_OUT 399
@@ -276,6 +278,13 @@ int hn_jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, i
  * 399..410, columns 0..8 of jac_o (hn_rigid_pose's Jacobian [F,412,18], with_palm == 0) ]; a NULL upstream gradient is zero;
  * g_obj_r2 / g_obj_t2: second addends of the object's upstream gradients (the render's and the loss's shares, summed in the
  * kernel); `which`: 1 the hand columns 0..35 only, 2 the object columns 36..44 only, 3 both. */
+/* The rows `rows` [n_rows] (int64) of a fitting_video sequence's six pose leaves (fitting_video.py:159-176; leaves6 = device pointers to
+ * obj_rot [n,6], obj_trans [n,3], palm_rot [n,6], palm_trans [n,3], joint_refine_angle [n,20], palm_refine_angle [n,7], contiguous) as
+ * the pose chain's input blocks, prm_hand [n_rows,36] (hn_pose_chain) and prm_obj [n_rows,18] (hn_rigid_pose; columns 9..17 zero), one
+ * launch; and back: g [n_rows,45] = hn_pose_side_vjp's output scattered into those rows of six contiguous gradient blocks laid out one
+ * behind the other in `out` (n_frames x 45 floats, zeroed by the caller): [n,6] [n,3] [n,6] [n,3] [n,20] [n,7]. */
+int hn_leaf_rows_gather(const float* const* leaves6, const long long* rows, int n_rows, float* prm_hand, float* prm_obj, hn_stream_t stream);
+int hn_leaf_rows_scatter(const float* g, const long long* rows, int n_rows, int n_frames, float* out, hn_stream_t stream);
 int hn_pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt_inv, const float* g_joint_3d, const float* g_obj_r,
                      const float* g_obj_t, const float* g_obj_r2, const float* g_obj_t2, int n_frames, int which, float* out,
                      hn_stream_t stream);

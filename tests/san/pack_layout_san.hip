@@ -10,7 +10,7 @@
 namespace hn {
 // the pieces of the other translation units the packer's device half refers to: never reached by the planner
 void set_error(const char*, ...) {}
-hipError_t pool_alloc(void**, size_t) { return hipErrorNotSupported; }
+hipError_t pool_alloc_on(void**, size_t, hipStream_t) { return hipErrorNotSupported; }
 void pool_free(void*) {}
 int current_device() { return 0; }
 }  // namespace hn

@@ -68,6 +68,32 @@ def test_pose_chain_kernel_matches_reference():
 
 
 @pytest.mark.gpu
+def test_pose_chain_values_only_and_jacobian_only_launches_are_the_joint_launch():
+    """hn_pose_chain's three forms -- values + Jacobian in one launch, values alone (jac NULL: tangents compiled out), Jacobian
+    alone (bt_inv / joint_3d NULL) -- give the same bits: the fitting steps ask for values and Jacobian separately."""
+    from honerf_amd import lib as L
+    lib = L.load()
+    g = np.load(GOLD)
+    dev = torch.device('cuda')
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev).contiguous()
+    ori, bl, prm = t(g['ori_pose']), t(g['bone_len']), t(g['params'])
+    F = ori.shape[0]
+    e = lambda *sh: torch.full(sh, float('nan'), device=dev, dtype=torch.float32)
+    bt_a, j3_a, jac_a = e(F, 21, 4, 4), e(F, 21, 3), e(F, 399, 36)
+    bt_b, j3_b, jac_c = e(F, 21, 4, 4), e(F, 21, 3), e(F, 399, 36)
+    st = L.stream_ptr()
+    L.check(lib.hn_pose_chain(L.ptr(ori), L.ptr(bl), None, L.ptr(prm), F, L.ptr(bt_a), L.ptr(j3_a), L.ptr(jac_a), st), 'joint')
+    L.check(lib.hn_pose_chain(L.ptr(ori), L.ptr(bl), None, L.ptr(prm), F, L.ptr(bt_b), L.ptr(j3_b), None, st), 'values')
+    L.check(lib.hn_pose_chain(L.ptr(ori), L.ptr(bl), None, L.ptr(prm), F, None, None, L.ptr(jac_c), st), 'jacobian')
+    torch.cuda.synchronize()
+    assert torch.equal(bt_a, bt_b) and torch.equal(j3_a, j3_b) and torch.equal(jac_a, jac_c)
+    assert not torch.isnan(jac_a).any()
+    # neither outputs nor Jacobian, or only one of the value outputs: refused
+    assert lib.hn_pose_chain(L.ptr(ori), L.ptr(bl), None, L.ptr(prm), F, None, None, None, st) != 0
+    assert lib.hn_pose_chain(L.ptr(ori), L.ptr(bl), None, L.ptr(prm), F, L.ptr(bt_b), None, None, st) != 0
+
+
+@pytest.mark.gpu
 def test_fit_step_with_the_reference_pose_chain():
     """fit_step (fit type 12) over HaloPoseChain: the six refine leaves of fitting_single.py:183-198 all receive gradients
     through hn_pose_chain_bwd, the initial state reproduces the predicted joints' refined pose, and a few Adam steps run."""
@@ -177,6 +203,41 @@ def test_pose_adam_is_torch_adam():
         e = float((a.detach() - b.detach()).abs().max() / (b.detach() - init[k].to(dev)).abs().max())
         record('PoseAdam vs torch.optim.Adam after 7 steps, block %d (difference / movement)' % k, e, 1e-5)
         assert e <= 1e-5, (k, e)
+
+
+@pytest.mark.gpu
+def test_pose_adam_state_dict_interchanges_with_torch_adam():
+    """PoseAdam.state_dict / load_state_dict carry torch.optim.Adam's layout: a fit checkpointed after 3 steps under one optimiser
+    resumes under the other and lands where an uninterrupted torch.optim.Adam run does."""
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    gen = torch.Generator().manual_seed(5)
+    shapes, lrs = [(1, 3, 2), (1, 20)], [5e-4, 1e-3]
+    init = [torch.randn(*s, generator=gen) for s in shapes]
+    grads = [[torch.randn(*s, generator=gen).to(dev) for s in shapes] for _ in range(6)]
+    mk = lambda: [torch.nn.Parameter(x.clone().to(dev)) for x in init]
+    groups = lambda ps: [{'params': p, 'lr': l} for p, l in zip(ps, lrs)]
+
+    def run(opt, ps, steps):
+        for gs in steps:
+            for p, g in zip(ps, gs):
+                p.grad = g.clone()
+            opt.step()
+
+    p_ref = mk()
+    run(torch.optim.Adam(groups(p_ref)), p_ref, grads)
+    for first, second in ((F.PoseAdam, torch.optim.Adam), (torch.optim.Adam, F.PoseAdam)):
+        ps = mk()
+        o1 = first(groups(ps))
+        run(o1, ps, grads[:3])
+        sd = o1.state_dict()
+        o2 = second(groups(ps))
+        o2.load_state_dict(sd)
+        run(o2, ps, grads[3:])
+        for k, (a, b) in enumerate(zip(ps, p_ref)):
+            e = float((a.detach() - b.detach()).abs().max() / (b.detach() - init[k].to(dev)).abs().max())
+            record('%s -> %s resume vs torch.optim.Adam, block %d' % (first.__name__, second.__name__, k), e, 1e-5)
+            assert e <= 1e-5, (first.__name__, k, e)
 
 
 @pytest.mark.gpu

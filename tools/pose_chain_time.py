@@ -1,20 +1,17 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
-from honerf_amd.pose import PoseChainFn
-g = np.load('/root/repo/tests/golden/pose_chain.npz')
-dev = torch.device('cuda')
-t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
-for F in (1, 4, 32):
-    ori, bl = t(np.repeat(g['ori_pose'][1:2], F, 0)), t(np.repeat(g['bone_len'][1:2], F, 0))
-    prm = t(np.repeat(g['params'][1:2], F, 0)).requires_grad_(True)
-    for _ in range(3):
-        bt, j3 = PoseChainFn.apply(ori, bl, prm); (bt.sum() + j3.sum()).backward()
-    torch.cuda.synchronize()
-    e0, e1, e2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    e0.record()
-    for _ in range(20): bt, j3 = PoseChainFn.apply(ori, bl, prm)
-    e1.record()
-    for _ in range(20):
-        bt, j3 = PoseChainFn.apply(ori, bl, prm); (bt.sum() + j3.sum()).backward()
-    e2.record(); torch.cuda.synchronize()
-    print('F=%d: forward (values + Jacobian) %.1f us, forward + backward %.1f us' % (F, e0.elapsed_time(e1) * 50, e1.elapsed_time(e2) * 50))
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch, numpy as np, time
+from honerf_amd import lib as L
+lib=L.load(); dev=torch.device('cuda')
+g=np.load('tests/golden/pose_chain.npz')
+t=lambda a: torch.tensor(a,dtype=torch.float32,device=dev).contiguous()
+ori,bl,prm=t(g['ori_pose'])[:1],t(g['bone_len'])[:1],t(g['params'])[:1]
+bt,j3,jac=torch.empty(1,21,4,4,device=dev),torch.empty(1,21,3,device=dev),torch.empty(1,399,36,device=dev)
+st=L.stream_ptr()
+for name,args in (('joint',(L.ptr(bt),L.ptr(j3),L.ptr(jac))),('values',(L.ptr(bt),L.ptr(j3),None)),('jac',(None,None,L.ptr(jac)))):
+    for _ in range(5): lib.hn_pose_chain(L.ptr(ori),L.ptr(bl),None,L.ptr(prm),1,*args,st)
+    a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(50): lib.hn_pose_chain(L.ptr(ori),L.ptr(bl),None,L.ptr(prm),1,*args,st)
+    b.record(); torch.cuda.synchronize()
+    print(name, a.elapsed_time(b)/50*1000,'us')
