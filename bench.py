@@ -15,10 +15,16 @@ Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel: the 
 hand field kernel, MFMA-bound), `cpu_baseline` (the CPU oracle -- a port of the
 reference's PyTorch path -- timed on this box's host cores on a bounded crop) and
 `fitting`: the second half of BASELINE's metric, frames/sec of the pose-fitting loops
-(configs[2..4]): one optimisation step of fitting_single (C3/C4: 196 rays x 192 shared
-depths, both fields, forward + losses + backward into the pose parameters + Adam) and of
-fitting_video (C5: a window of 4 frames x 40 rays, fit type '1234' incl. the stable
-loss), every rank fitting its own frame / window (frame-sharded, weak scaling).
+(configs[2..4]) on FIXED workloads at every N: `single_1` / `single_12` one
+optimisation step of fitting_single (C3: 196 rays x 192 shared depths, both fields, forward +
+losses + backward into the six pose leaves + Adam; the pipelined step of fit_frame;
+`single_12_autograd` the same step through autograd, `single_12_dense` with the far-field skip
+off), `frames_sharded_12` (C4: 8 frames x 200 steps dealt to the ranks by fit_frames_sharded, no
+data-path collective: strong scaling), `video_1234` (C5: ONE 32-frame sequence through
+fit_sequence_video -- 29 windows x 5 passes, windows sharded over the ranks, one all-reduce of
+the pose-gradient block per step), `video_1234_step` (one window step), `video_1234_weak` (a
+3 + 2 x world-frame sequence).  `fitting.roofline` prices the step on the samples it EXECUTED
+(the compacted launches' live counts), `roofline_dense` the dense step on the dense count.
 
 `training` (rank 0): one iteration of exp_runner.train's inner loop per field kind.
 

@@ -16,8 +16,9 @@
 {
     struct Act2 {
         f32x16 v;   // stashed activation a_{l+1}: sigma'(z_l) = 1 - exp(-100 a)
-        f32x16 x;   // 100 dz_l (forward-direction sweep) or w_l (second reverse sweep)
+        f32x16 x;   // dz_l (forward-direction sweep; kind 4 applies 100 / 256) or w_l (second reverse sweep)
     };
+    ws.stamp(10);   // (timing builds, tools/ts_report_adj.py: section starts 10 .. 15)
     // ---- seeds
     float gs = a.g_sdf[nn], gg[3], gr[3];
 #pragma unroll
@@ -137,6 +138,7 @@
                                                      FEAT + (4 * b + (i >> 1)) * KS_BYTES + (i & 1) * 1024, 0, STASH_AUX);
     };
 
+    ws.stamp(11);
     // ---- colour lin0^T over the feature rows (pass A of the input map): leftover rows first, then bone by bone
     //      (2 chunks each); per bone the colour network's share of qbar goes to the stash
     {
@@ -189,6 +191,7 @@
         }
     }
 
+    ws.stamp(12);
     // ---- J gb as fragments (the layout of the features): d(phi h)/dq . (R_b gb) per slot
     {
 #pragma unroll 1
@@ -241,14 +244,12 @@
         }
     }
 
+    ws.stamp(13);
     // ---- forward-direction sweep
     auto pre4 = [&](int act_slot, int dz_slot) {
         return [&sh, act_slot, dz_slot](auto T, const char*) {
             constexpr int t = decltype(T)::value;
-            Act2 o{sh.tile_load(act_slot, t), sh.tile_load(dz_slot, t)};
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o.x[i] *= 100.f * BWD_INV;
-            return o;
+            return Act2{sh.tile_load(act_slot, t), sh.tile_load(dz_slot, t)};   // (x = dz_l; kind 4 applies its 100 / 256)
         };
     };
     auto fin4 = [&](h8(&oh)[16], h8(&ol)[16], int w_slot) {
@@ -317,6 +318,7 @@
                                       },
                                       no_store);
 
+    ws.stamp(14);
     // ---- second reverse sweep.  ab_7 = W8[1:, :]^T fb + g_sdf W8[0, :];  zb_7 = sigma'_7 ab_7 + w_7
     auto pre5 = [&](int act_slot, int w_slot) {
         return [&sh, act_slot, w_slot](auto T, const char*) {
@@ -357,6 +359,7 @@
     run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, pre5(HS_A1 + 1, HS_DZ + 1), PhRev2{}, to_regs(ah, al), no_store);   // W2^T -> zb1
     run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 0, HS_DZ + 0), PhRev2{}, to_regs(bh, bl), no_store);   // W1^T -> zb0
 
+    ws.stamp(15);
     // ---- input map (pass B): X-adjoint rows W0^T zb0 + W4x^T zb4, leftover rows first, then bone by bone; per bone the
     //      pull, the Hessian-vector term and the pose gradients
     float gp[3] = {0.f, 0.f, 0.f};

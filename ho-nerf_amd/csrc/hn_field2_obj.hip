@@ -103,7 +103,7 @@ __device__ __forceinline__ void encode_v4(const float v[3], int h, float (&f)[2]
 // whatever the scale of the caller's loss; the outputs are scaled back by 1 / kappa (exact).
 struct Act2 {
     f32x16 v;   // stashed activation a_{l+1} (sigma'(z_l) = 1 - exp(-100 a))
-    f32x16 x;   // second tile: 100 dz_l (forward-direction sweep) or w_l (second reverse sweep)
+    f32x16 x;   // second tile: dz_l (forward-direction sweep; kind 4 applies 100 / 256) or w_l (second reverse sweep)
 };
 struct Act1 {
     f32x16 v;
@@ -231,10 +231,7 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
     auto pre4 = [&](int act_slot, int dz_slot) {
         return [&sh, act_slot, dz_slot](auto T, const char*) {
             constexpr int t = decltype(T)::value;
-            Act2 o{sh.tile_load(act_slot, t), sh.tile_load(dz_slot, t)};
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o.x[i] *= 100.f * BWD_INV;
-            return o;
+            return Act2{sh.tile_load(act_slot, t), sh.tile_load(dz_slot, t)};   // (x = dz_l; kind 4 applies its 100 / 256)
         };
     };
     auto fin4 = [&](h8(&oh)[16], h8(&ol)[16], int w_slot) {

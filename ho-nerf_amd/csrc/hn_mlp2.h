@@ -772,7 +772,7 @@ __device__ __forceinline__ void split_finish(EpiState& st) {
 // two elements per issue slot).  The wave is issue-bound -- every VALU instruction of the epilogue costs ~4 cycles
 // of the same in-order stream that has to issue the MFMAs -- so the instruction count, not the ALU rate, is what
 // matters.  kind: 0 softplus(beta=100), 1 g * sigma'(z) from the stashed activation, 2 relu, 3 identity;
-// adjoint (hn_field2_*_adj): 4 forward-direction sweep  v = z sigma',  w = z (1 - sigma') * pd.x  (pd.x = 100 dz / 256:
+// adjoint (hn_field2_*_adj): 4 forward-direction sweep  v = z sigma',  w = z (1 - sigma') * (pd.x 100 / 256)  (pd.x = dz:
 // w is the second-order source sigma'' u dzb of oracle/field_bwd.py written without a division by sigma');
 // 5 second reverse sweep  v = z sigma' + pd.x;  6 relu mask  v = pd.v > 0 ? z : 0.
 template <int J, int P, int KIND, bool FRAGS, typename PD>
@@ -801,7 +801,9 @@ __device__ __forceinline__ void pair_phase(EpiState& st, const PD& pd) {
         if constexpr (KIND == 3) v = st.z2;
         if constexpr (KIND == 4) {
             v = st.z2 - st.e2;
-            const f32x2 w = st.e2 * f32x2{pd.x[i0], pd.x[i1]};
+            // (pd.x is dz_l as the tape holds it; its factor 100 / 256 is applied HERE, a step after the load: applied where the tile is
+            // loaded -- in the layer's `pre` -- it made the wave wait for the tape's round trip in front of the step's MFMAs)
+            const f32x2 w = st.e2 * (f32x2{pd.x[i0], pd.x[i1]} * f32x2{100.f * BWD_INV, 100.f * BWD_INV});
             st.w[i0] = w[0];
             st.w[i1] = w[1];
         }
@@ -838,6 +840,17 @@ __device__ __forceinline__ void pair_phase(EpiState& st, const PD& pd) {
         }
     }
 }
+#ifndef HN_ADJ_EPI_DELAY
+#define HN_ADJ_EPI_DELAY 0
+#endif
+template <typename T, typename = void>
+struct ph_delay {
+    static constexpr int value = 0;
+};
+template <typename T>
+struct ph_delay<T, std::void_t<decltype(T::delay)>> {
+    static constexpr int value = T::delay;
+};
 template <bool FRAGS, typename Ph, typename PD>
 struct Epi {
     static constexpr bool branchy = Ph::branchy;
@@ -856,11 +869,17 @@ struct Epi {
             split_phase<I, FRAGS>(st);
 #endif
     }
-    // slots Q of NQ: phase calls [Q*48/NQ, (Q+1)*48/NQ)
+    // slots Q of NQ: phase calls [Q*48/NQ, (Q+1)*48/NQ).  A phase with side data from the tape (Ph::delay = D > 0: the adjoint's
+    // kinds 4 and 5) leaves the first D of a 48-slot tile's slots empty and packs its 48 calls into the others: the tile's side
+    // data was requested one step ago and an HBM round trip under load is longer than a step, so the first call's wait is pushed
+    // D MFMAs into the step instead of standing in front of them.
     template <int Q, int NQ>
     __device__ __forceinline__ void run() {
-        constexpr int lo = Q * 48 / NQ, hi = (Q + 1) * 48 / NQ;
-        static_for<hi - lo>([&](auto K) { call<lo + decltype(K)::value>(); });
+        constexpr int D = NQ == 48 ? ph_delay<Ph>::value : 0;
+        if constexpr (Q >= D) {
+            constexpr int lo = (Q - D) * 48 / (NQ - D), hi = (Q - D + 1) * 48 / (NQ - D);
+            static_for<hi - lo>([&](auto K) { call<lo + decltype(K)::value>(); });
+        }
     }
     __device__ __forceinline__ void run_all() {
         static_for<48>([&](auto K) { call<decltype(K)::value>(); });
@@ -985,6 +1004,7 @@ struct PhDsig {
 // 4 and 5, a second tile in .x.
 struct PhFwdDir {
     static constexpr int kind = 4;
+    static constexpr int delay = HN_ADJ_EPI_DELAY;
     static constexpr bool branchy = HN_BRANCHY_REV;
     template <typename I_, typename P_, typename PD>
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD& pd) const {
@@ -994,12 +1014,13 @@ struct PhFwdDir {
             st.e[I & 1] = __builtin_amdgcn_exp2f(pd.v[I] * -K100) * st.z[I & 1];
         } else {
             st.v[I] = st.z[I & 1] - st.e[I & 1];
-            st.w[I] = st.e[I & 1] * pd.x[I];
+            st.w[I] = st.e[I & 1] * (pd.x[I] * (100.f * BWD_INV));
         }
     }
 };
 struct PhRev2 {
     static constexpr int kind = 5;
+    static constexpr int delay = HN_ADJ_EPI_DELAY;
     static constexpr bool branchy = HN_BRANCHY_REV;
     template <typename I_, typename P_, typename PD>
     __device__ __forceinline__ void operator()(I_, P_, EpiState& st, const PD& pd) const {

@@ -56,3 +56,15 @@ for i in range(0, len(r), 50):
     print('chunks %4d..%4d: dma %7d bar %7d mma %8d tail %8d | per chunk %5d' % (i, min(i + 50, len(r)) - 1, *s, r[i:i + 50].sum() / len(r[i:i + 50])))
 print('largest tails', [(int(i), int(r[i, 3])) for i in np.argsort(-r[:, 3])[:16]])
 print('largest dma waits', [(int(i), int(r[i, 0])) for i in np.argsort(-r[:, 0])[:12]])
+
+# sections of the adjoint (stamps 10 .. 15 at their starts; the tile's end is the last stamp)
+names = {10: 'seeds + colour backward (lin4..1^T, lin0^T feature-vector / enc(g) rows)', 11: 'pass A: colour lin0^T over the feature rows, bone by bone',
+         12: 'J gb as fragments', 13: 'forward-direction sweep', 14: 'second reverse sweep', 15: 'pass B: input map, pose gradients'}
+sec = [(int(ids[x]), int(t[x])) for x in range(k) if ids[x] >= 10]
+if sec:
+    first = sec[0][1]
+    print('evaluation part of the tile: %d ticks' % (first - int(t[0])))
+    for i, (sid, ts) in enumerate(sec):
+        te = sec[i + 1][1] if i + 1 < len(sec) else int(t[-1])
+        nch = int(((ids == 1) & (t >= ts) & (t < te)).sum())
+        print('  %-78s %8d ticks  %4d chunks  %6d per chunk' % (names.get(sid, str(sid)), te - ts, nch, (te - ts) // max(nch, 1)))
