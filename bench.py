@@ -503,6 +503,10 @@ def main():
         import datetime
         import torch.distributed as dist
         backend = 'gloo' if share else 'nccl'
+        # stdout carries ONE JSON line: whatever the communicator libraries print while they connect (gloo does) goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         try:
             # an explicit, generous timeout: the fitting legs below keep the ranks apart for tens of seconds between collectives
             if share:
@@ -518,6 +522,9 @@ def main():
                              'rank and HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool; HONERF_BENCH_SHARE_GPU=1 runs the N > 1 code path on ONE GPU over gloo '
                              '(functional check only).\n' % (rank, backend, world, type(e).__name__, e))
             sys.exit(3)
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from honerf_amd import lib as L
     lib = L.load()

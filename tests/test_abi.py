@@ -71,3 +71,26 @@ def test_host_side_code_is_clean_under_address_and_ub_sanitizers():
         r = subprocess.run([os.path.join(san, '_build', exe)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and ok in r.stdout and 'Sanitizer' not in r.stderr and 'runtime error' not in r.stderr, \
             '%s: rc %d\n%s\n%s' % (exe, r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_field_kernels_wait_for_no_tape_load_in_front_of_their_mfmas(built_lib):
+    """A static check of the built field kernels' ISA (tools/isa_early_waits.py): in no weight-chunk step may a vector load issued in
+    that step be waited for before a quarter of the step's MFMAs have run -- that is a memory round trip in front of the matrix work
+    (round 4 found one per step of the adjoint kernels' forward-direction sweep that way: a multiply placed right behind the tape
+    load).  Known and accepted: the 8 steps of the second reverse sweep's first layer in the adjoint modes (2, 4), whose `pre` adds
+    the W8-row term to the loaded tile."""
+    import sys
+    build = os.path.join(ROOT, 'ho-nerf_amd', 'csrc', 'build')
+    objs = [os.path.join(build, f) for f in ('hn_field2_hand.o', 'hn_field2_hand_adj.o', 'hn_field2_obj.o')]
+    if not all(os.path.exists(o) for o in objs) or not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        pytest.skip('object files of the field kernels / llvm-objdump not present')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import isa_early_waits
+    seen = 0
+    for o in objs:
+        for name, (nseg, bad) in isa_early_waits.scan(o, 'k_field2').items():
+            adjoint = name.endswith('<2>') or name.endswith('<4>')
+            assert len(bad) <= (9 if adjoint else 0), (name, bad)
+            assert nseg > 50, (name, nseg)
+            seen += 1
+    assert seen >= 9
