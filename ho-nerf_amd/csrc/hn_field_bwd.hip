@@ -673,12 +673,30 @@ __global__ void k_hand_pull(const float* __restrict__ pts, int n, int ppf, int n
             spread(hv, p, m, fr.frame, b, gp, g_bt, g_T, uniform, lane);
         }
     }
-    if (valid) {   // the 21 grid rows add their bone's share (the caller zeroes `out` unless it accumulates)
-        float* o = out + 3 * (size_t)i;
+    if (valid) {
+        if (MODE == 0 && accumulate == 2) {
+            // the bone's share to its own plane of `out` [N_BONES][n][3]; k_sum_bones adds the planes in bone order.  This is the
+            // TAPE's d sdf / d pts -- the normals the colour network sees in the backward pass's forward tape: summed with atomics
+            // their last bits depended on the order the 21 grid rows arrived in, and one ReLU unit of one sample whose
+            // pre-activation is within rounding of 0 then flipped from run to run (a whole row of a dW moving by 1e-4 of its
+            // largest entry: found as an intermittent mismatch of two runs of the same training step, round 4)
+            float* o = out + ((size_t)blockIdx.y * n + i) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) atomicAdd(o + c, gp[c]);
+            for (int c = 0; c < 3; ++c) o[c] = gp[c];
+        } else {   // the 21 grid rows add their bone's share (the caller zeroes `out` unless it accumulates)
+            float* o = out + 3 * (size_t)i;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(o + c, gp[c]);
+        }
     }
-    (void)accumulate;
+}
+// out[n,3] = sum over the 21 bone planes of part [N_BONES][n][3], in bone order
+__global__ void k_sum_bones(const float* __restrict__ part, int n, float* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n * 3) return;
+    float acc = 0.f;
+    for (int b = 0; b < N_BONES; ++b) acc += part[(size_t)b * n * 3 + t];
+    out[t] = acc;
 }
 
 // ---- orchestration ---------------------------------------------------------------------------------------------
@@ -887,9 +905,11 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     if (obj) {
         hipLaunchKernelGGL(k_enc3_pull<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.GX, DP, nullptr, 0, nullptr, b.g, 0);
     } else {
-        HN_CHECK_HIP(hipMemsetAsync(b.g, 0, N * 3 * sizeof(float), s));
+        // (per-bone planes in b.zb -- [n, 256] floats, free until step 5 -- then summed in bone order: a reproducible tape)
+        static_assert(3 * N_BONES <= H, "the bone planes fit the [n, H] scratch array");
         hipLaunchKernelGGL(k_hand_pull<0>, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.GX, DP,
-                           (const float*)nullptr, b.g, 0, (float*)nullptr, (float*)nullptr);
+                           (const float*)nullptr, b.zb, 2, (float*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(k_sum_bones, g1(N * 3), dim3(256), 0, s, b.zb, n, b.g);
     }
     // 3. colour network forward + backward ------------------------------------------------------------------------
     const float* const* C = f->raw_col_w;

@@ -686,27 +686,52 @@ __global__ __launch_bounds__(256) void k_upsample_wave(const float* __restrict__
         wr[i + 1] = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
     }
     __builtin_amdgcn_wave_barrier();
+    // The two prefix recurrences stay strictly sequential, in torch.cumprod / torch.cumsum order and with the statements of
+    // UpsState::step -- but they run on REGISTERS, every lane computing the same (uniform) chain with element e fetched by
+    // v_readlane from the lane that holds it (slice r = e / 64, lane e % 64).  As loops of lane 0 over the LDS rows each of the
+    // ~2 k steps paid an LDS round trip inside its dependency chain: ~10 us of a ~20 us launch that sits four times on the critical
+    // path of a fitting step.
+    constexpr int UPS_SL = UPS_MAX_K / 64;
+    float areg[UPS_SL], wreg[UPS_SL];
+#pragma unroll
+    for (int r = 0; r < UPS_SL; ++r) {
+        const int e = r * 64 + lane;
+        areg[r] = (e >= 1 && e < k) ? wr[e] : 0.f;   // alpha of section e - 1
+        wreg[r] = 0.f;
+    }
     float sum = 0.f;
-    if (lane == 0) {   // sequential transmittance and weight sum (torch.cumprod / sum order)
+    {
         float T = 1.f;
-        for (int i = 0; i + 1 < k; ++i) {
-            const float alpha = wr[i + 1];
-            const float w = alpha * T + 1e-5f;
-            T = T * (1.f - alpha + 1e-7f);
-            wr[i + 1] = w;
-            sum += w;
+#pragma unroll
+        for (int r = 0; r < UPS_SL; ++r) {
+            const int e_hi = k - r * 64 < 64 ? k - r * 64 : 64;
+            for (int l = (r == 0 ? 1 : 0); l < e_hi; ++l) {
+                const float alpha = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, areg[r]), l));
+                const float w = alpha * T + 1e-5f;
+                T = T * (1.f - alpha + 1e-7f);
+                sum += w;
+                wreg[r] = lane == l ? w : wreg[r];
+            }
         }
     }
-    sum = __shfl(sum, 0, 64);
-    __builtin_amdgcn_wave_barrier();
-    for (int i = 1 + lane; i < k; i += 64) wr[i] = wr[i] / sum;   // pdf (element-wise)
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {   // cdf = [0, cumsum(pdf)], sequential
-        wr[0] = 0.f;
+#pragma unroll
+    for (int r = 0; r < UPS_SL; ++r) wreg[r] = wreg[r] / sum;   // pdf (element-wise)
+    {   // cdf = [0, cumsum(pdf)], sequential
         float run = 0.f;
-        for (int i = 1; i < k; ++i) {
-            run += wr[i];
-            wr[i] = run;
+        float creg[UPS_SL];
+#pragma unroll
+        for (int r = 0; r < UPS_SL; ++r) {
+            creg[r] = 0.f;
+            const int e_hi = k - r * 64 < 64 ? k - r * 64 : 64;
+            for (int l = (r == 0 ? 1 : 0); l < e_hi; ++l) {
+                run += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wreg[r]), l));
+                creg[r] = lane == l ? run : creg[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < UPS_SL; ++r) {
+            const int e = r * 64 + lane;
+            if (e < k) wr[e] = creg[r];   // (entry 0 is 0)
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -714,8 +739,19 @@ __global__ __launch_bounds__(256) void k_upsample_wave(const float* __restrict__
     const float u_step = n_new > 1 ? (u_end - u_start) / (float)(n_new - 1) : 0.f;
     for (int jj = lane; jj < n_new; jj += 64) {
         const float u = (jj < n_new / 2) ? u_start + (float)jj * u_step : u_end - (float)(n_new - 1 - jj) * u_step;
-        int ptr = 0;   // searchsorted(right=True) on a non-decreasing cdf: the number of entries <= u
-        while (ptr < k && wr[ptr] <= u) ++ptr;
+        // searchsorted(right=True) on the non-decreasing cdf: the number of entries <= u, by bisection (a scan from the left paid
+        // an LDS round trip per entry)
+        int ptr = 0;
+        {
+            int hi = k;
+            while (ptr < hi) {
+                const int mid = (ptr + hi) >> 1;
+                if (wr[mid] <= u)
+                    ptr = mid + 1;
+                else
+                    hi = mid;
+            }
+        }
         const int below = ptr - 1 > 0 ? ptr - 1 : 0;
         const int above = ptr < k - 1 ? ptr : k - 1;
         const float c_lo = wr[below], c_hi = wr[above];

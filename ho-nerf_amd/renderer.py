@@ -11,6 +11,8 @@ reproducible; when omitted the draw is made exactly where the reference makes
 it.
 """
 import numpy as np
+import os
+
 import torch
 
 from . import lib as _lib
@@ -23,6 +25,10 @@ def _t_rand(t_rand, shape, device):
     return _lib.f32(t_rand, device).reshape(shape)
 
 
+# HONERF_POISON_WORKSPACES=1 (tests, tools/ws_poison_check.py): workspaces are filled with 0xff bytes (fp32 NaNs, int -1) before every use
+_POISON = os.environ.get('HONERF_POISON_WORKSPACES') == '1'
+
+
 class _Workspace:
     """Grow-only device byte buffer reused across calls (no per-call hipMalloc)."""
 
@@ -32,6 +38,10 @@ class _Workspace:
     def get(self, nbytes, device):
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            if _POISON:
+                self.buf.fill_(0xff)
+        elif _POISON:
+            self.buf.fill_(0xff)      # (every use starts from NaNs: a kernel that reads what the call did not write shows up in its outputs)
         return self.buf
 
 
