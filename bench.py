@@ -498,6 +498,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    # the library's second stream and the extra stream get their hardware queues before the communicator's stream asks for one
+    from honerf_amd.pose import bind_streams
+    bind_streams(dev)
     dist = None
     if world > 1:
         import datetime

@@ -741,6 +741,8 @@ class PipelinedSingleFit:
         L.check(self.lib.hn_side_stream(ctypes.byref(sp)), 'hn_side_stream')
         self.side_ptr = ctypes.c_void_p(sp.value)
         self.side = torch.cuda.ExternalStream(sp.value, device=dev)
+        from .pose import bind_streams
+        bind_streams(dev)
         self.aux = _side_stream(dev)                          # the pose chain's Jacobian (see step); one such stream per device
         self.ev_prm, self.ev_jac = torch.cuda.Event(), torch.cuda.Event()
         e = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)

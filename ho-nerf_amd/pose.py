@@ -170,6 +170,33 @@ def _aux_stream(dev):
     return _AUX_STREAMS[key]
 
 
+_BOUND = set()
+
+
+def bind_streams(dev):
+    """Touch the library's second stream and the extra stream of `dev` NOW, so that the runtime gives them hardware queues of
+    their own before other streams of the process (a communicator's, a data loader's) ask for theirs.  The runtime multiplexes
+    streams onto a few hardware queues (4 by default) in the order of their first use, a later stream shares a queue with an
+    earlier one, and it matters which: a mostly idle stream sharing the caller's queue costs nothing, the object branch's 1.2 ms
+    adjoint kernel in front of the caller's launches costs a millisecond per fitting step (`tools/hw_queue_probe.py`: 2.54 ms with
+    these streams bound first whatever comes later, 3.7 ms when two other streams came first)."""
+    import ctypes
+    dev = torch.device(dev)
+    if dev.type != 'cuda' or str(dev) in _BOUND:
+        return
+    _BOUND.add(str(dev))
+    L = _lib
+    lib = L.load()
+    with torch.cuda.device(dev):
+        sp = ctypes.c_void_p()
+        L.check(lib.hn_side_stream(ctypes.byref(sp)), 'hn_side_stream')
+        side = torch.cuda.ExternalStream(sp.value, device=dev)
+        for st in (side, _aux_stream(dev)):
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=dev)
+            torch.cuda.current_stream(dev).wait_stream(st)
+
+
 class HaloChainFn(torch.autograd.Function):
     """The whole pose side of a fitting_single step as ONE autograd node over the six refine leaves (fitting_single.py:177-235):
     (obj_rot [F,3,2], obj_trans [F,3], palm_rot [F,3,2], palm_trans [F,3], joint_refine_angle [F,20], palm_refine_angle [F,7])
