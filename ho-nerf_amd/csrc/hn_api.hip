@@ -195,6 +195,7 @@ static std::atomic<int> g_quad_max_blocks{[] {
     return e ? atoi(e) : -1;
 }()};
 int quad_max_blocks_override() { return g_quad_max_blocks.load(std::memory_order_relaxed); }
+static std::atomic<int> g_fused_rounds{1};   // hn_debug_fused_rounds
 std::atomic<int> g_pace_phantom{0};
 int pace_phantom_members() { return g_pace_phantom.load(std::memory_order_relaxed); }
 static SideStream g_side[MAX_DEVICES];
@@ -851,6 +852,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
         };
         HN_TRY(sample_points(rays_o, rays_d, th.z_a, n_rays, n_samples, 0, 0.f, th.pts, nullptr, s));
         UpsPre coarse_gather{};
+        const bool fused_rounds = g_fused_rounds.load(std::memory_order_relaxed) != 0;
         if (coarse_compact) {
             // the hand's coarse pass on the samples with a live bone (the record of the final evaluation is written later)
             CompactRec cr;
@@ -864,7 +866,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
             set_launch_orig_idx(nullptr);
             HN_TRY(rc);
             HN_TRY(obj_coarse());
-            if (steps >= 1 && upsample_fused_ok(n_rays, n_samples, n_new)) {
+            if (steps >= 1 && fused_rounds && upsample_fused_ok(n_rays, n_samples, n_new)) {
                 coarse_gather = UpsPre{nullptr, nullptr, 0, 0, nullptr, th.sdf_a, cr.pos, cr.n_dev, cr.sdf_c};   // the first up_sample launch reads through the record
             } else {
                 hipLaunchKernelGGL(k_hand_scatter_sdf, dim3((nc + 255) / 256), dim3(256), 0, s, cr.pos, nc, cr.n_dev, cr.sdf_c, th.sdf_a);
@@ -896,7 +898,8 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
                 } else if (i == 0 && r.which == 0 && coarse_gather.pos != nullptr) {
                     pp = &coarse_gather;
                 }
-                if (!upsample_fused(t.z_a, t.sdf_a, n_rays, r.k, n_new, (float)(64 << i), z_out, zcat, S, col, r.ro, r.rd, more ? t.pts : nullptr, r.st, pp)) {
+                if (!fused_rounds ||
+                    !upsample_fused(t.z_a, t.sdf_a, n_rays, r.k, n_new, (float)(64 << i), z_out, zcat, S, col, r.ro, r.rd, more ? t.pts : nullptr, r.st, pp)) {
                     HN_REQUIRE(pp == nullptr, "render_dual: the fused up_sample launch failed");
                     HN_TRY(upsample(t.z_a, t.sdf_a, n_rays, r.k, n_new, (float)(64 << i), t.z_new, nullptr, r.st));
                     hipLaunchKernelGGL(k_copy_cols, dim3((n_rays * n_new + 255) / 256), dim3(256), 0, r.st, t.z_new, n_rays, n_new, zcat, S, col);
@@ -912,7 +915,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
                 if (i + 1 < steps) {
                     HN_TRY(field_sdf(r.f, t.pts, n_rays * n_new, bt_inv, T_pose, r.nf, r.which == 0 ? rpf * n_new : n_rays * n_new, t.sdf_new,
                                      r.fws, r.fwb, r.st));
-                    if (upsample_fused_ok(n_rays, r.k + n_new, n_new)) {
+                    if (fused_rounds && upsample_fused_ok(n_rays, r.k + n_new, n_new)) {
                         pending[r.which] = true;
                     } else {
                         HN_TRY(merge(t.z_a, t.z_new, t.sdf_a, t.sdf_new, n_rays, r.k, n_new, quirk, t.z_b, t.sdf_b, nullptr, r.st));
@@ -1323,6 +1326,10 @@ int hn_stream_wait(hn_stream_t waiter, hn_stream_t on) {
 }
 int hn_debug_quad_max_blocks(int max_blocks) {
     hn::g_quad_max_blocks.store(max_blocks);
+    return HN_OK;
+}
+int hn_debug_fused_rounds(int on) {
+    hn::g_fused_rounds.store(on != 0 ? 1 : 0);
     return HN_OK;
 }
 int hn_debug_pace_phantom(int members) {

@@ -25,7 +25,7 @@ PRECISIONS = {'fp32': HN_PREC_FP32, 'f16x3': HN_PREC_F16X3, 'f16': HN_PREC_F16}
 # 'fp32': the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32), 5x slower, kept as a second opinion
 DEFAULT_PRECISION = os.environ.get('HONERF_PRECISION', 'f16x3')
 HN_MAX_LAYERS = 9
-HN_VERSION = 113          # the include/honerf.h revision SIGNATURES below was written for
+HN_VERSION = 114          # the include/honerf.h revision SIGNATURES below was written for
 
 c_f = ctypes.c_void_p     # device float*
 c_i = ctypes.c_int
@@ -60,6 +60,7 @@ SIGNATURES = {
     'hn_debug_pace_phantom': (c_i, [c_i]),
     'hn_debug_mfma_probe': (c_i, [c_i, c_i, ctypes.POINTER(ctypes.c_double), c_vp]),
     'hn_debug_quad_max_blocks': (c_i, [c_i]),
+    'hn_debug_fused_rounds': (c_i, [c_i]),
     'hn_ray_gen': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
     'hn_obj_local_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
     'hn_obj_local_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_vp]),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 113 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 114 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -132,6 +132,11 @@ int hn_debug_pace_phantom(int members);
  * because they cannot fill the chip with whole 128-sample tiles.  Results are bit-identical either way.  max_blocks = 0:
  * never; > 0: up to that many blocks; -1: the default.  Process-wide; for tests and A/B timing. */
 int hn_debug_quad_max_blocks(int max_blocks);
+/* The importance rounds of hn_render_dual for small batches run cat_z_vals of the previous round, the gather of the hand's
+ * compacted coarse sdf row, the column copy and the new sample positions inside the up_sample launch (one launch per round and
+ * track).  on = 0: the separate launches (hn_merge, the scatter, hn_upsample, the copy, hn_sample_points) instead; results are
+ * bit-identical either way.  Process-wide; for tests and A/B timing. */
+int hn_debug_fused_rounds(int on);
 
 /* ---- rays -----------------------------------------------------------------------------
  * _xy_to_ray_bundle (utils/utils.py:31-115): NDC xy -> unproject at depth 1 and

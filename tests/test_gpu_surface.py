@@ -372,6 +372,52 @@ def test_far_field_compaction_is_exact_over_a_window_of_frames():
         bounded('far-field compaction over 4 frames: gradient of pose leaf %d vs dense' % i, e, 5e-5)
 
 
+def test_fused_importance_rounds_are_bit_identical():
+    """hn_render_dual's importance rounds for small batches run the previous round's cat_z_vals (with the batch quirk B-1), the
+    gather of the hand's compacted coarse sdf row, the column copy and the new sample positions INSIDE the up_sample launch (one
+    launch per round and track; hn_debug_fused_rounds).  Against the separate launches -- hn_merge, the scatter, hn_upsample, the copy,
+    hn_sample_points --: the final depths and every output of the render bit for bit, for the unbatched renderer (fitting_single:
+    196 rays, far-field skip on and off) and the frame-batched one (fitting_video: 4 frames x 40 rays, the sdf rows of frame 0
+    carried for every frame)."""
+    import bench
+    from honerf_amd import fitting as F, lib as Lm
+    dev = torch.device('cuda')
+    lib = Lm.load()
+    cases = [('single, far-field skip', 40, 1, bench.FIT_RAYS, True), ('single, dense', 40, 1, bench.FIT_RAYS, False), ('window of 4 frames', 41, 4, bench.VID_RAYS, True)]
+    try:
+        for name, seed, n_frames, n_rays, compact in cases:
+            res = {}
+            for fused in (1, 0):
+                Lm.check(lib.hn_debug_fused_rounds(fused), 'hn_debug_fused_rounds')
+                ren, nets, chain, views, _ = bench.build_fit(dev, seed, n_frames, n_rays, 'f16x3', halo=True)
+                ren.compact_far_field = compact
+                if n_frames > 1:
+                    with torch.no_grad():
+                        for i, p in enumerate(chain.parameters()):
+                            p.add_(1e-2 * torch.randn(p.shape, generator=torch.Generator().manual_seed(20 + i)).to(dev))
+                v = views[0]
+                with torch.no_grad():
+                    pose = chain(list(range(n_frames))) if n_frames > 1 else chain()
+                    o, d = F._rays(Lm, v['xy'], v['cam'], n_frames, n_rays)
+                    tr = torch.rand(n_frames * n_rays, 1, generator=torch.Generator().manual_seed(3)).to(dev)
+                    if n_frames > 1:
+                        out = ren.render(o.reshape(n_frames, n_rays, 3), d.reshape(n_frames, n_rays, 3), bench.NEAR, bench.FAR, pose['bt_inv'], pose['T_pose_21'],
+                                         None, torch.inverse(pose['obj_r']), pose['obj_t'], t_rand=tr)
+                    else:
+                        out = ren.render(o, d, bench.NEAR, bench.FAR, pose['bt_inv'][0], pose['T_pose_21'][0], None, pose['obj_r'][0].T.contiguous(),
+                                         pose['obj_t'][0], t_rand=tr)
+                res[fused] = ({k: x.detach().clone() for k, x in out.items() if isinstance(x, torch.Tensor)}, ren.last_z_vals.clone())
+            assert torch.equal(res[1][1], res[0][1]), name + ': final depths'
+            assert float(res[1][1].std()) > 0
+            for k in res[1][0]:
+                if k.startswith('gradient_error'):      # sums accumulated with float atomics: equal to rounding in ANY two runs
+                    assert abs(float(res[1][0][k].sum()) - float(res[0][0][k].sum())) <= 1e-6 * abs(float(res[0][0][k].sum())) + 1e-12, (name, k)
+                else:
+                    assert torch.equal(res[1][0][k], res[0][0][k]), '%s: %s' % (name, k)
+    finally:
+        Lm.check(lib.hn_debug_fused_rounds(1), 'hn_debug_fused_rounds')
+
+
 def test_window_step_side_stream_equals_single_stream():
     """fit_backward on a fitting_video window evaluates the stable term and the pose regularisers on a second stream beside the
     render (forward and backward).  The same step with everything on one stream: same loss terms, same gradients of the six
