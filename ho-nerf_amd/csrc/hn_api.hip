@@ -50,9 +50,10 @@ int composite1_bwd(const float*, const float*, const float*, const float*, const
 int composite2_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
                    float*, float*, float*, hipStream_t);
 int alpha_bwd_up(const float*, const float*, const float*, const float*, const float*, int, int, float, float, const float*, const float*, const float*,
-                 float*, float*, float*, const int*, const int*, const float*, float*, float*, float*, float* const*, const size_t*, int, hipStream_t);
+                 float*, float*, float*, const int*, const int*, const float*, float*, float*, float*, float* const*, const size_t*, int, hipStream_t, float* g_rays_d_samples = nullptr);
 int obj_rays_bwd(const float*, const float*, int, int, int, float, const float*, const float*, const float*, const float*, const float*, const float*,
-                 float*, float*, float*, float*, hipStream_t, bool transposed = false);
+                 float*, float*, float*, float*, hipStream_t, bool transposed = false, float* part = nullptr, unsigned* counter = nullptr,
+                 const float* gd_alpha_samples = nullptr, const float* gd_colour_samples = nullptr);
 int dual_prologue(const float*, const float*, const float*, const float*, int, int, float*, float*, const float*, int, float, float, float, float*, float*,
                   float*, int, hipStream_t, bool transposed = false);
 int mat3_inverse(const float*, int, float*, hipStream_t);
@@ -255,6 +256,11 @@ static int join_from(SideStream* x, hipStream_t s) {
 static thread_local const int* g_launch_n_pts_dev = nullptr;
 const int* launch_n_pts_dev() { return g_launch_n_pts_dev; }
 void set_launch_n_pts_dev(const int* p) { g_launch_n_pts_dev = p; }
+// (set by the caller around an object adjoint launch: g_rays_d is [n, 3], one row per SAMPLE, stored -- the caller sums the rows of a
+// ray in a fixed order -- instead of [n / spr, 3] accumulated with atomics)
+static thread_local bool g_launch_dir_per_sample = false;
+bool launch_dir_per_sample() { return g_launch_dir_per_sample; }
+void set_launch_dir_per_sample(bool on) { g_launch_dir_per_sample = on; }
 static thread_local const int* g_launch_orig_idx = nullptr;
 const int* launch_orig_idx() { return g_launch_orig_idx; }
 void set_launch_orig_idx(const int* p) { g_launch_orig_idx = p; }
@@ -1022,6 +1028,11 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     float *g_ah = ar.f(N), *g_ao = ar.f(N), *g_rgbh = ar.f(N * 3), *g_rgbo = ar.f(N * 3);
     float *pts_h = ar.f(N * 3), *dists_h = ar.f(N), *pts_o = ar.f(N * 3), *dists_o = ar.f(N);
     float *gs_h = ar.f(N), *gg_h = ar.f(N * 3), *gd_h = ar.f(R3), *gs_o = ar.f(N), *gg_o = ar.f(N * 3), *gd_o = ar.f(R3);
+    float* rays_part = ar.f((size_t)n_rays * 12);                                   // k_obj_rays_bwd: the rays' addends of g_Ro / g_To
+    unsigned* rays_counter = reinterpret_cast<unsigned*>(ar.f(64));
+    float* gd_os = ar.f(N * 3);                                                     // the object's alpha stage: d loss / d rays_d per sample
+    float* gdir_os = ar.f(N * 3);                                                   // ... and its colour network's
+    bool dir_per_sample = false;
     float *gp_h = ar.f(N * 3), *gp_o = ar.f(N * 3), *gdir_h = ar.f(R3), *gdir_o = ar.f(R3);
     float *go_h = ar.f(R3), *gdd_h = ar.f(R3), *g_ro2 = ar.f(R3), *g_rd2 = ar.f(R3);
     const size_t bws_h = bwd::field_bwd_workspace_bytes(hand, hand_cap(hand, N)), bws_o = bwd::field_bwd_workspace_bytes(obj, (int)N);
@@ -1080,12 +1091,13 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_l, d_l, so, ro_t));
     HN_TRY(sample_points(o_l, d_l, z, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
     {
-        float* zb[3] = {gd_o, g_Ro, g_To};
-        const size_t zn[3] = {R3, (size_t)n_frames * 9, (size_t)n_frames * 3};
-        // (gd_o is accumulated into by this very launch: zeroed by its own fill in front)
-        HN_CHECK_HIP(hipMemsetAsync(gd_o, 0, R3 * sizeof(float), so));
-        HN_TRY(alpha_bwd_up(sdf_o, grad_o, d_l, z, g_ao, n, S, sample_dist, obj->inv_s, g_sdf_o, g_grad_o, g_eik != nullptr ? g_eik + 1 : nullptr, gs_o, gg_o, gd_o,
-                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, zb + 1, zn + 1, 2, so));
+        // (g_Ro / g_To are written, not accumulated into, by k_obj_rays_bwd's last block; its counter must start at zero)
+        float* zb[4] = {gd_o, g_Ro, g_To, reinterpret_cast<float*>(rays_counter)};
+        const size_t zn[4] = {R3, (size_t)n_frames * 9, (size_t)n_frames * 3, 1};
+        // (the alpha stage's d loss / d rays_d goes out per SAMPLE, gd_os, and is summed per ray by k_obj_rays_bwd in sample order:
+        // summed here with atomics per ray, d loss / d Ro differed in its last bits from run to run)
+        HN_TRY(alpha_bwd_up(sdf_o, grad_o, d_l, z, g_ao, n, S, sample_dist, obj->inv_s, g_sdf_o, g_grad_o, g_eik != nullptr ? g_eik + 1 : nullptr, gs_o, gg_o, nullptr,
+                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, zb + 1, zn + 1, 3, so, gd_os));
     }
     if (side != nullptr) HN_TRY(gate_to(side, s));
     if (compact) {
@@ -1106,11 +1118,19 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
                                    g_T_pose, bwh, bws_h, s, tp_h, grad_h, rgb_h));
     }
     if (want_rays) HN_TRY(sample_points_bwd(z, gp_h, n_rays, S, 1, sample_dist, go_h, gdd_h, s));
-    HN_TRY(bwd::field_eval_bwd(obj, pts_o, d_l, n, S, nullptr, nullptr, 1, n, gs_o, gg_o, g_rgbo, gp_o, gdir_o, nullptr, nullptr, bwo,
-                               bws_o, so, tp_o, grad_o, rgb_o));
+    {
+        // (the colour network's d loss / d rays_d per SAMPLE for f16x3 fields, summed per ray by k_obj_rays_bwd: no atomics)
+        const bool per_sample = obj->v2_adj != nullptr;
+        set_launch_dir_per_sample(per_sample);
+        const int rc = bwd::field_eval_bwd(obj, pts_o, d_l, n, S, nullptr, nullptr, 1, n, gs_o, gg_o, g_rgbo, gp_o, per_sample ? gdir_os : gdir_o, nullptr,
+                                           nullptr, bwo, bws_o, so, tp_o, grad_o, rgb_o);
+        set_launch_dir_per_sample(false);
+        HN_TRY(rc);
+        dir_per_sample = per_sample;
+    }
     // behind the object's adjoint: the ray map and the adjoint of convert_obj_to_local in one launch
-    HN_TRY(obj_rays_bwd(z, gp_o, n_frames, rpf, S, sample_dist, gd_o, gdir_o, rays_o, rays_d, Ro, To, want_rays ? g_ro2 : nullptr,
-                        want_rays ? g_rd2 : nullptr, g_Ro, g_To, so, ro_t));
+    HN_TRY(obj_rays_bwd(z, gp_o, n_frames, rpf, S, sample_dist, nullptr, dir_per_sample ? nullptr : gdir_o, rays_o, rays_d, Ro, To, want_rays ? g_ro2 : nullptr,
+                        want_rays ? g_rd2 : nullptr, g_Ro, g_To, so, ro_t, rays_part, rays_counter, gd_os, dir_per_sample ? gdir_os : nullptr));
     HN_REQUIRE(!no_join || (!want_rays && side != nullptr), "HN_DUAL_BWD_NO_JOIN: no ray gradients, and the device's second stream");
     if (side != nullptr && !no_join) HN_TRY(join_from(side, s));
     if (want_rays) {

@@ -43,6 +43,7 @@ const int* launch_n_pts_dev();
 void set_launch_n_pts_dev(const int* p);
 const int* launch_orig_idx();
 void set_launch_orig_idx(const int* p);
+bool launch_dir_per_sample();     // hn_api.hip: the object adjoint launch writes d loss / d rays_d per sample (set around the launch)
 int quad_max_blocks_override();   // hn_debug_quad_max_blocks: -1 = default selection of the latency-form kernels
 int pace_phantom_members();    // hn_debug_pace_phantom: members that never arrive at the XCD meetings (timeout-path test hook), 0 = off
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): `mask` is the kernel's own

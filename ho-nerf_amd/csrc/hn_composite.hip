@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void k_alpha_bwd_up(const float* __restrict__ 
                                                       const float* __restrict__ g_eik, float* __restrict__ gs, float* __restrict__ gg,
                                                       float* __restrict__ g_rays_d, const int* __restrict__ pos, const int* __restrict__ n_dev,
                                                       const float* __restrict__ g_rgb, float* __restrict__ gs_c, float* __restrict__ gg_c,
-                                                      float* __restrict__ gr_c, AlphaUpZero zero) {
+                                                      float* __restrict__ gr_c, AlphaUpZero zero, float* __restrict__ g_rays_d_s) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -784,7 +784,11 @@ __global__ __launch_bounds__(256) void k_alpha_bwd_up(const float* __restrict__ 
             }
         }
     }
-    if (g_rays_d != nullptr) {
+    if (g_rays_d_s != nullptr) {   // per SAMPLE, summed per ray in sample order by the caller's next kernel (k_obj_rays_bwd): no atomics, the same bits in every run
+        g_rays_d_s[3 * (size_t)i] = gtc * q0;
+        g_rays_d_s[3 * (size_t)i + 1] = gtc * q1;
+        g_rays_d_s[3 * (size_t)i + 2] = gtc * q2;
+    } else if (g_rays_d != nullptr) {
         const int ray0 = __shfl(ray, 0, 64);
         const bool whole = __all(ray == ray0) && __popcll(__ballot(1)) == 64;
         if (whole) {
@@ -806,7 +810,7 @@ __global__ __launch_bounds__(256) void k_alpha_bwd_up(const float* __restrict__ 
 int alpha_bwd_up(const float* sdf, const float* grad, const float* rays_d, const float* z, const float* g_alpha, int n, int spr, float sample_dist,
                  float inv_s, const float* g_sdf_out, const float* g_grad_out, const float* g_eik, float* gs, float* gg, float* g_rays_d,
                  const int* pos, const int* n_dev, const float* g_rgb, float* gs_c, float* gg_c, float* gr_c, float* const* zero_bufs,
-                 const size_t* zero_sizes, int n_zero, hipStream_t s) {
+                 const size_t* zero_sizes, int n_zero, hipStream_t s, float* g_rays_d_samples) {
     HN_REQUIRE(spr > 0 && n_zero <= 4, "samples_per_ray must be positive, at most four buffers to zero");
     if (n == 0) return HN_OK;
     AlphaUpZero zl{};
@@ -817,7 +821,7 @@ int alpha_bwd_up(const float* sdf, const float* grad, const float* rays_d, const
         most = most > zl.n[b] ? most : zl.n[b];
     }
     hipLaunchKernelGGL(k_alpha_bwd_up, dim3((most + 255) / 256), dim3(256), 0, s, sdf, grad, rays_d, z, g_alpha, n, spr, sample_dist, inv_s, g_sdf_out,
-                       g_grad_out, g_eik, gs, gg, g_rays_d, pos, n_dev, g_rgb, gs_c, gg_c, gr_c, zl);
+                       g_grad_out, g_eik, gs, gg, g_rays_d, pos, n_dev, g_rgb, gs_c, gg_c, gr_c, zl, g_rays_d_samples);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

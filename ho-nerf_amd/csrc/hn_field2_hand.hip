@@ -71,6 +71,8 @@ struct Hand2Args {
     unsigned* xsync;       // 16 zeroed counters (8 XCDs x {members, arrivals}) or NULL: see "XCD pacing" in the kernel
     const int* n_pts_dev;  // NULL, or the sample count on the DEVICE (<= n_pts): a compacted list whose length the host does not know
     const int* orig_idx;   // NULL, or per sample of a compacted list its index in the dense list (what the frame is taken from)
+    float* pose_part;      // adjoint, ONE frame: NULL, or [gridDim.x * 4][21 * 12] -- every wave's own sums of the pose-gradient addends
+                           // (k_pose_part_reduce adds the rows in row order: the same bits in every run; atomics otherwise)
 };
 
 // stash slots of one wave (32 KiB each)
@@ -98,6 +100,8 @@ enum {
 };
 constexpr int FEAT_BLOCKS = 4 * N_BONES;     // first leftover block index
 constexpr int STAGE_BYTES = 8 * 1024;        // LDS staging of one bone's 4 fragment pairs (Jacobian pass)
+constexpr int POSE_ROW = 256;                // floats per wave: 21 bones x 12 pose-gradient addends (Hand2Args::pose_part)
+constexpr size_t HAND2_LDS_POSE = 2 * CHUNK_MAX + WG_WAVES * STAGE_BYTES + 16;   // (+ 16: the 4 per-wave bone masks of the culling)
 
 constexpr int HB_HID = chunk_bytes(1, 16, true);
 constexpr int HB_BWD = chunk_bytes(1, 16, false);
@@ -385,7 +389,11 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31;
     const int h = lane >> 5;
-    StashT<(MODE <= 1) ? STASH_ST_AUX : STASH_AUX> sh;   // (evaluation kernels: write-back stores; taped / adjoint kernels: nt -- hn_mlp2.h)
+#ifndef HN_ADJ_WB
+#define HN_ADJ_WB 0   // (A/B, round 4: write-back stores for the adjoint kernel's w_l tiles too, in the hope that the second reverse sweep
+                      //  finds them in L2 / MALL: k_field2_hand<4> 0.933 -> 0.971 ms.  nt stays.)
+#endif
+    StashT<(MODE <= 1 || (HN_ADJ_WB && MODE == 4)) ? STASH_ST_AUX : STASH_AUX> sh;   // (evaluation kernels: write-back stores; taped / adjoint kernels: nt -- hn_mlp2.h)
     sh.init(a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * N_SLOTS * SLOT_F4, N_SLOTS, lane);
     constexpr int FEAT = HS_FEAT * SLOT_BYTES;   // byte offset of the feature fragment blocks
     constexpr int LEFT = HS_LEFT * SLOT_BYTES;   // ... of the leftover values
@@ -411,6 +419,13 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
     XcdPace xp;
     xp.init(a.xsync);
     const int full_rounds = n_tiles / (int)gridDim.x;
+    float* const prow = reinterpret_cast<float*>(lds + HAND2_LDS_POSE) + wave * POSE_ROW;   // this wave's pose-gradient sums (adjoint modes)
+    if constexpr (RUN_ADJ) {
+        if (a.pose_part != nullptr) {
+            for (int i = lane; i < POSE_ROW; i += 64) prow[i] = 0.f;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     for (int tile = blockIdx.x, it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
         if (xp.on() && it >= 1 && it < full_rounds && it % XCD_PACE_EVERY == 0) xp.meet(it / XCD_PACE_EVERY);
         ws.stamp(6);   // (timing builds: tile start)
@@ -1141,6 +1156,26 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
             a.rgb[3 * n + 2] = rgb[2];
         }
     }
+    if constexpr (RUN_ADJ) {
+        if (a.pose_part != nullptr) {   // (workgroups without a tile write their zeros: the reduction reads every row)
+            __builtin_amdgcn_wave_barrier();
+            float* row = a.pose_part + ((size_t)blockIdx.x * WG_WAVES + wave) * (N_BONES * 12);
+            for (int i = lane; i < N_BONES * 12; i += 64) row[i] = prow[i];
+        }
+    }
+}
+
+// out += the rows of part [rows][21 * 12] added in row order: g_bt_inv [21,4,4] rows 0..2 (12 values per bone), g_T_pose [21,3] = minus
+// the translation column's sums (the statement of the adjoint kernel's atomics, hn_field2_hand_adj.inl)
+static __global__ __launch_bounds__(256) void k_pose_part_reduce(const float* __restrict__ part, int rows, float* __restrict__ g_bt_inv,
+                                                          float* __restrict__ g_T_pose) {
+    const int t = threadIdx.x;
+    if (t >= N_BONES * 12) return;
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc += part[(size_t)r * (N_BONES * 12) + t];
+    const int b = t / 12, k = t % 12;
+    if (g_bt_inv != nullptr) g_bt_inv[b * 16 + k] += acc;
+    if (g_T_pose != nullptr && (k & 3) == 3) g_T_pose[b * 3 + (k >> 2)] -= acc;
 }
 
 // the kernels proper: k_field2_hand<MODE> (fp32-equivalent, the names the profiles of every round carry) and the
@@ -1154,7 +1189,7 @@ __global__ __launch_bounds__(256) void k_field2_hand_f16(const Hand2Args a) {
     field2_hand_body<MODE, 1>(a);
 }
 
-constexpr size_t HAND2_LDS = 2 * CHUNK_MAX + WG_WAVES * STAGE_BYTES + 16;   // + the 4 per-wave bone masks (culling)
+constexpr size_t HAND2_LDS = HAND2_LDS_POSE + WG_WAVES * POSE_ROW * sizeof(float);   // + the waves' pose-gradient rows (adjoint modes)
 
 static int hand2_grid(int n_pts, int n_cus) {
     const int n_tiles = (n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
@@ -1267,8 +1302,10 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
     return HN_OK;
 }
 #else
+static size_t pose_part_bytes(int grid) { return (((size_t)grid * WG_WAVES * N_BONES * 12 * sizeof(float)) + 255) & ~size_t(255); }
 size_t field2_hand_adj_workspace_bytes(int n_pts, int n_cus) {
-    return (size_t)hand2_grid(n_pts, n_cus) * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
+    const int grid = hand2_grid(n_pts, n_cus);
+    return (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4) + pose_part_bytes(grid);
 }
 
 // bytes of the tape a taped full evaluation leaves for the adjoint launch: the adjoint's stash slots per sample TILE
@@ -1326,6 +1363,17 @@ int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const
     int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = hand2_grid(n_pts, n_cus);
+    // ONE frame (fitting_single): every wave sums its pose-gradient addends in LDS and writes one row; the rows are added in row
+    // order behind the launch -- bit-reproducible pose gradients (several frames: float atomics, as before).  The rows live
+    // behind the stash in the workspace (the adjoint from a tape has the whole workspace free).
+    const size_t stash_bytes = (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
+    const bool det = n_frames == 1 && (g_bt_inv != nullptr || g_T_pose != nullptr) && workspace != nullptr &&
+                     workspace_bytes >= (tape != nullptr ? pose_part_bytes(grid) : stash_bytes + pose_part_bytes(grid));
+    if (det) a.pose_part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (tape != nullptr ? 0 : stash_bytes));
+    auto reduce_rows = [&]() {
+        if (!det) return;
+        hipLaunchKernelGGL(k_pose_part_reduce, dim3(1), dim3(256), 0, stream, a.pose_part, grid * WG_WAVES, g_bt_inv, g_T_pose);
+    };
     if (tape != nullptr) {
         a.blob = reinterpret_cast<const char*>(f->v2_adjonly);
         a.blob_bytes = f->v2_adjonly_bytes;
@@ -1335,10 +1383,11 @@ int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const
         static std::atomic<uint64_t> lds_adjonly{0};
         HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<4>), (int)HAND2_LDS, &lds_adjonly));
         hipLaunchKernelGGL(k_field2_hand<4>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
+        reduce_rows();
         HN_LAUNCH_CHECK();
         return HN_OK;
     }
-    const size_t need = (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
+    const size_t need = stash_bytes;
     if (workspace == nullptr || workspace_bytes < need) {
         set_error("adjoint workspace too small: %zu < %zu", workspace_bytes, need);
         return HN_ENOMEM;
@@ -1346,6 +1395,7 @@ int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const
     static std::atomic<uint64_t> lds_adj{0};
     HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<2>), (int)HAND2_LDS, &lds_adj));
     hipLaunchKernelGGL(k_field2_hand<2>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
+    reduce_rows();
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

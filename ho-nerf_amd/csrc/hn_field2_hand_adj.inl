@@ -467,7 +467,10 @@
                     if (uni) {
 #pragma unroll
                         for (int k = 0; k < 12; ++k) vals[k] = wave_sum64(mine ? vals[k] : 0.f);
-                        if (lane == 0) {
+                        if (lane == 0 && a.pose_part != nullptr) {   // one frame: this wave's own row (LDS), added up in row order afterwards
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) prow[b * 12 + k] += vals[k];
+                        } else if (lane == 0) {
                             if (a.g_bt_inv != nullptr) {
                                 float* gm = a.g_bt_inv + ((size_t)frame0 * N_BONES + b) * 16;
 #pragma unroll

@@ -39,7 +39,8 @@ struct Obj2Args {
     const float* g_grad;   // [n,3]
     const float* g_rgb;    // [n,3]
     float* g_pts;          // [n,3]
-    float* g_rays_d;       // [n/spr,3] or NULL: accumulated with atomics (zeroed by the launcher)
+    float* g_rays_d;       // [n/spr,3] or NULL: accumulated with atomics (zeroed by the launcher); with dir_per_sample: [n,3], stored
+    int dir_per_sample;
 };
 
 // stash slots of one wave (32 KiB each)
@@ -434,9 +435,14 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
         a.g_pts[3 * n + 1] = gp[1];
         a.g_pts[3 * n + 2] = gp[2];
         if (a.g_rays_d != nullptr) {
-            const int ray = n / a.spr;
+            if (a.dir_per_sample) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) atomicAdd(a.g_rays_d + 3 * ray + c, gdir[c] * inv_kappa);
+                for (int c = 0; c < 3; ++c) a.g_rays_d[3 * (size_t)n + c] = gdir[c] * inv_kappa;
+            } else {
+                const int ray = n / a.spr;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) atomicAdd(a.g_rays_d + 3 * ray + c, gdir[c] * inv_kappa);
+            }
         }
     }
 }
@@ -1050,7 +1056,8 @@ int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays
     int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = obj2_grid(n_pts, n_cus);
-    if (g_rays_d != nullptr) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n_pts / a.spr) * 3 * sizeof(float), stream));
+    a.dir_per_sample = launch_dir_per_sample() ? 1 : 0;
+    if (g_rays_d != nullptr && !a.dir_per_sample) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n_pts / a.spr) * 3 * sizeof(float), stream));
     if (tape != nullptr) {
         a.blob = reinterpret_cast<const char*>(f->v2_adjonly);
         a.blob_bytes = f->v2_adjonly_bytes;

@@ -316,11 +316,15 @@ __global__ __launch_bounds__(256) void k_obj_rays_bwd(const float* __restrict__ 
                                                       const float* __restrict__ gd_alpha, const float* __restrict__ gd_colour,
                                                       const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ Ro,
                                                       const float* __restrict__ To, int rays_per_frame, float* __restrict__ g_o,
-                                                      float* __restrict__ g_d, float* __restrict__ g_Ro, float* __restrict__ g_To, int tr) {
+                                                      float* __restrict__ g_d, float* __restrict__ g_Ro, float* __restrict__ g_To, int tr,
+                                                      float* __restrict__ part, unsigned* __restrict__ counter, const float* __restrict__ gd_alpha_s,
+                                                      const float* __restrict__ gd_colour_s) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= n_rays) return;
-    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool active = ray < n_rays;
+    if (!active && part == nullptr) return;
+    if (active) {
+    float acc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = lane; k < n; k += 64) {
         const size_t i = (size_t)ray * n + k;
         float t = z[i];
@@ -330,10 +334,12 @@ __global__ __launch_bounds__(256) void k_obj_rays_bwd(const float* __restrict__ 
             const float g = g_pts[3 * i + c];
             acc[c] += g;
             acc[3 + c] += t * g;
+            if (gd_alpha_s != nullptr) acc[6 + c] += gd_alpha_s[3 * i + c];   // the alpha stage's d loss / d rays_d, per sample
+            if (gd_colour_s != nullptr) acc[9 + c] += gd_colour_s[3 * i + c];   // the colour network's
         }
     }
 #pragma unroll
-    for (int c = 0; c < 6; ++c)
+    for (int c = 0; c < 12; ++c)
         for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
     const int f = ray / rays_per_frame;
     const float* R = Ro + 9 * f;
@@ -341,22 +347,61 @@ __global__ __launch_bounds__(256) void k_obj_rays_bwd(const float* __restrict__ 
     const float go[3] = {acc[0], acc[1], acc[2]};
     float gd[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) gd[c] = acc[3 + c] + gd_alpha[3 * ray + c] + (gd_colour != nullptr ? gd_colour[3 * ray + c] : 0.f);
+    for (int c = 0; c < 3; ++c)
+        gd[c] = acc[3 + c] + (gd_alpha_s != nullptr ? acc[6 + c] : gd_alpha[3 * ray + c]) +
+                (gd_colour_s != nullptr ? acc[9 + c] : (gd_colour != nullptr ? gd_colour[3 * ray + c] : 0.f));
     // lanes 0..8: an element of g_Ro; 9..11: of g_To; 12..14 / 15..17: of g_o / g_d.  tr: `Ro` (and g_Ro) hold the transpose of
     // the rotation that was applied (k_obj_local_fwd): element (r, c) of the rotation is R[sr r + sc c]
     const int sr = tr ? 1 : 3, sc = tr ? 3 : 1;
+    // g_Ro / g_To: with `part` (the two-field render's backward pass) every ray writes its 12 addends to part [n_rays][12] and the
+    // LAST block to finish sums them per frame in ray order -- a fixed order: the same bits in every run, where float atomics
+    // gave the same value only to rounding (and a fit's pose a different last bit per run)
     if (lane < 9) {
         const int r = lane / 3, c = lane % 3;
-        atomicAdd(g_Ro + 9 * f + sr * r + sc * c, go[r] * (o[3 * ray + c] - T[c]) + gd[r] * d[3 * ray + c]);
+        const float v = go[r] * (o[3 * ray + c] - T[c]) + gd[r] * d[3 * ray + c];
+        if (part != nullptr)
+            part[(size_t)ray * 12 + sr * r + sc * c] = v;
+        else
+            atomicAdd(g_Ro + 9 * f + sr * r + sc * c, v);
     } else if (lane < 12) {
         const int c = lane - 9;
-        atomicAdd(g_To + 3 * f + c, -(R[sc * c] * go[0] + R[sr + sc * c] * go[1] + R[2 * sr + sc * c] * go[2]));
+        const float v = -(R[sc * c] * go[0] + R[sr + sc * c] * go[1] + R[2 * sr + sc * c] * go[2]);
+        if (part != nullptr)
+            part[(size_t)ray * 12 + 9 + c] = v;
+        else
+            atomicAdd(g_To + 3 * f + c, v);
     } else if (lane < 15 && g_o != nullptr) {
         const int c = lane - 12;
         g_o[3 * ray + c] = R[sc * c] * go[0] + R[sr + sc * c] * go[1] + R[2 * sr + sc * c] * go[2];
     } else if (lane >= 15 && lane < 18 && g_d != nullptr) {
         const int c = lane - 15;
         g_d[3 * ray + c] = R[sc * c] * gd[0] + R[sr + sc * c] * gd[1] + R[2 * sr + sc * c] * gd[2];
+    }
+    }   // active
+    if (part == nullptr) return;
+    // last block finalises (a counter that is zero before the launch and zero again after it)
+    __shared__ unsigned is_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = atomicAdd(counter, 1u) + 1u;
+        is_last = done == gridDim.x ? 1u : 0u;
+        if (is_last) *counter = 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const int n_frames = (n_rays + rays_per_frame - 1) / rays_per_frame;
+    for (int t = threadIdx.x; t < n_frames * 12; t += blockDim.x) {
+        const int fr = t / 12, e = t % 12;
+        const int r0 = fr * rays_per_frame, r1 = r0 + rays_per_frame < n_rays ? r0 + rays_per_frame : n_rays;
+        const volatile float* p = part;
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) acc += p[(size_t)r * 12 + e];
+        if (e < 9)
+            g_Ro[9 * fr + e] = acc;
+        else
+            g_To[3 * fr + e - 9] = acc;
     }
 }
 
@@ -1010,12 +1055,12 @@ int dual_prologue(const float* o, const float* d, const float* Ro, const float* 
 
 int obj_rays_bwd(const float* z, const float* g_pts, int n_frames, int rpf, int n, float sample_dist, const float* gd_alpha, const float* gd_colour,
                  const float* o, const float* d, const float* Ro, const float* To, float* g_o, float* g_d, float* g_Ro, float* g_To, hipStream_t s,
-                 bool transposed) {
+                 bool transposed, float* part, unsigned* counter, const float* gd_alpha_samples, const float* gd_colour_samples) {
     const int n_rays = n_frames * rpf;
     if (n_rays == 0) return HN_OK;
-    HN_REQUIRE(n >= 1 && rpf >= 1 && g_Ro != nullptr && g_To != nullptr && gd_alpha != nullptr, "obj_rays_bwd: bad arguments");
+    HN_REQUIRE(n >= 1 && rpf >= 1 && g_Ro != nullptr && g_To != nullptr && (gd_alpha != nullptr || gd_alpha_samples != nullptr), "obj_rays_bwd: bad arguments");
     hipLaunchKernelGGL(k_obj_rays_bwd, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, g_pts, n_rays, n, sample_dist, gd_alpha, gd_colour, o, d, Ro, To, rpf,
-                       g_o, g_d, g_Ro, g_To, transposed ? 1 : 0);
+                       g_o, g_d, g_Ro, g_To, transposed ? 1 : 0, counter != nullptr ? part : nullptr, counter, gd_alpha_samples, gd_colour_samples);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

@@ -670,6 +670,17 @@ class PoseAdam:
             v = st['exp_avg_sq'].to(device=p.device, dtype=torch.float32).reshape(p.shape).contiguous().clone()
             self.state[id(p)] = [m, v, int(float(st['step']))]
 
+    def ensure_state(self, p):
+        """The moment buffers of `p`, created (zero) on torch's CURRENT stream if they do not exist yet.  A caller that steps on
+        another stream (`step(stream=...)`) creates them beforehand and orders that stream behind the fills: created lazily inside
+        such a step, the zero fills sat on the current stream behind a millisecond of queued kernels while the Adam launch on
+        the other stream had already read -- and written -- the buffers (PipelinedSingleFit's first step, found by the
+        bit-reproducibility test of round 4)."""
+        st = self.state.get(id(p))
+        if st is None:
+            st = self.state[id(p)] = [torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format), 0]
+        return st
+
     @torch.no_grad()
     def step(self, only=None, stream=None):
         """only: restrict the step to these parameters (the pipelined fitting step updates the hand's and the object's leaves on
@@ -686,9 +697,7 @@ class PoseAdam:
         sizes, lrs, steps = (ctypes.c_int * n)(), (ctypes.c_float * n)(), (ctypes.c_int * n)()
         keep = []
         for i, (p, lr) in enumerate(todo):
-            st = self.state.get(id(p))
-            if st is None:
-                st = self.state[id(p)] = [torch.zeros_like(p, memory_format=torch.contiguous_format), torch.zeros_like(p, memory_format=torch.contiguous_format), 0]
+            st = self.ensure_state(p)
             st[2] += 1                                   # torch counts the steps per parameter
             g = p.grad if (p.grad.is_contiguous() and p.grad.dtype == torch.float32) else p.grad.contiguous().float()
             keep.append(g)
@@ -771,6 +780,8 @@ class PipelinedSingleFit:
                 view.copy_(p.detach().reshape(view.shape))
                 p.data = view
         self._homes = tuple((getattr(ch, k), view.data_ptr()) for k, view in homes.items())
+        for k in homes:
+            optimizer.ensure_state(getattr(ch, k))     # (before the second stream is ordered behind this one, below)
         self._jitter, self._jitter_at = None, 0
         g = self.g45
         self.grads = {'obj_rot': g[:, 36:42].view(1, 3, 2), 'obj_trans': g[:, 42:45], 'palm_rot': g[:, 27:33].view(1, 3, 2), 'palm_trans': g[:, 33:36],

@@ -595,6 +595,41 @@ def test_device_loss_terms_video(golden):
         assert_close(gr, g['mid_g_' + name], 1e-5, 'video g_%s (device)' % name)
 
 
+def test_fitting_single_is_bit_reproducible():
+    """"bit-identical to 1-GPU runs given per-frame seeds" for the frame-sharded fits (C4).  Two runs of the same
+    fitting_single frame -- same initial leaves, same pixels, same jitter -- give the SAME BITS in every leaf, its gradient and
+    the loss after 12 optimiser steps, in the pipelined form and through autograd: the sums over samples that end in the pose
+    leaves (d / d bt_inv, d / d T_pose: one row per wave added in row order, k_pose_part_reduce; d / d Ro, d / d To: the rays'
+    addends added in ray order by the last block of k_obj_rays_bwd; the loss sums: fixed-order partials) no longer pass through
+    float atomics.  (Frame-batched renders -- fitting_video -- still do for d / d bt_inv: reproducible to rounding.)"""
+    import bench
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    for pipelined in (True, False):
+        runs = []
+        for rep in range(2):
+            ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3', halo=True)
+            with torch.no_grad():
+                for i, p in enumerate(chain.parameters()):
+                    p.add_(4e-3 * torch.randn(p.shape, generator=torch.Generator().manual_seed(70 + i)).to(dev))
+            opt = F.make_optimizer(chain, video=False)
+            trs = [torch.rand(bench.FIT_RAYS, 1, generator=torch.Generator().manual_seed(190 + k)).to(dev) for k in range(12)]
+            for k in range(12):
+                terms = F.fit_step(ren, views[k % 8], chain, opt, bench.NEAR, bench.FAR, '12', t_rand=trs[k], pipelined=pipelined)
+            F.finish_pipeline(opt)
+            torch.cuda.synchronize()
+            runs.append(([p.detach().clone() for p in chain.parameters()], [p.grad.detach().clone() for p in chain.parameters()],
+                         {k: float(v) for k, v in terms.items()}, ren.last_z_vals.clone()))
+        (pa, ga, ta, za), (pb, gb, tb, zb) = runs
+        assert torch.equal(za, zb)
+        assert ta == tb, (pipelined, ta, tb)
+        for i, (a, b) in enumerate(zip(ga, gb)):
+            assert torch.equal(a, b), 'gradient of pose leaf %d differs between two runs (pipelined=%s): %g' % (i, pipelined, float((a - b).abs().max()))
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert torch.equal(a, b), 'pose leaf %d differs between two runs (pipelined=%s): %g' % (i, pipelined, float((a - b).abs().max()))
+        assert any(float(g.abs().max()) > 0 for g in ga)
+
+
 def test_pipelined_single_fit_equals_the_autograd_step():
     """fitting.PipelinedSingleFit -- fitting_single's step as explicit launches on two streams that stay apart across steps -- against
     `fit_backward` + `fit_apply` through autograd: the same kernels on the same inputs.  First step from identical parameters: the
