@@ -1165,17 +1165,41 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
     }
 }
 
-// out += the rows of part [rows][21 * 12] added in row order: g_bt_inv [21,4,4] rows 0..2 (12 values per bone), g_T_pose [21,3] = minus
-// the translation column's sums (the statement of the adjoint kernel's atomics, hn_field2_hand_adj.inl)
-static __global__ __launch_bounds__(256) void k_pose_part_reduce(const float* __restrict__ part, int rows, float* __restrict__ g_bt_inv,
-                                                          float* __restrict__ g_T_pose) {
-    const int t = threadIdx.x;
-    if (t >= N_BONES * 12) return;
-    float acc = 0.f;
-    for (int r = 0; r < rows; ++r) acc += part[(size_t)r * (N_BONES * 12) + t];
-    const int b = t / 12, k = t % 12;
-    if (g_bt_inv != nullptr) g_bt_inv[b * 16 + k] += acc;
-    if (g_T_pose != nullptr && (k & 3) == 3) g_T_pose[b * 3 + (k >> 2)] -= acc;
+// out += the rows of part [rows][21 * 12], added in a FIXED order: g_bt_inv [21,4,4] rows 0..2 (12 values per bone), g_T_pose [21,3] =
+// minus the translation column's sums (the statement of the adjoint kernel's atomics, hn_field2_hand_adj.inl).  1024 threads = 252
+// outputs x 4 row quarters; a thread adds its quarter's rows into 8 interleaved accumulators (row r into accumulator r mod 8: eight
+// loads in flight instead of one dependent chain of ~1 000), folds them 0..7, and the quarters are folded 0..3 through LDS.  Rows of
+// workgroups beyond the live tiles of a compacted launch are zeros and are skipped (x + 0 = x: the same bits).
+static __global__ __launch_bounds__(1024) void k_pose_part_reduce(const float* __restrict__ part, int rows, const int* __restrict__ n_pts_dev,
+                                                                  float* __restrict__ g_bt_inv, float* __restrict__ g_T_pose) {
+    constexpr int W = N_BONES * 12;
+    __shared__ float q[4][W];
+    if (n_pts_dev != nullptr) {
+        const int live = ((*n_pts_dev + WG_SAMPLES - 1) / WG_SAMPLES) * WG_WAVES;   // rows of the workgroups that had a tile (first round)
+        rows = rows < live ? rows : live;
+    }
+    const int t = threadIdx.x % 256, qi = threadIdx.x / 256;
+    if (t < W) {
+        const int per = (rows + 3) / 4, r0 = qi * per, r1 = r0 + per < rows ? r0 + per : rows;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(r + u) * W + t];
+        }
+        for (int u = 0; r < r1; ++r, ++u) acc[u] += part[(size_t)r * W + t];
+        float sum = acc[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) sum += acc[u];
+        q[qi][t] = sum;
+    }
+    __syncthreads();
+    if (qi == 0 && t < W) {
+        const float acc = ((q[0][t] + q[1][t]) + q[2][t]) + q[3][t];
+        const int b = t / 12, k = t % 12;
+        if (g_bt_inv != nullptr) g_bt_inv[b * 16 + k] += acc;
+        if (g_T_pose != nullptr && (k & 3) == 3) g_T_pose[b * 3 + (k >> 2)] -= acc;
+    }
 }
 
 // the kernels proper: k_field2_hand<MODE> (fp32-equivalent, the names the profiles of every round carry) and the
@@ -1372,7 +1396,7 @@ int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const
     if (det) a.pose_part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (tape != nullptr ? 0 : stash_bytes));
     auto reduce_rows = [&]() {
         if (!det) return;
-        hipLaunchKernelGGL(k_pose_part_reduce, dim3(1), dim3(256), 0, stream, a.pose_part, grid * WG_WAVES, g_bt_inv, g_T_pose);
+        hipLaunchKernelGGL(k_pose_part_reduce, dim3(1), dim3(1024), 0, stream, a.pose_part, grid * WG_WAVES, a.n_pts_dev, g_bt_inv, g_T_pose);
     };
     if (tape != nullptr) {
         a.blob = reinterpret_cast<const char*>(f->v2_adjonly);

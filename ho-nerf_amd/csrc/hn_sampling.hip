@@ -391,17 +391,23 @@ __global__ __launch_bounds__(256) void k_obj_rays_bwd(const float* __restrict__ 
     __syncthreads();
     if (!is_last) return;
     __threadfence();
+    // one wave per (frame, element): lane l adds the frame's rays l, l + 64, ... in that order, then the lanes fold by the fixed
+    // xor tree -- the same association in every run
     const int n_frames = (n_rays + rays_per_frame - 1) / rays_per_frame;
-    for (int t = threadIdx.x; t < n_frames * 12; t += blockDim.x) {
+    const int wv = threadIdx.x >> 6;
+    for (int t = wv; t < n_frames * 12; t += (int)(blockDim.x >> 6)) {
         const int fr = t / 12, e = t % 12;
         const int r0 = fr * rays_per_frame, r1 = r0 + rays_per_frame < n_rays ? r0 + rays_per_frame : n_rays;
         const volatile float* p = part;
         float acc = 0.f;
-        for (int r = r0; r < r1; ++r) acc += p[(size_t)r * 12 + e];
-        if (e < 9)
-            g_Ro[9 * fr + e] = acc;
-        else
-            g_To[3 * fr + e - 9] = acc;
+        for (int r = r0 + lane; r < r1; r += 64) acc += p[(size_t)r * 12 + e];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) {
+            if (e < 9)
+                g_Ro[9 * fr + e] = acc;
+            else
+                g_To[3 * fr + e - 9] = acc;
+        }
     }
 }
 
