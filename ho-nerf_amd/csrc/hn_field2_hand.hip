@@ -71,8 +71,9 @@ struct Hand2Args {
     unsigned* xsync;       // 16 zeroed counters (8 XCDs x {members, arrivals}) or NULL: see "XCD pacing" in the kernel
     const int* n_pts_dev;  // NULL, or the sample count on the DEVICE (<= n_pts): a compacted list whose length the host does not know
     const int* orig_idx;   // NULL, or per sample of a compacted list its index in the dense list (what the frame is taken from)
-    float* pose_part;      // adjoint, ONE frame: NULL, or [gridDim.x * 4][21 * 12] -- every wave's own sums of the pose-gradient addends
-                           // (k_pose_part_reduce adds the rows in row order: the same bits in every run; atomics otherwise)
+    float* pose_part;      // adjoint, at most POSE_FRAMES frames: NULL, or [gridDim.x * 4][n_frames][21 * 12] -- every wave's own sums of the
+                           // pose-gradient addends per frame (k_pose_part_reduce adds the rows in a fixed order: the same bits in every
+                           // run; atomics otherwise)
 };
 
 // stash slots of one wave (32 KiB each)
@@ -100,7 +101,8 @@ enum {
 };
 constexpr int FEAT_BLOCKS = 4 * N_BONES;     // first leftover block index
 constexpr int STAGE_BYTES = 8 * 1024;        // LDS staging of one bone's 4 fragment pairs (Jacobian pass)
-constexpr int POSE_ROW = 256;                // floats per wave: 21 bones x 12 pose-gradient addends (Hand2Args::pose_part)
+constexpr int POSE_ROW = 256;                // floats per wave and frame: 21 bones x 12 pose-gradient addends (Hand2Args::pose_part)
+constexpr int POSE_FRAMES = 8;               // frames a launch may have for the atomics-free pose gradients (fitting_video: 4)
 constexpr size_t HAND2_LDS_POSE = 2 * CHUNK_MAX + WG_WAVES * STAGE_BYTES + 16;   // (+ 16: the 4 per-wave bone masks of the culling)
 
 constexpr int HB_HID = chunk_bytes(1, 16, true);
@@ -419,10 +421,10 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
     XcdPace xp;
     xp.init(a.xsync);
     const int full_rounds = n_tiles / (int)gridDim.x;
-    float* const prow = reinterpret_cast<float*>(lds + HAND2_LDS_POSE) + wave * POSE_ROW;   // this wave's pose-gradient sums (adjoint modes)
+    float* const prow = reinterpret_cast<float*>(lds + HAND2_LDS_POSE) + wave * (POSE_FRAMES * POSE_ROW);   // this wave's pose-gradient sums per frame (adjoint modes)
     if constexpr (RUN_ADJ) {
         if (a.pose_part != nullptr) {
-            for (int i = lane; i < POSE_ROW; i += 64) prow[i] = 0.f;
+            for (int i = lane; i < a.n_frames * POSE_ROW; i += 64) prow[i] = 0.f;
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1159,8 +1161,9 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
     if constexpr (RUN_ADJ) {
         if (a.pose_part != nullptr) {   // (workgroups without a tile write their zeros: the reduction reads every row)
             __builtin_amdgcn_wave_barrier();
-            float* row = a.pose_part + ((size_t)blockIdx.x * WG_WAVES + wave) * (N_BONES * 12);
-            for (int i = lane; i < N_BONES * 12; i += 64) row[i] = prow[i];
+            float* row = a.pose_part + ((size_t)blockIdx.x * WG_WAVES + wave) * a.n_frames * (N_BONES * 12);
+            for (int f = 0; f < a.n_frames; ++f)
+                for (int i = lane; i < N_BONES * 12; i += 64) row[f * (N_BONES * 12) + i] = prow[f * POSE_ROW + i];
         }
     }
 }
@@ -1173,6 +1176,12 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
 static __global__ __launch_bounds__(1024) void k_pose_part_reduce(const float* __restrict__ part, int rows, const int* __restrict__ n_pts_dev,
                                                                   float* __restrict__ g_bt_inv, float* __restrict__ g_T_pose) {
     constexpr int W = N_BONES * 12;
+    // one block per frame: row r of frame f is part[(r * n_frames + f) * W ..]
+    const int n_frames = gridDim.x, fr = blockIdx.x;
+    part += (size_t)fr * W;
+    const size_t pitch = (size_t)n_frames * W;
+    if (g_bt_inv != nullptr) g_bt_inv += (size_t)fr * N_BONES * 16;
+    if (g_T_pose != nullptr) g_T_pose += (size_t)fr * N_BONES * 3;
     __shared__ float q[4][W];
     if (n_pts_dev != nullptr) {
         const int live = ((*n_pts_dev + WG_SAMPLES - 1) / WG_SAMPLES) * WG_WAVES;   // rows of the workgroups that had a tile (first round)
@@ -1185,9 +1194,9 @@ static __global__ __launch_bounds__(1024) void k_pose_part_reduce(const float* _
         int r = r0;
         for (; r + 8 <= r1; r += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(r + u) * W + t];
+            for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(r + u) * pitch + t];
         }
-        for (int u = 0; r < r1; ++r, ++u) acc[u] += part[(size_t)r * W + t];
+        for (int u = 0; r < r1; ++r, ++u) acc[u] += part[(size_t)r * pitch + t];
         float sum = acc[0];
 #pragma unroll
         for (int u = 1; u < 8; ++u) sum += acc[u];
@@ -1213,7 +1222,7 @@ __global__ __launch_bounds__(256) void k_field2_hand_f16(const Hand2Args a) {
     field2_hand_body<MODE, 1>(a);
 }
 
-constexpr size_t HAND2_LDS = HAND2_LDS_POSE + WG_WAVES * POSE_ROW * sizeof(float);   // + the waves' pose-gradient rows (adjoint modes)
+constexpr size_t HAND2_LDS = HAND2_LDS_POSE + WG_WAVES * POSE_FRAMES * POSE_ROW * sizeof(float);   // + the waves' pose-gradient rows (adjoint modes)
 
 static int hand2_grid(int n_pts, int n_cus) {
     const int n_tiles = (n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
@@ -1326,10 +1335,12 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
     return HN_OK;
 }
 #else
-static size_t pose_part_bytes(int grid) { return (((size_t)grid * WG_WAVES * N_BONES * 12 * sizeof(float)) + 255) & ~size_t(255); }
+static size_t pose_part_bytes(int grid, int n_frames) {
+    return (((size_t)grid * WG_WAVES * n_frames * N_BONES * 12 * sizeof(float)) + 255) & ~size_t(255);
+}
 size_t field2_hand_adj_workspace_bytes(int n_pts, int n_cus) {
     const int grid = hand2_grid(n_pts, n_cus);
-    return (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4) + pose_part_bytes(grid);
+    return (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4) + pose_part_bytes(grid, POSE_FRAMES);
 }
 
 // bytes of the tape a taped full evaluation leaves for the adjoint launch: the adjoint's stash slots per sample TILE
@@ -1387,16 +1398,18 @@ int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const
     int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = hand2_grid(n_pts, n_cus);
-    // ONE frame (fitting_single): every wave sums its pose-gradient addends in LDS and writes one row; the rows are added in row
-    // order behind the launch -- bit-reproducible pose gradients (several frames: float atomics, as before).  The rows live
-    // behind the stash in the workspace (the adjoint from a tape has the whole workspace free).
+    // Up to POSE_FRAMES frames (fitting_single: 1, a fitting_video window: 4): every wave sums its pose-gradient addends per frame
+    // in LDS and writes one row per frame; the rows are added in a fixed order behind the launch -- bit-reproducible pose
+    // gradients, and no atomics in the kernel (they cost it 0.17 ms of 0.93: every wave's 15 adds per bone on the same 315
+    // addresses stood in front of the next chunk's vmcnt(0)).  More frames: float atomics, as before.  The rows live behind the
+    // stash in the workspace (the adjoint from a tape has the whole workspace free).
     const size_t stash_bytes = (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
-    const bool det = n_frames == 1 && (g_bt_inv != nullptr || g_T_pose != nullptr) && workspace != nullptr &&
-                     workspace_bytes >= (tape != nullptr ? pose_part_bytes(grid) : stash_bytes + pose_part_bytes(grid));
+    const bool det = n_frames >= 1 && n_frames <= POSE_FRAMES && (g_bt_inv != nullptr || g_T_pose != nullptr) && workspace != nullptr &&
+                     workspace_bytes >= (tape != nullptr ? pose_part_bytes(grid, n_frames) : stash_bytes + pose_part_bytes(grid, n_frames));
     if (det) a.pose_part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (tape != nullptr ? 0 : stash_bytes));
     auto reduce_rows = [&]() {
         if (!det) return;
-        hipLaunchKernelGGL(k_pose_part_reduce, dim3(1), dim3(1024), 0, stream, a.pose_part, grid * WG_WAVES, a.n_pts_dev, g_bt_inv, g_T_pose);
+        hipLaunchKernelGGL(k_pose_part_reduce, dim3(n_frames), dim3(1024), 0, stream, a.pose_part, grid * WG_WAVES, a.n_pts_dev, g_bt_inv, g_T_pose);
     };
     if (tape != nullptr) {
         a.blob = reinterpret_cast<const char*>(f->v2_adjonly);

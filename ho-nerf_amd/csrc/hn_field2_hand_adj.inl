@@ -467,9 +467,9 @@
                     if (uni) {
 #pragma unroll
                         for (int k = 0; k < 12; ++k) vals[k] = wave_sum64(mine ? vals[k] : 0.f);
-                        if (lane == 0 && a.pose_part != nullptr) {   // one frame: this wave's own row (LDS), added up in row order afterwards
+                        if (lane == 0 && a.pose_part != nullptr) {   // this wave's own row of its frame (LDS), added up in a fixed order afterwards
 #pragma unroll
-                            for (int k = 0; k < 12; ++k) prow[b * 12 + k] += vals[k];
+                            for (int k = 0; k < 12; ++k) prow[frame0 * POSE_ROW + b * 12 + k] += vals[k];
                         } else if (lane == 0) {
                             if (a.g_bt_inv != nullptr) {
                                 float* gm = a.g_bt_inv + ((size_t)frame0 * N_BONES + b) * 16;
@@ -480,6 +480,17 @@
                                 float* gt = a.g_T_pose + ((size_t)frame0 * N_BONES + b) * 3;
 #pragma unroll
                                 for (int i = 0; i < 3; ++i) atomicAdd(gt + i, -vals[4 * i + 3]);
+                            }
+                        }
+                    } else if (a.pose_part != nullptr) {
+                        // a wave across a frame boundary (the samples keep the dense order: its frames are frame0 .. the last
+                        // lane's): the same sums per frame, the other frames' lanes contributing zeros
+                        const int f_last = __builtin_amdgcn_readlane(frame, 63);
+                        for (int f = frame0; f <= f_last; ++f) {
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) {
+                                const float sk = wave_sum64((mine && frame == f) ? vals[k] : 0.f);
+                                if (lane == 0) prow[f * POSE_ROW + b * 12 + k] += sk;
                             }
                         }
                     } else if (mine) {

@@ -630,6 +630,40 @@ def test_fitting_single_is_bit_reproducible():
         assert any(float(g.abs().max()) > 0 for g in ga)
 
 
+def test_fitting_video_window_steps_are_bit_reproducible():
+    """The same for the frame-batched renderer: six optimiser steps on a fitting_video window (4 frames x 40 rays, fit type 1234
+    with the stable term and an anchored sequence end) give the same bits in every loss term, leaf gradient and leaf in two runs.
+    The hand's adjoint kernel keeps one row of pose-gradient sums per wave AND FRAME (a wave across a frame boundary adds to
+    both), the rows are added in a fixed order; the object side as in fitting_single."""
+    import bench
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    runs = []
+    for rep in range(2):
+        ren, nets, chain, views, verts = bench.build_fit(dev, 41, 4, bench.VID_RAYS, 'f16x3', halo=True)
+        with torch.no_grad():
+            for i, p in enumerate(chain.parameters()):
+                p.add_(1e-2 * torch.randn(p.shape, generator=torch.Generator().manual_seed(20 + i)).to(dev))
+        opt = F.make_optimizer(chain, video=True)
+        steps = []
+        for k in range(6):
+            tr = torch.rand(4 * bench.VID_RAYS, 1, generator=torch.Generator().manual_seed(300 + k)).to(dev)
+            terms = F.fit_step(ren, views[k % len(views)], chain, opt, bench.NEAR, bench.FAR, '1234', index=[0, 1, 2, 3], smooth_ends=(k > 0, False),
+                               obj_verts_for_stable=verts[:, :400], t_rand=tr)
+            torch.cuda.synchronize()
+            steps.append(({kk: float(v) for kk, v in terms.items()}, [p.grad.detach().clone() for p in chain.parameters()],
+                          [p.detach().clone() for p in chain.parameters()], ren.last_z_vals.clone()))
+        runs.append(steps)
+    for k, ((ta, ga, pa, za), (tb, gb, pb, zb)) in enumerate(zip(*runs)):
+        assert torch.equal(za, zb), k
+        assert ta == tb, (k, ta, tb)
+        for i, (a, b) in enumerate(zip(ga, gb)):
+            assert torch.equal(a, b), 'step %d: gradient of pose leaf %d differs between two runs: %g' % (k, i, float((a - b).abs().max()))
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert torch.equal(a, b), 'step %d: pose leaf %d differs between two runs: %g' % (k, i, float((a - b).abs().max()))
+    assert all(float(g.abs().max()) > 0 for g in runs[0][0][1])
+
+
 def test_pipelined_single_fit_equals_the_autograd_step():
     """fitting.PipelinedSingleFit -- fitting_single's step as explicit launches on two streams that stay apart across steps -- against
     `fit_backward` + `fit_apply` through autograd: the same kernels on the same inputs.  First step from identical parameters: the
