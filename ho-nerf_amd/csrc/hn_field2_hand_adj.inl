@@ -463,7 +463,14 @@
                         for (int c = 0; c < 3; ++c) vals[4 * i + c] = fmaf(qbar[i], p[c], dqX[i] * gb[c] * inv_kappa);
                         vals[4 * i + 3] = qbar[i];
                     }
-                    const bool mine = valid && h == 0;   // both halves hold the same values: one of them contributes
+                    // A sample within ~2 mm of a bone's local origin has a true gradient ~1e6 x the others' (1 / v^2 terms of the bone
+                    // map): beyond the fp16 fragments' range however the seeds are scaled, its adjoint quantities overflow and come out
+                    // as inf / NaN.  Such a sample is DROPPED from the pose gradients (and gets g_pts = 0) instead of poisoning every
+                    // pose leaf with a NaN; the fp32 reference would add a huge finite value there.
+                    bool finite = true;
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) finite = finite && fabsf(vals[k]) <= 3.0e38f;
+                    const bool mine = valid && h == 0 && finite;   // both halves hold the same values: one of them contributes
                     if (uni) {
 #pragma unroll
                         for (int k = 0; k < 12; ++k) vals[k] = wave_sum64(mine ? vals[k] : 0.f);
@@ -511,8 +518,9 @@
         }
     }
     if (valid && h == 0) {
-        a.g_pts[3 * n] = gp[0];
-        a.g_pts[3 * n + 1] = gp[1];
-        a.g_pts[3 * n + 2] = gp[2];
+        const bool finite = fabsf(gp[0]) <= 3.0e38f && fabsf(gp[1]) <= 3.0e38f && fabsf(gp[2]) <= 3.0e38f;   // (see the pose gradients above)
+        a.g_pts[3 * n] = finite ? gp[0] : 0.f;
+        a.g_pts[3 * n + 1] = finite ? gp[1] : 0.f;
+        a.g_pts[3 * n + 2] = finite ? gp[2] : 0.f;
     }
 }

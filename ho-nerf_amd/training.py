@@ -131,8 +131,10 @@ class SingleRenderFn(torch.autograd.Function):
         g_params = torch.zeros(n_floats, device=dev)
         g_inv_s = torch.zeros(1, device=dev)
         g_ro, g_rd = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
-        g_bt = torch.zeros(21, 4, 4, device=dev) if hand else None
-        g_tp = torch.zeros(21, 3, device=dev) if hand else None
+        # pose gradients only when the caller differentiates the pose (exp_runner trains the networks on fixed poses: the bone maps'
+        # kernels then skip 15 wave sums and atomics per sample block and bone)
+        g_bt = torch.zeros(21, 4, 4, device=dev) if hand and ctx.needs_input_grad[7] else None
+        g_tp = torch.zeros(21, 3, device=dev) if hand and ctx.needs_input_grad[8] else None
         need = lib.hn_render_single_bwd_workspace_bytes(f.handle, B, S)
         if not hasattr(ren, '_ws_train'):
             from .renderer import _Workspace

@@ -1013,6 +1013,83 @@ def test_hand_field_adjoint(L, aprec):
     assert float(g_dirs.abs().max()) == 0.0
 
 
+def test_hand_pose_gradients_are_additive_over_launch_shapes(L):
+    """The atomics-free pose gradients of the fused hand adjoint (one row of sums per wave and frame, added in a fixed order)
+    over the launch shapes the small parity case does not reach: (i) more tiles than workgroups -- 40 064 samples = 313 tiles on
+    at most 256 persistent workgroups, a wave's row collecting several tiles --: d / d bt_inv, d / d T_pose of the whole launch
+    = the sum of the two halves' (each one round), to rounding, and two runs of the whole launch agree to the BIT; (ii) three
+    frames with waves across the frame boundaries (frame size not a multiple of 32): per frame = that frame's samples alone;
+    (iii) nine frames, beyond the rows' frame slots: the atomics path, same check."""
+    from honerf_amd import synth
+    hand, _ = packed_fields('cuda', 'f16x3')
+    gen = torch.Generator().manual_seed(16)
+
+    def problem(n, n_frames):
+        poses = [synth.synth_hand_pose(8 + f) for f in range(n_frames)]
+        bt = torch.stack([t(p[0]) for p in poses])
+        tp = torch.stack([t(p[1]) for p in poses])
+        ppf = n // n_frames
+        pts = torch.cat([t(poses[f][2])[torch.randint(0, 21, (ppf,), generator=gen)] + 0.03 * torch.randn(ppf, 3, generator=gen) for f in range(n_frames)])
+        d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+        gs, gg, gr = torch.randn(n, 1, generator=gen), torch.randn(n, 3, generator=gen), torch.randn(n, 3, generator=gen)
+        return pts, d, gs, gg, gr, bt, tp
+
+    # (i) one frame, two rounds of tiles
+    n = 40064
+    pts, d, gs, gg, gr, bt, tp = problem(n, 1)
+    # (points drawn around the joints land within millimetres of a bone's local origin once in ~10 000: their gradients are ~1e6 x
+    # the others' and the kernel drops them -- see the last check of this test; here they would dominate the sums' rounding)
+    near = (torch.einsum('bij,nj->nbi', bt[0, :, :3, :3], pts) + bt[0, :, :3, 3] - tp[0]).norm(dim=-1).min(dim=1).values < 6e-3
+    pts[near] += 0.02
+    whole = _field_adjoint_gpu(L, hand, pts, d, 1, gs, gg, gr, bt, tp)
+    again = _field_adjoint_gpu(L, hand, pts, d, 1, gs, gg, gr, bt, tp)
+    assert torch.equal(whole[2], again[2]) and torch.equal(whole[3], again[3]) and torch.equal(whole[0], again[0])
+    h = n // 2
+    a = _field_adjoint_gpu(L, hand, pts[:h], d[:h], 1, gs[:h], gg[:h], gr[:h], bt, tp)
+    b = _field_adjoint_gpu(L, hand, pts[h:], d[h:], 1, gs[h:], gg[h:], gr[h:], bt, tp)
+    bounded('hand pose gradients, 313 tiles: d/d bt_inv of the launch vs the sum of its halves', rel_err((a[2] + b[2]).cpu().numpy(), whole[2].cpu().numpy()), 2e-5)
+    bounded('hand pose gradients, 313 tiles: d/d T_pose of the launch vs the sum of its halves', rel_err((a[3] + b[3]).cpu().numpy(), whole[3].cpu().numpy()), 2e-5)
+    assert torch.equal(torch.cat([a[0], b[0]]), whole[0])                   # per-sample outputs do not depend on the grouping
+    # (ii), (iii) several frames, frame size 1 000 (not a multiple of 32: waves straddle the boundaries)
+    for n_frames in (3, 9):
+        n = 1000 * n_frames
+        pts, d, gs, gg, gr, bt, tp = problem(n, n_frames)
+        whole = _field_adjoint_gpu(L, hand, pts, d, 1, gs, gg, gr, bt, tp)
+        if n_frames <= 8:
+            again = _field_adjoint_gpu(L, hand, pts, d, 1, gs, gg, gr, bt, tp)
+            assert torch.equal(whole[2], again[2]) and torch.equal(whole[3], again[3])
+        for f in range(n_frames):
+            sl = slice(1000 * f, 1000 * (f + 1))
+            one = _field_adjoint_gpu(L, hand, pts[sl], d[sl], 1, gs[sl], gg[sl], gr[sl], bt[f:f + 1], tp[f:f + 1])
+            bounded('hand pose gradients, %d frames: d/d bt_inv of frame %d vs that frame alone' % (n_frames, f),
+                    rel_err(whole[2][f].cpu().numpy(), one[2][0].cpu().numpy()), 2e-5)
+            bounded('hand pose gradients, %d frames: d/d T_pose of frame %d vs that frame alone' % (n_frames, f),
+                    rel_err(whole[3][f].cpu().numpy(), one[3][0].cpu().numpy()), 2e-5)
+            assert torch.equal(whole[0][sl], one[0])
+    # a sample 1.6 mm from a bone's local origin (true gradient ~1.8e6 in fp64, beyond the fp16 fragments' range): dropped, not NaN --
+    # every output finite, and the rest of its tile as if it were not there
+    bt1, tp1, j1 = synth.synth_hand_pose(8)
+    bt1, tp1 = t(bt1)[None], t(tp1)[None]
+    g2 = torch.Generator().manual_seed(17)
+    n = 256
+    pts = t(j1)[torch.randint(0, 21, (n,), generator=g2)] + 0.05 * torch.randn(n, 3, generator=g2)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g2), dim=-1)
+    gs, gg, gr = torch.randn(n, 1, generator=g2), torch.randn(n, 3, generator=g2), torch.randn(n, 3, generator=g2)
+    far = pts.clone()
+    pts[77] = torch.tensor([-0.1095925122499466, 0.0975697860121727, 0.8473193645477295])
+    far[77] = torch.tensor([10.0, 10.0, 10.0])                               # (a far-field point contributes exactly nothing)
+    for k, v in (('gs', gs), ('gg', gg), ('gr', gr)):
+        v[77] = torch.tensor({'gs': [-0.31878435611724854], 'gg': [0.99062579870224, -1.940515398979187, 1.8684284687042236],
+                              'gr': [-0.3706848919391632, -0.16610954701900482, 1.46490478515625]}[k])
+    with_it = _field_adjoint_gpu(L, hand, pts, d, 1, gs, gg, gr, bt1, tp1)
+    without = _field_adjoint_gpu(L, hand, far, d, 1, gs, gg, gr, bt1, tp1)
+    assert all(bool(torch.isfinite(x).all()) for x in (with_it[0], with_it[2], with_it[3]))
+    assert float(with_it[0][77].abs().max()) == 0.0
+    keep = torch.arange(n) != 77
+    assert torch.equal(with_it[0][keep], without[0][keep])
+    bounded('hand pose gradients with a near-singular sample dropped vs without it: d/d bt_inv', rel_err(with_it[2].cpu().numpy(), without[2].cpu().numpy()), 2e-5)
+
+
 # ---------------------------------------------------------------------------------------------
 def _dual_renderer(n_samples, n_importance, prec='f16x3'):
     from honerf_amd.renderer import NeuSRenderer_fitting
