@@ -630,6 +630,48 @@ def test_fitting_single_is_bit_reproducible():
         assert any(float(g.abs().max()) > 0 for g in ga)
 
 
+def test_sharded_frames_do_not_depend_on_the_sharding():
+    """SURVEY 8(e) for C4: "frame-sharded results are bit-identical to 1-GPU runs given per-frame seeds".  Four fitting_single frames
+    (8 views, one pass, fit type 12; the frame's seed set where its data is made) fitted (a) by one rank in order 0, 1, 2, 3 and
+    (b) by the two ranks of a world of 2 (FrameShardedRunner's deal: rank 0 frames 0, 2; rank 1 frames 1, 3), the ranks emulated
+    one after the other in this process: every leaf of every frame bit for bit.  (A frame's fit uses no state but its own: the
+    renderer's workspaces are scratch, the jitter comes from the generator the frame seeded.)"""
+    import bench
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    ren, nets, _, _, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3', halo=True)
+
+    def make_frame(f):
+        ch, jf, _ = bench.build_fit_data(dev, 140 + f, 1, halo=True)
+        views = F.synthetic_views(8, 1, bench.FIT_RAYS, 140 + f, jf[9], device=dev)
+        torch.manual_seed(9000 + f)                          # the frame's seed: its jitter is drawn from here
+        return views, ch
+
+    def run(rank, world):
+        out = {}
+        runner = F.FrameShardedRunner(4, rank=rank, world=world)
+
+        def frame_fn(f):
+            views, chain = make_frame(f)
+            terms, n = F.fit_frame(ren, views, chain, bench.NEAR, bench.FAR, '12', n_iters=1)
+            torch.cuda.synchronize()
+            out[f] = ([p.detach().clone() for p in chain.parameters()], {k: float(v) for k, v in terms.items()})
+            return terms
+        runner.run(frame_fn)
+        return out
+
+    single = run(0, 1)
+    two = {}
+    two.update(run(0, 2))
+    two.update(run(1, 2))
+    assert sorted(single) == sorted(two) == [0, 1, 2, 3]
+    for f in range(4):
+        assert single[f][1] == two[f][1], (f, single[f][1], two[f][1])
+        for i, (a, b) in enumerate(zip(single[f][0], two[f][0])):
+            assert torch.equal(a, b), 'frame %d leaf %d: %g' % (f, i, float((a - b).abs().max()))
+    assert not torch.equal(single[0][0][4], single[1][0][4])          # (different frames, different fits)
+
+
 def test_fitting_video_window_steps_are_bit_reproducible():
     """The same for the frame-batched renderer: six optimiser steps on a fitting_video window (4 frames x 40 rays, fit type 1234
     with the stable term and an anchored sequence end) give the same bits in every loss term, leaf gradient and leaf in two runs.
