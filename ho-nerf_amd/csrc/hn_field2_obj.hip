@@ -1085,3 +1085,10 @@ int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays
 #endif   // HN_OBJ_QUAD_TU
 }  // namespace v2
 }  // namespace hn
+
+#if defined(HN_TS) && !defined(HN_OBJ_QUAD_TU)
+// timing builds (tools/ts_report_obj.py): workgroup 0's per-chunk stamps of the last object-field launch
+extern "C" int hn_debug_ts_obj(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(hn::v2::g_hn_ts), sizeof(unsigned long long) * n);
+}
+#endif
