@@ -262,7 +262,7 @@ _LOSS_SCRATCH = {}
 def _loss_scratch(lib, n_rays, n_samples, dev):
     """The partial-sum slots + counter of hn_fit_step_loss: zeroed once, every launch leaves it ready for the next.  One per
     (device, stream): steps of two streams must not share a counter."""
-    need = lib.hn_fit_step_loss_scratch_bytes(n_rays, n_samples)
+    need = max(lib.hn_fit_step_loss_scratch_bytes(n_rays, n_samples), lib.hn_window_loss_scratch_bytes(n_rays, n_samples))   # (one buffer serves both)
     key = (str(dev), torch.cuda.current_stream().cuda_stream)
     buf = _LOSS_SCRATCH.get(key)
     if buf is None or buf.numel() < need:

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_window_loss(const float* __restrict__ c
                                                      int n_verts, const float* __restrict__ stable, int anchor, WindowW w, float* __restrict__ partials,
                                                      unsigned* __restrict__ counter, float* __restrict__ pose3, float* __restrict__ sums6,
                                                      float* __restrict__ terms10, float* __restrict__ g_joint, float* __restrict__ gR,
-                                                     float* __restrict__ gt) {
+                                                     float* __restrict__ gt, float* __restrict__ pairs_g) {
     __shared__ float red[13][4];
     __shared__ float pair_out[2 * STABLE_MAX_F][13];
     __shared__ bool is_last;
@@ -277,12 +277,13 @@ __global__ __launch_bounds__(256) void k_window_loss(const float* __restrict__ c
     __syncthreads();
     if (threadIdx.x < 6) partials[6 * (size_t)blockIdx.x + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
     __syncthreads();
-    if (blockIdx.x == 0) {
-        // ---- the pose part (does not depend on the render: block 0 does it while the other blocks reduce their sums) ------------
-        // vertex pairs: p < F: (R_p, t_p) against the prediction; p >= F: (R_{q+1}, t_{q+1}) against (R_q, t_q), q = p - F.
-        // pair_out[p] = {mean |e|, mean u v^T (9), mean u (3)} (k_verts_loss)
-        const int n_pairs = 2 * F - 1;
-        for (int p = 0; p < n_pairs; ++p) {
+    // ---- the pose part (does not depend on the render) ---------------------------------------------------------------------------
+    // vertex pairs: p < F: (R_p, t_p) against the prediction; p >= F: (R_{q+1}, t_{q+1}) against (R_q, t_q), q = p - F.
+    // pairs_g[p] = {mean |e|, mean u v^T (9), mean u (3)} (k_verts_loss).  One pair per BLOCK (block p, beside its share of the sums): as
+    // a loop of block 0 over the 2 F - 1 pairs the launch took 48 us, most of it that loop; the last block combines them.
+    const int n_pairs = 2 * F - 1;
+    {
+        for (int p = blockIdx.x; p < n_pairs; p += gridDim.x) {
             const float *Ra, *ta, *Rb, *tb;
             if (p < F) {
                 Ra = R + 9 * p; ta = t + 3 * p; Rb = Rp + 9 * p; tb = tp + 3 * p;
@@ -316,9 +317,22 @@ __global__ __launch_bounds__(256) void k_window_loss(const float* __restrict__ c
                 if (lane == 0) red[k][wave] = s;
             }
             __syncthreads();
-            if (threadIdx.x < 13) pair_out[p][threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) / (float)n_verts;
+            if (threadIdx.x < 13) pairs_g[13 * p + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) / (float)n_verts;
             __syncthreads();
         }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    {
+        {   // the pairs of all blocks -> LDS
+            const volatile float* pg = reinterpret_cast<const volatile float*>(pairs_g);
+            for (int q = threadIdx.x; q < 13 * n_pairs; q += blockDim.x) pair_out[q / 13][q % 13] = pg[q];
+        }
+        __syncthreads();
         // joints: thread (f, k) for f < F, k < 21 (F <= 8: 168 threads)
         const int NJ = 21;
         const bool first = (anchor & 1) != 0, last = !first && (anchor & 2) != 0;
@@ -396,12 +410,6 @@ __global__ __launch_bounds__(256) void k_window_loss(const float* __restrict__ c
         }
         __syncthreads();
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(counter, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
     {   // the six sums over the blocks' slots, in a fixed order
         float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const volatile float* ps = reinterpret_cast<const volatile float*>(partials);
@@ -528,7 +536,7 @@ int stable_value(const float* sdf, const float* p0, int n_frames, int V, int str
 }
 size_t window_loss_scratch_bytes(int n_rays, int n_samples) {
     const int n = n_rays > n_samples ? n_rays : n_samples;
-    return ((size_t)((n + 255) / 256 + 1) * 6 + 16) * sizeof(float);
+    return ((size_t)((n + 255) / 256 + 1) * 6 + 16 + 2 * STABLE_MAX_F * 13) * sizeof(float);   // counter, pose terms, the blocks' sums, the vertex pairs
 }
 int window_loss(const float* color, const float* wsum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_h, const float* sdf_o,
                 int n_samples, const float* joint_3d, const float* joint_pred, int n_frames, const float* R, const float* t, const float* Rp, const float* tp,
@@ -544,7 +552,8 @@ int window_loss(const float* color, const float* wsum, const float* true_rgb, co
     WindowW w{w7[0], w7[1], w7[2], w7[3], w7[4], w7[5], w7[6]};
     hipLaunchKernelGGL(k_window_loss, dim3((n + 255) / 256), dim3(256), 0, s, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o, ns, joint_3d, joint_pred,
                        n_frames, R, t, Rp, tp, verts, n_verts, stable, anchor, w, reinterpret_cast<float*>(scratch) + 16, reinterpret_cast<unsigned*>(scratch),
-                       reinterpret_cast<float*>(scratch) + 4, sums6, terms10, g_joint, gR, gt);
+                       reinterpret_cast<float*>(scratch) + 4, sums6, terms10, g_joint, gR, gt,
+                       reinterpret_cast<float*>(scratch) + 16 + (size_t)((n + 255) / 256 + 1) * 6);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
