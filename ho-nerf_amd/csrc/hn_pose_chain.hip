@@ -24,7 +24,8 @@ __global__ __launch_bounds__(VALUES ? 64 : 192) void k_pose_chain(const float* _
                                                                    const unsigned char* __restrict__ is_right, const float* __restrict__ in,
                                                                    int n_frames, float* __restrict__ bt_inv, float* __restrict__ joint_3d,
                                                                    float* __restrict__ jac) {
-    using T = Dual<double>;
+    using S = std::conditional_t<VALUES, pose::VD, double>;   // VD: the chain without tangents (hn_pose_chain.h)
+    using T = Dual<S>;
     using pose::V3;
     constexpr int DIRS = VALUES ? 1 : PC_DIRS;
     __shared__ double xb[DIRS][5][VALUES ? 3 : 6];
@@ -33,20 +34,20 @@ __global__ __launch_bounds__(VALUES ? 64 : 192) void k_pose_chain(const float* _
     const bool active = fr < n_frames && f < 5;
     // In double: in fp32 the chain's angle / normalisation steps leave 3e-4 of relative error on the Jacobian (measured against
     // the reference's fp64 run; the reference's own fp32 run is 3e-5 off on the values).  Inputs and outputs stay fp32.
-    double pose[21][3], bl[20];
-    pose::ChainIn<double> ci;
+    S pose[21][3], bl[20];
+    pose::ChainIn<S> ci;
     pose::FingerState<T> st;
     if (active) {
-        for (int i = 0; i < 63; ++i) pose[i / 3][i % 3] = (double)ori_pose[(size_t)fr * 63 + i];
-        for (int i = 0; i < 20; ++i) bl[i] = (double)bone_len[(size_t)fr * 20 + i];
+        for (int i = 0; i < 63; ++i) pose[i / 3][i % 3] = S((double)ori_pose[(size_t)fr * 63 + i]);
+        for (int i = 0; i < 20; ++i) bl[i] = S((double)bone_len[(size_t)fr * 20 + i]);
         T x[N_IN];
-        for (int i = 0; i < N_IN; ++i) x[i] = T((double)in[(size_t)fr * N_IN + i], (!VALUES && i == k - 1) ? 1.0 : 0.0);
-        pose::chain_inputs<double>(pose, bl, is_right == nullptr || is_right[fr] != 0, x, ci);
+        for (int i = 0; i < N_IN; ++i) x[i] = T(S((double)in[(size_t)fr * N_IN + i]), S((!VALUES && i == k - 1) ? 1.0 : 0.0));
+        pose::chain_inputs<S>(pose, bl, is_right == nullptr || is_right[fr] != 0, x, ci);
     }
     auto publish = [&](const V3<T>& v) {
         for (int c = 0; c < 3; ++c) {
             if constexpr (VALUES) {
-                xb[k][f][c] = v.x[c].v;
+                xb[k][f][c] = (double)v.x[c].v;
             } else {
                 xb[k][f][2 * c] = v.x[c].v;
                 xb[k][f][2 * c + 1] = v.x[c].d;
@@ -57,19 +58,19 @@ __global__ __launch_bounds__(VALUES ? 64 : 192) void k_pose_chain(const float* _
         V3<T> v;
         for (int c = 0; c < 3; ++c) {
             if constexpr (VALUES)
-                v.x[c] = T(xb[k][g][c], 0.0);
+                v.x[c] = T(S(xb[k][g][c]));
             else
-                v.x[c] = T(xb[k][g][2 * c], xb[k][g][2 * c + 1]);
+                v.x[c] = T(S(xb[k][g][2 * c]), S(xb[k][g][2 * c + 1]));
         }
         return v;
     };
     V3<T> RB[5];
-    if (active) publish(pose::chain_phase_a<double>(f, ci, st));
+    if (active) publish(pose::chain_phase_a<S>(f, ci, st));
     __syncthreads();
     if (active)
         for (int g = 0; g < 5; ++g) RB[g] = fetch(g);
     __syncthreads();
-    if (active) publish(pose::chain_phase_b<double>(f, ci, RB, st));
+    if (active) publish(pose::chain_phase_b<S>(f, ci, RB, st));
     __syncthreads();
     V3<T> J1, J2;
     if (active) {
@@ -77,14 +78,14 @@ __global__ __launch_bounds__(VALUES ? 64 : 192) void k_pose_chain(const float* _
         J2 = fetch(2);
     }
     __syncthreads();
-    if (active) publish(pose::chain_phase_c<double>(f, ci, J1, J2, st));
+    if (active) publish(pose::chain_phase_c<S>(f, ci, J1, J2, st));
     __syncthreads();
     if (active) {
         for (int g = 0; g < 5; ++g) RB[g] = fetch(g);
         float* bt = bt_inv != nullptr ? bt_inv + (size_t)fr * 336 : nullptr;
         float* j3 = joint_3d != nullptr ? joint_3d + (size_t)fr * 63 : nullptr;
         float* J = jac != nullptr ? jac + (size_t)fr * N_OUT * N_IN : nullptr;
-        pose::chain_phase_d<double>(f, ci, RB, st, [&](int idx, const T& v) {
+        pose::chain_phase_d<S>(f, ci, RB, st, [&](int idx, const T& v) {
             if (k == 0) {
                 if (bt != nullptr) {
                     if (idx < 336)
