@@ -238,13 +238,15 @@ def build_fit_nets(dev, n_frames, precision):
     return ren, nets
 
 
-def build_fit_data(dev, seed, n_frames, halo=True, drift=0.0):
+def build_fit_data(dev, seed, n_frames, halo=True, drift=0.0, obj_offset=(0.02, 0.0, 0.01)):
     """A synthetic frame (or sequence of n_frames: the same pose with a small per-frame drift) and its pose chain:
     halo = the reference's six refine leaves through hn_pose_chain (fitting_single.py:183-226, honerf_amd.fitting.HaloPoseChain),
-    else the reduced rigid chain (palm + object motion only)."""
+    else the reduced rigid chain (palm + object motion only).  obj_offset: the object's centre relative to joint 9 (the synthetic
+    object field is a sphere-like SDF of radius ~0.4 in its own frame: the default puts the hand deep inside it -- penetration
+    everywhere, no contact; the whole-step tests' second scene moves the centre so that its SURFACE crosses the hand)."""
     from honerf_amd import fitting as F, synth
     bt, tp, j = synth.synth_hand_pose(seed)
-    R, tt = synth.synth_obj_pose(seed + 1, center=tuple(j[9] + np.array([0.02, 0.0, 0.01])))
+    R, tt = synth.synth_obj_pose(seed + 1, center=tuple(j[9] + np.asarray(obj_offset, dtype=np.float64)))
     rng = np.random.RandomState(seed)
     u = rng.standard_normal((2000, 3))
     verts = (u / np.linalg.norm(u, axis=1, keepdims=True) * 0.025).astype(np.float32)
@@ -260,10 +262,10 @@ def build_fit_data(dev, seed, n_frames, halo=True, drift=0.0):
     return chain, j, torch.from_numpy(verts).to(dev)
 
 
-def build_fit(dev, seed, n_frames, rays, precision, halo=False):
+def build_fit(dev, seed, n_frames, rays, precision, halo=False, obj_offset=(0.02, 0.0, 0.01)):
     from honerf_amd import fitting as F
     ren, nets = build_fit_nets(dev, n_frames, precision)
-    chain, j, verts = build_fit_data(dev, seed, n_frames, halo)
+    chain, j, verts = build_fit_data(dev, seed, n_frames, halo, obj_offset=obj_offset)
     views = F.synthetic_views(8, n_frames, rays, seed, j[9], device=dev)
     return ren, nets, chain, views, verts[None].expand(n_frames, -1, -1).contiguous()
 
@@ -382,7 +384,11 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
         dt, st = wall(lambda: F.fit_sequence_video(renb, window_views, chains, NEAR, FAR, n_frames, '1234', outer_iters=passes, obj_verts=ovs,
                                                    dist=dist))
         n_win = len(F.sliding_windows(n_frames))
-        return {'ms_per_step': dt / st['steps'] * 1e3, 'steps': st['steps'], 'data_num': n_frames, 'windows': n_win, 'outer_iters': passes,
+        rounds = (n_win + world - 1) // world
+        return {'ideal_rounds_cap': n_win / float(rounds * world),
+                'ideal_rounds_cap_what': '%d windows in %d rounds of %d concurrent windows: the efficiency this schedule can reach before any latency'
+                                         % (n_win, rounds, world),
+                'ms_per_step': dt / st['steps'] * 1e3, 'steps': st['steps'], 'data_num': n_frames, 'windows': n_win, 'outer_iters': passes,
                 'seconds': dt, 'windows_per_s': n_win * passes / dt, 'frames_per_s': n_frames / dt,
                 'allreduce_calls': st['allreduce_calls'], 'allreduce_floats_per_step': st['allreduce_floats'] // max(st['allreduce_calls'], 1),
                 'efficiency_vs_unsynced_step': sec_v / (dt / st['steps']), 'pose_chain': 'halo (six refine leaves, hn_pose_chain)', 'what': what}
@@ -462,6 +468,125 @@ def spawn_command(n_gpus, argv):
             '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def rccl_one_rank_leg(quick=False):
+    """RCCL on the hardware there is: a process group of ONE rank over the `nccl` backend (= RCCL) on this GPU, created before
+    anything else touches the device, and the two sharded loops driven through it with their collectives NOT short-circuited at
+    world == 1 (fitting.FORCE_COLLECTIVE): `fit_sequence_video` issues one device-side all-reduce of the pose-gradient block per step
+    between the backward pass and Adam, `fit_frames_sharded` the reduction of the loss vector.  A one-rank SUM is the identity, so
+    the run must equal the run without a collective TO THE BIT; it also says what the collective costs a step in launch latency.
+    Runs as a child process of `bench.py --gpus 1` (and of tests/test_gpu_surface.py); prints one JSON line."""
+    import datetime
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    from honerf_amd.pose import bind_streams
+    bind_streams(dev)
+    import torch.distributed as dist
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(minutes=5))
+        probe = torch.full((4,), 3.0, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        assert probe.tolist() == [3.0] * 4
+    finally:
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    from honerf_amd import fitting as F
+    res = {'backend': dist.get_backend(), 'world': dist.get_world_size(), 'rccl_version': list(torch.cuda.nccl.version()),
+           'device': torch.cuda.get_device_name(0)}
+    n_frames = 6 if quick else 8
+    renb, _ = build_fit_nets(dev, VID_FRAMES, 'f16x3')
+
+    def run_video(force):
+        F.FORCE_COLLECTIVE = force
+        torch.manual_seed(77)
+        chain, j, v = build_fit_data(dev, 60, n_frames, halo=True, drift=0.002)
+        ov = v[None].expand(VID_FRAMES, -1, -1).contiguous()
+        per_window = {tuple(w): F.synthetic_views(2 if quick else 8, VID_FRAMES, VID_RAYS, 300 + w[0], j[9], device=dev) for w in F.sliding_windows(n_frames)}
+
+        def window_views(index, vid, step):
+            return per_window[tuple(index)][vid]
+        window_views.n_views = 2 if quick else 8
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = F.fit_sequence_video(renb, window_views, chain, NEAR, FAR, n_frames, '1234', outer_iters=1, obj_verts=ov, dist=dist)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return [p.detach().clone() for p in chain.parameters()], st, dt
+    pw, _, _ = run_video(False)                           # warm (allocations, first-use costs)
+    p0, st0, dt0 = run_video(False)
+    p1, st1, dt1 = run_video(True)
+    maxdiff = lambda a, b: max(float((x - y).abs().max()) for x, y in zip(a, b))
+    res['diag'] = {'unforced_run_equals_its_repeat': all(torch.equal(a, b) for a, b in zip(pw, p0)), 'unforced_vs_repeat_maxdiff': maxdiff(pw, p0),
+                   'forced_vs_unforced_maxdiff': maxdiff(p0, p1)}
+    if os.environ.get('HONERF_RCCL_DIAG') == '1':
+        p1b, _, _ = run_video(True)
+        res['diag']['forced_run_equals_its_repeat'] = all(torch.equal(a, b) for a, b in zip(p1, p1b))
+        res['diag']['forced_vs_repeat_maxdiff'] = maxdiff(p1, p1b)
+    res['fit_sequence_video'] = {
+        'data_num': n_frames, 'steps': st1['steps'], 'allreduce_calls': st1['allreduce_calls'],
+        'allreduce_calls_equal_steps': st1['allreduce_calls'] == st1['steps'],
+        'allreduce_floats_per_step': st1['allreduce_floats'] // max(st1['allreduce_calls'], 1),
+        'allreduce_calls_without_force': st0['allreduce_calls'],
+        'ms_per_step_with_collective': dt1 / st1['steps'] * 1e3, 'ms_per_step_without': dt0 / st0['steps'] * 1e3,
+        'bit_identical_to_the_run_without_collective': all(torch.equal(a, b) for a, b in zip(p0, p1)),
+        'what': 'one pass over the %d windows of a %d-frame sequence, fit type 1234; the SUM all-reduce of the [data_num x 45] gradient block in place, '
+                'between fit_backward and the Adam step' % (n_frames - 3, n_frames)}
+    ren1, _ = build_fit_nets(dev, 1, 'f16x3')
+
+    def run_frames(force):
+        F.FORCE_COLLECTIVE = force
+        made = {}
+        for f in range(2):
+            torch.manual_seed(500 + f)
+            ch, jf, _ = build_fit_data(dev, 140 + f, 1, halo=True)
+            made[f] = (F.synthetic_views(8, 1, FIT_RAYS, 140 + f, jf[9], device=dev), ch)
+        torch.manual_seed(78)
+        out = F.fit_frames_sharded(ren1, 2, lambda f: made[f], NEAR, FAR, '12', n_iters=2 if quick else 5, dist=dist)
+        torch.cuda.synchronize()
+        return out, [p.detach().clone() for f in range(2) for p in made[f][1].parameters()]
+    o0, q0 = run_frames(False)
+    o1, q1 = run_frames(True)
+    res['fit_frames_sharded'] = {'frames': o1['frames'], 'steps': o1['steps'], 'allreduce_calls': o1['allreduce_calls'],
+                                 'allreduce_calls_without_force': o0['allreduce_calls'],
+                                 'bit_identical_to_the_run_without_collective': all(torch.equal(a, b) for a, b in zip(q0, q1)) and
+                                 all(o0[k] == o1[k] for k in F.LOSS_KEYS)}
+    F.FORCE_COLLECTIVE = False
+    dist.barrier()
+    dist.destroy_process_group()
+    res['ok'] = bool(res['fit_sequence_video']['allreduce_calls_equal_steps'] and res['fit_sequence_video']['bit_identical_to_the_run_without_collective']
+                     and res['fit_frames_sharded']['allreduce_calls'] == 1 and res['fit_frames_sharded']['bit_identical_to_the_run_without_collective'])
+    print(json.dumps(res))
+    return 0 if res['ok'] else 4
+
+
+def spawn_rccl_leg(quick=False, timeout=900):
+    """The one-rank RCCL leg as a CHILD process (its process group must come up before anything else touches the GPU, and a failure
+    of the communicator must not take the bench line with it) -> its JSON object, or {'error': ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--rccl-one-rank'] + (['--fit-quick'] if quick else [])
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {'error': 'the one-rank RCCL leg did not finish in %d s' % timeout}
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith('{'):
+            try:
+                out = json.loads(line)
+                out['returncode'] = r.returncode
+                return out
+            except ValueError:
+                pass
+    return {'error': 'no result line (exit %d)' % r.returncode, 'stderr_tail': r.stderr[-1500:]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -478,7 +603,12 @@ def main():
     ap.add_argument('--fit-steps', type=int, default=80, help='timed steps per fitting leg (after 10 untimed ones)')
     ap.add_argument('--fit-outer', type=int, default=5, help='passes over the video sequence (fitting_video.py:157: 5)')
     ap.add_argument('--fit-quick', action='store_true', help='functional check of the fitting legs: 2 frames, an 8-frame sequence, one pass')
+    ap.add_argument('--rccl-one-rank', action='store_true', help='run ONLY the one-rank RCCL leg (a process group of one rank over nccl on this GPU, the '
+                    'sharded loops with their collectives forced) and print its JSON line')
+    ap.add_argument('--no-rccl-leg', action='store_true', help='--gpus 1: skip the one-rank RCCL leg (run as a child process before the measurements)')
     args = ap.parse_args()
+    if args.rccl_one_rank:
+        sys.exit(rccl_one_rank_leg(args.fit_quick))
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # No torch.distributed environment: start the N ranks ourselves, as a CHILD process, before this process has
@@ -491,6 +621,9 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    rccl_leg = None
+    if world == 1 and not args.no_fitting and not args.no_rccl_leg and args.precision == 'f16x3':
+        rccl_leg = spawn_rccl_leg(args.fit_quick)          # a child process, before this process touches the GPU
     # HONERF_BENCH_SHARE_GPU=1: all ranks on device 0 with the gloo backend -- a functional check of the N > 1 code path
     # (sharding, the pose-gradient all-reduce between backward and Adam) on a box with ONE GPU; its timings mean nothing.
     share = os.environ.get('HONERF_BENCH_SHARE_GPU') == '1'
@@ -549,6 +682,10 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # the dominant kernel is timed INSIDE the timed steps: the library brackets every field-evaluation launch of these steps with two
+    # HIP events on the stream it launches on (hn_debug_field_timer), read back after the region -- kernel time <= step time by construction
+    import ctypes
+    L.check(lib.hn_debug_field_timer(1), 'hn_debug_field_timer')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -557,6 +694,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    L.check(lib.hn_debug_field_timer(0), 'hn_debug_field_timer')
+    k_total, k_count = ctypes.c_double(0.0), ctypes.c_int(0)
+    L.check(lib.hn_debug_field_timer_read(ctypes.byref(k_total), ctypes.byref(k_count)), 'hn_debug_field_timer_read')
+    kernel_ms_in_loop = k_total.value / max(k_count.value, 1)
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -603,7 +744,10 @@ def main():
         field_launch()
     e1.record()
     torch.cuda.synchronize()
-    kernel_ms = e0.elapsed_time(e1) / k_launches
+    kernel_ms_separate = e0.elapsed_time(e1) / k_launches
+    # `roofline` is priced on the launches of the TIMED steps (above); the separate pass -- the same launch alone, after the fitting
+    # legs have heated the part -- stays in the line as a cross-check
+    kernel_ms = kernel_ms_in_loop if k_count.value == args.steps else kernel_ms_separate
     achieved = n * HAND_FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12
     # ---- secondary figure: the same step with the exact far-field early-out enabled ("may additionally
     #      be reported culled"); `value` above stays the dense number
@@ -677,6 +821,8 @@ def main():
         fitting['roofline_dense'] = {'bound': 'mfma', 'what': 'the same step with every sample evaluated (single_12_dense)', 'flop_per_step': flop_d,
                                      'achieved': flop_d / sec_d / 1e12, 'peak': f16x3_peak, 'unit': 'TFLOP/s', 'frac': flop_d / sec_d / 1e12 / f16x3_peak}
         fitting['n_gpus'] = world
+        if rccl_leg is not None:
+            fitting['rccl_one_rank'] = rccl_leg
         fitting['config'] = ('C3/C4: fitting_single, %d rays x %d shared depths, both fields, 8 synthetic views, the reference\'s six-leaf pose chain, %d frames; '
                              'C5: fitting_video windows of %d frames x %d rays over a %d-frame sequence, fit type 1234, windows sharded over the GPUs with the '
                              'pose-gradient all-reduce' % (FIT_RAYS, FIT_N + 2 * FIT_IMP, C4_FRAMES, VID_FRAMES, VID_RAYS, C5_FRAMES))
@@ -718,6 +864,9 @@ def main():
         'roofline': {'bound': 'mfma', 'kernel': kname, 'achieved': achieved,
                      'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                      'traffic': traffic, 'traffic_source': traffic_src, 'traffic_note': traffic_note, 'kernel_ms': kernel_ms,
+                     'kernel_ms_what': ('mean over the %d field-evaluation launches of the timed steps themselves (HIP events on the launch stream, '
+                                        'hn_debug_field_timer)' % k_count.value) if k_count.value == args.steps else 'separate pass (the in-loop timer saw %d launches)' % k_count.value,
+                     'kernel_ms_separate_pass': kernel_ms_separate,
                      'flop_per_launch': n * HAND_FLOP_PER_SAMPLE,
                      'mfma_issued_tflops': achieved * (3.0 if args.precision == 'f16x3' else 1.0),
                      'mfma_peak_tflops': PEAK_F16_MFMA_TFLOPS if args.precision == 'f16x3' else PEAK_F32_MFMA_TFLOPS},

@@ -13,6 +13,7 @@ side by side on two streams; the per-field forward values it needs (rgb, alpha) 
 in the render workspace.  Nothing here computes on the host; torch only owns the buffers.
 """
 import ctypes
+import threading
 import weakref
 
 import torch
@@ -352,6 +353,7 @@ class Mat3InverseFn(torch.autograd.Function):
         L = _lib
         lib = L.load()
         (y,) = ctx.saved_tensors
+        _join_pending_side(y.device)        # (g may carry the stable term's share, produced on its own stream: see _PENDING_SIDE)
         gy = L.f32(g).reshape(-1, 9)
         gr = torch.empty_like(y)
         L.check(lib.hn_mat3_inverse_bwd(L.ptr(y), L.ptr(gy), y.shape[0], L.ptr(gr), L.stream_ptr()), 'hn_mat3_inverse_bwd')
@@ -455,13 +457,24 @@ class StableLossFn(torch.autograd.Function):
 # streams whose tail a step's main stream has still to wait for before gradients produced there are consumed: the stable term's
 # backward launches (FitWindowLossFn.backward, on the step's side stream); DualRenderFn.backward inserts the wait behind its own
 # launches -- the render's adjoint kernels are then already queued, and the wait costs nothing (they run longer)
-_PENDING_SIDE = []
+# Keyed per device; every node that may be the first consumer of those gradients drains its device's list (DualRenderFn, and --
+# for a loss used without the render's backward, detached render inputs, an exception in between -- the pose-side nodes
+# HaloChainFn / Mat3InverseFn, which receive them whatever else ran): a join is an event wait, and joining twice is free.
+_PENDING_SIDE = {}
+_PENDING_LOCK = threading.Lock()
 
 
-def _join_pending_side():
-    cur = torch.cuda.current_stream()
-    while _PENDING_SIDE:
-        cur.wait_stream(_PENDING_SIDE.pop())
+def _push_pending_side(stream):
+    with _PENDING_LOCK:
+        _PENDING_SIDE.setdefault(stream.device.index, []).append(stream)
+
+
+def _join_pending_side(device=None):
+    cur = torch.cuda.current_stream(device)
+    with _PENDING_LOCK:
+        todo = _PENDING_SIDE.pop(cur.device.index, [])
+    for st in todo:
+        cur.wait_stream(st)
 
 
 class FitWindowLossFn(torch.autograd.Function):
@@ -545,7 +558,7 @@ class FitWindowLossFn(torch.autograd.Function):
             if side != cur:
                 for x in (gb, gRt, gtt):
                     x.record_stream(cur)
-                _PENDING_SIDE.append(side)
+                _push_pending_side(side)
             gR_o, gt_o, g_bt = gRt, gtt, (gb.reshape(s_b) if s_b is not None else None)
         return (gc.reshape(s_c), gw.reshape(s_w), gsh.reshape(s_h), gso.reshape(s_o), gj_o.reshape(s_j), gR_o.reshape(s_r), gt_o.reshape(s_t),
                 gst.reshape(()) if (ctx.has_stable and term is None) else None, None, None, None, None, None, None, None, g_bt, None)

@@ -605,9 +605,31 @@ static size_t field_tape(const hn_field* f, int n_pts) {
     if (f->precision != HN_PREC_F16X3 || f->v2_adjonly == nullptr) return 0;
     return f->kind == HN_FIELD_OBJ ? v2::field2_obj_tape_bytes(n_pts) : v2::field2_hand_tape_bytes(n_pts);
 }
+// hn_debug_field_timer: event pairs around the evaluation launches (a measurement aid; see include/honerf.h)
+static std::atomic<int> g_field_timer{0};
+static std::mutex g_field_timer_mutex;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_field_timer_pairs;
+static int field_eval_launch(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt,
+                             const float* Tp, int n_frames, int ppf, float* sdf, float* grad, float* rgb, float* feat, void* ws,
+                             size_t ws_bytes, hipStream_t s, void* tape, size_t tape_bytes);
 static int field_eval(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt,
                       const float* Tp, int n_frames, int ppf, float* sdf, float* grad, float* rgb, float* feat, void* ws,
                       size_t ws_bytes, hipStream_t s, void* tape = nullptr, size_t tape_bytes = 0) {
+    if (g_field_timer.load(std::memory_order_relaxed) == 0 || n <= 0)
+        return field_eval_launch(f, pts, rays_d, n, spr, bt, Tp, n_frames, ppf, sdf, grad, rgb, feat, ws, ws_bytes, s, tape, tape_bytes);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HN_CHECK_HIP(hipEventCreate(&e0));
+    HN_CHECK_HIP(hipEventCreate(&e1));
+    HN_CHECK_HIP(hipEventRecord(e0, s));
+    const int rc = field_eval_launch(f, pts, rays_d, n, spr, bt, Tp, n_frames, ppf, sdf, grad, rgb, feat, ws, ws_bytes, s, tape, tape_bytes);
+    HN_CHECK_HIP(hipEventRecord(e1, s));
+    std::lock_guard<std::mutex> lk(g_field_timer_mutex);
+    g_field_timer_pairs.emplace_back(e0, e1);
+    return rc;
+}
+static int field_eval_launch(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt,
+                             const float* Tp, int n_frames, int ppf, float* sdf, float* grad, float* rgb, float* feat, void* ws,
+                             size_t ws_bytes, hipStream_t s, void* tape, size_t tape_bytes) {
     if (f->precision == HN_PREC_F16X3 && f->kind == HN_FIELD_OBJ)
         return v2::launch_field2_obj(f, pts, rays_d, n, spr, sdf, grad, rgb, feat, ws, ws_bytes, true, s, tape, tape_bytes);
     if (f->precision == HN_PREC_F16X3)
@@ -1303,8 +1325,9 @@ int hn_verts_loss(const float* Ra, const float* ta, const float* Rb, const float
                   float* gR, float* gt, hn_stream_t stream) {
     return hn::verts_loss(Ra, ta, Rb, tb, verts, n_verts, n_pairs, loss, gR, gt, (hipStream_t)stream);
 }
-int hn_leaf_rows_gather(const float* const* leaves6, const long long* rows, int n_rows, float* prm_hand, float* prm_obj, hn_stream_t stream) {
-    return hn::leaf_rows_gather(leaves6, rows, n_rows, prm_hand, prm_obj, (hipStream_t)stream);
+int hn_leaf_rows_gather(const float* const* leaves6, const long long* rows, int n_rows, int n_frames, float* prm_hand, float* prm_obj,
+                        hn_stream_t stream) {
+    return hn::leaf_rows_gather(leaves6, rows, n_rows, n_frames, prm_hand, prm_obj, (hipStream_t)stream);
 }
 int hn_leaf_rows_scatter(const float* g, const long long* rows, int n_rows, int n_frames, float* out, hn_stream_t stream) {
     return hn::leaf_rows_scatter(g, rows, n_rows, n_frames, out, (hipStream_t)stream);
@@ -1351,6 +1374,30 @@ int hn_debug_quad_max_blocks(int max_blocks) {
 int hn_debug_fused_rounds(int on) {
     hn::g_fused_rounds.store(on != 0 ? 1 : 0);
     return HN_OK;
+}
+int hn_debug_field_timer(int on) {
+    hn::g_field_timer.store(on != 0 ? 1 : 0);
+    return HN_OK;
+}
+int hn_debug_field_timer_read(double* total_ms, int* launches) {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
+    {
+        std::lock_guard<std::mutex> lk(hn::g_field_timer_mutex);
+        pairs.swap(hn::g_field_timer_pairs);
+    }
+    double sum = 0.0;
+    int rc = HN_OK;
+    for (auto& pr : pairs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pr.second) != hipSuccess || hipEventElapsedTime(&ms, pr.first, pr.second) != hipSuccess) rc = HN_EHIP;
+        sum += ms;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    if (total_ms != nullptr) *total_ms = sum;
+    if (launches != nullptr) *launches = (int)pairs.size();
+    if (rc != HN_OK) hn::set_error("hn_debug_field_timer_read: an event of the timer could not be read");
+    return rc;
 }
 int hn_debug_pace_phantom(int members) {
     hn::g_pace_phantom.store(members < 0 ? 0 : members);

@@ -69,7 +69,7 @@ struct UpsPre {
     const int *pos, *n_dev;
     const float* sdf_c;
 };
-int leaf_rows_gather(const float* const* leaves6, const long long* rows, int F, float* prm_h, float* prm_o, hipStream_t s);
+int leaf_rows_gather(const float* const* leaves6, const long long* rows, int F, int n, float* prm_h, float* prm_o, hipStream_t s);
 int leaf_rows_scatter(const float* g, const long long* rows, int F, int n, float* out, hipStream_t s);
 int pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt, const float* g_j3, const float* g_or, const float* g_ot, const float* g_or2,
                   const float* g_ot2, int n_frames, int which, float* out, hipStream_t s);

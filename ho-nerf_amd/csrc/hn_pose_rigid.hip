@@ -190,13 +190,15 @@ __global__ __launch_bounds__(256) void k_pose_side_vjp(const float* __restrict__
 struct LeafPtrs {
     const float* p[6];
 };
-__global__ void k_leaf_rows_gather(LeafPtrs L, const long long* __restrict__ rows, int F, float* __restrict__ prm_h, float* __restrict__ prm_o) {
+__global__ void k_leaf_rows_gather(LeafPtrs L, const long long* __restrict__ rows, int F, int n, float* __restrict__ prm_h, float* __restrict__ prm_o) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F * 54) return;
     const int f = i / 54, c = i % 54;
     const long long r = rows[f];
     float v = 0.f;
-    if (c < 20)
+    if (r < 0 || r >= n)                       // a row the leaves do not have: never dereferenced, and loud (NaN) in the step's losses
+        v = c < 45 ? __builtin_nanf("") : 0.f;
+    else if (c < 20)
         v = L.p[4][r * 20 + c];
     else if (c < 27)
         v = L.p[5][r * 7 + c - 20];
@@ -218,6 +220,7 @@ __global__ void k_leaf_rows_scatter(const float* __restrict__ g, const long long
     if (i >= F * 45) return;
     const int f = i / 45, c = i % 45;
     const long long r = rows[f];
+    if (r < 0 || r >= n) return;               // (no such row: nothing is written)
     const float v = g[i];
     // block offsets in `out`: obj_rot 0, obj_trans 6 n, palm_rot 9 n, palm_trans 15 n, joint 18 n, palm_angle 38 n
     size_t o;
@@ -262,12 +265,12 @@ int pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt, con
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
-int leaf_rows_gather(const float* const* leaves6, const long long* rows, int F, float* prm_h, float* prm_o, hipStream_t s) {
+int leaf_rows_gather(const float* const* leaves6, const long long* rows, int F, int n, float* prm_h, float* prm_o, hipStream_t s) {
     if (F <= 0) return HN_OK;
-    HN_REQUIRE(leaves6 != nullptr && rows != nullptr && prm_h != nullptr && prm_o != nullptr, "leaf_rows_gather: NULL argument");
+    HN_REQUIRE(leaves6 != nullptr && rows != nullptr && prm_h != nullptr && prm_o != nullptr && n >= 1, "leaf_rows_gather: NULL argument");
     LeafPtrs L;
     for (int i = 0; i < 6; ++i) L.p[i] = leaves6[i];
-    hipLaunchKernelGGL(k_leaf_rows_gather, dim3((F * 54 + 255) / 256), dim3(256), 0, s, L, rows, F, prm_h, prm_o);
+    hipLaunchKernelGGL(k_leaf_rows_gather, dim3((F * 54 + 255) / 256), dim3(256), 0, s, L, rows, F, n, prm_h, prm_o);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

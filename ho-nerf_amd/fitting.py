@@ -136,8 +136,10 @@ class FrameShardedRunner:
 
     def reduce(self):
         t = self.totals.to(self.device)
-        if self.dist is not None and self.world > 1:
+        self.allreduce_calls = getattr(self, 'allreduce_calls', 0)
+        if self.dist is not None and (self.world > 1 or FORCE_COLLECTIVE):
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            self.allreduce_calls += 1
         t = t.cpu()
         n = max(float(t[-1]), 1.0)
         out = {k: float(t[i]) / n for i, k in enumerate(LOSS_KEYS[:-1])}
@@ -157,7 +159,35 @@ def mask_pixels(mask, n_rays, rng):
     return np.stack([x, y], -1).astype(np.float32), py * W + px
 
 
-def allreduce_pose_gradients(params, dist=None, average=False):
+# HONERF_FORCE_COLLECTIVE=1 (or fitting.FORCE_COLLECTIVE = True): the collectives of the sharded loops are issued on a process group
+# of ONE rank too, where they are the identity -- so that the RCCL path (communicator, device-side all-reduce between the backward
+# pass and Adam, the loss reduction of the frame-sharded runner) can be executed and checked on a single GPU.
+FORCE_COLLECTIVE = os.environ.get('HONERF_FORCE_COLLECTIVE') == '1'
+
+
+def _grad_block(params):
+    """The gradients of `params` as ONE flat tensor when they already are one: contiguous fp32 views that tile a range of a single
+    storage without gaps IN THE ORDER OF `params` (HaloChainFn.backward hands out the six leaves' gradients of a window as views of
+    one [n x 45] block laid out in that order), so that the block is element for element what `cat` of the gradients would be --
+    every rank must present the same layout to the collective, and a rank without a window presents the cat of zeros.  None otherwise."""
+    gs = [p.grad for p in params]
+    if not gs or any(g is None or not g.is_contiguous() or g.dtype != torch.float32 for g in gs):
+        return None
+    base = gs[0].untyped_storage().data_ptr()
+    if any(g.untyped_storage().data_ptr() != base or g.device != gs[0].device for g in gs):
+        return None
+    spans = [(g.storage_offset(), g.numel()) for g in gs]
+    at = spans[0][0]
+    for off, n in spans:
+        if off != at:
+            return None
+        at += n
+    flat = gs[0].new_empty(0)
+    flat.set_(gs[0].untyped_storage(), spans[0][0], (at - spans[0][0],), (1,))
+    return flat
+
+
+def allreduce_pose_gradients(params, dist=None, average=False, force=None):
     """Window-parallel `fitting_video` step: every rank has back-propagated ITS window's loss into the
     shared `[data_num, ...]` pose parameters (non-zero on the window's 4 rows); one all-reduce (SUM) of the flattened
     gradient block -- data_num x 45 floats, ~18 KB at 100 frames: latency-bound, a single call -- makes the gradients
@@ -168,12 +198,24 @@ def allreduce_pose_gradients(params, dist=None, average=False):
     receives several contributions in one step, where the reference's sequential schedule would take as many Adam
     steps (fitting_video.py:340-342).  That is the schedule change SURVEY 8(e) accepts (Jacobi over `world` windows);
     Adam's per-element normalisation keeps the step size independent of how many windows touched a row.  Pass
-    `average=True` to divide by the world size instead (plain data-parallel mean)."""
+    `average=True` to divide by the world size instead (plain data-parallel mean).
+
+    The gradients the device loops produce are views of one contiguous block already (`_grad_block`): that block is reduced IN
+    PLACE -- one collective, no gather / scatter launches around it; anything else (a rank without a window, gradients from
+    separate allocations) is flattened, reduced and copied back.  `force` (default: FORCE_COLLECTIVE) issues the collective on
+    a one-rank group too."""
     if dist is None:
         import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    force = FORCE_COLLECTIVE if force is None else force
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return 0
     params = list(params)
+    flat = _grad_block(params)
+    if flat is not None:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if average:
+            flat /= dist.get_world_size()
+        return int(flat.numel())
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
@@ -211,7 +253,9 @@ def _index_tensor(owner, index, device):
     """The window's frame ids as a device tensor, cached on the chain: a window is visited sub_iters x views times per
     pass, and a fresh host list would be a host -> device copy in front of every step."""
     if isinstance(index, torch.Tensor):
-        return index.to(device)
+        if index.dtype == torch.bool or index.is_floating_point():
+            raise IndexError('a window is a list of integer frame ids')
+        return index.to(device=device, dtype=torch.long).contiguous()
     cache = owner.__dict__.setdefault('_idx_cache', {})
     key = tuple(int(i) for i in index)
     if key not in cache:
@@ -354,6 +398,12 @@ class HaloPoseChain:
             from .pose import HaloChainFn
             consts = (self.joints0, self.bone_len, self.Ro_pred, self.To_pred, self.T_pose_21)
             rows = index.tolist() if isinstance(index, torch.Tensor) else [int(i) for i in index]      # (a tensor index: one transfer)
+            n_all = self.joints0.shape[0]
+            if any(r < -n_all or r >= n_all for r in rows):
+                raise IndexError('window %s outside the sequence of %d frames' % (rows, n_all))
+            if any(r < 0 for r in rows):          # python's negative frame ids: as advanced indexing takes them
+                rows = [r % n_all for r in rows]
+                idx = _index_tensor(self, rows, self.joints0.device)
             # keyed on the constants' storage and version as well as on the rows: replacing or editing a constant drops its windows
             key = (tuple(rows), tuple((x.data_ptr(), x._version) for x in consts))
             cache = self.__dict__.setdefault('_window_consts', {})
@@ -540,8 +590,8 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
             if isinstance(x, torch.Tensor) and x.is_cuda:
                 x.record_stream(side)
     use_side = video and rays_o.is_cuda and rays_fn is None and USE_SIDE_STREAM and (want_stable or not fused_loss)
-    term_form = use_side and fused_loss and want_stable and getattr(renderer, 'fused_stable', True) and \
-        (getattr(renderer, 'precision', None) or 'f16x3') == 'f16x3'
+    term_form = use_side and fused_loss and want_stable and obj_verts_for_stable is not None and \
+        getattr(renderer, 'fused_stable_applies', lambda pts: False)(obj_verts_for_stable)
     if use_side:
         pose_ready = torch.cuda.Event()
         pose_ready.record()                      # the pose chain's outputs are complete here (the render's launches come after)
@@ -794,6 +844,10 @@ class PipelinedSingleFit:
     def _sized(self, R, S):
         if R == self._n_rays:
             return
+        if self._rays is not None:
+            # the previous step's object half (adjoint, Adam, VJP) may still be reading the buffers dropped below on the second
+            # stream; they were allocated on the caller's stream, so the allocator could hand their blocks to the new tensors at once
+            self.finish()
         dev = self.dev
         e = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         n = R * S
@@ -848,6 +902,9 @@ class PipelinedSingleFit:
         else:
             tr = L.f32(t_rand, dev).reshape(R, 1)
         need = lib.hn_render_dual_workspace_bytes(hand.handle, obj.handle, R, ren.n_samples, ren.n_importance)
+        from .renderer import _POISON
+        if _POISON:
+            self.finish()     # (the debug fill of workspace and tape runs on this stream: not under the previous step's object adjoint)
         ws = ren._ws.get(need, dev)
         tape_bytes = lib.hn_render_dual_tape_bytes(hand.handle, obj.handle, R, S)
         tape = ren._tape.get(tape_bytes, dev)
@@ -1005,7 +1062,7 @@ def fit_sequence_video(renderer, window_views, pose_chain, near, far, data_num, 
                     else:
                         for p in pose_chain.parameters():
                             p.grad = None
-                    n = fit_apply(optimizer, pose_chain, dist, sync=world > 1)
+                    n = fit_apply(optimizer, pose_chain, dist, sync=world > 1 or (dist is not None and FORCE_COLLECTIVE))
                     stats['allreduce_calls'] += int(n > 0)
                     stats['allreduce_floats'] += n
                     stats['steps'] += 1
@@ -1042,6 +1099,7 @@ def fit_frames_sharded(renderer, n_frames, make_frame, near, far, fit_type='12',
     out = runner.run(frame_fn)
     out['steps'] = steps[0]
     out['rank_frames'] = list(runner.frames)
+    out['allreduce_calls'] = getattr(runner, 'allreduce_calls', 0)
     return out
 
 

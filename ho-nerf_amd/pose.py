@@ -214,6 +214,12 @@ class HaloChainFn(torch.autograd.Function):
         F, dev = ori_pose.shape[0], ori_pose.device
         st = L.stream_ptr()
         n = obj_rot.shape[0]
+        if rows is not None:
+            # the kernels read the index as int64 whatever the caller's tensor held (an int32 / uint8 index tensor was accepted by
+            # index_select's successors here and read as garbage); rows outside [0, n) are never dereferenced (hn_leaf_rows_gather)
+            if rows.dtype == torch.bool or rows.dim() != 1 or rows.shape[0] != F:
+                raise IndexError('HaloChainFn: rows must be one integer frame id per frame of the window')
+            rows = rows.to(device=dev, dtype=torch.long).contiguous()
         ctx.rows, ctx.n = rows, n
         leaves = (obj_rot, obj_trans, palm_rot, palm_trans, joint_angle, palm_angle)
         if rows is not None and all(x.is_contiguous() and x.dtype == torch.float32 for x in leaves):
@@ -222,7 +228,7 @@ class HaloChainFn(torch.autograd.Function):
             prm_h = torch.empty(F, 36, device=dev, dtype=torch.float32)
             prm_o = torch.empty(F, 18, device=dev, dtype=torch.float32)
             ptrs = (ctypes.c_void_p * 6)(*[x.data_ptr() for x in leaves])
-            L.check(lib.hn_leaf_rows_gather(ptrs, L.ptr(rows), F, L.ptr(prm_h), L.ptr(prm_o), st), 'hn_leaf_rows_gather')
+            L.check(lib.hn_leaf_rows_gather(ptrs, L.ptr(rows), F, n, L.ptr(prm_h), L.ptr(prm_o), st), 'hn_leaf_rows_gather')
         else:
             prm = torch.cat([joint_angle.reshape(n, 20), palm_angle.reshape(n, 7), palm_rot.reshape(n, 6), palm_trans.reshape(n, 3),
                              obj_rot.reshape(n, 6), obj_trans.reshape(n, 3), _zeros9(n, dev)], dim=1)    # [n, 45 + 9]: one launch
@@ -263,6 +269,8 @@ class HaloChainFn(torch.autograd.Function):
         lib = L.load()
         F = ctx.F
         dev = ctx.jac_h.device
+        from .autograd import _join_pending_side
+        _join_pending_side(dev)      # (upstream gradients produced on a side stream by the loss node: joined by whoever consumes them first)
         c = lambda t, n: None if t is None else L.f32(t).reshape(F, n)
         gb, gj, gr, gt = c(g_bt, 336), c(g_j3, 63), c(g_or, 9), c(g_ot, 3)
         g = torch.empty(F, 45, device=dev, dtype=torch.float32)

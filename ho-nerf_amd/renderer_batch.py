@@ -36,6 +36,18 @@ class NeuSRenderer_fitting(_Unbatched):
             'gradient_obj': o['grad_obj'],
         }
 
+    STABLE_MAX_FRAMES, STABLE_MAX_SEL = 8, 1024     # hn_stable_value: frames per window, selected vertices (every 10th) per frame
+
+    def fused_stable_applies(self, pts):
+        """Whether the fused form of the stable term (StableTerm / StableLossFn over hn_stable_value) takes these vertices: an f16x3
+        hand field, at most 8 frames, at most 1024 SELECTED vertices per frame (hn_stable_value keeps the selection of a window in
+        LDS) -- i.e. object meshes of up to 10 240 vertices.  Anything else goes through the torch-operator form below, which has no
+        limit, as the reference (utils/renderer_batch.py:318-371)."""
+        hand = self.fields()[0]
+        shape = pts.shape if hasattr(pts, 'shape') else torch.as_tensor(pts).shape
+        return (getattr(self, 'fused_stable', True) and (hand.precision or 'f16x3') == 'f16x3' and len(shape) == 3
+                and shape[0] <= self.STABLE_MAX_FRAMES and (shape[1] + 9) // 10 <= self.STABLE_MAX_SEL)
+
     def get_stable_loss_cross(self, pts, bt_inv, T_pose_21, Ro, To, as_term=False):
         """utils/renderer_batch.py:318-371: the 'stable' term of fitting_video (fit type '1234', weight x100 at
         fitting_video.py:322-324).  pts [F,V,3]: the object's vertices per frame of the window; every 10th vertex is
@@ -50,7 +62,7 @@ class NeuSRenderer_fitting(_Unbatched):
         the mask takes (vertex 1 if any vertex is inside, vertex 0 if any is outside) and the 'outside' candidates
         include the inside vertices themselves; with strict_reference = False the complement of the inside set is used."""
         hand = self.fields()[0]
-        if getattr(self, 'fused_stable', True) and (hand.precision or 'f16x3') == 'f16x3' and _lib.f32(pts).shape[0] <= 8:
+        if self.fused_stable_applies(pts):
             # the whole term as one autograd node over a handful of launches (autograd.StableLossFn)
             from .autograd import StableLossFn, StableTerm
             from .renderer import _Workspace
@@ -61,7 +73,7 @@ class NeuSRenderer_fitting(_Unbatched):
                 with torch.no_grad():
                     return StableTerm(g_(pts), g_(bt_inv), g_(T_pose_21), g_(Ro), g_(To), hand, self._stable_state, bool(self.strict_reference))
             return StableLossFn.apply(g_(pts), g_(bt_inv), g_(T_pose_21), g_(Ro), g_(To), hand, self._stable_state, bool(self.strict_reference))
-        assert not as_term, 'the explicit form of the stable term needs an f16x3 hand field and at most 8 frames'
+        assert not as_term, 'the explicit form of the stable term needs an f16x3 hand field, at most 8 frames and at most 10 240 vertices'
         from .autograd import HandSdfFn
         dev = torch.device('cuda')
         g = lambda x: (x if isinstance(x, torch.Tensor) else torch.as_tensor(x)).to(device=dev, dtype=torch.float32)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 114 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 115 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -137,6 +137,13 @@ int hn_debug_quad_max_blocks(int max_blocks);
  * track).  on = 0: the separate launches (hn_merge, the scatter, hn_upsample, the copy, hn_sample_points) instead; results are
  * bit-identical either way.  Process-wide; for tests and A/B timing. */
 int hn_debug_fused_rounds(int on);
+/* Measurement aid (bench.py): while on, every EVALUATION launch of a field (hn_field_eval and the final evaluation inside
+ * hn_render_single / hn_render_dual) is bracketed by two HIP events recorded on the stream it is launched on;
+ * hn_debug_field_timer_read waits for the recorded pairs, returns their summed duration in milliseconds and their number, and
+ * forgets them.  This is how the bench line times the dominant kernel INSIDE the timed steps (so that kernel time <= step time by
+ * construction) instead of in a separate pass.  Process-wide; off by default; not a product path. */
+int hn_debug_field_timer(int on);
+int hn_debug_field_timer_read(double* total_ms, int* launches);
 
 /* ---- rays -----------------------------------------------------------------------------
  * _xy_to_ray_bundle (utils/utils.py:31-115): NDC xy -> unproject at depth 1 and
@@ -287,8 +294,11 @@ int hn_jacobian_vjp(const float* jac, const float* g, int n_frames, int n_out, i
  * obj_rot [n,6], obj_trans [n,3], palm_rot [n,6], palm_trans [n,3], joint_refine_angle [n,20], palm_refine_angle [n,7], contiguous) as
  * the pose chain's input blocks, prm_hand [n_rows,36] (hn_pose_chain) and prm_obj [n_rows,18] (hn_rigid_pose; columns 9..17 zero), one
  * launch; and back: g [n_rows,45] = hn_pose_side_vjp's output scattered into those rows of six contiguous gradient blocks laid out one
- * behind the other in `out` (n_frames x 45 floats, zeroed by the caller): [n,6] [n,3] [n,6] [n,3] [n,20] [n,7]. */
-int hn_leaf_rows_gather(const float* const* leaves6, const long long* rows, int n_rows, float* prm_hand, float* prm_obj, hn_stream_t stream);
+ * behind the other in `out` (n_frames x 45 floats, zeroed by the caller): [n,6] [n,3] [n,6] [n,3] [n,20] [n,7].  Both take the number
+ * of frames n the leaves hold: a row outside [0, n) is never dereferenced -- the gather writes NaN for it (the step's losses then say
+ * so), the scatter drops it (torch's index_select / index_copy_ would have raised; a device-side index cannot without a sync). */
+int hn_leaf_rows_gather(const float* const* leaves6, const long long* rows, int n_rows, int n_frames, float* prm_hand, float* prm_obj,
+                        hn_stream_t stream);
 int hn_leaf_rows_scatter(const float* g, const long long* rows, int n_rows, int n_frames, float* out, hn_stream_t stream);
 int hn_pose_side_vjp(const float* jac_h, const float* jac_o, const float* g_bt_inv, const float* g_joint_3d, const float* g_obj_r,
                      const float* g_obj_t, const float* g_obj_r2, const float* g_obj_t2, int n_frames, int which, float* out,

@@ -361,9 +361,88 @@ def pose_goldens():
         oris.append(joints); bls.append(bl); prms.append(prm); outs.append(o64); jacs.append(j64)
         floor.append(np.abs(o32 - o64).max() / np.abs(o64).max())
         print('pose chain case %d: |out| max %.3f, fp32 run vs fp64 run %.2e, |jac| max %.3f' % (c, np.abs(o64).max(), floor[-1], np.abs(j64).max()))
+    # ---- round 5: 24 more hands, so that the chain is pinned WHERE IT IS USED and away from the easy middle.
+    # Cases 0 .. 5 above are unchanged (same generator stream).  `kinds` names every case in the fixture.
+    kinds = ['initial state'] + ['moderate refinements'] * 5
+    rng2 = np.random.RandomState(2025)
+
+    def add(kind, joints, bl, prm):
+        o64, j64 = run(torch.float64, joints, bl, prm, True)
+        o32, _ = run(torch.float32, joints, bl, prm, False)
+        if not (np.isfinite(o64).all() and np.isfinite(j64).all()):
+            print('pose chain case (%s): the reference itself is not finite here -- not a fixture' % kind)
+            return
+        oris.append(joints); bls.append(bl); prms.append(prm); outs.append(o64); jacs.append(j64); kinds.append(kind)
+        floor.append(np.abs(o32 - o64).max() / np.abs(o64).max())
+        print('pose chain case %d (%s): |out| max %.3f, fp32 run vs fp64 run %.2e, |jac| max %.3f'
+              % (len(oris) - 1, kind, np.abs(o64).max(), floor[-1], np.abs(j64).max()))
+
+    def bone_lengths(j):          # what bench.build_fit_data passes: fitting.bone_lengths_of (kp3D_to_bones on the biomech order)
+        kb = j[m2b]
+        return np.array([np.linalg.norm(kb[i + 1] - kb[0 if i < 5 else i - 4]) for i in range(20)])
+
+    def leaves_to_prm(leaves, f):  # chain.parameters() order: obj_rot, obj_trans, palm_rot, palm_trans, joint_refine_angle, palm_refine_angle
+        return np.concatenate([leaves[4][f], leaves[5][f], leaves[2][f].reshape(-1), leaves[3][f]]).astype(np.float64)
+
+    def perturbed_leaves(n, scale, seed):      # tests/test_whole_step.py::_perturb on a HaloPoseChain of n frames at its initial state
+        shapes = [(n, 3, 2), (n, 3), (n, 3, 2), (n, 3), (n, 20), (n, 7)]
+        eye62 = np.eye(3)[:, :2]
+        init = [np.tile(eye62, (n, 1, 1)), np.zeros((n, 3)), np.tile(eye62, (n, 1, 1)), np.zeros((n, 3)), np.zeros((n, 20)), np.zeros((n, 7))]
+        return [a + (scale * torch.randn(sh, generator=torch.Generator().manual_seed(seed + i))).float().numpy()
+                for i, (a, sh) in enumerate(zip(init, shapes))]
+    # (a) the whole-step tests' own hands: bench.build_fit(seed 40, 1 frame) + _perturb(4e-3, 50); (seed 41, 4 frames) + _perturb(4e-3, 60);
+    #     the reproducibility tests' (4e-3, 70) and (1e-2, 20)
+    for seed, n, scale, pseed, what in ((40, 1, 4e-3, 50, 'whole-step C3'), (41, 4, 4e-3, 60, 'whole-step C5'), (40, 1, 4e-3, 70, 'reproducibility C3'),
+                                        (41, 4, 1e-2, 20, 'reproducibility C5')):
+        _, _, j = synth.synth_hand_pose(seed)
+        j = j.astype(np.float32)
+        from honerf_amd.fitting import bone_lengths_of          # exactly what bench.build_fit_data hands the chain (fp32)
+        bl = bone_lengths_of(j[None])[0].numpy()
+        lv = perturbed_leaves(n, scale, pseed)
+        for f in range(n):
+            add('%s hand, frame %d' % (what, f), j.astype(np.float64), bl.astype(np.float64), leaves_to_prm(lv, f))
+    # (b) large joint angles and palm motions (an optimisation that has moved far from the prediction)
+    for c in range(6):
+        _, _, joints = synth.synth_hand_pose(200 + c, center=(0.02 * c - 0.05, 0.03, 0.8 + 0.05 * c), flex=0.2 + 0.15 * c)
+        joints = joints.astype(np.float64) + 0.004 * rng2.standard_normal((21, 3))
+        bl = bone_lengths(joints) * (1.0 + 0.1 * rng2.standard_normal(20))
+        prm = np.zeros(36)
+        prm[27:33] = np.eye(3)[:, :2].reshape(-1)
+        prm[0:20] = 0.5 * rng2.standard_normal(20)
+        prm[20:27] = 0.9 * rng2.standard_normal(7)
+        prm[27:33] += 0.6 * rng2.standard_normal(6)
+        prm[33:36] = 0.05 * rng2.standard_normal(3)
+        add('large angles', joints, bl, prm)
+    # (c) near-degenerate geometry: a nearly planar hand (the synthetic hand's own plane, 2e-4 off it), nearly straight fingers
+    #     (flex 0.01), very short and very long bones
+    for c, (flex, off, bl_scale) in enumerate(((0.3, 2e-4, 1.0), (0.01, 4e-3, 1.0), (0.01, 5e-4, 1.0), (0.35, 4e-3, 0.05), (0.35, 4e-3, 3.0),
+                                               (0.6, 1e-3, 0.3))):
+        _, _, joints = synth.synth_hand_pose(300 + c, center=(0.0, 0.0, 0.9), flex=flex)
+        joints = joints.astype(np.float64) + off * rng2.standard_normal((21, 3))
+        bl = bone_lengths(joints) * bl_scale
+        prm = np.zeros(36)
+        prm[27:33] = np.eye(3)[:, :2].reshape(-1)
+        prm[0:20] = 0.1 * rng2.standard_normal(20)
+        prm[20:27] = 0.3 * rng2.standard_normal(7)
+        prm[27:33] += 0.15 * rng2.standard_normal(6)
+        prm[33:36] = 0.01 * rng2.standard_normal(3)
+        add('near-degenerate: flex %.2f, %.0e off the plane, bone lengths x %.2f' % (flex, off, bl_scale), joints, bl, prm)
+    # (d) the bench's sequence (seed 60, drift 0.002): two of its frames at moderate refinements
+    rs = np.random.RandomState(60)
+    _, _, j = synth.synth_hand_pose(60)
+    rs.standard_normal((2000, 3))
+    steps = np.cumsum(rs.standard_normal((8, 1, 3)).astype(np.float32) * 0.002, axis=0)
+    for f in (3, 7):
+        jj = (j[None] + steps)[f].astype(np.float64)
+        prm = np.zeros(36)
+        prm[27:33] = np.eye(3)[:, :2].reshape(-1)
+        prm[0:20] = 0.05 * rng2.standard_normal(20)
+        prm[20:27] = 0.1 * rng2.standard_normal(7)
+        add('bench sequence frame %d' % f, jj, bone_lengths_of(jj.astype(np.float32)[None])[0].numpy().astype(np.float64), prm)
+    N = len(oris)
     outs = np.stack(outs)
     save('pose_chain', ori_pose=np.stack(oris), bone_len=np.stack(bls), params=np.stack(prms), bt_inv=outs[:, :336].reshape(N, 21, 4, 4),
-         joint_3d=outs[:, 336:].reshape(N, 21, 3), jac=np.stack(jacs), ref32_vs_ref64=np.array(floor))
+         joint_3d=outs[:, 336:].reshape(N, 21, 3), jac=np.stack(jacs), ref32_vs_ref64=np.array(floor), kinds=np.array(kinds))
 
 
 def main():

@@ -394,6 +394,70 @@ def test_fit_sequence_video_two_ranks_match_the_jacobi_schedule():
         assert torch.equal(a, b.detach())
 
 
+def test_grad_block_is_the_cat_of_the_gradients_or_nothing():
+    """allreduce_pose_gradients reduces the leaves' gradients IN PLACE when they are views of one block laid out in parameter
+    order (what HaloChainFn.backward hands out for a window) -- and only then: any other layout goes through cat / copy."""
+    n = 5
+    sizes = (6, 3, 6, 3, 20, 7)
+    ps = [torch.zeros(n, k, requires_grad=True) for k in sizes]
+    block = torch.arange(n * 45, dtype=torch.float32)
+    off = 0
+    for p, k in zip(ps, sizes):
+        p.grad = block[off:off + n * k].view(n, k)
+        off += n * k
+    flat = fitting._grad_block(ps)
+    assert flat is not None and flat.data_ptr() == block.data_ptr() and torch.equal(flat, torch.cat([p.grad.reshape(-1) for p in ps]))
+    flat += 1.0                                   # in place: the leaves' gradients see it
+    assert float(ps[3].grad[0, 0]) == float(block[15 * n])
+    # a block whose storage order is not the parameter order is not "the cat": refused
+    ps[0].grad, ps[2].grad = ps[2].grad, ps[0].grad
+    assert fitting._grad_block(ps) is None
+    ps[0].grad, ps[2].grad = ps[2].grad, ps[0].grad
+    # a gap, a missing gradient, separate allocations: refused
+    g = ps[5].grad
+    ps[5].grad = g.clone()
+    assert fitting._grad_block(ps) is None
+    ps[5].grad = None
+    assert fitting._grad_block(ps) is None
+    ps[5].grad = g
+    assert fitting._grad_block(ps[1:]) is not None      # (a sub-range that starts inside the block is still contiguous)
+
+
+def test_forced_collective_on_a_one_rank_group_is_the_identity(monkeypatch):
+    """HONERF_FORCE_COLLECTIVE: the sharded loops' collectives are issued on a group of ONE rank too (the single-GPU RCCL check of
+    tests/test_gpu_surface.py / bench.py --rccl-one-rank); here over gloo: the count says they ran, the values say identity."""
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+    try:
+        ps = [torch.zeros(4, k, requires_grad=True) for k in (6, 3)]
+        block = torch.randn(4 * 9)
+        ps[0].grad, ps[1].grad = block[:24].view(4, 6), block[24:].view(4, 3)
+        before = block.clone()
+        assert fitting.allreduce_pose_gradients(ps, dist) == 0                     # one rank, not forced: no collective
+        assert fitting.allreduce_pose_gradients(ps, dist, force=True) == 36        # forced: the block, in place
+        assert torch.equal(block, before)
+        ps[1].grad = ps[1].grad.clone()                                            # separate allocations: the cat / copy path
+        assert fitting.allreduce_pose_gradients(ps, dist, force=True) == 36
+        assert torch.equal(torch.cat([p.grad.reshape(-1) for p in ps]), before)
+        plain = fitting.FrameShardedRunner(5, rank=0, world=1).run(_frame_terms)
+        monkeypatch.setattr(fitting, 'FORCE_COLLECTIVE', True)
+        runner = fitting.FrameShardedRunner(5)
+        forced = runner.run(_frame_terms)
+        assert runner.allreduce_calls == 1 and forced == plain
+        out = _run_sequence(dist)
+        assert out[1]['allreduce_calls'] == out[1]['steps'] > 0
+        monkeypatch.setattr(fitting, 'FORCE_COLLECTIVE', False)
+        ref = _run_sequence(None)
+        assert ref[1]['allreduce_calls'] == 0
+        for a, b in zip(out[0], ref[0]):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
+
+
 def _frames_worker(rank, world, port, q, tmp):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist

@@ -748,3 +748,95 @@ def test_pipelined_single_fit_equals_the_autograd_step():
         assert torch.equal(a, b), i
     for x, y in zip(la, lb):
         bounded('pipelined vs autograd: loss after further steps (relative difference)', abs(x - y) / abs(x), 0.0)
+
+
+def test_rccl_one_rank_group_runs_the_collectives_of_the_sharded_loops():
+    """north_star: "RCCL over xGMI for the loss all-reduce".  On the ONE GPU there is, a process group of one rank over the `nccl`
+    backend (= RCCL) is brought up in a child process before anything else touches the device; `fit_sequence_video` then issues its
+    device-side all-reduce of the [data_num x 45] pose-gradient block on EVERY step (between the backward pass and Adam, in place on
+    the block autograd hands out) and `fit_frames_sharded` its loss reduction, not short-circuited at world == 1
+    (fitting.FORCE_COLLECTIVE; fitting_video.py:340-342, fitting_single.py:289-291 are the loops it sits in).  A one-rank SUM is the
+    identity: the run equals the run without a collective to the bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    torch.cuda.synchronize()
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--rccl-one-rank', '--fit-quick'], capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')]
+    assert lines, (r.returncode, r.stderr[-2000:])
+    res = json.loads(lines[-1])
+    assert res['backend'] == 'nccl' and res['world'] == 1
+    v, f = res['fit_sequence_video'], res['fit_frames_sharded']
+    assert v['steps'] > 0 and v['allreduce_calls'] == v['steps'] and v['allreduce_calls_without_force'] == 0
+    assert v['allreduce_floats_per_step'] == v['data_num'] * 45
+    assert v['bit_identical_to_the_run_without_collective']
+    assert f['allreduce_calls'] == 1 and f['allreduce_calls_without_force'] == 0 and f['bit_identical_to_the_run_without_collective']
+    assert r.returncode == 0 and res['ok']
+    record('rccl one-rank leg: ms per window step with / without the all-reduce', v['ms_per_step_with_collective'], 1e9)
+
+
+def test_stable_term_of_a_large_mesh_takes_the_unbounded_form(golden):
+    """hn_stable_value keeps a window's selection in LDS (<= 1024 selected vertices per frame, i.e. object meshes of up to
+    10 240 vertices); a larger mesh must go through the torch-operator form, which has no limit -- as the reference
+    (utils/renderer_batch.py:318-371) -- instead of raising.  A 12 000-vertex mesh: dispatch refuses the fused form, the value is
+    finite and differentiable, and on a mesh both forms take they agree."""
+    g = golden('stable_loss')
+    ren = _dual(batched=True)
+    F_ = g['bt_inv'].shape[0]
+    rng = np.random.RandomState(3)
+    small = cu(g['obj_verts'])
+    assert ren.fused_stable_applies(small)
+    bt, R, T = (cu(g[k]).clone().requires_grad_(True) for k in ('bt_inv', 'obj_r', 'obj_t'))
+    fused = ren.get_stable_loss_cross(small, bt, cu(g['T_pose']), R, T)
+    ren.fused_stable = False
+    plain = ren.get_stable_loss_cross(small, bt, cu(g['T_pose']), R, T)
+    ren.fused_stable = True
+    assert_close(plain, fused.detach().cpu().numpy(), 2e-5, 'stable term: torch-operator form vs fused form')
+    big = np.repeat(g['obj_verts'], 30, axis=1)[:, :12000] + 1e-4 * rng.standard_normal((F_, 12000, 3)).astype(np.float32)
+    assert not ren.fused_stable_applies(cu(big))
+    loss = ren.get_stable_loss_cross(cu(big), bt, cu(g['T_pose']), R, T)
+    assert torch.isfinite(loss)
+    loss.backward()
+    assert all(torch.isfinite(x.grad).all() for x in (bt, R, T))
+
+
+def test_window_rows_are_read_as_int64_whatever_the_index_holds():
+    """the window path of the pose chain hands the frame ids to kernels that read int64.  An int32 index tensor, a python
+    list and an int64 tensor must give the same poses and the same leaf gradients; rows outside the sequence raise on the host (the
+    chain has the list there), and the kernels never dereference one (gather: NaN, scatter: dropped)."""
+    import bench
+    from honerf_amd import fitting as F, lib as L
+    dev = torch.device('cuda')
+    chain, j, verts = bench.build_fit_data(dev, 60, 7, halo=True, drift=0.002)
+    outs = []
+    for index in ([2, 3, 4, 5], torch.tensor([2, 3, 4, 5], dtype=torch.int32, device=dev), torch.tensor([2, 3, 4, 5]), [-5, -4, -3, -2]):
+        for p in chain.parameters():
+            p.grad = None
+        pose = chain(index)
+        (pose['bt_inv'].sum() + pose['obj_r'].sum() * 0.5 + pose['joint_3d'].sum()).backward()
+        torch.cuda.synchronize()
+        outs.append((pose['bt_inv'].detach().clone(), [p.grad.detach().clone() for p in chain.parameters()]))
+    for bt, gs in outs[1:]:
+        assert torch.equal(bt, outs[0][0])
+        for a, b in zip(gs, outs[0][1]):
+            assert torch.equal(a, b)
+    assert float(outs[0][1][4][:2].abs().max()) == 0.0 and float(outs[0][1][4][2:6].abs().max()) > 0.0
+    with pytest.raises(IndexError):
+        chain([4, 5, 6, 7])
+    with pytest.raises(IndexError):
+        chain(torch.tensor([True, False, True, True]))
+    # the kernels themselves: an out-of-range row reads as NaN and writes nothing
+    import ctypes
+    lib = L.load()
+    leaves = [p.detach() for p in chain.parameters()]
+    ptrs = (ctypes.c_void_p * 6)(*[x.data_ptr() for x in leaves])
+    rows = torch.tensor([1, 7, -1, 3], dtype=torch.long, device=dev)
+    ph, po = torch.zeros(4, 36, device=dev), torch.zeros(4, 18, device=dev)
+    L.check(lib.hn_leaf_rows_gather(ptrs, L.ptr(rows), 4, 7, L.ptr(ph), L.ptr(po), L.stream_ptr()), 'hn_leaf_rows_gather')
+    assert torch.isnan(ph[1]).all() and torch.isnan(ph[2]).all() and torch.isfinite(ph[0]).all() and torch.isfinite(ph[3]).all()
+    out = torch.zeros(7 * 45, device=dev)
+    gsrc = torch.ones(4, 45, device=dev)
+    L.check(lib.hn_leaf_rows_scatter(L.ptr(gsrc), L.ptr(rows), 4, 7, L.ptr(out), L.stream_ptr()), 'hn_leaf_rows_scatter')
+    assert float(out.sum()) == 2 * 45.0

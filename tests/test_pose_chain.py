@@ -86,7 +86,9 @@ def test_pose_chain_values_only_and_jacobian_only_launches_are_the_joint_launch(
     L.check(lib.hn_pose_chain(L.ptr(ori), L.ptr(bl), None, L.ptr(prm), F, L.ptr(bt_b), L.ptr(j3_b), None, st), 'values')
     L.check(lib.hn_pose_chain(L.ptr(ori), L.ptr(bl), None, L.ptr(prm), F, None, None, L.ptr(jac_c), st), 'jacobian')
     torch.cuda.synchronize()
-    assert torch.equal(bt_a, bt_b) and torch.equal(j3_a, j3_b) and torch.equal(jac_a, jac_c)
+    for name, x, y in (('bt_inv', bt_a, bt_b), ('joint_3d', j3_a, j3_b), ('jacobian', jac_a, jac_c)):
+        bad = [f for f in range(F) if not torch.equal(x[f], y[f])]
+        assert not bad, '%s: hands %s differ between the launch forms (max %g)' % (name, bad, float((x - y).abs().max()))
     assert not torch.isnan(jac_a).any()
     # neither outputs nor Jacobian, or only one of the value outputs: refused
     assert lib.hn_pose_chain(L.ptr(ori), L.ptr(bl), None, L.ptr(prm), F, None, None, None, st) != 0

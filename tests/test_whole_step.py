@@ -181,13 +181,22 @@ def _compare(tag, got_terms, got_grads, ref32, ref64, keys, threshold_flips, gra
         assert ok, '%s d/d %s: product vs fp32 oracle %.3e, fp32 oracle vs float64 %.3e, product vs float64 %.3e' % (tag, name, e_hr, e_ref, e_hip)
 
 
-def test_fitting_single_step_matches_the_oracle_composition():
+# Two synthetic scenes.  'inside': the object's centre 2 cm from joint 9 -- its sphere-like field (radius ~0.4 in its own frame)
+# contains the whole hand: thousands of samples in the PENETRATION set, none in the contact set.  'surface': the centre 0.30 m above
+# the hand, so that the object's zero level crosses the fingers -- hundreds of samples with |s_h| + |s_o| < 1e-2 (the CONTACT branch of
+# fitting_single.py:268-275 / fitting_video.py:293-300) and a penetration set beside them (tools/contact_scene_probe.py: 1 440 / 2 485
+# samples on view 0 of the C3 step).
+SCENES = {'inside': (0.02, 0.0, 0.01), 'surface': (0.0, 0.30, 0.0)}
+
+
+@pytest.mark.parametrize('scene', ['inside', 'surface'])
+def test_fitting_single_step_matches_the_oracle_composition(scene):
     """C3 / C4: one fit_backward of fitting_single at 196 rays x 192 depths, fit type 12, the reference's six-leaf chain, fixed
     t_rand, with and without the far-field compaction."""
     import bench
     from honerf_amd import fitting as F
     dev = torch.device('cuda')
-    ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3', halo=True)
+    ren, nets, chain, views, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3', halo=True, obj_offset=SCENES[scene])
     _perturb(chain, 4e-3, 50)
     tr = torch.rand(bench.FIT_RAYS, 1, generator=torch.Generator().manual_seed(7)).to(dev)
     view = views[0]
@@ -203,25 +212,28 @@ def test_fitting_single_step_matches_the_oracle_composition():
     assert z.shape == (bench.FIT_RAYS, bench.FIT_N + 2 * bench.FIT_IMP)
     ref32 = _oracle_step(nets, chain, None, view, z, '12', torch.float32, video=False)
     ref64 = _oracle_step(nets, chain, None, view, z, '12', torch.float64, video=False)
-    record('C3 step: samples in the contact set', ref32[2]['contact_n'], float('inf'), kind='value')
-    record('C3 step: samples in the penetration set', ref32[2]['penet_n'], float('inf'), kind='value')
+    record('C3 step (%s scene): samples in the contact set' % scene, ref32[2]['contact_n'], float('inf'), kind='value')
+    record('C3 step (%s scene): samples in the penetration set' % scene, ref32[2]['penet_n'], float('inf'), kind='value')
     assert ref32[2]['penet_n'] + ref32[2]['contact_n'] > 0, 'the interaction terms are not exercised by this scene'
+    if scene == 'surface':      # the contact branch's gradient flows through the render's adjoint end to end
+        assert ref32[2]['contact_n'] >= 200 and float(ref32[0]['contact']) > 0.0, ref32[2]
+        assert ref32[2]['penet_n'] >= 200, ref32[2]
     # samples whose threshold membership the fp32 and the float64 oracle disagree on (what rounding can flip)
     sel = lambda d: ((d['sdf_hand'].abs() + d['sdf_obj'].abs()) < 1e-2, (d['sdf_hand'] < 0) & (d['sdf_obj'] < 0))
     flips = int(sum((a != b).sum() for a, b in zip(sel(ref32[2]), sel(ref64[2]))))
     for compact in (True, False):
-        _compare('C3 step (compaction %s)' % ('on' if compact else 'off'), runs[compact][0], runs[compact][1], ref32, ref64, TERM_KEYS_SINGLE, flips,
-                 grad_cap=GRAD_CAP)
+        _compare('C3 step (%s scene, compaction %s)' % (scene, 'on' if compact else 'off'), runs[compact][0], runs[compact][1], ref32, ref64, TERM_KEYS_SINGLE,
+                 flips, grad_cap=GRAD_CAP)
 
 
-@pytest.mark.parametrize('ends', [(True, False), (False, True)])
-def test_fitting_video_window_step_matches_the_oracle_composition(ends):
+@pytest.mark.parametrize('ends,scene', [((True, False), 'inside'), ((False, True), 'inside'), ((True, False), 'surface')])
+def test_fitting_video_window_step_matches_the_oracle_composition(ends, scene):
     """C5: one fit_backward of a fitting_video window -- 4 frames x 40 rays, fit type 1234 (stable term on the object's vertices),
     anchored at the sequence start / at its end, batched renderer with the reference's SDF-row quirk B-1 in the sampling."""
     import bench
     from honerf_amd import fitting as F
     dev = torch.device('cuda')
-    ren, nets, chain, views, verts = bench.build_fit(dev, 41, 4, bench.VID_RAYS, 'f16x3', halo=True)
+    ren, nets, chain, views, verts = bench.build_fit(dev, 41, 4, bench.VID_RAYS, 'f16x3', halo=True, obj_offset=SCENES[scene])
     assert ren.strict_reference and ren.batched
     _perturb(chain, 4e-3, 60)
     tr = torch.rand(4 * bench.VID_RAYS, 1, generator=torch.Generator().manual_seed(8)).to(dev)
@@ -241,5 +253,8 @@ def test_fitting_video_window_step_matches_the_oracle_composition(ends):
     keys = ['loss', 'color', 'mask', 'contact', 'penetration', 'joint', 'obj_verts', 'smooth']
     if float(ref32[0].get('stable', torch.zeros(()))) != 0.0:
         keys.append('stable')
-    record('C5 window step: stable term of the oracle', float(ref32[0].get('stable', torch.zeros(()))), float('inf'), kind='value')
-    _compare('C5 window step (anchor %s)' % ('first' if ends[0] else 'last'), got_terms, got_grads, ref32, ref64, keys, flips, grad_cap=GRAD_CAP)
+    record('C5 window step (%s scene): stable term of the oracle' % scene, float(ref32[0].get('stable', torch.zeros(()))), float('inf'), kind='value')
+    record('C5 window step (%s scene): samples in the contact set' % scene, ref32[2]['contact_n'], float('inf'), kind='value')
+    if scene == 'surface':
+        assert ref32[2]['contact_n'] >= 50 and float(ref32[0]['contact']) > 0.0, ref32[2]
+    _compare('C5 window step (%s scene, anchor %s)' % (scene, 'first' if ends[0] else 'last'), got_terms, got_grads, ref32, ref64, keys, flips, grad_cap=GRAD_CAP)
