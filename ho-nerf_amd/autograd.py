@@ -360,6 +360,9 @@ class Mat3InverseFn(torch.autograd.Function):
         return gr.reshape(ctx.shape)
 
 
+_DIAG, _DIAG_CHECK = [], [False]
+
+
 class StableTerm:
     """`get_stable_loss_cross` (utils/renderer_batch.py:318-371) in explicit halves, no autograd: `StableTerm(...)` runs the forward
     -- hn_stable_pts (every 10th vertex to the world), the hand field's TAPED evaluation on those points, hn_stable_value (inside sets,
@@ -385,6 +388,10 @@ class StableTerm:
         R, t = L.f32(obj_r, dev).reshape(Fr, 9), L.f32(obj_t, dev).reshape(Fr, 3)
         pw, p0 = _empty(n, 3, dev=dev), _empty(V, 3, dev=dev)
         L.check(lib.hn_stable_pts(L.ptr(p), Fr, Vfull, stride, L.ptr(R), L.ptr(t), L.ptr(pw), L.ptr(p0), st), 'hn_stable_pts')
+        if _DIAG_CHECK[0]:       # (tools/seq_repro_diag.py: what this stream sees of its inputs right behind the launch, kept for the caller to compare)
+            ref = torch.einsum('frc,fvc->fvr', R.view(Fr, 3, 3), p[:, ::stride]) + t[:, None]
+            _DIAG.append({'pw_vs_ref_on_side': (pw.view(Fr, V, 3) - ref).abs().max().reshape(1), 'R_side': R.clone(), 't_side': t.clone(),
+                          'obj_r': obj_r, 'obj_t': obj_t})
         sdf, grad, rgb = _empty(n, dev=dev), _empty(n, 3, dev=dev), _empty(n, 3, dev=dev)
         tape_bytes = lib.hn_field_tape_bytes(field.handle, n)
         need = lib.hn_field_workspace_bytes(field.handle, n)

@@ -50,7 +50,8 @@ int composite1_bwd(const float*, const float*, const float*, const float*, const
 int composite2_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
                    float*, float*, float*, hipStream_t);
 int alpha_bwd_up(const float*, const float*, const float*, const float*, const float*, int, int, float, float, const float*, const float*, const float*,
-                 float*, float*, float*, const int*, const int*, const float*, float*, float*, float*, float* const*, const size_t*, int, hipStream_t, float* g_rays_d_samples = nullptr);
+                 float*, float*, float*, const int*, const int*, const float*, float*, float*, float*, float* const*, const size_t*, int, hipStream_t, float* g_rays_d_samples = nullptr,
+                 const int* seg = nullptr);
 int obj_rays_bwd(const float*, const float*, int, int, int, float, const float*, const float*, const float*, const float*, const float*, const float*,
                  float*, float*, float*, float*, hipStream_t, bool transposed = false, float* part = nullptr, unsigned* counter = nullptr,
                  const float* gd_alpha_samples = nullptr, const float* gd_colour_samples = nullptr);
@@ -264,6 +265,9 @@ void set_launch_dir_per_sample(bool on) { g_launch_dir_per_sample = on; }
 static thread_local const int* g_launch_orig_idx = nullptr;
 const int* launch_orig_idx() { return g_launch_orig_idx; }
 void set_launch_orig_idx(const int* p) { g_launch_orig_idx = p; }
+static thread_local const int* g_launch_frame_seg = nullptr;
+const int* launch_frame_seg() { return g_launch_frame_seg; }
+void set_launch_frame_seg(const int* p) { g_launch_frame_seg = p; }
 
 // ---- exact far-field skip of the hand field (SURVEY B-11, hn_field_set_compaction) ---------------------------------------
 // A sample whose bone masks h_b = 1 - sigmoid(200 (v_b - cutoff_b)) (utils/fields.py:33-35) are ALL exactly 0 in fp32 sees
@@ -299,7 +303,7 @@ __device__ __forceinline__ bool hand_sample_live(const float* __restrict__ pts, 
     }
     return live;
 }
-// pass 1 (one sample per thread): pos[i] = 1 (live) / 0, counts[b] = live samples of the 256-sample block b
+// pass 1 (one sample per thread): pos[i] = 1 (live) / 0, counts[u] = live samples of the 128-sample UNIT u (two per block)
 __global__ __launch_bounds__(256) void k_hand_live_count(const float* __restrict__ pts, int n, const float* __restrict__ bt_inv,
                                                          const float* __restrict__ T_pose, int n_frames, int pts_per_frame,
                                                          int* __restrict__ pos, int* __restrict__ counts) {
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256) void k_hand_live_count(const float* __restrict
     const int c = __popcll(__ballot(live));
     if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (threadIdx.x < 2 && (int)(2 * blockIdx.x + threadIdx.x) * 128 < n) counts[2 * blockIdx.x + threadIdx.x] = wave_cnt[2 * threadIdx.x] + wave_cnt[2 * threadIdx.x + 1];
 }
 // pass 2: slots in dense order; the last block appends the far sample behind the M live ones and writes n_dev = M + 1, the
 // sample count the field kernels read.  The far sample -- the stand-in whose outputs every skipped sample receives -- is
@@ -321,55 +325,94 @@ __global__ __launch_bounds__(256) void k_hand_live_count(const float* __restrict
 // dense index, which is where the field kernels take a compact sample's frame from), so that it is dead by construction
 // whatever the scene's scale or frame of reference; a launch without a dead sample has nobody to stand in for and gets a
 // placeholder that nothing reads.
+//
+// FRAME-ALIGNED layout (`af` = the number of frames, > 1; pts_per_frame a multiple of 128; `seg` = the record's table): the live samples
+// of frame f start at slot seg[f], a multiple of 128 -- every 128-sample tile and every wave of the field kernels then holds samples
+// of ONE frame, and the tiles of a frame hold exactly the samples, in the lanes, that a launch of that frame ALONE would give them:
+// what a frame's fit computes does not depend on which other frames share its launches (fitting.fit_frames_batched; the sums over a
+// frame's samples are formed per tile and added per frame, k_pose_part_reduce).  The slots between a frame's last live sample and the
+// next frame's start (at most 127) are PADS: copies of that last live sample's point with idx = -1 - (its dense index) -- evaluated
+// like any sample (same frame: the wave stays uniform), never scattered back (no pos[] points at them), their upstream gradients
+// zero (k_alpha_bwd_up / k_hand_gather_up), so that they add exact zeros.  The last frame has no pads: the far sample follows its live
+// samples directly, as in a one-frame launch.  seg[0 .. af]: first slot per frame (seg[af]: the far sample's slot);
+// seg[af + 1 + f]: live samples of frame f; n_dev[2] = af.  pts_per_frame a multiple of 128 bounds the slots by n + 1, as before.
+constexpr int COMPACT_MAX_FRAMES = 64;
+constexpr int COMPACT_UPB = COMPACT_SPB / 128;   // units per block of pass 2
 __global__ __launch_bounds__(256) void k_hand_compact_write(const float* __restrict__ pts, int n, const int* __restrict__ counts,
                                                             int* __restrict__ idx, int* __restrict__ pos, float* __restrict__ pts_c,
                                                             int* __restrict__ n_dev, const float* __restrict__ bt_inv,
-                                                            const float* __restrict__ T_pose, int n_frames, int pts_per_frame) {
+                                                            const float* __restrict__ T_pose, int n_frames, int pts_per_frame, int af,
+                                                            int* __restrict__ seg) {
     __shared__ int red[4];
     __shared__ int wcnt[2][4];
-    __shared__ int far_blk[4], far_lane[4];
+    __shared__ int far_unit[4], far_lane[4];
+    __shared__ int tot[COMPACT_MAX_FRAMES + 1], segs[COMPACT_MAX_FRAMES + 2];
+    __shared__ int ubase[COMPACT_UPB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the block behind the COMPACT_SPB-sample blocks appends the far sample (beside them, not after them: the launch is on the
     // critical path of a fitting step twice)
     const bool tail = blockIdx.x == gridDim.x - 1;
-    const int n256 = (n + 255) / 256;
-    int part = 0;   // live samples in front of this block: the counts of its (COMPACT_SPB / 256) x blockIdx.x preceding 256-sample blocks
-    const int n_before = tail ? n256 : (int)blockIdx.x * (COMPACT_SPB / 256);
-    int first_dead_blk = 0x7fffffff;   // (tail block) the first 256-sample block of pass 1 that holds a dead sample
-    for (int t = threadIdx.x; t < n_before; t += 256) {
+    const int n_units = (n + 127) / 128;
+    const int upf = af > 0 ? pts_per_frame / 128 : 1;   // units per frame
+    if (af > 0) {
+        for (int f = threadIdx.x; f <= af; f += 256) tot[f] = 0;
+        __syncthreads();
+        for (int t = threadIdx.x; t < n_units; t += 256) atomicAdd(&tot[t / upf], counts[t]);   // (integers: any order, the same sums)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int s = 0;
+            for (int f = 0; f < af; ++f) {
+                segs[f] = s;
+                s += f + 1 < af ? ((tot[f] + 127) & ~127) : tot[f];
+            }
+            segs[af] = s;
+        }
+        __syncthreads();
+    }
+    // live samples in front of this block's first unit (frame-aligned: in front of it IN ITS FRAME); the tail block: in all units
+    const int u0 = tail ? n_units : (int)blockIdx.x * COMPACT_UPB;
+    const int t_first = (af > 0 && !tail) ? (u0 / upf) * upf : 0;
+    int part = 0;
+    int first_dead_unit = 0x7fffffff;   // (tail block) the first unit that holds a dead sample
+    for (int t = t_first + threadIdx.x; t < u0; t += 256) {
         const int c = counts[t];
         part += c;
         if (tail) {
-            const int valid = n - t * 256 < 256 ? n - t * 256 : 256;
-            if (c < valid) first_dead_blk = first_dead_blk < t ? first_dead_blk : t;
+            const int valid = n - t * 128 < 128 ? n - t * 128 : 128;
+            if (c < valid) first_dead_unit = first_dead_unit < t ? first_dead_unit : t;
         }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         part += __shfl_xor(part, o, 64);
-        const int other = __shfl_xor(first_dead_blk, o, 64);
-        first_dead_blk = first_dead_blk < other ? first_dead_blk : other;
+        const int other = __shfl_xor(first_dead_unit, o, 64);
+        first_dead_unit = first_dead_unit < other ? first_dead_unit : other;
     }
     if (lane == 0) {
         red[wave] = part;
-        far_blk[wave] = first_dead_blk;
+        far_unit[wave] = first_dead_unit;
     }
     __syncthreads();
     int run = red[0] + red[1] + red[2] + red[3];
     if (tail) {
         int far_i = -1;
-        int b = far_blk[0];
+        int b = far_unit[0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) b = b < far_blk[w] ? b : far_blk[w];
-        if (b != 0x7fffffff) {   // re-classify that block's samples (pos[] is being rewritten by the other blocks): its first dead one
-            const int i = b * 256 + threadIdx.x;
-            const bool dead = i < n && !hand_sample_live(pts, i, bt_inv, T_pose, n_frames, pts_per_frame);
+        for (int w = 1; w < 4; ++w) b = b < far_unit[w] ? b : far_unit[w];
+        if (b != 0x7fffffff) {   // re-classify that unit's samples (pos[] is being rewritten by the other blocks): its first dead one
+            const int i = b * 128 + threadIdx.x;
+            const bool dead = threadIdx.x < 128 && i < n && !hand_sample_live(pts, i, bt_inv, T_pose, n_frames, pts_per_frame);
             const unsigned long long m = __ballot(dead);
             if (lane == 0) far_lane[wave] = m != 0ull ? __ffsll((long long)m) - 1 : -1;
             __syncthreads();
 #pragma unroll
-            for (int w = 3; w >= 0; --w)
-                if (far_lane[w] >= 0) far_i = b * 256 + w * 64 + far_lane[w];
+            for (int w = 1; w >= 0; --w)
+                if (far_lane[w] >= 0) far_i = b * 128 + w * 64 + far_lane[w];
+        }
+        if (af > 0) {
+            run = segs[af];
+            for (int f = threadIdx.x; f <= af; f += 256) seg[f] = segs[f];
+            for (int f = threadIdx.x; f < af; f += 256) seg[af + 1 + f] = tot[f];
         }
         if (threadIdx.x == 0) {
             idx[run] = far_i >= 0 ? far_i : 0;
@@ -377,35 +420,56 @@ __global__ __launch_bounds__(256) void k_hand_compact_write(const float* __restr
             for (int c = 0; c < 3; ++c) pts_c[3 * (size_t)run + c] = far_i >= 0 ? pts[3 * (size_t)far_i + c] : 10.f;
             n_dev[0] = run + 1;
             n_dev[1] = far_i;   // dense index of the stand-in (-1: the launch has no dead sample)
+            n_dev[2] = af;
         }
         return;
     }
+    // first slot of every unit of this block
+    if (threadIdx.x == 0) {
+        int r = run + (af > 0 ? segs[u0 / upf] : 0);
+        for (int k = 0; k < COMPACT_UPB; ++k) {
+            const int u = u0 + k;
+            if (u >= n_units) {
+                ubase[k] = r;
+                continue;
+            }
+            if (af > 0 && k > 0 && u % upf == 0) r = segs[u / upf];   // a new frame starts with this unit
+            ubase[k] = r;
+            r += counts[u];
+        }
+    }
+    __syncthreads();
     for (int it = 0; it < COMPACT_SPB / 256; ++it) {
         const int i = blockIdx.x * COMPACT_SPB + it * 256 + threadIdx.x;
         const bool live = i < n && pos[i] != 0;
         const unsigned long long m = __ballot(live);
         if (lane == 0) wcnt[it & 1][wave] = __popcll(m);
         __syncthreads();   // (double-buffered: the next iteration's writes cannot pass this iteration's reads)
-        int before = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int c = wcnt[it & 1][w];
-            before += w < wave ? c : 0;
-            all += c;
-        }
         if (i < n) {
             if (live) {
-                const int k = run + before + __popcll(m & ((1ull << lane) - 1ull));
+                const int unit = 2 * it + (wave >> 1);
+                const int k = ubase[unit] + ((wave & 1) ? wcnt[it & 1][wave - 1] : 0) + __popcll(m & ((1ull << lane) - 1ull));
                 idx[k] = i;
                 pos[i] = k;
-                pts_c[3 * (size_t)k] = pts[3 * (size_t)i];
-                pts_c[3 * (size_t)k + 1] = pts[3 * (size_t)i + 1];
-                pts_c[3 * (size_t)k + 2] = pts[3 * (size_t)i + 2];
+                const float p0 = pts[3 * (size_t)i], p1 = pts[3 * (size_t)i + 1], p2 = pts[3 * (size_t)i + 2];
+                pts_c[3 * (size_t)k] = p0;
+                pts_c[3 * (size_t)k + 1] = p1;
+                pts_c[3 * (size_t)k + 2] = p2;
+                if (af > 0) {   // the frame's last live sample fills the pads up to the next frame's first slot
+                    const int f = (u0 + unit) / upf;
+                    if (f + 1 < af && k == segs[f] + tot[f] - 1) {
+                        for (int q = k + 1; q < segs[f + 1]; ++q) {
+                            idx[q] = -1 - i;
+                            pts_c[3 * (size_t)q] = p0;
+                            pts_c[3 * (size_t)q + 1] = p1;
+                            pts_c[3 * (size_t)q + 2] = p2;
+                        }
+                    }
+                }
             } else {
                 pos[i] = -1;
             }
         }
-        run += all;
     }
 }
 // compact results -> the dense per-sample arrays (dead samples: the far sample's values)
@@ -434,8 +498,9 @@ __global__ void k_hand_gather_up(const int* __restrict__ idx, int n_max, const i
                                  float* __restrict__ gg_c, float* __restrict__ gr_c) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_max || k >= n_dev[0]) return;
-    const bool far = k == n_dev[0] - 1;
-    const int i = far ? 0 : idx[k];
+    const int src = idx[k];
+    const bool far = k == n_dev[0] - 1 || src < 0;   // (the stand-in; a pad of the frame-aligned layout: zero upstream gradients)
+    const int i = far ? 0 : src;
     gs_c[k] = far ? 0.f : gs[i];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -504,10 +569,12 @@ static bool hand_compaction(const hn_field* hand, int n_frames, size_t N) {
 // the compaction record kept with the tape (the backward pass needs it): [n_dev, pad x3 | counts | idx N + 1 | pos N | pts_c | grad_c |
 // rgb_c | sdf_c], the per-sample float arrays N + 1 long
 struct CompactRec {
-    int *n_dev, *counts, *idx, *pos;
+    int *n_dev, *counts, *idx, *pos, *seg;
     float *pts_c, *grad_c, *rgb_c, *sdf_c;
-    static size_t n_counts(size_t N) { return ((N + 255) / 256 + 3) & ~size_t(3); }
-    static size_t bytes(size_t N) { return 16 + (n_counts(N) + 2 * N + 4) * sizeof(int) + (N + 1) * 10 * sizeof(float) + 64; }
+    static size_t n_counts(size_t N) { return ((N + 127) / 128 + 3) & ~size_t(3); }
+    static size_t bytes(size_t N) {
+        return 16 + (n_counts(N) + 2 * N + 4) * sizeof(int) + (N + 1) * 10 * sizeof(float) + 64 + (2 * COMPACT_MAX_FRAMES + 2) * sizeof(int);
+    }
     void at(void* base, size_t N) {
         char* p = reinterpret_cast<char*>(base);
         n_dev = reinterpret_cast<int*>(p);
@@ -518,6 +585,11 @@ struct CompactRec {
         grad_c = pts_c + 3 * (N + 1);
         rgb_c = grad_c + 3 * (N + 1);
         sdf_c = rgb_c + 3 * (N + 1);
+        seg = reinterpret_cast<int*>(sdf_c + (N + 1)) + 16;   // the frame table of the frame-aligned layout (k_hand_compact_write)
+    }
+    // frames of the frame-aligned layout for these sizes (0: the plain layout)
+    static int aligned_frames(int n, int n_frames, int pts_per_frame) {
+        return (n_frames > 1 && n_frames <= COMPACT_MAX_FRAMES && pts_per_frame % 128 == 0 && (size_t)n_frames * pts_per_frame == (size_t)n) ? n_frames : 0;
     }
 };
 // the compact list of the hand's live samples of `pts` (dense order) + the far sample
@@ -526,7 +598,7 @@ static int compact_hand(CompactRec& cr, const float* pts, int n, const float* bt
     const int nb = (n + COMPACT_SPB - 1) / COMPACT_SPB;
     hipLaunchKernelGGL(k_hand_live_count, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, bt_inv, T_pose, n_frames, pts_per_frame, cr.pos, cr.counts);
     hipLaunchKernelGGL(k_hand_compact_write, dim3(nb + 1), dim3(256), 0, s, pts, n, cr.counts, cr.idx, cr.pos, cr.pts_c, cr.n_dev, bt_inv, T_pose, n_frames,
-                       pts_per_frame);
+                       pts_per_frame, CompactRec::aligned_frames(n, n_frames, pts_per_frame), cr.seg);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -1107,7 +1179,8 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
         float* zb[2] = {g_bt_inv, g_T_pose};
         const size_t zn[2] = {(size_t)n_frames * 21 * 16, (size_t)n_frames * 21 * 3};
         HN_TRY(alpha_bwd_up(sdf_h, grad_h, rays_d, z, g_ah, n, S, sample_dist, hand->inv_s, g_sdf_h, g_grad_h, g_eik, gs_h, gg_h, want_rays ? gd_h : nullptr,
-                            compact ? cr.pos : nullptr, compact ? cr.n_dev : nullptr, g_rgbh, gs_c, gg_c, gr_c, zb, zn, 2, s));
+                            compact ? cr.pos : nullptr, compact ? cr.n_dev : nullptr, g_rgbh, gs_c, gg_c, gr_c, zb, zn, 2, s, nullptr,
+                            (compact && CompactRec::aligned_frames(n, n_frames, rpf * S) > 0) ? cr.seg : nullptr));
     }
     // object branch (so) up to its adjoint kernel
     HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_l, d_l, so, ro_t));
@@ -1125,11 +1198,13 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
     if (compact) {
         set_launch_n_pts_dev(cr.n_dev);
         set_launch_orig_idx(cr.idx);
+        set_launch_frame_seg(CompactRec::aligned_frames(n, n_frames, rpf * S) > 0 ? cr.seg : nullptr);
         // (the hand's colour network ignores the view direction, utils/fields.py:222-240: no d loss / d rays_d through it)
         const int rc = bwd::field_eval_bwd(hand, cr.pts_c, rays_d, n + 1, 1, bt_inv, T_pose, n_frames, rpf * S, gs_c, gg_c, gr_c, gp_c, nullptr, g_bt_inv,
                                            g_T_pose, bwh, bws_h, s, tp_h, cr.grad_c, cr.rgb_c);
         set_launch_n_pts_dev(nullptr);
         set_launch_orig_idx(nullptr);
+        set_launch_frame_seg(nullptr);
         HN_TRY(rc);
         if (want_rays) {
             hipLaunchKernelGGL(k_hand_scatter3, dim3((n + 255) / 256), dim3(256), 0, s, cr.pos, n, gp_c, gp_h);

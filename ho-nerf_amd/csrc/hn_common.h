@@ -43,6 +43,11 @@ const int* launch_n_pts_dev();
 void set_launch_n_pts_dev(const int* p);
 const int* launch_orig_idx();
 void set_launch_orig_idx(const int* p);
+// The frame table of a FRAME-ALIGNED compact list (hn_api.hip, k_hand_compact_write: [first slot per frame, af + 1 | live samples per
+// frame, af]; n_pts_dev[2] = af) for the next hand-field ADJOINT launch of this host thread: k_pose_part_reduce takes a frame's rows
+// from it.  NULL: a dense list, or the plain compact layout of a one-frame launch.
+const int* launch_frame_seg();
+void set_launch_frame_seg(const int* p);
 bool launch_dir_per_sample();     // hn_api.hip: the object adjoint launch writes d loss / d rays_d per sample (set around the launch)
 int quad_max_blocks_override();   // hn_debug_quad_max_blocks: -1 = default selection of the latency-form kernels
 int pace_phantom_members();    // hn_debug_pace_phantom: members that never arrive at the XCD meetings (timeout-path test hook), 0 = off

@@ -718,11 +718,28 @@ __global__ __launch_bounds__(256) void k_alpha_bwd_up(const float* __restrict__ 
                                                       const float* __restrict__ g_eik, float* __restrict__ gs, float* __restrict__ gg,
                                                       float* __restrict__ g_rays_d, const int* __restrict__ pos, const int* __restrict__ n_dev,
                                                       const float* __restrict__ g_rgb, float* __restrict__ gs_c, float* __restrict__ gg_c,
-                                                      float* __restrict__ gr_c, AlphaUpZero zero, float* __restrict__ g_rays_d_s) {
+                                                      float* __restrict__ gr_c, AlphaUpZero zero, float* __restrict__ g_rays_d_s,
+                                                      const int* __restrict__ seg) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
 #pragma unroll
     for (int b = 0; b < 4; ++b)
         if (zero.p[b] != nullptr && i < zero.n[b]) zero.p[b][i] = 0.f;
+    if (pos != nullptr && seg != nullptr) {
+        // frame-aligned compact list (hn_api.hip, k_hand_compact_write): the pads behind a frame's live samples get zero upstream gradients
+        const int af = n_dev[2];
+        const int f = i >> 7;
+        if (f + 1 < af) {
+            const int slot = seg[f] + seg[af + 1 + f] + (i & 127);
+            if (slot < seg[f + 1]) {
+                gs_c[slot] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    gg_c[3 * (size_t)slot + c] = 0.f;
+                    gr_c[3 * (size_t)slot + c] = 0.f;
+                }
+            }
+        }
+    }
     if (pos != nullptr && i == 0) {
         const int M = n_dev[0] - 1;
         gs_c[M] = 0.f;
@@ -810,7 +827,7 @@ __global__ __launch_bounds__(256) void k_alpha_bwd_up(const float* __restrict__ 
 int alpha_bwd_up(const float* sdf, const float* grad, const float* rays_d, const float* z, const float* g_alpha, int n, int spr, float sample_dist,
                  float inv_s, const float* g_sdf_out, const float* g_grad_out, const float* g_eik, float* gs, float* gg, float* g_rays_d,
                  const int* pos, const int* n_dev, const float* g_rgb, float* gs_c, float* gg_c, float* gr_c, float* const* zero_bufs,
-                 const size_t* zero_sizes, int n_zero, hipStream_t s, float* g_rays_d_samples) {
+                 const size_t* zero_sizes, int n_zero, hipStream_t s, float* g_rays_d_samples, const int* seg) {
     HN_REQUIRE(spr > 0 && n_zero <= 4, "samples_per_ray must be positive, at most four buffers to zero");
     if (n == 0) return HN_OK;
     AlphaUpZero zl{};
@@ -821,7 +838,7 @@ int alpha_bwd_up(const float* sdf, const float* grad, const float* rays_d, const
         most = most > zl.n[b] ? most : zl.n[b];
     }
     hipLaunchKernelGGL(k_alpha_bwd_up, dim3((most + 255) / 256), dim3(256), 0, s, sdf, grad, rays_d, z, g_alpha, n, spr, sample_dist, inv_s, g_sdf_out,
-                       g_grad_out, g_eik, gs, gg, g_rays_d, pos, n_dev, g_rgb, gs_c, gg_c, gr_c, zl, g_rays_d_samples);
+                       g_grad_out, g_eik, gs, gg, g_rays_d, pos, n_dev, g_rgb, gs_c, gg_c, gr_c, zl, g_rays_d_samples, seg);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

@@ -71,9 +71,11 @@ struct Hand2Args {
     unsigned* xsync;       // 16 zeroed counters (8 XCDs x {members, arrivals}) or NULL: see "XCD pacing" in the kernel
     const int* n_pts_dev;  // NULL, or the sample count on the DEVICE (<= n_pts): a compacted list whose length the host does not know
     const int* orig_idx;   // NULL, or per sample of a compacted list its index in the dense list (what the frame is taken from)
-    float* pose_part;      // adjoint, at most POSE_FRAMES frames: NULL, or [gridDim.x * 4][n_frames][21 * 12] -- every wave's own sums of the
-                           // pose-gradient addends per frame (k_pose_part_reduce adds the rows in a fixed order: the same bits in every
-                           // run; atomics otherwise)
+    float* pose_part;      // adjoint: NULL, or [n_tiles * 4][2][21 * 12] -- per sample TILE and wave the sums of the pose-gradient addends of
+                           // the wave's first frame [0] and of the frame behind it [1] (a wave of a dense multi-frame list may cross one
+                           // frame boundary); k_pose_part_reduce adds a frame's rows in a fixed order that depends on that frame's own
+                           // tiles only: the same bits in every run AND whatever other frames share the launch.  Atomics otherwise.
+    const int* frame_seg;  // NULL, or the frame table of a frame-aligned compact list (hn_common.h: launch_frame_seg)
 };
 
 // stash slots of one wave (32 KiB each)
@@ -102,7 +104,8 @@ enum {
 constexpr int FEAT_BLOCKS = 4 * N_BONES;     // first leftover block index
 constexpr int STAGE_BYTES = 8 * 1024;        // LDS staging of one bone's 4 fragment pairs (Jacobian pass)
 constexpr int POSE_ROW = 256;                // floats per wave and frame: 21 bones x 12 pose-gradient addends (Hand2Args::pose_part)
-constexpr int POSE_FRAMES = 8;               // frames a launch may have for the atomics-free pose gradients (fitting_video: 4)
+constexpr int POSE_FRAMES = 2;               // frames a WAVE may touch for the atomics-free pose gradients: its first sample's and the next
+constexpr int POSE_MAX_TILES = 8192;         // tiles of a launch up to which the rows are kept (8 KiB per tile); beyond: atomics
 constexpr size_t HAND2_LDS_POSE = 2 * CHUNK_MAX + WG_WAVES * STAGE_BYTES + 16;   // (+ 16: the 4 per-wave bone masks of the culling)
 
 constexpr int HB_HID = chunk_bytes(1, 16, true);
@@ -422,13 +425,13 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
     xp.init(a.xsync);
     const int full_rounds = n_tiles / (int)gridDim.x;
     float* const prow = reinterpret_cast<float*>(lds + HAND2_LDS_POSE) + wave * (POSE_FRAMES * POSE_ROW);   // this wave's pose-gradient sums per frame (adjoint modes)
-    if constexpr (RUN_ADJ) {
-        if (a.pose_part != nullptr) {
-            for (int i = lane; i < a.n_frames * POSE_ROW; i += 64) prow[i] = 0.f;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
     for (int tile = blockIdx.x, it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
+        if constexpr (RUN_ADJ) {
+            if (a.pose_part != nullptr) {   // this tile's rows start from zero (a wave's LDS operations complete in order)
+                for (int i = lane; i < POSE_FRAMES * POSE_ROW; i += 64) prow[i] = 0.f;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         if (xp.on() && it >= 1 && it < full_rounds && it % XCD_PACE_EVERY == 0) xp.meet(it / XCD_PACE_EVERY);
         ws.stamp(6);   // (timing builds: tile start)
         const bool more = tile + (int)gridDim.x < n_tiles;
@@ -436,7 +439,9 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
         const bool valid = n < n_pts;
         const int nn = valid ? n : n_pts - 1;
         const float p[3] = {a.pts[3 * nn], a.pts[3 * nn + 1], a.pts[3 * nn + 2]};
-        int frame = (a.orig_idx != nullptr ? a.orig_idx[nn] : nn) / a.pts_per_frame;
+        int dense_i = a.orig_idx != nullptr ? a.orig_idx[nn] : nn;
+        dense_i = dense_i < 0 ? -1 - dense_i : dense_i;   // (a pad of the frame-aligned compact list: a copy of dense sample -1 - idx)
+        int frame = dense_i / a.pts_per_frame;
         frame = frame < a.n_frames ? frame : a.n_frames - 1;
         const float* M = a.bt_inv + (size_t)frame * N_BONES * 16;
         const float* Tp = a.T_pose + (size_t)frame * N_BONES * 3;
@@ -1146,6 +1151,13 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
         }   // RUN_FWD
         if constexpr (RUN_ADJ) {
 #include "hn_field2_hand_adj.inl"
+            if (a.pose_part != nullptr) {   // this tile's two rows of this wave: [first frame | the other frame]
+                __builtin_amdgcn_wave_barrier();
+                float* row = a.pose_part + ((size_t)tile * WG_WAVES + wave) * POSE_FRAMES * (N_BONES * 12);
+                for (int f = 0; f < POSE_FRAMES; ++f)
+                    for (int i = lane; i < N_BONES * 12; i += 64) row[f * (N_BONES * 12) + i] = prow[f * POSE_ROW + i];
+                __builtin_amdgcn_wave_barrier();
+            }
             continue;
         }
         if (valid && h == 0) {
@@ -1158,45 +1170,55 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
             a.rgb[3 * n + 2] = rgb[2];
         }
     }
-    if constexpr (RUN_ADJ) {
-        if (a.pose_part != nullptr) {   // (workgroups without a tile write their zeros: the reduction reads every row)
-            __builtin_amdgcn_wave_barrier();
-            float* row = a.pose_part + ((size_t)blockIdx.x * WG_WAVES + wave) * a.n_frames * (N_BONES * 12);
-            for (int f = 0; f < a.n_frames; ++f)
-                for (int i = lane; i < N_BONES * 12; i += 64) row[f * (N_BONES * 12) + i] = prow[f * POSE_ROW + i];
-        }
-    }
 }
 
-// out += the rows of part [rows][21 * 12], added in a FIXED order: g_bt_inv [21,4,4] rows 0..2 (12 values per bone), g_T_pose [21,3] =
-// minus the translation column's sums (the statement of the adjoint kernel's atomics, hn_field2_hand_adj.inl).  1024 threads = 252
-// outputs x 4 row quarters; a thread adds its quarter's rows into 8 interleaved accumulators (row r into accumulator r mod 8: eight
-// loads in flight instead of one dependent chain of ~1 000), folds them 0..7, and the quarters are folded 0..3 through LDS.  Rows of
-// workgroups beyond the live tiles of a compacted launch are zeros and are skipped (x + 0 = x: the same bits).
-static __global__ __launch_bounds__(1024) void k_pose_part_reduce(const float* __restrict__ part, int rows, const int* __restrict__ n_pts_dev,
+// out += the rows of part [n_tiles * 4][2][21 * 12] that belong to frame `blockIdx.x`, added in a FIXED order: g_bt_inv [21,4,4] rows
+// 0..2 (12 values per bone), g_T_pose [21,3] = minus the translation column's sums (the statement of the adjoint kernel's atomics,
+// hn_field2_hand_adj.inl).  The frame's rows are those of the waves whose FIRST sample is the frame's (slot 0) -- waves w_a .. w_b - 1,
+// consecutive because the lists keep the dense order -- plus slot 1 of wave w_a - 1 where that wave crossed into the frame (a dense
+// list whose frames are not wave-aligned).  1024 threads = 252 outputs x 4 row quarters of [w_a, w_b); a thread adds its quarter's rows
+// into 8 interleaved accumulators (row w_a + r into accumulator r mod 8: eight loads in flight instead of one dependent chain), folds
+// them 0..7, the quarters are folded 0..3 through LDS, the crossing wave's share is added last.  Every index is RELATIVE to the
+// frame's first wave and the count is the frame's own: a frame's sums are the same bits whether it is alone in the launch or one of
+// several (frame-aligned compact lists, and dense lists with pts_per_frame a multiple of 128: fitting.BatchedSingleFit).
+//   dense list:            w_a = ceil(f ppf / 32), w_b = ceil((f + 1) ppf / 32)
+//   frame-aligned compact: w_a = seg[f] / 32, w_b = w_a + 4 ceil(live_f / 128)       (a tile that holds only the stand-in adds zeros)
+//   plain compact (1 frame): w_a = 0, w_b = 4 ceil((n_dev - 1) / 128)
+static __global__ __launch_bounds__(1024) void k_pose_part_reduce(const float* __restrict__ part, int n_pts, int pts_per_frame,
+                                                                  const int* __restrict__ n_pts_dev, const int* __restrict__ seg,
                                                                   float* __restrict__ g_bt_inv, float* __restrict__ g_T_pose) {
     constexpr int W = N_BONES * 12;
-    // one block per frame: row r of frame f is part[(r * n_frames + f) * W ..]
     const int n_frames = gridDim.x, fr = blockIdx.x;
-    part += (size_t)fr * W;
-    const size_t pitch = (size_t)n_frames * W;
     if (g_bt_inv != nullptr) g_bt_inv += (size_t)fr * N_BONES * 16;
     if (g_T_pose != nullptr) g_T_pose += (size_t)fr * N_BONES * 3;
     __shared__ float q[4][W];
-    if (n_pts_dev != nullptr) {
-        const int live = ((*n_pts_dev + WG_SAMPLES - 1) / WG_SAMPLES) * WG_WAVES;   // rows of the workgroups that had a tile (first round)
-        rows = rows < live ? rows : live;
+    int wa, wb;
+    bool crossing = false;
+    if (n_pts_dev == nullptr) {
+        const long long lo = (long long)fr * pts_per_frame, hi = lo + pts_per_frame < n_pts ? lo + pts_per_frame : n_pts;
+        wa = (int)((lo + 31) / 32);
+        wb = (int)((hi + 31) / 32);
+        crossing = (lo % 32) != 0;   // wave wa - 1 starts in frame fr - 1 and ends in this one
+    } else if (seg != nullptr) {
+        wa = seg[fr] / 32;
+        wb = wa + ((seg[n_frames + 1 + fr] + WG_SAMPLES - 1) / WG_SAMPLES) * WG_WAVES;
+    } else {
+        wa = 0;
+        wb = ((n_pts_dev[0] - 1 + WG_SAMPLES - 1) / WG_SAMPLES) * WG_WAVES;
     }
+    const size_t pitch = (size_t)POSE_FRAMES * W;
+    const int rows = wb - wa;
     const int t = threadIdx.x % 256, qi = threadIdx.x / 256;
     if (t < W) {
+        const float* p0 = part + (size_t)wa * pitch + t;
         const int per = (rows + 3) / 4, r0 = qi * per, r1 = r0 + per < rows ? r0 + per : rows;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int r = r0;
         for (; r + 8 <= r1; r += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(r + u) * pitch + t];
+            for (int u = 0; u < 8; ++u) acc[u] += p0[(size_t)(r + u) * pitch];
         }
-        for (int u = 0; r < r1; ++r, ++u) acc[u] += part[(size_t)r * pitch + t];
+        for (int u = 0; r < r1; ++r, ++u) acc[u] += p0[(size_t)r * pitch];
         float sum = acc[0];
 #pragma unroll
         for (int u = 1; u < 8; ++u) sum += acc[u];
@@ -1204,7 +1226,8 @@ static __global__ __launch_bounds__(1024) void k_pose_part_reduce(const float* _
     }
     __syncthreads();
     if (qi == 0 && t < W) {
-        const float acc = ((q[0][t] + q[1][t]) + q[2][t]) + q[3][t];
+        float acc = ((q[0][t] + q[1][t]) + q[2][t]) + q[3][t];
+        if (crossing && wa > 0) acc += part[(size_t)(wa - 1) * pitch + W + t];
         const int b = t / 12, k = t % 12;
         if (g_bt_inv != nullptr) g_bt_inv[b * 16 + k] += acc;
         if (g_T_pose != nullptr && (k & 3) == 3) g_T_pose[b * 3 + (k >> 2)] -= acc;
@@ -1335,12 +1358,14 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
     return HN_OK;
 }
 #else
-static size_t pose_part_bytes(int grid, int n_frames) {
-    return (((size_t)grid * WG_WAVES * n_frames * N_BONES * 12 * sizeof(float)) + 255) & ~size_t(255);
+static size_t pose_part_bytes(int n_pts) {   // the rows of Hand2Args::pose_part (0: too many tiles, atomics)
+    const size_t n_tiles = ((size_t)(n_pts > 0 ? n_pts : 0) + WG_SAMPLES - 1) / WG_SAMPLES;
+    if (n_tiles > (size_t)POSE_MAX_TILES) return 0;
+    return ((n_tiles * WG_WAVES * POSE_FRAMES * N_BONES * 12 * sizeof(float)) + 255) & ~size_t(255);
 }
 size_t field2_hand_adj_workspace_bytes(int n_pts, int n_cus) {
     const int grid = hand2_grid(n_pts, n_cus);
-    return (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4) + pose_part_bytes(grid, POSE_FRAMES);
+    return (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4) + pose_part_bytes(n_pts);
 }
 
 // bytes of the tape a taped full evaluation leaves for the adjoint launch: the adjoint's stash slots per sample TILE
@@ -1398,18 +1423,24 @@ int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const
     int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     const int grid = hand2_grid(n_pts, n_cus);
-    // Up to POSE_FRAMES frames (fitting_single: 1, a fitting_video window: 4): every wave sums its pose-gradient addends per frame
-    // in LDS and writes one row per frame; the rows are added in a fixed order behind the launch -- bit-reproducible pose
-    // gradients, and no atomics in the kernel (they cost it 0.17 ms of 0.93: every wave's 15 adds per bone on the same 315
-    // addresses stood in front of the next chunk's vmcnt(0)).  More frames: float atomics, as before.  The rows live behind the
-    // stash in the workspace (the adjoint from a tape has the whole workspace free).
+    // Every wave sums the pose-gradient addends of each of its tiles in LDS -- per frame: its first sample's and, where a wave of a
+    // dense multi-frame list crosses a frame boundary, the next one's -- and writes the two rows per tile; the rows of a frame are
+    // added in a fixed order behind the launch (k_pose_part_reduce): bit-reproducible pose gradients that do not depend on the
+    // launch's other frames, and no atomics in the kernel (they cost it 0.17 ms of 0.93: every wave's 15 adds per bone on the same
+    // 315 addresses stood in front of the next chunk's vmcnt(0)).  Any number of frames of at least 32 samples (a wave then touches
+    // at most two), a compact multi-frame list only in its frame-aligned layout (hn_api.hip), up to POSE_MAX_TILES tiles; otherwise
+    // float atomics.  The rows live behind the stash in the workspace (the adjoint from a tape has the whole workspace free).
     const size_t stash_bytes = (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
-    const bool det = n_frames >= 1 && n_frames <= POSE_FRAMES && (g_bt_inv != nullptr || g_T_pose != nullptr) && workspace != nullptr &&
-                     workspace_bytes >= (tape != nullptr ? pose_part_bytes(grid, n_frames) : stash_bytes + pose_part_bytes(grid, n_frames));
+    a.frame_seg = launch_frame_seg();
+    const size_t rows_bytes = pose_part_bytes(n_pts);
+    const bool frames_ok = n_frames == 1 || (a.n_pts_dev == nullptr ? pts_per_frame >= 32 : a.frame_seg != nullptr);
+    const bool det = n_frames >= 1 && frames_ok && rows_bytes != 0 && (g_bt_inv != nullptr || g_T_pose != nullptr) && workspace != nullptr &&
+                     workspace_bytes >= (tape != nullptr ? rows_bytes : stash_bytes + rows_bytes);
     if (det) a.pose_part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (tape != nullptr ? 0 : stash_bytes));
     auto reduce_rows = [&]() {
         if (!det) return;
-        hipLaunchKernelGGL(k_pose_part_reduce, dim3(n_frames), dim3(1024), 0, stream, a.pose_part, grid * WG_WAVES, a.n_pts_dev, g_bt_inv, g_T_pose);
+        hipLaunchKernelGGL(k_pose_part_reduce, dim3(n_frames), dim3(1024), 0, stream, a.pose_part, n_pts, pts_per_frame, a.n_pts_dev, a.frame_seg, g_bt_inv,
+                           g_T_pose);
     };
     if (tape != nullptr) {
         a.blob = reinterpret_cast<const char*>(f->v2_adjonly);

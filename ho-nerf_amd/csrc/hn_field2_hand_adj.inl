@@ -474,9 +474,9 @@
                     if (uni) {
 #pragma unroll
                         for (int k = 0; k < 12; ++k) vals[k] = wave_sum64(mine ? vals[k] : 0.f);
-                        if (lane == 0 && a.pose_part != nullptr) {   // this wave's own row of its frame (LDS), added up in a fixed order afterwards
+                        if (lane == 0 && a.pose_part != nullptr) {   // this wave's row of its frame for this tile (LDS), added up in a fixed order afterwards
 #pragma unroll
-                            for (int k = 0; k < 12; ++k) prow[frame0 * POSE_ROW + b * 12 + k] += vals[k];
+                            for (int k = 0; k < 12; ++k) prow[b * 12 + k] += vals[k];
                         } else if (lane == 0) {
                             if (a.g_bt_inv != nullptr) {
                                 float* gm = a.g_bt_inv + ((size_t)frame0 * N_BONES + b) * 16;
@@ -490,14 +490,17 @@
                             }
                         }
                     } else if (a.pose_part != nullptr) {
-                        // a wave across a frame boundary (the samples keep the dense order: its frames are frame0 .. the last
-                        // lane's): the same sums per frame, the other frames' lanes contributing zeros
-                        const int f_last = __builtin_amdgcn_readlane(frame, 63);
-                        for (int f = frame0; f <= f_last; ++f) {
+                        // a wave that holds samples of TWO frames -- its first sample's and the last lane's (a dense list crossing a
+                        // frame boundary: the next frame; the wave of a compact list that holds the stand-in, whose frame is its own
+                        // dense index's: any; lanes past the list replicate the last sample) -- : the same sums per frame, the other
+                        // frame's lanes contributing zeros; row 0: the first sample's frame, row 1: the other one
+                        const int f_b = __builtin_amdgcn_readlane(frame, 63);
+                        for (int sl = 0; sl < POSE_FRAMES; ++sl) {
+                            const int f = sl == 0 ? frame0 : f_b;
 #pragma unroll
                             for (int k = 0; k < 12; ++k) {
                                 const float sk = wave_sum64((mine && frame == f) ? vals[k] : 0.f);
-                                if (lane == 0) prow[f * POSE_ROW + b * 12 + k] += sk;
+                                if (lane == 0) prow[sl * POSE_ROW + b * 12 + k] += sk;
                             }
                         }
                     } else if (mine) {

@@ -134,6 +134,18 @@ class FrameShardedRunner:
             self.totals[-1] += 1
         return self.reduce()
 
+    def run_groups(self, group_fn, batch):
+        """As `run`, the rank's frames taken `batch` at a time: group_fn([frame ids]) -> [terms per frame]."""
+        for a in range(0, len(self.frames), batch):
+            fs = self.frames[a:a + batch]
+            for terms in group_fn(fs):
+                for k, key in enumerate(LOSS_KEYS[:-1]):
+                    if key in terms:
+                        v = terms[key]
+                        self.totals[k] += float(v.detach()) if isinstance(v, torch.Tensor) else float(v)
+                self.totals[-1] += 1
+        return self.reduce()
+
     def reduce(self):
         t = self.totals.to(self.device)
         self.allreduce_calls = getattr(self, 'allreduce_calls', 0)
@@ -369,6 +381,35 @@ class HaloPoseChain:
         if self.T_pose_21.shape[0] != n:
             self.T_pose_21 = self.T_pose_21[:1].expand(n, 21, 3).contiguous()
 
+    LEAF_NAMES = ('obj_rot', 'obj_trans', 'palm_rot', 'palm_trans', 'joint_refine_angle', 'palm_refine_angle')
+
+    @classmethod
+    def stack(cls, chains):
+        """ONE chain over the frames of several one-frame chains (fitting_single's independent frames fitted side by side,
+        BatchedSingleFit): the constants and the current values of the six leaves row by row.  The frames stay independent problems
+        -- every kernel of the chain works per frame -- and `unstack_into` writes the fitted rows back."""
+        self = cls.__new__(cls)
+        self._fn = chains[0]._fn
+        cat = lambda name: torch.cat([getattr(c, name).detach() for c in chains], dim=0).contiguous()
+        for name in ('joints0', 'bone_len', 'Ro_pred', 'To_pred', 'T_pose_21'):
+            setattr(self, name, cat(name))
+        same = all(c.obj_verts.data_ptr() == chains[0].obj_verts.data_ptr() or (c.obj_verts.shape == chains[0].obj_verts.shape and
+                                                                              torch.equal(c.obj_verts, chains[0].obj_verts)) for c in chains[1:])
+        self.obj_verts = chains[0].obj_verts
+        self.obj_verts_per_frame = None if same else [c.obj_verts for c in chains]
+        for name in cls.LEAF_NAMES:
+            setattr(self, name, torch.nn.Parameter(cat(name)))
+        return self
+
+    def unstack_into(self, chains):
+        with torch.no_grad():
+            off = 0
+            for c in chains:
+                n = c.joints0.shape[0]
+                for name in self.LEAF_NAMES:
+                    getattr(c, name).copy_(getattr(self, name)[off:off + n])
+                off += n
+
     def param_groups(self, video=False):
         """fitting_single.py:191-198; fitting_video.py:177-184: 1e-4 for all leaves but palm_refine_angle (5e-4)."""
         lr = (1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 5e-4) if video else (5e-4, 5e-4, 5e-4, 3e-4, 1e-3, 1e-3)
@@ -473,6 +514,7 @@ def step_loss(render_out, true_rgb, true_mask, pose, fit_type='1', video=False, 
     return terms
 
 
+DEFER_JACOBIAN = True      # fit_backward, window steps with the stable term: the chain's Jacobian launch behind the stable term's forward pass
 FUSED_WINDOW_LOSS = True   # fitting_video on the device: the window's loss as one launch each way (False: the torch-operator form)
 
 
@@ -556,7 +598,20 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
     video = bool(getattr(renderer, 'batched', False))
     for p in pose_chain.parameters():
         p.grad = None
-    pose = pose_chain(index)
+    # A window step with the stable term: the chain's Jacobian goes to the extra stream BEHIND the stable term's forward pass (its
+    # value is what the loss waits for; the Jacobian is not read before the backward pass reaches the pose side).  It is also a
+    # matter of correctness on this runtime (round 5, tools/seq_repro_diag.py, profiles/r05/seq_repro_*): the Jacobian kernel
+    # keeps ~39 KB of private scratch per lane, for which the runtime re-sizes the queue's scratch at every launch, and a dispatch
+    # queued on the SAME stream right behind it -- the stable term's first launches -- read its inputs' previous contents about once
+    # in a hundred steps (hn_stable_pts against a torch restatement issued right behind it on the same stream: 3 mm apart, the
+    # inputs equal).  Nothing is queued directly behind a Jacobian launch any more.
+    defer = video and fit_type == '1234' and rays_fn is None and USE_SIDE_STREAM and DEFER_JACOBIAN
+    if defer:
+        from .pose import deferred_jacobians, flush_deferred_jacobians
+        with deferred_jacobians():
+            pose = pose_chain(index)
+    else:
+        pose = pose_chain(index)
     n_cams = view['cam']['R'].shape[0]
     P = view['xy'].shape[0] // n_cams
     if rays_fn is None:
@@ -596,6 +651,10 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
         pose_ready = torch.cuda.Event()
         pose_ready.record()                      # the pose chain's outputs are complete here (the render's launches come after)
         pose_only_terms()
+    if defer:
+        flush_deferred_jacobians()
+    if use_side:
+        pass
     elif want_stable:
         stable = renderer.get_stable_loss_cross(obj_verts_for_stable, pose['bt_inv'], T_pose, pose['obj_r'], pose['obj_t'])
     if video:
@@ -760,10 +819,11 @@ class PoseAdam:
 
 class PipelinedSingleFit:
     """One optimisation step of fitting_single (fitting_single.py:201-291) as explicit launches on TWO streams that stay apart
-    across steps -- the same kernels and the same arithmetic as `fit_backward` + `fit_apply`, without autograd in between.
+    across steps -- the same kernels and the same arithmetic as `fit_backward` + `fit_apply`, without autograd in between -- for ONE
+    frame or for SEVERAL independent frames side by side (a chain of F frames: `HaloPoseChain.stack`, `fit_frames_batched`).
 
-    Why: a step is `pose chain -> sampling -> both fields -> loss -> both adjoints -> Adam`, and the object's kernels are the long
-    pole of both field phases (294 tiles on the CUs the hand leaves free: `k_field2_obj<4>` ends ~0.35 ms after
+    Why two streams: a step is `pose chain -> sampling -> both fields -> loss -> both adjoints -> Adam`, and the object's kernels are
+    the long pole of both field phases (294 tiles on the CUs the hand leaves free: `k_field2_obj<4>` ends ~0.35 ms after
     `k_field2_hand<4>`).  But the hand's half of what follows -- its leaf gradients, Adam on its four leaves, the pose chain of the
     NEXT step (0.19 ms) and that step's hand sampling track (0.5 ms, the longer of the two tracks) -- needs nothing from the
     object's adjoint.  So the hand's half lives on the caller's stream and the object's half (its adjoint, its leaf gradients,
@@ -773,19 +833,29 @@ class PipelinedSingleFit:
     is owned here and lives as long as the object; the one buffer the next step's hand side would overwrite while the object's
     adjoint of this step still reads it -- the world rays -- is double-buffered.
 
+    Why several frames: one frame's launches leave the chip half empty (a step's 294 object + ~160 live hand tiles are 1.8 rounds of
+    256 one-workgroup CUs, its sampling rounds light 25 .. 100 CUs for 80 us each); frames of fitting_single are independent problems
+    (own leaves, own Adam moments, fitting_single.py:134-199), so F of them go through the SAME launches -- rays [F x R], per-frame
+    poses, per-frame losses with fitting_single's own normalisation, element-wise Adam over [F, .] leaf blocks.  Nothing a frame
+    computes depends on its batch partners, to the BIT: per-ray / per-sample kernels do not look across rays, the hand's compacted
+    list is frame-aligned (hn_api.hip, k_hand_compact_write), every sum over a frame's samples is formed from that frame's own tiles
+    in an order relative to its first one (k_pose_part_reduce, k_obj_rays_bwd), and the loss kernels run once per frame
+    (tests/test_gpu_surface.py::test_sharded_frames_do_not_depend_on_the_sharding_nor_on_the_batch_partners).
+
     Call `finish()` before reading the parameters from another stream (or synchronise the device): the object's leaves are
     updated on the second stream."""
 
     JITTER_BLOCK = 64
     HAND_LEAVES = ('palm_rot', 'palm_trans', 'joint_refine_angle', 'palm_refine_angle')
     OBJ_LEAVES = ('obj_rot', 'obj_trans')
+    MAX_FRAMES = 16
 
     @staticmethod
-    def applicable(renderer, pose_chain, optimizer, fit_type, index, rays_fn):
+    def applicable(renderer, pose_chain, optimizer, fit_type, index, rays_fn, frames=1):
         from .renderer import NeuSRenderer_fitting
         return (isinstance(renderer, NeuSRenderer_fitting) and not renderer.batched and isinstance(pose_chain, HaloPoseChain)
                 and isinstance(optimizer, PoseAdam) and index is None and rays_fn is None and fit_type in ('1', '12')
-                and pose_chain.joints0.is_cuda and pose_chain.joints0.shape[0] == 1
+                and pose_chain.joints0.is_cuda and pose_chain.joints0.shape[0] == frames and 1 <= frames <= PipelinedSingleFit.MAX_FRAMES
                 and (renderer.precision or 'f16x3') == 'f16x3' and renderer.n_importance > 0)
 
     def __init__(self, renderer, pose_chain, optimizer, near, far, fit_type):
@@ -796,6 +866,7 @@ class PipelinedSingleFit:
         self.near, self.far, self.fit_type = float(near), float(far), fit_type
         dev = pose_chain.joints0.device
         self.dev = dev
+        Fr = self.F = int(pose_chain.joints0.shape[0])
         sp = ctypes.c_void_p()
         L.check(self.lib.hn_side_stream(ctypes.byref(sp)), 'hn_side_stream')
         self.side_ptr = ctypes.c_void_p(sp.value)
@@ -805,14 +876,19 @@ class PipelinedSingleFit:
         self.aux = _side_stream(dev)                          # the pose chain's Jacobian (see step); one such stream per device
         self.ev_prm, self.ev_jac = torch.cuda.Event(), torch.cuda.Event()
         e = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-        self.prm_h, self.prm_o = e(1, 36), torch.zeros(1, 18, device=dev)
-        self.bt, self.j3, self.jac_h = e(1, 21, 4, 4), e(1, 21, 3), e(1, 399, 36)
-        self.out_o, self.jac_o = e(1, 412), e(1, 412, 18)
-        self.obj_r, self.obj_t = self.out_o[:, 399:408], self.out_o[:, 408:411]          # views: contiguous 9 / 3 floats
-        self.g45 = torch.zeros(1, 45, device=dev)
+        z = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
+        self.prm_h, self.prm_o = e(Fr, 36), z(Fr, 18)
+        self.bt, self.j3, self.jac_h = e(Fr, 21, 4, 4), e(Fr, 21, 3), e(Fr, 399, 36)
+        self.out_o, self.jac_o = e(Fr, 412), e(Fr, 412, 18)
+        if Fr == 1:
+            self.obj_r, self.obj_t = self.out_o[:, 399:408], self.out_o[:, 408:411]          # views: contiguous 9 / 3 floats
+        else:
+            self.obj_r, self.obj_t = e(Fr, 9), e(Fr, 3)                                       # (copied out of the [F, 412] block on the second stream)
         self.g_loss = torch.ones(1, device=dev)
-        self.g_bt, self.g_tp, self.g_Ro, self.g_To = e(1, 21, 4, 4), e(1, 21, 3), e(1, 3, 3), e(1, 3)
-        self.loss_buf = e(6 + 63 + 9 + 3 + 63 + 9 + 3)
+        self.g_bt, self.g_tp, self.g_Ro, self.g_To = e(Fr, 21, 4, 4), e(Fr, 21, 3), e(Fr, 3, 3), e(Fr, 3)
+        # the loss node's per-frame blocks, one plane per quantity (frame f of each: base + f x width)
+        self.sums, self.gj, self.gR, self.gt = e(Fr, 6), e(Fr, 63), e(Fr, 9), e(Fr, 3)
+        self.gj_o, self.gR_o, self.gt_o = e(Fr, 63), e(Fr, 9), e(Fr, 3)
         self._rays = None
         self._n_rays = -1
         self._step = 0
@@ -820,24 +896,49 @@ class PipelinedSingleFit:
         self.interaction = interaction
         self.w5 = (ctypes.c_float * 5)(*((1.0, 30.0, 20.0, 30.0, 20.0) if interaction else (1.0, 0.0, 0.0, 100.0, 5.0)))
         ch = pose_chain
-        # the six leaves move into the two parameter blocks the chain kernels read (views of them from here on: same values, same
-        # shapes, contiguous), so that a step does not gather them (a cat launch on each stream)
-        homes = {'joint_refine_angle': self.prm_h[:, 0:20], 'palm_refine_angle': self.prm_h[:, 20:27], 'palm_rot': self.prm_h[:, 27:33].view(1, 3, 2),
-                 'palm_trans': self.prm_h[:, 33:36], 'obj_rot': self.prm_o[:, 0:6].view(1, 3, 2), 'obj_trans': self.prm_o[:, 6:9]}
-        with torch.no_grad():
-            for k, view in homes.items():
+        names = ('joint_refine_angle', 'palm_refine_angle', 'palm_rot', 'palm_trans', 'obj_rot', 'obj_trans')
+        if Fr == 1:
+            # the six leaves move into the two parameter blocks the chain kernels read (views of them from here on: same values, same
+            # shapes, contiguous), so that a step does not gather them (a cat launch on each stream)
+            self.g45 = z(1, 45)
+            homes = {'joint_refine_angle': self.prm_h[:, 0:20], 'palm_refine_angle': self.prm_h[:, 20:27], 'palm_rot': self.prm_h[:, 27:33].view(1, 3, 2),
+                     'palm_trans': self.prm_h[:, 33:36], 'obj_rot': self.prm_o[:, 0:6].view(1, 3, 2), 'obj_trans': self.prm_o[:, 6:9]}
+            with torch.no_grad():
+                for k, view in homes.items():
+                    p = getattr(ch, k)
+                    view.copy_(p.detach().reshape(view.shape))
+                    p.data = view
+            self._homes = tuple((getattr(ch, k), view.data_ptr()) for k, view in homes.items())
+            g = self.g45
+            self.g45_h = self.g45_o = g
+            self.grads = {'obj_rot': g[:, 36:42].view(1, 3, 2), 'obj_trans': g[:, 42:45], 'palm_rot': g[:, 27:33].view(1, 3, 2), 'palm_trans': g[:, 33:36],
+                          'joint_refine_angle': g[:, 0:20], 'palm_refine_angle': g[:, 20:27]}
+        else:
+            # F frames: the leaves are [F, .] blocks of their own (Adam runs over whole blocks); the chain's input rows are gathered
+            # from them (one cat per stream and step) and the [F, 45] gradient rows scattered into six contiguous gradient blocks
+            # (hn_leaf_rows_scatter, one launch per stream: the hand's four from its stream's block, the object's two from the other)
+            self._homes = ()
+            self.g45_h, self.g45_o = z(Fr, 45), z(Fr, 45)
+            self.rows = torch.arange(Fr, device=dev, dtype=torch.long)
+            self.gblk_h, self.gblk_o = z(Fr * 45), z(Fr * 45)
+
+            def blocks(buf):      # hn_leaf_rows_scatter's layout: obj_rot, obj_trans, palm_rot, palm_trans, joint, palm_angle
+                n = Fr
+                return {'obj_rot': buf[:6 * n].view(n, 3, 2), 'obj_trans': buf[6 * n:9 * n].view(n, 3), 'palm_rot': buf[9 * n:15 * n].view(n, 3, 2),
+                        'palm_trans': buf[15 * n:18 * n].view(n, 3), 'joint_refine_angle': buf[18 * n:38 * n].view(n, 20),
+                        'palm_refine_angle': buf[38 * n:45 * n].view(n, 7)}
+            bh, bo = blocks(self.gblk_h), blocks(self.gblk_o)
+            self.grads = {k: (bo[k] if k in self.OBJ_LEAVES else bh[k]) for k in names}
+            for k in names:
                 p = getattr(ch, k)
-                view.copy_(p.detach().reshape(view.shape))
-                p.data = view
-        self._homes = tuple((getattr(ch, k), view.data_ptr()) for k, view in homes.items())
-        for k in homes:
+                assert p.is_contiguous() and p.shape[0] == Fr, 'the leaves of a stacked chain are contiguous [F, .] blocks'
+        for k in names:
             optimizer.ensure_state(getattr(ch, k))     # (before the second stream is ordered behind this one, below)
         self._jitter, self._jitter_at = None, 0
-        g = self.g45
-        self.grads = {'obj_rot': g[:, 36:42].view(1, 3, 2), 'obj_trans': g[:, 42:45], 'palm_rot': g[:, 27:33].view(1, 3, 2), 'palm_trans': g[:, 33:36],
-                      'joint_refine_angle': g[:, 0:20], 'palm_refine_angle': g[:, 20:27]}
+        self.jitter_states = None      # per-frame generator states (fit_frames_batched: every frame draws its own jitter stream)
         self.hand_params = [getattr(ch, k) for k in self.HAND_LEAVES]
         self.obj_params = [getattr(ch, k) for k in self.OBJ_LEAVES]
+        self.verts = [ch.obj_verts] * Fr if getattr(ch, 'obj_verts_per_frame', None) is None else list(ch.obj_verts_per_frame)
         # whatever the caller's stream has queued so far (the leaves' initial values, earlier steps through autograd) comes first
         L.check(self.lib.hn_stream_wait(self.side_ptr, L.stream_ptr()), 'hn_stream_wait')
 
@@ -850,121 +951,173 @@ class PipelinedSingleFit:
             self.finish()
         dev = self.dev
         e = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-        n = R * S
+        N = self.F * R
+        n = N * S
         self._n_rays = R
-        self._rays = [(e(R, 3), e(R, 3)), (e(R, 3), e(R, 3))]
-        self.color, self.wsum, self.gerr, self.z = e(R, 3), e(R, 1), e(2), e(R, S)
+        self._rays = [(e(N, 3), e(N, 3)), (e(N, 3), e(N, 3))]
+        self.color, self.wsum, self.gerr, self.z = e(N, 3), e(N, 1), e(2), e(N, S)
         self.sdf_h, self.sdf_o, self.grad_h, self.grad_o = e(n, 1), e(n, 1), e(n, 3), e(n, 3)
-        self.gc, self.gw, self.gsh, self.gso = e(R, 3), e(R), e(n), e(n)
+        self.gc, self.gw, self.gsh, self.gso = e(N, 3), e(N), e(n), e(n)
+
+    def _draw_jitter(self, R):
+        """JITTER_BLOCK steps of jitter numbers [block, F x R, 1] in one launch per frame (fresh uniform numbers every step, as
+        torch.rand per render gives).  With per-frame generator states every frame continues ITS OWN stream -- the numbers a
+        one-frame fit of that frame would draw after the same seed -- whatever its batch partners are."""
+        if self.jitter_states is None:
+            return torch.rand(self.JITTER_BLOCK, self.F * R, 1, device=self.dev)
+        keep = torch.cuda.get_rng_state(self.dev)
+        parts = []
+        for f in range(self.F):
+            torch.cuda.set_rng_state(self.jitter_states[f], self.dev)
+            parts.append(torch.rand(self.JITTER_BLOCK, R, 1, device=self.dev))
+            self.jitter_states[f] = torch.cuda.get_rng_state(self.dev)
+        torch.cuda.set_rng_state(keep, self.dev)
+        return parts[0] if self.F == 1 else torch.cat(parts, dim=1)
 
     @torch.no_grad()
     def step(self, view, t_rand=None):
-        """-> the step's loss terms (device scalars, as fit_step returns them).  The six leaves' .grad hold the step's gradient."""
+        """-> the step's loss terms (device scalars, as fit_step returns them; [F] vectors for a chain of F > 1 frames).  The six
+        leaves' .grad hold the step's gradient.  view: the step's pixels -- for F frames `cam` holds F cameras and xy / true_rgb /
+        true_mask the F frames' R rows each, frame after frame (`stack_views`)."""
         L, lib, ren, ch = self.L, self.lib, self.ren, self.chain
         dev = self.dev
+        Fr = self.F
         hand, obj = ren.fields()
         s, so = L.stream_ptr(), self.side_ptr
         n_cams = view['cam']['R'].shape[0]
+        assert n_cams == Fr, 'fitting_single: one camera per frame and step'
         R = view['xy'].shape[0] // n_cams
-        assert n_cams == 1, 'fitting_single: one camera per step'
         S = ren.n_samples + 2 * ren.n_importance
-        n = R * S
+        N = Fr * R
+        n = N * S
         self._sized(R, S)
         rays_o, rays_d = self._rays[self._step & 1]
         self._step += 1
         # ---- pose side: the hand's chain on the caller's stream, the object's on the second stream
-        homed = all(p.data_ptr() == at for p, at in self._homes)      # (a caller that re-assigned a leaf's storage: gather as before)
+        homed = Fr == 1 and all(p.data_ptr() == at for p, at in self._homes)      # (a caller that re-assigned a leaf's storage: gather as before)
         if not homed:
-            torch.cat([ch.joint_refine_angle, ch.palm_refine_angle, ch.palm_rot.reshape(1, 6), ch.palm_trans], dim=1, out=self.prm_h)
+            torch.cat([ch.joint_refine_angle, ch.palm_refine_angle, ch.palm_rot.reshape(Fr, 6), ch.palm_trans], dim=1, out=self.prm_h)
         # (values and Jacobian as two launches: the render waits for the values, a third of the chain's time; the Jacobian is read
         # by this step's hn_pose_side_vjp, ~2 ms from here, and runs beside the sampling on a stream of its own)
         self.ev_prm.record()
-        L.check(lib.hn_pose_chain(L.ptr(ch.joints0), L.ptr(ch.bone_len), None, L.ptr(self.prm_h), 1, L.ptr(self.bt), L.ptr(self.j3), None, s), 'hn_pose_chain')
+        L.check(lib.hn_pose_chain(L.ptr(ch.joints0), L.ptr(ch.bone_len), None, L.ptr(self.prm_h), Fr, L.ptr(self.bt), L.ptr(self.j3), None, s), 'hn_pose_chain')
         self.aux.wait_event(self.ev_prm)
-        L.check(lib.hn_pose_chain(L.ptr(ch.joints0), L.ptr(ch.bone_len), None, L.ptr(self.prm_h), 1, None, None, L.ptr(self.jac_h), self.aux.cuda_stream),
+        L.check(lib.hn_pose_chain(L.ptr(ch.joints0), L.ptr(ch.bone_len), None, L.ptr(self.prm_h), Fr, None, None, L.ptr(self.jac_h), self.aux.cuda_stream),
                 'hn_pose_chain')
         self.ev_jac.record(self.aux)
         if not homed:
             with torch.cuda.stream(self.side):
-                torch.cat([ch.obj_rot.reshape(1, 6), ch.obj_trans], dim=1, out=self.prm_o[:, :9])
-        L.check(lib.hn_rigid_pose(None, None, L.ptr(ch.Ro_pred), L.ptr(ch.To_pred), L.ptr(self.prm_o), 1, 0, L.ptr(self.out_o), L.ptr(self.jac_o), so),
+                torch.cat([ch.obj_rot.reshape(Fr, 6), ch.obj_trans], dim=1, out=self.prm_o[:, :9])
+        L.check(lib.hn_rigid_pose(None, None, L.ptr(ch.Ro_pred), L.ptr(ch.To_pred), L.ptr(self.prm_o), Fr, 0, L.ptr(self.out_o), L.ptr(self.jac_o), so),
                 'hn_rigid_pose')
+        if Fr > 1:
+            with torch.cuda.stream(self.side):
+                self.obj_r.copy_(self.out_o[:, 399:408])
+                self.obj_t.copy_(self.out_o[:, 408:411])
         cam = view['cam']
-        L.check(lib.hn_ray_gen(L.ptr(view['xy']), L.ptr(cam['R']), L.ptr(cam['T']), L.ptr(cam['focal']), L.ptr(cam['principal']), 1, R, L.ptr(rays_o),
+        L.check(lib.hn_ray_gen(L.ptr(view['xy']), L.ptr(cam['R']), L.ptr(cam['T']), L.ptr(cam['focal']), L.ptr(cam['principal']), Fr, R, L.ptr(rays_o),
                                L.ptr(rays_d), s), 'hn_ray_gen')
         # ---- the two-field render, taped; the object's pose comes from the second stream, as obj_r (its transpose is applied)
         if t_rand is None:
-            # the jitter of JITTER_BLOCK steps in one launch (fresh uniform numbers every step, as torch.rand per render gives)
-            if self._jitter is None or self._jitter_at >= self._jitter.shape[0] or self._jitter.shape[1] != R:
-                self._jitter, self._jitter_at = torch.rand(self.JITTER_BLOCK, R, 1, device=dev), 0
+            if self._jitter is None or self._jitter_at >= self._jitter.shape[0] or self._jitter.shape[1] != N:
+                self._jitter, self._jitter_at = self._draw_jitter(R), 0
             tr = self._jitter[self._jitter_at]
             self._jitter_at += 1
         else:
-            tr = L.f32(t_rand, dev).reshape(R, 1)
-        need = lib.hn_render_dual_workspace_bytes(hand.handle, obj.handle, R, ren.n_samples, ren.n_importance)
+            tr = L.f32(t_rand, dev).reshape(N, 1)
+        need = lib.hn_render_dual_workspace_bytes(hand.handle, obj.handle, N, ren.n_samples, ren.n_importance)
         from .renderer import _POISON
         if _POISON:
             self.finish()     # (the debug fill of workspace and tape runs on this stream: not under the previous step's object adjoint)
         ws = ren._ws.get(need, dev)
-        tape_bytes = lib.hn_render_dual_tape_bytes(hand.handle, obj.handle, R, S)
+        tape_bytes = lib.hn_render_dual_tape_bytes(hand.handle, obj.handle, N, S)
         tape = ren._tape.get(tape_bytes, dev)
         flags = L.HN_DUAL_RO_TRANSPOSED | L.HN_DUAL_OBJ_POSE_ON_SIDE
         prev = getattr(ren, '_pending_aux', None)
         prev = prev() if prev is not None else None
         if prev is not None:
             prev.own()        # an autograd render of this renderer whose backward pass has not run yet: its arrays leave the tape first
-        L.check(lib.hn_render_dual(hand.handle, obj.handle, L.ptr(rays_o), L.ptr(rays_d), L.ptr(tr), 1, R, self.near, self.far, ren.n_samples,
+        L.check(lib.hn_render_dual(hand.handle, obj.handle, L.ptr(rays_o), L.ptr(rays_d), L.ptr(tr), Fr, R, self.near, self.far, ren.n_samples,
                                    ren.n_importance, ren.up_sample_steps, L.ptr(self.bt), L.ptr(ch.T_pose_21), L.ptr(self.obj_r), L.ptr(self.obj_t), 0,
                                    L.ptr(self.color), L.ptr(self.wsum), L.ptr(self.sdf_h), L.ptr(self.sdf_o), L.ptr(self.grad_h), L.ptr(self.grad_o),
                                    L.ptr(self.gerr), L.ptr(self.z), L.ptr(ws), ws.numel(), L.ptr(tape), tape_bytes, flags, s), 'hn_render_dual')
         ren._last_z_raw = ren.last_z_vals = self.z
         ren._tape_serial = getattr(ren, '_tape_serial', 0) + 1     # (an autograd render's pending backward must not read this tape)
-        # ---- the loss and its gradient w.r.t. the render outputs and the pose-side values, one launch each
-        lb = self.loss_buf
-        sums, gj, gR, gt = lb[0:6], lb[6:69], lb[69:78], lb[78:81]
-        gj_o, gR_o, gt_o = lb[81:144], lb[144:153], lb[153:156]
-        terms = torch.empty(8, device=dev, dtype=torch.float32)
+        # ---- the loss and its gradient w.r.t. the render outputs and the pose-side values: one launch each per FRAME (every frame is
+        #      its own problem with fitting_single's own normalisation; a frame's launch is the one its one-frame fit makes)
+        terms = torch.empty(Fr, 8, device=dev, dtype=torch.float32)
         from .autograd import _loss_scratch
-        scratch, sneed = _loss_scratch(lib, R, n if self.interaction else 0, dev)
-        sh = L.ptr(self.sdf_h) if self.interaction else None
-        so_ = L.ptr(self.sdf_o) if self.interaction else None
+        nf = R * S
+        scratch, sneed = _loss_scratch(lib, R, nf if self.interaction else 0, dev)
         tm, tc = L.f32(view['true_mask'], dev).reshape(-1), L.f32(view['true_rgb'], dev).reshape(-1, 3)
-        L.check(lib.hn_fit_step_loss(L.ptr(self.color), L.ptr(self.wsum), L.ptr(tc), L.ptr(tm), R, sh, so_, n, L.ptr(self.j3), L.ptr(ch.joints0), 21,
-                                     L.ptr(self.obj_r), L.ptr(self.obj_t), L.ptr(ch.Ro_pred), L.ptr(ch.To_pred), L.ptr(ch.obj_verts), ch.obj_verts.shape[0],
-                                     self.w5, L.ptr(scratch), sneed, L.ptr(sums), L.ptr(terms), L.ptr(gj), L.ptr(gR), L.ptr(gt), s), 'hn_fit_step_loss')
-        L.check(lib.hn_fit_step_loss_bwd(L.ptr(self.color), L.ptr(self.wsum), L.ptr(tc), L.ptr(tm), R, sh, so_, n, L.ptr(sums), L.ptr(self.g_loss), self.w5,
-                                         L.ptr(gj), L.ptr(gR), L.ptr(gt), 21, L.ptr(self.gc), L.ptr(self.gw), L.ptr(self.gsh) if self.interaction else None,
-                                         L.ptr(self.gso) if self.interaction else None, L.ptr(gj_o), L.ptr(gR_o), L.ptr(gt_o), s), 'hn_fit_step_loss_bwd')
+        P = lambda t, off: ctypes_ptr(t, off)
+        for f in range(Fr):
+            sh = P(self.sdf_h, f * nf) if self.interaction else None
+            so_ = P(self.sdf_o, f * nf) if self.interaction else None
+            vf = self.verts[f]
+            L.check(lib.hn_fit_step_loss(P(self.color, 3 * f * R), P(self.wsum, f * R), P(tc, 3 * f * R), P(tm, f * R), R, sh, so_, nf, P(self.j3, 63 * f),
+                                         P(ch.joints0, 63 * f), 21, P(self.obj_r, 9 * f), P(self.obj_t, 3 * f), P(ch.Ro_pred, 9 * f), P(ch.To_pred, 3 * f),
+                                         L.ptr(vf), vf.shape[0], self.w5, L.ptr(scratch), sneed, P(self.sums, 6 * f), P(terms, 8 * f), P(self.gj, 63 * f),
+                                         P(self.gR, 9 * f), P(self.gt, 3 * f), s), 'hn_fit_step_loss')
+        for f in range(Fr):
+            sh = P(self.sdf_h, f * nf) if self.interaction else None
+            so_ = P(self.sdf_o, f * nf) if self.interaction else None
+            L.check(lib.hn_fit_step_loss_bwd(P(self.color, 3 * f * R), P(self.wsum, f * R), P(tc, 3 * f * R), P(tm, f * R), R, sh, so_, nf, P(self.sums, 6 * f),
+                                             L.ptr(self.g_loss), self.w5, P(self.gj, 63 * f), P(self.gR, 9 * f), P(self.gt, 3 * f), 21, P(self.gc, 3 * f * R),
+                                             P(self.gw, f * R), P(self.gsh, f * nf) if self.interaction else None,
+                                             P(self.gso, f * nf) if self.interaction else None, P(self.gj_o, 63 * f), P(self.gR_o, 9 * f), P(self.gt_o, 3 * f), s),
+                    'hn_fit_step_loss_bwd')
         # ---- backward pass of the render: the hand's branch ends on s, the object's on the second stream (no join)
-        aux_off = lib.hn_render_dual_tape_aux_offset(hand.handle, obj.handle, R, S)
+        aux_off = lib.hn_render_dual_tape_aux_offset(hand.handle, obj.handle, N, S)
         a = tape[aux_off:aux_off + 32 * n].view(torch.float32)
         rgb_h, rgb_o, al_h, al_o = a[:3 * n], a[3 * n:6 * n], a[6 * n:7 * n], a[7 * n:8 * n]
-        bneed = lib.hn_render_dual_bwd_workspace_bytes(hand.handle, obj.handle, R, S)
+        bneed = lib.hn_render_dual_bwd_workspace_bytes(hand.handle, obj.handle, N, S)
         wsb = ren._ws_bwd.get(bneed, dev)
         sample_dist = float(torch.tensor((self.far - self.near) / ren.n_samples, dtype=torch.float32))
         flags = L.HN_DUAL_RO_TRANSPOSED | L.HN_DUAL_BWD_NO_JOIN
         gsh_p = L.ptr(self.gsh) if self.interaction else None
         gso_p = L.ptr(self.gso) if self.interaction else None
-        L.check(lib.hn_render_dual_bwd(hand.handle, obj.handle, L.ptr(rays_o), L.ptr(rays_d), 1, R, S, sample_dist, L.ptr(self.bt), L.ptr(ch.T_pose_21),
+        L.check(lib.hn_render_dual_bwd(hand.handle, obj.handle, L.ptr(rays_o), L.ptr(rays_d), Fr, R, S, sample_dist, L.ptr(self.bt), L.ptr(ch.T_pose_21),
                                        L.ptr(self.obj_r), L.ptr(self.obj_t), L.ptr(self.z), L.ptr(self.sdf_h), L.ptr(self.grad_h), L.ptr(rgb_h), L.ptr(al_h),
                                        L.ptr(self.sdf_o), L.ptr(self.grad_o), L.ptr(rgb_o), L.ptr(al_o), L.ptr(self.gc), L.ptr(self.gw), gsh_p, gso_p, None, None,
                                        None, None, None, L.ptr(self.g_bt), L.ptr(self.g_tp), L.ptr(self.g_Ro), L.ptr(self.g_To), L.ptr(wsb), bneed, L.ptr(tape),
                                        flags, s), 'hn_render_dual_bwd')
         # ---- leaf gradients and Adam: the hand's four leaves on s, the object's two on the second stream
         torch.cuda.current_stream().wait_event(self.ev_jac)
-        L.check(lib.hn_pose_side_vjp(L.ptr(self.jac_h), None, L.ptr(self.g_bt), L.ptr(gj_o), None, None, None, None, 1, 1, L.ptr(self.g45), s), 'hn_pose_side_vjp')
-        L.check(lib.hn_pose_side_vjp(None, L.ptr(self.jac_o), None, None, L.ptr(self.g_Ro), L.ptr(self.g_To), L.ptr(gR_o), L.ptr(gt_o), 1, 2, L.ptr(self.g45), so),
+        L.check(lib.hn_pose_side_vjp(L.ptr(self.jac_h), None, L.ptr(self.g_bt), L.ptr(self.gj_o), None, None, None, None, Fr, 1, L.ptr(self.g45_h), s),
                 'hn_pose_side_vjp')
+        L.check(lib.hn_pose_side_vjp(None, L.ptr(self.jac_o), None, None, L.ptr(self.g_Ro), L.ptr(self.g_To), L.ptr(self.gR_o), L.ptr(self.gt_o), Fr, 2,
+                                     L.ptr(self.g45_o), so), 'hn_pose_side_vjp')
+        if Fr > 1:
+            L.check(lib.hn_leaf_rows_scatter(L.ptr(self.g45_h), L.ptr(self.rows), Fr, Fr, L.ptr(self.gblk_h), s), 'hn_leaf_rows_scatter')
+            L.check(lib.hn_leaf_rows_scatter(L.ptr(self.g45_o), L.ptr(self.rows), Fr, Fr, L.ptr(self.gblk_o), so), 'hn_leaf_rows_scatter')
         for k, gview in self.grads.items():
             getattr(ch, k).grad = gview
         self.opt.step(only=self.hand_params, stream=s)
         self.opt.step(only=self.obj_params, stream=so)
-        return {'loss': terms[0], 'color': terms[1], 'mask': terms[2], 'contact': terms[3], 'penetration': terms[4], 'joint': terms[5], 'obj_verts': terms[6]}
+        keys = ('loss', 'color', 'mask', 'contact', 'penetration', 'joint', 'obj_verts')
+        if Fr == 1:
+            return {k: terms[0, i] for i, k in enumerate(keys)}
+        return {k: terms[:, i] for i, k in enumerate(keys)}
 
     def finish(self):
         """The caller's stream waits for the second stream's tail: from here on the parameters (all six leaves) and their .grad are
         visible to work queued on the caller's stream (and to a host read that synchronises with it)."""
         self.L.check(self.lib.hn_stream_wait(self.L.stream_ptr(), self.side_ptr), 'hn_stream_wait')
+
+
+def ctypes_ptr(t, offset_floats=0):
+    """Device address of element `offset_floats` of a contiguous fp32 tensor, as the C ABI takes it."""
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + 4 * int(offset_floats))
+
+
+def stack_views(views):
+    """The step's pixels of F frames as ONE view dict for PipelinedSingleFit.step: F cameras, the frames' xy / true_rgb / true_mask rows
+    one frame after the other."""
+    cam = {k: torch.cat([v['cam'][k] for v in views], dim=0).contiguous() for k in ('R', 'T', 'focal', 'principal')}
+    cat = lambda k: torch.cat([v[k].reshape(-1, v[k].shape[-1]) for v in views], dim=0).contiguous()
+    return {'cam': cam, 'xy': cat('xy'), 'true_rgb': cat('true_rgb'), 'true_mask': cat('true_mask')}
 
 
 def pipelined_fit(renderer, pose_chain, optimizer, near, far, fit_type):
@@ -998,6 +1151,63 @@ def fit_frame(renderer, views, pose_chain, near, far, fit_type='1', n_iters=None
             step += 1
     finish_pipeline(opt)
     return last, step
+
+
+FRAME_BATCH = int(os.environ.get('HONERF_FRAME_BATCH', '4'))   # frames a rank fits side by side when it owns several (fit_frames_sharded)
+
+
+def frame_batch_capable(renderer, frame, fit_type, rays_fn=None):
+    """Whether this (views, chain[, sample_view]) frame runs on the device path that fits several frames side by side."""
+    try:
+        from .renderer import NeuSRenderer_fitting
+    except Exception:      # (no library: the host-logic tests over stub renderers)
+        return False
+    chain = frame[1]
+    return (rays_fn is None and PIPELINE_SINGLE and isinstance(renderer, NeuSRenderer_fitting) and not renderer.batched and fit_type in ('1', '12')
+            and renderer.n_importance > 0 and (renderer.precision or 'f16x3') == 'f16x3' and isinstance(chain, HaloPoseChain)
+            and chain.joints0.is_cuda and chain.joints0.shape[0] == 1)
+
+
+def frames_batchable(renderer, frames, fit_type, rays_fn=None):
+    """Whether these (views, chain[, sample_view]) frames can go through ONE PipelinedSingleFit: the device path of fitting_single on
+    the reference's pose chain, the same number of views and of pixels per view in every frame."""
+    if len(frames) < 2 or len(frames) > PipelinedSingleFit.MAX_FRAMES or not all(frame_batch_capable(renderer, fr, fit_type, rays_fn) for fr in frames):
+        return False
+    v0 = frames[0][0]
+    return all(len(fr[0]) == len(v0) and all(a['xy'].shape == b['xy'].shape and a['cam']['R'].shape[0] == 1 for a, b in zip(fr[0], v0)) for fr in frames)
+
+
+def fit_frames_batched(renderer, frames, near, far, fit_type='12', n_iters=None, jitter_states=None):
+    """fitting_single.py:200-291 for SEVERAL frames at once: `frames` = [(views, chain[, sample_view]), ...], every one its own
+    optimisation problem (own six leaves, own Adam moments), all of them stepped through the SAME launches (PipelinedSingleFit over
+    the stacked chain): per frame the same kernels on the same numbers as `fit_frame` of that frame alone, to the bit -- the batch is
+    a way to fill the GPU when a rank owns more than one frame, not a change of the fit.  jitter_states: per frame the state of the
+    CUDA generator its jitter is to be drawn from (what the global generator held when the frame's data was made: `fit_frame` draws
+    from there), None: the global generator for all.  -> ([terms of the last step per frame], steps per frame)."""
+    Fr = len(frames)
+    chains = [fr[1] for fr in frames]
+    n_views = len(frames[0][0])
+    if n_iters is None:
+        n_iters = {('1', False): 30, ('1', True): 40, ('12', False): 25, ('12', True): 35}[(fit_type, n_views == 3)]
+    stacked = HaloPoseChain.stack(chains)
+    opt = make_optimizer(stacked, video=False)
+    assert PipelinedSingleFit.applicable(renderer, stacked, opt, fit_type, None, None, frames=Fr), 'frames_batchable() first'
+    fit = PipelinedSingleFit(renderer, stacked, opt, near, far, fit_type)
+    fit.jitter_states = list(jitter_states) if jitter_states is not None else None
+    samplers = [fr[2] if len(fr) > 2 else None for fr in frames]
+    static = None if any(sv is not None for sv in samplers) else [stack_views([fr[0][vid] for fr in frames]) for vid in range(n_views)]
+    last, step = None, 0
+    for _ in range(n_iters):
+        for vid in range(n_views):
+            if static is not None:
+                view = static[vid]
+            else:
+                view = stack_views([(sv(vid, step) if sv is not None else fr[0][vid]) for sv, fr in zip(samplers, frames)])
+            last = fit.step(view)
+            step += 1
+    fit.finish()
+    stacked.unstack_into(chains)
+    return [{k: v[f] for k, v in last.items()} for f in range(Fr)], step
 
 
 def fit_window(renderer, views, pose_chain, optimizer, near, far, index, data_num, fit_type='1234', first_pass=False,
@@ -1074,17 +1284,22 @@ def fit_sequence_video(renderer, window_views, pose_chain, near, far, data_num, 
 
 
 def fit_frames_sharded(renderer, n_frames, make_frame, near, far, fit_type='12', n_iters=None, done=None, save=None, dist=None,
-                       rays_fn=None):
+                       rays_fn=None, batch=None):
     """fitting_single.py:134-315 over a set of frames, sharded over the ranks: every frame is its own optimisation
     problem (own six parameters and Adam state, :177-199), so rank r fits frames r, r + world, .. with NO data-path
     collective; a frame whose result already exists is skipped (`done(frame_id)`, :156-158: a restarted or re-sharded
     run picks up what is missing, dealt out evenly over the ranks); `save(frame_id, pose_chain, terms)` is the pose dump of :293-315.  The only
     exchange is the SUM of the small loss vector at the end (`FrameShardedRunner.reduce`).
 
+    batch (default FRAME_BATCH = 4): a rank that owns several frames fits up to `batch` of them SIDE BY SIDE through the same launches
+    (`fit_frames_batched`) where the device path applies -- one frame's launches leave the GPU half empty -- with per-frame results
+    that equal the one-by-one fits to the bit; 1: one by one.
+
     make_frame(frame_id) -> (views, pose_chain[, sample_view]).  Returns the reduced means + 'frames' + 'steps' of this rank."""
     dist, rank, world = _dist_state(dist)
     runner = FrameShardedRunner(n_frames, rank=rank, world=world, done=done)
     steps = [0]
+    batch = FRAME_BATCH if batch is None else int(batch)
 
     def frame_fn(f):
         made = make_frame(f)
@@ -1096,8 +1311,44 @@ def fit_frames_sharded(renderer, n_frames, make_frame, near, far, fit_type='12',
             save(f, chain, terms)
         return terms
 
-    out = runner.run(frame_fn)
+    def group_fn(fs):
+        """-> the frames' terms, in order.  The frames' data are made one after the other; a frame's jitter is drawn from the generator
+        state its make_frame left (where `fit_frame` of that frame alone would draw it from)."""
+        first = make_frame(fs[0])
+        if len(fs) == 1 or not frame_batch_capable(renderer, first, fit_type, rays_fn):
+            # not the device path (or nothing to batch): strictly one after the other, every frame's data made right before its fit
+            terms = []
+            for k, f in enumerate(fs):
+                m = first if k == 0 else make_frame(f)
+                t, n = fit_frame(renderer, m[0], m[1], near, far, fit_type, n_iters, m[2] if len(m) > 2 else None, rays_fn=rays_fn)
+                steps[0] += n
+                if save is not None:
+                    save(f, m[1], t)
+                terms.append(t)
+            return terms
+        made, states = [], []
+        for k, f in enumerate(fs):
+            made.append(first if k == 0 else make_frame(f))
+            states.append(torch.cuda.get_rng_state(made[-1][1].joints0.device))
+        if frames_batchable(renderer, made, fit_type, rays_fn):
+            terms, n = fit_frames_batched(renderer, made, near, far, fit_type, n_iters, jitter_states=states)
+            steps[0] += n * len(fs)
+        else:
+            terms = []
+            for f, m, st in zip(fs, made, states):
+                if st is not None:
+                    torch.cuda.set_rng_state(st, m[1].joints0.device)
+                t, n = fit_frame(renderer, m[0], m[1], near, far, fit_type, n_iters, m[2] if len(m) > 2 else None, rays_fn=rays_fn)
+                steps[0] += n
+                terms.append(t)
+        if save is not None:
+            for f, m, t in zip(fs, made, terms):
+                save(f, m[1], t)
+        return terms
+
+    out = runner.run(frame_fn) if batch <= 1 else runner.run_groups(group_fn, batch)
     out['steps'] = steps[0]
+    out['frame_batch'] = batch
     out['rank_frames'] = list(runner.frames)
     out['allreduce_calls'] = getattr(runner, 'allreduce_calls', 0)
     return out

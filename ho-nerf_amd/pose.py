@@ -160,6 +160,31 @@ def _zeros9(F, dev):
 
 
 _AUX_STREAMS = {}
+_DEFER_JACOBIAN = [False]
+_DEFERRED = []
+
+
+class deferred_jacobians:
+    """with deferred_jacobians(): ... -- HaloChainFn.forward inside the block does not launch the chain's Jacobian on the extra stream
+    but leaves it pending; `flush_deferred_jacobians()` launches what is pending (the backward pass would, at the latest).  For
+    callers that put their own work on that stream first."""
+
+    def __enter__(self):
+        self.prev = _DEFER_JACOBIAN[0]
+        _DEFER_JACOBIAN[0] = True
+
+    def __exit__(self, *exc):
+        _DEFER_JACOBIAN[0] = self.prev
+
+
+def flush_deferred_jacobians():
+    while _DEFERRED:
+        ctx = _DEFERRED.pop(0)
+        if getattr(ctx, 'jac_pending', None) is not None:
+            ctx.jac_pending()
+
+
+JACOBIAN_ON_AUX = True     # HaloChainFn: the chain's Jacobian launch on the extra stream beside the render's sampling (False: on the caller's stream)
 
 
 def _aux_stream(dev):
@@ -243,16 +268,29 @@ class HaloChainFn(torch.autograd.Function):
         # values and Jacobian as two launches: what follows (the render) waits for the values, a third of the chain's time; the
         # Jacobian is read by backward() and runs on a stream of its own beside the render's sampling
         ctx.jac_ev = None
-        if need:
+        ctx.jac_pending = None
+        if need and not JACOBIAN_ON_AUX:
+            L.check(lib.hn_pose_chain(L.ptr(ori_pose), L.ptr(bone_len), None, L.ptr(prm_h), F, None, None, L.ptr(jac_h), st), 'hn_pose_chain')
+        elif need:
             aux = _aux_stream(dev)
             ready = torch.cuda.Event()
             ready.record()
-            aux.wait_event(ready)
-            L.check(lib.hn_pose_chain(L.ptr(ori_pose), L.ptr(bone_len), None, L.ptr(prm_h), F, None, None, L.ptr(jac_h), aux.cuda_stream), 'hn_pose_chain')
-            ctx.jac_ev = torch.cuda.Event()
-            ctx.jac_ev.record(aux)
+
+            def launch_jacobian():
+                aux.wait_event(ready)
+                L.check(lib.hn_pose_chain(L.ptr(ori_pose), L.ptr(bone_len), None, L.ptr(prm_h), F, None, None, L.ptr(jac_h), aux.cuda_stream), 'hn_pose_chain')
+                ctx.jac_ev = torch.cuda.Event()
+                ctx.jac_ev.record(aux)
+                ctx.jac_pending = None
             for t in (prm_h, jac_h, ori_pose, bone_len):
                 t.record_stream(aux)
+            if _DEFER_JACOBIAN[0]:
+                # the caller has more work for the extra stream that the step needs SOONER than the Jacobian (fitting_video's stable
+                # term, whose value the loss waits for): it launches the Jacobian behind that work (flush_deferred_jacobians)
+                ctx.jac_pending = launch_jacobian
+                _DEFERRED.append(ctx)
+            else:
+                launch_jacobian()
         L.check(lib.hn_pose_chain(L.ptr(ori_pose), L.ptr(bone_len), None, L.ptr(prm_h), F, L.ptr(bt), L.ptr(j3), None, st), 'hn_pose_chain')
         # (object half only: entries 399 .. 410 of out / jac_o are written, and only those are read below)
         out = torch.empty(F, 412, device=dev, dtype=torch.float32)
@@ -271,6 +309,8 @@ class HaloChainFn(torch.autograd.Function):
         dev = ctx.jac_h.device
         from .autograd import _join_pending_side
         _join_pending_side(dev)      # (upstream gradients produced on a side stream by the loss node: joined by whoever consumes them first)
+        if ctx.jac_pending is not None:      # (deferred and never flushed: now)
+            ctx.jac_pending()
         c = lambda t, n: None if t is None else L.f32(t).reshape(F, n)
         gb, gj, gr, gt = c(g_bt, 336), c(g_j3, 63), c(g_or, 9), c(g_ot, 3)
         g = torch.empty(F, 45, device=dev, dtype=torch.float32)

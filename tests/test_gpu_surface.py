@@ -671,6 +671,52 @@ def test_sharded_frames_do_not_depend_on_the_sharding():
     assert not torch.equal(single[0][0][4], single[1][0][4])          # (different frames, different fits)
 
 
+def test_sharded_frames_do_not_depend_on_the_sharding_nor_on_the_batch_partners():
+    """C4 at N < 8: a rank that owns several frames fits them SIDE BY SIDE through the same launches (fitting.fit_frames_batched over a
+    stacked chain: rays [F x R], per-frame poses, per-frame losses, element-wise Adam) -- and every frame's result must be the one its
+    own one-by-one fit gives, TO THE BIT, whatever its batch partners are: five fitting_single frames (8 views, one pass, fit type 12,
+    the frame's seed set where its data is made) fitted one by one (batch 1), in batches of 2 (partners {0,1} {2,3} {4}), of 3 ({0,1,2}
+    {3,4}) and all five at once.  What makes it hold: the hand's compacted sample list is frame-aligned (a frame's tiles hold the
+    samples a launch of that frame alone gives them), the pose-gradient rows are formed per tile and added per frame relative to the
+    frame's first tile, the object's ray sums per frame in ray order, the loss kernels run once per frame, and every frame draws its
+    jitter from its own generator state."""
+    import bench
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    ren, nets, _, _, _ = bench.build_fit(dev, 40, 1, bench.FIT_RAYS, 'f16x3', halo=True)
+    n_frames = 5
+
+    def make_frame(f):
+        ch, jf, _ = bench.build_fit_data(dev, 140 + f, 1, halo=True)
+        with torch.no_grad():      # away from the identity start: every leaf has a generic gradient from the first step on
+            for i, p in enumerate(ch.parameters()):
+                p.add_(3e-3 * torch.randn(p.shape, generator=torch.Generator().manual_seed(1000 * f + i)).to(dev))
+        views = F.synthetic_views(8, 1, bench.FIT_RAYS, 140 + f, jf[9], device=dev)
+        torch.manual_seed(9000 + f)                          # the frame's seed: its jitter is drawn from here
+        return views, ch
+
+    def run(batch):
+        out = {}
+
+        def save(f, chain, terms):
+            torch.cuda.synchronize()
+            out[f] = ([p.detach().clone() for p in chain.parameters()], {k: float(v) for k, v in terms.items()})
+        red = F.fit_frames_sharded(ren, n_frames, make_frame, bench.NEAR, bench.FAR, '12', n_iters=1, save=save, batch=batch)
+        assert red['frames'] == n_frames and red['steps'] == 8 * n_frames and red['frame_batch'] == batch
+        return out
+
+    one = run(1)
+    assert not torch.equal(one[0][0][4], one[1][0][4])          # (different frames, different fits)
+    for batch in (2, 3, 5):
+        got = run(batch)
+        assert sorted(got) == list(range(n_frames))
+        for f in range(n_frames):
+            assert got[f][1] == one[f][1], 'batch %d, frame %d: loss terms %s vs %s' % (batch, f, got[f][1], one[f][1])
+            for i, (a, b) in enumerate(zip(got[f][0], one[f][0])):
+                assert torch.equal(a, b), 'batch %d, frame %d, leaf %d: %g' % (batch, f, i, float((a - b).abs().max()))
+    record('frames fitted side by side (batches of 2, 3, 5) vs one by one: leaves and loss terms', 0.0, 0.0)
+
+
 def test_fitting_video_window_steps_are_bit_reproducible():
     """The same for the frame-batched renderer: six optimiser steps on a fitting_video window (4 frames x 40 rays, fit type 1234
     with the stable term and an anchored sequence end) give the same bits in every loss term, leaf gradient and leaf in two runs.
@@ -840,3 +886,35 @@ def test_window_rows_are_read_as_int64_whatever_the_index_holds():
     gsrc = torch.ones(4, 45, device=dev)
     L.check(lib.hn_leaf_rows_scatter(L.ptr(gsrc), L.ptr(rows), 4, 7, L.ptr(out), L.stream_ptr()), 'hn_leaf_rows_scatter')
     assert float(out.sum()) == 2 * 45.0
+
+
+def test_fit_sequence_video_is_bit_reproducible():
+    """The sequence loop of fitting_video (fit_sequence_video: windows x sub-iterations x views, no host synchronisation between steps)
+    gives the same leaves in every run -- what keeps the replicas of a multi-GPU run identical too.  Round 5 found it did NOT: about
+    once in a hundred steps the stable term's forward pass, queued on the extra stream right behind the pose chain's Jacobian launch,
+    read the previous contents of its inputs (tools/seq_repro_diag.py; a window's steps in isolation, with a synchronisation per
+    step, were reproducible and hid it).  The Jacobian launch now follows the stable term's forward pass.  Three runs of a 6-frame
+    sequence, 96 steps each."""
+    import bench
+    from honerf_amd import fitting as F
+    dev = torch.device('cuda')
+    renb, _ = bench.build_fit_nets(dev, bench.VID_FRAMES, 'f16x3')
+    n_frames, n_views = 6, 8
+    runs = []
+    for rep in range(3):
+        torch.manual_seed(77)
+        chain, j, v = bench.build_fit_data(dev, 60, n_frames, halo=True, drift=0.002)
+        ov = v[None].expand(bench.VID_FRAMES, -1, -1).contiguous()
+        per_window = {tuple(w): F.synthetic_views(n_views, bench.VID_FRAMES, bench.VID_RAYS, 300 + w[0], j[9], device=dev) for w in F.sliding_windows(n_frames)}
+
+        def window_views(index, vid, step):
+            return per_window[tuple(index)][vid]
+        window_views.n_views = n_views
+        st = F.fit_sequence_video(renb, window_views, chain, bench.NEAR, bench.FAR, n_frames, '1234', outer_iters=1, obj_verts=ov)
+        torch.cuda.synchronize()
+        assert st['steps'] == 3 * 4 * n_views
+        runs.append([p.detach().clone() for p in chain.parameters()])
+    for rep in (1, 2):
+        for i, (a, b) in enumerate(zip(runs[0], runs[rep])):
+            assert torch.equal(a, b), 'run %d, leaf %d: %g' % (rep, i, float((a - b).abs().max()))
+    record('fit_sequence_video: three runs of 96 steps, leaves', 0.0, 0.0)
