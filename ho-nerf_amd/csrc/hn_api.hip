@@ -1043,6 +1043,23 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     // 294-tile kernel takes every CU (one 512-register workgroup per CU) and the small launches in front of the hand's
     // evaluation -- its sample points, the compaction -- wait a whole tile time for a wave slot (measured: 245 us).
     bool forked = false;
+    // CROWDED (several frames side by side: more than two tiles per CU): the hand's evaluation alone fills every CU for a tile time or
+    // more, and a small launch of the object branch queued beside it -- its sample points -- waits that long for a wave slot, the
+    // object's evaluation behind it (measured, 4 frames: k_sample_points_t 1.25 ms in front of k_field2_obj<3>).  So the object's
+    // small launches go FIRST, beside the hand's small ones, the hand's stream waits for them, and the two evaluations are queued
+    // back to back.
+    const bool crowded = side != nullptr && (N + 127) / 128 >= (size_t)2 * (size_t)(device_cus() > 0 ? device_cus() : 256);
+    bool obj_pts_made = false;
+    if (crowded) {
+        HN_TRY(fork_to(side, s));
+        forked = true;
+        if (!obj_rays_made) {
+            HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_obj, d_obj, so, ro_t));
+            obj_rays_made = true;
+        }
+        HN_TRY(sample_points(o_obj, d_obj, z_final, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
+        obj_pts_made = true;
+    }
     HN_TRY(sample_points(rays_o, rays_d, z_final, n_rays, S, 1, sample_dist, pts, dists, s));
     if (hand_compaction(hand, n_frames, N)) {
         // the hand field on the samples with a live bone + one far sample; the record stays with the tape for the backward pass
@@ -1051,7 +1068,10 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
         CompactRec cr;
         cr.at(in_tape ? reinterpret_cast<char*>(tape) + rec_off : crec_ws, N);
         HN_TRY(compact_hand(cr, pts, (int)N, bt_inv, T_pose, n_frames, rpf * S, s));
-        if (side != nullptr) HN_TRY(fork_to(side, s));
+        if (crowded)
+            HN_TRY(join_from(side, s));
+        else if (side != nullptr)
+            HN_TRY(fork_to(side, s));
         forked = true;
         set_launch_n_pts_dev(cr.n_dev);
         set_launch_orig_idx(cr.idx);
@@ -1064,7 +1084,10 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
                            grad_hand, rgb_h);
         HN_LAUNCH_CHECK();
     } else {
-        if (side != nullptr) HN_TRY(fork_to(side, s));
+        if (crowded)
+            HN_TRY(join_from(side, s));
+        else if (side != nullptr)
+            HN_TRY(fork_to(side, s));
         forked = true;
         HN_TRY(field_eval(hand, pts, rays_d, (int)N, S, bt_inv, T_pose, n_frames, rpf * S, sdf_hand, grad_hand, rgb_h, nullptr,
                           fwsh, fws_h, s, tp_h, tape_h));
@@ -1072,7 +1095,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     (void)forked;
     HN_TRY(alpha(sdf_hand, grad_hand, rays_d, dists, (int)N, S, hand->inv_s, al_h, nullptr, s));
     if (!obj_rays_made) HN_TRY(obj_local_fwd(rays_o, rays_d, Ro, To, n_frames, rpf, o_obj, d_obj, so, ro_t));
-    HN_TRY(sample_points(o_obj, d_obj, z_final, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
+    if (!obj_pts_made) HN_TRY(sample_points(o_obj, d_obj, z_final, n_rays, S, 1, sample_dist, pts_o, dists_o, so));
     HN_TRY(field_eval(obj, pts_o, d_obj, (int)N, S, nullptr, nullptr, 1, (int)N, sdf_obj, grad_obj, rgb_o, nullptr, fwso,
                       fws_o, so, tp_o, tape_o));
     HN_TRY(alpha(sdf_obj, grad_obj, d_obj, dists_o, (int)N, S, obj->inv_s, al_o, nullptr, so));
@@ -1194,7 +1217,13 @@ static int render_dual_bwd_impl(const hn_field* hand, const hn_field* obj, const
         HN_TRY(alpha_bwd_up(sdf_o, grad_o, d_l, z, g_ao, n, S, sample_dist, obj->inv_s, g_sdf_o, g_grad_o, g_eik != nullptr ? g_eik + 1 : nullptr, gs_o, gg_o, nullptr,
                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, zb + 1, zn + 1, 3, so, gd_os));
     }
-    if (side != nullptr) HN_TRY(gate_to(side, s));
+    // (crowded -- several frames side by side, see render_dual_impl --: the hand's adjoint kernel waits for the object's small launches
+    // instead of the other way round: queued beside a kernel that fills every CU they waited a tile time, 1.65 ms, for a wave slot)
+    const bool crowded = side != nullptr && (N + 127) / 128 >= (size_t)2 * (size_t)(device_cus() > 0 ? device_cus() : 256);
+    if (crowded)
+        HN_TRY(join_from(side, s));
+    else if (side != nullptr)
+        HN_TRY(gate_to(side, s));
     if (compact) {
         set_launch_n_pts_dev(cr.n_dev);
         set_launch_orig_idx(cr.idx);

@@ -1252,6 +1252,22 @@ static int hand2_grid(int n_pts, int n_cus) {
     return n_tiles < n_cus ? n_tiles : n_cus;
 }
 
+// Grid of the TAPED evaluation and of the adjoint from a tape (modes 3 / 4: their stash is indexed by tile, so any grid works).  These
+// two run in PAIRS -- the hand's beside the object's, on two streams -- and a persistent grid of one workgroup per CU never gives a CU
+// back before its last tile: with more tiles than CUs in the first kernel (several frames side by side, fitting.fit_frames_batched)
+// the second kernel's small launches and then its tiles waited for the first one's tail (measured, 4 frames: k_sample_points_t 1.25 ms
+// in front of k_field2_obj<3>, the phase 3.45 ms for 2.7 ms of tile time).  One workgroup per TILE instead: the dispatcher hands
+// freed CUs to whichever kernel has workgroups waiting, and the tail is one tile.  HN_TAPED_GRID=cus: the persistent grid (A/B).
+static int taped_grid(int n_pts, int n_cus) {
+    static const int mode = [] {
+        const char* e = getenv("HN_TAPED_GRID");
+        return (e != nullptr && e[0] == 'c') ? 0 : 1;
+    }();
+    const int n_tiles = (n_pts + WG_SAMPLES - 1) / WG_SAMPLES;
+    if (mode == 0) return n_tiles < n_cus ? n_tiles : n_cus;
+    return n_tiles < 65535 ? n_tiles : 65535;
+}
+
 static void hand2_common_args(Hand2Args& a, const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose,
                               int n_frames, int pts_per_frame, void* workspace) {
     a.pts = pts;
@@ -1395,7 +1411,7 @@ int launch_field2_hand_taped(const hn_field* f, const float* pts, int n_pts, con
     if (n_cus <= 0) n_cus = 256;
     static std::atomic<uint64_t> lds_tape{0};
     HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<3>), (int)HAND2_LDS, &lds_tape));
-    hipLaunchKernelGGL(k_field2_hand<3>, dim3(hand2_grid(n_pts, n_cus)), dim3(256), HAND2_LDS, stream, a);
+    hipLaunchKernelGGL(k_field2_hand<3>, dim3(taped_grid(n_pts, n_cus)), dim3(256), HAND2_LDS, stream, a);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -1450,7 +1466,7 @@ int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const
         a.rgb = const_cast<float*>(rgb);
         static std::atomic<uint64_t> lds_adjonly{0};
         HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<4>), (int)HAND2_LDS, &lds_adjonly));
-        hipLaunchKernelGGL(k_field2_hand<4>, dim3(grid), dim3(256), HAND2_LDS, stream, a);
+        hipLaunchKernelGGL(k_field2_hand<4>, dim3(taped_grid(n_pts, n_cus)), dim3(256), HAND2_LDS, stream, a);
         reduce_rows();
         HN_LAUNCH_CHECK();
         return HN_OK;

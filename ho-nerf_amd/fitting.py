@@ -1153,7 +1153,7 @@ def fit_frame(renderer, views, pose_chain, near, far, fit_type='1', n_iters=None
     return last, step
 
 
-FRAME_BATCH = int(os.environ.get('HONERF_FRAME_BATCH', '4'))   # frames a rank fits side by side when it owns several (fit_frames_sharded)
+FRAME_BATCH = int(os.environ.get('HONERF_FRAME_BATCH', '8'))   # frames a rank fits side by side when it owns several (fit_frames_sharded)
 
 
 def frame_batch_capable(renderer, frame, fit_type, rays_fn=None):
@@ -1291,7 +1291,7 @@ def fit_frames_sharded(renderer, n_frames, make_frame, near, far, fit_type='12',
     run picks up what is missing, dealt out evenly over the ranks); `save(frame_id, pose_chain, terms)` is the pose dump of :293-315.  The only
     exchange is the SUM of the small loss vector at the end (`FrameShardedRunner.reduce`).
 
-    batch (default FRAME_BATCH = 4): a rank that owns several frames fits up to `batch` of them SIDE BY SIDE through the same launches
+    batch (default FRAME_BATCH = 8): a rank that owns several frames fits up to `batch` of them SIDE BY SIDE through the same launches
     (`fit_frames_batched`) where the device path applies -- one frame's launches leave the GPU half empty -- with per-frame results
     that equal the one-by-one fits to the bit; 1: one by one.
 

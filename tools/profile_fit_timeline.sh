@@ -3,13 +3,14 @@
 # Usage (through gpurun, from the repo root): bash tools/profile_fit_timeline.sh <tag>  -> gpurun_out/prof_fit_<tag>/
 set -u
 TAG=${1:-run}
+FRAMES=${2:-1}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_fit_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-python3 $R/tools/fit_profile.py 40 > $OUT/unprofiled.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_stats_$TAG -- python3 $R/tools/fit_profile.py 20 > $OUT/stats.log 2>&1
+python3 $R/tools/fit_profile.py 40 halo pipe $FRAMES > $OUT/unprofiled.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_stats_$TAG -- python3 $R/tools/fit_profile.py 20 halo pipe $FRAMES > $OUT/stats.log 2>&1
 find /tmp/pf_stats_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 T=$(find /tmp/pf_stats_$TAG -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/trace_gaps.py $T 12 4 > $OUT/busy_idle.txt 2>&1
