@@ -58,5 +58,13 @@ for k in (64, 112):
     zo, so, idx = torch.empty(B, k + 16, device=dev), torch.empty(B, k + 16, device=dev), torch.empty(B, k + 16, dtype=torch.int64, device=dev)
     report('hn_merge k=%d' % k, B * ((k + 16) * 8 * 2 + (k + 16) * 8),
            lambda: L.check(lib.hn_merge(L.ptr(z), L.ptr(zn), L.ptr(s), L.ptr(sn), B, k, 16, 0, L.ptr(zo), L.ptr(so), L.ptr(idx), st), 'merge'))
+# the wave-per-ray form of up_sample (the fitting loops: <= 8192 rays), at the fitting size and at its largest batch
+for Bw in (196, 8192):
+    for k in (64, 112):
+        z = torch.sort(rnd(Bw, k) * 1.1 + 0.4, dim=-1)[0].contiguous()
+        s = (z - 0.9).contiguous()
+        zn, inds = torch.empty(Bw, 16, device=dev), torch.empty(Bw, 16, dtype=torch.int64, device=dev)
+        report('hn_upsample wave form, %d rays, k=%d' % (Bw, k), Bw * (k * 8 + 16 * 4 + 16 * 8),
+               lambda: L.check(lib.hn_upsample(L.ptr(z), L.ptr(s), Bw, k, 16, 64.0, L.ptr(zn), L.ptr(inds), st), 'up'))
 if len(sys.argv) > 1:
     json.dump({'rays': B, 'hbm_peak_GB_per_s': PEAK, 'kernels': rows}, open(sys.argv[1], 'w'), indent=1)
