@@ -347,19 +347,21 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
     def make_frame(f):
         ch, jf, _ = build_fit_data(dev, 140 + f, 1, halo=True)
         return F.synthetic_views(8, 1, FIT_RAYS, 140 + f, jf[9], device=dev), ch
-    def c4_leg(batch):
+    def c4_leg(batch, n_iters=None):
         made = {f: make_frame(f) for f in F.shard_frames(n_c4, rank, world)}           # data "loading" is not timed
         def frame(f):
             torch.manual_seed(5000 + f)      # the frame's seed, set where its data is handed over: its jitter stream (per-frame seeds)
             return made[f]
-        dt, red = wall(lambda: F.fit_frames_sharded(ren, n_c4, frame, NEAR, FAR, '12', dist=dist, batch=batch))
+        dt, red = wall(lambda: F.fit_frames_sharded(ren, n_c4, frame, NEAR, FAR, '12', n_iters=n_iters, dist=dist, batch=batch))
         return {'frames': red['frames'], 'steps_per_frame': STEPS_PER_FRAME['12'], 'seconds': dt,
                 'frames_per_s': red['frames'] / dt, 'ms_per_step': dt / (STEPS_PER_FRAME['12'] * max(len(made), 1)) * 1e3,
                 'frames_per_rank': len(made), 'frame_batch': min(batch, max(len(made), 1)), 'scaling': 'strong (the same %d frames at every N)' % n_c4,
                 'collectives': 'one SUM all-reduce of %d loss values at the end' % len(F.LOSS_KEYS), 'loss_mean': red['loss']}
     # a rank that owns several frames fits up to FRAME_BATCH of them side by side through the same launches (per-frame results equal
     # the one-by-one fits to the bit: tests/test_gpu_surface.py); `frames_sharded_12_one_by_one`: the same frames strictly one after the other
-    c4_leg(F.FRAME_BATCH) if quick else None          # (warm: the batched sizes' workspaces)
+    # (untimed: one pass of 8 steps at the batched sizes -- the renderer's grow-only workspaces and the 2.6 GB-per-frame tape are
+    # allocated once per process and re-used by every later batch; the one-by-one sizes were warmed by the step legs above)
+    c4_leg(F.FRAME_BATCH, n_iters=1)
     res['frames_sharded_12'] = c4_leg(F.FRAME_BATCH)
     res['frames_sharded_12']['what'] = ('C4: fitting_single fit_12_8views, %d frames dealt out over the GPUs, fit_frames_sharded end to end; a rank fits up to %d of '
                                         'its frames side by side (fit_frames_batched)' % (n_c4, F.FRAME_BATCH))

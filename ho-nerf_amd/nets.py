@@ -76,17 +76,115 @@ def _filler_state_dict(kind):
     return sd
 
 
+class _FieldCallFn(torch.autograd.Function):
+    """A stand-alone SDF-module call WITH a graph: (pts [n,3], bt_inv [F,21,4,4] | None, T_pose [F,21,3] | None, *the module's
+    parameters) -> (sdf [n,1], d sdf / d pts [n,3]).  The reference's `.sdf()` is an nn.Module forward and its `.gradient()` an
+    `autograd.grad(..., create_graph=True)` (utils/fields.py:158-177, 330-347): both can be differentiated again, w.r.t. the points,
+    the hand's pose inputs and every parameter -- that is how the eikonal term reaches the weights.  Backward here = hn_field_param_bwd
+    (the adjoint of one field evaluation incl. the second-order path through the gradient output, with d / d folded weights) +
+    hn_weight_norm_bwd (the weight-norm chain rule), as the training iteration has them."""
+
+    @staticmethod
+    def forward(ctx, module, pts, bt_inv, T_pose, *params):
+        pf = module._packed()
+        p = _lib.f32(pts).reshape(-1, 3)
+        bt = None if bt_inv is None else _lib.f32(bt_inv, p.device).reshape(-1, 21, 4, 4)
+        tp = None if T_pose is None else _lib.f32(T_pose, p.device).reshape(-1, 21, 3)
+        sdf, grad, _ = pf.evaluate(p, torch.zeros_like(p), 1, bt, tp)
+        ctx.module, ctx.pf = module, pf
+        ctx.shapes = (pts.shape, None if bt_inv is None else bt_inv.shape, None if T_pose is None else T_pose.shape)
+        ctx.save_for_backward(p, *([bt, tp] if bt is not None else []))
+        return sdf, grad
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_grad):
+        L = _lib
+        module, pf = ctx.module, ctx.pf
+        lib = pf.lib
+        sv = ctx.saved_tensors
+        p = sv[0]
+        hand = len(sv) > 1
+        bt, tp = (sv[1], sv[2]) if hand else (None, None)
+        n, dev = p.shape[0], p.device
+        nf = bt.shape[0] if hand else 1
+        if hand and tp.shape[0] != nf:
+            tp = tp.expand(nf, 21, 3).contiguous()
+        gs = None if g_sdf is None else L.f32(g_sdf).reshape(n)
+        gg = None if g_grad is None else L.f32(g_grad).reshape(n, 3)
+        if gs is None and gg is None:
+            return (None,) * (4 + len(module._call_params()))
+        zeros3 = torch.zeros(n, 3, device=dev)
+        # (the adjoint takes all three upstream gradients or the sdf's alone: a missing one is zero)
+        gs = torch.zeros(n, device=dev) if gs is None else gs
+        gg = zeros3 if gg is None else gg
+        g_params = torch.zeros(lib.hn_field_param_floats(pf.handle), device=dev)
+        g_pts, g_dir = torch.empty(n, 3, device=dev), torch.zeros(n, 3, device=dev)
+        g_bt = torch.zeros(nf, 21, 4, 4, device=dev) if hand else None
+        g_tp = torch.zeros(nf, 21, 3, device=dev) if hand else None
+        need = lib.hn_field_bwd_workspace_bytes(pf.handle, n)
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        L.check(lib.hn_field_param_bwd(pf.handle, L.ptr(p), L.ptr(zeros3), n, 1, L.ptr(bt), L.ptr(tp), nf, max(n // nf, 1), L.ptr(gs), L.ptr(gg),
+                                       L.ptr(zeros3), L.ptr(g_params), L.ptr(g_pts), L.ptr(g_dir), L.ptr(g_bt), L.ptr(g_tp), L.ptr(ws), need,
+                                       L.stream_ptr()), 'hn_field_param_bwd')
+        # weight-norm chain rule (hn_weight_norm_bwd) into this module's (weight_g, weight_v, bias); the placeholder network of the
+        # other half of the field receives its (zero) gradients into scratch
+        keep = []
+        mine, other = module.state_dict(), module._filler
+        d_sdf, d_col = (_mlp_desc(mine, keep), _mlp_desc(other, keep)) if module._is_sdf else (_mlp_desc(other, keep), _mlp_desc(mine, keep))
+        grads, outs = [], []
+        for sd_, is_mine in ((mine, module._is_sdf), (other, not module._is_sdf)) if module._is_sdf else ((other, False), (mine, True)):
+            d = L.MlpDesc()
+            l = 0
+            while ('lin%d.bias' % l) in sd_:
+                v, b = sd_['lin%d.weight_v' % l], sd_['lin%d.bias' % l]
+                dg, dv, db = torch.empty(v.shape[0], 1, device=dev), torch.empty(v.shape, device=dev), torch.empty(b.shape, device=dev)
+                d.weight_g[l], d.weight_v[l], d.bias[l] = dg.data_ptr(), dv.data_ptr(), db.data_ptr()
+                d.out_dim[l], d.in_dim[l] = v.shape
+                keep += [dg, dv, db]
+                if is_mine:
+                    grads += [dg, dv, db]
+                l += 1
+            d.n_layers = l
+            outs.append(d)
+        L.check(lib.hn_weight_norm_bwd(pf.handle, ctypes.byref(d_sdf), ctypes.byref(d_col), L.ptr(g_params), ctypes.byref(outs[0]),
+                                       ctypes.byref(outs[1]), L.stream_ptr()), 'hn_weight_norm_bwd')
+        s_p, s_b, s_t = ctx.shapes
+        g_tp_out = None
+        if hand:
+            g_tp_out = g_tp.reshape(s_t) if g_tp.numel() == int(torch.Size(s_t).numel()) else g_tp.sum(0).reshape(s_t)
+        return (None, g_pts.reshape(s_p), g_bt.reshape(s_b) if hand else None, g_tp_out, *grads)
+
+
 class _Standalone:
     """A module called on its own (utils/fields.py `forward` / `.sdf` / `.gradient`), outside a renderer: it packs
     itself (lazily, re-packed when its parameters change) next to a placeholder for the other network of the field.
-    Forward only -- the differentiable path is the renderers' (autograd.DualRenderFn)."""
+    `.sdf()` / `.gradient()` of the SDF modules build a graph when grad mode is on and a point, pose input or parameter requires
+    grad (`_FieldCallFn`); `forward()`'s feature columns and the colour modules' calls are forward only -- their differentiable path
+    is the renderers' (autograd.DualRenderFn, training.SingleRenderFn)."""
     _field_kind = None      # 'obj' | 'hand'
     _is_sdf = True
+
+    def _call_params(self):
+        """(weight_g, weight_v, bias) per layer, the order _FieldCallFn.backward returns their gradients in."""
+        ps = []
+        for lin in self.layers():
+            ps += [lin.weight_g, lin.weight_v, lin.bias]
+        return ps
+
+    def _wants_graph(self, *inputs):
+        if not torch.is_grad_enabled():
+            return False
+        return any(isinstance(x, torch.Tensor) and x.requires_grad for x in inputs) or any(p.requires_grad for p in self._call_params())
+
+    def _sdf_and_gradient(self, pts, bt_inv=None, T_pose=None):
+        """(sdf [n,1], gradient [n,3]) with a graph."""
+        return _FieldCallFn.apply(self, pts, bt_inv, T_pose, *self._call_params())
 
     def _packed(self):
         ver = params_version(self)
         if getattr(self, '_pf', None) is None or self._pf_ver != ver:
-            other = _filler_state_dict(('color_' if self._is_sdf else 'sdf_') + self._field_kind)
+            other = {k: v.cuda() for k, v in _filler_state_dict(('color_' if self._is_sdf else 'sdf_') + self._field_kind).items()}
+            object.__setattr__(self, '_filler', other)
             mine = self
             sdf, col = (mine, other) if self._is_sdf else (other, mine)
             object.__setattr__(self, '_pf', PackedField(self._field_kind, sdf, col, 0.3, scale=float(getattr(self, 'scale', 1.0))))
@@ -107,10 +205,15 @@ class SDFNetwork_OBJ(_MLPParams, _Standalone):
 
     def sdf(self, x):
         """utils/fields.py:330-331 -> [N,1]."""
+        if self._wants_graph(x):
+            return self._sdf_and_gradient(x.reshape(-1, 3))[0]
         return self._packed().sdf(x)
 
     def gradient(self, x):
-        """utils/fields.py:336-347: d sdf / d x, [N,1,3] (analytic reverse sweep instead of autograd.grad)."""
+        """utils/fields.py:336-347: d sdf / d x, [N,1,3] (analytic reverse sweep instead of autograd.grad); differentiable again, as
+        the reference's create_graph=True result is (hn_field_param_bwd)."""
+        if self._wants_graph(x):
+            return self._sdf_and_gradient(x.reshape(-1, 3))[1].unsqueeze(1)
         pts = _lib.f32(x).reshape(-1, 3)
         _, grad, _ = self._packed().evaluate(pts, torch.zeros_like(pts), 1)
         return grad.unsqueeze(1)
@@ -159,13 +262,26 @@ class SDFNetwork(_MLPParams, _Standalone):
                                            _lib.ptr(h), _lib.stream_ptr()), 'hn_hand_features')
         return torch.cat([sdf, feat], dim=-1), X, r, h
 
+    def _graph_inputs(self, x, bt_inv, T_pose_21):
+        """The call's inputs as autograd sees them (no detach): points [M,3], bt_inv [F,21,4,4], T_pose [F,21,3]."""
+        t = lambda v: v if isinstance(v, torch.Tensor) else torch.as_tensor(v, dtype=torch.float32, device=x.device if isinstance(x, torch.Tensor) else 'cuda')
+        bt, tp = t(bt_inv).reshape(-1, 21, 4, 4), t(T_pose_21).reshape(-1, 21, 3)
+        if not self.use_batch:
+            bt, tp = bt[:1], tp[:1]
+        return t(x).reshape(-1, 3), bt, tp
+
     def sdf(self, x, bt_inv, T_pose_21):
         """utils/fields.py:158-160 -> [M,1]."""
+        if self._wants_graph(x, bt_inv, T_pose_21):
+            return self._sdf_and_gradient(*self._graph_inputs(x, bt_inv, T_pose_21))[0]
         pts, bt, tp = self._frames(x, bt_inv, T_pose_21)
         return self._packed().sdf(pts, bt, tp)
 
     def gradient(self, x, bt_inv, T_pose_21):
-        """utils/fields.py:165-177: d sdf / d x, [M,1,3] (use_batch: [F,1,N,3] squeezes to the same rows)."""
+        """utils/fields.py:165-177: d sdf / d x, [M,1,3] (use_batch: [F,1,N,3] squeezes to the same rows); differentiable again, as
+        the reference's create_graph=True result is."""
+        if self._wants_graph(x, bt_inv, T_pose_21):
+            return self._sdf_and_gradient(*self._graph_inputs(x, bt_inv, T_pose_21))[1].unsqueeze(1)
         pts, bt, tp = self._frames(x, bt_inv, T_pose_21)
         _, grad, _ = self._packed().evaluate(pts, torch.zeros_like(pts), 1, bt, tp)
         return grad.unsqueeze(1)
