@@ -472,6 +472,31 @@ def pmc_traffic(kernel):
     return newest[0], newest[1], 'collected on the kernel sources of this tree (csrc_sha16 %s)' % now
 
 
+def fit_kernel_traffic():
+    """HBM-side bytes per fitting_single step of the four field kernels of a step (taped evaluation + adjoint of both fields), from the
+    committed PMC summaries of tools/profile_fit.sh (profiles/r*/pmc_fit_k_field2_{hand3,hand4,obj3,obj4}.json, one frame per launch) --
+    quoted only if they were collected on the kernel sources of this tree.  -> (bytes or None, note)"""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import srchash
+    now = srchash.source_hash()
+    dirs = sorted(d for d in glob.glob(os.path.join(ROOT, 'profiles', 'r*')) if os.path.exists(os.path.join(d, 'pmc_fit_k_field2_hand3.json')))
+    if not dirs:
+        return None, 'no PMC summary of the fitting kernels is committed'
+    total, parts = 0.0, {}
+    for k in ('hand3', 'hand4', 'obj3', 'obj4'):
+        try:
+            d = json.load(open(os.path.join(dirs[-1], 'pmc_fit_k_field2_%s.json' % k)))
+        except Exception:
+            return None, 'incomplete PMC summaries in %s' % os.path.relpath(dirs[-1], ROOT)
+        if d.get('csrc_sha16') != now:
+            return None, 'STALE: %s was collected on kernel sources %s, this tree is %s' % (os.path.relpath(dirs[-1], ROOT), d.get('csrc_sha16'), now)
+        parts[k] = d['derived']['hbm_bytes_per_launch']
+        total += parts[k]
+    return total, ('k_field2_hand<3> %.3g + hand<4> %.3g + obj<3> %.3g + obj<4> %.3g bytes per one-frame step (tapes written and read back: ~5.4 + 3.4 MB per 128-sample '
+                   'tile), %s, csrc_sha16 %s' % (parts['hand3'], parts['hand4'], parts['obj3'], parts['obj4'], os.path.relpath(dirs[-1], ROOT), now))
+
+
 def spawn_command(n_gpus, argv):
     """The launch line of the driver contract: one rank per GPU of one node over RCCL, rendezvous on 127.0.0.1."""
     import socket
@@ -834,6 +859,13 @@ def main():
         flop_d = fit_step_flop(FIT_RAYS)
         fitting['roofline_dense'] = {'bound': 'mfma', 'what': 'the same step with every sample evaluated (single_12_dense)', 'flop_per_step': flop_d,
                                      'achieved': flop_d / sec_d / 1e12, 'peak': f16x3_peak, 'unit': 'TFLOP/s', 'frac': flop_d / sec_d / 1e12 / f16x3_peak}
+        # the same priced on the C4 leg, where a rank fits its frames side by side (per frame-step: the whole leg / (frames x steps))
+        sec_b = fitting['frames_sharded_12']['ms_per_step'] * 1e-3
+        fitting['roofline_frames_side_by_side'] = {'bound': 'mfma', 'what': 'frames_sharded_12: per frame-step of the C4 leg (%d frames side by side), the FLOP of one '
+                                                                              'executed fitting_single step' % fitting['frames_sharded_12'].get('frame_batch', 1),
+                                                   'flop_per_step': flop, 'achieved': flop / sec_b / 1e12, 'peak': f16x3_peak, 'unit': 'TFLOP/s',
+                                                   'frac': flop / sec_b / 1e12 / f16x3_peak}
+        fitting['roofline']['traffic'], fitting['roofline']['traffic_note'] = fit_kernel_traffic()
         fitting['n_gpus'] = world
         if rccl_leg is not None:
             fitting['rccl_one_rank'] = rccl_leg

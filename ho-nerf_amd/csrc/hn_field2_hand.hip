@@ -611,9 +611,13 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
         //      sharing the bone's fragments, then NB leftover chunks (4 tiles x 3 k-steps [+ tail: the 4 biases,
         //      added here when BIAS]).  c1/c2[4 blk + ti] += W[tile, features] * feat.  Bone b+1's fragments are
         //      loaded while bone b's MFMAs run.
-        auto bone_loads = [&](int b) { return b >= N_BONES || ((nz >> b) & 1u); };   // load_bone issues its 8 loads
+#ifndef HN_DBG_NO_FEAT_LOADS
+#define HN_DBG_NO_FEAT_LOADS 0   // 1 (measurement only, WRONG results): the feature passes never read the bones' fragments back from the stash -- an
+                                 // upper bound on what reading them twice instead of four times could buy (round 5, profiles/r05/README.md)
+#endif
+        auto bone_loads = [&](int b) { return !HN_DBG_NO_FEAT_LOADS && (b >= N_BONES || ((nz >> b) & 1u)); };   // load_bone issues its 8 loads
         auto load_bone = [&](int b, h8(&oh)[4], h8(&ol)[4]) {
-            if (b >= N_BONES || ((nz >> b) & 1u)) {
+            if (!HN_DBG_NO_FEAT_LOADS && (b >= N_BONES || ((nz >> b) & 1u))) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) sh.frag_load(feat_base, 4 * b + s, oh[s], ol[s]);
             } else {

@@ -775,8 +775,13 @@ __device__ __forceinline__ void split_finish(EpiState& st) {
 // adjoint (hn_field2_*_adj): 4 forward-direction sweep  v = z sigma',  w = z (1 - sigma') * (pd.x 100 / 256)  (pd.x = dz:
 // w is the second-order source sigma'' u dzb of oracle/field_bwd.py written without a division by sigma');
 // 5 second reverse sweep  v = z sigma' + pd.x;  6 relu mask  v = pd.v > 0 ? z : 0.
-template <int J, int P, int KIND, bool FRAGS, typename PD>
+#ifndef HN_DBG_SOFTPLUS_AS_RELU
+#define HN_DBG_SOFTPLUS_AS_RELU 0   // 1 (measurement only, WRONG results): the softplus epilogue issues a ReLU's instructions -- an upper bound on
+                                    // what a cheaper activation epilogue could buy the evaluation kernels (round 5, profiles/r05/README.md)
+#endif
+template <int J, int P, int KIND_, bool FRAGS, typename PD>
 __device__ __forceinline__ void pair_phase(EpiState& st, const PD& pd) {
+    constexpr int KIND = (HN_DBG_SOFTPLUS_AS_RELU && KIND_ == 0) ? 2 : KIND_;
     constexpr int i0 = 2 * J, i1 = 2 * J + 1;
     if constexpr (P == 0) {
         const f32x2 c1 = {st.c1[i0], st.c1[i1]}, c2 = {st.c2[i0], st.c2[i1]};
