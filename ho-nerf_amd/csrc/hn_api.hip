@@ -1114,12 +1114,13 @@ size_t pool_trim();
 namespace bwd {
 int weight_norm_bwd(const hn_field*, const hn_mlp_desc*, const hn_mlp_desc*, const float*, const hn_mlp_desc*, const hn_mlp_desc*, hipStream_t);
 typedef std::function<int(const float* z8, const float* grad, const float* rgb_pre)> MidHook;
+typedef std::function<int(const float* sdf, const float* grad, const float* rgb)> MidHook2;
 size_t field_bwd_workspace_bytes(const hn_field* f, int n);
 int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int n, int spr, const float* bt_inv,
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
                    size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb,
-                   float* g_params = nullptr, const MidHook* mid = nullptr);
+                   float* g_params = nullptr, const MidHook* mid = nullptr, const MidHook2* mid2 = nullptr);
 }
 
 // Backward pass of the two-field render (what loss.backward() runs through NeuSRenderer_fitting.render in the fitting
@@ -1360,6 +1361,20 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
         HN_LAUNCH_CHECK();
         return HN_OK;
     };
+    // ... the same stages for the FUSED parameter-gradient path of an f16x3 object field (hn_field_bwd.hip): the taped evaluation's own
+    // outputs instead of the generic tape's last-layer rows
+    const bwd::MidHook2 mid2 = [&](const float* sdf_t, const float* grad_t, const float* rgb_t) -> int {
+        HN_TRY(alpha(sdf_t, grad_t, rays_d, dists, n, S, f->inv_s, al, c, s));
+        HN_TRY(composite1_bwd(al, c, rgb_t, g_color, g_wsum, n_rays, S, g_al, g_c, g_rgb, s));
+        HN_TRY(alpha_bwd(sdf_t, grad_t, rays_d, dists, g_al, g_c, n, S, f->inv_s, gs, gg, gd, s));
+        if (g_inv_s != nullptr) {
+            HN_CHECK_HIP(hipMemsetAsync(g_inv_s, 0, sizeof(float), s));
+            HN_TRY(alpha_inv_s_bwd(sdf_t, grad_t, rays_d, dists, g_al, g_c, n, S, f->inv_s, g_inv_s, s));
+        }
+        hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs, gg, (const float*)nullptr, (const float*)nullptr, grad_t, g_eik, n);
+        HN_LAUNCH_CHECK();
+        return HN_OK;
+    };
     float *gbt = g_bt_inv, *gtp = g_T_pose;
     if (hand) {   // the adjoint accumulates the pose gradients: into the caller's arrays when given, else into scratch
         if (gbt == nullptr) gbt = pose_scratch;
@@ -1376,7 +1391,7 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
         HN_LAUNCH_CHECK();
     } else {
         HN_TRY(bwd::field_eval_bwd(f, pts, rays_d, n, S, bt_inv, T_pose, 1, n, gs, gg, g_rgb, gp, gdir, gbt, gtp, bws, bws_bytes, s, nullptr,
-                                   nullptr, nullptr, g_params, &mid));
+                                   nullptr, nullptr, g_params, &mid, &mid2));
     }
     HN_TRY(sample_points_bwd(z, gp, n_rays, S, 1, sample_dist, go, gdd, s));
     if (g_rays_o != nullptr) HN_CHECK_HIP(hipMemcpyAsync(g_rays_o, go, R3 * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -41,7 +41,18 @@ struct Obj2Args {
     float* g_pts;          // [n,3]
     float* g_rays_d;       // [n/spr,3] or NULL: accumulated with atomics (zeroed by the launcher); with dir_per_sample: [n,3], stored
     int dir_per_sample;
+    // MODE 5 (the adjoint from a tape that also leaves the PER-LAYER SIGNALS of the parameter gradients): OSG_COUNT row-major
+    // [n, 256] fp32 arrays `sig + k * sig_pitch` (enum below), unscaled, and gb [n,3] (the adjoint of d sdf / d pts incl. the colour
+    // network's share: J gb is the forward-direction sweep's input)
+    float* sig;
+    size_t sig_pitch;      // floats between two signal arrays
+    float* gb_out;
 };
+// signal arrays of MODE 5 (what hn_field_bwd.hip's outer products pair up: zb_l (x) a_l, dz_l (x) v_{l-1}, cb_l (x) c_l, fb (x) a_8):
+//   OSG_CB + k: adjoint of colour layer (3 - k)'s pre-activation;  OSG_C + k: c_{k+1} (colour activations);  OSG_A + l: a_{l+1};
+//   OSG_DZ + l: dz_l of the reverse sweep;  OSG_V + l: v_l = sigma'_l dzb_l (forward-direction sweep);  OSG_ZB + l: zb_l (second reverse
+//   sweep);  OSG_FB: the feature vector's adjoint
+enum { OSG_CB = 0, OSG_C = 4, OSG_A = 8, OSG_DZ = 16, OSG_V = 24, OSG_ZB = 32, OSG_FB = 40, OSG_COUNT = 41 };
 
 // stash slots of one wave (32 KiB each)
 enum { OS_A1 = 0 /* a1..a7 -> 0..6 */, OS_DZ7 = 7, OS_FVEC = 8, OS_DZ4 = 9, OS_X = 10, OBJ2_SLOTS = 11 };
@@ -109,11 +120,31 @@ struct Act2 {
 struct Act1 {
     f32x16 v;
 };
+template <bool PG>
 __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stash& sh, int lane, int h, int n, int nn, bool valid,
                                             int next_first /* first chunk of the next tile's program, 0 = none */, const float (&p)[3], const float (&d)[3], const float (&g)[3],
                                             const float (&rgb)[3], h8 (&ah)[16], h8 (&al)[16], h8 (&bh)[16], h8 (&bl)[16]) {
     auto no_store = [](auto, const auto&) {};
     auto no_pre = [](auto, const char*) { return NoData{}; };
+    // MODE 5: tile t of a [neurons x samples] accumulator tile -> columns 32 t .. 32 t + 31 of this lane's sample row of signal array
+    // `arr` (register i of lane (h, j): neuron 8 (i / 4) + 4 h + (i % 4), sample j), times `scale` (powers of two: exact)
+    float sig_scale = 1.f;   // 1 / kappa once it is known (below)
+    auto sig = [&](int arr, int t, const f32x16& y, float scale) {
+        if constexpr (PG) {
+            if (valid) {
+                using f32x4 = float __attribute__((ext_vector_type(4)));
+                float* row = a.sig + (size_t)arr * a.sig_pitch + (size_t)n * 256 + 32 * t + 4 * h;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<f32x4*>(row + 8 * g4) = f32x4{y[4 * g4] * scale, y[4 * g4 + 1] * scale, y[4 * g4 + 2] * scale, y[4 * g4 + 3] * scale};
+            }
+        }
+    };
+    auto sig1 = [&](int arr, int col, float v) {   // one column (lin3's neuron 192: register 0 of tile 6, half 0)
+        if constexpr (PG) {
+            if (valid && h == 0) a.sig[(size_t)arr * a.sig_pitch + (size_t)n * 256 + col] = v;
+        }
+    };
     auto to_regs = [&](h8(&oh)[16], h8(&ol)[16]) {
         return [&oh, &ol](auto T, EpiState& st, const auto&) {
             constexpr int t = decltype(T)::value;
@@ -125,6 +156,25 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
 #if HN_PARK_AGPR
             asm volatile("" : "+a"(oh[2 * t]), "+a"(ol[2 * t]), "+a"(oh[2 * t + 1]), "+a"(ol[2 * t + 1]));
 #endif
+            return NoData{};
+        };
+    };
+    // ... the same, and the tile's value -> signal array `arr` (times 1 / kappa), the pre-data's first tile -> `arr_pre` (as it is)
+    auto to_regs_sig = [&](h8(&oh)[16], h8(&ol)[16], int arr, int arr_pre) {
+        return [&oh, &ol, arr, arr_pre, &sig, &sig_scale](auto T, EpiState& st, const auto& pd) {
+            constexpr int t = decltype(T)::value;
+            asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+            oh[2 * t] = st.hi[0];
+            ol[2 * t] = st.lo[0];
+            oh[2 * t + 1] = st.hi[1];
+            ol[2 * t + 1] = st.lo[1];
+#if HN_PARK_AGPR
+            asm volatile("" : "+a"(oh[2 * t]), "+a"(ol[2 * t]), "+a"(oh[2 * t + 1]), "+a"(ol[2 * t + 1]));
+#endif
+            if constexpr (PG) {
+                sig(arr, t, st.vec(), sig_scale);
+                if (arr_pre >= 0) sig(arr_pre, t, pd.v, 1.f);
+            }
             return NoData{};
         };
     };
@@ -154,6 +204,7 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
             inv_kappa = __builtin_bit_cast(float, e << 23);
         }
     }
+    sig_scale = inv_kappa;
     const float gsk = gs * kappa * a.inv_scale;
     float xb[3];
 #pragma unroll
@@ -172,11 +223,13 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = c4[i] > 0.f ? fmaf(w0[i], xb[0], fmaf(w1[i], xb[1], w2[i] * xb[2])) : 0.f;
             split_tile(v, ah[2 * t], al[2 * t], ah[2 * t + 1], al[2 * t + 1]);
+            sig(OSG_CB + 0, t, v, sig_scale);
+            sig(OSG_C + 3, t, c4, 1.f);
         });
     }
-    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, mask_of(OS_C + 2), PhMask{}, to_regs(bh, bl), no_store);   // C3^T -> cb3
-    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, bh, bl, lane, h, mask_of(OS_C + 1), PhMask{}, to_regs(ah, al), no_store);   // C2^T -> cb2
-    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, mask_of(OS_C + 0), PhMask{}, to_regs(bh, bl), no_store);   // C1^T -> cb1
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, mask_of(OS_C + 2), PhMask{}, to_regs_sig(bh, bl, OSG_CB + 1, OSG_C + 2), no_store);   // C3^T -> cb3
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, bh, bl, lane, h, mask_of(OS_C + 1), PhMask{}, to_regs_sig(ah, al, OSG_CB + 2, OSG_C + 1), no_store);   // C2^T -> cb2
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, mask_of(OS_C + 0), PhMask{}, to_regs_sig(bh, bl, OSG_CB + 3, OSG_C + 0), no_store);   // C1^T -> cb1
     // ---- colour lin0^T: feature-vector rows -> fb (kept as fragments in the OS_FVEC slot for the W8 product) ...
     run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(
         ws, bh, bl, lane, h, no_pre, PhIdentity{},
@@ -184,6 +237,7 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
             constexpr int t = decltype(T)::value;
             sh.frag_store(OS_FVEC * SLOT_BYTES, 2 * t, st.hi[0], st.lo[0]);
             sh.frag_store(OS_FVEC * SLOT_BYTES, 2 * t + 1, st.hi[1], st.lo[1]);
+            sig(OSG_FB, t, st.vec(), sig_scale);
             return NoData{};
         },
         no_store);
@@ -226,6 +280,12 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
     });
 #pragma unroll
     for (int c = 0; c < 3; ++c) gb[c] += kappa * gg[c];   // gb = g_grad + J_enc^T (colour net's gradient w.r.t. enc(g))
+    if constexpr (PG) {
+        if (valid && h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.gb_out[3 * (size_t)n + c] = gb[c] * inv_kappa;
+        }
+    }
 
     // ---- forward-direction sweep: GXb = J gb -> dzb_0 = W0 GXb -> ... ; v_l = sigma'_l dzb_l feeds the next layer,
     //      w_l = (1 - sigma'_l) dzb_l * 100 dz_l replaces dz_l in the stash
@@ -236,8 +296,13 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
         };
     };
     auto fin4 = [&](h8(&oh)[16], h8(&ol)[16], int w_slot) {
-        return [&oh, &ol, w_slot, &sh](auto T, EpiState& st, const auto&) {
+        return [&oh, &ol, w_slot, &sh, &sig, &sig_scale](auto T, EpiState& st, const auto& pd) {
             constexpr int t = decltype(T)::value;
+            if constexpr (PG) {   // layer l = w_slot - OS_DZ: v_l, a_{l+1}, dz_l
+                sig(OSG_V + (w_slot - OS_DZ), t, st.vec(), sig_scale);
+                sig(OSG_A + (w_slot - OS_DZ), t, pd.v, 1.f);
+                sig(OSG_DZ + (w_slot - OS_DZ), t, pd.x, BWD_INV);
+            }
             asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
             oh[2 * t] = st.hi[0];
             ol[2 * t] = st.lo[0];
@@ -282,9 +347,20 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
     run_layer_c<8, 16, 1, false, true, CB_HID, CB_HID>(ws, bh, bl, lane, h, pre4(OS_A1 + 2, OS_DZ + 2), PhFwdDir{}, fin4(ah, al, OS_DZ + 2), no_store);   // lin2
     float v3_192 = 0.f;
     run_layer_c<7, 16, 1, false, true, CB_HID, CB_HID>(ws, ah, al, lane, h, pre4(OS_A1 + 3, OS_DZ + 3), PhFwdDir{},                                    // lin3 (193 rows)
-                                     [&](auto T, EpiState& st, const auto&) {
+                                     [&](auto T, EpiState& st, const auto& pd) {
                                          constexpr int t = decltype(T)::value;
                                          asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+                                         if constexpr (PG) {
+                                             if constexpr (t == 6) {
+                                                 sig1(OSG_V + 3, 192, st.v[0] * sig_scale);
+                                                 sig1(OSG_A + 3, 192, pd.v[0]);
+                                                 sig1(OSG_DZ + 3, 192, pd.x[0] * BWD_INV);
+                                             } else {
+                                                 sig(OSG_V + 3, t, st.vec(), sig_scale);
+                                                 sig(OSG_A + 3, t, pd.v, 1.f);
+                                                 sig(OSG_DZ + 3, t, pd.x, BWD_INV);
+                                             }
+                                         }
                                          if constexpr (t == 6) {
                                              v3_192 = st.v[0];   // row 0 of tile 6 = neuron 192 (half 0); the padding rows are 0 (sigma' = 0)
                                          } else {
@@ -310,7 +386,12 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
     run_layer_c<8, 16, 1, false, true, CB_HID, CB_HID>(ws, ah, al, lane, h, pre4(OS_A1 + 5, OS_DZ + 5), PhFwdDir{}, fin4(bh, bl, OS_DZ + 5), no_store);   // lin5
     run_layer_c<8, 16, 1, false, true, CB_HID, CB_HID>(ws, bh, bl, lane, h, pre4(OS_A1 + 6, OS_DZ + 6), PhFwdDir{}, fin4(ah, al, OS_DZ + 6), no_store);   // lin6
     run_layer_c<8, 16, 1, false, false, CB_HID, CB_HID>(ws, ah, al, lane, h, pre4(OS_A8, OS_DZ + 7), PhFwdDir{},                                       // lin7: only w_7
-                                      [&](auto T, EpiState& st, const auto&) {
+                                      [&](auto T, EpiState& st, const auto& pd) {
+                                          if constexpr (PG) {
+                                              sig(OSG_V + 7, decltype(T)::value, st.vec(), sig_scale);
+                                              sig(OSG_A + 7, decltype(T)::value, pd.v, 1.f);
+                                              sig(OSG_DZ + 7, decltype(T)::value, pd.x, BWD_INV);
+                                          }
                                           sh.tile_store(OS_DZ + 7, decltype(T)::value, st.wvec());
                                           return NoData{};
                                       },
@@ -335,9 +416,9 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
             for (int i = 0; i < 16; ++i) o.x[i] = fmaf(gsk * w8[i], dsoftplus_from_act(o.v[i]), o.x[i]);   // + sigma'_7 g_sdf W8[0, :]
             return o;
         },
-        PhRev2{}, to_regs(ah, al), no_store);
-    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, pre5(OS_A1 + 6, OS_DZ + 6), PhRev2{}, to_regs(bh, bl), no_store);   // W7^T -> zb6
-    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, bh, bl, lane, h, pre5(OS_A1 + 5, OS_DZ + 5), PhRev2{}, to_regs(ah, al), no_store);   // W6^T -> zb5
+        PhRev2{}, to_regs_sig(ah, al, OSG_ZB + 7, -1), no_store);
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, pre5(OS_A1 + 6, OS_DZ + 6), PhRev2{}, to_regs_sig(bh, bl, OSG_ZB + 6, -1), no_store);   // W7^T -> zb6
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, bh, bl, lane, h, pre5(OS_A1 + 5, OS_DZ + 5), PhRev2{}, to_regs_sig(ah, al, OSG_ZB + 5, -1), no_store);   // W6^T -> zb5
     run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, pre5(OS_A1 + 4, OS_DZ + 4), PhRev2{},                               // W5^T -> zb4 (kept)
                                      [&](auto T, EpiState& st, const auto&) {
                                          constexpr int t = decltype(T)::value;
@@ -348,6 +429,7 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
                                          bl[2 * t + 1] = st.lo[1];
                                          sh.frag_store(OS_ZB4 * SLOT_BYTES, 2 * t, st.hi[0], st.lo[0]);
                                          sh.frag_store(OS_ZB4 * SLOT_BYTES, 2 * t + 1, st.hi[1], st.lo[1]);
+                                         sig(OSG_ZB + 4, t, st.vec(), sig_scale);
                                          return NoData{};
                                      },
                                      no_store);
@@ -360,16 +442,18 @@ __device__ __forceinline__ void obj_adjoint(const Obj2Args& a, WStream& ws, Stas
                                              al[2 * t] = st.lo[0];
                                              ah[2 * t + 1] = st.hi[1];
                                              al[2 * t + 1] = st.lo[1];
+                                             sig(OSG_ZB + 3, t, st.vec(), sig_scale);
                                          } else {
                                              ah[12] = st.hi[0];
                                              al[12] = st.lo[0];
+                                             sig1(OSG_ZB + 3, 192, st.v[0] * sig_scale);
                                          }
                                          return NoData{};
                                      },
                                      no_store);
-    run_layer_c<8, 13, 1, false, true, CB_BWD3, CB_BWD>(ws, ah, al, lane, h, pre5(OS_A1 + 2, OS_DZ + 2), PhRev2{}, to_regs(bh, bl), no_store);   // W3^T -> zb2
-    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, bh, bl, lane, h, pre5(OS_A1 + 1, OS_DZ + 1), PhRev2{}, to_regs(ah, al), no_store);    // W2^T -> zb1
-    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, pre5(OS_A1 + 0, OS_DZ + 0), PhRev2{}, to_regs(bh, bl), no_store);    // W1^T -> zb0
+    run_layer_c<8, 13, 1, false, true, CB_BWD3, CB_BWD>(ws, ah, al, lane, h, pre5(OS_A1 + 2, OS_DZ + 2), PhRev2{}, to_regs_sig(bh, bl, OSG_ZB + 2, -1), no_store);   // W3^T -> zb2
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, bh, bl, lane, h, pre5(OS_A1 + 1, OS_DZ + 1), PhRev2{}, to_regs_sig(ah, al, OSG_ZB + 1, -1), no_store);    // W2^T -> zb1
+    run_layer_c<8, 16, 1, false, true, CB_BWD, CB_BWD>(ws, ah, al, lane, h, pre5(OS_A1 + 0, OS_DZ + 0), PhRev2{}, to_regs_sig(bh, bl, OSG_ZB + 0, -1), no_store);    // W1^T -> zb0
     // X adjoint = W0^T zb0 + W4[:, 193:]^T zb4 + the colour net's share
     f32x16 G1[2] = {zero16(), zero16()}, G2[2] = {zero16(), zero16()};
     static_for<2>([&](auto U) {
@@ -456,11 +540,11 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
     constexpr bool FULL = MODE >= 1;
     constexpr bool ADJ = MODE >= 2;                    // the forward pass writes the tape
-    constexpr bool RUN_FWD = MODE != 4;
-    constexpr bool RUN_ADJ = MODE == 2 || MODE == 4;
+    constexpr bool RUN_FWD = MODE != 4 && MODE != 5;
+    constexpr bool RUN_ADJ = MODE == 2 || MODE == 4 || MODE == 5;   // 5: 4 + the per-layer signals of the parameter gradients (Obj2Args::sig)
     constexpr bool PER_TILE = MODE >= 3;               // stash indexed by tile (kept across launches), not by workgroup
     constexpr int N_SLOTS = ADJ ? OBJ2_SLOTS_ADJ : OBJ2_SLOTS;
-    constexpr int FIRST_CHUNK = MODE == 4 ? CB_W4ROWS : CB_L0;   // first chunk of a tile's program
+    constexpr int FIRST_CHUNK = MODE >= 4 ? CB_W4ROWS : CB_L0;   // first chunk of a tile's program
     extern __shared__ __attribute__((aligned(16))) char lds[];
     f16_flush_mode();
     const int lane = threadIdx.x & 63;
@@ -912,7 +996,7 @@ __global__ __launch_bounds__(256) void k_field2_obj(const Obj2Args a) {
         for (int c = 0; c < 3; ++c) rgb[c] = sigmoid_fast(half_sum(rgb[c]) + a.c_blast[c]);
         }   // RUN_FWD
         if constexpr (RUN_ADJ) {
-            obj_adjoint(a, ws, sh, lane, h, n, nn, valid, more ? FIRST_CHUNK : 0, p, d, g, rgb, ah, al, bh, bl);
+            obj_adjoint<MODE == 5>(a, ws, sh, lane, h, n, nn, valid, more ? FIRST_CHUNK : 0, p, d, g, rgb, ah, al, bh, bl);
             continue;
         }
         if (valid && h == 0) {
@@ -1037,6 +1121,7 @@ int launch_field2_obj(const hn_field* f, const float* pts, const float* rays_d, 
     return HN_OK;
 }
 
+int field2_obj_signal_arrays() { return OSG_COUNT; }
 size_t field2_obj_adj_workspace_bytes(int n_pts, int n_cus) {
     return (size_t)obj2_grid(n_pts, n_cus) * WG_WAVES * OBJ2_SLOTS_ADJ * SLOT_F4 * sizeof(float4);
 }
@@ -1047,11 +1132,15 @@ size_t field2_obj_adj_workspace_bytes(int n_pts, int n_cus) {
 int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int spr, const float* g_sdf,
                           const float* g_grad, const float* g_rgb, float* g_pts, float* g_rays_d, void* workspace,
                           size_t workspace_bytes, hipStream_t stream, const void* tape = nullptr, const float* grad = nullptr,
-                          const float* rgb = nullptr) {
+                          const float* rgb = nullptr, float* sig = nullptr, size_t sig_pitch = 0, float* gb_out = nullptr) {
     if (n_pts <= 0) return HN_OK;
-    HN_REQUIRE(f->v2_adj != nullptr && f->v2_adjonly != nullptr, "field has no adjoint program");
+    HN_REQUIRE((tape != nullptr ? f->v2_adjonly : f->v2_adj) != nullptr, "field has no adjoint program");
     HN_REQUIRE(tape == nullptr || (grad != nullptr && rgb != nullptr), "the adjoint from a tape needs the evaluation's grad / rgb");
+    HN_REQUIRE(sig == nullptr || (tape != nullptr && gb_out != nullptr && sig_pitch >= (size_t)n_pts * 256), "the signal arrays belong to the adjoint from a tape");
     Obj2Args a{};
+    a.sig = sig;
+    a.sig_pitch = sig_pitch;
+    a.gb_out = gb_out;
     a.pts = pts;
     a.rays_d = rays_d;
     a.n_pts = n_pts;
@@ -1079,6 +1168,13 @@ int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays
         a.scratch = reinterpret_cast<float4*>(const_cast<void*>(tape));
         a.grad = const_cast<float*>(grad);   // read only in this mode
         a.rgb = const_cast<float*>(rgb);
+        if (sig != nullptr) {   // MODE 5: the same adjoint, leaving the per-layer signals of the parameter gradients
+            static std::atomic<uint64_t> lds_sig{0};
+            HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<5>), (int)OBJ2_LDS, &lds_sig));
+            hipLaunchKernelGGL(k_field2_obj<5>, dim3(taped_grid(n_pts, n_cus)), dim3(256), OBJ2_LDS, stream, a);
+            HN_LAUNCH_CHECK();
+            return HN_OK;
+        }
         static std::atomic<uint64_t> lds_adjonly{0};
         HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_obj<4>), (int)OBJ2_LDS, &lds_adjonly));
         hipLaunchKernelGGL(k_field2_obj<4>, dim3(taped_grid(n_pts, n_cus)), dim3(256), OBJ2_LDS, stream, a);

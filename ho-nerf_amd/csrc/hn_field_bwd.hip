@@ -23,7 +23,11 @@ namespace v2 {
 size_t field2_obj_adj_workspace_bytes(int n_pts, int n_cus);
 int launch_field2_obj_adj(const hn_field* f, const float* pts, const float* rays_d, int n_pts, int spr, const float* g_sdf,
                           const float* g_grad, const float* g_rgb, float* g_pts, float* g_rays_d, void* workspace,
-                          size_t workspace_bytes, hipStream_t stream, const void* tape, const float* grad, const float* rgb);
+                          size_t workspace_bytes, hipStream_t stream, const void* tape, const float* grad, const float* rgb,
+                          float* sig = nullptr, size_t sig_pitch = 0, float* gb_out = nullptr);
+int launch_field2_obj(const hn_field*, const float*, const float*, int, int, float*, float*, float*, float*, void*, size_t, bool, hipStream_t, void*, size_t);
+size_t field2_obj_tape_bytes(int n_pts);
+int field2_obj_signal_arrays();
 size_t field2_hand_adj_workspace_bytes(int n_pts, int n_cus);
 int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
                            int pts_per_frame, const float* g_sdf, const float* g_grad, const float* g_rgb, float* g_pts,
@@ -787,6 +791,59 @@ static void layout(const hn_field* f, int n, Arena& ar, Bufs& b) {
     b.zb = ar.take(N * H);
 }
 
+// xb = g_rgb * rgb (1 - rgb) from the colour itself
+__global__ void k_rgb_seed2(const float* __restrict__ rgb, const float* __restrict__ g_rgb, float* __restrict__ xb, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) xb[i] = g_rgb[i] * rgb[i] * (1.f - rgb[i]);
+}
+__global__ void k_scale1(const float* __restrict__ x, float scale, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] * scale;
+}
+
+// HN_TRAIN_FUSED=0: the parameter gradients of an f16x3 object field through the generic launch sequence (A/B, cross-check)
+static bool train_fused_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("HN_TRAIN_FUSED");
+        return !(e != nullptr && e[0] == '0');
+    }();
+    return on;
+}
+static bool fused_param_path(const hn_field* f) {
+    return train_fused_enabled() && f->kind == HN_FIELD_OBJ && f->precision == HN_PREC_F16X3 && f->v2_adjonly != nullptr &&
+           f->v2_full != nullptr;   // (a field packed for training has no evaluation + adjoint program: v2_adj is not asked for)
+}
+// Buffers of the FUSED parameter-gradient path of an object field (round 5; SURVEY 8 f1, exp_runner.py:196-232): the taped f16x3
+// evaluation (k_field2_obj<3>) and the adjoint from its tape in the form that also leaves the per-layer signals (k_field2_obj<5>:
+// OSG_COUNT row-major [n, 256] arrays) replace the generic sequence's forward tape, its three sweeps and their element-wise launches
+// (54 k_dense + ~40 small launches); the outer products over the samples (k_outer) and the encodings' small kernels stay.
+struct FusedBufs {
+    void* tape;
+    size_t tape_bytes;
+    float *sig, *sdf, *grad, *rgb, *feat, *gb, *X, *din, *gin, *xb, *GXb, *z8b0;
+    size_t pitch;
+};
+static void layout_fused(const hn_field* f, int n, Arena& ar, FusedBufs& b) {
+    const size_t N = (size_t)n;
+    const int DP = (OBJ_IN + 3) & ~3;
+    (void)f;
+    b.tape_bytes = v2::field2_obj_tape_bytes(n);
+    b.tape = ar.take((b.tape_bytes + 3) / 4);
+    b.pitch = ((N * H + 63) / 64) * 64;
+    b.sig = ar.take(b.pitch * (size_t)v2::field2_obj_signal_arrays());
+    b.sdf = ar.take(N);
+    b.grad = ar.take(N * 3);
+    b.rgb = ar.take(N * 3);
+    b.feat = ar.take(N * H);
+    b.gb = ar.take(N * 3);
+    b.X = ar.take(N * DP);
+    b.din = ar.take(N * 27);
+    b.gin = ar.take(N * 27);
+    b.xb = ar.take(N * 3);
+    b.GXb = ar.take(N * DP);
+    b.z8b0 = ar.take(N);
+}
+
 size_t field_bwd_workspace_bytes(const hn_field* f, int n) {
     Arena ar{nullptr, 0, 0};
     Bufs b;
@@ -798,6 +855,12 @@ size_t field_bwd_workspace_bytes(const hn_field* f, int n) {
         const size_t fused = f->kind == HN_FIELD_OBJ ? v2::field2_obj_adj_workspace_bytes(n, cus) : v2::field2_hand_adj_workspace_bytes(n, cus);
         need = fused > need ? fused : need;
     }
+    if (fused_param_path(f)) {
+        Arena af{nullptr, 0, 0};
+        FusedBufs fb;
+        layout_fused(f, n, af, fb);
+        need = af.used > need ? af.used : need;
+    }
     return need;
 }
 
@@ -806,6 +869,9 @@ size_t field_bwd_workspace_bytes(const hn_field* f, int n) {
 // the caller derives g_sdf / g_grad / g_rgb from these values there (hn_render_single_bwd: alpha stage and compositing
 // and their adjoints), so a training step's backward pass does not evaluate the field a second time.
 typedef std::function<int(const float* z8, const float* grad, const float* rgb_pre)> MidHook;
+// ... and for the fused form of the parameter-gradient path (below): the taped evaluation's outputs themselves (sdf [n], d sdf / d pts [n,3],
+// rgb [n,3])
+typedef std::function<int(const float* sdf, const float* grad, const float* rgb)> MidHook2;
 
 // tape / grad / rgb (HN_PREC_F16X3 only, may be NULL): the tape a taped evaluation of the same points left and that
 // evaluation's outputs -- the adjoint then runs alone instead of re-evaluating the field first
@@ -813,7 +879,7 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
                    size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb, float* g_params,
-                   const MidHook* mid) {
+                   const MidHook* mid, const MidHook2* mid2) {
     HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");
     const bool obj = f->kind == HN_FIELD_OBJ;
     HN_REQUIRE(obj || (bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1),
@@ -825,6 +891,85 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     if (n == 0) return HN_OK;
     HN_REQUIRE(g_params == nullptr || !sdf_only, "parameter gradients need g_grad and g_rgb");
     HN_REQUIRE(mid == nullptr || g_params != nullptr, "the mid hook belongs to the parameter-gradient path");
+    if (g_params != nullptr && fused_param_path(f) && (mid == nullptr || mid2 != nullptr)) {
+        // ---- FUSED parameter-gradient path (object field): taped evaluation -> [hook] -> adjoint from the tape that leaves the per-layer
+        //      signals -> the outer products over the samples.  Same gradient slots, same pairs as the generic sequence below.
+        Arena ar{reinterpret_cast<char*>(workspace), 0, workspace_bytes};
+        FusedBufs b;
+        layout_fused(f, n, ar, b);
+        if (workspace == nullptr || ar.used > workspace_bytes) {
+            set_error("adjoint workspace too small: %zu < %zu", workspace_bytes, ar.used);
+            return HN_ENOMEM;
+        }
+        const Ctx cx{s, n};
+        const size_t N = (size_t)n;
+        constexpr int Din = OBJ_IN, DP = (OBJ_IN + 3) & ~3;
+        const int* LW = f->sdf_ld;
+        const int LC0 = f->col_ld[0];
+        const float rs2 = 0.70710678118654752f;
+        const float inv_scale = 1.f / f->scale;
+        const float* const* W = f->raw_sdf_w;
+        const float* const* Bv = f->raw_sdf_b;
+        const float* const* C = f->raw_col_w;
+        const float* const* Cb = f->raw_col_b;
+        const int H4 = f->sdf_in[4] - Din;
+        auto width = [&](int l) { return f->sdf_out[l]; };
+        float* const gp = g_params;
+        auto G = [&](const float* w) { return gp + (w - reinterpret_cast<const float*>(f->raw)); };
+        auto S = [&](int k) { return b.sig + (size_t)k * b.pitch; };
+        enum { CB = 0, CC = 4, AA = 8, DZ = 16, VV = 24, ZB = 32, FB = 40 };   // OSG_* of hn_field2_obj.hip
+        HN_REQUIRE(v2::field2_obj_signal_arrays() == 41, "signal array layout changed");
+        // 1. the taped evaluation (sdf, d sdf / d pts, rgb, the feature vector); 2. the caller's stages between the outputs and their adjoints
+        HN_TRY_RC(v2::launch_field2_obj(f, pts, rays_d, n, spr, b.sdf, b.grad, b.rgb, b.feat, nullptr, 0, true, s, b.tape, b.tape_bytes));
+        if (mid2 != nullptr) {
+            HN_LAUNCH_CHECK();
+            const int rc = (*mid2)(b.sdf, b.grad, b.rgb);
+            if (rc != HN_OK) return rc;
+        }
+        // 3. the adjoint from the tape, leaving the signals (its sig arrays are written for every valid sample; columns 193 .. 255 of the
+        //    193-wide layer-3 arrays are never read)
+        HN_TRY_RC(v2::launch_field2_obj_adj(f, pts, rays_d, n, spr, g_sdf, g_grad, g_rgb, g_pts, g_rays_d, nullptr, 0, s, b.tape, b.grad, b.rgb, b.sig,
+                                            b.pitch, b.gb));
+        // 4. what the outer products pair the signals with: the encodings, the colour seed, J gb, g_sdf / scale
+        hipLaunchKernelGGL(k_enc3<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.X, DP);
+        hipLaunchKernelGGL(k_enc3<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, rays_d, n, spr, b.din, 27);
+        hipLaunchKernelGGL(k_enc3<4>, g1(n), dim3(256), 0, s, b.grad, n, 1, b.gin, 27);
+        hipLaunchKernelGGL(k_rgb_seed2, g1(N * 3), dim3(256), 0, s, b.rgb, g_rgb, b.xb, N * 3);
+        hipLaunchKernelGGL(k_enc3_push<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, b.gb, b.GXb, DP);
+        hipLaunchKernelGGL(k_scale1, g1(n), dim3(256), 0, s, g_sdf, inv_scale, b.z8b0, n);
+        const int o_d = Din, o_f = Din + 27, o_g = o_f + H;
+        // 5. colour network
+        cx.outer(b.xb, 3, 3, S(CC + 3), H, H, 1.f, G(C[4]), f->col_ld[4], G(Cb[4]));
+        for (int l = 3; l >= 1; --l) cx.outer(S(CB + (3 - l)), H, H, S(CC + l - 1), H, H, 1.f, G(C[l]), f->col_ld[l], G(Cb[l]));
+        {
+            const float* cb1 = S(CB + 3);
+            cx.outer(cb1, H, H, b.X, DP, Din, 1.f, G(C[0]), LC0, G(Cb[0]));
+            cx.outer(cb1, H, H, b.din, 27, 27, 1.f, G(C[0]) + o_d, LC0, nullptr);
+            cx.outer(cb1, H, H, b.feat, H, H, 1.f, G(C[0]) + o_f, LC0, nullptr);
+            cx.outer(cb1, H, H, b.gin, 27, 27, 1.f, G(C[0]) + o_g, LC0, nullptr);
+        }
+        // 6. the reverse sweep's own use of the matrices (the path through `.gradient()`)
+        cx.outer(S(DZ + 0), H, H, b.GXb, DP, Din, 1.f, G(W[0]), LW[0], nullptr);
+        cx.outer(S(DZ + 4), H, H, b.GXb, DP, Din, rs2, G(W[4]) + H4, LW[4], nullptr);
+        for (int l = 1; l <= 7; ++l) cx.outer(S(DZ + l), H, width(l), S(VV + l - 1), H, width(l - 1), l == 4 ? rs2 : 1.f, G(W[l]), LW[l], nullptr);
+        hipLaunchKernelGGL(k_colsum, dim3((n + 255) / 256), dim3(256), 0, s, S(VV + 7), n, H, H, inv_scale, G(W[8]));
+        // 7. the first-order path with the second-order sources
+        cx.outer(b.z8b0, 1, 1, S(AA + 7), H, H, 1.f, G(W[8]), LW[8], G(Bv[8]));
+        cx.outer(S(FB), H, H, S(AA + 7), H, H, 1.f, G(W[8]) + LW[8], LW[8], G(Bv[8]) + 1);
+        for (int l = 7; l >= 0; --l) {
+            const float* zb = S(ZB + l);
+            if (l == 4) {
+                cx.outer(zb, H, H, S(AA + 3), H, H4, rs2, G(W[4]), LW[4], G(Bv[4]));
+                cx.outer(zb, H, H, b.X, DP, Din, rs2, G(W[4]) + H4, LW[4], nullptr);
+            } else if (l == 0) {
+                cx.outer(zb, H, H, b.X, DP, Din, 1.f, G(W[0]), LW[0], G(Bv[0]));
+            } else {
+                cx.outer(zb, H, width(l), S(AA + l - 1), H, f->sdf_in[l], 1.f, G(W[l]), LW[l], G(Bv[l]));
+            }
+        }
+        HN_LAUNCH_CHECK();
+        return HN_OK;
+    }
     // g_params: gradients w.r.t. the folded weights / biases in the layout of f->raw (hn_field_param_offset), accumulated.
     // They are formed by the launch sequence below for either precision (the fused kernels keep no per-layer arrays).
     if (g_params == nullptr && fused_adjoint(f, sdf_only)) {

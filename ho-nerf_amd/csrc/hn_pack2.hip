@@ -498,7 +498,12 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
     std::lock_guard<std::mutex> pack_lock(g_pack_mu);
     const auto t_begin = std::chrono::steady_clock::now();
     const bool eval16_ = f->kind == HN_FIELD_OBJ ? (HN_OBJ_EVAL_MFMA16 != 0) : (HN_HAND_EVAL_MFMA16 != 0);
-    const int n_modes = eval_only ? 2 : (eval16_ ? 5 : 4);
+    const int n_modes = eval16_ ? 5 : 4;
+    // HN_PACK_EVAL_ONLY (a training step's per-iteration re-pack): the sdf-only and evaluation programs, and for the object field the
+    // adjoint-from-a-tape program too (+ the taped evaluation's copy where it is a separate one) -- its parameter gradients come from the
+    // taped evaluation and that adjoint (hn_field_bwd.hip, fused parameter-gradient path).  Never the evaluation + adjoint program (mode 2).
+    const bool obj_train = f->kind == HN_FIELD_OBJ;
+    auto wanted = [&](int mode) { return !eval_only || mode < 2 || (obj_train && mode >= 3); };
     const int plan_dev = current_device();   // (a plan's arrays live on the device it was derived on)
     auto plan_key = [&](int mode) { return (long long)(plan_dev + 1) * 100000 + (long long)f->kind * 100 + mode * 10 + (eval16_ ? 1 : 0); };
     auto slot_of = [&](int mode, void*** dst, size_t** nb) {
@@ -509,6 +514,7 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
     {   // every program of this pack has a checked plan: the device does it all, nothing waits
         bool all = getenv("HN_PACK_NO_PLAN") == nullptr;
         for (int mode = 0; mode < n_modes && all; ++mode) {
+            if (!wanted(mode)) continue;
             auto it = g_plans.find(plan_key(mode));
             all = it != g_plans.end() && it->second.usable;
         }
@@ -522,7 +528,10 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
                 tab.p[9 + l] = w_col[l];
                 tab.p[23 + l] = reinterpret_cast<const float*>(col->bias[l]);
             }
+            int n_built = 0;
             for (int mode = 0; mode < n_modes; ++mode) {
+                if (!wanted(mode)) continue;
+                ++n_built;
                 const PackPlan& P = g_plans[plan_key(mode)];
                 void** dst;
                 size_t* nb;
@@ -538,7 +547,7 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
                 *nb = P.bytes;
             }
             if (getenv("HN_PACK_TIMING") != nullptr)
-                fprintf(stderr, "[hn pack] %d programs from their plans %.2f ms\n", n_modes,
+                fprintf(stderr, "[hn pack] %d programs from their plans %.2f ms\n", n_built,
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
             return HN_OK;
         }
@@ -583,7 +592,7 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
     // adjoint kernels' MFMA shape, built only where the evaluation kernels use the other one
     const bool eval16 = f->kind == HN_FIELD_OBJ ? (HN_OBJ_EVAL_MFMA16 != 0) : (HN_HAND_EVAL_MFMA16 != 0);
     for (int mode = 0; mode < (eval16 ? 5 : 4); ++mode) {
-        if (eval_only && mode >= 2) break;   // sdf-only and evaluation programs only (HN_PACK_EVAL_ONLY)
+        if (!wanted(mode)) continue;
         const auto t_mode = now();
         Builder B;
         g_s16 = eval16 && mode < 2;

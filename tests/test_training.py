@@ -403,11 +403,13 @@ def test_parameter_order_matches_reference_modules():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('kind', ['obj', 'hand'])
-def test_field_param_bwd_matches_render_single_bwd_pieces(kind):
+@pytest.mark.parametrize('kind,n,spr', [('obj', 7, 7), ('hand', 7, 7), ('obj', 1160, 8), ('obj', 4480, 64)])
+def test_field_param_bwd_matches_render_single_bwd_pieces(kind, n, spr):
     """hn_field_param_bwd on its own (the adjoint of one hn_field_eval call with parameter gradients) against float64
     autograd of the oracle field on a handful of points with random cotangents: small, ragged sizes (7 points, one
-    ray of 7 samples) -- the edge of the tile / slice logic of k_outer and k_dense."""
+    ray of 7 samples) -- the edge of the tile / slice logic of k_outer and k_dense -- and, for the object field (whose
+    f16x3 form takes the fused path: taped evaluation, adjoint with the per-layer signals, outer products), ten tiles with
+    a ragged last one and several rays per tile."""
     import ctypes
     from honerf_amd import lib as L
     from honerf_amd import training
@@ -419,9 +421,8 @@ def test_field_param_bwd_matches_render_single_bwd_pieces(kind):
     var = VAR_OBJ if kind == 'obj' else VAR_HAND
     field, leaves = trainable_field(kind, sd['sdf_' + kind], sd['color_' + kind], var, dtype=torch.float64)
     gen = torch.Generator().manual_seed(17)
-    n = 7
     if kind == 'obj':
-        pts = (torch.rand(n, 3, generator=gen) - 0.5) * 0.8
+        pts = (torch.rand(n, 3, generator=gen) - 0.5) * (0.8 if n < 4000 else 0.9)
         bt = tp = None
     else:
         from honerf_amd import synth
@@ -433,19 +434,38 @@ def test_field_param_bwd_matches_render_single_bwd_pieces(kind):
         pts = torch.from_numpy(joints[9]).float()[None, :] + torch.tensor([0.008, -0.003, 0.0]) + \
             torch.linspace(-0.06, 0.06, n)[:, None] * torch.tensor([0.0, 0.0, 1.0])
         bt, tp = torch.from_numpy(bt_np), torch.from_numpy(tp_np)
-    dirs = torch.nn.functional.normalize(torch.randn(1, 3, generator=gen), dim=-1)
+    dirs = torch.nn.functional.normalize(torch.randn(n // spr, 3, generator=gen), dim=-1)
+    dirs_n = dirs[:, None, :].expand(n // spr, spr, 3).reshape(n, 3)
     g_sdf, g_grad, g_rgb = torch.randn(n, generator=gen), torch.randn(n, 3, generator=gen) * 0.1, torch.randn(n, 3, generator=gen)
-    # float64 specification
     d64 = lambda x: None if x is None else x.double()
-    sdf, grad, rgb = field.evaluate(d64(pts), d64(dirs).expand(n, 3), d64(bt), d64(tp))
-    loss = (sdf.reshape(n) * d64(g_sdf)).sum() + (grad * d64(g_grad)).sum() + (rgb * d64(g_rgb)).sum()
     names = [k for k in leaves if k != 'var.variance']
-    ref = dict(zip(names, torch.autograd.grad(loss, [leaves[k] for k in names])))
-    # the same statement in float32 (what the reference's autograd computes): its distance to float64 is the noise floor
     f32, leaves32 = trainable_field(kind, sd['sdf_' + kind], sd['color_' + kind], var)
-    s32, g32, c32 = f32.evaluate(pts, dirs.expand(n, 3), bt, tp)
-    loss32 = (s32.reshape(n) * g_sdf).sum() + (g32 * g_grad).sum() + (c32 * g_rgb).sum()
-    ref32 = dict(zip(names, torch.autograd.grad(loss32, [leaves32[k] for k in names])))
+
+    def references(pts):
+        # float64 specification
+        pts64 = d64(pts).requires_grad_(True)
+        sdf, grad, rgb = field.evaluate(pts64, d64(dirs_n), d64(bt), d64(tp))
+        loss = (sdf.reshape(n) * d64(g_sdf)).sum() + (grad * d64(g_grad)).sum() + (rgb * d64(g_rgb)).sum()
+        all_grads = torch.autograd.grad(loss, [leaves[k] for k in names] + [pts64], retain_graph=True)   # (the folded weights' graph is shared)
+        # the same statement in float32 (what the reference's autograd computes): its distance to float64 is the noise floor
+        pts32 = pts.clone().requires_grad_(True)
+        s32, g32, c32 = f32.evaluate(pts32, dirs_n, bt, tp)
+        loss32 = (s32.reshape(n) * g_sdf).sum() + (g32 * g_grad).sum() + (c32 * g_rgb).sum()
+        all32 = torch.autograd.grad(loss32, [leaves32[k] for k in names] + [pts32], retain_graph=True)
+        return dict(zip(names, all_grads[:-1])), all_grads[-1], dict(zip(names, all32[:-1])), all32[-1]
+    ref, ref_g_pts, ref32, ref32_g_pts = references(pts)
+    # Thousands of random points: a few sit on a kink of the colour network (a ReLU pre-activation within rounding of 0 takes one side in
+    # float32 and the other in float64, and that sample's gradient changes by O(1)).  Neither side is wrong and no implementation can be
+    # held to either there: such samples (the two oracles themselves disagree on them) are replaced by copies of a sample they agree on.
+    for _ in range(4):
+        if n <= 7:
+            break
+        off = (ref32_g_pts.double() - ref_g_pts).abs().amax(dim=1) > 1e-4 * ref_g_pts.abs().max()
+        if not bool(off.any()):
+            break
+        keep = int(torch.nonzero(~off)[0])
+        pts = torch.where(off[:, None], pts[keep][None, :], pts)
+        ref, ref_g_pts, ref32, ref32_g_pts = references(pts)
     # product
     pf = PackedField(kind, sd['sdf_' + kind], sd['color_' + kind], var)
     c = lambda x: None if x is None else x.float().contiguous().to(dev)
@@ -453,14 +473,18 @@ def test_field_param_bwd_matches_render_single_bwd_pieces(kind):
     bt_d = None if bt is None else c(bt).reshape(1, 21, 4, 4)
     tp_d = None if tp is None else c(tp).reshape(1, 21, 3)
     g_params = torch.zeros(lib.hn_field_param_floats(pf.handle), device=dev)
-    g_pts, g_dir = torch.empty(n, 3, device=dev), torch.empty(1, 3, device=dev)
+    g_pts, g_dir = torch.empty(n, 3, device=dev), torch.empty(n // spr, 3, device=dev)
     g_bt, g_tp = torch.zeros(1, 21, 4, 4, device=dev), torch.zeros(1, 21, 3, device=dev)
     need = lib.hn_field_bwd_workspace_bytes(pf.handle, n)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
-    L.check(lib.hn_field_param_bwd(pf.handle, L.ptr(p_d), L.ptr(d_d), n, n, L.ptr(bt_d), L.ptr(tp_d), 1, n, L.ptr(gs_d), L.ptr(gg_d),
+    L.check(lib.hn_field_param_bwd(pf.handle, L.ptr(p_d), L.ptr(d_d), n, spr, L.ptr(bt_d), L.ptr(tp_d), 1, n, L.ptr(gs_d), L.ptr(gg_d),
                                    L.ptr(gr_d), L.ptr(g_params), L.ptr(g_pts), L.ptr(g_dir), L.ptr(g_bt), L.ptr(g_tp), L.ptr(ws), need,
                                    L.stream_ptr()), 'hn_field_param_bwd')
     worst = 0.0
+    e, floor = rel_err(g_pts.double().cpu().numpy(), ref_g_pts.numpy()), rel_err(ref32_g_pts.double().numpy(), ref_g_pts.numpy())
+    bound = max(2e-5, min(4.0 * floor, 5e-3))
+    record('param_bwd %s n=%d g_pts (fp32 autograd vs fp64: %.1e)' % (kind, n, floor), e, bound)
+    assert e <= bound, 'g_pts: %.3e > %.1e (fp32 autograd is %.1e from fp64)' % (e, bound, floor)
     folded = training.folded_gradients(lib, pf, g_params)
     for i, (dW, db) in enumerate(folded):
         prefix, l = ('sdf', i) if i < 9 else ('color', i - 9)
@@ -471,7 +495,7 @@ def test_field_param_bwd_matches_render_single_bwd_pieces(kind):
             e = rel_err(got.numpy(), ref[key].numpy())
             floor = rel_err(ref32[key].double().numpy(), ref[key].numpy())
             bound = max(2e-5, min(4.0 * floor, 5e-3))
-            record('param_bwd %s %s (fp32 autograd vs fp64: %.1e)' % (kind, key, floor), e, bound)
+            record('param_bwd %s n=%d %s (fp32 autograd vs fp64: %.1e)' % (kind, n, key, floor), e, bound)
             assert e <= bound, '%s: %.3e > %.1e (fp32 autograd is %.1e from fp64)' % (key, e, bound, floor)
             worst = max(worst, e)
 
