@@ -183,6 +183,7 @@ struct OuterArgs {
     float* db;
     float alpha, alpha_b;
     int n, chunk;
+    int dbg;
 };
 __global__ __launch_bounds__(256) void k_outer(const OuterArgs a) {
     constexpr int T = 128;                         // workgroup tile of dW: T x T, one 64 x 64 quadrant per wave
@@ -238,9 +239,11 @@ __global__ __launch_bounds__(256) void k_outer(const OuterArgs a) {
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
-                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+                for (int y = 0; y < 2; ++y)
+                    if (!(a.dbg & 2) || ks == 0) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
         }
     }
+    if ((a.dbg & 1) && acc[0][0][0] != 12345.f) return;
 #pragma unroll
     for (int y = 0; y < 2; ++y) {
         const int c = k0 + wc * 64 + y * 32 + j;
@@ -256,6 +259,171 @@ __global__ __launch_bounds__(256) void k_outer(const OuterArgs a) {
                     else
                         atomicAdd(a.db + m, a.alpha_b * acc[x][y][r]);
                 }
+            }
+    }
+}
+// ---- the same outer products, GROUPED: every product of one backward pass in ONE launch, on the bf16 MFMA -------------------------------
+// A parameter-gradient pass forms ~20 .. 30 such products from arrays that all stand when the adjoint kernel has finished.  Launched one by
+// one (k_outer) each needs ~128 slices of the samples to fill the chip and pays 128 x M x K atomics for it (~0.5 ms of a 2.9 ms total on the
+// object field) plus a ramp and a tail per launch; together they are ~100 tiles of 128 x 128, so ~5 slices fill 512 workgroup slots and the
+// atomics drop 25-fold.  Work item = (product, m tile, k tile, slice), consecutive items = the tiles of one (product, slice), which share their
+// operand rows: the block index is mapped so that they run on ONE XCD (blocks b, b + 8, ... are neighbours there) and meet in its L2.
+// Arithmetic: fp32 operands split three ways into bf16 (x = h + m + l EXACTLY: 8 + 8 + 8 significant bits, round-to-nearest each, fp32's exponent range,
+// no scaling) and six v_mfma_f32_32x32x16_bf16 per tile pair (hh, hm, mh, mm, hl, lh: what is dropped is below 2^-23 of the product) -- 6 x 32
+// cycles per 32 x 32 x 16 block against 8 x 64 on v_mfma_f32_32x32x2_f32.  A lane's MFMA operand is 8 consecutive SAMPLES of one column: the
+// staging thread owns a column and 16 consecutive samples (row-coalesced dword loads, as k_outer), so the transposition costs nothing -- two
+// ds_write_b128 per part; LDS image [part][column][32 samples] at an 80-byte column pitch (conflict-free for the 8-lane groups of the stores
+// and the 16-lane groups of ds_read_b128).  Bias gradients: the staging threads of the first k tile sum their column on the way.
+// A desc may carry a SECOND operand pair accumulated into the same tile (dW_l = zb_l^T a_{l-1} + dz_l^T v_{l-1}: one set of atomics for both).
+struct OuterDesc {
+    const float *A, *B, *A2, *B2;
+    float *dW, *db;
+    int lda, ldb, lda2, ldb2, M, K, ldw, kt, item0, chunk;   // chunk: samples per slice of THIS product (a two-pair product gets twice the slices)
+    float alpha, alpha_b;
+};
+constexpr int OUTER_MAX_DESCS = 32;
+struct OuterGroupArgs {
+    OuterDesc d[OUTER_MAX_DESCS];
+    int n_desc, n, items, per_xcd, dbg;
+};
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int OG_T = 128, OG_PITCH = 80;                       // tile edge; bytes per column of one part's image (32 samples x 2 B + 16)
+constexpr int OG_PART = OG_T * OG_PITCH, OG_LDS = 6 * OG_PART;  // 61,440 B
+__global__ __launch_bounds__(256, 2) void k_outer_group(const OuterGroupArgs g) {
+    __shared__ __attribute__((aligned(16))) char lds[OG_LDS];
+    // block -> item: blocks b, b + 8, b + 16, ... share an XCD; item ids run along them
+    const int item = (blockIdx.x & 7) * g.per_xcd + (blockIdx.x >> 3);
+    if (item >= g.items) return;
+    int p = 0;
+    while (p + 1 < g.n_desc && g.d[p + 1].item0 <= item) ++p;
+    const OuterDesc& d = g.d[p];
+    const int local = item - d.item0;
+    const int mt_n = (d.M + OG_T - 1) / OG_T;
+    const int tiles = mt_n * d.kt;
+    const int slice = local / tiles, tile = local - slice * tiles;
+    const int mt = tile / d.kt, kt = tile - mt * d.kt;
+    const int m0 = mt * OG_T, k0 = kt * OG_T;
+    const int i_begin = slice * d.chunk, i_end = min(g.n, i_begin + d.chunk);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1, h = lane >> 5, j = lane & 31;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    // staging: thread = (column of the tile, 16 consecutive samples of the step's 32)
+    const int col = t & (OG_T - 1), s0 = (t >> 7) * 16;
+    const bool a_ok = m0 + col < d.M, b_ok = k0 + col < d.K;
+    const bool want_bias = d.db != nullptr && kt == 0;
+    float bsum = 0.f;
+    char* const wbase = lds + col * OG_PITCH + s0 * 2;                       // this thread's 32 bytes of a part: + part * OG_PART
+    const char* const ra = lds + (wr * 64 + j) * OG_PITCH + h * 16;          // A parts 0..2; + x * 32 columns, + ks * 32 bytes
+    const char* const rb = lds + 3 * OG_PART + (wc * 64 + j) * OG_PITCH + h * 16;
+    const int n_pairs = d.A2 != nullptr ? 2 : 1;
+    const int rows = i_end - i_begin;
+    for (int pair = 0; pair < n_pairs; ++pair) {
+        // The slice of each operand as a raw buffer that ends with the slice's last row: rows past i_end and (offset pushed out of range)
+        // columns past the matrix edge read as 0 without a predicate, and the row part of an address is wave-uniform arithmetic.
+        const int lda = pair == 0 ? d.lda : d.lda2, ldb = pair == 0 ? d.ldb : d.ldb2;
+        const float* A = pair == 0 ? d.A : d.A2;
+        const float* B = pair == 0 ? d.B : d.B2;
+        const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (size_t)i_begin * lda + m0), 0,
+                                                                             rows > 0 ? ((rows - 1) * lda + min(OG_T, d.M - m0)) * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(B != nullptr ? B + (size_t)i_begin * ldb + k0 : A), 0,
+            (rows > 0 && B != nullptr) ? ((rows - 1) * ldb + min(OG_T, d.K - k0)) * 4 : 0, 0x00020000);
+        const unsigned OUT = 0x80000000u;                                   // beyond any slice (launch(): a slice is < 2^31 bytes)
+        const unsigned voa = a_ok ? (unsigned)col * 4u : OUT, vob = b_ok ? (unsigned)col * 4u : OUT;
+        float va[16], vb[16];
+        auto fetch = [&](int i0) {                     // rows i0 + s0 .. + 15 of both operands, this thread's column
+            const unsigned ra0 = (unsigned)(i0 - i_begin + s0) * (unsigned)lda * 4u, rb0 = (unsigned)(i0 - i_begin + s0) * (unsigned)ldb * 4u;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                va[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra_, voa + ra0 + (unsigned)(e * lda * 4), 0, 0));
+                vb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_, vob + rb0 + (unsigned)(e * ldb * 4), 0, 0));
+            }
+        };
+        auto stage = [&](const float* v, char* w) {   // 16 floats -> h | m | l images (x = h + m + l exactly, each bf16 by RNE), 2 x 16 bytes each
+            unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x2 x = {v[2 * q], v[2 * q + 1]};
+                hh[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+                const f32x2 r = {x[0] - __uint_as_float(hh[q] << 16), x[1] - __uint_as_float(hh[q] & 0xffff0000u)};
+                mm[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+                const f32x2 r2 = {r[0] - __uint_as_float(mm[q] << 16), r[1] - __uint_as_float(mm[q] & 0xffff0000u)};
+                ll[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+            }
+            uint4* w0 = reinterpret_cast<uint4*>(w);
+            uint4* w1 = reinterpret_cast<uint4*>(w + OG_PART);
+            uint4* w2 = reinterpret_cast<uint4*>(w + 2 * OG_PART);
+            w0[0] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+            w0[1] = make_uint4(hh[4], hh[5], hh[6], hh[7]);
+            w1[0] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+            w1[1] = make_uint4(mm[4], mm[5], mm[6], mm[7]);
+            w2[0] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+            w2[1] = make_uint4(ll[4], ll[5], ll[6], ll[7]);
+        };
+        if (i_begin < i_end) fetch(i_begin);
+        for (int i0 = i_begin; i0 < i_end; i0 += 32) {
+            __syncthreads();                           // the previous step's MFMAs have read the images
+            if (!(g.dbg & 4) || i0 == i_begin) {
+                stage(va, wbase);
+                stage(vb, wbase + 3 * OG_PART);
+            } else if (va[3] == 12345.f || vb[5] == 12345.f) {
+                bsum += 1.f;
+            }
+            if (want_bias && pair == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bsum += va[e];
+            }
+            __syncthreads();
+            if (i0 + 32 < i_end) fetch(i0 + 32);       // the next step's reads are in flight under this step's MFMAs
+            if (d.K > 0 && !(g.dbg & 2)) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 A_[2][3], B_[2][3];
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int part = 0; part < 3; ++part)
+                            A_[x][part] = *reinterpret_cast<const bf16x8*>(ra + part * OG_PART + x * 32 * OG_PITCH + ks * 32);
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+#pragma unroll
+                        for (int part = 0; part < 3; ++part)
+                            B_[y][part] = *reinterpret_cast<const bf16x8*>(rb + part * OG_PART + y * 32 * OG_PITCH + ks * 32);
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) {   // small terms first
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[x][2], B_[y][0], acc[x][y], 0, 0, 0);
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[x][0], B_[y][2], acc[x][y], 0, 0, 0);
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[x][1], B_[y][1], acc[x][y], 0, 0, 0);
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[x][1], B_[y][0], acc[x][y], 0, 0, 0);
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[x][0], B_[y][1], acc[x][y], 0, 0, 0);
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[x][0], B_[y][0], acc[x][y], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+    if (want_bias && a_ok) atomicAdd(d.db + m0 + col, d.alpha_b * bsum);
+    if (d.K <= 0) return;
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const int c = k0 + wc * 64 + y * 32 + j;
+        if (c >= d.K) continue;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < d.M) atomicAdd(d.dW + (size_t)m * d.ldw + c, d.alpha * acc[x][y][r]);
             }
     }
 }
@@ -746,8 +914,65 @@ struct Ctx {
         int chunk = (n + slices - 1) / slices;
         chunk = (chunk + 31) & ~31;
         slices = (n + chunk - 1) / chunk;
-        OuterArgs a{A, lda, M, B, ldb, K, dW, ldw, db, alpha, 1.f, n, chunk};
+        static const int dbg = getenv("HN_DBG_OUTER") ? atoi(getenv("HN_DBG_OUTER")) : 0;
+        OuterArgs a{A, lda, M, B, ldb, K, dW, ldw, db, alpha, 1.f, n, chunk, dbg};
         hipLaunchKernelGGL(k_outer, dim3((KB + 127) / 128, (M + 127) / 128, slices), dim3(256), 0, s, a);
+    }
+};
+
+// The products of one backward pass, collected and launched together (k_outer_group)
+struct OuterGroup {
+    OuterGroupArgs g{};
+    int tiles = 0;
+    // dW[M, K] += alpha * A^T B over the samples (+ db[M] += alpha_b * sum A when db != NULL); K == 0: the column sums alone
+    OuterDesc& add(const float* A, int lda, int M, const float* B, int ldb, int K, float alpha, float* dW, int ldw, float* db, float alpha_b = 1.f) {
+        OuterDesc& d = g.d[g.n_desc++];
+        d = OuterDesc{A, B, nullptr, nullptr, dW, db, lda, ldb, 0, 0, M, K, ldw, K > 0 ? (K + OG_T - 1) / OG_T : 1, 0, 0, alpha, alpha_b};
+        tiles += ((M + OG_T - 1) / OG_T) * d.kt;
+        return d;
+    }
+    // ... + alpha * A2^T B2 into the same dW (same M, K)
+    void add2(const float* A, int lda, const float* B, int ldb, const float* A2, int lda2, const float* B2, int ldb2, int M, int K, float alpha,
+              float* dW, int ldw, float* db) {
+        OuterDesc& d = add(A, lda, M, B, ldb, K, alpha, dW, ldw, db);
+        d.A2 = A2;
+        d.lda2 = lda2;
+        d.B2 = B2;
+        d.ldb2 = ldb2;
+        tiles += ((M + OG_T - 1) / OG_T) * d.kt;   // twice the work per sample: counted twice, sliced twice as finely
+    }
+    bool full() const { return g.n_desc >= OUTER_MAX_DESCS; }
+    int launch(hipStream_t s, int n) {
+        if (g.n_desc == 0 || n <= 0) return HN_OK;
+        int cus = device_cus();
+        if (cus <= 0) cus = 256;
+        int slices = (2 * cus) / tiles;                 // one resident round: two workgroups per CU
+        const int max_slices = (n + 255) / 256;         // a slice at least 256 samples long
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+        int items = 0;
+        for (int p = 0; p < g.n_desc; ++p) {
+            OuterDesc& d = g.d[p];
+            int sl = d.A2 != nullptr ? 2 * slices : slices;
+            int chunk = (n + sl - 1) / sl;
+            // (the kernel addresses a slice of an operand as one raw buffer: its rows x pitch stay below 2^31 bytes)
+            const int max_ld = std::max(std::max(d.lda, d.ldb), std::max(d.lda2, d.ldb2));
+            const int max_chunk = (int)(((1u << 31) - 4096u) / (4u * (unsigned)std::max(max_ld, 1))) & ~31;
+            if (chunk > max_chunk) chunk = max_chunk;
+            chunk = (chunk + 31) & ~31;
+            sl = (n + chunk - 1) / chunk;
+            d.chunk = chunk;
+            d.item0 = items;
+            items += ((d.M + OG_T - 1) / OG_T) * d.kt * sl;
+        }
+        g.n = n;
+        g.items = items;
+        static const int dbg = getenv("HN_DBG_OUTER") ? atoi(getenv("HN_DBG_OUTER")) : 0;
+        g.dbg = dbg;
+        g.per_xcd = (items + 7) / 8;
+        hipLaunchKernelGGL(k_outer_group, dim3(g.per_xcd * 8), dim3(256), 0, s, g);
+        HN_LAUNCH_CHECK();
+        return HN_OK;
     }
 };
 
@@ -938,35 +1163,59 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
         hipLaunchKernelGGL(k_enc3_push<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, b.gb, b.GXb, DP);
         hipLaunchKernelGGL(k_scale1, g1(n), dim3(256), 0, s, g_sdf, inv_scale, b.z8b0, n);
         const int o_d = Din, o_f = Din + 27, o_g = o_f + H;
-        // 5. colour network
-        cx.outer(b.xb, 3, 3, S(CC + 3), H, H, 1.f, G(C[4]), f->col_ld[4], G(Cb[4]));
-        for (int l = 3; l >= 1; --l) cx.outer(S(CB + (3 - l)), H, H, S(CC + l - 1), H, H, 1.f, G(C[l]), f->col_ld[l], G(Cb[l]));
+        // 5.-7. the products, in one grouped launch (k_outer_group); HN_OUTER_GROUP=0: one k_outer launch each (A/B, cross-check)
+        static const bool grouped = [] {
+            const char* e = getenv("HN_OUTER_GROUP");
+            return !(e != nullptr && e[0] == '0');
+        }();
+        OuterGroup og;
+        auto prod = [&](const float* A, int lda, int M, const float* B, int ldb, int K, float alpha, float* dW, int ldw, float* db) {
+            if (grouped)
+                og.add(A, lda, M, B, ldb, K, alpha, dW, ldw, db);
+            else
+                cx.outer(A, lda, M, B, ldb, K, alpha, dW, ldw, db);
+        };
+        // dW += alpha (A^T B + A2^T B2): the first-order path's product (with the bias) and the reverse sweep's own use of the same matrix
+        auto prod2 = [&](const float* A, int lda, const float* B, int ldb, const float* A2, int lda2, const float* B2, int ldb2, int M, int K,
+                         float alpha, float* dW, int ldw, float* db) {
+            if (grouped) {
+                og.add2(A, lda, B, ldb, A2, lda2, B2, ldb2, M, K, alpha, dW, ldw, db);
+            } else {
+                cx.outer(A, lda, M, B, ldb, K, alpha, dW, ldw, db);
+                cx.outer(A2, lda2, M, B2, ldb2, K, alpha, dW, ldw, nullptr);
+            }
+        };
+        // colour network
+        prod(b.xb, 3, 3, S(CC + 3), H, H, 1.f, G(C[4]), f->col_ld[4], G(Cb[4]));
+        for (int l = 3; l >= 1; --l) prod(S(CB + (3 - l)), H, H, S(CC + l - 1), H, H, 1.f, G(C[l]), f->col_ld[l], G(Cb[l]));
         {
             const float* cb1 = S(CB + 3);
-            cx.outer(cb1, H, H, b.X, DP, Din, 1.f, G(C[0]), LC0, G(Cb[0]));
-            cx.outer(cb1, H, H, b.din, 27, 27, 1.f, G(C[0]) + o_d, LC0, nullptr);
-            cx.outer(cb1, H, H, b.feat, H, H, 1.f, G(C[0]) + o_f, LC0, nullptr);
-            cx.outer(cb1, H, H, b.gin, 27, 27, 1.f, G(C[0]) + o_g, LC0, nullptr);
+            prod(cb1, H, H, b.X, DP, Din, 1.f, G(C[0]), LC0, G(Cb[0]));
+            prod(cb1, H, H, b.din, 27, 27, 1.f, G(C[0]) + o_d, LC0, nullptr);
+            prod(cb1, H, H, b.feat, H, H, 1.f, G(C[0]) + o_f, LC0, nullptr);
+            prod(cb1, H, H, b.gin, 27, 27, 1.f, G(C[0]) + o_g, LC0, nullptr);
         }
-        // 6. the reverse sweep's own use of the matrices (the path through `.gradient()`)
-        cx.outer(S(DZ + 0), H, H, b.GXb, DP, Din, 1.f, G(W[0]), LW[0], nullptr);
-        cx.outer(S(DZ + 4), H, H, b.GXb, DP, Din, rs2, G(W[4]) + H4, LW[4], nullptr);
-        for (int l = 1; l <= 7; ++l) cx.outer(S(DZ + l), H, width(l), S(VV + l - 1), H, width(l - 1), l == 4 ? rs2 : 1.f, G(W[l]), LW[l], nullptr);
-        hipLaunchKernelGGL(k_colsum, dim3((n + 255) / 256), dim3(256), 0, s, S(VV + 7), n, H, H, inv_scale, G(W[8]));
-        // 7. the first-order path with the second-order sources
-        cx.outer(b.z8b0, 1, 1, S(AA + 7), H, H, 1.f, G(W[8]), LW[8], G(Bv[8]));
-        cx.outer(S(FB), H, H, S(AA + 7), H, H, 1.f, G(W[8]) + LW[8], LW[8], G(Bv[8]) + 1);
+        // W_8: row 0 <- g_sdf / scale (first-order) and the column sums of v_7 (the row seeds the reverse sweep); rows 1.. <- fb
+        prod(b.z8b0, 1, 1, S(AA + 7), H, H, 1.f, G(W[8]), LW[8], G(Bv[8]));
+        prod(S(FB), H, H, S(AA + 7), H, H, 1.f, G(W[8]) + LW[8], LW[8], G(Bv[8]) + 1);
+        if (grouped)
+            og.add(S(VV + 7), H, H, nullptr, 0, 0, 0.f, nullptr, 0, G(W[8]), inv_scale);
+        else
+            hipLaunchKernelGGL(k_colsum, dim3((n + 255) / 256), dim3(256), 0, s, S(VV + 7), n, H, H, inv_scale, G(W[8]));
+        // W_l, l = 7 .. 0: zb_l^T [its input] (first-order path with the second-order sources; bias) + dz_l^T [the forward-direction sweep's
+        // input of the layer] (the path through `.gradient()`)
         for (int l = 7; l >= 0; --l) {
-            const float* zb = S(ZB + l);
+            const float *zb = S(ZB + l), *dz = S(DZ + l);
             if (l == 4) {
-                cx.outer(zb, H, H, S(AA + 3), H, H4, rs2, G(W[4]), LW[4], G(Bv[4]));
-                cx.outer(zb, H, H, b.X, DP, Din, rs2, G(W[4]) + H4, LW[4], nullptr);
+                prod2(zb, H, S(AA + 3), H, dz, H, S(VV + 3), H, H, H4, rs2, G(W[4]), LW[4], G(Bv[4]));
+                prod2(zb, H, b.X, DP, dz, H, b.GXb, DP, H, Din, rs2, G(W[4]) + H4, LW[4], nullptr);
             } else if (l == 0) {
-                cx.outer(zb, H, H, b.X, DP, Din, 1.f, G(W[0]), LW[0], G(Bv[0]));
+                prod2(zb, H, b.X, DP, dz, H, b.GXb, DP, H, Din, 1.f, G(W[0]), LW[0], G(Bv[0]));
             } else {
-                cx.outer(zb, H, width(l), S(AA + l - 1), H, f->sdf_in[l], 1.f, G(W[l]), LW[l], G(Bv[l]));
+                prod2(zb, H, S(AA + l - 1), H, dz, H, S(VV + l - 1), H, width(l), f->sdf_in[l], 1.f, G(W[l]), LW[l], G(Bv[l]));
             }
         }
+        if (grouped) HN_TRY_RC(og.launch(s, n));
         HN_LAUNCH_CHECK();
         return HN_OK;
     }
