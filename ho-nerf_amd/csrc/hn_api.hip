@@ -1361,9 +1361,16 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
         HN_LAUNCH_CHECK();
         return HN_OK;
     };
-    // ... the same stages for the FUSED parameter-gradient path of an f16x3 object field (hn_field_bwd.hip): the taped evaluation's own
+    // ... the same stages for the FUSED parameter-gradient path of an f16x3 field (hn_field_bwd.hip): the taped evaluation's own
     // outputs instead of the generic tape's last-layer rows
     const bwd::MidHook2 mid2 = [&](const float* sdf_t, const float* grad_t, const float* rgb_t) -> int {
+        if (compact) {   // the compact rows' outputs -> dense per-sample arrays (dead samples: the far sample's values)
+            hipLaunchKernelGGL(k_hand_scatter, dim3((n + 255) / 256), dim3(256), 0, s, cr.pos, n, cr.n_dev, sdf_t, grad_t, rgb_t, sdf, grad_d, rgb);
+            HN_LAUNCH_CHECK();
+            sdf_t = sdf;
+            grad_t = grad_d;
+            rgb_t = rgb;
+        }
         HN_TRY(alpha(sdf_t, grad_t, rays_d, dists, n, S, f->inv_s, al, c, s));
         HN_TRY(composite1_bwd(al, c, rgb_t, g_color, g_wsum, n_rays, S, g_al, g_c, g_rgb, s));
         HN_TRY(alpha_bwd(sdf_t, grad_t, rays_d, dists, g_al, g_c, n, S, f->inv_s, gs, gg, gd, s));
@@ -1372,6 +1379,10 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
             HN_TRY(alpha_inv_s_bwd(sdf_t, grad_t, rays_d, dists, g_al, g_c, n, S, f->inv_s, g_inv_s, s));
         }
         hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs, gg, (const float*)nullptr, (const float*)nullptr, grad_t, g_eik, n);
+        if (compact) {   // dense upstream gradients -> the compact rows; the far sample's = the sums over the dead samples
+            hipLaunchKernelGGL(k_zero_slot, dim3(1), dim3(64), 0, s, cr.n_dev, gs_c, gg_c, gr_c);
+            hipLaunchKernelGGL(k_hand_gather_up_sum, dim3((n + 255) / 256), dim3(256), 0, s, cr.idx, cr.pos, n, cr.n_dev, gs, gg, g_rgb, gs_c, gg_c, gr_c);
+        }
         HN_LAUNCH_CHECK();
         return HN_OK;
     };
@@ -1386,7 +1397,7 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
         // (the hand's colour network ignores the view direction: d loss / d rays_d through it is exactly 0)
         HN_CHECK_HIP(hipMemsetAsync(gdir, 0, R3 * sizeof(float), s));
         HN_TRY(bwd::field_eval_bwd(f, cr.pts_c, rays_d, n_c, 1, bt_inv, T_pose, 1, n_c, gs_c, gg_c, gr_c, gp_c, nullptr, gbt, gtp, bws, bws_bytes, s,
-                                   nullptr, nullptr, nullptr, g_params, &mid));
+                                   nullptr, nullptr, nullptr, g_params, &mid, &mid2));
         hipLaunchKernelGGL(k_hand_scatter3, dim3((n + 255) / 256), dim3(256), 0, s, cr.pos, n, gp_c, gp);
         HN_LAUNCH_CHECK();
     } else {

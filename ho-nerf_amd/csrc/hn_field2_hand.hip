@@ -76,7 +76,16 @@ struct Hand2Args {
                            // frame boundary); k_pose_part_reduce adds a frame's rows in a fixed order that depends on that frame's own
                            // tiles only: the same bits in every run AND whatever other frames share the launch.  Atomics otherwise.
     const int* frame_seg;  // NULL, or the frame table of a frame-aligned compact list (hn_common.h: launch_frame_seg)
+    // MODE 5 (the adjoint from a tape that also leaves the PER-LAYER SIGNALS of the parameter gradients): HSG_COUNT row-major
+    // [n, 256] fp32 arrays `sig + k * sig_pitch` (enum below; the layout of hn_field2_obj.hip's), unscaled, and gb [n,3] (the adjoint of
+    // d sdf / d pts incl. the colour network's share: J gb is the forward-direction sweep's input)
+    float* sig;
+    size_t sig_pitch;      // floats between two signal arrays
+    float* gb_out;
 };
+//   HSG_CB + k: adjoint of colour layer (3 - k)'s pre-activation;  HSG_C + k: c_{k+1};  HSG_A + l: a_{l+1};  HSG_DZ + l: dz_l of the reverse
+//   sweep;  HSG_V + l: v_l = sigma'_l dzb_l (forward-direction sweep);  HSG_ZB + l: zb_l (second reverse sweep);  HSG_FB: the feature vector's adjoint
+enum { HSG_CB = 0, HSG_C = 4, HSG_A = 8, HSG_DZ = 16, HSG_V = 24, HSG_ZB = 32, HSG_FB = 40, HSG_COUNT = 41 };
 
 // stash slots of one wave (32 KiB each)
 enum {
@@ -383,11 +392,12 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
     using IP3 = std::integral_constant<int, 3>;
     constexpr bool FULL = MODE >= 1;
     constexpr bool ADJ = MODE >= 2;                    // the forward pass writes the tape
-    constexpr bool RUN_FWD = MODE != 4;
-    constexpr bool RUN_ADJ = MODE == 2 || MODE == 4;
+    constexpr bool RUN_FWD = MODE != 4 && MODE != 5;
+    constexpr bool RUN_ADJ = MODE == 2 || MODE == 4 || MODE == 5;   // 5: 4 + the per-layer signals of the parameter gradients (Hand2Args::sig)
+    [[maybe_unused]] constexpr bool PG = MODE == 5;
     constexpr bool PER_TILE = MODE >= 3;               // stash indexed by tile (kept across launches), not by workgroup
     constexpr int N_SLOTS = ADJ ? HAND2_SLOTS_ADJ : HAND2_SLOTS;
-    constexpr int FIRST_CHUNK = MODE == 4 ? HB_W4ROWS : HB_BONE;   // first chunk of a tile's program
+    constexpr int FIRST_CHUNK = MODE >= 4 ? HB_W4ROWS : HB_BONE;   // first chunk of a tile's program
     extern __shared__ __attribute__((aligned(16))) char lds[];
     f16_flush_mode();
     const int lane = threadIdx.x & 63;
@@ -398,7 +408,7 @@ __device__ __forceinline__ void field2_hand_body(const Hand2Args& a) {
 #define HN_ADJ_WB 0   // (A/B, round 4: write-back stores for the adjoint kernel's w_l tiles too, in the hope that the second reverse sweep
                       //  finds them in L2 / MALL: k_field2_hand<4> 0.933 -> 0.971 ms.  nt stays.)
 #endif
-    StashT<(MODE <= 1 || (HN_ADJ_WB && MODE == 4)) ? STASH_ST_AUX : STASH_AUX> sh;   // (evaluation kernels: write-back stores; taped / adjoint kernels: nt -- hn_mlp2.h)
+    StashT<(MODE <= 1 || (HN_ADJ_WB && MODE >= 4)) ? STASH_ST_AUX : STASH_AUX> sh;   // (evaluation kernels: write-back stores; taped / adjoint kernels: nt -- hn_mlp2.h)
     sh.init(a.scratch + ((size_t)blockIdx.x * WG_WAVES + wave) * N_SLOTS * SLOT_F4, N_SLOTS, lane);
     constexpr int FEAT = HS_FEAT * SLOT_BYTES;   // byte offset of the feature fragment blocks
     constexpr int LEFT = HS_LEFT * SLOT_BYTES;   // ... of the leftover values
@@ -1318,7 +1328,7 @@ size_t field2_hand_workspace_bytes(int n_pts, int n_cus) {
 }
 
 int launch_field2_hand_taped(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
-                             int pts_per_frame, float* sdf, float* grad, float* rgb, void* tape, size_t tape_bytes, hipStream_t stream);
+                             int pts_per_frame, float* sdf, float* grad, float* rgb, float* feat, void* tape, size_t tape_bytes, hipStream_t stream);
 
 // tape != NULL (full evaluation only): the evaluation keeps its tape there (field2_hand_tape_bytes) for a later
 // adjoint launch, instead of using the workspace (k_field2_hand<3>, compiled in hn_field2_hand_adj.hip)
@@ -1326,7 +1336,7 @@ int launch_field2_hand(const hn_field* f, const float* pts, int n_pts, const flo
                        int n_frames, int pts_per_frame, float* sdf, float* grad, float* rgb, float* feat, void* workspace,
                        size_t workspace_bytes, bool full, hipStream_t stream, void* tape = nullptr, size_t tape_bytes = 0) {
     if (full && tape != nullptr && n_pts > 0)
-        return launch_field2_hand_taped(f, pts, n_pts, bt_inv, T_pose, n_frames, pts_per_frame, sdf, grad, rgb, tape, tape_bytes, stream);
+        return launch_field2_hand_taped(f, pts, n_pts, bt_inv, T_pose, n_frames, pts_per_frame, sdf, grad, rgb, feat, tape, tape_bytes, stream);
     if (n_pts <= 0) return HN_OK;
     HN_REQUIRE(bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1,
                "hand field needs bt_inv / T_pose and frame sizes");
@@ -1383,6 +1393,8 @@ static size_t pose_part_bytes(int n_pts) {   // the rows of Hand2Args::pose_part
     if (n_tiles > (size_t)POSE_MAX_TILES) return 0;
     return ((n_tiles * WG_WAVES * POSE_FRAMES * N_BONES * 12 * sizeof(float)) + 255) & ~size_t(255);
 }
+int field2_hand_signal_arrays() { return HSG_COUNT; }
+size_t field2_hand_pose_rows_bytes(int n_pts) { return pose_part_bytes(n_pts); }
 size_t field2_hand_adj_workspace_bytes(int n_pts, int n_cus) {
     const int grid = hand2_grid(n_pts, n_cus);
     return (size_t)grid * WG_WAVES * HAND2_SLOTS_ADJ * SLOT_F4 * sizeof(float4) + pose_part_bytes(n_pts);
@@ -1396,7 +1408,7 @@ size_t field2_hand_tape_bytes(int n_pts) {
 
 // the full evaluation that keeps its tape (MODE 3)
 int launch_field2_hand_taped(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
-                             int pts_per_frame, float* sdf, float* grad, float* rgb, void* tape, size_t tape_bytes, hipStream_t stream) {
+                             int pts_per_frame, float* sdf, float* grad, float* rgb, float* feat, void* tape, size_t tape_bytes, hipStream_t stream) {
     HN_REQUIRE(bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1,
                "hand field needs bt_inv / T_pose and frame sizes");
     HN_REQUIRE(f->v2_full != nullptr, "field was not created with HN_PREC_F16X3");
@@ -1411,6 +1423,7 @@ int launch_field2_hand_taped(const hn_field* f, const float* pts, int n_pts, con
     a.sdf = sdf;
     a.grad = grad;
     a.rgb = rgb;
+    a.feat = feat;   // (NULL, or the feature vector [n, 256]: the parameter-gradient path pairs it with the colour network's first layer)
     int n_cus = device_cus();
     if (n_cus <= 0) n_cus = 256;
     static std::atomic<uint64_t> lds_tape{0};
@@ -1426,11 +1439,16 @@ int launch_field2_hand_taped(const hn_field* f, const float* pts, int n_pts, con
 int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
                            int pts_per_frame, const float* g_sdf, const float* g_grad, const float* g_rgb, float* g_pts,
                            float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes, hipStream_t stream,
-                           const void* tape = nullptr, const float* grad = nullptr, const float* rgb = nullptr) {
+                           const void* tape = nullptr, const float* grad = nullptr, const float* rgb = nullptr, float* sig = nullptr,
+                           size_t sig_pitch = 0, float* gb_out = nullptr) {
     if (n_pts <= 0) return HN_OK;
-    HN_REQUIRE(f->v2_adj != nullptr && f->v2_adjonly != nullptr, "field has no adjoint program");
+    HN_REQUIRE((tape != nullptr ? f->v2_adjonly : f->v2_adj) != nullptr, "field has no adjoint program");
     HN_REQUIRE(tape == nullptr || (grad != nullptr && rgb != nullptr), "the adjoint from a tape needs the evaluation's grad / rgb");
+    HN_REQUIRE(sig == nullptr || (tape != nullptr && gb_out != nullptr && sig_pitch >= (size_t)n_pts * 256), "the signal arrays belong to the adjoint from a tape");
     Hand2Args a{};
+    a.sig = sig;
+    a.sig_pitch = sig_pitch;
+    a.gb_out = gb_out;
     hand2_common_args(a, f, pts, n_pts, bt_inv, T_pose, n_frames, pts_per_frame, workspace);
     a.blob = reinterpret_cast<const char*>(f->v2_adj);
     a.blob_bytes = f->v2_adj_bytes;
@@ -1468,6 +1486,14 @@ int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const
         a.scratch = reinterpret_cast<float4*>(const_cast<void*>(tape));
         a.grad = const_cast<float*>(grad);   // read only in this mode
         a.rgb = const_cast<float*>(rgb);
+        if (sig != nullptr) {   // MODE 5: the same adjoint, leaving the per-layer signals of the parameter gradients
+            static std::atomic<uint64_t> lds_sig{0};
+            HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<5>), (int)HAND2_LDS, &lds_sig));
+            hipLaunchKernelGGL(k_field2_hand<5>, dim3(taped_grid(n_pts, n_cus)), dim3(256), HAND2_LDS, stream, a);
+            reduce_rows();
+            HN_LAUNCH_CHECK();
+            return HN_OK;
+        }
         static std::atomic<uint64_t> lds_adjonly{0};
         HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_field2_hand<4>), (int)HAND2_LDS, &lds_adjonly));
         hipLaunchKernelGGL(k_field2_hand<4>, dim3(taped_grid(n_pts, n_cus)), dim3(256), HAND2_LDS, stream, a);

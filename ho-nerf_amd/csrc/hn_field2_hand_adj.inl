@@ -18,6 +18,39 @@
         f32x16 v;   // stashed activation a_{l+1}: sigma'(z_l) = 1 - exp(-100 a)
         f32x16 x;   // dz_l (forward-direction sweep; kind 4 applies 100 / 256) or w_l (second reverse sweep)
     };
+    // MODE 5: tile t of a [neurons x samples] accumulator tile -> columns 32 t .. 32 t + 31 of this lane's sample row of signal array
+    // `arr` (register i of lane (h, j): neuron 8 (i / 4) + 4 h + (i % 4), sample j), times `scale` (powers of two: exact)
+    float sig_scale = 1.f;   // 1 / kappa once it is known (below)
+    [[maybe_unused]] auto sig = [&](int arr, int t, const f32x16& y, float scale) {
+        if constexpr (PG) {
+            if (valid) {
+                using f32x4 = float __attribute__((ext_vector_type(4)));
+                float* row = a.sig + (size_t)arr * a.sig_pitch + (size_t)n * 256 + 32 * t + 4 * h;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<f32x4*>(row + 8 * g4) = f32x4{y[4 * g4] * scale, y[4 * g4 + 1] * scale, y[4 * g4 + 2] * scale, y[4 * g4 + 3] * scale};
+            }
+        }
+    };
+    // to_regs, and the tile's value -> signal array `arr` (times 1 / kappa), the pre-data's tile -> `arr_pre` (as it is; < 0: none)
+    [[maybe_unused]] auto to_regs_sig = [&](h8(&oh)[16], h8(&ol)[16], int arr, int arr_pre) {
+        return [&oh, &ol, arr, arr_pre, &sig, &sig_scale, &park](auto T, EpiState& st, const auto& pd) {
+            constexpr int t = decltype(T)::value;
+            asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
+            oh[2 * t] = st.hi[0];
+            ol[2 * t] = st.lo[0];
+            oh[2 * t + 1] = st.hi[1];
+            ol[2 * t + 1] = st.lo[1];
+            park(oh[2 * t], ol[2 * t], oh[2 * t + 1], ol[2 * t + 1]);
+            if constexpr (PG) {
+                sig(arr, t, st.vec(), sig_scale);
+                if constexpr (!std::is_same_v<std::decay_t<decltype(pd)>, NoData>) {
+                    if (arr_pre >= 0) sig(arr_pre, t, pd.v, 1.f);
+                }
+            }
+            return NoData{};
+        };
+    };
     ws.stamp(10);   // (timing builds, tools/ts_report_adj.py: section starts 10 .. 15)
     // ---- seeds
     float gs = a.g_sdf[nn], gg[3], gr[3];
@@ -42,6 +75,7 @@
             inv_kappa = __builtin_bit_cast(float, e << 23);
         }
     }
+    sig_scale = inv_kappa;
     const float gsk = gs * kappa;
     float xb[3];
 #pragma unroll
@@ -65,11 +99,19 @@
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = c4[i] > 0.f ? fmaf(w0[i], xb[0], fmaf(w1[i], xb[1], w2[i] * xb[2])) : 0.f;
             split_tile(v, ah[2 * t], al[2 * t], ah[2 * t + 1], al[2 * t + 1]);
+            sig(HSG_CB + 0, t, v, sig_scale);
+            sig(HSG_C + 3, t, c4, 1.f);
         });
     }
+    if constexpr (PG) {
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, mask_of(HS_C + 2), PhMask{}, to_regs_sig(bh, bl, HSG_CB + 1, HSG_C + 2), no_store);   // C3^T -> cb3
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, mask_of(HS_C + 1), PhMask{}, to_regs_sig(ah, al, HSG_CB + 2, HSG_C + 1), no_store);   // C2^T -> cb2
+        run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, mask_of(HS_C + 0), PhMask{}, to_regs_sig(bh, bl, HSG_CB + 3, HSG_C + 0), no_store);   // C1^T -> cb1
+    } else {
     run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, mask_of(HS_C + 2), PhMask{}, to_regs(bh, bl), no_store);   // C3^T -> cb3
     run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, mask_of(HS_C + 1), PhMask{}, to_regs(ah, al), no_store);   // C2^T -> cb2
     run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, mask_of(HS_C + 0), PhMask{}, to_regs(bh, bl), no_store);   // C1^T -> cb1
+    }
     // ---- colour lin0^T, feature-vector rows -> fb (fragments, kept in the HS_FVEC slot for the W8 product)
     run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(
         ws, bh, bl, lane, h, no_pre, PhIdentity{},
@@ -77,6 +119,7 @@
             constexpr int t = decltype(T)::value;
             sh.frag_store(HS_FVEC * SLOT_BYTES, 2 * t, st.hi[0], st.lo[0]);
             sh.frag_store(HS_FVEC * SLOT_BYTES, 2 * t + 1, st.hi[1], st.lo[1]);
+            sig(HSG_FB, t, st.vec(), sig_scale);
             return NoData{};
         },
         no_store);
@@ -105,6 +148,12 @@
         gb[1] += h ? 0.f : Mg[13];
 #pragma unroll
         for (int c = 0; c < 3; ++c) gb[c] = fmaf(kappa, gg[c], half_sum(gb[c]));
+        if constexpr (PG) {
+            if (valid && h == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a.gb_out[3 * (size_t)n + c] = gb[c] * inv_kappa;
+            }
+        }
     }
     // the rows of an X-space adjoint that belong to the leftover block: 2 tiles; register 8 (u & 1) + jj of tile u >> 1
     // <-> bone 8 u + jj.  Parked per bone (one float per lane) for the bone loop that follows.
@@ -253,8 +302,13 @@
         };
     };
     auto fin4 = [&](h8(&oh)[16], h8(&ol)[16], int w_slot) {
-        return [&oh, &ol, w_slot, &sh, &park](auto T, EpiState& st, const auto&) {
+        return [&oh, &ol, w_slot, &sh, &park, &sig, &sig_scale](auto T, EpiState& st, const auto& pd) {
             constexpr int t = decltype(T)::value;
+            if constexpr (PG) {   // layer l = w_slot - HS_DZ: v_l, a_{l+1}, dz_l
+                sig(HSG_V + (w_slot - HS_DZ), t, st.vec(), sig_scale);
+                sig(HSG_A + (w_slot - HS_DZ), t, pd.v, 1.f);
+                sig(HSG_DZ + (w_slot - HS_DZ), t, pd.x, BWD_INV);
+            }
             asm volatile("" : "+v"(st.hi[0]), "+v"(st.lo[0]), "+v"(st.hi[1]), "+v"(st.lo[1]));
             oh[2 * t] = st.hi[0];
             ol[2 * t] = st.lo[0];
@@ -312,7 +366,12 @@
     run_layer_c<8, 16, 1, false, true, HB_HID, HB_HID>(ws, ah, al, lane, h, pre4(HS_A1 + 5, HS_DZ + 5), PhFwdDir{}, fin4(bh, bl, HS_DZ + 5), no_store);   // lin5
     run_layer_c<8, 16, 1, false, true, HB_HID, HB_HID>(ws, bh, bl, lane, h, pre4(HS_A1 + 6, HS_DZ + 6), PhFwdDir{}, fin4(ah, al, HS_DZ + 6), no_store);   // lin6
     run_layer_c<8, 16, 1, false, false, HB_HID, HB_HID>(ws, ah, al, lane, h, pre4(HS_A8, HS_DZ + 7), PhFwdDir{},                                       // lin7: only w_7
-                                      [&](auto T, EpiState& st, const auto&) {
+                                      [&](auto T, EpiState& st, const auto& pd) {
+                                          if constexpr (PG) {
+                                              sig(HSG_V + 7, decltype(T)::value, st.vec(), sig_scale);
+                                              sig(HSG_A + 7, decltype(T)::value, pd.v, 1.f);
+                                              sig(HSG_DZ + 7, decltype(T)::value, pd.x, BWD_INV);
+                                          }
                                           sh.tile_store(HS_DZ + 7, decltype(T)::value, st.wvec());
                                           return NoData{};
                                       },
@@ -338,9 +397,9 @@
             for (int i = 0; i < 16; ++i) o.x[i] = fmaf(gsk * w8[i], dsoftplus_from_act(o.v[i]), o.x[i]);   // + sigma'_7 g_sdf W8[0, :]
             return o;
         },
-        PhRev2{}, to_regs(ah, al), no_store);
-    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 6, HS_DZ + 6), PhRev2{}, to_regs(bh, bl), no_store);   // W7^T -> zb6
-    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, pre5(HS_A1 + 5, HS_DZ + 5), PhRev2{}, to_regs(ah, al), no_store);   // W6^T -> zb5
+        PhRev2{}, to_regs_sig(ah, al, HSG_ZB + 7, -1), no_store);
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 6, HS_DZ + 6), PhRev2{}, to_regs_sig(bh, bl, HSG_ZB + 6, -1), no_store);   // W7^T -> zb6
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, pre5(HS_A1 + 5, HS_DZ + 5), PhRev2{}, to_regs_sig(ah, al, HSG_ZB + 5, -1), no_store);   // W6^T -> zb5
     run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 4, HS_DZ + 4), PhRev2{},                               // W5^T -> zb4 (kept)
                                      [&](auto T, EpiState& st, const auto&) {
                                          constexpr int t = decltype(T)::value;
@@ -351,13 +410,14 @@
                                          bl[2 * t + 1] = st.lo[1];
                                          sh.frag_store(HS_ZB4 * SLOT_BYTES, 2 * t, st.hi[0], st.lo[0]);
                                          sh.frag_store(HS_ZB4 * SLOT_BYTES, 2 * t + 1, st.hi[1], st.lo[1]);
+                                         sig(HSG_ZB + 4, t, st.vec(), sig_scale);
                                          return NoData{};
                                      },
                                      no_store);
-    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, pre5(HS_A1 + 3, HS_DZ + 3), PhRev2{}, to_regs(ah, al), no_store);   // W4h^T -> zb3
-    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 2, HS_DZ + 2), PhRev2{}, to_regs(bh, bl), no_store);   // W3^T -> zb2
-    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, pre5(HS_A1 + 1, HS_DZ + 1), PhRev2{}, to_regs(ah, al), no_store);   // W2^T -> zb1
-    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 0, HS_DZ + 0), PhRev2{}, to_regs(bh, bl), no_store);   // W1^T -> zb0
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, pre5(HS_A1 + 3, HS_DZ + 3), PhRev2{}, to_regs_sig(ah, al, HSG_ZB + 3, -1), no_store);   // W4h^T -> zb3
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 2, HS_DZ + 2), PhRev2{}, to_regs_sig(bh, bl, HSG_ZB + 2, -1), no_store);   // W3^T -> zb2
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, bh, bl, lane, h, pre5(HS_A1 + 1, HS_DZ + 1), PhRev2{}, to_regs_sig(ah, al, HSG_ZB + 1, -1), no_store);   // W2^T -> zb1
+    run_layer_c<8, 16, 1, false, true, HB_BWD, HB_BWD>(ws, ah, al, lane, h, pre5(HS_A1 + 0, HS_DZ + 0), PhRev2{}, to_regs_sig(bh, bl, HSG_ZB + 0, -1), no_store);   // W1^T -> zb0
 
     ws.stamp(15);
     // ---- input map (pass B): X-adjoint rows W0^T zb0 + W4x^T zb4, leftover rows first, then bone by bone; per bone the
@@ -525,5 +585,21 @@
         a.g_pts[3 * n] = finite ? gp[0] : 0.f;
         a.g_pts[3 * n + 1] = finite ? gp[1] : 0.f;
         a.g_pts[3 * n + 2] = finite ? gp[2] : 0.f;
+    }
+    if constexpr (PG) {
+        // ... and from the parameter gradients: the rows this lane wrote into the signal arrays hold inf / NaN from the forward-direction
+        // sweep on (J gb left the fragments' range); one such row would turn every parameter gradient into NaN.  Zeros instead: the sample
+        // does not contribute (the fp32 launch sequence adds its huge finite share).
+        const bool finite = fabsf(gp[0]) <= 3.0e38f && fabsf(gp[1]) <= 3.0e38f && fabsf(gp[2]) <= 3.0e38f;
+        if (valid && !finite) {
+            using f32x4 = float __attribute__((ext_vector_type(4)));
+#pragma unroll 1
+            for (int arr = 0; arr < HSG_COUNT; ++arr) {
+                float* row = a.sig + (size_t)arr * a.sig_pitch + (size_t)n * 256 + 4 * h;
+#pragma unroll 1
+                for (int q = 0; q < 32; ++q) *reinterpret_cast<f32x4*>(row + 8 * q) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (h == 0) a.gb_out[3 * (size_t)n] = a.gb_out[3 * (size_t)n + 1] = a.gb_out[3 * (size_t)n + 2] = 0.f;
+        }
     }
 }

@@ -32,7 +32,13 @@ size_t field2_hand_adj_workspace_bytes(int n_pts, int n_cus);
 int launch_field2_hand_adj(const hn_field* f, const float* pts, int n_pts, const float* bt_inv, const float* T_pose, int n_frames,
                            int pts_per_frame, const float* g_sdf, const float* g_grad, const float* g_rgb, float* g_pts,
                            float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes, hipStream_t stream,
-                           const void* tape, const float* grad, const float* rgb);
+                           const void* tape, const float* grad, const float* rgb, float* sig = nullptr, size_t sig_pitch = 0,
+                           float* gb_out = nullptr);
+int launch_field2_hand(const hn_field*, const float*, int, const float*, const float*, int, int, float*, float*, float*, float*, void*, size_t, bool,
+                       hipStream_t, void* tape, size_t tape_bytes);
+size_t field2_hand_tape_bytes(int n_pts);
+int field2_hand_signal_arrays();
+size_t field2_hand_pose_rows_bytes(int n_pts);
 }
 namespace bwd {
 
@@ -1026,7 +1032,7 @@ __global__ void k_scale1(const float* __restrict__ x, float scale, float* __rest
     if (i < n) out[i] = x[i] * scale;
 }
 
-// HN_TRAIN_FUSED=0: the parameter gradients of an f16x3 object field through the generic launch sequence (A/B, cross-check)
+// HN_TRAIN_FUSED=0: the parameter gradients of an f16x3 field through the generic launch sequence (A/B, cross-check)
 static bool train_fused_enabled() {
     static const bool on = [] {
         const char* e = getenv("HN_TRAIN_FUSED");
@@ -1035,10 +1041,10 @@ static bool train_fused_enabled() {
     return on;
 }
 static bool fused_param_path(const hn_field* f) {
-    return train_fused_enabled() && f->kind == HN_FIELD_OBJ && f->precision == HN_PREC_F16X3 && f->v2_adjonly != nullptr &&
+    return train_fused_enabled() && f->precision == HN_PREC_F16X3 && f->v2_adjonly != nullptr &&
            f->v2_full != nullptr;   // (a field packed for training has no evaluation + adjoint program: v2_adj is not asked for)
 }
-// Buffers of the FUSED parameter-gradient path of an object field (round 5; SURVEY 8 f1, exp_runner.py:196-232): the taped f16x3
+// Buffers of the FUSED parameter-gradient path of an f16x3 field (round 5; SURVEY 8 f1, exp_runner.py:196-232): the taped f16x3
 // evaluation (k_field2_obj<3>) and the adjoint from its tape in the form that also leaves the per-layer signals (k_field2_obj<5>:
 // OSG_COUNT row-major [n, 256] arrays) replace the generic sequence's forward tape, its three sweeps and their element-wise launches
 // (54 k_dense + ~40 small launches); the outer products over the samples (k_outer) and the encodings' small kernels stay.
@@ -1047,15 +1053,17 @@ struct FusedBufs {
     size_t tape_bytes;
     float *sig, *sdf, *grad, *rgb, *feat, *gb, *X, *din, *gin, *xb, *GXb, *z8b0;
     size_t pitch;
+    void* rows;          // hand: the adjoint kernel's per-tile pose-gradient rows (k_pose_part_reduce)
+    size_t rows_bytes;
 };
 static void layout_fused(const hn_field* f, int n, Arena& ar, FusedBufs& b) {
     const size_t N = (size_t)n;
-    const int DP = (OBJ_IN + 3) & ~3;
-    (void)f;
-    b.tape_bytes = v2::field2_obj_tape_bytes(n);
+    const bool obj = f->kind == HN_FIELD_OBJ;
+    const int DP = ((obj ? OBJ_IN : HAND_IN) + 3) & ~3;
+    b.tape_bytes = obj ? v2::field2_obj_tape_bytes(n) : v2::field2_hand_tape_bytes(n);
     b.tape = ar.take((b.tape_bytes + 3) / 4);
     b.pitch = ((N * H + 63) / 64) * 64;
-    b.sig = ar.take(b.pitch * (size_t)v2::field2_obj_signal_arrays());
+    b.sig = ar.take(b.pitch * (size_t)(obj ? v2::field2_obj_signal_arrays() : v2::field2_hand_signal_arrays()));
     b.sdf = ar.take(N);
     b.grad = ar.take(N * 3);
     b.rgb = ar.take(N * 3);
@@ -1067,6 +1075,8 @@ static void layout_fused(const hn_field* f, int n, Arena& ar, FusedBufs& b) {
     b.xb = ar.take(N * 3);
     b.GXb = ar.take(N * DP);
     b.z8b0 = ar.take(N);
+    b.rows_bytes = obj ? 0 : v2::field2_hand_pose_rows_bytes(n);
+    b.rows = ar.take((b.rows_bytes + 3) / 4);
 }
 
 size_t field_bwd_workspace_bytes(const hn_field* f, int n) {
@@ -1117,7 +1127,7 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
     HN_REQUIRE(g_params == nullptr || !sdf_only, "parameter gradients need g_grad and g_rgb");
     HN_REQUIRE(mid == nullptr || g_params != nullptr, "the mid hook belongs to the parameter-gradient path");
     if (g_params != nullptr && fused_param_path(f) && (mid == nullptr || mid2 != nullptr)) {
-        // ---- FUSED parameter-gradient path (object field): taped evaluation -> [hook] -> adjoint from the tape that leaves the per-layer
+        // ---- FUSED parameter-gradient path: taped evaluation -> [hook] -> adjoint from the tape that leaves the per-layer
         //      signals -> the outer products over the samples.  Same gradient slots, same pairs as the generic sequence below.
         Arena ar{reinterpret_cast<char*>(workspace), 0, workspace_bytes};
         FusedBufs b;
@@ -1128,7 +1138,7 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
         }
         const Ctx cx{s, n};
         const size_t N = (size_t)n;
-        constexpr int Din = OBJ_IN, DP = (OBJ_IN + 3) & ~3;
+        const int Din = obj ? OBJ_IN : HAND_IN, DP = (Din + 3) & ~3;
         const int* LW = f->sdf_ld;
         const int LC0 = f->col_ld[0];
         const float rs2 = 0.70710678118654752f;
@@ -1142,27 +1152,45 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
         float* const gp = g_params;
         auto G = [&](const float* w) { return gp + (w - reinterpret_cast<const float*>(f->raw)); };
         auto S = [&](int k) { return b.sig + (size_t)k * b.pitch; };
-        enum { CB = 0, CC = 4, AA = 8, DZ = 16, VV = 24, ZB = 32, FB = 40 };   // OSG_* of hn_field2_obj.hip
-        HN_REQUIRE(v2::field2_obj_signal_arrays() == 41, "signal array layout changed");
+        enum { CB = 0, CC = 4, AA = 8, DZ = 16, VV = 24, ZB = 32, FB = 40 };   // OSG_* / HSG_* of hn_field2_obj.hip / hn_field2_hand.hip
+        HN_REQUIRE(v2::field2_obj_signal_arrays() == 41 && v2::field2_hand_signal_arrays() == 41, "signal array layout changed");
         // 1. the taped evaluation (sdf, d sdf / d pts, rgb, the feature vector); 2. the caller's stages between the outputs and their adjoints
-        HN_TRY_RC(v2::launch_field2_obj(f, pts, rays_d, n, spr, b.sdf, b.grad, b.rgb, b.feat, nullptr, 0, true, s, b.tape, b.tape_bytes));
+        if (obj)
+            HN_TRY_RC(v2::launch_field2_obj(f, pts, rays_d, n, spr, b.sdf, b.grad, b.rgb, b.feat, nullptr, 0, true, s, b.tape, b.tape_bytes));
+        else
+            HN_TRY_RC(v2::launch_field2_hand(f, pts, n, bt_inv, T_pose, n_frames, pts_per_frame, b.sdf, b.grad, b.rgb, b.feat, nullptr, 0, true, s, b.tape,
+                                             b.tape_bytes));
         if (mid2 != nullptr) {
             HN_LAUNCH_CHECK();
             const int rc = (*mid2)(b.sdf, b.grad, b.rgb);
             if (rc != HN_OK) return rc;
         }
         // 3. the adjoint from the tape, leaving the signals (its sig arrays are written for every valid sample; columns 193 .. 255 of the
-        //    193-wide layer-3 arrays are never read)
-        HN_TRY_RC(v2::launch_field2_obj_adj(f, pts, rays_d, n, spr, g_sdf, g_grad, g_rgb, g_pts, g_rays_d, nullptr, 0, s, b.tape, b.grad, b.rgb, b.sig,
-                                            b.pitch, b.gb));
-        // 4. what the outer products pair the signals with: the encodings, the colour seed, J gb, g_sdf / scale
-        hipLaunchKernelGGL(k_enc3<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.X, DP);
-        hipLaunchKernelGGL(k_enc3<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, rays_d, n, spr, b.din, 27);
+        //    object field's 193-wide layer-3 arrays are never read)
+        if (obj) {
+            HN_TRY_RC(v2::launch_field2_obj_adj(f, pts, rays_d, n, spr, g_sdf, g_grad, g_rgb, g_pts, g_rays_d, nullptr, 0, s, b.tape, b.grad, b.rgb, b.sig,
+                                                b.pitch, b.gb));
+        } else {
+            // (the hand's colour network ignores the view direction, utils/fields.py:222-240: its gradient is exactly 0; the pose gradients
+            //  accumulate into the caller's zeroed g_bt_inv / g_T_pose)
+            if (g_rays_d != nullptr) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n / spr) * 3 * sizeof(float), s));
+            HN_TRY_RC(v2::launch_field2_hand_adj(f, pts, n, bt_inv, T_pose, n_frames, pts_per_frame, g_sdf, g_grad, g_rgb, g_pts, g_bt_inv, g_T_pose, b.rows,
+                                                 b.rows_bytes, s, b.tape, b.grad, b.rgb, b.sig, b.pitch, b.gb));
+        }
+        // 4. what the outer products pair the signals with: the input features, the colour seed, J gb, g_sdf / scale
+        if (obj) {
+            hipLaunchKernelGGL(k_enc3<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, 1, b.X, DP);
+            hipLaunchKernelGGL(k_enc3<OBJ_DIR_FREQS>, g1(n), dim3(256), 0, s, rays_d, n, spr, b.din, 27);
+            hipLaunchKernelGGL(k_enc3_push<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, b.gb, b.GXb, DP);
+        } else {
+            hipLaunchKernelGGL(k_hand_feat, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.X, DP,
+                               (float*)nullptr, (float*)nullptr);
+            hipLaunchKernelGGL(k_hand_push, dim3((n + 63) / 64, N_BONES), dim3(64), 0, s, pts, n, pts_per_frame, n_frames, bt_inv, T_pose, b.gb, b.GXb, DP);
+        }
         hipLaunchKernelGGL(k_enc3<4>, g1(n), dim3(256), 0, s, b.grad, n, 1, b.gin, 27);
         hipLaunchKernelGGL(k_rgb_seed2, g1(N * 3), dim3(256), 0, s, b.rgb, g_rgb, b.xb, N * 3);
-        hipLaunchKernelGGL(k_enc3_push<PTS_FREQS>, g1(n), dim3(256), 0, s, pts, n, b.gb, b.GXb, DP);
         hipLaunchKernelGGL(k_scale1, g1(n), dim3(256), 0, s, g_sdf, inv_scale, b.z8b0, n);
-        const int o_d = Din, o_f = Din + 27, o_g = o_f + H;
+        const int o_d = Din, o_f = obj ? Din + 27 : Din, o_g = o_f + H;
         // 5.-7. the products, in one grouped launch (k_outer_group); HN_OUTER_GROUP=0: one k_outer launch each (A/B, cross-check)
         static const bool grouped = [] {
             const char* e = getenv("HN_OUTER_GROUP");
@@ -1191,7 +1219,7 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
         {
             const float* cb1 = S(CB + 3);
             prod(cb1, H, H, b.X, DP, Din, 1.f, G(C[0]), LC0, G(Cb[0]));
-            prod(cb1, H, H, b.din, 27, 27, 1.f, G(C[0]) + o_d, LC0, nullptr);
+            if (obj) prod(cb1, H, H, b.din, 27, 27, 1.f, G(C[0]) + o_d, LC0, nullptr);
             prod(cb1, H, H, b.feat, H, H, 1.f, G(C[0]) + o_f, LC0, nullptr);
             prod(cb1, H, H, b.gin, 27, 27, 1.f, G(C[0]) + o_g, LC0, nullptr);
         }

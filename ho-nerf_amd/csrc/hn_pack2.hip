@@ -499,11 +499,10 @@ int build_v2_streams(hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* col
     const auto t_begin = std::chrono::steady_clock::now();
     const bool eval16_ = f->kind == HN_FIELD_OBJ ? (HN_OBJ_EVAL_MFMA16 != 0) : (HN_HAND_EVAL_MFMA16 != 0);
     const int n_modes = eval16_ ? 5 : 4;
-    // HN_PACK_EVAL_ONLY (a training step's per-iteration re-pack): the sdf-only and evaluation programs, and for the object field the
-    // adjoint-from-a-tape program too (+ the taped evaluation's copy where it is a separate one) -- its parameter gradients come from the
-    // taped evaluation and that adjoint (hn_field_bwd.hip, fused parameter-gradient path).  Never the evaluation + adjoint program (mode 2).
-    const bool obj_train = f->kind == HN_FIELD_OBJ;
-    auto wanted = [&](int mode) { return !eval_only || mode < 2 || (obj_train && mode >= 3); };
+    // HN_PACK_EVAL_ONLY (a training step's per-iteration re-pack): the sdf-only and evaluation programs and the adjoint-from-a-tape program
+    // (+ the taped evaluation's copy where it is a separate one) -- the parameter gradients come from the taped evaluation and that
+    // adjoint (hn_field_bwd.hip, fused parameter-gradient path).  Never the evaluation + adjoint program (mode 2).
+    auto wanted = [&](int mode) { return !eval_only || mode != 2; };
     const int plan_dev = current_device();   // (a plan's arrays live on the device it was derived on)
     auto plan_key = [&](int mode) { return (long long)(plan_dev + 1) * 100000 + (long long)f->kind * 100 + mode * 10 + (eval16_ ? 1 : 0); };
     auto slot_of = [&](int mode, void*** dst, size_t** nb) {
