@@ -77,7 +77,7 @@ def test_field_kernels_wait_for_no_tape_load_in_front_of_their_mfmas(built_lib):
     """A static check of the built field kernels' ISA (tools/isa_early_waits.py): in no weight-chunk step may a vector load issued in
     that step be waited for before a quarter of the step's MFMAs have run -- that is a memory round trip in front of the matrix work
     (round 4 found one per step of the adjoint kernels' forward-direction sweep that way: a multiply placed right behind the tape
-    load).  Known and accepted: the 8 steps of the second reverse sweep's first layer in the adjoint modes (2, 4), whose `pre` adds
+    load).  Known and accepted: the 8 steps of the second reverse sweep's first layer in the adjoint modes (2, 4, 5), whose `pre` adds
     the W8-row term to the loaded tile."""
     import sys
     build = os.path.join(ROOT, 'ho-nerf_amd', 'csrc', 'build')
@@ -89,7 +89,7 @@ def test_field_kernels_wait_for_no_tape_load_in_front_of_their_mfmas(built_lib):
     seen = 0
     for o in objs:
         for name, (nseg, bad) in isa_early_waits.scan(o, 'k_field2').items():
-            adjoint = name.endswith('<2>') or name.endswith('<4>')
+            adjoint = name.endswith('<2>') or name.endswith('<4>') or name.endswith('<5>')
             assert len(bad) <= (9 if adjoint else 0), (name, bad)
             assert nseg > 50, (name, nseg)
             seen += 1
