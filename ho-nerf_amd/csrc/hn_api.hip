@@ -733,11 +733,43 @@ static void track_alloc(Arena& ar, Track& t, size_t n_rays, int S, int n_new) {
     t.pts = ar.f(n_rays * S * 3);
 }
 
+namespace bwd {
+bool param_path_is_fused(const hn_field* f);   // hn_field_bwd.hip
+}
+// What a training render keeps for its backward pass (hn_render_single_taped -> hn_render_single_bwd_taped): the tape of
+// the final evaluation of the n_rays x S samples (the compacted list's rows for a hand field with the far-field aggregation) and that
+// evaluation's outputs.  One caller-owned block: [tape | sdf | grad | rgb | feature vector], `rows` rows.
+struct SingleKeep {
+    void* tape;
+    size_t tape_bytes;
+    float *sdf, *grad, *rgb, *feat;
+    size_t total;
+    SingleKeep(const hn_field* f, size_t N, void* base) {
+        const size_t rows = (size_t)hand_cap(f->kind == HN_FIELD_HAND ? f : nullptr, N);
+        tape_bytes = (field_tape(f, (int)rows) + 255) & ~size_t(255);
+        char* p = reinterpret_cast<char*>(base);
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            void* q = p ? p + off : nullptr;
+            off += (bytes + 255) & ~size_t(255);
+            return q;
+        };
+        tape = take(tape_bytes);
+        sdf = reinterpret_cast<float*>(take(rows * sizeof(float)));
+        grad = reinterpret_cast<float*>(take(rows * 3 * sizeof(float)));
+        rgb = reinterpret_cast<float*>(take(rows * 3 * sizeof(float)));
+        feat = reinterpret_cast<float*>(take(rows * H * sizeof(float)));
+        total = off;
+    }
+};
+// a render whose backward pass takes the fused parameter-gradient path (f16x3 field packed with its tape programs) can keep its tape
+static bool single_keep_applies(const hn_field* f) { return f != nullptr && bwd::param_path_is_fused(f) && field_tape(f, 128) != 0; }
+
 static int render_single_impl(const hn_field* f, const float* rays_o, const float* rays_d, const float* t_rand,
                               int n_rays, double near, double far, int n_samples, int n_importance, int steps,
                               const float* bt_inv, const float* T_pose, float* color, float* cdf, float* weight_sum,
                               float* weight_max, float* gradient_error, float* z_vals, void* workspace,
-                              size_t workspace_bytes, hipStream_t s, size_t* need) {
+                              size_t workspace_bytes, hipStream_t s, size_t* need, void* keep_block = nullptr, size_t keep_bytes = 0) {
     HN_REQUIRE(n_samples >= 2 && n_importance >= 0 && n_rays >= 0, "bad sample counts");
     HN_REQUIRE(n_importance == 0 || (steps >= 1 && n_importance % steps == 0), "n_importance must divide into steps");
     const int S = n_samples + n_importance;
@@ -808,18 +840,32 @@ static int render_single_impl(const hn_field* f, const float* rays_o, const floa
         z_cur = za;
     }
     HN_TRY(sample_points(rays_o, rays_d, z_cur, n_rays, S, 1, sample_dist, t.pts, dists, s));
+    // keep_block (hn_render_single_taped): the final evaluation keeps its tape and leaves its outputs there, row for row what the
+    // backward pass's own taped evaluation of the same points would produce (the same kernel on the same list)
+    SingleKeep kp(f, N, keep_block);
+    if (keep_block != nullptr) {
+        HN_REQUIRE(single_keep_applies(f), "hn_render_single_taped: the field's backward pass does not take a tape (hn_render_single_tape_bytes is 0)");
+        HN_REQUIRE(keep_bytes >= kp.total, "hn_render_single_taped: tape block too small (%zu < %zu)", keep_bytes, kp.total);
+    }
     if (may_compact && hand_compaction(f, 1, N)) {
         CompactRec cr;
         cr.at(crec_ws, N);
         HN_TRY(compact_hand(cr, t.pts, (int)N, bt_inv, T_pose, 1, hand_ppf, s));
+        float *sdf_c = keep_block ? kp.sdf : cr.sdf_c, *grad_c = keep_block ? kp.grad : cr.grad_c, *rgb_c = keep_block ? kp.rgb : cr.rgb_c;
         set_launch_n_pts_dev(cr.n_dev);
         set_launch_orig_idx(cr.idx);
-        const int rc = field_eval(f, cr.pts_c, rays_d, (int)N + 1, S, bt_inv, T_pose, 1, hand_ppf, cr.sdf_c, cr.grad_c, cr.rgb_c, nullptr, fws, fws_bytes, s);
+        const int rc = field_eval(f, cr.pts_c, rays_d, (int)N + 1, S, bt_inv, T_pose, 1, hand_ppf, sdf_c, grad_c, rgb_c, keep_block ? kp.feat : nullptr, fws,
+                                  fws_bytes, s, keep_block ? kp.tape : nullptr, keep_block ? kp.tape_bytes : 0);
         set_launch_n_pts_dev(nullptr);
         set_launch_orig_idx(nullptr);
         HN_TRY(rc);
-        hipLaunchKernelGGL(k_hand_scatter, dim3(((int)N + 255) / 256), dim3(256), 0, s, cr.pos, (int)N, cr.n_dev, cr.sdf_c, cr.grad_c, cr.rgb_c, sdf, grad, rgb);
+        hipLaunchKernelGGL(k_hand_scatter, dim3(((int)N + 255) / 256), dim3(256), 0, s, cr.pos, (int)N, cr.n_dev, sdf_c, grad_c, rgb_c, sdf, grad, rgb);
         HN_LAUNCH_CHECK();
+    } else if (keep_block != nullptr) {
+        HN_TRY(field_eval(f, t.pts, rays_d, (int)N, S, bt_inv, T_pose, 1, hand_ppf, kp.sdf, kp.grad, kp.rgb, kp.feat, fws, fws_bytes, s, kp.tape, kp.tape_bytes));
+        sdf = kp.sdf;
+        grad = kp.grad;
+        rgb = kp.rgb;
     } else {
         HN_TRY(field_eval(f, t.pts, rays_d, (int)N, S, bt_inv, T_pose, 1, hand_ppf, sdf, grad, rgb, nullptr, fws, fws_bytes, s));
     }
@@ -1120,7 +1166,8 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
                    size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb,
-                   float* g_params = nullptr, const MidHook* mid = nullptr, const MidHook2* mid2 = nullptr);
+                   float* g_params = nullptr, const MidHook* mid = nullptr, const MidHook2* mid2 = nullptr, const float* sdf_t = nullptr,
+                   const float* feat_t = nullptr);
 }
 
 // Backward pass of the two-field render (what loss.backward() runs through NeuSRenderer_fitting.render in the fitting
@@ -1286,7 +1333,7 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
                                   const float* bt_inv, const float* T_pose, const float* z, const float* g_color,
                                   const float* g_wsum, const float* g_eik, float* g_params, float* g_inv_s, float* g_rays_o,
                                   float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace, size_t workspace_bytes,
-                                  hipStream_t s, size_t* need) {
+                                  hipStream_t s, size_t* need, const void* keep_block = nullptr, size_t keep_bytes = 0) {
     HN_REQUIRE(n_rays >= 0 && S >= 1, "bad sizes");
     const size_t N = (size_t)n_rays * S, R3 = (size_t)n_rays * 3;
     Arena ar(workspace, workspace_bytes);
@@ -1393,16 +1440,25 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
         HN_CHECK_HIP(hipMemsetAsync(gbt, 0, 21 * 16 * sizeof(float), s));
         HN_CHECK_HIP(hipMemsetAsync(gtp, 0, 21 * 3 * sizeof(float), s));
     }
+    // keep_block (hn_render_single_bwd_taped): the forward pass's tape and outputs stand in for the taped evaluation
+    const SingleKeep kp(f, N, const_cast<void*>(keep_block));
+    if (keep_block != nullptr) {
+        HN_REQUIRE(single_keep_applies(f), "hn_render_single_bwd_taped: the field's backward pass does not take a tape");
+        HN_REQUIRE(keep_bytes >= kp.total, "hn_render_single_bwd_taped: tape block too small (%zu < %zu)", keep_bytes, kp.total);
+    }
+    const void* k_tape = keep_block ? kp.tape : nullptr;
+    const float *k_sdf = keep_block ? kp.sdf : nullptr, *k_grad = keep_block ? kp.grad : nullptr, *k_rgb = keep_block ? kp.rgb : nullptr,
+                *k_feat = keep_block ? kp.feat : nullptr;
     if (compact) {
         // (the hand's colour network ignores the view direction: d loss / d rays_d through it is exactly 0)
         HN_CHECK_HIP(hipMemsetAsync(gdir, 0, R3 * sizeof(float), s));
         HN_TRY(bwd::field_eval_bwd(f, cr.pts_c, rays_d, n_c, 1, bt_inv, T_pose, 1, n_c, gs_c, gg_c, gr_c, gp_c, nullptr, gbt, gtp, bws, bws_bytes, s,
-                                   nullptr, nullptr, nullptr, g_params, &mid, &mid2));
+                                   k_tape, k_grad, k_rgb, g_params, &mid, &mid2, k_sdf, k_feat));
         hipLaunchKernelGGL(k_hand_scatter3, dim3((n + 255) / 256), dim3(256), 0, s, cr.pos, n, gp_c, gp);
         HN_LAUNCH_CHECK();
     } else {
-        HN_TRY(bwd::field_eval_bwd(f, pts, rays_d, n, S, bt_inv, T_pose, 1, n, gs, gg, g_rgb, gp, gdir, gbt, gtp, bws, bws_bytes, s, nullptr,
-                                   nullptr, nullptr, g_params, &mid, &mid2));
+        HN_TRY(bwd::field_eval_bwd(f, pts, rays_d, n, S, bt_inv, T_pose, 1, n, gs, gg, g_rgb, gp, gdir, gbt, gtp, bws, bws_bytes, s, k_tape,
+                                   k_grad, k_rgb, g_params, &mid, &mid2, k_sdf, k_feat));
     }
     HN_TRY(sample_points_bwd(z, gp, n_rays, S, 1, sample_dist, go, gdd, s));
     if (g_rays_o != nullptr) HN_CHECK_HIP(hipMemcpyAsync(g_rays_o, go, R3 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1608,6 +1664,21 @@ int hn_render_single_bwd(const hn_field* f, const float* rays_o, const float* ra
     return render_single_bwd_impl(f, rays_o, rays_d, n_rays, samples_per_ray, sample_dist, bt_inv, T_pose, z_vals, g_color,
                                   g_weight_sum, g_gradient_error, g_params, g_inv_s, g_rays_o, g_rays_d, g_bt_inv, g_T_pose, workspace,
                                   workspace_bytes, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+size_t hn_render_single_tape_bytes(const hn_field* f, int n_rays, int samples_per_ray) {
+    if (f == nullptr || n_rays <= 0 || samples_per_ray <= 0 || !single_keep_applies(f)) return 0;
+    return SingleKeep(f, (size_t)n_rays * samples_per_ray, nullptr).total;
+}
+int hn_render_single_bwd_taped(const hn_field* f, const float* rays_o, const float* rays_d, int n_rays, int samples_per_ray,
+                               float sample_dist, const float* bt_inv, const float* T_pose, const float* z_vals, const float* g_color,
+                               const float* g_weight_sum, const float* g_gradient_error, float* g_params, float* g_inv_s, float* g_rays_o,
+                               float* g_rays_d, float* g_bt_inv, float* g_T_pose, const void* tape, size_t tape_bytes, void* workspace,
+                               size_t workspace_bytes, hn_stream_t stream) {
+    HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");
+    HN_REQUIRE(tape != nullptr, "hn_render_single_bwd_taped: tape is NULL");
+    return render_single_bwd_impl(f, rays_o, rays_d, n_rays, samples_per_ray, sample_dist, bt_inv, T_pose, z_vals, g_color,
+                                  g_weight_sum, g_gradient_error, g_params, g_inv_s, g_rays_o, g_rays_d, g_bt_inv, g_T_pose, workspace,
+                                  workspace_bytes, reinterpret_cast<hipStream_t>(stream), nullptr, tape, tape_bytes);
 }
 float hn_field_inv_s(const hn_field* f) { return f ? f->inv_s : 0.f; }
 int hn_field_set_compaction(hn_field* f, int enabled) {
@@ -1823,6 +1894,18 @@ int hn_render_single(const hn_field* f, const float* rays_o, const float* rays_d
     return render_single_impl(f, rays_o, rays_d, t_rand, n_rays, near, far, n_samples, n_importance, up_sample_steps,
                               bt_inv, T_pose, color, cdf, weight_sum, weight_max, gradient_error, z_vals, workspace,
                               workspace_bytes, (hipStream_t)stream, nullptr);
+}
+
+int hn_render_single_taped(const hn_field* f, const float* rays_o, const float* rays_d, const float* t_rand, int n_rays,
+                           double near, double far, int n_samples, int n_importance, int up_sample_steps, const float* bt_inv,
+                           const float* T_pose, float* color, float* cdf, float* weight_sum, float* weight_max,
+                           float* gradient_error, float* z_vals, void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                           hn_stream_t stream) {
+    HN_REQUIRE(f != nullptr, "null field");
+    HN_REQUIRE(tape != nullptr, "hn_render_single_taped: tape is NULL");
+    return render_single_impl(f, rays_o, rays_d, t_rand, n_rays, near, far, n_samples, n_importance, up_sample_steps,
+                              bt_inv, T_pose, color, cdf, weight_sum, weight_max, gradient_error, z_vals, workspace,
+                              workspace_bytes, (hipStream_t)stream, nullptr, tape, tape_bytes);
 }
 
 size_t hn_render_dual_workspace_bytes(const hn_field* hand, const hn_field* obj, int n_rays, int n_samples,

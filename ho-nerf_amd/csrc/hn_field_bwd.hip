@@ -1040,6 +1040,9 @@ static bool train_fused_enabled() {
     }();
     return on;
 }
+static bool fused_param_path(const hn_field* f);
+// (hn_api.hip: whether a training render may keep its evaluation's tape for the backward pass)
+bool param_path_is_fused(const hn_field* f) { return fused_param_path(f); }
 static bool fused_param_path(const hn_field* f) {
     return train_fused_enabled() && f->precision == HN_PREC_F16X3 && f->v2_adjonly != nullptr &&
            f->v2_full != nullptr;   // (a field packed for training has no evaluation + adjoint program: v2_adj is not asked for)
@@ -1114,7 +1117,7 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
                    const float* T_pose, int n_frames, int pts_per_frame, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* g_pts, float* g_rays_d, float* g_bt_inv, float* g_T_pose, void* workspace,
                    size_t workspace_bytes, hipStream_t s, const void* tape, const float* grad, const float* rgb, float* g_params,
-                   const MidHook* mid, const MidHook2* mid2) {
+                   const MidHook* mid, const MidHook2* mid2, const float* sdf_t, const float* feat_t) {
     HN_REQUIRE(f != nullptr && f->raw != nullptr, "field has no folded weights");
     const bool obj = f->kind == HN_FIELD_OBJ;
     HN_REQUIRE(obj || (bt_inv != nullptr && T_pose != nullptr && n_frames >= 1 && pts_per_frame >= 1),
@@ -1154,12 +1157,21 @@ int field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, int
         auto S = [&](int k) { return b.sig + (size_t)k * b.pitch; };
         enum { CB = 0, CC = 4, AA = 8, DZ = 16, VV = 24, ZB = 32, FB = 40 };   // OSG_* / HSG_* of hn_field2_obj.hip / hn_field2_hand.hip
         HN_REQUIRE(v2::field2_obj_signal_arrays() == 41 && v2::field2_hand_signal_arrays() == 41, "signal array layout changed");
-        // 1. the taped evaluation (sdf, d sdf / d pts, rgb, the feature vector); 2. the caller's stages between the outputs and their adjoints
-        if (obj)
+        // 1. the taped evaluation (sdf, d sdf / d pts, rgb, the feature vector) -- or the one the caller kept from the forward pass
+        //    (hn_render_single_taped: tape + its four outputs); 2. the caller's stages between the outputs and their adjoints
+        if (tape != nullptr) {
+            HN_REQUIRE(grad != nullptr && rgb != nullptr && sdf_t != nullptr && feat_t != nullptr, "a kept tape comes with the evaluation's sdf / grad / rgb / feature vector");
+            b.tape = const_cast<void*>(tape);
+            b.sdf = const_cast<float*>(sdf_t);
+            b.grad = const_cast<float*>(grad);
+            b.rgb = const_cast<float*>(rgb);
+            b.feat = const_cast<float*>(feat_t);
+        } else if (obj) {
             HN_TRY_RC(v2::launch_field2_obj(f, pts, rays_d, n, spr, b.sdf, b.grad, b.rgb, b.feat, nullptr, 0, true, s, b.tape, b.tape_bytes));
-        else
+        } else {
             HN_TRY_RC(v2::launch_field2_hand(f, pts, n, bt_inv, T_pose, n_frames, pts_per_frame, b.sdf, b.grad, b.rgb, b.feat, nullptr, 0, true, s, b.tape,
                                              b.tape_bytes));
+        }
         if (mid2 != nullptr) {
             HN_LAUNCH_CHECK();
             const int rc = (*mid2)(b.sdf, b.grad, b.rgb);

@@ -25,7 +25,7 @@ PRECISIONS = {'fp32': HN_PREC_FP32, 'f16x3': HN_PREC_F16X3, 'f16': HN_PREC_F16}
 # 'fp32': the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32), 5x slower, kept as a second opinion
 DEFAULT_PRECISION = os.environ.get('HONERF_PRECISION', 'f16x3')
 HN_MAX_LAYERS = 9
-HN_VERSION = 115          # the include/honerf.h revision SIGNATURES below was written for
+HN_VERSION = 116          # the include/honerf.h revision SIGNATURES below was written for
 
 c_f = ctypes.c_void_p     # device float*
 c_i = ctypes.c_int
@@ -142,6 +142,11 @@ SIGNATURES = {
     'hn_render_single_bwd_workspace_bytes': (c_sz, [c_vp, c_i, c_i]),
     'hn_render_single_bwd': (c_i, [c_vp, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp,
                                    c_sz, c_vp]),
+    'hn_render_single_tape_bytes': (c_sz, [c_vp, c_i, c_i]),
+    'hn_render_single_taped': (c_i, [c_vp, c_f, c_f, c_f, c_i, c_db, c_db, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f,
+                                     c_f, c_f, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    'hn_render_single_bwd_taped': (c_i, [c_vp, c_f, c_f, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp,
+                                         c_sz, c_vp, c_sz, c_vp]),
     'hn_render_dual': (c_i, [c_vp, c_vp, c_f, c_f, c_f, c_i, c_i, c_db, c_db, c_i, c_i, c_i, c_f, c_f, c_f, c_f,
                              c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_sz, c_vp, c_sz, c_i, c_vp]),
     'hn_side_stream': (c_i, [ctypes.POINTER(c_vp)]),

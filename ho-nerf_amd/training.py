@@ -68,6 +68,9 @@ def weight_norm_backward(g, v, dW):
     return proj, (g / nrm) * (dW - vh * proj)
 
 
+KEEP_TAPE = os.environ.get('HONERF_TRAIN_KEEP_TAPE', '1') != '0'   # the training render keeps its evaluation's tape for the backward pass
+
+
 class SingleRenderFn(torch.autograd.Function):
     """(rays_o [B,3], rays_d [B,3] in the FIELD's frame, bt_inv [21,4,4] | None, T_pose [21,3] | None, *parameters) ->
     (color_fine [B,3], weight_sum [B,1], gradient_error [], cdf_fine [B,S], weight_max [B,1]); the last two carry no
@@ -83,6 +86,7 @@ class SingleRenderFn(torch.autograd.Function):
         B = ro.shape[0]
         S = renderer.n_samples + renderer.n_importance
         hand = f.kind == 'hand'
+        tape = None
         bt = L.f32(bt_inv, dev).reshape(1, 21, 4, 4) if hand else None
         tp = L.f32(T_pose, dev).reshape(1, 21, 3) if hand else None
         sample_dist = float(torch.tensor((float(far) - float(near)) / renderer.n_samples, dtype=torch.float32))
@@ -101,14 +105,26 @@ class SingleRenderFn(torch.autograd.Function):
             gerr, z = torch.empty(1, device=dev), torch.empty(B, S, device=dev)
             need = lib.hn_render_single_workspace_bytes(f.handle, B, renderer.n_samples, renderer.n_importance)
             ws = renderer._ws.get(need, dev)
-            L.check(lib.hn_render_single(f.handle, L.ptr(ro), L.ptr(rd), L.ptr(tr), B, float(near), float(far), renderer.n_samples,
-                                         renderer.n_importance, renderer.up_sample_steps, L.ptr(bt), L.ptr(tp), L.ptr(color),
-                                         L.ptr(cdf), L.ptr(wsum), L.ptr(wmax), L.ptr(gerr), L.ptr(z), L.ptr(ws), ws.numel(),
-                                         L.stream_ptr()), 'hn_render_single')
+            # The final evaluation keeps its tape for the backward pass where that pass takes one (an f16x3 field packed with its tape
+            # programs: hn_render_single_tape_bytes > 0) -- the backward pass then does not evaluate the field a second time.
+            # KEEP_TAPE = False: the plain pair (the same numbers to the bit; tests, A/B).
+            tape_bytes = lib.hn_render_single_tape_bytes(f.handle, B, S) if (KEEP_TAPE and B > 0 and any(ctx.needs_input_grad)) else 0
+            if tape_bytes:
+                tape = torch.empty(tape_bytes, dtype=torch.uint8, device=dev)
+                L.check(lib.hn_render_single_taped(f.handle, L.ptr(ro), L.ptr(rd), L.ptr(tr), B, float(near), float(far), renderer.n_samples,
+                                                   renderer.n_importance, renderer.up_sample_steps, L.ptr(bt), L.ptr(tp), L.ptr(color),
+                                                   L.ptr(cdf), L.ptr(wsum), L.ptr(wmax), L.ptr(gerr), L.ptr(z), L.ptr(tape), tape_bytes, L.ptr(ws),
+                                                   ws.numel(), L.stream_ptr()), 'hn_render_single_taped')
+            else:
+                L.check(lib.hn_render_single(f.handle, L.ptr(ro), L.ptr(rd), L.ptr(tr), B, float(near), float(far), renderer.n_samples,
+                                             renderer.n_importance, renderer.up_sample_steps, L.ptr(bt), L.ptr(tp), L.ptr(color),
+                                             L.ptr(cdf), L.ptr(wsum), L.ptr(wmax), L.ptr(gerr), L.ptr(z), L.ptr(ws), ws.numel(),
+                                             L.stream_ptr()), 'hn_render_single')
         renderer.last_z_vals = z
         ctx.renderer, ctx.field, ctx.S = renderer, f, S
         ctx.sample_dist = sample_dist
         ctx.n_params = len(params)
+        ctx.tape = tape                # (a plain attribute: the block is this call's own, nothing else reads or versions it)
         ctx.save_for_backward(ro, rd, z, *([bt, tp] if hand else []))
         ctx.mark_non_differentiable(cdf, wmax)
         return color, wsum, gerr.reshape(()), cdf, wmax
@@ -140,9 +156,17 @@ class SingleRenderFn(torch.autograd.Function):
             from .renderer import _Workspace
             ren._ws_train = _Workspace()
         ws = ren._ws_train.get(need, dev)
-        L.check(lib.hn_render_single_bwd(f.handle, L.ptr(ro), L.ptr(rd), B, S, ctx.sample_dist, L.ptr(bt), L.ptr(tp), L.ptr(z), L.ptr(gc),
-                                         L.ptr(gw), L.ptr(ge), L.ptr(g_params), L.ptr(g_inv_s), L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_bt),
-                                         L.ptr(g_tp), L.ptr(ws), need, L.stream_ptr()), 'hn_render_single_bwd')
+        tape = getattr(ctx, 'tape', None)
+        if tape is not None:
+            L.check(lib.hn_render_single_bwd_taped(f.handle, L.ptr(ro), L.ptr(rd), B, S, ctx.sample_dist, L.ptr(bt), L.ptr(tp), L.ptr(z), L.ptr(gc),
+                                                   L.ptr(gw), L.ptr(ge), L.ptr(g_params), L.ptr(g_inv_s), L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_bt),
+                                                   L.ptr(g_tp), L.ptr(tape), tape.numel(), L.ptr(ws), need, L.stream_ptr()), 'hn_render_single_bwd_taped')
+            ctx.tape = None            # (a second backward through the same graph -- retain_graph -- would need it: not offered, as the
+            del tape                   #  reference's training loop does not; the block goes back to the allocator here)
+        else:
+            L.check(lib.hn_render_single_bwd(f.handle, L.ptr(ro), L.ptr(rd), B, S, ctx.sample_dist, L.ptr(bt), L.ptr(tp), L.ptr(z), L.ptr(gc),
+                                             L.ptr(gw), L.ptr(ge), L.ptr(g_params), L.ptr(g_inv_s), L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_bt),
+                                             L.ptr(g_tp), L.ptr(ws), need, L.stream_ptr()), 'hn_render_single_bwd')
         # weight-norm chain rule of all 14 layers: one C-ABI call (hn_weight_norm_bwd), outputs in the parameter order of
         # trainable_parameters()
         from .nets import _mlp_desc

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 115 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 116 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -587,6 +587,25 @@ int hn_render_single_bwd(const hn_field* f, const float* rays_o, const float* ra
                          const float* g_color, const float* g_weight_sum, const float* g_gradient_error, float* g_params,
                          float* g_inv_s, float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose,
                          void* workspace, size_t workspace_bytes, hn_stream_t stream);
+/* The same pair with the evaluation's tape kept between the passes (a training iteration: exp_runner.py:196-232 renders, then calls
+ * loss.backward()).  hn_render_single_taped = hn_render_single whose final evaluation of the n_rays x (n_samples + n_importance) samples
+ * keeps its tape and outputs in the caller's block `tape` (hn_render_single_tape_bytes bytes; 0: this field's backward pass takes
+ * no tape -- not HN_PREC_F16X3, or packed without its tape programs -- use the plain pair); hn_render_single_bwd_taped =
+ * hn_render_single_bwd that reads that block instead of evaluating the field again.  The gradients are those of the plain pair (whose
+ * backward pass runs the same taped evaluation itself; float atomics aside); the render outputs equal hn_render_single's to the bit for
+ * an object field and to fp32 rounding for a hand field (its taped kernel contracts d sdf / d pts through the per-bone sums the
+ * adjoint needs again: the same sums in another order).  The block must be the one the forward call of the SAME rays, poses,
+ * weights and compaction setting filled. */
+size_t hn_render_single_tape_bytes(const hn_field* f, int n_rays, int samples_per_ray);
+int hn_render_single_taped(const hn_field* f, const float* rays_o, const float* rays_d, const float* t_rand, int n_rays, double near,
+                           double far, int n_samples, int n_importance, int up_sample_steps, const float* bt_inv, const float* T_pose,
+                           float* color, float* cdf, float* weight_sum, float* weight_max, float* gradient_error, float* z_vals,
+                           void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, hn_stream_t stream);
+int hn_render_single_bwd_taped(const hn_field* f, const float* rays_o, const float* rays_d, int n_rays, int samples_per_ray,
+                               float sample_dist, const float* bt_inv, const float* T_pose, const float* z_vals, const float* g_color,
+                               const float* g_weight_sum, const float* g_gradient_error, float* g_params, float* g_inv_s,
+                               float* g_rays_o, float* g_rays_d, float* g_bt_inv, float* g_T_pose, const void* tape, size_t tape_bytes,
+                               void* workspace, size_t workspace_bytes, hn_stream_t stream);
 
 #ifdef __cplusplus
 }
