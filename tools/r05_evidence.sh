@@ -17,6 +17,16 @@ timeout 400 bash tools/profile_fit_video_timeline.sh r05 > $O/profile_fitv.log 2
 cd $GRAFT_REPO_ROOT
 cp gpurun_out/prof_r05/pmc_summary.json $O/pmc_bench_field2_hand_full_r05.json
 mkdir -p profiles/r05 && cp $O/pmc_bench_field2_hand_full_r05.json profiles/r05/      # (bench.py quotes roofline.traffic from it when the source hash matches)
+# the training iteration: kernel stats per field kind, the fused parameter-gradient path beside the generic sequence
+timeout 400 bash tools/profile_train.sh r05_obj obj > $O/profile_train_obj.log 2>&1
+timeout 400 bash tools/profile_train.sh r05_hand hand > $O/profile_train_hand.log 2>&1
+cp gpurun_out/prof_train_r05_obj/kernel_stats.csv $O/train_step_obj_kernel_stats.csv
+cp gpurun_out/prof_train_r05_hand/kernel_stats.csv $O/train_step_hand_kernel_stats.csv
+(timeout 300 python tools/train_fused_ab.py 56448 obj 2>&1 | grep -v amdgpu > $O/train_fused_ab_obj.txt)
+(timeout 300 python tools/train_fused_ab.py 56448 hand 2>&1 | grep -v amdgpu > $O/train_fused_ab_hand.txt)
+(timeout 300 python tools/train_grad_ab.py obj 0 2>&1 | grep -v "amdgpu\|UserWarning\|Consider\|np.savez" > $O/train_grad_ab_obj.txt)
+(timeout 300 python tools/train_grad_ab.py hand 1 2>&1 | grep -v "amdgpu\|UserWarning\|Consider\|np.savez" > $O/train_grad_ab_hand.txt)
+(for d in 0 2 4 6; do echo "HN_DBG_OUTER=$d (2: no MFMAs, 4: no splits / LDS stores after the first step; results wrong, timing only)"; HN_DBG_OUTER=$d timeout 200 python tools/train_fused_ab.py 56448 obj 2>&1 | grep "^n ="; done > $O/outer_group_parts.txt)
 timeout 300 python tools/scan_bench.py $O/scan_kernels_hbm.json > $O/scan_kernels.log 2>&1
 timeout 600 python tools/secondary_bench.py $O/secondary_bench.json > $O/secondary_bench.log 2>&1
 # the sequence loop's reproducibility: as shipped (Jacobian launch behind the stable term), and with the round-4 order

@@ -106,17 +106,21 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3', compac
     from honerf_amd import synth as _synth
     macs = lambda k: sum(o * i for o, i in _synth.layer_shapes(k, 256))
     p_sdf, p_col = macs('sdf_' + kind), macs('color_' + kind)
-    flop_sweeps = 2.0 * (4 * p_sdf + 2 * p_col) * n_rays * S
+    fused = precision == 'f16x3' and os.environ.get('HN_TRAIN_FUSED', '1') != '0'
+    kept_tape = fused and training.KEEP_TAPE
+    # (with the tape kept by the forward pass the backward pass holds the adjoint's two sweeps and the colour network's backward only: the
+    #  taped evaluation -- tape sweep, reverse sweep, colour forward -- is the render's own final evaluation)
+    flop_sweeps = 2.0 * ((2 * p_sdf + p_col) if kept_tape else (4 * p_sdf + 2 * p_col)) * n_rays * S
     flop_outer = 2.0 * (2 * p_sdf + p_col) * n_rays * S
     flop = flop_sweeps + flop_outer
     bwd_s = parts['backward'] / steps * 1e-3
-    fused = precision == 'f16x3' and os.environ.get('HN_TRAIN_FUSED', '1') != '0'
     if fused:
         # the pipes actually used: the sweeps in the fused f16x3 kernels (three fp16 MFMA passes per product: 2500 / 3 dense TFLOP/s of
         # fp32-equivalent work), the outer products in k_outer_group (six bf16 passes: 2500 / 6)
         peak = flop / (flop_sweeps / (2500.0 / 3) + flop_outer / (2500.0 / 6))
-        what = ('backward pass: taped evaluation + adjoint with the per-layer signals (k_field2_*<3>, <5>: f16x3, 3 MFMA passes) and the grouped '
-                'outer products (k_outer_group: bf16, 6 passes); peak = the flop-weighted harmonic mean of 2500/3 and 2500/6 TFLOP/s')
+        what = ('backward pass: %sadjoint with the per-layer signals (k_field2_*<5>: f16x3, 3 MFMA passes) and the grouped outer products '
+                '(k_outer_group: bf16, 6 passes); peak = the flop-weighted harmonic mean of 2500/3 and 2500/6 TFLOP/s' % (
+                    '' if kept_tape else 'taped evaluation (k_field2_*<3>) + '))
     else:
         peak, what = 157.3, 'backward pass: launch sequence on v_mfma_f32_32x32x2_f32 (k_dense, k_outer)'
     roof = {'bound': 'mfma', 'what': what, 'flop_per_step': flop, 'achieved': flop / bwd_s / 1e12, 'peak': round(peak, 1), 'unit': 'TFLOP/s',
