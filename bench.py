@@ -282,7 +282,9 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
     C5 `fit_sequence_video`: the same C5_FRAMES-frame sequence, `outer_iters` passes over its 29 windows, window-parallel with
     the pose-gradient all-reduce per step.  (`video_1234_weak`: the round-3 variant, 3 + windows_per_rank x world frames.)"""
     from honerf_amd import fitting as F
+    from honerf_amd import lib as _L
     res = {}
+    _L.dropped_samples(reset=True)
 
     def wall(fn):
         torch.cuda.synchronize()
@@ -413,6 +415,9 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
                                      % (n_c5, n_c5 - 3))
     res['video_1234_weak'] = run_sequence(data_num, 1 if quick else outer_iters,
                                           'secondary (round 3\'s workload): a %d-frame sequence = %d windows per rank and pass' % (data_num, windows_per_rank))
+    # samples the hand adjoint dropped over ALL fitting legs of this rank (out of the fp16 fragments' range next to a bone's origin: g_pts = 0,
+    # no share in the pose gradients; hn_dropped_samples) -- 0 on these scenes means no step's gradient was touched by the rule
+    res['dropped_samples'] = _L.dropped_samples()
     return res, single
 
 

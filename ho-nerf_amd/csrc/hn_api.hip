@@ -96,6 +96,7 @@ int launch_field2_hand(const hn_field*, const float*, int, const float*, const f
                        float*, void*, size_t, bool, hipStream_t, void* tape, size_t tape_bytes);
 size_t field2_obj_tape_bytes(int n_pts);
 size_t field2_hand_tape_bytes(int n_pts);
+int hand_dropped_samples(unsigned long long* n, bool reset);
 }
 
 constexpr int MAX_DEVICES = 64;
@@ -1589,6 +1590,7 @@ int hn_debug_pace_phantom(int members) {
     hn::g_pace_phantom.store(members < 0 ? 0 : members);
     return HN_OK;
 }
+int hn_dropped_samples(unsigned long long* count, int reset) { return hn::v2::hand_dropped_samples(count, reset != 0); }
 const char* hn_last_error(void) { return g_err; }
 int hn_device_cus(void) { return device_cus(); }
 

@@ -42,6 +42,10 @@ namespace v2 {
 __constant__ float c_cutoff2[N_BONES] = {0.08f, 0.03f, 0.03f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f,
                                          0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f, 0.03f, 0.02f, 0.02f, 0.02f};
 constexpr float TAU2 = 200.f;
+// Samples the adjoint DROPPED (g_pts = 0, no share in the pose gradients, zero rows in the parameter-gradient signals) because their
+// adjoint quantities left the fp16 fragments' range -- within ~2 mm of a bone's origin, hn_field2_hand_adj.inl.  Counted per device since
+// the library was loaded (hn_dropped_samples).  Only the adjoint translation unit's copy is ever written or read.
+static __device__ unsigned long long g_hn_dropped_samples = 0ull;
 
 struct Hand2Args {
     const float* pts;      // [n,3]
@@ -1394,6 +1398,16 @@ static size_t pose_part_bytes(int n_pts) {   // the rows of Hand2Args::pose_part
     return ((n_tiles * WG_WAVES * POSE_FRAMES * N_BONES * 12 * sizeof(float)) + 255) & ~size_t(255);
 }
 int field2_hand_signal_arrays() { return HSG_COUNT; }
+int hand_dropped_samples(unsigned long long* n, bool reset) {   // (waits for the device: diagnostics, not a launch path)
+    unsigned long long v = 0ull;
+    HN_CHECK_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_hn_dropped_samples), sizeof(v)));
+    if (reset) {
+        const unsigned long long z = 0ull;
+        HN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_hn_dropped_samples), &z, sizeof(z)));
+    }
+    if (n != nullptr) *n = v;
+    return HN_OK;
+}
 size_t field2_hand_pose_rows_bytes(int n_pts) { return pose_part_bytes(n_pts); }
 size_t field2_hand_adj_workspace_bytes(int n_pts, int n_cus) {
     const int grid = hand2_grid(n_pts, n_cus);

@@ -585,6 +585,7 @@
         a.g_pts[3 * n] = finite ? gp[0] : 0.f;
         a.g_pts[3 * n + 1] = finite ? gp[1] : 0.f;
         a.g_pts[3 * n + 2] = finite ? gp[2] : 0.f;
+        if (!finite) atomicAdd(&g_hn_dropped_samples, 1ull);   // (hn_dropped_samples: how often this happened)
     }
     if constexpr (PG) {
         // ... and from the parameter gradients: the rows this lane wrote into the signal arrays hold inf / NaN from the forward-direction

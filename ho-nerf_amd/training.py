@@ -69,6 +69,10 @@ def weight_norm_backward(g, v, dW):
 
 
 KEEP_TAPE = os.environ.get('HONERF_TRAIN_KEEP_TAPE', '1') != '0'   # the training render keeps its evaluation's tape for the backward pass
+# ... when the block is no larger than this (41 KB per sample for the object nets, 42 KB per evaluated sample for the hand nets: 2.4 GB for
+# the confs' 441 x 128 batch).  A differentiable render of a whole IMAGE (262 144 rays: 670 GB) goes through the plain pair, whose backward
+# pass -- should one ever be asked for at that size -- evaluates the field again.
+KEEP_TAPE_MAX_BYTES = int(float(os.environ.get('HONERF_TRAIN_KEEP_TAPE_MAX_GB', '24')) * (1 << 30))
 
 
 class SingleRenderFn(torch.autograd.Function):
@@ -109,6 +113,8 @@ class SingleRenderFn(torch.autograd.Function):
             # programs: hn_render_single_tape_bytes > 0) -- the backward pass then does not evaluate the field a second time.
             # KEEP_TAPE = False: the plain pair (the same numbers to the bit; tests, A/B).
             tape_bytes = lib.hn_render_single_tape_bytes(f.handle, B, S) if (KEEP_TAPE and B > 0 and any(ctx.needs_input_grad)) else 0
+            if tape_bytes > KEEP_TAPE_MAX_BYTES:
+                tape_bytes = 0
             if tape_bytes:
                 tape = torch.empty(tape_bytes, dtype=torch.uint8, device=dev)
                 L.check(lib.hn_render_single_taped(f.handle, L.ptr(ro), L.ptr(rd), L.ptr(tr), B, float(near), float(far), renderer.n_samples,

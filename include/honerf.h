@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 116 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 117 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -144,6 +144,11 @@ int hn_debug_fused_rounds(int on);
  * construction) instead of in a separate pass.  Process-wide; off by default; not a product path. */
 int hn_debug_field_timer(int on);
 int hn_debug_field_timer_read(double* total_ms, int* launches);
+/* Samples the hand field's adjoint kernels DROPPED on the current device since the library was loaded (or since the last call with
+ * reset != 0): a sample within ~2 mm of a bone's origin, whose adjoint quantities leave the fp16 fragments' range, gets g_pts = 0, no
+ * share in the pose gradients and zero rows in the parameter-gradient signals, where the fp32 reference adds a huge finite value
+ * (DESIGN.md 3.5).  Waits for the device: a diagnostic for tests, the bench line and a caller's logging, not a launch path. */
+int hn_dropped_samples(unsigned long long* count, int reset);
 
 /* ---- rays -----------------------------------------------------------------------------
  * _xy_to_ray_bundle (utils/utils.py:31-115): NDC xy -> unproject at depth 1 and

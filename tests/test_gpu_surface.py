@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import record, assert_close, assert_parity, bounded, cu, oracle_fields, oracle_fields_fp64, product_modules, rel_err, t
+from helpers import record, assert_close, assert_parity, bounded, cu, oracle_fields, oracle_fields_fp64, product_modules, rel_err, t, state_dicts, VAR_HAND
 
 pytestmark = pytest.mark.gpu
 RT = 1e-4
@@ -995,3 +995,61 @@ def test_module_sdf_and_gradient_calls_build_a_graph(kind):
     with torch.no_grad():
         s0 = mod.sdf(p_d.detach()) if kind == 'obj' else mod.sdf(p_d.detach(), bt_d.detach(), tp_d.detach())
     assert not s0.requires_grad and torch.equal(s0, sdf.detach())
+
+
+@pytest.mark.gpu
+def test_dropped_samples_are_counted_and_leave_finite_gradients():
+    """hn_dropped_samples: a sample a micrometre from a bone's origin (a joint) drives the 1 / v factors of the bone map out of the fp16
+    fragments' range; the hand adjoint kernels DROP it -- g_pts = 0, no share in the pose gradients, zero rows in the parameter-gradient
+    signals -- and count it.  Every output stays finite, the count equals the number of zeroed g_pts rows, and the other samples'
+    g_pts do not depend on the dropped ones sharing their tile."""
+    from honerf_amd import lib as L
+    from honerf_amd import synth
+    from honerf_amd.nets import PackedField
+    lib = L.load()
+    dev = torch.device('cuda:0')
+    sd = state_dicts()
+    pf = PackedField('hand', sd['sdf_hand'], sd['color_hand'], VAR_HAND, precision='f16x3')
+    bt_np, tp_np, joints = synth.synth_hand_pose(9)
+    gen = torch.Generator().manual_seed(23)
+    n = 256
+    pts = torch.from_numpy(joints).float()[torch.randint(0, 21, (n,), generator=gen)] + 0.015 * torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    at_origin = [5, 77, 130, 201]
+    for k, i in enumerate(at_origin):
+        pts[i] = torch.from_numpy(joints[3 + 4 * k]).float() + torch.tensor([1e-6, 0.0, 0.0])
+    c = lambda x: x.float().contiguous().to(dev)
+    p_d, bt, tp = c(pts), c(torch.from_numpy(bt_np)).reshape(1, 21, 4, 4), c(torch.from_numpy(tp_np)).reshape(1, 21, 3)
+    dirs = c(torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1))
+    gs, gg, gr = c(torch.randn(n, generator=gen)), c(torch.randn(n, 3, generator=gen) * 0.1), c(torch.randn(n, 3, generator=gen))
+    need = lib.hn_field_bwd_workspace_bytes(pf.handle, n)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+
+    def adjoint(points):
+        g_pts, g_dir = torch.empty(n, 3, device=dev), torch.zeros(n, 3, device=dev)
+        g_bt, g_tp = torch.zeros(1, 21, 4, 4, device=dev), torch.zeros(1, 21, 3, device=dev)
+        L.check(lib.hn_field_eval_bwd(pf.handle, L.ptr(points), L.ptr(dirs), n, 1, L.ptr(bt), L.ptr(tp), 1, n, L.ptr(gs), L.ptr(gg), L.ptr(gr), L.ptr(g_pts),
+                                      L.ptr(g_dir), L.ptr(g_bt), L.ptr(g_tp), L.ptr(ws), need, L.stream_ptr()), 'hn_field_eval_bwd')
+        return g_pts, g_bt, g_tp
+    L.dropped_samples(reset=True)
+    g_pts, g_bt, g_tp = adjoint(p_d)
+    dropped = L.dropped_samples(reset=True)
+    zero_rows = [i for i in range(n) if float(g_pts[i].abs().max()) == 0.0]
+    assert all(bool(torch.isfinite(x).all()) for x in (g_pts, g_bt, g_tp))
+    assert dropped == len(zero_rows) and set(at_origin) <= set(zero_rows), (dropped, zero_rows)
+    assert dropped <= len(at_origin) + 2, zero_rows            # (the regular samples sit 15 mm from their joint: none of them is dropped)
+    # the same points with the four moved away: everybody else's g_pts is what it was (a dropped lane poisons nobody)
+    moved = p_d.clone()
+    moved[at_origin] += 0.01
+    g_pts2, _, _ = adjoint(moved)
+    assert L.dropped_samples(reset=True) == len(zero_rows) - len(at_origin)
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[at_origin] = False
+    assert torch.equal(g_pts[keep.to(dev)], g_pts2[keep.to(dev)])
+    # the parameter-gradient path: finite, and the dropped samples are counted there too
+    g_params = torch.zeros(lib.hn_field_param_floats(pf.handle), device=dev)
+    g_pts3, g_dir3 = torch.empty(n, 3, device=dev), torch.zeros(n, 3, device=dev)
+    g_bt3, g_tp3 = torch.zeros(1, 21, 4, 4, device=dev), torch.zeros(1, 21, 3, device=dev)
+    L.check(lib.hn_field_param_bwd(pf.handle, L.ptr(p_d), L.ptr(dirs), n, 1, L.ptr(bt), L.ptr(tp), 1, n, L.ptr(gs), L.ptr(gg), L.ptr(gr), L.ptr(g_params),
+                                   L.ptr(g_pts3), L.ptr(g_dir3), L.ptr(g_bt3), L.ptr(g_tp3), L.ptr(ws), need, L.stream_ptr()), 'hn_field_param_bwd')
+    assert L.dropped_samples(reset=True) == dropped
+    assert bool(torch.isfinite(g_params).all()) and float(g_params.abs().max()) > 0.0

@@ -68,6 +68,8 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3', compac
     true_rgb = torch.rand(n_rays, 3, generator=g).to(dev)
     true_mask = (torch.rand(n_rays, 1, generator=g) > 0.3).float().to(dev)
     opt = training.make_optimizer(ren, 1e-4)          # exp_runner.py:107-110, confs learning_rate = 1e-4
+    from honerf_amd import lib as _L
+    _L.dropped_samples(reset=True)
 
     def step(parts=None):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
@@ -130,7 +132,9 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3', compac
     return {'roofline': roof, 'workload': 'exp_runner.train iteration, %s nets, %d rays x (64+64) samples' % (kind, n_rays), 'ms_per_step': round(ms, 3),
             'far_field_aggregation': bool(compact and kind == 'hand'),
             'iterations_per_s': round(1e3 / ms, 2), 'ray_samples_per_s': round(n_rays * S / ms * 1e3),
-            'parts_ms': {k: round(v / steps, 3) for k, v in parts.items()}, 'loss': float(terms['loss'].detach()), 'precision': precision}
+            'parts_ms': {k: round(v / steps, 3) for k, v in parts.items()}, 'loss': float(terms['loss'].detach()), 'precision': precision,
+            # samples the hand adjoint dropped (out of the fp16 fragments' range next to a bone's origin) over all %d iterations of this leg
+            'dropped_samples': _L.dropped_samples(), 'dropped_samples_of': (warmup + 2 * steps) * n_rays * S}
 
 
 def main():
