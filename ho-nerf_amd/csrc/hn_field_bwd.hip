@@ -281,6 +281,10 @@ __global__ __launch_bounds__(256) void k_outer(const OuterArgs a) {
 // ds_write_b128 per part; LDS image [part][column][32 samples] at an 80-byte column pitch (conflict-free for the 8-lane groups of the stores
 // and the 16-lane groups of ds_read_b128).  Bias gradients: the staging threads of the first k tile sum their column on the way.
 // A desc may carry a SECOND operand pair accumulated into the same tile (dW_l = zb_l^T a_{l-1} + dz_l^T v_{l-1}: one set of atomics for both).
+// Measured and not kept (round 5): a second register set of loads in flight (two steps ahead) 1.3 -> 1.6 ms; eight-wave workgroups with four
+// producer waves (loads two steps ahead, split, LDS images) and four consumer waves (MFMAs), two image buffers, one barrier per step, one
+// workgroup per CU: 1.0 -> 1.15 ms (obj), 1.2 -> 2.0 ms (hand) -- the step's three parts (loads alone 0.5 ms, MFMAs +0.34, splits +0.17)
+// overlap no better that way than across two independent workgroups per CU.
 struct OuterDesc {
     const float *A, *B, *A2, *B2;
     float *dW, *db;
@@ -931,7 +935,13 @@ struct OuterGroup {
     OuterGroupArgs g{};
     int tiles = 0;
     // dW[M, K] += alpha * A^T B over the samples (+ db[M] += alpha_b * sum A when db != NULL); K == 0: the column sums alone
+    bool overflow = false;   // more products than the kernel's table holds: launch() refuses (the callers add ~20)
+    OuterDesc spare{};
     OuterDesc& add(const float* A, int lda, int M, const float* B, int ldb, int K, float alpha, float* dW, int ldw, float* db, float alpha_b = 1.f) {
+        if (g.n_desc >= OUTER_MAX_DESCS) {
+            overflow = true;
+            return spare;
+        }
         OuterDesc& d = g.d[g.n_desc++];
         d = OuterDesc{A, B, nullptr, nullptr, dW, db, lda, ldb, 0, 0, M, K, ldw, K > 0 ? (K + OG_T - 1) / OG_T : 1, 0, 0, alpha, alpha_b};
         tiles += ((M + OG_T - 1) / OG_T) * d.kt;
@@ -949,6 +959,7 @@ struct OuterGroup {
     }
     bool full() const { return g.n_desc >= OUTER_MAX_DESCS; }
     int launch(hipStream_t s, int n) {
+        HN_REQUIRE(!overflow, "more than %d outer products in one group", OUTER_MAX_DESCS);
         if (g.n_desc == 0 || n <= 0) return HN_OK;
         int cus = device_cus();
         if (cus <= 0) cus = 256;

@@ -131,6 +131,7 @@ class SingleRenderFn(torch.autograd.Function):
         ctx.sample_dist = sample_dist
         ctx.n_params = len(params)
         ctx.tape = tape                # (a plain attribute: the block is this call's own, nothing else reads or versions it)
+        ctx.tape_compact = bool(getattr(renderer, 'compact_far_field', False))   # the block's rows are the compacted list's when this is on
         ctx.save_for_backward(ro, rd, z, *([bt, tp] if hand else []))
         ctx.mark_non_differentiable(cdf, wmax)
         return color, wsum, gerr.reshape(()), cdf, wmax
@@ -163,6 +164,8 @@ class SingleRenderFn(torch.autograd.Function):
             ren._ws_train = _Workspace()
         ws = ren._ws_train.get(need, dev)
         tape = getattr(ctx, 'tape', None)
+        if tape is not None and ctx.tape_compact != bool(getattr(ren, 'compact_far_field', False)):
+            tape = None                # the far-field setting changed between the passes: the block's layout is the other one's -- re-evaluate
         if tape is not None:
             L.check(lib.hn_render_single_bwd_taped(f.handle, L.ptr(ro), L.ptr(rd), B, S, ctx.sample_dist, L.ptr(bt), L.ptr(tp), L.ptr(z), L.ptr(gc),
                                                    L.ptr(gw), L.ptr(ge), L.ptr(g_params), L.ptr(g_inv_s), L.ptr(g_ro), L.ptr(g_rd), L.ptr(g_bt),
