@@ -27,6 +27,8 @@ cp gpurun_out/prof_train_r05_hand/kernel_stats.csv $O/train_step_hand_kernel_sta
 (timeout 300 python tools/train_grad_ab.py obj 0 2>&1 | grep -v "amdgpu\|UserWarning\|Consider\|np.savez" > $O/train_grad_ab_obj.txt)
 (timeout 300 python tools/train_grad_ab.py hand 1 2>&1 | grep -v "amdgpu\|UserWarning\|Consider\|np.savez" > $O/train_grad_ab_hand.txt)
 (for d in 0 2 4 6; do echo "HN_DBG_OUTER=$d (2: no MFMAs, 4: no splits / LDS stores after the first step; results wrong, timing only)"; HN_DBG_OUTER=$d timeout 200 python tools/train_fused_ab.py 56448 obj 2>&1 | grep "^n ="; done > $O/outer_group_parts.txt)
+(timeout 400 python tools/train_soak.py hand 300 2>&1 | grep -v "amdgpu\|Warning\|Consider\|float(" > $O/train_soak_hand.txt)
+(timeout 400 python tools/train_soak.py obj 300 2>&1 | grep -v "amdgpu\|Warning\|Consider\|float(" > $O/train_soak_obj.txt)
 timeout 300 python tools/scan_bench.py $O/scan_kernels_hbm.json > $O/scan_kernels.log 2>&1
 timeout 600 python tools/secondary_bench.py $O/secondary_bench.json > $O/secondary_bench.log 2>&1
 # the sequence loop's reproducibility: as shipped (Jacobian launch behind the stable term), and with the round-4 order
