@@ -127,9 +127,21 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3', compac
         peak, what = 157.3, 'backward pass: launch sequence on v_mfma_f32_32x32x2_f32 (k_dense, k_outer)'
     roof = {'bound': 'mfma', 'what': what, 'flop_per_step': flop, 'achieved': flop / bwd_s / 1e12, 'peak': round(peak, 1), 'unit': 'TFLOP/s',
             'frac': flop / bwd_s / 1e12 / peak}
+    roof_hbm = None
+    if fused:
+        # ... and what the two kernels of that pass are actually bound by: HBM.  Algorithmic bytes of the backward pass per evaluated sample:
+        # 41 KB of per-layer signals written by k_field2_*<5> + the tape it reads (the block the render kept) + ~58 KB the outer products
+        # read (41 signal rows + X + GXb + feature vector, ~1.4 uses each; hand: X and GXb are 1 386 wide: + ~20 KB)
+        from honerf_amd import lib as _L2
+        tape_b = _L2.load().hn_render_single_tape_bytes(ren.field().handle, n_rays, S) if kept_tape else 0
+        per_sample = 41 * 1024 + (58 if kind == 'obj' else 78) * 1024
+        hbm_bytes = n_rays * S * per_sample + tape_b
+        roof_hbm = {'bound': 'hbm', 'what': 'backward pass, algorithmic bytes: signals written + tape read + operands of the outer products read (dense sample count)',
+                    'bytes_per_step': hbm_bytes, 'achieved': hbm_bytes / bwd_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': hbm_bytes / bwd_s / 1e9 / 8000.0}
     if compact and kind == 'hand':      # the work of the aggregated iteration depends on the batch's live fraction: priced in `hand_dense`
         roof = {'note': 'far-field aggregation on: fewer samples than the dense FLOP count assumes; the roofline entry is on the dense iteration (hand_dense)'}
-    return {'roofline': roof, 'workload': 'exp_runner.train iteration, %s nets, %d rays x (64+64) samples' % (kind, n_rays), 'ms_per_step': round(ms, 3),
+        roof_hbm = None
+    return {'roofline': roof, 'roofline_hbm': roof_hbm, 'workload': 'exp_runner.train iteration, %s nets, %d rays x (64+64) samples' % (kind, n_rays), 'ms_per_step': round(ms, 3),
             'far_field_aggregation': bool(compact and kind == 'hand'),
             'iterations_per_s': round(1e3 / ms, 2), 'ray_samples_per_s': round(n_rays * S / ms * 1e3),
             'parts_ms': {k: round(v / steps, 3) for k, v in parts.items()}, 'loss': float(terms['loss'].detach()), 'precision': precision,
