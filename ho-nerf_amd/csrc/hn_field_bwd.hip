@@ -963,7 +963,10 @@ struct OuterGroup {
         if (g.n_desc == 0 || n <= 0) return HN_OK;
         int cus = device_cus();
         if (cus <= 0) cus = 256;
-        int slices = (2 * cus) / tiles;                 // one resident round: two workgroups per CU
+        // two workgroups are resident per CU; items for ~two rounds of them: the object nets' ~124 work units measure the same with one
+        // round (3.34 ms of a 56 448-sample pass either way), the hand nets' ~210 -- two slices per product at one round -- 7.00 -> 6.74 ms
+        static const int wg_per_cu = getenv("HN_OUTER_WGS") ? atoi(getenv("HN_OUTER_WGS")) : 4;
+        int slices = (wg_per_cu * cus) / tiles;
         const int max_slices = (n + 255) / 256;         // a slice at least 256 samples long
         if (slices > max_slices) slices = max_slices;
         if (slices < 1) slices = 1;
