@@ -1435,7 +1435,10 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
         return HN_OK;
     };
     float *gbt = g_bt_inv, *gtp = g_T_pose;
-    if (hand) {   // the adjoint accumulates the pose gradients: into the caller's arrays when given, else into scratch
+    // the adjoint accumulates the pose gradients: into the caller's arrays when given.  The generic sequence's bone-map kernels always write
+    // them (scratch when nobody asks); the fused adjoint kernel skips its pose-gradient block when neither is asked for (exp_runner trains the
+    // networks on fixed poses)
+    if (hand && !(bwd::param_path_is_fused(f) && gbt == nullptr && gtp == nullptr)) {
         if (gbt == nullptr) gbt = pose_scratch;
         if (gtp == nullptr) gtp = pose_scratch + 21 * 16;
         HN_CHECK_HIP(hipMemsetAsync(gbt, 0, 21 * 16 * sizeof(float), s));
