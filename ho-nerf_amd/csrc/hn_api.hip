@@ -36,15 +36,15 @@ bool upsample_fused_ok(int n_rays, int k, int n_new);
 int merge(const float*, const float*, const float*, const float*, int, int, int, int, float*, float*, int64_t*,
           hipStream_t);
 int sort_rows(const float*, int, int, float*, hipStream_t);
-int alpha(const float*, const float*, const float*, const float*, int, int, float, float*, float*, hipStream_t);
+int alpha(const float*, const float*, const float*, const float*, int, int, float, float*, float*, hipStream_t, const float* inv_s_dev = nullptr);
 int composite1(const float*, const float*, const float*, const float*, int, int, float*, float*, float*, float*, float*,
                hipStream_t);
 int composite2(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
                float*, float*, float*, float*, hipStream_t, float eik_scale = 1.f);
 int alpha_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float, float*,
-              float*, float*, hipStream_t, bool g_rays_d_zeroed = false);
+              float*, float*, hipStream_t, bool g_rays_d_zeroed = false, const float* inv_s_dev = nullptr);
 int alpha_inv_s_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float, float*,
-                    hipStream_t);
+                    hipStream_t, const float* inv_s_dev = nullptr);
 int composite1_bwd(const float*, const float*, const float*, const float*, const float*, int, int, float*, float*, float*,
                    hipStream_t);
 int composite2_bwd(const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*,
@@ -870,7 +870,7 @@ static int render_single_impl(const hn_field* f, const float* rays_o, const floa
     } else {
         HN_TRY(field_eval(f, t.pts, rays_d, (int)N, S, bt_inv, T_pose, 1, hand_ppf, sdf, grad, rgb, nullptr, fws, fws_bytes, s));
     }
-    HN_TRY(alpha(sdf, grad, rays_d, dists, (int)N, S, f->inv_s, al, cdf, s));
+    HN_TRY(alpha(sdf, grad, rays_d, dists, (int)N, S, f->inv_s, al, cdf, s, f->inv_s_dev));
     HN_CHECK_HIP(hipMemsetAsync(gradient_error, 0, sizeof(float), s));
     HN_TRY(composite1(al, cdf, rgb, grad, n_rays, S, color, nullptr, weight_sum, weight_max, gradient_error, s));
     hipLaunchKernelGGL(k_scale, dim3(1), dim3(64), 0, s, gradient_error, 1, 1.f / (float)N);
@@ -891,6 +891,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     HN_REQUIRE(n_samples >= 2 && n_importance >= 0 && n_frames >= 1 && rpf >= 0, "bad sizes");
     HN_REQUIRE(n_importance == 0 || (steps >= 1 && n_importance % steps == 0), "n_importance must divide into steps");
     HN_REQUIRE(hand->kind == HN_FIELD_HAND && obj->kind == HN_FIELD_OBJ, "field kinds (hand, obj) expected");
+    HN_REQUIRE(hand->inv_s_dev == nullptr && obj->inv_s_dev == nullptr, "a field whose inv_s lives on the device (hn_field_set_inv_s_device) serves the single-field renders only");
     const int n_rays = n_frames * rpf;
     const int S = n_samples + 2 * n_importance;
     const int St = n_samples + n_importance;   // per-track length
@@ -1393,12 +1394,12 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
             g_field = grad_d;
         } else
         hipLaunchKernelGGL(k_tape_outputs, dim3((n + 255) / 256), dim3(256), 0, s, z8, rgb_pre, 1.f / f->scale, n, sdf, rgb);
-        HN_TRY(alpha(sdf, g_field, rays_d, dists, n, S, f->inv_s, al, c, s));
+        HN_TRY(alpha(sdf, g_field, rays_d, dists, n, S, f->inv_s, al, c, s, f->inv_s_dev));
         HN_TRY(composite1_bwd(al, c, rgb, g_color, g_wsum, n_rays, S, g_al, g_c, g_rgb, s));
-        HN_TRY(alpha_bwd(sdf, g_field, rays_d, dists, g_al, g_c, n, S, f->inv_s, gs, gg, gd, s));
+        HN_TRY(alpha_bwd(sdf, g_field, rays_d, dists, g_al, g_c, n, S, f->inv_s, gs, gg, gd, s, false, f->inv_s_dev));
         if (g_inv_s != nullptr) {
             HN_CHECK_HIP(hipMemsetAsync(g_inv_s, 0, sizeof(float), s));
-            HN_TRY(alpha_inv_s_bwd(sdf, g_field, rays_d, dists, g_al, g_c, n, S, f->inv_s, g_inv_s, s));
+            HN_TRY(alpha_inv_s_bwd(sdf, g_field, rays_d, dists, g_al, g_c, n, S, f->inv_s, g_inv_s, s, f->inv_s_dev));
         }
         hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs, gg, (const float*)nullptr, (const float*)nullptr, g_field,
                            g_eik, n);
@@ -1419,12 +1420,12 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
             grad_t = grad_d;
             rgb_t = rgb;
         }
-        HN_TRY(alpha(sdf_t, grad_t, rays_d, dists, n, S, f->inv_s, al, c, s));
+        HN_TRY(alpha(sdf_t, grad_t, rays_d, dists, n, S, f->inv_s, al, c, s, f->inv_s_dev));
         HN_TRY(composite1_bwd(al, c, rgb_t, g_color, g_wsum, n_rays, S, g_al, g_c, g_rgb, s));
-        HN_TRY(alpha_bwd(sdf_t, grad_t, rays_d, dists, g_al, g_c, n, S, f->inv_s, gs, gg, gd, s));
+        HN_TRY(alpha_bwd(sdf_t, grad_t, rays_d, dists, g_al, g_c, n, S, f->inv_s, gs, gg, gd, s, false, f->inv_s_dev));
         if (g_inv_s != nullptr) {
             HN_CHECK_HIP(hipMemsetAsync(g_inv_s, 0, sizeof(float), s));
-            HN_TRY(alpha_inv_s_bwd(sdf_t, grad_t, rays_d, dists, g_al, g_c, n, S, f->inv_s, g_inv_s, s));
+            HN_TRY(alpha_inv_s_bwd(sdf_t, grad_t, rays_d, dists, g_al, g_c, n, S, f->inv_s, g_inv_s, s, f->inv_s_dev));
         }
         hipLaunchKernelGGL(k_upstream, dim3((n + 255) / 256), dim3(256), 0, s, gs, gg, (const float*)nullptr, (const float*)nullptr, grad_t, g_eik, n);
         if (compact) {   // dense upstream gradients -> the compact rows; the far sample's = the sums over the dead samples
@@ -1686,6 +1687,14 @@ int hn_render_single_bwd_taped(const hn_field* f, const float* rays_o, const flo
                                   workspace_bytes, reinterpret_cast<hipStream_t>(stream), nullptr, tape, tape_bytes);
 }
 float hn_field_inv_s(const hn_field* f) { return f ? f->inv_s : 0.f; }
+int hn_field_set_inv_s_device(hn_field* f, const float* inv_s_dev) {
+    if (f == nullptr) {
+        hn::set_error("hn_field_set_inv_s_device: null field");
+        return HN_EINVAL;
+    }
+    f->inv_s_dev = inv_s_dev;
+    return HN_OK;
+}
 int hn_field_set_compaction(hn_field* f, int enabled) {
     if (f == nullptr) {
         hn::set_error("hn_field_set_compaction: null field");

@@ -133,6 +133,7 @@ struct hn_field {
     int precision = 0;
     float variance = 0.f;
     float inv_s = 0.f;
+    const float* inv_s_dev = nullptr;   // hn_field_set_inv_s_device: inv_s lives on the device (borrowed; `inv_s` is then not meaningful)
     float scale = 1.f;
     void* blob = nullptr;       // one device allocation holding every packed array
     size_t blob_bytes = 0;

@@ -10,10 +10,11 @@ namespace hn {
 __device__ __forceinline__ float sigmoid_e(float x) { return 1.f / (1.f + expf(-x)); }
 
 __global__ void k_alpha(const float* __restrict__ sdf, const float* __restrict__ grad, const float* __restrict__ rays_d,
-                        const float* __restrict__ dists, int n, int spr, float inv_s, float* __restrict__ alpha,
-                        float* __restrict__ c_out) {
+                        const float* __restrict__ dists, int n, int spr, float inv_s_host, float* __restrict__ alpha,
+                        float* __restrict__ c_out, const float* __restrict__ inv_s_dev) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const float inv_s = inv_s_dev != nullptr ? inv_s_dev[0] : inv_s_host;   // (hn_field_set_inv_s_device: a trained value that never visits the host)
     const int ray = i / spr;
     const float true_cos = rays_d[3 * ray] * grad[3 * (size_t)i] + rays_d[3 * ray + 1] * grad[3 * (size_t)i + 1] +
                            rays_d[3 * ray + 2] * grad[3 * (size_t)i + 2];
@@ -409,10 +410,11 @@ __global__ __launch_bounds__(256) void k_composite2_rows(const float* __restrict
 // from depths the reference samples under no_grad (utils/renderer.py:215, 461).
 __global__ void k_alpha_bwd(const float* __restrict__ sdf, const float* __restrict__ grad, const float* __restrict__ rays_d,
                             const float* __restrict__ dists, const float* __restrict__ g_alpha,
-                            const float* __restrict__ g_c, int n, int spr, float inv_s, float* __restrict__ g_sdf,
-                            float* __restrict__ g_grad, float* __restrict__ g_rays_d) {
+                            const float* __restrict__ g_c, int n, int spr, float inv_s_host, float* __restrict__ g_sdf,
+                            float* __restrict__ g_grad, float* __restrict__ g_rays_d, const float* __restrict__ inv_s_dev) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;   // (the wave-level reduction below checks that all 64 lanes are present)
+    const float inv_s = inv_s_dev != nullptr ? inv_s_dev[0] : inv_s_host;
     const int ray = i / spr;
     const float d0 = rays_d[3 * ray], d1 = rays_d[3 * ray + 1], d2 = rays_d[3 * ray + 2];
     const float q0 = grad[3 * (size_t)i], q1 = grad[3 * (size_t)i + 1], q2 = grad[3 * (size_t)i + 2];
@@ -623,11 +625,11 @@ static int composite_grid(int n_rays) {
 }
 
 int alpha(const float* sdf, const float* grad, const float* rays_d, const float* dists, int n, int spr, float inv_s,
-          float* alpha_out, float* c, hipStream_t s) {
+          float* alpha_out, float* c, hipStream_t s, const float* inv_s_dev) {
     HN_REQUIRE(spr > 0, "samples_per_ray must be positive");
     if (n == 0) return HN_OK;
     hipLaunchKernelGGL(k_alpha, dim3((n + 255) / 256), dim3(256), 0, s, sdf, grad, rays_d, dists, n, spr, inv_s,
-                       alpha_out, c);
+                       alpha_out, c, inv_s_dev);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -689,12 +691,12 @@ int composite2(const float* ah, const float* rgbh, const float* gh, const float*
 
 int alpha_bwd(const float* sdf, const float* grad, const float* rays_d, const float* dists, const float* g_alpha,
               const float* g_c, int n, int spr, float inv_s, float* g_sdf, float* g_grad, float* g_rays_d, hipStream_t s,
-              bool g_rays_d_zeroed) {
+              bool g_rays_d_zeroed, const float* inv_s_dev) {
     HN_REQUIRE(spr > 0, "samples_per_ray must be positive");
     if (n == 0) return HN_OK;
     if (g_rays_d != nullptr && !g_rays_d_zeroed) HN_CHECK_HIP(hipMemsetAsync(g_rays_d, 0, (size_t)(n / spr) * 3 * sizeof(float), s));
     hipLaunchKernelGGL(k_alpha_bwd, dim3((n + 255) / 256), dim3(256), 0, s, sdf, grad, rays_d, dists, g_alpha, g_c, n, spr,
-                       inv_s, g_sdf, g_grad, g_rays_d);
+                       inv_s, g_sdf, g_grad, g_rays_d, inv_s_dev);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -848,9 +850,10 @@ int alpha_bwd_up(const float* sdf, const float* grad, const float* rays_d, const
 // x1 = (s - half) inv_s, x2 = (s + half) inv_s.  One atomic per block (caller zeroes g_inv_s).
 __global__ void k_alpha_inv_s_bwd(const float* __restrict__ sdf, const float* __restrict__ grad, const float* __restrict__ rays_d,
                                   const float* __restrict__ dists, const float* __restrict__ g_alpha, const float* __restrict__ g_c,
-                                  int n, int spr, float inv_s, float* __restrict__ g_inv_s) {
+                                  int n, int spr, float inv_s_host, float* __restrict__ g_inv_s, const float* __restrict__ inv_s_dev) {
     __shared__ float part[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float inv_s = inv_s_dev != nullptr ? inv_s_dev[0] : inv_s_host;
     float v = 0.f;
     if (i < n) {
         const int ray = i / spr;
@@ -875,11 +878,11 @@ __global__ void k_alpha_inv_s_bwd(const float* __restrict__ sdf, const float* __
     if (threadIdx.x == 0) atomicAdd(g_inv_s, part[0] + part[1] + part[2] + part[3]);
 }
 int alpha_inv_s_bwd(const float* sdf, const float* grad, const float* rays_d, const float* dists, const float* g_alpha,
-                    const float* g_c, int n, int spr, float inv_s, float* g_inv_s, hipStream_t s) {
+                    const float* g_c, int n, int spr, float inv_s, float* g_inv_s, hipStream_t s, const float* inv_s_dev) {
     HN_REQUIRE(spr > 0 && g_inv_s != nullptr, "bad arguments");
     if (n == 0) return HN_OK;
     hipLaunchKernelGGL(k_alpha_inv_s_bwd, dim3((n + 255) / 256), dim3(256), 0, s, sdf, grad, rays_d, dists, g_alpha, g_c, n, spr,
-                       inv_s, g_inv_s);
+                       inv_s, g_inv_s, inv_s_dev);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }

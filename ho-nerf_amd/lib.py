@@ -25,7 +25,7 @@ PRECISIONS = {'fp32': HN_PREC_FP32, 'f16x3': HN_PREC_F16X3, 'f16': HN_PREC_F16}
 # 'fp32': the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32), 5x slower, kept as a second opinion
 DEFAULT_PRECISION = os.environ.get('HONERF_PRECISION', 'f16x3')
 HN_MAX_LAYERS = 9
-HN_VERSION = 117          # the include/honerf.h revision SIGNATURES below was written for
+HN_VERSION = 118          # the include/honerf.h revision SIGNATURES below was written for
 
 c_f = ctypes.c_void_p     # device float*
 c_i = ctypes.c_int
@@ -64,6 +64,7 @@ SIGNATURES = {
     'hn_debug_field_timer': (c_i, [c_i]),
     'hn_debug_field_timer_read': (c_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i)]),
     'hn_dropped_samples': (c_i, [ctypes.POINTER(ctypes.c_ulonglong), c_i]),
+    'hn_field_set_inv_s_device': (c_i, [c_vp, c_f]),
     'hn_ray_gen': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
     'hn_obj_local_fwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_vp]),
     'hn_obj_local_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, c_vp]),

@@ -410,21 +410,39 @@ class PackedField:
     state dicts in the reference layout; `variance` a SingleVarianceNetwork, a
     tensor or a float."""
 
-    def __init__(self, kind, sdf, color, variance, scale=None, precision=None, eval_only=False):
+    def __init__(self, kind, sdf, color, variance, scale=None, precision=None, eval_only=False, device_variance=False):
+        """`device_variance` (single-field renderers: `NeuSRenderer.field()`): a variance given as a device tensor stays there --
+        `inv_s = clip(exp(10 variance), 1e-6, 1e6)` is formed by torch operators on the current stream and handed to the library as
+        a device scalar (hn_field_set_inv_s_device), so that packing a field does not wait for the device (a training iteration
+        re-packs after every optimiser step: exp_runner.py:107-110 trains the variance too).  `.inv_s` / `.variance` then read the
+        value back on first use; `.inv_s_t` is the device scalar.  Such a field serves the single-field renders only."""
         self.lib = _lib.load()
         self.kind = kind
         precision = precision or _lib.DEFAULT_PRECISION
         self.precision = precision
+        self.eval_only = bool(eval_only)
         sdf_sd, col_sd = _state_of(sdf), _state_of(color)
         if isinstance(variance, nn.Module):
             variance = variance.variance
-        var = float(variance.detach().cpu()) if isinstance(variance, torch.Tensor) else float(variance)
+        self.inv_s_t = None
+        self._variance_t = None
+        if device_variance and isinstance(variance, torch.Tensor) and variance.is_cuda:
+            v = variance.detach().reshape(1).float()
+            self._variance_t = v
+            self.inv_s_t = torch.exp(v * 10.0).clamp(1e-6, 1e6).contiguous()
+            var = 0.0                                   # (not read by the single-field renders of such a field)
+            self._variance, self._inv_s = None, None
+        else:
+            var = float(variance.detach().cpu()) if isinstance(variance, torch.Tensor) else float(variance)
         if scale is None:
             scale = float(getattr(sdf, 'scale', 1.0)) if not isinstance(sdf, dict) else 1.0
         keep = []
         d_sdf, d_col = _mlp_desc(sdf_sd, keep), _mlp_desc(col_sd, keep)
         handle = ctypes.c_void_p()
-        torch.cuda.synchronize()
+        # (a training re-pack -- eval_only, everything on the current stream, whose order keeps the recycled device blocks safe -- waits
+        #  for nothing; any other pack first lets the device finish what may still read the blocks it recycles)
+        if not (self.eval_only and self.inv_s_t is not None):
+            torch.cuda.synchronize()
         rc = self.lib.hn_field_create(_lib.HN_FIELD_OBJ if kind == 'obj' else _lib.HN_FIELD_HAND,
                                       ctypes.byref(d_sdf), ctypes.byref(d_col), var, float(scale),
                                       _lib.PRECISIONS[precision] | (_lib.HN_PACK_EVAL_ONLY if eval_only else 0),
@@ -432,14 +450,36 @@ class PackedField:
         _lib.check(rc, 'hn_field_create')
         del keep
         self.handle = handle
-        self.variance = var
-        self.inv_s = float(self.lib.hn_field_inv_s(handle))
+        if self.inv_s_t is not None:
+            _lib.check(self.lib.hn_field_set_inv_s_device(handle, _lib.ptr(self.inv_s_t)), 'hn_field_set_inv_s_device')
+        else:
+            self._variance = var
+            self._inv_s = float(self.lib.hn_field_inv_s(handle))
+
+    @property
+    def variance(self):
+        if self._variance is None:
+            self._variance = float(self._variance_t.cpu())
+        return self._variance
+
+    @property
+    def inv_s(self):
+        if self._inv_s is None:
+            self._inv_s = float(self.inv_s_t.cpu())
+        return self._inv_s
+
+    def s_val(self, n, device):
+        """1 / inv_s as an [n, 1] tensor (the `s_val` of the render dictionaries, utils/renderer.py:236, logged only)."""
+        if self.inv_s_t is not None:
+            return (1.0 / self.inv_s_t).reshape(1, 1).expand(n, 1).contiguous()
+        return torch.full((n, 1), 1.0 / self.inv_s, device=device)
 
     def __del__(self):
         h = getattr(self, 'handle', None)
         if h is not None and h.value:
             try:
-                torch.cuda.synchronize()
+                if not (getattr(self, 'eval_only', False) and getattr(self, 'inv_s_t', None) is not None):
+                    torch.cuda.synchronize()   # (a training re-pack's predecessor: same stream, its blocks are recycled in stream order)
                 self.lib.hn_field_destroy(h)
             except Exception:
                 pass

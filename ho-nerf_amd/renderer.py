@@ -175,7 +175,7 @@ class NeuSRenderer:
         ver = params_version(self.sdf_network, self.color_network, self.deviation_network) + (self.precision, eval_only, compact)
         if self._field is None or ver != self._version:
             self._field = PackedField(self.model_type, self.sdf_network, self.color_network, self.deviation_network,
-                                      precision=self.precision, eval_only=eval_only)
+                                      precision=self.precision, eval_only=eval_only, device_variance=True)
             if compact:
                 self._field.set_compaction(True)
             self._version = ver
@@ -242,7 +242,7 @@ class NeuSRenderer:
         self.last_z_vals = z
         return {
             'color_fine': color,
-            's_val': torch.full((B, 1), 1.0 / f.inv_s, device=dev),
+            's_val': f.s_val(B, dev),
             'cdf_fine': cdf,
             'weight_sum': wsum,
             'weight_max': wmax,
@@ -298,7 +298,7 @@ class NeuSRenderer:
         self.N = B * S
         return {
             'color': color,
-            's_val': torch.full((B * S, 1), 1.0 / f.inv_s, device=dev),
+            's_val': f.s_val(B * S, dev),
             'weights': weights,
             'cdf': a['c'],
             'gradient_error': (gerr / float(B * S)).reshape(()),

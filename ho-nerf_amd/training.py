@@ -197,8 +197,12 @@ class SingleRenderFn(torch.autograd.Function):
                                        ctypes.byref(descs[1]), L.stream_ptr()), 'hn_weight_norm_bwd')
         del keep
         # inv_s = clip(exp(10 variance), 1e-6, 1e6) (utils/fields.py:248-249, utils/renderer.py:144)
-        inv_s = float(f.inv_s)
-        grads.append((g_inv_s * (10.0 * inv_s if 1e-6 < inv_s < 1e6 else 0.0)).reshape(()))
+        if f.inv_s_t is not None:       # the trained value never visited the host: the chain rule on the device too
+            inv = f.inv_s_t
+            grads.append((g_inv_s * torch.where((inv > 1e-6) & (inv < 1e6), 10.0 * inv, torch.zeros_like(inv))).reshape(()))
+        else:
+            inv_s = float(f.inv_s)
+            grads.append((g_inv_s * (10.0 * inv_s if 1e-6 < inv_s < 1e6 else 0.0)).reshape(()))
         assert len(grads) == ctx.n_params, 'pass trainable_parameters(renderer) as the parameter list'
         return (None, None, None, None, None, g_ro, g_rd, g_bt, g_tp, *grads)
 
@@ -268,7 +272,7 @@ def render_train(renderer, rays_o, rays_d, near, far, bt_inv, T_pose_21, verts, 
     B = color.shape[0]
     return {
         'color_fine': color,
-        's_val': torch.full((B, 1), 1.0 / renderer.field().inv_s, device=dev),
+        's_val': renderer.field().s_val(B, dev),
         'cdf_fine': cdf,
         'weight_sum': wsum,
         'weight_max': wmax,

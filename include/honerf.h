@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 117 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 118 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -99,6 +99,12 @@ int hn_field_destroy(hn_field* f);
 size_t hn_release_cached_memory(void);
 /* clip(exp(10 * variance), 1e-6, 1e6): utils/renderer.py:144. */
 float hn_field_inv_s(const hn_field* f);
+/* A TRAINED variance (exp_runner.py:107-110 steps `deviation_network.variance` with Adam every iteration) need not visit the host: with
+ * `inv_s_dev` = a device float the caller keeps equal to clip(exp(10 variance), 1e-6, 1e6) (and alive while the field is used), the
+ * single-field renders -- hn_render_single[_taped], hn_render_single_bwd[_taped] -- read inv_s from there at launch time and the
+ * `variance` given to hn_field_create is ignored by them, so a training loop's per-iteration re-pack waits for nothing.  The two-field
+ * renders refuse such a field (their fields are created once; HN_EINVAL).  NULL: back to the host value. */
+int hn_field_set_inv_s_device(hn_field* f, const float* inv_s_dev);
 
 /* Exact far-field early-out of the hand field (SURVEY B-11): a bone whose mask h = 1 - sigmoid(200 (v - cutoff))
  * (utils/fields.py:33-35) is exactly 0 in fp32 for every sample of a 128-sample workgroup contributes exactly 0
