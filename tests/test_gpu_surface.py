@@ -332,7 +332,7 @@ def test_far_field_compaction_is_exact():
         assert torch.equal(dense[3][k], comp[3][k]), 'compaction changed %s of the render without a tape' % k
     for k in dense[0]:
         if k.startswith('gradient_error'):      # a sum accumulated with float atomics: equal to rounding, not to the bit, in ANY two runs
-            assert abs(float(dense[0][k]) - float(comp[0][k])) <= 1e-6 * abs(float(dense[0][k])), k
+            assert abs(float(dense[0][k]) - float(comp[0][k])) <= 5e-6 * abs(float(dense[0][k])), k
         else:
             assert torch.equal(dense[0][k], comp[0][k]), 'compaction changed ' + k
     sh = dense[0]['sdf_hand'].reshape(-1)
@@ -411,7 +411,7 @@ def test_fused_importance_rounds_are_bit_identical():
             assert float(res[1][1].std()) > 0
             for k in res[1][0]:
                 if k.startswith('gradient_error'):      # sums accumulated with float atomics: equal to rounding in ANY two runs
-                    assert abs(float(res[1][0][k].sum()) - float(res[0][0][k].sum())) <= 1e-6 * abs(float(res[0][0][k].sum())) + 1e-12, (name, k)
+                    assert abs(float(res[1][0][k].sum()) - float(res[0][0][k].sum())) <= 5e-6 * abs(float(res[0][0][k].sum())) + 1e-12, (name, k)
                 else:
                     assert torch.equal(res[1][0][k], res[0][0][k]), '%s: %s' % (name, k)
     finally:
