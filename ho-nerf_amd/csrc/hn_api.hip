@@ -4,6 +4,7 @@
 #include <atomic>
 #include <functional>
 #include <mutex>
+#include <unordered_map>
 #include <stdlib.h>
 #include <string.h>
 
@@ -763,6 +764,39 @@ struct SingleKeep {
         total = off;
     }
 };
+// The live count of a kept block's compacted list, on its way to the host while the render is still running: hn_render_single_taped
+// starts the copy right behind its compaction and records an event; hn_render_single_bwd_taped -- whose launches are sized by that
+// count -- waits for THAT event only (long past when the backward pass is called) instead of for the whole stream.  Keyed by the block.
+struct KeptCount {
+    int* host = nullptr;      // pinned
+    hipEvent_t ev = nullptr;
+};
+static std::mutex g_kept_mu;
+static std::unordered_map<const void*, KeptCount> g_kept;
+static int kept_count_send(const void* block, const int* n_dev, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_kept_mu);
+    KeptCount& e = g_kept[block];
+    if (e.host == nullptr) {
+        HN_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&e.host), sizeof(int), hipHostMallocDefault));
+        HN_CHECK_HIP(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
+    }
+    *e.host = -1;
+    HN_CHECK_HIP(hipMemcpyAsync(e.host, n_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    HN_CHECK_HIP(hipEventRecord(e.ev, s));
+    return HN_OK;
+}
+static bool kept_count_take(const void* block, int* n_c) {   // false: no count was sent for this block
+    KeptCount e;
+    {
+        std::lock_guard<std::mutex> lk(g_kept_mu);
+        auto it = g_kept.find(block);
+        if (it == g_kept.end()) return false;
+        e = it->second;
+    }
+    if (hipEventSynchronize(e.ev) != hipSuccess || *e.host < 0) return false;
+    *n_c = *e.host;
+    return true;
+}
 // a render whose backward pass takes the fused parameter-gradient path (f16x3 field packed with its tape programs) can keep its tape
 static bool single_keep_applies(const hn_field* f) { return f != nullptr && bwd::param_path_is_fused(f) && field_tape(f, 128) != 0; }
 
@@ -852,6 +886,7 @@ static int render_single_impl(const hn_field* f, const float* rays_o, const floa
         CompactRec cr;
         cr.at(crec_ws, N);
         HN_TRY(compact_hand(cr, t.pts, (int)N, bt_inv, T_pose, 1, hand_ppf, s));
+        if (keep_block != nullptr) HN_TRY(kept_count_send(keep_block, cr.n_dev, s));
         float *sdf_c = keep_block ? kp.sdf : cr.sdf_c, *grad_c = keep_block ? kp.grad : cr.grad_c, *rgb_c = keep_block ? kp.rgb : cr.rgb_c;
         set_launch_n_pts_dev(cr.n_dev);
         set_launch_orig_idx(cr.idx);
@@ -1377,10 +1412,13 @@ static int render_single_bwd_impl(const hn_field* f, const float* rays_o, const 
     if (compact) {
         cr.at(crec_ws, N);
         HN_TRY(compact_hand(cr, pts, n, bt_inv, T_pose, 1, n, s));
-        // The launch sequence of the parameter-gradient adjoint is sized on the host: the live count is read back (the one
-        // place this library waits for a stream; a training iteration is ~20 ms of device time behind it).
-        HN_CHECK_HIP(hipMemcpyAsync(&n_c, cr.n_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-        HN_CHECK_HIP(hipStreamSynchronize(s));
+        // The launch sequence of the parameter-gradient adjoint is sized on the host by the live count.  With a kept block the forward pass
+        // has sent it already (the same points give the same list); otherwise it is read back here (the one place this library waits for
+        // a stream).
+        if (!(keep_block != nullptr && kept_count_take(keep_block, &n_c))) {
+            HN_CHECK_HIP(hipMemcpyAsync(&n_c, cr.n_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+            HN_CHECK_HIP(hipStreamSynchronize(s));
+        }
         HN_REQUIRE(n_c >= 1 && n_c <= n + 1, "compaction count out of range: %d", n_c);
     }
     // The field is NOT evaluated again: the adjoint's own forward tape (exact fp32) supplies sdf / gradient / colour;
