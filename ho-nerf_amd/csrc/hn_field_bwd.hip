@@ -1683,3 +1683,12 @@ int nearest_masked(const float* pts, int n_verts, int n_sets, const unsigned cha
 
 }  // namespace bwd
 }  // namespace hn
+
+// Not part of the C ABI (no declaration in include/honerf.h; tests/test_training.py binds it by name): ONE outer product
+// dW[M, K] += alpha A^T B, db[M] += sum A through k_outer_group, for checking the kernel against numpy on its own.
+extern "C" int hn_debug_outer_product(const float* A, int lda, int M, const float* B, int ldb, int K, int n, float alpha, float* dW, int ldw, float* db,
+                                      void* stream) {
+    hn::bwd::OuterGroup og;
+    og.add(A, lda, M, B, ldb, K, alpha, dW, ldw, db);
+    return og.launch(reinterpret_cast<hipStream_t>(stream), n);
+}

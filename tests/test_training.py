@@ -803,3 +803,33 @@ def test_train_loop_logs_checkpoints_and_resumes(tmp_path):
     n = training.train(r, [batch], 13, str(tmp_path), learning_rate=1e-3, learning_rate_alpha=0.1, warm_up_end=4, save_freq=5,
                        report_freq=2, is_continue=True, step_fn=fake_step)
     assert n == 13 and len(seen) == 3          # resumed at iteration 10
+
+
+@pytest.mark.gpu
+def test_outer_group_kernel_against_numpy():
+    """k_outer_group on its own (hn_debug_outer_product: one product dW += alpha A^T B, db += sum A): against float64 numpy on shapes with
+    ragged edges in every dimension -- 193 / 63 / 27 / 3 / 1 columns, sample counts that are no multiple of the 32-sample step or of a
+    slice, row pitches wider than the matrices -- and on operands spanning six decades (the three-way bf16 split has fp32's range).
+    The padding columns of dW stay untouched."""
+    import ctypes
+    from honerf_amd import lib as L
+    lib = L.load()
+    fn = lib.hn_debug_outer_product
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
+                   ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(3)
+    for (n, M, K, lda, ldb) in ((128, 256, 256, 256, 256), (1000, 193, 63, 256, 64), (4097, 256, 27, 256, 27), (50, 3, 256, 3, 256), (777, 1, 256, 1, 256),
+                                (56448, 256, 256, 256, 256), (33, 256, 1386, 256, 1388)):
+        A = torch.randn(n, lda, generator=gen) * torch.exp(torch.randn(n, 1, generator=gen) * 3.0)
+        B = torch.randn(n, ldb, generator=gen)
+        ref = 0.5 * (A[:, :M].double().T @ B[:, :K].double()).numpy()
+        refb = A[:, :M].double().sum(0).numpy()
+        Ad, Bd = A.to(dev).contiguous(), B.to(dev).contiguous()
+        dW, db = torch.zeros(M, K + 5, device=dev), torch.zeros(M, device=dev)
+        L.check(fn(L.ptr(Ad), lda, M, L.ptr(Bd), ldb, K, n, 0.5, L.ptr(dW), K + 5, L.ptr(db), L.stream_ptr()), 'hn_debug_outer_product')
+        torch.cuda.synchronize()
+        bounded('k_outer_group n=%d M=%d K=%d: dW vs float64' % (n, M, K), rel_err(dW[:, :K].cpu().double().numpy(), ref), 2e-6)
+        bounded('k_outer_group n=%d M=%d K=%d: db vs float64' % (n, M, K), rel_err(db.cpu().double().numpy(), refb), 2e-6)
+        assert float(dW[:, K:].abs().max()) == 0.0
