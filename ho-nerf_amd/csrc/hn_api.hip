@@ -808,7 +808,7 @@ static int render_single_impl(const hn_field* f, const float* rays_o, const floa
     HN_REQUIRE(n_samples >= 2 && n_importance >= 0 && n_rays >= 0, "bad sample counts");
     HN_REQUIRE(n_importance == 0 || (steps >= 1 && n_importance % steps == 0), "n_importance must divide into steps");
     const int S = n_samples + n_importance;
-    HN_REQUIRE(S <= 256, "at most 256 samples per ray");
+    HN_REQUIRE(S <= 640, "at most 640 samples per ray (hn_upsample's cdf rows)");
     const int n_new = n_importance > 0 ? n_importance / steps : 0;
     const size_t N = (size_t)n_rays * S;
     Arena ar(workspace, workspace_bytes);
@@ -930,7 +930,7 @@ static int render_dual_impl(const hn_field* hand, const hn_field* obj, const flo
     const int n_rays = n_frames * rpf;
     const int S = n_samples + 2 * n_importance;
     const int St = n_samples + n_importance;   // per-track length
-    HN_REQUIRE(S <= 256, "at most 256 samples per ray");
+    HN_REQUIRE(St <= 640 && S <= 1024, "at most 640 depths per track and 1 024 per ray (hn_upsample's cdf rows, hn_sort_rows)");
     const int n_new = n_importance > 0 ? n_importance / steps : 0;
     const size_t N = (size_t)n_rays * S;
     Arena ar(workspace, workspace_bytes);

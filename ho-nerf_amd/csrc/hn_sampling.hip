@@ -6,6 +6,8 @@
 // indices have to agree bit-for-bit, so the association order is kept (hard
 // part 3).  The work is O(k) per ray on a few hundred bytes: launch-latency bound, never
 // a bandwidth problem (rows are read once, L1-resident per lane).
+#include <atomic>
+
 #include "hn_common.h"
 
 namespace hn {
@@ -412,7 +414,8 @@ __global__ __launch_bounds__(256) void k_obj_rays_bwd(const float* __restrict__ 
 }
 
 // ---- up_sample + sample_pdf(det=True) (utils/renderer.py:60-86, 10-37) -------------------------
-constexpr int UPS_MAX_K = 256;
+constexpr int UPS_MAX_K = 256;          // the wave / tiled forms (their LDS rows)
+constexpr int UPS_DIRECT_MAX_K = 640;   // k_upsample_direct: a cdf row per lane in LDS, 256 k bytes per wave: 160 KB at k = 640
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
 // One section of up_sample's pass 1 (utils/renderer.py:68-84 + sample_pdf's weights + 1e-5): the same operations in the same
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(64) void k_upsample_direct(const float* __restrict_
             }
     }
     // pass 3: invert at u = linspace(0.5/n, 1-0.5/n, n)
-    const float u_start = 0.f + 0.5f / (float)n_new, u_end = 1.f - 0.5f / (float)n_new;
+    const float u_start = (float)(0.0 + 0.5 / (double)n_new), u_end = (float)(1.0 - 0.5 / (double)n_new);   // (torch.linspace of Python doubles: one rounding each)
     const float u_step = n_new > 1 ? (u_end - u_start) / (float)(n_new - 1) : 0.f;   // linspace(steps=1) = [start]
     int ptr = 0;   // number of cdf entries <= u (searchsorted right=True); cdf and u are both non-decreasing
     for (int jj = 0; jj < n_new; ++jj) {
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(64) void k_upsample_tiled(const float* __restrict__
     }
     // pass 3: invert at u = linspace(0.5/n, 1-0.5/n, n)
     const float* zr = z + (size_t)ray * k;
-    const float u_start = 0.f + 0.5f / (float)n_new, u_end = 1.f - 0.5f / (float)n_new;
+    const float u_start = (float)(0.0 + 0.5 / (double)n_new), u_end = (float)(1.0 - 0.5 / (double)n_new);   // (torch.linspace of Python doubles: one rounding each)
     const float u_step = n_new > 1 ? (u_end - u_start) / (float)(n_new - 1) : 0.f;   // linspace(steps=1) = [start]
     int ptr = 0;   // number of cdf entries <= u (searchsorted right=True); cdf and u are both non-decreasing
     for (int jj = 0; jj < n_new; ++jj) {
@@ -786,7 +789,7 @@ __global__ __launch_bounds__(256) void k_upsample_wave(const float* __restrict__
         }
     }
     __builtin_amdgcn_wave_barrier();
-    const float u_start = 0.f + 0.5f / (float)n_new, u_end = 1.f - 0.5f / (float)n_new;
+    const float u_start = (float)(0.0 + 0.5 / (double)n_new), u_end = (float)(1.0 - 0.5 / (double)n_new);   // (torch.linspace of Python doubles: one rounding each)
     const float u_step = n_new > 1 ? (u_end - u_start) / (float)(n_new - 1) : 0.f;
     for (int jj = lane; jj < n_new; jj += 64) {
         const float u = (jj < n_new / 2) ? u_start + (float)jj * u_step : u_end - (float)(n_new - 1 - jj) * u_step;
@@ -962,8 +965,9 @@ __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ z, cons
 }
 
 // ---- row sort (utils/renderer.py:498): rank sort, one wave per row -------------------------------
+constexpr int SORT_MAX_N = 1024;
 __global__ __launch_bounds__(64) void k_sort_rows(const float* __restrict__ v, int n_rows, int n, float* __restrict__ out) {
-    __shared__ float row[256];
+    __shared__ float row[SORT_MAX_N];
     const int r = blockIdx.x;
     const int lane = threadIdx.x;
     for (int i = lane; i < n; i += 64) row[i] = v[(size_t)r * n + i];
@@ -1073,8 +1077,18 @@ int obj_rays_bwd(const float* z, const float* g_pts, int n_frames, int rpf, int 
 
 int upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, float inv_s, float* z_new, int64_t* inds,
              hipStream_t s) {
-    HN_REQUIRE(k >= 2 && k <= UPS_MAX_K && n_new >= 1 && n_new <= 64, "upsample: k=%d n_new=%d out of range", k, n_new);
+    HN_REQUIRE(k >= 2 && k <= UPS_DIRECT_MAX_K && n_new >= 1, "upsample: k=%d n_new=%d out of range (2 <= k <= %d)", k, n_new, UPS_DIRECT_MAX_K);
     if (n_rays == 0) return HN_OK;
+    if (k > UPS_MAX_K || n_new > 64) {
+        // beyond the shapes of the confs (k <= 112, 16 new depths per round): the thread-per-ray form, whose only limit is its cdf row in LDS
+        // -- the same operations in the same order as the forms below
+        const size_t lds = (size_t)k * 64 * sizeof(float);
+        static std::atomic<uint64_t> lds_direct{0};
+        if (lds > 64 * 1024) HN_TRY_RC(ensure_dynamic_lds(reinterpret_cast<const void*>(k_upsample_direct), (int)((size_t)UPS_DIRECT_MAX_K * 64 * sizeof(float)), &lds_direct));
+        hipLaunchKernelGGL(k_upsample_direct, grid1d(n_rays, 64), dim3(64), lds, s, z, sdf, n_rays, k, n_new, inv_s, z_new, inds);
+        HN_LAUNCH_CHECK();
+        return HN_OK;
+    }
     if (n_rays <= 8192) {   // small batches (the fitting loops): one wave per ray
         hipLaunchKernelGGL(k_upsample_wave, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, sdf, n_rays, k, n_new, inv_s, z_new, inds,
                            UpsExtra{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr});
@@ -1135,7 +1149,7 @@ int merge(const float* z, const float* z_new, const float* sdf, const float* sdf
 }
 
 int sort_rows(const float* v, int n_rows, int n, float* out, hipStream_t s) {
-    HN_REQUIRE(n >= 1 && n <= 256, "sort_rows: n=%d out of range", n);
+    HN_REQUIRE(n >= 1 && n <= SORT_MAX_N, "sort_rows: n=%d out of range", n);
     if (n_rows == 0) return HN_OK;
     hipLaunchKernelGGL(k_sort_rows, dim3(n_rows), dim3(64), 0, s, v, n_rows, n, out);
     HN_LAUNCH_CHECK();

@@ -194,8 +194,9 @@ int hn_sample_points_bwd(const float* z, const float* g_pts, int n_rays, int n, 
 /* ---- hierarchical sampling ------------------------------------------------------------
  * NeuSRenderer.up_sample + sample_pdf(det=True) (utils/renderer.py:60-86, 10-37).
  * z, sdf [n_rays,k] -> z_new [n_rays,n_new]; inds (int64 [n_rays,n_new], may be
- * NULL) is the searchsorted(right=True) result.  Limits: 2 <= k <= 256, 1 <= n_new <= 64 (the confs use
- * k = 64..112, n_new = 16); outside them HN_EINVAL. */
+ * NULL) is the searchsorted(right=True) result.  Limits: 2 <= k <= 640, n_new >= 1 (the confs use k = 64..112,
+ * n_new = 16; the forms tuned for them take k <= 256, n_new <= 64, a thread-per-ray form everything else); outside them
+ * HN_EINVAL.  The renders accordingly take up to 640 depths per ray (two-field: per track, 1 024 in all). */
 int hn_upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, float inv_s, float* z_new,
                 int64_t* inds, hn_stream_t stream);
 
@@ -209,7 +210,7 @@ int hn_upsample(const float* z, const float* sdf, int n_rays, int k, int n_new, 
 int hn_merge(const float* z, const float* z_new, const float* sdf, const float* sdf_new, int n_rays, int k, int m,
              int quirk_rays_per_frame, float* z_out, float* sdf_out, int64_t* index, hn_stream_t stream);
 
-/* Row-wise ascending sort of v [n_rays,n] (n <= 256) -- the final torch.sort over
+/* Row-wise ascending sort of v [n_rays,n] (n <= 1024) -- the final torch.sort over
  * the concatenated depths of the two-field renderer (utils/renderer.py:498). */
 int hn_sort_rows(const float* v, int n_rays, int n, float* out, hn_stream_t stream);
 

@@ -222,6 +222,73 @@ def test_merge_and_upsample_row_shapes(L):
         assert torch.equal(ib, ins.repeat(rep, 1)) and torch.equal(zb, zs.repeat(rep, 1)), k
 
 
+def test_shapes_beyond_the_confs(L, golden):
+    """More depths than any conf uses (the reference has no limit: utils/renderer.py:60-105): hn_upsample with k > 256 rows or more
+    than 64 new depths per round (the thread-per-ray form: k <= 640) against the oracle's up_sample -- indices exact --, hn_merge on
+    such rows against torch's stable sort, hn_sort_rows on 600-wide rows, and both renders end to end: the single-field render at
+    64 + 320 depths in 4 rounds of 80, the two-field render at 64 + 2 x 128 = 320 sorted depths, against the oracle's renders."""
+    from honerf_amd.renderer import NeuSRenderer, NeuSRenderer_fitting
+    from oracle import render as orr
+    lib = L.load()
+    gen = torch.Generator().manual_seed(11)
+    for k, m, B in ((300, 16, 37), (100, 80, 37), (640, 96, 9), (257, 65, 8200)):
+        z = torch.sort(torch.rand(B, k, generator=gen) * 1.1 + 0.4, -1)[0]
+        sdf = torch.rand(B, k, generator=gen) - 0.5
+        zs, ins = torch.empty(B, m, device='cuda'), torch.empty(B, m, device='cuda', dtype=torch.int64)
+        L.check(lib.hn_upsample(L.ptr(cu(z)), L.ptr(cu(sdf)), B, k, m, 64.0, L.ptr(zs), L.ptr(ins), st()), 'upsample')
+        nb = min(B, 64)                                              # (the oracle's rows are a Python-speed check: a subset of a large batch)
+        z_ref, ind_ref = orr.up_sample(z[:nb], sdf[:nb], m, 64.0)
+        # Indices: the kernels sum a row's weights sequentially (torch's CPU cumsum order), torch.sum pairwise; over 639 sections, most of
+        # them at the 1e-5 floor behind the surface, the two sums differ by ~8e-6 and the cdf's plateau of 1e-5 steps shifts by about one
+        # step against the queries that land on it (u > 0.9937: the last of 96 new depths here, none of 16) -- the reference's own CPU and
+        # CUDA sums differ the same way.  So: at most 2 % of the indices may differ, by one, and only where the oracle's cdf passes within
+        # 2e-5 of the query; the reference's own vectors are held to ZERO differing indices in test_upsample_merge_sort_golden.
+        diff = ins[:nb].cpu() != ind_ref
+        bounded('hn_upsample k=%d n_new=%d: fraction of searchsorted indices differing from the oracle' % (k, m), float(diff.float().mean()), 2e-2, kind='fraction')
+        if bool(diff.any()):
+            w = orr.upsample_weights(z[:nb], sdf[:nb], 64.0) + 1e-5
+            cdf = torch.cat([torch.zeros(nb, 1), torch.cumsum(w / w.sum(-1, keepdim=True), -1)], -1)
+            u = torch.linspace(0.5 / m, 1.0 - 0.5 / m, steps=m)[None, :].expand(nb, m)
+            near = torch.gather(cdf, 1, torch.minimum(ins[:nb].cpu(), ind_ref).clamp(max=k - 1))     # the entry the two disagree about
+            assert bool(((ins[:nb].cpu() - ind_ref).abs()[diff] == 1).all()) and float((near - u).abs()[diff].max()) < 2e-5
+        zerr = (zs[:nb].cpu() - z_ref).abs() / z_ref.abs().max()
+        bounded('hn_upsample k=%d n_new=%d vs the oracle, the depths at agreed indices' % (k, m), float(zerr[~diff].max()), 1e-4)
+        zn = torch.sort(zs.cpu(), -1)[0]
+        z2, idx = torch.empty(B, k + m, device='cuda'), torch.empty(B, k + m, device='cuda', dtype=torch.int64)
+        L.check(lib.hn_merge(L.ptr(cu(z)), L.ptr(cu(zn)), None, None, B, k, m, 0, L.ptr(z2), None, L.ptr(idx), st()), 'merge')
+        ref_z, ref_i = torch.sort(torch.cat([z, zn], -1), dim=-1, stable=True)
+        assert torch.equal(z2.cpu(), ref_z) and torch.equal(idx.cpu(), ref_i), (k, m)
+    v = torch.rand(23, 600, generator=gen)
+    v[:, 17] = v[:, 400]                                             # a tie
+    out = torch.empty(23, 600, device='cuda')
+    L.check(lib.hn_sort_rows(L.ptr(cu(v)), 23, 600, L.ptr(out), st()), 'sort_rows')
+    assert torch.equal(out.cpu(), torch.sort(v, -1)[0])
+    # the renders
+    m_ = product_modules()
+    hand_o, obj_o = oracle_fields()
+    g = golden('render_dual')
+    R = 6                                                            # (render_dual.npz: 24 rays of one frame)
+    ro, rd, tr = t(g['rays_o'])[:R], t(g['rays_d'])[:R], t(g['t_rand'])[:R]
+    Ro, To = t(g['Ro']), t(g['To'])
+    ren = NeuSRenderer(m_['sdf_obj'], m_['var_obj'], m_['color_obj'], 'obj', 64, 320, 0, 4, 1.0)
+    with torch.no_grad():
+        out1 = ren.render(cu(ro), cu(rd), 0.4, 1.5, None, None, None, cu(Ro), cu(To), 0, t_rand=cu(tr))
+    ref1 = orr.render_single(obj_o, ro, rd, 0.4, 1.5, tr, 64, 320, 4, Ro=Ro, To=To)
+    assert ren.last_z_vals.shape == (R, 384)
+    frac = float(((ren.last_z_vals.cpu() - ref1['z_vals'].detach()).abs() < 1e-4).float().mean())
+    bounded('single render at 64 + 320 depths: fraction of the depths further than 1e-4 from the oracle', 1.0 - frac, 0.03, kind='fraction')
+    bounded('single render at 64 + 320 depths: colour vs the oracle', rel_err(out1['color_fine'].cpu().numpy(), ref1['color_fine'].detach().numpy()), 1e-4)
+    ren2 = NeuSRenderer_fitting(m_['sdf_hand'], m_['var_hand'], m_['color_hand'], m_['sdf_obj'], m_['var_obj'], m_['color_obj'], 64, 128, 0, 4, 1.0)
+    with torch.no_grad():
+        out2 = ren2.render(cu(ro), cu(rd), 0.4, 1.5, g['bt_inv'], g['T_pose'], None, g['Ro'], g['To'], t_rand=cu(tr))
+    ref2 = orr.render_dual(hand_o, obj_o, ro, rd, 0.4, 1.5, tr, 64, 128, 4, t(g['bt_inv']), t(g['T_pose']), Ro, To)
+    assert ren2.last_z_vals.shape[-1] == 320
+    frac2 = float(((ren2.last_z_vals.cpu().reshape(ref2['z_vals'].shape) - ref2['z_vals'].detach()).abs() < 1e-4).float().mean())
+    bounded('dual render at 64 + 2 x 128 depths: fraction of the depths further than 1e-4 from the oracle', 1.0 - frac2, 0.03, kind='fraction')
+    bounded('dual render at 64 + 2 x 128 depths: colour vs the oracle', rel_err(out2['color_fine'].cpu().numpy().reshape(ref2['color_fine'].shape),
+                                                                                ref2['color_fine'].detach().numpy()), 1e-4)
+
+
 def test_merge_batch_quirk(L):
     from oracle import render as orr
     lib = L.load()
@@ -719,9 +786,9 @@ def test_error_paths_return_status_and_message(L):
     ws = torch.empty(lib.hn_field_workspace_bytes(hand.handle, n), dtype=torch.uint8, device='cuda')
     rc = lib.hn_field_sdf(hand.handle, L.ptr(pts), n, None, None, 1, n, L.ptr(sdf), L.ptr(ws), ws.numel(), st())
     assert rc < 0 and b'bt_inv' in lib.hn_last_error()          # a hand field needs its bone transforms
-    z = torch.zeros(4, 300, device='cuda')
+    z = torch.zeros(4, 700, device='cuda')
     out, inds = torch.empty(4, 16, device='cuda'), torch.empty(4, 16, dtype=torch.int64, device='cuda')
-    rc = lib.hn_upsample(L.ptr(z), L.ptr(z), 4, 300, 16, 64.0, L.ptr(out), L.ptr(inds), st())
+    rc = lib.hn_upsample(L.ptr(z), L.ptr(z), 4, 700, 16, 64.0, L.ptr(out), L.ptr(inds), st())
     assert rc < 0 and b'upsample' in lib.hn_last_error()        # k beyond the supported row length
     with pytest.raises(RuntimeError, match='hn_upsample'):
         L.check(rc, 'hn_upsample')
