@@ -139,7 +139,7 @@ def _grad_worker(rank, world, port, q):
                 for p in pose:
                     p -= 0.1 * p.grad
             log.append(n)
-        q.put((rank, [p.detach().clone() for p in pose], log))
+        q.put((rank, [p.detach().numpy().copy() for p in pose], log))     # (numpy: a tensor would travel as a file descriptor this process must outlive)
     finally:
         dist.destroy_process_group()
 
@@ -160,6 +160,7 @@ def test_window_parallel_gradient_allreduce_keeps_replicas_identical():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, pose0, log0), (_, pose1, log1) = res
+    pose0, pose1 = [torch.from_numpy(x) for x in pose0], [torch.from_numpy(x) for x in pose1]
     assert log0 == log1 and all(n == 9 * 29 for n in log0)
     for a, b in zip(pose0, pose1):
         assert torch.equal(a, b)
