@@ -785,6 +785,15 @@ static int kept_count_send(const void* block, const int* n_dev, hipStream_t s) {
     HN_CHECK_HIP(hipEventRecord(e.ev, s));
     return HN_OK;
 }
+static void kept_counts_release() {
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_kept_mu);
+    for (auto& kv : g_kept) {
+        if (kv.second.ev != nullptr) (void)hipEventDestroy(kv.second.ev);
+        if (kv.second.host != nullptr) (void)hipHostFree(kv.second.host);
+    }
+    g_kept.clear();
+}
 static bool kept_count_take(const void* block, int* n_c) {   // false: no count was sent for this block
     KeptCount e;
     {
@@ -1664,7 +1673,10 @@ int hn_field_eval_bwd(const hn_field* f, const float* pts, const float* rays_d, 
                                    g_rgb, g_pts, g_rays_d, g_bt_inv, g_T_pose, workspace, workspace_bytes,
                                    reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, nullptr);
 }
-size_t hn_release_cached_memory(void) { return hn::pool_trim(); }
+size_t hn_release_cached_memory(void) {
+    hn::kept_counts_release();   // (the pinned words and events of hn_render_single_taped's counts: pool_trim synchronises the device first)
+    return hn::pool_trim();
+}
 int hn_weight_norm_bwd(const hn_field* f, const hn_mlp_desc* sdf, const hn_mlp_desc* color, const float* g_params,
                        const hn_mlp_desc* g_sdf, const hn_mlp_desc* g_color, hn_stream_t stream) {
     return hn::bwd::weight_norm_bwd(f, sdf, color, g_params, g_sdf, g_color, reinterpret_cast<hipStream_t>(stream));
