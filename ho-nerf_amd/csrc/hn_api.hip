@@ -775,6 +775,18 @@ static std::mutex g_kept_mu;
 static std::unordered_map<const void*, KeptCount> g_kept;
 static int kept_count_send(const void* block, const int* n_dev, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_kept_mu);
+    // (blocks come and go with the caller's allocator: beyond 256 entries the ones whose copy has landed long ago are dropped --
+    // a backward pass that still wanted one reads its count back itself)
+    if (g_kept.size() >= 256 && g_kept.find(block) == g_kept.end()) {
+        for (auto it = g_kept.begin(); it != g_kept.end();) {
+            if (hipEventQuery(it->second.ev) == hipSuccess) {
+                (void)hipEventDestroy(it->second.ev);
+                (void)hipHostFree(it->second.host);
+                it = g_kept.erase(it);
+            } else
+                ++it;
+        }
+    }
     KeptCount& e = g_kept[block];
     if (e.host == nullptr) {
         HN_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&e.host), sizeof(int), hipHostMallocDefault));
@@ -795,13 +807,10 @@ static void kept_counts_release() {
     g_kept.clear();
 }
 static bool kept_count_take(const void* block, int* n_c) {   // false: no count was sent for this block
-    KeptCount e;
-    {
-        std::lock_guard<std::mutex> lk(g_kept_mu);
-        auto it = g_kept.find(block);
-        if (it == g_kept.end()) return false;
-        e = it->second;
-    }
+    std::lock_guard<std::mutex> lk(g_kept_mu);   // (held over the wait: the entry must not be dropped under it; the copy landed long ago)
+    auto it = g_kept.find(block);
+    if (it == g_kept.end()) return false;
+    const KeptCount& e = it->second;
     if (hipEventSynchronize(e.ev) != hipSuccess || *e.host < 0) return false;
     *n_c = *e.host;
     return true;
