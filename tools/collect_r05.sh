@@ -9,6 +9,7 @@ cp $O/csrc_sha16.txt $O/parity_report.json $O/frames_side_by_side.txt $O/host_ti
    $O/seq_repro_jacobian_first.txt $O/seq_repro_shipped.txt $O/bench_2ranks_one_gpu_gloo_functional.json $O/pmc_bench_field2_hand_full_r05.json \
    $O/train_step_obj_kernel_stats.csv $O/train_step_hand_kernel_stats.csv $O/train_fused_ab_obj.txt $O/train_fused_ab_hand.txt \
    $O/train_grad_ab_obj.txt $O/train_grad_ab_hand.txt $O/outer_group_parts.txt $O/train_soak_hand.txt $O/train_soak_obj.txt $P/
+cp $O/pmc_train_*.json $P/
 grep '^{' $O/bench_line.json | tail -1 > $P/bench_r05_line.json
 cp gpurun_out/prof_r05/kernel_stats.csv $P/bench_r05_kernel_stats.csv
 for f in busy_idle.txt kernel_stats.csv timeline.txt timeline_all.txt; do

@@ -20,6 +20,10 @@ mkdir -p profiles/r05 && cp $O/pmc_bench_field2_hand_full_r05.json profiles/r05/
 # the training iteration: kernel stats per field kind, the fused parameter-gradient path beside the generic sequence
 timeout 400 bash tools/profile_train.sh r05_obj obj > $O/profile_train_obj.log 2>&1
 timeout 400 bash tools/profile_train.sh r05_hand hand > $O/profile_train_hand.log 2>&1
+timeout 400 bash tools/profile_train.sh r05_hand_dense hand_dense > $O/profile_train_hand_dense.log 2>&1
+# (PMC summaries of the backward pass's two kernels: train_step_bench.py / bench.py quote roofline_hbm.traffic from them when the source hash matches)
+for k in k_outer_group k_field2_obj5 k_field2_obj3; do cp gpurun_out/prof_train_r05_obj/pmc_$k.json $O/pmc_train_obj_$k.json; cp $O/pmc_train_obj_$k.json profiles/r05/; done
+for k in k_outer_group k_field2_hand5 k_field2_hand3; do cp gpurun_out/prof_train_r05_hand_dense/pmc_$k.json $O/pmc_train_hand_dense_$k.json; cp $O/pmc_train_hand_dense_$k.json profiles/r05/; done
 cp gpurun_out/prof_train_r05_obj/kernel_stats.csv $O/train_step_obj_kernel_stats.csv
 cp gpurun_out/prof_train_r05_hand/kernel_stats.csv $O/train_step_hand_kernel_stats.csv
 (timeout 300 python tools/train_fused_ab.py 56448 obj 2>&1 | grep -v amdgpu > $O/train_fused_ab_obj.txt)

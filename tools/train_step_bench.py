@@ -138,6 +138,7 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3', compac
         hbm_bytes = n_rays * S * per_sample + tape_b
         roof_hbm = {'bound': 'hbm', 'what': 'backward pass, algorithmic bytes: signals written + tape read + operands of the outer products read (dense sample count)',
                     'bytes_per_step': hbm_bytes, 'achieved': hbm_bytes / bwd_s / 1e9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': hbm_bytes / bwd_s / 1e9 / 8000.0}
+        roof_hbm['traffic'], roof_hbm['traffic_note'] = train_kernel_traffic(kind if (compact or kind == 'obj') else kind + '_dense', kind)
     if compact and kind == 'hand':      # the work of the aggregated iteration depends on the batch's live fraction: priced in `hand_dense`
         roof = {'note': 'far-field aggregation on: fewer samples than the dense FLOP count assumes; the roofline entry is on the dense iteration (hand_dense)'}
         roof_hbm = None
@@ -147,6 +148,30 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3', compac
             'parts_ms': {k: round(v / steps, 3) for k, v in parts.items()}, 'loss': float(terms['loss'].detach()), 'precision': precision,
             # samples the hand adjoint dropped (out of the fp16 fragments' range next to a bone's origin) over all %d iterations of this leg
             'dropped_samples': _L.dropped_samples(), 'dropped_samples_of': (warmup + 2 * steps) * n_rays * S}
+
+
+def train_kernel_traffic(tag, kind):
+    """HBM-side bytes per backward pass of its two kernels (k_field2_<kind><5> once, k_outer_group as often as the pass launches it), from the
+    committed PMC summaries of tools/profile_train.sh (profiles/r*/pmc_train_<kind>_*.json: FETCH_SIZE / WRITE_SIZE in separate --pmc passes,
+    FETCH_SIZE doubled for gfx950) -- quoted only if collected on the kernel sources of this tree.  -> (bytes or None, note)"""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import srchash
+    now = srchash.source_hash()
+    dirs = sorted(d for d in glob.glob(os.path.join(ROOT, 'profiles', 'r*')) if os.path.exists(os.path.join(d, 'pmc_train_%s_k_outer_group.json' % tag)))
+    if not dirs:
+        return None, 'no PMC summary of the training kernels is committed'
+    try:
+        adj = json.load(open(os.path.join(dirs[-1], 'pmc_train_%s_k_field2_%s5.json' % (tag, kind))))
+        out = json.load(open(os.path.join(dirs[-1], 'pmc_train_%s_k_outer_group.json' % tag)))
+    except Exception:
+        return None, 'incomplete PMC summaries in %s' % os.path.relpath(dirs[-1], ROOT)
+    if adj.get('csrc_sha16') != now or out.get('csrc_sha16') != now:
+        return None, 'STALE: %s was collected on kernel sources %s, this tree is %s' % (os.path.relpath(dirs[-1], ROOT), adj.get('csrc_sha16'), now)
+    per_pass = out['dispatches']['FETCH_SIZE'] / float(adj['dispatches']['FETCH_SIZE'])     # k_outer_group launches per backward pass
+    a_b, o_b = adj['derived']['hbm_bytes_per_launch'], out['derived']['hbm_bytes_per_launch'] * per_pass
+    return a_b + o_b, ('k_field2_%s<5> %.3g + k_outer_group %.3g bytes per backward pass (%.3g launches of %.3g), '
+                       '%s, csrc_sha16 %s' % (kind, a_b, o_b, per_pass, out['derived']['hbm_bytes_per_launch'], os.path.relpath(dirs[-1], ROOT), now))
 
 
 def main():
@@ -161,7 +186,7 @@ def main():
     dev = torch.device('cuda:0')
     lines = []
     for kind in a.kinds.split(','):
-        line = measure(kind, dev, a.rays, a.steps, a.warmup, a.precision)
+        line = measure(kind.split('_')[0], dev, a.rays, a.steps, a.warmup, a.precision, compact=not kind.endswith('_dense'))
         print(json.dumps(line))
         lines.append(line)
     if a.out:
