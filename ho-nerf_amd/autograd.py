@@ -260,11 +260,13 @@ class FitLossFn(torch.autograd.Function):
 _LOSS_SCRATCH = {}
 
 
-def _loss_scratch(lib, n_rays, n_samples, dev):
+def _loss_scratch(lib, n_rays, n_samples, dev, frames=1):
     """The partial-sum slots + counter of hn_fit_step_loss: zeroed once, every launch leaves it ready for the next.  One per
-    (device, stream): steps of two streams must not share a counter."""
-    need = max(lib.hn_fit_step_loss_scratch_bytes(n_rays, n_samples), lib.hn_window_loss_scratch_bytes(n_rays, n_samples))   # (one buffer serves both)
-    key = (str(dev), torch.cuda.current_stream().cuda_stream)
+    (device, stream): steps of two streams must not share a counter.  frames > 1: that many frames' slots behind one another
+    (hn_fit_step_loss_frames) -- a buffer of its own per layout, because frame f's counter sits where another layout keeps sums."""
+    per_frame = lib.hn_fit_step_loss_scratch_bytes(n_rays, n_samples)
+    need = max(per_frame * int(frames), lib.hn_window_loss_scratch_bytes(n_rays, n_samples))   # (one buffer serves both)
+    key = (str(dev), torch.cuda.current_stream().cuda_stream) + ((int(frames), int(per_frame)) if frames > 1 else ())
     buf = _LOSS_SCRATCH.get(key)
     if buf is None or buf.numel() < need:
         buf = _LOSS_SCRATCH[key] = torch.zeros(int(need), dtype=torch.uint8, device=dev)

@@ -75,6 +75,11 @@ int fit_step_loss(const float*, const float*, const float*, const float*, int, c
                   const float*, const float*, const float*, const float*, int, const float*, void*, size_t, float*, float*, float*, float*, float*, hipStream_t);
 int fit_step_loss_bwd(const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*, const float*,
                       const float*, const float*, const float*, int, float*, float*, float*, float*, float*, float*, float*, hipStream_t);
+int fit_step_loss_frames(int, const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*, int,
+                         const float*, const float*, const float*, const float*, const float* const*, const int*, const float*, void*, size_t, float*, float*,
+                         float*, float*, float*, hipStream_t);
+int fit_step_loss_bwd_frames(int, const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*,
+                             const float*, const float*, const float*, const float*, int, float*, float*, float*, float*, float*, float*, float*, hipStream_t);
 int fit_loss_sums(const float*, const float*, const float*, const float*, int, const float*, const float*, int, float*, hipStream_t);
 int fit_total(const float*, const float*, const float*, const float*, int, const float*, float*, float*, hipStream_t);
 int adam_step(int, float* const*, const float* const*, float* const*, float* const*, const int*, const float*, float, float, float, const int*, hipStream_t);
@@ -1944,6 +1949,23 @@ int hn_fit_step_loss_bwd(const float* color, const float* weight_sum, const floa
                          float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream) {
     return hn::fit_step_loss_bwd(color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, sums6, g_loss, weights5, g_joint, gR, gt,
                                  n_joints, g_color, g_weight_sum, g_sdf_hand, g_sdf_obj, g_joint_out, gR_out, gt_out, (hipStream_t)stream);
+}
+int hn_fit_step_loss_frames(int n_frames, const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays,
+                            const float* sdf_hand, const float* sdf_obj, int n_samples, const float* joint_3d, const float* joint3d_pred, int n_joints,
+                            const float* Ra, const float* ta, const float* Rb, const float* tb, const float* const* verts, const int* n_verts,
+                            const float* weights5, void* scratch, size_t scratch_bytes, float* sums6, float* terms8, float* g_joint, float* gR, float* gt,
+                            hn_stream_t stream) {
+    return hn::fit_step_loss_frames(n_frames, color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, joint_3d, joint3d_pred, n_joints,
+                                    Ra, ta, Rb, tb, verts, n_verts, weights5, scratch, scratch_bytes, sums6, terms8, g_joint, gR, gt, (hipStream_t)stream);
+}
+int hn_fit_step_loss_bwd_frames(int n_frames, const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays,
+                                const float* sdf_hand, const float* sdf_obj, int n_samples, const float* sums6, const float* g_loss,
+                                const float* weights5, const float* g_joint, const float* gR, const float* gt, int n_joints, float* g_color,
+                                float* g_weight_sum, float* g_sdf_hand, float* g_sdf_obj, float* g_joint_out, float* gR_out, float* gt_out,
+                                hn_stream_t stream) {
+    return hn::fit_step_loss_bwd_frames(n_frames, color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, sums6, g_loss, weights5,
+                                        g_joint, gR, gt, n_joints, g_color, g_weight_sum, g_sdf_hand, g_sdf_obj, g_joint_out, gR_out, gt_out,
+                                        (hipStream_t)stream);
 }
 int hn_fit_total_bwd(const float* g_loss, const float* weights5, const float* g_joint, const float* gR, const float* gt, int n_joints,
                      float* g4, float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream) {

@@ -1079,23 +1079,42 @@ int fit_total_bwd(const float* g_loss, const float* w5, const float* g_joint, co
     return HN_OK;
 }
 
+constexpr int FIT_LOSS_MAX_FRAMES = 16;
 // ---- the whole loss of a fitting_single step as ONE launch forward and ONE backward (fitting_single.py:251-288) -------------
 // Forward (k_fit_step_loss): every block reduces its share of the six sums of k_fit_loss_sums to a slot of `partials`; the block
 // that finishes last (a counter it resets for the next call) adds the slots IN INDEX ORDER -- the sums do not depend on the order
 // the blocks ran in: two runs of a step give the same loss terms bit for bit -- and goes on to the vertex loss (k_verts_loss's
 // statements for one pose pair), the joint loss and the weighted total (k_fit_total's).  As separate launches (memset, sums,
 // vertex loss, total) it was four links of the dependent-launch chain between the render and its backward pass.
+// Several frames in one launch (blockIdx.y = frame): every frame is its own problem -- its own blocks, slots, counter and last block,
+// the arithmetic and the order of every sum those of a one-frame launch on that frame's planes (frame f of every per-frame array: base +
+// f x its width; the object's vertices per frame through FrameVerts).
+struct FrameVerts {
+    const float* p[FIT_LOSS_MAX_FRAMES];
+    int n[FIT_LOSS_MAX_FRAMES];
+};
 __global__ __launch_bounds__(256) void k_fit_step_loss(const float* __restrict__ color, const float* __restrict__ wsum, const float* __restrict__ true_rgb,
                                                        const float* __restrict__ true_mask, int n_rays, const float* __restrict__ sdf_h,
                                                        const float* __restrict__ sdf_o, int n_samples, const float* __restrict__ joint_3d,
                                                        const float* __restrict__ joint_pred, int n_joints, const float* __restrict__ Ra,
                                                        const float* __restrict__ ta, const float* __restrict__ Rb, const float* __restrict__ tb,
-                                                       const float* __restrict__ verts, int n_verts, float w0, float w1, float w2, float w3, float w4,
-                                                       float* __restrict__ partials, unsigned* __restrict__ counter, float* __restrict__ pose2,
+                                                       const FrameVerts fv, float w0, float w1, float w2, float w3, float w4,
+                                                       float* __restrict__ scratch, int scratch_floats,
                                                        float* __restrict__ sums6, float* __restrict__ terms8, float* __restrict__ g_joint,
                                                        float* __restrict__ gR, float* __restrict__ gt) {
     __shared__ float red[13][4];
     __shared__ bool is_last;
+    const int fr = blockIdx.y;
+    color += 3 * (size_t)fr * n_rays, true_rgb += 3 * (size_t)fr * n_rays, wsum += (size_t)fr * n_rays, true_mask += (size_t)fr * n_rays;
+    if (sdf_h != nullptr) sdf_h += (size_t)fr * n_samples, sdf_o += (size_t)fr * n_samples;
+    joint_3d += 3 * fr * n_joints, joint_pred += 3 * fr * n_joints, g_joint += 3 * fr * n_joints;
+    Ra += 9 * fr, Rb += 9 * fr, ta += 3 * fr, tb += 3 * fr, gR += 9 * fr, gt += 3 * fr, sums6 += 6 * fr, terms8 += 8 * fr;
+    const float* __restrict__ verts = fv.p[fr];
+    const int n_verts = fv.n[fr];
+    scratch += (size_t)fr * scratch_floats;
+    float* __restrict__ partials = scratch + 16;
+    unsigned* __restrict__ counter = reinterpret_cast<unsigned*>(scratch);
+    float* __restrict__ pose2 = scratch + 4;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1237,6 +1256,11 @@ __global__ __launch_bounds__(256) void k_fit_step_loss_bwd(const float* __restri
                                                            float* __restrict__ g_sdf_h, float* __restrict__ g_sdf_o, float* __restrict__ g_joint_out,
                                                            float* __restrict__ gR_out, float* __restrict__ gt_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int fr = blockIdx.y;      // (frame f of every per-frame array: base + f x its width; g_loss is the one upstream scalar)
+    color += 3 * (size_t)fr * n_rays, true_rgb += 3 * (size_t)fr * n_rays, wsum += (size_t)fr * n_rays, true_mask += (size_t)fr * n_rays;
+    g_color += 3 * (size_t)fr * n_rays, g_wsum += (size_t)fr * n_rays;
+    if (sdf_h != nullptr) sdf_h += (size_t)fr * n_samples, sdf_o += (size_t)fr * n_samples, g_sdf_h += (size_t)fr * n_samples, g_sdf_o += (size_t)fr * n_samples;
+    sums += 6 * fr, g_joint += 3 * fr * n_joints, g_joint_out += 3 * fr * n_joints, gR += 9 * fr, gt += 3 * fr, gR_out += 9 * fr, gt_out += 3 * fr;
     const float gl = g_loss[0];
     const float g0 = gl * w0, g1 = gl * w0 * 0.5f, g2 = gl * w1, g3 = gl * w2;
     if (blockIdx.x == 0) {
@@ -1270,23 +1294,54 @@ size_t fit_step_loss_scratch_bytes(int n_rays, int n_samples) {
     const int n = n_rays > n_samples ? n_rays : n_samples;
     return ((size_t)((n + 255) / 256 + 1) * 6 + 16) * sizeof(float);
 }
+int fit_step_loss_frames(int n_frames, const float* color, const float* wsum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_h,
+                         const float* sdf_o, int n_samples, const float* joint_3d, const float* joint_pred, int n_joints, const float* Ra, const float* ta,
+                         const float* Rb, const float* tb, const float* const* verts, const int* n_verts, const float* w5, void* scratch, size_t scratch_bytes,
+                         float* sums6, float* terms8, float* g_joint, float* gR, float* gt, hipStream_t s) {
+    HN_REQUIRE(color && wsum && true_rgb && true_mask && joint_3d && joint_pred && Ra && ta && Rb && tb && verts && n_verts && w5 && scratch && sums6 &&
+                   terms8 && g_joint && gR && gt,
+               "fit_step_loss: null argument");
+    HN_REQUIRE(n_frames >= 1 && n_frames <= FIT_LOSS_MAX_FRAMES, "fit_step_loss: 1 .. %d frames per launch", FIT_LOSS_MAX_FRAMES);
+    HN_REQUIRE(n_rays >= 1 && (sdf_h == nullptr) == (sdf_o == nullptr) && n_joints >= 1 && n_joints <= 64, "fit_step_loss: bad sizes");
+    const int ns = sdf_h != nullptr ? n_samples : 0;
+    const size_t per_frame = fit_step_loss_scratch_bytes(n_rays, ns);
+    HN_REQUIRE(scratch_bytes >= per_frame * (size_t)n_frames, "fit_step_loss: scratch too small");
+    FrameVerts fv{};
+    for (int f = 0; f < n_frames; ++f) {
+        HN_REQUIRE(verts[f] != nullptr && n_verts[f] >= 1, "fit_step_loss: the vertices of frame %d", f);
+        fv.p[f] = verts[f];
+        fv.n[f] = n_verts[f];
+    }
+    const int n = n_rays > ns ? n_rays : ns;
+    const int blocks = (n + 255) / 256;
+    // (per frame: counter at float 0 -- zero when the scratch is first handed over, every launch leaves it zero --, pose part at 4, slots at 16)
+    hipLaunchKernelGGL(k_fit_step_loss, dim3(blocks, n_frames), dim3(256), 0, s, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o, ns, joint_3d,
+                       joint_pred, n_joints, Ra, ta, Rb, tb, fv, w5[0], w5[1], w5[2], w5[3], w5[4], reinterpret_cast<float*>(scratch),
+                       (int)(per_frame / sizeof(float)), sums6, terms8, g_joint, gR, gt);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
 int fit_step_loss(const float* color, const float* wsum, const float* true_rgb, const float* true_mask, int n_rays, const float* sdf_h, const float* sdf_o,
                   int n_samples, const float* joint_3d, const float* joint_pred, int n_joints, const float* Ra, const float* ta, const float* Rb,
                   const float* tb, const float* verts, int n_verts, const float* w5, void* scratch, size_t scratch_bytes, float* sums6, float* terms8,
                   float* g_joint, float* gR, float* gt, hipStream_t s) {
-    HN_REQUIRE(color && wsum && true_rgb && true_mask && joint_3d && joint_pred && Ra && ta && Rb && tb && verts && w5 && scratch && sums6 && terms8 &&
-                   g_joint && gR && gt,
-               "fit_step_loss: null argument");
-    HN_REQUIRE(n_rays >= 1 && (sdf_h == nullptr) == (sdf_o == nullptr) && n_joints >= 1 && n_joints <= 64 && n_verts >= 1, "fit_step_loss: bad sizes");
+    return fit_step_loss_frames(1, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o, n_samples, joint_3d, joint_pred, n_joints, Ra, ta, Rb, tb, &verts,
+                                &n_verts, w5, scratch, scratch_bytes, sums6, terms8, g_joint, gR, gt, s);
+}
+int fit_step_loss_bwd_frames(int n_frames, const float* color, const float* wsum, const float* true_rgb, const float* true_mask, int n_rays,
+                             const float* sdf_h, const float* sdf_o, int n_samples, const float* sums6, const float* g_loss, const float* w5,
+                             const float* g_joint, const float* gR, const float* gt, int n_joints, float* g_color, float* g_wsum, float* g_sdf_h,
+                             float* g_sdf_o, float* g_joint_out, float* gR_out, float* gt_out, hipStream_t s) {
+    HN_REQUIRE(color && wsum && true_rgb && true_mask && sums6 && g_loss && w5 && g_joint && gR && gt && g_color && g_wsum && g_joint_out && gR_out && gt_out,
+               "fit_step_loss_bwd: null argument");
+    HN_REQUIRE(n_frames >= 1 && n_frames <= FIT_LOSS_MAX_FRAMES, "fit_step_loss_bwd: 1 .. %d frames per launch", FIT_LOSS_MAX_FRAMES);
+    HN_REQUIRE(sdf_h == nullptr || (sdf_o && g_sdf_h && g_sdf_o), "sdf gradients need both fields");
     const int ns = sdf_h != nullptr ? n_samples : 0;
-    HN_REQUIRE(scratch_bytes >= fit_step_loss_scratch_bytes(n_rays, ns), "fit_step_loss: scratch too small");
     const int n = n_rays > ns ? n_rays : ns;
-    const int blocks = (n + 255) / 256;
-    float* partials = reinterpret_cast<float*>(scratch) + 16;
-    unsigned* counter = reinterpret_cast<unsigned*>(scratch);   // zero when the scratch is first handed over; every launch leaves it zero
-    hipLaunchKernelGGL(k_fit_step_loss, dim3(blocks), dim3(256), 0, s, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o, ns, joint_3d, joint_pred,
-                       n_joints, Ra, ta, Rb, tb, verts, n_verts, w5[0], w5[1], w5[2], w5[3], w5[4], partials, counter, reinterpret_cast<float*>(scratch) + 4,
-                       sums6, terms8, g_joint, gR, gt);
+    if (n <= 0) return HN_OK;
+    hipLaunchKernelGGL(k_fit_step_loss_bwd, dim3((n + 255) / 256, n_frames), dim3(256), 0, s, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o, ns,
+                       sums6, g_loss, w5[0], w5[1], w5[2], w5[3], w5[4], g_joint, gR, gt, n_joints, g_color, g_wsum, g_sdf_h, g_sdf_o, g_joint_out, gR_out,
+                       gt_out);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
@@ -1294,16 +1349,8 @@ int fit_step_loss_bwd(const float* color, const float* wsum, const float* true_r
                       const float* sdf_o, int n_samples, const float* sums6, const float* g_loss, const float* w5, const float* g_joint, const float* gR,
                       const float* gt, int n_joints, float* g_color, float* g_wsum, float* g_sdf_h, float* g_sdf_o, float* g_joint_out, float* gR_out,
                       float* gt_out, hipStream_t s) {
-    HN_REQUIRE(color && wsum && true_rgb && true_mask && sums6 && g_loss && w5 && g_joint && gR && gt && g_color && g_wsum && g_joint_out && gR_out && gt_out,
-               "fit_step_loss_bwd: null argument");
-    HN_REQUIRE(sdf_h == nullptr || (sdf_o && g_sdf_h && g_sdf_o), "sdf gradients need both fields");
-    const int ns = sdf_h != nullptr ? n_samples : 0;
-    const int n = n_rays > ns ? n_rays : ns;
-    if (n <= 0) return HN_OK;
-    hipLaunchKernelGGL(k_fit_step_loss_bwd, dim3((n + 255) / 256), dim3(256), 0, s, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o, ns, sums6, g_loss,
-                       w5[0], w5[1], w5[2], w5[3], w5[4], g_joint, gR, gt, n_joints, g_color, g_wsum, g_sdf_h, g_sdf_o, g_joint_out, gR_out, gt_out);
-    HN_LAUNCH_CHECK();
-    return HN_OK;
+    return fit_step_loss_bwd_frames(1, color, wsum, true_rgb, true_mask, n_rays, sdf_h, sdf_o, n_samples, sums6, g_loss, w5, g_joint, gR, gt, n_joints,
+                                    g_color, g_wsum, g_sdf_h, g_sdf_o, g_joint_out, gR_out, gt_out, s);
 }
 
 }  // namespace hn

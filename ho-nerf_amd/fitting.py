@@ -839,7 +839,7 @@ class PipelinedSingleFit:
     poses, per-frame losses with fitting_single's own normalisation, element-wise Adam over [F, .] leaf blocks.  Nothing a frame
     computes depends on its batch partners, to the BIT: per-ray / per-sample kernels do not look across rays, the hand's compacted
     list is frame-aligned (hn_api.hip, k_hand_compact_write), every sum over a frame's samples is formed from that frame's own tiles
-    in an order relative to its first one (k_pose_part_reduce, k_obj_rays_bwd), and the loss kernels run once per frame
+    in an order relative to its first one (k_pose_part_reduce, k_obj_rays_bwd), and the loss kernels give every frame its own blocks and sums
     (tests/test_gpu_surface.py::test_sharded_frames_do_not_depend_on_the_sharding_nor_on_the_batch_partners).
 
     Call `finish()` before reading the parameters from another stream (or synchronise the device): the object's leaves are
@@ -939,6 +939,7 @@ class PipelinedSingleFit:
         self.hand_params = [getattr(ch, k) for k in self.HAND_LEAVES]
         self.obj_params = [getattr(ch, k) for k in self.OBJ_LEAVES]
         self.verts = [ch.obj_verts] * Fr if getattr(ch, 'obj_verts_per_frame', None) is None else list(ch.obj_verts_per_frame)
+        self._verts_p = self._verts_n = None     # (host arrays of the frames' vertex pointers / counts, made at the first step)
         # whatever the caller's stream has queued so far (the leaves' initial values, earlier steps through autograd) comes first
         L.check(self.lib.hn_stream_wait(self.side_ptr, L.stream_ptr()), 'hn_stream_wait')
 
@@ -1043,30 +1044,28 @@ class PipelinedSingleFit:
                                    L.ptr(self.gerr), L.ptr(self.z), L.ptr(ws), ws.numel(), L.ptr(tape), tape_bytes, flags, s), 'hn_render_dual')
         ren._last_z_raw = ren.last_z_vals = self.z
         ren._tape_serial = getattr(ren, '_tape_serial', 0) + 1     # (an autograd render's pending backward must not read this tape)
-        # ---- the loss and its gradient w.r.t. the render outputs and the pose-side values: one launch each per FRAME (every frame is
-        #      its own problem with fitting_single's own normalisation; a frame's launch is the one its one-frame fit makes)
+        # ---- the loss and its gradient w.r.t. the render outputs and the pose-side values: one launch each for all frames (every frame
+        #      is its own problem with fitting_single's own normalisation: blockIdx.y = frame, and what a frame's blocks compute is what
+        #      the launch of its one-frame fit computes)
+        import ctypes
         terms = torch.empty(Fr, 8, device=dev, dtype=torch.float32)
         from .autograd import _loss_scratch
         nf = R * S
-        scratch, sneed = _loss_scratch(lib, R, nf if self.interaction else 0, dev)
+        scratch, sneed = _loss_scratch(lib, R, nf if self.interaction else 0, dev, frames=Fr)
         tm, tc = L.f32(view['true_mask'], dev).reshape(-1), L.f32(view['true_rgb'], dev).reshape(-1, 3)
-        P = lambda t, off: ctypes_ptr(t, off)
-        for f in range(Fr):
-            sh = P(self.sdf_h, f * nf) if self.interaction else None
-            so_ = P(self.sdf_o, f * nf) if self.interaction else None
-            vf = self.verts[f]
-            L.check(lib.hn_fit_step_loss(P(self.color, 3 * f * R), P(self.wsum, f * R), P(tc, 3 * f * R), P(tm, f * R), R, sh, so_, nf, P(self.j3, 63 * f),
-                                         P(ch.joints0, 63 * f), 21, P(self.obj_r, 9 * f), P(self.obj_t, 3 * f), P(ch.Ro_pred, 9 * f), P(ch.To_pred, 3 * f),
-                                         L.ptr(vf), vf.shape[0], self.w5, L.ptr(scratch), sneed, P(self.sums, 6 * f), P(terms, 8 * f), P(self.gj, 63 * f),
-                                         P(self.gR, 9 * f), P(self.gt, 3 * f), s), 'hn_fit_step_loss')
-        for f in range(Fr):
-            sh = P(self.sdf_h, f * nf) if self.interaction else None
-            so_ = P(self.sdf_o, f * nf) if self.interaction else None
-            L.check(lib.hn_fit_step_loss_bwd(P(self.color, 3 * f * R), P(self.wsum, f * R), P(tc, 3 * f * R), P(tm, f * R), R, sh, so_, nf, P(self.sums, 6 * f),
-                                             L.ptr(self.g_loss), self.w5, P(self.gj, 63 * f), P(self.gR, 9 * f), P(self.gt, 3 * f), 21, P(self.gc, 3 * f * R),
-                                             P(self.gw, f * R), P(self.gsh, f * nf) if self.interaction else None,
-                                             P(self.gso, f * nf) if self.interaction else None, P(self.gj_o, 63 * f), P(self.gR_o, 9 * f), P(self.gt_o, 3 * f), s),
-                    'hn_fit_step_loss_bwd')
+        sh = L.ptr(self.sdf_h) if self.interaction else None
+        so_ = L.ptr(self.sdf_o) if self.interaction else None
+        if self._verts_p is None:
+            self._verts_p = (ctypes.c_void_p * Fr)(*[v.data_ptr() for v in self.verts])
+            self._verts_n = (ctypes.c_int * Fr)(*[int(v.shape[0]) for v in self.verts])
+        L.check(lib.hn_fit_step_loss_frames(Fr, L.ptr(self.color), L.ptr(self.wsum), L.ptr(tc), L.ptr(tm), R, sh, so_, nf, L.ptr(self.j3), L.ptr(ch.joints0), 21,
+                                            L.ptr(self.obj_r), L.ptr(self.obj_t), L.ptr(ch.Ro_pred), L.ptr(ch.To_pred), self._verts_p, self._verts_n, self.w5,
+                                            L.ptr(scratch), sneed, L.ptr(self.sums), L.ptr(terms), L.ptr(self.gj), L.ptr(self.gR), L.ptr(self.gt), s),
+                'hn_fit_step_loss_frames')
+        L.check(lib.hn_fit_step_loss_bwd_frames(Fr, L.ptr(self.color), L.ptr(self.wsum), L.ptr(tc), L.ptr(tm), R, sh, so_, nf, L.ptr(self.sums), L.ptr(self.g_loss),
+                                                self.w5, L.ptr(self.gj), L.ptr(self.gR), L.ptr(self.gt), 21, L.ptr(self.gc), L.ptr(self.gw),
+                                                L.ptr(self.gsh) if self.interaction else None, L.ptr(self.gso) if self.interaction else None,
+                                                L.ptr(self.gj_o), L.ptr(self.gR_o), L.ptr(self.gt_o), s), 'hn_fit_step_loss_bwd_frames')
         # ---- backward pass of the render: the hand's branch ends on s, the object's on the second stream (no join)
         aux_off = lib.hn_render_dual_tape_aux_offset(hand.handle, obj.handle, N, S)
         a = tape[aux_off:aux_off + 32 * n].view(torch.float32)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 118 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 119 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -527,6 +527,22 @@ int hn_fit_step_loss_bwd(const float* color, const float* weight_sum, const floa
                          const float* sdf_obj, int n_samples, const float* sums6, const float* g_loss, const float* weights5, const float* g_joint,
                          const float* gR, const float* gt, int n_joints, float* g_color, float* g_weight_sum, float* g_sdf_hand, float* g_sdf_obj,
                          float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream);
+/* The same two launches for SEVERAL independent frames at once (fitting_single frames a rank fits side by side: every frame is its own
+ * loss with its own normalisation, fitting_single.py:251-288): every per-frame array holds n_frames (<= 16) planes, frame after frame
+ * (color [n_frames x n_rays,3], sdf [n_frames x n_samples], joint_3d [n_frames,n_joints,3], Ra [n_frames,9], sums6 [n_frames,6], terms8
+ * [n_frames,8], ...), `verts` / `n_verts` are HOST arrays of the frames' vertex pointers and counts, `scratch` holds n_frames x
+ * hn_fit_step_loss_scratch_bytes(n_rays, n_samples) bytes (zeroed once), g_loss is the one upstream scalar.  Frame f's results are
+ * bit for bit those of hn_fit_step_loss / _bwd on that frame's planes: its own blocks, partial-sum slots and summation order. */
+int hn_fit_step_loss_frames(int n_frames, const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays,
+                            const float* sdf_hand, const float* sdf_obj, int n_samples, const float* joint_3d, const float* joint3d_pred, int n_joints,
+                            const float* Ra, const float* ta, const float* Rb, const float* tb, const float* const* verts, const int* n_verts,
+                            const float* weights5, void* scratch, size_t scratch_bytes, float* sums6, float* terms8, float* g_joint, float* gR, float* gt,
+                            hn_stream_t stream);
+int hn_fit_step_loss_bwd_frames(int n_frames, const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays,
+                                const float* sdf_hand, const float* sdf_obj, int n_samples, const float* sums6, const float* g_loss,
+                                const float* weights5, const float* g_joint, const float* gR, const float* gt, int n_joints, float* g_color,
+                                float* g_weight_sum, float* g_sdf_hand, float* g_sdf_obj, float* g_joint_out, float* gR_out, float* gt_out,
+                                hn_stream_t stream);
 
 /* torch.optim.Adam's step (defaults: betas as given, no weight decay, no amsgrad) over up to 16 small parameter blocks
  * with one learning rate each, ONE launch: the six pose-parameter groups of fitting_single.py:191-199 /

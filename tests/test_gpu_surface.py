@@ -581,6 +581,73 @@ def test_fused_step_loss_matches_reference_statements(golden, fit_type):
     assert_close(obj_t.grad, otr.grad, 2e-5, 'd loss / d obj_t (fused)')
 
 
+@pytest.mark.parametrize('interaction', [False, True])
+def test_step_loss_of_several_frames_equals_the_one_frame_launches(interaction):
+    """hn_fit_step_loss_frames / _bwd_frames (the loss of fitting_single for the frames a rank fits side by side, one launch each):
+    frame f's sums, terms and gradients are BIT FOR BIT those of hn_fit_step_loss / _bwd on that frame's planes -- ragged vertex
+    counts, a scratch block that is used twice, a frame without any contact / penetration sample."""
+    import ctypes
+    from honerf_amd import lib as Lm
+    lib = Lm.load()
+    gen = torch.Generator().manual_seed(17)
+    Fr, R, S = 5, 196, 24
+    nf = R * S if interaction else 0
+    r = lambda *sh: torch.randn(*sh, generator=gen)
+    color, rgb = cu(torch.rand(Fr * R, 3, generator=gen)), cu(torch.rand(Fr * R, 3, generator=gen))
+    wsum, mask = cu(torch.rand(Fr * R, generator=gen)), cu((torch.rand(Fr * R, generator=gen) > 0.4).float())
+    sdf_h, sdf_o = cu(0.01 * r(Fr * R * S)), cu(0.01 * r(Fr * R * S))
+    sdf_h[2 * R * S:3 * R * S] = 0.5                                  # frame 2: no contact, no penetration
+    j3, jp = cu(0.05 * r(Fr, 21, 3)), cu(0.05 * r(Fr, 21, 3))
+    Ra, ta, Rb, tb = cu(r(Fr, 9)), cu(0.1 * r(Fr, 3)), cu(r(Fr, 9)), cu(0.1 * r(Fr, 3))
+    verts = [cu(0.03 * r(n, 3)) for n in (300, 17, 1, 1000, 256)]
+    w5 = (ctypes.c_float * 5)(1.0, 30.0, 20.0, 30.0, 20.0) if interaction else (ctypes.c_float * 5)(1.0, 0.0, 0.0, 100.0, 5.0)
+    g_loss = cu(torch.tensor([0.37]))
+    per = lib.hn_fit_step_loss_scratch_bytes(R, nf)
+    z = lambda *sh: torch.zeros(*sh, device='cuda')
+    P = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + 4 * off)
+    sh_p = lambda off=0: P(sdf_h, off) if interaction else None
+    so_p = lambda off=0: P(sdf_o, off) if interaction else None
+    st = Lm.stream_ptr()
+    # ---- frame by frame
+    one = dict(sums=z(Fr, 6), terms=z(Fr, 8), gj=z(Fr, 63), gR=z(Fr, 9), gt=z(Fr, 3), gc=z(Fr * R, 3), gw=z(Fr * R), gsh=z(Fr * R * S), gso=z(Fr * R * S),
+               gjo=z(Fr, 63), gRo=z(Fr, 9), gto=z(Fr, 3))
+    scr1 = torch.zeros(per, dtype=torch.uint8, device='cuda')
+    for f in range(Fr):
+        Lm.check(lib.hn_fit_step_loss(P(color, 3 * f * R), P(wsum, f * R), P(rgb, 3 * f * R), P(mask, f * R), R, sh_p(f * R * S), so_p(f * R * S), nf,
+                                      P(j3, 63 * f), P(jp, 63 * f), 21, P(Ra, 9 * f), P(ta, 3 * f), P(Rb, 9 * f), P(tb, 3 * f), Lm.ptr(verts[f]),
+                                      verts[f].shape[0], w5, Lm.ptr(scr1), per, P(one['sums'], 6 * f), P(one['terms'], 8 * f), P(one['gj'], 63 * f),
+                                      P(one['gR'], 9 * f), P(one['gt'], 3 * f), st), 'hn_fit_step_loss')
+        Lm.check(lib.hn_fit_step_loss_bwd(P(color, 3 * f * R), P(wsum, f * R), P(rgb, 3 * f * R), P(mask, f * R), R, sh_p(f * R * S), so_p(f * R * S), nf,
+                                          P(one['sums'], 6 * f), Lm.ptr(g_loss), w5, P(one['gj'], 63 * f), P(one['gR'], 9 * f), P(one['gt'], 3 * f), 21,
+                                          P(one['gc'], 3 * f * R), P(one['gw'], f * R), P(one['gsh'], f * R * S) if interaction else None,
+                                          P(one['gso'], f * R * S) if interaction else None, P(one['gjo'], 63 * f), P(one['gRo'], 9 * f),
+                                          P(one['gto'], 3 * f), st), 'hn_fit_step_loss_bwd')
+    # ---- all frames in one launch each, twice on the same scratch block
+    scr = torch.zeros(per * Fr, dtype=torch.uint8, device='cuda')
+    vp = (ctypes.c_void_p * Fr)(*[v.data_ptr() for v in verts])
+    vn = (ctypes.c_int * Fr)(*[v.shape[0] for v in verts])
+    for rep in range(2):
+        al = {k: torch.full_like(v, float('nan')) for k, v in one.items()}
+        Lm.check(lib.hn_fit_step_loss_frames(Fr, Lm.ptr(color), Lm.ptr(wsum), Lm.ptr(rgb), Lm.ptr(mask), R, sh_p(), so_p(), nf, Lm.ptr(j3), Lm.ptr(jp), 21,
+                                             Lm.ptr(Ra), Lm.ptr(ta), Lm.ptr(Rb), Lm.ptr(tb), vp, vn, w5, Lm.ptr(scr), per * Fr, Lm.ptr(al['sums']),
+                                             Lm.ptr(al['terms']), Lm.ptr(al['gj']), Lm.ptr(al['gR']), Lm.ptr(al['gt']), st), 'hn_fit_step_loss_frames')
+        Lm.check(lib.hn_fit_step_loss_bwd_frames(Fr, Lm.ptr(color), Lm.ptr(wsum), Lm.ptr(rgb), Lm.ptr(mask), R, sh_p(), so_p(), nf, Lm.ptr(al['sums']),
+                                                 Lm.ptr(g_loss), w5, Lm.ptr(al['gj']), Lm.ptr(al['gR']), Lm.ptr(al['gt']), 21, Lm.ptr(al['gc']),
+                                                 Lm.ptr(al['gw']), Lm.ptr(al['gsh']) if interaction else None,
+                                                 Lm.ptr(al['gso']) if interaction else None, Lm.ptr(al['gjo']), Lm.ptr(al['gRo']), Lm.ptr(al['gto']), st),
+                 'hn_fit_step_loss_bwd_frames')
+        for k in one:
+            if not interaction and k in ('gsh', 'gso'):
+                continue
+            assert torch.equal(one[k], al[k]), 'frames form differs in %s (pass %d)' % (k, rep)
+    assert torch.isfinite(one['terms']).all() and float(one['terms'][:, 0].abs().min()) > 0
+    # more frames than a launch takes: refused, not truncated
+    rc = lib.hn_fit_step_loss_frames(17, Lm.ptr(color), Lm.ptr(wsum), Lm.ptr(rgb), Lm.ptr(mask), R, None, None, 0, Lm.ptr(j3), Lm.ptr(jp), 21, Lm.ptr(Ra),
+                                     Lm.ptr(ta), Lm.ptr(Rb), Lm.ptr(tb), vp, vn, w5, Lm.ptr(scr), per * Fr, Lm.ptr(al['sums']), Lm.ptr(al['terms']),
+                                     Lm.ptr(al['gj']), Lm.ptr(al['gR']), Lm.ptr(al['gt']), st)
+    assert rc != 0
+
+
 def test_device_loss_terms_video(golden):
     from honerf_amd import fitting as F
     g = golden('loss_video')
