@@ -80,6 +80,8 @@ int fit_step_loss_frames(int, const float*, const float*, const float*, const fl
                          float*, float*, float*, hipStream_t);
 int fit_step_loss_bwd_frames(int, const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*,
                              const float*, const float*, const float*, const float*, int, float*, float*, float*, float*, float*, float*, float*, hipStream_t);
+int train_loss(const float*, const float*, const float*, const float*, const float*, int, float, float, float*, hipStream_t);
+int train_loss_bwd(const float*, const float*, const float*, const float*, int, const float*, const float*, float, float, float*, float*, float*, hipStream_t);
 int fit_loss_sums(const float*, const float*, const float*, const float*, int, const float*, const float*, int, float*, hipStream_t);
 int fit_total(const float*, const float*, const float*, const float*, int, const float*, float*, float*, hipStream_t);
 int adam_step(int, float* const*, const float* const*, float* const*, float* const*, const int*, const float*, float, float, float, const int*, hipStream_t);
@@ -1966,6 +1968,16 @@ int hn_fit_step_loss_bwd_frames(int n_frames, const float* color, const float* w
     return hn::fit_step_loss_bwd_frames(n_frames, color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, sums6, g_loss, weights5,
                                         g_joint, gR, gt, n_joints, g_color, g_weight_sum, g_sdf_hand, g_sdf_obj, g_joint_out, gR_out, gt_out,
                                         (hipStream_t)stream);
+}
+int hn_train_loss(const float* color, const float* weight_sum, const float* gradient_error, const float* true_rgb, const float* true_mask, int n_rays,
+                  float igr_weight, float mask_weight, float* terms6, hn_stream_t stream) {
+    return hn::train_loss(color, weight_sum, gradient_error, true_rgb, true_mask, n_rays, igr_weight, mask_weight, terms6, (hipStream_t)stream);
+}
+int hn_train_loss_bwd(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* terms6,
+                      const float* g_loss, float igr_weight, float mask_weight, float* g_color, float* g_weight_sum, float* g_gradient_error,
+                      hn_stream_t stream) {
+    return hn::train_loss_bwd(color, weight_sum, true_rgb, true_mask, n_rays, terms6, g_loss, igr_weight, mask_weight, g_color, g_weight_sum,
+                              g_gradient_error, (hipStream_t)stream);
 }
 int hn_fit_total_bwd(const float* g_loss, const float* weights5, const float* g_joint, const float* gR, const float* gt, int n_joints,
                      float* g4, float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream) {

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 119 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 120 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -511,6 +511,16 @@ int hn_fit_total(const float* sums6, const float* verts_loss, const float* joint
                  const float* weights5, float* terms8, float* g_joint, hn_stream_t stream);
 int hn_fit_total_bwd(const float* g_loss, const float* weights5, const float* g_joint, const float* gR, const float* gt, int n_joints,
                      float* g4, float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream);
+/* The loss of a training iteration (exp_runner.py:202-212 without the VGG term, which stays a torch module on color_fine) as ONE launch
+ * forward and ONE backward: m = (true_mask > 0.5), mask_sum = sum m + 1e-5, colour = sum |(color - true_rgb) m| / mask_sum, mask =
+ * binary_cross_entropy(clip(weight_sum, 1e-3, 1 - 1e-3), m), loss = colour + mask_weight mask + igr_weight gradient_error.
+ * terms6 (device) = loss, colour, mask, gradient_error, psnr (:206), mask_sum; sums in a fixed order.  hn_train_loss_bwd: the upstream
+ * gradient of the loss (device scalar) -> g_color [n_rays,3], g_weight_sum [n_rays], g_gradient_error [1]. */
+int hn_train_loss(const float* color, const float* weight_sum, const float* gradient_error, const float* true_rgb, const float* true_mask, int n_rays,
+                  float igr_weight, float mask_weight, float* terms6, hn_stream_t stream);
+int hn_train_loss_bwd(const float* color, const float* weight_sum, const float* true_rgb, const float* true_mask, int n_rays, const float* terms6,
+                      const float* g_loss, float igr_weight, float mask_weight, float* g_color, float* g_weight_sum, float* g_gradient_error,
+                      hn_stream_t stream);
 /* The same loss (fitting_single.py:251-288) as ONE launch forward and ONE backward -- what the fitting loop runs: the sums, the
  * vertex loss of the pose pair (Ra, ta) / (Rb, tb) over `verts` [n_verts,3] (fitting_single.py:232-233), the joint loss and the
  * weighted total in hn_fit_step_loss (sums6 [6], terms8 [8], g_joint [n_joints,3], gR [9], gt [3] as above; the sums are

@@ -354,6 +354,42 @@ def test_far_field_aggregation_in_the_training_backward_is_exact():
 
 
 @pytest.mark.gpu
+def test_fused_train_loss_equals_the_reference_statements():
+    """training.train_loss on the device is ONE launch each way (hn_train_loss / _bwd): value, terms and the gradients w.r.t.
+    color_fine / weight_sum / gradient_error against exp_runner.py:202-212 written out in torch on the same tensors -- weight sums
+    outside the clip range, an all-zero mask, a non-trivial upstream gradient, 1 ray and 5 000."""
+    from honerf_amd import training
+    gen = torch.Generator().manual_seed(21)
+    for B, mask_kind in ((441, 'mixed'), (1, 'mixed'), (5000, 'mixed'), (64, 'none')):
+        color = torch.rand(B, 3, generator=gen)
+        wsum = torch.rand(B, 1, generator=gen) * 1.2 - 0.1            # some outside [1e-3, 1 - 1e-3]: clipped, no gradient there
+        gerr = torch.rand((), generator=gen) * 0.3
+        rgb = torch.rand(B, 3, generator=gen)
+        mask = (torch.rand(B, 1, generator=gen) > 0.4).float() if mask_kind == 'mixed' else torch.zeros(B, 1)
+        res = {}
+        for fused in (False, True):
+            training.FUSED_TRAIN_LOSS = fused
+            try:
+                leaves = [x.clone().cuda().requires_grad_(True) for x in (color, wsum, gerr)]
+                out = {'color_fine': leaves[0], 'weight_sum': leaves[1], 'gradient_error': leaves[2]}
+                terms = training.train_loss(out, rgb.cuda(), mask.cuda(), 0.1, 0.5)
+                (terms['loss'] * 0.37).backward()
+                res[fused] = ({k: float(v.detach()) for k, v in terms.items()}, [x.grad.detach().cpu().double() for x in leaves])
+            finally:
+                training.FUSED_TRAIN_LOSS = True
+        for k, ref in res[False][0].items():
+            got = res[True][0][k]
+            if k == 'psnr' and not np.isfinite(ref):
+                continue
+            assert abs(got - ref) <= 2e-6 * max(abs(ref), 1e-3), (B, mask_kind, k, got, ref)
+        for name, a, b in zip(('color_fine', 'weight_sum', 'gradient_error'), res[False][1], res[True][1]):
+            scale = max(float(a.abs().max()), 1e-30)
+            e = float((a - b).abs().max()) / scale
+            record('fused train loss: d loss / d %s, B = %d (%s)' % (name, B, mask_kind), e, 2e-6)
+            assert e <= 2e-6, (B, mask_kind, name, e)
+
+
+@pytest.mark.gpu
 def test_train_step_decreases_loss():
     """A few Adam steps of honerf_amd.training.train_step on a fixed batch: the loss goes down and the packed field
     follows the parameters (the renderer re-packs when Adam's in-place update bumps their versions)."""
