@@ -618,6 +618,81 @@ __global__ __launch_bounds__(256) void k_composite2_bwd_wave(const float* __rest
     }
 }
 
+// The one-field adjoint (k_composite1_bwd) with one wave per ray, as k_composite2_bwd_wave: T_k = c_0 prod_{j<k} f_j is the seed times an
+// exclusive product scan, P_k a suffix scan of affine maps; g_c = (P_{-1}, 0, 0, ..).  The thread-per-ray form took 67 us for the 441 x 128
+// samples of a training iteration (128 dependent, uncoalesced rows per ray), this one ~6.
+template <int CPL>
+__global__ __launch_bounds__(256) void k_composite1_bwd_wave(const float* __restrict__ alpha, const float* __restrict__ c, const float* __restrict__ rgb,
+                                                             const float* __restrict__ g_color, const float* __restrict__ g_wsum, int n_rays, int S,
+                                                             float* __restrict__ g_alpha, float* __restrict__ g_c, float* __restrict__ g_rgb) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const size_t base = (size_t)ray * S;
+    const float gC0 = g_color[3 * ray], gC1 = g_color[3 * ray + 1], gC2 = g_color[3 * ray + 2];
+    const float gW = g_wsum != nullptr ? g_wsum[ray] : 0.f;
+    const float seed = c[base];
+    float a[CPL], u[CPL], f[CPL];
+    float Fl = 1.f;   // product of this lane's factors
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int k = lane * CPL + j;
+        const bool in = k < S;
+        a[j] = in ? alpha[base + k] : 0.f;
+        u[j] = 0.f;
+        if (in) {
+            const float* r = rgb + 3 * (base + k);
+            u[j] = gC0 * r[0] + gC1 * r[1] + gC2 * r[2] + gW;   // dL/dw_k
+        }
+        f[j] = in ? 1.f - a[j] + 1e-7f : 1.f;
+        Fl *= f[j];
+    }
+    float incl = Fl;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl *= o;
+    }
+    float T = __shfl_up(incl, 1, 64);
+    T = lane == 0 ? seed : seed * T;   // the transmittance in front of this lane's first sample (seeded with c_0: SURVEY B-3)
+    float Tk[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        Tk[j] = T;
+        T *= f[j];
+    }
+    float M = 1.f, C = 0.f;   // this lane's composite map x -> C + M x (its samples applied last to first)
+#pragma unroll
+    for (int j = CPL - 1; j >= 0; --j) {
+        C = a[j] * u[j] + f[j] * C;
+        M = f[j] * M;
+    }
+    float sm = M, sc = C;   // inclusive suffix: lanes l .. 63
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float om = __shfl_down(sm, off, 64), oc = __shfl_down(sc, off, 64);
+        if (lane + off < 64) {
+            sc = sc + sm * oc;
+            sm = sm * om;
+        }
+    }
+    float P = __shfl_down(sc, 1, 64);   // the recurrence's value behind this lane's last sample
+    if (lane == 63) P = 0.f;
+#pragma unroll
+    for (int j = CPL - 1; j >= 0; --j) {
+        const int k = lane * CPL + j;
+        if (k < S) {
+            g_alpha[base + k] = Tk[j] * u[j] - Tk[j] * P;
+            const float w = a[j] * Tk[j];
+            g_rgb[3 * (base + k)] = w * gC0;
+            g_rgb[3 * (base + k) + 1] = w * gC1;
+            g_rgb[3 * (base + k) + 2] = w * gC2;
+        }
+        P = a[j] * u[j] + f[j] * P;
+        if (k < S) g_c[base + k] = k == 0 ? P : 0.f;   // dL/dseed = P_{-1}: T_k is linear in the seed c_0
+    }
+}
+
 // 4 rays per block; at most 8 blocks per CU, grid-stride beyond that
 static int composite_grid(int n_rays) {
     const int blocks = (n_rays + 3) / 4;
@@ -891,8 +966,18 @@ int composite1_bwd(const float* alpha_in, const float* c, const float* rgb, cons
                    int n_rays, int S, float* g_alpha, float* g_c, float* g_rgb, hipStream_t s) {
     HN_REQUIRE(S >= 1, "S must be positive");
     if (n_rays == 0) return HN_OK;
-    hipLaunchKernelGGL(k_composite1_bwd, dim3((n_rays + 63) / 64), dim3(64), 0, s, alpha_in, c, rgb, g_color, g_wsum, n_rays,
-                       S, g_alpha, g_c, g_rgb);
+    const dim3 wgrid((n_rays + 3) / 4);   // 4 rays (waves) per block
+    if (S <= 64)
+        hipLaunchKernelGGL(k_composite1_bwd_wave<1>, wgrid, dim3(256), 0, s, alpha_in, c, rgb, g_color, g_wsum, n_rays, S, g_alpha, g_c, g_rgb);
+    else if (S <= 128)
+        hipLaunchKernelGGL(k_composite1_bwd_wave<2>, wgrid, dim3(256), 0, s, alpha_in, c, rgb, g_color, g_wsum, n_rays, S, g_alpha, g_c, g_rgb);
+    else if (S <= 192)
+        hipLaunchKernelGGL(k_composite1_bwd_wave<3>, wgrid, dim3(256), 0, s, alpha_in, c, rgb, g_color, g_wsum, n_rays, S, g_alpha, g_c, g_rgb);
+    else if (S <= 256)
+        hipLaunchKernelGGL(k_composite1_bwd_wave<4>, wgrid, dim3(256), 0, s, alpha_in, c, rgb, g_color, g_wsum, n_rays, S, g_alpha, g_c, g_rgb);
+    else
+        hipLaunchKernelGGL(k_composite1_bwd, dim3((n_rays + 63) / 64), dim3(64), 0, s, alpha_in, c, rgb, g_color, g_wsum, n_rays, S, g_alpha, g_c,
+                           g_rgb);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
