@@ -81,6 +81,8 @@ int fit_step_loss_frames(int, const float*, const float*, const float*, const fl
 int fit_step_loss_bwd_frames(int, const float*, const float*, const float*, const float*, int, const float*, const float*, int, const float*, const float*,
                              const float*, const float*, const float*, const float*, int, float*, float*, float*, float*, float*, float*, float*, hipStream_t);
 int train_loss(const float*, const float*, const float*, const float*, const float*, int, float, float, float*, hipStream_t);
+int variance_to_inv_s(const float*, float*, hipStream_t);
+int variance_chain(const float*, const float*, float*, hipStream_t);
 int train_loss_bwd(const float*, const float*, const float*, const float*, int, const float*, const float*, float, float, float*, float*, float*, hipStream_t);
 int fit_loss_sums(const float*, const float*, const float*, const float*, int, const float*, const float*, int, float*, hipStream_t);
 int fit_total(const float*, const float*, const float*, const float*, int, const float*, float*, float*, hipStream_t);
@@ -1968,6 +1970,10 @@ int hn_fit_step_loss_bwd_frames(int n_frames, const float* color, const float* w
     return hn::fit_step_loss_bwd_frames(n_frames, color, weight_sum, true_rgb, true_mask, n_rays, sdf_hand, sdf_obj, n_samples, sums6, g_loss, weights5,
                                         g_joint, gR, gt, n_joints, g_color, g_weight_sum, g_sdf_hand, g_sdf_obj, g_joint_out, gR_out, gt_out,
                                         (hipStream_t)stream);
+}
+int hn_variance_to_inv_s(const float* variance, float* inv_s, hn_stream_t stream) { return hn::variance_to_inv_s(variance, inv_s, (hipStream_t)stream); }
+int hn_variance_chain(const float* g_inv_s, const float* inv_s, float* g_variance, hn_stream_t stream) {
+    return hn::variance_chain(g_inv_s, inv_s, g_variance, (hipStream_t)stream);
 }
 int hn_train_loss(const float* color, const float* weight_sum, const float* gradient_error, const float* true_rgb, const float* true_mask, int n_rays,
                   float igr_weight, float mask_weight, float* terms6, hn_stream_t stream) {

@@ -1505,6 +1505,30 @@ __global__ __launch_bounds__(256) void k_train_loss_bwd(const float* __restrict_
     const bool inside = wv >= 1e-3f && wv <= 1.f - 1e-3f;
     g_wsum[i] = inside ? gl * mask_weight * (w - m) / fmaxf((1.f - w) * w, 1e-12f) / (float)n_rays : 0.f;
 }
+// SingleVarianceNetwork (utils/fields.py:248-249, utils/renderer.py:144): inv_s = clip(exp(10 variance), 1e-6, 1e6) and its chain rule
+// g_variance = g_inv_s x (10 inv_s inside the clip range, else 0) on device scalars: one tiny launch each where torch operators take 3 / 7
+// (a training iteration re-forms inv_s after every optimiser step and needs the chain rule in every backward pass).
+__global__ void k_variance_to_inv_s(const float* __restrict__ variance, float* __restrict__ inv_s) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) inv_s[0] = fminf(fmaxf(expf(10.f * variance[0]), 1e-6f), 1e6f);
+}
+__global__ void k_variance_chain(const float* __restrict__ g_inv_s, const float* __restrict__ inv_s, float* __restrict__ g_variance) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float v = inv_s[0];
+        g_variance[0] = g_inv_s[0] * ((v > 1e-6f && v < 1e6f) ? 10.f * v : 0.f);
+    }
+}
+int variance_to_inv_s(const float* variance, float* inv_s, hipStream_t s) {
+    HN_REQUIRE(variance && inv_s, "variance_to_inv_s: null argument");
+    hipLaunchKernelGGL(k_variance_to_inv_s, dim3(1), dim3(64), 0, s, variance, inv_s);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
+int variance_chain(const float* g_inv_s, const float* inv_s, float* g_variance, hipStream_t s) {
+    HN_REQUIRE(g_inv_s && inv_s && g_variance, "variance_chain: null argument");
+    hipLaunchKernelGGL(k_variance_chain, dim3(1), dim3(64), 0, s, g_inv_s, inv_s, g_variance);
+    HN_LAUNCH_CHECK();
+    return HN_OK;
+}
 int train_loss(const float* color, const float* wsum, const float* gerr, const float* true_rgb, const float* true_mask, int n_rays, float igr_weight,
                float mask_weight, float* terms6, hipStream_t s) {
     HN_REQUIRE(color && wsum && gerr && true_rgb && true_mask && terms6 && n_rays >= 1, "train_loss: bad arguments");

@@ -25,7 +25,7 @@ PRECISIONS = {'fp32': HN_PREC_FP32, 'f16x3': HN_PREC_F16X3, 'f16': HN_PREC_F16}
 # 'fp32': the exact-fp32 MFMA path (v_mfma_f32_32x32x2_f32), 5x slower, kept as a second opinion
 DEFAULT_PRECISION = os.environ.get('HONERF_PRECISION', 'f16x3')
 HN_MAX_LAYERS = 9
-HN_VERSION = 120          # the include/honerf.h revision SIGNATURES below was written for
+HN_VERSION = 121          # the include/honerf.h revision SIGNATURES below was written for
 
 c_f = ctypes.c_void_p     # device float*
 c_i = ctypes.c_int
@@ -122,6 +122,8 @@ SIGNATURES = {
                                c_f, c_f, c_f, c_f, c_f, c_vp]),
     'hn_fit_step_loss_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, ctypes.POINTER(c_fl), c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f,
                                    c_f, c_f, c_vp]),
+    'hn_variance_to_inv_s': (c_i, [c_f, c_f, c_vp]),
+    'hn_variance_chain': (c_i, [c_f, c_f, c_f, c_vp]),
     'hn_train_loss': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_fl, c_fl, c_f, c_vp]),
     'hn_train_loss_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_fl, c_fl, c_f, c_f, c_f, c_vp]),
     'hn_fit_step_loss_frames': (c_i, [c_i, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_i, c_f, c_f, c_f, c_f, ctypes.POINTER(c_vp),

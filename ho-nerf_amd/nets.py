@@ -412,7 +412,7 @@ class PackedField:
 
     def __init__(self, kind, sdf, color, variance, scale=None, precision=None, eval_only=False, device_variance=False):
         """`device_variance` (single-field renderers: `NeuSRenderer.field()`): a variance given as a device tensor stays there --
-        `inv_s = clip(exp(10 variance), 1e-6, 1e6)` is formed by torch operators on the current stream and handed to the library as
+        `inv_s = clip(exp(10 variance), 1e-6, 1e6)` is formed on the current stream (hn_variance_to_inv_s) and handed to the library as
         a device scalar (hn_field_set_inv_s_device), so that packing a field does not wait for the device (a training iteration
         re-packs after every optimiser step: exp_runner.py:107-110 trains the variance too).  `.inv_s` / `.variance` then read the
         value back on first use; `.inv_s_t` is the device scalar.  Such a field serves the single-field renders only."""
@@ -429,7 +429,8 @@ class PackedField:
         if device_variance and isinstance(variance, torch.Tensor) and variance.is_cuda:
             v = variance.detach().reshape(1).float()
             self._variance_t = v
-            self.inv_s_t = torch.exp(v * 10.0).clamp(1e-6, 1e6).contiguous()
+            self.inv_s_t = torch.empty(1, device=v.device, dtype=torch.float32)
+            _lib.check(self.lib.hn_variance_to_inv_s(_lib.ptr(v.contiguous()), _lib.ptr(self.inv_s_t), _lib.stream_ptr()), 'hn_variance_to_inv_s')
             var = 0.0                                   # (not read by the single-field renders of such a field)
             self._variance, self._inv_s = None, None
         else:
@@ -471,7 +472,7 @@ class PackedField:
     def s_val(self, n, device):
         """1 / inv_s as an [n, 1] tensor (the `s_val` of the render dictionaries, utils/renderer.py:236, logged only)."""
         if self.inv_s_t is not None:
-            return (1.0 / self.inv_s_t).reshape(1, 1).expand(n, 1).contiguous()
+            return self.inv_s_t.reciprocal().reshape(1, 1).expand(n, 1)     # (a broadcast view: s_val is logged, never written)
         return torch.full((n, 1), 1.0 / self.inv_s, device=device)
 
     def __del__(self):

@@ -198,8 +198,9 @@ class SingleRenderFn(torch.autograd.Function):
         del keep
         # inv_s = clip(exp(10 variance), 1e-6, 1e6) (utils/fields.py:248-249, utils/renderer.py:144)
         if f.inv_s_t is not None:       # the trained value never visited the host: the chain rule on the device too
-            inv = f.inv_s_t
-            grads.append((g_inv_s * torch.where((inv > 1e-6) & (inv < 1e6), 10.0 * inv, torch.zeros_like(inv))).reshape(()))
+            g_var = torch.empty(1, device=dev, dtype=torch.float32)
+            L.check(lib.hn_variance_chain(L.ptr(g_inv_s), L.ptr(f.inv_s_t), L.ptr(g_var), L.stream_ptr()), 'hn_variance_chain')
+            grads.append(g_var.reshape(()))
         else:
             inv_s = float(f.inv_s)
             grads.append((g_inv_s * (10.0 * inv_s if 1e-6 < inv_s < 1e6 else 0.0)).reshape(()))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HN_VERSION 120 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
+#define HN_VERSION 121 /* 0.1.3: bumped whenever a signature changes; lib.py refuses a library of another version */
 
 #define HN_OK 0
 #define HN_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -511,6 +511,11 @@ int hn_fit_total(const float* sums6, const float* verts_loss, const float* joint
                  const float* weights5, float* terms8, float* g_joint, hn_stream_t stream);
 int hn_fit_total_bwd(const float* g_loss, const float* weights5, const float* g_joint, const float* gR, const float* gt, int n_joints,
                      float* g4, float* g_joint_out, float* gR_out, float* gt_out, hn_stream_t stream);
+/* SingleVarianceNetwork on device scalars (utils/fields.py:248-249, utils/renderer.py:144): inv_s = clip(exp(10 variance), 1e-6, 1e6), and the
+ * chain rule of a backward pass, g_variance = g_inv_s x (10 inv_s inside the clip range, else 0) -- for hn_field_set_inv_s_device fields, whose
+ * variance never visits the host. */
+int hn_variance_to_inv_s(const float* variance, float* inv_s, hn_stream_t stream);
+int hn_variance_chain(const float* g_inv_s, const float* inv_s, float* g_variance, hn_stream_t stream);
 /* The loss of a training iteration (exp_runner.py:202-212 without the VGG term, which stays a torch module on color_fine) as ONE launch
  * forward and ONE backward: m = (true_mask > 0.5), mask_sum = sum m + 1e-5, colour = sum |(color - true_rgb) m| / mask_sum, mask =
  * binary_cross_entropy(clip(weight_sum, 1e-3, 1 - 1e-3), m), loss = colour + mask_weight mask + igr_weight gradient_error.

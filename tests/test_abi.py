@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_binding_covers_header(built_lib):
     assert sorted(built_lib.SIGNATURES) == header_functions()
     lib = built_lib.load()
-    assert lib.hn_version() == built_lib.HN_VERSION == 120
+    assert lib.hn_version() == built_lib.HN_VERSION == 121
 
 
 def test_missing_library_fails_loudly(monkeypatch):
