@@ -343,7 +343,8 @@ int adam_step(int n_tensors, float* const* p, const float* const* g, float* cons
     a.b1 = beta1;
     a.b2 = beta2;
     a.eps = eps;
-    const int blocks = total > 65536 ? 64 : (total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1;
+    // (the pose leaves: a few hundred floats; the networks of a training iteration: up to ~1 M per launch)
+    const int blocks = total > 262144 ? 256 : total > 65536 ? 64 : (total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1;
     hipLaunchKernelGGL(k_pose_adam, dim3(blocks), dim3(256), 0, s, a);
     HN_LAUNCH_CHECK();
     return HN_OK;

@@ -801,6 +801,15 @@ class PoseAdam:
                 if p.grad is not None and (keep_ids is None or id(p) in keep_ids)]
         if not todo:
             return
+        if len(todo) > 16:      # (a launch takes 16 blocks: the networks of a training iteration, 43 tensors, go in three)
+            for at in range(0, len(todo), 16):
+                self._launch(todo[at:at + 16], stream)
+            return
+        self._launch(todo, stream)
+
+    def _launch(self, todo, stream):
+        import ctypes
+        from . import lib as L
         n = len(todo)
         P, G, M, V = ((ctypes.c_void_p * n)() for _ in range(4))
         sizes, lrs, steps = (ctypes.c_int * n)(), (ctypes.c_float * n)(), (ctypes.c_int * n)()

@@ -390,12 +390,21 @@ def train_loss(render_out, true_rgb, true_mask, igr_weight=0.1, mask_weight=0.1)
 
 
 # ---- the rest of exp_runner's training surface: optimiser, learning-rate schedule, checkpoints (host code) ------------
+DEVICE_ADAM = os.environ.get('HONERF_TRAIN_TORCH_ADAM', '0') != '1'    # Adam of the networks as hn_adam_step launches (fitting.PoseAdam)
+
+
 def make_optimizer(renderer, learning_rate, extra_params=()):
     """Adam over `sdf_network.parameters() + deviation_network.parameters() + color_network.parameters()` in that order
     (exp_runner.py:107-110; `se3_refine` is one of sdf_network's parameters), so that the optimiser state of a
-    reference checkpoint loads by index.  On the GPU the fused multi-tensor form (one launch per step)."""
+    reference checkpoint loads by index.  On the GPU: `fitting.PoseAdam` -- torch.optim.Adam's defaults and update formula, its
+    `param_groups` / `zero_grad` / `step` / `state_dict` (in torch.optim.Adam's layout: checkpoints interchange), the 43 tensors
+    in three hn_adam_step launches (~25 us) where torch's fused multi-tensor step takes two of ~43 us each.
+    HONERF_TRAIN_TORCH_ADAM=1 (or CPU / non-fp32 parameters): torch.optim.Adam."""
     params = list(renderer.sdf_network.parameters()) + list(renderer.deviation_network.parameters()) + \
         list(renderer.color_network.parameters()) + list(extra_params)
+    if DEVICE_ADAM and params and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+        from .fitting import PoseAdam
+        return PoseAdam([{'params': params, 'lr': learning_rate}])
     try:
         return torch.optim.Adam(params, lr=learning_rate, fused=all(p.is_cuda for p in params))
     except (RuntimeError, TypeError):

@@ -390,6 +390,43 @@ def test_fused_train_loss_equals_the_reference_statements():
 
 
 @pytest.mark.gpu
+def test_device_adam_over_many_tensors_equals_torch_adam():
+    """training.make_optimizer on the device = fitting.PoseAdam over the networks' 43 tensors, three hn_adam_step launches per step (a
+    launch takes 16): parameters after four steps with changing gradients and a changed learning rate against torch.optim.Adam (its
+    single-tensor formula, what the reference's exp_runner.py:107-110 runs); a parameter without a gradient is left alone; the state
+    dictionary loads into torch.optim.Adam."""
+    from honerf_amd.fitting import PoseAdam
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(256, 1386), (256,), (256, 1), ()] + [(256, 256), (256,), (256, 1)] * 11 + [(3, 256), (3,), (1,)]
+    assert len(shapes) == 40
+    ref_p = [torch.nn.Parameter(torch.randn(sh, generator=gen).cuda()) for sh in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    ref, ours = torch.optim.Adam(ref_p, lr=1e-3), PoseAdam([{'params': our_p, 'lr': 1e-3}])
+    for it in range(4):
+        if it == 2:
+            for o in (ref, ours):
+                o.param_groups[0]['lr'] = 3e-4
+        for i, (a, b) in enumerate(zip(ref_p, our_p)):
+            if i == 7 and it % 2 == 0:
+                a.grad = b.grad = None                           # (torch skips it and does not count the step)
+                continue
+            g = torch.randn(tuple(a.shape), generator=gen).cuda() * (10.0 ** (i % 5 - 3))
+            a.grad, b.grad = g.clone(), g.clone()
+        ref.step()
+        ours.step()
+    worst = 0.0
+    for a, b in zip(ref_p, our_p):
+        worst = max(worst, float((a - b).abs().max() / a.abs().max().clamp_min(1e-30)))
+    record('device Adam vs torch.optim.Adam, 40 tensors x 4 steps', worst, 2e-6)
+    assert worst <= 2e-6, worst
+    sd = ours.state_dict()
+    assert float(sd['state'][7]['step']) == 2.0 and float(sd['state'][8]['step']) == 4.0
+    fresh = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in our_p], lr=1e-3)
+    fresh.load_state_dict(sd)
+    assert fresh.param_groups[0]['lr'] == 3e-4
+
+
+@pytest.mark.gpu
 def test_train_step_decreases_loss():
     """A few Adam steps of honerf_amd.training.train_step on a fixed batch: the loss goes down and the packed field
     follows the parameters (the renderer re-packs when Adam's in-place update bumps their versions)."""
@@ -402,8 +439,8 @@ def test_train_step_decreases_loss():
     sdf_net.reset_parameters(SEEDS['sdf_obj'])
     col_net.reset_parameters(SEEDS['color_obj'])
     ren = NeuSRenderer(sdf_net, var, col_net, 'obj', 64, 64, 0, 4, 1.0)
-    # the fused multi-tensor Adam of training.make_optimizer: its in-place update does not advance the parameters'
-    # version counters, which is why render_train re-packs unconditionally
+    # training.make_optimizer's Adam on the device (hn_adam_step, as torch's fused multi-tensor step before it): its in-place update
+    # does not advance the parameters' version counters, which is why render_train re-packs unconditionally
     opt = training.make_optimizer(ren, 5e-4)
     c = lambda k: t(g[k]).to(dev)
     losses = []
