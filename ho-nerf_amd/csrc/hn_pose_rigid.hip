@@ -305,20 +305,27 @@ struct AdamArgs {
     float bc1[16], bc2_sqrt[16];   // per block: torch keeps one step count per parameter (a block without a gradient is skipped)
     float b1, b2, eps;
 };
+// (one grid-stride pass over the blocks laid end to end -- element e belongs to the block whose range holds it -- so that a launch over a
+// network's tensors, 16 of up to 355 k floats, does not walk them one behind the other: 19 -> ~7 us per launch of a training iteration)
 __global__ __launch_bounds__(256) void k_pose_adam(const AdamArgs a) {
-    for (int t = 0; t < a.n_tensors; ++t) {
+    int total = 0;
+    for (int t = 0; t < a.n_tensors; ++t) total += a.n[t];
+    for (int e = threadIdx.x + blockIdx.x * blockDim.x; e < total; e += blockDim.x * gridDim.x) {
+        int t = 0, i = e;
+        while (i >= a.n[t]) {
+            i -= a.n[t];
+            ++t;
+        }
         const float step_size = a.lr[t] / a.bc1[t];
         const float bc2s = a.bc2_sqrt[t];
-        for (int i = threadIdx.x + blockIdx.x * blockDim.x; i < a.n[t]; i += blockDim.x * gridDim.x) {
-            const float g = a.g[t][i];
-            float m = a.m[t][i], v = a.v[t][i];
-            m = m + (g - m) * (1.f - a.b1);
-            v = v * a.b2 + (1.f - a.b2) * g * g;
-            a.m[t][i] = m;
-            a.v[t][i] = v;
-            const float denom = sqrtf(v) / bc2s + a.eps;
-            a.p[t][i] = a.p[t][i] - step_size * (m / denom);
-        }
+        const float g = a.g[t][i];
+        float m = a.m[t][i], v = a.v[t][i];
+        m = m + (g - m) * (1.f - a.b1);
+        v = v * a.b2 + (1.f - a.b2) * g * g;
+        a.m[t][i] = m;
+        a.v[t][i] = v;
+        const float denom = sqrtf(v) / bc2s + a.eps;
+        a.p[t][i] = a.p[t][i] - step_size * (m / denom);
     }
 }
 int adam_step(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int* sizes, const float* lr,

@@ -134,6 +134,7 @@ class SingleRenderFn(torch.autograd.Function):
         ctx.tape_compact = bool(getattr(renderer, 'compact_far_field', False))   # the block's rows are the compacted list's when this is on
         ctx.save_for_backward(ro, rd, z, *([bt, tp] if hand else []))
         ctx.mark_non_differentiable(cdf, wmax)
+        ctx.set_materialize_grads(False)       # (no zero tensors for outputs the loss does not use: [B,S] and [B,1] fills per iteration)
         return color, wsum, gerr.reshape(()), cdf, wmax
 
     @staticmethod
@@ -150,9 +151,11 @@ class SingleRenderFn(torch.autograd.Function):
         gc = L.f32(g_color).reshape(B, 3) if g_color is not None else torch.zeros(B, 3, device=dev)
         gw = None if g_wsum is None else L.f32(g_wsum).reshape(B)
         ge = None if g_gerr is None else L.f32(g_gerr).reshape(1)
+        if g_color is None and g_wsum is None and g_gerr is None:
+            return (None,) * (9 + ctx.n_params)
         n_floats = lib.hn_field_param_floats(f.handle)
-        g_params = torch.zeros(n_floats, device=dev)
-        g_inv_s = torch.zeros(1, device=dev)
+        zeros = torch.zeros(n_floats + 1, device=dev)        # (one fill for both)
+        g_params, g_inv_s = zeros[:n_floats], zeros[n_floats:]
         g_ro, g_rd = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
         # pose gradients only when the caller differentiates the pose (exp_runner trains the networks on fixed poses: the bone maps'
         # kernels then skip 15 wave sums and atomics per sample block and bone)
@@ -348,6 +351,7 @@ class TrainLossFn(torch.autograd.Function):
         B = c.shape[0]
         assert w.shape[0] == B and t.shape[0] == B and m.shape[0] == B, 'train loss: one colour, weight sum, target and mask per ray'
         terms = torch.empty(6, device=dev, dtype=torch.float32)
+        ctx.set_materialize_grads(False)       # (no zero tensor for the gradient of `terms`, which nothing reads)
         L.check(lib.hn_train_loss(L.ptr(c), L.ptr(w), L.ptr(ge), L.ptr(t), L.ptr(m), B, float(igr_weight), float(mask_weight), L.ptr(terms), L.stream_ptr()),
                 'hn_train_loss')
         ctx.save_for_backward(c, w, t, m, terms)
@@ -360,6 +364,8 @@ class TrainLossFn(torch.autograd.Function):
     def backward(ctx, g_loss, _g_terms):
         L = _lib
         lib = L.load()
+        if g_loss is None:
+            return (None,) * 7
         c, w, t, m, terms = ctx.saved_tensors
         B = c.shape[0]
         gc, gw, gg = torch.empty_like(c), torch.empty_like(w), torch.empty(1, device=c.device, dtype=torch.float32)
