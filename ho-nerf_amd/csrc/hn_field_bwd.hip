@@ -704,17 +704,31 @@ __device__ __forceinline__ FrameRef frame_of(int i, int ppf, int nf, const float
     return {bt_inv + (size_t)fr * N_BONES * 16, T_pose + (size_t)fr * N_BONES * 3, fr};
 }
 
+constexpr int HAND_BONE_F = 66;   // values per (sample, bone): v, enc10(v), r, enc7(r)
+// tile [66][65] (value f of the wave's sample s at f * 65 + s) -> rows i0 .. i0 + 63 of `out`, columns 66 b ..: per sample one 256-byte store
+// of the wave and one of two lanes (reads: lane l takes f = l, stride 65 floats -- two lanes per bank)
+__device__ __forceinline__ void store_bone_tile(const float* tile, float* __restrict__ out, int ld, int i0, int n, int b) {
+    const int l = threadIdx.x;
+    const int rows = n - i0 < 64 ? n - i0 : 64;
+    for (int sidx = 0; sidx < rows; ++sidx) {
+        float* o = out + (size_t)(i0 + sidx) * ld + b * HAND_BONE_F;
+        o[l] = tile[l * 65 + sidx];
+        if (l < HAND_BONE_F - 64) o[64 + l] = tile[(64 + l) * 65 + sidx];
+    }
+}
 __global__ void k_hand_feat(const float* __restrict__ pts, int n, int ppf, int nf, const float* __restrict__ bt_inv,
                             const float* __restrict__ T_pose, float* __restrict__ X, int ld, float* __restrict__ r_out,
                             float* __restrict__ h_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
-    const FrameRef fr = frame_of(i, ppf, nf, bt_inv, T_pose);
-    for (int b = blockIdx.y; b <= (int)blockIdx.y; ++b) {   // one bone per grid row: 21 x the parallelism of a loop
+    // one wave = 64 samples x ONE bone (grid row: 21 x the parallelism of a loop).  The 66 values of a (sample, bone) are a 264-byte piece
+    // of the sample's row: written by the lane that computed them they are 66 store instructions of 64 different cache lines each (the
+    // kernel ran at 0.7 TB/s, store-bound); staged through LDS, the wave writes every sample's piece as one 256-byte + one 8-byte store.
+    __shared__ float tile[HAND_BONE_F * 65];
+    const int i0 = blockIdx.x * blockDim.x, i = i0 + threadIdx.x, b = blockIdx.y;
+    if (i < n) {
+        const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+        const FrameRef fr = frame_of(i, ppf, nf, bt_inv, T_pose);
         const BoneQ q = bone_q(p, fr.M + 16 * b, fr.T + 3 * b, b);
-        float* o = X + (size_t)i * ld + b * 66;
-        bone_features(q, [&](int f, int, float phi, float, float) { o[f] = phi * q.h; });
+        bone_features(q, [&](int f, int, float phi, float, float) { tile[f * 65 + threadIdx.x] = phi * q.h; });
         if (r_out != nullptr) {
             float* ro = r_out + ((size_t)i * N_BONES + b) * 3;
             ro[0] = q.r[0];
@@ -723,25 +737,28 @@ __global__ void k_hand_feat(const float* __restrict__ pts, int n, int ppf, int n
         }
         if (h_out != nullptr) h_out[(size_t)i * N_BONES + b] = q.h;
     }
+    __syncthreads();
+    store_bone_tile(tile, X, ld, i0, n, b);
 }
 // J gbar: directional derivative of every feature along dq = R_b gbar
 __global__ void k_hand_push(const float* __restrict__ pts, int n, int ppf, int nf, const float* __restrict__ bt_inv,
                             const float* __restrict__ T_pose, const float* __restrict__ gbar, float* __restrict__ out, int ld) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
-    const float gb[3] = {gbar[3 * (size_t)i], gbar[3 * (size_t)i + 1], gbar[3 * (size_t)i + 2]};
-    const FrameRef fr = frame_of(i, ppf, nf, bt_inv, T_pose);
-    for (int b = blockIdx.y; b <= (int)blockIdx.y; ++b) {   // one bone per grid row: 21 x the parallelism of a loop
+    __shared__ float tile[HAND_BONE_F * 65];   // (staged stores: k_hand_feat)
+    const int i0 = blockIdx.x * blockDim.x, i = i0 + threadIdx.x, b = blockIdx.y;
+    if (i < n) {
+        const float p[3] = {pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+        const float gb[3] = {gbar[3 * (size_t)i], gbar[3 * (size_t)i + 1], gbar[3 * (size_t)i + 2]};
+        const FrameRef fr = frame_of(i, ppf, nf, bt_inv, T_pose);
         const float* m = fr.M + 16 * b;
         const BoneQ q = bone_q(p, m, fr.T + 3 * b, b);
         const float w[3] = {m[0] * gb[0] + m[1] * gb[1] + m[2] * gb[2], m[4] * gb[0] + m[5] * gb[1] + m[6] * gb[2],
                             m[8] * gb[0] + m[9] * gb[1] + m[10] * gb[2]};
         const float rw = q.r[0] * w[0] + q.r[1] * w[1] + q.r[2] * w[2];
         const float dy[4] = {rw, (w[0] - q.r[0] * rw) / q.v, (w[1] - q.r[1] * rw) / q.v, (w[2] - q.r[2] * rw) / q.v};
-        float* o = out + (size_t)i * ld + b * 66;
-        bone_features(q, [&](int f, int a, float phi, float phi1, float) { o[f] = phi1 * q.h * dy[a] + phi * q.h1 * rw; });
+        bone_features(q, [&](int f, int a, float phi, float phi1, float) { tile[f * 65 + threadIdx.x] = phi1 * q.h * dy[a] + phi * q.h1 * rw; });
     }
+    __syncthreads();
+    store_bone_tile(tile, out, ld, i0, n, b);
 }
 __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
