@@ -552,23 +552,38 @@ __global__ void k_z8_bar(const float* __restrict__ g_sdf, float inv_scale, float
 
 // ---- [x, enc_L(x)] of a 3-vector: features, J^T, J, second derivative ------------------------------------------
 // layout: x (3), then per channel c: sin(2^k x_c) k<L, cos(2^k x_c) k<L
+// (rows of W = 3 + 6 L <= 63 floats: a lane that wrote its own row made every store instruction touch 64 cache lines; each wave stages its 64
+// rows in an LDS tile [W][65] and writes them one row per store instruction, W lanes wide -- blocks of 256 threads, a tile per wave)
+template <int W>
+__device__ __forceinline__ void store_row_tile(const float* tile, float* __restrict__ out, int ld, int i0, int n) {
+    const int l = threadIdx.x & 63;
+    const int rows = n - i0 < 64 ? n - i0 : 64;
+    if (l < W)
+        for (int sidx = 0; sidx < rows; ++sidx) out[(size_t)(i0 + sidx) * ld + l] = tile[l * 65 + sidx];
+}
 template <int L>
-__global__ void k_enc3(const float* __restrict__ x, int n, int rep, float* __restrict__ out, int ld) {
+__global__ __launch_bounds__(256) void k_enc3(const float* __restrict__ x, int n, int rep, float* __restrict__ out, int ld) {
+    constexpr int W = 3 + 6 * L;
+    __shared__ float tiles[4][W * 65];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* xi = x + 3 * (size_t)(i / rep);
-    float* o = out + (size_t)i * ld;
+    float* tile = tiles[threadIdx.x >> 6];
+    const int ls = threadIdx.x & 63;
+    if (i < n) {
+        const float* xi = x + 3 * (size_t)(i / rep);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        o[c] = xi[c];
+        for (int c = 0; c < 3; ++c) {
+            tile[c * 65 + ls] = xi[c];
 #pragma unroll
-        for (int k = 0; k < L; ++k) {
-            float s, co;
-            sincosf(xi[c] * (float)(1 << k), &s, &co);
-            o[3 + c * 2 * L + k] = s;
-            o[3 + c * 2 * L + L + k] = co;
+            for (int k = 0; k < L; ++k) {
+                float s, co;
+                sincosf(xi[c] * (float)(1 << k), &s, &co);
+                tile[(3 + c * 2 * L + k) * 65 + ls] = s;
+                tile[(3 + c * 2 * L + L + k) * 65 + ls] = co;
+            }
         }
     }
+    __syncthreads();
+    store_row_tile<W>(tile, out, ld, blockIdx.x * blockDim.x + (threadIdx.x & ~63), n);
 }
 // out[i] (+)= J^T fbar [+ second-order term sum_f GX_f d2X_f gbar_c];  fbar row width ld
 template <int L>
@@ -601,24 +616,30 @@ __global__ void k_enc3_pull(const float* __restrict__ x, int n, int rep, const f
 }
 // J gbar -> [n, 3 + 6L]
 template <int L>
-__global__ void k_enc3_push(const float* __restrict__ x, int n, const float* __restrict__ gbar, float* __restrict__ out, int ld) {
+__global__ __launch_bounds__(256) void k_enc3_push(const float* __restrict__ x, int n, const float* __restrict__ gbar, float* __restrict__ out, int ld) {
+    constexpr int W = 3 + 6 * L;
+    __shared__ float tiles[4][W * 65];   // (staged stores: k_enc3)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* xi = x + 3 * (size_t)i;
-    float* o = out + (size_t)i * ld;
+    float* tile = tiles[threadIdx.x >> 6];
+    const int ls = threadIdx.x & 63;
+    if (i < n) {
+        const float* xi = x + 3 * (size_t)i;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float gb = gbar[3 * (size_t)i + c];
-        o[c] = gb;
+        for (int c = 0; c < 3; ++c) {
+            const float gb = gbar[3 * (size_t)i + c];
+            tile[c * 65 + ls] = gb;
 #pragma unroll
-        for (int k = 0; k < L; ++k) {
-            const float f = (float)(1 << k);
-            float s, co;
-            sincosf(xi[c] * f, &s, &co);
-            o[3 + c * 2 * L + k] = f * co * gb;
-            o[3 + c * 2 * L + L + k] = -f * s * gb;
+            for (int k = 0; k < L; ++k) {
+                const float f = (float)(1 << k);
+                float s, co;
+                sincosf(xi[c] * f, &s, &co);
+                tile[(3 + c * 2 * L + k) * 65 + ls] = f * co * gb;
+                tile[(3 + c * 2 * L + L + k) * 65 + ls] = -f * s * gb;
+            }
         }
     }
+    __syncthreads();
+    store_row_tile<W>(tile, out, ld, blockIdx.x * blockDim.x + (threadIdx.x & ~63), n);
 }
 // rows of x [n, ld] scaled by s [n]
 __global__ void k_scale_rows(float* __restrict__ x, const float* __restrict__ sc, int ld, size_t total) {
