@@ -864,8 +864,12 @@ static int render_single_impl(const hn_field* f, const float* rays_o, const floa
     const float sample_dist = (float)((far - near) / (double)n_samples);
     const int hand_ppf = n_rays * S;   // single field: one frame
     // sdf at n points: dense, or through the compacted list
+    // (a pass of at most one 32-sample block per CU runs in the latency form, whose launch takes the same ~85 us for 1 block as for 256:
+    //  compacting it -- three more launches, ~22 us -- cannot shorten it; the results are the same bits either way)
+    const int cus_now = device_cus() > 0 ? device_cus() : 256;
     auto sdf_pass = [&](const float* p, int n, float* out) -> int {
-        if (!(may_compact && hand_compaction(f, 1, (size_t)n))) return field_sdf(f, p, n, bt_inv, T_pose, 1, n, out, fws, fws_bytes, s);
+        if (!(may_compact && hand_compaction(f, 1, (size_t)n) && (size_t)n > (size_t)32 * (size_t)cus_now))
+            return field_sdf(f, p, n, bt_inv, T_pose, 1, n, out, fws, fws_bytes, s);
         CompactRec cr;
         cr.at(crec_ws, (size_t)n);
         HN_TRY(compact_hand(cr, p, n, bt_inv, T_pose, 1, n, s));
