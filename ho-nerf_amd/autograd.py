@@ -529,10 +529,13 @@ class FitWindowLossFn(torch.autograd.Function):
         ctx.w7, ctx.Fr, ctx.has_stable = w7, Fr, stable is not None
         ctx.shapes = (color.shape, wsum.shape, sdf_h.shape, sdf_o.shape, joint_3d.shape, obj_r.shape, obj_t.shape, None if bt_inv is None else bt_inv.shape)
         ctx.mark_non_differentiable(terms)
+        ctx.set_materialize_grads(False)       # (no zero tensor for the gradient of `terms`)
         return terms[0], terms
 
     @staticmethod
     def backward(ctx, g_loss, _g_terms):
+        if g_loss is None:
+            return (None,) * 17
         L = _lib
         lib = L.load()
         c, w, t, m, buf, sh, so = ctx.saved_tensors

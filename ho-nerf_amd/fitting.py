@@ -585,6 +585,20 @@ def _side_stream(device):
     return _aux_stream(device)
 
 
+_UNIT = {}
+
+
+def _unit_gradient(loss):
+    """The 1 that `loss.backward()` starts from, kept per device: autograd otherwise allocates and fills one in every step (one more
+    launch in a chain of dependent launches)."""
+    if not loss.is_cuda or loss.dim() != 0 or loss.dtype != torch.float32:
+        return None
+    key = str(loss.device)
+    if key not in _UNIT:
+        _UNIT[key] = torch.ones((), device=loss.device, dtype=torch.float32)
+    return _UNIT[key]
+
+
 def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None, smooth_ends=(False, False),
                  obj_verts_for_stable=None, t_rand=None, rays_fn=None):
     """The forward + backward half of one optimiser step of the fitting loops: pose chain -> rays of the view's sampled
@@ -678,7 +692,7 @@ def fit_backward(renderer, view, pose_chain, near, far, fit_type='1', index=None
         for x in shared + (list(pterms.values()) if pterms is not None else []):
             x.record_stream(main)
     terms = step_loss(out, view['true_rgb'], view['true_mask'], pose, fit_type, video, smooth_ends, stable, pterms)
-    terms['loss'].backward()
+    terms['loss'].backward(gradient=_unit_gradient(terms['loss']))
     return terms
 
 

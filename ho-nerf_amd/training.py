@@ -324,7 +324,8 @@ def train_step(renderer, optimizer, rays_o, rays_d, near, far, bt_inv, T_pose_21
     if extra_loss is not None:
         terms['loss'] = terms['loss'] + extra_loss(out)
     optimizer.zero_grad(set_to_none=True)
-    terms['loss'].backward()
+    from .fitting import _unit_gradient
+    terms['loss'].backward(gradient=_unit_gradient(terms['loss']))
     # everything the optimiser steps (se3_refine and a caller's extra parameters included), so that no replica drifts
     allreduce_gradients([p for g in optimizer.param_groups for p in g['params']], dist)
     optimizer.step()

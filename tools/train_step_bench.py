@@ -71,6 +71,8 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3', compac
     from honerf_amd import lib as _L
     _L.dropped_samples(reset=True)
 
+    from honerf_amd.fitting import _unit_gradient as _unit
+
     def step(parts=None):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
@@ -81,7 +83,7 @@ def measure(kind, dev, n_rays=441, steps=10, warmup=3, precision='f16x3', compac
         terms = training.train_loss(out, true_rgb, true_mask, 1.0, 1.0)
         ev[2].record()
         opt.zero_grad(set_to_none=True)
-        terms['loss'].backward()
+        terms['loss'].backward(gradient=_unit(terms['loss']))           # (as training.train_step)
         ev[3].record()
         opt.step()
         ev[4].record()
