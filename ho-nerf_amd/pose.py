@@ -299,7 +299,9 @@ class HaloChainFn(torch.autograd.Function):
                 'hn_rigid_pose')
         ctx.jac_h, ctx.jac_o, ctx.F = jac_h, jac_o, F
         ctx.shapes = tuple(x.shape for x in (obj_rot, obj_trans, palm_rot, palm_trans, joint_angle, palm_angle))
-        return bt, j3, out[:, 399:408].reshape(F, 3, 3), out[:, 408:411]
+        # (F > 1: the two slices of the [F, 412] block are strided; every consumer -- the loss node, the inverse, the stable term, the
+        #  render -- would make its own contiguous copy: one copy each here instead)
+        return bt, j3, out[:, 399:408].contiguous().reshape(F, 3, 3), out[:, 408:411].contiguous()
 
     @staticmethod
     def backward(ctx, g_bt, g_j3, g_or, g_ot):
