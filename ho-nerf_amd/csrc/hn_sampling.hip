@@ -320,11 +320,11 @@ __global__ __launch_bounds__(256) void k_obj_rays_bwd(const float* __restrict__ 
                                                       const float* __restrict__ To, int rays_per_frame, float* __restrict__ g_o,
                                                       float* __restrict__ g_d, float* __restrict__ g_Ro, float* __restrict__ g_To, int tr,
                                                       float* __restrict__ part, unsigned* __restrict__ counter, const float* __restrict__ gd_alpha_s,
-                                                      const float* __restrict__ gd_colour_s) {
+                                                      const float* __restrict__ gd_colour_s, int finalize) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool active = ray < n_rays;
-    if (!active && part == nullptr) return;
+    if (!active && (part == nullptr || !finalize)) return;
     if (active) {
     float acc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = lane; k < n; k += 64) {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void k_obj_rays_bwd(const float* __restrict__ 
         g_d[3 * ray + c] = R[sc * c] * gd[0] + R[sr + sc * c] * gd[1] + R[2 * sr + sc * c] * gd[2];
     }
     }   // active
-    if (part == nullptr) return;
+    if (part == nullptr || !finalize) return;   // (finalize = 0: k_obj_rays_finalize adds the rows, a block per frame)
     // last block finalises (a counter that is zero before the launch and zero again after it)
     __shared__ unsigned is_last;
     __threadfence();
@@ -403,6 +403,26 @@ __global__ __launch_bounds__(256) void k_obj_rays_bwd(const float* __restrict__ 
         const volatile float* p = part;
         float acc = 0.f;
         for (int r = r0 + lane; r < r1; r += 64) acc += p[(size_t)r * 12 + e];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) {
+            if (e < 9)
+                g_Ro[9 * fr + e] = acc;
+            else
+                g_To[3 * fr + e - 9] = acc;
+        }
+    }
+}
+
+// The per-frame sums of k_obj_rays_bwd's rows with ONE BLOCK PER FRAME (several frames side by side: the last block of that kernel walks
+// 12 sums per frame on its four waves -- 24 rounds of dependent loads at 8 frames, 0.1 ms on the object's critical chain of a step).  The same
+// association: lane l adds the frame's rays l, l + 64, .. in that order, then the xor tree.
+__global__ __launch_bounds__(256) void k_obj_rays_finalize(const float* __restrict__ part, int n_rays, int rays_per_frame, float* __restrict__ g_Ro,
+                                                           float* __restrict__ g_To) {
+    const int fr = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = fr * rays_per_frame, r1 = r0 + rays_per_frame < n_rays ? r0 + rays_per_frame : n_rays;
+    for (int e = wv; e < 12; e += 4) {
+        float acc = 0.f;
+        for (int r = r0 + lane; r < r1; r += 64) acc += part[(size_t)r * 12 + e];
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
         if (lane == 0) {
             if (e < 9)
@@ -1069,8 +1089,11 @@ int obj_rays_bwd(const float* z, const float* g_pts, int n_frames, int rpf, int 
     const int n_rays = n_frames * rpf;
     if (n_rays == 0) return HN_OK;
     HN_REQUIRE(n >= 1 && rpf >= 1 && g_Ro != nullptr && g_To != nullptr && (gd_alpha != nullptr || gd_alpha_samples != nullptr), "obj_rays_bwd: bad arguments");
+    float* const rows = counter != nullptr ? part : nullptr;
+    const bool own_launch = rows != nullptr && n_frames >= 3;   // (the rows' sums per frame: in the kernel's last block, or a block per frame behind it)
     hipLaunchKernelGGL(k_obj_rays_bwd, dim3((n_rays + 3) / 4), dim3(256), 0, s, z, g_pts, n_rays, n, sample_dist, gd_alpha, gd_colour, o, d, Ro, To, rpf,
-                       g_o, g_d, g_Ro, g_To, transposed ? 1 : 0, counter != nullptr ? part : nullptr, counter, gd_alpha_samples, gd_colour_samples);
+                       g_o, g_d, g_Ro, g_To, transposed ? 1 : 0, rows, counter, gd_alpha_samples, gd_colour_samples, own_launch ? 0 : 1);
+    if (own_launch) hipLaunchKernelGGL(k_obj_rays_finalize, dim3(n_frames), dim3(256), 0, s, rows, n_rays, rpf, g_Ro, g_To);
     HN_LAUNCH_CHECK();
     return HN_OK;
 }
