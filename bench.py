@@ -301,9 +301,20 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
         return dt, out
 
     def timed(fn):
+        # (as timeit does: what earlier legs left behind is collected BEFORE the leg, and the cyclic collector stays off inside the timed
+        #  window -- a packed field of an earlier leg dying there synchronises the device in its destructor: 2.3 ms steps read as 2.7 - 4.3)
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
         for i in range(warmup):
             fn(i)
-        return wall(lambda: [fn(warmup + i) for i in range(steps)])[0] / steps
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            return wall(lambda: [fn(warmup + i) for i in range(steps)])[0] / steps
+        finally:
+            if was:
+                gc.enable()
 
     # ---- C3 / C4 per step -----------------------------------------------------------------------------------------
     ren, nets = build_fit_nets(dev, 1, precision)
