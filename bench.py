@@ -300,9 +300,14 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
             dt = float(tt.item())
         return dt, out
 
+    WINDOWS = 3
+
     def timed(fn):
-        # (as timeit does: what earlier legs left behind is collected BEFORE the leg, and the cyclic collector stays off inside the timed
-        #  window -- a packed field of an earlier leg dying there synchronises the device in its destructor: 2.3 ms steps read as 2.7 - 4.3)
+        """Seconds per step of a per-step leg: `warmup` untimed steps, then WINDOWS timed windows of `steps` steps each, the MEDIAN window.
+        (As timeit does, what earlier legs left behind is collected before the leg and the cyclic collector stays off inside the windows.  The
+        median of three: a window is 0.2 s, and on a box whose host was busy with something else the one leg that goes through autograd --
+        1.4 ms of host work per 2.3 ms window step -- read 3.2 and 4.3 ms in a single window beside 2.3 in the sequence leg of the same
+        process; the windows are kept in `timed.last`.)"""
         import gc
         gc.collect()
         torch.cuda.synchronize()
@@ -311,10 +316,12 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
         was = gc.isenabled()
         gc.disable()
         try:
-            return wall(lambda: [fn(warmup + i) for i in range(steps)])[0] / steps
+            secs = [wall(lambda: [fn(warmup + w * steps + i) for i in range(steps)])[0] / steps for w in range(WINDOWS)]
         finally:
             if was:
                 gc.enable()
+        timed.last = [round(x * 1e3, 4) for x in secs]
+        return sorted(secs)[len(secs) // 2]
 
     # ---- C3 / C4 per step -----------------------------------------------------------------------------------------
     ren, nets = build_fit_nets(dev, 1, precision)
@@ -325,7 +332,7 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
         # the step as fit_frame runs it: PipelinedSingleFit (the hand's and the object's halves on two streams that stay apart across
         # steps); `single_12_autograd`: the same step through autograd on one stream + the library's fork / join inside the render
         sec = timed(lambda i: F.fit_step(ren, views[i % 8], chain, opt, NEAR, FAR, ft, pipelined=True))
-        res['single_' + ft] = {'ms_per_step': sec * 1e3, 'steps_per_frame': STEPS_PER_FRAME[ft],
+        res['single_' + ft] = {'ms_per_step': sec * 1e3, 'ms_per_step_timed_windows': list(timed.last), 'steps_per_frame': STEPS_PER_FRAME[ft],
                                'frames_per_s': world / (STEPS_PER_FRAME[ft] * sec), 'pose_chain': 'halo (six refine leaves, hn_pose_chain)',
                                'form': 'PipelinedSingleFit (two streams across steps)'}
     F.finish_pipeline(opt)
@@ -396,7 +403,7 @@ def time_fit(dev, dist, rank, world, precision, steps, warmup, outer_iters=5, wi
     vwin = F.synthetic_views(8, VID_FRAMES, VID_RAYS, 60 + rank, jb[9], device=dev)
     sec_v = timed(lambda i: F.fit_step(renb, vwin[i % 8], chainb, optb, NEAR, FAR, '1234', index=my, smooth_ends=(my[0] == 0, False),
                                        obj_verts_for_stable=ov))
-    res['video_1234_step'] = {'ms_per_step': sec_v * 1e3, 'steps_per_window': 32, 'windows_per_s': world / (32 * sec_v),
+    res['video_1234_step'] = {'ms_per_step': sec_v * 1e3, 'ms_per_step_timed_windows': list(timed.last), 'steps_per_window': 32, 'windows_per_s': world / (32 * sec_v),
                               'what': 'one window per rank, no collective (the N = 1 step)'}
 
     # ---- C5: the sequence loop, window-parallel, pose-gradient all-reduce between backward and Adam --------------------
@@ -655,7 +662,7 @@ def main():
     ap.add_argument('--no-c1', action='store_true', help='skip the C1 (128x128x32 obj) measurement')
     ap.add_argument('--no-fitting', action='store_true', help='skip the fitting-loop measurements')
     ap.add_argument('--no-training', action='store_true', help='skip the training-iteration measurement')
-    ap.add_argument('--fit-steps', type=int, default=80, help='timed steps per fitting leg (after 10 untimed ones)')
+    ap.add_argument('--fit-steps', type=int, default=80, help='steps per timed window of a per-step fitting leg (10 untimed ones, then 3 windows: the median is reported)')
     ap.add_argument('--fit-outer', type=int, default=5, help='passes over the video sequence (fitting_video.py:157: 5)')
     ap.add_argument('--fit-quick', action='store_true', help='functional check of the fitting legs: 2 frames, an 8-frame sequence, one pass')
     ap.add_argument('--rccl-one-rank', action='store_true', help='run ONLY the one-rank RCCL leg (a process group of one rank over nccl on this GPU, the '
