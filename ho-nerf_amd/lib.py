@@ -212,7 +212,12 @@ def ptr(t):
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The raw handle of torch's current stream on the current device.  (Through the C bindings directly: `torch.cuda.current_stream()`
+    builds a Stream object behind three Python calls, ~10 us, and a fitting step asks a dozen times.)"""
+    try:
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except Exception:
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def f32(t, device=None):

@@ -13,6 +13,8 @@ import ctypes
 import math
 
 import numpy as np
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -543,13 +545,24 @@ class PackedField:
         return out + (feat,) if want_feat else out
 
 
+_SUBMODULES = weakref.WeakKeyDictionary()     # module -> its submodules (the tree is walked once per module, not at every render)
+
+
 def params_version(*modules):
     """A cheap fingerprint of the parameters' in-place versions: the adapters
-    re-pack when a checkpoint is loaded after construction."""
+    re-pack when a checkpoint is loaded after construction.  Called several times per optimisation step of the fitting loops
+    (every render, the stable term): the parameters are read straight from the submodules' own tables -- `Module.parameters()` walks the
+    module tree through generators and de-duplicating sets at every call, 0.17 ms per call for the six networks, 0.8 ms per window step."""
     v = []
     for m in modules:
         if isinstance(m, nn.Module):
-            v += [(id(p), p._version) for p in m.parameters()]
+            subs = _SUBMODULES.get(m)
+            if subs is None:
+                subs = _SUBMODULES[m] = list(m.modules())
+            for sm in subs:
+                for q in sm._parameters.values():
+                    if q is not None:
+                        v.append((id(q), q._version))
         elif isinstance(m, dict):
             v.append(id(m))
         else:
