@@ -556,10 +556,11 @@ def params_version(*modules):
     v = []
     for m in modules:
         if isinstance(m, nn.Module):
-            subs = _SUBMODULES.get(m)
-            if subs is None:
-                subs = _SUBMODULES[m] = list(m.modules())
-            for sm in subs:
+            ent = _SUBMODULES.get(m)
+            if ent is None or ent[1] != sum(len(sm._modules) for sm in ent[0]):      # (a child added or removed since: walk again)
+                subs = list(m.modules())
+                ent = _SUBMODULES[m] = (subs, sum(len(sm._modules) for sm in subs))
+            for sm in ent[0]:
                 for q in sm._parameters.values():
                     if q is not None:
                         v.append((id(q), q._version))
