@@ -890,17 +890,47 @@ static int render_single_impl(const hn_field* f, const float* rays_o, const floa
         HN_TRY(sample_points(rays_o, rays_d, t.z_a, n_rays, k, 0, 0.f, t.pts, nullptr, s));
         HN_TRY(sdf_pass(t.pts, n_rays * k, t.sdf_a));
         float *za = t.z_a, *zb = t.z_b, *sa = t.sdf_a, *sb = t.sdf_b;
+        // A round is up_sample -> sdf of the new depths -> cat_z_vals.  For the batch sizes of a training iteration the wave form of up_sample
+        // takes the round's other small launches along, as in the two-field render (hn_debug_fused_rounds: off): the previous round's
+        // cat_z_vals runs at the head of this round's launch (`pending`), the new depths' sample positions at its end -- one launch per round
+        // beside the field's instead of three; the same operations in the same order.
+        const bool fused_rounds = g_fused_rounds.load(std::memory_order_relaxed) != 0;
+        float *zn = t.z_new, *zn2 = t.z_new2;
+        bool pending = false;
         for (int i = 0; i < steps; ++i) {
-            HN_TRY(upsample(za, sa, n_rays, k, n_new, (float)(64 << i), t.z_new, nullptr, s));
-            if (i + 1 < steps) {
-                HN_TRY(sample_points(rays_o, rays_d, t.z_new, n_rays, n_new, 0, 0.f, t.pts, nullptr, s));
-                HN_TRY(sdf_pass(t.pts, n_rays * n_new, t.sdf_new));
-                HN_TRY(merge(za, t.z_new, sa, t.sdf_new, n_rays, k, n_new, 0, zb, sb, nullptr, s));
-            } else {
-                HN_TRY(merge(za, t.z_new, nullptr, nullptr, n_rays, k, n_new, 0, zb, nullptr, nullptr, s));
+            const bool more = i + 1 < steps;
+            UpsPre pre{};
+            const UpsPre* pp = nullptr;
+            float* z_out = zn;
+            if (pending) {   // (k counts the merged row already; this round's depths go to the other small buffer)
+                pre = UpsPre{zn, t.sdf_new, n_new, 0, zb, sb, nullptr, nullptr, nullptr};
+                pp = &pre;
+                z_out = zn2;
             }
-            float* tmp = za; za = zb; zb = tmp;
-            tmp = sa; sa = sb; sb = tmp;
+            if (!fused_rounds || !upsample_fused(za, sa, n_rays, k, n_new, (float)(64 << i), z_out, nullptr, 0, 0, rays_o, rays_d, more ? t.pts : nullptr, s, pp)) {
+                HN_REQUIRE(pp == nullptr, "render_single: the fused up_sample launch failed");
+                HN_TRY(upsample(za, sa, n_rays, k, n_new, (float)(64 << i), zn, nullptr, s));
+                if (more) HN_TRY(sample_points(rays_o, rays_d, zn, n_rays, n_new, 0, 0.f, t.pts, nullptr, s));
+            }
+            if (pending) {
+                float* tmp = za; za = zb; zb = tmp;
+                tmp = sa; sa = sb; sb = tmp;
+                tmp = zn; zn = zn2; zn2 = tmp;
+                pending = false;
+            }
+            if (more) {
+                HN_TRY(sdf_pass(t.pts, n_rays * n_new, t.sdf_new));
+                if (fused_rounds && upsample_fused_ok(n_rays, k + n_new, n_new)) {
+                    pending = true;
+                } else {
+                    HN_TRY(merge(za, zn, sa, t.sdf_new, n_rays, k, n_new, 0, zb, sb, nullptr, s));
+                    float* tmp = za; za = zb; zb = tmp;
+                    tmp = sa; sa = sb; sb = tmp;
+                }
+            } else {
+                HN_TRY(merge(za, zn, nullptr, nullptr, n_rays, k, n_new, 0, zb, nullptr, nullptr, s));
+                float* tmp = za; za = zb; zb = tmp;
+            }
             k += n_new;
         }
         z_cur = za;

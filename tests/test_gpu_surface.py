@@ -418,6 +418,41 @@ def test_fused_importance_rounds_are_bit_identical():
         Lm.check(lib.hn_debug_fused_rounds(1), 'hn_debug_fused_rounds')
 
 
+@pytest.mark.parametrize('kind', ['obj', 'hand'])
+def test_fused_importance_rounds_of_the_single_field_render_are_bit_identical(kind):
+    """hn_render_single takes the same route for the batch sizes of a training iteration: the previous round's cat_z_vals at the head of the
+    up_sample launch, the new depths' sample positions at its end (hn_debug_fused_rounds).  Against the separate launches: final depths, cdf,
+    colour, weight sums bit for bit -- 441 rays of the training batch and a ragged 37, far-field skip on for the hand."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import train_step_bench as T
+    from honerf_amd import lib as Lm
+    lib = Lm.load()
+    dev = torch.device('cuda')
+    ren, synth_ = T.build(kind, dev)
+    ren.precision = 'f16x3'
+    try:
+        for B in (441, 37):
+            o, d, ex = T.rays(kind, synth_, B, dev)
+            tr = torch.rand(B, 1, generator=torch.Generator().manual_seed(8)).to(dev)
+            res = {}
+            for fused in (1, 0):
+                Lm.check(lib.hn_debug_fused_rounds(fused), 'hn_debug_fused_rounds')
+                with torch.no_grad():
+                    out = ren.render(o, d, 0.4, 1.5, ex['bt_inv'], ex['T_pose'], None, ex['Ro'], ex['To'], 0, t_rand=tr)
+                res[fused] = ({k: x.detach().clone() for k, x in out.items() if isinstance(x, torch.Tensor)}, ren.last_z_vals.clone())
+            assert torch.equal(res[1][1], res[0][1]), 'final depths (%s, %d rays)' % (kind, B)
+            assert float(res[1][1].std()) > 0
+            for k in res[1][0]:
+                if k.startswith('gradient_error'):
+                    assert abs(float(res[1][0][k]) - float(res[0][0][k])) <= 5e-6 * abs(float(res[0][0][k])) + 1e-12, (kind, B, k)
+                else:
+                    assert torch.equal(res[1][0][k], res[0][0][k]), '%s, %d rays: %s' % (kind, B, k)
+    finally:
+        Lm.check(lib.hn_debug_fused_rounds(1), 'hn_debug_fused_rounds')
+
+
 def test_window_step_side_stream_equals_single_stream():
     """fit_backward on a fitting_video window evaluates the stable term and the pose regularisers on a second stream beside the
     render (forward and backward).  The same step with everything on one stream: same loss terms, same gradients of the six
